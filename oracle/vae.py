@@ -1,0 +1,294 @@
+"""Oracle for the dense-bottleneck AE / VAE train step and reconstruct().
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED (no TF).
+
+Restates, with hand-written backward passes:
+  models/customlayers.py:16-38          unified encoder / decoder
+  models/autoencoder.py:9-40            AE graph
+  models/variational_autoencoder.py:9-47 VAE graph
+  trainers/AE.py:28-29, VAE.py:36-42    losses
+  trainers/DLMODEL.py:112-131           Adam (TF form), beta1 from
+                                        utils/default_config_setup.py:257
+Parameter order = TF variable-creation order (Encoder, Bottleneck, Decoder).
+The reparameterisation noise `eps` and the (pre-scaled) dropout masks are
+explicit inputs because the TF graph RNG is unseeded.
+"""
+import math
+
+import numpy as np
+
+from . import nn
+
+LRELU_ALPHA = 0.3  # keras LeakyReLU() default, customlayers.py:23,36
+
+
+def param_spec(arch, height, width, channels, inter_res, zdim):
+    """[(name, shape, kind)] in TF variable-creation order."""
+    assert arch in ('AE', 'VAE')
+    assert height == width, 'reference derives num_pooling from input_shape[1] only (customlayers.py:18)'
+    n_pool = int(math.log(height, 2) - math.log(float(inter_res), 2))
+    spec = []
+    cin = channels
+    for i in range(n_pool):
+        f = int(min(128, 32 * (2 ** i)))
+        spec += [(f'Encoder/enc_conv2D_{i}/kernel', (5, 5, cin, f), 'conv_w'),
+                 (f'Encoder/enc_conv2D_{i}/bias', (f,), 'bias'),
+                 (f'Encoder/batch_normalization_{i}/gamma', (f,), 'gamma'),
+                 (f'Encoder/batch_normalization_{i}/beta', (f,), 'beta')]
+        cin = f
+    cenc = cin
+    cmid = cenc // 8
+    flat = inter_res * inter_res * cmid
+    spec += [('Bottleneck/conv2d/kernel', (1, 1, cenc, cmid), 'conv_w'),
+             ('Bottleneck/conv2d/bias', (cmid,), 'bias')]
+    if arch == 'VAE':
+        spec += [('Bottleneck/dense_mu/kernel', (flat, zdim), 'dense_w'),
+                 ('Bottleneck/dense_mu/bias', (zdim,), 'bias'),
+                 ('Bottleneck/dense_sigma/kernel', (flat, zdim), 'dense_w'),
+                 ('Bottleneck/dense_sigma/bias', (zdim,), 'bias')]
+    else:
+        spec += [('Bottleneck/dense_z/kernel', (flat, zdim), 'dense_w'),
+                 ('Bottleneck/dense_z/bias', (zdim,), 'bias')]
+    spec += [('Bottleneck/dense_dec/kernel', (zdim, flat), 'dense_w'),
+             ('Bottleneck/dense_dec/bias', (flat,), 'bias'),
+             ('Bottleneck/conv2d_1/kernel', (1, 1, cmid, cenc), 'conv_w'),
+             ('Bottleneck/conv2d_1/bias', (cenc,), 'bias'),
+             ('Decoder/batch_normalization/gamma', (cenc,), 'gamma'),
+             ('Decoder/batch_normalization/beta', (cenc,), 'beta')]
+    cin = cenc
+    for i in range(n_pool):
+        f = int(max(32, 128 / (2 ** i)))
+        spec += [(f'Decoder/dec_Conv2DT_{i}/kernel', (5, 5, f, cin), 'conv_w'),
+                 (f'Decoder/dec_Conv2DT_{i}/bias', (f,), 'bias'),
+                 (f'Decoder/batch_normalization_{i + 1}/gamma', (f,), 'gamma'),
+                 (f'Decoder/batch_normalization_{i + 1}/beta', (f,), 'beta')]
+        cin = f
+    spec += [('Decoder/dec_Conv2D_final/kernel', (1, 1, cin, channels), 'conv_w'),
+             ('Decoder/dec_Conv2D_final/bias', (channels,), 'bias')]
+    return spec
+
+
+def init_params(spec, seed=3, dtype=np.float32, perturb=False):
+    """glorot_uniform kernels, zero bias, gamma=1, beta=0 (TF/keras defaults).
+    perturb=True jitters bias/gamma/beta so parity tests exercise them."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shape, kind in spec:
+        if kind in ('conv_w', 'dense_w'):
+            p[name] = nn.glorot_uniform(rng, shape, dtype)
+        elif kind == 'gamma':
+            p[name] = np.ones(shape, dtype)
+            if perturb:
+                p[name] += rng.uniform(-0.2, 0.2, shape).astype(dtype)
+        else:
+            p[name] = np.zeros(shape, dtype)
+            if perturb:
+                p[name] += rng.uniform(-0.1, 0.1, shape).astype(dtype)
+    return p
+
+
+def flatten_params(spec, p):
+    return np.concatenate([p[name].reshape(-1) for name, _, _ in spec])
+
+
+def unflatten_params(spec, flat):
+    p, off = {}, 0
+    for name, shape, _ in spec:
+        n = int(np.prod(shape))
+        p[name] = flat[off:off + n].reshape(shape)
+        off += n
+    assert off == flat.size
+    return p
+
+
+class Model:
+    def __init__(self, arch, height=128, width=128, channels=1, inter_res=8, zdim=128):
+        self.arch, self.h, self.w, self.c = arch, height, width, channels
+        self.inter, self.zdim = inter_res, zdim
+        self.spec = param_spec(arch, height, width, channels, inter_res, zdim)
+        self.n_pool = int(math.log(height, 2) - math.log(float(inter_res), 2))
+
+    # ------------------------------------------------------------------
+    def forward(self, p, x, eps=None, masks=None):
+        """masks: dict with optional pre-scaled keep masks
+             VAE: 'mu','sigma' [N,zdim], 'dec' [N,flat]   (variational_autoencoder.py:31,32,35)
+             AE : 'z' [N,zdim]                             (autoencoder.py:29; dec_dense dropout never active, :30 / A2)
+           eps: [N,zdim] N(0,1) noise (VAE only; variational_autoencoder.py:34)."""
+        masks = masks or {}
+        cache = {'x': x}
+        a = x
+        for i in range(self.n_pool):
+            pre = f'Encoder/enc_conv2D_{i}'
+            bnp = f'Encoder/batch_normalization_{i}'
+            c = nn.conv2d_fwd(a, p[pre + '/kernel'], p[pre + '/bias'], 2)
+            bn = nn.bn_frozen_fwd(c, p[bnp + '/gamma'], p[bnp + '/beta'])
+            cache[f'enc_in{i}'], cache[f'enc_c{i}'], cache[f'enc_bn{i}'] = a, c, bn
+            a = nn.leaky_relu_fwd(bn, LRELU_ALPHA)
+        cache['enc_out'] = a
+        t = nn.conv2d_fwd(a, p['Bottleneck/conv2d/kernel'], p['Bottleneck/conv2d/bias'], 1)
+        n = x.shape[0]
+        cache['t_shape'] = t.shape
+        flat = t.reshape(n, -1)  # H,W,C-major flatten
+        cache['flat'] = flat
+        out = {}
+        if self.arch == 'VAE':
+            mu = nn.dense_fwd(flat, p['Bottleneck/dense_mu/kernel'], p['Bottleneck/dense_mu/bias'])
+            ls = nn.dense_fwd(flat, p['Bottleneck/dense_sigma/kernel'], p['Bottleneck/dense_sigma/bias'])
+            if 'mu' in masks:
+                mu = mu * masks['mu']
+            if 'sigma' in masks:
+                ls = ls * masks['sigma']
+            sigma = np.exp(ls)
+            if eps is None:
+                eps = np.zeros_like(mu)
+            z = mu + eps * sigma
+            out.update(z_mu=mu, z_log_sigma=ls, z_sigma=sigma)
+            cache.update(mu=mu, ls=ls, sigma=sigma, eps=eps)
+        else:
+            z = nn.dense_fwd(flat, p['Bottleneck/dense_z/kernel'], p['Bottleneck/dense_z/bias'])
+            if 'z' in masks:
+                z = z * masks['z']
+            out['z'] = z
+        cache['z'] = z
+        d = nn.dense_fwd(z, p['Bottleneck/dense_dec/kernel'], p['Bottleneck/dense_dec/bias'])
+        if self.arch == 'VAE' and 'dec' in masks:
+            d = d * masks['dec']
+        d4 = d.reshape(cache['t_shape'])
+        cache['d4'] = d4
+        c = nn.conv2d_fwd(d4, p['Bottleneck/conv2d_1/kernel'], p['Bottleneck/conv2d_1/bias'], 1)
+        bn = nn.bn_frozen_fwd(c, p['Decoder/batch_normalization/gamma'], p['Decoder/batch_normalization/beta'])
+        cache['dec_c_in'], cache['dec_bn_in'] = c, bn
+        a = nn.leaky_relu_fwd(bn, 0.0)  # ReLU, customlayers.py:31
+        for i in range(self.n_pool):
+            pre = f'Decoder/dec_Conv2DT_{i}'
+            bnp = f'Decoder/batch_normalization_{i + 1}'
+            c = nn.conv2d_transpose_fwd(a, p[pre + '/kernel'], p[pre + '/bias'], 2)
+            bn = nn.bn_frozen_fwd(c, p[bnp + '/gamma'], p[bnp + '/beta'])
+            cache[f'dec_in{i}'], cache[f'dec_c{i}'], cache[f'dec_bn{i}'] = a, c, bn
+            a = nn.leaky_relu_fwd(bn, LRELU_ALPHA)
+        cache['dec_out'] = a
+        xh = nn.conv2d_fwd(a, p['Decoder/dec_Conv2D_final/kernel'], p['Decoder/dec_Conv2D_final/bias'], 1)
+        out['x_hat'] = xh
+        return out, cache
+
+    # ------------------------------------------------------------------
+    def losses(self, x, out):
+        """trainers/AE.py:28-29 ; trainers/VAE.py:36-42.  KL uses the analytic
+        2*log_sigma for log(sigma^2)."""
+        l1 = np.abs(out['x_hat'] - x)
+        rec = l1.reshape(x.shape[0], -1).sum(axis=1)
+        res = {'L1': l1, 'reconstructionLoss': rec.mean()}
+        if self.arch == 'VAE':
+            mu, ls, sg = out['z_mu'], out['z_log_sigma'], out['z_sigma']
+            kl = 0.5 * (mu * mu + sg * sg - 2.0 * ls - 1.0).sum(axis=1)
+            res['kl'] = kl.mean()
+            res['loss'] = (rec + kl).mean()
+        else:
+            res['loss'] = res['reconstructionLoss']
+        return res
+
+    # ------------------------------------------------------------------
+    def backward(self, p, x, out, cache, masks=None):
+        """Gradient of losses()['loss'] w.r.t. every parameter (dict by name)."""
+        masks = masks or {}
+        n = x.shape[0]
+        dt = x.dtype.type
+        g = {}
+        # d loss / d x_hat = sign(x_hat - x) / N   (tf.abs gradient: sign, 0 at 0)
+        gx = np.sign(out['x_hat'] - x) * dt(1.0 / n)
+        a = cache['dec_out']
+        da, g['Decoder/dec_Conv2D_final/kernel'], g['Decoder/dec_Conv2D_final/bias'] = \
+            nn.conv2d_bwd(a, p['Decoder/dec_Conv2D_final/kernel'], gx, 1)
+        for i in reversed(range(self.n_pool)):
+            pre = f'Decoder/dec_Conv2DT_{i}'
+            bnp = f'Decoder/batch_normalization_{i + 1}'
+            dbn = nn.leaky_relu_bwd(cache[f'dec_bn{i}'], da, LRELU_ALPHA)
+            dc, g[bnp + '/gamma'], g[bnp + '/beta'] = nn.bn_frozen_bwd(cache[f'dec_c{i}'], p[bnp + '/gamma'], dbn)
+            da, g[pre + '/kernel'], g[pre + '/bias'] = \
+                nn.conv2d_transpose_bwd(cache[f'dec_in{i}'], p[pre + '/kernel'], dc, 2)
+        dbn = nn.leaky_relu_bwd(cache['dec_bn_in'], da, 0.0)
+        dc, g['Decoder/batch_normalization/gamma'], g['Decoder/batch_normalization/beta'] = \
+            nn.bn_frozen_bwd(cache['dec_c_in'], p['Decoder/batch_normalization/gamma'], dbn)
+        dd4, g['Bottleneck/conv2d_1/kernel'], g['Bottleneck/conv2d_1/bias'] = \
+            nn.conv2d_bwd(cache['d4'], p['Bottleneck/conv2d_1/kernel'], dc, 1)
+        dd = dd4.reshape(n, -1)
+        if self.arch == 'VAE' and 'dec' in masks:
+            dd = dd * masks['dec']
+        dz, g['Bottleneck/dense_dec/kernel'], g['Bottleneck/dense_dec/bias'] = \
+            nn.dense_bwd(cache['z'], p['Bottleneck/dense_dec/kernel'], dd)
+        if self.arch == 'VAE':
+            mu, ls, sg, eps = cache['mu'], cache['ls'], cache['sigma'], cache['eps']
+            # z = mu + eps*exp(ls); kl_n = 0.5*sum(mu^2 + exp(2 ls) - 2 ls - 1); loss += mean_n kl_n
+            dmu = dz + mu * dt(1.0 / n)
+            dls = dz * eps * sg + (sg * sg - dt(1.0)) * dt(1.0 / n)
+            if 'mu' in masks:
+                dmu = dmu * masks['mu']
+            if 'sigma' in masks:
+                dls = dls * masks['sigma']
+            df1, g['Bottleneck/dense_mu/kernel'], g['Bottleneck/dense_mu/bias'] = \
+                nn.dense_bwd(cache['flat'], p['Bottleneck/dense_mu/kernel'], dmu)
+            df2, g['Bottleneck/dense_sigma/kernel'], g['Bottleneck/dense_sigma/bias'] = \
+                nn.dense_bwd(cache['flat'], p['Bottleneck/dense_sigma/kernel'], dls)
+            dflat = df1 + df2
+        else:
+            if 'z' in masks:
+                dz = dz * masks['z']
+            dflat, g['Bottleneck/dense_z/kernel'], g['Bottleneck/dense_z/bias'] = \
+                nn.dense_bwd(cache['flat'], p['Bottleneck/dense_z/kernel'], dz)
+        dt4 = dflat.reshape(cache['t_shape'])
+        da, g['Bottleneck/conv2d/kernel'], g['Bottleneck/conv2d/bias'] = \
+            nn.conv2d_bwd(cache['enc_out'], p['Bottleneck/conv2d/kernel'], dt4, 1)
+        for i in reversed(range(self.n_pool)):
+            pre = f'Encoder/enc_conv2D_{i}'
+            bnp = f'Encoder/batch_normalization_{i}'
+            dbn = nn.leaky_relu_bwd(cache[f'enc_bn{i}'], da, LRELU_ALPHA)
+            dc, g[bnp + '/gamma'], g[bnp + '/beta'] = nn.bn_frozen_bwd(cache[f'enc_c{i}'], p[bnp + '/gamma'], dbn)
+            da, g[pre + '/kernel'], g[pre + '/bias'] = \
+                nn.conv2d_bwd(cache[f'enc_in{i}'], p[pre + '/kernel'], dc, 2)
+        g['__dx'] = da
+        return g
+
+    # ------------------------------------------------------------------
+    def train_step(self, p, opt, x, eps=None, masks=None, lr=1e-4, beta1=0.5):
+        """One sess.run of trainers/VAE.py:83-96 (fetches + optimizer).
+        opt = {'t': int, 'm': {name: arr}, 'v': {name: arr}}; updated in place."""
+        out, cache = self.forward(p, x, eps, masks)
+        ls = self.losses(x, out)
+        g = self.backward(p, x, out, cache, masks)
+        opt['t'] += 1
+        for name, _, _ in self.spec:
+            nn.adam_tf_step(p[name], g[name], opt['m'][name], opt['v'][name], opt['t'], lr, beta1)
+        return out, ls, g
+
+    def new_opt(self, p):
+        return {'t': 0, 'm': {k: np.zeros_like(v) for k, v in p.items()},
+                'v': {k: np.zeros_like(v) for k, v in p.items()}}
+
+    def reconstruct(self, p, x, eps=None, masks=None):
+        """trainers/VAE.py:105-123 / AE.py:92-110 (l2err == l1err, sic; A4)."""
+        if x.ndim < 4:
+            x = x[None]
+        out, _ = self.forward(p, x, eps, masks)
+        rec = out['x_hat']
+        return {'reconstruction': rec, 'l1err': np.sum(np.abs(x - rec)),
+                'l2err': np.sum(np.sqrt((x - rec) ** 2))}
+
+
+# ----------------------------------------------------------------------
+# synthetic Brainweb-like batch
+# ----------------------------------------------------------------------
+def synthetic_slices(n, h=128, w=128, seed=0, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    cy, cx = (h - 1) / 2.0, (w - 1) / 2.0
+    out = np.zeros((n, h, w, 1), dtype=dtype)
+    for i in range(n):
+        ry = h * rng.uniform(0.36, 0.42)
+        rx = w * rng.uniform(0.30, 0.36)
+        mask = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        ph = rng.uniform(0, 2 * np.pi, 4)
+        f = (0.55 + 0.2 * np.sin(yy / h * 2 * np.pi * 1.5 + ph[0]) * np.cos(xx / w * 2 * np.pi * 1.2 + ph[1])
+             + 0.12 * np.sin(xx / w * 2 * np.pi * 3 + ph[2]) * np.sin(yy / h * 2 * np.pi * 2.5 + ph[3]))
+        img = np.clip(f + rng.normal(0, 0.03, f.shape), 0.0, 1.0)
+        out[i, :, :, 0] = (img * mask).astype(dtype)
+    return out

@@ -1,0 +1,97 @@
+"""CPU: the numpy oracle (hand-written backward, TF semantics) vs an independent
+torch-autograd formulation.  This is the strongest pin available for the model
+path (no TF in the image): two independent restatements must agree to fp64
+round-off."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn as onn
+from oracle import vae as ovae
+from tests import torch_ref
+
+
+def _setup(arch, h, inter, zdim, n, dtype=np.float64, seed=0):
+    m = ovae.Model(arch, h, h, 1, inter, zdim)
+    p = ovae.init_params(m.spec, seed=3 + seed, dtype=dtype, perturb=True)
+    x = ovae.synthetic_slices(n, h, h, seed=seed, dtype=dtype)
+    rng = np.random.default_rng(100 + seed)
+    eps = rng.standard_normal((n, zdim)).astype(dtype)
+    flat = inter * inter * (p['Bottleneck/conv2d/kernel'].shape[-1])
+    if arch == 'VAE':
+        masks = {'mu': onn.make_dropout_mask(rng, (n, zdim), 0.2, dtype),
+                 'sigma': onn.make_dropout_mask(rng, (n, zdim), 0.2, dtype),
+                 'dec': onn.make_dropout_mask(rng, (n, flat), 0.2, dtype)}
+    else:
+        masks = {'z': onn.make_dropout_mask(rng, (n, zdim), 0.2, dtype)}
+    return m, p, x, eps, masks
+
+
+def test_same_pads():
+    assert onn.same_pads(128, 5, 2) == (64, 1, 2)
+    assert onn.same_pads(8, 1, 1) == (8, 0, 0)
+    assert onn.same_pads(64, 3, 2) == (32, 0, 1)
+    assert onn.same_pads(64, 4, 2) == (32, 1, 1)
+    assert onn.same_pads(7, 5, 2) == (4, 2, 2)
+
+
+def test_param_count_matches_survey():
+    m = ovae.Model('VAE', 128, 128, 1, 8, 128)
+    assert sum(int(np.prod(s)) for _, s, _ in m.spec) == 1758449
+    m = ovae.Model('AE', 128, 128, 1, 8, 128)
+    assert sum(int(np.prod(s)) for _, s, _ in m.spec) == 1627249
+
+
+@pytest.mark.parametrize('arch,h,inter,zdim,n', [('VAE', 32, 8, 16, 2), ('AE', 32, 8, 16, 2), ('VAE', 64, 8, 32, 1)])
+def test_forward_backward_vs_torch(arch, h, inter, zdim, n):
+    m, p, x, eps, masks = _setup(arch, h, inter, zdim, n)
+    out, cache = m.forward(p, x, eps if arch == 'VAE' else None, masks)
+    ls = m.losses(x, out)
+    g = m.backward(p, x, out, cache, masks)
+
+    tp = torch_ref.to_torch(p)
+    tm = {k: torch.tensor(v) for k, v in masks.items()}
+    xt = torch.tensor(x, requires_grad=True)
+    tl, xh, extras = torch_ref.forward_loss(arch, m.spec, tp, xt, torch.tensor(eps), tm, inter, m.n_pool)
+    tl['loss'].backward()
+
+    np.testing.assert_allclose(out['x_hat'], xh.detach().numpy(), rtol=1e-10, atol=1e-12)
+    for k in tl:
+        np.testing.assert_allclose(ls[k], tl[k].item(), rtol=1e-11)
+    for name, _, _ in m.spec:
+        np.testing.assert_allclose(g[name], tp[name].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=name)
+    # torch's x.grad also holds the direct d|x_hat - x|/dx = -sign/N term; __dx is the path through the net
+    direct = -np.sign(out['x_hat'] - x) / n
+    np.testing.assert_allclose(g['__dx'] + direct, xt.grad.numpy(), rtol=1e-8, atol=1e-12)
+
+
+def test_conv_transpose_is_adjoint_of_conv():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 16, 16, 3))
+    w = rng.standard_normal((5, 5, 3, 4))          # HWIO for the fwd conv 16x16x3 -> 8x8x4
+    g = rng.standard_normal((2, 8, 8, 4))
+    y = onn.conv2d_fwd(x, w, None, 2)
+    # ConvT with kernel [kh,kw,Cout=3,Cin=4] == w maps g (8x8x4) -> 16x16x3
+    xt = onn.conv2d_transpose_fwd(g, w, None, 2)
+    np.testing.assert_allclose((y * g).sum(), (x * xt).sum(), rtol=1e-12)
+
+
+def test_adam_tf_form_first_steps():
+    p = np.array([1.0, -2.0]); g = np.array([0.5, -0.25])
+    m = np.zeros(2); v = np.zeros(2)
+    onn.adam_tf_step(p, g, m, v, 1, lr=0.1, beta1=0.5, beta2=0.999, eps=1e-8)
+    # step 1: lr_t = lr*sqrt(1-b2)/(1-b1); m=(1-b1)g; v=(1-b2)g^2 -> update ~= lr*sign(g)
+    lr_t = 0.1 * np.sqrt(1 - 0.999) / (1 - 0.5)
+    exp = np.array([1.0, -2.0]) - lr_t * (0.5 * g) / (np.sqrt(0.001 * g * g) + 1e-8)
+    np.testing.assert_allclose(p, exp, rtol=1e-14)
+
+
+def test_train_steps_decrease_loss_and_match_torch_adam_free_grads():
+    m, p, x, eps, masks = _setup('VAE', 32, 8, 16, 4, dtype=np.float64, seed=1)
+    opt = m.new_opt(p)
+    losses = []
+    for _ in range(15):
+        _, ls, _ = m.train_step(p, opt, x, eps, masks, lr=1e-3)
+        losses.append(float(ls['loss']))
+    assert losses[-1] < losses[0]
+    assert opt['t'] == 15

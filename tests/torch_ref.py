@@ -1,0 +1,98 @@
+"""Independent torch-CPU (autograd) formulation of the AE/VAE step, used ONLY by
+tests to cross-check the numpy oracle's hand-written backward (the oracle itself
+is "parity unpinned": no TF here).  TF-SAME geometry is made explicit:
+conv k5 s2 -> F.pad (1,2,1,2); ConvT k5 s2 -> conv_transpose2d(padding=1), crop
+the last row/col (SURVEY.md §8a note 2)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3
+ALPHA = 0.3
+
+
+def _conv_same(x, w_hwio, b, stride):
+    # x NCHW; w HWIO -> OIHW
+    k = w_hwio.shape[0]
+    h = x.shape[2]
+    out = -(-h // stride)
+    total = max((out - 1) * stride + k - h, 0)
+    pb, pa = total // 2, total - total // 2
+    xp = F.pad(x, (pb, pa, pb, pa))
+    return F.conv2d(xp, w_hwio.permute(3, 2, 0, 1), b, stride=stride)
+
+
+def _convT_same(x, w_hwoi, b, stride):
+    # TF kernel [kh,kw,Cout,Cin]; torch conv_transpose2d weight [Cin, Cout, kh, kw]
+    k = w_hwoi.shape[0]
+    h = x.shape[2]
+    oh = h * stride
+    total = max((h - 1) * stride + k - oh, 0)
+    pb = total // 2
+    y = F.conv_transpose2d(x, w_hwoi.permute(3, 2, 0, 1), None, stride=stride, padding=0)
+    y = y[:, :, pb:pb + oh, pb:pb + oh]
+    return y + b.view(1, -1, 1, 1)
+
+
+def forward_loss(arch, spec, params, x_nhwc, eps, masks, inter_res, n_pool):
+    """params: dict name -> torch tensor (requires_grad). Returns (loss dict, x_hat NHWC, extras)."""
+    rstd = 1.0 / math.sqrt(1.0 + BN_EPS)
+    p = params
+    a = x_nhwc.permute(0, 3, 1, 2)
+    for i in range(n_pool):
+        c = _conv_same(a, p[f'Encoder/enc_conv2D_{i}/kernel'], p[f'Encoder/enc_conv2D_{i}/bias'], 2)
+        bn = c * (p[f'Encoder/batch_normalization_{i}/gamma'] * rstd).view(1, -1, 1, 1) \
+            + p[f'Encoder/batch_normalization_{i}/beta'].view(1, -1, 1, 1)
+        a = F.leaky_relu(bn, ALPHA)
+    t = _conv_same(a, p['Bottleneck/conv2d/kernel'], p['Bottleneck/conv2d/bias'], 1)
+    n = t.shape[0]
+    t_nhwc = t.permute(0, 2, 3, 1)
+    flat = t_nhwc.reshape(n, -1)
+    extras = {}
+    if arch == 'VAE':
+        mu = flat @ p['Bottleneck/dense_mu/kernel'] + p['Bottleneck/dense_mu/bias']
+        ls = flat @ p['Bottleneck/dense_sigma/kernel'] + p['Bottleneck/dense_sigma/bias']
+        if 'mu' in masks:
+            mu = mu * masks['mu']
+        if 'sigma' in masks:
+            ls = ls * masks['sigma']
+        sg = torch.exp(ls)
+        z = mu + eps * sg
+        extras.update(z_mu=mu, z_log_sigma=ls, z_sigma=sg)
+    else:
+        z = flat @ p['Bottleneck/dense_z/kernel'] + p['Bottleneck/dense_z/bias']
+        if 'z' in masks:
+            z = z * masks['z']
+        extras['z'] = z
+    d = z @ p['Bottleneck/dense_dec/kernel'] + p['Bottleneck/dense_dec/bias']
+    if arch == 'VAE' and 'dec' in masks:
+        d = d * masks['dec']
+    d4 = d.reshape(t_nhwc.shape).permute(0, 3, 1, 2)
+    c = _conv_same(d4, p['Bottleneck/conv2d_1/kernel'], p['Bottleneck/conv2d_1/bias'], 1)
+    bn = c * (p['Decoder/batch_normalization/gamma'] * rstd).view(1, -1, 1, 1) \
+        + p['Decoder/batch_normalization/beta'].view(1, -1, 1, 1)
+    a = F.relu(bn)
+    for i in range(n_pool):
+        c = _convT_same(a, p[f'Decoder/dec_Conv2DT_{i}/kernel'], p[f'Decoder/dec_Conv2DT_{i}/bias'], 2)
+        bn = c * (p[f'Decoder/batch_normalization_{i + 1}/gamma'] * rstd).view(1, -1, 1, 1) \
+            + p[f'Decoder/batch_normalization_{i + 1}/beta'].view(1, -1, 1, 1)
+        a = F.leaky_relu(bn, ALPHA)
+    xh = _conv_same(a, p['Decoder/dec_Conv2D_final/kernel'], p['Decoder/dec_Conv2D_final/bias'], 1)
+    xh_nhwc = xh.permute(0, 2, 3, 1)
+    l1 = (xh_nhwc - x_nhwc).abs()
+    rec = l1.reshape(n, -1).sum(dim=1)
+    losses = {'reconstructionLoss': rec.mean()}
+    if arch == 'VAE':
+        # trainers/VAE.py:38 literally: 0.5*sum(mu^2 + sigma^2 - log(sigma^2) - 1)
+        kl = 0.5 * (mu ** 2 + sg ** 2 - torch.log(sg ** 2) - 1).sum(dim=1)
+        losses['kl'] = kl.mean()
+        losses['loss'] = (rec + kl).mean()
+    else:
+        losses['loss'] = losses['reconstructionLoss']
+    return losses, xh_nhwc, extras
+
+
+def to_torch(params_np, dtype=torch.float64, requires_grad=True):
+    return {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=requires_grad) for k, v in params_np.items()}
