@@ -1,0 +1,137 @@
+/* uad_hip.h — C-ABI of libuad_hip.so: the MI355X (gfx950) conv autoencoder train / reconstruct hot path.
+ *
+ * This is the drop-in boundary for the reference's TF-1.15 `sess.run` calls (the reference has no native code and
+ * no FFI of its own; every entry below names the reference lines whose device work it replaces):
+ *
+ *   uad_forward / uad_backward / uad_adam_step / uad_train_step
+ *       <- trainers/VAE.py:83-96, trainers/AE.py:70-83  (one sess.run({reconstruction, **losses, optimizer}))
+ *          graph = models/variational_autoencoder.py:9-47 | models/autoencoder.py:9-40 on
+ *                  models/customlayers.py:16-38; losses trainers/VAE.py:36-42 | AE.py:28-29;
+ *                  optimizer trainers/DLMODEL.py:112-131 (tf.train.AdamOptimizer, beta1 from
+ *                  utils/default_config_setup.py:257)
+ *   uad_forward(want_backward = 0)
+ *       <- trainers/VAE.py:105-118, AE.py:92-105 (reconstruct: sess.run({'reconstruction'})) and the VAL pass
+ *   uad_residual
+ *       <- utils/Evaluation.py:282-289 (residual map, brain mask, hyper-intensity prior) and
+ *          trainers/VAE.py:120 (l1err)
+ *   uad_set_params / uad_get_params / uad_tensor_info
+ *       <- tf.global_variables_initializer / tf.train.Saver variable access (trainers/DLMODEL.py:63-110)
+ *   uad_op_*  — single-kernel entry points used by the parity tests (no reference counterpart).
+ *
+ * Conventions: plain C, no torch types.  All tensor arguments are DEVICE pointers to fp32 NHWC buffers owned by the
+ * caller unless stated otherwise; `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ * asynchronous on `stream` except the ones documented as synchronous.  Every function returns 0 on success or a
+ * UAD_ERR_* code; uad_last_error() returns the thread-local message of the last failure.  A handle is not thread-safe.
+ */
+#ifndef UAD_HIP_H
+#define UAD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { UAD_OK = 0, UAD_ERR_INVALID = 1, UAD_ERR_HIP = 2, UAD_ERR_UNSUPPORTED = 3 };
+enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1 };
+enum { UAD_BUF_PARAMS = 0, UAD_BUF_GRADS = 1, UAD_BUF_ADAM_M = 2, UAD_BUF_ADAM_V = 3 };
+enum { UAD_SEG_DECODER = 0, UAD_SEG_BOTTLENECK = 1, UAD_SEG_ENCODER = 2, UAD_SEG_ALL = -1 };
+
+typedef struct uad_model uad_model_t;
+
+typedef struct {
+    int arch;       /* UAD_ARCH_*                                              */
+    int height;     /* config.outputHeight  (trainers/AEMODEL.py:18-19)         */
+    int width;      /* config.outputWidth   (must equal height; power of two)   */
+    int channels;   /* config.numChannels   (1 supported)                       */
+    int inter_res;  /* config.intermediateResolutions[0]                        */
+    int zdim;       /* config.zDim                                              */
+    int max_batch;  /* largest n any later call will pass                       */
+} uad_config_t;
+
+typedef struct {
+    const float* x;          /* in  [n,H,W,C]                                                        */
+    const float* eps;        /* in  [n,zdim] N(0,1) noise (VAE); NULL = 0                            */
+    const float* mask_mu;    /* in  [n,zdim] keep-mask pre-scaled by 1/(1-rate), NULL = no dropout.
+                                     VAE: on z_mu (variational_autoencoder.py:31); AE: on z (autoencoder.py:29) */
+    const float* mask_sigma; /* in  [n,zdim] VAE: on z_log_sigma (:32)                               */
+    const float* mask_dec;   /* in  [n,flat] VAE: on dec_dense output (:35); ignored for AE (autoencoder.py:30) */
+    float* x_hat;            /* out [n,H,W,C] reconstruction                                         */
+    float* l1_map;           /* out [n,H,W,C] |x_hat - x|, may be NULL                               */
+    float* z_mu;             /* out [n,zdim] (AE: z), may be NULL                                    */
+    float* z_log_sigma;      /* out [n,zdim] VAE, may be NULL                                        */
+    float* z_sigma;          /* out [n,zdim] VAE, may be NULL                                        */
+    float* scalars;          /* out [4] reconstructionLoss, kl, loss, 0  (means over the n samples)  */
+    float* rec_per_sample;   /* out [n] sum_hwc L1, may be NULL                                      */
+} uad_io_t;
+
+const char* uad_last_error(void);
+const char* uad_version(void);
+
+int uad_create(const uad_config_t* cfg, uad_model_t** out);
+int uad_destroy(uad_model_t* m);
+
+long long uad_param_count(const uad_model_t* m);
+int uad_num_tensors(const uad_model_t* m);
+/* name (NUL-terminated, truncated to name_cap), flat offset, rank and shape (padded with 1s to 4) of tensor idx,
+ * in TF variable-creation order (Encoder, Bottleneck, Decoder). */
+int uad_tensor_info(const uad_model_t* m, int idx, char* name, int name_cap, long long* offset, int* rank, int* shape4);
+/* device pointer to a handle-owned flat fp32 buffer of uad_param_count() elements (UAD_BUF_*) */
+float* uad_buffer(uad_model_t* m, int which);
+/* flat [offset, offset+count) range of one gradient segment; segments complete in the order DECODER, BOTTLENECK,
+ * ENCODER during uad_backward — the data-parallel layer all-reduces each as soon as it is done. */
+int uad_grad_segment(const uad_model_t* m, int segment, long long* offset, long long* count);
+
+/* synchronous host<->device copies of the flat parameter vector */
+int uad_set_params(uad_model_t* m, const float* host, long long count);
+int uad_get_params(uad_model_t* m, float* host, long long count);
+int uad_get_buffer(uad_model_t* m, int which, float* host, long long count);
+int uad_set_buffer(uad_model_t* m, int which, const float* host, long long count);
+int uad_reset_optimizer(uad_model_t* m);            /* zero Adam slots, t = 0 (synchronous) */
+long long uad_get_step(const uad_model_t* m);
+int uad_set_step(uad_model_t* m, long long t);
+
+/* forward pass + losses.  want_backward != 0 additionally keeps what uad_backward needs and starts the backward
+ * (d loss / d c of the last decoder block is produced by the fused loss kernel). */
+int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, void* stream);
+/* gradient of `loss` w.r.t. every parameter into the UAD_BUF_GRADS buffer; segment = UAD_SEG_* (call DECODER,
+ * BOTTLENECK, ENCODER in that order, or UAD_SEG_ALL). */
+int uad_backward(uad_model_t* m, int segment, void* stream);
+/* TF-1.15 Adam: t += 1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps); grads scaled by grad_scale first */
+int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* uad_forward(want_backward=1) + uad_backward(ALL) + uad_adam_step */
+int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float beta1, float beta2, float eps,
+                   void* stream);
+
+/* residual anomaly map: out = mask * (pos_only ? max(x - xr, 0) : |x - xr|), zero where x < prior_thresh
+ * (pass -INFINITY to disable); l1err[n] = sum |x - xr| per sample (may be NULL); mask may be NULL. hw = H*W*C. */
+int uad_residual(const float* x, const float* xr, const float* mask, int n, int hw, int pos_only, float prior_thresh,
+                 float* out, float* l1err, void* stream);
+
+/* ---- single-kernel entry points (parity tests) ------------------------------------------------------------
+ * geometry of one strided-conv relation: big pixel (S*i-P+ky, S*j-P+kx) <-> small pixel (i,j); weights W[tap][cb][cs]
+ * (= HWIO for Conv2D with big=input, [kh,kw,Cout,Cin] for Conv2DTranspose with big=output). */
+typedef struct { int N, HB, WB, CB, HS, WS, CS, KS, S, P; } uad_conv_desc_t;
+/* activation-on-load v -> lrelu_alpha(scale[c]*v + shift[c]); scale == NULL = identity */
+typedef struct { const float* scale; const float* shift; float alpha; } uad_xform_t;
+
+int uad_op_conv_f(const uad_conv_desc_t* d, const float* big_in, const uad_xform_t* xf, const float* W,
+                  const float* bias, const float* mul, const float* add, float* small_out, void* stream);
+int uad_op_conv_d(const uad_conv_desc_t* d, const float* small_in, const uad_xform_t* xf, const float* W,
+                  const float* bias, const float* mul, const float* add, float* big_out, void* stream);
+/* data-gradient forms with the fused activation backward: out = acc*lrelu'(es*cprev+eh)*es; s1[c]=sum d_bn,
+ * s2[c]=sum d_bn*cprev (synchronous: allocates scratch) */
+int uad_op_conv_f_bwdact(const uad_conv_desc_t* d, const float* big_in, const float* W, const float* cprev,
+                         const uad_xform_t* act, float* small_out, float* s1, float* s2, void* stream);
+int uad_op_conv_d_bwdact(const uad_conv_desc_t* d, const float* small_in, const float* W, const float* cprev,
+                         const uad_xform_t* act, float* big_out, float* s1, float* s2, void* stream);
+int uad_op_conv_w(const uad_conv_desc_t* d, const float* big, const uad_xform_t* xfb, const float* small_,
+                  const uad_xform_t* xfs, float* dW, void* stream);
+int uad_op_conv_first_fwd(const uad_conv_desc_t* d, const float* x, const float* W, const float* bias, float* out,
+                          void* stream);
+int uad_op_conv_first_wgrad(const uad_conv_desc_t* d, const float* x, const float* g, float* dW, void* stream);
+int uad_op_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float beta1, float beta2,
+                float eps, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAD_HIP_H */

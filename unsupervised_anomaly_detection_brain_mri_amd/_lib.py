@@ -1,0 +1,107 @@
+"""ctypes binding of libuad_hip.so (C-ABI: include/uad_hip.h).  Fails loudly when the library is missing —
+there is no CPU / eager fallback anywhere in the product path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libuad_hip.so')
+
+UAD_OK = 0
+ARCH_AE, ARCH_VAE = 0, 1
+BUF_PARAMS, BUF_GRADS, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
+SEG_DECODER, SEG_BOTTLENECK, SEG_ENCODER, SEG_ALL = 0, 1, 2, -1
+
+c_float_p = C.c_void_p  # device pointers are passed as integers
+
+
+class UadConfig(C.Structure):
+    _fields_ = [('arch', C.c_int), ('height', C.c_int), ('width', C.c_int), ('channels', C.c_int),
+                ('inter_res', C.c_int), ('zdim', C.c_int), ('max_batch', C.c_int)]
+
+
+class UadIO(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('eps', C.c_void_p), ('mask_mu', C.c_void_p), ('mask_sigma', C.c_void_p),
+                ('mask_dec', C.c_void_p), ('x_hat', C.c_void_p), ('l1_map', C.c_void_p), ('z_mu', C.c_void_p),
+                ('z_log_sigma', C.c_void_p), ('z_sigma', C.c_void_p), ('scalars', C.c_void_p),
+                ('rec_per_sample', C.c_void_p)]
+
+
+class UadConvDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ('N', 'HB', 'WB', 'CB', 'HS', 'WS', 'CS', 'KS', 'S', 'P')]
+
+
+class UadXform(C.Structure):
+    _fields_ = [('scale', C.c_void_p), ('shift', C.c_void_p), ('alpha', C.c_float)]
+
+
+# every symbol include/uad_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    'uad_last_error': (C.c_char_p, []),
+    'uad_version': (C.c_char_p, []),
+    'uad_create': (C.c_int, [C.POINTER(UadConfig), C.POINTER(C.c_void_p)]),
+    'uad_destroy': (C.c_int, [C.c_void_p]),
+    'uad_param_count': (C.c_longlong, [C.c_void_p]),
+    'uad_num_tensors': (C.c_int, [C.c_void_p]),
+    'uad_tensor_info': (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_longlong),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'uad_buffer': (C.c_void_p, [C.c_void_p, C.c_int]),
+    'uad_grad_segment': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    'uad_set_params': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
+    'uad_get_params': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong]),
+    'uad_get_buffer': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),
+    'uad_set_buffer': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),
+    'uad_reset_optimizer': (C.c_int, [C.c_void_p]),
+    'uad_get_step': (C.c_longlong, [C.c_void_p]),
+    'uad_set_step': (C.c_int, [C.c_void_p, C.c_longlong]),
+    'uad_forward': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_int, C.c_void_p]),
+    'uad_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'uad_adam_step': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'uad_train_step': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_void_p]),
+    'uad_residual': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
+    'uad_op_conv_f': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'uad_op_conv_d': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'uad_op_conv_f_bwdact': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(UadXform), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'uad_op_conv_d_bwdact': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(UadXform), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'uad_op_conv_w': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p,
+                                C.POINTER(UadXform), C.c_void_p, C.c_void_p]),
+    'uad_op_conv_first_fwd': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    'uad_op_conv_first_wgrad': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'uad_op_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float,
+                              C.c_float, C.c_float, C.c_float, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libuad_hip.so and bind every declared symbol.  Raises RuntimeError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: the HIP extension has not been built '
+            f'(run `python -m unsupervised_anomaly_detection_brain_mri_amd.build` or __graft_entry__.build()). '
+            f'There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != UAD_OK:
+        msg = load().uad_last_error().decode('utf-8', 'replace')
+        if rc in (1, 3):
+            raise ValueError(f'uad_hip: {msg}')
+        raise RuntimeError(f'uad_hip (code {rc}): {msg}')

@@ -1,0 +1,58 @@
+"""Builds libuad_hip.so (the C-ABI library declared in include/uad_hip.h) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU.  The .so is written IN-TREE next to this file so that it travels with the
+repo snapshot to the GPU box; objects are cached under build/ and rebuilt only when a source is newer.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, 'libuad_hip.so')
+SOURCES = ['uad_gemm.hip', 'uad_misc.hip', 'uad_model.hip']
+ARCH = 'gfx950'
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found (need ROCm to build libuad_hip.so)')
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force=False, verbose=False):
+    hipcc = _hipcc()
+    objdir = os.path.join(ROOT, 'build', 'uad_hip')
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, 'uad_kernels.h'), os.path.join(ROOT, 'include', 'uad_hip.h')]
+    objs = []
+    flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace('.hip', '.o'))
+        if force or _newer([src] + headers, obj):
+            cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _newer(objs, LIB):
+        cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC'] + objs + ['-o', LIB]
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,609 @@
+// Implicit-GEMM convolution kernels for gfx950 (CDNA4), fp32 in / fp32 accumulate on the
+// matrix cores (v_mfma_f32_32x32x2_f32: exact f32, 157 TFLOP/s chip peak).
+//
+// Three kernel families cover every contraction on the AE/VAE hot path
+// (reference: models/customlayers.py:16-38 Conv2D / Conv2DTranspose k5 s2 SAME, the 1x1 convs and
+//  Dense layers of models/variational_autoencoder.py:20-36, and their tf.gradients):
+//   F ("gather")  : small[n,i,j,cs]            = sum_tap,cb big[n,S*i-P+ky,S*j-P+kx,cb] * W[tap][cb][cs]
+//   D ("scatter") : big[n,S*i-P+ky,S*j-P+kx,cb] += small[n,i,j,cs] * W[tap][cb][cs]   (per output-parity class)
+//   W ("filter")  : dW[tap][cb][cs]             = sum_n,i,j big[..tap..,cb] * small[n,i,j,cs]
+// Layout: NHWC activations, W[tap][cb][cs] weights (HWIO for Conv2D, [kh,kw,Cout,Cin] for Conv2DTranspose),
+// so the channel (contraction) axis is always contiguous: 16-byte coalesced global loads, one 128-B line per
+// pixel per 32 channels.  Tiles are staged global -> VGPR -> LDS (double buffered, one barrier per K-step) because
+// the producer layer's frozen-BN affine + LeakyReLU is applied on load (activation tensors are stored once, pre-BN).
+// The 64-lane wavefront owns (32*FM)x(32*FN) of the block tile; K is walked 8 at a time with the lane-half
+// permutation k = 8*kk + 4*(lane>>5) + s so that one ds_read_b128 feeds four MFMAs.
+#include "uad_kernels.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define KIND_F 0
+#define KIND_D 1
+
+namespace {
+
+struct ConvGemmArgs {
+    const float* A;
+    const float* W;
+    float* Out;
+    UadXform xf;
+    UadEpilogue ep;
+    UadConvDesc d;
+    int M;         // N*HS*WS rows (small-image positions)
+    int CA;        // channels of the A operand (contraction per tap)
+    int Nn;        // output channels
+    int lws, lhs;  // log2(WS), log2(HS) or -1 when not a power of two
+};
+
+__device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int lws, int& n, int& i, int& j) {
+    if (lws >= 0 && lhs >= 0) {
+        j = m & (WS - 1);
+        int t = m >> lws;
+        i = t & (HS - 1);
+        n = t >> lhs;
+    } else {
+        j = m % WS;
+        int t = m / WS;
+        i = t % HS;
+        n = t / HS;
+    }
+}
+
+__device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, float alpha) {
+    float4 r;
+    r.x = fmaf(v.x, sc.x, sh.x); r.x = r.x > 0.f ? r.x : r.x * alpha;
+    r.y = fmaf(v.y, sc.y, sh.y); r.y = r.y > 0.f ? r.y : r.y * alpha;
+    r.z = fmaf(v.z, sc.z, sh.z); r.z = r.z > 0.f ? r.z : r.z * alpha;
+    r.w = fmaf(v.w, sc.w, sh.w); r.w = r.w > 0.f ? r.w : r.w * alpha;
+    return r;
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN, int KIND>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGemmArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int FM = WTM / 32, FN = WTN / 32;
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
+    static_assert(BK % 8 == 0, "BK multiple of 8");
+    constexpr int LDA = BK + 4;  // (LDA/4) odd -> conflict-free ds_read_b128 across 16-lane groups
+    constexpr int LDB = (KIND == KIND_F) ? (BN + 4) : (BK + 4);
+    constexpr int A_EL = BM * LDA;
+    constexpr int B_EL = (KIND == KIND_F) ? (BK * LDB) : (BN * LDB);
+    constexpr int STAGE = A_EL + B_EL;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const UadConvDesc& d = a.d;
+    const int S = d.S, P = d.P, KS = d.KS;
+
+    // ---- tap set: all KS*KS taps (F) or the taps of this output-parity class (D) ----
+    int py = 0, px = 0, ky0 = 0, kx0 = 0, nty = KS, ntx = KS, dy0 = 0, dx0 = 0;
+    if (KIND == KIND_D) {
+        const int cz = blockIdx.z;
+        py = (S - 1) - cz / S;
+        px = (S - 1) - cz % S;
+        ky0 = (py + P) % S;
+        kx0 = (px + P) % S;
+        dy0 = (py + P) / S;
+        dx0 = (px + P) / S;
+        nty = ky0 < KS ? (KS - ky0 + S - 1) / S : 0;
+        ntx = kx0 < KS ? (KS - kx0 + S - 1) / S : 0;
+    }
+    const int ntaps = nty * ntx;
+    const int ncc = a.CA / BK;
+    const int nk = ntaps * ncc;
+
+    // ---- per-thread A rows (positions) ----
+    constexpr int TPR = BK / 4, RPP = NT / TPR, PA = (BM + RPP - 1) / RPP;
+    const int acol = (tid % TPR) * 4;
+    const int arow0 = tid / TPR;
+    int rbase[PA], ry[PA], rx[PA];
+    bool rok[PA];
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+        const int r = arow0 + q * RPP;
+        const int m = m0 + r;
+        rok[q] = (r < BM) && (m < a.M);
+        int n, i, j;
+        decode_pos(rok[q] ? m : 0, d.HS, d.WS, a.lhs, a.lws, n, i, j);
+        if (KIND == KIND_F) {
+            rbase[q] = n * d.HB * d.WB;
+            ry[q] = S * i - P;
+            rx[q] = S * j - P;
+        } else {
+            rbase[q] = n * d.HS * d.WS;
+            ry[q] = i;
+            rx[q] = j;
+        }
+    }
+    const int AH = (KIND == KIND_F) ? d.HB : d.HS;
+    const int AW = (KIND == KIND_F) ? d.WB : d.WS;
+
+    // ---- per-thread B slots ----
+    constexpr int TPRB = (KIND == KIND_F) ? (BN / 4) : (BK / 4);
+    constexpr int RPB = NT / TPRB;
+    constexpr int BROWS = (KIND == KIND_F) ? BK : BN;
+    constexpr int PB = (BROWS + RPB - 1) / RPB;
+    const int bcol = (tid % TPRB) * 4;
+    const int brow0 = tid / TPRB;
+
+    float4 va[PA], vb[PB];
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned okbits = 0;
+    const bool xf = a.xf.scale != nullptr;
+
+    auto load_tiles = [&](int tap, int c0) {
+        int ky, kx, oy, ox;
+        {
+            const int ty = tap / ntx, tx = tap - ty * ntx;
+            ky = ky0 + S * ty;
+            kx = kx0 + S * tx;
+            if (KIND == KIND_F) { oy = ky; ox = kx; } else { oy = dy0 - ty; ox = dx0 - tx; }
+        }
+        if (xf) {
+            xsc = *reinterpret_cast<const float4*>(a.xf.scale + c0 + acol);
+            xsh = *reinterpret_cast<const float4*>(a.xf.shift + c0 + acol);
+        }
+        okbits = 0;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int y = ry[q] + oy, x = rx[q] + ox;
+            const bool ok = rok[q] && (unsigned)y < (unsigned)AH && (unsigned)x < (unsigned)AW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const size_t off = (size_t)(rbase[q] + y * AW + x) * a.CA + c0 + acol;
+                v = *reinterpret_cast<const float4*>(a.A + off);
+                okbits |= 1u << q;
+            }
+            va[q] = v;
+        }
+        const int tapw = ky * KS + kx;
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int r = brow0 + q * RPB;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KIND == KIND_F) {
+                if (r < BK && (n0 + bcol) < a.Nn)
+                    v = *reinterpret_cast<const float4*>(a.W + ((size_t)tapw * d.CB + c0 + r) * d.CS + n0 + bcol);
+            } else {
+                if (r < BN && (n0 + r) < a.Nn)
+                    v = *reinterpret_cast<const float4*>(a.W + ((size_t)tapw * d.CB + n0 + r) * d.CS + c0 + bcol);
+            }
+            vb[q] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* sA = smem + buf * STAGE;
+        float* sB = sA + A_EL;
+        float4 sc = xsc;
+        sc.x *= a.xf.mult; sc.y *= a.xf.mult; sc.z *= a.xf.mult; sc.w *= a.xf.mult;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int r = arow0 + q * RPP;
+            float4 v = va[q];
+            // padding pixels stay exactly 0 (the pad is applied to the ACTIVATED tensor)
+            if (xf && ((okbits >> q) & 1u)) v = xform4(v, sc, xsh, a.xf.alpha);
+            if (r < BM) *reinterpret_cast<float4*>(sA + r * LDA + acol) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int r = brow0 + q * RPB;
+            if (r < BROWS) *reinterpret_cast<float4*>(sB + r * LDB + bcol) = vb[q];
+        }
+    };
+
+    v16f acc[FM][FN];
+#pragma unroll
+    for (int im = 0; im < FM; ++im)
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[im][jn][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    if (nk > 0) {
+        load_tiles(0, 0);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    int tap = 0, cc = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        // advance (tap, cc) to step ks+1 and prefetch it into registers
+        int ntap = tap, ncc_ = cc + 1;
+        if (ncc_ == ncc) { ncc_ = 0; ntap = tap + 1; }
+        const bool more = (ks + 1 < nk);
+        if (more) load_tiles(ntap, ncc_ * BK);
+
+        const float* sA = smem + buf * STAGE;
+        const float* sB = sA + A_EL;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 af[FM];
+            float bf[FN][4];
+#pragma unroll
+            for (int im = 0; im < FM; ++im)
+                af[im] = *reinterpret_cast<const float4*>(sA + (wm * WTM + im * 32 + l31) * LDA + kk * 8 + 4 * lh);
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                if (KIND == KIND_F) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        bf[jn][s] = sB[(kk * 8 + 4 * lh + s) * LDB + wn * WTN + jn * 32 + l31];
+                } else {
+                    const float4 t = *reinterpret_cast<const float4*>(sB + (wn * WTN + jn * 32 + l31) * LDB + kk * 8 + 4 * lh);
+                    bf[jn][0] = t.x; bf[jn][1] = t.y; bf[jn][2] = t.z; bf[jn][3] = t.w;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int im = 0; im < FM; ++im) {
+                    const float av = (s == 0) ? af[im].x : (s == 1) ? af[im].y : (s == 2) ? af[im].z : af[im].w;
+#pragma unroll
+                    for (int jn = 0; jn < FN; ++jn)
+                        acc[im][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[jn][s], acc[im][jn], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+        tap = ntap;
+        cc = ncc_;
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
+    float s1[FN], s2[FN];
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) { s1[jn] = 0.f; s2[jn] = 0.f; }
+
+#pragma unroll
+    for (int im = 0; im < FM; ++im) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + row;
+            if (m >= a.M) continue;
+            size_t obase;
+            if (KIND == KIND_F) {
+                obase = (size_t)m * a.Nn;
+            } else {
+                int n, i, j;
+                decode_pos(m, d.HS, d.WS, a.lhs, a.lws, n, i, j);
+                obase = ((size_t)(n * d.HB + S * i + py) * d.WB + (S * j + px)) * a.Nn;
+            }
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                const int col = n0 + wn * WTN + jn * 32 + l31;
+                if (col >= a.Nn) continue;
+                const size_t off = obase + col;
+                float v = acc[im][jn][r];
+                if (!bwd) {
+                    if (a.ep.bias) v += a.ep.bias[col];
+                    if (a.ep.mul) v *= a.ep.mul[off];
+                    if (a.ep.add) v += a.ep.add[off];
+                    a.Out[off] = v;
+                } else {
+                    const float c = a.ep.cprev[off];
+                    const float esc = a.ep.escale[col] * a.ep.emult;
+                    const float bn = fmaf(esc, c, a.ep.eshift[col]);
+                    const float dbn = bn > 0.f ? v : v * a.ep.ealpha;
+                    a.Out[off] = dbn * esc;
+                    s1[jn] += dbn;
+                    s2[jn] = fmaf(dbn, c, s2[jn]);
+                }
+            }
+        }
+    }
+    if (bwd) {
+        // column sums: lane halves -> waves along M -> one partial row per block tile
+        float* red = smem;  // [WGM][2][BN]
+        __syncthreads();
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn) {
+            float t1 = s1[jn] + __shfl_xor(s1[jn], 32);
+            float t2 = s2[jn] + __shfl_xor(s2[jn], 32);
+            if (lh == 0) {
+                red[(wm * 2 + 0) * BN + wn * WTN + jn * 32 + l31] = t1;
+                red[(wm * 2 + 1) * BN + wn * WTN + jn * 32 + l31] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) t += red[(w * 2 + which) * BN + c];
+            const int col = n0 + c;
+            const size_t tile = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+            if (col < a.Nn) a.ep.colpart[(tile * 2 + which) * a.Nn + col] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// W-type: filter gradient.  GEMM M = (tap, cb) flattened, N = cs, K = positions (split over blockIdx.z).
+// ------------------------------------------------------------------------------------------------
+struct ConvWArgs {
+    const float* big;
+    const float* small_;
+    float* partial;
+    UadXform xfb, xfs;
+    UadConvDesc d;
+    int Mtot;  // KS*KS*CB
+    int Kt;    // N*HS*WS
+    int kper;  // positions per split (multiple of BK)
+    int lws, lhs;
+};
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv_w_kernel(const ConvWArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int FM = WTM / 32, FN = WTN / 32;
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int A_EL = BK * LDA, B_EL = BK * LDB, STAGE = A_EL + B_EL;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const UadConvDesc& d = a.d;
+    const int kbeg = blockIdx.z * a.kper;
+    const int kend = min(kbeg + a.kper, a.Kt);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    constexpr int TPRA = BM / 4, RPA = NT / TPRA, PA = (BK + RPA - 1) / RPA;
+    const int acol = (tid % TPRA) * 4, arow0 = tid / TPRA;
+    const int mcol = m0 + acol;
+    const bool acolok = mcol < a.Mtot;
+    const int tapA = acolok ? mcol / d.CB : 0;
+    const int cbA = acolok ? mcol - tapA * d.CB : 0;
+    const int kyA = tapA / d.KS, kxA = tapA - kyA * d.KS;
+    float4 scA = make_float4(1, 1, 1, 1), shA = make_float4(0, 0, 0, 0);
+    const bool xfa = a.xfb.scale != nullptr;
+    if (xfa && acolok) {
+        scA = *reinterpret_cast<const float4*>(a.xfb.scale + cbA);
+        shA = *reinterpret_cast<const float4*>(a.xfb.shift + cbA);
+        scA.x *= a.xfb.mult; scA.y *= a.xfb.mult; scA.z *= a.xfb.mult; scA.w *= a.xfb.mult;
+    }
+    constexpr int TPRB = BN / 4, RPB = NT / TPRB, PB = (BK + RPB - 1) / RPB;
+    const int bcol = (tid % TPRB) * 4, brow0 = tid / TPRB;
+    const int ncol = n0 + bcol;
+    const bool bcolok = ncol < d.CS;
+    float4 scB = make_float4(1, 1, 1, 1), shB = make_float4(0, 0, 0, 0);
+    const bool xfs = a.xfs.scale != nullptr;
+    if (xfs && bcolok) {
+        scB = *reinterpret_cast<const float4*>(a.xfs.scale + ncol);
+        shB = *reinterpret_cast<const float4*>(a.xfs.shift + ncol);
+        scB.x *= a.xfs.mult; scB.y *= a.xfs.mult; scB.z *= a.xfs.mult; scB.w *= a.xfs.mult;
+    }
+
+    float4 va[PA], vb[PB];
+    unsigned okA = 0, okB = 0;
+    auto load_tiles = [&](int kpos) {
+        okA = 0; okB = 0;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int r = arow0 + q * RPA;
+            const int pos = kpos + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < BK && pos < kend && acolok) {
+                int n, i, j;
+                decode_pos(pos, d.HS, d.WS, a.lhs, a.lws, n, i, j);
+                const int y = d.S * i - d.P + kyA, x = d.S * j - d.P + kxA;
+                if ((unsigned)y < (unsigned)d.HB && (unsigned)x < (unsigned)d.WB) {
+                    v = *reinterpret_cast<const float4*>(a.big + ((size_t)(n * d.HB + y) * d.WB + x) * d.CB + cbA);
+                    okA |= 1u << q;
+                }
+            }
+            va[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int r = brow0 + q * RPB;
+            const int pos = kpos + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < BK && pos < kend && bcolok) {
+                v = *reinterpret_cast<const float4*>(a.small_ + (size_t)pos * d.CS + ncol);
+                okB |= 1u << q;
+            }
+            vb[q] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* sA = smem + buf * STAGE;
+        float* sB = sA + A_EL;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int r = arow0 + q * RPA;
+            float4 v = va[q];
+            if (xfa && ((okA >> q) & 1u)) v = xform4(v, scA, shA, a.xfb.alpha);
+            if (r < BK) *reinterpret_cast<float4*>(sA + r * LDA + acol) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int r = brow0 + q * RPB;
+            float4 v = vb[q];
+            if (xfs && ((okB >> q) & 1u)) v = xform4(v, scB, shB, a.xfs.alpha);
+            if (r < BK) *reinterpret_cast<float4*>(sB + r * LDB + bcol) = v;
+        }
+    };
+
+    v16f acc[FM][FN];
+#pragma unroll
+    for (int im = 0; im < FM; ++im)
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[im][jn][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (nk > 0) {
+        load_tiles(kbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        const bool more = ks + 1 < nk;
+        if (more) load_tiles(kbeg + (ks + 1) * BK);
+        const float* sA = smem + buf * STAGE;
+        const float* sB = sA + A_EL;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = kk * 8 + 4 * lh + s;
+                float av[FM], bv[FN];
+#pragma unroll
+                for (int im = 0; im < FM; ++im) av[im] = sA[k * LDA + wm * WTM + im * 32 + l31];
+#pragma unroll
+                for (int jn = 0; jn < FN; ++jn) bv[jn] = sB[k * LDB + wn * WTN + jn * 32 + l31];
+#pragma unroll
+                for (int im = 0; im < FM; ++im)
+#pragma unroll
+                    for (int jn = 0; jn < FN; ++jn)
+                        acc[im][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[im], bv[jn], acc[im][jn], 0, 0, 0);
+            }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.partial + (size_t)blockIdx.z * a.Mtot * d.CS;
+#pragma unroll
+    for (int im = 0; im < FM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= a.Mtot) continue;
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                const int col = n0 + wn * WTN + jn * 32 + l31;
+                if (col < d.CS) out[(size_t)m * d.CS + col] = acc[im][jn][r];
+            }
+        }
+}
+
+inline int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+struct TileChoice { int BM, BN, BK; };
+
+inline TileChoice choose_tile(long M, int Nn, int CA, int classes) {
+    TileChoice t;
+    t.BK = (CA % 32 == 0) ? 32 : 16;
+    t.BN = (Nn > 32) ? 64 : 32;
+    auto nwg = [&](int bm) { return ((M + bm - 1) / bm) * ((Nn + t.BN - 1) / t.BN) * classes; };
+    t.BM = (t.BK == 32 && nwg(128) >= 512) ? 128 : 64;
+    return t;
+}
+
+template <int KIND>
+void launch_gemm(const ConvGemmArgs& a, int classes, hipStream_t st) {
+    const TileChoice t = choose_tile(a.M, a.Nn, a.CA, classes);
+    dim3 grid((a.M + t.BM - 1) / t.BM, (a.Nn + t.BN - 1) / t.BN, classes);
+#define UAD_GEMM_CASE(bm, bn, bk, wgm, wgn)                                                              \
+    if (t.BM == bm && t.BN == bn && t.BK == bk) {                                                        \
+        hipLaunchKernelGGL((conv_gemm_kernel<bm, bn, bk, wgm, wgn, KIND>), grid, dim3(64 * wgm * wgn), 0, st, a); \
+        return;                                                                                          \
+    }
+    UAD_GEMM_CASE(128, 64, 32, 2, 2)
+    UAD_GEMM_CASE(128, 32, 32, 4, 1)
+    UAD_GEMM_CASE(64, 64, 32, 2, 2)
+    UAD_GEMM_CASE(64, 32, 32, 2, 1)
+    UAD_GEMM_CASE(64, 64, 16, 2, 2)
+    UAD_GEMM_CASE(64, 32, 16, 2, 1)
+#undef UAD_GEMM_CASE
+}
+
+}  // namespace
+
+int uad_conv_f_tiles(const UadConvDesc& d) {
+    const long M = (long)d.N * d.HS * d.WS;
+    const TileChoice t = choose_tile(M, d.CS, d.CB, 1);
+    return (int)((M + t.BM - 1) / t.BM);
+}
+
+int uad_conv_d_tiles(const UadConvDesc& d) {
+    const long M = (long)d.N * d.HS * d.WS;
+    const int classes = d.S * d.S;
+    const TileChoice t = choose_tile(M, d.CB, d.CS, classes);
+    return (int)((M + t.BM - 1) / t.BM) * classes;
+}
+
+void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W, float* small_out,
+                       UadEpilogue ep, hipStream_t st) {
+    ConvGemmArgs a;
+    a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
+    a.M = d.N * d.HS * d.WS; a.CA = d.CB; a.Nn = d.CS;
+    a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
+    launch_gemm<KIND_F>(a, 1, st);
+}
+
+void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W, float* big_out,
+                       UadEpilogue ep, hipStream_t st) {
+    ConvGemmArgs a;
+    a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
+    a.M = d.N * d.HS * d.WS; a.CA = d.CS; a.Nn = d.CB;
+    a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
+    launch_gemm<KIND_D>(a, d.S * d.S, st);
+}
+
+// ---- W-type host side -------------------------------------------------------------------------
+namespace {
+struct WChoice { int BM, BN, splits, kper; };
+inline WChoice choose_w(const UadConvDesc& d) {
+    WChoice c;
+    const int Mtot = d.KS * d.KS * d.CB;
+    const long Kt = (long)d.N * d.HS * d.WS;
+    c.BM = (Mtot >= 128) ? 128 : 64;
+    c.BN = (d.CS > 32) ? 64 : 32;
+    const long tiles = (long)((Mtot + c.BM - 1) / c.BM) * ((d.CS + c.BN - 1) / c.BN);
+    const long ksteps = (Kt + 31) / 32;
+    long splits = (1024 + tiles - 1) / tiles;          // aim for >= ~1024 workgroups
+    long max_splits = (ksteps + 7) / 8;                // but keep >= 8 K-steps per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long steps_per = (ksteps + splits - 1) / splits;
+    c.kper = (int)steps_per * 32;
+    c.splits = (int)((Kt + c.kper - 1) / c.kper);
+    return c;
+}
+}  // namespace
+
+size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
+    const WChoice c = choose_w(d);
+    return (size_t)c.splits * d.KS * d.KS * d.CB * d.CS;
+}
+
+void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
+                       float* dW, float* partial, hipStream_t st) {
+    const WChoice c = choose_w(d);
+    ConvWArgs a;
+    a.big = big; a.small_ = small; a.partial = (c.splits == 1) ? dW : partial;
+    a.xfb = xfb; a.xfs = xfs; a.d = d;
+    a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = c.kper;
+    a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
+    dim3 grid((a.Mtot + c.BM - 1) / c.BM, (d.CS + c.BN - 1) / c.BN, c.splits);
+    if (c.BM == 128 && c.BN == 64)
+        hipLaunchKernelGGL((conv_w_kernel<128, 64, 32, 2, 2>), grid, dim3(256), 0, st, a);
+    else if (c.BM == 128 && c.BN == 32)
+        hipLaunchKernelGGL((conv_w_kernel<128, 32, 32, 4, 1>), grid, dim3(256), 0, st, a);
+    else if (c.BM == 64 && c.BN == 64)
+        hipLaunchKernelGGL((conv_w_kernel<64, 64, 32, 2, 2>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_w_kernel<64, 32, 32, 2, 1>), grid, dim3(128), 0, st, a);
+    if (c.splits > 1) uad_launch_reduce_partials(partial, c.splits, a.Mtot * d.CS, 1.0f, dW, st);
+}

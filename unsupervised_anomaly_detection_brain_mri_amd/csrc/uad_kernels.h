@@ -1,0 +1,121 @@
+// Internal C++ launch interface for the gfx950 kernels (not the public C-ABI;
+// that is include/uad_hip.h).  All pointers are device pointers, all tensors are
+// fp32 NHWC, all launches are asynchronous on the given stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// One strided-conv relation between a "big" (finer grid) and a "small" image:
+//   big pixel  (S*i - P + ky, S*j - P + kx)  <->  small pixel (i, j),  tap (ky,kx)
+// Weight tensor is always W[tap][cb][cs] (big-side channel first):
+//   Conv2D          kernel [kh,kw,Cin ,Cout] : big = input , small = output
+//   Conv2DTranspose kernel [kh,kw,Cout,Cin ] : big = output, small = input
+// Dense [in,out] and 1x1 convs are the KS=1,S=1,P=0 case.
+struct UadConvDesc {
+    int N;
+    int HB, WB, CB;
+    int HS, WS, CS;
+    int KS, S, P;
+};
+
+// Activation-on-load: v -> lrelu_alpha(scale[c]*v + shift[c]) (frozen-stats BN +
+// LeakyReLU/ReLU of the producer layer, applied by the consumer).  scale == nullptr
+// means identity.
+struct UadXform {
+    const float* scale;   // gamma (or a ready-made scale when mult == 1)
+    const float* shift;   // beta
+    float alpha;
+    float mult;           // scale multiplier: 1/sqrt(1+eps) of the frozen-stats BN
+};
+
+enum { UAD_EPI_BIAS = 0, UAD_EPI_BWD_ACT = 1 };
+
+struct UadEpilogue {
+    int kind;             // UAD_EPI_*
+    const float* bias;    // EPI_BIAS: per output channel, may be null
+    const float* mul;     // EPI_BIAS: optional elementwise multiplier, same layout as out
+    const float* add;     // EPI_BIAS: optional elementwise addend (applied after mul), same layout as out
+    // EPI_BWD_ACT: out = acc * lrelu'(escale*cprev+eshift) * escale ; column sums of
+    // d_bn and d_bn*cprev are written to colpart[tile][2][Cout]
+    const float* cprev;
+    const float* escale;
+    const float* eshift;
+    float ealpha;
+    float emult;          // escale multiplier (see UadXform::mult)
+    float* colpart;
+};
+
+// F-type: small_out[n,i,j,cs] = sum_{tap,cb} xf(big_in)[n,S*i-P+ky,S*j-P+kx,cb] * W[tap][cb][cs]
+void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W,
+                       float* small_out, UadEpilogue ep, hipStream_t st);
+// D-type: big_out[n,S*i-P+ky,S*j-P+kx,cb] += xf(small_in)[n,i,j,cs] * W[tap][cb][cs]
+void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W,
+                       float* big_out, UadEpilogue ep, hipStream_t st);
+// number of colpart tiles the above launches write for EPI_BWD_ACT
+int uad_conv_f_tiles(const UadConvDesc& d);
+int uad_conv_d_tiles(const UadConvDesc& d);
+// W-type: dW[tap][cb][cs] = sum_{n,i,j} xfb(big)[..tap..,cb] * xfs(small)[n,i,j,cs]
+// `partial` must hold uad_conv_w_partial_floats(d) floats.
+size_t uad_conv_w_partial_floats(const UadConvDesc& d);
+void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
+                       float* dW, float* partial, hipStream_t st);
+
+// out[j] = scale * sum_{s<S} partial[s*L + j]
+void uad_launch_reduce_partials(const float* partial, int S, int L, float scale, float* out, hipStream_t st);
+// dbeta = S1, dgamma = rstd*S2, dbias = gamma*rstd*S1 with S1,S2 = sum over T tiles of colpart[t][0/1][c]
+void uad_launch_bn_grad_finalize(const float* colpart, int T, int C, const float* gamma, float rstd,
+                                 float* dgamma, float* dbeta, float* dbias, hipStream_t st);
+// out[c] = sum_rows g[row][c]
+void uad_launch_colsum(const float* g, int rows, int C, float* out, float* scratch, hipStream_t st);
+size_t uad_colsum_scratch_floats(int rows, int C);
+
+// first layer (tiny Cin, raw image input): direct conv + bias, and its weight gradient
+void uad_launch_conv_first_fwd(const UadConvDesc& d, const float* x, const float* W, const float* bias,
+                               float* out, hipStream_t st);
+size_t uad_conv_first_wgrad_partial_floats(const UadConvDesc& d);
+void uad_launch_conv_first_wgrad(const UadConvDesc& d, const float* x, const float* g, float* dW,
+                                 float* partial, hipStream_t st);
+
+// final 1x1 conv (C -> 1) fused with the L1 loss and its backward
+struct UadFinalArgs {
+    int N, H, W, C;          // c_last is [N,H,W,C]
+    const float* c_last;     // pre-BN output of the last ConvT
+    const float* scale;      // BN scale/shift of the last block (activation on load)
+    const float* shift;
+    float alpha;
+    float mult;              // scale multiplier (1/sqrt(1+eps))
+    const float* wf;         // [C] final conv kernel
+    const float* bf;         // [1]
+    const float* x;          // [N,H,W,1] target
+    float* x_hat;            // [N,H,W,1]
+    float* l1_map;           // [N,H,W,1] or null
+    float* rec_partial;      // [N][blocks_per_sample]
+    // backward (null d_c => forward only)
+    float* d_c;              // [N,H,W,C]
+    float* red_partial;      // [N*blocks_per_sample][3*C+1]: dwf[C], S1[C], S2[C], dbf
+    float inv_batch;         // 1/global_batch
+};
+int uad_final_blocks_per_sample(int H, int W);
+void uad_launch_final_fwd_bwd(const UadFinalArgs& a, hipStream_t st);
+
+// reparameterisation + KL (VAE bottleneck)
+void uad_launch_reparam_fwd(int n, int zdim, const float* mu_raw, const float* ls_raw, const float* mask_mu,
+                            const float* mask_ls, const float* eps, float* mu, float* ls, float* sigma, float* z,
+                            float* kl_per_sample, hipStream_t st);
+void uad_launch_reparam_bwd(int n, int zdim, const float* dz, const float* mu, const float* sigma, const float* eps,
+                            const float* mask_mu, const float* mask_ls, float inv_batch, float* dmu_raw,
+                            float* dls_raw, hipStream_t st);
+// y = x * mask (mask may be null -> copy)
+void uad_launch_mul(const float* x, const float* mask, float* y, size_t n, hipStream_t st);
+// scalars[0]=reconstructionLoss, [1]=kl, [2]=loss  (means over the LOCAL batch * local_weight)
+void uad_launch_loss_finalize(const float* rec_partial, int n, int bps, const float* kl_per_sample, float inv_batch,
+                              float* rec_per_sample, float* scalars, hipStream_t st);
+
+// TF-form Adam over a flat parameter buffer: g is multiplied by gscale first
+void uad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2,
+                     float eps, float gscale, hipStream_t st);
+
+// residual anomaly map (utils/Evaluation.py:282-289): out = mask * (pos_only ? max(x-xr,0) : |x-xr|),
+// zeroed where x < prior_thresh (pass -inf to disable); per-sample sum|x-xr| into l1err[n] (may be null)
+void uad_launch_residual(const float* x, const float* xr, const float* mask, int n, int hw, int pos_only,
+                         float prior_thresh, float* out, float* l1err, hipStream_t st);

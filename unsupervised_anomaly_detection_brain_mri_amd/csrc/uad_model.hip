@@ -1,0 +1,657 @@
+// Model-level orchestration + the C-ABI (include/uad_hip.h) for the dense-bottleneck AE / VAE.
+// One handle owns the flat fp32 parameter / gradient / Adam-slot buffers, every pre-BN activation of the step and
+// the reduction scratch; a train step is ~60 asynchronous kernel launches on the caller's stream, no host sync.
+//
+// Graph restated (reference): models/customlayers.py:16-38, models/autoencoder.py:9-40,
+// models/variational_autoencoder.py:9-47; losses trainers/AE.py:28-29, trainers/VAE.py:36-42;
+// Adam trainers/DLMODEL.py:112-131.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/uad_hip.h"
+#include "uad_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(UAD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr float kBnEps = 1e-3f;     // tf.layers.BatchNormalization default epsilon
+constexpr float kLrelu = 0.3f;      // keras LeakyReLU() default (customlayers.py:23,36)
+
+struct Tensor {
+    std::string name;
+    long long off;
+    int rank;
+    int shape[4];
+    long long count() const { return (long long)shape[0] * shape[1] * shape[2] * shape[3]; }
+};
+
+struct ConvLayer {        // conv / convT block followed by BN + (Leaky)ReLU
+    UadConvDesc d;        // geometry at batch 1 (N filled per call)
+    long long w, b, gamma, beta;   // flat offsets
+    float* c;             // pre-BN output [N, ., ., C]
+};
+
+}  // namespace
+
+struct uad_model {
+    uad_config_t cfg;
+    int n_pool, cenc, cmid, flat;
+    std::vector<Tensor> tensors;
+    long long nparams;
+    long long seg_off[3], seg_cnt[3];
+    float *params, *grads, *adam_m, *adam_v;
+    long long step;
+    // layers
+    std::vector<ConvLayer> enc, dec;
+    long long bw, bb;                 // Bottleneck/conv2d
+    long long muw, mub, sgw, sgb;     // dense mu / sigma (AE: muw/mub = dense_z)
+    long long dw, db;                 // dense_dec
+    long long rw, rb;                 // Bottleneck/conv2d_1
+    long long dbn_g, dbn_b;           // Decoder/batch_normalization (input BN + ReLU)
+    long long fw, fb;                 // dec_Conv2D_final
+    // activations
+    float *t, *mu_raw, *ls_raw, *mu, *ls, *sigma, *z, *dvec, *cb, *kl;
+    float *xhat_own;
+    // gradient ping-pong + small grads
+    float *G0, *G1;
+    float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
+    // scratch
+    float *colpart, *wpartial, *colscratch, *red_partial, *rec_partial, *rec_ps, *scalars_own;
+    size_t colpart_cap, wpartial_cap;
+    // state of the last forward
+    int last_n;
+    uad_io_t last_io;
+    bool have_fwd;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+float* P(uad_model* m, long long off) { return m->params + off; }
+float* Gr(uad_model* m, long long off) { return m->grads + off; }
+
+UadXform bn_xform(uad_model* m, long long gamma, long long beta, float alpha) {
+    UadXform x;
+    x.scale = P(m, gamma); x.shift = P(m, beta); x.alpha = alpha; x.mult = 1.0f / sqrtf(1.0f + kBnEps);
+    return x;
+}
+UadXform no_xform() { UadXform x; x.scale = nullptr; x.shift = nullptr; x.alpha = 1.f; x.mult = 1.f; return x; }
+
+UadEpilogue epi_bias(const float* bias, const float* mul = nullptr, const float* add = nullptr) {
+    UadEpilogue e;
+    memset(&e, 0, sizeof e);
+    e.kind = UAD_EPI_BIAS; e.bias = bias; e.mul = mul; e.add = add;
+    return e;
+}
+UadEpilogue epi_bwd(uad_model* m, const float* cprev, long long gamma, long long beta, float alpha) {
+    UadEpilogue e;
+    memset(&e, 0, sizeof e);
+    e.kind = UAD_EPI_BWD_ACT; e.cprev = cprev; e.escale = P(m, gamma); e.eshift = P(m, beta); e.ealpha = alpha;
+    e.emult = 1.0f / sqrtf(1.0f + kBnEps); e.colpart = m->colpart;
+    return e;
+}
+
+long long add_tensor(uad_model* m, const std::string& name, int rank, int s0, int s1, int s2, int s3) {
+    Tensor t;
+    t.name = name; t.off = m->nparams; t.rank = rank;
+    t.shape[0] = s0; t.shape[1] = s1; t.shape[2] = s2; t.shape[3] = s3;
+    m->nparams += t.count();
+    m->tensors.push_back(t);
+    return t.off;
+}
+
+int dev_alloc(uad_model* m, float** p, size_t floats) {
+    void* q = nullptr;
+    if (floats == 0) floats = 4;
+    HIP_TRY(hipMalloc(&q, floats * sizeof(float)));
+    HIP_TRY(hipMemset(q, 0, floats * sizeof(float)));
+    m->allocs.push_back(q);
+    *p = (float*)q;
+    return UAD_OK;
+}
+
+UadConvDesc dense_desc(int n, int in, int out) { return UadConvDesc{n, 1, 1, in, 1, 1, out, 1, 1, 0}; }
+UadConvDesc conv1x1_desc(int n, int h, int w, int cin, int cout) { return UadConvDesc{n, h, w, cin, h, w, cout, 1, 1, 0}; }
+
+int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+}  // namespace
+
+extern "C" {
+
+const char* uad_last_error(void) { return g_err.c_str(); }
+const char* uad_version(void) { return "uad_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int uad_create(const uad_config_t* cfg, uad_model_t** out) {
+    if (!cfg || !out) return fail(UAD_ERR_INVALID, "null argument");
+    const int H = cfg->height, Wd = cfg->width;
+    if (H != Wd || H <= 0 || (H & (H - 1))) return fail(UAD_ERR_INVALID, "height/width must be equal powers of two");
+    if (cfg->inter_res <= 0 || (cfg->inter_res & (cfg->inter_res - 1)) || cfg->inter_res >= H)
+        return fail(UAD_ERR_INVALID, "inter_res must be a power of two smaller than height");
+    if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
+    if (cfg->arch != UAD_ARCH_AE && cfg->arch != UAD_ARCH_VAE) return fail(UAD_ERR_INVALID, "bad arch");
+    if (cfg->zdim <= 0 || cfg->zdim % 16) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 16");
+    if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
+
+    uad_model* m = new uad_model();
+    m->cfg = *cfg;
+    m->nparams = 0;
+    m->step = 0;
+    m->have_fwd = false;
+    const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
+    m->n_pool = npool;
+    const bool vae = cfg->arch == UAD_ARCH_VAE;
+    char nm[128];
+
+    // ---- parameter table in TF variable-creation order ----
+    int cin = cfg->channels, res = H;
+    for (int i = 0; i < npool; ++i) {
+        const int f = (32 << i) < 128 ? (32 << i) : 128;
+        ConvLayer L;
+        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
+        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
+        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        snprintf(nm, sizeof nm, "Encoder/batch_normalization_%d/gamma", i); L.gamma = add_tensor(m, nm, 1, f, 1, 1, 1);
+        snprintf(nm, sizeof nm, "Encoder/batch_normalization_%d/beta", i); L.beta = add_tensor(m, nm, 1, f, 1, 1, 1);
+        L.c = nullptr;
+        m->enc.push_back(L);
+        cin = f; res /= 2;
+    }
+    m->seg_off[UAD_SEG_ENCODER] = 0; m->seg_cnt[UAD_SEG_ENCODER] = m->nparams;
+    m->cenc = cin; m->cmid = cin / 8;
+    const int ir = cfg->inter_res;
+    m->flat = ir * ir * m->cmid;
+    if (m->cmid % 16 || m->flat % 16) { delete m; return fail(UAD_ERR_UNSUPPORTED, "bottleneck channels must be a multiple of 16"); }
+    m->bw = add_tensor(m, "Bottleneck/conv2d/kernel", 4, 1, 1, m->cenc, m->cmid);
+    m->bb = add_tensor(m, "Bottleneck/conv2d/bias", 1, m->cmid, 1, 1, 1);
+    if (vae) {
+        m->muw = add_tensor(m, "Bottleneck/dense_mu/kernel", 2, m->flat, cfg->zdim, 1, 1);
+        m->mub = add_tensor(m, "Bottleneck/dense_mu/bias", 1, cfg->zdim, 1, 1, 1);
+        m->sgw = add_tensor(m, "Bottleneck/dense_sigma/kernel", 2, m->flat, cfg->zdim, 1, 1);
+        m->sgb = add_tensor(m, "Bottleneck/dense_sigma/bias", 1, cfg->zdim, 1, 1, 1);
+    } else {
+        m->muw = add_tensor(m, "Bottleneck/dense_z/kernel", 2, m->flat, cfg->zdim, 1, 1);
+        m->mub = add_tensor(m, "Bottleneck/dense_z/bias", 1, cfg->zdim, 1, 1, 1);
+        m->sgw = m->sgb = -1;
+    }
+    m->dw = add_tensor(m, "Bottleneck/dense_dec/kernel", 2, cfg->zdim, m->flat, 1, 1);
+    m->db = add_tensor(m, "Bottleneck/dense_dec/bias", 1, m->flat, 1, 1, 1);
+    m->rw = add_tensor(m, "Bottleneck/conv2d_1/kernel", 4, 1, 1, m->cmid, m->cenc);
+    m->rb = add_tensor(m, "Bottleneck/conv2d_1/bias", 1, m->cenc, 1, 1, 1);
+    m->seg_off[UAD_SEG_BOTTLENECK] = m->seg_cnt[UAD_SEG_ENCODER];
+    m->seg_cnt[UAD_SEG_BOTTLENECK] = m->nparams - m->seg_off[UAD_SEG_BOTTLENECK];
+    m->dbn_g = add_tensor(m, "Decoder/batch_normalization/gamma", 1, m->cenc, 1, 1, 1);
+    m->dbn_b = add_tensor(m, "Decoder/batch_normalization/beta", 1, m->cenc, 1, 1, 1);
+    cin = m->cenc; res = ir;
+    for (int i = 0; i < npool; ++i) {
+        const int f = (128 >> i) > 32 ? (128 >> i) : 32;
+        ConvLayer L;
+        L.d = UadConvDesc{1, res * 2, res * 2, f, res, res, cin, 5, 2, 1};   // big = output (f ch), small = input (cin ch)
+        snprintf(nm, sizeof nm, "Decoder/dec_Conv2DT_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, f, cin);
+        snprintf(nm, sizeof nm, "Decoder/dec_Conv2DT_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        snprintf(nm, sizeof nm, "Decoder/batch_normalization_%d/gamma", i + 1); L.gamma = add_tensor(m, nm, 1, f, 1, 1, 1);
+        snprintf(nm, sizeof nm, "Decoder/batch_normalization_%d/beta", i + 1); L.beta = add_tensor(m, nm, 1, f, 1, 1, 1);
+        L.c = nullptr;
+        m->dec.push_back(L);
+        cin = f; res *= 2;
+    }
+    m->fw = add_tensor(m, "Decoder/dec_Conv2D_final/kernel", 4, 1, 1, cin, cfg->channels);
+    m->fb = add_tensor(m, "Decoder/dec_Conv2D_final/bias", 1, cfg->channels, 1, 1, 1);
+    m->seg_off[UAD_SEG_DECODER] = m->seg_off[UAD_SEG_BOTTLENECK] + m->seg_cnt[UAD_SEG_BOTTLENECK];
+    m->seg_cnt[UAD_SEG_DECODER] = m->nparams - m->seg_off[UAD_SEG_DECODER];
+    if (cin > 64 || cin % 4) { delete m; return fail(UAD_ERR_UNSUPPORTED, "last decoder width %d unsupported", cin); }
+    if (m->enc[0].d.CS % 8 || 256 % m->enc[0].d.CS) { delete m; return fail(UAD_ERR_UNSUPPORTED, "first conv width"); }
+
+    // ---- device memory ----
+    const size_t NB = (size_t)cfg->max_batch;
+    int rc = UAD_OK;
+#define ALLOC(ptr, n) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n))
+    ALLOC(m->params, (size_t)m->nparams); ALLOC(m->grads, (size_t)m->nparams);
+    ALLOC(m->adam_m, (size_t)m->nparams); ALLOC(m->adam_v, (size_t)m->nparams);
+    size_t maxact = 0;
+    for (auto& L : m->enc) { size_t n = NB * L.d.HS * L.d.WS * L.d.CS; ALLOC(L.c, n); if (n > maxact) maxact = n; }
+    for (auto& L : m->dec) { size_t n = NB * L.d.HB * L.d.WB * L.d.CB; ALLOC(L.c, n); if (n > maxact) maxact = n; }
+    const size_t nz = NB * cfg->zdim, nflat = NB * m->flat, ncb = NB * ir * ir * m->cenc;
+    ALLOC(m->t, nflat); ALLOC(m->mu_raw, nz); ALLOC(m->ls_raw, nz); ALLOC(m->mu, nz); ALLOC(m->ls, nz);
+    ALLOC(m->sigma, nz); ALLOC(m->z, nz); ALLOC(m->dvec, nflat); ALLOC(m->cb, ncb); ALLOC(m->kl, NB);
+    ALLOC(m->xhat_own, NB * H * Wd * cfg->channels);
+    ALLOC(m->G0, maxact); ALLOC(m->G1, maxact);
+    ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
+    ALLOC(m->g_small[4], nflat); ALLOC(m->g_small[5], nflat);
+    // column-partial scratch: worst case 64-row tiles
+    size_t cp = 0;
+    auto cp_need = [&](size_t rows, int classes, int C) { size_t v = ((rows + 63) / 64) * classes * 2 * C; if (v > cp) cp = v; };
+    for (auto& L : m->enc) cp_need(NB * L.d.HS * L.d.WS, 4, L.d.CB);
+    for (auto& L : m->dec) cp_need(NB * L.d.HS * L.d.WS, 1, L.d.CS);
+    cp_need(NB * ir * ir, 1, m->cenc);
+    m->colpart_cap = cp; ALLOC(m->colpart, cp);
+    size_t wp = 0;
+    auto wp_need = [&](UadConvDesc d) { d.N = (int)NB; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
+    for (size_t i = 1; i < m->enc.size(); ++i) wp_need(m->enc[i].d);
+    for (auto& L : m->dec) wp_need(L.d);
+    wp_need(conv1x1_desc(1, ir, ir, m->cenc, m->cmid)); wp_need(conv1x1_desc(1, ir, ir, m->cmid, m->cenc));
+    wp_need(dense_desc(1, m->flat, cfg->zdim)); wp_need(dense_desc(1, cfg->zdim, m->flat));
+    { UadConvDesc d0 = m->enc[0].d; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
+    m->wpartial_cap = wp; ALLOC(m->wpartial, wp);
+    ALLOC(m->colscratch, 64 * 1024);
+    const int bps = uad_final_blocks_per_sample(H, Wd);
+    ALLOC(m->red_partial, NB * bps * (3 * cin + 1)); ALLOC(m->rec_partial, NB * bps);
+    ALLOC(m->rec_ps, NB); ALLOC(m->scalars_own, 4);
+#undef ALLOC
+    if (rc != UAD_OK) { uad_destroy(m); return rc; }
+    *out = m;
+    return UAD_OK;
+}
+
+int uad_destroy(uad_model_t* m) {
+    if (!m) return UAD_OK;
+    for (void* p : m->allocs) hipFree(p);
+    delete m;
+    return UAD_OK;
+}
+
+long long uad_param_count(const uad_model_t* m) { return m ? m->nparams : 0; }
+int uad_num_tensors(const uad_model_t* m) { return m ? (int)m->tensors.size() : 0; }
+
+int uad_tensor_info(const uad_model_t* m, int idx, char* name, int name_cap, long long* offset, int* rank, int* shape4) {
+    if (!m || idx < 0 || idx >= (int)m->tensors.size()) return fail(UAD_ERR_INVALID, "tensor index out of range");
+    const Tensor& t = m->tensors[idx];
+    if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = t.off;
+    if (rank) *rank = t.rank;
+    if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+    return UAD_OK;
+}
+
+float* uad_buffer(uad_model_t* m, int which) {
+    if (!m) return nullptr;
+    switch (which) {
+        case UAD_BUF_PARAMS: return m->params;
+        case UAD_BUF_GRADS: return m->grads;
+        case UAD_BUF_ADAM_M: return m->adam_m;
+        case UAD_BUF_ADAM_V: return m->adam_v;
+    }
+    return nullptr;
+}
+
+int uad_grad_segment(const uad_model_t* m, int segment, long long* offset, long long* count) {
+    if (!m || segment < 0 || segment > 2) return fail(UAD_ERR_INVALID, "bad segment");
+    if (offset) *offset = m->seg_off[segment];
+    if (count) *count = m->seg_cnt[segment];
+    return UAD_OK;
+}
+
+int uad_set_buffer(uad_model_t* m, int which, const float* host, long long count) {
+    float* p = uad_buffer(m, which);
+    if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "set_buffer: bad arguments (count=%lld, expected %lld)", count, m ? m->nparams : -1);
+    HIP_TRY(hipMemcpy(p, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+    return UAD_OK;
+}
+int uad_get_buffer(uad_model_t* m, int which, float* host, long long count) {
+    float* p = uad_buffer(m, which);
+    if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "get_buffer: bad arguments");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return UAD_OK;
+}
+int uad_set_params(uad_model_t* m, const float* host, long long count) { return uad_set_buffer(m, UAD_BUF_PARAMS, host, count); }
+int uad_get_params(uad_model_t* m, float* host, long long count) { return uad_get_buffer(m, UAD_BUF_PARAMS, host, count); }
+
+int uad_reset_optimizer(uad_model_t* m) {
+    if (!m) return fail(UAD_ERR_INVALID, "null model");
+    HIP_TRY(hipMemset(m->adam_m, 0, (size_t)m->nparams * sizeof(float)));
+    HIP_TRY(hipMemset(m->adam_v, 0, (size_t)m->nparams * sizeof(float)));
+    m->step = 0;
+    return UAD_OK;
+}
+long long uad_get_step(const uad_model_t* m) { return m ? m->step : 0; }
+int uad_set_step(uad_model_t* m, long long t) { if (!m || t < 0) return fail(UAD_ERR_INVALID, "bad step"); m->step = t; return UAD_OK; }
+
+// ------------------------------------------------------------------------------------------------ forward
+int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, void* stream) {
+    if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
+    if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
+    if (!io->x) return fail(UAD_ERR_INVALID, "io.x is null");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vae = m->cfg.arch == UAD_ARCH_VAE;
+    const int ir = m->cfg.inter_res;
+
+    // encoder
+    {
+        UadConvDesc d = m->enc[0].d; d.N = n;
+        uad_launch_conv_first_fwd(d, io->x, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st);
+    }
+    for (size_t i = 1; i < m->enc.size(); ++i) {
+        UadConvDesc d = m->enc[i].d; d.N = n;
+        uad_launch_conv_f(d, m->enc[i - 1].c, bn_xform(m, m->enc[i - 1].gamma, m->enc[i - 1].beta, kLrelu),
+                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st);
+    }
+    const ConvLayer& EL = m->enc.back();
+    // bottleneck
+    uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cenc, m->cmid), EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu),
+                      P(m, m->bw), m->t, epi_bias(P(m, m->bb)), st);
+    if (vae) {
+        uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->muw), m->mu_raw, epi_bias(P(m, m->mub)), st);
+        uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->sgw), m->ls_raw, epi_bias(P(m, m->sgb)), st);
+        uad_launch_reparam_fwd(n, m->cfg.zdim, m->mu_raw, m->ls_raw, io->mask_mu, io->mask_sigma, io->eps, m->mu, m->ls,
+                               m->sigma, m->z, m->kl, st);
+        uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), m->z, no_xform(), P(m, m->dw), m->dvec,
+                          epi_bias(P(m, m->db), io->mask_dec), st);
+    } else {
+        uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->muw), m->z,
+                          epi_bias(P(m, m->mub), io->mask_mu), st);
+        uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), m->z, no_xform(), P(m, m->dw), m->dvec, epi_bias(P(m, m->db)), st);
+    }
+    uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cmid, m->cenc), m->dvec, no_xform(), P(m, m->rw), m->cb, epi_bias(P(m, m->rb)), st);
+    // decoder
+    for (size_t i = 0; i < m->dec.size(); ++i) {
+        UadConvDesc d = m->dec[i].d; d.N = n;
+        const float* in = (i == 0) ? m->cb : m->dec[i - 1].c;
+        UadXform xf = (i == 0) ? bn_xform(m, m->dbn_g, m->dbn_b, 0.0f)
+                               : bn_xform(m, m->dec[i - 1].gamma, m->dec[i - 1].beta, kLrelu);
+        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), m->dec[i].c, epi_bias(P(m, m->dec[i].b)), st);
+    }
+    // final 1x1 conv + L1 loss (+ start of the backward)
+    const ConvLayer& DL = m->dec.back();
+    UadFinalArgs fa;
+    fa.N = n; fa.H = m->cfg.height; fa.W = m->cfg.width; fa.C = DL.d.CB;
+    fa.c_last = DL.c; fa.scale = P(m, DL.gamma); fa.shift = P(m, DL.beta); fa.alpha = kLrelu;
+    fa.mult = 1.0f / sqrtf(1.0f + kBnEps);
+    fa.wf = P(m, m->fw); fa.bf = P(m, m->fb); fa.x = io->x;
+    fa.x_hat = io->x_hat ? io->x_hat : m->xhat_own; fa.l1_map = io->l1_map;
+    fa.rec_partial = m->rec_partial;
+    fa.d_c = want_backward ? m->G0 : nullptr;
+    fa.red_partial = m->red_partial;
+    fa.inv_batch = 1.0f / (float)n;
+    uad_launch_final_fwd_bwd(fa, st);
+    const int bps = uad_final_blocks_per_sample(fa.H, fa.W);
+    uad_launch_loss_finalize(m->rec_partial, n, bps, vae ? m->kl : nullptr, 1.0f / (float)n,
+                             io->rec_per_sample ? io->rec_per_sample : m->rec_ps,
+                             io->scalars ? io->scalars : m->scalars_own, st);
+    // optional latent outputs
+    const size_t zb = (size_t)n * m->cfg.zdim * sizeof(float);
+    if (io->z_mu) hipMemcpyAsync(io->z_mu, vae ? m->mu : m->z, zb, hipMemcpyDeviceToDevice, st);
+    if (vae && io->z_log_sigma) hipMemcpyAsync(io->z_log_sigma, m->ls, zb, hipMemcpyDeviceToDevice, st);
+    if (vae && io->z_sigma) hipMemcpyAsync(io->z_sigma, m->sigma, zb, hipMemcpyDeviceToDevice, st);
+    m->last_n = n; m->last_io = *io; m->have_fwd = want_backward != 0;
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+static int backward_decoder(uad_model* m, hipStream_t st) {
+    const int n = m->last_n;
+    const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
+    const ConvLayer& DL = m->dec.back();
+    const int C = DL.d.CB;
+    const int bps = uad_final_blocks_per_sample(m->cfg.height, m->cfg.width);
+    // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials:
+    // red_partial[T][3C+1] = {dwf[C], S1[C], S2[C], dbf}
+    const int T = n * bps, L = 3 * C + 1;
+    // reuse colscratch [L] for the reduced vector
+    uad_launch_reduce_partials(m->red_partial, T, L, 1.0f, m->colscratch, st);
+    hipMemcpyAsync(Gr(m, m->fw), m->colscratch, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(Gr(m, m->fb), m->colscratch + 3 * C, sizeof(float), hipMemcpyDeviceToDevice, st);
+    // view {S1,S2} as a single-tile colpart [1][2][C]
+    uad_launch_bn_grad_finalize(m->colscratch + C, 1, C, P(m, DL.gamma), rstd, Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), st);
+
+    float* g = m->G0;      // d loss / d c of dec[i]
+    float* gn = m->G1;
+    for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
+        UadConvDesc d = m->dec[i].d; d.N = n;
+        const float* in = (i == 0) ? m->cb : m->dec[i - 1].c;
+        const long long ig = (i == 0) ? m->dbn_g : m->dec[i - 1].gamma;
+        const long long ib = (i == 0) ? m->dbn_b : m->dec[i - 1].beta;
+        const float ia = (i == 0) ? 0.0f : kLrelu;
+        const long long ibias = (i == 0) ? m->rb : m->dec[i - 1].b;
+        // filter gradient: big = d c (raw), small = layer input (activation on load)
+        uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wpartial, st);
+        // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
+        uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st);
+        uad_launch_bn_grad_finalize(m->colpart, uad_conv_f_tiles(d), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), st);
+        float* tsw = g; g = gn; gn = tsw;
+    }
+    // g now holds d loss / d cb (pre-BN output of Bottleneck/conv2d_1); remember which buffer
+    m->G0 = g; m->G1 = gn;
+    return UAD_OK;
+}
+
+static int backward_bottleneck(uad_model* m, hipStream_t st) {
+    const int n = m->last_n;
+    const bool vae = m->cfg.arch == UAD_ARCH_VAE;
+    const int ir = m->cfg.inter_res, zd = m->cfg.zdim;
+    const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
+    const uad_io_t& io = m->last_io;
+    float* dcb = m->G0;                         // [n,ir,ir,cenc]
+    float* dd = m->g_small[0];                  // [n,flat]
+    float* dz = m->g_small[1];
+    float* dmu = m->g_small[2];
+    float* dls = m->g_small[3];
+    float* dflat = m->g_small[4];
+    // conv2d_1 (1x1, cmid -> cenc): bias grad came from the decoder stage (BN finalize).
+    {
+        UadConvDesc d = conv1x1_desc(n, ir, ir, m->cmid, m->cenc);
+        uad_launch_conv_w(d, m->dvec, no_xform(), dcb, no_xform(), Gr(m, m->rw), m->wpartial, st);
+        uad_launch_conv_d(d, dcb, no_xform(), P(m, m->rw), dd, epi_bias(nullptr, vae ? io.mask_dec : nullptr), st);
+    }
+    // dense_dec
+    {
+        UadConvDesc d = dense_desc(n, zd, m->flat);
+        uad_launch_conv_w(d, m->z, no_xform(), dd, no_xform(), Gr(m, m->dw), m->wpartial, st);
+        uad_launch_colsum(dd, n, m->flat, Gr(m, m->db), m->colscratch, st);
+        uad_launch_conv_d(d, dd, no_xform(), P(m, m->dw), dz, epi_bias(nullptr, vae ? nullptr : io.mask_mu), st);
+    }
+    UadConvDesc dd_in = dense_desc(n, m->flat, zd);
+    if (vae) {
+        uad_launch_reparam_bwd(n, zd, dz, m->mu, m->sigma, io.eps, io.mask_mu, io.mask_sigma, 1.0f / (float)n, dmu, dls, st);
+        uad_launch_conv_w(dd_in, m->t, no_xform(), dmu, no_xform(), Gr(m, m->muw), m->wpartial, st);
+        uad_launch_colsum(dmu, n, zd, Gr(m, m->mub), m->colscratch, st);
+        uad_launch_conv_w(dd_in, m->t, no_xform(), dls, no_xform(), Gr(m, m->sgw), m->wpartial, st);
+        uad_launch_colsum(dls, n, zd, Gr(m, m->sgb), m->colscratch, st);
+        uad_launch_conv_d(dd_in, dmu, no_xform(), P(m, m->muw), m->g_small[5], epi_bias(nullptr), st);
+        uad_launch_conv_d(dd_in, dls, no_xform(), P(m, m->sgw), dflat, epi_bias(nullptr, nullptr, m->g_small[5]), st);
+    } else {
+        uad_launch_conv_w(dd_in, m->t, no_xform(), dz, no_xform(), Gr(m, m->muw), m->wpartial, st);
+        uad_launch_colsum(dz, n, zd, Gr(m, m->mub), m->colscratch, st);
+        uad_launch_conv_d(dd_in, dz, no_xform(), P(m, m->muw), dflat, epi_bias(nullptr), st);
+    }
+    // Bottleneck/conv2d (1x1, cenc -> cmid): input = act(enc_last.c)
+    {
+        const ConvLayer& EL = m->enc.back();
+        UadConvDesc d = conv1x1_desc(n, ir, ir, m->cenc, m->cmid);
+        uad_launch_conv_w(d, EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu), dflat, no_xform(), Gr(m, m->bw), m->wpartial, st);
+        uad_launch_colsum(dflat, n * ir * ir, m->cmid, Gr(m, m->bb), m->colscratch, st);
+        uad_launch_conv_d(d, dflat, no_xform(), P(m, m->bw), m->G1, epi_bwd(m, EL.c, EL.gamma, EL.beta, kLrelu), st);
+        uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma),
+                                    Gr(m, EL.beta), Gr(m, EL.b), st);
+    }
+    float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;   // G0 = d loss / d c of the last encoder conv
+    return UAD_OK;
+}
+
+static int backward_encoder(uad_model* m, hipStream_t st) {
+    const int n = m->last_n;
+    const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
+    float* g = m->G0;
+    float* gn = m->G1;
+    for (int i = (int)m->enc.size() - 1; i >= 1; --i) {
+        UadConvDesc d = m->enc[i].d; d.N = n;
+        const ConvLayer& PL = m->enc[i - 1];
+        uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wpartial, st);
+        uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st);
+        uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
+                                    Gr(m, PL.beta), Gr(m, PL.b), st);
+        float* tsw = g; g = gn; gn = tsw;
+    }
+    UadConvDesc d0 = m->enc[0].d; d0.N = n;
+    uad_launch_conv_first_wgrad(d0, m->last_io.x, g, Gr(m, m->enc[0].w), m->wpartial, st);
+    m->G0 = g; m->G1 = gn;
+    return UAD_OK;
+}
+
+int uad_backward(uad_model_t* m, int segment, void* stream) {
+    if (!m) return fail(UAD_ERR_INVALID, "null model");
+    if (!m->have_fwd) return fail(UAD_ERR_INVALID, "uad_backward without a preceding uad_forward(want_backward=1)");
+    if (segment < UAD_SEG_ALL || segment > UAD_SEG_ENCODER) return fail(UAD_ERR_INVALID, "bad segment %d", segment);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = UAD_OK;
+    if (segment == UAD_SEG_ALL || segment == UAD_SEG_DECODER) rc = backward_decoder(m, st);
+    if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_BOTTLENECK)) rc = backward_bottleneck(m, st);
+    if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_ENCODER)) {
+        rc = backward_encoder(m, st);
+        m->have_fwd = false;
+    }
+    HIP_TRY(hipGetLastError());
+    return rc;
+}
+
+int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (!m) return fail(UAD_ERR_INVALID, "null model");
+    m->step += 1;
+    const double t = (double)m->step;
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    uad_launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr_t, beta1, beta2, eps, grad_scale,
+                    (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float beta1, float beta2, float eps, void* stream) {
+    int rc = uad_forward(m, io, n, 1, stream);
+    if (rc == UAD_OK) rc = uad_backward(m, UAD_SEG_ALL, stream);
+    if (rc == UAD_OK) rc = uad_adam_step(m, lr, beta1, beta2, eps, 1.0f, stream);
+    return rc;
+}
+
+int uad_residual(const float* x, const float* xr, const float* mask, int n, int hw, int pos_only, float prior_thresh,
+                 float* out, float* l1err, void* stream) {
+    if (!x || !xr || !out || n <= 0 || hw <= 0) return fail(UAD_ERR_INVALID, "uad_residual: bad arguments");
+    uad_launch_residual(x, xr, mask, n, hw, pos_only, prior_thresh, out, l1err, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ op-level entry points
+static UadConvDesc to_desc(const uad_conv_desc_t* d) { return UadConvDesc{d->N, d->HB, d->WB, d->CB, d->HS, d->WS, d->CS, d->KS, d->S, d->P}; }
+static UadXform to_xf(const uad_xform_t* x) {
+    UadXform r; r.scale = x ? x->scale : nullptr; r.shift = x ? x->shift : nullptr; r.alpha = x ? x->alpha : 1.f; r.mult = 1.f;
+    return r;
+}
+static int check_gemm_desc(const uad_conv_desc_t* d, bool f_type) {
+    if (!d) return fail(UAD_ERR_INVALID, "null desc");
+    const int ca = f_type ? d->CB : d->CS, nn = f_type ? d->CS : d->CB;
+    if (ca % 16 || nn % 4) return fail(UAD_ERR_UNSUPPORTED, "contraction channels must be a multiple of 16 and output channels of 4");
+    return UAD_OK;
+}
+
+int uad_op_conv_f(const uad_conv_desc_t* d, const float* big_in, const uad_xform_t* xf, const float* W, const float* bias,
+                  const float* mul, const float* add, float* small_out, void* stream) {
+    if (int rc = check_gemm_desc(d, true)) return rc;
+    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+int uad_op_conv_d(const uad_conv_desc_t* d, const float* small_in, const uad_xform_t* xf, const float* W, const float* bias,
+                  const float* mul, const float* add, float* big_out, void* stream) {
+    if (int rc = check_gemm_desc(d, false)) return rc;
+    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+static int bwdact_common(bool f_type, const uad_conv_desc_t* dd, const float* in, const float* W, const float* cprev,
+                         const uad_xform_t* act, float* out, float* s1, float* s2, void* stream) {
+    if (int rc = check_gemm_desc(dd, f_type)) return rc;
+    if (!act || !act->scale) return fail(UAD_ERR_INVALID, "bwdact needs the activation scale/shift");
+    UadConvDesc d = to_desc(dd);
+    const int C = f_type ? d.CS : d.CB;
+    const int T = f_type ? uad_conv_f_tiles(d) : uad_conv_d_tiles(d);
+    float *colpart = nullptr, *tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&colpart, (size_t)T * 2 * C * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&tmp, (size_t)3 * C * sizeof(float)));
+    UadEpilogue e;
+    memset(&e, 0, sizeof e);
+    e.kind = UAD_EPI_BWD_ACT; e.cprev = cprev; e.escale = act->scale; e.eshift = act->shift; e.ealpha = act->alpha;
+    e.emult = 1.f; e.colpart = colpart;
+    hipStream_t st = (hipStream_t)stream;
+    if (f_type) uad_launch_conv_f(d, in, no_xform(), W, out, e, st);
+    else uad_launch_conv_d(d, in, no_xform(), W, out, e, st);
+    // rstd = 1, gamma unused for dbias=null: dbeta -> s1, dgamma -> s2
+    uad_launch_bn_grad_finalize(colpart, T, C, act->scale, 1.0f, s2, s1, nullptr, st);
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(colpart); hipFree(tmp);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+int uad_op_conv_f_bwdact(const uad_conv_desc_t* d, const float* big_in, const float* W, const float* cprev,
+                         const uad_xform_t* act, float* small_out, float* s1, float* s2, void* stream) {
+    return bwdact_common(true, d, big_in, W, cprev, act, small_out, s1, s2, stream);
+}
+int uad_op_conv_d_bwdact(const uad_conv_desc_t* d, const float* small_in, const float* W, const float* cprev,
+                         const uad_xform_t* act, float* big_out, float* s1, float* s2, void* stream) {
+    return bwdact_common(false, d, small_in, W, cprev, act, big_out, s1, s2, stream);
+}
+
+int uad_op_conv_w(const uad_conv_desc_t* dd, const float* big, const uad_xform_t* xfb, const float* small_,
+                  const uad_xform_t* xfs, float* dW, void* stream) {
+    if (!dd) return fail(UAD_ERR_INVALID, "null desc");
+    if (dd->CB % 4 || dd->CS % 4) return fail(UAD_ERR_UNSUPPORTED, "channels must be multiples of 4");
+    UadConvDesc d = to_desc(dd);
+    float* partial = nullptr;
+    HIP_TRY(hipMalloc((void**)&partial, uad_conv_w_partial_floats(d) * sizeof(float)));
+    hipStream_t st = (hipStream_t)stream;
+    uad_launch_conv_w(d, big, to_xf(xfb), small_, to_xf(xfs), dW, partial, st);
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(partial);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+int uad_op_conv_first_fwd(const uad_conv_desc_t* d, const float* x, const float* W, const float* bias, float* out, void* stream) {
+    if (!d || d->CS % 8 || 256 % (d->CS / 8)) return fail(UAD_ERR_UNSUPPORTED, "first conv: Cout must be a multiple of 8 dividing 2048");
+    uad_launch_conv_first_fwd(to_desc(d), x, W, bias, out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+int uad_op_conv_first_wgrad(const uad_conv_desc_t* dd, const float* x, const float* g, float* dW, void* stream) {
+    if (!dd || dd->KS != 5 || (dd->CB != 1 && dd->CB != 3) || 256 % dd->CS) return fail(UAD_ERR_UNSUPPORTED, "first wgrad: KS=5, Cin in {1,3}, Cout | 256");
+    UadConvDesc d = to_desc(dd);
+    float* partial = nullptr;
+    HIP_TRY(hipMalloc((void**)&partial, uad_conv_first_wgrad_partial_floats(d) * sizeof(float)));
+    hipStream_t st = (hipStream_t)stream;
+    uad_launch_conv_first_wgrad(d, x, g, dW, partial, st);
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(partial);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+int uad_op_adam(float* p, const float* g, float* mm, float* v, long long n, float lr_t, float beta1, float beta2, float eps,
+                float gscale, void* stream) {
+    uad_launch_adam(p, g, mm, v, (size_t)n, lr_t, beta1, beta2, eps, gscale, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+}  // extern "C"

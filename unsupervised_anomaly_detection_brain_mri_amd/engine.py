@@ -1,0 +1,199 @@
+"""Host-side handle around the C-ABI model (include/uad_hip.h).  PyTorch is plumbing only: device buffers for the
+caller-owned inputs/outputs, the current HIP stream, and zero-copy tensor views of the handle-owned flat
+parameter / gradient buffers for torch.distributed (RCCL) all-reduce."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class _DevArray:
+    """__cuda_array_interface__ shim: lets torch alias a raw device pointer without copying."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<f4', 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One AE/VAE instance on one GPU.  Mirrors what a tf.Session + graph holds in the reference
+    (trainers/VAE.py:18-29): variables, optimizer slots and the compiled step."""
+
+    def __init__(self, arch, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        torch.cuda.set_device(self.device)
+        self.arch = arch
+        self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
+        cfg = _lib.UadConfig(_lib.ARCH_VAE if arch == 'VAE' else _lib.ARCH_AE, height, width, channels, inter_res, zdim,
+                             max_batch)
+        if arch not in ('AE', 'VAE'):
+            raise ValueError(f'unknown arch {arch!r}')
+        h = C.c_void_p()
+        _lib.check(self.lib.uad_create(C.byref(cfg), C.byref(h)))
+        self.handle = h
+        self.nparams = int(self.lib.uad_param_count(h))
+        self.spec = []
+        name = C.create_string_buffer(160)
+        off = C.c_longlong()
+        rank = C.c_int()
+        shape = (C.c_int * 4)()
+        for i in range(self.lib.uad_num_tensors(h)):
+            _lib.check(self.lib.uad_tensor_info(h, i, name, 160, C.byref(off), C.byref(rank), shape))
+            self.spec.append((name.value.decode(), tuple(shape[:rank.value]), int(off.value)))
+        self.flat = inter_res * inter_res * (self._cenc() // 8)
+        self._views = {}
+        self.scalars = torch.zeros(4, device=self.device)
+
+    def _cenc(self):
+        n_pool = int(math.log2(self.h) - math.log2(self.inter))
+        return min(128, 32 * 2 ** (n_pool - 1))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            torch.cuda.synchronize(self.device)
+            self.lib.uad_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- buffers
+    def buffer(self, which=_lib.BUF_PARAMS):
+        """Zero-copy torch view (1-D fp32) of a handle-owned flat buffer."""
+        if which not in self._views:
+            ptr = self.lib.uad_buffer(self.handle, which)
+            self._views[which] = torch.as_tensor(_DevArray(ptr, self.nparams), device=self.device)
+        return self._views[which]
+
+    def grad_segment(self, seg):
+        off, cnt = C.c_longlong(), C.c_longlong()
+        _lib.check(self.lib.uad_grad_segment(self.handle, seg, C.byref(off), C.byref(cnt)))
+        return int(off.value), int(cnt.value)
+
+    def set_params(self, params):
+        """params: flat float32 array, or dict name -> array (all tensors of the spec)."""
+        if isinstance(params, dict):
+            flat = np.concatenate([np.asarray(params[n], np.float32).reshape(-1) for n, _, _ in self.spec])
+        else:
+            flat = np.ascontiguousarray(params, np.float32).reshape(-1)
+        _lib.check(self.lib.uad_set_params(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size))
+
+    def get_buffer_host(self, which=_lib.BUF_PARAMS):
+        torch.cuda.synchronize(self.device)
+        out = np.empty(self.nparams, np.float32)
+        _lib.check(self.lib.uad_get_buffer(self.handle, which, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def set_buffer_host(self, which, flat):
+        flat = np.ascontiguousarray(flat, np.float32).reshape(-1)
+        _lib.check(self.lib.uad_set_buffer(self.handle, which, flat.ctypes.data_as(C.c_void_p), flat.size))
+
+    def unflatten(self, flat):
+        return {n: flat[o:o + int(np.prod(s))].reshape(s) for n, s, o in self.spec}
+
+    def get_params(self):
+        return self.unflatten(self.get_buffer_host(_lib.BUF_PARAMS))
+
+    def get_grads(self):
+        return self.unflatten(self.get_buffer_host(_lib.BUF_GRADS))
+
+    def reset_optimizer(self):
+        _lib.check(self.lib.uad_reset_optimizer(self.handle))
+
+    @property
+    def step_count(self):
+        return int(self.lib.uad_get_step(self.handle))
+
+    @step_count.setter
+    def step_count(self, t):
+        _lib.check(self.lib.uad_set_step(self.handle, int(t)))
+
+    # ---------------------------------------------------------------- compute
+    def _dev(self, a, shape=None):
+        if a is None:
+            return None
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=torch.float32).contiguous()
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f'expected shape {tuple(shape)}, got {tuple(t.shape)}')
+        return t
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def forward(self, x, eps=None, masks=None, want_backward=False, want_l1=True, want_latents=True):
+        """Returns a dict of DEVICE tensors: x_hat, L1 (opt), z_mu/z_log_sigma/z_sigma or z (opt), scalars [4]
+        (reconstructionLoss, kl, loss, 0), rec_per_sample [n].  Asynchronous on the current stream."""
+        masks = masks or {}
+        x = self._dev(x)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (self.h, self.w, self.c):
+            raise ValueError(f'x must be [n,{self.h},{self.w},{self.c}], got {tuple(x.shape)}')
+        n = x.shape[0]
+        if n > self.max_batch:
+            raise ValueError(f'batch {n} > max_batch {self.max_batch}')
+        zs = (n, self.zdim)
+        eps = self._dev(eps, zs)
+        if self.arch == 'VAE':
+            m_mu, m_sg = self._dev(masks.get('mu'), zs), self._dev(masks.get('sigma'), zs)
+            m_dec = self._dev(masks.get('dec'), (n, self.flat))
+        else:
+            m_mu, m_sg, m_dec = self._dev(masks.get('z'), zs), None, None
+        out = {'x_hat': torch.empty_like(x), 'scalars': torch.empty(4, device=self.device),
+               'rec_per_sample': torch.empty(n, device=self.device)}
+        if want_l1:
+            out['L1'] = torch.empty_like(x)
+        lat = {}
+        if want_latents:
+            if self.arch == 'VAE':
+                lat = {k: torch.empty(zs, device=self.device) for k in ('z_mu', 'z_log_sigma', 'z_sigma')}
+            else:
+                lat = {'z': torch.empty(zs, device=self.device)}
+            out.update(lat)
+        io = _lib.UadIO(_ptr(x), _ptr(eps), _ptr(m_mu), _ptr(m_sg), _ptr(m_dec), _ptr(out['x_hat']),
+                        _ptr(out.get('L1')), _ptr(lat.get('z_mu', lat.get('z'))), _ptr(lat.get('z_log_sigma')),
+                        _ptr(lat.get('z_sigma')), _ptr(out['scalars']), _ptr(out['rec_per_sample']))
+        # keep the inputs alive until the (asynchronous) backward has consumed them
+        self._keep = (x, eps, m_mu, m_sg, m_dec, out)
+        _lib.check(self.lib.uad_forward(self.handle, C.byref(io), n, 1 if want_backward else 0, self._stream()))
+        return out
+
+    def backward(self, segment=_lib.SEG_ALL):
+        _lib.check(self.lib.uad_backward(self.handle, segment, self._stream()))
+
+    def adam_step(self, lr, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        _lib.check(self.lib.uad_adam_step(self.handle, lr, beta1, beta2, eps, grad_scale, self._stream()))
+
+    def train_step(self, x, eps=None, masks=None, lr=1e-4, beta1=0.5, beta2=0.999, adam_eps=1e-8, **kw):
+        out = self.forward(x, eps, masks, want_backward=True, **kw)
+        self.backward(_lib.SEG_ALL)
+        self.adam_step(lr, beta1, beta2, adam_eps)
+        return out
+
+    def residual(self, x, x_rec, mask=None, pos_only=True, prior_thresh=None):
+        """Residual anomaly map on device (utils/Evaluation.py:282-289).  Returns (map, l1err_per_sample)."""
+        x = self._dev(x)
+        xr = self._dev(x_rec, x.shape)
+        mk = self._dev(mask, x.shape) if mask is not None else None
+        n = x.shape[0]
+        hw = int(np.prod(x.shape[1:]))
+        out = torch.empty_like(x)
+        l1 = torch.empty(n, device=self.device)
+        thr = -math.inf if prior_thresh is None else float(prior_thresh)
+        _lib.check(self.lib.uad_residual(_ptr(x), _ptr(xr), _ptr(mk), n, hw, 1 if pos_only else 0, thr, _ptr(out),
+                                         _ptr(l1), self._stream()))
+        return out, l1
