@@ -138,9 +138,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
         int ky, kx, oy, ox;
         {
             const int ty = tap / ntx, tx = tap - ty * ntx;
-            ky = ky0 + S * ty;
-            kx = kx0 + S * tx;
-            if (KIND == KIND_F) { oy = ky; ox = kx; } else { oy = dy0 - ty; ox = dx0 - tx; }
+            if (KIND == KIND_F) { ky = ty; kx = tx; oy = ky; ox = kx; }
+            else { ky = ky0 + S * ty; kx = kx0 + S * tx; oy = dy0 - ty; ox = dx0 - tx; }
         }
         if (xf) {
             xsc = *reinterpret_cast<const float4*>(a.xf.scale + c0 + acol);
@@ -503,7 +502,7 @@ struct TileChoice { int BM, BN, BK; };
 
 inline TileChoice choose_tile(long M, int Nn, int CA, int classes) {
     TileChoice t;
-    t.BK = (CA % 32 == 0) ? 32 : 16;
+    t.BK = (CA % 32 == 0) ? 32 : (CA % 16 == 0) ? 16 : 8;
     t.BN = (Nn > 32) ? 64 : 32;
     auto nwg = [&](int bm) { return ((M + bm - 1) / bm) * ((Nn + t.BN - 1) / t.BN) * classes; };
     t.BM = (t.BK == 32 && nwg(128) >= 512) ? 128 : 64;
@@ -525,6 +524,8 @@ void launch_gemm(const ConvGemmArgs& a, int classes, hipStream_t st) {
     UAD_GEMM_CASE(64, 32, 32, 2, 1)
     UAD_GEMM_CASE(64, 64, 16, 2, 2)
     UAD_GEMM_CASE(64, 32, 16, 2, 1)
+    UAD_GEMM_CASE(64, 64, 8, 2, 2)
+    UAD_GEMM_CASE(64, 32, 8, 2, 1)
 #undef UAD_GEMM_CASE
 }
 

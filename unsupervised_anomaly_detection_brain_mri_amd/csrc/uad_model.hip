@@ -152,7 +152,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
         return fail(UAD_ERR_INVALID, "inter_res must be a power of two smaller than height");
     if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
     if (cfg->arch != UAD_ARCH_AE && cfg->arch != UAD_ARCH_VAE) return fail(UAD_ERR_INVALID, "bad arch");
-    if (cfg->zdim <= 0 || cfg->zdim % 16) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 16");
+    if (cfg->zdim <= 0 || cfg->zdim % 8) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
     if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
 
     uad_model* m = new uad_model();
@@ -183,7 +183,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     m->cenc = cin; m->cmid = cin / 8;
     const int ir = cfg->inter_res;
     m->flat = ir * ir * m->cmid;
-    if (m->cmid % 16 || m->flat % 16) { delete m; return fail(UAD_ERR_UNSUPPORTED, "bottleneck channels must be a multiple of 16"); }
+    if (m->cmid % 8 || m->flat % 8) { delete m; return fail(UAD_ERR_UNSUPPORTED, "bottleneck channels must be a multiple of 8"); }
     m->bw = add_tensor(m, "Bottleneck/conv2d/kernel", 4, 1, 1, m->cenc, m->cmid);
     m->bb = add_tensor(m, "Bottleneck/conv2d/bias", 1, m->cmid, 1, 1, 1);
     if (vae) {
@@ -562,7 +562,7 @@ static UadXform to_xf(const uad_xform_t* x) {
 static int check_gemm_desc(const uad_conv_desc_t* d, bool f_type) {
     if (!d) return fail(UAD_ERR_INVALID, "null desc");
     const int ca = f_type ? d->CB : d->CS, nn = f_type ? d->CS : d->CB;
-    if (ca % 16 || nn % 4) return fail(UAD_ERR_UNSUPPORTED, "contraction channels must be a multiple of 16 and output channels of 4");
+    if (ca % 8 || nn % 4) return fail(UAD_ERR_UNSUPPORTED, "contraction channels must be a multiple of 8 and output channels of 4");
     return UAD_OK;
 }
 
