@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py — VAE train step (fwd + bwd + TF-Adam) on synthetic Brainweb-like slices, one process per GPU.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: VAE (variational_autoencoder) 128x128, batch 64 per GPU, computed in fp32
+(the parity bar "1e-4 rel fp32" rules out bf16 arithmetic).  Inputs (x, eps, dropout masks) are
+resident in HBM before the timed region.  N>1: slice-batch data parallel, weak scaling (64 slices per GPU), the three
+gradient segments are all-reduced over RCCL as soon as each is complete, overlapped with the rest of the backward.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 128
+BATCH = 64
+ZDIM = 128
+INTER = 8
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_layers():
+    """(tag-prefix, positions_per_slice, taps*CB*CS) of every k5 s2 conv block; MACs/slice = positions * taps*CB*CS."""
+    layers = []
+    cin, res = 1, H
+    i = 0
+    while res > INTER:
+        f = min(128, 32 * 2 ** i)
+        layers.append((f'enc{i}', (res // 2) ** 2, 25 * cin * f))
+        cin, res, i = f, res // 2, i + 1
+    i = 0
+    while res < H:
+        f = max(32, 128 // 2 ** i)
+        layers.append((f'dec{i}', res * res, 25 * f * cin))
+        cin, res, i = f, res * 2, i + 1
+    return layers
+
+
+def flops_per_tag(n):
+    fl = {}
+    for name, pos, k in conv_layers():
+        f = 2.0 * n * pos * k
+        for kind in ('fwd', 'dgrad', 'wgrad'):
+            fl[f'{name}.{kind}'] = f
+    return fl
+
+
+def train_flops_per_slice():
+    """371.5 M MAC fwd -> 0.743 GFLOP; train step = 3x fwd minus the enc0 data-grad."""
+    fwd_macs = sum(pos * k for _, pos, k in conv_layers())
+    small = 128 * 16 * 64 + 2 * 1024 * 128 + 128 * 1024 + 16 * 128 * 64 + 32 * H * W
+    return 2.0 * (3 * (fwd_macs + small) - conv_layers()[0][1] * conv_layers()[0][2])
+
+
+def cpu_baseline(sample_batch=8, steps=2):
+    """The numpy oracle (a PORT of the reference semantics, not TF — TF 1.15 cannot be installed here) timed on this
+    host's cores on a bounded sample: `steps` VAE train steps at batch `sample_batch`, fp32."""
+    from oracle import nn as onn, vae as ovae
+    m = ovae.Model('VAE', H, W, 1, INTER, ZDIM)
+    p = ovae.init_params(m.spec, seed=3)
+    opt = m.new_opt(p)
+    x = ovae.synthetic_slices(sample_batch, H, W, seed=0)
+    rng = np.random.default_rng(1)
+    eps = rng.standard_normal((sample_batch, ZDIM)).astype(np.float32)
+    masks = {'mu': onn.make_dropout_mask(rng, (sample_batch, ZDIM), 0.2),
+             'sigma': onn.make_dropout_mask(rng, (sample_batch, ZDIM), 0.2),
+             'dec': onn.make_dropout_mask(rng, (sample_batch, INTER * INTER * 16), 0.2)}
+    m.train_step(p, opt, x, eps, masks)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train_step(p, opt, x, eps, masks)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([d.get('num_threads', 1) for d in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {'value': round(sample_batch * steps / dt, 2), 'unit': 'slices/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'{steps} fp32 VAE train steps at batch {sample_batch} with the numpy oracle '
+                      f'(BLAS-threaded matmuls; TF-CPU itself is not installable), {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from unsupervised_anomaly_detection_brain_mri_amd import _lib
+    from unsupervised_anomaly_detection_brain_mri_amd.engine import Engine
+    from unsupervised_anomaly_detection_brain_mri_amd.parallel import DataParallelStep
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import synthetic_slices
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    eng = Engine('VAE', H, W, 1, INTER, ZDIM, max_batch=BATCH, device=f'cuda:{local_rank}')
+    # identical glorot-uniform init on every rank (seed 3), zero bias, gamma 1, beta 0
+    rng = np.random.default_rng(3)
+    flat = np.zeros(eng.nparams, np.float32)
+    for name, shape, off in eng.spec:
+        cnt = int(np.prod(shape))
+        if name.endswith('kernel'):
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            lim = np.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf))
+            flat[off:off + cnt] = rng.uniform(-lim, lim, cnt)
+        elif name.endswith('gamma'):
+            flat[off:off + cnt] = 1.0
+    eng.set_params(flat)
+    # per-rank shard of the global synthetic batch, resident in HBM
+    x = torch.from_numpy(synthetic_slices(BATCH, H, W, seed=1000 + rank)).cuda()
+    g = torch.Generator(device='cuda').manual_seed(1 + rank)
+    eps = torch.randn(BATCH, ZDIM, device='cuda', generator=g)
+    keep = lambda shape: (torch.rand(shape, device='cuda', generator=g) >= 0.2).float() / 0.8   # rate 0.2, run.py:40
+    masks = {'mu': keep((BATCH, ZDIM)), 'sigma': keep((BATCH, ZDIM)), 'dec': keep((BATCH, INTER * INTER * 16))}
+    dp = DataParallelStep(eng, world)
+
+    def step():
+        return dp.train_step(x, eps, masks, lr=1e-4, beta1=0.5, want_l1=True, want_latents=False)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out['scalars'][2].item())
+    assert np.isfinite(loss), 'loss diverged'
+
+    # ---- roofline leg: per-launch-group HIP-event timing of the same step (profiling pass after the timed region)
+    eng.profile(True)
+    prof_steps = max(3, min(args.steps, 10))
+    for _ in range(prof_steps):
+        step()
+    rep = eng.profile_report()
+    eng.profile(False)
+    fl = flops_per_tag(BATCH)
+    gemm = {t: (c, ms) for t, (c, ms) in rep.items() if t in fl}
+    dom = max(gemm, key=lambda t: gemm[t][1])
+    dom_ms = gemm[dom][1] / gemm[dom][0]
+    achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
+    kernels = {t: {'ms': round(ms / c, 4), 'tflops': round(fl[t] / (ms / c * 1e-3) / 1e12, 2) if t in fl else None}
+               for t, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+
+    if rank == 0:
+        slices = BATCH * world * args.steps
+        value = slices / dt
+        res = {
+            'metric': 'MRI slices/sec VAE train step (128x128, bs=64)',
+            'value': round(value, 1), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[1]: VAE 128x128x1 slices, batch 64 per GPU, '
+                                   'fwd + bwd + TF-Adam (lr 1e-4, beta1 0.5), dropout 0.2, inter_res 8, zDim 128',
+                       'global_batch': BATCH * world, 'per_gpu_batch': BATCH,
+                       'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'step_tflops': round(value * train_flops_per_slice() / 1e12, 2), 'final_loss': round(loss, 4)},
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'avg_launch_ms': round(dom_ms, 4),
+                         'whole_step_frac': round(value * train_flops_per_slice() / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            'kernels': kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

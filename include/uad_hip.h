@@ -101,6 +101,12 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
 int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float beta1, float beta2, float eps,
                    void* stream);
 
+/* per-launch-group HIP-event profiler (bench.py's roofline leg).  While enabled, every launch group of
+ * uad_forward / uad_backward / uad_adam_step is bracketed by hipEventRecord on the caller's stream.
+ * uad_profile_report synchronises the device and writes lines "tag count total_ms\n" into buf, then clears. */
+int uad_profile_enable(uad_model_t* m, int on);
+int uad_profile_report(uad_model_t* m, char* buf, int cap);
+
 /* residual anomaly map: out = mask * (pos_only ? max(x - xr, 0) : |x - xr|), zero where x < prior_thresh
  * (pass -INFINITY to disable); l1err[n] = sum |x - xr| per sample (may be NULL); mask may be NULL. hw = H*W*C. */
 int uad_residual(const float* x, const float* xr, const float* mask, int n, int hw, int pos_only, float prior_thresh,

@@ -58,6 +58,8 @@ SYMBOLS = {
     'uad_adam_step': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_train_step': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),
+    'uad_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
+    'uad_profile_report': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     'uad_residual': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
     'uad_op_conv_f': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p, C.c_void_p,

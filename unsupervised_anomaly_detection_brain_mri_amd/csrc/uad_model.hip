@@ -85,9 +85,29 @@ struct uad_model {
     uad_io_t last_io;
     bool have_fwd;
     std::vector<void*> allocs;
+    // optional per-launch-group HIP-event profiler (uad_profile_*)
+    bool prof_on;
+    struct ProfRec { const char* tag; hipEvent_t a, b; };
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace {
+
+struct ProfScope {
+    uad_model* m; hipStream_t st; hipEvent_t a, b; const char* tag; bool on;
+    static hipEvent_t get(uad_model* m) {
+        if (!m->ev_pool.empty()) { hipEvent_t e = m->ev_pool.back(); m->ev_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    ProfScope(uad_model* m_, const char* tag_, hipStream_t st_) : m(m_), st(st_), tag(tag_), on(m_->prof_on) {
+        if (on) { a = get(m); b = get(m); (void)hipEventRecord(a, st); }
+    }
+    ~ProfScope() {
+        if (on) { (void)hipEventRecord(b, st); m->prof.push_back({tag, a, b}); }
+    }
+};
+#define PROF(tag) ProfScope prof_scope_##__LINE__(m, tag, st)
 
 float* P(uad_model* m, long long off) { return m->params + off; }
 float* Gr(uad_model* m, long long off) { return m->grads + off; }
@@ -160,6 +180,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     m->nparams = 0;
     m->step = 0;
     m->have_fwd = false;
+    m->prof_on = false;
     const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
     m->n_pool = npool;
     const bool vae = cfg->arch == UAD_ARCH_VAE;
@@ -339,17 +360,23 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     const int ir = m->cfg.inter_res;
 
     // encoder
+    static const char* kEncF[] = {"enc0.fwd", "enc1.fwd", "enc2.fwd", "enc3.fwd", "enc4.fwd", "enc5.fwd", "enc6.fwd", "enc7.fwd"};
+    static const char* kDecF[] = {"dec0.fwd", "dec1.fwd", "dec2.fwd", "dec3.fwd", "dec4.fwd", "dec5.fwd", "dec6.fwd", "dec7.fwd"};
     {
+        PROF(kEncF[0]);
         UadConvDesc d = m->enc[0].d; d.N = n;
         uad_launch_conv_first_fwd(d, io->x, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st);
     }
     for (size_t i = 1; i < m->enc.size(); ++i) {
+        PROF(kEncF[i & 7]);
         UadConvDesc d = m->enc[i].d; d.N = n;
         uad_launch_conv_f(d, m->enc[i - 1].c, bn_xform(m, m->enc[i - 1].gamma, m->enc[i - 1].beta, kLrelu),
                           P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st);
     }
     const ConvLayer& EL = m->enc.back();
     // bottleneck
+    {
+    PROF("bott.fwd");
     uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cenc, m->cmid), EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu),
                       P(m, m->bw), m->t, epi_bias(P(m, m->bb)), st);
     if (vae) {
@@ -365,8 +392,10 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), m->z, no_xform(), P(m, m->dw), m->dvec, epi_bias(P(m, m->db)), st);
     }
     uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cmid, m->cenc), m->dvec, no_xform(), P(m, m->rw), m->cb, epi_bias(P(m, m->rb)), st);
+    }
     // decoder
     for (size_t i = 0; i < m->dec.size(); ++i) {
+        PROF(kDecF[i & 7]);
         UadConvDesc d = m->dec[i].d; d.N = n;
         const float* in = (i == 0) ? m->cb : m->dec[i - 1].c;
         UadXform xf = (i == 0) ? bn_xform(m, m->dbn_g, m->dbn_b, 0.0f)
@@ -385,7 +414,8 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     fa.d_c = want_backward ? m->G0 : nullptr;
     fa.red_partial = m->red_partial;
     fa.inv_batch = 1.0f / (float)n;
-    uad_launch_final_fwd_bwd(fa, st);
+    { PROF(want_backward ? "final.fwd+bwd" : "final.fwd"); uad_launch_final_fwd_bwd(fa, st); }
+    PROF("loss.finalize");
     const int bps = uad_final_blocks_per_sample(fa.H, fa.W);
     uad_launch_loss_finalize(m->rec_partial, n, bps, vae ? m->kl : nullptr, 1.0f / (float)n,
                              io->rec_per_sample ? io->rec_per_sample : m->rec_ps,
@@ -410,12 +440,17 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
     // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials:
     // red_partial[T][3C+1] = {dwf[C], S1[C], S2[C], dbf}
     const int T = n * bps, L = 3 * C + 1;
+    static const char* kDecW[] = {"dec0.wgrad", "dec1.wgrad", "dec2.wgrad", "dec3.wgrad", "dec4.wgrad", "dec5.wgrad", "dec6.wgrad", "dec7.wgrad"};
+    static const char* kDecD[] = {"dec0.dgrad", "dec1.dgrad", "dec2.dgrad", "dec3.dgrad", "dec4.dgrad", "dec5.dgrad", "dec6.dgrad", "dec7.dgrad"};
     // reuse colscratch [L] for the reduced vector
+    {
+    PROF("final.gradfin");
     uad_launch_reduce_partials(m->red_partial, T, L, 1.0f, m->colscratch, st);
     hipMemcpyAsync(Gr(m, m->fw), m->colscratch, C * sizeof(float), hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(Gr(m, m->fb), m->colscratch + 3 * C, sizeof(float), hipMemcpyDeviceToDevice, st);
     // view {S1,S2} as a single-tile colpart [1][2][C]
     uad_launch_bn_grad_finalize(m->colscratch + C, 1, C, P(m, DL.gamma), rstd, Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), st);
+    }
 
     float* g = m->G0;      // d loss / d c of dec[i]
     float* gn = m->G1;
@@ -427,10 +462,10 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         const float ia = (i == 0) ? 0.0f : kLrelu;
         const long long ibias = (i == 0) ? m->rb : m->dec[i - 1].b;
         // filter gradient: big = d c (raw), small = layer input (activation on load)
-        uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wpartial, st);
+        { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wpartial, st); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
-        uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st);
-        uad_launch_bn_grad_finalize(m->colpart, uad_conv_f_tiles(d), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), st);
+        { PROF(kDecD[i & 7]); uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st); }
+        { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_f_tiles(d), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), st); }
         float* tsw = g; g = gn; gn = tsw;
     }
     // g now holds d loss / d cb (pre-BN output of Bottleneck/conv2d_1); remember which buffer
@@ -450,6 +485,7 @@ static int backward_bottleneck(uad_model* m, hipStream_t st) {
     float* dmu = m->g_small[2];
     float* dls = m->g_small[3];
     float* dflat = m->g_small[4];
+    PROF("bott.bwd");
     // conv2d_1 (1x1, cmid -> cenc): bias grad came from the decoder stage (BN finalize).
     {
         UadConvDesc d = conv1x1_desc(n, ir, ir, m->cmid, m->cenc);
@@ -499,14 +535,16 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
     for (int i = (int)m->enc.size() - 1; i >= 1; --i) {
         UadConvDesc d = m->enc[i].d; d.N = n;
         const ConvLayer& PL = m->enc[i - 1];
-        uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wpartial, st);
-        uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st);
-        uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
-                                    Gr(m, PL.beta), Gr(m, PL.b), st);
+        static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
+        static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
+        { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wpartial, st); }
+        { PROF(kEncD[i & 7]); uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st); }
+        { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
+                                    Gr(m, PL.beta), Gr(m, PL.b), st); }
         float* tsw = g; g = gn; gn = tsw;
     }
     UadConvDesc d0 = m->enc[0].d; d0.N = n;
-    uad_launch_conv_first_wgrad(d0, m->last_io.x, g, Gr(m, m->enc[0].w), m->wpartial, st);
+    { PROF("enc0.wgrad"); uad_launch_conv_first_wgrad(d0, m->last_io.x, g, Gr(m, m->enc[0].w), m->wpartial, st); }
     m->G0 = g; m->G1 = gn;
     return UAD_OK;
 }
@@ -532,8 +570,8 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
     m->step += 1;
     const double t = (double)m->step;
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
-    uad_launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr_t, beta1, beta2, eps, grad_scale,
-                    (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    { PROF("adam"); uad_launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr_t, beta1, beta2, eps, grad_scale, st); }
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
@@ -543,6 +581,37 @@ int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float be
     if (rc == UAD_OK) rc = uad_backward(m, UAD_SEG_ALL, stream);
     if (rc == UAD_OK) rc = uad_adam_step(m, lr, beta1, beta2, eps, 1.0f, stream);
     return rc;
+}
+
+int uad_profile_enable(uad_model_t* m, int on) {
+    if (!m) return fail(UAD_ERR_INVALID, "null model");
+    m->prof_on = on != 0;
+    return UAD_OK;
+}
+
+int uad_profile_report(uad_model_t* m, char* buf, int cap) {
+    if (!m || !buf || cap <= 0) return fail(UAD_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipDeviceSynchronize());
+    struct Agg { const char* tag; int count; double ms; };
+    std::vector<Agg> agg;
+    for (auto& r : m->prof) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        size_t k = 0;
+        for (; k < agg.size(); ++k) if (!strcmp(agg[k].tag, r.tag)) break;
+        if (k == agg.size()) agg.push_back({r.tag, 0, 0.0});
+        agg[k].count += 1; agg[k].ms += ms;
+        m->ev_pool.push_back(r.a); m->ev_pool.push_back(r.b);
+    }
+    m->prof.clear();
+    int off = 0;
+    buf[0] = 0;
+    for (auto& a : agg) {
+        int w = snprintf(buf + off, cap - off, "%s %d %.6f\n", a.tag, a.count, a.ms);
+        if (w < 0 || w >= cap - off) break;
+        off += w;
+    }
+    return UAD_OK;
 }
 
 int uad_residual(const float* x, const float* xr, const float* mask, int n, int hw, int pos_only, float prior_thresh,

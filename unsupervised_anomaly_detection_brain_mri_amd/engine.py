@@ -184,6 +184,19 @@ class Engine:
         self.adam_step(lr, beta1, beta2, adam_eps)
         return out
 
+    def profile(self, on):
+        _lib.check(self.lib.uad_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_report(self):
+        """{tag: (count, total_ms)} of the launch groups recorded since the last report (synchronises)."""
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(self.lib.uad_profile_report(self.handle, buf, len(buf)))
+        rep = {}
+        for line in buf.value.decode().splitlines():
+            tag, cnt, ms = line.split()
+            rep[tag] = (int(cnt), float(ms))
+        return rep
+
     def residual(self, x, x_rec, mask=None, pos_only=True, prior_thresh=None):
         """Residual anomaly map on device (utils/Evaluation.py:282-289).  Returns (map, l1err_per_sample)."""
         x = self._dev(x)

@@ -1,0 +1,62 @@
+"""Slice-batch data parallelism: one process per GPU, gradients summed with RCCL all-reduce over xGMI
+(torch.distributed backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+
+The reference has no distributed code; this is the build's addition.  Because BatchNorm runs
+with frozen statistics (SURVEY.md §8a note 1) per-sample gradients are independent, so DP over the slice batch equals
+the single-device big batch up to fp32 summation order.  The flat fp32 gradient buffer is laid out Encoder | Bottleneck |
+Decoder; the backward finishes the segments in the order Decoder, Bottleneck, Encoder and each segment's all-reduce
+is issued (async, on RCCL's stream) as soon as its kernels are enqueued, overlapping with the remaining backward.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+SEGMENT_ORDER = (_lib.SEG_DECODER, _lib.SEG_BOTTLENECK, _lib.SEG_ENCODER)
+
+
+def allreduce_segments(grads_flat, segments, world, async_op=True):
+    """grads_flat: 1-D tensor (device or CPU); segments: [(offset, count)] -> list of work handles."""
+    works = []
+    for off, cnt in segments:
+        if world > 1:
+            works.append(dist.all_reduce(grads_flat[off:off + cnt], op=dist.ReduceOp.SUM, async_op=async_op))
+    return works
+
+
+class DataParallelStep:
+    """train_step() for rank-local shards; equal per-rank batch sizes are assumed (weak scaling)."""
+
+    def __init__(self, engine, world=None):
+        self.eng = engine
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.grads = engine.buffer(_lib.BUF_GRADS) if self.world > 1 else None
+        self.segs = {s: engine.grad_segment(s) for s in SEGMENT_ORDER}
+
+    def broadcast_params(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.eng.buffer(_lib.BUF_PARAMS), src=src)
+
+    def train_step(self, x, eps=None, masks=None, lr=1e-4, beta1=0.5, beta2=0.999, adam_eps=1e-8, **kw):
+        eng = self.eng
+        out = eng.forward(x, eps, masks, want_backward=True, **kw)
+        if self.world == 1:
+            eng.backward(_lib.SEG_ALL)
+            eng.adam_step(lr, beta1, beta2, adam_eps, 1.0)
+            return out
+        works = []
+        for seg in SEGMENT_ORDER:
+            eng.backward(seg)
+            off, cnt = self.segs[seg]
+            works.append(dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        # local grads are d(mean over the local batch); sum / world = d(mean over the global batch)
+        eng.adam_step(lr, beta1, beta2, adam_eps, 1.0 / self.world)
+        return out
+
+    def allreduce_scalars(self, scalars):
+        if self.world > 1:
+            dist.all_reduce(scalars, op=dist.ReduceOp.SUM)
+            scalars /= self.world
+        return scalars
