@@ -13,13 +13,33 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int S, int L, float scale,
-                                       float* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= L) return;
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += partial[(size_t)s * L + j];
-    out[j] = acc * scale;
+// out[j] = scale * sum_s partial[s][j].  Block = 64 j-lanes x SL s-lanes; each thread walks s with stride SL and four
+// independent accumulators (loads in flight), then the s-lanes are folded through LDS in a fixed order (deterministic).
+template <int SL>
+__global__ void __launch_bounds__(64 * SL) reduce_partials_kernel(const float* __restrict__ partial, int S, int L,
+                                                                  float scale, float* __restrict__ out) {
+    __shared__ float red[SL][64];
+    const int jl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (j < L) {
+        int s = sl;
+        for (; s + 3 * SL < S; s += 4 * SL) {
+            a0 += partial[(size_t)s * L + j];
+            a1 += partial[(size_t)(s + SL) * L + j];
+            a2 += partial[(size_t)(s + 2 * SL) * L + j];
+            a3 += partial[(size_t)(s + 3 * SL) * L + j];
+        }
+        for (; s < S; s += SL) a0 += partial[(size_t)s * L + j];
+    }
+    red[sl][jl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && j < L) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < SL; ++k) t += red[k][jl];
+        out[j] = t * scale;
+    }
 }
 
 // colpart[T][2][C] -> dgamma, dbeta, dbias.  One block (1024 threads = 32 channels x 32 tile-lanes) per 32 channels.
@@ -397,7 +417,11 @@ __global__ void __launch_bounds__(256) residual_kernel(const float* __restrict__
 
 // ================================================================================================
 void uad_launch_reduce_partials(const float* partial, int S, int L, float scale, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((L + 255) / 256), dim3(256), 0, st, partial, S, L, scale, out);
+    const int blocks = (L + 63) / 64;
+    if (blocks >= 256 || S <= 8)
+        hipLaunchKernelGGL((reduce_partials_kernel<4>), dim3(blocks), dim3(256), 0, st, partial, S, L, scale, out);
+    else
+        hipLaunchKernelGGL((reduce_partials_kernel<16>), dim3(blocks), dim3(1024), 0, st, partial, S, L, scale, out);
 }
 
 void uad_launch_bn_grad_finalize(const float* colpart, int T, int C, const float* gamma, float rstd, float* dgamma,
