@@ -1,0 +1,90 @@
+"""GPU: the reference's trainer surface (trainers/AE.py, trainers/VAE.py: Config / train / process / reconstruct,
+model_dir, checkpoint resume) and the evaluation driver on top of the HIP engine."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vae as ovae
+
+pytestmark = pytest.mark.gpu
+
+try:
+    from unsupervised_anomaly_detection_brain_mri_amd import _lib
+    from unsupervised_anomaly_detection_brain_mri_amd.models import autoencoder, variational_autoencoder
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import AE, VAE, Phase
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import Evaluation
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_config, get_options
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset, synthetic_slices
+except Exception:
+    pass
+
+
+def _config(trainer, tmp_path, h=64, bs=8, epochs=2):
+    opt = get_options(batchsize=bs, learningrate=1e-3, numEpochs=epochs, zDim=64, outputWidth=h, outputHeight=h,
+                      config={'CHECKPOINTDIR': str(tmp_path / 'ck'), 'SAMPLEDIR': str(tmp_path / 'smp')})
+    ds = SyntheticDataset(32, 16, h, h, seed=0)
+    return get_config(trainer, opt, 'ADAM', [8, 8], 0.2, ds), opt, ds
+
+
+def test_vae_train_process_reconstruct_resume(tmp_path):
+    cfg, opt, ds = _config(VAE, tmp_path)
+    model = VAE(None, cfg, network=variational_autoencoder)
+    assert model.network.__name__ == 'variational_autoencoder'
+    assert model.model_dir == 'VAE_dSyntheticDataset_s64x64_variational_autoencoder_b8_z64_'
+    model.train(ds)
+    tr = model.curves['TRAIN/loss']
+    assert len(tr) == 2 and tr[1] < tr[0]
+    assert set(model.curves) >= {'TRAIN/loss', 'TRAIN/kl', 'TRAIN/reconstructionLoss', 'VAL/loss'}
+    ck = os.path.join(model.checkpointDir, model.model_dir)
+    assert os.path.isfile(os.path.join(ck, 'VAE.model-2.npz')) and os.path.isfile(os.path.join(ck, 'Config-2.json'))
+    # reconstruct(): 3-D input is expanded, keys / shapes as trainers/VAE.py:105-123
+    x = ds.next_batch(1, set='VAL')[0][0]
+    r = model.reconstruct(x, eps=0.0)
+    assert r['reconstruction'].shape == (1, 64, 64, 1) and r['l1err'] == pytest.approx(r['l2err'], rel=1e-6)
+    # step() returns the reference fetch keys
+    run = model.step(ds.next_batch(8, set='VAL')[0], Phase.VAL)
+    assert set(run) == {'reconstruction', 'L1', 'reconstructionLoss', 'kl', 'loss'}
+    assert run['loss'] == pytest.approx(run['reconstructionLoss'] + run['kl'], rel=1e-5)
+    # resume: a fresh trainer picks up epoch 2 and the same weights
+    w = model.engine.get_buffer_host(_lib.BUF_PARAMS)
+    model.engine.close()
+    cfg2, _, _ = _config(VAE, tmp_path)
+    m2 = VAE(None, cfg2, network=variational_autoencoder, seed=123)
+    assert m2.load_checkpoint() == 2
+    assert np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w) and m2.engine.step_count == 8
+    m2.engine.close()
+
+
+def test_ae_step_matches_oracle_with_injected_masks(tmp_path):
+    cfg, opt, ds = _config(AE, tmp_path, h=64, bs=4)
+    model = AE(None, cfg, network=autoencoder)
+    m = ovae.Model('AE', 64, 64, 1, 8, 64)
+    p = {k: v.astype(np.float64) for k, v in model.engine.get_params().items()}
+    x = ds.next_batch(4, set='TRAIN')[0]
+    mask = {'z': (np.random.default_rng(0).random((4, 64)) >= 0.2).astype(np.float32) / 0.8}
+    out, _ = m.forward(p, x.astype(np.float64), None, {'z': mask['z'].astype(np.float64)})
+    ls = m.losses(x.astype(np.float64), out)
+    run = model.step(x, Phase.TRAIN, dropout_masks=mask)
+    assert set(run) == {'reconstruction', 'L1', 'reconstructionLoss', 'loss'}
+    assert run['loss'] == pytest.approx(ls['loss'], rel=1e-4)
+    assert np.abs(run['reconstruction'] - out['x_hat']).max() <= 1e-4 * np.abs(out['x_hat']).max()
+    with pytest.raises(ValueError):
+        AE(None, cfg, network=variational_autoencoder)      # trainer / network mismatch
+    model.engine.close()
+
+
+def test_evaluation_driver_runs_and_scores(tmp_path):
+    cfg, opt, ds = _config(VAE, tmp_path, h=64, bs=8, epochs=1)
+    model = VAE(None, cfg, network=variational_autoencoder)
+    model.train(ds)
+    vols, labs, masks = [], [], []
+    for pth in range(2):
+        x, lab, msk = synthetic_slices(12, 64, 64, seed=70 + pth, lesions=True)
+        vols.append(x[..., 0].astype(np.float64)); labs.append(lab); masks.append(msk)
+    ev = Evaluation.evaluate(vols, labs, masks, model, opt)
+    assert 0.0 <= ev['diff_AUPRC'] <= 1.0 and 0.0 <= ev['diff_AUC'] <= 1.0 and len(ev['Dice']) == 2
+    # residual volume of one patient vs the numpy formula on the same reconstructions
+    d, l1 = Evaluation.evaluate_volume(model, vols[0], masks[0], {**opt, 'medianFiltering': False})
+    assert d.shape == vols[0].shape and (d >= 0).all() and np.isfinite(l1).all()
+    model.engine.close()

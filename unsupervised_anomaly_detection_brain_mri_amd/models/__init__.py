@@ -1,0 +1,5 @@
+"""Network descriptors with the reference's model-function names.  In the reference a model is a function that builds
+a TF graph (models/<name>.py::<name>); here it is a marker whose `__name__` selects the HIP engine's architecture
+(the trainer reads `network.__name__` for paths exactly like trainers/AEMODEL.py:32-35 / utils/Evaluation.py:382)."""
+from .autoencoder import autoencoder  # noqa: F401
+from .variational_autoencoder import variational_autoencoder  # noqa: F401

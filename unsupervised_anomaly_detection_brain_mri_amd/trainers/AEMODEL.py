@@ -1,0 +1,165 @@
+"""trainers/AEMODEL.py — Config defaults, model_dir, checkpoint resume, early stopping, plus the shared
+process()/step()/reconstruct() machinery of the AE-family trainers (trainers/AE.py:63-110, VAE.py:76-123)."""
+import os
+from collections import defaultdict
+from enum import Enum
+from math import inf
+
+import numpy as np
+
+from .DLMODEL import DLMODEL
+from ..engine import Engine
+from ..parallel import DataParallelStep
+
+
+class Phase(Enum):          # utils/logger.py:8-11
+    TRAIN = 'TRAIN'
+    VAL = 'VAL'
+    TEST = 'TEST'
+
+
+def indicate_early_stopping(current_cost, best_cost, last_improvement):   # trainers/AEMODEL.py:70-79
+    if current_cost < best_cost:
+        return current_cost, 0, False
+    last_improvement += 1
+    return best_cost, last_improvement, last_improvement >= 5
+
+
+class AEMODEL(DLMODEL):
+    class Config(DLMODEL.Config):
+        def __init__(self, modelname='AE'):       # trainers/AEMODEL.py:13-23
+            super().__init__()
+            self.modelname = modelname
+            self.intermediateResolutions = [8, 8]
+            self.outputWidth = 256
+            self.outputHeight = 256
+            self.numChannels = 3
+            self.dropout = False
+            self.dropout_rate = 0.2
+            self.zDim = 128
+
+    ARCH = 'AE'
+    SCALAR_KEYS = ('reconstructionLoss', 'loss')
+
+    def __init__(self, sess, config=None, network=None, seed=0, world=None, device=None):
+        super().__init__(sess, config if config is not None else self.Config())
+        if network is None or not hasattr(network, 'arch'):
+            raise ValueError('network= must be one of unsupervised_anomaly_detection_brain_mri_amd.models.*')
+        if network.arch != self.ARCH:
+            raise ValueError(f'trainer {type(self).__name__} expects a {self.ARCH} network, got {network.__name__}')
+        self.network = network
+        self.losses = {}
+        c = self.config
+        self.checkpointDir = os.path.join(c.checkpointDir or 'checkpoints', self.network.__name__)
+        self.engine = Engine(self.ARCH, c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]),
+                             c.zDim, max_batch=max(int(c.batchsize), 1), device=device)
+        self.dp = DataParallelStep(self.engine, world)
+        self.rng = np.random.default_rng(seed)       # host RNG for eps / dropout masks (TF graph RNG is unseeded)
+        self.initialize_variables()
+        self.get_number_of_trainable_params()
+
+    def initialize_variables(self):
+        """tf.global_variables_initializer(): glorot_uniform kernels, zero bias, gamma 1, beta 0 (SURVEY §8a note 3)."""
+        flat = np.zeros(self.engine.nparams, np.float32)
+        rng = np.random.default_rng(int(self.rng.integers(1 << 31)))
+        for name, shape, off in self.engine.spec:
+            cnt = int(np.prod(shape))
+            if name.endswith('kernel'):
+                rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+                lim = np.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf))
+                flat[off:off + cnt] = rng.uniform(-lim, lim, cnt)
+            elif name.endswith('gamma'):
+                flat[off:off + cnt] = 1.0
+        self.engine.set_params(flat)
+        self.engine.reset_optimizer()
+        self.dp.broadcast_params(0)
+
+    @property
+    def model_dir(self):            # trainers/AEMODEL.py:54-61
+        c = self.config
+        return "{}_d{}_s{}x{}_{}_b{}_z{}_{}".format(c.modelname, c.dataset, c.outputWidth, c.outputHeight,
+                                                    self.network.__name__, c.batchsize, c.zDim, c.description)
+
+    def load_checkpoint(self):      # trainers/AEMODEL.py:44-52
+        could_load, counter = self.load(self.checkpointDir)
+        print(" [*] Load SUCCESS" if could_load else " [!] Load failed...")
+        return counter if could_load else 0
+
+    # ------------------------------------------------------------------ RNG inputs of one sess.run
+    def _draw(self, n, dropout):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ one sess.run
+    def step(self, batch, phase, *, eps=None, dropout_masks=None, fetch_maps=True):
+        """The body of the reference's process() loop (= one sess.run, VAE.py:83-96): returns the same fetch keys.
+        TRAIN runs fwd + bwd + Adam; VAL/TEST run the forward + losses only (dropout False).
+        eps / dropout_masks may be injected (parity tests); otherwise they are drawn from the trainer's host RNG."""
+        phase = Phase(phase) if not isinstance(phase, Phase) else phase
+        train = phase == Phase.TRAIN
+        n = len(batch)
+        d_eps, d_masks = self._draw(n, dropout=train)
+        eps = d_eps if eps is None else eps
+        masks = d_masks if dropout_masks is None else dropout_masks
+        c = self.config
+        if train:
+            out = self.dp.train_step(batch, eps, masks, lr=c.learningrate, beta1=c.beta1, want_l1=fetch_maps)
+        else:
+            out = self.engine.forward(batch, eps, masks, want_backward=False, want_l1=fetch_maps)
+        sc = self.dp.allreduce_scalars(out['scalars'].clone()).cpu().numpy()       # the only host sync of the step
+        run = {'reconstructionLoss': np.float32(sc[0]), 'loss': np.float32(sc[2])}
+        if 'kl' in self.SCALAR_KEYS:
+            run['kl'] = np.float32(sc[1])
+        else:
+            run['loss'] = run['reconstructionLoss']
+        if fetch_maps:
+            run['reconstruction'] = out['x_hat'].cpu().numpy()
+            run['L1'] = out['L1'].cpu().numpy()
+        return run
+
+    def process(self, dataset, epoch, phase, optim=None):       # trainers/VAE.py:76-103
+        phase = Phase(phase) if not isinstance(phase, Phase) else phase
+        scalars = defaultdict(list)
+        num_batches = dataset.num_batches(self.config.batchsize, set=phase.value)
+        for idx in range(num_batches):
+            batch, _, _ = dataset.next_batch(self.config.batchsize, set=phase.value)
+            run = self.step(batch, phase, fetch_maps=False)    # maps are opt-in (4 MB D2H per step otherwise)
+            print(f'Epoch ({phase.value}): [{epoch:2d}] [{idx:4d}/{num_batches:4d}] loss: {run["loss"]:.8f}')
+            for k, v in run.items():
+                if np.ndim(v) == 0:
+                    scalars[k].append(v)
+        out = {k: np.mean(v) for k, v in scalars.items()}
+        for k, v in out.items():
+            self.curves.setdefault(f'{phase.value}/{k}', []).append(float(v))
+        return out
+
+    def train(self, dataset):       # trainers/VAE.py:31-74
+        self.create_optimizer(type=getattr(self.config, 'optimizer', 'ADAM'))
+        best_cost, last_improvement = inf, 0
+        last_epoch = self.load_checkpoint()
+        for epoch in range(last_epoch, self.config.numEpochs):
+            self.process(dataset, epoch, Phase.TRAIN, optim=True)
+            last_epoch += 1
+            self.save(self.checkpointDir, last_epoch)
+            val_scalars = self.process(dataset, epoch, Phase.VAL)
+            best_cost, last_improvement, stop = indicate_early_stopping(val_scalars['loss'], best_cost, last_improvement)
+            if stop:
+                print('Early stopping was triggered due to no improvement over the last 5 epochs')
+                break
+
+    def reconstruct(self, x, dropout=False, eps=None):
+        """trainers/VAE.py:105-123: {'reconstruction', 'l1err', 'l2err'} (l2err == l1err, sic).  The reference samples
+        z = mu + eps*sigma at eval too: eps is drawn unless given; pass eps=0 for the deterministic mode."""
+        x = np.asarray(x, np.float32)
+        if x.ndim < 4:
+            x = np.expand_dims(x, 0)
+        d_eps, masks = self._draw(len(x), dropout=bool(dropout))
+        if eps is None:
+            eps = d_eps
+        elif np.isscalar(eps):
+            eps = None if float(eps) == 0.0 else np.full((len(x), self.config.zDim), eps, np.float32)
+        out = self.engine.forward(x, eps, masks, want_backward=False, want_l1=False, want_latents=False)
+        rec = out['x_hat'].cpu().numpy()
+        results = {'reconstruction': rec}
+        results['l1err'] = np.sum(np.abs(x - rec))
+        results['l2err'] = np.sum(np.sqrt((x - rec) ** 2))
+        return results

@@ -1,0 +1,103 @@
+"""trainers/DLMODEL.py — base class: Config, save/load, optimizer validation.  The TF session / Saver are replaced by
+the HIP engine handle and a flat-fp32 .npz checkpoint (the TF checkpoint FORMAT is out of scope, SURVEY.md §2 row 6;
+the directory layout, file names and resume-by-epoch behaviour are kept: DLMODEL.py:63-110)."""
+import json
+import os
+import re
+
+import numpy as np
+
+from .. import _lib
+
+OPTIMIZERS = ('ADAM', 'SGD', 'MOMENTUM', 'RMS')   # DLMODEL.py:113-123
+
+
+class DLMODEL(object):
+    class Config(object):
+        def __init__(self):          # trainers/DLMODEL.py:13-26
+            self.modelname = ''
+            self.model_config = {}
+            self.checkpointDir = None
+            self.description = ''
+            self.batchsize = 6
+            self.useTensorboard = True
+            self.tensorboardPort = 8008
+            self.useMatplotlib = False
+            self.debugGradients = False
+            self.tfSummaryAfter = 100
+            self.dataset = ''
+            self.beta1 = 0.5
+
+    def __init__(self, sess, config=None):
+        self.sess = sess                 # accepted for signature compatibility; unused (no tf.Session here)
+        self.config = config if config is not None else self.Config()
+        self.variables = {}
+        self.curves = {}
+        self.losses = None
+        self.engine = None
+
+    @property
+    def model_dir(self):
+        return "{}_d{}_b{}_{}".format(self.config.modelname, self.config.dataset, self.config.batchsize, self.config.description)
+
+    @staticmethod
+    def create_optimizer(type='ADAM'):
+        """Validates the optimizer string like DLMODEL.create_optimizer (:112-123).  Only ADAM has a HIP kernel."""
+        if type not in OPTIMIZERS:
+            raise ValueError('Invalid optimizer type')
+        if type != 'ADAM':
+            raise NotImplementedError(f"optimizer {type!r}: only 'ADAM' (the reference default) is implemented on the HIP path")
+        return type
+
+    def save(self, checkpoint_dir, step):
+        model_name = self.config.modelname + ".model"
+        checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        eng = self.engine
+        np.savez(os.path.join(checkpoint_dir, f'{model_name}-{step}.npz'),
+                 params=eng.get_buffer_host(_lib.BUF_PARAMS), adam_m=eng.get_buffer_host(_lib.BUF_ADAM_M),
+                 adam_v=eng.get_buffer_host(_lib.BUF_ADAM_V), adam_t=np.int64(eng.step_count),
+                 names=np.array([n for n, _, _ in eng.spec]))
+        with open(os.path.join(checkpoint_dir, 'checkpoint'), 'w') as f:
+            f.write(f'model_checkpoint_path: "{model_name}-{step}"\n')
+        with open(os.path.join(checkpoint_dir, 'Config-{}.json'.format(step)), 'w') as outfile:
+            try:
+                json.dump({k: v for k, v in self.config.__dict__.items() if k != 'options'}, outfile, default=str)
+            except Exception:
+                print("Failed to save config json")
+        np.save(os.path.join(checkpoint_dir, 'Curves.npy'), self.curves)
+
+    def load(self, checkpoint_dir, iteration=None):
+        print(" [*] Reading checkpoints...")
+        checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
+        curves_file = os.path.join(checkpoint_dir, 'Curves.npy')
+        if os.path.isfile(curves_file):
+            self.curves = np.load(curves_file, allow_pickle=True).item()
+        name = None
+        if iteration is not None:
+            name = self.config.modelname + '.model-' + str(iteration)
+        else:
+            ck = os.path.join(checkpoint_dir, 'checkpoint')
+            if os.path.isfile(ck):
+                mt = re.search(r'model_checkpoint_path: "(.*)"', open(ck).read())
+                name = mt.group(1) if mt else None
+        if name and os.path.isfile(os.path.join(checkpoint_dir, name + '.npz')):
+            z = np.load(os.path.join(checkpoint_dir, name + '.npz'))
+            self.engine.set_params(z['params'])
+            self.engine.set_buffer_host(_lib.BUF_ADAM_M, z['adam_m'])
+            self.engine.set_buffer_host(_lib.BUF_ADAM_V, z['adam_v'])
+            self.engine.step_count = int(z['adam_t'])
+            counter = int(next(re.finditer(r'(\d+)(?!.*\d)', name)).group(0))
+            print(" [*] Success to read {}".format(name))
+            return True, counter
+        print(" [*] Failed to find a checkpoint")
+        return False, 0
+
+    def get_number_of_trainable_params(self):
+        scopes = {}
+        for name, shape, _ in self.engine.spec:
+            scopes[name.split('/')[0]] = scopes.get(name.split('/')[0], 0) + int(np.prod(shape))
+        for scope, cnt in scopes.items():
+            print(f'#Params in {scope}: {cnt}')
+        print(f'#Params in total: {self.engine.nparams}')
+        return self.engine.nparams

@@ -1,0 +1,23 @@
+"""trainers/VAE.py — VAE: rec = sum_hwc |x_hat - x|, kl = 0.5 sum(mu^2 + sigma^2 - log sigma^2 - 1),
+loss = mean(rec + kl) (VAE.py:36-42); dropout on mu, log_sigma and dec_dense (variational_autoencoder.py:31-35)."""
+import numpy as np
+
+from .AEMODEL import AEMODEL, Phase, indicate_early_stopping  # noqa: F401
+
+
+class VAE(AEMODEL):
+    class Config(AEMODEL.Config):
+        def __init__(self):
+            super().__init__('VAE')
+
+    ARCH = 'VAE'
+    SCALAR_KEYS = ('reconstructionLoss', 'kl', 'loss')
+
+    def _draw(self, n, dropout):
+        z = self.config.zDim
+        eps = self.rng.standard_normal((n, z)).astype(np.float32)
+        if not dropout or self.config.dropout_rate <= 0:
+            return eps, None
+        r = float(self.config.dropout_rate)
+        keep = lambda shape: (self.rng.random(shape) >= r).astype(np.float32) / (1.0 - r)
+        return eps, {'mu': keep((n, z)), 'sigma': keep((n, z)), 'dec': keep((n, self.engine.flat))}

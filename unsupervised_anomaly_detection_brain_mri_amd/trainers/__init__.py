@@ -1,0 +1,3 @@
+from .AE import AE  # noqa: F401
+from .VAE import VAE  # noqa: F401
+from .AEMODEL import Phase  # noqa: F401
