@@ -49,6 +49,11 @@ __device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int l
     }
 }
 
+// component-wise select (a float4 `c ? v : zero` is lowered through scratch memory by the compiler)
+__device__ __forceinline__ float4 keep4(bool c, float4 v) {
+    return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f);
+}
+
 __device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, float alpha) {
     float4 r;
     r.x = fmaf(v.x, sc.x, sh.x); r.x = r.x > 0.f ? r.x : r.x * alpha;
@@ -58,6 +63,8 @@ __device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, float a
     return r;
 }
 
+constexpr int XF_LDS_CH = 512;  // activation-on-load tables (gamma', beta) staged once per workgroup
+
 template <int BM, int BN, int BK, int WGM, int WGN, int KIND>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
@@ -65,12 +72,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
     constexpr int FM = WTM / 32, FN = WTN / 32;
     static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
     static_assert(BK % 8 == 0, "BK multiple of 8");
+    constexpr int NKK = BK / 8;
     constexpr int LDA = BK + 4;  // (LDA/4) odd -> conflict-free ds_read_b128 across 16-lane groups
     constexpr int LDB = (KIND == KIND_F) ? (BN + 4) : (BK + 4);
     constexpr int A_EL = BM * LDA;
     constexpr int B_EL = (KIND == KIND_F) ? (BK * LDB) : (BN * LDB);
     constexpr int STAGE = A_EL + B_EL;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float s_xf[2 * XF_LDS_CH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -94,6 +103,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
     const int ntaps = nty * ntx;
     const int ncc = a.CA / BK;
     const int nk = ntaps * ncc;
+
+    // ---- activation-on-load tables -> LDS (once) ----
+    const bool xf = a.xf.scale != nullptr;
+    if (xf) {
+        for (int c = tid; c < a.CA; c += NT) {
+            s_xf[c] = a.xf.scale[c] * a.xf.mult;
+            s_xf[XF_LDS_CH + c] = a.xf.shift[c];
+        }
+    }
 
     // ---- per-thread A rows (positions) ----
     constexpr int TPR = BK / 4, RPP = NT / TPR, PA = (BM + RPP - 1) / RPP;
@@ -121,19 +139,32 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
     const int AH = (KIND == KIND_F) ? d.HB : d.HS;
     const int AW = (KIND == KIND_F) ? d.WB : d.WS;
 
-    // ---- per-thread B slots ----
+    // ---- per-thread B slots (predicates are loop invariant; out-of-range slots read element 0 and are zeroed) ----
     constexpr int TPRB = (KIND == KIND_F) ? (BN / 4) : (BK / 4);
     constexpr int RPB = NT / TPRB;
     constexpr int BROWS = (KIND == KIND_F) ? BK : BN;
     constexpr int PB = (BROWS + RPB - 1) / RPB;
     const int bcol = (tid % TPRB) * 4;
     const int brow0 = tid / TPRB;
+    bool bok[PB];
+    int boff[PB];   // loop-invariant part of the weight offset
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int r = brow0 + q * RPB;
+        if (KIND == KIND_F) {
+            bok[q] = (r < BK) && (n0 + bcol) < a.Nn;
+            boff[q] = bok[q] ? (r * d.CS + n0 + bcol) : 0;
+        } else {
+            bok[q] = (r < BN) && (n0 + r) < a.Nn;
+            boff[q] = bok[q] ? ((n0 + r) * d.CS + bcol) : 0;
+        }
+    }
 
     float4 va[PA], vb[PB];
-    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned okbits = 0;
-    const bool xf = a.xf.scale != nullptr;
+    int xc0 = 0;
 
+    // branch-free tile fetch: every load is issued unconditionally from a clamped (always valid) address
     auto load_tiles = [&](int tap, int c0) {
         int ky, kx, oy, ox;
         {
@@ -141,55 +172,43 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
             if (KIND == KIND_F) { ky = ty; kx = tx; oy = ky; ox = kx; }
             else { ky = ky0 + S * ty; kx = kx0 + S * tx; oy = dy0 - ty; ox = dx0 - tx; }
         }
-        if (xf) {
-            xsc = *reinterpret_cast<const float4*>(a.xf.scale + c0 + acol);
-            xsh = *reinterpret_cast<const float4*>(a.xf.shift + c0 + acol);
-        }
+        xc0 = c0;
         okbits = 0;
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
             const int y = ry[q] + oy, x = rx[q] + ox;
             const bool ok = rok[q] && (unsigned)y < (unsigned)AH && (unsigned)x < (unsigned)AW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const size_t off = (size_t)(rbase[q] + y * AW + x) * a.CA + c0 + acol;
-                v = *reinterpret_cast<const float4*>(a.A + off);
-                okbits |= 1u << q;
-            }
-            va[q] = v;
+            const int pix = ok ? (rbase[q] + y * AW + x) : 0;
+            va[q] = *reinterpret_cast<const float4*>(a.A + (size_t)pix * a.CA + c0 + acol);
+            okbits |= (ok ? 1u : 0u) << q;
         }
         const int tapw = ky * KS + kx;
+        const size_t wbase = (KIND == KIND_F) ? ((size_t)tapw * d.CB + c0) * d.CS : ((size_t)tapw * d.CB) * d.CS + c0;
 #pragma unroll
-        for (int q = 0; q < PB; ++q) {
-            const int r = brow0 + q * RPB;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (KIND == KIND_F) {
-                if (r < BK && (n0 + bcol) < a.Nn)
-                    v = *reinterpret_cast<const float4*>(a.W + ((size_t)tapw * d.CB + c0 + r) * d.CS + n0 + bcol);
-            } else {
-                if (r < BN && (n0 + r) < a.Nn)
-                    v = *reinterpret_cast<const float4*>(a.W + ((size_t)tapw * d.CB + n0 + r) * d.CS + c0 + bcol);
-            }
-            vb[q] = v;
-        }
+        for (int q = 0; q < PB; ++q) vb[q] = *reinterpret_cast<const float4*>(a.W + wbase + boff[q]);
     };
     auto store_tiles = [&](int buf) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + A_EL;
-        float4 sc = xsc;
-        sc.x *= a.xf.mult; sc.y *= a.xf.mult; sc.z *= a.xf.mult; sc.w *= a.xf.mult;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xf) {
+            sc = *reinterpret_cast<const float4*>(s_xf + xc0 + acol);
+            sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + xc0 + acol);
+        }
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
             const int r = arow0 + q * RPP;
             float4 v = va[q];
+            if (xf) v = xform4(v, sc, sh, a.xf.alpha);
             // padding pixels stay exactly 0 (the pad is applied to the ACTIVATED tensor)
-            if (xf && ((okbits >> q) & 1u)) v = xform4(v, sc, xsh, a.xf.alpha);
+            v = keep4((okbits >> q) & 1u, v);
             if (r < BM) *reinterpret_cast<float4*>(sA + r * LDA + acol) = v;
         }
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
             const int r = brow0 + q * RPB;
-            if (r < BROWS) *reinterpret_cast<float4*>(sB + r * LDB + bcol) = vb[q];
+            const float4 v = keep4(bok[q], vb[q]);
+            if (r < BROWS) *reinterpret_cast<float4*>(sB + r * LDB + bcol) = v;
         }
     };
 
@@ -203,49 +222,55 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
 
     const int l31 = lane & 31, lh = lane >> 5;
 
+    __syncthreads();   // s_xf visible
     if (nk > 0) {
         load_tiles(0, 0);
         store_tiles(0);
     }
     __syncthreads();
 
+    // fragment double buffer: the ds_reads of k-slice kk+1 are in flight while the MFMAs of kk issue
+    float4 af[2][FM];
+    float bf[2][FN][4];
+    auto load_frags = [&](int slot, const float* sA, const float* sB, int kk) {
+#pragma unroll
+        for (int im = 0; im < FM; ++im)
+            af[slot][im] = *reinterpret_cast<const float4*>(sA + (wm * WTM + im * 32 + l31) * LDA + kk * 8 + 4 * lh);
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn) {
+            if (KIND == KIND_F) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    bf[slot][jn][s] = sB[(kk * 8 + 4 * lh + s) * LDB + wn * WTN + jn * 32 + l31];
+            } else {
+                const float4 t = *reinterpret_cast<const float4*>(sB + (wn * WTN + jn * 32 + l31) * LDB + kk * 8 + 4 * lh);
+                bf[slot][jn][0] = t.x; bf[slot][jn][1] = t.y; bf[slot][jn][2] = t.z; bf[slot][jn][3] = t.w;
+            }
+        }
+    };
+
     int tap = 0, cc = 0;
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
-        // advance (tap, cc) to step ks+1 and prefetch it into registers
         int ntap = tap, ncc_ = cc + 1;
         if (ncc_ == ncc) { ncc_ = 0; ntap = tap + 1; }
         const bool more = (ks + 1 < nk);
-        if (more) load_tiles(ntap, ncc_ * BK);
-
         const float* sA = smem + buf * STAGE;
         const float* sB = sA + A_EL;
+        load_frags(0, sA, sB, 0);
+        if (more) load_tiles(ntap, ncc_ * BK);
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 af[FM];
-            float bf[FN][4];
-#pragma unroll
-            for (int im = 0; im < FM; ++im)
-                af[im] = *reinterpret_cast<const float4*>(sA + (wm * WTM + im * 32 + l31) * LDA + kk * 8 + 4 * lh);
-#pragma unroll
-            for (int jn = 0; jn < FN; ++jn) {
-                if (KIND == KIND_F) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        bf[jn][s] = sB[(kk * 8 + 4 * lh + s) * LDB + wn * WTN + jn * 32 + l31];
-                } else {
-                    const float4 t = *reinterpret_cast<const float4*>(sB + (wn * WTN + jn * 32 + l31) * LDB + kk * 8 + 4 * lh);
-                    bf[jn][0] = t.x; bf[jn][1] = t.y; bf[jn][2] = t.z; bf[jn][3] = t.w;
-                }
-            }
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int cur = kk & 1;
+            if (kk + 1 < NKK) load_frags(cur ^ 1, sA, sB, kk + 1);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int im = 0; im < FM; ++im) {
-                    const float av = (s == 0) ? af[im].x : (s == 1) ? af[im].y : (s == 2) ? af[im].z : af[im].w;
+                    const float av = (s == 0) ? af[cur][im].x : (s == 1) ? af[cur][im].y : (s == 2) ? af[cur][im].z : af[cur][im].w;
 #pragma unroll
                     for (int jn = 0; jn < FN; ++jn)
-                        acc[im][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[jn][s], acc[im][jn], 0, 0, 0);
+                        acc[im][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[cur][jn][s], acc[im][jn], 0, 0, 0);
                 }
             }
         }
@@ -257,42 +282,78 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
 
     // ---------------------------------------------------------------- epilogue
     const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
+    // per-lane column constants
+    bool colok[FN];
+    int colc[FN];
+    float c_a[FN], c_b[FN];   // !bwd: bias, -- ; bwd: escale*emult, eshift
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) {
+        const int col = n0 + wn * WTN + jn * 32 + l31;
+        colok[jn] = col < a.Nn;
+        colc[jn] = colok[jn] ? col : 0;
+        if (!bwd) {
+            c_a[jn] = a.ep.bias ? a.ep.bias[colc[jn]] : 0.f;
+            c_b[jn] = 0.f;
+        } else {
+            c_a[jn] = a.ep.escale[colc[jn]] * a.ep.emult;
+            c_b[jn] = a.ep.eshift[colc[jn]];
+        }
+    }
     float s1[FN], s2[FN];
 #pragma unroll
     for (int jn = 0; jn < FN; ++jn) { s1[jn] = 0.f; s2[jn] = 0.f; }
 
 #pragma unroll
     for (int im = 0; im < FM; ++im) {
+        // row bases of this fragment's 16 rows
+        size_t obase[16];
+        bool rowok[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int m = m0 + row;
-            if (m >= a.M) continue;
-            size_t obase;
+            rowok[r] = m < a.M;
+            const int mc = rowok[r] ? m : 0;
             if (KIND == KIND_F) {
-                obase = (size_t)m * a.Nn;
+                obase[r] = (size_t)mc * a.Nn;
             } else {
                 int n, i, j;
-                decode_pos(m, d.HS, d.WS, a.lhs, a.lws, n, i, j);
-                obase = ((size_t)(n * d.HB + S * i + py) * d.WB + (S * j + px)) * a.Nn;
+                decode_pos(mc, d.HS, d.WS, a.lhs, a.lws, n, i, j);
+                obase[r] = ((size_t)(n * d.HB + S * i + py) * d.WB + (S * j + px)) * a.Nn;
             }
+        }
+        if (!bwd) {
 #pragma unroll
             for (int jn = 0; jn < FN; ++jn) {
-                const int col = n0 + wn * WTN + jn * 32 + l31;
-                if (col >= a.Nn) continue;
-                const size_t off = obase + col;
-                float v = acc[im][jn][r];
-                if (!bwd) {
-                    if (a.ep.bias) v += a.ep.bias[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (!(rowok[r] && colok[jn])) continue;
+                    const size_t off = obase[r] + colc[jn];
+                    float v = acc[im][jn][r] + c_a[jn];
                     if (a.ep.mul) v *= a.ep.mul[off];
                     if (a.ep.add) v += a.ep.add[off];
                     a.Out[off] = v;
-                } else {
-                    const float c = a.ep.cprev[off];
-                    const float esc = a.ep.escale[col] * a.ep.emult;
-                    const float bn = fmaf(esc, c, a.ep.eshift[col]);
-                    const float dbn = bn > 0.f ? v : v * a.ep.ealpha;
-                    a.Out[off] = dbn * esc;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                // all 16 c_prev loads of this fragment are issued before the first one is consumed
+                float cp[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = rowok[r] && colok[jn];
+                    cp[r] = a.ep.cprev[ok ? (obase[r] + colc[jn]) : 0];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = rowok[r] && colok[jn];
+                    const float c = cp[r];
+                    const float bn = fmaf(c_a[jn], c, c_b[jn]);
+                    const float v = acc[im][jn][r];
+                    float dbn = bn > 0.f ? v : v * a.ep.ealpha;
+                    dbn = ok ? dbn : 0.f;
+                    if (ok) a.Out[obase[r] + colc[jn]] = dbn * c_a[jn];
                     s1[jn] += dbn;
                     s2[jn] = fmaf(dbn, c, s2[jn]);
                 }
