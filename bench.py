@@ -159,7 +159,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(out['scalars'][2].item())
-    assert np.isfinite(loss), 'loss diverged'
+    assert np.isfinite(loss) or os.environ.get('UAD_BENCH_ALLOW_NAN'), 'loss diverged'
 
     # ---- roofline leg: per-launch-group HIP-event timing of the same step (profiling pass after the timed region)
     eng.profile(True)

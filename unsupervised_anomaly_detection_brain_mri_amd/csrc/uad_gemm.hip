@@ -14,6 +14,7 @@
 // The 64-lane wavefront owns (32*FM)x(32*FN) of the block tile; K is walked 8 at a time with the lane-half
 // permutation k = 8*kk + 4*(lane>>5) + s so that one ds_read_b128 feeds four MFMAs.
 #include "uad_kernels.h"
+#include <stdlib.h>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -25,6 +26,7 @@ namespace {
 struct ConvGemmArgs {
     const float* A;
     const float* W;
+    const float* Wp;   // k-quad-interleaved copy of W for the spatial kernels (uad_launch_pack_weights)
     float* Out;
     UadXform xf;
     UadEpilogue ep;
@@ -33,6 +35,7 @@ struct ConvGemmArgs {
     int CA;        // channels of the A operand (contraction per tap)
     int Nn;        // output channels
     int lws, lhs;  // log2(WS), log2(HS) or -1 when not a power of two
+    int dbg;       // UAD_DBG ablation bits (timing experiments only; results are wrong when set)
 };
 
 __device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int lws, int& n, int& i, int& j) {
@@ -386,6 +389,373 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
     }
 }
 
+// ================================================================================================
+// k5 s2 SAME specialisations ("spatial" kernels): the input halo tile of one channel chunk is staged in LDS ONCE
+// (activation applied on the way in) and all 25 taps are contracted from it; the weight fragments go global -> VGPR,
+// prefetched one tap ahead, so the tap loop has no barrier and no per-tap address arithmetic (tap offsets are
+// immediates).  One workgroup = TH x TW output positions (F) / input-resolution positions (D) x 32*WGN channels.
+// ================================================================================================
+template <int NKK>
+struct BFragF { float v[NKK][4]; };
+template <int NKK>
+struct BFragD { float4 v[NKK]; };
+
+// common epilogue for one 32x32 accumulator fragment whose 16 row offsets are known
+template <int KIND_UNUSED>
+__device__ __forceinline__ void epilogue_frag(const ConvGemmArgs& a, const v16f& acc, const size_t (&obase)[16],
+                                              bool colok, int colc, float c_a, float c_b, float& s1, float& s2) {
+    if (a.ep.kind != UAD_EPI_BWD_ACT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (!colok) continue;
+            const size_t off = obase[r] + colc;
+            float v = acc[r] + c_a;
+            if (a.ep.mul) v *= a.ep.mul[off];
+            if (a.ep.add) v += a.ep.add[off];
+            a.Out[off] = v;
+        }
+    } else {
+        float cp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cp[r] = a.ep.cprev[colok ? (obase[r] + colc) : 0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float c = cp[r];
+            const float bn = fmaf(c_a, c, c_b);
+            float dbn = bn > 0.f ? acc[r] : acc[r] * a.ep.ealpha;
+            dbn = colok ? dbn : 0.f;
+            if (colok) a.Out[obase[r] + colc] = dbn * c_a;
+            s1 += dbn;
+            s2 = fmaf(dbn, c, s2);
+        }
+    }
+}
+
+template <int TH, int TW, int CK, int WGM, int WGN>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv5_f_kernel(const ConvGemmArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int IH = 2 * TH + 3, IW = 2 * TW + 3;
+    constexpr int LDC = CK + 4, NKK = CK / 8, CQ = CK / 4;
+    constexpr int BN = 32 * WGN;
+    static_assert(TH * TW == 32 * WGM, "one 32-row fragment per wave along M");
+    __shared__ __attribute__((aligned(16))) float sIn[IH * IW * LDC];
+    __shared__ __attribute__((aligned(16))) float s_xf[2 * XF_LDS_CH];
+    __shared__ float s_red[WGM * 2 * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const UadConvDesc& d = a.d;
+    const int tilesx = d.WS / TW;
+    const int ty0 = (blockIdx.x / tilesx) * TH, tx0 = (blockIdx.x % tilesx) * TW;
+    const int n = blockIdx.y;
+    const int n0 = blockIdx.z * BN;
+    const int CB = d.CB, CS = d.CS;
+
+    const bool xf = a.xf.scale != nullptr;
+    if (xf)
+        for (int c = tid; c < CB; c += NT) {
+            s_xf[c] = a.xf.scale[c] * a.xf.mult;
+            s_xf[XF_LDS_CH + c] = a.xf.shift[c];
+        }
+
+    const int m = wm * 32 + l31;
+    const int pty = m / TW, ptx = m % TW;
+    const int aoff = ((2 * pty) * IW + 2 * ptx) * LDC + 4 * lh;
+    const int col = n0 + wn * 32 + l31;
+    const bool colok = col < CS;
+    const int colc = colok ? col : 0;
+    // packed weights Wp[tap][cb/4][cs][4]: the lane's four k-slots of one k-slice are ONE 16-byte load and the
+    // 32 lanes of a half-wave read 512 contiguous bytes
+    const float* wptr = a.Wp + ((size_t)lh * CS + colc) * 4;
+
+    BFragD<NKK> b0, b1;
+    auto loadB = [&](BFragD<NKK>& b, int tap, int c0) {
+        const float* w = wptr + ((size_t)tap * CB + c0) * CS;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) b.v[kk] = *reinterpret_cast<const float4*>(w + (size_t)(kk * 2) * CS * 4);
+    };
+
+    // four independent accumulator chains (one per k-slot of the float4 fragment): an MFMA never waits on its
+    // predecessor, so the ds_reads / weight loads interleaved between them cost no matrix-pipe time
+    v16f acc4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
+
+    const int nchunks = CB / CK;
+    const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
+    const float* inb = a.A + (size_t)n * d.HB * d.WB * CB;
+    loadB(b0, 0, 0);
+    __syncthreads();  // s_xf visible
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK;
+        if (ch > 0) __syncthreads();  // everyone is done reading the previous chunk's tile
+        // ---- stage the halo tile of this channel chunk (activation on the way in, padding = exact 0) ----
+        constexpr int TOT = IH * IW * CQ;
+        constexpr int BATCH = 6;
+        for (int f0 = tid; f0 < ((a.dbg & 2) ? 0 : TOT); f0 += NT * BATCH) {
+            float4 v[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                const int pix = f / CQ, cq = f % CQ;
+                const int iy = pix / IW, ix = pix % IW;
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
+                const int gp = ok[u] ? (gy * d.WB + gx) : 0;
+                v[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CB + c0 + (ok[u] ? cq * 4 : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                if (f >= TOT) continue;
+                const int pix = f / CQ, cq = f % CQ;
+                float4 t = v[u];
+                if (xf) {
+                    const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
+                    const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
+                    t = xform4(t, sc, sh, a.xf.alpha);
+                }
+                *reinterpret_cast<float4*>(sIn + pix * LDC + cq * 4) = keep4(ok[u], t);
+            }
+        }
+        __syncthreads();
+        // ---- 25 taps from LDS; weights one tap ahead in registers ----
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            const int ky = tap / 5, kx = tap % 5;
+            BFragD<NKK>& cur = (tap & 1) ? b1 : b0;
+            BFragD<NKK>& nxt = (tap & 1) ? b0 : b1;
+            if (!(a.dbg & 1)) {
+                if (tap < 24) loadB(nxt, tap + 1, c0);
+                else if (ch + 1 < nchunks) loadB(nxt, 0, c0 + CK);
+            }
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const float4 av = *reinterpret_cast<const float4*>(sIn + aoff + (ky * IW + kx) * LDC + kk * 8);
+                acc4[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, cur.v[kk].x, acc4[0], 0, 0, 0);
+                acc4[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, cur.v[kk].y, acc4[1], 0, 0, 0);
+                acc4[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, cur.v[kk].z, acc4[2], 0, 0, 0);
+                acc4[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, cur.v[kk].w, acc4[3], 0, 0, 0);
+            }
+        }
+        b0 = b1;  // 25 taps is odd: the prefetched tap 0 of the next chunk sits in b1
+    }
+
+    // ---- epilogue ----
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
+    const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
+    float c_a, c_b = 0.f;
+    if (!bwd) c_a = a.ep.bias ? a.ep.bias[colc] : 0.f;
+    else { c_a = a.ep.escale[colc] * a.ep.emult; c_b = a.ep.eshift[colc]; }
+    size_t obase[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int oy = ty0 + mm / TW, ox = tx0 + mm % TW;
+        obase[r] = ((size_t)(n * d.HS + oy) * d.WS + ox) * CS;
+    }
+    float s1 = 0.f, s2 = 0.f;
+    if (!(a.dbg & 4) || acc[0] == 12345.f) epilogue_frag<0>(a, acc, obase, colok, colc, c_a, c_b, s1, s2);
+    if (bwd) {
+        const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+        if (lh == 0) {
+            s_red[(wm * 2 + 0) * BN + wn * 32 + l31] = t1;
+            s_red[(wm * 2 + 1) * BN + wn * 32 + l31] = t2;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) t += s_red[(w * 2 + which) * BN + c];
+            const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            if (n0 + c < CS) a.ep.colpart[(tile * 2 + which) * CS + n0 + c] = t;
+        }
+    }
+}
+
+template <int TH, int TW, int CK, int WGM, int WGN>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int IH = TH + 2, IW = TW + 2;
+    constexpr int LDC = CK + 4, NKK = CK / 8, CQ = CK / 4;
+    constexpr int BN = 32 * WGN;
+    static_assert(TH * TW == 32 * WGM, "one 32-row fragment per wave along M");
+    __shared__ __attribute__((aligned(16))) float sIn[IH * IW * LDC];
+    __shared__ __attribute__((aligned(16))) float s_xf[2 * XF_LDS_CH];
+    __shared__ float s_red[WGM * 2 * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const UadConvDesc& d = a.d;
+    const int tilesx = d.WS / TW;
+    const int ty0 = (blockIdx.x / tilesx) * TH, tx0 = (blockIdx.x % tilesx) * TW;
+    const int n = blockIdx.y;
+    const int n0 = blockIdx.z * BN;
+    const int CB = d.CB, CS = d.CS;   // output channels = CB, contraction = CS
+
+    const bool xf = a.xf.scale != nullptr;
+    if (xf)
+        for (int c = tid; c < CS; c += NT) {
+            s_xf[c] = a.xf.scale[c] * a.xf.mult;
+            s_xf[XF_LDS_CH + c] = a.xf.shift[c];
+        }
+
+    const int m = wm * 32 + l31;
+    const int pty = m / TW, ptx = m % TW;
+    const int aoff = ((pty + 1) * IW + ptx + 1) * LDC + 4 * lh;
+    const int col = n0 + wn * 32 + l31;
+    const bool colok = col < CB;
+    const int colc = colok ? col : 0;
+    // packed weights Wq[tap][cs/4][cb][4] (contraction quad innermost, output channel next): coalesced 16-byte loads
+    const float* wptr = a.Wp + ((size_t)lh * CB + colc) * 4;
+
+    BFragD<NKK> b0, b1;
+    auto loadB = [&](BFragD<NKK>& b, int tap, int c0) {
+        const float* w = wptr + ((size_t)tap * CS + c0) * CB;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) b.v[kk] = *reinterpret_cast<const float4*>(w + (size_t)(kk * 2) * CB * 4);
+    };
+
+    v16f acc[4];   // output-parity classes (py, px)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    const int nchunks = CS / CK;
+    const float* inb = a.A + (size_t)n * d.HS * d.WS * CS;
+    loadB(b0, 0, 0);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK;
+        if (ch > 0) __syncthreads();
+        constexpr int TOT = IH * IW * CQ;
+        constexpr int BATCH = 4;
+        for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
+            float4 v[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                const int pix = f / CQ, cq = f % CQ;
+                const int iy = pix / IW, ix = pix % IW;
+                const int gy = ty0 - 1 + iy, gx = tx0 - 1 + ix;
+                ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HS && (unsigned)gx < (unsigned)d.WS;
+                const int gp = ok[u] ? (gy * d.WS + gx) : 0;
+                v[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CS + c0 + (ok[u] ? cq * 4 : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                if (f >= TOT) continue;
+                const int pix = f / CQ, cq = f % CQ;
+                float4 t = v[u];
+                if (xf) {
+                    const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
+                    const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
+                    t = xform4(t, sc, sh, a.xf.alpha);
+                }
+                *reinterpret_cast<float4*>(sIn + pix * LDC + cq * 4) = keep4(ok[u], t);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            const int ky = tap / 5, kx = tap % 5;
+            // y[2i-1+ky] += x[i]: output parity py = (ky+1)&1, source row i + dy with dy = (py + 1 - ky) / 2
+            const int py = (ky + 1) & 1, px = (kx + 1) & 1;
+            const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+            const int cls = py * 2 + px;
+            BFragD<NKK>& cur = (tap & 1) ? b1 : b0;
+            BFragD<NKK>& nxt = (tap & 1) ? b0 : b1;
+            if (tap < 24) loadB(nxt, tap + 1, c0);
+            else if (ch + 1 < nchunks) loadB(nxt, 0, c0 + CK);
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const float4 av = *reinterpret_cast<const float4*>(sIn + aoff + (dy * IW + dx) * LDC + kk * 8);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, cur.v[kk].x, acc[cls], 0, 0, 0);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, cur.v[kk].y, acc[cls], 0, 0, 0);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, cur.v[kk].z, acc[cls], 0, 0, 0);
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, cur.v[kk].w, acc[cls], 0, 0, 0);
+            }
+        }
+        b0 = b1;
+    }
+
+    const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
+    float c_a, c_b = 0.f;
+    if (!bwd) c_a = a.ep.bias ? a.ep.bias[colc] : 0.f;
+    else { c_a = a.ep.escale[colc] * a.ep.emult; c_b = a.ep.eshift[colc]; }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+        const int py = cls >> 1, px = cls & 1;
+        size_t obase[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int Y = 2 * (ty0 + mm / TW) + py, X = 2 * (tx0 + mm % TW) + px;
+            obase[r] = ((size_t)(n * d.HB + Y) * d.WB + X) * CB;
+        }
+        epilogue_frag<0>(a, acc[cls], obase, colok, colc, c_a, c_b, s1, s2);
+    }
+    if (bwd) {
+        const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+        if (lh == 0) {
+            s_red[(wm * 2 + 0) * BN + wn * 32 + l31] = t1;
+            s_red[(wm * 2 + 1) * BN + wn * 32 + l31] = t2;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) t += s_red[(w * 2 + which) * BN + c];
+            const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            if (n0 + c < CB) a.ep.colpart[(tile * 2 + which) * CB + n0 + c] = t;
+        }
+    }
+}
+
+// Weight re-layout for the spatial kernels.  One thread per source element W[tap][cb][cs] of any of up to 8 tensors:
+//   F-pack: Wp[tap][cb/4][cs][cb%4]     D-pack: Wq[tap][cs/4][cb][cs%4]      (both at the tensor's own flat offset)
+struct PackDesc { long long off[8]; int cb[8], cs[8], count[8]; int n; };
+__global__ void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ Wf, float* __restrict__ Wd, PackDesc pd) {
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int t = 0;
+    while (t < pd.n && gid >= pd.count[t]) { gid -= pd.count[t]; ++t; }
+    if (t >= pd.n) return;
+    const int CB = pd.cb[t], CS = pd.cs[t];
+    const int cs = (int)(gid % CS);
+    const int r = (int)(gid / CS);
+    const int cb = r % CB, tap = r / CB;
+    const float v = W[pd.off[t] + gid];
+    Wf[pd.off[t] + ((size_t)(tap * (CB / 4) + cb / 4) * CS + cs) * 4 + (cb & 3)] = v;
+    Wd[pd.off[t] + ((size_t)(tap * (CS / 4) + cs / 4) * CB + cb) * 4 + (cs & 3)] = v;
+}
+
+// eligibility + tile choice of the spatial kernels (shared by the launchers and the *_tiles() queries)
+struct SpatialChoice { bool ok; int TH, TW, BN; };
+inline SpatialChoice choose_spatial(const UadConvDesc& d, int CA, int Nn) {
+    SpatialChoice c{false, 0, 0, 0};
+    if (!(d.KS == 5 && d.S == 2 && d.P == 1)) return c;
+    if (d.HB != 2 * d.HS || d.WB != 2 * d.WS) return c;
+    if (CA > XF_LDS_CH) return c;
+    if (Nn % 64 == 0 && CA % 32 == 0 && d.HS % 8 == 0 && d.WS % 8 == 0) { c = SpatialChoice{true, 8, 8, 64}; return c; }
+    if (Nn % 32 == 0 && CA % 16 == 0 && d.HS % 8 == 0 && d.WS % 16 == 0) { c = SpatialChoice{true, 8, 16, 32}; return c; }
+    return c;
+}
+
 // ------------------------------------------------------------------------------------------------
 // W-type: filter gradient.  GEMM M = (tap, cb) flattened, N = cs, K = positions (split over blockIdx.z).
 // ------------------------------------------------------------------------------------------------
@@ -592,34 +962,73 @@ void launch_gemm(const ConvGemmArgs& a, int classes, hipStream_t st) {
 
 }  // namespace
 
+bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
+    return f_type ? choose_spatial(d, d.CB, d.CS).ok : choose_spatial(d, d.CS, d.CB).ok;
+}
+
 int uad_conv_f_tiles(const UadConvDesc& d) {
+    const SpatialChoice sc = choose_spatial(d, d.CB, d.CS);
+    if (sc.ok) return d.N * (d.HS / sc.TH) * (d.WS / sc.TW);
     const long M = (long)d.N * d.HS * d.WS;
     const TileChoice t = choose_tile(M, d.CS, d.CB, 1);
     return (int)((M + t.BM - 1) / t.BM);
 }
 
 int uad_conv_d_tiles(const UadConvDesc& d) {
+    const SpatialChoice sc = choose_spatial(d, d.CS, d.CB);
+    if (sc.ok) return d.N * (d.HS / sc.TH) * (d.WS / sc.TW);
     const long M = (long)d.N * d.HS * d.WS;
     const int classes = d.S * d.S;
     const TileChoice t = choose_tile(M, d.CB, d.CS, classes);
     return (int)((M + t.BM - 1) / t.BM) * classes;
 }
 
+void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d, const long long* offs, const int* cbs,
+                             const int* css, const int* taps, int n, hipStream_t st) {
+    PackDesc pd;
+    long long total = 0;
+    pd.n = n;
+    for (int i = 0; i < n; ++i) {
+        pd.off[i] = offs[i]; pd.cb[i] = cbs[i]; pd.cs[i] = css[i]; pd.count[i] = taps[i] * cbs[i] * css[i];
+        total += pd.count[i];
+    }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, wpack_f, wpack_d, pd);
+}
+
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W, float* small_out,
-                       UadEpilogue ep, hipStream_t st) {
+                       UadEpilogue ep, hipStream_t st, const float* Wpacked) {
     ConvGemmArgs a;
+    a.Wp = Wpacked;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CB; a.Nn = d.CS;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
+    static const int dbg = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0;
+    a.dbg = dbg;
+    const SpatialChoice sc = choose_spatial(d, a.CA, a.Nn);
+    if (sc.ok && Wpacked) {
+        dim3 grid((d.HS / sc.TH) * (d.WS / sc.TW), d.N, a.Nn / sc.BN);
+        if (sc.BN == 64) hipLaunchKernelGGL((conv5_f_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv5_f_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
+        return;
+    }
     launch_gemm<KIND_F>(a, 1, st);
 }
 
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W, float* big_out,
-                       UadEpilogue ep, hipStream_t st) {
+                       UadEpilogue ep, hipStream_t st, const float* Wpacked) {
     ConvGemmArgs a;
+    a.Wp = Wpacked;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CS; a.Nn = d.CB;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
+    a.dbg = 0;
+    const SpatialChoice sc = choose_spatial(d, a.CA, a.Nn);
+    if (sc.ok && Wpacked) {
+        dim3 grid((d.HS / sc.TH) * (d.WS / sc.TW), d.N, a.Nn / sc.BN);
+        if (sc.BN == 64) hipLaunchKernelGGL((conv5_d_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv5_d_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
+        return;
+    }
     launch_gemm<KIND_D>(a, d.S * d.S, st);
 }
 

@@ -46,11 +46,17 @@ struct UadEpilogue {
 };
 
 // F-type: small_out[n,i,j,cs] = sum_{tap,cb} xf(big_in)[n,S*i-P+ky,S*j-P+kx,cb] * W[tap][cb][cs]
+// Wpacked (optional): this tensor inside the F-pack buffer written by uad_launch_pack_weights; enables the k5 s2
+// spatial kernel.  The tile count of EPI_BWD_ACT (uad_conv_*_tiles) assumes Wpacked is given whenever it can be used.
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W,
-                       float* small_out, UadEpilogue ep, hipStream_t st);
+                       float* small_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr);
 // D-type: big_out[n,S*i-P+ky,S*j-P+kx,cb] += xf(small_in)[n,i,j,cs] * W[tap][cb][cs]
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W,
-                       float* big_out, UadEpilogue ep, hipStream_t st);
+                       float* big_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr);
+// re-layout of n (<= 8) weight tensors W[tap][cb][cs] living at params+offs[i] into the F-pack / D-pack buffers
+void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d, const long long* offs, const int* cbs,
+                             const int* css, const int* taps, int n, hipStream_t st);
+bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type);
 // number of colpart tiles the above launches write for EPI_BWD_ACT
 int uad_conv_f_tiles(const UadConvDesc& d);
 int uad_conv_d_tiles(const UadConvDesc& d);

@@ -62,6 +62,8 @@ struct uad_model {
     long long nparams;
     long long seg_off[3], seg_cnt[3];
     float *params, *grads, *adam_m, *adam_v;
+    float *wpack_f, *wpack_d;          // k-quad-interleaved copies of the 5x5 kernels (refreshed once per forward)
+    bool packed_valid;
     long long step;
     // layers
     std::vector<ConvLayer> enc, dec;
@@ -251,6 +253,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
 #define ALLOC(ptr, n) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n))
     ALLOC(m->params, (size_t)m->nparams); ALLOC(m->grads, (size_t)m->nparams);
     ALLOC(m->adam_m, (size_t)m->nparams); ALLOC(m->adam_v, (size_t)m->nparams);
+    ALLOC(m->wpack_f, (size_t)m->nparams); ALLOC(m->wpack_d, (size_t)m->nparams);
+    m->packed_valid = false;
     size_t maxact = 0;
     for (auto& L : m->enc) { size_t n = NB * L.d.HS * L.d.WS * L.d.CS; ALLOC(L.c, n); if (n > maxact) maxact = n; }
     for (auto& L : m->dec) { size_t n = NB * L.d.HB * L.d.WB * L.d.CB; ALLOC(L.c, n); if (n > maxact) maxact = n; }
@@ -328,6 +332,7 @@ int uad_set_buffer(uad_model_t* m, int which, const float* host, long long count
     float* p = uad_buffer(m, which);
     if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "set_buffer: bad arguments (count=%lld, expected %lld)", count, m ? m->nparams : -1);
     HIP_TRY(hipMemcpy(p, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+    if (which == UAD_BUF_PARAMS) m->packed_valid = false;
     return UAD_OK;
 }
 int uad_get_buffer(uad_model_t* m, int which, float* host, long long count) {
@@ -359,6 +364,16 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     const bool vae = m->cfg.arch == UAD_ARCH_VAE;
     const int ir = m->cfg.inter_res;
 
+    // refresh the packed 5x5 kernels if the parameters changed since the last pack
+    if (!m->packed_valid) {
+        PROF("pack.weights");
+        long long offs[8]; int cbs[8], css[8], taps[8]; int np = 0;
+        auto add = [&](const ConvLayer& L) { if (np < 8 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
+        for (size_t i = 1; i < m->enc.size(); ++i) add(m->enc[i]);
+        for (auto& L : m->dec) add(L);
+        if (np > 0) uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
+        m->packed_valid = true;
+    }
     // encoder
     static const char* kEncF[] = {"enc0.fwd", "enc1.fwd", "enc2.fwd", "enc3.fwd", "enc4.fwd", "enc5.fwd", "enc6.fwd", "enc7.fwd"};
     static const char* kDecF[] = {"dec0.fwd", "dec1.fwd", "dec2.fwd", "dec3.fwd", "dec4.fwd", "dec5.fwd", "dec6.fwd", "dec7.fwd"};
@@ -371,7 +386,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         PROF(kEncF[i & 7]);
         UadConvDesc d = m->enc[i].d; d.N = n;
         uad_launch_conv_f(d, m->enc[i - 1].c, bn_xform(m, m->enc[i - 1].gamma, m->enc[i - 1].beta, kLrelu),
-                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st);
+                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, m->wpack_f + m->enc[i].w);
     }
     const ConvLayer& EL = m->enc.back();
     // bottleneck
@@ -400,7 +415,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         const float* in = (i == 0) ? m->cb : m->dec[i - 1].c;
         UadXform xf = (i == 0) ? bn_xform(m, m->dbn_g, m->dbn_b, 0.0f)
                                : bn_xform(m, m->dec[i - 1].gamma, m->dec[i - 1].beta, kLrelu);
-        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), m->dec[i].c, epi_bias(P(m, m->dec[i].b)), st);
+        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), m->dec[i].c, epi_bias(P(m, m->dec[i].b)), st, m->wpack_d + m->dec[i].w);
     }
     // final 1x1 conv + L1 loss (+ start of the backward)
     const ConvLayer& DL = m->dec.back();
@@ -464,7 +479,7 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         // filter gradient: big = d c (raw), small = layer input (activation on load)
         { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wpartial, st); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
-        { PROF(kDecD[i & 7]); uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st); }
+        { PROF(kDecD[i & 7]); uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st, m->wpack_f + m->dec[i].w); }
         { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_f_tiles(d), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), st); }
         float* tsw = g; g = gn; gn = tsw;
     }
@@ -538,7 +553,7 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
         static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
         static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
         { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wpartial, st); }
-        { PROF(kEncD[i & 7]); uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st); }
+        { PROF(kEncD[i & 7]); uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st, m->wpack_d + m->enc[i].w); }
         { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), st); }
         float* tsw = g; g = gn; gn = tsw;
@@ -571,6 +586,7 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
     const double t = (double)m->step;
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
     hipStream_t st = (hipStream_t)stream;
+    m->packed_valid = false;
     { PROF("adam"); uad_launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr_t, beta1, beta2, eps, grad_scale, st); }
     HIP_TRY(hipGetLastError());
     return UAD_OK;
@@ -635,19 +651,38 @@ static int check_gemm_desc(const uad_conv_desc_t* d, bool f_type) {
     return UAD_OK;
 }
 
+// op-level helpers: the spatial kernels need the packed weight copy; build it on the fly (synchronous, tests only)
+static int pack_for_op(const UadConvDesc& d, const float* W, bool f_type, float** pf, float** pd, hipStream_t st) {
+    *pf = *pd = nullptr;
+    if (!uad_conv_spatial_ok(d, f_type)) return UAD_OK;
+    const size_t n = (size_t)d.KS * d.KS * d.CB * d.CS;
+    HIP_TRY(hipMalloc((void**)pf, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)pd, n * sizeof(float)));
+    long long off = 0; int cb = d.CB, cs = d.CS, taps = d.KS * d.KS;
+    uad_launch_pack_weights(W, *pf, *pd, &off, &cb, &cs, &taps, 1, st);
+    return UAD_OK;
+}
+static int finish_op(float* pf, float* pd, hipStream_t st) {
+    if (pf || pd) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(pf); (void)hipFree(pd); }
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
 int uad_op_conv_f(const uad_conv_desc_t* d, const float* big_in, const uad_xform_t* xf, const float* W, const float* bias,
                   const float* mul, const float* add, float* small_out, void* stream) {
     if (int rc = check_gemm_desc(d, true)) return rc;
-    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
-    return UAD_OK;
+    float *pf = nullptr, *pd = nullptr;
+    if (int rc = pack_for_op(to_desc(d), W, true, &pf, &pd, (hipStream_t)stream)) return rc;
+    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream, pf);
+    return finish_op(pf, pd, (hipStream_t)stream);
 }
 int uad_op_conv_d(const uad_conv_desc_t* d, const float* small_in, const uad_xform_t* xf, const float* W, const float* bias,
                   const float* mul, const float* add, float* big_out, void* stream) {
     if (int rc = check_gemm_desc(d, false)) return rc;
-    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
-    return UAD_OK;
+    float *pf = nullptr, *pd = nullptr;
+    if (int rc = pack_for_op(to_desc(d), W, false, &pf, &pd, (hipStream_t)stream)) return rc;
+    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream, pd);
+    return finish_op(pf, pd, (hipStream_t)stream);
 }
 
 static int bwdact_common(bool f_type, const uad_conv_desc_t* dd, const float* in, const float* W, const float* cprev,
@@ -665,12 +700,14 @@ static int bwdact_common(bool f_type, const uad_conv_desc_t* dd, const float* in
     e.kind = UAD_EPI_BWD_ACT; e.cprev = cprev; e.escale = act->scale; e.eshift = act->shift; e.ealpha = act->alpha;
     e.emult = 1.f; e.colpart = colpart;
     hipStream_t st = (hipStream_t)stream;
-    if (f_type) uad_launch_conv_f(d, in, no_xform(), W, out, e, st);
-    else uad_launch_conv_d(d, in, no_xform(), W, out, e, st);
+    float *pf = nullptr, *pd = nullptr;
+    if (int rc = pack_for_op(d, W, f_type, &pf, &pd, st)) return rc;
+    if (f_type) uad_launch_conv_f(d, in, no_xform(), W, out, e, st, pf);
+    else uad_launch_conv_d(d, in, no_xform(), W, out, e, st, pd);
     // rstd = 1, gamma unused for dbias=null: dbeta -> s1, dgamma -> s2
     uad_launch_bn_grad_finalize(colpart, T, C, act->scale, 1.0f, s2, s1, nullptr, st);
     HIP_TRY(hipStreamSynchronize(st));
-    hipFree(colpart); hipFree(tmp);
+    hipFree(colpart); hipFree(tmp); hipFree(pf); hipFree(pd);
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
