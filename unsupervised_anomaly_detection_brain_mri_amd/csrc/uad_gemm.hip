@@ -922,6 +922,150 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_w_kernel(const ConvWArgs 
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k5 s2 SAME filter gradient, spatial form: one workgroup owns a 32(cb) x 32(cs) channel block and walks a list of
+// 8x8 tiles of the small image.  Per tile the big halo tile [19x19][32] and the small tile [64][32] are staged in LDS
+// once; wave w accumulates taps {w, w+4, ...} (7/6/6/6 independent 32x32 accumulators), contraction = the 64
+// positions of the tile (A[m=cb][k=pos], B[k=pos][n=cs]: both read from LDS with conflict-free ds_read_b32).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv5_w_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
+    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256;
+    __shared__ __attribute__((aligned(16))) float sBig[IH * IW * CK];
+    __shared__ __attribute__((aligned(16))) float sSmall[TH * TW * CK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const UadConvDesc& d = a.d;
+    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32;
+    const int tilesx = d.WS / TW, tilesy = d.HS / TH;
+    const int t_begin = blockIdx.z * tiles_per_split;
+    const int t_end = min(t_begin + tiles_per_split, total_tiles);
+
+    // this thread's channel quad is the same for every float4 it stages (NT % CQ == 0)
+    const int cq = tid % CQ;
+    const bool xfa = a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
+    float4 scA = make_float4(1, 1, 1, 1), shA = make_float4(0, 0, 0, 0), scB = scA, shB = shA;
+    if (xfa) {
+        scA = *reinterpret_cast<const float4*>(a.xfb.scale + cb0 + cq * 4);
+        shA = *reinterpret_cast<const float4*>(a.xfb.shift + cb0 + cq * 4);
+        scA.x *= a.xfb.mult; scA.y *= a.xfb.mult; scA.z *= a.xfb.mult; scA.w *= a.xfb.mult;
+    }
+    if (xfs) {
+        scB = *reinterpret_cast<const float4*>(a.xfs.scale + cs0 + cq * 4);
+        shB = *reinterpret_cast<const float4*>(a.xfs.shift + cs0 + cq * 4);
+        scB.x *= a.xfs.mult; scB.y *= a.xfs.mult; scB.z *= a.xfs.mult; scB.w *= a.xfs.mult;
+    }
+
+    // taps of this wave and their LDS offsets
+    constexpr int MAXT = 7;
+    int aaddr[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+        const int tap = wave + 4 * j;
+        const int ky = tap / 5, kx = tap % 5;
+        aaddr[j] = ((ky * IW + kx) + 2 * lh) * CK + l31;   // + lane part: pixel x offset 2*lh, channel l31
+    }
+    const int baddr = lh * CK + l31;
+
+    v16f acc[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int tx0 = (t % tilesx) * TW;
+        const int ty0 = ((t / tilesx) % tilesy) * TH;
+        const int n = t / (tilesx * tilesy);
+        const float* bigb = a.big + (size_t)n * d.HB * d.WB * d.CB + cb0;
+        const float* smb = a.small_ + ((size_t)(n * d.HS + ty0) * d.WS + tx0) * d.CS + cs0;
+        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
+        __syncthreads();   // previous tile fully consumed
+        {
+            constexpr int TOT = IH * IW * CQ;   // 2888 float4
+            constexpr int BATCH = 6;
+            for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
+                float4 v[BATCH];
+                bool ok[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int f = f0 + u * NT;
+                    const int pix = f / CQ;
+                    const int iy = pix / IW, ix = pix % IW;
+                    const int gy = gy0 + iy, gx = gx0 + ix;
+                    ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
+                    const int gp = ok[u] ? (gy * d.WB + gx) : 0;
+                    v[u] = *reinterpret_cast<const float4*>(bigb + (size_t)gp * d.CB + cq * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int f = f0 + u * NT;
+                    if (f >= TOT) continue;
+                    float4 tv = v[u];
+                    if (xfa) tv = xform4(tv, scA, shA, a.xfb.alpha);
+                    *reinterpret_cast<float4*>(sBig + (f / CQ) * CK + cq * 4) = keep4(ok[u], tv);
+                }
+            }
+            // small tile: 64 positions x 8 quads = 512 float4 -> 2 per thread
+            float4 sv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = tid + u * NT;
+                const int pos = f / CQ;
+                sv[u] = *reinterpret_cast<const float4*>(smb + (size_t)((pos / TW) * d.WS + (pos % TW)) * d.CS + cq * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = tid + u * NT;
+                float4 tv = sv[u];
+                if (xfs) tv = xform4(tv, scB, shB, a.xfs.alpha);
+                *reinterpret_cast<float4*>(sSmall + (f / CQ) * CK + cq * 4) = tv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < TH * TW / 2; ++st) {
+            // positions 2*st + lh: row st/4, column 2*(st%4) + lh
+            const int cst = ((2 * (st / 4)) * IW + 4 * (st % 4)) * CK;
+            const float bv = sSmall[baddr + (2 * st) * CK];
+#pragma unroll
+            for (int j = 0; j < MAXT; ++j) {
+                if (j == MAXT - 1 && wave != 0) break;   // only wave 0 owns a 7th tap (tap 24)
+                const float av = sBig[aaddr[j] + cst];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+    }
+
+    float* out = a.partial + (size_t)blockIdx.z * a.Mtot * d.CS;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+        const int tap = wave + 4 * j;
+        if (tap >= 25) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[((size_t)tap * d.CB + cb) * d.CS + cs0 + l31] = acc[j][r];
+        }
+    }
+}
+
+struct W5Choice { bool ok; int splits, tiles_per_split, total_tiles; };
+inline W5Choice choose_w5(const UadConvDesc& d) {
+    W5Choice c{false, 0, 0, 0};
+    if (!(d.KS == 5 && d.S == 2 && d.P == 1 && d.HB == 2 * d.HS && d.WB == 2 * d.WS)) return c;
+    if (d.CB % 32 || d.CS % 32 || d.HS % 8 || d.WS % 8) return c;
+    c.total_tiles = d.N * (d.HS / 8) * (d.WS / 8);
+    const int blocks = (d.CB / 32) * (d.CS / 32);
+    int splits = (512 + blocks - 1) / blocks;
+    if (splits > c.total_tiles) splits = c.total_tiles;
+    if (splits < 1) splits = 1;
+    c.tiles_per_split = (c.total_tiles + splits - 1) / splits;
+    c.splits = (c.total_tiles + c.tiles_per_split - 1) / c.tiles_per_split;
+    c.ok = true;
+    return c;
+}
+
 inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;
@@ -1055,12 +1199,25 @@ inline WChoice choose_w(const UadConvDesc& d) {
 }  // namespace
 
 size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
+    const W5Choice w5 = choose_w5(d);
+    if (w5.ok) return (size_t)w5.splits * d.KS * d.KS * d.CB * d.CS;
     const WChoice c = choose_w(d);
     return (size_t)c.splits * d.KS * d.KS * d.CB * d.CS;
 }
 
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
                        float* dW, float* partial, hipStream_t st) {
+    const W5Choice w5 = choose_w5(d);
+    if (w5.ok) {
+        ConvWArgs a;
+        a.big = big; a.small_ = small; a.partial = (w5.splits == 1) ? dW : partial;
+        a.xfb = xfb; a.xfs = xfs; a.d = d;
+        a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = 0; a.lws = a.lhs = -1;
+        dim3 grid(d.CB / 32, d.CS / 32, w5.splits);
+        hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
+        if (w5.splits > 1) uad_launch_reduce_partials(partial, w5.splits, a.Mtot * d.CS, 1.0f, dW, st);
+        return;
+    }
     const WChoice c = choose_w(d);
     ConvWArgs a;
     a.big = big; a.small_ = small; a.partial = (c.splits == 1) ? dW : partial;
