@@ -36,6 +36,8 @@ struct ConvGemmArgs {
     int Nn;        // output channels
     int lws, lhs;  // log2(WS), log2(HS) or -1 when not a power of two
     int dbg;       // UAD_DBG ablation bits (timing experiments only; results are wrong when set)
+    int nsplit;    // split-K factor (>1: raw partial tiles go to Out + split*out_elems, see splitk_epilogue_kernel)
+    long long out_elems;
 };
 
 __device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int lws, int& n, int& i, int& j) {
@@ -92,8 +94,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
 
     // ---- tap set: all KS*KS taps (F) or the taps of this output-parity class (D) ----
     int py = 0, px = 0, ky0 = 0, kx0 = 0, nty = KS, ntx = KS, dy0 = 0, dx0 = 0;
+    const int nsplit = a.nsplit;
+    const int split = (KIND == KIND_D) ? (int)(blockIdx.z % nsplit) : (int)blockIdx.z;
     if (KIND == KIND_D) {
-        const int cz = blockIdx.z;
+        const int cz = blockIdx.z / nsplit;
         py = (S - 1) - cz / S;
         px = (S - 1) - cz % S;
         ky0 = (py + P) % S;
@@ -106,6 +110,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
     const int ntaps = nty * ntx;
     const int ncc = a.CA / BK;
     const int nk = ntaps * ncc;
+    // split-K: this workgroup contracts K-steps [ks0, ks1)
+    const int kper = (nk + nsplit - 1) / nsplit;
+    const int ks0 = split * kper;
+    const int ks1 = min(nk, ks0 + kper);
 
     // ---- activation-on-load tables -> LDS (once) ----
     const bool xf = a.xf.scale != nullptr;
@@ -226,8 +234,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
     const int l31 = lane & 31, lh = lane >> 5;
 
     __syncthreads();   // s_xf visible
-    if (nk > 0) {
-        load_tiles(0, 0);
+    int tap = ks0 / ncc, cc = ks0 - tap * ncc;
+    if (ks0 < ks1) {
+        load_tiles(tap, cc * BK);
         store_tiles(0);
     }
     __syncthreads();
@@ -252,12 +261,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
         }
     };
 
-    int tap = 0, cc = 0;
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int buf = (ks - ks0) & 1;
         int ntap = tap, ncc_ = cc + 1;
         if (ncc_ == ncc) { ncc_ = 0; ntap = tap + 1; }
-        const bool more = (ks + 1 < nk);
+        const bool more = (ks + 1 < ks1);
         const float* sA = smem + buf * STAGE;
         const float* sB = sA + A_EL;
         load_frags(0, sA, sB, 0);
@@ -284,6 +292,32 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
     }
 
     // ---------------------------------------------------------------- epilogue
+    if (nsplit > 1) {
+        // raw partial tile into this split's slab (output layout); bias / activation-backward / column sums are
+        // applied by splitk_epilogue_kernel after the slabs are summed in a fixed order
+        float* slab = a.Out + (size_t)split * a.out_elems;
+#pragma unroll
+        for (int im = 0; im < FM; ++im)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + row;
+                if (m >= a.M) continue;
+                size_t ob;
+                if (KIND == KIND_F) ob = (size_t)m * a.Nn;
+                else {
+                    int n, i, j;
+                    decode_pos(m, d.HS, d.WS, a.lhs, a.lws, n, i, j);
+                    ob = ((size_t)(n * d.HB + S * i + py) * d.WB + (S * j + px)) * a.Nn;
+                }
+#pragma unroll
+                for (int jn = 0; jn < FN; ++jn) {
+                    const int col = n0 + wn * WTN + jn * 32 + l31;
+                    if (col < a.Nn) slab[ob + col] = acc[im][jn][r];
+                }
+            }
+        return;
+    }
     const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
     // per-lane column constants
     bool colok[FN];
@@ -727,6 +761,71 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmA
     }
 }
 
+// Sums S split-K slabs (fixed order -> deterministic) and applies the epilogue.  Block = 64 rows x 64 columns:
+// 16 column-quad lanes x 16 row lanes, 4 rows per thread.
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __restrict__ slabs, int S, long long out_elems,
+                                                              int rows, int Nn, UadEpilogue ep, float* __restrict__ out) {
+    __shared__ float red[2][16][64];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.y * 64 + cq * 4;
+    const bool colok = col < Nn;
+    const bool bwd = ep.kind == UAD_EPI_BWD_ACT;
+    float4 ca = make_float4(0, 0, 0, 0), cb = ca;
+    if (colok) {
+        if (!bwd) { if (ep.bias) ca = *reinterpret_cast<const float4*>(ep.bias + col); }
+        else {
+            ca = *reinterpret_cast<const float4*>(ep.escale + col);
+            ca.x *= ep.emult; ca.y *= ep.emult; ca.z *= ep.emult; ca.w *= ep.emult;
+            cb = *reinterpret_cast<const float4*>(ep.eshift + col);
+        }
+    }
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = blockIdx.x * 64 + u * 16 + rl;
+        if (row >= rows || !colok) continue;
+        const size_t off = (size_t)row * Nn + col;
+        float4 v = *reinterpret_cast<const float4*>(slabs + off);
+        for (int s = 1; s < S; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(slabs + (size_t)s * out_elems + off);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (!bwd) {
+            v.x += ca.x; v.y += ca.y; v.z += ca.z; v.w += ca.w;
+            if (ep.mul) { const float4 t = *reinterpret_cast<const float4*>(ep.mul + off); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+            if (ep.add) { const float4 t = *reinterpret_cast<const float4*>(ep.add + off); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            *reinterpret_cast<float4*>(out + off) = v;
+        } else {
+            const float4 c = *reinterpret_cast<const float4*>(ep.cprev + off);
+            const float vv[4] = {v.x, v.y, v.z, v.w}, cc[4] = {c.x, c.y, c.z, c.w};
+            const float aa[4] = {ca.x, ca.y, ca.z, ca.w}, bb[4] = {cb.x, cb.y, cb.z, cb.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float bn = fmaf(aa[e], cc[e], bb[e]);
+                const float dbn = bn > 0.f ? vv[e] : vv[e] * ep.ealpha;
+                o[e] = dbn * aa[e];
+                s1[e] += dbn;
+                s2[e] = fmaf(dbn, cc[e], s2[e]);
+            }
+            *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (bwd) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[0][rl][cq * 4 + e] = s1[e]; red[1][rl][cq * 4 + e] = s2[e]; }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[which][k][c];
+            const int gc = blockIdx.y * 64 + c;
+            if (gc < Nn) ep.colpart[((size_t)blockIdx.x * 2 + which) * Nn + gc] = t;
+        }
+    }
+}
+
 // Weight re-layout for the spatial kernels.  One thread per source element W[tap][cb][cs] of any of up to 8 tensors:
 //   F-pack: Wp[tap][cb/4][cs][cb%4]     D-pack: Wq[tap][cs/4][cb][cs%4]      (both at the tensor's own flat offset)
 struct PackDesc { long long off[8]; int cb[8], cs[8], count[8]; int n; };
@@ -1084,10 +1183,22 @@ inline TileChoice choose_tile(long M, int Nn, int CA, int classes) {
     return t;
 }
 
+// split-K factor of the generic kernel: only when the plain grid cannot fill the chip and K is long enough
+inline int choose_nsplit(long M, int Nn, int CA, int classes, int min_taps) {
+    const TileChoice t = choose_tile(M, Nn, CA, classes);
+    const long wgs = ((M + t.BM - 1) / t.BM) * ((Nn + t.BN - 1) / t.BN) * classes;
+    const int nk_min = min_taps * (CA / t.BK);
+    if (wgs >= 256 || nk_min < 8 || (Nn % 4)) return 1;
+    long s = (512 + wgs - 1) / wgs;
+    if (s > nk_min / 4) s = nk_min / 4;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : (int)s;
+}
+
 template <int KIND>
 void launch_gemm(const ConvGemmArgs& a, int classes, hipStream_t st) {
     const TileChoice t = choose_tile(a.M, a.Nn, a.CA, classes);
-    dim3 grid((a.M + t.BM - 1) / t.BM, (a.Nn + t.BN - 1) / t.BN, classes);
+    dim3 grid((a.M + t.BM - 1) / t.BM, (a.Nn + t.BN - 1) / t.BN, classes * a.nsplit);
 #define UAD_GEMM_CASE(bm, bn, bk, wgm, wgn)                                                              \
     if (t.BM == bm && t.BN == bn && t.BK == bk) {                                                        \
         hipLaunchKernelGGL((conv_gemm_kernel<bm, bn, bk, wgm, wgn, KIND>), grid, dim3(64 * wgm * wgn), 0, st, a); \
@@ -1106,26 +1217,50 @@ void launch_gemm(const ConvGemmArgs& a, int classes, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+enum { PATH_GENERIC = 0, PATH_SPATIAL = 1, PATH_SPLITK = 2 };
+struct GemmPlan { int path; SpatialChoice sc; int nsplit; int tiles; size_t ws_floats; long long out_elems; int out_rows; };
+
+// One decision procedure for launchers and for the colpart-tile / workspace queries.
+inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, size_t ws_cap) {
+    GemmPlan p;
+    const int CA = f_type ? d.CB : d.CS, Nn = f_type ? d.CS : d.CB;
+    const long M = (long)d.N * d.HS * d.WS;
+    const int classes = f_type ? 1 : d.S * d.S;
+    int min_taps = d.KS * d.KS;
+    if (!f_type && d.S > 1) { const int t = d.KS / d.S; min_taps = t * t; }
+    p.out_rows = f_type ? (int)M : d.N * d.HB * d.WB;
+    p.out_elems = (long long)p.out_rows * Nn;
+    p.sc = have_pack ? choose_spatial(d, CA, Nn) : SpatialChoice{false, 0, 0, 0};
+    p.nsplit = 1; p.ws_floats = 0;
+    const TileChoice t = choose_tile(M, Nn, CA, classes);
+    int ns = choose_nsplit(M, Nn, CA, classes, min_taps);
+    if (ns > 1 && (size_t)ns * p.out_elems > ws_cap) ns = 1;
+    if (p.sc.ok) {
+        const long wgs = (long)d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW) * (Nn / p.sc.BN);
+        if (wgs >= 512) {   // the spatial kernels need >= 2 workgroups per CU to overlap staging/epilogue with MFMA work
+            p.path = PATH_SPATIAL;
+            p.tiles = d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW);
+            return p;
+        }
+    }
+    if (ns > 1) {
+        p.path = PATH_SPLITK; p.nsplit = ns; p.ws_floats = (size_t)ns * p.out_elems;
+        p.tiles = (p.out_rows + 63) / 64;
+        return p;
+    }
+    p.path = PATH_GENERIC;
+    p.tiles = (int)((M + t.BM - 1) / t.BM) * classes;
+    return p;
+}
+}  // namespace
+
 bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
     return f_type ? choose_spatial(d, d.CB, d.CS).ok : choose_spatial(d, d.CS, d.CB).ok;
 }
-
-int uad_conv_f_tiles(const UadConvDesc& d) {
-    const SpatialChoice sc = choose_spatial(d, d.CB, d.CS);
-    if (sc.ok) return d.N * (d.HS / sc.TH) * (d.WS / sc.TW);
-    const long M = (long)d.N * d.HS * d.WS;
-    const TileChoice t = choose_tile(M, d.CS, d.CB, 1);
-    return (int)((M + t.BM - 1) / t.BM);
-}
-
-int uad_conv_d_tiles(const UadConvDesc& d) {
-    const SpatialChoice sc = choose_spatial(d, d.CS, d.CB);
-    if (sc.ok) return d.N * (d.HS / sc.TH) * (d.WS / sc.TW);
-    const long M = (long)d.N * d.HS * d.WS;
-    const int classes = d.S * d.S;
-    const TileChoice t = choose_tile(M, d.CB, d.CS, classes);
-    return (int)((M + t.BM - 1) / t.BM) * classes;
-}
+int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, true, have_pack, ws_floats).tiles; }
+int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, false, have_pack, ws_floats).tiles; }
+size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack) { return plan_gemm(d, f_type, have_pack, (size_t)1 << 40).ws_floats; }
 
 void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d, const long long* offs, const int* cbs,
                              const int* css, const int* taps, int n, hipStream_t st) {
@@ -1139,8 +1274,36 @@ void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, wpack_f, wpack_d, pd);
 }
 
+namespace {
+void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStream_t st) {
+    const UadConvDesc& d = a.d;
+    a.nsplit = 1; a.out_elems = p.out_elems;
+    if (p.path == PATH_SPATIAL) {
+        dim3 grid((d.HS / p.sc.TH) * (d.WS / p.sc.TW), d.N, a.Nn / p.sc.BN);
+        if (f_type) {
+            if (p.sc.BN == 64) hipLaunchKernelGGL((conv5_f_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv5_f_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
+        } else {
+            if (p.sc.BN == 64) hipLaunchKernelGGL((conv5_d_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv5_d_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
+        }
+        return;
+    }
+    const int classes = f_type ? 1 : d.S * d.S;
+    if (p.path == PATH_SPLITK) {
+        float* out = a.Out;
+        a.Out = ws; a.nsplit = p.nsplit;
+        if (f_type) launch_gemm<KIND_F>(a, classes, st); else launch_gemm<KIND_D>(a, classes, st);
+        dim3 grid((p.out_rows + 63) / 64, (a.Nn + 63) / 64);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, grid, dim3(256), 0, st, ws, p.nsplit, p.out_elems, p.out_rows, a.Nn, a.ep, out);
+        return;
+    }
+    if (f_type) launch_gemm<KIND_F>(a, classes, st); else launch_gemm<KIND_D>(a, classes, st);
+}
+}  // namespace
+
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W, float* small_out,
-                       UadEpilogue ep, hipStream_t st, const float* Wpacked) {
+                       UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws) {
     ConvGemmArgs a;
     a.Wp = Wpacked;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
@@ -1148,32 +1311,20 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
     static const int dbg = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0;
     a.dbg = dbg;
-    const SpatialChoice sc = choose_spatial(d, a.CA, a.Nn);
-    if (sc.ok && Wpacked) {
-        dim3 grid((d.HS / sc.TH) * (d.WS / sc.TW), d.N, a.Nn / sc.BN);
-        if (sc.BN == 64) hipLaunchKernelGGL((conv5_f_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv5_f_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
-        return;
-    }
-    launch_gemm<KIND_F>(a, 1, st);
+    const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr, ws.ptr ? ws.floats : 0);
+    run_plan(p, a, true, ws.ptr, st);
 }
 
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W, float* big_out,
-                       UadEpilogue ep, hipStream_t st, const float* Wpacked) {
+                       UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws) {
     ConvGemmArgs a;
     a.Wp = Wpacked;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CS; a.Nn = d.CB;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
     a.dbg = 0;
-    const SpatialChoice sc = choose_spatial(d, a.CA, a.Nn);
-    if (sc.ok && Wpacked) {
-        dim3 grid((d.HS / sc.TH) * (d.WS / sc.TW), d.N, a.Nn / sc.BN);
-        if (sc.BN == 64) hipLaunchKernelGGL((conv5_d_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv5_d_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
-        return;
-    }
-    launch_gemm<KIND_D>(a, d.S * d.S, st);
+    const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr, ws.ptr ? ws.floats : 0);
+    run_plan(p, a, false, ws.ptr, st);
 }
 
 // ---- W-type host side -------------------------------------------------------------------------

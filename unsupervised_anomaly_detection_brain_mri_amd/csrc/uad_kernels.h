@@ -30,6 +30,9 @@ struct UadXform {
 
 enum { UAD_EPI_BIAS = 0, UAD_EPI_BWD_ACT = 1 };
 
+// optional split-K workspace of the generic kernels (slabs of raw partial outputs)
+struct UadGemmWs { float* ptr; size_t floats; };
+
 struct UadEpilogue {
     int kind;             // UAD_EPI_*
     const float* bias;    // EPI_BIAS: per output channel, may be null
@@ -49,17 +52,22 @@ struct UadEpilogue {
 // Wpacked (optional): this tensor inside the F-pack buffer written by uad_launch_pack_weights; enables the k5 s2
 // spatial kernel.  The tile count of EPI_BWD_ACT (uad_conv_*_tiles) assumes Wpacked is given whenever it can be used.
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W,
-                       float* small_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr);
+                       float* small_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr,
+                       UadGemmWs ws = UadGemmWs{nullptr, 0});
 // D-type: big_out[n,S*i-P+ky,S*j-P+kx,cb] += xf(small_in)[n,i,j,cs] * W[tap][cb][cs]
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W,
-                       float* big_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr);
+                       float* big_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr,
+                       UadGemmWs ws = UadGemmWs{nullptr, 0});
 // re-layout of n (<= 8) weight tensors W[tap][cb][cs] living at params+offs[i] into the F-pack / D-pack buffers
 void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d, const long long* offs, const int* cbs,
                              const int* css, const int* taps, int n, hipStream_t st);
 bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type);
 // number of colpart tiles the above launches write for EPI_BWD_ACT
-int uad_conv_f_tiles(const UadConvDesc& d);
-int uad_conv_d_tiles(const UadConvDesc& d);
+// (the same have_pack / workspace capacity as the launch must be passed: they select the kernel path)
+int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0);
+int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0);
+// workspace floats the split-K path would like for this op (0 = it would not split)
+size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack);
 // W-type: dW[tap][cb][cs] = sum_{n,i,j} xfb(big)[..tap..,cb] * xfs(small)[n,i,j,cs]
 // `partial` must hold uad_conv_w_partial_floats(d) floats.
 size_t uad_conv_w_partial_floats(const UadConvDesc& d);

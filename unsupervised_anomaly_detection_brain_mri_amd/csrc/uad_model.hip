@@ -63,6 +63,7 @@ struct uad_model {
     long long seg_off[3], seg_cnt[3];
     float *params, *grads, *adam_m, *adam_v;
     float *wpack_f, *wpack_d;          // k-quad-interleaved copies of the 5x5 kernels (refreshed once per forward)
+    UadGemmWs ws;                      // split-K slabs for the GEMMs that cannot fill the chip on their own
     bool packed_valid;
     long long step;
     // layers
@@ -280,6 +281,18 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     wp_need(dense_desc(1, m->flat, cfg->zdim)); wp_need(dense_desc(1, cfg->zdim, m->flat));
     { UadConvDesc d0 = m->enc[0].d; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
     m->wpartial_cap = wp; ALLOC(m->wpartial, wp);
+    {
+        size_t need = (size_t)4 << 20;
+        auto want = [&](UadConvDesc d, bool f, bool pack) { d.N = (int)NB; size_t v = uad_conv_ws_floats(d, f, pack); if (v > need) need = v; };
+        for (size_t i = 1; i < m->enc.size(); ++i) { want(m->enc[i].d, true, true); want(m->enc[i].d, false, true); }
+        for (auto& L : m->dec) { want(L.d, true, true); want(L.d, false, true); }
+        want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), true, false); want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), false, false);
+        want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), true, false); want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), false, false);
+        want(dense_desc(1, m->flat, cfg->zdim), true, false); want(dense_desc(1, m->flat, cfg->zdim), false, false);
+        want(dense_desc(1, cfg->zdim, m->flat), true, false); want(dense_desc(1, cfg->zdim, m->flat), false, false);
+        m->ws.floats = need; m->ws.ptr = nullptr;
+        ALLOC(m->ws.ptr, need);
+    }
     ALLOC(m->colscratch, 64 * 1024);
     const int bps = uad_final_blocks_per_sample(H, Wd);
     ALLOC(m->red_partial, NB * bps * (3 * cin + 1)); ALLOC(m->rec_partial, NB * bps);
@@ -386,27 +399,27 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         PROF(kEncF[i & 7]);
         UadConvDesc d = m->enc[i].d; d.N = n;
         uad_launch_conv_f(d, m->enc[i - 1].c, bn_xform(m, m->enc[i - 1].gamma, m->enc[i - 1].beta, kLrelu),
-                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, m->wpack_f + m->enc[i].w);
+                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, m->wpack_f + m->enc[i].w, m->ws);
     }
     const ConvLayer& EL = m->enc.back();
     // bottleneck
     {
     PROF("bott.fwd");
     uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cenc, m->cmid), EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu),
-                      P(m, m->bw), m->t, epi_bias(P(m, m->bb)), st);
+                      P(m, m->bw), m->t, epi_bias(P(m, m->bb)), st, nullptr, m->ws);
     if (vae) {
-        uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->muw), m->mu_raw, epi_bias(P(m, m->mub)), st);
-        uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->sgw), m->ls_raw, epi_bias(P(m, m->sgb)), st);
+        uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->muw), m->mu_raw, epi_bias(P(m, m->mub)), st, nullptr, m->ws);
+        uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->sgw), m->ls_raw, epi_bias(P(m, m->sgb)), st, nullptr, m->ws);
         uad_launch_reparam_fwd(n, m->cfg.zdim, m->mu_raw, m->ls_raw, io->mask_mu, io->mask_sigma, io->eps, m->mu, m->ls,
                                m->sigma, m->z, m->kl, st);
         uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), m->z, no_xform(), P(m, m->dw), m->dvec,
-                          epi_bias(P(m, m->db), io->mask_dec), st);
+                          epi_bias(P(m, m->db), io->mask_dec), st, nullptr, m->ws);
     } else {
         uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->muw), m->z,
-                          epi_bias(P(m, m->mub), io->mask_mu), st);
-        uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), m->z, no_xform(), P(m, m->dw), m->dvec, epi_bias(P(m, m->db)), st);
+                          epi_bias(P(m, m->mub), io->mask_mu), st, nullptr, m->ws);
+        uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), m->z, no_xform(), P(m, m->dw), m->dvec, epi_bias(P(m, m->db)), st, nullptr, m->ws);
     }
-    uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cmid, m->cenc), m->dvec, no_xform(), P(m, m->rw), m->cb, epi_bias(P(m, m->rb)), st);
+    uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cmid, m->cenc), m->dvec, no_xform(), P(m, m->rw), m->cb, epi_bias(P(m, m->rb)), st, nullptr, m->ws);
     }
     // decoder
     for (size_t i = 0; i < m->dec.size(); ++i) {
@@ -415,7 +428,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         const float* in = (i == 0) ? m->cb : m->dec[i - 1].c;
         UadXform xf = (i == 0) ? bn_xform(m, m->dbn_g, m->dbn_b, 0.0f)
                                : bn_xform(m, m->dec[i - 1].gamma, m->dec[i - 1].beta, kLrelu);
-        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), m->dec[i].c, epi_bias(P(m, m->dec[i].b)), st, m->wpack_d + m->dec[i].w);
+        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), m->dec[i].c, epi_bias(P(m, m->dec[i].b)), st, m->wpack_d + m->dec[i].w, m->ws);
     }
     // final 1x1 conv + L1 loss (+ start of the backward)
     const ConvLayer& DL = m->dec.back();
@@ -479,8 +492,8 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         // filter gradient: big = d c (raw), small = layer input (activation on load)
         { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wpartial, st); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
-        { PROF(kDecD[i & 7]); uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st, m->wpack_f + m->dec[i].w); }
-        { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_f_tiles(d), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), st); }
+        { PROF(kDecD[i & 7]); uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st, m->wpack_f + m->dec[i].w, m->ws); }
+        { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), st); }
         float* tsw = g; g = gn; gn = tsw;
     }
     // g now holds d loss / d cb (pre-BN output of Bottleneck/conv2d_1); remember which buffer
@@ -505,14 +518,14 @@ static int backward_bottleneck(uad_model* m, hipStream_t st) {
     {
         UadConvDesc d = conv1x1_desc(n, ir, ir, m->cmid, m->cenc);
         uad_launch_conv_w(d, m->dvec, no_xform(), dcb, no_xform(), Gr(m, m->rw), m->wpartial, st);
-        uad_launch_conv_d(d, dcb, no_xform(), P(m, m->rw), dd, epi_bias(nullptr, vae ? io.mask_dec : nullptr), st);
+        uad_launch_conv_d(d, dcb, no_xform(), P(m, m->rw), dd, epi_bias(nullptr, vae ? io.mask_dec : nullptr), st, nullptr, m->ws);
     }
     // dense_dec
     {
         UadConvDesc d = dense_desc(n, zd, m->flat);
         uad_launch_conv_w(d, m->z, no_xform(), dd, no_xform(), Gr(m, m->dw), m->wpartial, st);
         uad_launch_colsum(dd, n, m->flat, Gr(m, m->db), m->colscratch, st);
-        uad_launch_conv_d(d, dd, no_xform(), P(m, m->dw), dz, epi_bias(nullptr, vae ? nullptr : io.mask_mu), st);
+        uad_launch_conv_d(d, dd, no_xform(), P(m, m->dw), dz, epi_bias(nullptr, vae ? nullptr : io.mask_mu), st, nullptr, m->ws);
     }
     UadConvDesc dd_in = dense_desc(n, m->flat, zd);
     if (vae) {
@@ -521,12 +534,12 @@ static int backward_bottleneck(uad_model* m, hipStream_t st) {
         uad_launch_colsum(dmu, n, zd, Gr(m, m->mub), m->colscratch, st);
         uad_launch_conv_w(dd_in, m->t, no_xform(), dls, no_xform(), Gr(m, m->sgw), m->wpartial, st);
         uad_launch_colsum(dls, n, zd, Gr(m, m->sgb), m->colscratch, st);
-        uad_launch_conv_d(dd_in, dmu, no_xform(), P(m, m->muw), m->g_small[5], epi_bias(nullptr), st);
-        uad_launch_conv_d(dd_in, dls, no_xform(), P(m, m->sgw), dflat, epi_bias(nullptr, nullptr, m->g_small[5]), st);
+        uad_launch_conv_d(dd_in, dmu, no_xform(), P(m, m->muw), m->g_small[5], epi_bias(nullptr), st, nullptr, m->ws);
+        uad_launch_conv_d(dd_in, dls, no_xform(), P(m, m->sgw), dflat, epi_bias(nullptr, nullptr, m->g_small[5]), st, nullptr, m->ws);
     } else {
         uad_launch_conv_w(dd_in, m->t, no_xform(), dz, no_xform(), Gr(m, m->muw), m->wpartial, st);
         uad_launch_colsum(dz, n, zd, Gr(m, m->mub), m->colscratch, st);
-        uad_launch_conv_d(dd_in, dz, no_xform(), P(m, m->muw), dflat, epi_bias(nullptr), st);
+        uad_launch_conv_d(dd_in, dz, no_xform(), P(m, m->muw), dflat, epi_bias(nullptr), st, nullptr, m->ws);
     }
     // Bottleneck/conv2d (1x1, cenc -> cmid): input = act(enc_last.c)
     {
@@ -534,8 +547,8 @@ static int backward_bottleneck(uad_model* m, hipStream_t st) {
         UadConvDesc d = conv1x1_desc(n, ir, ir, m->cenc, m->cmid);
         uad_launch_conv_w(d, EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu), dflat, no_xform(), Gr(m, m->bw), m->wpartial, st);
         uad_launch_colsum(dflat, n * ir * ir, m->cmid, Gr(m, m->bb), m->colscratch, st);
-        uad_launch_conv_d(d, dflat, no_xform(), P(m, m->bw), m->G1, epi_bwd(m, EL.c, EL.gamma, EL.beta, kLrelu), st);
-        uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma),
+        uad_launch_conv_d(d, dflat, no_xform(), P(m, m->bw), m->G1, epi_bwd(m, EL.c, EL.gamma, EL.beta, kLrelu), st, nullptr, m->ws);
+        uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d, false, m->ws.floats), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma),
                                     Gr(m, EL.beta), Gr(m, EL.b), st);
     }
     float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;   // G0 = d loss / d c of the last encoder conv
@@ -553,8 +566,8 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
         static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
         static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
         { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wpartial, st); }
-        { PROF(kEncD[i & 7]); uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st, m->wpack_d + m->enc[i].w); }
-        { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
+        { PROF(kEncD[i & 7]); uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st, m->wpack_d + m->enc[i].w, m->ws); }
+        { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), st); }
         float* tsw = g; g = gn; gn = tsw;
     }
@@ -652,6 +665,11 @@ static int check_gemm_desc(const uad_conv_desc_t* d, bool f_type) {
 }
 
 // op-level helpers: the spatial kernels need the packed weight copy; build it on the fly (synchronous, tests only)
+static int ws_for_op(const UadConvDesc& d, bool f_type, bool have_pack, UadGemmWs* ws) {
+    ws->ptr = nullptr; ws->floats = uad_conv_ws_floats(d, f_type, have_pack);
+    if (ws->floats) HIP_TRY(hipMalloc((void**)&ws->ptr, ws->floats * sizeof(float)));
+    return UAD_OK;
+}
 static int pack_for_op(const UadConvDesc& d, const float* W, bool f_type, float** pf, float** pd, hipStream_t st) {
     *pf = *pd = nullptr;
     if (!uad_conv_spatial_ok(d, f_type)) return UAD_OK;
@@ -662,8 +680,8 @@ static int pack_for_op(const UadConvDesc& d, const float* W, bool f_type, float*
     uad_launch_pack_weights(W, *pf, *pd, &off, &cb, &cs, &taps, 1, st);
     return UAD_OK;
 }
-static int finish_op(float* pf, float* pd, hipStream_t st) {
-    if (pf || pd) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(pf); (void)hipFree(pd); }
+static int finish_op(float* pf, float* pd, hipStream_t st, float* wsp = nullptr) {
+    if (pf || pd || wsp) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(pf); (void)hipFree(pd); (void)hipFree(wsp); }
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
@@ -673,16 +691,20 @@ int uad_op_conv_f(const uad_conv_desc_t* d, const float* big_in, const uad_xform
     if (int rc = check_gemm_desc(d, true)) return rc;
     float *pf = nullptr, *pd = nullptr;
     if (int rc = pack_for_op(to_desc(d), W, true, &pf, &pd, (hipStream_t)stream)) return rc;
-    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream, pf);
-    return finish_op(pf, pd, (hipStream_t)stream);
+    UadGemmWs ws;
+    if (int rc = ws_for_op(to_desc(d), true, pf != nullptr, &ws)) return rc;
+    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream, pf, ws);
+    return finish_op(pf, pd, (hipStream_t)stream, ws.ptr);
 }
 int uad_op_conv_d(const uad_conv_desc_t* d, const float* small_in, const uad_xform_t* xf, const float* W, const float* bias,
                   const float* mul, const float* add, float* big_out, void* stream) {
     if (int rc = check_gemm_desc(d, false)) return rc;
     float *pf = nullptr, *pd = nullptr;
     if (int rc = pack_for_op(to_desc(d), W, false, &pf, &pd, (hipStream_t)stream)) return rc;
-    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream, pd);
-    return finish_op(pf, pd, (hipStream_t)stream);
+    UadGemmWs ws;
+    if (int rc = ws_for_op(to_desc(d), false, pd != nullptr, &ws)) return rc;
+    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream, pd, ws);
+    return finish_op(pf, pd, (hipStream_t)stream, ws.ptr);
 }
 
 static int bwdact_common(bool f_type, const uad_conv_desc_t* dd, const float* in, const float* W, const float* cprev,
@@ -691,7 +713,10 @@ static int bwdact_common(bool f_type, const uad_conv_desc_t* dd, const float* in
     if (!act || !act->scale) return fail(UAD_ERR_INVALID, "bwdact needs the activation scale/shift");
     UadConvDesc d = to_desc(dd);
     const int C = f_type ? d.CS : d.CB;
-    const int T = f_type ? uad_conv_f_tiles(d) : uad_conv_d_tiles(d);
+    const bool can_pack = uad_conv_spatial_ok(d, f_type);
+    UadGemmWs ws;
+    if (int rc = ws_for_op(d, f_type, can_pack, &ws)) return rc;
+    const int T = f_type ? uad_conv_f_tiles(d, can_pack, ws.floats) : uad_conv_d_tiles(d, can_pack, ws.floats);
     float *colpart = nullptr, *tmp = nullptr;
     HIP_TRY(hipMalloc((void**)&colpart, (size_t)T * 2 * C * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&tmp, (size_t)3 * C * sizeof(float)));
@@ -702,12 +727,12 @@ static int bwdact_common(bool f_type, const uad_conv_desc_t* dd, const float* in
     hipStream_t st = (hipStream_t)stream;
     float *pf = nullptr, *pd = nullptr;
     if (int rc = pack_for_op(d, W, f_type, &pf, &pd, st)) return rc;
-    if (f_type) uad_launch_conv_f(d, in, no_xform(), W, out, e, st, pf);
-    else uad_launch_conv_d(d, in, no_xform(), W, out, e, st, pd);
+    if (f_type) uad_launch_conv_f(d, in, no_xform(), W, out, e, st, pf, ws);
+    else uad_launch_conv_d(d, in, no_xform(), W, out, e, st, pd, ws);
     // rstd = 1, gamma unused for dbias=null: dbeta -> s1, dgamma -> s2
     uad_launch_bn_grad_finalize(colpart, T, C, act->scale, 1.0f, s2, s1, nullptr, st);
     HIP_TRY(hipStreamSynchronize(st));
-    hipFree(colpart); hipFree(tmp); hipFree(pf); hipFree(pd);
+    hipFree(colpart); hipFree(tmp); hipFree(pf); hipFree(pd); hipFree(ws.ptr);
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
