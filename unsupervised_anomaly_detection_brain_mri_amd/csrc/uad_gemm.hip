@@ -35,7 +35,6 @@ struct ConvGemmArgs {
     int CA;        // channels of the A operand (contraction per tap)
     int Nn;        // output channels
     int lws, lhs;  // log2(WS), log2(HS) or -1 when not a power of two
-    int dbg;       // UAD_DBG ablation bits (timing experiments only; results are wrong when set)
     int nsplit;    // split-K factor (>1: raw partial tiles go to Out + split*out_elems, see splitk_epilogue_kernel)
     long long out_elems;
 };
@@ -530,7 +529,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_f_kernel(const ConvGemmA
         // ---- stage the halo tile of this channel chunk (activation on the way in, padding = exact 0) ----
         constexpr int TOT = IH * IW * CQ;
         constexpr int BATCH = 6;
-        for (int f0 = tid; f0 < ((a.dbg & 2) ? 0 : TOT); f0 += NT * BATCH) {
+        for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
             float4 v[BATCH];
             bool ok[BATCH];
 #pragma unroll
@@ -564,10 +563,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_f_kernel(const ConvGemmA
             const int ky = tap / 5, kx = tap % 5;
             BFragD<NKK>& cur = (tap & 1) ? b1 : b0;
             BFragD<NKK>& nxt = (tap & 1) ? b0 : b1;
-            if (!(a.dbg & 1)) {
-                if (tap < 24) loadB(nxt, tap + 1, c0);
-                else if (ch + 1 < nchunks) loadB(nxt, 0, c0 + CK);
-            }
+            if (tap < 24) loadB(nxt, tap + 1, c0);
+            else if (ch + 1 < nchunks) loadB(nxt, 0, c0 + CK);
+            // keep the prefetch a full tap ahead: without this fence the scheduler sinks the loads to their first
+            // use (vmcnt(0) right behind the issue) and every tap eats an L2 round trip
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 const float4 av = *reinterpret_cast<const float4*>(sIn + aoff + (ky * IW + kx) * LDC + kk * 8);
@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_f_kernel(const ConvGemmA
         obase[r] = ((size_t)(n * d.HS + oy) * d.WS + ox) * CS;
     }
     float s1 = 0.f, s2 = 0.f;
-    if (!(a.dbg & 4) || acc[0] == 12345.f) epilogue_frag<0>(a, acc, obase, colok, colc, c_a, c_b, s1, s2);
+    epilogue_frag<0>(a, acc, obase, colok, colc, c_a, c_b, s1, s2);
     if (bwd) {
         const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
         if (lh == 0) {
@@ -714,6 +714,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmA
             BFragD<NKK>& nxt = (tap & 1) ? b0 : b1;
             if (tap < 24) loadB(nxt, tap + 1, c0);
             else if (ch + 1 < nchunks) loadB(nxt, 0, c0 + CK);
+            // keep the prefetch a full tap ahead: without this fence the scheduler sinks the loads to their first
+            // use (vmcnt(0) right behind the issue) and every tap eats an L2 round trip
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 const float4 av = *reinterpret_cast<const float4*>(sIn + aoff + (dy * IW + dx) * LDC + kk * 8);
@@ -1309,8 +1312,6 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CB; a.Nn = d.CS;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
-    static const int dbg = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0;
-    a.dbg = dbg;
     const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr, ws.ptr ? ws.floats : 0);
     run_plan(p, a, true, ws.ptr, st);
 }
@@ -1322,7 +1323,6 @@ void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf,
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CS; a.Nn = d.CB;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
-    a.dbg = 0;
     const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr, ws.ptr ? ws.floats : 0);
     run_plan(p, a, false, ws.ptr, st);
 }
