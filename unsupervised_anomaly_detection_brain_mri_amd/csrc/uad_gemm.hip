@@ -1058,12 +1058,13 @@ __global__ void __launch_bounds__(256) conv5_w_kernel(const ConvWArgs a, int til
         scB.x *= a.xfs.mult; scB.y *= a.xfs.mult; scB.z *= a.xfs.mult; scB.w *= a.xfs.mult;
     }
 
-    // taps of this wave and their LDS offsets
+    // taps of this wave and their LDS offsets: taps {w, w+4, .., w+20} in full, and the 25th tap (24) for one quarter of
+    // the tile's positions per wave (its four partial tiles are folded through LDS at the end) -> perfectly balanced
     constexpr int MAXT = 7;
     int aaddr[MAXT];
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
-        const int tap = wave + 4 * j;
+        const int tap = (j < MAXT - 1) ? wave + 4 * j : 24;
         const int ky = tap / 5, kx = tap % 5;
         aaddr[j] = ((ky * IW + kx) + 2 * lh) * CK + l31;   // + lane part: pixel x offset 2*lh, channel l31
     }
@@ -1131,23 +1132,38 @@ __global__ void __launch_bounds__(256) conv5_w_kernel(const ConvWArgs a, int til
             const int cst = ((2 * (st / 4)) * IW + 4 * (st % 4)) * CK;
             const float bv = sSmall[baddr + (2 * st) * CK];
 #pragma unroll
-            for (int j = 0; j < MAXT; ++j) {
-                if (j == MAXT - 1 && wave != 0) break;   // only wave 0 owns a 7th tap (tap 24)
+            for (int j = 0; j < MAXT - 1; ++j) {
                 const float av = sBig[aaddr[j] + cst];
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+            if ((st >> 3) == wave) {   // wave-uniform: this wave's quarter of tap 24
+                const float av = sBig[aaddr[MAXT - 1] + cst];
+                acc[MAXT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[MAXT - 1], 0, 0, 0);
             }
         }
     }
 
     float* out = a.partial + (size_t)blockIdx.z * a.Mtot * d.CS;
 #pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
+    for (int j = 0; j < MAXT - 1; ++j) {
         const int tap = wave + 4 * j;
-        if (tap >= 25) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             out[((size_t)tap * d.CB + cb) * d.CS + cs0 + l31] = acc[j][r];
+        }
+    }
+    // tap 24: fixed-order sum of the four waves' quarter-tile partials
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sBig[(wave * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = (sBig[r * 64 + lane] + sBig[(16 + r) * 64 + lane]) + (sBig[(32 + r) * 64 + lane] + sBig[(48 + r) * 64 + lane]);
+            const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[((size_t)24 * d.CB + cb) * d.CS + cs0 + l31] = v;
         }
     }
 }
