@@ -63,10 +63,18 @@ def train_flops_per_slice():
     return 2.0 * (3 * (fwd_macs + small) - conv_layers()[0][1] * conv_layers()[0][2])
 
 
-def cpu_baseline(sample_batch=8, steps=2):
+def cpu_baseline(sample_batch=16, steps=4):
     """The numpy oracle (a PORT of the reference semantics, not TF — TF 1.15 cannot be installed here) timed on this
-    host's cores on a bounded sample: `steps` VAE train steps at batch `sample_batch`, fp32."""
+    host's cores on a bounded sample: `steps` VAE train steps at batch `sample_batch`, fp32.  BLAS threads are capped
+    (UAD_CPU_THREADS, default 32): the per-tap matmuls are small and oversubscribing a 256-thread host is slower."""
     from oracle import nn as onn, vae as ovae
+    threads = int(os.environ.get('UAD_CPU_THREADS', '32'))
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:
+        limiter = None
     m = ovae.Model('VAE', H, W, 1, INTER, ZDIM)
     p = ovae.init_params(m.spec, seed=3)
     opt = m.new_opt(p)
@@ -85,10 +93,13 @@ def cpu_baseline(sample_batch=8, steps=2):
         from threadpoolctl import threadpool_info
         cores = max([d.get('num_threads', 1) for d in threadpool_info()] or [1])
     except Exception:
-        cores = os.cpu_count() or 1
+        cores = threads
+    if limiter is not None:
+        limiter.restore_original_limits()
     return {'value': round(sample_batch * steps / dt, 2), 'unit': 'slices/s', 'cores': int(cores), 'kind': 'port',
             'sample': f'{steps} fp32 VAE train steps at batch {sample_batch} with the numpy oracle '
-                      f'(BLAS-threaded matmuls; TF-CPU itself is not installable), {dt:.1f} s'}
+                      f'(BLAS matmuls on {cores} threads of {os.cpu_count()} host CPUs; TF-CPU itself is not '
+                      f'installable), {dt:.1f} s'}
 
 
 def main():
@@ -173,6 +184,15 @@ def main():
     dom = max(gemm, key=lambda t: gemm[t][1])
     dom_ms = gemm[dom][1] / gemm[dom][0]
     achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
+    # HBM traffic of the dominant launch group: rocprofv3 PMC passes of this same command, committed under profiles/
+    traffic = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'))).get(dom)
+        if tr:
+            traffic = {'bytes': int(tr['fetch_bytes'] + tr['write_bytes']), 'fetch_bytes': int(tr['fetch_bytes']),
+                       'write_bytes': int(tr['write_bytes']), 'source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)'}
+    except Exception:
+        traffic = None
     kernels = {t: {'ms': round(ms / c, 4), 'tflops': round(fl[t] / (ms / c * 1e-3) / 1e12, 2) if t in fl else None}
                for t, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
 
@@ -190,7 +210,7 @@ def main():
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'step_tflops': round(value * train_flops_per_slice() / 1e12, 2), 'final_loss': round(loss, 4)},
             'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
                          'avg_launch_ms': round(dom_ms, 4),
                          'whole_step_frac': round(value * train_flops_per_slice() / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             'kernels': kernels,
