@@ -482,7 +482,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_f_kernel(const ConvGemmA
     const int tilesx = d.WS / TW;
     const int ty0 = (blockIdx.x / tilesx) * TH, tx0 = (blockIdx.x % tilesx) * TW;
     const int n = blockIdx.y;
-    const int n0 = blockIdx.z * BN;
+    const int nsplit = a.nsplit;
+    const int n0 = (blockIdx.z / nsplit) * BN;
+    const int split = blockIdx.z % nsplit;
     const int CB = d.CB, CS = d.CS;
 
     const bool xf = a.xf.scale != nullptr;
@@ -517,15 +519,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_f_kernel(const ConvGemmA
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
 
-    const int nchunks = CB / CK;
+    // split-K: this workgroup contracts channel chunks [ch0, nchunks)
+    const int cper = (CB / CK + nsplit - 1) / nsplit;
+    const int ch0 = split * cper;
+    const int nchunks = min(CB / CK, ch0 + cper);
     const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
     const float* inb = a.A + (size_t)n * d.HB * d.WB * CB;
-    loadB(b0, 0, 0);
+    loadB(b0, 0, ch0 * CK);
     __syncthreads();  // s_xf visible
 
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = ch0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
-        if (ch > 0) __syncthreads();  // everyone is done reading the previous chunk's tile
+        if (ch > ch0) __syncthreads();  // everyone is done reading the previous chunk's tile
         // ---- stage the halo tile of this channel chunk (activation on the way in, padding = exact 0) ----
         constexpr int TOT = IH * IW * CQ;
         constexpr int BATCH = 6;
@@ -596,6 +601,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_f_kernel(const ConvGemmA
         obase[r] = ((size_t)(n * d.HS + oy) * d.WS + ox) * CS;
     }
     float s1 = 0.f, s2 = 0.f;
+    if (nsplit > 1) {   // raw partial tile into this split's slab; splitk_epilogue_kernel finishes the job
+        float* slab = a.Out + (size_t)split * a.out_elems;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (colok) slab[obase[r] + colc] = acc[r];
+        return;
+    }
     epilogue_frag<0>(a, acc, obase, colok, colc, c_a, c_b, s1, s2);
     if (bwd) {
         const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
@@ -633,7 +645,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmA
     const int tilesx = d.WS / TW;
     const int ty0 = (blockIdx.x / tilesx) * TH, tx0 = (blockIdx.x % tilesx) * TW;
     const int n = blockIdx.y;
-    const int n0 = blockIdx.z * BN;
+    const int nsplit = a.nsplit;
+    const int n0 = (blockIdx.z / nsplit) * BN;
+    const int split = blockIdx.z % nsplit;
     const int CB = d.CB, CS = d.CS;   // output channels = CB, contraction = CS
 
     const bool xf = a.xf.scale != nullptr;
@@ -665,14 +679,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmA
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-    const int nchunks = CS / CK;
+    const int cper = (CS / CK + nsplit - 1) / nsplit;
+    const int ch0 = split * cper;
+    const int nchunks = min(CS / CK, ch0 + cper);
     const float* inb = a.A + (size_t)n * d.HS * d.WS * CS;
-    loadB(b0, 0, 0);
+    loadB(b0, 0, ch0 * CK);
     __syncthreads();
 
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = ch0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
-        if (ch > 0) __syncthreads();
+        if (ch > ch0) __syncthreads();
         constexpr int TOT = IH * IW * CQ;
         constexpr int BATCH = 4;
         for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
@@ -744,8 +760,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmA
             const int Y = 2 * (ty0 + mm / TW) + py, X = 2 * (tx0 + mm % TW) + px;
             obase[r] = ((size_t)(n * d.HB + Y) * d.WB + X) * CB;
         }
-        epilogue_frag<0>(a, acc[cls], obase, colok, colc, c_a, c_b, s1, s2);
+        if (nsplit > 1) {
+            float* slab = a.Out + (size_t)split * a.out_elems;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (colok) slab[obase[r] + colc] = acc[cls][r];
+        } else {
+            epilogue_frag<0>(a, acc[cls], obase, colok, colc, c_a, c_b, s1, s2);
+        }
     }
+    if (nsplit > 1) return;
     if (bwd) {
         const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
         if (lh == 0) {
@@ -1256,10 +1280,17 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
     int ns = choose_nsplit(M, Nn, CA, classes, min_taps);
     if (ns > 1 && (size_t)ns * p.out_elems > ws_cap) ns = 1;
     if (p.sc.ok) {
+        // the spatial kernels want >= 2 workgroups per CU (staging / epilogue of one overlaps the MFMA work of the other);
+        // if the plain grid is smaller, split the channel chunks over workgroups (slabs + splitk_epilogue_kernel)
         const long wgs = (long)d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW) * (Nn / p.sc.BN);
-        if (wgs >= 512) {   // the spatial kernels need >= 2 workgroups per CU to overlap staging/epilogue with MFMA work
+        const int chunks = CA / (p.sc.BN == 64 ? 32 : 16);
+        int sp = 1;
+        while (wgs * sp < 512 && sp * 2 <= chunks && (size_t)(sp * 2) * p.out_elems <= ws_cap) sp *= 2;
+        if (wgs * sp >= 512 || wgs * sp >= 256) {
             p.path = PATH_SPATIAL;
-            p.tiles = d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW);
+            p.nsplit = sp;
+            p.ws_floats = sp > 1 ? (size_t)sp * p.out_elems : 0;
+            p.tiles = sp > 1 ? (p.out_rows + 63) / 64 : d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW);
             return p;
         }
     }
@@ -1298,13 +1329,19 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
     const UadConvDesc& d = a.d;
     a.nsplit = 1; a.out_elems = p.out_elems;
     if (p.path == PATH_SPATIAL) {
-        dim3 grid((d.HS / p.sc.TH) * (d.WS / p.sc.TW), d.N, a.Nn / p.sc.BN);
+        float* out = a.Out;
+        if (p.nsplit > 1) { a.Out = ws; a.nsplit = p.nsplit; }
+        dim3 grid((d.HS / p.sc.TH) * (d.WS / p.sc.TW), d.N, (a.Nn / p.sc.BN) * p.nsplit);
         if (f_type) {
             if (p.sc.BN == 64) hipLaunchKernelGGL((conv5_f_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv5_f_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
         } else {
             if (p.sc.BN == 64) hipLaunchKernelGGL((conv5_d_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv5_d_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
+        }
+        if (p.nsplit > 1) {
+            dim3 g2((p.out_rows + 63) / 64, (a.Nn + 63) / 64);
+            hipLaunchKernelGGL(splitk_epilogue_kernel, g2, dim3(256), 0, st, ws, p.nsplit, p.out_elems, p.out_rows, a.Nn, a.ep, out);
         }
         return;
     }
