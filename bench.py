@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'f32'), choices=['f32', 'bf16x3'])
     args = ap.parse_args()
 
     import torch
@@ -127,7 +128,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    eng = Engine('VAE', H, W, 1, INTER, ZDIM, max_batch=BATCH, device=f'cuda:{local_rank}')
+    eng = Engine('VAE', H, W, 1, INTER, ZDIM, max_batch=BATCH, device=f'cuda:{local_rank}', math=args.math)
     # identical glorot-uniform init on every rank (seed 3), zero bias, gamma 1, beta 0
     rng = np.random.default_rng(3)
     flat = np.zeros(eng.nparams, np.float32)
@@ -203,7 +204,7 @@ def main():
             'metric': 'MRI slices/sec VAE train step (128x128, bs=64)',
             'value': round(value, 1), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32' if args.math == 'f32' else 'f32 via bf16x3 (split-bf16 MFMA, fp32 accumulate)', 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[1]: VAE 128x128x1 slices, batch 64 per GPU, '
                                    'fwd + bwd + TF-Adam (lr 1e-4, beta1 0.5), dropout 0.2, inter_res 8, zDim 128',
                        'global_batch': BATCH * world, 'per_gpu_batch': BATCH,

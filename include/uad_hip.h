@@ -34,6 +34,9 @@ enum { UAD_OK = 0, UAD_ERR_INVALID = 1, UAD_ERR_HIP = 2, UAD_ERR_UNSUPPORTED = 3
 enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1 };
 enum { UAD_BUF_PARAMS = 0, UAD_BUF_GRADS = 1, UAD_BUF_ADAM_M = 2, UAD_BUF_ADAM_V = 3 };
 enum { UAD_SEG_DECODER = 0, UAD_SEG_BOTTLENECK = 1, UAD_SEG_ENCODER = 2, UAD_SEG_ALL = -1 };
+/* arithmetic of the k5 s2 forward / data-gradient contractions: exact fp32 MFMA (default), or split-bf16 (x = hi + lo,
+ * hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate: ~2^-17 relative error per product) */
+enum { UAD_MATH_F32 = 0, UAD_MATH_BF16X3 = 1 };
 
 typedef struct uad_model uad_model_t;
 
@@ -100,6 +103,9 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
 /* uad_forward(want_backward=1) + uad_backward(ALL) + uad_adam_step */
 int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float beta1, float beta2, float eps,
                    void* stream);
+
+int uad_set_math_mode(uad_model_t* m, int mode);   /* UAD_MATH_* ; takes effect at the next uad_forward */
+int uad_get_math_mode(const uad_model_t* m);
 
 /* per-launch-group HIP-event profiler (bench.py's roofline leg).  While enabled, every launch group of
  * uad_forward / uad_backward / uad_adam_step is bracketed by hipEventRecord on the caller's stream.

@@ -44,16 +44,19 @@ def test_param_table_matches_oracle_spec():
     eng.close()
 
 
+@pytest.mark.parametrize('math', ['f32', 'bf16x3'])
 @pytest.mark.parametrize('arch,h,inter,zdim,n', [('VAE', 32, 8, 16, 2), ('AE', 32, 8, 32, 3), ('VAE', 64, 8, 64, 5),
                                                   ('VAE', 128, 8, 128, 2), ('AE', 128, 8, 128, 1), ('VAE', 64, 16, 128, 2)])
-def test_forward_backward_parity(arch, h, inter, zdim, n):
+def test_forward_backward_parity(arch, h, inter, zdim, n, math):
+    """Both math modes must meet the same 1e-4 bar: 'f32' = exact fp32 MFMA, 'bf16x3' = split-bf16 products on the
+    bf16 matrix cores with fp32 accumulation (forward and data-gradient k5 s2 contractions)."""
     m, p32, x, eps, masks = _setup(arch, h, inter, zdim, n)
     p64 = _f64(p32)
     out, cache = m.forward(p64, x.astype(np.float64), eps.astype(np.float64) if arch == 'VAE' else None, _f64(masks))
     ls = m.losses(x.astype(np.float64), out)
     g = m.backward(p64, x.astype(np.float64), out, cache, _f64(masks))
 
-    eng = Engine(arch, h, h, 1, inter, zdim, max_batch=n)
+    eng = Engine(arch, h, h, 1, inter, zdim, max_batch=n, math=math)
     eng.set_params(p32)
     got = eng.forward(x, eps if arch == 'VAE' else None, masks, want_backward=True)
     eng.backward()

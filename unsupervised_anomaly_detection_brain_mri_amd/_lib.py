@@ -10,6 +10,7 @@ UAD_OK = 0
 ARCH_AE, ARCH_VAE = 0, 1
 BUF_PARAMS, BUF_GRADS, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
 SEG_DECODER, SEG_BOTTLENECK, SEG_ENCODER, SEG_ALL = 0, 1, 2, -1
+MATH_F32, MATH_BF16X3 = 0, 1
 
 c_float_p = C.c_void_p  # device pointers are passed as integers
 
@@ -58,6 +59,8 @@ SYMBOLS = {
     'uad_adam_step': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_train_step': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),
+    'uad_set_math_mode': (C.c_int, [C.c_void_p, C.c_int]),
+    'uad_get_math_mode': (C.c_int, [C.c_void_p]),
     'uad_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'uad_profile_report': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     'uad_residual': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,

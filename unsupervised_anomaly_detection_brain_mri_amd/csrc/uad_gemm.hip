@@ -27,6 +27,8 @@ struct ConvGemmArgs {
     const float* A;
     const float* W;
     const float* Wp;   // k-quad-interleaved copy of W for the spatial kernels (uad_launch_pack_weights)
+    const unsigned short* Wp16;   // bf16 hi|lo planes, k-octet-interleaved (bf16x3 math mode)
+    long long w16_plane;          // elements per plane
     float* Out;
     UadXform xf;
     UadEpilogue ep;
@@ -788,6 +790,256 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmA
     }
 }
 
+// ================================================================================================
+// bf16x3 math mode ("split-bf16"): every fp32 operand x is written x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
+// a product is computed as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (products exact, fp32 accumulate), i.e. with
+// ~2^-17 relative error per product -- inside the 1e-4 parity bar -- at 3 x 32-cycle v_mfma_f32_32x32x16_bf16 per K=16
+// instead of 8 x 64-cycle fp32 MFMAs.  Activations are split while they are staged into LDS (two bf16 planes, same
+// bytes as fp32), weights are pre-split by pack_weights_bf16_kernel.
+// ================================================================================================
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x, float y) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));   // lo16 = bf16_rne(x), hi16 = bf16_rne(y)
+    return r;
+}
+__device__ __forceinline__ void split_bf16(float4 v, uint2& hi, uint2& lo) {
+    hi.x = cvt_pk_bf16(v.x, v.y);
+    hi.y = cvt_pk_bf16(v.z, v.w);
+    const float rx = v.x - __uint_as_float(hi.x << 16), ry = v.y - __uint_as_float(hi.x & 0xFFFF0000u);
+    const float rz = v.z - __uint_as_float(hi.y << 16), rw = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
+    lo.x = cvt_pk_bf16(rx, ry);
+    lo.y = cvt_pk_bf16(rz, rw);
+}
+__device__ __forceinline__ v16f mfma_bf16(uint4 a, uint4 b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+template <int NKS>
+struct BFrag16 { uint4 hi[NKS], lo[NKS]; };
+
+// KIND_F: halo (2TH+3)x(2TW+3), stride-2 gather;  KIND_D: halo (TH+2)x(TW+2), four output-parity classes
+template <int TH, int TW, int CK, int WGM, int WGN, int KIND>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv5_bf16_kernel(const ConvGemmArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int IH = (KIND == KIND_F) ? 2 * TH + 3 : TH + 2, IW = (KIND == KIND_F) ? 2 * TW + 3 : TW + 2;
+    constexpr int LDH = CK + 8;                 // ushorts per pixel row (+16 B pad: odd number of 16-B slots)
+    constexpr int NKS = CK / 16, CQ = CK / 4;
+    constexpr int BN = 32 * WGN;
+    constexpr int NACC = (KIND == KIND_F) ? 3 : 8;
+    static_assert(TH * TW == 32 * WGM, "one 32-row fragment per wave along M");
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned short* sHi = reinterpret_cast<unsigned short*>(dsm);
+    unsigned short* sLo = sHi + IH * IW * LDH;
+    float* s_xf = reinterpret_cast<float*>(sLo + IH * IW * LDH);
+    float* s_red = s_xf + 2 * XF_LDS_CH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const UadConvDesc& d = a.d;
+    const int tilesx = d.WS / TW;
+    const int ty0 = (blockIdx.x / tilesx) * TH, tx0 = (blockIdx.x % tilesx) * TW;
+    const int n = blockIdx.y;
+    const int nsplit = a.nsplit;
+    const int n0 = (blockIdx.z / nsplit) * BN;
+    const int split = blockIdx.z % nsplit;
+    const int CA = a.CA, Nn = a.Nn;   // contraction / output channels
+    const int AH = (KIND == KIND_F) ? d.HB : d.HS, AW = (KIND == KIND_F) ? d.WB : d.WS;
+
+    const bool xf = a.xf.scale != nullptr;
+    if (xf)
+        for (int c = tid; c < CA; c += NT) {
+            s_xf[c] = a.xf.scale[c] * a.xf.mult;
+            s_xf[XF_LDS_CH + c] = a.xf.shift[c];
+        }
+
+    const int m = wm * 32 + l31;
+    const int pty = m / TW, ptx = m % TW;
+    const int aoff = (KIND == KIND_F) ? ((2 * pty) * IW + 2 * ptx) * LDH + 8 * lh : ((pty + 1) * IW + ptx + 1) * LDH + 8 * lh;
+    const int col = n0 + wn * 32 + l31;
+    const bool colok = col < Nn;
+    const int colc = colok ? col : 0;
+    // packed planes [tap][k/8][n][8] bf16: one uint4 per (k-octet, n)
+    const uint4* wq = reinterpret_cast<const uint4*>(a.Wp16) + (size_t)lh * Nn + colc;
+    const size_t plane_q = (size_t)a.w16_plane / 8;
+
+    BFrag16<NKS> b0, b1;
+    auto loadB = [&](BFrag16<NKS>& b, int tap, int c0) {
+        const uint4* w = wq + ((size_t)tap * (CA / 8) + c0 / 8) * Nn;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            b.hi[j] = w[(size_t)(2 * j) * Nn];
+            b.lo[j] = w[(size_t)(2 * j) * Nn + plane_q];
+        }
+    };
+
+    v16f acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int cper = (CA / CK + nsplit - 1) / nsplit;
+    const int ch0 = split * cper;
+    const int nchunks = min(CA / CK, ch0 + cper);
+    const int gy0 = (KIND == KIND_F) ? 2 * ty0 - 1 : ty0 - 1, gx0 = (KIND == KIND_F) ? 2 * tx0 - 1 : tx0 - 1;
+    const float* inb = a.A + (size_t)n * AH * AW * CA;
+    loadB(b0, 0, ch0 * CK);
+    __syncthreads();
+
+    for (int ch = ch0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK;
+        if (ch > ch0) __syncthreads();
+        constexpr int TOT = IH * IW * CQ;
+        constexpr int BATCH = (KIND == KIND_F) ? 6 : 4;
+        for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
+            float4 v[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                const int pix = f / CQ, cq = f % CQ;
+                const int iy = pix / IW, ix = pix % IW;
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                ok[u] = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
+                const int gp = ok[u] ? (gy * AW + gx) : 0;
+                v[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok[u] ? cq * 4 : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                if (f >= TOT) continue;
+                const int pix = f / CQ, cq = f % CQ;
+                float4 t = v[u];
+                if (xf) {
+                    const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
+                    const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
+                    t = xform4(t, sc, sh, a.xf.alpha);
+                }
+                t = keep4(ok[u], t);
+                uint2 hi, lo;
+                split_bf16(t, hi, lo);
+                *reinterpret_cast<uint2*>(sHi + pix * LDH + cq * 4) = hi;
+                *reinterpret_cast<uint2*>(sLo + pix * LDH + cq * 4) = lo;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            const int ky = tap / 5, kx = tap % 5;
+            int toff, cls = 0;
+            if (KIND == KIND_F) {
+                toff = (ky * IW + kx) * LDH;
+            } else {
+                const int py = (ky + 1) & 1, px = (kx + 1) & 1;
+                const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+                toff = (dy * IW + dx) * LDH;
+                cls = py * 2 + px;
+            }
+            BFrag16<NKS>& cur = (tap & 1) ? b1 : b0;
+            BFrag16<NKS>& nxt = (tap & 1) ? b0 : b1;
+            if (tap < 24) loadB(nxt, tap + 1, c0);
+            else if (ch + 1 < nchunks) loadB(nxt, 0, c0 + CK);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NKS; ++j) {
+                const uint4 ah = *reinterpret_cast<const uint4*>(sHi + aoff + toff + 16 * j);
+                const uint4 al = *reinterpret_cast<const uint4*>(sLo + aoff + toff + 16 * j);
+                if (KIND == KIND_F) {
+                    acc[0] = mfma_bf16(ah, cur.hi[j], acc[0]);
+                    acc[1] = mfma_bf16(ah, cur.lo[j], acc[1]);
+                    acc[2] = mfma_bf16(al, cur.hi[j], acc[2]);
+                } else {
+                    acc[2 * cls] = mfma_bf16(ah, cur.hi[j], acc[2 * cls]);
+                    acc[2 * cls + 1] = mfma_bf16(ah, cur.lo[j], acc[2 * cls + 1]);
+                    acc[2 * cls + 1] = mfma_bf16(al, cur.hi[j], acc[2 * cls + 1]);
+                }
+            }
+        }
+        b0 = b1;
+    }
+
+    // ---- epilogue (identical to the fp32 spatial kernels: the C layout of the MFMA is dtype independent) ----
+    const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
+    float c_a, c_b = 0.f;
+    if (!bwd) c_a = a.ep.bias ? a.ep.bias[colc] : 0.f;
+    else { c_a = a.ep.escale[colc] * a.ep.emult; c_b = a.ep.eshift[colc]; }
+    float s1 = 0.f, s2 = 0.f;
+    constexpr int NCLS = (KIND == KIND_F) ? 1 : 4;
+#pragma unroll
+    for (int cls = 0; cls < NCLS; ++cls) {
+        v16f o;
+        if (KIND == KIND_F) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = acc[0][r] + (acc[1][r] + acc[2][r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = acc[2 * cls][r] + acc[2 * cls + 1][r];
+        }
+        size_t obase[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (KIND == KIND_F) {
+                obase[r] = ((size_t)(n * d.HS + ty0 + mm / TW) * d.WS + tx0 + mm % TW) * Nn;
+            } else {
+                const int Y = 2 * (ty0 + mm / TW) + (cls >> 1), X = 2 * (tx0 + mm % TW) + (cls & 1);
+                obase[r] = ((size_t)(n * d.HB + Y) * d.WB + X) * Nn;
+            }
+        }
+        if (nsplit > 1) {
+            float* slab = a.Out + (size_t)split * a.out_elems;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (colok) slab[obase[r] + colc] = o[r];
+        } else {
+            epilogue_frag<0>(a, o, obase, colok, colc, c_a, c_b, s1, s2);
+        }
+    }
+    if (nsplit > 1) return;
+    if (bwd) {
+        const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+        if (lh == 0) {
+            s_red[(wm * 2 + 0) * BN + wn * 32 + l31] = t1;
+            s_red[(wm * 2 + 1) * BN + wn * 32 + l31] = t2;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) t += s_red[(w * 2 + which) * BN + c];
+            const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            if (n0 + c < Nn) a.ep.colpart[(tile * 2 + which) * Nn + n0 + c] = t;
+        }
+    }
+}
+
+template <int TH, int TW, int CK, int WGM, int WGN, int KIND>
+constexpr size_t conv5_bf16_lds_bytes() {
+    return (size_t)2 * ((KIND == KIND_F) ? (2 * TH + 3) * (2 * TW + 3) : (TH + 2) * (TW + 2)) * (CK + 8) * 2 +
+           (size_t)2 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
+}
+
+template <int TH, int TW, int CK, int WGM, int WGN, int KIND>
+void launch_conv5_bf16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = conv5_bf16_lds_bytes<TH, TW, CK, WGM, WGN, KIND>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_bf16_kernel<TH, TW, CK, WGM, WGN, KIND>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv5_bf16_kernel<TH, TW, CK, WGM, WGN, KIND>), grid, dim3(64 * WGM * WGN), lds, st, a);
+}
+
+// bf16 hi|lo planes for the bf16x3 kernels: Wf16[plane][tap][cb/8][cs][8], Wd16[plane][tap][cs/8][cb][8] (ushort),
+// each tensor at 2*off with its lo plane `count` elements behind the hi plane
+__device__ __forceinline__ unsigned bf16_rne_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
 // Sums S split-K slabs (fixed order -> deterministic) and applies the epilogue.  Block = 64 rows x 64 columns:
 // 16 column-quad lanes x 16 row lanes, 4 rows per thread.
 __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __restrict__ slabs, int S, long long out_elems,
@@ -868,6 +1120,25 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, float* __restri
     const float v = W[pd.off[t] + gid];
     Wf[pd.off[t] + ((size_t)(tap * (CB / 4) + cb / 4) * CS + cs) * 4 + (cb & 3)] = v;
     Wd[pd.off[t] + ((size_t)(tap * (CS / 4) + cs / 4) * CB + cb) * 4 + (cs & 3)] = v;
+}
+
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ W, unsigned short* __restrict__ Wf, unsigned short* __restrict__ Wd, PackDesc pd) {
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int t = 0;
+    while (t < pd.n && gid >= pd.count[t]) { gid -= pd.count[t]; ++t; }
+    if (t >= pd.n) return;
+    const int CB = pd.cb[t], CS = pd.cs[t];
+    const int cs = (int)(gid % CS);
+    const int r = (int)(gid / CS);
+    const int cb = r % CB, tap = r / CB;
+    const float v = W[pd.off[t] + gid];
+    const unsigned hi = bf16_rne_bits(v);
+    const unsigned lo = bf16_rne_bits(v - __uint_as_float(hi << 16));
+    const size_t base = 2 * (size_t)pd.off[t], cnt = (size_t)pd.count[t];
+    const size_t fi = ((size_t)(tap * (CB / 8) + cb / 8) * CS + cs) * 8 + (cb & 7);
+    const size_t di = ((size_t)(tap * (CS / 8) + cs / 8) * CB + cb) * 8 + (cs & 7);
+    Wf[base + fi] = (unsigned short)hi; Wf[base + cnt + fi] = (unsigned short)lo;
+    Wd[base + di] = (unsigned short)hi; Wd[base + cnt + di] = (unsigned short)lo;
 }
 
 // eligibility + tile choice of the spatial kernels (shared by the launchers and the *_tiles() queries)
@@ -1332,7 +1603,15 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
         float* out = a.Out;
         if (p.nsplit > 1) { a.Out = ws; a.nsplit = p.nsplit; }
         dim3 grid((d.HS / p.sc.TH) * (d.WS / p.sc.TW), d.N, (a.Nn / p.sc.BN) * p.nsplit);
-        if (f_type) {
+        if (a.Wp16) {   // bf16x3 math mode
+            if (f_type) {
+                if (p.sc.BN == 64) launch_conv5_bf16<8, 8, 32, 2, 2, KIND_F>(a, grid, st);
+                else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_F>(a, grid, st);
+            } else {
+                if (p.sc.BN == 64) launch_conv5_bf16<8, 8, 32, 2, 2, KIND_D>(a, grid, st);
+                else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_D>(a, grid, st);
+            }
+        } else if (f_type) {
             if (p.sc.BN == 64) hipLaunchKernelGGL((conv5_f_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv5_f_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
         } else {
@@ -1358,25 +1637,39 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
 }
 }  // namespace
 
+void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, unsigned short* w16_d, const long long* offs,
+                                  const int* cbs, const int* css, const int* taps, int n, hipStream_t st) {
+    PackDesc pd;
+    long long total = 0;
+    pd.n = n;
+    for (int i = 0; i < n; ++i) {
+        pd.off[i] = offs[i]; pd.cb[i] = cbs[i]; pd.cs[i] = css[i]; pd.count[i] = taps[i] * cbs[i] * css[i];
+        total += pd.count[i];
+    }
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w16_f, w16_d, pd);
+}
+
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W, float* small_out,
-                       UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws) {
+                       UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
+                       long long w16_plane) {
     ConvGemmArgs a;
-    a.Wp = Wpacked;
+    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CB; a.Nn = d.CS;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
-    const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr, ws.ptr ? ws.floats : 0);
+    const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0);
     run_plan(p, a, true, ws.ptr, st);
 }
 
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W, float* big_out,
-                       UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws) {
+                       UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
+                       long long w16_plane) {
     ConvGemmArgs a;
-    a.Wp = Wpacked;
+    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CS; a.Nn = d.CB;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
-    const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr, ws.ptr ? ws.floats : 0);
+    const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0);
     run_plan(p, a, false, ws.ptr, st);
 }
 

@@ -9,6 +9,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -63,6 +64,8 @@ struct uad_model {
     long long seg_off[3], seg_cnt[3];
     float *params, *grads, *adam_m, *adam_v;
     float *wpack_f, *wpack_d;          // k-quad-interleaved copies of the 5x5 kernels (refreshed once per forward)
+    float *wpack16_f, *wpack16_d;      // bf16 hi|lo planes of the same kernels (bf16x3 math mode); 2*nparams ushorts each
+    int math;                          // UAD_MATH_F32 | UAD_MATH_BF16X3
     UadGemmWs ws;                      // split-K slabs for the GEMMs that cannot fill the chip on their own
     bool packed_valid;
     long long step;
@@ -113,6 +116,12 @@ struct ProfScope {
 #define PROF(tag) ProfScope prof_scope_##__LINE__(m, tag, st)
 
 float* P(uad_model* m, long long off) { return m->params + off; }
+// packed-weight views of one 5x5 tensor for the current math mode (the unused one is null)
+const float* PKF(uad_model* m, long long off) { return m->math == UAD_MATH_F32 ? m->wpack_f + off : nullptr; }
+const float* PKD(uad_model* m, long long off) { return m->math == UAD_MATH_F32 ? m->wpack_d + off : nullptr; }
+const unsigned short* PK16F(uad_model* m, long long off) { return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_f + 2 * off : nullptr; }
+const unsigned short* PK16D(uad_model* m, long long off) { return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_d + 2 * off : nullptr; }
+long long PLANE(const ConvLayer& L) { return (long long)L.d.KS * L.d.KS * L.d.CB * L.d.CS; }
 float* Gr(uad_model* m, long long off) { return m->grads + off; }
 
 UadXform bn_xform(uad_model* m, long long gamma, long long beta, float alpha) {
@@ -255,6 +264,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->params, (size_t)m->nparams); ALLOC(m->grads, (size_t)m->nparams);
     ALLOC(m->adam_m, (size_t)m->nparams); ALLOC(m->adam_v, (size_t)m->nparams);
     ALLOC(m->wpack_f, (size_t)m->nparams); ALLOC(m->wpack_d, (size_t)m->nparams);
+    ALLOC(m->wpack16_f, (size_t)m->nparams); ALLOC(m->wpack16_d, (size_t)m->nparams);
+    m->math = UAD_MATH_F32;
     m->packed_valid = false;
     size_t maxact = 0;
     for (auto& L : m->enc) { size_t n = NB * L.d.HS * L.d.WS * L.d.CS; ALLOC(L.c, n); if (n > maxact) maxact = n; }
@@ -384,7 +395,12 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         auto add = [&](const ConvLayer& L) { if (np < 8 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
         for (size_t i = 1; i < m->enc.size(); ++i) add(m->enc[i]);
         for (auto& L : m->dec) add(L);
-        if (np > 0) uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
+        if (np > 0) {
+            if (m->math == UAD_MATH_BF16X3)
+                uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
+            else
+                uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
+        }
         m->packed_valid = true;
     }
     // encoder
@@ -399,7 +415,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         PROF(kEncF[i & 7]);
         UadConvDesc d = m->enc[i].d; d.N = n;
         uad_launch_conv_f(d, m->enc[i - 1].c, bn_xform(m, m->enc[i - 1].gamma, m->enc[i - 1].beta, kLrelu),
-                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, m->wpack_f + m->enc[i].w, m->ws);
+                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, PKF(m, m->enc[i].w), m->ws, PK16F(m, m->enc[i].w), PLANE(m->enc[i]));
     }
     const ConvLayer& EL = m->enc.back();
     // bottleneck
@@ -428,7 +444,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         const float* in = (i == 0) ? m->cb : m->dec[i - 1].c;
         UadXform xf = (i == 0) ? bn_xform(m, m->dbn_g, m->dbn_b, 0.0f)
                                : bn_xform(m, m->dec[i - 1].gamma, m->dec[i - 1].beta, kLrelu);
-        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), m->dec[i].c, epi_bias(P(m, m->dec[i].b)), st, m->wpack_d + m->dec[i].w, m->ws);
+        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), m->dec[i].c, epi_bias(P(m, m->dec[i].b)), st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]));
     }
     // final 1x1 conv + L1 loss (+ start of the backward)
     const ConvLayer& DL = m->dec.back();
@@ -492,7 +508,7 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         // filter gradient: big = d c (raw), small = layer input (activation on load)
         { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wpartial, st); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
-        { PROF(kDecD[i & 7]); uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st, m->wpack_f + m->dec[i].w, m->ws); }
+        { PROF(kDecD[i & 7]); uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
         { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), st); }
         float* tsw = g; g = gn; gn = tsw;
     }
@@ -566,7 +582,7 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
         static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
         static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
         { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wpartial, st); }
-        { PROF(kEncD[i & 7]); uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st, m->wpack_d + m->enc[i].w, m->ws); }
+        { PROF(kEncD[i & 7]); uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i])); }
         { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), st); }
         float* tsw = g; g = gn; gn = tsw;
@@ -611,6 +627,14 @@ int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float be
     if (rc == UAD_OK) rc = uad_adam_step(m, lr, beta1, beta2, eps, 1.0f, stream);
     return rc;
 }
+
+int uad_set_math_mode(uad_model_t* m, int mode) {
+    if (!m || (mode != UAD_MATH_F32 && mode != UAD_MATH_BF16X3)) return fail(UAD_ERR_INVALID, "bad math mode");
+    m->math = mode;
+    m->packed_valid = false;
+    return UAD_OK;
+}
+int uad_get_math_mode(const uad_model_t* m) { return m ? m->math : -1; }
 
 int uad_profile_enable(uad_model_t* m, int on) {
     if (!m) return fail(UAD_ERR_INVALID, "null model");
@@ -670,6 +694,7 @@ static int ws_for_op(const UadConvDesc& d, bool f_type, bool have_pack, UadGemmW
     if (ws->floats) HIP_TRY(hipMalloc((void**)&ws->ptr, ws->floats * sizeof(float)));
     return UAD_OK;
 }
+static bool op_bf16x3() { const char* e = getenv("UAD_MATH"); return e && !strcmp(e, "bf16x3"); }
 static int pack_for_op(const UadConvDesc& d, const float* W, bool f_type, float** pf, float** pd, hipStream_t st) {
     *pf = *pd = nullptr;
     if (!uad_conv_spatial_ok(d, f_type)) return UAD_OK;
@@ -677,9 +702,13 @@ static int pack_for_op(const UadConvDesc& d, const float* W, bool f_type, float*
     HIP_TRY(hipMalloc((void**)pf, n * sizeof(float)));
     HIP_TRY(hipMalloc((void**)pd, n * sizeof(float)));
     long long off = 0; int cb = d.CB, cs = d.CS, taps = d.KS * d.KS;
-    uad_launch_pack_weights(W, *pf, *pd, &off, &cb, &cs, &taps, 1, st);
+    if (op_bf16x3()) uad_launch_pack_weights_bf16(W, (unsigned short*)*pf, (unsigned short*)*pd, &off, &cb, &cs, &taps, 1, st);
+    else uad_launch_pack_weights(W, *pf, *pd, &off, &cb, &cs, &taps, 1, st);
     return UAD_OK;
 }
+// launch arguments for the op-level entry points in the selected math mode
+#define OP_PACK_ARGS(pk, d) (op_bf16x3() ? nullptr : (pk)), ws, (op_bf16x3() ? (const unsigned short*)(pk) : nullptr), \
+                            (long long)(d).KS * (d).KS * (d).CB * (d).CS
 static int finish_op(float* pf, float* pd, hipStream_t st, float* wsp = nullptr) {
     if (pf || pd || wsp) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(pf); (void)hipFree(pd); (void)hipFree(wsp); }
     HIP_TRY(hipGetLastError());
@@ -693,7 +722,7 @@ int uad_op_conv_f(const uad_conv_desc_t* d, const float* big_in, const uad_xform
     if (int rc = pack_for_op(to_desc(d), W, true, &pf, &pd, (hipStream_t)stream)) return rc;
     UadGemmWs ws;
     if (int rc = ws_for_op(to_desc(d), true, pf != nullptr, &ws)) return rc;
-    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream, pf, ws);
+    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pf, *d));
     return finish_op(pf, pd, (hipStream_t)stream, ws.ptr);
 }
 int uad_op_conv_d(const uad_conv_desc_t* d, const float* small_in, const uad_xform_t* xf, const float* W, const float* bias,
@@ -703,7 +732,7 @@ int uad_op_conv_d(const uad_conv_desc_t* d, const float* small_in, const uad_xfo
     if (int rc = pack_for_op(to_desc(d), W, false, &pf, &pd, (hipStream_t)stream)) return rc;
     UadGemmWs ws;
     if (int rc = ws_for_op(to_desc(d), false, pd != nullptr, &ws)) return rc;
-    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream, pd, ws);
+    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pd, *d));
     return finish_op(pf, pd, (hipStream_t)stream, ws.ptr);
 }
 
@@ -727,8 +756,8 @@ static int bwdact_common(bool f_type, const uad_conv_desc_t* dd, const float* in
     hipStream_t st = (hipStream_t)stream;
     float *pf = nullptr, *pd = nullptr;
     if (int rc = pack_for_op(d, W, f_type, &pf, &pd, st)) return rc;
-    if (f_type) uad_launch_conv_f(d, in, no_xform(), W, out, e, st, pf, ws);
-    else uad_launch_conv_d(d, in, no_xform(), W, out, e, st, pd, ws);
+    if (f_type) uad_launch_conv_f(d, in, no_xform(), W, out, e, st, OP_PACK_ARGS(pf, d));
+    else uad_launch_conv_d(d, in, no_xform(), W, out, e, st, OP_PACK_ARGS(pd, d));
     // rstd = 1, gamma unused for dbias=null: dbeta -> s1, dgamma -> s2
     uad_launch_bn_grad_finalize(colpart, T, C, act->scale, 1.0f, s2, s1, nullptr, st);
     HIP_TRY(hipStreamSynchronize(st));

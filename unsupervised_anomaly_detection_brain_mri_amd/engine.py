@@ -26,7 +26,8 @@ class Engine:
     """One AE/VAE instance on one GPU.  Mirrors what a tf.Session + graph holds in the reference
     (trainers/VAE.py:18-29): variables, optimizer slots and the compiled step."""
 
-    def __init__(self, arch, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, device=None):
+    def __init__(self, arch, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, device=None,
+                 math='f32'):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
@@ -52,6 +53,7 @@ class Engine:
             self.spec.append((name.value.decode(), tuple(shape[:rank.value]), int(off.value)))
         self.flat = inter_res * inter_res * (self._cenc() // 8)
         self._views = {}
+        self.set_math(math)
         self.scalars = torch.zeros(4, device=self.device)
 
     def _cenc(self):
@@ -183,6 +185,14 @@ class Engine:
         self.backward(_lib.SEG_ALL)
         self.adam_step(lr, beta1, beta2, adam_eps)
         return out
+
+    def set_math(self, math):
+        """'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 on the bf16 matrix cores, ~2^-17 relative product error)."""
+        modes = {'f32': _lib.MATH_F32, 'bf16x3': _lib.MATH_BF16X3}
+        if math not in modes:
+            raise ValueError(f'unknown math mode {math!r}')
+        _lib.check(self.lib.uad_set_math_mode(self.handle, modes[math]))
+        self.math = math
 
     def profile(self, on):
         _lib.check(self.lib.uad_profile_enable(self.handle, 1 if on else 0))
