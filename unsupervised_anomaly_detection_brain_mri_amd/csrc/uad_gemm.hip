@@ -1463,6 +1463,176 @@ __global__ void __launch_bounds__(256) conv5_w_kernel(const ConvWArgs a, int til
     }
 }
 
+// bf16x3 form of the spatial filter gradient.  The contraction runs over positions, so the MFMA wants 8 consecutive
+// positions per lane for a fixed channel: the small tile is stored transposed ([cs][pos] bf16 planes -> one aligned
+// ds_read_b128 per fragment, shared by the wave's 6-7 taps), the big tile stays [pixel][cb] and each A fragment is
+// gathered with eight 16-bit LDS reads per plane (lane = channel, so a wave reads 64 contiguous bytes per pixel).
+__global__ void __launch_bounds__(256) conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
+    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256;
+    constexpr int LDH = CK + 8;       // ushorts per big-tile pixel
+    constexpr int LDP = TH * TW + 8;  // ushorts per channel row of the transposed small tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned short* bHi = reinterpret_cast<unsigned short*>(dsm);
+    unsigned short* bLo = bHi + IH * IW * LDH;
+    unsigned short* sHiT = bLo + IH * IW * LDH;
+    unsigned short* sLoT = sHiT + CK * LDP;
+    float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const UadConvDesc& d = a.d;
+    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32;
+    const int tilesx = d.WS / TW, tilesy = d.HS / TH;
+    const int t_begin = blockIdx.z * tiles_per_split;
+    const int t_end = min(t_begin + tiles_per_split, total_tiles);
+
+    const int cq = tid % CQ;
+    const bool xfa = a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
+    float4 scA = make_float4(1, 1, 1, 1), shA = make_float4(0, 0, 0, 0), scB = scA, shB = shA;
+    if (xfa) {
+        scA = *reinterpret_cast<const float4*>(a.xfb.scale + cb0 + cq * 4);
+        shA = *reinterpret_cast<const float4*>(a.xfb.shift + cb0 + cq * 4);
+        scA.x *= a.xfb.mult; scA.y *= a.xfb.mult; scA.z *= a.xfb.mult; scA.w *= a.xfb.mult;
+    }
+    if (xfs) {
+        scB = *reinterpret_cast<const float4*>(a.xfs.scale + cs0 + cq * 4);
+        shB = *reinterpret_cast<const float4*>(a.xfs.shift + cs0 + cq * 4);
+        scB.x *= a.xfs.mult; scB.y *= a.xfs.mult; scB.z *= a.xfs.mult; scB.w *= a.xfs.mult;
+    }
+
+    constexpr int MAXT = 7;
+    int aaddr[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+        const int tap = (j < MAXT - 1) ? wave + 4 * j : 24;
+        const int ky = tap / 5, kx = tap % 5;
+        aaddr[j] = ((ky + 2 * lh) * IW + kx) * LDH + l31;   // tile row 2*jstep + lh -> pixel row 4*jstep + 2*lh + ky
+    }
+    const int baddr = l31 * LDP + 8 * lh;
+
+    v16f acc[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    auto gatherA = [&](const unsigned short* plane, int addr) {
+        uint4 r;
+        r.x = (unsigned)plane[addr] | ((unsigned)plane[addr + 2 * LDH] << 16);
+        r.y = (unsigned)plane[addr + 4 * LDH] | ((unsigned)plane[addr + 6 * LDH] << 16);
+        r.z = (unsigned)plane[addr + 8 * LDH] | ((unsigned)plane[addr + 10 * LDH] << 16);
+        r.w = (unsigned)plane[addr + 12 * LDH] | ((unsigned)plane[addr + 14 * LDH] << 16);
+        return r;
+    };
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int tx0 = (t % tilesx) * TW;
+        const int ty0 = ((t / tilesx) % tilesy) * TH;
+        const int n = t / (tilesx * tilesy);
+        const float* bigb = a.big + (size_t)n * d.HB * d.WB * d.CB + cb0;
+        const float* smb = a.small_ + ((size_t)(n * d.HS + ty0) * d.WS + tx0) * d.CS + cs0;
+        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
+        __syncthreads();
+        {
+            constexpr int TOT = IH * IW * CQ;
+            constexpr int BATCH = 6;
+            for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
+                float4 v[BATCH];
+                bool ok[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int f = f0 + u * NT;
+                    const int pix = f / CQ;
+                    const int iy = pix / IW, ix = pix % IW;
+                    const int gy = gy0 + iy, gx = gx0 + ix;
+                    ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
+                    const int gp = ok[u] ? (gy * d.WB + gx) : 0;
+                    v[u] = *reinterpret_cast<const float4*>(bigb + (size_t)gp * d.CB + cq * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int f = f0 + u * NT;
+                    if (f >= TOT) continue;
+                    float4 tv = v[u];
+                    if (xfa) tv = xform4(tv, scA, shA, a.xfb.alpha);
+                    tv = keep4(ok[u], tv);
+                    uint2 hi, lo;
+                    split_bf16(tv, hi, lo);
+                    *reinterpret_cast<uint2*>(bHi + (f / CQ) * LDH + cq * 4) = hi;
+                    *reinterpret_cast<uint2*>(bLo + (f / CQ) * LDH + cq * 4) = lo;
+                }
+            }
+            float4 sv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pos = (tid + u * NT) / CQ;
+                sv[u] = *reinterpret_cast<const float4*>(smb + (size_t)((pos / TW) * d.WS + (pos % TW)) * d.CS + cq * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pos = (tid + u * NT) / CQ;
+                float4 tv = sv[u];
+                if (xfs) tv = xform4(tv, scB, shB, a.xfs.alpha);
+                uint2 hi, lo;
+                split_bf16(tv, hi, lo);
+                unsigned short* ph = sHiT + (cq * 4) * LDP + pos;
+                unsigned short* pl = sLoT + (cq * 4) * LDP + pos;
+                ph[0] = (unsigned short)hi.x; ph[LDP] = (unsigned short)(hi.x >> 16);
+                ph[2 * LDP] = (unsigned short)hi.y; ph[3 * LDP] = (unsigned short)(hi.y >> 16);
+                pl[0] = (unsigned short)lo.x; pl[LDP] = (unsigned short)(lo.x >> 16);
+                pl[2 * LDP] = (unsigned short)lo.y; pl[3 * LDP] = (unsigned short)(lo.y >> 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int js = 0; js < TH * TW / 16; ++js) {
+            // positions 16*js .. 16*js+15 = tile rows 2*js (lanes 0-31) and 2*js+1 (lanes 32-63), tx = element index
+            const uint4 bh = *reinterpret_cast<const uint4*>(sHiT + baddr + 16 * js);
+            const uint4 bl = *reinterpret_cast<const uint4*>(sLoT + baddr + 16 * js);
+            const int cst = (4 * js) * IW * LDH;
+#pragma unroll
+            for (int j = 0; j < MAXT - 1; ++j) {
+                const uint4 ah = gatherA(bHi, aaddr[j] + cst);
+                const uint4 al = gatherA(bLo, aaddr[j] + cst);
+                acc[j] = mfma_bf16(ah, bh, acc[j]);
+                acc[j] = mfma_bf16(ah, bl, acc[j]);
+                acc[j] = mfma_bf16(al, bh, acc[j]);
+            }
+            if (js == wave) {   // wave-uniform: this wave's quarter of tap 24
+                const uint4 ah = gatherA(bHi, aaddr[MAXT - 1] + cst);
+                const uint4 al = gatherA(bLo, aaddr[MAXT - 1] + cst);
+                acc[MAXT - 1] = mfma_bf16(ah, bh, acc[MAXT - 1]);
+                acc[MAXT - 1] = mfma_bf16(ah, bl, acc[MAXT - 1]);
+                acc[MAXT - 1] = mfma_bf16(al, bh, acc[MAXT - 1]);
+            }
+        }
+    }
+
+    float* out = a.partial + (size_t)blockIdx.z * a.Mtot * d.CS;
+#pragma unroll
+    for (int j = 0; j < MAXT - 1; ++j) {
+        const int tap = wave + 4 * j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[((size_t)tap * d.CB + cb) * d.CS + cs0 + l31] = acc[j][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[(wave * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = (sRed[r * 64 + lane] + sRed[(16 + r) * 64 + lane]) + (sRed[(32 + r) * 64 + lane] + sRed[(48 + r) * 64 + lane]);
+            const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[((size_t)24 * d.CB + cb) * d.CS + cs0 + l31] = v;
+        }
+    }
+}
+constexpr size_t conv5_w_bf16_lds_bytes() { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)2 * 32 * 72 * 2; }
+
 struct W5Choice { bool ok; int splits, tiles_per_split, total_tiles; };
 inline W5Choice choose_w5(const UadConvDesc& d) {
     W5Choice c{false, 0, 0, 0};
@@ -1703,7 +1873,7 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
 }
 
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
-                       float* dW, float* partial, hipStream_t st) {
+                       float* dW, float* partial, hipStream_t st, bool math_bf16x3) {
     const W5Choice w5 = choose_w5(d);
     if (w5.ok) {
         ConvWArgs a;
@@ -1711,7 +1881,17 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         a.xfb = xfb; a.xfs = xfs; a.d = d;
         a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = 0; a.lws = a.lhs = -1;
         dim3 grid(d.CB / 32, d.CS / 32, w5.splits);
-        hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
+        if (math_bf16x3) {
+            constexpr size_t lds = conv5_w_bf16_lds_bytes();
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(conv5_w_bf16_kernel, grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+        } else {
+            hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
+        }
         if (w5.splits > 1) uad_launch_reduce_partials(partial, w5.splits, a.Mtot * d.CS, 1.0f, dW, st);
         return;
     }

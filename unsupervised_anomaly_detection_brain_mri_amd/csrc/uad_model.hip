@@ -506,7 +506,7 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         const float ia = (i == 0) ? 0.0f : kLrelu;
         const long long ibias = (i == 0) ? m->rb : m->dec[i - 1].b;
         // filter gradient: big = d c (raw), small = layer input (activation on load)
-        { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wpartial, st); }
+        { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wpartial, st, m->math == UAD_MATH_BF16X3); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
         { PROF(kDecD[i & 7]); uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
         { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), st); }
@@ -581,7 +581,7 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
         const ConvLayer& PL = m->enc[i - 1];
         static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
         static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
-        { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wpartial, st); }
+        { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wpartial, st, m->math == UAD_MATH_BF16X3); }
         { PROF(kEncD[i & 7]); uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i])); }
         { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), st); }
@@ -782,7 +782,7 @@ int uad_op_conv_w(const uad_conv_desc_t* dd, const float* big, const uad_xform_t
     float* partial = nullptr;
     HIP_TRY(hipMalloc((void**)&partial, uad_conv_w_partial_floats(d) * sizeof(float)));
     hipStream_t st = (hipStream_t)stream;
-    uad_launch_conv_w(d, big, to_xf(xfb), small_, to_xf(xfs), dW, partial, st);
+    uad_launch_conv_w(d, big, to_xf(xfb), small_, to_xf(xfs), dW, partial, st, op_bf16x3());
     HIP_TRY(hipStreamSynchronize(st));
     hipFree(partial);
     HIP_TRY(hipGetLastError());
