@@ -1142,14 +1142,18 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, unsigned s
 }
 
 // eligibility + tile choice of the spatial kernels (shared by the launchers and the *_tiles() queries)
-struct SpatialChoice { bool ok; int TH, TW, BN; };
-inline SpatialChoice choose_spatial(const UadConvDesc& d, int CA, int Nn) {
-    SpatialChoice c{false, 0, 0, 0};
+struct SpatialChoice { bool ok; int TH, TW, BN, CK; };
+inline SpatialChoice choose_spatial(const UadConvDesc& d, int CA, int Nn, bool f_type = true) {
+    SpatialChoice c{false, 0, 0, 0, 0};
     if (!(d.KS == 5 && d.S == 2 && d.P == 1)) return c;
     if (d.HB != 2 * d.HS || d.WB != 2 * d.WS) return c;
     if (CA > XF_LDS_CH) return c;
-    if (Nn % 64 == 0 && CA % 32 == 0 && d.HS % 8 == 0 && d.WS % 8 == 0) { c = SpatialChoice{true, 8, 8, 64}; return c; }
-    if (Nn % 32 == 0 && CA % 16 == 0 && d.HS % 8 == 0 && d.WS % 16 == 0) { c = SpatialChoice{true, 8, 16, 32}; return c; }
+    if (Nn % 64 == 0 && CA % 32 == 0 && d.HS % 8 == 0 && d.WS % 8 == 0) { c = SpatialChoice{true, 8, 8, 64, 32}; return c; }
+    // 8x16 tile, 32 output channels: the D-type halo (10x18) is small enough for 32-channel chunks, the F-type one is not
+    if (Nn % 32 == 0 && CA % 16 == 0 && d.HS % 8 == 0 && d.WS % 16 == 0) {
+        c = SpatialChoice{true, 8, 16, 32, (!f_type && CA % 32 == 0) ? 32 : 16};
+        return c;
+    }
     return c;
 }
 
@@ -1715,7 +1719,7 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
     if (!f_type && d.S > 1) { const int t = d.KS / d.S; min_taps = t * t; }
     p.out_rows = f_type ? (int)M : d.N * d.HB * d.WB;
     p.out_elems = (long long)p.out_rows * Nn;
-    p.sc = have_pack ? choose_spatial(d, CA, Nn) : SpatialChoice{false, 0, 0, 0};
+    p.sc = have_pack ? choose_spatial(d, CA, Nn, f_type) : SpatialChoice{false, 0, 0, 0, 0};
     p.nsplit = 1; p.ws_floats = 0;
     const TileChoice t = choose_tile(M, Nn, CA, classes);
     int ns = choose_nsplit(M, Nn, CA, classes, min_taps);
@@ -1724,7 +1728,7 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
         // the spatial kernels want >= 2 workgroups per CU (staging / epilogue of one overlaps the MFMA work of the other);
         // if the plain grid is smaller, split the channel chunks over workgroups (slabs + splitk_epilogue_kernel)
         const long wgs = (long)d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW) * (Nn / p.sc.BN);
-        const int chunks = CA / (p.sc.BN == 64 ? 32 : 16);
+        const int chunks = CA / p.sc.CK;
         int sp = 1;
         while (wgs * sp < 512 && sp * 2 <= chunks && (size_t)(sp * 2) * p.out_elems <= ws_cap) sp *= 2;
         if (wgs * sp >= 512 || wgs * sp >= 256) {
@@ -1747,7 +1751,7 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
 }  // namespace
 
 bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
-    return f_type ? choose_spatial(d, d.CB, d.CS).ok : choose_spatial(d, d.CS, d.CB).ok;
+    return f_type ? choose_spatial(d, d.CB, d.CS, true).ok : choose_spatial(d, d.CS, d.CB, false).ok;
 }
 int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, true, have_pack, ws_floats).tiles; }
 int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, false, have_pack, ws_floats).tiles; }
@@ -1779,6 +1783,7 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
                 else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_F>(a, grid, st);
             } else {
                 if (p.sc.BN == 64) launch_conv5_bf16<8, 8, 32, 2, 2, KIND_D>(a, grid, st);
+                else if (p.sc.CK == 32) launch_conv5_bf16<8, 16, 32, 4, 1, KIND_D>(a, grid, st);
                 else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_D>(a, grid, st);
             }
         } else if (f_type) {
@@ -1786,6 +1791,7 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
             else hipLaunchKernelGGL((conv5_f_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
         } else {
             if (p.sc.BN == 64) hipLaunchKernelGGL((conv5_d_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
+            else if (p.sc.CK == 32) hipLaunchKernelGGL((conv5_d_kernel<8, 16, 32, 4, 1>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv5_d_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
         }
         if (p.nsplit > 1) {
