@@ -5,8 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1]: VAE (variational_autoencoder) 128x128, batch 64 per GPU, computed in fp32
-(the parity bar "1e-4 rel fp32" rules out bf16 arithmetic).  Inputs (x, eps, dropout masks) are
+Workload = BASELINE.json configs[1]: VAE (variational_autoencoder) 128x128 "bf16", batch 64 per GPU.  Plain bf16
+arithmetic cannot meet the north_star parity bar (1e-4 rel vs fp32), so the default math mode is bf16x3: every fp32
+operand is split hi+lo into two bf16 values and a product is hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32
+accumulation (~2^-17 relative error per product; tests/test_gpu_model.py holds it to the same 1e-4 bar as --math f32,
+the exact-fp32-MFMA mode, whose number is reported alongside on 1 GPU).  Inputs (x, eps, dropout masks) are
 resident in HBM before the timed region.  N>1: slice-batch data parallel, weak scaling (64 slices per GPU), the three
 gradient segments are all-reduced over RCCL as soon as each is complete, overlapped with the rest of the backward.
 Prints ONE JSON line on rank 0.
@@ -27,6 +30,7 @@ BATCH = 64
 ZDIM = 128
 INTER = 8
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 dense MFMA peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -108,7 +112,9 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'f32'), choices=['f32', 'bf16x3'])
+    ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'bf16x3'), choices=['f32', 'bf16x3'],
+                    help='bf16x3 (default): split-bf16 products on the bf16 matrix cores, fp32 accumulate, parity 1e-4 vs the '
+                         'fp32 oracle; f32: exact fp32 MFMA')
     args = ap.parse_args()
 
     import torch
@@ -152,50 +158,74 @@ def main():
     def step():
         return dp.train_step(x, eps, masks, lr=1e-4, beta1=0.5, want_l1=True, want_latents=False)
 
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss = float(out['scalars'][2].item())
-    assert np.isfinite(loss) or os.environ.get('UAD_BENCH_ALLOW_NAN'), 'loss diverged'
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        loss = float(out['scalars'][2].item())
+        assert np.isfinite(loss) or os.environ.get('UAD_BENCH_ALLOW_NAN'), 'loss diverged'
+        return dt, loss
 
-    # ---- roofline leg: per-launch-group HIP-event timing of the same step (profiling pass after the timed region)
-    eng.profile(True)
-    prof_steps = max(3, min(args.steps, 10))
-    for _ in range(prof_steps):
-        step()
-    rep = eng.profile_report()
-    eng.profile(False)
-    fl = flops_per_tag(BATCH)
-    gemm = {t: (c, ms) for t, (c, ms) in rep.items() if t in fl}
-    dom = max(gemm, key=lambda t: gemm[t][1])
-    dom_ms = gemm[dom][1] / gemm[dom][0]
-    achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
-    # HBM traffic of the dominant launch group: rocprofv3 PMC passes of this same command, committed under profiles/
-    traffic = None
-    try:
-        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'))).get(dom)
-        if tr:
-            traffic = {'bytes': int(tr['fetch_bytes'] + tr['write_bytes']), 'fetch_bytes': int(tr['fetch_bytes']),
-                       'write_bytes': int(tr['write_bytes']), 'source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)'}
-    except Exception:
+    def profiled(math):
+        """Roofline leg: per-launch-group HIP-event timing of the same step (profiling pass after the timed region)."""
+        eng.profile(True)
+        for _ in range(max(3, min(args.steps, 10))):
+            step()
+        rep = eng.profile_report()
+        eng.profile(False)
+        fl = flops_per_tag(BATCH)
+        gemm = {t: (c, ms) for t, (c, ms) in rep.items() if t in fl}
+        dom = max(gemm, key=lambda t: gemm[t][1])
+        dom_ms = gemm[dom][1] / gemm[dom][0]
+        alg = fl[dom] / (dom_ms * 1e-3) / 1e12            # algorithmic (fp32-equivalent) TFLOP/s
+        if math == 'f32':
+            achieved, peak, note = alg, PEAK_F32_MFMA_TFLOPS, 'v_mfma_f32_32x32x2_f32 (exact fp32)'
+        else:
+            achieved, peak, note = 3.0 * alg, PEAK_BF16_MFMA_TFLOPS, ('3 x v_mfma_f32_32x32x16_bf16 per fp32 product '
+                                                                       '(achieved = executed bf16 FLOP/s = 3 x algorithmic)')
         traffic = None
-    kernels = {t: {'ms': round(ms / c, 4), 'tflops': round(fl[t] / (ms / c * 1e-3) / 1e12, 2) if t in fl else None}
-               for t, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+        try:
+            tr = json.load(open(os.path.join(ROOT, 'profiles', f'r01_traffic_{math}.json'))).get(dom)
+            if tr:
+                traffic = {'bytes': int(tr['fetch_bytes'] + tr['write_bytes']), 'fetch_bytes': int(tr['fetch_bytes']),
+                           'write_bytes': int(tr['write_bytes']),
+                           'source': f'profiles/r01_traffic_{math}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)'}
+        except Exception:
+            traffic = None
+        kernels = {t: {'ms': round(ms / c, 4), 'tflops': round(fl[t] / (ms / c * 1e-3) / 1e12, 2) if t in fl else None}
+                   for t, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(achieved / peak, 4), 'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4),
+                'algorithmic_tflops': round(alg, 2), 'instruction': note}
+        return roof, kernels
+
+    dt, loss = timed(args.steps, args.warmup)
+    roof, kernels = profiled(args.math)
+    # the other math mode, same handle, for the record (rank 0 / single GPU only; not the headline value)
+    other = None
+    if world == 1:
+        om = 'f32' if args.math == 'bf16x3' else 'bf16x3'
+        eng.set_math(om)
+        odt, _ = timed(args.steps, max(2, args.warmup))
+        oroof, _ = profiled(om)
+        other = {'math': om, 'value': round(BATCH * args.steps / odt, 1), 'ms_per_step': round(odt / args.steps * 1e3, 4),
+                 'roofline': oroof}
+        eng.set_math(args.math)
 
     if rank == 0:
         slices = BATCH * world * args.steps
@@ -204,18 +234,20 @@ def main():
             'metric': 'MRI slices/sec VAE train step (128x128, bs=64)',
             'value': round(value, 1), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.math == 'f32' else 'f32 via bf16x3 (split-bf16 MFMA, fp32 accumulate)', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[1]: VAE 128x128x1 slices, batch 64 per GPU, '
                                    'fwd + bwd + TF-Adam (lr 1e-4, beta1 0.5), dropout 0.2, inter_res 8, zDim 128',
+                       'math': args.math + (' = fp32 operands split hi+lo into bf16, hi*hi+hi*lo+lo*hi on the bf16 MFMA, fp32 accumulate; '
+                                            'parity 1e-4 vs the fp32 oracle (tests/test_gpu_model.py)' if args.math == 'bf16x3' else ' = exact fp32 MFMA'),
                        'global_batch': BATCH * world, 'per_gpu_batch': BATCH,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'step_tflops': round(value * train_flops_per_slice() / 1e12, 2), 'final_loss': round(loss, 4)},
-            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
-                         'avg_launch_ms': round(dom_ms, 4),
-                         'whole_step_frac': round(value * train_flops_per_slice() / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             'kernels': kernels,
         }
+        res['roofline'] = roof
+        res['roofline']['whole_step_algorithmic_tflops'] = res['config']['step_tflops']
+        if other:
+            res['other_math_mode'] = other
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))
