@@ -1879,7 +1879,14 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
 }
 
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
-                       float* dW, float* partial, hipStream_t st, bool math_bf16x3) {
+                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev) {
+    // reduce_st/ev (optional): run the split-K slab reduction on a second stream, ordered after the main kernel by `ev`
+    auto hop = [&]() -> hipStream_t {
+        if (!reduce_st) return st;
+        (void)hipEventRecord(ev, st);
+        (void)hipStreamWaitEvent(reduce_st, ev, 0);
+        return reduce_st;
+    };
     const W5Choice w5 = choose_w5(d);
     if (w5.ok) {
         ConvWArgs a;
@@ -1898,7 +1905,7 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         } else {
             hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
         }
-        if (w5.splits > 1) uad_launch_reduce_partials(partial, w5.splits, a.Mtot * d.CS, 1.0f, dW, st);
+        if (w5.splits > 1) uad_launch_reduce_partials(partial, w5.splits, a.Mtot * d.CS, 1.0f, dW, hop());
         return;
     }
     const WChoice c = choose_w(d);
@@ -1916,5 +1923,5 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         hipLaunchKernelGGL((conv_w_kernel<64, 64, 32, 2, 2>), grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((conv_w_kernel<64, 32, 32, 2, 1>), grid, dim3(128), 0, st, a);
-    if (c.splits > 1) uad_launch_reduce_partials(partial, c.splits, a.Mtot * d.CS, 1.0f, dW, st);
+    if (c.splits > 1) uad_launch_reduce_partials(partial, c.splits, a.Mtot * d.CS, 1.0f, dW, hop());
 }

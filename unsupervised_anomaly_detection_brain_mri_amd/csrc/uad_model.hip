@@ -91,6 +91,12 @@ struct uad_model {
     uad_io_t last_io;
     bool have_fwd;
     std::vector<void*> allocs;
+    // second stream + events of the backward pass; per-layer scratch touched by that stream
+    hipStream_t side;
+    std::vector<hipEvent_t> sync_events;
+    size_t ev_next;
+    float* cp_slot[16];
+    float* wp_slot[16];
     // optional per-launch-group HIP-event profiler (uad_profile_*)
     bool prof_on;
     struct ProfRec { const char* tag; hipEvent_t a, b; };
@@ -284,6 +290,9 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     for (auto& L : m->dec) cp_need(NB * L.d.HS * L.d.WS, 1, L.d.CS);
     cp_need(NB * ir * ir, 1, m->cenc);
     m->colpart_cap = cp; ALLOC(m->colpart, cp);
+    for (int k = 0; k < 16; ++k) { m->cp_slot[k] = nullptr; ALLOC(m->cp_slot[k], cp); }
+    m->ev_next = 0; m->side = nullptr;
+    if (rc == UAD_OK && hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) rc = fail(UAD_ERR_HIP, "hipStreamCreate failed");
     size_t wp = 0;
     auto wp_need = [&](UadConvDesc d) { d.N = (int)NB; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
     for (size_t i = 1; i < m->enc.size(); ++i) wp_need(m->enc[i].d);
@@ -292,6 +301,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     wp_need(dense_desc(1, m->flat, cfg->zdim)); wp_need(dense_desc(1, cfg->zdim, m->flat));
     { UadConvDesc d0 = m->enc[0].d; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
     m->wpartial_cap = wp; ALLOC(m->wpartial, wp);
+    for (int k = 0; k < 16; ++k) { m->wp_slot[k] = nullptr; ALLOC(m->wp_slot[k], wp); }
     {
         size_t need = (size_t)4 << 20;
         auto want = [&](UadConvDesc d, bool f, bool pack) { d.N = (int)NB; size_t v = uad_conv_ws_floats(d, f, pack); if (v > need) need = v; };
@@ -317,6 +327,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
 int uad_destroy(uad_model_t* m) {
     if (!m) return UAD_OK;
     for (void* p : m->allocs) hipFree(p);
+    for (hipEvent_t e : m->sync_events) (void)hipEventDestroy(e);
+    if (m->side) (void)hipStreamDestroy(m->side);
     delete m;
     return UAD_OK;
 }
@@ -475,27 +487,49 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// Two streams.  MAIN (the caller's stream) runs every heavy kernel: the data-gradient chain and the k5 s2 filter
+// gradients.  SIDE (handle-owned) runs the small kernels that only finish parameter gradients -- split-K slab
+// reductions, BN/bias finalizes, the bottleneck's dense weight gradients and column sums -- so that they overlap with
+// the next heavy kernel instead of each costing a serialized 4-10 us.  Edges are hipEvents; every segment ends with MAIN
+// waiting for SIDE, so the caller (Adam, or the DP all-reduce of that gradient segment) sees complete gradients.
+// Scratch touched by SIDE is per layer (column partials, split-K slabs), so MAIN never overwrites what SIDE still reads.
+static hipEvent_t next_event(uad_model* m) {
+    if (m->ev_next == m->sync_events.size()) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        m->sync_events.push_back(e);
+    }
+    return m->sync_events[m->ev_next++];
+}
+static void edge(uad_model* m, hipStream_t from, hipStream_t to) {
+    hipEvent_t e = next_event(m);
+    (void)hipEventRecord(e, from);
+    (void)hipStreamWaitEvent(to, e, 0);
+}
+#define PROF_ON(tag, stream) ProfScope prof_scope_s_##__LINE__(m, tag, stream)
+
 static int backward_decoder(uad_model* m, hipStream_t st) {
     const int n = m->last_n;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
+    hipStream_t sd = m->side;
+    const bool bf = m->math == UAD_MATH_BF16X3;
     const ConvLayer& DL = m->dec.back();
     const int C = DL.d.CB;
     const int bps = uad_final_blocks_per_sample(m->cfg.height, m->cfg.width);
-    // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials:
-    // red_partial[T][3C+1] = {dwf[C], S1[C], S2[C], dbf}
     const int T = n * bps, L = 3 * C + 1;
     static const char* kDecW[] = {"dec0.wgrad", "dec1.wgrad", "dec2.wgrad", "dec3.wgrad", "dec4.wgrad", "dec5.wgrad", "dec6.wgrad", "dec7.wgrad"};
     static const char* kDecD[] = {"dec0.dgrad", "dec1.dgrad", "dec2.dgrad", "dec3.dgrad", "dec4.dgrad", "dec5.dgrad", "dec6.dgrad", "dec7.dgrad"};
-    // reuse colscratch [L] for the reduced vector
+    m->ev_next = 0;
+    edge(m, st, sd);   // forward (d c of the last block, loss partials) is complete
     {
-    PROF("final.gradfin");
-    uad_launch_reduce_partials(m->red_partial, T, L, 1.0f, m->colscratch, st);
-    hipMemcpyAsync(Gr(m, m->fw), m->colscratch, C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(Gr(m, m->fb), m->colscratch + 3 * C, sizeof(float), hipMemcpyDeviceToDevice, st);
-    // view {S1,S2} as a single-tile colpart [1][2][C]
-    uad_launch_bn_grad_finalize(m->colscratch + C, 1, C, P(m, DL.gamma), rstd, Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), st);
+        // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials:
+        // red_partial[T][3C+1] = {dwf[C], S1[C], S2[C], dbf}
+        PROF_ON("final.gradfin", sd);
+        uad_launch_reduce_partials(m->red_partial, T, L, 1.0f, m->colscratch, sd);
+        hipMemcpyAsync(Gr(m, m->fw), m->colscratch, C * sizeof(float), hipMemcpyDeviceToDevice, sd);
+        hipMemcpyAsync(Gr(m, m->fb), m->colscratch + 3 * C, sizeof(float), hipMemcpyDeviceToDevice, sd);
+        uad_launch_bn_grad_finalize(m->colscratch + C, 1, C, P(m, DL.gamma), rstd, Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), sd);
     }
-
     float* g = m->G0;      // d loss / d c of dec[i]
     float* gn = m->G1;
     for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
@@ -505,15 +539,18 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         const long long ib = (i == 0) ? m->dbn_b : m->dec[i - 1].beta;
         const float ia = (i == 0) ? 0.0f : kLrelu;
         const long long ibias = (i == 0) ? m->rb : m->dec[i - 1].b;
-        // filter gradient: big = d c (raw), small = layer input (activation on load)
-        { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wpartial, st, m->math == UAD_MATH_BF16X3); }
+        float* cp = m->cp_slot[i];
+        // filter gradient on MAIN (big = d c raw, small = layer input with activation on load); slab reduce on SIDE
+        { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, sd, next_event(m)); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
-        { PROF(kDecD[i & 7]); uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, epi_bwd(m, in, ig, ib, ia), st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
-        { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), st); }
+        { PROF(kDecD[i & 7]); UadEpilogue e = epi_bwd(m, in, ig, ib, ia); e.colpart = cp;
+          uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
+        edge(m, st, sd);   // column partials of this layer are ready
+        { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), sd); }
         float* tsw = g; g = gn; gn = tsw;
     }
-    // g now holds d loss / d cb (pre-BN output of Bottleneck/conv2d_1); remember which buffer
-    m->G0 = g; m->G1 = gn;
+    m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
+    edge(m, sd, st);         // join: decoder gradients complete
     return UAD_OK;
 }
 
@@ -523,73 +560,89 @@ static int backward_bottleneck(uad_model* m, hipStream_t st) {
     const int ir = m->cfg.inter_res, zd = m->cfg.zdim;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
     const uad_io_t& io = m->last_io;
+    hipStream_t sd = m->side;
     float* dcb = m->G0;                         // [n,ir,ir,cenc]
     float* dd = m->g_small[0];                  // [n,flat]
     float* dz = m->g_small[1];
     float* dmu = m->g_small[2];
     float* dls = m->g_small[3];
     float* dflat = m->g_small[4];
-    PROF("bott.bwd");
-    // conv2d_1 (1x1, cmid -> cenc): bias grad came from the decoder stage (BN finalize).
+    float* cp = m->cp_slot[15];
+    float* wp = m->wp_slot[15];                 // SIDE-only slab scratch of the bottleneck weight gradients
+    const UadConvDesc d_r = conv1x1_desc(n, ir, ir, m->cmid, m->cenc);
+    const UadConvDesc d_dec = dense_desc(n, zd, m->flat);
+    const UadConvDesc d_in = dense_desc(n, m->flat, zd);
+    const UadConvDesc d_b = conv1x1_desc(n, ir, ir, m->cenc, m->cmid);
+    const ConvLayer& EL = m->enc.back();
+    edge(m, st, sd);
+    // SIDE: conv2d_1 weight gradient (its bias gradient came from the decoder's BN finalize)
+    { PROF_ON("bott.wgrad", sd); uad_launch_conv_w(d_r, m->dvec, no_xform(), dcb, no_xform(), Gr(m, m->rw), wp, sd); }
     {
-        UadConvDesc d = conv1x1_desc(n, ir, ir, m->cmid, m->cenc);
-        uad_launch_conv_w(d, m->dvec, no_xform(), dcb, no_xform(), Gr(m, m->rw), m->wpartial, st);
-        uad_launch_conv_d(d, dcb, no_xform(), P(m, m->rw), dd, epi_bias(nullptr, vae ? io.mask_dec : nullptr), st, nullptr, m->ws);
+        PROF("bott.bwd");
+        uad_launch_conv_d(d_r, dcb, no_xform(), P(m, m->rw), dd, epi_bias(nullptr, vae ? io.mask_dec : nullptr), st, nullptr, m->ws);
+        edge(m, st, sd);
+        { PROF_ON("bott.wgrad", sd);
+          uad_launch_conv_w(d_dec, m->z, no_xform(), dd, no_xform(), Gr(m, m->dw), wp, sd);
+          uad_launch_colsum(dd, n, m->flat, Gr(m, m->db), m->colscratch, sd); }
+        uad_launch_conv_d(d_dec, dd, no_xform(), P(m, m->dw), dz, epi_bias(nullptr, vae ? nullptr : io.mask_mu), st, nullptr, m->ws);
+        if (vae) {
+            uad_launch_reparam_bwd(n, zd, dz, m->mu, m->sigma, io.eps, io.mask_mu, io.mask_sigma, 1.0f / (float)n, dmu, dls, st);
+            edge(m, st, sd);
+            { PROF_ON("bott.wgrad", sd);
+              uad_launch_conv_w(d_in, m->t, no_xform(), dmu, no_xform(), Gr(m, m->muw), wp, sd);
+              uad_launch_colsum(dmu, n, zd, Gr(m, m->mub), m->colscratch, sd);
+              uad_launch_conv_w(d_in, m->t, no_xform(), dls, no_xform(), Gr(m, m->sgw), wp, sd);
+              uad_launch_colsum(dls, n, zd, Gr(m, m->sgb), m->colscratch, sd); }
+            uad_launch_conv_d(d_in, dmu, no_xform(), P(m, m->muw), m->g_small[5], epi_bias(nullptr), st, nullptr, m->ws);
+            uad_launch_conv_d(d_in, dls, no_xform(), P(m, m->sgw), dflat, epi_bias(nullptr, nullptr, m->g_small[5]), st, nullptr, m->ws);
+        } else {
+            edge(m, st, sd);
+            { PROF_ON("bott.wgrad", sd);
+              uad_launch_conv_w(d_in, m->t, no_xform(), dz, no_xform(), Gr(m, m->muw), wp, sd);
+              uad_launch_colsum(dz, n, zd, Gr(m, m->mub), m->colscratch, sd); }
+            uad_launch_conv_d(d_in, dz, no_xform(), P(m, m->muw), dflat, epi_bias(nullptr), st, nullptr, m->ws);
+        }
+        edge(m, st, sd);
+        { PROF_ON("bott.wgrad", sd);
+          uad_launch_conv_w(d_b, EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu), dflat, no_xform(), Gr(m, m->bw), wp, sd);
+          uad_launch_colsum(dflat, n * ir * ir, m->cmid, Gr(m, m->bb), m->colscratch, sd); }
+        UadEpilogue e = epi_bwd(m, EL.c, EL.gamma, EL.beta, kLrelu); e.colpart = cp;
+        uad_launch_conv_d(d_b, dflat, no_xform(), P(m, m->bw), m->G1, e, st, nullptr, m->ws);
     }
-    // dense_dec
-    {
-        UadConvDesc d = dense_desc(n, zd, m->flat);
-        uad_launch_conv_w(d, m->z, no_xform(), dd, no_xform(), Gr(m, m->dw), m->wpartial, st);
-        uad_launch_colsum(dd, n, m->flat, Gr(m, m->db), m->colscratch, st);
-        uad_launch_conv_d(d, dd, no_xform(), P(m, m->dw), dz, epi_bias(nullptr, vae ? nullptr : io.mask_mu), st, nullptr, m->ws);
-    }
-    UadConvDesc dd_in = dense_desc(n, m->flat, zd);
-    if (vae) {
-        uad_launch_reparam_bwd(n, zd, dz, m->mu, m->sigma, io.eps, io.mask_mu, io.mask_sigma, 1.0f / (float)n, dmu, dls, st);
-        uad_launch_conv_w(dd_in, m->t, no_xform(), dmu, no_xform(), Gr(m, m->muw), m->wpartial, st);
-        uad_launch_colsum(dmu, n, zd, Gr(m, m->mub), m->colscratch, st);
-        uad_launch_conv_w(dd_in, m->t, no_xform(), dls, no_xform(), Gr(m, m->sgw), m->wpartial, st);
-        uad_launch_colsum(dls, n, zd, Gr(m, m->sgb), m->colscratch, st);
-        uad_launch_conv_d(dd_in, dmu, no_xform(), P(m, m->muw), m->g_small[5], epi_bias(nullptr), st, nullptr, m->ws);
-        uad_launch_conv_d(dd_in, dls, no_xform(), P(m, m->sgw), dflat, epi_bias(nullptr, nullptr, m->g_small[5]), st, nullptr, m->ws);
-    } else {
-        uad_launch_conv_w(dd_in, m->t, no_xform(), dz, no_xform(), Gr(m, m->muw), m->wpartial, st);
-        uad_launch_colsum(dz, n, zd, Gr(m, m->mub), m->colscratch, st);
-        uad_launch_conv_d(dd_in, dz, no_xform(), P(m, m->muw), dflat, epi_bias(nullptr), st, nullptr, m->ws);
-    }
-    // Bottleneck/conv2d (1x1, cenc -> cmid): input = act(enc_last.c)
-    {
-        const ConvLayer& EL = m->enc.back();
-        UadConvDesc d = conv1x1_desc(n, ir, ir, m->cenc, m->cmid);
-        uad_launch_conv_w(d, EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu), dflat, no_xform(), Gr(m, m->bw), m->wpartial, st);
-        uad_launch_colsum(dflat, n * ir * ir, m->cmid, Gr(m, m->bb), m->colscratch, st);
-        uad_launch_conv_d(d, dflat, no_xform(), P(m, m->bw), m->G1, epi_bwd(m, EL.c, EL.gamma, EL.beta, kLrelu), st, nullptr, m->ws);
-        uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d, false, m->ws.floats), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma),
-                                    Gr(m, EL.beta), Gr(m, EL.b), st);
-    }
+    edge(m, st, sd);
+    { PROF_ON("bn.gradfin", sd);
+      uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d_b, false, m->ws.floats), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma),
+                                  Gr(m, EL.beta), Gr(m, EL.b), sd); }
     float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;   // G0 = d loss / d c of the last encoder conv
+    edge(m, sd, st);   // join: bottleneck gradients complete (SIDE no longer reads dcb, now G1)
     return UAD_OK;
 }
 
 static int backward_encoder(uad_model* m, hipStream_t st) {
     const int n = m->last_n;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
+    hipStream_t sd = m->side;
+    const bool bf = m->math == UAD_MATH_BF16X3;
     float* g = m->G0;
     float* gn = m->G1;
+    static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
+    static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
     for (int i = (int)m->enc.size() - 1; i >= 1; --i) {
         UadConvDesc d = m->enc[i].d; d.N = n;
         const ConvLayer& PL = m->enc[i - 1];
-        static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
-        static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
-        { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wpartial, st, m->math == UAD_MATH_BF16X3); }
-        { PROF(kEncD[i & 7]); uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu), st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i])); }
-        { PROF("bn.gradfin"); uad_launch_bn_grad_finalize(m->colpart, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
-                                    Gr(m, PL.beta), Gr(m, PL.b), st); }
+        float* cp = m->cp_slot[8 + (i & 7)];
+        { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, sd, next_event(m)); }
+        { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
+          uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i])); }
+        edge(m, st, sd);
+        { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
+                                    Gr(m, PL.beta), Gr(m, PL.b), sd); }
         float* tsw = g; g = gn; gn = tsw;
     }
     UadConvDesc d0 = m->enc[0].d; d0.N = n;
-    { PROF("enc0.wgrad"); uad_launch_conv_first_wgrad(d0, m->last_io.x, g, Gr(m, m->enc[0].w), m->wpartial, st); }
+    { PROF("enc0.wgrad"); uad_launch_conv_first_wgrad(d0, m->last_io.x, g, Gr(m, m->enc[0].w), m->wp_slot[8], st); }
     m->G0 = g; m->G1 = gn;
+    edge(m, sd, st);   // join: all gradients complete
     return UAD_OK;
 }
 

@@ -27,7 +27,7 @@ class Engine:
     (trainers/VAE.py:18-29): variables, optimizer slots and the compiled step."""
 
     def __init__(self, arch, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, device=None,
-                 math='f32'):
+                 math='bf16x3'):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
