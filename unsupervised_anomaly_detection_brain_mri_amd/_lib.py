@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libuad_hip.so')
+LIB_PATH = os.environ.get('UAD_LIB') or os.path.join(_HERE, 'libuad_hip.so')   # UAD_LIB: A/B builds for kernel tuning
 
 UAD_OK = 0
 ARCH_AE, ARCH_VAE = 0, 1
