@@ -1,4 +1,4 @@
-"""Oracle for the dense-bottleneck AE / VAE train step and reconstruct().
+"""Oracle for the dense-bottleneck AE / VAE / ceVAE train step and reconstruct().
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED (no TF).
 
@@ -6,7 +6,9 @@ Restates, with hand-written backward passes:
   models/customlayers.py:16-38          unified encoder / decoder
   models/autoencoder.py:9-40            AE graph
   models/variational_autoencoder.py:9-47 VAE graph
-  trainers/AE.py:28-29, VAE.py:36-42    losses
+  models/context_encoder_variational_autoencoder.py:9-59  ceVAE graph
+  trainers/AE.py:28-29, VAE.py:36-42, ceVAE.py:38-51      losses
+  trainers/CE.py:123-139                host-side context masking
   trainers/DLMODEL.py:112-131           Adam (TF form), beta1 from
                                         utils/default_config_setup.py:257
 Parameter order = TF variable-creation order (Encoder, Bottleneck, Decoder).
@@ -22,9 +24,19 @@ from . import nn
 LRELU_ALPHA = 0.3  # keras LeakyReLU() default, customlayers.py:23,36
 
 
+def dense_names(arch):
+    """Variable scopes of the bottleneck Dense layers.  AE/VAE name them (autoencoder.py:26-27,
+    variational_autoencoder.py:26-28); the ceVAE graph leaves them unnamed
+    (context_encoder_variational_autoencoder.py:30-32), so keras numbers them in construction order."""
+    if arch == 'ceVAE':
+        return {'mu': 'Bottleneck/dense', 'sigma': 'Bottleneck/dense_1', 'dec': 'Bottleneck/dense_2'}
+    return {'mu': 'Bottleneck/dense_mu', 'sigma': 'Bottleneck/dense_sigma', 'z': 'Bottleneck/dense_z',
+            'dec': 'Bottleneck/dense_dec'}
+
+
 def param_spec(arch, height, width, channels, inter_res, zdim):
     """[(name, shape, kind)] in TF variable-creation order."""
-    assert arch in ('AE', 'VAE')
+    assert arch in ('AE', 'VAE', 'ceVAE')
     assert height == width, 'reference derives num_pooling from input_shape[1] only (customlayers.py:18)'
     n_pool = int(math.log(height, 2) - math.log(float(inter_res), 2))
     spec = []
@@ -41,16 +53,17 @@ def param_spec(arch, height, width, channels, inter_res, zdim):
     flat = inter_res * inter_res * cmid
     spec += [('Bottleneck/conv2d/kernel', (1, 1, cenc, cmid), 'conv_w'),
              ('Bottleneck/conv2d/bias', (cmid,), 'bias')]
-    if arch == 'VAE':
-        spec += [('Bottleneck/dense_mu/kernel', (flat, zdim), 'dense_w'),
-                 ('Bottleneck/dense_mu/bias', (zdim,), 'bias'),
-                 ('Bottleneck/dense_sigma/kernel', (flat, zdim), 'dense_w'),
-                 ('Bottleneck/dense_sigma/bias', (zdim,), 'bias')]
+    nm = dense_names(arch)
+    if arch != 'AE':
+        spec += [(nm['mu'] + '/kernel', (flat, zdim), 'dense_w'),
+                 (nm['mu'] + '/bias', (zdim,), 'bias'),
+                 (nm['sigma'] + '/kernel', (flat, zdim), 'dense_w'),
+                 (nm['sigma'] + '/bias', (zdim,), 'bias')]
     else:
-        spec += [('Bottleneck/dense_z/kernel', (flat, zdim), 'dense_w'),
-                 ('Bottleneck/dense_z/bias', (zdim,), 'bias')]
-    spec += [('Bottleneck/dense_dec/kernel', (zdim, flat), 'dense_w'),
-             ('Bottleneck/dense_dec/bias', (flat,), 'bias'),
+        spec += [(nm['z'] + '/kernel', (flat, zdim), 'dense_w'),
+                 (nm['z'] + '/bias', (zdim,), 'bias')]
+    spec += [(nm['dec'] + '/kernel', (zdim, flat), 'dense_w'),
+             (nm['dec'] + '/bias', (flat,), 'bias'),
              ('Bottleneck/conv2d_1/kernel', (1, 1, cmid, cenc), 'conv_w'),
              ('Bottleneck/conv2d_1/bias', (cenc,), 'bias'),
              ('Decoder/batch_normalization/gamma', (cenc,), 'gamma'),
@@ -107,6 +120,8 @@ class Model:
         self.inter, self.zdim = inter_res, zdim
         self.spec = param_spec(arch, height, width, channels, inter_res, zdim)
         self.n_pool = int(math.log(height, 2) - math.log(float(inter_res), 2))
+        self.nm = dense_names(arch)
+        self.variational = arch != 'AE'
 
     # ------------------------------------------------------------------
     def forward(self, p, x, eps=None, masks=None):
@@ -131,9 +146,9 @@ class Model:
         flat = t.reshape(n, -1)  # H,W,C-major flatten
         cache['flat'] = flat
         out = {}
-        if self.arch == 'VAE':
-            mu = nn.dense_fwd(flat, p['Bottleneck/dense_mu/kernel'], p['Bottleneck/dense_mu/bias'])
-            ls = nn.dense_fwd(flat, p['Bottleneck/dense_sigma/kernel'], p['Bottleneck/dense_sigma/bias'])
+        if self.variational:
+            mu = nn.dense_fwd(flat, p[self.nm['mu'] + '/kernel'], p[self.nm['mu'] + '/bias'])
+            ls = nn.dense_fwd(flat, p[self.nm['sigma'] + '/kernel'], p[self.nm['sigma'] + '/bias'])
             if 'mu' in masks:
                 mu = mu * masks['mu']
             if 'sigma' in masks:
@@ -145,13 +160,13 @@ class Model:
             out.update(z_mu=mu, z_log_sigma=ls, z_sigma=sigma)
             cache.update(mu=mu, ls=ls, sigma=sigma, eps=eps)
         else:
-            z = nn.dense_fwd(flat, p['Bottleneck/dense_z/kernel'], p['Bottleneck/dense_z/bias'])
+            z = nn.dense_fwd(flat, p[self.nm['z'] + '/kernel'], p[self.nm['z'] + '/bias'])
             if 'z' in masks:
                 z = z * masks['z']
             out['z'] = z
         cache['z'] = z
-        d = nn.dense_fwd(z, p['Bottleneck/dense_dec/kernel'], p['Bottleneck/dense_dec/bias'])
-        if self.arch == 'VAE' and 'dec' in masks:
+        d = nn.dense_fwd(z, p[self.nm['dec'] + '/kernel'], p[self.nm['dec'] + '/bias'])
+        if self.variational and 'dec' in masks:
             d = d * masks['dec']
         d4 = d.reshape(cache['t_shape'])
         cache['d4'] = d4
@@ -178,7 +193,7 @@ class Model:
         l1 = np.abs(out['x_hat'] - x)
         rec = l1.reshape(x.shape[0], -1).sum(axis=1)
         res = {'L1': l1, 'reconstructionLoss': rec.mean()}
-        if self.arch == 'VAE':
+        if self.variational:
             mu, ls, sg = out['z_mu'], out['z_log_sigma'], out['z_sigma']
             kl = 0.5 * (mu * mu + sg * sg - 2.0 * ls - 1.0).sum(axis=1)
             res['kl'] = kl.mean()
@@ -188,8 +203,9 @@ class Model:
         return res
 
     # ------------------------------------------------------------------
-    def backward(self, p, x, out, cache, masks=None):
-        """Gradient of losses()['loss'] w.r.t. every parameter (dict by name)."""
+    def backward(self, p, x, out, cache, masks=None, kl=True):
+        """Gradient of losses()['loss'] w.r.t. every parameter (dict by name).  kl=False drops the KL term
+        (the ceVAE context branch, whose loss is the reconstruction sum only: trainers/ceVAE.py:43,49)."""
         masks = masks or {}
         n = x.shape[0]
         dt = x.dtype.type
@@ -212,29 +228,30 @@ class Model:
         dd4, g['Bottleneck/conv2d_1/kernel'], g['Bottleneck/conv2d_1/bias'] = \
             nn.conv2d_bwd(cache['d4'], p['Bottleneck/conv2d_1/kernel'], dc, 1)
         dd = dd4.reshape(n, -1)
-        if self.arch == 'VAE' and 'dec' in masks:
+        if self.variational and 'dec' in masks:
             dd = dd * masks['dec']
-        dz, g['Bottleneck/dense_dec/kernel'], g['Bottleneck/dense_dec/bias'] = \
-            nn.dense_bwd(cache['z'], p['Bottleneck/dense_dec/kernel'], dd)
-        if self.arch == 'VAE':
+        dz, g[self.nm['dec'] + '/kernel'], g[self.nm['dec'] + '/bias'] = \
+            nn.dense_bwd(cache['z'], p[self.nm['dec'] + '/kernel'], dd)
+        if self.variational:
             mu, ls, sg, eps = cache['mu'], cache['ls'], cache['sigma'], cache['eps']
             # z = mu + eps*exp(ls); kl_n = 0.5*sum(mu^2 + exp(2 ls) - 2 ls - 1); loss += mean_n kl_n
-            dmu = dz + mu * dt(1.0 / n)
-            dls = dz * eps * sg + (sg * sg - dt(1.0)) * dt(1.0 / n)
+            klw = dt(1.0 / n) if kl else dt(0.0)
+            dmu = dz + mu * klw
+            dls = dz * eps * sg + (sg * sg - dt(1.0)) * klw
             if 'mu' in masks:
                 dmu = dmu * masks['mu']
             if 'sigma' in masks:
                 dls = dls * masks['sigma']
-            df1, g['Bottleneck/dense_mu/kernel'], g['Bottleneck/dense_mu/bias'] = \
-                nn.dense_bwd(cache['flat'], p['Bottleneck/dense_mu/kernel'], dmu)
-            df2, g['Bottleneck/dense_sigma/kernel'], g['Bottleneck/dense_sigma/bias'] = \
-                nn.dense_bwd(cache['flat'], p['Bottleneck/dense_sigma/kernel'], dls)
+            df1, g[self.nm['mu'] + '/kernel'], g[self.nm['mu'] + '/bias'] = \
+                nn.dense_bwd(cache['flat'], p[self.nm['mu'] + '/kernel'], dmu)
+            df2, g[self.nm['sigma'] + '/kernel'], g[self.nm['sigma'] + '/bias'] = \
+                nn.dense_bwd(cache['flat'], p[self.nm['sigma'] + '/kernel'], dls)
             dflat = df1 + df2
         else:
             if 'z' in masks:
                 dz = dz * masks['z']
-            dflat, g['Bottleneck/dense_z/kernel'], g['Bottleneck/dense_z/bias'] = \
-                nn.dense_bwd(cache['flat'], p['Bottleneck/dense_z/kernel'], dz)
+            dflat, g[self.nm['z'] + '/kernel'], g[self.nm['z'] + '/bias'] = \
+                nn.dense_bwd(cache['flat'], p[self.nm['z'] + '/kernel'], dz)
         dt4 = dflat.reshape(cache['t_shape'])
         da, g['Bottleneck/conv2d/kernel'], g['Bottleneck/conv2d/bias'] = \
             nn.conv2d_bwd(cache['enc_out'], p['Bottleneck/conv2d/kernel'], dt4, 1)
@@ -272,6 +289,103 @@ class Model:
         rec = out['x_hat']
         return {'reconstruction': rec, 'l1err': np.sum(np.abs(x - rec)),
                 'l2err': np.sum(np.sqrt((x - rec) ** 2))}
+
+
+class CeVAE(Model):
+    """models/context_encoder_variational_autoencoder.py:9-59 + trainers/ceVAE.py:38-51: the same layer objects
+    run twice -- x through the full VAE path, the masked x_ce through mu only (z_ce = z_mu_ce, no sampling, :37,43).
+    masks: 'mu','sigma','dec' (VAE branch, :36,38,41) and 'mu_ce','dec_ce' (context branch, :37,43)."""
+
+    def __init__(self, height=128, width=128, channels=1, inter_res=8, zdim=128):
+        super().__init__('ceVAE', height, width, channels, inter_res, zdim)
+
+    @staticmethod
+    def _split(masks):
+        masks = masks or {}
+        mv = {k: masks[k] for k in ('mu', 'sigma', 'dec') if k in masks}
+        mc = {k[:-3]: masks[k] for k in ('mu_ce', 'dec_ce') if k in masks}
+        return mv, mc
+
+    def ce_forward(self, p, x, x_ce, eps=None, masks=None):
+        mv, mc = self._split(masks)
+        out_v, cache_v = self.forward(p, x, eps, mv)
+        out_c, cache_c = self.forward(p, x_ce, None, mc)      # eps = 0: z = z_mu_ce
+        out = dict(out_v)
+        out['x_hat_ce'], out['z_mu_ce'] = out_c['x_hat'], out_c['z_mu']
+        return out, (out_v, cache_v, out_c, cache_c)
+
+    def ce_losses(self, x, x_ce, out):
+        """trainers/ceVAE.py:38-50"""
+        n = x.shape[0]
+        l1v = np.abs(out['x_hat'] - x)
+        l1c = np.abs(out['x_hat_ce'] - x_ce)
+        rv = l1v.reshape(n, -1).sum(axis=1)
+        rc = l1c.reshape(n, -1).sum(axis=1)
+        mu, ls, sg = out['z_mu'], out['z_log_sigma'], out['z_sigma']
+        kl = 0.5 * (mu * mu + sg * sg - 2.0 * ls - 1.0).sum(axis=1)
+        return {'L1_vae': l1v, 'L1_ce': l1c, 'L1': 0.5 * (l1v + l1c), 'Rec_ce': rc.mean(), 'Rec_vae': rv.mean(),
+                'reconstructionLoss': 0.5 * (rv + rc).mean(), 'kl': kl.mean(), 'loss': (rv + kl + rc).mean(),
+                'loss_vae': (rv + kl).mean()}
+
+    def ce_backward(self, p, x, x_ce, out, caches, masks=None):
+        """d loss / d params (sum of both branches through the shared variables) and
+        anomaly = L1_vae * |d loss_vae / d x| (trainers/ceVAE.py:51; x enters loss_vae through the encoder AND
+        directly as the L1 label, whose tf.abs gradient is sign(x - x_hat)/N)."""
+        mv, mc = self._split(masks)
+        out_v, cache_v, out_c, cache_c = caches
+        gv = self.backward(p, x, out_v, cache_v, mv, kl=True)
+        gc = self.backward(p, x_ce, out_c, cache_c, mc, kl=False)
+        g = {name: gv[name] + gc[name] for name, _, _ in self.spec}
+        n = x.shape[0]
+        dx = gv['__dx'] + np.sign(x - out['x_hat']) * x.dtype.type(1.0 / n)
+        g['__dx_vae'] = dx
+        g['anomaly'] = np.abs(out['x_hat'] - x) * np.abs(dx)
+        return g
+
+    def ce_train_step(self, p, opt, x, x_ce, eps=None, masks=None, lr=1e-4, beta1=0.5):
+        out, caches = self.ce_forward(p, x, x_ce, eps, masks)
+        ls = self.ce_losses(x, x_ce, out)
+        g = self.ce_backward(p, x, x_ce, out, caches, masks)
+        ls['anomaly'] = g['anomaly']
+        opt['t'] += 1
+        for name, _, _ in self.spec:
+            nn.adam_tf_step(p[name], g[name], opt['m'][name], opt['v'][name], opt['t'], lr, beta1)
+        return out, ls, g
+
+    def ce_reconstruct(self, p, x, eps=None, use_gradient_based_restoration=True):
+        """trainers/ceVAE.py:119-144: x_ce = x, dropout off; 'reconstruction' = x - c*anomaly when c is truthy."""
+        if x.ndim < 4:
+            x = x[None]
+        out, caches = self.ce_forward(p, x, x, eps, None)
+        res = self.ce_losses(x, x, out)
+        res['anomaly'] = self.ce_backward(p, x, x, out, caches)['anomaly']
+        rec = out['x_hat']
+        if use_gradient_based_restoration:
+            rec = x - x.dtype.type(use_gradient_based_restoration) * res['anomaly']
+        res['reconstruction'] = rec
+        res['l1err'] = np.sum(np.abs(x - rec))
+        res['l2err'] = np.sum(np.sqrt((x - rec) ** 2))
+        return res
+
+
+def retrieve_masked_batch(batch, brainmasks, rng):
+    """trainers/CE.py:123-139, INCLUDING its defect: the loop variable shadows the mask array, so
+    `m` after the loop is the LAST sample's [H,W,C] mask and it is broadcast over the whole batch.  `rng` must offer
+    randint(a, b) with both ends inclusive (the reference uses the `random` module)."""
+    ranges = []
+    for bm in brainmasks:
+        px = np.argwhere(bm).T
+        ranges.append(((px[0].min(), px[0].max()), (px[1].min(), px[1].max())))
+    masks = np.ones(batch.shape)
+    m = masks
+    for m, br in zip(masks, ranges):
+        for _ in range(rng.randint(1, 3)):
+            sw, sh = 20, 20
+            if br[0][0] < br[0][1] - sw and br[1][0] < br[1][1] - sh:
+                xx = rng.randint(br[0][0], br[0][1] - sw)
+                yy = rng.randint(br[1][0], br[1][1] - sh)
+                m[xx:xx + sw, yy:yy + sh] = 0
+    return batch * m
 
 
 # ----------------------------------------------------------------------

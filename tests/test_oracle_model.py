@@ -95,3 +95,77 @@ def test_train_steps_decrease_loss_and_match_torch_adam_free_grads():
         losses.append(float(ls['loss']))
     assert losses[-1] < losses[0]
     assert opt['t'] == 15
+
+
+def _setup_ce(h, inter, zdim, n, seed=4, dropout=True):
+    m = ovae.CeVAE(h, h, 1, inter, zdim)
+    p = ovae.init_params(m.spec, seed, np.float64, perturb=True)
+    rng = np.random.default_rng(seed + 1)
+    x = ovae.synthetic_slices(n, h, h, seed, np.float64)
+    x_ce = x.copy()
+    x_ce[:, h // 4:h // 4 + 6, h // 3:h // 3 + 6] = 0
+    eps = rng.standard_normal((n, zdim))
+    flat = inter * inter * (min(128, 32 * 2 ** (m.n_pool - 1)) // 8)
+    masks = {}
+    if dropout:
+        for k, w in (('mu', zdim), ('sigma', zdim), ('dec', flat), ('mu_ce', zdim), ('dec_ce', flat)):
+            masks[k] = onn.make_dropout_mask(rng, (n, w), 0.2, np.float64)
+    return m, p, x, x_ce, eps, masks
+
+
+@pytest.mark.parametrize('h,inter,zdim,n', [(32, 8, 16, 2), (64, 8, 32, 1)])
+def test_cevae_vs_torch(h, inter, zdim, n):
+    """ceVAE restatement (two passes through shared layers, summed gradients, anomaly map) against one autograd
+    graph built like the reference's (context_encoder_variational_autoencoder.py, trainers/ceVAE.py:38-51)."""
+    m, p, x, x_ce, eps, masks = _setup_ce(h, inter, zdim, n)
+    out, caches = m.ce_forward(p, x, x_ce, eps, masks)
+    ls = m.ce_losses(x, x_ce, out)
+    g = m.ce_backward(p, x, x_ce, out, caches, masks)
+
+    tp = torch_ref.to_torch(p)
+    tm = {k: torch.tensor(v) for k, v in masks.items()}
+    tl, xh, xh_ce = torch_ref.cevae_losses(tp, torch.tensor(x), torch.tensor(x_ce), torch.tensor(eps), tm, m.n_pool)
+    tl['loss'].backward()
+    np.testing.assert_allclose(out['x_hat'], xh.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(out['x_hat_ce'], xh_ce.detach().numpy(), rtol=1e-10, atol=1e-12)
+    for k in ('Rec_ce', 'Rec_vae', 'reconstructionLoss', 'kl', 'loss', 'loss_vae'):
+        np.testing.assert_allclose(ls[k], tl[k].item(), rtol=1e-11, err_msg=k)
+    for k in ('L1_vae', 'L1_ce', 'L1'):
+        np.testing.assert_allclose(ls[k], tl[k].detach().numpy(), rtol=1e-10, atol=1e-12, err_msg=k)
+    for name, _, _ in m.spec:
+        np.testing.assert_allclose(g[name], tp[name].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=name)
+    np.testing.assert_allclose(g['anomaly'], tl['anomaly'].numpy(), rtol=1e-8, atol=1e-14)
+
+
+def test_cevae_names_and_reconstruct():
+    m = ovae.CeVAE(128, 128, 1, 8, 128)
+    names = [s[0] for s in m.spec]
+    # unnamed Dense layers are numbered in construction order: mu, sigma, dec (context_encoder_..._autoencoder.py:30-32)
+    assert names[names.index('Bottleneck/conv2d/bias') + 1] == 'Bottleneck/dense/kernel'
+    assert 'Bottleneck/dense_1/kernel' in names and 'Bottleneck/dense_2/bias' in names
+    assert sum(int(np.prod(s[1])) for s in m.spec) == 1758449
+    m, p, x, _, eps, _ = _setup_ce(32, 8, 16, 2, dropout=False)
+    r = m.ce_reconstruct(p, x, eps)
+    assert r['reconstruction'].shape == x.shape
+    np.testing.assert_allclose(r['reconstruction'], x - r['anomaly'])
+    np.testing.assert_allclose(r['l1err'], np.abs(r['anomaly']).sum())
+    r0 = m.ce_reconstruct(p, x, eps, use_gradient_based_restoration=False)
+    out, _ = m.ce_forward(p, x, x, eps)
+    np.testing.assert_allclose(r0['reconstruction'], out['x_hat'])
+
+
+def test_retrieve_masked_batch_replays_reference_defect():
+    """trainers/CE.py:123-139: the returned batch is batch * (LAST sample's mask), broadcast."""
+    import random
+    n, h = 3, 64
+    x = np.ones((n, h, h, 1))
+    bm = np.zeros((n, h, h, 1)); bm[:, 8:56, 10:50] = 1
+    out = ovae.retrieve_masked_batch(x, bm, random.Random(5))
+    assert out.shape == x.shape
+    holes = (out == 0)
+    assert holes.any()
+    for i in range(1, n):
+        assert (holes[i] == holes[0]).all()
+    # holes are unions of 20x20 squares inside the brain bounding box
+    ys, xs = np.nonzero(holes[0, :, :, 0])
+    assert ys.min() >= 8 and ys.max() <= 55 and xs.min() >= 10 and xs.max() <= 49

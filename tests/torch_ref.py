@@ -96,3 +96,61 @@ def forward_loss(arch, spec, params, x_nhwc, eps, masks, inter_res, n_pool):
 
 def to_torch(params_np, dtype=torch.float64, requires_grad=True):
     return {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=requires_grad) for k, v in params_np.items()}
+
+
+def cevae_losses(params, x, x_ce, eps, masks, n_pool):
+    """ceVAE graph written the way the reference builds it (context_encoder_variational_autoencoder.py:9-59): one set
+    of layers applied to x and to x_ce inside ONE autograd graph; losses as trainers/ceVAE.py:38-51.  Returns
+    (losses incl. 'anomaly', x_hat, x_hat_ce); parameter gradients come from losses['loss'].backward()."""
+    rstd = 1.0 / math.sqrt(1.0 + BN_EPS)
+    p = params
+
+    def bn(c, scope):
+        return c * (p[scope + '/gamma'] * rstd).view(1, -1, 1, 1) + p[scope + '/beta'].view(1, -1, 1, 1)
+
+    def encoder(img):
+        a = img.permute(0, 3, 1, 2)
+        for i in range(n_pool):
+            c = _conv_same(a, p[f'Encoder/enc_conv2D_{i}/kernel'], p[f'Encoder/enc_conv2D_{i}/bias'], 2)
+            a = F.leaky_relu(bn(c, f'Encoder/batch_normalization_{i}'), ALPHA)
+        t = _conv_same(a, p['Bottleneck/conv2d/kernel'], p['Bottleneck/conv2d/bias'], 1).permute(0, 2, 3, 1)
+        return t.reshape(t.shape[0], -1), t.shape
+
+    def decoder(z, mask, tshape):
+        d = z @ p['Bottleneck/dense_2/kernel'] + p['Bottleneck/dense_2/bias']
+        if mask is not None:
+            d = d * mask
+        a = _conv_same(d.reshape(tshape).permute(0, 3, 1, 2), p['Bottleneck/conv2d_1/kernel'],
+                       p['Bottleneck/conv2d_1/bias'], 1)
+        a = F.relu(bn(a, 'Decoder/batch_normalization'))
+        for i in range(n_pool):
+            c = _convT_same(a, p[f'Decoder/dec_Conv2DT_{i}/kernel'], p[f'Decoder/dec_Conv2DT_{i}/bias'], 2)
+            a = F.leaky_relu(bn(c, f'Decoder/batch_normalization_{i + 1}'), ALPHA)
+        xh = _conv_same(a, p['Decoder/dec_Conv2D_final/kernel'], p['Decoder/dec_Conv2D_final/bias'], 1)
+        return xh.permute(0, 2, 3, 1)
+
+    x = x.clone().requires_grad_(True)
+    flat, tshape = encoder(x)
+    flat_ce, _ = encoder(x_ce)
+    mu = flat @ p['Bottleneck/dense/kernel'] + p['Bottleneck/dense/bias']
+    mu_ce = flat_ce @ p['Bottleneck/dense/kernel'] + p['Bottleneck/dense/bias']
+    ls = flat @ p['Bottleneck/dense_1/kernel'] + p['Bottleneck/dense_1/bias']
+    if 'mu' in masks:
+        mu = mu * masks['mu']
+    if 'mu_ce' in masks:
+        mu_ce = mu_ce * masks['mu_ce']
+    if 'sigma' in masks:
+        ls = ls * masks['sigma']
+    sg = torch.exp(ls)
+    x_hat = decoder(mu + eps * sg, masks.get('dec'), tshape)
+    x_hat_ce = decoder(mu_ce, masks.get('dec_ce'), tshape)
+    n = x.shape[0]
+    l1v, l1c = (x - x_hat).abs(), (x_ce - x_hat_ce).abs()
+    rv, rc = l1v.reshape(n, -1).sum(dim=1), l1c.reshape(n, -1).sum(dim=1)
+    kl = 0.5 * (mu ** 2 + sg ** 2 - torch.log(sg ** 2) - 1).sum(dim=1)
+    L = {'L1_vae': l1v, 'L1_ce': l1c, 'L1': 0.5 * (l1v + l1c), 'Rec_ce': rc.mean(), 'Rec_vae': rv.mean(),
+         'reconstructionLoss': 0.5 * (rv + rc).mean(), 'kl': kl.mean(), 'loss': (rv + kl + rc).mean(),
+         'loss_vae': (rv + kl).mean()}
+    gx, = torch.autograd.grad(L['loss_vae'], x, retain_graph=True)
+    L['anomaly'] = l1v.detach() * gx.abs()
+    return L, x_hat, x_hat_ce
