@@ -5,6 +5,8 @@
  *
  *   uad_forward / uad_backward / uad_adam_step / uad_train_step
  *       <- trainers/VAE.py:83-96, trainers/AE.py:70-83  (one sess.run({reconstruction, **losses, optimizer}))
+ *          (+ trainers/ceVAE.py:86-117 on models/context_encoder_variational_autoencoder.py:9-59, losses
+ *          trainers/ceVAE.py:38-51)
  *          graph = models/variational_autoencoder.py:9-47 | models/autoencoder.py:9-40 on
  *                  models/customlayers.py:16-38; losses trainers/VAE.py:36-42 | AE.py:28-29;
  *                  optimizer trainers/DLMODEL.py:112-131 (tf.train.AdamOptimizer, beta1 from
@@ -31,7 +33,7 @@ extern "C" {
 #endif
 
 enum { UAD_OK = 0, UAD_ERR_INVALID = 1, UAD_ERR_HIP = 2, UAD_ERR_UNSUPPORTED = 3 };
-enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1 };
+enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1, UAD_ARCH_CEVAE = 2 };
 enum { UAD_BUF_PARAMS = 0, UAD_BUF_GRADS = 1, UAD_BUF_ADAM_M = 2, UAD_BUF_ADAM_V = 3 };
 enum { UAD_SEG_DECODER = 0, UAD_SEG_BOTTLENECK = 1, UAD_SEG_ENCODER = 2, UAD_SEG_ALL = -1 };
 /* arithmetic of the k5 s2 forward / data-gradient contractions: exact fp32 MFMA (default), or split-bf16 (x = hi + lo,
@@ -62,8 +64,17 @@ typedef struct {
     float* z_mu;             /* out [n,zdim] (AE: z), may be NULL                                    */
     float* z_log_sigma;      /* out [n,zdim] VAE, may be NULL                                        */
     float* z_sigma;          /* out [n,zdim] VAE, may be NULL                                        */
-    float* scalars;          /* out [4] reconstructionLoss, kl, loss, 0  (means over the n samples)  */
-    float* rec_per_sample;   /* out [n] sum_hwc L1, may be NULL                                      */
+    float* scalars;          /* out [8] reconstructionLoss, kl, loss, 0, Rec_vae, Rec_ce, loss_vae, 0
+                                     (means over the n samples; [4..6] are written for ceVAE only)       */
+    float* rec_per_sample;   /* out [n] sum_hwc L1 (ceVAE: [2n], VAE branch then context branch), may be NULL */
+    /* ---- ceVAE only (models/context_encoder_variational_autoencoder.py:9-59); NULL / ignored otherwise ---- */
+    const float* x_ce;       /* in  [n,H,W,C] context-masked input (trainers/CE.py:123-139); NULL = x */
+    const float* mask_mu_ce; /* in  [n,zdim] keep-mask on z_mu_ce (:37); given iff mask_mu is         */
+    const float* mask_dec_ce;/* in  [n,flat] keep-mask on dec_dense(z_mu_ce) (:43); given iff mask_dec is */
+    float* x_hat_ce;         /* out [n,H,W,C] reconstruction of the context branch, may be NULL      */
+    float* l1_map_ce;        /* out [n,H,W,C] |x_hat_ce - x_ce|, may be NULL                         */
+    float* anomaly;          /* out [n,H,W,C] L1_vae * |d loss_vae / d x| (trainers/ceVAE.py:51); written by
+                                     uad_backward's ENCODER segment, may be NULL                          */
 } uad_io_t;
 
 const char* uad_last_error(void);
@@ -93,7 +104,10 @@ long long uad_get_step(const uad_model_t* m);
 int uad_set_step(uad_model_t* m, long long t);
 
 /* forward pass + losses.  want_backward != 0 additionally keeps what uad_backward needs and starts the backward
- * (d loss / d c of the last decoder block is produced by the fused loss kernel). */
+ * (d loss / d c of the last decoder block is produced by the fused loss kernel).  want_backward == 2 asks for the
+ * data-gradient chain only (ceVAE validation / reconstruct: the anomaly map needs d loss_vae / d x but no parameter
+ * gradient); the following uad_backward then leaves UAD_BUF_GRADS untouched.
+ * ceVAE runs both branches as one 2n-sample pass through the shared layers (VAE-branch samples first). */
 int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, void* stream);
 /* gradient of `loss` w.r.t. every parameter into the UAD_BUF_GRADS buffer; segment = UAD_SEG_* (call DECODER,
  * BOTTLENECK, ENCODER in that order, or UAD_SEG_ALL). */

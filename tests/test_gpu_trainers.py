@@ -88,3 +88,62 @@ def test_evaluation_driver_runs_and_scores(tmp_path):
     d, l1 = Evaluation.evaluate_volume(model, vols[0], masks[0], {**opt, 'medianFiltering': False})
     assert d.shape == vols[0].shape and (d >= 0).all() and np.isfinite(l1).all()
     model.engine.close()
+
+
+def test_cevae_trainer_surface_and_oracle_step(tmp_path):
+    """trainers/ceVAE.py: Config, train/process (context masking on the host, x_ce = batch outside TRAIN), the fetch keys
+    of one step, reconstruct() with gradient-based restoration -- and one injected-RNG step against the oracle."""
+    from unsupervised_anomaly_detection_brain_mri_amd.models import context_encoder_variational_autoencoder as net
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import ceVAE
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers.CE import retrieve_masked_batch
+    cfg, opt, ds = _config(ceVAE, tmp_path, h=64, bs=4, epochs=2)
+    assert cfg.modelname == 'ceVAE' and cfg.use_gradient_based_restoration is True
+    cfg.learningrate = 2e-4
+    model = ceVAE(None, cfg, network=net)
+    assert model.model_dir == 'ceVAE_dSyntheticDataset_s64x64_context_encoder_variational_autoencoder_b4_z64_'
+
+    # one TRAIN step with injected eps / masks / masked batch == oracle ce_train_step on the same weights
+    m = ovae.CeVAE(64, 64, 1, 8, 64)
+    p64 = {k: np.asarray(v, np.float64) for k, v in model.engine.get_params().items()}
+    opt_state = m.new_opt(p64)
+    batch, _, bm = ds.next_batch(4, set='TRAIN', return_brainmask=True)
+    import random
+    xce = retrieve_masked_batch(batch, bm, random.Random(3))
+    assert (xce == 0).sum() > (batch == 0).sum()
+    eps, masks = model._draw(4, dropout=True)
+    assert set(masks) == {'mu', 'mu_ce', 'sigma', 'dec', 'dec_ce'}
+    run = model.step(batch, Phase.TRAIN, masked_batch=xce, eps=eps, dropout_masks=masks)
+    assert set(run) == {'reconstruction', 'reconstruction_ce', 'L1_vae', 'L1_ce', 'L1', 'Rec_ce', 'Rec_vae',
+                        'reconstructionLoss', 'kl', 'loss', 'loss_vae', 'anomaly'}
+    _, ls, g = m.ce_train_step(p64, opt_state, batch.astype(np.float64), xce.astype(np.float64), eps.astype(np.float64),
+                               {k: v.astype(np.float64) for k, v in masks.items()}, lr=cfg.learningrate, beta1=0.5)
+    for k in ('Rec_ce', 'Rec_vae', 'reconstructionLoss', 'kl', 'loss', 'loss_vae'):
+        assert run[k] == pytest.approx(ls[k], rel=1e-4), k
+    assert np.abs(run['anomaly'] - g['anomaly']).max() <= 3e-4 * np.abs(g['anomaly']).max()
+    assert np.abs(run['L1'] - ls['L1']).max() <= 2e-4 * np.abs(ls['L1']).max()
+    flat = model.engine.get_buffer_host(_lib.BUF_PARAMS)
+    ref = ovae.flatten_params(m.spec, p64)
+    assert np.abs(flat - ref).max() <= 1e-4 * np.abs(ref).max()
+
+    # VAL step: x_ce = batch, no dropout, anomaly still fetched (it sits in self.losses)
+    v = model.step(batch, Phase.VAL, masked_batch=xce, eps=eps)
+    out, caches = m.ce_forward(p64, batch.astype(np.float64), batch.astype(np.float64), eps.astype(np.float64))
+    lv = m.ce_losses(batch.astype(np.float64), batch.astype(np.float64), out)
+    assert v['loss'] == pytest.approx(lv['loss'], rel=2e-4) and v['Rec_ce'] == pytest.approx(lv['Rec_ce'], rel=2e-4)
+
+    # train(): epoch loop with host masking, checkpoints, early-stopping bookkeeping
+    model.train(ds)
+    assert len(model.curves['TRAIN/loss']) == 2 and len(model.curves['VAL/loss_vae']) == 2
+    assert model.curves['TRAIN/loss'][1] < model.curves['TRAIN/loss'][0]
+    ck = os.path.join(model.checkpointDir, model.model_dir)
+    assert os.path.isfile(os.path.join(ck, 'ceVAE.model-2.npz'))
+
+    # reconstruct(): 'reconstruction' = x - anomaly (use_gradient_based_restoration), l1err = sum |anomaly|
+    x = ds.next_batch(2, set='VAL')[0]
+    r = model.reconstruct(x, eps=0.0)
+    assert np.allclose(r['reconstruction'], x - r['anomaly'])
+    assert r['l1err'] == pytest.approx(np.abs(r['anomaly']).sum(), rel=1e-5)
+    model.config.use_gradient_based_restoration = False
+    r0 = model.reconstruct(x, eps=0.0)
+    assert not np.allclose(r0['reconstruction'], r['reconstruction'])
+    model.engine.close()

@@ -96,3 +96,20 @@ def test_synthetic_dataset_duck_type():
     x = synthetic_slices(4, 64, 64, seed=1)
     frac = (x > 0).mean()
     assert 0.3 < frac < 0.6 and x[:, 0, 0, 0].max() == 0.0
+
+
+def test_retrieve_masked_batch_matches_reference_golden():
+    """tests/golden/cemask_golden.npz = outputs of the reference's trainers/CE.py:retrieve_masked_batch on seeded
+    inputs (made by tests/golden/make_cemask_golden.py).  The oracle restatement and the product's trainers/CE.py must
+    both replay them exactly, 32x32 'box too small for a 20x20 square' case included."""
+    import random
+    from oracle import vae as ovae
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers.CE import retrieve_masked_batch
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'cemask_golden.npz'))
+    for i in range(4):
+        bm, seed, holes = g[f'bm{i}'], int(g[f'seed{i}']), g[f'holes{i}']
+        x = np.ones(bm.shape)
+        a = ovae.retrieve_masked_batch(x, bm, random.Random(seed))
+        b = retrieve_masked_batch(x.astype(np.float32), bm, random.Random(seed))
+        assert np.array_equal(a == 0, holes), i
+        assert np.array_equal(b == 0, holes), i

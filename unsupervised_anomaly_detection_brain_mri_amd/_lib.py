@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('UAD_LIB') or os.path.join(_HERE, 'libuad_hip.so')   # UAD_LIB: A/B builds for kernel tuning
 
 UAD_OK = 0
-ARCH_AE, ARCH_VAE = 0, 1
+ARCH_AE, ARCH_VAE, ARCH_CEVAE = 0, 1, 2
 BUF_PARAMS, BUF_GRADS, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
 SEG_DECODER, SEG_BOTTLENECK, SEG_ENCODER, SEG_ALL = 0, 1, 2, -1
 MATH_F32, MATH_BF16X3 = 0, 1
@@ -24,7 +24,10 @@ class UadIO(C.Structure):
     _fields_ = [('x', C.c_void_p), ('eps', C.c_void_p), ('mask_mu', C.c_void_p), ('mask_sigma', C.c_void_p),
                 ('mask_dec', C.c_void_p), ('x_hat', C.c_void_p), ('l1_map', C.c_void_p), ('z_mu', C.c_void_p),
                 ('z_log_sigma', C.c_void_p), ('z_sigma', C.c_void_p), ('scalars', C.c_void_p),
-                ('rec_per_sample', C.c_void_p)]
+                ('rec_per_sample', C.c_void_p),
+                # ceVAE only
+                ('x_ce', C.c_void_p), ('mask_mu_ce', C.c_void_p), ('mask_dec_ce', C.c_void_p),
+                ('x_hat_ce', C.c_void_p), ('l1_map_ce', C.c_void_p), ('anomaly', C.c_void_p)]
 
 
 class UadConvDesc(C.Structure):

@@ -117,18 +117,22 @@ struct UadFinalArgs {
 int uad_final_blocks_per_sample(int H, int W);
 void uad_launch_final_fwd_bwd(const UadFinalArgs& a, hipStream_t st);
 
-// reparameterisation + KL (VAE bottleneck)
-void uad_launch_reparam_fwd(int n, int zdim, const float* mu_raw, const float* ls_raw, const float* mask_mu,
-                            const float* mask_ls, const float* eps, float* mu, float* ls, float* sigma, float* z,
-                            float* kl_per_sample, hipStream_t st);
-void uad_launch_reparam_bwd(int n, int zdim, const float* dz, const float* mu, const float* sigma, const float* eps,
-                            const float* mask_mu, const float* mask_ls, float inv_batch, float* dmu_raw,
-                            float* dls_raw, hipStream_t st);
+// reparameterisation + KL (VAE bottleneck).  Samples [n_vae, n) are the ceVAE context branch: z = mu (masked by
+// mask_mu_ce, indexed from 0), no noise, no KL, zero log-sigma gradient.
+void uad_launch_reparam_fwd(int n, int n_vae, int zdim, const float* mu_raw, const float* ls_raw, const float* mask_mu,
+                            const float* mask_ls, const float* mask_mu_ce, const float* eps, float* mu, float* ls,
+                            float* sigma, float* z, float* kl_per_sample, hipStream_t st);
+void uad_launch_reparam_bwd(int n, int n_vae, int zdim, const float* dz, const float* mu, const float* sigma,
+                            const float* eps, const float* mask_mu, const float* mask_ls, const float* mask_mu_ce,
+                            float inv_batch, float* dmu_raw, float* dls_raw, hipStream_t st);
+// ceVAE: data gradient of the first conv (d.N samples) + direct L1-label term -> anomaly = |x-x_hat| * |d loss_vae/dx|
+void uad_launch_conv_first_dgrad(const UadConvDesc& d, const float* g, const float* W, const float* x,
+                                 const float* x_hat, float inv_batch, float* anomaly, float* dx, hipStream_t st);
 // y = x * mask (mask may be null -> copy)
 void uad_launch_mul(const float* x, const float* mask, float* y, size_t n, hipStream_t st);
-// scalars[0]=reconstructionLoss, [1]=kl, [2]=loss  (means over the LOCAL batch * local_weight)
-void uad_launch_loss_finalize(const float* rec_partial, int n, int bps, const float* kl_per_sample, float inv_batch,
-                              float* rec_per_sample, float* scalars, hipStream_t st);
+// scalars[8] = {reconstructionLoss, kl, loss, 0, Rec_vae, Rec_ce, loss_vae, 0}; samples [n_vae, n) = ceVAE context branch
+void uad_launch_loss_finalize(const float* rec_partial, int n, int n_vae, int bps, const float* kl_per_sample,
+                              float inv_batch, float rec_scale, float* rec_per_sample, float* scalars, hipStream_t st);
 
 // TF-form Adam over a flat parameter buffer: g is multiplied by gscale first
 void uad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2,

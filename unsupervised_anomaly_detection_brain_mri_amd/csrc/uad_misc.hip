@@ -306,18 +306,28 @@ __global__ void __launch_bounds__(256) final_kernel(const UadFinalArgs a, int pi
 // reference: models/variational_autoencoder.py:31-34 ; trainers/VAE.py:38 (KL with log(sigma^2) = 2 log_sigma)
 // one wavefront per sample
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) reparam_fwd_kernel(int zdim, const float* __restrict__ mu_raw,
+__global__ void __launch_bounds__(64) reparam_fwd_kernel(int zdim, int n_vae, const float* __restrict__ mu_raw,
                                                          const float* __restrict__ ls_raw,
                                                          const float* __restrict__ mask_mu,
                                                          const float* __restrict__ mask_ls,
+                                                         const float* __restrict__ mask_mu_ce,
                                                          const float* __restrict__ eps, float* __restrict__ mu,
                                                          float* __restrict__ ls, float* __restrict__ sigma,
                                                          float* __restrict__ z, float* __restrict__ kl) {
     const int n = blockIdx.x;
+    // samples >= n_vae are the ceVAE context branch: z = z_mu_ce, no sampling, no KL
+    // (context_encoder_variational_autoencoder.py:37,43); their log-sigma head is never used.
+    const bool ctx = n >= n_vae;
     float acc = 0.f;
     for (int k = threadIdx.x; k < zdim; k += 64) {
         const size_t i = (size_t)n * zdim + k;
-        float m = mu_raw[i], l = ls_raw[i];
+        float m = mu_raw[i];
+        if (ctx) {
+            if (mask_mu_ce) m *= mask_mu_ce[(size_t)(n - n_vae) * zdim + k];
+            mu[i] = m; ls[i] = 0.f; sigma[i] = 1.f; z[i] = m;
+            continue;
+        }
+        float l = ls_raw[i];
         if (mask_mu) m *= mask_mu[i];
         if (mask_ls) l *= mask_ls[i];
         const float s = expf(l);
@@ -330,13 +340,21 @@ __global__ void __launch_bounds__(64) reparam_fwd_kernel(int zdim, const float* 
     if (threadIdx.x == 0) kl[n] = 0.5f * acc;
 }
 
-__global__ void reparam_bwd_kernel(size_t total, const float* __restrict__ dz, const float* __restrict__ mu,
-                                   const float* __restrict__ sigma, const float* __restrict__ eps,
-                                   const float* __restrict__ mask_mu, const float* __restrict__ mask_ls,
+__global__ void reparam_bwd_kernel(size_t total, int zdim, int n_vae, const float* __restrict__ dz,
+                                   const float* __restrict__ mu, const float* __restrict__ sigma,
+                                   const float* __restrict__ eps, const float* __restrict__ mask_mu,
+                                   const float* __restrict__ mask_ls, const float* __restrict__ mask_mu_ce,
                                    float inv_batch, float* __restrict__ dmu_raw, float* __restrict__ dls_raw) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const float g = dz[i], s = sigma[i];
+    const size_t n = i / zdim;
+    const float g = dz[i];
+    if (n >= (size_t)n_vae) {
+        dmu_raw[i] = mask_mu_ce ? g * mask_mu_ce[i - (size_t)n_vae * zdim] : g;
+        dls_raw[i] = 0.f;
+        return;
+    }
+    const float s = sigma[i];
     const float e = eps ? eps[i] : 0.f;
     float dm = g + mu[i] * inv_batch;
     float dl = g * e * s + (s * s - 1.f) * inv_batch;
@@ -351,30 +369,88 @@ __global__ void mul_kernel(const float* __restrict__ x, const float* __restrict_
     if (i < n) y[i] = mask ? x[i] * mask[i] : x[i];
 }
 
-// rec_per_sample[n] = sum_b rec_partial[n][b]; scalars = {mean rec, mean kl, mean (rec+kl)}
-__global__ void __launch_bounds__(256) loss_finalize_kernel(const float* __restrict__ rec_partial, int n, int bps,
-                                                            const float* __restrict__ kl, float inv_batch,
-                                                            float* __restrict__ rec_per_sample,
+// rec_per_sample[i] = sum_b rec_partial[i][b].  Samples [0,n_vae) carry the VAE-branch losses, [n_vae,n) the ceVAE context
+// branch (none for AE/VAE).  scalars = {reconstructionLoss, kl, loss, 0, Rec_vae, Rec_ce, loss_vae, 0}, all divided by the
+// user batch (inv_batch); reconstructionLoss = rec_scale * (Rec_vae + Rec_ce)   (trainers/ceVAE.py:45-50)
+__global__ void __launch_bounds__(256) loss_finalize_kernel(const float* __restrict__ rec_partial, int n, int n_vae,
+                                                            int bps, const float* __restrict__ kl, float inv_batch,
+                                                            float rec_scale, float* __restrict__ rec_per_sample,
                                                             float* __restrict__ scalars) {
-    __shared__ float sr[256], sk[256];
-    float ar = 0.f, ak = 0.f;
+    __shared__ float sr[256], sc[256], sk[256];
+    float ar = 0.f, ac = 0.f, ak = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
         float r = 0.f;
         for (int b = 0; b < bps; ++b) r += rec_partial[(size_t)i * bps + b];
         rec_per_sample[i] = r;
-        ar += r;
-        if (kl) ak += kl[i];
+        if (i < n_vae) { ar += r; if (kl) ak += kl[i]; }
+        else ac += r;
     }
     sr[threadIdx.x] = ar;
+    sc[threadIdx.x] = ac;
     sk[threadIdx.x] = ak;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float tr = 0.f, tk = 0.f;
-        for (int i = 0; i < 256; ++i) { tr += sr[i]; tk += sk[i]; }
-        scalars[0] = tr * inv_batch;
+        float tr = 0.f, tc = 0.f, tk = 0.f;
+        for (int i = 0; i < 256; ++i) { tr += sr[i]; tc += sc[i]; tk += sk[i]; }
+        scalars[0] = rec_scale * (tr + tc) * inv_batch;
         scalars[1] = tk * inv_batch;
-        scalars[2] = (tr + tk) * inv_batch;
+        scalars[2] = (tr + tk + tc) * inv_batch;
+        scalars[3] = 0.f;
+        scalars[4] = tr * inv_batch;
+        scalars[5] = tc * inv_batch;
+        scalars[6] = (tr + tk) * inv_batch;
+        scalars[7] = 0.f;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ceVAE anomaly map (trainers/ceVAE.py:51): anomaly = |x - x_hat| * |d loss_vae / d x| with
+//   d loss_vae / d x = (data gradient of the first encoder conv) + sign(x - x_hat) / N      (x is also the L1 label)
+// One thread per input pixel; it gathers the <= 3x3 output pixels whose 5x5 s2 window covers it (CB = 1).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_first_dgrad_kernel(UadConvDesc d, const float* __restrict__ g,
+                                                               const float* __restrict__ W,
+                                                               const float* __restrict__ x,
+                                                               const float* __restrict__ x_hat, float inv_batch,
+                                                               float* __restrict__ anomaly, float* __restrict__ dx_out) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];     // [KS*KS][CS]
+    const int CS = d.CS, KS = d.KS, S = d.S, P = d.P;
+    for (int i = threadIdx.x; i < KS * KS * CS; i += 256) sw[i] = W[i];
+    __syncthreads();
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)d.N * d.HB * d.WB;
+    if (pix >= total) return;
+    const int xx = (int)(pix % d.WB);
+    const int yy = (int)((pix / d.WB) % d.HB);
+    const int n = (int)(pix / ((size_t)d.WB * d.HB));
+    float acc = 0.f;
+    for (int ky = 0; ky < KS; ++ky) {
+        const int ty = yy + P - ky;
+        if (ty < 0 || ty % S) continue;
+        const int i = ty / S;
+        if (i >= d.HS) continue;
+        for (int kx = 0; kx < KS; ++kx) {
+            const int tx = xx + P - kx;
+            if (tx < 0 || tx % S) continue;
+            const int j = tx / S;
+            if (j >= d.WS) continue;
+            const float4* gp = reinterpret_cast<const float4*>(g + ((size_t)(n * d.HS + i) * d.WS + j) * CS);
+            const float4* wp = reinterpret_cast<const float4*>(sw + (ky * KS + kx) * CS);
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < CS / 4; c += 2) {
+                const float4 g0 = gp[c], g1 = gp[c + 1];
+                const float4 w0 = wp[c], w1 = wp[c + 1];
+                a0 = fmaf(g0.x, w0.x, a0); a0 = fmaf(g0.y, w0.y, a0); a0 = fmaf(g0.z, w0.z, a0); a0 = fmaf(g0.w, w0.w, a0);
+                a1 = fmaf(g1.x, w1.x, a1); a1 = fmaf(g1.y, w1.y, a1); a1 = fmaf(g1.z, w1.z, a1); a1 = fmaf(g1.w, w1.w, a1);
+            }
+            acc += a0 + a1;
+        }
+    }
+    const float diff = x[pix] - x_hat[pix];
+    const float gx = acc + (diff > 0.f ? inv_batch : (diff < 0.f ? -inv_batch : 0.f));
+    if (dx_out) dx_out[pix] = gx;
+    if (anomaly) anomaly[pix] = fabsf(diff) * fabsf(gx);
 }
 
 // TF-1.15 AdamOptimizer update (trainers/DLMODEL.py:112-131): lr_t is computed on the host.
@@ -500,26 +576,32 @@ void uad_launch_final_fwd_bwd(const UadFinalArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((final_kernel<false>), grid, dim3(256), 0, st, a, ppb);
 }
 
-void uad_launch_reparam_fwd(int n, int zdim, const float* mu_raw, const float* ls_raw, const float* mask_mu,
-                            const float* mask_ls, const float* eps, float* mu, float* ls, float* sigma, float* z,
-                            float* kl_per_sample, hipStream_t st) {
-    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(n), dim3(64), 0, st, zdim, mu_raw, ls_raw, mask_mu, mask_ls, eps, mu,
-                       ls, sigma, z, kl_per_sample);
+void uad_launch_reparam_fwd(int n, int n_vae, int zdim, const float* mu_raw, const float* ls_raw, const float* mask_mu,
+                            const float* mask_ls, const float* mask_mu_ce, const float* eps, float* mu, float* ls,
+                            float* sigma, float* z, float* kl_per_sample, hipStream_t st) {
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(n), dim3(64), 0, st, zdim, n_vae, mu_raw, ls_raw, mask_mu, mask_ls,
+                       mask_mu_ce, eps, mu, ls, sigma, z, kl_per_sample);
 }
-void uad_launch_reparam_bwd(int n, int zdim, const float* dz, const float* mu, const float* sigma, const float* eps,
-                            const float* mask_mu, const float* mask_ls, float inv_batch, float* dmu_raw,
-                            float* dls_raw, hipStream_t st) {
+void uad_launch_reparam_bwd(int n, int n_vae, int zdim, const float* dz, const float* mu, const float* sigma,
+                            const float* eps, const float* mask_mu, const float* mask_ls, const float* mask_mu_ce,
+                            float inv_batch, float* dmu_raw, float* dls_raw, hipStream_t st) {
     const size_t total = (size_t)n * zdim;
-    hipLaunchKernelGGL(reparam_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, total, dz, mu, sigma, eps,
-                       mask_mu, mask_ls, inv_batch, dmu_raw, dls_raw);
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, total, zdim, n_vae, dz, mu,
+                       sigma, eps, mask_mu, mask_ls, mask_mu_ce, inv_batch, dmu_raw, dls_raw);
+}
+void uad_launch_conv_first_dgrad(const UadConvDesc& d, const float* g, const float* W, const float* x,
+                                 const float* x_hat, float inv_batch, float* anomaly, float* dx, hipStream_t st) {
+    const size_t total = (size_t)d.N * d.HB * d.WB;
+    hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3((total + 255) / 256), dim3(256),
+                       (size_t)d.KS * d.KS * d.CS * sizeof(float), st, d, g, W, x, x_hat, inv_batch, anomaly, dx);
 }
 void uad_launch_mul(const float* x, const float* mask, float* y, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(mul_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, mask, y, n);
 }
-void uad_launch_loss_finalize(const float* rec_partial, int n, int bps, const float* kl_per_sample, float inv_batch,
-                              float* rec_per_sample, float* scalars, hipStream_t st) {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, rec_partial, n, bps, kl_per_sample, inv_batch,
-                       rec_per_sample, scalars);
+void uad_launch_loss_finalize(const float* rec_partial, int n, int n_vae, int bps, const float* kl_per_sample,
+                              float inv_batch, float rec_scale, float* rec_per_sample, float* scalars, hipStream_t st) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, rec_partial, n, n_vae, bps, kl_per_sample,
+                       inv_batch, rec_scale, rec_per_sample, scalars);
 }
 void uad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2,
                      float eps, float gscale, hipStream_t st) {

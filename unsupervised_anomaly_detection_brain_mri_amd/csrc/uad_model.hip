@@ -80,6 +80,9 @@ struct uad_model {
     // activations
     float *t, *mu_raw, *ls_raw, *mu, *ls, *sigma, *z, *dvec, *cb, *kl;
     float *xhat_own;
+    // ceVAE: both branches run as one 2n-sample pass; staging for the concatenated inputs / outputs
+    float *xcat, *mdec_cat, *l1_own;
+    int nmul;                          // samples per user sample inside the handle (2 for ceVAE)
     // gradient ping-pong + small grads
     float *G0, *G1;
     float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
@@ -87,9 +90,12 @@ struct uad_model {
     float *colpart, *wpartial, *colscratch, *red_partial, *rec_partial, *rec_ps, *scalars_own;
     size_t colpart_cap, wpartial_cap;
     // state of the last forward
-    int last_n;
+    int last_n, last_nuser;            // samples inside the handle / samples the caller passed
     uad_io_t last_io;
+    const float* x_eff;                // [last_n] input of the last forward (xcat for ceVAE)
+    const float* mask_dec_eff;         // [last_n, flat] or null
     bool have_fwd;
+    bool data_only;                    // uad_forward(want_backward = 2): no parameter gradients
     std::vector<void*> allocs;
     // second stream + events of the backward pass; per-layer scratch touched by that stream
     hipStream_t side;
@@ -189,7 +195,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     if (cfg->inter_res <= 0 || (cfg->inter_res & (cfg->inter_res - 1)) || cfg->inter_res >= H)
         return fail(UAD_ERR_INVALID, "inter_res must be a power of two smaller than height");
     if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
-    if (cfg->arch != UAD_ARCH_AE && cfg->arch != UAD_ARCH_VAE) return fail(UAD_ERR_INVALID, "bad arch");
+    if (cfg->arch != UAD_ARCH_AE && cfg->arch != UAD_ARCH_VAE && cfg->arch != UAD_ARCH_CEVAE) return fail(UAD_ERR_INVALID, "bad arch");
     if (cfg->zdim <= 0 || cfg->zdim % 8) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
     if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
 
@@ -201,7 +207,10 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     m->prof_on = false;
     const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
     m->n_pool = npool;
-    const bool vae = cfg->arch == UAD_ARCH_VAE;
+    const bool vae = cfg->arch != UAD_ARCH_AE;
+    const bool cevae = cfg->arch == UAD_ARCH_CEVAE;
+    m->nmul = cevae ? 2 : 1;
+    m->data_only = false;
     char nm[128];
 
     // ---- parameter table in TF variable-creation order ----
@@ -225,18 +234,22 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     if (m->cmid % 8 || m->flat % 8) { delete m; return fail(UAD_ERR_UNSUPPORTED, "bottleneck channels must be a multiple of 8"); }
     m->bw = add_tensor(m, "Bottleneck/conv2d/kernel", 4, 1, 1, m->cenc, m->cmid);
     m->bb = add_tensor(m, "Bottleneck/conv2d/bias", 1, m->cmid, 1, 1, 1);
+    // the ceVAE graph leaves its Dense layers unnamed (context_encoder_variational_autoencoder.py:30-32): keras numbers them
+    const char* n_mu = cevae ? "Bottleneck/dense" : "Bottleneck/dense_mu";
+    const char* n_sg = cevae ? "Bottleneck/dense_1" : "Bottleneck/dense_sigma";
+    const char* n_dec = cevae ? "Bottleneck/dense_2" : "Bottleneck/dense_dec";
     if (vae) {
-        m->muw = add_tensor(m, "Bottleneck/dense_mu/kernel", 2, m->flat, cfg->zdim, 1, 1);
-        m->mub = add_tensor(m, "Bottleneck/dense_mu/bias", 1, cfg->zdim, 1, 1, 1);
-        m->sgw = add_tensor(m, "Bottleneck/dense_sigma/kernel", 2, m->flat, cfg->zdim, 1, 1);
-        m->sgb = add_tensor(m, "Bottleneck/dense_sigma/bias", 1, cfg->zdim, 1, 1, 1);
+        m->muw = add_tensor(m, std::string(n_mu) + "/kernel", 2, m->flat, cfg->zdim, 1, 1);
+        m->mub = add_tensor(m, std::string(n_mu) + "/bias", 1, cfg->zdim, 1, 1, 1);
+        m->sgw = add_tensor(m, std::string(n_sg) + "/kernel", 2, m->flat, cfg->zdim, 1, 1);
+        m->sgb = add_tensor(m, std::string(n_sg) + "/bias", 1, cfg->zdim, 1, 1, 1);
     } else {
         m->muw = add_tensor(m, "Bottleneck/dense_z/kernel", 2, m->flat, cfg->zdim, 1, 1);
         m->mub = add_tensor(m, "Bottleneck/dense_z/bias", 1, cfg->zdim, 1, 1, 1);
         m->sgw = m->sgb = -1;
     }
-    m->dw = add_tensor(m, "Bottleneck/dense_dec/kernel", 2, cfg->zdim, m->flat, 1, 1);
-    m->db = add_tensor(m, "Bottleneck/dense_dec/bias", 1, m->flat, 1, 1, 1);
+    m->dw = add_tensor(m, std::string(n_dec) + "/kernel", 2, cfg->zdim, m->flat, 1, 1);
+    m->db = add_tensor(m, std::string(n_dec) + "/bias", 1, m->flat, 1, 1, 1);
     m->rw = add_tensor(m, "Bottleneck/conv2d_1/kernel", 4, 1, 1, m->cmid, m->cenc);
     m->rb = add_tensor(m, "Bottleneck/conv2d_1/bias", 1, m->cenc, 1, 1, 1);
     m->seg_off[UAD_SEG_BOTTLENECK] = m->seg_cnt[UAD_SEG_ENCODER];
@@ -264,7 +277,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     if (m->enc[0].d.CS % 8 || 256 % m->enc[0].d.CS) { delete m; return fail(UAD_ERR_UNSUPPORTED, "first conv width"); }
 
     // ---- device memory ----
-    const size_t NB = (size_t)cfg->max_batch;
+    const size_t NB = (size_t)cfg->max_batch * m->nmul;
     int rc = UAD_OK;
 #define ALLOC(ptr, n) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n))
     ALLOC(m->params, (size_t)m->nparams); ALLOC(m->grads, (size_t)m->nparams);
@@ -280,6 +293,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->t, nflat); ALLOC(m->mu_raw, nz); ALLOC(m->ls_raw, nz); ALLOC(m->mu, nz); ALLOC(m->ls, nz);
     ALLOC(m->sigma, nz); ALLOC(m->z, nz); ALLOC(m->dvec, nflat); ALLOC(m->cb, ncb); ALLOC(m->kl, NB);
     ALLOC(m->xhat_own, NB * H * Wd * cfg->channels);
+    m->xcat = m->mdec_cat = m->l1_own = nullptr;
+    if (cevae) { ALLOC(m->xcat, NB * H * Wd * cfg->channels); ALLOC(m->mdec_cat, nflat); ALLOC(m->l1_own, NB * H * Wd * cfg->channels); }
     ALLOC(m->G0, maxact); ALLOC(m->G1, maxact);
     ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
     ALLOC(m->g_small[4], nflat); ALLOC(m->g_small[5], nflat);
@@ -317,7 +332,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->colscratch, 64 * 1024);
     const int bps = uad_final_blocks_per_sample(H, Wd);
     ALLOC(m->red_partial, NB * bps * (3 * cin + 1)); ALLOC(m->rec_partial, NB * bps);
-    ALLOC(m->rec_ps, NB); ALLOC(m->scalars_own, 4);
+    ALLOC(m->rec_ps, NB); ALLOC(m->scalars_own, 8);
 #undef ALLOC
     if (rc != UAD_OK) { uad_destroy(m); return rc; }
     *out = m;
@@ -397,8 +412,28 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
     if (!io->x) return fail(UAD_ERR_INVALID, "io.x is null");
     hipStream_t st = (hipStream_t)stream;
-    const bool vae = m->cfg.arch == UAD_ARCH_VAE;
+    const bool vae = m->cfg.arch != UAD_ARCH_AE;
+    const bool cevae = m->cfg.arch == UAD_ARCH_CEVAE;
     const int ir = m->cfg.inter_res;
+    const int nu = n;                 // samples the caller passed
+    const float* xin = io->x;
+    const float* mask_dec = io->mask_dec;
+    if (cevae) {
+        // both branches as ONE pass over 2n samples through the shared layers: [x ; x_ce]
+        if ((io->mask_mu == nullptr) != (io->mask_mu_ce == nullptr) || (io->mask_dec == nullptr) != (io->mask_dec_ce == nullptr))
+            return fail(UAD_ERR_INVALID, "ceVAE: mask_mu/mask_mu_ce and mask_dec/mask_dec_ce must be given together");
+        const size_t xb = (size_t)nu * m->cfg.height * m->cfg.width * m->cfg.channels * sizeof(float);
+        HIP_TRY(hipMemcpyAsync(m->xcat, io->x, xb, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync((char*)m->xcat + xb, io->x_ce ? io->x_ce : io->x, xb, hipMemcpyDeviceToDevice, st));
+        xin = m->xcat;
+        if (io->mask_dec) {
+            const size_t mb = (size_t)nu * m->flat * sizeof(float);
+            HIP_TRY(hipMemcpyAsync(m->mdec_cat, io->mask_dec, mb, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync((char*)m->mdec_cat + mb, io->mask_dec_ce, mb, hipMemcpyDeviceToDevice, st));
+            mask_dec = m->mdec_cat;
+        }
+        n = 2 * nu;
+    }
 
     // refresh the packed 5x5 kernels if the parameters changed since the last pack
     if (!m->packed_valid) {
@@ -421,7 +456,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     {
         PROF(kEncF[0]);
         UadConvDesc d = m->enc[0].d; d.N = n;
-        uad_launch_conv_first_fwd(d, io->x, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st);
+        uad_launch_conv_first_fwd(d, xin, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st);
     }
     for (size_t i = 1; i < m->enc.size(); ++i) {
         PROF(kEncF[i & 7]);
@@ -438,10 +473,10 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     if (vae) {
         uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->muw), m->mu_raw, epi_bias(P(m, m->mub)), st, nullptr, m->ws);
         uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->sgw), m->ls_raw, epi_bias(P(m, m->sgb)), st, nullptr, m->ws);
-        uad_launch_reparam_fwd(n, m->cfg.zdim, m->mu_raw, m->ls_raw, io->mask_mu, io->mask_sigma, io->eps, m->mu, m->ls,
-                               m->sigma, m->z, m->kl, st);
+        uad_launch_reparam_fwd(n, nu, m->cfg.zdim, m->mu_raw, m->ls_raw, io->mask_mu, io->mask_sigma,
+                               cevae ? io->mask_mu_ce : nullptr, io->eps, m->mu, m->ls, m->sigma, m->z, m->kl, st);
         uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), m->z, no_xform(), P(m, m->dw), m->dvec,
-                          epi_bias(P(m, m->db), io->mask_dec), st, nullptr, m->ws);
+                          epi_bias(P(m, m->db), mask_dec), st, nullptr, m->ws);
     } else {
         uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->t, no_xform(), P(m, m->muw), m->z,
                           epi_bias(P(m, m->mub), io->mask_mu), st, nullptr, m->ws);
@@ -464,24 +499,33 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     fa.N = n; fa.H = m->cfg.height; fa.W = m->cfg.width; fa.C = DL.d.CB;
     fa.c_last = DL.c; fa.scale = P(m, DL.gamma); fa.shift = P(m, DL.beta); fa.alpha = kLrelu;
     fa.mult = 1.0f / sqrtf(1.0f + kBnEps);
-    fa.wf = P(m, m->fw); fa.bf = P(m, m->fb); fa.x = io->x;
-    fa.x_hat = io->x_hat ? io->x_hat : m->xhat_own; fa.l1_map = io->l1_map;
+    fa.wf = P(m, m->fw); fa.bf = P(m, m->fb); fa.x = xin;
+    fa.x_hat = (io->x_hat && !cevae) ? io->x_hat : m->xhat_own;
+    fa.l1_map = cevae ? ((io->l1_map || io->l1_map_ce) ? m->l1_own : nullptr) : io->l1_map;
     fa.rec_partial = m->rec_partial;
     fa.d_c = want_backward ? m->G0 : nullptr;
     fa.red_partial = m->red_partial;
-    fa.inv_batch = 1.0f / (float)n;
+    fa.inv_batch = 1.0f / (float)nu;
     { PROF(want_backward ? "final.fwd+bwd" : "final.fwd"); uad_launch_final_fwd_bwd(fa, st); }
     PROF("loss.finalize");
     const int bps = uad_final_blocks_per_sample(fa.H, fa.W);
-    uad_launch_loss_finalize(m->rec_partial, n, bps, vae ? m->kl : nullptr, 1.0f / (float)n,
+    uad_launch_loss_finalize(m->rec_partial, n, nu, bps, vae ? m->kl : nullptr, 1.0f / (float)nu, cevae ? 0.5f : 1.0f,
                              io->rec_per_sample ? io->rec_per_sample : m->rec_ps,
                              io->scalars ? io->scalars : m->scalars_own, st);
-    // optional latent outputs
-    const size_t zb = (size_t)n * m->cfg.zdim * sizeof(float);
+    if (cevae) {
+        const size_t xe = (size_t)nu * m->cfg.height * m->cfg.width * m->cfg.channels, xb = xe * sizeof(float);
+        if (io->x_hat) HIP_TRY(hipMemcpyAsync(io->x_hat, m->xhat_own, xb, hipMemcpyDeviceToDevice, st));
+        if (io->x_hat_ce) HIP_TRY(hipMemcpyAsync(io->x_hat_ce, m->xhat_own + xe, xb, hipMemcpyDeviceToDevice, st));
+        if (io->l1_map) HIP_TRY(hipMemcpyAsync(io->l1_map, m->l1_own, xb, hipMemcpyDeviceToDevice, st));
+        if (io->l1_map_ce) HIP_TRY(hipMemcpyAsync(io->l1_map_ce, m->l1_own + xe, xb, hipMemcpyDeviceToDevice, st));
+    }
+    // optional latent outputs (VAE-branch samples)
+    const size_t zb = (size_t)nu * m->cfg.zdim * sizeof(float);
     if (io->z_mu) hipMemcpyAsync(io->z_mu, vae ? m->mu : m->z, zb, hipMemcpyDeviceToDevice, st);
     if (vae && io->z_log_sigma) hipMemcpyAsync(io->z_log_sigma, m->ls, zb, hipMemcpyDeviceToDevice, st);
     if (vae && io->z_sigma) hipMemcpyAsync(io->z_sigma, m->sigma, zb, hipMemcpyDeviceToDevice, st);
-    m->last_n = n; m->last_io = *io; m->have_fwd = want_backward != 0;
+    m->last_n = n; m->last_nuser = nu; m->last_io = *io; m->have_fwd = want_backward != 0;
+    m->x_eff = xin; m->mask_dec_eff = mask_dec; m->data_only = want_backward == 2;
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
@@ -519,9 +563,10 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
     const int T = n * bps, L = 3 * C + 1;
     static const char* kDecW[] = {"dec0.wgrad", "dec1.wgrad", "dec2.wgrad", "dec3.wgrad", "dec4.wgrad", "dec5.wgrad", "dec6.wgrad", "dec7.wgrad"};
     static const char* kDecD[] = {"dec0.dgrad", "dec1.dgrad", "dec2.dgrad", "dec3.dgrad", "dec4.dgrad", "dec5.dgrad", "dec6.dgrad", "dec7.dgrad"};
+    const bool pg = !m->data_only;   // parameter gradients wanted
     m->ev_next = 0;
     edge(m, st, sd);   // forward (d c of the last block, loss partials) is complete
-    {
+    if (pg) {
         // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials:
         // red_partial[T][3C+1] = {dwf[C], S1[C], S2[C], dbf}
         PROF_ON("final.gradfin", sd);
@@ -541,12 +586,12 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         const long long ibias = (i == 0) ? m->rb : m->dec[i - 1].b;
         float* cp = m->cp_slot[i];
         // filter gradient on MAIN (big = d c raw, small = layer input with activation on load); slab reduce on SIDE
-        { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, sd, next_event(m)); }
+        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, sd, next_event(m)); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
         { PROF(kDecD[i & 7]); UadEpilogue e = epi_bwd(m, in, ig, ib, ia); e.colpart = cp;
           uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
         edge(m, st, sd);   // column partials of this layer are ready
-        { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), sd); }
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), sd); }
         float* tsw = g; g = gn; gn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
@@ -555,8 +600,10 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
 }
 
 static int backward_bottleneck(uad_model* m, hipStream_t st) {
-    const int n = m->last_n;
-    const bool vae = m->cfg.arch == UAD_ARCH_VAE;
+    const int n = m->last_n, nu = m->last_nuser;
+    const bool vae = m->cfg.arch != UAD_ARCH_AE;
+    const bool cevae = m->cfg.arch == UAD_ARCH_CEVAE;
+    const bool pg = !m->data_only;
     const int ir = m->cfg.inter_res, zd = m->cfg.zdim;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
     const uad_io_t& io = m->last_io;
@@ -576,19 +623,20 @@ static int backward_bottleneck(uad_model* m, hipStream_t st) {
     const ConvLayer& EL = m->enc.back();
     edge(m, st, sd);
     // SIDE: conv2d_1 weight gradient (its bias gradient came from the decoder's BN finalize)
-    { PROF_ON("bott.wgrad", sd); uad_launch_conv_w(d_r, m->dvec, no_xform(), dcb, no_xform(), Gr(m, m->rw), wp, sd); }
+    if (pg) { PROF_ON("bott.wgrad", sd); uad_launch_conv_w(d_r, m->dvec, no_xform(), dcb, no_xform(), Gr(m, m->rw), wp, sd); }
     {
         PROF("bott.bwd");
-        uad_launch_conv_d(d_r, dcb, no_xform(), P(m, m->rw), dd, epi_bias(nullptr, vae ? io.mask_dec : nullptr), st, nullptr, m->ws);
+        uad_launch_conv_d(d_r, dcb, no_xform(), P(m, m->rw), dd, epi_bias(nullptr, vae ? m->mask_dec_eff : nullptr), st, nullptr, m->ws);
         edge(m, st, sd);
-        { PROF_ON("bott.wgrad", sd);
+        if (pg) { PROF_ON("bott.wgrad", sd);
           uad_launch_conv_w(d_dec, m->z, no_xform(), dd, no_xform(), Gr(m, m->dw), wp, sd);
           uad_launch_colsum(dd, n, m->flat, Gr(m, m->db), m->colscratch, sd); }
         uad_launch_conv_d(d_dec, dd, no_xform(), P(m, m->dw), dz, epi_bias(nullptr, vae ? nullptr : io.mask_mu), st, nullptr, m->ws);
         if (vae) {
-            uad_launch_reparam_bwd(n, zd, dz, m->mu, m->sigma, io.eps, io.mask_mu, io.mask_sigma, 1.0f / (float)n, dmu, dls, st);
+            uad_launch_reparam_bwd(n, nu, zd, dz, m->mu, m->sigma, io.eps, io.mask_mu, io.mask_sigma,
+                                   cevae ? io.mask_mu_ce : nullptr, 1.0f / (float)nu, dmu, dls, st);
             edge(m, st, sd);
-            { PROF_ON("bott.wgrad", sd);
+            if (pg) { PROF_ON("bott.wgrad", sd);
               uad_launch_conv_w(d_in, m->t, no_xform(), dmu, no_xform(), Gr(m, m->muw), wp, sd);
               uad_launch_colsum(dmu, n, zd, Gr(m, m->mub), m->colscratch, sd);
               uad_launch_conv_w(d_in, m->t, no_xform(), dls, no_xform(), Gr(m, m->sgw), wp, sd);
@@ -597,20 +645,20 @@ static int backward_bottleneck(uad_model* m, hipStream_t st) {
             uad_launch_conv_d(d_in, dls, no_xform(), P(m, m->sgw), dflat, epi_bias(nullptr, nullptr, m->g_small[5]), st, nullptr, m->ws);
         } else {
             edge(m, st, sd);
-            { PROF_ON("bott.wgrad", sd);
+            if (pg) { PROF_ON("bott.wgrad", sd);
               uad_launch_conv_w(d_in, m->t, no_xform(), dz, no_xform(), Gr(m, m->muw), wp, sd);
               uad_launch_colsum(dz, n, zd, Gr(m, m->mub), m->colscratch, sd); }
             uad_launch_conv_d(d_in, dz, no_xform(), P(m, m->muw), dflat, epi_bias(nullptr), st, nullptr, m->ws);
         }
         edge(m, st, sd);
-        { PROF_ON("bott.wgrad", sd);
+        if (pg) { PROF_ON("bott.wgrad", sd);
           uad_launch_conv_w(d_b, EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu), dflat, no_xform(), Gr(m, m->bw), wp, sd);
           uad_launch_colsum(dflat, n * ir * ir, m->cmid, Gr(m, m->bb), m->colscratch, sd); }
         UadEpilogue e = epi_bwd(m, EL.c, EL.gamma, EL.beta, kLrelu); e.colpart = cp;
         uad_launch_conv_d(d_b, dflat, no_xform(), P(m, m->bw), m->G1, e, st, nullptr, m->ws);
     }
     edge(m, st, sd);
-    { PROF_ON("bn.gradfin", sd);
+    if (pg) { PROF_ON("bn.gradfin", sd);
       uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d_b, false, m->ws.floats), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma),
                                   Gr(m, EL.beta), Gr(m, EL.b), sd); }
     float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;   // G0 = d loss / d c of the last encoder conv
@@ -623,6 +671,7 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
     hipStream_t sd = m->side;
     const bool bf = m->math == UAD_MATH_BF16X3;
+    const bool pg = !m->data_only;
     float* g = m->G0;
     float* gn = m->G1;
     static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
@@ -631,16 +680,23 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
         UadConvDesc d = m->enc[i].d; d.N = n;
         const ConvLayer& PL = m->enc[i - 1];
         float* cp = m->cp_slot[8 + (i & 7)];
-        { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, sd, next_event(m)); }
+        if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, sd, next_event(m)); }
         { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
           uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i])); }
         edge(m, st, sd);
-        { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd); }
         float* tsw = g; g = gn; gn = tsw;
     }
     UadConvDesc d0 = m->enc[0].d; d0.N = n;
-    { PROF("enc0.wgrad"); uad_launch_conv_first_wgrad(d0, m->last_io.x, g, Gr(m, m->enc[0].w), m->wp_slot[8], st); }
+    if (pg) { PROF("enc0.wgrad"); uad_launch_conv_first_wgrad(d0, m->x_eff, g, Gr(m, m->enc[0].w), m->wp_slot[8], st); }
+    if (m->cfg.arch == UAD_ARCH_CEVAE && m->last_io.anomaly) {
+        // d loss_vae / d x of the VAE-branch samples (the leading last_nuser rows) -> anomaly map (trainers/ceVAE.py:51)
+        PROF("enc0.dgrad");
+        UadConvDesc dv = d0; dv.N = m->last_nuser;
+        uad_launch_conv_first_dgrad(dv, g, P(m, m->enc[0].w), m->x_eff, m->xhat_own, 1.0f / (float)m->last_nuser,
+                                    m->last_io.anomaly, nullptr, st);
+    }
     m->G0 = g; m->G1 = gn;
     edge(m, sd, st);   // join: all gradients complete
     return UAD_OK;

@@ -23,7 +23,7 @@ def _ptr(t):
 
 
 class Engine:
-    """One AE/VAE instance on one GPU.  Mirrors what a tf.Session + graph holds in the reference
+    """One AE / VAE / ceVAE instance on one GPU.  Mirrors what a tf.Session + graph holds in the reference
     (trainers/VAE.py:18-29): variables, optimizer slots and the compiled step."""
 
     def __init__(self, arch, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, device=None,
@@ -35,10 +35,10 @@ class Engine:
         torch.cuda.set_device(self.device)
         self.arch = arch
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
-        cfg = _lib.UadConfig(_lib.ARCH_VAE if arch == 'VAE' else _lib.ARCH_AE, height, width, channels, inter_res, zdim,
-                             max_batch)
-        if arch not in ('AE', 'VAE'):
+        archs = {'AE': _lib.ARCH_AE, 'VAE': _lib.ARCH_VAE, 'ceVAE': _lib.ARCH_CEVAE}
+        if arch not in archs:
             raise ValueError(f'unknown arch {arch!r}')
+        cfg = _lib.UadConfig(archs[arch], height, width, channels, inter_res, zdim, max_batch)
         h = C.c_void_p()
         _lib.check(self.lib.uad_create(C.byref(cfg), C.byref(h)))
         self.handle = h
@@ -54,7 +54,6 @@ class Engine:
         self.flat = inter_res * inter_res * (self._cenc() // 8)
         self._views = {}
         self.set_math(math)
-        self.scalars = torch.zeros(4, device=self.device)
 
     def _cenc(self):
         n_pool = int(math.log2(self.h) - math.log2(self.inter))
@@ -138,9 +137,13 @@ class Engine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def forward(self, x, eps=None, masks=None, want_backward=False, want_l1=True, want_latents=True):
-        """Returns a dict of DEVICE tensors: x_hat, L1 (opt), z_mu/z_log_sigma/z_sigma or z (opt), scalars [4]
-        (reconstructionLoss, kl, loss, 0), rec_per_sample [n].  Asynchronous on the current stream."""
+    def forward(self, x, eps=None, masks=None, want_backward=False, want_l1=True, want_latents=True, x_ce=None,
+                want_anomaly=True):
+        """Returns a dict of DEVICE tensors: x_hat, L1 (opt), z_mu/z_log_sigma/z_sigma or z (opt), scalars [8]
+        (reconstructionLoss, kl, loss, 0, Rec_vae, Rec_ce, loss_vae, 0), rec_per_sample [n] ([2n] for ceVAE).
+        ceVAE additionally takes x_ce (None = x) and masks 'mu_ce'/'dec_ce', and returns x_hat_ce, L1_vae / L1_ce
+        (instead of L1) and -- filled in by backward() -- 'anomaly'.  want_backward: False | True | 'data' (data-gradient
+        chain only: the ceVAE anomaly map without parameter gradients).  Asynchronous on the current stream."""
         masks = masks or {}
         x = self._dev(x)
         if x.dim() != 4 or tuple(x.shape[1:]) != (self.h, self.w, self.c):
@@ -148,30 +151,46 @@ class Engine:
         n = x.shape[0]
         if n > self.max_batch:
             raise ValueError(f'batch {n} > max_batch {self.max_batch}')
+        ce = self.arch == 'ceVAE'
+        if x_ce is not None and not ce:
+            raise ValueError('x_ce is a ceVAE input')
         zs = (n, self.zdim)
         eps = self._dev(eps, zs)
-        if self.arch == 'VAE':
+        m_mu_ce = m_dec_ce = None
+        if self.arch != 'AE':
             m_mu, m_sg = self._dev(masks.get('mu'), zs), self._dev(masks.get('sigma'), zs)
             m_dec = self._dev(masks.get('dec'), (n, self.flat))
+            if ce:
+                m_mu_ce, m_dec_ce = self._dev(masks.get('mu_ce'), zs), self._dev(masks.get('dec_ce'), (n, self.flat))
         else:
             m_mu, m_sg, m_dec = self._dev(masks.get('z'), zs), None, None
-        out = {'x_hat': torch.empty_like(x), 'scalars': torch.empty(4, device=self.device),
-               'rec_per_sample': torch.empty(n, device=self.device)}
+        x_ce = self._dev(x_ce, x.shape)
+        out = {'x_hat': torch.empty_like(x), 'scalars': torch.empty(8, device=self.device),
+               'rec_per_sample': torch.empty(2 * n if ce else n, device=self.device)}
         if want_l1:
-            out['L1'] = torch.empty_like(x)
+            out['L1_vae' if ce else 'L1'] = torch.empty_like(x)
+        if ce:
+            out['x_hat_ce'] = torch.empty_like(x)
+            if want_l1:
+                out['L1_ce'] = torch.empty_like(x)
+            if want_backward and want_anomaly:
+                out['anomaly'] = torch.empty_like(x)
         lat = {}
         if want_latents:
-            if self.arch == 'VAE':
+            if self.arch != 'AE':
                 lat = {k: torch.empty(zs, device=self.device) for k in ('z_mu', 'z_log_sigma', 'z_sigma')}
             else:
                 lat = {'z': torch.empty(zs, device=self.device)}
             out.update(lat)
         io = _lib.UadIO(_ptr(x), _ptr(eps), _ptr(m_mu), _ptr(m_sg), _ptr(m_dec), _ptr(out['x_hat']),
-                        _ptr(out.get('L1')), _ptr(lat.get('z_mu', lat.get('z'))), _ptr(lat.get('z_log_sigma')),
-                        _ptr(lat.get('z_sigma')), _ptr(out['scalars']), _ptr(out['rec_per_sample']))
+                        _ptr(out.get('L1_vae' if ce else 'L1')), _ptr(lat.get('z_mu', lat.get('z'))),
+                        _ptr(lat.get('z_log_sigma')), _ptr(lat.get('z_sigma')), _ptr(out['scalars']),
+                        _ptr(out['rec_per_sample']), _ptr(x_ce), _ptr(m_mu_ce), _ptr(m_dec_ce), _ptr(out.get('x_hat_ce')),
+                        _ptr(out.get('L1_ce')), _ptr(out.get('anomaly')))
         # keep the inputs alive until the (asynchronous) backward has consumed them
-        self._keep = (x, eps, m_mu, m_sg, m_dec, out)
-        _lib.check(self.lib.uad_forward(self.handle, C.byref(io), n, 1 if want_backward else 0, self._stream()))
+        self._keep = (x, eps, m_mu, m_sg, m_dec, x_ce, m_mu_ce, m_dec_ce, out)
+        wb = 2 if want_backward == 'data' else (1 if want_backward else 0)
+        _lib.check(self.lib.uad_forward(self.handle, C.byref(io), n, wb, self._stream()))
         return out
 
     def backward(self, segment=_lib.SEG_ALL):
@@ -181,6 +200,7 @@ class Engine:
         _lib.check(self.lib.uad_adam_step(self.handle, lr, beta1, beta2, eps, grad_scale, self._stream()))
 
     def train_step(self, x, eps=None, masks=None, lr=1e-4, beta1=0.5, beta2=0.999, adam_eps=1e-8, **kw):
+        """forward + backward + Adam; ceVAE: pass x_ce=... (its 'anomaly' output is filled by the backward)."""
         out = self.forward(x, eps, masks, want_backward=True, **kw)
         self.backward(_lib.SEG_ALL)
         self.adam_step(lr, beta1, beta2, adam_eps)

@@ -3,3 +3,4 @@ a TF graph (models/<name>.py::<name>); here it is a marker whose `__name__` sele
 (the trainer reads `network.__name__` for paths exactly like trainers/AEMODEL.py:32-35 / utils/Evaluation.py:382)."""
 from .autoencoder import autoencoder  # noqa: F401
 from .variational_autoencoder import variational_autoencoder  # noqa: F401
+from .context_encoder_variational_autoencoder import context_encoder_variational_autoencoder  # noqa: F401
