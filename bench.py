@@ -115,7 +115,14 @@ def main():
     ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'bf16x3'), choices=['f32', 'bf16x3'],
                     help='bf16x3 (default): split-bf16 products on the bf16 matrix cores, fp32 accumulate, parity 1e-4 vs the '
                          'fp32 oracle; f32: exact fp32 MFMA')
+    ap.add_argument('--arch', default='VAE', choices=['VAE', 'ceVAE'],
+                    help='VAE = the headline workload (BASELINE.json configs[1]); ceVAE = configs[3] (16 slices per GPU: both '
+                         'branches + the input-gradient anomaly map every step), reported for the record')
+    ap.add_argument('--batch', type=int, default=0, help='slices per GPU (default 64 for VAE, 16 for ceVAE)')
     args = ap.parse_args()
+    global BATCH
+    BATCH = args.batch or (64 if args.arch == 'VAE' else 16)
+    cevae = args.arch == 'ceVAE'
 
     import torch
     import torch.distributed as dist
@@ -134,7 +141,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    eng = Engine('VAE', H, W, 1, INTER, ZDIM, max_batch=BATCH, device=f'cuda:{local_rank}', math=args.math)
+    eng = Engine(args.arch, H, W, 1, INTER, ZDIM, max_batch=BATCH, device=f'cuda:{local_rank}', math=args.math)
     # identical glorot-uniform init on every rank (seed 3), zero bias, gamma 1, beta 0
     rng = np.random.default_rng(3)
     flat = np.zeros(eng.nparams, np.float32)
@@ -153,10 +160,16 @@ def main():
     eps = torch.randn(BATCH, ZDIM, device='cuda', generator=g)
     keep = lambda shape: (torch.rand(shape, device='cuda', generator=g) >= 0.2).float() / 0.8   # rate 0.2, run.py:40
     masks = {'mu': keep((BATCH, ZDIM)), 'sigma': keep((BATCH, ZDIM)), 'dec': keep((BATCH, INTER * INTER * 16))}
+    extra = {}
+    if cevae:
+        x_ce = x.clone()
+        x_ce[:, 40:60, 50:70] = 0          # one 20x20 context hole, the same for every slice (trainers/CE.py:130-139, A3)
+        masks.update(mu_ce=keep((BATCH, ZDIM)), dec_ce=keep((BATCH, INTER * INTER * 16)))
+        extra = {'x_ce': x_ce}
     dp = DataParallelStep(eng, world)
 
     def step():
-        return dp.train_step(x, eps, masks, lr=1e-4, beta1=0.5, want_l1=True, want_latents=False)
+        return dp.train_step(x, eps, masks, lr=1e-4, beta1=0.5, want_l1=True, want_latents=False, **extra)
 
     def timed(steps, warmup):
         for _ in range(warmup):
@@ -188,7 +201,7 @@ def main():
             step()
         rep = eng.profile_report()
         eng.profile(False)
-        fl = flops_per_tag(BATCH)
+        fl = flops_per_tag(BATCH * (2 if cevae else 1))
         gemm = {t: (c, ms) for t, (c, ms) in rep.items() if t in fl}
         dom = max(gemm, key=lambda t: gemm[t][1])
         dom_ms = gemm[dom][1] / gemm[dom][0]
@@ -231,24 +244,29 @@ def main():
         slices = BATCH * world * args.steps
         value = slices / dt
         res = {
-            'metric': 'MRI slices/sec VAE train step (128x128, bs=64)',
+            'metric': 'MRI slices/sec VAE train step (128x128, bs=64)' if not cevae else
+                      f'MRI slices/sec ceVAE train step (128x128, bs={BATCH}/GPU)',
             'value': round(value, 1), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[1]: VAE 128x128x1 slices, batch 64 per GPU, '
-                                   'fwd + bwd + TF-Adam (lr 1e-4, beta1 0.5), dropout 0.2, inter_res 8, zDim 128',
+            'config': {'workload': ('BASELINE.json configs[1]: VAE 128x128x1 slices, batch 64 per GPU, '
+                                    'fwd + bwd + TF-Adam (lr 1e-4, beta1 0.5), dropout 0.2, inter_res 8, zDim 128') if not cevae else
+                                   (f'BASELINE.json configs[3]: ceVAE 128x128x1 slices, batch {BATCH} per GPU; x and the context-masked '
+                                    'x_ce through shared layers (one 2n-sample pass), loss = mean(rec_vae + kl + rec_ce), '
+                                    'fwd + bwd + TF-Adam + the input-gradient anomaly map of every step'),
                        'math': args.math + (' = fp32 operands split hi+lo into bf16, hi*hi+hi*lo+lo*hi on the bf16 MFMA, fp32 accumulate; '
                                             'parity 1e-4 vs the fp32 oracle (tests/test_gpu_model.py)' if args.math == 'bf16x3' else ' = exact fp32 MFMA'),
                        'global_batch': BATCH * world, 'per_gpu_batch': BATCH,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
-                       'step_tflops': round(value * train_flops_per_slice() / 1e12, 2), 'final_loss': round(loss, 4)},
+                       'step_tflops': round(value * train_flops_per_slice() * (2 if cevae else 1) / 1e12, 2),
+                       'final_loss': round(loss, 4)},
             'kernels': kernels,
         }
         res['roofline'] = roof
         res['roofline']['whole_step_algorithmic_tflops'] = res['config']['step_tflops']
         if other:
             res['other_math_mode'] = other
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not cevae:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))
     if world > 1:

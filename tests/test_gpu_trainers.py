@@ -134,7 +134,8 @@ def test_cevae_trainer_surface_and_oracle_step(tmp_path):
     # train(): epoch loop with host masking, checkpoints, early-stopping bookkeeping
     model.train(ds)
     assert len(model.curves['TRAIN/loss']) == 2 and len(model.curves['VAL/loss_vae']) == 2
-    assert model.curves['TRAIN/loss'][1] < model.curves['TRAIN/loss'][0]
+    # TRAIN means are noisy (fresh random context holes + dropout every step); VAL runs x_ce = x without dropout
+    assert model.curves['VAL/loss'][1] < model.curves['VAL/loss'][0]
     ck = os.path.join(model.checkpointDir, model.model_dir)
     assert os.path.isfile(os.path.join(ck, 'ceVAE.model-2.npz'))
 
