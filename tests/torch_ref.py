@@ -154,3 +154,60 @@ def cevae_losses(params, x, x_ce, eps, masks, n_pool):
     gx, = torch.autograd.grad(L['loss_vae'], x, retain_graph=True)
     L['anomaly'] = l1v.detach() * gx.abs()
     return L, x_hat, x_hat_ce
+
+
+def gmvae_losses(params, bn_names, x, e_w, e_z, n_pool, dim_c, dim_z, c_lambda, tv_lambda):
+    """Spatial GMVAE graph + losses written the way the reference builds them
+    (models/gaussian_mixture_variational_autoencoder_spatial.py:9-65, trainers/GMVAE_spatial.py:61-92), in autograd."""
+    rstd = 1.0 / math.sqrt(1.0 + BN_EPS)
+    p = params
+
+    def bn(c, scope):
+        return c * (p[scope + '/gamma'] * rstd).view(1, -1, 1, 1) + p[scope + '/beta'].view(1, -1, 1, 1)
+
+    def conv1(t, name):
+        return _conv_same(t, p[name + '/kernel'], p[name + '/bias'], 1)
+
+    x = x.clone().requires_grad_(True)
+    a = x.permute(0, 3, 1, 2)
+    for i in range(n_pool):
+        a = F.leaky_relu(bn(_conv_same(a, p[f'enc_conv2D_{i}/kernel'], p[f'enc_conv2D_{i}/bias'], 2), bn_names[i]), ALPHA)
+    h = a
+    nhwc = lambda t: t.permute(0, 2, 3, 1)
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    w_mu, w_ls = nhwc(conv1(h, 'q_wz_x/w_mu')), nhwc(conv1(h, 'q_wz_x/w_log_sigma'))
+    z_mu, z_ls = nhwc(conv1(h, 'q_wz_x/z_mu')), nhwc(conv1(h, 'q_wz_x/z_log_sigma'))
+    w_s = w_mu + e_w * torch.exp(0.5 * w_ls)
+    z_s = z_mu + e_z * torch.exp(0.5 * z_ls)
+    mid = F.relu(conv1(nchw(w_s), 'p_z_wc/1x1convlayer'))
+    n, hh, ww = z_mu.shape[:3]
+    M = nhwc(conv1(mid, 'p_z_wc/z_wc_mu')).reshape(n, hh, ww, dim_z, dim_c)
+    Lq = (nhwc(conv1(mid, 'p_z_wc/z_wc_log_sigma')) + p['Variable']).reshape(n, hh, ww, dim_z, dim_c)
+    a = F.relu(bn(h, bn_names[n_pool]))
+    for i in range(n_pool):
+        c = _convT_same(a, p[f'dec_Conv2DT_{i}/kernel'], p[f'dec_Conv2DT_{i}/bias'], 2)
+        a = F.leaky_relu(bn(c, bn_names[n_pool + 1 + i]), ALPHA)
+    xh = nhwc(_conv_same(a, p['dec_Conv2D_final/kernel'], p['dec_Conv2D_final/bias'], 1))
+    z_t = z_s.unsqueeze(-1).expand(-1, -1, -1, -1, dim_c)
+    loglh = -0.5 * ((z_t - M) ** 2 * torch.exp(Lq)) - Lq + math.log(math.pi)
+    logit = loglh.sum(dim=3)
+    pc = torch.softmax(logit, dim=-1)
+    L = {}
+    l1 = (x - xh).abs()
+    L['mean_p_loss'] = l1.reshape(n, -1).sum(dim=1).mean()
+    zm = z_mu.unsqueeze(-1).expand(-1, -1, -1, -1, dim_c)
+    zl = z_ls.unsqueeze(-1).expand(-1, -1, -1, -1, dim_c)
+    d_var = (torch.exp(zl) + (zm - M) ** 2) * (torch.exp(Lq) + 1e-6)
+    kl = (d_var - (Lq + zl) - 1) * 0.5
+    con = torch.matmul(kl, pc.unsqueeze(-1)).squeeze(-1).sum(dim=(1, 2, 3))
+    L['conditional_prior_loss'] = con.mean()
+    L['w_prior_loss'] = (0.5 * (w_mu ** 2 + torch.exp(w_ls) - w_ls - 1).sum(dim=(1, 2, 3))).mean()
+    closs1 = (pc * torch.log(pc * dim_c + 1e-8)).sum(dim=3)
+    L['c_prior_loss'] = torch.maximum(closs1, torch.full_like(closs1, c_lambda)).sum(dim=(1, 2)).mean()
+    L['loss'] = L['mean_p_loss'] + L['conditional_prior_loss'] + L['w_prior_loss'] + L['c_prior_loss']
+    r = x - xh
+    tv = (r[:, 1:] - r[:, :-1]).abs().sum(dim=(1, 2, 3)) + (r[:, :, 1:] - r[:, :, :-1]).abs().sum(dim=(1, 2, 3))
+    L['restore'] = tv_lambda * tv
+    L['grads'], = torch.autograd.grad(L['loss'] + L['restore'].sum(), x, retain_graph=True)
+    L['dx_loss'], = torch.autograd.grad(L['loss'], x, retain_graph=True)
+    return L, xh, {'pc': pc, 'z_wc_mus': M, 'z_wc_log_sigma_invs': Lq, 'w_sampled': w_s, 'z_sampled': z_s}
