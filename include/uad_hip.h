@@ -13,6 +13,9 @@
  *                  utils/default_config_setup.py:257)
  *   uad_forward(want_backward = 0)
  *       <- trainers/VAE.py:105-118, AE.py:92-105 (reconstruct: sess.run({'reconstruction'})) and the VAL pass
+ *   uad_restore_step
+ *       <- trainers/GMVAE_spatial.py:178-190 (150 x sess.run({'grads'}) + host `restored -= restore_lr * grads`), graph
+ *          models/gaussian_mixture_variational_autoencoder_spatial.py:9-65, losses trainers/GMVAE_spatial.py:61-92
  *   uad_residual
  *       <- utils/Evaluation.py:282-289 (residual map, brain mask, hyper-intensity prior) and
  *          trainers/VAE.py:120 (l1err)
@@ -33,7 +36,7 @@ extern "C" {
 #endif
 
 enum { UAD_OK = 0, UAD_ERR_INVALID = 1, UAD_ERR_HIP = 2, UAD_ERR_UNSUPPORTED = 3 };
-enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1, UAD_ARCH_CEVAE = 2 };
+enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1, UAD_ARCH_CEVAE = 2, UAD_ARCH_GMVAE_SPATIAL = 3 };
 enum { UAD_BUF_PARAMS = 0, UAD_BUF_GRADS = 1, UAD_BUF_ADAM_M = 2, UAD_BUF_ADAM_V = 3 };
 enum { UAD_SEG_DECODER = 0, UAD_SEG_BOTTLENECK = 1, UAD_SEG_ENCODER = 2, UAD_SEG_ALL = -1 };
 /* arithmetic of the k5 s2 forward / data-gradient contractions: exact fp32 MFMA (default), or split-bf16 (x = hi + lo,
@@ -50,6 +53,11 @@ typedef struct {
     int inter_res;  /* config.intermediateResolutions[0]                        */
     int zdim;       /* config.zDim                                              */
     int max_batch;  /* largest n any later call will pass                       */
+    /* spatial GMVAE only (trainers/GMVAE_spatial.py:12-21); ignored otherwise */
+    int dim_c;      /* config.dim_c  mixture components                         */
+    int dim_z;      /* config.dim_z                                             */
+    int dim_w;      /* config.dim_w                                             */
+    float c_lambda; /* config.c_lambda                                          */
 } uad_config_t;
 
 typedef struct {
@@ -75,6 +83,14 @@ typedef struct {
     float* l1_map_ce;        /* out [n,H,W,C] |x_hat_ce - x_ce|, may be NULL                         */
     float* anomaly;          /* out [n,H,W,C] L1_vae * |d loss_vae / d x| (trainers/ceVAE.py:51); written by
                                      uad_backward's ENCODER segment, may be NULL                          */
+    /* ---- spatial GMVAE only (models/gaussian_mixture_variational_autoencoder_spatial.py:9-65) ----
+     * x_hat = xz_mu; z_mu / z_log_sigma are the [n,r,r,dim_z] maps (r = inter_res); scalars = {mean_p_loss
+     * (= reconstructionLoss), conditional_prior_loss, loss, w_prior_loss, c_prior_loss, 0, 0, 0} */
+    const float* eps_w;      /* in  [n,r,r,dim_w] N(0,1) noise of w_sampled (:27); NULL = 0          */
+    const float* eps_z;      /* in  [n,r,r,dim_z] N(0,1) noise of z_sampled (:32); NULL = 0          */
+    float* w_mu;             /* out [n,r,r,dim_w], may be NULL                                       */
+    float* w_log_sigma;      /* out [n,r,r,dim_w], may be NULL                                       */
+    float* pc;               /* out [n,r,r,dim_c] softmax mixture posterior (:63), may be NULL       */
 } uad_io_t;
 
 const char* uad_last_error(void);
@@ -117,6 +133,13 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
 /* uad_forward(want_backward=1) + uad_backward(ALL) + uad_adam_step */
 int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float beta1, float beta2, float eps,
                    void* stream);
+
+/* spatial GMVAE restoration (trainers/GMVAE_spatial.py:178-190): one `sess.run(grads)` + host update, on device.
+ * grads = d( loss + sum_n tv_lambda * TV_n(x - xz_mu) ) / d x  at the current x_restored; then
+ * x_restored -= restore_lr * grads in place.  grads_out (may be NULL) receives the gradient.  No parameter gradient is
+ * computed and no host synchronisation happens: the caller enqueues restore_steps calls back to back. */
+int uad_restore_step(uad_model_t* m, float* x_restored, const float* eps_w, const float* eps_z, int n, float tv_lambda,
+                     float restore_lr, float* grads_out, void* stream);
 
 int uad_set_math_mode(uad_model_t* m, int mode);   /* UAD_MATH_* ; takes effect at the next uad_forward */
 int uad_get_math_mode(const uad_model_t* m);

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('UAD_LIB') or os.path.join(_HERE, 'libuad_hip.so')   # UAD_LIB: A/B builds for kernel tuning
 
 UAD_OK = 0
-ARCH_AE, ARCH_VAE, ARCH_CEVAE = 0, 1, 2
+ARCH_AE, ARCH_VAE, ARCH_CEVAE, ARCH_GMVAE_SPATIAL = 0, 1, 2, 3
 BUF_PARAMS, BUF_GRADS, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
 SEG_DECODER, SEG_BOTTLENECK, SEG_ENCODER, SEG_ALL = 0, 1, 2, -1
 MATH_F32, MATH_BF16X3 = 0, 1
@@ -17,7 +17,8 @@ c_float_p = C.c_void_p  # device pointers are passed as integers
 
 class UadConfig(C.Structure):
     _fields_ = [('arch', C.c_int), ('height', C.c_int), ('width', C.c_int), ('channels', C.c_int),
-                ('inter_res', C.c_int), ('zdim', C.c_int), ('max_batch', C.c_int)]
+                ('inter_res', C.c_int), ('zdim', C.c_int), ('max_batch', C.c_int),
+                ('dim_c', C.c_int), ('dim_z', C.c_int), ('dim_w', C.c_int), ('c_lambda', C.c_float)]
 
 
 class UadIO(C.Structure):
@@ -27,7 +28,10 @@ class UadIO(C.Structure):
                 ('rec_per_sample', C.c_void_p),
                 # ceVAE only
                 ('x_ce', C.c_void_p), ('mask_mu_ce', C.c_void_p), ('mask_dec_ce', C.c_void_p),
-                ('x_hat_ce', C.c_void_p), ('l1_map_ce', C.c_void_p), ('anomaly', C.c_void_p)]
+                ('x_hat_ce', C.c_void_p), ('l1_map_ce', C.c_void_p), ('anomaly', C.c_void_p),
+                # spatial GMVAE only
+                ('eps_w', C.c_void_p), ('eps_z', C.c_void_p), ('w_mu', C.c_void_p), ('w_log_sigma', C.c_void_p),
+                ('pc', C.c_void_p)]
 
 
 class UadConvDesc(C.Structure):
@@ -62,6 +66,8 @@ SYMBOLS = {
     'uad_adam_step': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_train_step': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),
+    'uad_restore_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                   C.c_void_p, C.c_void_p]),
     'uad_set_math_mode': (C.c_int, [C.c_void_p, C.c_int]),
     'uad_get_math_mode': (C.c_int, [C.c_void_p]),
     'uad_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),

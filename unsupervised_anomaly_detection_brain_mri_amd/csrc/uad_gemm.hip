@@ -1107,7 +1107,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __res
 
 // Weight re-layout for the spatial kernels.  One thread per source element W[tap][cb][cs] of any of up to 8 tensors:
 //   F-pack: Wp[tap][cb/4][cs][cb%4]     D-pack: Wq[tap][cs/4][cb][cs%4]      (both at the tensor's own flat offset)
-struct PackDesc { long long off[8]; int cb[8], cs[8], count[8]; int n; };
+struct PackDesc { long long off[16]; int cb[16], cs[16], count[16]; int n; };
 __global__ void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ Wf, float* __restrict__ Wd, PackDesc pd) {
     long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int t = 0;

@@ -113,6 +113,8 @@ struct UadFinalArgs {
     float* d_c;              // [N,H,W,C]
     float* red_partial;      // [N*blocks_per_sample][3*C+1]: dwf[C], S1[C], S2[C], dbf
     float inv_batch;         // 1/global_batch
+    const float* dxhat_in;   // optional [N,H,W,1]: d objective / d x_hat given by the caller (GMVAE restore term);
+                             // null => sign(x_hat - x) * inv_batch
 };
 int uad_final_blocks_per_sample(int H, int W);
 void uad_launch_final_fwd_bwd(const UadFinalArgs& a, hipStream_t st);
@@ -128,6 +130,45 @@ void uad_launch_reparam_bwd(int n, int n_vae, int zdim, const float* dz, const f
 // ceVAE: data gradient of the first conv (d.N samples) + direct L1-label term -> anomaly = |x-x_hat| * |d loss_vae/dx|
 void uad_launch_conv_first_dgrad(const UadConvDesc& d, const float* g, const float* W, const float* x,
                                  const float* x_hat, float inv_batch, float* anomaly, float* dx, hipStream_t st);
+// GMVAE form: gx = (data gradient) - dxhat[pix] (x's direct term is minus the reconstruction's), dx (optional) = gx,
+// and, if x_upd is given, the restoration update x_upd[pix] -= restore_lr * gx (trainers/GMVAE_spatial.py:189-190)
+void uad_launch_conv_first_dgrad_restore(const UadConvDesc& d, const float* g, const float* W, const float* dxhat,
+                                         float* dx, float* x_upd, float restore_lr, hipStream_t st);
+
+// ---- spatial GMVAE latent heads (uad_gmvae.hip) ----
+struct UadGmArgs {
+    int cenc, W, Z, C;                  // encoder width, dim_w, dim_z, dim_c
+    float c_lambda, inv_batch;
+    // last encoder block: pre-BN output + its BN (activation on load)
+    const float* c_enc; const float* scale; const float* shift; float alpha, mult;
+    // head parameters (flat-buffer pointers)
+    const float *wmu_k, *wmu_b, *wls_k, *wls_b, *zmu_k, *zmu_b, *zls_k, *zls_b, *c7_k, *c7_b, *m_k, *m_b, *l_k, *l_b, *var;
+    const float *eps_w, *eps_z;         // [L,W], [L,Z] or null
+    // forward outputs
+    float* h_out;                       // [L,cenc] activated encoder feature map (decoder input, wgrad operand)
+    float* loc_loss;                    // [L,3] con, w-prior, c-prior of each location
+    float *w_mu, *w_ls, *z_mu, *z_ls, *pc;   // optional maps
+    // backward
+    const float* dh_dec;                // [L,cenc] d loss / d h through the decoder
+    float* g_out;                       // [L,cenc] d loss / d c_enc
+    float* colpart;                     // [L][2][cenc]
+    float *dvec_heads, *dvec_a7, *dvec_M, *dvec_Lq, *ws_out, *mid_out;   // per-location vectors for the weight gradients
+};
+struct UadGmWgradArgs {
+    struct Job { const float* A; int lda; const float* B; int ldb; int b; int off; };
+    Job job[16];
+    int njobs, total, L, chunk;
+    float* partial;                     // [chunks][total]
+};
+size_t uad_gm_lds_bytes(const UadGmArgs& a, bool bwd);
+void uad_launch_gm_heads_fwd(const UadGmArgs& a, int locations, hipStream_t st);
+void uad_launch_gm_heads_bwd(const UadGmArgs& a, int locations, hipStream_t st);
+int uad_gm_wgrad_chunks(int L);
+void uad_launch_gm_heads_wgrad(UadGmWgradArgs a, float* out, hipStream_t st);
+void uad_launch_tv_dxhat(const float* x, const float* xh, int N, int H, int W, float inv_batch, float tv_lambda,
+                         float* dxhat, hipStream_t st);
+void uad_launch_gm_loss_finalize(const float* rec_partial, int n, int bps, const float* loc_loss, int lps,
+                                 float inv_batch, float* rec_per_sample, float* scalars, hipStream_t st);
 // y = x * mask (mask may be null -> copy)
 void uad_launch_mul(const float* x, const float* mask, float* y, size_t n, hipStream_t st);
 // scalars[8] = {reconstructionLoss, kl, loss, 0, Rec_vae, Rec_ce, loss_vae, 0}; samples [n_vae, n) = ceVAE context branch

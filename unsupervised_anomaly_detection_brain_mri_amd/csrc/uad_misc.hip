@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) final_kernel(const UadFinalArgs a, int pi
             rec += fabsf(diff);
         }
         if (BWD) {
-            const float s = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * a.inv_batch;
+            const float s = a.dxhat_in ? a.dxhat_in[pix] : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * a.inv_batch;
             const float wv[4] = {wf.x, wf.y, wf.z, wf.w};
             const float cv[4] = {c.x, c.y, c.z, c.w};
             const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
@@ -412,7 +412,9 @@ __global__ void __launch_bounds__(256) conv_first_dgrad_kernel(UadConvDesc d, co
                                                                const float* __restrict__ W,
                                                                const float* __restrict__ x,
                                                                const float* __restrict__ x_hat, float inv_batch,
-                                                               float* __restrict__ anomaly, float* __restrict__ dx_out) {
+                                                               float* __restrict__ anomaly, float* __restrict__ dx_out,
+                                                               const float* __restrict__ dxhat, float* __restrict__ x_upd,
+                                                               float restore_lr) {
     extern __shared__ __attribute__((aligned(16))) float sw[];     // [KS*KS][CS]
     const int CS = d.CS, KS = d.KS, S = d.S, P = d.P;
     for (int i = threadIdx.x; i < KS * KS * CS; i += 256) sw[i] = W[i];
@@ -446,6 +448,13 @@ __global__ void __launch_bounds__(256) conv_first_dgrad_kernel(UadConvDesc d, co
             }
             acc += a0 + a1;
         }
+    }
+    if (dxhat) {
+        // GMVAE restore objective: x enters it directly only through r = x - x_hat, so its direct gradient is -dxhat
+        const float gx = acc - dxhat[pix];
+        if (dx_out) dx_out[pix] = gx;
+        if (x_upd) x_upd[pix] -= restore_lr * gx;
+        return;
     }
     const float diff = x[pix] - x_hat[pix];
     const float gx = acc + (diff > 0.f ? inv_batch : (diff < 0.f ? -inv_batch : 0.f));
@@ -593,7 +602,15 @@ void uad_launch_conv_first_dgrad(const UadConvDesc& d, const float* g, const flo
                                  const float* x_hat, float inv_batch, float* anomaly, float* dx, hipStream_t st) {
     const size_t total = (size_t)d.N * d.HB * d.WB;
     hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3((total + 255) / 256), dim3(256),
-                       (size_t)d.KS * d.KS * d.CS * sizeof(float), st, d, g, W, x, x_hat, inv_batch, anomaly, dx);
+                       (size_t)d.KS * d.KS * d.CS * sizeof(float), st, d, g, W, x, x_hat, inv_batch, anomaly, dx,
+                       (const float*)nullptr, (float*)nullptr, 0.f);
+}
+void uad_launch_conv_first_dgrad_restore(const UadConvDesc& d, const float* g, const float* W, const float* dxhat,
+                                         float* dx, float* x_upd, float restore_lr, hipStream_t st) {
+    const size_t total = (size_t)d.N * d.HB * d.WB;
+    hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3((total + 255) / 256), dim3(256),
+                       (size_t)d.KS * d.KS * d.CS * sizeof(float), st, d, g, W, (const float*)nullptr,
+                       (const float*)nullptr, 0.f, (float*)nullptr, dx, dxhat, x_upd, restore_lr);
 }
 void uad_launch_mul(const float* x, const float* mask, float* y, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(mul_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, mask, y, n);

@@ -83,6 +83,15 @@ struct uad_model {
     // ceVAE: both branches run as one 2n-sample pass; staging for the concatenated inputs / outputs
     float *xcat, *mdec_cat, *l1_own;
     int nmul;                          // samples per user sample inside the handle (2 for ceVAE)
+    // spatial GMVAE: latent heads (15 contiguous tensors), their per-location scratch, TV-restore state
+    long long gm_off[15];              // wmu_k,wmu_b,wls_k,wls_b,zmu_k,zmu_b,zls_k,zls_b,c7_k,c7_b,m_k,m_b,l_k,l_b,var
+    long long gm_total;                // elements of the heads segment
+    float *gm_h, *gm_loc_loss, *gm_dheads, *gm_da7, *gm_mid, *gm_dM, *gm_dLq, *gm_ws, *gm_partial, *gm_dxhat;
+    const float* dec_in0;              // input of the first decoder ConvT: cb (AE family) or gm_h (GMVAE)
+    bool restore;                      // last forward was a restoration pass (TV term in the objective)
+    float restore_tv, restore_lr;
+    float* restore_x;                  // x_restored (updated in place by the backward) or null
+    float* restore_grads;              // optional gradient output
     // gradient ping-pong + small grads
     float *G0, *G1;
     float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
@@ -176,6 +185,22 @@ int dev_alloc(uad_model* m, float** p, size_t floats) {
     return UAD_OK;
 }
 
+// latent-head launch arguments of the spatial GMVAE (parameters + the last encoder block's activation-on-load)
+UadGmArgs gm_args(uad_model* m, const float* eps_w, const float* eps_z, float inv_batch) {
+    UadGmArgs a;
+    memset(&a, 0, sizeof a);
+    const ConvLayer& EL = m->enc.back();
+    a.cenc = m->cenc; a.W = m->cfg.dim_w; a.Z = m->cfg.dim_z; a.C = m->cfg.dim_c;
+    a.c_lambda = m->cfg.c_lambda; a.inv_batch = inv_batch;
+    a.c_enc = EL.c; a.scale = P(m, EL.gamma); a.shift = P(m, EL.beta); a.alpha = kLrelu; a.mult = 1.0f / sqrtf(1.0f + kBnEps);
+    const float** slots[15] = {&a.wmu_k, &a.wmu_b, &a.wls_k, &a.wls_b, &a.zmu_k, &a.zmu_b, &a.zls_k, &a.zls_b,
+                               &a.c7_k, &a.c7_b, &a.m_k, &a.m_b, &a.l_k, &a.l_b, &a.var};
+    for (int k = 0; k < 15; ++k) *slots[k] = P(m, m->gm_off[k]);
+    a.eps_w = eps_w; a.eps_z = eps_z;
+    a.h_out = m->gm_h; a.loc_loss = m->gm_loc_loss;
+    return a;
+}
+
 UadConvDesc dense_desc(int n, int in, int out) { return UadConvDesc{n, 1, 1, in, 1, 1, out, 1, 1, 0}; }
 UadConvDesc conv1x1_desc(int n, int h, int w, int cin, int cout) { return UadConvDesc{n, h, w, cin, h, w, cout, 1, 1, 0}; }
 
@@ -195,8 +220,11 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     if (cfg->inter_res <= 0 || (cfg->inter_res & (cfg->inter_res - 1)) || cfg->inter_res >= H)
         return fail(UAD_ERR_INVALID, "inter_res must be a power of two smaller than height");
     if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
-    if (cfg->arch != UAD_ARCH_AE && cfg->arch != UAD_ARCH_VAE && cfg->arch != UAD_ARCH_CEVAE) return fail(UAD_ERR_INVALID, "bad arch");
-    if (cfg->zdim <= 0 || cfg->zdim % 8) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
+    if (cfg->arch < UAD_ARCH_AE || cfg->arch > UAD_ARCH_GMVAE_SPATIAL) return fail(UAD_ERR_INVALID, "bad arch");
+    const bool gm = cfg->arch == UAD_ARCH_GMVAE_SPATIAL;
+    if (gm && (cfg->dim_c < 1 || cfg->dim_c > 64 || cfg->dim_z < 1 || cfg->dim_w < 1 || cfg->dim_z * cfg->dim_c > 4096 || cfg->dim_w > 64))
+        return fail(UAD_ERR_UNSUPPORTED, "GMVAE: need 1 <= dim_c <= 64, dim_z*dim_c <= 4096, 1 <= dim_w <= 64");
+    if (!gm && (cfg->zdim <= 0 || cfg->zdim % 8)) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
     if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
 
     uad_model* m = new uad_model();
@@ -207,11 +235,24 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     m->prof_on = false;
     const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
     m->n_pool = npool;
-    const bool vae = cfg->arch != UAD_ARCH_AE;
+    if (npool < 1 || npool > 7) { delete m; return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 1..7 conv blocks supported", npool); }
+    const bool vae = cfg->arch == UAD_ARCH_VAE || cfg->arch == UAD_ARCH_CEVAE;
     const bool cevae = cfg->arch == UAD_ARCH_CEVAE;
     m->nmul = cevae ? 2 : 1;
     m->data_only = false;
+    m->restore = false; m->restore_x = nullptr; m->restore_grads = nullptr; m->restore_tv = 0.f; m->restore_lr = 0.f;
+    m->gm_total = 0;
     char nm[128];
+    // the GMVAE graph opens no variable scope: plain layer names, BN layers numbered across encoder and decoder
+    const char* ENC = gm ? "" : "Encoder/";
+    const char* DEC = gm ? "" : "Decoder/";
+    int bn_idx = 0;
+    auto bn_scope = [&](const char* scope, int ae_idx) {
+        std::string r = scope;
+        if (gm) { r += bn_idx == 0 ? "batch_normalization" : "batch_normalization_" + std::to_string(bn_idx); ++bn_idx; }
+        else r += ae_idx < 0 ? "batch_normalization" : "batch_normalization_" + std::to_string(ae_idx);
+        return r;
+    };
 
     // ---- parameter table in TF variable-creation order ----
     int cin = cfg->channels, res = H;
@@ -219,10 +260,11 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
         const int f = (32 << i) < 128 ? (32 << i) : 128;
         ConvLayer L;
         L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
-        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
-        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
-        snprintf(nm, sizeof nm, "Encoder/batch_normalization_%d/gamma", i); L.gamma = add_tensor(m, nm, 1, f, 1, 1, 1);
-        snprintf(nm, sizeof nm, "Encoder/batch_normalization_%d/beta", i); L.beta = add_tensor(m, nm, 1, f, 1, 1, 1);
+        snprintf(nm, sizeof nm, "%senc_conv2D_%d/kernel", ENC, i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
+        snprintf(nm, sizeof nm, "%senc_conv2D_%d/bias", ENC, i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        const std::string bs = bn_scope(ENC, i);
+        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
+        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
         L.c = nullptr;
         m->enc.push_back(L);
         cin = f; res /= 2;
@@ -232,6 +274,25 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     const int ir = cfg->inter_res;
     m->flat = ir * ir * m->cmid;
     if (m->cmid % 8 || m->flat % 8) { delete m; return fail(UAD_ERR_UNSUPPORTED, "bottleneck channels must be a multiple of 8"); }
+    m->bw = m->bb = m->muw = m->mub = m->sgw = m->sgb = m->dw = m->db = m->rw = m->rb = -1;
+    if (gm) {
+        // models/gaussian_mixture_variational_autoencoder_spatial.py:14-43, creation (= first call) order
+        const int W = cfg->dim_w, Z = cfg->dim_z, Q = cfg->dim_z * cfg->dim_c;
+        const char* hn[4] = {"q_wz_x/w_mu", "q_wz_x/w_log_sigma", "q_wz_x/z_mu", "q_wz_x/z_log_sigma"};
+        const int hd[4] = {W, W, Z, Z};
+        for (int k = 0; k < 4; ++k) {
+            m->gm_off[2 * k] = add_tensor(m, std::string(hn[k]) + "/kernel", 4, 1, 1, m->cenc, hd[k]);
+            m->gm_off[2 * k + 1] = add_tensor(m, std::string(hn[k]) + "/bias", 1, hd[k], 1, 1, 1);
+        }
+        m->gm_off[8] = add_tensor(m, "p_z_wc/1x1convlayer/kernel", 4, 1, 1, W, 64);
+        m->gm_off[9] = add_tensor(m, "p_z_wc/1x1convlayer/bias", 1, 64, 1, 1, 1);
+        m->gm_off[10] = add_tensor(m, "p_z_wc/z_wc_mu/kernel", 4, 1, 1, 64, Q);
+        m->gm_off[11] = add_tensor(m, "p_z_wc/z_wc_mu/bias", 1, Q, 1, 1, 1);
+        m->gm_off[12] = add_tensor(m, "p_z_wc/z_wc_log_sigma/kernel", 4, 1, 1, 64, Q);
+        m->gm_off[13] = add_tensor(m, "p_z_wc/z_wc_log_sigma/bias", 1, Q, 1, 1, 1);
+        m->gm_off[14] = add_tensor(m, "Variable", 1, Q, 1, 1, 1);
+        m->gm_total = m->nparams - m->gm_off[0];
+    } else {
     m->bw = add_tensor(m, "Bottleneck/conv2d/kernel", 4, 1, 1, m->cenc, m->cmid);
     m->bb = add_tensor(m, "Bottleneck/conv2d/bias", 1, m->cmid, 1, 1, 1);
     // the ceVAE graph leaves its Dense layers unnamed (context_encoder_variational_autoencoder.py:30-32): keras numbers them
@@ -252,25 +313,30 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     m->db = add_tensor(m, std::string(n_dec) + "/bias", 1, m->flat, 1, 1, 1);
     m->rw = add_tensor(m, "Bottleneck/conv2d_1/kernel", 4, 1, 1, m->cmid, m->cenc);
     m->rb = add_tensor(m, "Bottleneck/conv2d_1/bias", 1, m->cenc, 1, 1, 1);
+    }
     m->seg_off[UAD_SEG_BOTTLENECK] = m->seg_cnt[UAD_SEG_ENCODER];
     m->seg_cnt[UAD_SEG_BOTTLENECK] = m->nparams - m->seg_off[UAD_SEG_BOTTLENECK];
-    m->dbn_g = add_tensor(m, "Decoder/batch_normalization/gamma", 1, m->cenc, 1, 1, 1);
-    m->dbn_b = add_tensor(m, "Decoder/batch_normalization/beta", 1, m->cenc, 1, 1, 1);
+    {
+        const std::string bs = bn_scope(DEC, -1);
+        m->dbn_g = add_tensor(m, bs + "/gamma", 1, m->cenc, 1, 1, 1);
+        m->dbn_b = add_tensor(m, bs + "/beta", 1, m->cenc, 1, 1, 1);
+    }
     cin = m->cenc; res = ir;
     for (int i = 0; i < npool; ++i) {
         const int f = (128 >> i) > 32 ? (128 >> i) : 32;
         ConvLayer L;
         L.d = UadConvDesc{1, res * 2, res * 2, f, res, res, cin, 5, 2, 1};   // big = output (f ch), small = input (cin ch)
-        snprintf(nm, sizeof nm, "Decoder/dec_Conv2DT_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, f, cin);
-        snprintf(nm, sizeof nm, "Decoder/dec_Conv2DT_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
-        snprintf(nm, sizeof nm, "Decoder/batch_normalization_%d/gamma", i + 1); L.gamma = add_tensor(m, nm, 1, f, 1, 1, 1);
-        snprintf(nm, sizeof nm, "Decoder/batch_normalization_%d/beta", i + 1); L.beta = add_tensor(m, nm, 1, f, 1, 1, 1);
+        snprintf(nm, sizeof nm, "%sdec_Conv2DT_%d/kernel", DEC, i); L.w = add_tensor(m, nm, 4, 5, 5, f, cin);
+        snprintf(nm, sizeof nm, "%sdec_Conv2DT_%d/bias", DEC, i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        const std::string bs = bn_scope(DEC, i + 1);
+        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
+        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
         L.c = nullptr;
         m->dec.push_back(L);
         cin = f; res *= 2;
     }
-    m->fw = add_tensor(m, "Decoder/dec_Conv2D_final/kernel", 4, 1, 1, cin, cfg->channels);
-    m->fb = add_tensor(m, "Decoder/dec_Conv2D_final/bias", 1, cfg->channels, 1, 1, 1);
+    m->fw = add_tensor(m, std::string(DEC) + "dec_Conv2D_final/kernel", 4, 1, 1, cin, cfg->channels);
+    m->fb = add_tensor(m, std::string(DEC) + "dec_Conv2D_final/bias", 1, cfg->channels, 1, 1, 1);
     m->seg_off[UAD_SEG_DECODER] = m->seg_off[UAD_SEG_BOTTLENECK] + m->seg_cnt[UAD_SEG_BOTTLENECK];
     m->seg_cnt[UAD_SEG_DECODER] = m->nparams - m->seg_off[UAD_SEG_DECODER];
     if (cin > 64 || cin % 4) { delete m; return fail(UAD_ERR_UNSUPPORTED, "last decoder width %d unsupported", cin); }
@@ -289,12 +355,20 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     size_t maxact = 0;
     for (auto& L : m->enc) { size_t n = NB * L.d.HS * L.d.WS * L.d.CS; ALLOC(L.c, n); if (n > maxact) maxact = n; }
     for (auto& L : m->dec) { size_t n = NB * L.d.HB * L.d.WB * L.d.CB; ALLOC(L.c, n); if (n > maxact) maxact = n; }
-    const size_t nz = NB * cfg->zdim, nflat = NB * m->flat, ncb = NB * ir * ir * m->cenc;
+    const size_t nz = NB * (gm ? 8 : cfg->zdim), nflat = NB * m->flat, ncb = NB * ir * ir * m->cenc;
     ALLOC(m->t, nflat); ALLOC(m->mu_raw, nz); ALLOC(m->ls_raw, nz); ALLOC(m->mu, nz); ALLOC(m->ls, nz);
     ALLOC(m->sigma, nz); ALLOC(m->z, nz); ALLOC(m->dvec, nflat); ALLOC(m->cb, ncb); ALLOC(m->kl, NB);
     ALLOC(m->xhat_own, NB * H * Wd * cfg->channels);
     m->xcat = m->mdec_cat = m->l1_own = nullptr;
     if (cevae) { ALLOC(m->xcat, NB * H * Wd * cfg->channels); ALLOC(m->mdec_cat, nflat); ALLOC(m->l1_own, NB * H * Wd * cfg->channels); }
+    m->gm_h = m->gm_loc_loss = m->gm_dheads = m->gm_da7 = m->gm_mid = m->gm_dM = m->gm_dLq = m->gm_ws = m->gm_partial = m->gm_dxhat = nullptr;
+    if (gm) {
+        const size_t L = NB * ir * ir, Q = (size_t)cfg->dim_z * cfg->dim_c, O = 2 * (size_t)cfg->dim_w + 2 * (size_t)cfg->dim_z;
+        ALLOC(m->gm_h, L * m->cenc); ALLOC(m->gm_loc_loss, L * 3); ALLOC(m->gm_dheads, L * O); ALLOC(m->gm_da7, L * 64);
+        ALLOC(m->gm_mid, L * 64); ALLOC(m->gm_dM, L * Q); ALLOC(m->gm_dLq, L * Q); ALLOC(m->gm_ws, L * cfg->dim_w);
+        ALLOC(m->gm_partial, (size_t)64 * m->gm_total); ALLOC(m->gm_dxhat, NB * H * Wd * cfg->channels);
+    }
+    m->dec_in0 = gm ? m->gm_h : m->cb;
     ALLOC(m->G0, maxact); ALLOC(m->G1, maxact);
     ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
     ALLOC(m->g_small[4], nflat); ALLOC(m->g_small[5], nflat);
@@ -304,6 +378,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     for (auto& L : m->enc) cp_need(NB * L.d.HS * L.d.WS, 4, L.d.CB);
     for (auto& L : m->dec) cp_need(NB * L.d.HS * L.d.WS, 1, L.d.CS);
     cp_need(NB * ir * ir, 1, m->cenc);
+    if (gm) { size_t v = NB * ir * ir * 2 * m->cenc; if (v > cp) cp = v; }
     m->colpart_cap = cp; ALLOC(m->colpart, cp);
     for (int k = 0; k < 16; ++k) { m->cp_slot[k] = nullptr; ALLOC(m->cp_slot[k], cp); }
     m->ev_next = 0; m->side = nullptr;
@@ -312,8 +387,10 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     auto wp_need = [&](UadConvDesc d) { d.N = (int)NB; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
     for (size_t i = 1; i < m->enc.size(); ++i) wp_need(m->enc[i].d);
     for (auto& L : m->dec) wp_need(L.d);
-    wp_need(conv1x1_desc(1, ir, ir, m->cenc, m->cmid)); wp_need(conv1x1_desc(1, ir, ir, m->cmid, m->cenc));
-    wp_need(dense_desc(1, m->flat, cfg->zdim)); wp_need(dense_desc(1, cfg->zdim, m->flat));
+    if (!gm) {
+        wp_need(conv1x1_desc(1, ir, ir, m->cenc, m->cmid)); wp_need(conv1x1_desc(1, ir, ir, m->cmid, m->cenc));
+        wp_need(dense_desc(1, m->flat, cfg->zdim)); wp_need(dense_desc(1, cfg->zdim, m->flat));
+    }
     { UadConvDesc d0 = m->enc[0].d; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
     m->wpartial_cap = wp; ALLOC(m->wpartial, wp);
     for (int k = 0; k < 16; ++k) { m->wp_slot[k] = nullptr; ALLOC(m->wp_slot[k], wp); }
@@ -322,10 +399,12 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
         auto want = [&](UadConvDesc d, bool f, bool pack) { d.N = (int)NB; size_t v = uad_conv_ws_floats(d, f, pack); if (v > need) need = v; };
         for (size_t i = 1; i < m->enc.size(); ++i) { want(m->enc[i].d, true, true); want(m->enc[i].d, false, true); }
         for (auto& L : m->dec) { want(L.d, true, true); want(L.d, false, true); }
+        if (!gm) {
         want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), true, false); want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), false, false);
         want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), true, false); want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), false, false);
         want(dense_desc(1, m->flat, cfg->zdim), true, false); want(dense_desc(1, m->flat, cfg->zdim), false, false);
         want(dense_desc(1, cfg->zdim, m->flat), true, false); want(dense_desc(1, cfg->zdim, m->flat), false, false);
+        }
         m->ws.floats = need; m->ws.ptr = nullptr;
         ALLOC(m->ws.ptr, need);
     }
@@ -412,8 +491,9 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
     if (!io->x) return fail(UAD_ERR_INVALID, "io.x is null");
     hipStream_t st = (hipStream_t)stream;
-    const bool vae = m->cfg.arch != UAD_ARCH_AE;
+    const bool vae = m->cfg.arch == UAD_ARCH_VAE || m->cfg.arch == UAD_ARCH_CEVAE;
     const bool cevae = m->cfg.arch == UAD_ARCH_CEVAE;
+    const bool gm = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL;
     const int ir = m->cfg.inter_res;
     const int nu = n;                 // samples the caller passed
     const float* xin = io->x;
@@ -438,8 +518,8 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     // refresh the packed 5x5 kernels if the parameters changed since the last pack
     if (!m->packed_valid) {
         PROF("pack.weights");
-        long long offs[8]; int cbs[8], css[8], taps[8]; int np = 0;
-        auto add = [&](const ConvLayer& L) { if (np < 8 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
+        long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
+        auto add = [&](const ConvLayer& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
         for (size_t i = 1; i < m->enc.size(); ++i) add(m->enc[i]);
         for (auto& L : m->dec) add(L);
         if (np > 0) {
@@ -466,7 +546,12 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     }
     const ConvLayer& EL = m->enc.back();
     // bottleneck
-    {
+    if (gm) {
+        PROF("gm.heads.fwd");
+        UadGmArgs ga = gm_args(m, io->eps_w, io->eps_z, 1.0f / (float)nu);
+        ga.w_mu = io->w_mu; ga.w_ls = io->w_log_sigma; ga.z_mu = io->z_mu; ga.z_ls = io->z_log_sigma; ga.pc = io->pc;
+        uad_launch_gm_heads_fwd(ga, n * ir * ir, st);
+    } else {
     PROF("bott.fwd");
     uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cenc, m->cmid), EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu),
                       P(m, m->bw), m->t, epi_bias(P(m, m->bb)), st, nullptr, m->ws);
@@ -488,7 +573,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     for (size_t i = 0; i < m->dec.size(); ++i) {
         PROF(kDecF[i & 7]);
         UadConvDesc d = m->dec[i].d; d.N = n;
-        const float* in = (i == 0) ? m->cb : m->dec[i - 1].c;
+        const float* in = (i == 0) ? m->dec_in0 : m->dec[i - 1].c;
         UadXform xf = (i == 0) ? bn_xform(m, m->dbn_g, m->dbn_b, 0.0f)
                                : bn_xform(m, m->dec[i - 1].gamma, m->dec[i - 1].beta, kLrelu);
         uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), m->dec[i].c, epi_bias(P(m, m->dec[i].b)), st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]));
@@ -506,9 +591,25 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     fa.d_c = want_backward ? m->G0 : nullptr;
     fa.red_partial = m->red_partial;
     fa.inv_batch = 1.0f / (float)nu;
-    { PROF(want_backward ? "final.fwd+bwd" : "final.fwd"); uad_launch_final_fwd_bwd(fa, st); }
+    fa.dxhat_in = nullptr;
+    if (m->restore && want_backward) {
+        // restoration objective: d / d x_hat needs the finished reconstruction's neighbours (TV), so two passes
+        PROF("final.fwd+tv+bwd");
+        float* dc = fa.d_c; fa.d_c = nullptr;
+        uad_launch_final_fwd_bwd(fa, st);
+        uad_launch_tv_dxhat(xin, fa.x_hat, n, fa.H, fa.W, fa.inv_batch, m->restore_tv, m->gm_dxhat, st);
+        fa.d_c = dc; fa.dxhat_in = m->gm_dxhat;
+        uad_launch_final_fwd_bwd(fa, st);
+    } else {
+        PROF(want_backward ? "final.fwd+bwd" : "final.fwd"); uad_launch_final_fwd_bwd(fa, st);
+    }
     PROF("loss.finalize");
     const int bps = uad_final_blocks_per_sample(fa.H, fa.W);
+    if (gm) {
+        uad_launch_gm_loss_finalize(m->rec_partial, n, bps, m->gm_loc_loss, ir * ir, 1.0f / (float)nu,
+                                    io->rec_per_sample ? io->rec_per_sample : m->rec_ps,
+                                    io->scalars ? io->scalars : m->scalars_own, st);
+    } else
     uad_launch_loss_finalize(m->rec_partial, n, nu, bps, vae ? m->kl : nullptr, 1.0f / (float)nu, cevae ? 0.5f : 1.0f,
                              io->rec_per_sample ? io->rec_per_sample : m->rec_ps,
                              io->scalars ? io->scalars : m->scalars_own, st);
@@ -520,8 +621,8 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         if (io->l1_map_ce) HIP_TRY(hipMemcpyAsync(io->l1_map_ce, m->l1_own + xe, xb, hipMemcpyDeviceToDevice, st));
     }
     // optional latent outputs (VAE-branch samples)
-    const size_t zb = (size_t)nu * m->cfg.zdim * sizeof(float);
-    if (io->z_mu) hipMemcpyAsync(io->z_mu, vae ? m->mu : m->z, zb, hipMemcpyDeviceToDevice, st);
+    const size_t zb = gm ? 0 : (size_t)nu * m->cfg.zdim * sizeof(float);
+    if (!gm && io->z_mu) hipMemcpyAsync(io->z_mu, vae ? m->mu : m->z, zb, hipMemcpyDeviceToDevice, st);
     if (vae && io->z_log_sigma) hipMemcpyAsync(io->z_log_sigma, m->ls, zb, hipMemcpyDeviceToDevice, st);
     if (vae && io->z_sigma) hipMemcpyAsync(io->z_sigma, m->sigma, zb, hipMemcpyDeviceToDevice, st);
     m->last_n = n; m->last_nuser = nu; m->last_io = *io; m->have_fwd = want_backward != 0;
@@ -579,7 +680,7 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
     float* gn = m->G1;
     for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
         UadConvDesc d = m->dec[i].d; d.N = n;
-        const float* in = (i == 0) ? m->cb : m->dec[i - 1].c;
+        const float* in = (i == 0) ? m->dec_in0 : m->dec[i - 1].c;
         const long long ig = (i == 0) ? m->dbn_g : m->dec[i - 1].gamma;
         const long long ib = (i == 0) ? m->dbn_b : m->dec[i - 1].beta;
         const float ia = (i == 0) ? 0.0f : kLrelu;
@@ -591,7 +692,7 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         { PROF(kDecD[i & 7]); UadEpilogue e = epi_bwd(m, in, ig, ib, ia); e.colpart = cp;
           uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
         edge(m, st, sd);   // column partials of this layer are ready
-        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), Gr(m, ibias), sd); }
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd); }
         float* tsw = g; g = gn; gn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
@@ -666,6 +767,51 @@ static int backward_bottleneck(uad_model* m, hipStream_t st) {
     return UAD_OK;
 }
 
+// spatial GMVAE: the "bottleneck" segment is the latent heads.  One kernel per map location recomputes the head forward,
+// back-propagates the three prior terms, adds the decoder's d loss / d h and applies the last encoder block's activation
+// backward; the head weight gradients are outer-product sums over the locations, reduced on the side stream.
+static int backward_gm_heads(uad_model* m, hipStream_t st) {
+    const int n = m->last_n;
+    const int ir = m->cfg.inter_res, L = n * ir * ir;
+    const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
+    const bool pg = !m->data_only;
+    hipStream_t sd = m->side;
+    const ConvLayer& EL = m->enc.back();
+    float* cp = m->cp_slot[15];
+    UadGmArgs ga = gm_args(m, m->last_io.eps_w, m->last_io.eps_z, 1.0f / (float)m->last_nuser);
+    ga.h_out = nullptr;
+    ga.dh_dec = m->G0; ga.g_out = m->G1; ga.colpart = cp;
+    ga.dvec_heads = m->gm_dheads; ga.dvec_a7 = m->gm_da7; ga.dvec_M = m->gm_dM; ga.dvec_Lq = m->gm_dLq;
+    ga.ws_out = m->gm_ws; ga.mid_out = m->gm_mid;
+    { PROF("gm.heads.bwd"); uad_launch_gm_heads_bwd(ga, L, st); }
+    edge(m, st, sd);
+    if (pg) {
+        PROF_ON("gm.heads.wgrad", sd);
+        uad_launch_bn_grad_finalize(cp, L, m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma), Gr(m, EL.beta), Gr(m, EL.b), sd);
+        const int W = ga.W, Z = ga.Z, Q = ga.Z * ga.C, O = 2 * W + 2 * Z, CE = m->cenc;
+        UadGmWgradArgs wa;
+        memset(&wa, 0, sizeof wa);
+        const long long base = m->gm_off[0];
+        auto job = [&](int k, const float* A, int lda, const float* B, int ldb, int b) {
+            wa.job[k] = UadGmWgradArgs::Job{A, lda, B, ldb, b, (int)(m->gm_off[k] - base)};
+        };
+        const float* dh = m->gm_dheads;
+        job(0, m->gm_h, CE, dh, O, W);              job(1, nullptr, 0, dh, O, W);
+        job(2, m->gm_h, CE, dh + W, O, W);          job(3, nullptr, 0, dh + W, O, W);
+        job(4, m->gm_h, CE, dh + 2 * W, O, Z);      job(5, nullptr, 0, dh + 2 * W, O, Z);
+        job(6, m->gm_h, CE, dh + 2 * W + Z, O, Z);  job(7, nullptr, 0, dh + 2 * W + Z, O, Z);
+        job(8, m->gm_ws, W, m->gm_da7, 64, 64);     job(9, nullptr, 0, m->gm_da7, 64, 64);
+        job(10, m->gm_mid, 64, m->gm_dM, Q, Q);     job(11, nullptr, 0, m->gm_dM, Q, Q);
+        job(12, m->gm_mid, 64, m->gm_dLq, Q, Q);    job(13, nullptr, 0, m->gm_dLq, Q, Q);
+        job(14, nullptr, 0, m->gm_dLq, Q, Q);
+        wa.njobs = 15; wa.total = (int)m->gm_total; wa.L = L; wa.partial = m->gm_partial;
+        uad_launch_gm_heads_wgrad(wa, Gr(m, base), sd);
+    }
+    float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;   // G0 = d loss / d c of the last encoder conv
+    edge(m, sd, st);
+    return UAD_OK;
+}
+
 static int backward_encoder(uad_model* m, hipStream_t st) {
     const int n = m->last_n;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
@@ -690,6 +836,12 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
     }
     UadConvDesc d0 = m->enc[0].d; d0.N = n;
     if (pg) { PROF("enc0.wgrad"); uad_launch_conv_first_wgrad(d0, m->x_eff, g, Gr(m, m->enc[0].w), m->wp_slot[8], st); }
+    if (m->restore && (m->restore_x || m->restore_grads)) {
+        // d (loss + TV restore) / d x, and the in-place restoration update (trainers/GMVAE_spatial.py:186-190)
+        PROF("enc0.dgrad");
+        uad_launch_conv_first_dgrad_restore(d0, g, P(m, m->enc[0].w), m->gm_dxhat, m->restore_grads, m->restore_x,
+                                            m->restore_lr, st);
+    }
     if (m->cfg.arch == UAD_ARCH_CEVAE && m->last_io.anomaly) {
         // d loss_vae / d x of the VAE-branch samples (the leading last_nuser rows) -> anomaly map (trainers/ceVAE.py:51)
         PROF("enc0.dgrad");
@@ -709,7 +861,8 @@ int uad_backward(uad_model_t* m, int segment, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int rc = UAD_OK;
     if (segment == UAD_SEG_ALL || segment == UAD_SEG_DECODER) rc = backward_decoder(m, st);
-    if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_BOTTLENECK)) rc = backward_bottleneck(m, st);
+    if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_BOTTLENECK))
+        rc = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL ? backward_gm_heads(m, st) : backward_bottleneck(m, st);
     if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_ENCODER)) {
         rc = backward_encoder(m, st);
         m->have_fwd = false;
@@ -734,6 +887,21 @@ int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float be
     int rc = uad_forward(m, io, n, 1, stream);
     if (rc == UAD_OK) rc = uad_backward(m, UAD_SEG_ALL, stream);
     if (rc == UAD_OK) rc = uad_adam_step(m, lr, beta1, beta2, eps, 1.0f, stream);
+    return rc;
+}
+
+int uad_restore_step(uad_model_t* m, float* x_restored, const float* eps_w, const float* eps_z, int n, float tv_lambda,
+                     float restore_lr, float* grads_out, void* stream) {
+    if (!m || !x_restored) return fail(UAD_ERR_INVALID, "null argument");
+    if (m->cfg.arch != UAD_ARCH_GMVAE_SPATIAL) return fail(UAD_ERR_INVALID, "uad_restore_step needs a spatial GMVAE handle");
+    uad_io_t io;
+    memset(&io, 0, sizeof io);
+    io.x = x_restored; io.eps_w = eps_w; io.eps_z = eps_z;
+    m->restore = true; m->restore_tv = tv_lambda; m->restore_lr = restore_lr;
+    m->restore_x = x_restored; m->restore_grads = grads_out;
+    int rc = uad_forward(m, &io, n, 2, stream);
+    if (rc == UAD_OK) rc = uad_backward(m, UAD_SEG_ALL, stream);
+    m->restore = false; m->restore_x = nullptr; m->restore_grads = nullptr;
     return rc;
 }
 

@@ -27,7 +27,7 @@ class Engine:
     (trainers/VAE.py:18-29): variables, optimizer slots and the compiled step."""
 
     def __init__(self, arch, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, device=None,
-                 math='bf16x3'):
+                 math='bf16x3', dim_c=9, dim_z=1, dim_w=1, c_lambda=1.0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
@@ -35,10 +35,13 @@ class Engine:
         torch.cuda.set_device(self.device)
         self.arch = arch
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
-        archs = {'AE': _lib.ARCH_AE, 'VAE': _lib.ARCH_VAE, 'ceVAE': _lib.ARCH_CEVAE}
+        archs = {'AE': _lib.ARCH_AE, 'VAE': _lib.ARCH_VAE, 'ceVAE': _lib.ARCH_CEVAE,
+                 'GMVAE_spatial': _lib.ARCH_GMVAE_SPATIAL}
         if arch not in archs:
             raise ValueError(f'unknown arch {arch!r}')
-        cfg = _lib.UadConfig(archs[arch], height, width, channels, inter_res, zdim, max_batch)
+        self.dim_c, self.dim_z, self.dim_w = int(dim_c), int(dim_z), int(dim_w)
+        cfg = _lib.UadConfig(archs[arch], height, width, channels, inter_res, zdim, max_batch, self.dim_c, self.dim_z,
+                             self.dim_w, float(c_lambda))
         h = C.c_void_p()
         _lib.check(self.lib.uad_create(C.byref(cfg), C.byref(h)))
         self.handle = h
@@ -192,6 +195,59 @@ class Engine:
         wb = 2 if want_backward == 'data' else (1 if want_backward else 0)
         _lib.check(self.lib.uad_forward(self.handle, C.byref(io), n, wb, self._stream()))
         return out
+
+    # ---------------------------------------------------------------- spatial GMVAE
+    def gm_forward(self, x, eps_w=None, eps_z=None, want_backward=False, want_l1=True, want_latents=True):
+        """Spatial GMVAE forward + losses.  eps_w [n,r,r,dim_w], eps_z [n,r,r,dim_z] (None = 0).  Returns DEVICE tensors:
+        x_hat (= xz_mu), L1 (opt), scalars [8] = (mean_p_loss, conditional_prior_loss, loss, w_prior_loss, c_prior_loss,
+        0, 0, 0), rec_per_sample, and (opt) z_mu, z_log_sigma, w_mu, w_log_sigma, pc maps."""
+        if self.arch != 'GMVAE_spatial':
+            raise ValueError('gm_forward needs a GMVAE_spatial engine')
+        x = self._dev(x)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (self.h, self.w, self.c):
+            raise ValueError(f'x must be [n,{self.h},{self.w},{self.c}], got {tuple(x.shape)}')
+        n, r = x.shape[0], self.inter
+        if n > self.max_batch:
+            raise ValueError(f'batch {n} > max_batch {self.max_batch}')
+        eps_w = self._dev(eps_w, (n, r, r, self.dim_w))
+        eps_z = self._dev(eps_z, (n, r, r, self.dim_z))
+        new = lambda *shape: torch.empty(shape, device=self.device)
+        out = {'x_hat': torch.empty_like(x), 'scalars': new(8), 'rec_per_sample': new(n)}
+        if want_l1:
+            out['L1'] = torch.empty_like(x)
+        if want_latents:
+            out.update(z_mu=new(n, r, r, self.dim_z), z_log_sigma=new(n, r, r, self.dim_z), w_mu=new(n, r, r, self.dim_w),
+                       w_log_sigma=new(n, r, r, self.dim_w), pc=new(n, r, r, self.dim_c))
+        io = _lib.UadIO(x=_ptr(x), x_hat=_ptr(out['x_hat']), l1_map=_ptr(out.get('L1')), z_mu=_ptr(out.get('z_mu')),
+                        z_log_sigma=_ptr(out.get('z_log_sigma')), scalars=_ptr(out['scalars']),
+                        rec_per_sample=_ptr(out['rec_per_sample']), eps_w=_ptr(eps_w), eps_z=_ptr(eps_z),
+                        w_mu=_ptr(out.get('w_mu')), w_log_sigma=_ptr(out.get('w_log_sigma')), pc=_ptr(out.get('pc')))
+        self._keep = (x, eps_w, eps_z, out)
+        _lib.check(self.lib.uad_forward(self.handle, C.byref(io), n, 1 if want_backward else 0, self._stream()))
+        return out
+
+    def gm_train_step(self, x, eps_w=None, eps_z=None, lr=5e-5, beta1=0.5, beta2=0.999, adam_eps=1e-8, **kw):
+        out = self.gm_forward(x, eps_w, eps_z, want_backward=True, **kw)
+        self.backward(_lib.SEG_ALL)
+        self.adam_step(lr, beta1, beta2, adam_eps)
+        return out
+
+    def restore_step(self, x_restored, eps_w=None, eps_z=None, tv_lambda=1.8, restore_lr=1e-3, want_grads=False):
+        """One restoration iteration ON DEVICE (trainers/GMVAE_spatial.py:178-190): x_restored (a contiguous fp32 CUDA
+        tensor [n,H,W,1]) is updated in place, x -= restore_lr * d(loss + tv_lambda * TV(x - xz_mu))/dx.  No host sync."""
+        if not (isinstance(x_restored, torch.Tensor) and x_restored.is_cuda and x_restored.dtype == torch.float32
+                and x_restored.is_contiguous()):
+            raise ValueError('x_restored must be a contiguous fp32 CUDA tensor (it is updated in place)')
+        n, r = x_restored.shape[0], self.inter
+        if tuple(x_restored.shape[1:]) != (self.h, self.w, self.c) or n > self.max_batch:
+            raise ValueError(f'x_restored must be [n<={self.max_batch},{self.h},{self.w},{self.c}]')
+        eps_w = self._dev(eps_w, (n, r, r, self.dim_w))
+        eps_z = self._dev(eps_z, (n, r, r, self.dim_z))
+        grads = torch.empty_like(x_restored) if want_grads else None
+        self._keep = (x_restored, eps_w, eps_z, grads)
+        _lib.check(self.lib.uad_restore_step(self.handle, _ptr(x_restored), _ptr(eps_w), _ptr(eps_z), n, float(tv_lambda),
+                                             float(restore_lr), _ptr(grads), self._stream()))
+        return grads
 
     def backward(self, segment=_lib.SEG_ALL):
         _lib.check(self.lib.uad_backward(self.handle, segment, self._stream()))
