@@ -106,6 +106,91 @@ def cpu_baseline(sample_batch=16, steps=4):
                       f'installable), {dt:.1f} s'}
 
 
+def bench_gmvae(args):
+    """BASELINE.json configs[4]: spatial GMVAE 256x256 restoration-mode inference, slices sharded over the GPUs (no
+    collective on the data path: replicas with different slices).  One 'step' = restore_steps restoration iterations
+    (forward + data-only backward of loss + tv*TV + in-place update, all on device) for a batch of slices; value =
+    restored slices per second."""
+    import torch
+    import torch.distributed as dist
+    from unsupervised_anomaly_detection_brain_mri_amd.engine import Engine
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import synthetic_slices
+    world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    hh, bs, rs = 256, BATCH, args.restore_steps
+    eng = Engine('GMVAE_spatial', hh, hh, 1, 8, max_batch=bs, device=f'cuda:{local_rank}', math=args.math, dim_c=9, dim_z=1, dim_w=1)
+    rng = np.random.default_rng(3)
+    flat = np.zeros(eng.nparams, np.float32)
+    for name, shape, off in eng.spec:
+        cnt = int(np.prod(shape))
+        if name.endswith('kernel'):
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            lim = np.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf))
+            flat[off:off + cnt] = rng.uniform(-lim, lim, cnt)
+        elif name.endswith('gamma'):
+            flat[off:off + cnt] = 1.0
+        elif name == 'Variable':
+            flat[off:off + cnt] = 0.1
+    eng.set_params(flat)
+    x0 = torch.from_numpy(synthetic_slices(bs, hh, hh, seed=1000 + rank)).cuda()
+    g = torch.Generator(device='cuda').manual_seed(1 + rank)
+    e_w = torch.randn(bs, 8, 8, 1, device='cuda', generator=g); e_z = torch.randn(bs, 8, 8, 1, device='cuda', generator=g)
+
+    def step():
+        xr = x0.clone()
+        for _ in range(rs):
+            eng.restore_step(xr, e_w, e_z, tv_lambda=1.8, restore_lr=1e-3)
+        return xr
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        xr = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(xr).all()
+    eng.profile(True)
+    xr = x0.clone()
+    for _ in range(5):
+        eng.restore_step(xr, e_w, e_z, tv_lambda=1.8, restore_lr=1e-3)
+    rep = eng.profile_report()
+    eng.profile(False)
+    if rank == 0:
+        value = bs * world * args.steps / dt
+        flop_slice_step = 4.88e9          # SURVEY.md §8d: fwd + data-only bwd at 256x256
+        res = {'metric': f'MRI slices/sec GMVAE-spatial restoration ({rs} steps, 256x256, bs={bs}/GPU)', 'value': round(value, 2),
+               'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': args.math, 'data': 'synthetic',
+               'config': {'workload': f'BASELINE.json configs[4]: spatial GMVAE 256x256x1, {rs} restoration steps per slice '
+                                      f'(forward + data-gradient backward of loss + 1.8*TV + in-place update, on device), '
+                                      f'{bs} slices per GPU per step, dim_c 9 dim_z 1 dim_w 1',
+                          'ms_per_restore_iteration': round(dt / args.steps / rs * 1e3, 4),
+                          'algorithmic_tflops': round(value * rs * flop_slice_step / 1e12, 2), 'parallelism': f'replicas{world}'},
+               'kernels': {t: {'ms': round(ms / c, 4)} for t, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -115,7 +200,8 @@ def main():
     ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'bf16x3'), choices=['f32', 'bf16x3'],
                     help='bf16x3 (default): split-bf16 products on the bf16 matrix cores, fp32 accumulate, parity 1e-4 vs the '
                          'fp32 oracle; f32: exact fp32 MFMA')
-    ap.add_argument('--arch', default='VAE', choices=['VAE', 'ceVAE'],
+    ap.add_argument('--restore-steps', type=int, default=150, help='GMVAE_spatial: restoration iterations per slice')
+    ap.add_argument('--arch', default='VAE', choices=['VAE', 'ceVAE', 'GMVAE_spatial'],
                     help='VAE = the headline workload (BASELINE.json configs[1]); ceVAE = configs[3] (16 slices per GPU: both '
                          'branches + the input-gradient anomaly map every step), reported for the record')
     ap.add_argument('--batch', type=int, default=0, help='slices per GPU (default 64 for VAE, 16 for ceVAE)')
@@ -123,6 +209,8 @@ def main():
     global BATCH
     BATCH = args.batch or (64 if args.arch == 'VAE' else 16)
     cevae = args.arch == 'ceVAE'
+    if args.arch == 'GMVAE_spatial':
+        return bench_gmvae(args)
 
     import torch
     import torch.distributed as dist

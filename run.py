@@ -67,4 +67,12 @@ if __name__ == '__main__':
     ap.add_argument('-O', '--threshold', default=None, type=float)
     ap.add_argument('-d', '--ds', default=None, type=str)
     ap.add_argument('-n', '--numMonteCarloSamples', default=0, type=int)
+    # GMVAE-only flags (reference run.py:144-150, same defaults)
+    ap.add_argument('-C', '--dim_c', default=9, type=int, help='only for GMVAE')
+    ap.add_argument('-Z', '--dim_z', default=128, type=int, help='only for GMVAE')
+    ap.add_argument('-W', '--dim_w', default=1, type=int, help='only for GMVAE')
+    ap.add_argument('-A', '--c_lambda', default=1, type=int, help='only for GMVAE')
+    ap.add_argument('-L', '--restore_lr', default=1e-3, type=float, help='only for GMVAE')
+    ap.add_argument('-S', '--restore_steps', default=150, type=int, help='only for GMVAE')
+    ap.add_argument('-T', '--tv_lambda', default=-1.0, type=float, help='only for GMVAE')
     main(ap.parse_args())

@@ -148,3 +148,57 @@ def test_cevae_trainer_surface_and_oracle_step(tmp_path):
     r0 = model.reconstruct(x, eps=0.0)
     assert not np.allclose(r0['reconstruction'], r['reconstruction'])
     model.engine.close()
+
+
+def test_gmvae_spatial_trainer_surface(tmp_path):
+    """trainers/GMVAE_spatial.py: Config defaults, train/process, step() fetch keys, reconstruct() = restoration loop on
+    the device (matches the oracle loop with injected noise), restore_steps == 0 path, determine_best_lambda."""
+    from oracle import gmvae as og
+    from unsupervised_anomaly_detection_brain_mri_amd.models import gaussian_mixture_variational_autoencoder_spatial as net
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import GMVAE_spatial
+    d = GMVAE_spatial.Config()
+    assert (d.dim_c, d.dim_z, d.dim_w, d.c_lambda, d.restore_lr, d.restore_steps, d.tv_lambda) == (6, 1, 1, 1, 1e-3, 150, 1.8)
+    cfg, opt, ds = _config(GMVAE_spatial, tmp_path, h=64, bs=4, epochs=2)
+    cfg.learningrate = 5e-5
+    cfg.dim_c, cfg.restore_steps, cfg.restore_lr = 9, 4, 5e-3
+    model = GMVAE_spatial(None, cfg, network=net)
+    assert model.model_dir == 'GMVAE_spatial_dSyntheticDataset_s64x64_gaussian_mixture_variational_autoencoder_spatial_b4_z64_'
+    p = model.engine.get_params()
+    assert np.allclose(p['Variable'], 0.1) and np.allclose(p['batch_normalization_3/gamma'], 1.0)
+
+    batch = ds.next_batch(4, set='VAL')[0]
+    eps = model._draw(4)
+    run = model.step(batch, Phase.VAL, eps=eps)
+    assert set(run) == {'reconstruction', 'L1', 'L2', 'L1_sum', 'L2_sum', 'reconstructionLoss', 'mean_p_loss',
+                        'conditional_prior_loss', 'w_prior_loss', 'c_prior_loss', 'loss'}
+    m = og.GMVAE(64, 64, 1, 8, 9, 1, 1, 1.0)
+    p64 = {k: np.asarray(v, np.float64) for k, v in p.items()}
+    out, _ = m.forward(p64, batch.astype(np.float64), eps[0].astype(np.float64), eps[1].astype(np.float64))
+    ls = m.losses(batch.astype(np.float64), out)
+    for k in ('mean_p_loss', 'conditional_prior_loss', 'w_prior_loss', 'c_prior_loss', 'loss'):
+        assert run[k] == pytest.approx(ls[k], rel=2e-4, abs=1e-3), k
+    assert run['L2_sum'] == pytest.approx(ls['L2_sum'], rel=1e-3)
+
+    # reconstruct(): restore_steps x in-place update on device == oracle loop with the same injected noise
+    r = model.reconstruct(batch[:2], eps=(eps[0][:2], eps[1][:2]))
+    noise = lambda step: (eps[0][:2].astype(np.float64), eps[1][:2].astype(np.float64))
+    ref = m.reconstruct(p64, batch[:2].astype(np.float64), noise, restore_steps=4, restore_lr=5e-3, tv_lambda=1.8)
+    assert np.mean(np.abs(r['reconstruction'] - ref['reconstruction'])) <= 1e-5
+    assert r['l1err'] == pytest.approx(ref['l1err'], rel=5e-3)
+    g = model.restore_gradients(batch[:2], eps=(eps[0][:2], eps[1][:2]))
+    gref = m.restore_grads(p64, batch[:2].astype(np.float64), *noise(0), 1.8)
+    assert np.abs(g - gref).max() <= 3e-4 * np.abs(gref).max()
+    model.restore_steps = 0
+    r0 = model.reconstruct(batch[:2], eps=(eps[0][:2], eps[1][:2]))
+    assert np.abs(r0['reconstruction'] - out['xz_mu'][:2]).max() <= 1e-4 * np.abs(out['xz_mu']).max()
+    model.restore_steps = 4
+
+    model.train(ds)
+    assert len(model.curves['TRAIN/loss']) == 2 and model.curves['VAL/loss'][1] < model.curves['VAL/loss'][0]
+    assert os.path.isfile(os.path.join(model.checkpointDir, model.model_dir, 'GMVAE_spatial.model-2.npz'))
+    # tv_lambda == -1: lambda sweep on 20 % of the VAL batches (GMVAE_spatial.py:201-225)
+    model.restore_steps = 2
+    ds16 = SyntheticDataset(8, 20, 64, 64, seed=3)
+    model.determine_best_lambda(ds16)
+    assert 0.0 <= model.tv_lambda_value <= 1.9
+    model.engine.close()

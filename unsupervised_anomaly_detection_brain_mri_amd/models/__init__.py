@@ -4,3 +4,4 @@ a TF graph (models/<name>.py::<name>); here it is a marker whose `__name__` sele
 from .autoencoder import autoencoder  # noqa: F401
 from .variational_autoencoder import variational_autoencoder  # noqa: F401
 from .context_encoder_variational_autoencoder import context_encoder_variational_autoencoder  # noqa: F401
+from .gaussian_mixture_variational_autoencoder_spatial import gaussian_mixture_variational_autoencoder_spatial  # noqa: F401

@@ -51,12 +51,16 @@ class AEMODEL(DLMODEL):
         self.losses = {}
         c = self.config
         self.checkpointDir = os.path.join(c.checkpointDir or 'checkpoints', self.network.__name__)
-        self.engine = Engine(self.ARCH, c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]),
-                             c.zDim, max_batch=max(int(c.batchsize), 1), device=device)
+        self.engine = self._make_engine(device)
         self.dp = DataParallelStep(self.engine, world)
         self.rng = np.random.default_rng(seed)       # host RNG for eps / dropout masks (TF graph RNG is unseeded)
         self.initialize_variables()
         self.get_number_of_trainable_params()
+
+    def _make_engine(self, device):
+        c = self.config
+        return Engine(self.ARCH, c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]),
+                      c.zDim, max_batch=max(int(c.batchsize), 1), device=device)
 
     def initialize_variables(self):
         """tf.global_variables_initializer(): glorot_uniform kernels, zero bias, gamma 1, beta 0 (SURVEY §8a note 3)."""
@@ -70,6 +74,8 @@ class AEMODEL(DLMODEL):
                 flat[off:off + cnt] = rng.uniform(-lim, lim, cnt)
             elif name.endswith('gamma'):
                 flat[off:off + cnt] = 1.0
+            elif name == 'Variable':      # gaussian_mixture_variational_autoencoder_spatial.py:43: tf.constant(0.1)
+                flat[off:off + cnt] = 0.1
         self.engine.set_params(flat)
         self.engine.reset_optimizer()
         self.dp.broadcast_params(0)

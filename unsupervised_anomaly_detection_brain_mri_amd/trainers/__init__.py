@@ -2,3 +2,4 @@ from .AE import AE  # noqa: F401
 from .VAE import VAE  # noqa: F401
 from .AEMODEL import Phase  # noqa: F401
 from .ceVAE import ceVAE  # noqa: F401
+from .GMVAE_spatial import GMVAE_spatial  # noqa: F401
