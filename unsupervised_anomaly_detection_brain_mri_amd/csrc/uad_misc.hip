@@ -369,6 +369,77 @@ __global__ void mul_kernel(const float* __restrict__ x, const float* __restrict_
     if (i < n) y[i] = mask ? x[i] * mask[i] : x[i];
 }
 
+// Tiled form for the real layer shape (k5 s2 SAME, 32 output channels): one workgroup per 16x16 input-pixel tile.  The 10x10
+// patch of d c0 vectors that the tile touches is staged in LDS once; 8 lanes share a pixel (one float4 of channels each,
+// weights of the pixel's parity class in registers, 3-step shuffle reduction).
+struct FirstDgradEpi {
+    const float* x; const float* x_hat; float inv_batch; float* anomaly; float* dx_out;
+    const float* dxhat; float* x_upd; float restore_lr;
+};
+__device__ __forceinline__ void first_dgrad_store(const FirstDgradEpi& e, size_t pix, float acc) {
+    if (e.dxhat) {
+        const float gx = acc - e.dxhat[pix];
+        if (e.dx_out) e.dx_out[pix] = gx;
+        if (e.x_upd) e.x_upd[pix] -= e.restore_lr * gx;
+        return;
+    }
+    const float diff = e.x[pix] - e.x_hat[pix];
+    const float gx = acc + (diff > 0.f ? e.inv_batch : (diff < 0.f ? -e.inv_batch : 0.f));
+    if (e.dx_out) e.dx_out[pix] = gx;
+    if (e.anomaly) e.anomaly[pix] = fabsf(diff) * fabsf(gx);
+}
+template <int PY, int PX>
+__device__ __forceinline__ void first_dgrad_class(const float4* sg, const float* __restrict__ W, int cq, int slot,
+                                                  int HB, int WB, int n, int ty0, int tx0, const FirstDgradEpi& e) {
+    constexpr int NKY = PY ? 3 : 2, NKX = PX ? 3 : 2, KY0 = PY ? 0 : 1, KX0 = PX ? 0 : 1;
+    float4 w[NKY][NKX];
+#pragma unroll
+    for (int a = 0; a < NKY; ++a)
+#pragma unroll
+        for (int b = 0; b < NKX; ++b)
+            w[a][b] = *reinterpret_cast<const float4*>(W + ((KY0 + 2 * a) * 5 + (KX0 + 2 * b)) * 32 + cq * 4);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int p = slot + 32 * r, pyy = p >> 3, pxx = p & 7;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < NKY; ++a)
+#pragma unroll
+            for (int b = 0; b < NKX; ++b) {
+                const float4 gv = sg[((pyy - a + 1 + PY) * 10 + (pxx - b + 1 + PX)) * 8 + cq];
+                acc = fmaf(gv.x, w[a][b].x, acc); acc = fmaf(gv.y, w[a][b].y, acc);
+                acc = fmaf(gv.z, w[a][b].z, acc); acc = fmaf(gv.w, w[a][b].w, acc);
+            }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        if (cq == 0) {
+            const int y = ty0 + 2 * pyy + PY, x = tx0 + 2 * pxx + PX;
+            first_dgrad_store(e, ((size_t)n * HB + y) * WB + x, acc);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) conv_first_dgrad_tiled_kernel(UadConvDesc d, const float* __restrict__ g,
+                                                                     const float* __restrict__ W, FirstDgradEpi e) {
+    __shared__ float4 sg[10 * 10 * 8];
+    const int n = blockIdx.z, ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
+    const int i0 = ty0 / 2 - 1, j0 = tx0 / 2 - 1;
+    for (int idx = threadIdx.x; idx < 800; idx += 256) {
+        const int cq = idx & 7, jj = (idx >> 3) % 10, ii = idx / 80;
+        const int i = i0 + ii, j = j0 + jj;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)i < (unsigned)d.HS && (unsigned)j < (unsigned)d.WS)
+            v = *reinterpret_cast<const float4*>(g + (((size_t)n * d.HS + i) * d.WS + j) * 32 + cq * 4);
+        sg[idx] = v;
+    }
+    __syncthreads();
+    const int cq = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    first_dgrad_class<0, 0>(sg, W, cq, slot, d.HB, d.WB, n, ty0, tx0, e);
+    first_dgrad_class<0, 1>(sg, W, cq, slot, d.HB, d.WB, n, ty0, tx0, e);
+    first_dgrad_class<1, 0>(sg, W, cq, slot, d.HB, d.WB, n, ty0, tx0, e);
+    first_dgrad_class<1, 1>(sg, W, cq, slot, d.HB, d.WB, n, ty0, tx0, e);
+}
+
 // rec_per_sample[i] = sum_b rec_partial[i][b].  Samples [0,n_vae) carry the VAE-branch losses, [n_vae,n) the ceVAE context
 // branch (none for AE/VAE).  scalars = {reconstructionLoss, kl, loss, 0, Rec_vae, Rec_ce, loss_vae, 0}, all divided by the
 // user batch (inv_batch); reconstructionLoss = rec_scale * (Rec_vae + Rec_ce)   (trainers/ceVAE.py:45-50)
@@ -598,8 +669,17 @@ void uad_launch_reparam_bwd(int n, int n_vae, int zdim, const float* dz, const f
     hipLaunchKernelGGL(reparam_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, total, zdim, n_vae, dz, mu,
                        sigma, eps, mask_mu, mask_ls, mask_mu_ce, inv_batch, dmu_raw, dls_raw);
 }
+static bool first_dgrad_tiled_ok(const UadConvDesc& d) {
+    return d.KS == 5 && d.S == 2 && d.P == 1 && d.CB == 1 && d.CS == 32 && d.HB % 16 == 0 && d.WB % 16 == 0 &&
+           d.HB == 2 * d.HS && d.WB == 2 * d.WS && d.N <= 65535;
+}
 void uad_launch_conv_first_dgrad(const UadConvDesc& d, const float* g, const float* W, const float* x,
                                  const float* x_hat, float inv_batch, float* anomaly, float* dx, hipStream_t st) {
+    if (first_dgrad_tiled_ok(d)) {
+        FirstDgradEpi e{x, x_hat, inv_batch, anomaly, dx, nullptr, nullptr, 0.f};
+        hipLaunchKernelGGL(conv_first_dgrad_tiled_kernel, dim3(d.WB / 16, d.HB / 16, d.N), dim3(256), 0, st, d, g, W, e);
+        return;
+    }
     const size_t total = (size_t)d.N * d.HB * d.WB;
     hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3((total + 255) / 256), dim3(256),
                        (size_t)d.KS * d.KS * d.CS * sizeof(float), st, d, g, W, x, x_hat, inv_batch, anomaly, dx,
@@ -607,6 +687,11 @@ void uad_launch_conv_first_dgrad(const UadConvDesc& d, const float* g, const flo
 }
 void uad_launch_conv_first_dgrad_restore(const UadConvDesc& d, const float* g, const float* W, const float* dxhat,
                                          float* dx, float* x_upd, float restore_lr, hipStream_t st) {
+    if (first_dgrad_tiled_ok(d)) {
+        FirstDgradEpi e{nullptr, nullptr, 0.f, nullptr, dx, dxhat, x_upd, restore_lr};
+        hipLaunchKernelGGL(conv_first_dgrad_tiled_kernel, dim3(d.WB / 16, d.HB / 16, d.N), dim3(256), 0, st, d, g, W, e);
+        return;
+    }
     const size_t total = (size_t)d.N * d.HB * d.WB;
     hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3((total + 255) / 256), dim3(256),
                        (size_t)d.KS * d.KS * d.CS * sizeof(float), st, d, g, W, (const float*)nullptr,

@@ -603,16 +603,20 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     } else {
         PROF(want_backward ? "final.fwd+bwd" : "final.fwd"); uad_launch_final_fwd_bwd(fa, st);
     }
-    PROF("loss.finalize");
     const int bps = uad_final_blocks_per_sample(fa.H, fa.W);
-    if (gm) {
+    if (m->restore) {
+        // restoration iterations fetch only `grads` (trainers/GMVAE_spatial.py:186): no loss scalars
+    } else if (gm) {
+        PROF("loss.finalize");
         uad_launch_gm_loss_finalize(m->rec_partial, n, bps, m->gm_loc_loss, ir * ir, 1.0f / (float)nu,
                                     io->rec_per_sample ? io->rec_per_sample : m->rec_ps,
                                     io->scalars ? io->scalars : m->scalars_own, st);
-    } else
+    } else {
+    PROF("loss.finalize");
     uad_launch_loss_finalize(m->rec_partial, n, nu, bps, vae ? m->kl : nullptr, 1.0f / (float)nu, cevae ? 0.5f : 1.0f,
                              io->rec_per_sample ? io->rec_per_sample : m->rec_ps,
                              io->scalars ? io->scalars : m->scalars_own, st);
+    }
     if (cevae) {
         const size_t xe = (size_t)nu * m->cfg.height * m->cfg.width * m->cfg.channels, xb = xe * sizeof(float);
         if (io->x_hat) HIP_TRY(hipMemcpyAsync(io->x_hat, m->xhat_own, xb, hipMemcpyDeviceToDevice, st));
