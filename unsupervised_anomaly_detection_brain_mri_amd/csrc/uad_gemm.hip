@@ -39,6 +39,8 @@ struct ConvGemmArgs {
     int lws, lhs;  // log2(WS), log2(HS) or -1 when not a power of two
     int nsplit;    // split-K factor (>1: raw partial tiles go to Out + split*out_elems, see splitk_epilogue_kernel)
     long long out_elems;
+    unsigned long long* dbgbuf;   // per-phase clock stamps of a few workgroups (UAD_DBG & 8)
+    int dbg;       // ablation switches for kernel tuning (UAD_DBG): 1 = no epilogue stores, 2 = no MFMA loop, 4 = no staging
 };
 
 __device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int lws, int& n, int& i, int& j) {
@@ -1016,6 +1018,300 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_bf16_kernel(const ConvGe
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// D-kind, class-sequential form (bf16x3).  Every tap of a k5 s2 transposed contraction feeds exactly ONE of the four
+// output-parity classes, so the classes share no operand: the workgroup stages its WHOLE channel range (CST channels of the
+// (TH+2)x(TW+2) halo) once, then walks the classes one after the other -- 3 accumulator fragments live instead of 8
+// (340 -> ~150 registers: two-three waves per SIMD instead of one), and each class's epilogue stores overlap the next
+// class's MFMAs.  Requires CA == CST * nsplit.
+// ------------------------------------------------------------------------------------------------
+struct TapOrderD { int tap[25]; int start[5]; };
+constexpr TapOrderD make_tap_order_d() {
+    TapOrderD o{};
+    int n = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        o.start[cls] = n;
+        for (int tap = 0; tap < 25; ++tap) {
+            const int ky = tap / 5, kx = tap % 5;
+            const int py = (ky + 1) & 1, px = (kx + 1) & 1;
+            if (py * 2 + px == cls) o.tap[n++] = tap;
+        }
+    }
+    o.start[4] = n;
+    return o;
+}
+constexpr TapOrderD kTapOrderD = make_tap_order_d();
+
+template <int TH, int TW, int CST, int WGM, int WGN>
+__global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_per_eu(2))) conv5_d16_kernel(const ConvGemmArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int IH = TH + 2, IW = TW + 2;
+    constexpr int LDH = CST + 8;                // ushorts per pixel row (+16 B pad)
+    constexpr int NCH = CST / 32, CQ = CST / 4;
+    constexpr int BN = 32 * WGN;
+    static_assert(TH * TW == 32 * WGM, "one 32-row fragment per wave along M");
+    static_assert(CST % 32 == 0, "32-channel weight-fragment units");
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned short* sHi = reinterpret_cast<unsigned short*>(dsm);
+    unsigned short* sLo = sHi + IH * IW * LDH;
+    float* s_xf = reinterpret_cast<float*>(sLo + IH * IW * LDH);
+    float* s_red = s_xf + 2 * XF_LDS_CH;
+    float* s_epi = s_red + WGM * 2 * BN;        // per-wave 32 x EPI_LD transpose tile of the epilogue
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const UadConvDesc& d = a.d;
+    const int tilesx = d.WS / TW;
+    const int ty0 = (blockIdx.x / tilesx) * TH, tx0 = (blockIdx.x % tilesx) * TW;
+    const int n = blockIdx.y;
+    const int nsplit = a.nsplit;
+    const int n0 = (blockIdx.z / nsplit) * BN;
+    const int split = blockIdx.z % nsplit;
+    const int CA = a.CA, Nn = a.Nn;
+    const int cbase = split * CST;
+    const int AH = d.HS, AW = d.WS;
+
+    const bool xf = a.xf.scale != nullptr;
+    if (xf)
+        for (int c = tid; c < CST; c += NT) {
+            s_xf[c] = a.xf.scale[cbase + c] * a.xf.mult;
+            s_xf[XF_LDS_CH + c] = a.xf.shift[cbase + c];
+        }
+
+    const int m = wm * 32 + l31;
+    const int pty = m / TW, ptx = m % TW;
+    const int aoff = ((pty + 1) * IW + ptx + 1) * LDH + 8 * lh;
+    const int col = n0 + wn * 32 + l31;
+    const bool colok = col < Nn;
+    const int colc = colok ? col : 0;
+    const size_t plane_q = (size_t)a.w16_plane / 8;
+
+    // Weight fragments: global -> VGPR ring of four, three units (one unit = one tap x 32 channels) ahead of their use: the
+    // loads are L2 hits (a layer's planes exceed the 32 KB L1), ~500+ cycles against 192 cycles of MFMA work per unit.
+    // (Sharing them through LDS was measured slower: it doubles the LDS read traffic, which then bounds the loop.)
+    // Activation fragments: LDS -> VGPR, double-buffered one unit ahead, so the MFMAs of a unit never wait for LDS.
+    constexpr int NUNIT = 25 * NCH;
+    const uint4* wq = reinterpret_cast<const uint4*>(a.Wp16) + (size_t)lh * Nn + colc;
+    BFrag16<2> b0, b1, b2, b3;
+    auto loadB = [&](BFrag16<2>& b, int unit) {
+        const int tap = kTapOrderD.tap[unit / NCH], c0 = cbase + (unit % NCH) * 32;
+        const uint4* w = wq + ((size_t)tap * (CA / 8) + c0 / 8) * Nn;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            b.hi[j] = w[(size_t)(2 * j) * Nn];
+            b.lo[j] = w[(size_t)(2 * j) * Nn + plane_q];
+        }
+    };
+    auto loadA = [&](BFrag16<2>& f, int unit) {
+        const int tap = kTapOrderD.tap[unit / NCH], kc = unit % NCH;
+        const int ky = tap / 5, kx = tap % 5;
+        const int py = (ky + 1) & 1, px = (kx + 1) & 1;
+        const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+        const int toff = (dy * IW + dx) * LDH;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f.hi[j] = *reinterpret_cast<const uint4*>(sHi + aoff + toff + kc * 32 + 16 * j);
+            f.lo[j] = *reinterpret_cast<const uint4*>(sLo + aoff + toff + kc * 32 + 16 * j);
+        }
+    };
+    const bool stamp = (a.dbg & 8) && a.dbgbuf && lane == 0 && blockIdx.y == 1 && blockIdx.z == 0 && blockIdx.x < 8;
+    unsigned long long* stp = a.dbgbuf + ((size_t)blockIdx.x * 4 + wave) * 16;
+    if (stamp) stp[0] = clock64();
+    loadB(b0, 0);
+    if (1 < NUNIT) loadB(b1, 1);
+    if (2 < NUNIT) loadB(b2, 2);
+    if (xf) __syncthreads();
+
+    // ---- stage the whole halo tile of this workgroup's channel range: global fp32 -> activation -> bf16 hi|lo planes ----
+    const int gy0 = ty0 - 1, gx0 = tx0 - 1;
+    const float* inb = a.A + (size_t)n * AH * AW * CA + cbase;
+    {
+        constexpr int TOT = IH * IW * CQ;
+        constexpr int BATCH = 4;
+        for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
+            float4 v[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                const int pix = f / CQ, cq = f % CQ;
+                const int iy = pix / IW, ix = pix % IW;
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                ok[u] = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
+                const int gp = ok[u] ? (gy * AW + gx) : 0;
+                v[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + (ok[u] ? cq * 4 : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                if (f >= TOT) continue;
+                const int pix = f / CQ, cq = f % CQ;
+                float4 t = v[u];
+                if (xf) {
+                    const float4 sc = *reinterpret_cast<const float4*>(s_xf + cq * 4);
+                    const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + cq * 4);
+                    t = xform4(t, sc, sh, a.xf.alpha);
+                }
+                t = keep4(ok[u], t);
+                uint2 hi, lo;
+                split_bf16(t, hi, lo);
+                *reinterpret_cast<uint2*>(sHi + pix * LDH + cq * 4) = hi;
+                *reinterpret_cast<uint2*>(sLo + pix * LDH + cq * 4) = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // Epilogue: the 32x32 C fragment (lane = column) is transposed through a wave-private LDS tile so that every lane owns
+    // 4 consecutive channels of 4 rows: 4 x 16-byte stores (and cprev loads) per class instead of 16 x 4-byte ones -- the
+    // scattered dword form spent ~190 cycles per store instruction in the address path (3000 of 10000 cycles per class).
+    constexpr int EPI_LD = 36;
+    const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
+    float* etile = s_epi + wave * 32 * EPI_LD;
+    const int ec4 = (lane & 7) * 4, erow = lane >> 3;
+    const int ecol = n0 + wn * 32 + ec4;                 // Nn % 32 == 0 on this path: always in range
+    float4 e_a = make_float4(0.f, 0.f, 0.f, 0.f), e_b = e_a;
+    if (!bwd) { if (a.ep.bias) e_a = *reinterpret_cast<const float4*>(a.ep.bias + ecol); }
+    else {
+        e_a = *reinterpret_cast<const float4*>(a.ep.escale + ecol);
+        e_a.x *= a.ep.emult; e_a.y *= a.ep.emult; e_a.z *= a.ep.emult; e_a.w *= a.ep.emult;
+        e_b = *reinterpret_cast<const float4*>(a.ep.eshift + ecol);
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    auto class_epilogue = [&](const v16f& o, int py, int px) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) etile[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + l31] = o[r];
+        __builtin_amdgcn_wave_barrier();
+        float4 v[4];
+        size_t off[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = erow + 8 * k;
+            v[k] = *reinterpret_cast<const float4*>(etile + row * EPI_LD + ec4);
+            const int mm = wm * 32 + row;
+            const int Y = 2 * (ty0 + mm / TW) + py, X = 2 * (tx0 + mm % TW) + px;
+            off[k] = ((size_t)(n * d.HB + Y) * d.WB + X) * Nn + ecol;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (nsplit > 1) {
+            float* slab = a.Out + (size_t)split * a.out_elems;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(slab + off[k]) = v[k];
+        } else if (!bwd) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float4 t = v[k];
+                t.x += e_a.x; t.y += e_a.y; t.z += e_a.z; t.w += e_a.w;
+                if (a.ep.mul) { const float4 q = *reinterpret_cast<const float4*>(a.ep.mul + off[k]); t.x *= q.x; t.y *= q.y; t.z *= q.z; t.w *= q.w; }
+                if (a.ep.add) { const float4 q = *reinterpret_cast<const float4*>(a.ep.add + off[k]); t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+                *reinterpret_cast<float4*>(a.Out + off[k]) = t;
+            }
+        } else {
+            float4 cp[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cp[k] = *reinterpret_cast<const float4*>(a.ep.cprev + off[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, cc[4] = {cp[k].x, cp[k].y, cp[k].z, cp[k].w};
+                const float aa[4] = {e_a.x, e_a.y, e_a.z, e_a.w}, bb[4] = {e_b.x, e_b.y, e_b.z, e_b.w};
+                float oo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bn = fmaf(aa[e], cc[e], bb[e]);
+                    const float dbn = bn > 0.f ? vv[e] : vv[e] * a.ep.ealpha;
+                    oo[e] = dbn * aa[e];
+                    s1[e] += dbn;
+                    s2[e] = fmaf(dbn, cc[e], s2[e]);
+                }
+                *reinterpret_cast<float4*>(a.Out + off[k]) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+            }
+        }
+    };
+
+    v16f acc0, acc1, acc2;
+    BFrag16<2> a0, a1;
+    if (stamp) stp[1] = clock64();
+    loadA(a0, 0);
+    if (stamp) stp[2] = clock64();
+    auto unit = [&](const BFrag16<2>& bc, BFrag16<2>& bpf, const BFrag16<2>& ac, BFrag16<2>& an, const int sidx) {
+        const int t = sidx / NCH, kc = sidx % NCH;
+        const int tap = kTapOrderD.tap[t];
+        const int ky = tap / 5, kx = tap % 5;
+        const int py = (ky + 1) & 1, px = (kx + 1) & 1;
+        const int cls = py * 2 + px;
+        if (kc == 0 && t == kTapOrderD.start[cls]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+        }
+        if (sidx + 3 < NUNIT) loadB(bpf, sidx + 3);
+        if (sidx + 1 < NUNIT) loadA(an, sidx + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(a.dbg & 2))
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc0 = mfma_bf16(ac.hi[j], bc.hi[j], acc0);
+            acc1 = mfma_bf16(ac.hi[j], bc.lo[j], acc1);
+            acc2 = mfma_bf16(ac.lo[j], bc.hi[j], acc2);
+        }
+        if (kc == NCH - 1 && t + 1 == kTapOrderD.start[cls + 1]) {
+            // ---- epilogue of this parity class ----
+            if (stamp) stp[3 + 2 * cls] = clock64();
+            v16f o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = acc0[r] + (acc1[r] + acc2[r]);
+            if (!(a.dbg & 1) || o[0] == 1.2345e30f) class_epilogue(o, py, px);
+            if (stamp) stp[4 + 2 * cls] = clock64();
+        }
+    };
+#pragma unroll
+    for (int g4 = 0; g4 < (NUNIT + 3) / 4; ++g4) {
+        if (4 * g4 + 0 < NUNIT) unit(b0, b3, a0, a1, 4 * g4 + 0);
+        if (4 * g4 + 1 < NUNIT) unit(b1, b0, a1, a0, 4 * g4 + 1);
+        if (4 * g4 + 2 < NUNIT) unit(b2, b1, a0, a1, 4 * g4 + 2);
+        if (4 * g4 + 3 < NUNIT) unit(b3, b2, a1, a0, 4 * g4 + 3);
+    }
+    if (nsplit > 1) return;
+    if (bwd) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t1 = s1[e], t2 = s2[e];
+            t1 += __shfl_xor(t1, 8); t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
+            t2 += __shfl_xor(t2, 8); t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
+            if (lane < 8) {
+                s_red[(wm * 2 + 0) * BN + wn * 32 + ec4 + e] = t1;
+                s_red[(wm * 2 + 1) * BN + wn * 32 + ec4 + e] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) t += s_red[(w * 2 + which) * BN + c];
+            const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            if (n0 + c < Nn) a.ep.colpart[(tile * 2 + which) * Nn + n0 + c] = t;
+        }
+    }
+}
+
+template <int TH, int TW, int CST, int WGM, int WGN>
+constexpr size_t conv5_d16_lds_bytes() {
+    return (size_t)2 * (TH + 2) * (TW + 2) * (CST + 8) * 2 + (size_t)2 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4 +
+           (size_t)WGM * WGN * 32 * 36 * 4;
+}
+template <int TH, int TW, int CST, int WGM, int WGN>
+void launch_conv5_d16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = conv5_d16_lds_bytes<TH, TW, CST, WGM, WGN>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_d16_kernel<TH, TW, CST, WGM, WGN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv5_d16_kernel<TH, TW, CST, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, a);
+}
+
 template <int TH, int TW, int CK, int WGM, int WGN, int KIND>
 constexpr size_t conv5_bf16_lds_bytes() {
     return (size_t)2 * ((KIND == KIND_F) ? (2 * TH + 3) * (2 * TW + 3) : (TH + 2) * (TW + 2)) * (CK + 8) * 2 +
@@ -1773,6 +2069,23 @@ namespace {
 void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStream_t st) {
     const UadConvDesc& d = a.d;
     a.nsplit = 1; a.out_elems = p.out_elems;
+    { static const int dbg = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0; a.dbg = dbg; a.dbgbuf = nullptr; }
+    static unsigned long long* dbgbuf = nullptr;
+    static int dbg_calls = 0;
+    const bool dbg_this = (a.dbg & 8) && !f_type && a.Wp16 && a.Nn == 32 && a.CA == 32 && dbg_calls < 3;
+    if (dbg_this) {
+        if (!dbgbuf) (void)hipMalloc((void**)&dbgbuf, 8 * 4 * 16 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbgbuf, 0, 8 * 4 * 16 * sizeof(unsigned long long), st);
+        a.dbgbuf = dbgbuf;
+    }
+    struct DbgDump { bool on; hipStream_t st; unsigned long long* buf; int* calls;
+        ~DbgDump() { if (!on) return; (void)hipStreamSynchronize(st); unsigned long long h[8 * 4 * 16];
+            (void)hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost); ++*calls;
+            for (int b = 0; b < 8; b += 3) for (int w = 0; w < 4; w += 3) { const unsigned long long* p = h + (b * 4 + w) * 16;
+                fprintf(stderr, "[d16 wg%d w%d] stage=%llu bstore+bar=%llu", b, w, p[1] - p[0], p[2] - p[1]);
+                unsigned long long prev = p[2];
+                for (int c = 0; c < 4; ++c) { fprintf(stderr, " | cls%d mma=%llu epi=%llu", c, p[3 + 2 * c] - prev, p[4 + 2 * c] - p[3 + 2 * c]); prev = p[4 + 2 * c]; }
+                fprintf(stderr, " | total=%llu\n", prev - p[0]); } } } dbg_dump{dbg_this, st, dbgbuf, &dbg_calls};
     if (p.path == PATH_SPATIAL) {
         float* out = a.Out;
         if (p.nsplit > 1) { a.Out = ws; a.nsplit = p.nsplit; }
@@ -1782,7 +2095,16 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
                 if (p.sc.BN == 64) launch_conv5_bf16<8, 8, 32, 2, 2, KIND_F>(a, grid, st);
                 else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_F>(a, grid, st);
             } else {
-                if (p.sc.BN == 64) launch_conv5_bf16<8, 8, 32, 2, 2, KIND_D>(a, grid, st);
+                // class-sequential kernel whenever the workgroup's whole channel range fits in LDS (CA == cst * nsplit)
+                const int cst = (a.CA % p.nsplit == 0) ? a.CA / p.nsplit : 0;
+                const bool seq = !getenv("UAD_NO_D16");
+                if (p.sc.BN == 64) {
+                    if (seq && cst == 128) launch_conv5_d16<8, 8, 128, 2, 2>(a, grid, st);
+                    else if (seq && cst == 64) launch_conv5_d16<8, 8, 64, 2, 2>(a, grid, st);
+                    else if (seq && cst == 32) launch_conv5_d16<8, 8, 32, 2, 2>(a, grid, st);
+                    else launch_conv5_bf16<8, 8, 32, 2, 2, KIND_D>(a, grid, st);
+                } else if (seq && cst == 64) launch_conv5_d16<8, 16, 64, 4, 1>(a, grid, st);
+                else if (seq && cst == 32) launch_conv5_d16<8, 16, 32, 4, 1>(a, grid, st);
                 else if (p.sc.CK == 32) launch_conv5_bf16<8, 16, 32, 4, 1, KIND_D>(a, grid, st);
                 else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_D>(a, grid, st);
             }
