@@ -1295,6 +1295,251 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// F-kind (gather) bf16x3 kernel with the same pipeline as conv5_d16_kernel: weight fragments three taps ahead in a VGPR ring,
+// activation fragments double-buffered out of LDS one tap ahead, transposed 16-byte epilogue.  The (2TH+3)x(2TW+3) halo is
+// too large to hold every channel at once, so channels are walked in CK-wide chunks (restaged per chunk, accumulators live
+// across chunks); the weight ring runs through the chunk boundary.
+// ------------------------------------------------------------------------------------------------
+template <int TH, int TW, int CK, int WGM, int WGN>
+__global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_per_eu(2))) conv5_f16_kernel(const ConvGemmArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int IH = 2 * TH + 3, IW = 2 * TW + 3;
+    constexpr int LDH = CK + 8;
+    constexpr int NKS = CK / 16, CQ = CK / 4;
+    constexpr int BN = 32 * WGN;
+    static_assert(TH * TW == 32 * WGM, "one 32-row fragment per wave along M");
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned short* sHi = reinterpret_cast<unsigned short*>(dsm);
+    unsigned short* sLo = sHi + IH * IW * LDH;
+    float* s_xf = reinterpret_cast<float*>(sLo + IH * IW * LDH);
+    float* s_red = s_xf + 2 * XF_LDS_CH;
+    float* s_epi = reinterpret_cast<float*>(dsm);      // aliases the activation tile (dead after the last chunk)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const UadConvDesc& d = a.d;
+    const int tilesx = d.WS / TW;
+    const int ty0 = (blockIdx.x / tilesx) * TH, tx0 = (blockIdx.x % tilesx) * TW;
+    const int n = blockIdx.y;
+    const int nsplit = a.nsplit;
+    const int n0 = (blockIdx.z / nsplit) * BN;
+    const int split = blockIdx.z % nsplit;
+    const int CA = a.CA, Nn = a.Nn;
+    const int AH = d.HB, AW = d.WB;
+
+    const bool xf = a.xf.scale != nullptr;
+    if (xf)
+        for (int c = tid; c < CA; c += NT) {
+            s_xf[c] = a.xf.scale[c] * a.xf.mult;
+            s_xf[XF_LDS_CH + c] = a.xf.shift[c];
+        }
+
+    const int m = wm * 32 + l31;
+    const int pty = m / TW, ptx = m % TW;
+    const int aoff = ((2 * pty) * IW + 2 * ptx) * LDH + 8 * lh;
+    const int col = n0 + wn * 32 + l31;
+    const int colc = col < Nn ? col : 0;
+    const uint4* wq = reinterpret_cast<const uint4*>(a.Wp16) + (size_t)lh * Nn + colc;
+    const size_t plane_q = (size_t)a.w16_plane / 8;
+
+    const int cper = (CA / CK + nsplit - 1) / nsplit;
+    const int ch0 = split * cper;
+    const int nchunks = min(CA / CK, ch0 + cper);
+
+    BFrag16<NKS> b0, b1, b2, b3, a0, a1;
+    auto loadB = [&](BFrag16<NKS>& b, int tap, int c0) {
+        const uint4* w = wq + ((size_t)tap * (CA / 8) + c0 / 8) * Nn;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            b.hi[j] = w[(size_t)(2 * j) * Nn];
+            b.lo[j] = w[(size_t)(2 * j) * Nn + plane_q];
+        }
+    };
+    auto loadA = [&](BFrag16<NKS>& f, int tap) {
+        const int toff = ((tap / 5) * IW + (tap % 5)) * LDH;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            f.hi[j] = *reinterpret_cast<const uint4*>(sHi + aoff + toff + 16 * j);
+            f.lo[j] = *reinterpret_cast<const uint4*>(sLo + aoff + toff + 16 * j);
+        }
+    };
+    loadB(b0, 0, ch0 * CK);
+    loadB(b1, 1, ch0 * CK);
+    loadB(b2, 2, ch0 * CK);
+
+    v16f acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+
+    const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
+    const float* inb = a.A + (size_t)n * AH * AW * CA;
+    __syncthreads();
+
+    for (int ch = ch0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK;
+        if (ch > ch0) __syncthreads();
+        constexpr int TOT = IH * IW * CQ;
+        constexpr int BATCH = 6;
+        for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
+            float4 v[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                const int pix = f / CQ, cq = f % CQ;
+                const int iy = pix / IW, ix = pix % IW;
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                ok[u] = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
+                const int gp = ok[u] ? (gy * AW + gx) : 0;
+                v[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok[u] ? cq * 4 : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + u * NT;
+                if (f >= TOT) continue;
+                const int pix = f / CQ, cq = f % CQ;
+                float4 t = v[u];
+                if (xf) {
+                    const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
+                    const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
+                    t = xform4(t, sc, sh, a.xf.alpha);
+                }
+                t = keep4(ok[u], t);
+                uint2 hi, lo;
+                split_bf16(t, hi, lo);
+                *reinterpret_cast<uint2*>(sHi + pix * LDH + cq * 4) = hi;
+                *reinterpret_cast<uint2*>(sLo + pix * LDH + cq * 4) = lo;
+            }
+        }
+        __syncthreads();
+        loadA(a0, 0);
+        const bool more = ch + 1 < nchunks;
+        auto unit = [&](const BFrag16<NKS>& bc, BFrag16<NKS>& bpf, const BFrag16<NKS>& ac, BFrag16<NKS>& an, const int t) {
+            if (t + 3 < 25) loadB(bpf, t + 3, c0);
+            else if (more) loadB(bpf, t + 3 - 25, c0 + CK);
+            if (t + 1 < 25) loadA(an, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NKS; ++j) {
+                acc0 = mfma_bf16(ac.hi[j], bc.hi[j], acc0);
+                acc1 = mfma_bf16(ac.hi[j], bc.lo[j], acc1);
+                acc2 = mfma_bf16(ac.lo[j], bc.hi[j], acc2);
+            }
+        };
+#pragma unroll
+        for (int g4 = 0; g4 < 7; ++g4) {
+            if (4 * g4 + 0 < 25) unit(b0, b3, a0, a1, 4 * g4 + 0);
+            if (4 * g4 + 1 < 25) unit(b1, b0, a1, a0, 4 * g4 + 1);
+            if (4 * g4 + 2 < 25) unit(b2, b1, a0, a1, 4 * g4 + 2);
+            if (4 * g4 + 3 < 25) unit(b3, b2, a1, a0, 4 * g4 + 3);
+        }
+        // 25 = 6*4 + 1: the ring advanced by one slot; rotate so the next chunk starts at slot 0 again
+        b0 = b1; b1 = b2; b2 = b3;
+    }
+
+    // ---- epilogue: transpose through a wave-private LDS tile, 16-byte accesses (see conv5_d16_kernel) ----
+    __syncthreads();                                   // every wave is done with the activation tile
+    constexpr int EPI_LD = 36;
+    static_assert((size_t)WGM * WGN * 32 * EPI_LD * 4 <= (size_t)2 * IH * IW * LDH * 2, "epilogue tile fits in the activation tile");
+    const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
+    float* etile = s_epi + wave * 32 * EPI_LD;
+    const int ec4 = (lane & 7) * 4, erow = lane >> 3;
+    const int ecol = n0 + wn * 32 + ec4;
+    v16f o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = acc0[r] + (acc1[r] + acc2[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) etile[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + l31] = o[r];
+    __builtin_amdgcn_wave_barrier();
+    float4 v[4];
+    size_t off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = erow + 8 * k;
+        v[k] = *reinterpret_cast<const float4*>(etile + row * EPI_LD + ec4);
+        const int mm = wm * 32 + row;
+        off[k] = ((size_t)(n * d.HS + ty0 + mm / TW) * d.WS + tx0 + mm % TW) * Nn + ecol;
+    }
+    if (nsplit > 1) {
+        float* slab = a.Out + (size_t)split * a.out_elems;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(slab + off[k]) = v[k];
+        return;
+    }
+    if (!bwd) {
+        float4 e_a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.ep.bias) e_a = *reinterpret_cast<const float4*>(a.ep.bias + ecol);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 t = v[k];
+            t.x += e_a.x; t.y += e_a.y; t.z += e_a.z; t.w += e_a.w;
+            if (a.ep.mul) { const float4 q = *reinterpret_cast<const float4*>(a.ep.mul + off[k]); t.x *= q.x; t.y *= q.y; t.z *= q.z; t.w *= q.w; }
+            if (a.ep.add) { const float4 q = *reinterpret_cast<const float4*>(a.ep.add + off[k]); t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+            *reinterpret_cast<float4*>(a.Out + off[k]) = t;
+        }
+        return;
+    }
+    float4 e_a = *reinterpret_cast<const float4*>(a.ep.escale + ecol);
+    e_a.x *= a.ep.emult; e_a.y *= a.ep.emult; e_a.z *= a.ep.emult; e_a.w *= a.ep.emult;
+    const float4 e_b = *reinterpret_cast<const float4*>(a.ep.eshift + ecol);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 cp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cp[k] = *reinterpret_cast<const float4*>(a.ep.cprev + off[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, cc[4] = {cp[k].x, cp[k].y, cp[k].z, cp[k].w};
+        const float aa[4] = {e_a.x, e_a.y, e_a.z, e_a.w}, bb[4] = {e_b.x, e_b.y, e_b.z, e_b.w};
+        float oo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float bn = fmaf(aa[e], cc[e], bb[e]);
+            const float dbn = bn > 0.f ? vv[e] : vv[e] * a.ep.ealpha;
+            oo[e] = dbn * aa[e];
+            s1[e] += dbn;
+            s2[e] = fmaf(dbn, cc[e], s2[e]);
+        }
+        *reinterpret_cast<float4*>(a.Out + off[k]) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t1 = s1[e], t2 = s2[e];
+        t1 += __shfl_xor(t1, 8); t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
+        t2 += __shfl_xor(t2, 8); t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
+        if (lane < 8) {
+            s_red[(wm * 2 + 0) * BN + wn * 32 + ec4 + e] = t1;
+            s_red[(wm * 2 + 1) * BN + wn * 32 + ec4 + e] = t2;
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+        const int which = tid / BN, c = tid % BN;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) t += s_red[(w * 2 + which) * BN + c];
+        const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        if (n0 + c < Nn) a.ep.colpart[(tile * 2 + which) * Nn + n0 + c] = t;
+    }
+}
+
+template <int TH, int TW, int CK, int WGM, int WGN>
+constexpr size_t conv5_f16_lds_bytes() {
+    return (size_t)2 * (2 * TH + 3) * (2 * TW + 3) * (CK + 8) * 2 + (size_t)2 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
+}
+template <int TH, int TW, int CK, int WGM, int WGN>
+void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = conv5_f16_lds_bytes<TH, TW, CK, WGM, WGN>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_f16_kernel<TH, TW, CK, WGM, WGN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv5_f16_kernel<TH, TW, CK, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, a);
+}
+
 template <int TH, int TW, int CST, int WGM, int WGN>
 constexpr size_t conv5_d16_lds_bytes() {
     return (size_t)2 * (TH + 2) * (TW + 2) * (CST + 8) * 2 + (size_t)2 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4 +
@@ -2092,8 +2337,9 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
         dim3 grid((d.HS / p.sc.TH) * (d.WS / p.sc.TW), d.N, (a.Nn / p.sc.BN) * p.nsplit);
         if (a.Wp16) {   // bf16x3 math mode
             if (f_type) {
-                if (p.sc.BN == 64) launch_conv5_bf16<8, 8, 32, 2, 2, KIND_F>(a, grid, st);
-                else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_F>(a, grid, st);
+                const bool f16 = !getenv("UAD_NO_F16");
+                if (p.sc.BN == 64) { if (f16) launch_conv5_f16<8, 8, 32, 2, 2>(a, grid, st); else launch_conv5_bf16<8, 8, 32, 2, 2, KIND_F>(a, grid, st); }
+                else { if (f16) launch_conv5_f16<8, 16, 16, 4, 1>(a, grid, st); else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_F>(a, grid, st); }
             } else {
                 // class-sequential kernel whenever the workgroup's whole channel range fits in LDS (CA == cst * nsplit)
                 const int cst = (a.CA % p.nsplit == 0) ? a.CA / p.nsplit : 0;
