@@ -1377,42 +1377,51 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     const float* inb = a.A + (size_t)n * AH * AW * CA;
     __syncthreads();
 
+    // The activation tile of chunk ch+1 is fetched into registers while chunk ch is contracted (the tile's two dependent
+    // HBM/L2 latencies were ~60 % of a workgroup's lifetime); conversion + LDS store happen once every wave has left chunk ch.
+    constexpr int TOT = IH * IW * CQ;
+    constexpr int PER = (TOT + NT - 1) / NT;
+    float4 pf[PER];
+    auto issue_stage = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int f = tid + u * NT;
+            const int pix = f / CQ, cq = f % CQ;
+            const int iy = pix / IW, ix = pix % IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            const bool ok = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
+            const int gp = ok ? (gy * AW + gx) : 0;
+            pf[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok ? cq * 4 : 0));
+        }
+    };
+    auto convert_stage = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int f = tid + u * NT;
+            if (f >= TOT) continue;
+            const int pix = f / CQ, cq = f % CQ;
+            const int iy = pix / IW, ix = pix % IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            const bool ok = (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
+            float4 t = pf[u];
+            if (xf) {
+                const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
+                const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
+                t = xform4(t, sc, sh, a.xf.alpha);
+            }
+            t = keep4(ok, t);
+            uint2 hi, lo;
+            split_bf16(t, hi, lo);
+            *reinterpret_cast<uint2*>(sHi + pix * LDH + cq * 4) = hi;
+            *reinterpret_cast<uint2*>(sLo + pix * LDH + cq * 4) = lo;
+        }
+    };
+    issue_stage(ch0 * CK);
     for (int ch = ch0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
         if (ch > ch0) __syncthreads();
-        constexpr int TOT = IH * IW * CQ;
-        constexpr int BATCH = 6;
-        for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
-            float4 v[BATCH];
-            bool ok[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int f = f0 + u * NT;
-                const int pix = f / CQ, cq = f % CQ;
-                const int iy = pix / IW, ix = pix % IW;
-                const int gy = gy0 + iy, gx = gx0 + ix;
-                ok[u] = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
-                const int gp = ok[u] ? (gy * AW + gx) : 0;
-                v[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok[u] ? cq * 4 : 0));
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int f = f0 + u * NT;
-                if (f >= TOT) continue;
-                const int pix = f / CQ, cq = f % CQ;
-                float4 t = v[u];
-                if (xf) {
-                    const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
-                    const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
-                    t = xform4(t, sc, sh, a.xf.alpha);
-                }
-                t = keep4(ok[u], t);
-                uint2 hi, lo;
-                split_bf16(t, hi, lo);
-                *reinterpret_cast<uint2*>(sHi + pix * LDH + cq * 4) = hi;
-                *reinterpret_cast<uint2*>(sLo + pix * LDH + cq * 4) = lo;
-            }
-        }
+        convert_stage(c0);
+        if (ch + 1 < nchunks) issue_stage(c0 + CK);
         __syncthreads();
         loadA(a0, 0);
         const bool more = ch + 1 < nchunks;
