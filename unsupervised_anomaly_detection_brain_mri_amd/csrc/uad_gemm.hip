@@ -1720,6 +1720,7 @@ struct ConvWArgs {
     int Kt;    // N*HS*WS
     int kper;  // positions per split (multiple of BK)
     int lws, lhs;
+    unsigned long long* dbgbuf;   // UAD_DBG & 32: per-workgroup start / end clocks
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN>
@@ -2021,37 +2022,43 @@ __global__ void __launch_bounds__(256) conv5_w_kernel(const ConvWArgs a, int til
 // positions per lane for a fixed channel: the small tile is stored transposed ([cs][pos] bf16 planes -> one aligned
 // ds_read_b128 per fragment, shared by the wave's 6-7 taps), the big tile stays [pixel][cb] and each A fragment is
 // gathered with eight 16-bit LDS reads per plane (lane = channel, so a wave reads 64 contiguous bytes per pixel).
-__global__ void __launch_bounds__(256) conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
-    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256;
+// NCSB = 1: one 32-cb x 32-cs block per 4-wave workgroup.  NCSB = 2: two cs blocks share ONE staged big tile in an 8-wave
+// workgroup (waves 0-3 / 4-7): the big tile (46 KB of fp32 per 8x8 positions, the kernel's dominant cost) is staged once for
+// twice the MFMA work and by twice the threads (one round of loads instead of two).
+template <int NCSB>
+__global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
+conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
+    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256 * NCSB, CSQ = 8 * NCSB;
     constexpr int LDH = CK + 8;       // ushorts per big-tile pixel
     constexpr int LDP = TH * TW + 8;  // ushorts per channel row of the transposed small tile
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     unsigned short* bHi = reinterpret_cast<unsigned short*>(dsm);
     unsigned short* bLo = bHi + IH * IW * LDH;
     unsigned short* sHiT = bLo + IH * IW * LDH;
-    unsigned short* sLoT = sHiT + CK * LDP;
+    unsigned short* sLoT = sHiT + NCSB * CK * LDP;
+    float* sXf = reinterpret_cast<float*>(sLoT + NCSB * CK * LDP);   // [32] big scale, [32] big shift, [64] small scale, [64] small shift
     float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+    const int wave = wave_all & 3, csb = wave_all >> 2;   // tap group / cs block of this wave
     const int l31 = lane & 31, lh = lane >> 5;
     const UadConvDesc& d = a.d;
-    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32;
+    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32 * NCSB;
     const int tilesx = d.WS / TW, tilesy = d.HS / TH;
     const int t_begin = blockIdx.z * tiles_per_split;
     const int t_end = min(t_begin + tiles_per_split, total_tiles);
 
     const int cq = tid % CQ;
     const bool xfa = a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
-    float4 scA = make_float4(1, 1, 1, 1), shA = make_float4(0, 0, 0, 0), scB = scA, shB = shA;
-    if (xfa) {
-        scA = *reinterpret_cast<const float4*>(a.xfb.scale + cb0 + cq * 4);
-        shA = *reinterpret_cast<const float4*>(a.xfb.shift + cb0 + cq * 4);
-        scA.x *= a.xfb.mult; scA.y *= a.xfb.mult; scA.z *= a.xfb.mult; scA.w *= a.xfb.mult;
+    // activation-on-load tables in LDS
+    if (tid < 32) {
+        sXf[tid] = xfa ? a.xfb.scale[cb0 + tid] * a.xfb.mult : 1.f;
+        sXf[32 + tid] = xfa ? a.xfb.shift[cb0 + tid] : 0.f;
     }
-    if (xfs) {
-        scB = *reinterpret_cast<const float4*>(a.xfs.scale + cs0 + cq * 4);
-        shB = *reinterpret_cast<const float4*>(a.xfs.shift + cs0 + cq * 4);
-        scB.x *= a.xfs.mult; scB.y *= a.xfs.mult; scB.z *= a.xfs.mult; scB.w *= a.xfs.mult;
+    if (tid < 32 * NCSB) {
+        sXf[64 + tid] = xfs ? a.xfs.scale[cs0 + tid] * a.xfs.mult : 1.f;
+        sXf[128 + tid] = xfs ? a.xfs.shift[cs0 + tid] : 0.f;
     }
 
     constexpr int MAXT = 7;
@@ -2062,7 +2069,7 @@ __global__ void __launch_bounds__(256) conv5_w_bf16_kernel(const ConvWArgs a, in
         const int ky = tap / 5, kx = tap % 5;
         aaddr[j] = ((ky + 2 * lh) * IW + kx) * LDH + l31;   // tile row 2*jstep + lh -> pixel row 4*jstep + 2*lh + ky
     }
-    const int baddr = l31 * LDP + 8 * lh;
+    const int baddr = (csb * 32 + l31) * LDP + 8 * lh;
 
     v16f acc[MAXT];
 #pragma unroll
@@ -2108,7 +2115,7 @@ __global__ void __launch_bounds__(256) conv5_w_bf16_kernel(const ConvWArgs a, in
                     const int f = f0 + u * NT;
                     if (f >= TOT) continue;
                     float4 tv = v[u];
-                    if (xfa) tv = xform4(tv, scA, shA, a.xfb.alpha);
+                    if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
                     tv = keep4(ok[u], tv);
                     uint2 hi, lo;
                     split_bf16(tv, hi, lo);
@@ -2119,18 +2126,20 @@ __global__ void __launch_bounds__(256) conv5_w_bf16_kernel(const ConvWArgs a, in
             float4 sv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int pos = (tid + u * NT) / CQ;
-                sv[u] = *reinterpret_cast<const float4*>(smb + (size_t)((pos / TW) * d.WS + (pos % TW)) * d.CS + cq * 4);
+                const int idx = tid + u * NT;
+                const int pos = idx / CSQ, csq = idx % CSQ;
+                sv[u] = *reinterpret_cast<const float4*>(smb + (size_t)((pos / TW) * d.WS + (pos % TW)) * d.CS + csq * 4);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int pos = (tid + u * NT) / CQ;
+                const int idx = tid + u * NT;
+                const int pos = idx / CSQ, csq = idx % CSQ;
                 float4 tv = sv[u];
-                if (xfs) tv = xform4(tv, scB, shB, a.xfs.alpha);
+                if (xfs) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + 64 + csq * 4), *reinterpret_cast<const float4*>(sXf + 128 + csq * 4), a.xfs.alpha);
                 uint2 hi, lo;
                 split_bf16(tv, hi, lo);
-                unsigned short* ph = sHiT + (cq * 4) * LDP + pos;
-                unsigned short* pl = sLoT + (cq * 4) * LDP + pos;
+                unsigned short* ph = sHiT + (csq * 4) * LDP + pos;
+                unsigned short* pl = sLoT + (csq * 4) * LDP + pos;
                 ph[0] = (unsigned short)hi.x; ph[LDP] = (unsigned short)(hi.x >> 16);
                 ph[2 * LDP] = (unsigned short)hi.y; ph[3 * LDP] = (unsigned short)(hi.y >> 16);
                 pl[0] = (unsigned short)lo.x; pl[LDP] = (unsigned short)(lo.x >> 16);
@@ -2169,23 +2178,29 @@ __global__ void __launch_bounds__(256) conv5_w_bf16_kernel(const ConvWArgs a, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[((size_t)tap * d.CB + cb) * d.CS + cs0 + l31] = acc[j][r];
+            out[((size_t)tap * d.CB + cb) * d.CS + cs0 + csb * 32 + l31] = acc[j][r];
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sRed[(wave * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
+    for (int r = 0; r < 16; ++r) sRed[(wave_all * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v = (sRed[r * 64 + lane] + sRed[(16 + r) * 64 + lane]) + (sRed[(32 + r) * 64 + lane] + sRed[(48 + r) * 64 + lane]);
+            const float* q = sRed + (size_t)csb * 64 * 64;
+            const float v = (q[r * 64 + lane] + q[(16 + r) * 64 + lane]) + (q[(32 + r) * 64 + lane] + q[(48 + r) * 64 + lane]);
             const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[((size_t)24 * d.CB + cb) * d.CS + cs0 + l31] = v;
+            out[((size_t)24 * d.CB + cb) * d.CS + cs0 + csb * 32 + l31] = v;
         }
     }
+    if (a.dbgbuf && tid == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        a.dbgbuf[2 * b] = dbg_t0;
+        a.dbgbuf[2 * b + 1] = wall_clock64();
+    }
 }
-constexpr size_t conv5_w_bf16_lds_bytes() { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)2 * 32 * 72 * 2; }
+constexpr size_t conv5_w_bf16_lds_bytes(int ncsb) { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)ncsb * 2 * 32 * 72 * 2 + 192 * 4; }
 
 struct W5Choice { bool ok; int splits, tiles_per_split, total_tiles; };
 inline W5Choice choose_w5(const UadConvDesc& d) {
@@ -2409,7 +2424,7 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CB; a.Nn = d.CS;
-    a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
+    a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;
     const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0);
     run_plan(p, a, true, ws.ptr, st);
 }
@@ -2421,7 +2436,7 @@ void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf,
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CS; a.Nn = d.CB;
-    a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
+    a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;
     const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0);
     run_plan(p, a, false, ws.ptr, st);
 }
@@ -2469,16 +2484,35 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         ConvWArgs a;
         a.big = big; a.small_ = small; a.partial = (w5.splits == 1) ? dW : partial;
         a.xfb = xfb; a.xfs = xfs; a.d = d;
-        a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = 0; a.lws = a.lhs = -1;
+        a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = 0; a.lws = a.lhs = -1; a.dbgbuf = nullptr;
         dim3 grid(d.CB / 32, d.CS / 32, w5.splits);
         if (math_bf16x3) {
-            constexpr size_t lds = conv5_w_bf16_lds_bytes();
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_lds_bytes(1));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_lds_bytes(2));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(conv5_w_bf16_kernel, grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+            static const int dbgw = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0;
+            static unsigned long long* wbuf = nullptr;
+            static int wcalls = 0;
+            const bool dbg_this = (dbgw & 32) && wcalls < 8;
+            if (dbg_this) { if (!wbuf) (void)hipMalloc((void**)&wbuf, 2 * 2048 * 8); (void)hipMemsetAsync(wbuf, 0, 2 * 2048 * 8, st); a.dbgbuf = wbuf; }
+            struct Dump { bool on; hipStream_t st; unsigned long long* buf; dim3* g; int* calls; UadConvDesc d;
+                ~Dump() { if (!on) return; (void)hipStreamSynchronize(st); const int nb = g->x * g->y * g->z; static unsigned long long h[2 * 2048];
+                    (void)hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost); ++*calls;
+                    unsigned long long t0 = ~0ull, t1 = 0, dmin = ~0ull, dmax = 0, dsum = 0, smax = 0;
+                    for (int b = 0; b < nb && b < 2048; ++b) { if (h[2 * b] < t0) t0 = h[2 * b]; if (h[2 * b + 1] > t1) t1 = h[2 * b + 1]; }
+                    for (int b = 0; b < nb && b < 2048; ++b) { const unsigned long long dd = h[2 * b + 1] - h[2 * b]; dsum += dd; if (dd < dmin) dmin = dd; if (dd > dmax) dmax = dd; if (h[2 * b] - t0 > smax) smax = h[2 * b] - t0; }
+                    fprintf(stderr, "[w5 CB=%d CS=%d HS=%d grid=%d,%d,%d] span=%llu (100MHz ticks) wg dur min=%llu avg=%llu max=%llu latest start=%llu\n", d.CB, d.CS, d.HS, g->x, g->y, g->z,
+                            t1 - t0, dmin, dsum / nb, dmax, smax); } } dump{dbg_this, st, wbuf, &grid, &wcalls, d};
+            static const bool pair_ok = !getenv("UAD_NO_W2");
+            if (pair_ok && d.CS % 64 == 0) {
+                grid.y = d.CS / 64;
+                hipLaunchKernelGGL(conv5_w_bf16_kernel<2>, grid, dim3(512), conv5_w_bf16_lds_bytes(2), st, a, w5.tiles_per_split, w5.total_tiles);
+            } else {
+                hipLaunchKernelGGL(conv5_w_bf16_kernel<1>, grid, dim3(256), conv5_w_bf16_lds_bytes(1), st, a, w5.tiles_per_split, w5.total_tiles);
+            }
         } else {
             hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
         }
@@ -2490,7 +2524,7 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
     a.big = big; a.small_ = small; a.partial = (c.splits == 1) ? dW : partial;
     a.xfb = xfb; a.xfs = xfs; a.d = d;
     a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = c.kper;
-    a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS);
+    a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;
     dim3 grid((a.Mtot + c.BM - 1) / c.BM, (d.CS + c.BN - 1) / c.BN, c.splits);
     if (c.BM == 128 && c.BN == 64)
         hipLaunchKernelGGL((conv_w_kernel<128, 64, 32, 2, 2>), grid, dim3(256), 0, st, a);
