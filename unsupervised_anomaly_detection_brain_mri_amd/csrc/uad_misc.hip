@@ -425,8 +425,7 @@ __device__ __forceinline__ void first_dgrad_store(const FirstDgradEpi& e, size_t
     if (e.anomaly) e.anomaly[pix] = fabsf(diff) * fabsf(gx);
 }
 template <int PY, int PX>
-__device__ __forceinline__ void first_dgrad_class(const float4* sg, const float* __restrict__ W, int cq, int slot,
-                                                  int HB, int WB, int n, int ty0, int tx0, const FirstDgradEpi& e) {
+__device__ __forceinline__ void first_dgrad_class(const float4* sg, const float* __restrict__ W, int cq, int slot, float* sout) {
     constexpr int NKY = PY ? 3 : 2, NKX = PX ? 3 : 2, KY0 = PY ? 0 : 1, KX0 = PX ? 0 : 1;
     float4 w[NKY][NKX];
 #pragma unroll
@@ -449,15 +448,15 @@ __device__ __forceinline__ void first_dgrad_class(const float4* sg, const float*
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
         acc += __shfl_xor(acc, 4);
-        if (cq == 0) {
-            const int y = ty0 + 2 * pyy + PY, x = tx0 + 2 * pxx + PX;
-            first_dgrad_store(e, ((size_t)n * HB + y) * WB + x, acc);
-        }
+        // park the pixel's data gradient in the tile buffer; the epilogue (all 256 threads, one pixel each, coalesced rows)
+        // runs after every parity class is done -- storing from the 8 lanes with cq == 0 used 1/8 of each memory instruction
+        if (cq == 0) sout[(2 * pyy + PY) * 16 + 2 * pxx + PX] = acc;
     }
 }
 __global__ void __launch_bounds__(256) conv_first_dgrad_tiled_kernel(UadConvDesc d, const float* __restrict__ g,
                                                                      const float* __restrict__ W, FirstDgradEpi e) {
     __shared__ float4 sg[10 * 10 * 8];
+    __shared__ float sout[16 * 16];
     const int n = blockIdx.z, ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
     const int i0 = ty0 / 2 - 1, j0 = tx0 / 2 - 1;
     for (int idx = threadIdx.x; idx < 800; idx += 256) {
@@ -470,10 +469,13 @@ __global__ void __launch_bounds__(256) conv_first_dgrad_tiled_kernel(UadConvDesc
     }
     __syncthreads();
     const int cq = threadIdx.x & 7, slot = threadIdx.x >> 3;
-    first_dgrad_class<0, 0>(sg, W, cq, slot, d.HB, d.WB, n, ty0, tx0, e);
-    first_dgrad_class<0, 1>(sg, W, cq, slot, d.HB, d.WB, n, ty0, tx0, e);
-    first_dgrad_class<1, 0>(sg, W, cq, slot, d.HB, d.WB, n, ty0, tx0, e);
-    first_dgrad_class<1, 1>(sg, W, cq, slot, d.HB, d.WB, n, ty0, tx0, e);
+    first_dgrad_class<0, 0>(sg, W, cq, slot, sout);
+    first_dgrad_class<0, 1>(sg, W, cq, slot, sout);
+    first_dgrad_class<1, 0>(sg, W, cq, slot, sout);
+    first_dgrad_class<1, 1>(sg, W, cq, slot, sout);
+    __syncthreads();
+    const int y = threadIdx.x >> 4, x = threadIdx.x & 15;
+    first_dgrad_store(e, ((size_t)n * d.HB + ty0 + y) * d.WB + tx0 + x, sout[threadIdx.x]);
 }
 
 // rec_per_sample[i] = sum_b rec_partial[i][b].  Samples [0,n_vae) carry the VAE-branch losses, [n_vae,n) the ceVAE context
