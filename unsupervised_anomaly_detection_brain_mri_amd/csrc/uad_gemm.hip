@@ -1179,6 +1179,19 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         e_b = *reinterpret_cast<const float4*>(a.ep.eshift + ecol);
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // EPI_FINAL: e_a := conv bias, f_sc/f_sh := this layer's BN, f_w := final 1x1 kernel; per-lane running sums of the
+    // final conv's kernel gradient (dwf), the loss (rec) and the final bias gradient (dbf)
+    const bool fin = (a.ep.kind == UAD_EPI_FINAL);
+    float4 f_sc = make_float4(0.f, 0.f, 0.f, 0.f), f_sh = f_sc, f_w = f_sc;
+    float f_bf = 0.f, rec = 0.f, dbf = 0.f;
+    float dwf[4] = {0.f, 0.f, 0.f, 0.f};
+    if (fin) {
+        f_sc = *reinterpret_cast<const float4*>(a.ep.escale + ecol);
+        f_sc.x *= a.ep.emult; f_sc.y *= a.ep.emult; f_sc.z *= a.ep.emult; f_sc.w *= a.ep.emult;
+        f_sh = *reinterpret_cast<const float4*>(a.ep.eshift + ecol);
+        f_w = *reinterpret_cast<const float4*>(a.ep.fin_wf + ecol);
+        f_bf = a.ep.fin_bf[0];
+    }
     auto class_epilogue = [&](const v16f& o, int py, int px) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) etile[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + l31] = o[r];
@@ -1198,6 +1211,53 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             float* slab = a.Out + (size_t)split * a.out_elems;
 #pragma unroll
             for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(slab + off[k]) = v[k];
+        } else if (fin) {
+            // last decoder block: BN + LeakyReLU, final 1x1 conv (C -> 1, reduced over the 8 lanes that share a pixel), L1 loss
+            // and, if wanted, its gradient back to this layer's pre-BN output (models/customlayers.py:35-37, trainers/VAE.py:36-40)
+            float xin[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xin[k] = a.ep.fin_x[off[k] / Nn];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float cc[4] = {v[k].x + e_a.x, v[k].y + e_a.y, v[k].z + e_a.z, v[k].w + e_a.w};
+                const float scv[4] = {f_sc.x, f_sc.y, f_sc.z, f_sc.w}, shv[4] = {f_sh.x, f_sh.y, f_sh.z, f_sh.w};
+                const float wv[4] = {f_w.x, f_w.y, f_w.z, f_w.w};
+                float bn[4], av[4];
+                float dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bn[e] = fmaf(cc[e], scv[e], shv[e]);
+                    av[e] = bn[e] > 0.f ? bn[e] : bn[e] * a.ep.ealpha;
+                    dot = fmaf(av[e], wv[e], dot);
+                }
+                dot += __shfl_xor(dot, 1);
+                dot += __shfl_xor(dot, 2);
+                dot += __shfl_xor(dot, 4);
+                const float xh = dot + f_bf;
+                const float diff = xh - xin[k];
+                const size_t pix = off[k] / Nn;
+                if ((lane & 7) == 0) {
+                    a.ep.fin_xhat[pix] = xh;
+                    if (a.ep.fin_l1) a.ep.fin_l1[pix] = fabsf(diff);
+                    rec += fabsf(diff);
+                }
+                if (a.Out) *reinterpret_cast<float4*>(a.Out + off[k]) = make_float4(cc[0], cc[1], cc[2], cc[3]);
+                if (a.ep.fin_dc) {
+                    const float sgn = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * a.ep.fin_inv_batch;
+                    float dc[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float da = sgn * wv[e];
+                        const float dbn = bn[e] > 0.f ? da : da * a.ep.ealpha;
+                        dc[e] = dbn * scv[e];
+                        dwf[e] = fmaf(sgn, av[e], dwf[e]);
+                        s1[e] += dbn;
+                        s2[e] = fmaf(dbn, cc[e], s2[e]);
+                    }
+                    *reinterpret_cast<float4*>(a.ep.fin_dc + off[k]) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+                    if ((lane & 7) == 0) dbf += sgn;
+                }
+            }
         } else if (!bwd) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1270,6 +1330,38 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         if (4 * g4 + 1 < NUNIT) unit(b1, b0, a1, a0, 4 * g4 + 1);
         if (4 * g4 + 2 < NUNIT) unit(b2, b1, a0, a1, 4 * g4 + 2);
         if (4 * g4 + 3 < NUNIT) unit(b3, b2, a1, a0, 4 * g4 + 3);
+    }
+    if (fin) {
+        // workgroup partials in the final kernel's layout: red_partial[tile][3C+1] = {dwf[C], S1[C], S2[C], dbf}, rec_partial[tile]
+        __syncthreads();                        // every wave is done with its transpose tile (s_epi is reused below)
+        float* fr = s_epi;                      // [waves][3*BN + 2]
+        constexpr int FL = 3 * BN + 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t0 = dwf[e], t1 = s1[e], t2 = s2[e];
+            t0 += __shfl_xor(t0, 8); t0 += __shfl_xor(t0, 16); t0 += __shfl_xor(t0, 32);
+            t1 += __shfl_xor(t1, 8); t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
+            t2 += __shfl_xor(t2, 8); t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
+            if (lane < 8) {
+                fr[wave * FL + 0 * BN + wn * 32 + ec4 + e] = t0;
+                fr[wave * FL + 1 * BN + wn * 32 + ec4 + e] = t1;
+                fr[wave * FL + 2 * BN + wn * 32 + ec4 + e] = t2;
+            }
+        }
+        float r0 = rec, r1 = dbf;
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); }
+        if (lane == 0) { fr[wave * FL + 3 * BN] = r1; fr[wave * FL + 3 * BN + 1] = r0; }
+        __syncthreads();
+        const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        if (tid < FL) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM * WGN; ++w) t += fr[w * FL + tid];
+            if (tid == 3 * BN + 1) a.ep.fin_rec_partial[tile] = t;
+            else if (a.ep.fin_dc) a.ep.fin_red_partial[tile * (3 * BN + 1) + tid] = t;
+        }
+        return;
     }
     if (nsplit > 1) return;
     if (bwd) {
@@ -2320,6 +2412,12 @@ bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
 }
 int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, true, have_pack, ws_floats).tiles; }
 int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, false, have_pack, ws_floats).tiles; }
+bool uad_conv_d_can_fuse_final(const UadConvDesc& d, bool have_pack16, size_t ws_floats) {
+    if (!have_pack16 || getenv("UAD_NO_FUSED_FINAL")) return false;
+    const GemmPlan p = plan_gemm(d, false, true, ws_floats);
+    // conv5_d16_kernel<8,16,CST,4,1> with the whole channel range in one workgroup column block
+    return p.path == PATH_SPATIAL && p.nsplit == 1 && p.sc.BN == 32 && d.CB == 32 && (d.CS == 32 || d.CS == 64) && !getenv("UAD_NO_D16");
+}
 size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack) { return plan_gemm(d, f_type, have_pack, (size_t)1 << 40).ws_floats; }
 
 void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d, const long long* offs, const int* cbs,

@@ -28,7 +28,7 @@ struct UadXform {
     float mult;           // scale multiplier: 1/sqrt(1+eps) of the frozen-stats BN
 };
 
-enum { UAD_EPI_BIAS = 0, UAD_EPI_BWD_ACT = 1 };
+enum { UAD_EPI_BIAS = 0, UAD_EPI_BWD_ACT = 1, UAD_EPI_FINAL = 2 };
 
 // optional split-K workspace of the generic kernels (slabs of raw partial outputs)
 struct UadGemmWs { float* ptr; size_t floats; };
@@ -46,6 +46,18 @@ struct UadEpilogue {
     float ealpha;
     float emult;          // escale multiplier (see UadXform::mult)
     float* colpart;
+    // EPI_FINAL (last decoder ConvT, all output channels in one workgroup): the layer's own BN + LeakyReLU
+    // (escale/eshift/ealpha/emult), the final 1x1 conv C -> 1 and the L1 loss are applied to the accumulator tile, with the
+    // loss gradient when fin_dc is given -- the pre-BN output never goes to HBM unless Out is non-null.
+    const float* fin_wf;        // [C] final conv kernel
+    const float* fin_bf;        // [1]
+    const float* fin_x;         // [N,H,W,1] target
+    float* fin_xhat;            // [N,H,W,1]
+    float* fin_l1;              // [N,H,W,1] or null
+    float* fin_rec_partial;     // [tiles]               (tile = blockIdx.y * gridDim.x + blockIdx.x)
+    float* fin_red_partial;     // [tiles][3C+1]: dwf[C], S1[C], S2[C], dbf   (backward only)
+    float* fin_dc;              // [N,H,W,C] d loss / d c, or null (forward only)
+    float fin_inv_batch;
 };
 
 // F-type: small_out[n,i,j,cs] = sum_{tap,cb} xf(big_in)[n,S*i-P+ky,S*j-P+kx,cb] * W[tap][cb][cs]
@@ -69,6 +81,9 @@ bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type);
 // number of colpart tiles the above launches write for EPI_BWD_ACT
 // (the same have_pack / workspace capacity as the launch must be passed: they select the kernel path)
 int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0);
+// true when uad_launch_conv_d(d, ..., UAD_EPI_FINAL) is available: bf16x3 planes given, class-sequential spatial kernel, all
+// output channels (32) in one workgroup, no split
+bool uad_conv_d_can_fuse_final(const UadConvDesc& d, bool have_pack16, size_t ws_floats);
 int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0);
 // workspace floats the split-K path would like for this op (0 = it would not split)
 size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack);

@@ -570,16 +570,36 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cmid, m->cenc), m->dvec, no_xform(), P(m, m->rw), m->cb, epi_bias(P(m, m->rb)), st, nullptr, m->ws);
     }
     // decoder
+    const ConvLayer& DL = m->dec.back();
+    const int bps = uad_final_blocks_per_sample(m->cfg.height, m->cfg.width);
+    bool fused_final = false;
     for (size_t i = 0; i < m->dec.size(); ++i) {
         PROF(kDecF[i & 7]);
         UadConvDesc d = m->dec[i].d; d.N = n;
         const float* in = (i == 0) ? m->dec_in0 : m->dec[i - 1].c;
         UadXform xf = (i == 0) ? bn_xform(m, m->dbn_g, m->dbn_b, 0.0f)
                                : bn_xform(m, m->dec[i - 1].gamma, m->dec[i - 1].beta, kLrelu);
-        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), m->dec[i].c, epi_bias(P(m, m->dec[i].b)), st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]));
+        UadEpilogue ep = epi_bias(P(m, m->dec[i].b));
+        float* out = m->dec[i].c;
+        if (i + 1 == m->dec.size() && m->math == UAD_MATH_BF16X3 && uad_conv_d_can_fuse_final(d, true, m->ws.floats) &&
+            (d.HS / 8) * (d.WS / 16) == bps) {
+            // last block: its BN + LeakyReLU, the final 1x1 conv, the L1 loss and (training) the loss gradient run in the
+            // ConvT kernel's epilogue; the pre-BN output is only written when a later pass needs it (restoration: TV term)
+            fused_final = true;
+            const bool restore_bwd = m->restore && want_backward;
+            ep.kind = UAD_EPI_FINAL;
+            ep.escale = P(m, DL.gamma); ep.eshift = P(m, DL.beta); ep.ealpha = kLrelu; ep.emult = 1.0f / sqrtf(1.0f + kBnEps);
+            ep.fin_wf = P(m, m->fw); ep.fin_bf = P(m, m->fb); ep.fin_x = xin;
+            ep.fin_xhat = (io->x_hat && !cevae) ? io->x_hat : m->xhat_own;
+            ep.fin_l1 = cevae ? ((io->l1_map || io->l1_map_ce) ? m->l1_own : nullptr) : io->l1_map;
+            ep.fin_rec_partial = m->rec_partial; ep.fin_red_partial = m->red_partial;
+            ep.fin_dc = (want_backward && !restore_bwd) ? m->G0 : nullptr;
+            ep.fin_inv_batch = 1.0f / (float)nu;
+            out = restore_bwd ? DL.c : nullptr;
+        }
+        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), out, ep, st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]));
     }
     // final 1x1 conv + L1 loss (+ start of the backward)
-    const ConvLayer& DL = m->dec.back();
     UadFinalArgs fa;
     fa.N = n; fa.H = m->cfg.height; fa.W = m->cfg.width; fa.C = DL.d.CB;
     fa.c_last = DL.c; fa.scale = P(m, DL.gamma); fa.shift = P(m, DL.beta); fa.alpha = kLrelu;
@@ -592,18 +612,19 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     fa.red_partial = m->red_partial;
     fa.inv_batch = 1.0f / (float)nu;
     fa.dxhat_in = nullptr;
-    if (m->restore && want_backward) {
+    if (fused_final && !(m->restore && want_backward)) {
+        // everything already happened in the last ConvT's epilogue
+    } else if (m->restore && want_backward) {
         // restoration objective: d / d x_hat needs the finished reconstruction's neighbours (TV), so two passes
         PROF("final.fwd+tv+bwd");
         float* dc = fa.d_c; fa.d_c = nullptr;
-        uad_launch_final_fwd_bwd(fa, st);
+        if (!fused_final) uad_launch_final_fwd_bwd(fa, st);
         uad_launch_tv_dxhat(xin, fa.x_hat, n, fa.H, fa.W, fa.inv_batch, m->restore_tv, m->gm_dxhat, st);
         fa.d_c = dc; fa.dxhat_in = m->gm_dxhat;
         uad_launch_final_fwd_bwd(fa, st);
     } else {
         PROF(want_backward ? "final.fwd+bwd" : "final.fwd"); uad_launch_final_fwd_bwd(fa, st);
     }
-    const int bps = uad_final_blocks_per_sample(fa.H, fa.W);
     if (m->restore) {
         // restoration iterations fetch only `grads` (trainers/GMVAE_spatial.py:186): no loss scalars
     } else if (gm) {
