@@ -19,6 +19,9 @@
  *   uad_residual
  *       <- utils/Evaluation.py:282-289 (residual map, brain mask, hyper-intensity prior) and
  *          trainers/VAE.py:120 (l1err)
+ *   uad_erode_cross / uad_median3d / uad_scores_*
+ *       <- utils/Evaluation.py:84-89 (scipy binary_erosion), :108-110 (scipy median_filter), trainers/Metrics.py:17-19,45-47,
+ *          67-72,138-162 (sklearn AUPRC / AUROC, Dice threshold sweep)
  *   uad_set_params / uad_get_params / uad_tensor_info
  *       <- tf.global_variables_initializer / tf.train.Saver variable access (trainers/DLMODEL.py:63-110)
  *   uad_op_*  — single-kernel entry points used by the parity tests (no reference counterpart).
@@ -154,6 +157,22 @@ int uad_profile_report(uad_model_t* m, char* buf, int cap);
  * (pass -INFINITY to disable); l1err[n] = sum |x - xr| per sample (may be NULL); mask may be NULL. hw = H*W*C. */
 int uad_residual(const float* x, const float* xr, const float* mask, int n, int hw, int pos_only, float prior_thresh,
                  float* out, float* l1err, void* stream);
+
+/* ---- residual-map scoring on the device (utils/Evaluation.py:84-127, 238-312; trainers/Metrics.py) ----------------------
+ * uad_erode_cross: scipy.ndimage.binary_erosion(mask, generate_binary_structure(2,1), iterations) per [H,W] slice, zero
+ *   border (utils/Evaluation.py:84-89 with iterations = 12); mask/out are fp32 [n,H,W], out = 1.0 where the pixel survives.
+ * uad_median3d: scipy.ndimage.median_filter(vol, (5,5,5)) with the default 'reflect' boundary (utils/Evaluation.py:108-110).
+ * uad_scores_*: every threshold metric of trainers/Metrics.py from ONE descending device sort of the n voxel scores:
+ *   AUROC (sklearn roc_curve + auc, Metrics.py:45-47), AUPRC (sklearn average_precision_score, :17-19) and
+ *   dice(score > t, label) for batches of thresholds (the inner step of compute_dice_curve_recursive, :138-162).
+ *   label: fp32, nonzero = positive.  create is synchronous (allocates; one 32-bit radix sort + scans). */
+typedef struct uad_scores uad_scores_t;
+int uad_erode_cross(const float* mask, int n, int H, int W, int iterations, float* out, void* stream);
+int uad_median3d(const float* vol, int D, int H, int W, int ksize, float* out, void* stream);
+int uad_scores_create(const float* pred, const float* label, long long n, uad_scores_t** out, void* stream);
+int uad_scores_auc(const uad_scores_t* s, double* auroc, double* auprc, double* positives);
+int uad_scores_dice(uad_scores_t* s, const double* thresholds_host, int k, double* dice_host, void* stream);
+int uad_scores_destroy(uad_scores_t* s);
 
 /* ---- single-kernel entry points (parity tests) ------------------------------------------------------------
  * geometry of one strided-conv relation: big pixel (S*i-P+ky, S*j-P+kx) <-> small pixel (i,j); weights W[tap][cb][cs]

@@ -74,6 +74,12 @@ SYMBOLS = {
     'uad_profile_report': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     'uad_residual': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
+    'uad_erode_cross': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'uad_median3d': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'uad_scores_create': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.POINTER(C.c_void_p), C.c_void_p]),
+    'uad_scores_auc': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'uad_scores_dice': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_void_p]),
+    'uad_scores_destroy': (C.c_int, [C.c_void_p]),
     'uad_op_conv_f': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'uad_op_conv_d': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p, C.c_void_p,

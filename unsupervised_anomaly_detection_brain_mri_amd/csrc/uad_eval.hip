@@ -1,0 +1,286 @@
+// Residual-map scoring on the device (reference utils/Evaluation.py:84-127, trainers/Metrics.py):
+//   * binary erosion of the brain masks (cross structuring element, `iterations` passes, zero border),
+//   * 5x5x5 median filter of a residual volume (scipy default boundary: reflect),
+//   * exact AUROC / AUPRC / Dice-at-threshold over tens of millions of voxels from ONE descending sort
+//     (sklearn's definitions: distinct-score thresholds; the reference sorts on the host for AUPRC and re-thresholds the
+//     whole array ~170 times for the Dice search).
+// All of it is HBM-bound integer / order-statistic work: coalesced loads, LDS tiles, no matrix cores.
+// The sort and the scans are rocPRIM device primitives (part of ROCm); everything else is hand-written.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "uad_kernels.h"
+#include "../../include/uad_hip.h"
+
+int uad_fail(int code, const char* fmt, ...);   // uad_model.hip
+#define fail uad_fail
+
+#define EV_TRY(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(UAD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Erosion: one workgroup per slice, the mask lives in LDS as bytes (two buffers), `iterations` passes.
+// out = 1.0f where the pixel survives.  scipy.ndimage.binary_erosion(..., structure=cross, border_value=0).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) erode_cross_kernel(const float* __restrict__ mask, int H, int W, int iterations,
+                                                           float* __restrict__ out) {
+    extern __shared__ unsigned char sm[];
+    const int hw = H * W;
+    unsigned char* a = sm;
+    unsigned char* b = sm + hw;
+    const float* src = mask + (size_t)blockIdx.x * hw;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) a[i] = src[i] != 0.f;
+    __syncthreads();
+    for (int it = 0; it < iterations; ++it) {
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+            const int y = i / W, x = i - y * W;
+            unsigned char v = a[i];
+            v &= (y > 0) ? a[i - W] : 0;
+            v &= (y < H - 1) ? a[i + W] : 0;
+            v &= (x > 0) ? a[i - 1] : 0;
+            v &= (x < W - 1) ? a[i + 1] : 0;
+            b[i] = v;
+        }
+        __syncthreads();
+        unsigned char* t = a; a = b; b = t;
+    }
+    float* dst = out + (size_t)blockIdx.x * hw;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = a[i] ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 5x5x5 median (rank 62 of 125), reflect boundary.  One thread per voxel; an 8x8x8 output tile + 2-voxel halo is staged in
+// LDS as order-preserving unsigned keys; each thread copies its 125 keys to registers and runs a 32-step bitwise
+// selection (largest prefix p with count(key < p) <= 62), no sorting, no divergence.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ int reflect_idx(int i, int n) {   // numpy 'symmetric' == scipy 'reflect': (d c b a | a b c d | d c b a)
+    if (n == 1) return 0;
+    const int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+__global__ void __launch_bounds__(512) median5_kernel(const float* __restrict__ vol, int D, int H, int W,
+                                                      float* __restrict__ out) {
+    constexpr int T = 8, R = 2, E = T + 2 * R;   // 12
+    __shared__ unsigned tile[E * E * E];
+    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T, z0 = blockIdx.z * T;
+    for (int i = threadIdx.x; i < E * E * E; i += 512) {
+        const int lx = i % E, ly = (i / E) % E, lz = i / (E * E);
+        const int gz = reflect_idx(z0 + lz - R, D), gy = reflect_idx(y0 + ly - R, H), gx = reflect_idx(x0 + lx - R, W);
+        tile[i] = f2key(vol[((size_t)gz * H + gy) * W + gx]);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % T, ly = (threadIdx.x / T) % T, lz = threadIdx.x / (T * T);
+    const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+    unsigned k[125];
+#pragma unroll
+    for (int dz = 0; dz < 5; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) k[(dz * 5 + dy) * 5 + dx] = tile[((lz + dz) * E + ly + dy) * E + lx + dx];
+    unsigned prefix = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 125; ++i) cnt += (k[i] < cand) ? 1 : 0;
+        if (cnt <= 62) prefix = cand;
+    }
+    if (gx < W && gy < H && gz < D) out[((size_t)gz * H + gy) * W + gx] = key2f(prefix);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Metrics from one descending sort.  After the sort: score[i] (desc), lab[i] in {0,1}; tp[i] = inclusive prefix sum of lab.
+// A "distinct" position closes a run of equal scores (sklearn's thresholds).  For the m-th distinct position i:
+//   tps = tp[i], fps = i + 1 - tps;  AP += (tps - tps_prev) / P * tps / (i + 1);  AUC += (fpr - fpr_prev) * (tpr + tpr_prev) / 2
+// ------------------------------------------------------------------------------------------------
+__global__ void lab_to_u32_kernel(const float* __restrict__ lab, unsigned* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = lab[i] != 0.f ? 1u : 0u;
+}
+__global__ void iota_distinct_kernel(const float* __restrict__ score, unsigned* __restrict__ idx, unsigned char* __restrict__ flag,
+                                     size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    idx[i] = (unsigned)i;
+    flag[i] = (i + 1 == n) || (score[i] != score[i + 1]);
+}
+// one block: fixed-order double accumulation over the compacted distinct positions (deterministic)
+__global__ void __launch_bounds__(1024) auc_ap_kernel(const unsigned* __restrict__ didx, unsigned nd,
+                                                      const unsigned long long* __restrict__ tp, unsigned long long n,
+                                                      double* __restrict__ out) {
+    __shared__ double s_ap[1024], s_auc[1024];
+    const double P = (double)tp[n - 1], Nn = (double)n - P;
+    double ap = 0.0, auc = 0.0;
+    for (unsigned m = threadIdx.x; m < nd; m += 1024) {
+        const unsigned i = didx[m];
+        const double tps = (double)tp[i], fps = (double)(i + 1) - tps;
+        double tps_p = 0.0, fps_p = 0.0;
+        if (m > 0) { const unsigned j = didx[m - 1]; tps_p = (double)tp[j]; fps_p = (double)(j + 1) - tps_p; }
+        if (P > 0) ap += (tps - tps_p) / P * (tps / (tps + fps));
+        if (P > 0 && Nn > 0) auc += (fps - fps_p) / Nn * (tps + tps_p) / P * 0.5;
+    }
+    s_ap[threadIdx.x] = ap;
+    s_auc[threadIdx.x] = auc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { s_ap[threadIdx.x] += s_ap[threadIdx.x + o]; s_auc[threadIdx.x] += s_auc[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = s_auc[0]; out[1] = s_ap[0]; out[2] = P; }
+}
+// Dice of (score > t) against the labels for a batch of thresholds: count = first index with score <= t (descending order)
+__global__ void dice_at_kernel(const float* __restrict__ score, const unsigned long long* __restrict__ tp, unsigned long long n,
+                               const double* __restrict__ thr, int k, double* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= k) return;
+    const double t = thr[q];
+    unsigned long long lo = 0, hi = n;           // first index whose score is NOT > t
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if ((double)score[mid] > t) lo = mid + 1; else hi = mid;
+    }
+    const double cnt = (double)lo;
+    const double tps = lo ? (double)tp[lo - 1] : 0.0;
+    const double P = (double)tp[n - 1];
+    out[q] = (2.0 * tps) / (cnt + P);            // 0/0 -> nan like the reference's numpy division
+}
+
+}  // namespace
+
+struct uad_scores {
+    unsigned long long n;
+    float* score;               // descending
+    unsigned long long* tp;     // inclusive prefix sum of the labels in that order
+    double auc, ap, npos;
+    double* dthr;               // device scratch for threshold batches
+    double* dout;
+    int cap;
+};
+
+extern "C" {
+
+int uad_erode_cross(const float* mask, int n, int H, int W, int iterations, float* out, void* stream) {
+    if (!mask || !out || n <= 0 || H <= 0 || W <= 0 || iterations < 0) return fail(UAD_ERR_INVALID, "erode: bad arguments");
+    const size_t lds = (size_t)2 * H * W;
+    if (lds > 160 * 1024) return fail(UAD_ERR_UNSUPPORTED, "erode: slice %dx%d does not fit in LDS", H, W);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(erode_cross_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(erode_cross_kernel, dim3(n), dim3(1024), lds, (hipStream_t)stream, mask, H, W, iterations, out);
+    EV_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+int uad_median3d(const float* vol, int D, int H, int W, int ksize, float* out, void* stream) {
+    if (!vol || !out || D <= 0 || H <= 0 || W <= 0) return fail(UAD_ERR_INVALID, "median3d: bad arguments");
+    if (ksize != 5) return fail(UAD_ERR_UNSUPPORTED, "median3d: only the reference's 5x5x5 window is implemented");
+    if (vol == out) return fail(UAD_ERR_INVALID, "median3d: in-place is not supported");
+    dim3 grid((W + 7) / 8, (H + 7) / 8, (D + 7) / 8);
+    hipLaunchKernelGGL(median5_kernel, grid, dim3(512), 0, (hipStream_t)stream, vol, D, H, W, out);
+    EV_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+int uad_scores_create(const float* pred, const float* label, long long n, uad_scores_t** out, void* stream) {
+    if (!pred || !label || !out || n <= 0 || n > 0x7fffffffLL) return fail(UAD_ERR_INVALID, "scores: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    uad_scores* s = new uad_scores();
+    memset(s, 0, sizeof *s);
+    s->n = (unsigned long long)n;
+    unsigned *lab_in = nullptr, *lab_sorted = nullptr, *idx = nullptr, *didx = nullptr, *d_nd = nullptr;
+    unsigned char* flag = nullptr;
+    void* tmp = nullptr;
+    double* d_res = nullptr;
+    int rc = UAD_OK;
+    auto cleanup = [&]() { hipFree(lab_in); hipFree(lab_sorted); hipFree(idx); hipFree(didx); hipFree(d_nd); hipFree(flag); hipFree(tmp); hipFree(d_res); };
+#define EV_TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(UAD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); cleanup(); uad_scores_destroy(s); return rc; } } while (0)
+    EV_TRY2(hipMalloc((void**)&s->score, n * sizeof(float)));
+    EV_TRY2(hipMalloc((void**)&s->tp, n * sizeof(unsigned long long)));
+    EV_TRY2(hipMalloc((void**)&lab_in, n * sizeof(unsigned)));
+    EV_TRY2(hipMalloc((void**)&lab_sorted, n * sizeof(unsigned)));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(lab_to_u32_kernel, dim3(blocks), dim3(256), 0, st, label, lab_in, (size_t)n);
+    size_t tb = 0;
+    EV_TRY2(rocprim::radix_sort_pairs_desc(nullptr, tb, pred, s->score, lab_in, lab_sorted, (size_t)n, 0, 32, st));
+    EV_TRY2(hipMalloc(&tmp, tb));
+    EV_TRY2(rocprim::radix_sort_pairs_desc(tmp, tb, pred, s->score, lab_in, lab_sorted, (size_t)n, 0, 32, st));
+    hipFree(tmp); tmp = nullptr;
+    // tp = inclusive scan of the labels (64-bit)
+    auto lab64 = rocprim::make_transform_iterator(lab_sorted, [] __device__(unsigned v) { return (unsigned long long)v; });
+    tb = 0;
+    EV_TRY2(rocprim::inclusive_scan(nullptr, tb, lab64, s->tp, (size_t)n, rocprim::plus<unsigned long long>(), st));
+    EV_TRY2(hipMalloc(&tmp, tb));
+    EV_TRY2(rocprim::inclusive_scan(tmp, tb, lab64, s->tp, (size_t)n, rocprim::plus<unsigned long long>(), st));
+    hipFree(tmp); tmp = nullptr;
+    // distinct-threshold positions, compacted
+    EV_TRY2(hipMalloc((void**)&idx, n * sizeof(unsigned)));
+    EV_TRY2(hipMalloc((void**)&didx, n * sizeof(unsigned)));
+    EV_TRY2(hipMalloc((void**)&flag, n));
+    EV_TRY2(hipMalloc((void**)&d_nd, sizeof(unsigned)));
+    hipLaunchKernelGGL(iota_distinct_kernel, dim3(blocks), dim3(256), 0, st, s->score, idx, flag, (size_t)n);
+    tb = 0;
+    EV_TRY2(rocprim::select(nullptr, tb, idx, flag, didx, d_nd, (size_t)n, st));
+    EV_TRY2(hipMalloc(&tmp, tb));
+    EV_TRY2(rocprim::select(tmp, tb, idx, flag, didx, d_nd, (size_t)n, st));
+    unsigned nd = 0;
+    EV_TRY2(hipMemcpyAsync(&nd, d_nd, sizeof nd, hipMemcpyDeviceToHost, st));
+    EV_TRY2(hipStreamSynchronize(st));
+    EV_TRY2(hipMalloc((void**)&d_res, 3 * sizeof(double)));
+    hipLaunchKernelGGL(auc_ap_kernel, dim3(1), dim3(1024), 0, st, didx, nd, s->tp, s->n, d_res);
+    double res[3];
+    EV_TRY2(hipMemcpyAsync(res, d_res, sizeof res, hipMemcpyDeviceToHost, st));
+    EV_TRY2(hipStreamSynchronize(st));
+    s->auc = res[0]; s->ap = res[1]; s->npos = res[2];
+    s->cap = 64;
+    EV_TRY2(hipMalloc((void**)&s->dthr, s->cap * sizeof(double)));
+    EV_TRY2(hipMalloc((void**)&s->dout, s->cap * sizeof(double)));
+    cleanup();
+#undef EV_TRY2
+    *out = s;
+    return UAD_OK;
+}
+
+int uad_scores_auc(const uad_scores_t* s, double* auroc, double* auprc, double* positives) {
+    if (!s) return fail(UAD_ERR_INVALID, "scores: null handle");
+    if (auroc) *auroc = s->auc;
+    if (auprc) *auprc = s->ap;
+    if (positives) *positives = s->npos;
+    return UAD_OK;
+}
+
+int uad_scores_dice(uad_scores_t* s, const double* thresholds, int k, double* dice, void* stream) {
+    if (!s || !thresholds || !dice || k <= 0) return fail(UAD_ERR_INVALID, "scores_dice: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int o = 0; o < k; o += s->cap) {
+        const int c = (k - o < s->cap) ? k - o : s->cap;
+        EV_TRY(hipMemcpyAsync(s->dthr, thresholds + o, c * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(dice_at_kernel, dim3(1), dim3(64), 0, st, s->score, s->tp, s->n, s->dthr, c, s->dout);
+        EV_TRY(hipMemcpyAsync(dice + o, s->dout, c * sizeof(double), hipMemcpyDeviceToHost, st));
+        EV_TRY(hipStreamSynchronize(st));
+    }
+    return UAD_OK;
+}
+
+int uad_scores_destroy(uad_scores_t* s) {
+    if (!s) return UAD_OK;
+    hipFree(s->score); hipFree(s->tp); hipFree(s->dthr); hipFree(s->dout);
+    delete s;
+    return UAD_OK;
+}
+
+}  // extern "C"

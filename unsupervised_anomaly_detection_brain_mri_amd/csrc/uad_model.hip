@@ -17,11 +17,10 @@
 #include "../../include/uad_hip.h"
 #include "uad_kernels.h"
 
-namespace {
+static thread_local std::string g_err;
 
-thread_local std::string g_err;
-
-int fail(int code, const char* fmt, ...) {
+// records the message uad_last_error() returns; shared with uad_eval.hip
+int uad_fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -30,6 +29,9 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+#define fail uad_fail
+
+namespace {
 
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \

@@ -283,6 +283,30 @@ class Engine:
             rep[tag] = (int(cnt), float(ms))
         return rep
 
+    # ---------------------------------------------------------------- scoring
+    def erode_cross(self, masks, iterations=12):
+        """Brain-mask erosion on device (utils/Evaluation.py:84-89): masks [n,H,W] (any dtype, nonzero = set) -> fp32 0/1 tensor."""
+        mk = self._dev(np.asarray(masks, np.float32) if not isinstance(masks, torch.Tensor) else masks)
+        if mk.dim() != 3:
+            raise ValueError(f'masks must be [n,H,W], got {tuple(mk.shape)}')
+        out = torch.empty_like(mk)
+        _lib.check(self.lib.uad_erode_cross(_ptr(mk), mk.shape[0], mk.shape[1], mk.shape[2], int(iterations), _ptr(out),
+                                            self._stream()))
+        return out
+
+    def median3d(self, volume, ksize=5):
+        """5x5x5 median filter of a [D,H,W] volume, scipy 'reflect' boundary (utils/Evaluation.py:108-110)."""
+        v = self._dev(np.asarray(volume, np.float32) if not isinstance(volume, torch.Tensor) else volume)
+        if v.dim() != 3:
+            raise ValueError(f'volume must be [D,H,W], got {tuple(v.shape)}')
+        out = torch.empty_like(v)
+        _lib.check(self.lib.uad_median3d(_ptr(v), v.shape[0], v.shape[1], v.shape[2], int(ksize), _ptr(out), self._stream()))
+        return out
+
+    def scores(self, predictions, labels):
+        """One descending device sort of all voxel scores -> Scores object (AUROC, AUPRC, dice at thresholds)."""
+        return Scores(self, predictions, labels)
+
     def residual(self, x, x_rec, mask=None, pos_only=True, prior_thresh=None):
         """Residual anomaly map on device (utils/Evaluation.py:282-289).  Returns (map, l1err_per_sample)."""
         x = self._dev(x)
@@ -296,3 +320,43 @@ class Engine:
         _lib.check(self.lib.uad_residual(_ptr(x), _ptr(xr), _ptr(mk), n, hw, 1 if pos_only else 0, thr, _ptr(out),
                                          _ptr(l1), self._stream()))
         return out, l1
+
+
+class Scores:
+    """trainers/Metrics.py's threshold metrics from ONE device sort (uad_scores_*): auroc (sklearn roc_curve + auc),
+    auprc (sklearn average_precision_score), dice(pred > t, label) for arbitrary thresholds."""
+
+    def __init__(self, engine, predictions, labels):
+        self.lib = engine.lib
+        self._stream = engine._stream
+        p = engine._dev(predictions).reshape(-1)
+        if isinstance(labels, torch.Tensor):
+            y = labels.to(device=engine.device, dtype=torch.float32).reshape(-1)
+        else:
+            y = torch.from_numpy(np.ascontiguousarray(np.asarray(labels).reshape(-1) != 0, np.float32)).to(engine.device)
+        if p.numel() != y.numel():
+            raise ValueError(f'predictions ({p.numel()}) and labels ({y.numel()}) differ in size')
+        h = C.c_void_p()
+        _lib.check(self.lib.uad_scores_create(_ptr(p), _ptr(y), p.numel(), C.byref(h), self._stream()))
+        self.handle = h
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.lib.uad_scores_auc(h, C.byref(a), C.byref(b), C.byref(c)))
+        self.auroc, self.auprc, self.positives = a.value, b.value, c.value
+
+    def dice_at(self, thresholds):
+        t = np.ascontiguousarray(np.atleast_1d(thresholds), np.float64)
+        out = np.empty_like(t)
+        _lib.check(self.lib.uad_scores_dice(self.handle, t.ctypes.data_as(C.POINTER(C.c_double)), t.size,
+                                            out.ctypes.data_as(C.POINTER(C.c_double)), self._stream()))
+        return out
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.uad_scores_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

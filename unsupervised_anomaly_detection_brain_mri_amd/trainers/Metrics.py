@@ -49,23 +49,18 @@ def xfrange(start, stop, step):
         i += 1
 
 
-def compute_dice_score(predictions, labels, granularity):
-    """Metrics.py:138-162 — identical control flow; dice(pred > t, labels) is read off the sorted cumulative sums."""
-    p, ctp, gsum = _sorted_state(predictions, labels)
-    asc = p[::-1]
-
-    def dice_at(t):
-        k = p.size - np.searchsorted(asc, t, side='right')      # number of predictions > t
-        tp = ctp[k - 1] if k > 0 else 0.0
-        return (2 * tp) / (k + gsum)
-
+def _dice_sweep(dice_batch, granularity):
+    """The greedy recursive threshold sweep of Metrics.py:138-162 (identical control flow) over a provider
+    dice_batch(list of thresholds) -> dice(pred > t, labels) for each: one call per recursion level."""
     def inner(start, stop, decimal):
         _threshs, _scores = [], []
         had_recursion = False
         if decimal == granularity:
             return _threshs, _scores
-        for i, t in enumerate(xfrange(start, stop, (1.0 / (10.0 ** decimal)))):
-            score = dice_at(t)
+        ts = list(xfrange(start, stop, (1.0 / (10.0 ** decimal))))
+        vals = dice_batch(ts) if ts else []
+        for i, t in enumerate(ts):
+            score = vals[i]
             if i >= 2 and score <= _scores[i - 1] and not had_recursion:
                 st, ss = inner(_threshs[i - 2], t, decimal + 1)
                 _threshs.extend(st)
@@ -78,6 +73,26 @@ def compute_dice_score(predictions, labels, granularity):
     threshs, scores = inner(0, 1.0, 1)
     threshs, scores = list(zip(*sorted(zip(threshs, scores))))
     return scores, threshs
+
+
+def compute_dice_score(predictions, labels, granularity):
+    """Metrics.py:138-162; dice(pred > t, labels) is read off the sorted cumulative sums."""
+    p, ctp, gsum = _sorted_state(predictions, labels)
+    asc = p[::-1]
+
+    def dice_at(t):
+        k = p.size - np.searchsorted(asc, t, side='right')      # number of predictions > t
+        tp = ctp[k - 1] if k > 0 else 0.0
+        return (2 * tp) / (k + gsum)
+
+    return _dice_sweep(lambda ts: [dice_at(t) for t in ts], granularity)
+
+
+def compute_dice_curve_recursive_device(scores, granularity=5):
+    """compute_dice_curve_recursive on a device-side engine.Scores object (one sort for every threshold of the sweep)."""
+    sc, th = _dice_sweep(lambda ts: list(scores.dice_at(ts)), granularity)
+    best = int(np.argmax(sc))
+    return sc[best], th[best]
 
 
 def compute_dice_curve_recursive(predictions, labels, filename=None, plottitle=None, granularity=5):
