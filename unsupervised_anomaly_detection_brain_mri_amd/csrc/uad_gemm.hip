@@ -1057,6 +1057,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     float* s_xf = reinterpret_cast<float*>(sLo + IH * IW * LDH);
     float* s_red = s_xf + 2 * XF_LDS_CH;
     float* s_epi = s_red + WGM * 2 * BN;        // per-wave 32 x EPI_LD transpose tile of the epilogue
+    float* s_fx = s_epi + WGM * WGN * 32 * 36;  // EPI_FINAL: target / reconstruction / L1 tiles of the 2TH x 2TW output block
+    float* s_fo = s_fx + 4 * TH * TW;
+    float* s_fl = s_fo + 4 * TH * TW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -1077,6 +1080,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         for (int c = tid; c < CST; c += NT) {
             s_xf[c] = a.xf.scale[cbase + c] * a.xf.mult;
             s_xf[XF_LDS_CH + c] = a.xf.shift[cbase + c];
+        }
+
+    if (a.ep.kind == UAD_EPI_FINAL)
+        for (int idx = tid; idx < 4 * TH * TW; idx += NT) {
+            const int yl = idx / (2 * TW), xl = idx % (2 * TW);
+            s_fx[idx] = a.ep.fin_x[((size_t)n * d.HB + 2 * ty0 + yl) * d.WB + 2 * tx0 + xl];
         }
 
     const int m = wm * 32 + l31;
@@ -1214,9 +1223,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         } else if (fin) {
             // last decoder block: BN + LeakyReLU, final 1x1 conv (C -> 1, reduced over the 8 lanes that share a pixel), L1 loss
             // and, if wanted, its gradient back to this layer's pre-BN output (models/customlayers.py:35-37, trainers/VAE.py:36-40)
+            int lidx[4];
             float xin[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xin[k] = a.ep.fin_x[off[k] / Nn];
+            for (int k = 0; k < 4; ++k) {
+                const int mm = wm * 32 + erow + 8 * k;
+                lidx[k] = (2 * (mm / TW) + py) * (2 * TW) + 2 * (mm % TW) + px;
+                xin[k] = s_fx[lidx[k]];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float cc[4] = {v[k].x + e_a.x, v[k].y + e_a.y, v[k].z + e_a.z, v[k].w + e_a.w};
@@ -1235,10 +1249,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
                 dot += __shfl_xor(dot, 4);
                 const float xh = dot + f_bf;
                 const float diff = xh - xin[k];
-                const size_t pix = off[k] / Nn;
                 if ((lane & 7) == 0) {
-                    a.ep.fin_xhat[pix] = xh;
-                    if (a.ep.fin_l1) a.ep.fin_l1[pix] = fabsf(diff);
+                    s_fo[lidx[k]] = xh;                 // written to HBM as coalesced rows after the last class
+                    s_fl[lidx[k]] = fabsf(diff);
                     rec += fabsf(diff);
                 }
                 if (a.Out) *reinterpret_cast<float4*>(a.Out + off[k]) = make_float4(cc[0], cc[1], cc[2], cc[3]);
@@ -1334,6 +1347,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     if (fin) {
         // workgroup partials in the final kernel's layout: red_partial[tile][3C+1] = {dwf[C], S1[C], S2[C], dbf}, rec_partial[tile]
         __syncthreads();                        // every wave is done with its transpose tile (s_epi is reused below)
+        for (int idx = tid; idx < 4 * TH * TW; idx += NT) {
+            const int yl = idx / (2 * TW), xl = idx % (2 * TW);
+            const size_t pix = ((size_t)n * d.HB + 2 * ty0 + yl) * d.WB + 2 * tx0 + xl;
+            a.ep.fin_xhat[pix] = s_fo[idx];
+            if (a.ep.fin_l1) a.ep.fin_l1[pix] = s_fl[idx];
+        }
         float* fr = s_epi;                      // [waves][3*BN + 2]
         constexpr int FL = 3 * BN + 2;
 #pragma unroll
@@ -1644,7 +1663,7 @@ void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
 template <int TH, int TW, int CST, int WGM, int WGN>
 constexpr size_t conv5_d16_lds_bytes() {
     return (size_t)2 * (TH + 2) * (TW + 2) * (CST + 8) * 2 + (size_t)2 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4 +
-           (size_t)WGM * WGN * 32 * 36 * 4;
+           (size_t)WGM * WGN * 32 * 36 * 4 + (size_t)3 * 4 * TH * TW * 4;
 }
 template <int TH, int TW, int CST, int WGM, int WGN>
 void launch_conv5_d16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
