@@ -123,7 +123,10 @@ def test_cevae_trainer_surface_and_oracle_step(tmp_path):
     assert np.abs(run['L1'] - ls['L1']).max() <= 2e-4 * np.abs(ls['L1']).max()
     flat = model.engine.get_buffer_host(_lib.BUF_PARAMS)
     ref = ovae.flatten_params(m.spec, p64)
-    assert np.abs(flat - ref).max() <= 1e-4 * np.abs(ref).max()
+    # first Adam step = lr * g / (|g| + eps): entries whose gradient is ~0 (|g| ~ 1e-8) move by up to +-lr whatever their
+    # rounding, so the bound is 2 * lr relative to max|param| = 1 (the gradients themselves are held to 1e-4 in test_gpu_cevae.py)
+    assert np.abs(flat - ref).max() <= 2.5 * cfg.learningrate * np.abs(ref).max()
+    assert np.mean(np.abs(flat - ref)) <= 1e-6
 
     # VAL step: x_ce = batch, no dropout, anomaly still fetched (it sits in self.losses)
     v = model.step(batch, Phase.VAL, masked_batch=xce, eps=eps)

@@ -150,6 +150,27 @@ void uad_launch_conv_first_dgrad(const UadConvDesc& d, const float* g, const flo
 void uad_launch_conv_first_dgrad_restore(const UadConvDesc& d, const float* g, const float* W, const float* dxhat,
                                          float* dx, float* x_upd, float restore_lr, hipStream_t st);
 
+// ---- dense bottleneck, one workgroup per sample (uad_bott.hip) ----
+struct UadBottArgs {
+    int cenc, cmid, npos, zdim;          // encoder width, conv2d width, r*r positions, zDim
+    int n_vae;                           // samples >= n_vae are the ceVAE context branch
+    float alpha, mult, inv_batch;
+    const float* c_enc; const float* scale; const float* shift;      // last encoder block (pre-BN) + its BN
+    const float *Wb, *bb, *Wmu, *bmu, *Wsg, *bsg, *Wd, *bd, *Wr, *br; // Wsg == null: AE (Wmu = dense_z)
+    const float *WdT, *WmuT, *WsgT;      // transposed copies ([F][Z], [Z][F], [Z][F]) for the backward's coalesced GEMVs
+    const float *eps, *mask_mu, *mask_ls, *mask_mu_ce, *mask_dec;
+    // forward outputs (all kept for the backward / the parameter-gradient GEMMs)
+    float *t, *mu, *ls, *sigma, *z, *kl, *dvec, *cb;
+    // backward
+    const float* dcb;                    // [n, npos, cenc] d loss / d cb
+    float *dd, *dmu, *dls, *dflat, *g_out, *colpart;   // colpart [n][2][cenc]
+};
+size_t uad_bottleneck_lds_bytes(const UadBottArgs& a, bool bwd);
+bool uad_bottleneck_fused_ok(const UadBottArgs& a);
+void uad_launch_bottleneck_fwd(const UadBottArgs& a, int n, hipStream_t st);
+void uad_launch_bottleneck_bwd(const UadBottArgs& a, int n, hipStream_t st);
+void uad_launch_transpose(const float* in, int R, int C, float* out, hipStream_t st);   // out[c][r] = in[r][c]
+
 // ---- spatial GMVAE latent heads (uad_gmvae.hip) ----
 struct UadGmArgs {
     int cenc, W, Z, C;                  // encoder width, dim_w, dim_z, dim_c

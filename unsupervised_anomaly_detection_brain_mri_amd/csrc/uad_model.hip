@@ -82,6 +82,7 @@ struct uad_model {
     // activations
     float *t, *mu_raw, *ls_raw, *mu, *ls, *sigma, *z, *dvec, *cb, *kl;
     float *xhat_own;
+    float *wT_d, *wT_mu, *wT_sg;       // transposed copies of the dense kernels (fused bottleneck backward), refreshed with the packs
     // ceVAE: both branches run as one 2n-sample pass; staging for the concatenated inputs / outputs
     float *xcat, *mdec_cat, *l1_own;
     int nmul;                          // samples per user sample inside the handle (2 for ceVAE)
@@ -200,6 +201,26 @@ UadGmArgs gm_args(uad_model* m, const float* eps_w, const float* eps_z, float in
     for (int k = 0; k < 15; ++k) *slots[k] = P(m, m->gm_off[k]);
     a.eps_w = eps_w; a.eps_z = eps_z;
     a.h_out = m->gm_h; a.loc_loss = m->gm_loc_loss;
+    return a;
+}
+
+// launch arguments of the per-sample fused bottleneck (AE / VAE / ceVAE)
+UadBottArgs bott_args(uad_model* m, const uad_io_t& io, const float* mask_dec, int nu) {
+    UadBottArgs a;
+    memset(&a, 0, sizeof a);
+    const ConvLayer& EL = m->enc.back();
+    const bool vae = m->sgw >= 0;
+    a.cenc = m->cenc; a.cmid = m->cmid; a.npos = m->cfg.inter_res * m->cfg.inter_res; a.zdim = m->cfg.zdim;
+    a.n_vae = nu; a.alpha = kLrelu; a.mult = 1.0f / sqrtf(1.0f + kBnEps); a.inv_batch = 1.0f / (float)nu;
+    a.c_enc = EL.c; a.scale = P(m, EL.gamma); a.shift = P(m, EL.beta);
+    a.Wb = P(m, m->bw); a.bb = P(m, m->bb); a.Wmu = P(m, m->muw); a.bmu = P(m, m->mub);
+    a.Wsg = vae ? P(m, m->sgw) : nullptr; a.bsg = vae ? P(m, m->sgb) : nullptr;
+    a.Wd = P(m, m->dw); a.bd = P(m, m->db); a.Wr = P(m, m->rw); a.br = P(m, m->rb);
+    a.WdT = m->wT_d; a.WmuT = m->wT_mu; a.WsgT = vae ? m->wT_sg : nullptr;
+    a.eps = io.eps; a.mask_mu = io.mask_mu; a.mask_ls = io.mask_sigma;
+    a.mask_mu_ce = m->cfg.arch == UAD_ARCH_CEVAE ? io.mask_mu_ce : nullptr;
+    a.mask_dec = vae ? mask_dec : nullptr;        // AE: the dec_dense dropout is never active (autoencoder.py:30)
+    a.t = m->t; a.mu = m->mu; a.ls = m->ls; a.sigma = m->sigma; a.z = m->z; a.kl = m->kl; a.dvec = m->dvec; a.cb = m->cb;
     return a;
 }
 
@@ -361,6 +382,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->t, nflat); ALLOC(m->mu_raw, nz); ALLOC(m->ls_raw, nz); ALLOC(m->mu, nz); ALLOC(m->ls, nz);
     ALLOC(m->sigma, nz); ALLOC(m->z, nz); ALLOC(m->dvec, nflat); ALLOC(m->cb, ncb); ALLOC(m->kl, NB);
     ALLOC(m->xhat_own, NB * H * Wd * cfg->channels);
+    m->wT_d = m->wT_mu = m->wT_sg = nullptr;
+    if (!gm) { const size_t fz = (size_t)m->flat * cfg->zdim; ALLOC(m->wT_d, fz); ALLOC(m->wT_mu, fz); ALLOC(m->wT_sg, fz); }
     m->xcat = m->mdec_cat = m->l1_own = nullptr;
     if (cevae) { ALLOC(m->xcat, NB * H * Wd * cfg->channels); ALLOC(m->mdec_cat, nflat); ALLOC(m->l1_own, NB * H * Wd * cfg->channels); }
     m->gm_h = m->gm_loc_loss = m->gm_dheads = m->gm_da7 = m->gm_mid = m->gm_dM = m->gm_dLq = m->gm_ws = m->gm_partial = m->gm_dxhat = nullptr;
@@ -530,6 +553,12 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
             else
                 uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
         }
+        if (!gm) {
+            // transposed copies of the dense kernels for the fused bottleneck backward
+            uad_launch_transpose(P(m, m->dw), m->cfg.zdim, m->flat, m->wT_d, st);
+            uad_launch_transpose(P(m, m->muw), m->flat, m->cfg.zdim, m->wT_mu, st);
+            if (m->sgw >= 0) uad_launch_transpose(P(m, m->sgw), m->flat, m->cfg.zdim, m->wT_sg, st);
+        }
         m->packed_valid = true;
     }
     // encoder
@@ -553,6 +582,9 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         UadGmArgs ga = gm_args(m, io->eps_w, io->eps_z, 1.0f / (float)nu);
         ga.w_mu = io->w_mu; ga.w_ls = io->w_log_sigma; ga.z_mu = io->z_mu; ga.z_ls = io->z_log_sigma; ga.pc = io->pc;
         uad_launch_gm_heads_fwd(ga, n * ir * ir, st);
+    } else if (uad_bottleneck_fused_ok(bott_args(m, *io, mask_dec, nu))) {
+        PROF("bott.fwd");
+        uad_launch_bottleneck_fwd(bott_args(m, *io, mask_dec, nu), n, st);
     } else {
     PROF("bott.fwd");
     uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cenc, m->cmid), EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu),
@@ -727,7 +759,9 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
     return UAD_OK;
 }
 
-static int backward_bottleneck(uad_model* m, hipStream_t st) {
+// join_now: the caller asked for this gradient segment on its own (DP all-reduce), so SIDE must be joined before returning;
+// inside uad_backward(UAD_SEG_ALL) the join is left to the encoder segment's end.
+static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
     const int n = m->last_n, nu = m->last_nuser;
     const bool vae = m->cfg.arch != UAD_ARCH_AE;
     const bool cevae = m->cfg.arch == UAD_ARCH_CEVAE;
@@ -749,6 +783,43 @@ static int backward_bottleneck(uad_model* m, hipStream_t st) {
     const UadConvDesc d_in = dense_desc(n, m->flat, zd);
     const UadConvDesc d_b = conv1x1_desc(n, ir, ir, m->cenc, m->cmid);
     const ConvLayer& EL = m->enc.back();
+    {
+        UadBottArgs ba = bott_args(m, io, m->mask_dec_eff, nu);
+        if (uad_bottleneck_fused_ok(ba)) {
+            // MAIN: one workgroup per sample does the whole data-gradient chain.  SIDE: the parameter-gradient GEMMs -- conv2d_1's
+            // (it needs only dcb / dvec) before that kernel, the others from the vectors it leaves behind.
+            hipEvent_t ev_r = nullptr;
+            edge(m, st, sd);
+            if (pg) {
+                PROF_ON("bott.wgrad", sd);
+                uad_launch_conv_w(d_r, m->dvec, no_xform(), dcb, no_xform(), Gr(m, m->rw), wp, sd);
+                ev_r = next_event(m);
+                (void)hipEventRecord(ev_r, sd);
+            }
+            ba.dcb = dcb; ba.dd = dd; ba.dmu = vae ? dmu : dz; ba.dls = dls; ba.dflat = dflat; ba.g_out = m->G1; ba.colpart = cp;
+            { PROF("bott.bwd"); uad_launch_bottleneck_bwd(ba, n, st); }
+            edge(m, st, sd);
+            if (pg) {
+                PROF_ON("bott.wgrad", sd);
+                uad_launch_conv_w(d_dec, m->z, no_xform(), dd, no_xform(), Gr(m, m->dw), wp, sd);
+                uad_launch_colsum(dd, n, m->flat, Gr(m, m->db), m->colscratch, sd);
+                uad_launch_conv_w(d_in, m->t, no_xform(), vae ? dmu : dz, no_xform(), Gr(m, m->muw), wp, sd);
+                uad_launch_colsum(vae ? dmu : dz, n, zd, Gr(m, m->mub), m->colscratch, sd);
+                if (vae) {
+                    uad_launch_conv_w(d_in, m->t, no_xform(), dls, no_xform(), Gr(m, m->sgw), wp, sd);
+                    uad_launch_colsum(dls, n, zd, Gr(m, m->sgb), m->colscratch, sd);
+                }
+                uad_launch_conv_w(d_b, EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu), dflat, no_xform(), Gr(m, m->bw), wp, sd);
+                uad_launch_colsum(dflat, n * ir * ir, m->cmid, Gr(m, m->bb), m->colscratch, sd);
+                uad_launch_bn_grad_finalize(cp, n, m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma), Gr(m, EL.beta), Gr(m, EL.b), sd);
+            }
+            float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;
+            // dcb (now G1) becomes the encoder chain's scratch: SIDE must be done reading it (only conv2d_1's gradient does)
+            if (ev_r) (void)hipStreamWaitEvent(st, ev_r, 0);
+            if (join_now) edge(m, sd, st);
+            return UAD_OK;
+        }
+    }
     edge(m, st, sd);
     // SIDE: conv2d_1 weight gradient (its bias gradient came from the decoder's BN finalize)
     if (pg) { PROF_ON("bott.wgrad", sd); uad_launch_conv_w(d_r, m->dvec, no_xform(), dcb, no_xform(), Gr(m, m->rw), wp, sd); }
@@ -889,7 +960,7 @@ int uad_backward(uad_model_t* m, int segment, void* stream) {
     int rc = UAD_OK;
     if (segment == UAD_SEG_ALL || segment == UAD_SEG_DECODER) rc = backward_decoder(m, st);
     if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_BOTTLENECK))
-        rc = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL ? backward_gm_heads(m, st) : backward_bottleneck(m, st);
+        rc = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL ? backward_gm_heads(m, st) : backward_bottleneck(m, st, segment == UAD_SEG_BOTTLENECK);
     if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_ENCODER)) {
         rc = backward_encoder(m, st);
         m->have_fwd = false;
