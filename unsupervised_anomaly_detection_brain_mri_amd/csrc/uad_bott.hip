@@ -48,12 +48,12 @@ __device__ __forceinline__ void gemv_cols_partial(const float* __restrict__ W, c
     const int kper = (K + G - 1) / G, k0 = kg * kper, k1 = min(k0 + kper, K);
     float acc = 0.f;
     int k = k0;
-    for (; k + 16 <= k1; k += 16) {
-        float w[16];
+    for (; k + 32 <= k1; k += 32) {
+        float w[32];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = W[(size_t)(k + u) * NO + o];
+        for (int u = 0; u < 32; ++u) w[u] = W[(size_t)(k + u) * NO + o];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = fmaf(x_lds[k + u], w[u], acc);
+        for (int u = 0; u < 32; ++u) acc = fmaf(x_lds[k + u], w[u], acc);
     }
     for (; k < k1; ++k) acc = fmaf(x_lds[k], W[(size_t)k * NO + o], acc);
     s_part[tid] = acc;
@@ -97,12 +97,12 @@ __global__ void __launch_bounds__(NT) bottleneck_fwd_kernel(const UadBottArgs a)
         const int kper = (F + G - 1) / G, k0 = kg * kper, k1 = min(k0 + kper, F);
         float acc = 0.f;
         int k = k0;
-        for (; k + 16 <= k1; k += 16) {
-            float w[16];
+        for (; k + 32 <= k1; k += 32) {
+            float w[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = W[(size_t)(k + u) * Z + o];
+            for (int u = 0; u < 32; ++u) w[u] = W[(size_t)(k + u) * Z + o];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc = fmaf(s_t[k + u], w[u], acc);
+            for (int u = 0; u < 32; ++u) acc = fmaf(s_t[k + u], w[u], acc);
         }
         for (; k < k1; ++k) acc = fmaf(s_t[k], W[(size_t)k * Z + o], acc);
         s_part[tid] = acc;
@@ -281,8 +281,12 @@ __global__ void __launch_bounds__(NT) bottleneck_bwd_kernel(const UadBottArgs a)
 }
 
 // out[c][r] = in[r][c]  (32x32 LDS tiles): transposed copies of the dense kernels for the backward's coalesced GEMVs
-__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ in, int R, int Cc, float* __restrict__ out) {
+struct TransposeJobs { const float* in[3]; float* out[3]; int R[3], C[3]; };
+__global__ void __launch_bounds__(256) transpose_kernel(const TransposeJobs jb) {
     __shared__ float tile[32][33];
+    const float* __restrict__ in = jb.in[blockIdx.z];
+    float* __restrict__ out = jb.out[blockIdx.z];
+    const int R = jb.R[blockIdx.z], Cc = jb.C[blockIdx.z];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int y = ty; y < 32; y += 8)
@@ -319,6 +323,14 @@ void uad_launch_bottleneck_bwd(const UadBottArgs& a, int n, hipStream_t st) {
     bott_attrs();
     hipLaunchKernelGGL(bottleneck_bwd_kernel, dim3(n), dim3(NT), uad_bottleneck_lds_bytes(a, true), st, a);
 }
-void uad_launch_transpose(const float* in, int R, int C, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, in, R, C, out);
+void uad_launch_transpose(const float* const* in, const int* R, const int* C, float* const* out, int njobs, hipStream_t st) {
+    TransposeJobs jb;
+    int gx = 1, gy = 1;
+    for (int i = 0; i < 3; ++i) {
+        const int k = i < njobs ? i : 0;
+        jb.in[i] = in[k]; jb.out[i] = out[k]; jb.R[i] = R[k]; jb.C[i] = C[k];
+        if ((C[k] + 31) / 32 > gx) gx = (C[k] + 31) / 32;
+        if ((R[k] + 31) / 32 > gy) gy = (R[k] + 31) / 32;
+    }
+    hipLaunchKernelGGL(transpose_kernel, dim3(gx, gy, njobs), dim3(256), 0, st, jb);
 }

@@ -169,7 +169,8 @@ size_t uad_bottleneck_lds_bytes(const UadBottArgs& a, bool bwd);
 bool uad_bottleneck_fused_ok(const UadBottArgs& a);
 void uad_launch_bottleneck_fwd(const UadBottArgs& a, int n, hipStream_t st);
 void uad_launch_bottleneck_bwd(const UadBottArgs& a, int n, hipStream_t st);
-void uad_launch_transpose(const float* in, int R, int C, float* out, hipStream_t st);   // out[c][r] = in[r][c]
+// out_i[c][r] = in_i[r][c] for up to 3 matrices in one launch
+void uad_launch_transpose(const float* const* in, const int* R, const int* C, float* const* out, int njobs, hipStream_t st);
 
 // ---- spatial GMVAE latent heads (uad_gmvae.hip) ----
 struct UadGmArgs {

@@ -555,9 +555,10 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         }
         if (!gm) {
             // transposed copies of the dense kernels for the fused bottleneck backward
-            uad_launch_transpose(P(m, m->dw), m->cfg.zdim, m->flat, m->wT_d, st);
-            uad_launch_transpose(P(m, m->muw), m->flat, m->cfg.zdim, m->wT_mu, st);
-            if (m->sgw >= 0) uad_launch_transpose(P(m, m->sgw), m->flat, m->cfg.zdim, m->wT_sg, st);
+            const float* tin[3] = {P(m, m->dw), P(m, m->muw), m->sgw >= 0 ? P(m, m->sgw) : nullptr};
+            float* tout[3] = {m->wT_d, m->wT_mu, m->wT_sg};
+            const int tr[3] = {m->cfg.zdim, m->flat, m->flat}, tc[3] = {m->flat, m->cfg.zdim, m->cfg.zdim};
+            uad_launch_transpose(tin, tr, tc, tout, m->sgw >= 0 ? 3 : 2, st);
         }
         m->packed_valid = true;
     }
