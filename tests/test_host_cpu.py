@@ -113,3 +113,25 @@ def test_retrieve_masked_batch_matches_reference_golden():
         b = retrieve_masked_batch(x.astype(np.float32), bm, random.Random(seed))
         assert np.array_equal(a == 0, holes), i
         assert np.array_equal(b == 0, holes), i
+
+
+def test_evaluation_host_helpers_against_golden_and_oracle():
+    """Host-side helpers of utils/Evaluation.py: squash_intensities / apply_brainmask against the reference-generated golden,
+    the connected-component filter against the oracle restatement, lesion-wise detection counts on a constructed case."""
+    from oracle import scoring as osc
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import Evaluation as E
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'scoring_golden.npz'))
+    np.testing.assert_allclose(E.squash_intensities(g['diffs'][3]), g['squashed'], rtol=1e-12)
+    for s in (0, 5, 11):
+        assert np.array_equal(E.apply_brainmask(np.ones((64, 64)), g['bm'][s], erode=True).astype(np.uint8), g['eroded'][s])
+    rng = np.random.default_rng(0)
+    v = (rng.random((12, 32, 32)) < 0.04) * rng.random((12, 32, 32))
+    assert np.array_equal(E.filter_3d_connected_components(v.copy()), osc.filter_3d_connected_components(v.copy()))
+    v4 = v.reshape(3, 4, 32, 32)
+    assert E.filter_3d_connected_components(v4.copy()).shape == v4.shape
+    gt = np.zeros((25, 32, 32), int); gt[3:6, 5:9, 5:9] = 1; gt[22:24, 20:23, 20:23] = 1
+    pr = np.zeros_like(gt); pr[4:7, 6:10, 6:10] = 1; pr[10:13, 1:4, 1:4] = 1; pr[0, 0, 0] = 1
+    assert E.compute_detection_rate(pr, gt) == (1, 1, 1)       # hit lesion, 27-voxel false blob (the 1-voxel one is ignored), missed lesion
+    x = np.full((8, 8), 0.8); xr = np.full((8, 8), 0.5); x[0, 0] = 0.3
+    d = E.postprocess_slice(x, xr)
+    assert d[0, 0] == 0 and np.allclose(d[1:, 1:], 0.3)

@@ -26,6 +26,88 @@ def apply_3d_median_filter(volume, kernelsize=5):
     return scipy.ndimage.median_filter(volume, (kernelsize, kernelsize, kernelsize))
 
 
+def apply_brainmask(x, brainmask, erode=True):
+    """utils/Evaluation.py:84-89 (host form): x * (12x cross-eroded) brain mask."""
+    bm = erode_brainmask(brainmask) if erode else np.squeeze(brainmask)
+    return np.multiply(bm, np.squeeze(x))
+
+
+def squash_intensities(img):
+    """utils/Evaluation.py:70-74: logistic squash of reconstruction errors, 2 * (sigmoid(100 x) - 0.5)."""
+    return 2.0 * (1.0 / (1.0 + np.exp(-100.0 * np.asarray(img))) - 0.5)
+
+
+def postprocess_slice(x, x_rec, slice_skullmap=None):
+    """utils/Evaluation.py:92-105: positive residual inside the eroded skull map, zeroed where x < 0.6 (fixed prior)."""
+    x, x_rec = np.squeeze(x), np.squeeze(x_rec)
+    mask = np.ones(x.shape) if slice_skullmap is None else erode_brainmask(slice_skullmap)
+    d = np.multiply(mask, x - x_rec)
+    d[d < 0] = 0
+    d[x < 0.6] = 0
+    return d
+
+
+def filter_3d_connected_components(volume, max_voxels=7):
+    """utils/Evaluation.py:113-127: zero every 26-connected component of at most 7 voxels (4-D input is folded to 3-D like the
+    reference).  scikit-image is not available here: scipy.ndimage.label with the full 3x3x3 structure is the same labelling."""
+    volume = np.asarray(volume)
+    shape = volume.shape
+    v3 = volume.reshape(shape[0] * shape[1], shape[2], shape[3]) if volume.ndim > 3 else volume
+    lab, n = scipy.ndimage.label(v3 != 0, structure=np.ones((3, 3, 3), bool))
+    if n:
+        sizes = np.bincount(lab.ravel(), minlength=n + 1)
+        small = sizes <= max_voxels
+        small[0] = False
+        v3 = np.where(small[lab], 0, v3)
+    return v3.reshape(shape)
+
+
+def postprocess_volume(volume):
+    """utils/Evaluation.py:175-180: 5x5x5 median, then the connected-component filter."""
+    return filter_3d_connected_components(apply_3d_median_filter(volume))
+
+
+def compute_detection_rate(predicted_volume, groundtruth_volume):
+    """utils/Evaluation.py:130-172: lesion-wise (TP, FP, FN) counted on 26-connected components in chunks of 20 slices: a TP is a
+    component of prediction AND ground truth; predicted components under 8 voxels are ignored; predicted / true components that
+    contain no TP are FPs / FNs."""
+    full = np.ones((3, 3, 3), bool)
+    pred = np.asarray(predicted_volume) != 0
+    gt = np.asarray(groundtruth_volume) != 0
+    tps = fps = fns = 0
+    for s0 in range(0, gt.shape[0], 20):
+        p, g = pred[s0:s0 + 20], gt[s0:s0 + 20]
+        li, ni = scipy.ndimage.label(p & g, structure=full)
+        lp, npred = scipy.ndimage.label(p, structure=full)
+        lg, ng = scipy.ndimage.label(g, structure=full)
+        psz = np.bincount(lp.ravel(), minlength=npred + 1)
+        keep_p = psz >= 8
+        keep_p[0] = False
+        hit_p = np.zeros(npred + 1, bool)
+        hit_g = np.zeros(ng + 1, bool)
+        if ni:
+            first = scipy.ndimage.find_objects(li)
+            for k, sl in enumerate(first, start=1):
+                idx = np.argwhere(li[sl] == k)[0]                 # the reference takes the component's first coordinate
+                z, y, x = (sl[0].start + idx[0], sl[1].start + idx[1], sl[2].start + idx[2])
+                hit_p[lp[z, y, x]] = True
+                hit_g[lg[z, y, x]] = True
+        tps += ni
+        fps += int(np.count_nonzero(keep_p & ~hit_p))
+        fns += int(np.count_nonzero(~hit_g[1:]))
+    return tps, fps, fns
+
+
+def determine_threshold_on_labeled_patients(volumes, labels, brainmasks, model, options, eps=0.0):
+    """utils/Evaluation.py:529-570: the Dice-optimal threshold of the residual maps of labelled VALIDATION patients
+    (granularity-10 sweep), on the device path.  Returns (bestDiceScore, bestThreshold)."""
+    diffs = [evaluate_volume(model, v, b, options, eps, device_out=True)[0] for v, b in zip(volumes, brainmasks)]
+    sc = model.engine.scores(torch.cat([d.reshape(-1) for d in diffs]), np.concatenate([np.asarray(l).flatten() for l in labels]))
+    best = Metrics.compute_dice_curve_recursive_device(sc, granularity=10)
+    sc.close()
+    return best
+
+
 def evaluate_volume(model, volume, brainmasks, options, eps=0.0, device_out=False):
     """volume [S,H,W] in [0,1]; brainmasks [S,H,W].  Returns the post-processed residual sub-volume [S,H,W] (numpy, or the
     device tensor with device_out=True) and per-slice l1 reconstruction errors (utils/Evaluation.py:223-312)."""
