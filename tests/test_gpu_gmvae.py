@@ -77,7 +77,7 @@ def test_gmvae_forward_backward_parity(h, inter, dim_c, dim_z, dim_w, n, c_lambd
     eng.close()
 
 
-@pytest.mark.parametrize('h,dim_c,dim_z,n', [(64, 9, 1, 2), (128, 6, 2, 1)])
+@pytest.mark.parametrize('h,dim_c,dim_z,n', [(64, 9, 1, 2), (128, 6, 2, 1), (256, 9, 1, 4)])   # the last one takes the bench's kernel path
 def test_gmvae_restore_step_matches_oracle(h, dim_c, dim_z, n):
     """`grads` of trainers/GMVAE_spatial.py:91-92 and the in-place update of :189-190, three chained steps."""
     m, p32, x, e_w, e_z = _setup(h, 8, dim_c, dim_z, 1, n, seed=5)
@@ -95,12 +95,21 @@ def test_gmvae_restore_step_matches_oracle(h, dim_c, dim_z, n):
         ggot = eng.restore_step(xr, e_w, e_z, tv_lambda=tv, restore_lr=lr, want_grads=True)
         torch.cuda.synchronize()
         if step == 0:
-            # identical inputs: the TV sign pattern is identical too
-            assert_close(ggot.cpu().numpy(), gref, tol=3e-4, name='grads')
+            # identical inputs.  The TV term contributes +-tv_lambda per neighbour through sign(r[p] - r[q]); where two
+            # neighbouring residuals agree to ~1e-6 that sign is decided by rounding, so a few pixels may differ by multiples of
+            # tv_lambda -- everything else must agree to 3e-4 of the gradient's max
+            gg = ggot.cpu().numpy()
+            bad = np.abs(gg - gref) > 3e-4 * np.abs(gref).max()
+            assert bad.mean() <= 2e-3, f'{bad.mean():.2e} of the pixels differ'
+            if bad.any():
+                q = np.abs(gg - gref)[bad] / tv
+                assert np.abs(q - np.round(q)).max() <= 1e-2, 'differences are not TV sign flips'
         ref = ref - lr * gref
     # after chained steps single pixels may flip a TV sign (|step| = tv_lambda); compare the restored images
-    assert np.abs(xr.cpu().numpy() - ref).max() <= 2e-2 * lr * 10 + 1e-4
-    assert np.mean(np.abs(xr.cpu().numpy() - ref)) <= 1e-5
+    # (a flipped sign moves a pixel by lr * 2 * tv per step and can flip its neighbours' next step: bound the worst pixel by a few
+    # such events, and require the images to agree on average)
+    assert np.abs(xr.cpu().numpy() - ref).max() <= 8 * lr * tv + 1e-4
+    assert np.mean(np.abs(xr.cpu().numpy() - ref)) <= 2e-5
     assert np.array_equal(eng.get_buffer_host(_lib.BUF_GRADS), sentinel)     # no parameter gradient was written
     eng.close()
 

@@ -1412,7 +1412,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 // too large to hold every channel at once, so channels are walked in CK-wide chunks (restaged per chunk, accumulators live
 // across chunks); the weight ring runs through the chunk boundary.
 // ------------------------------------------------------------------------------------------------
-template <int TH, int TW, int CK, int WGM, int WGN>
+template <int TH, int TW, int CK, int WGM, int WGN, bool FB>
 __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_per_eu(2))) conv5_f16_kernel(const ConvGemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int IH = 2 * TH + 3, IW = 2 * TW + 3;
@@ -1424,7 +1424,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     unsigned short* sHi = reinterpret_cast<unsigned short*>(dsm);
     unsigned short* sLo = sHi + IH * IW * LDH;
     float* s_xf = reinterpret_cast<float*>(sLo + IH * IW * LDH);
-    float* s_red = s_xf + 2 * XF_LDS_CH;
+    float* s_red = s_xf + 3 * XF_LDS_CH;      // s_xf: scale | shift | final-conv kernel (fb mode)
     float* s_epi = reinterpret_cast<float*>(dsm);      // aliases the activation tile (dead after the last chunk)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1441,10 +1441,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     const int AH = d.HB, AW = d.WB;
 
     const bool xf = a.xf.scale != nullptr;
+    constexpr bool fb = FB;                  // final-backward on load (UadXform::fb_*): its own instantiation, the extra
+                                             // prefetch registers would otherwise spill the 64-column variant
     if (xf)
         for (int c = tid; c < CA; c += NT) {
             s_xf[c] = a.xf.scale[c] * a.xf.mult;
             s_xf[XF_LDS_CH + c] = a.xf.shift[c];
+            if (fb) s_xf[2 * XF_LDS_CH + c] = a.xf.fb_wf[c];
         }
 
     const int m = wm * 32 + l31;
@@ -1493,6 +1496,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     constexpr int TOT = IH * IW * CQ;
     constexpr int PER = (TOT + NT - 1) / NT;
     float4 pf[PER];
+    float pg[FB ? PER : 1];                  // fb mode: the pixel's d objective / d x_hat, fetched with the tile
     auto issue_stage = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -1503,6 +1507,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             const bool ok = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
             const int gp = ok ? (gy * AW + gx) : 0;
             pf[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok ? cq * 4 : 0));
+            if (fb) pg[u] = a.xf.fb_dxhat[(size_t)n * AH * AW + gp];
         }
     };
     auto convert_stage = [&](int c0) {
@@ -1515,7 +1520,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             const int gy = gy0 + iy, gx = gx0 + ix;
             const bool ok = (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
             float4 t = pf[u];
-            if (xf) {
+            if (fb) {
+                // final-backward on load: t = dxhat[pixel] * wf * lrelu'(bn(c)) * scale  (see UadXform::fb_*)
+                const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
+                const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
+                const float4 wf = *reinterpret_cast<const float4*>(s_xf + 2 * XF_LDS_CH + c0 + cq * 4);
+                const float g = ok ? pg[u] : 0.f;
+                t.x = g * wf.x * (fmaf(t.x, sc.x, sh.x) > 0.f ? sc.x : sc.x * a.xf.alpha);
+                t.y = g * wf.y * (fmaf(t.y, sc.y, sh.y) > 0.f ? sc.y : sc.y * a.xf.alpha);
+                t.z = g * wf.z * (fmaf(t.z, sc.z, sh.z) > 0.f ? sc.z : sc.z * a.xf.alpha);
+                t.w = g * wf.w * (fmaf(t.w, sc.w, sh.w) > 0.f ? sc.w : sc.w * a.xf.alpha);
+            } else if (xf) {
                 const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
                 const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
                 t = xform4(t, sc, sh, a.xf.alpha);
@@ -1646,18 +1661,23 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 
 template <int TH, int TW, int CK, int WGM, int WGN>
 constexpr size_t conv5_f16_lds_bytes() {
-    return (size_t)2 * (2 * TH + 3) * (2 * TW + 3) * (CK + 8) * 2 + (size_t)2 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
+    return (size_t)2 * (2 * TH + 3) * (2 * TW + 3) * (CK + 8) * 2 + (size_t)3 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
 }
-template <int TH, int TW, int CK, int WGM, int WGN>
-void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
+template <int TH, int TW, int CK, int WGM, int WGN, bool FB>
+void launch_conv5_f16_v(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = conv5_f16_lds_bytes<TH, TW, CK, WGM, WGN>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_f16_kernel<TH, TW, CK, WGM, WGN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv5_f16_kernel<TH, TW, CK, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, a);
+    hipLaunchKernelGGL((conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB>), grid, dim3(64 * WGM * WGN), lds, st, a);
+}
+template <int TH, int TW, int CK, int WGM, int WGN>
+void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
+    if (a.xf.fb_dxhat) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, true>(a, grid, st);
+    else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, false>(a, grid, st);
 }
 
 template <int TH, int TW, int CST, int WGM, int WGN>
@@ -2431,6 +2451,11 @@ bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
 }
 int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, true, have_pack, ws_floats).tiles; }
 int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, false, have_pack, ws_floats).tiles; }
+bool uad_conv_f_supports_final_bwd(const UadConvDesc& d, bool have_pack16, size_t ws_floats) {
+    if (!have_pack16 || getenv("UAD_NO_F16") || getenv("UAD_NO_FB_ON_LOAD")) return false;
+    const GemmPlan p = plan_gemm(d, true, true, ws_floats);
+    return p.path == PATH_SPATIAL;
+}
 bool uad_conv_d_can_fuse_final(const UadConvDesc& d, bool have_pack16, size_t ws_floats) {
     if (!have_pack16 || getenv("UAD_NO_FUSED_FINAL")) return false;
     const GemmPlan p = plan_gemm(d, false, true, ws_floats);

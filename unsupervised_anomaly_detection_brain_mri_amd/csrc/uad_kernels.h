@@ -26,6 +26,11 @@ struct UadXform {
     const float* shift;   // beta
     float alpha;
     float mult;           // scale multiplier: 1/sqrt(1+eps) of the frozen-stats BN
+    // F-kind bf16x3 kernel only ("final-backward on load", GMVAE restoration): the staged value becomes
+    //   d loss / d c = dxhat[pixel] * wf[ch] * lrelu'(scale*c + shift) * scale     instead of lrelu(scale*c + shift),
+    // i.e. the big operand is the last block's PRE-BN output and the loss gradient is never materialised.
+    const float* fb_dxhat = nullptr;   // [N, HB, WB]
+    const float* fb_wf = nullptr;      // [CB]
 };
 
 enum { UAD_EPI_BIAS = 0, UAD_EPI_BWD_ACT = 1, UAD_EPI_FINAL = 2 };
@@ -84,6 +89,8 @@ int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floa
 // true when uad_launch_conv_d(d, ..., UAD_EPI_FINAL) is available: bf16x3 planes given, class-sequential spatial kernel, all
 // output channels (32) in one workgroup, no split
 bool uad_conv_d_can_fuse_final(const UadConvDesc& d, bool have_pack16, size_t ws_floats);
+// true when uad_launch_conv_f would run the bf16x3 spatial kernel that understands UadXform::fb_* (see there)
+bool uad_conv_f_supports_final_bwd(const UadConvDesc& d, bool have_pack16, size_t ws_floats);
 int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0);
 // workspace floats the split-K path would like for this op (0 = it would not split)
 size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack);

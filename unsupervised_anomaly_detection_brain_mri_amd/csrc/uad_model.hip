@@ -92,6 +92,7 @@ struct uad_model {
     float *gm_h, *gm_loc_loss, *gm_dheads, *gm_da7, *gm_mid, *gm_dM, *gm_dLq, *gm_ws, *gm_partial, *gm_dxhat;
     const float* dec_in0;              // input of the first decoder ConvT: cb (AE family) or gm_h (GMVAE)
     bool restore;                      // last forward was a restoration pass (TV term in the objective)
+    bool fb_on_load;                   // ... whose d loss / d c of the last block is formed inside dec.back()'s data-gradient kernel
     float restore_tv, restore_lr;
     float* restore_x;                  // x_restored (updated in place by the backward) or null
     float* restore_grads;              // optional gradient output
@@ -154,6 +155,12 @@ UadXform bn_xform(uad_model* m, long long gamma, long long beta, float alpha) {
     return x;
 }
 UadXform no_xform() { UadXform x; x.scale = nullptr; x.shift = nullptr; x.alpha = 1.f; x.mult = 1.f; return x; }
+// restoration: d loss / d c of the last block is formed while the data-gradient kernel stages its input (no final<BWD> pass)
+bool restore_fb_on_load(uad_model* m, int n) {
+    if (!m->restore || m->math != UAD_MATH_BF16X3) return false;
+    UadConvDesc d = m->dec.back().d; d.N = n;
+    return uad_conv_f_supports_final_bwd(d, true, m->ws.floats);
+}
 
 UadEpilogue epi_bias(const float* bias, const float* mul = nullptr, const float* add = nullptr) {
     UadEpilogue e;
@@ -263,7 +270,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     const bool cevae = cfg->arch == UAD_ARCH_CEVAE;
     m->nmul = cevae ? 2 : 1;
     m->data_only = false;
-    m->restore = false; m->restore_x = nullptr; m->restore_grads = nullptr; m->restore_tv = 0.f; m->restore_lr = 0.f;
+    m->restore = false; m->fb_on_load = false; m->restore_x = nullptr; m->restore_grads = nullptr; m->restore_tv = 0.f; m->restore_lr = 0.f;
     m->gm_total = 0;
     char nm[128];
     // the GMVAE graph opens no variable scope: plain layer names, BN layers numbered across encoder and decoder
@@ -656,7 +663,8 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         if (!fused_final) uad_launch_final_fwd_bwd(fa, st);
         uad_launch_tv_dxhat(xin, fa.x_hat, n, fa.H, fa.W, fa.inv_batch, m->restore_tv, m->gm_dxhat, st);
         fa.d_c = dc; fa.dxhat_in = m->gm_dxhat;
-        uad_launch_final_fwd_bwd(fa, st);
+        m->fb_on_load = fused_final && restore_fb_on_load(m, n);
+        if (!m->fb_on_load) uad_launch_final_fwd_bwd(fa, st);   // else: folded into dec.back()'s data gradient
     } else {
         PROF(want_backward ? "final.fwd+bwd" : "final.fwd"); uad_launch_final_fwd_bwd(fa, st);
     }
@@ -750,7 +758,10 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, sd, next_event(m)); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
         { PROF(kDecD[i & 7]); UadEpilogue e = epi_bwd(m, in, ig, ib, ia); e.colpart = cp;
-          uad_launch_conv_f(d, g, no_xform(), P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
+          const bool fb = m->restore && m->fb_on_load && i + 1 == (int)m->dec.size();
+          UadXform gx = no_xform();
+          if (fb) { gx = bn_xform(m, DL.gamma, DL.beta, kLrelu); gx.fb_dxhat = m->gm_dxhat; gx.fb_wf = P(m, m->fw); }
+          uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
         edge(m, st, sd);   // column partials of this layer are ready
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd); }
         float* tsw = g; g = gn; gn = tsw;
@@ -1000,7 +1011,7 @@ int uad_restore_step(uad_model_t* m, float* x_restored, const float* eps_w, cons
     m->restore_x = x_restored; m->restore_grads = grads_out;
     int rc = uad_forward(m, &io, n, 2, stream);
     if (rc == UAD_OK) rc = uad_backward(m, UAD_SEG_ALL, stream);
-    m->restore = false; m->restore_x = nullptr; m->restore_grads = nullptr;
+    m->restore = false; m->fb_on_load = false; m->restore_x = nullptr; m->restore_grads = nullptr;
     return rc;
 }
 
