@@ -1,0 +1,106 @@
+"""CPU: numpy f-AnoGAN oracle (hand-written backward, incl. the second-order pass of the WGAN-GP penalty through
+LayerNorm-HW) vs an autograd graph written like the reference's (fp64 round-off agreement)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fanogan as ofa
+from oracle import vae as ovae
+from tests import torch_ref
+
+
+def _setup(h, inter, zdim, n, seed=0, dtype=np.float64):
+    m = ofa.FAnoGAN(h, inter, zdim, scale=10.0, kappa=1.3)
+    p = ovae.init_params(m.spec, seed=11 + seed, dtype=dtype, perturb=True)
+    rng = np.random.default_rng(70 + seed)
+    x = ovae.synthetic_slices(n, h, h, seed=seed, dtype=dtype)
+    z = rng.standard_normal((n, zdim)).astype(dtype)
+    alpha = rng.uniform(0, 1, (n, 1)).astype(dtype)
+    return m, p, x, z, alpha, rng
+
+
+def test_ln_second_order_vs_autograd():
+    rng = np.random.default_rng(0)
+    c = rng.standard_normal((2, 6, 6, 3)); v = rng.standard_normal(c.shape); q = rng.standard_normal(c.shape)
+    gamma = 1 + 0.2 * rng.standard_normal((6, 6)); beta = rng.standard_normal((6, 6))
+    y, cache = ofa.ln_fwd(c, gamma, beta)
+    dc, dg, db = ofa.ln_bwd(v, gamma, cache)
+    vbar, gbar, cbar = ofa.ln_bwd2(q, v, gamma, cache)
+    tc, tv, tg = (torch.tensor(a, requires_grad=True) for a in (c, v, gamma))
+    tb = torch.tensor(beta, requires_grad=True)
+    ty = torch_ref._ln_hw(tc.permute(0, 3, 1, 2), tg, tb).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(y, ty.detach().numpy(), rtol=1e-12, atol=1e-13)
+    tdc, tdg, tdb = torch.autograd.grad(ty, (tc, tg, tb), tv, create_graph=True)
+    np.testing.assert_allclose(dc, tdc.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(dg, tdg.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(db, tdb.detach().numpy(), rtol=1e-10, atol=1e-12)
+    rv, rg, rc = torch.autograd.grad((tdc * torch.tensor(q)).sum(), (tv, tg, tc))
+    np.testing.assert_allclose(vbar, rv.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gbar, rg.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(cbar, rc.numpy(), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('h,inter,zdim,n,drop', [(32, 8, 16, 2, False), (32, 4, 8, 3, True), (64, 8, 16, 1, False)])
+def test_fanogan_phases_vs_torch(h, inter, zdim, n, drop):
+    m, p, x, z, alpha, rng = _setup(h, inter, zdim, n)
+    flat = inter * inter * (min(128, 32 * 2 ** (m.npool - 1)) // 8)
+    mz = mg = mge = None
+    if drop:
+        mz = (rng.random((n, zdim)) > 0.2) / 0.8; mg = (rng.random((n, flat)) > 0.2) / 0.8; mge = (rng.random((n, flat)) > 0.2) / 0.8
+    tp = torch_ref.to_torch(p)
+    tt = lambda a: None if a is None else torch.tensor(a)
+    o = torch_ref.fanogan_graph(tp, torch.tensor(x), torch.tensor(z), torch.tensor(alpha), m.npool, inter, m.scale, m.kappa,
+                                tt(mz), tt(mg), tt(mge))
+    groups = {g: [k for k, _, _ in m.spec if ofa.group_of(k) == g] for g in ('Encoder', 'Generator', 'Discriminator')}
+
+    def tgrads(loss, group):
+        gs = torch.autograd.grad(loss, [tp[k] for k in groups[group]], retain_graph=True, allow_unused=True)
+        return {k: (np.zeros(p[k].shape) if g is None else g.numpy()) for k, g in zip(groups[group], gs)}
+
+    def check(mine, ref, group, tag):
+        for k in groups[group]:
+            a = np.asarray(mine.get(k, np.zeros(p[k].shape))).reshape(p[k].shape)
+            np.testing.assert_allclose(a, ref[k], rtol=2e-7, atol=1e-11 + 1e-8 * np.abs(ref[k]).max(), err_msg=tag + ':' + k)
+
+    # generator phase (trainers/fAnoGAN.py:75, 100-113)
+    ls, g = m.gen_phase(p, z, mg)
+    np.testing.assert_allclose(ls['gen_loss'], o['gen_loss'].item(), rtol=1e-11)
+    np.testing.assert_allclose(ls['generated'], o['x_'].detach().numpy(), rtol=1e-10, atol=1e-13)
+    check(g, tgrads(o['gen_loss'], 'Generator'), 'Generator', 'gen')
+    # critic phase (:50-58, 74, 115-130)
+    ls, g = m.disc_phase(p, x, z, alpha, mg)
+    for k in ('disc_fake', 'disc_real', 'disc_loss', 'penalty'):
+        np.testing.assert_allclose(ls[k], o[k].item(), rtol=1e-10, err_msg=k)
+    check(g, tgrads(o['disc_loss'], 'Discriminator'), 'Discriminator', 'disc')
+    # encoder phase (:60-66, 76, 146-166)
+    ls, g = m.enc_phase(p, x, mz, mge)
+    for k in ('loss_img', 'loss_fts', 'enc_loss', 'reconstructionLoss'):
+        np.testing.assert_allclose(ls[k], o[k].item(), rtol=1e-10, err_msg=k)
+    np.testing.assert_allclose(ls['z_enc'], o['z_enc'].detach().numpy(), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(ls['reconstruction'], o['x_enc'].detach().numpy(), rtol=1e-10, atol=1e-13)
+    check(g, tgrads(o['enc_loss'], 'Encoder'), 'Encoder', 'enc')
+
+
+def test_fanogan_param_table():
+    m = ofa.FAnoGAN(128, 8, 128)
+    names = [s[0] for s in m.spec]
+    assert m.npool == 4 and len(m.ln_g) == 5 and len(m.ln_d) == 4
+    assert names[0] == 'Encoder/enc_conv2D_0/kernel' and 'Encoder/dense/kernel' in names
+    assert names.index('Generator/dense/kernel') < names.index('Generator/conv2d_1/kernel') < names.index('Generator/layer_normalization/gamma')
+    assert m.ln_d[0] == 'Discriminator/layer_normalization_5' and names[-2:] == ['Discriminator/dense/kernel', 'Discriminator/dense/bias']
+    shp = dict((s[0], s[1]) for s in m.spec)
+    assert shp['Generator/layer_normalization_4/gamma'] == (128, 128) and shp['Discriminator/layer_normalization_8/gamma'] == (8, 8)
+    assert shp['Discriminator/dense/kernel'] == (128, 1)
+
+
+def test_fanogan_adam_groups():
+    m, p, x, z, alpha, _ = _setup(32, 8, 16, 2, dtype=np.float32)
+    opt = m.new_opt(p)
+    before = {k: v.copy() for k, v in p.items()}
+    _, g = m.disc_phase(p, x, z, alpha)
+    m.apply(p, opt, g, 'Discriminator', 1e-3)
+    for k in p:
+        changed = not np.array_equal(before[k], p[k])
+        # the critic's dense bias sees +1/size from the fake and -1/size from the real half: exactly zero
+        assert changed == (ofa.group_of(k) == 'Discriminator' and k in g and np.any(g[k] != 0)), k
+    assert opt['t'] == {'Encoder': 0, 'Generator': 0, 'Discriminator': 1}

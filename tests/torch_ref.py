@@ -211,3 +211,85 @@ def gmvae_losses(params, bn_names, x, e_w, e_z, n_pool, dim_c, dim_z, c_lambda, 
     L['grads'], = torch.autograd.grad(L['loss'] + L['restore'].sum(), x, retain_graph=True)
     L['dx_loss'], = torch.autograd.grad(L['loss'], x, retain_graph=True)
     return L, xh, {'pc': pc, 'z_wc_mus': M, 'z_wc_log_sigma_invs': Lq, 'w_sampled': w_s, 'z_sampled': z_s}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# f-AnoGAN (unified graph): models/fanogan.py:11-84 + the loss graph of trainers/fAnoGAN.py:50-66, written with autograd
+# (torch.autograd.grad(create_graph=True) plays tf.gradients(d_hat, x_hat) inside the penalty).
+# ---------------------------------------------------------------------------------------------------------------
+LN_EPS = 1e-3
+
+
+def _ln_hw(c, gamma, beta):
+    # c NCHW; keras LayerNormalization([1, 2]) of the NHWC tensor = statistics over (H, W), gamma/beta [H, W]
+    mu = c.mean(dim=(2, 3), keepdim=True)
+    var = ((c - mu) ** 2).mean(dim=(2, 3), keepdim=True)
+    return (c - mu) / torch.sqrt(var + LN_EPS) * gamma[None, None] + beta[None, None]
+
+
+def fanogan_graph(P, x_nhwc, z, alpha, n_pool, inter_res, scale=10.0, kappa=1.0, mask_z=None, mask_g=None, mask_g_enc=None):
+    """P: name -> tensor.  Returns the dict of graph outputs / losses (torch tensors, NHWC where images)."""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    n = x.shape[0]
+    ln_names = sorted({k.rsplit('/', 1)[0] for k in P if 'layer_normalization' in k},
+                      key=lambda s: int(s.rsplit('_', 1)[1]) if s.rsplit('_', 1)[1].isdigit() else 0)
+    ln_g = [k for k in ln_names if k.startswith('Generator/')]
+    ln_d = [k for k in ln_names if k.startswith('Discriminator/')]
+
+    def encoder(a):
+        for i in range(n_pool):
+            a = _conv_same(a, P['Encoder/enc_conv2D_%d/kernel' % i], P['Encoder/enc_conv2D_%d/bias' % i], 2)
+            bn = 'Encoder/batch_normalization' + ('' if i == 0 else '_%d' % i)
+            a = a * (P[bn + '/gamma'] / math.sqrt(1.0 + BN_EPS)).view(1, -1, 1, 1) + P[bn + '/beta'].view(1, -1, 1, 1)
+            a = F.leaky_relu(a, ALPHA)
+        t = _conv_same(a, P['Encoder/conv2d/kernel'], P['Encoder/conv2d/bias'], 1)
+        flat = t.permute(0, 2, 3, 1).reshape(n, -1)
+        zr = flat @ P['Encoder/dense/kernel'] + P['Encoder/dense/bias']
+        if mask_z is not None:
+            zr = zr * mask_z
+        return torch.tanh(zr)
+
+    def generator(zz, mask):
+        dv = zz @ P['Generator/dense/kernel'] + P['Generator/dense/bias']
+        if mask is not None:
+            dv = dv * mask
+        a = dv.reshape(n, inter_res, inter_res, -1).permute(0, 3, 1, 2)
+        a = _conv_same(a, P['Generator/conv2d_1/kernel'], P['Generator/conv2d_1/bias'], 1)
+        a = F.relu(_ln_hw(a, P[ln_g[0] + '/gamma'], P[ln_g[0] + '/beta']))
+        for i in range(n_pool):
+            a = _convT_same(a, P['Generator/dec_Conv2DT_%d/kernel' % i], P['Generator/dec_Conv2DT_%d/bias' % i], 2)
+            a = F.leaky_relu(_ln_hw(a, P[ln_g[i + 1] + '/gamma'], P[ln_g[i + 1] + '/beta']), ALPHA)
+        return torch.sigmoid(_conv_same(a, P['Generator/dec_Conv2D_final/kernel'], P['Generator/dec_Conv2D_final/bias'], 1))
+
+    def critic(a):
+        for i in range(n_pool):
+            a = _conv_same(a, P['Discriminator/enc_conv2D_%d/kernel' % i], P['Discriminator/enc_conv2D_%d/bias' % i], 2)
+            a = F.leaky_relu(_ln_hw(a, P[ln_d[i] + '/gamma'], P[ln_d[i] + '/beta']), ALPHA)
+        feat = a.permute(0, 2, 3, 1)                                   # NHWC
+        return feat, feat @ P['Discriminator/dense/kernel'] + P['Discriminator/dense/bias']
+
+    o = {}
+    o['z_enc'] = z_enc = encoder(x)
+    o['x_enc'] = x_enc = generator(z_enc, mask_g_enc)
+    o['x_'] = x_ = generator(z, mask_g)
+    o['d_fake_features'], o['d_'] = critic(x_)
+    o['d_features'], o['d'] = critic(x)
+    x_hat = x + alpha.view(n, 1, 1, 1) * (x_ - x)
+    o['d_hat_features'], o['d_hat'] = critic(x_hat)
+    o['d_enc_features'], o['d_enc'] = critic(x_enc)
+    o['disc_real'] = o['d'].mean()
+    o['disc_fake'] = o['d_'].mean()
+    o['gen_loss'] = -o['disc_fake']
+    ddx = torch.autograd.grad(o['d_hat'].sum(), x_hat, create_graph=True)[0].permute(0, 2, 3, 1)   # NHWC
+    slopes = torch.sqrt((ddx ** 2).sum(dim=1))
+    o['penalty'] = ((slopes - 1.0) ** 2).mean() * scale
+    o['disc_loss'] = o['disc_fake'] - o['disc_real'] + o['penalty']
+    xe, xx = x_enc.permute(0, 2, 3, 1), x_nhwc
+    o['loss_img'] = ((xx - xe) ** 2).mean(dim=(1, 2, 3)).mean()
+    o['loss_fts'] = ((o['d_enc_features'] - o['d_features']) ** 2).mean(dim=(1, 2, 3)).mean()
+    o['enc_loss'] = o['loss_img'] + kappa * o['loss_fts']
+    o['reconstructionLoss'] = (xx - xe).abs().sum(dim=(1, 2, 3)).mean()
+    o['x_enc'] = xe
+    o['x_'] = x_.permute(0, 2, 3, 1)
+    o['ddx'] = ddx
+    return o
