@@ -174,6 +174,57 @@ int uad_scores_auc(const uad_scores_t* s, double* auroc, double* auprc, double* 
 int uad_scores_dice(uad_scores_t* s, const double* thresholds_host, int k, double* dice_host, void* stream);
 int uad_scores_destroy(uad_scores_t* s);
 
+/* ---- f-AnoGAN (unified graph) ------------------------------------------------------------------------------
+ * Replaces models/fanogan.py:11-84 (encoder + generator + critic graph) and the three optimisation phases of
+ * trainers/fAnoGAN.py:45-77 (losses :50-66, the WGAN-GP penalty's tf.gradients :55-57, three Adams :71-77);
+ * uad_gan_reconstruct replaces fAnoGAN.reconstruct :220-239.  One handle owns one flat fp32 parameter buffer in TF
+ * variable-creation order (Encoder, Generator, Discriminator groups), its gradient and Adam slots.
+ * A phase runs the forward graph the reference's sess.run of that phase needs, the phase's loss, and (want_backward)
+ * the gradient of that loss w.r.t. the phase's variable group into the gradient buffer; uad_gan_adam then applies
+ * TF-Adam to that group only (each group keeps its own step counter).  All calls are asynchronous on `stream`. */
+enum { UAD_GAN_ENCODER = 0, UAD_GAN_GENERATOR = 1, UAD_GAN_DISCRIMINATOR = 2 };
+/* scalars[16] written by uad_gan_phase (entries a phase does not compute are left untouched) */
+enum { UAD_GAN_S_GEN_LOSS = 0, UAD_GAN_S_DISC_FAKE = 1, UAD_GAN_S_DISC_REAL = 2, UAD_GAN_S_PENALTY = 3, UAD_GAN_S_DISC_LOSS = 4,
+       UAD_GAN_S_LOSS_IMG = 5, UAD_GAN_S_LOSS_FTS = 6, UAD_GAN_S_ENC_LOSS = 7, UAD_GAN_S_REC_LOSS = 8 };
+typedef struct uad_gan uad_gan_t;
+typedef struct {
+    int height, width, channels;   /* square power-of-two slices, 1 channel */
+    int inter_res;                 /* config.intermediateResolutions[0] */
+    int zdim;                      /* config.zDim */
+    int max_batch;
+    float scale, kappa;            /* fAnoGAN.Config :15-16 (gradient-penalty weight, feature-loss weight) */
+} uad_gan_config_t;
+typedef struct {
+    const float* x;                /* [n,H,W,1] batch (critic and encoder phases, reconstruct) */
+    const float* z;                /* [n,zDim] sample_z() (generator and critic phases) */
+    const float* alpha;            /* [n] the critic phase's interpolation coefficients (tf.random_uniform, fanogan.py:67) */
+    const float* mask_z;           /* optional [n,zDim] inverted-dropout keep mask on the encoder's latent (fanogan.py:30) */
+    const float* mask_g;           /* optional [n,flat] mask on the generator's dense output (fanogan.py:39,44) */
+    float* generated;              /* optional out [n,H,W,1]: x_ (generator / critic phases) */
+    float* reconstruction;         /* optional out [n,H,W,1]: x_enc (encoder phase, reconstruct) */
+    float* z_enc;                  /* optional out [n,zDim] */
+    float* l1_map;                 /* optional out [n,H,W,1]: |x - x_enc| (losses['L1']) */
+    float* scalars;                /* optional out [16], UAD_GAN_S_* */
+} uad_gan_io_t;
+int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out);
+int uad_gan_destroy(uad_gan_t* g);
+long long uad_gan_param_count(const uad_gan_t* g);
+int uad_gan_num_tensors(const uad_gan_t* g);
+int uad_gan_tensor_info(const uad_gan_t* g, int idx, char* name, int name_cap, long long* offset, int* rank, int* shape4);
+float* uad_gan_buffer(uad_gan_t* g, int which);                         /* UAD_BUF_* device pointers */
+int uad_gan_group(const uad_gan_t* g, int group, long long* offset, long long* count);   /* UAD_GAN_* slice of the buffers */
+int uad_gan_set_buffer(uad_gan_t* g, int which, const float* host, long long count);
+int uad_gan_get_buffer(uad_gan_t* g, int which, float* host, long long count);
+int uad_gan_set_math_mode(uad_gan_t* g, int mode);                      /* UAD_MATH_* */
+long long uad_gan_get_step(const uad_gan_t* g, int group);
+int uad_gan_set_step(uad_gan_t* g, int group, long long t);
+/* phase = the variable group being trained: GENERATOR (gen_loss), DISCRIMINATOR (disc_loss incl. penalty), ENCODER (enc_loss) */
+int uad_gan_phase(uad_gan_t* g, int phase, const uad_gan_io_t* io, int n, int want_backward, void* stream);
+int uad_gan_adam(uad_gan_t* g, int group, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int uad_gan_reconstruct(uad_gan_t* g, const uad_gan_io_t* io, int n, void* stream);
+/* tests: device pointer + element count of a named intermediate of the last phase (NULL name table entry -> error) */
+int uad_gan_debug_buffer(uad_gan_t* g, const char* name, float** ptr, long long* count);
+
 /* ---- single-kernel entry points (parity tests) ------------------------------------------------------------
  * geometry of one strided-conv relation: big pixel (S*i-P+ky, S*j-P+kx) <-> small pixel (i,j); weights W[tap][cb][cs]
  * (= HWIO for Conv2D with big=input, [kh,kw,Cout,Cin] for Conv2DTranspose with big=output). */

@@ -289,22 +289,26 @@ class FAnoGAN:
         return g, inject
 
     # ------------------------------------------------------------------ phases (trainers/fAnoGAN.py:50-77)
-    def gen_phase(self, p, z, mask_g=None):
-        n = z.shape[0]
+    def gen_phase(self, p, z, mask_g=None, caches=None):
+        """`caches` (optional dict) receives the forward caches -- the GPU parity tests compare activation signs with them."""
         xg, gc = self.gen_forward(p, z, mask_g)
         _, d, dcache = self.disc_forward(p, xg)
+        if caches is not None:
+            caches.update(gen=gc, disc=[dcache])
         gen_loss = -d.mean()
         dd = np.full_like(d, -1.0 / d.size)
         _, dx = self.disc_backward(p, dcache, dd=dd, want_params=False)
         grads, _ = self.gen_backward(p, gc, dx)
         return {'gen_loss': gen_loss, 'generated': xg}, grads
 
-    def disc_phase(self, p, x, z, alpha, mask_g=None):
-        xg, _ = self.gen_forward(p, z, mask_g)
+    def disc_phase(self, p, x, z, alpha, mask_g=None, caches=None):
+        xg, gcache = self.gen_forward(p, z, mask_g)
         _, d_fake, c_fake = self.disc_forward(p, xg)
         _, d_real, c_real = self.disc_forward(p, x)
         x_hat = x + alpha.reshape(-1, 1, 1, 1).astype(x.dtype) * (xg - x)
         _, _, c_hat = self.disc_forward(p, x_hat)
+        if caches is not None:
+            caches.update(gen=gcache, disc=[c_fake, c_real, c_hat])
         ddx, tape = self.disc_input_grad(p, c_hat)
         pen, gbar = self.gradient_penalty(ddx)
         losses = {'disc_fake': d_fake.mean(), 'disc_real': d_real.mean(), 'generated': xg}
@@ -320,11 +324,13 @@ class FAnoGAN:
                 grads[k] = grads.get(k, 0) + v
         return losses, grads
 
-    def enc_phase(self, p, x, mask_z=None, mask_g=None):
+    def enc_phase(self, p, x, mask_z=None, mask_g=None, caches=None):
         z_enc, ec = self.enc_forward(p, x, mask_z)
         x_enc, gc = self.gen_forward(p, z_enc, mask_g)
         f_enc, _, c_enc = self.disc_forward(p, x_enc)
-        f_real, _, _ = self.disc_forward(p, x)
+        f_real, _, c_real = self.disc_forward(p, x)
+        if caches is not None:
+            caches.update(enc=ec, gen=gc, disc=[c_enc, c_real])
         loss_img = ((x - x_enc) ** 2).mean()
         loss_fts = ((f_enc - f_real) ** 2).mean()
         l1 = np.abs(x - x_enc)

@@ -1,0 +1,160 @@
+"""GPU parity of the f-AnoGAN path through the C-ABI (uad_gan_*) against the numpy oracle (float64): the three optimisation
+phases (losses, outputs, gradients of the trained variable group, incl. the second-order gradient-penalty term), reconstruct(),
+and the per-group TF-Adam.  Tolerance: 1e-4 of the tensor's max-norm (fp32 device arithmetic vs fp64 oracle), stated below."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fanogan as ofa
+from oracle import vae as ovae
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+# Gradients when the fp32 device run took the other (Leaky)ReLU branch than the fp64 oracle on some activation whose
+# pre-activation is within round-off of zero: one flipped element moves a filter gradient (a sum of sign-alternating terms) by
+# up to ~1e-2 of its max-norm.  The tests count the flips exactly (activation signs, device vs oracle); with zero flips the
+# gradients are held to TOL.  Forward values and losses are always held to TOL.
+TOL_KINK = 5e-2
+
+
+def _flips(eng, m, caches):
+    total = 0
+
+    def cnt(name, ref):
+        nonlocal total
+        dev = eng.debug_buffer(name)[:ref.size].cpu().numpy().reshape(ref.shape)
+        total += int(((dev > 0) != (ref > 0)).sum())
+
+    if 'enc' in caches:
+        for i in range(m.npool):
+            cnt(f'ea{i + 1}', caches['enc']['a'][i + 1])
+    for i in range(m.npool + 1):
+        cnt(f'ga{i}', caches['gen']['a'][i])
+    for i in range(m.npool):
+        cnt(f'Da{i + 1}', np.concatenate([c['a'][i + 1] for c in caches['disc']]))
+    return total
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _setup(h, inter, zdim, n, seed=0, drop=False):
+    m = ofa.FAnoGAN(h, inter, zdim, scale=10.0, kappa=1.0)
+    p = ovae.init_params(m.spec, seed=21 + seed, dtype=np.float64, perturb=True)
+    rng = np.random.default_rng(90 + seed)
+    x = ovae.synthetic_slices(n, h, h, seed=seed, dtype=np.float64)
+    z = rng.standard_normal((n, zdim))
+    alpha = rng.uniform(0, 1, (n, 1))
+    flat = [s for k, s, _ in m.spec if k == 'Generator/dense/kernel'][0][1]
+    mz = mg = None
+    if drop:
+        mz = (rng.random((n, zdim)) > 0.2) / 0.8
+        mg = (rng.random((n, flat)) > 0.2) / 0.8
+    return m, p, x, z, alpha, mz, mg
+
+
+def _engine(m, p, n, math):
+    from unsupervised_anomaly_detection_brain_mri_amd.gan_engine import GanEngine
+    eng = GanEngine(m.height, m.height, 1, m.inter_res, m.zdim, max_batch=n, scale=m.scale, kappa=m.kappa, math=math)
+    assert [(k, tuple(s)) for k, s, _ in eng.spec] == [(k, tuple(s)) for k, s, _ in m.spec]
+    eng.set_params(p)
+    return eng
+
+
+def _check_grads(eng, m, g_ref, group, tag, tol=TOL):
+    g_dev = eng.get_grads()
+    scale = max(np.abs(np.asarray(v)).max() for k, v in g_ref.items() if ofa.group_of(k) == group)
+    for k, s, _ in m.spec:
+        if ofa.group_of(k) != group:
+            continue
+        ref = np.asarray(g_ref.get(k, np.zeros(s)), np.float64).reshape(s)
+        dev = g_dev[k].astype(np.float64)
+        # biases feeding a LayerNorm over (H, W) have an identically zero gradient; the device writes exact zeros, the
+        # oracle carries fp64 round-off
+        err = np.abs(dev - ref).max()
+        assert err <= tol * max(np.abs(ref).max(), 1e-3 * scale), f'{tag}:{k} err {err:.3e} ref max {np.abs(ref).max():.3e}'
+
+
+CASES = [(32, 8, 16, 2, 'f32', False), (64, 8, 16, 3, 'bf16x3', True), (128, 8, 128, 2, 'bf16x3', False)]
+
+
+@pytest.mark.parametrize('h,inter,zdim,n,math,drop', CASES)
+def test_generator_phase(h, inter, zdim, n, math, drop):
+    m, p, x, z, alpha, mz, mg = _setup(h, inter, zdim, n, drop=drop)
+    eng = _engine(m, p, n, math)
+    out = eng.phase('Generator', z=z, mask_g=mg)
+    caches = {}
+    ls, g = m.gen_phase(p, z, mg, caches)
+    assert _rel(out['generated'].cpu().numpy(), ls['generated']) < TOL
+    assert abs(out['gen_loss'].item() - ls['gen_loss']) < TOL * max(1.0, abs(ls['gen_loss']))
+    flips = _flips(eng, m, caches)
+    _check_grads(eng, m, g, 'Generator', 'gen', TOL if flips == 0 else TOL_KINK)
+    assert h > 32 or flips == 0      # the small case must exercise the tight tolerance
+
+
+@pytest.mark.parametrize('h,inter,zdim,n,math,drop', CASES)
+def test_critic_phase(h, inter, zdim, n, math, drop):
+    m, p, x, z, alpha, mz, mg = _setup(h, inter, zdim, n, seed=1, drop=drop)
+    eng = _engine(m, p, n, math)
+    out = eng.phase('Discriminator', x=x, z=z, alpha=alpha, mask_g=mg)
+    caches = {}
+    ls, g = m.disc_phase(p, x, z, alpha, mg, caches)
+    for k in ('disc_fake', 'disc_real', 'penalty', 'disc_loss'):
+        assert abs(out[k].item() - ls[k]) < TOL * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
+    flips = _flips(eng, m, caches)
+    _check_grads(eng, m, g, 'Discriminator', 'disc', TOL if flips == 0 else TOL_KINK)
+    assert h > 32 or flips == 0
+
+
+@pytest.mark.parametrize('h,inter,zdim,n,math,drop', CASES)
+def test_encoder_phase_and_reconstruct(h, inter, zdim, n, math, drop):
+    m, p, x, z, alpha, mz, mg = _setup(h, inter, zdim, n, seed=2, drop=drop)
+    eng = _engine(m, p, n, math)
+    out = eng.phase('Encoder', x=x, mask_z=mz, mask_g=mg, want_l1=True)
+    caches = {}
+    ls, g = m.enc_phase(p, x, mz, mg, caches)
+    for k in ('loss_img', 'loss_fts', 'enc_loss', 'reconstructionLoss'):
+        assert abs(out[k].item() - ls[k]) < TOL * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
+    assert _rel(out['z_enc'].cpu().numpy(), ls['z_enc']) < TOL
+    assert _rel(out['reconstruction'].cpu().numpy(), ls['reconstruction']) < TOL
+    assert _rel(out['L1'].cpu().numpy(), ls['L1']) < TOL
+    flips = _flips(eng, m, caches)
+    _check_grads(eng, m, g, 'Encoder', 'enc', TOL if flips == 0 else TOL_KINK)
+    assert h > 32 or flips == 0
+    rec = eng.reconstruct(x)
+    assert _rel(rec['reconstruction'].cpu().numpy(), m.reconstruct(p, x)) < TOL
+
+
+def test_adam_touches_only_its_group():
+    m, p, x, z, alpha, mz, mg = _setup(32, 8, 16, 2, seed=3)
+    eng = _engine(m, p, 2, 'f32')
+    p32 = {k: v.astype(np.float32) for k, v in p.items()}
+    opt = m.new_opt(p32)
+    lr = 1e-3
+    for group, kw in (('Generator', dict(z=z)), ('Discriminator', dict(x=x, z=z, alpha=alpha)), ('Encoder', dict(x=x))):
+        before = eng.get_params()
+        eng.phase(group, **kw)
+        eng.adam(group, lr)
+        after = eng.get_params()
+        if group == 'Generator':
+            _, g = m.gen_phase(p32, z.astype(np.float32))
+        elif group == 'Discriminator':
+            _, g = m.disc_phase(p32, x.astype(np.float32), z.astype(np.float32), alpha.astype(np.float32))
+        else:
+            _, g = m.enc_phase(p32, x.astype(np.float32))
+        m.apply(p32, opt, g, group, lr)
+        for k in after:
+            if ofa.group_of(k) != group:
+                assert np.array_equal(before[k], after[k]), k
+        assert eng.step_count(group) == 1
+        # first Adam step moves every entry with a non-negligible gradient by ~lr in the gradient's direction
+        gscale = max(np.abs(np.asarray(v)).max() for v in g.values())
+        for k, gk in g.items():
+            gk = np.asarray(gk).reshape(after[k].shape)
+            big = np.abs(gk) > max(1e-3 * np.abs(gk).max(), 1e-6 * gscale)   # skips the identically-zero bias gradients
+            if big.any():
+                np.testing.assert_allclose((after[k] - before[k])[big], -lr * np.sign(gk[big]), rtol=2e-2, atol=1e-7, err_msg=k)
+        eng.set_params(p32)      # keep device and oracle parameters identical for the next group

@@ -34,6 +34,21 @@ class UadIO(C.Structure):
                 ('pc', C.c_void_p)]
 
 
+class UadGanConfig(C.Structure):
+    _fields_ = [('height', C.c_int), ('width', C.c_int), ('channels', C.c_int), ('inter_res', C.c_int), ('zdim', C.c_int),
+                ('max_batch', C.c_int), ('scale', C.c_float), ('kappa', C.c_float)]
+
+
+class UadGanIO(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ('x', 'z', 'alpha', 'mask_z', 'mask_g', 'generated', 'reconstruction', 'z_enc',
+                                          'l1_map', 'scalars')]
+
+
+GAN_ENCODER, GAN_GENERATOR, GAN_DISCRIMINATOR = 0, 1, 2
+GAN_SCALARS = ('gen_loss', 'disc_fake', 'disc_real', 'penalty', 'disc_loss', 'loss_img', 'loss_fts', 'enc_loss',
+               'reconstructionLoss')
+
+
 class UadConvDesc(C.Structure):
     _fields_ = [(k, C.c_int) for k in ('N', 'HB', 'WB', 'CB', 'HS', 'WS', 'CS', 'KS', 'S', 'P')]
 
@@ -80,6 +95,23 @@ SYMBOLS = {
     'uad_scores_auc': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'uad_scores_dice': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     'uad_scores_destroy': (C.c_int, [C.c_void_p]),
+    'uad_gan_create': (C.c_int, [C.POINTER(UadGanConfig), C.POINTER(C.c_void_p)]),
+    'uad_gan_destroy': (C.c_int, [C.c_void_p]),
+    'uad_gan_param_count': (C.c_longlong, [C.c_void_p]),
+    'uad_gan_num_tensors': (C.c_int, [C.c_void_p]),
+    'uad_gan_tensor_info': (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_longlong),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'uad_gan_buffer': (C.c_void_p, [C.c_void_p, C.c_int]),
+    'uad_gan_group': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    'uad_gan_set_buffer': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),
+    'uad_gan_get_buffer': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),
+    'uad_gan_set_math_mode': (C.c_int, [C.c_void_p, C.c_int]),
+    'uad_gan_get_step': (C.c_longlong, [C.c_void_p, C.c_int]),
+    'uad_gan_set_step': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong]),
+    'uad_gan_phase': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(UadGanIO), C.c_int, C.c_int, C.c_void_p]),
+    'uad_gan_adam': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'uad_gan_reconstruct': (C.c_int, [C.c_void_p, C.POINTER(UadGanIO), C.c_int, C.c_void_p]),
+    'uad_gan_debug_buffer': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     'uad_op_conv_f': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'uad_op_conv_d': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p, C.c_void_p,

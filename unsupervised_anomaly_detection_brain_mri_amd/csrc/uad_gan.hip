@@ -1,0 +1,1107 @@
+// f-AnoGAN (unified graph) on gfx950: LayerNorm-HW kernels (forward, backward, and the second-order backward the WGAN-GP
+// penalty needs), the small heads / losses, and the orchestration of the three optimisation phases behind the C-ABI
+// (include/uad_hip.h, uad_gan_*).  The k5 s2 convolutions, their data and filter gradients, the dense layers and Adam are
+// the kernels of uad_gemm.hip / uad_misc.hip.
+//
+// Graph restated (reference): models/fanogan.py:11-84, models/customlayers.py:16-38 (use_batchnorm=False branches),
+// losses / optimisers trainers/fAnoGAN.py:50-77, reconstruct :220-239.
+//
+// Critic phase = four passes over the critic (per-sample normalisation makes every pass batchable):
+//   A  forward of [x_ ; x ; x_hat]                                   (3n samples)
+//   B  input gradient of sum(d_hat) on the x_hat third               (tf.gradients(d_hat, x_hat), n samples)
+//   C  adjoint of pass B, bottom-up (forward convs of the adjoint, second-order LayerNorm term)
+//   D  ordinary backward of all 3n samples with pass C's d penalty / d c injected on the x_hat third; each filter gradient
+//      runs once over 4n "samples": the 3n (input, d c) pairs plus pass C's (adjoint, pass-B d c) pairs of the same layer.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/uad_hip.h"
+#include "uad_kernels.h"
+
+int uad_fail(int code, const char* fmt, ...);
+#define fail uad_fail
+
+namespace {
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(UAD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr float kBnEps = 1e-3f;     // tf.layers.BatchNormalization default epsilon (encoder, frozen statistics)
+constexpr float kLnEps = 1e-3f;     // keras LayerNormalization default epsilon
+constexpr float kLrelu = 0.3f;      // keras LeakyReLU() default
+
+// ================================================================================================ LayerNorm over (H, W)
+// One workgroup per (sample, 32-channel group): 256 threads = 32 pixel lanes x 8 channel quads (float4 = 16-byte NHWC
+// accesses).  Per-channel sums are folded through LDS in a fixed order.
+__device__ __forceinline__ float4 chan_reduce(float4 v, float (*red)[36], int pl, int cq) {
+    red[pl][cq * 4 + 0] = v.x; red[pl][cq * 4 + 1] = v.y; red[pl][cq * 4 + 2] = v.z; red[pl][cq * 4 + 3] = v.w;
+    __syncthreads();
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        if (pl < o) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[pl][cq * 4 + k] += red[pl + o][cq * 4 + k];
+        }
+        __syncthreads();
+    }
+    const float4 r = make_float4(red[0][cq * 4 + 0], red[0][cq * 4 + 1], red[0][cq * 4 + 2], red[0][cq * 4 + 3]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float4 f4(float s) { return make_float4(s, s, s, s); }
+__device__ __forceinline__ float4 act_grad(float4 y, float4 g, float alpha) {
+    return make_float4(y.x > 0.f ? g.x : alpha * g.x, y.y > 0.f ? g.y : alpha * g.y, y.z > 0.f ? g.z : alpha * g.z,
+                       y.w > 0.f ? g.w : alpha * g.w);
+}
+__device__ __forceinline__ float hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float quad8_sum(float v) {   // over the 8 channel-quad lanes of one pixel
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+
+// a = act(gamma[p] * (c - mean) * rstd + beta[p]); stats[n][0][ch] = mean, stats[n][1][ch] = rstd
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float alpha, int HW, int C,
+                                                     float* __restrict__ a, float* __restrict__ stats) {
+    __shared__ float red[32][36];
+    const int n = blockIdx.y, cq = threadIdx.x & 7, pl = threadIdx.x >> 3, ch0 = blockIdx.x * 32 + cq * 4;
+    const size_t off = (size_t)n * HW * C + ch0;
+    float4 s = f4(0.f);
+    for (int p = pl; p < HW; p += 32) s = s + *reinterpret_cast<const float4*>(c + off + (size_t)p * C);
+    const float inv = 1.0f / (float)HW;
+    const float4 mean = chan_reduce(s, red, pl, cq) * inv;
+    float4 q = f4(0.f);
+    for (int p = pl; p < HW; p += 32) {
+        const float4 d = *reinterpret_cast<const float4*>(c + off + (size_t)p * C) - mean;
+        q = q + d * d;
+    }
+    const float4 var = chan_reduce(q, red, pl, cq) * inv;
+    const float4 r = make_float4(1.0f / sqrtf(var.x + kLnEps), 1.0f / sqrtf(var.y + kLnEps), 1.0f / sqrtf(var.z + kLnEps),
+                                 1.0f / sqrtf(var.w + kLnEps));
+    if (pl == 0) {
+        *reinterpret_cast<float4*>(stats + ((size_t)n * 2 + 0) * C + ch0) = mean;
+        *reinterpret_cast<float4*>(stats + ((size_t)n * 2 + 1) * C + ch0) = r;
+    }
+    for (int p = pl; p < HW; p += 32) {
+        const float4 xh = (*reinterpret_cast<const float4*>(c + off + (size_t)p * C) - mean) * r;
+        const float4 y = xh * gamma[p] + f4(beta[p]);
+        *reinterpret_cast<float4*>(a + off + (size_t)p * C) = act_grad(y, y, alpha);
+    }
+}
+
+struct LnBwdArgs {
+    const float* da;        // d / d activation output
+    const float* c;         // pre-norm tensor
+    const float* stats;
+    const float* gamma; const float* beta;
+    float alpha;
+    int HW, C;
+    const float* add;       // optional extra d / d c for samples [add_lo, add_hi), indexed from add_lo
+    int add_lo, add_hi;
+    float* dc;
+    float* v_out;           // optional: d / d (norm output) = da * act'
+    float* gpart;           // optional [slot][2][HW]: per-pixel sums over the block's channels of dn*xhat, dn
+    int slot0;
+};
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs A) {
+    __shared__ float red[32][36];
+    const int n = blockIdx.y, cq = threadIdx.x & 7, pl = threadIdx.x >> 3, ch0 = blockIdx.x * 32 + cq * 4;
+    const int HW = A.HW, C = A.C;
+    const size_t off = (size_t)n * HW * C + ch0;
+    const float4 mean = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 0) * C + ch0);
+    const float4 r = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 1) * C + ch0);
+    const size_t slot = (size_t)(A.slot0 + n) * gridDim.x + blockIdx.x;
+    float4 sp = f4(0.f), spx = f4(0.f);
+    for (int p = pl; p < HW; p += 32) {
+        const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
+        const float g = A.gamma[p];
+        const float4 y = xh * g + f4(A.beta[p]);
+        const float4 dn = act_grad(y, *reinterpret_cast<const float4*>(A.da + off + (size_t)p * C), A.alpha);
+        const float4 pp = dn * g;
+        sp = sp + pp; spx = spx + pp * xh;
+        if (A.gpart) {
+            const float t1 = quad8_sum(hsum(dn * xh)), t2 = quad8_sum(hsum(dn));
+            if (cq == 0) { A.gpart[(slot * 2 + 0) * HW + p] = t1; A.gpart[(slot * 2 + 1) * HW + p] = t2; }
+        }
+    }
+    const float inv = 1.0f / (float)HW;
+    const float4 ep = chan_reduce(sp, red, pl, cq) * inv;
+    const float4 epx = chan_reduce(spx, red, pl, cq) * inv;
+    const bool has_add = A.add && n >= A.add_lo && n < A.add_hi;
+    const size_t aoff = has_add ? (size_t)(n - A.add_lo) * HW * C + ch0 : 0;
+    for (int p = pl; p < HW; p += 32) {
+        const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
+        const float g = A.gamma[p];
+        const float4 y = xh * g + f4(A.beta[p]);
+        const float4 dn = act_grad(y, *reinterpret_cast<const float4*>(A.da + off + (size_t)p * C), A.alpha);
+        float4 dc = r * (dn * g - ep - xh * epx);
+        if (has_add) dc = dc + *reinterpret_cast<const float4*>(A.add + aoff + (size_t)p * C);
+        *reinterpret_cast<float4*>(A.dc + off + (size_t)p * C) = dc;
+        if (A.v_out) *reinterpret_cast<float4*>(A.v_out + off + (size_t)p * C) = dn;
+    }
+}
+
+// Adjoint of (v, gamma, c) -> dc = r (p - E[p] - xh E[p xh]), p = v gamma:  given q = d P / d dc
+//   pbar  = r (q - E[q] - xh E[q xh])                       -> ubar = pbar * gamma * act'(y),  dgamma[p] += sum_ch pbar * v
+//   xhbar = -r (q E[p xh] + p E[q xh])
+//   cbar  = r (xhbar - E[xhbar] - xh E[xhbar xh]) - r E[q dc] xh
+struct LnBwd2Args {
+    const float* q; const float* v; const float* c; const float* stats; const float* gamma; const float* beta;
+    float alpha;
+    int HW, C;
+    float* ubar; float* inj; float* gpart;
+    int slot0;
+};
+__global__ void __launch_bounds__(256) ln_bwd2_kernel(const LnBwd2Args A) {
+    __shared__ float red[32][36];
+    const int n = blockIdx.y, cq = threadIdx.x & 7, pl = threadIdx.x >> 3, ch0 = blockIdx.x * 32 + cq * 4;
+    const int HW = A.HW, C = A.C;
+    const size_t off = (size_t)n * HW * C + ch0;
+    const float4 mean = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 0) * C + ch0);
+    const float4 r = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 1) * C + ch0);
+    const size_t slot = (size_t)(A.slot0 + n) * gridDim.x + blockIdx.x;
+    float4 sp = f4(0.f), spx = f4(0.f), sq = f4(0.f), sqx = f4(0.f), sqp = f4(0.f);
+    for (int p = pl; p < HW; p += 32) {
+        const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
+        const float4 pp = *reinterpret_cast<const float4*>(A.v + off + (size_t)p * C) * A.gamma[p];
+        const float4 qq = *reinterpret_cast<const float4*>(A.q + off + (size_t)p * C);
+        sp = sp + pp; spx = spx + pp * xh; sq = sq + qq; sqx = sqx + qq * xh; sqp = sqp + qq * pp;
+    }
+    const float inv = 1.0f / (float)HW;
+    const float4 ep = chan_reduce(sp, red, pl, cq) * inv, epx = chan_reduce(spx, red, pl, cq) * inv;
+    const float4 eq = chan_reduce(sq, red, pl, cq) * inv, eqx = chan_reduce(sqx, red, pl, cq) * inv;
+    const float4 eqp = chan_reduce(sqp, red, pl, cq) * inv;
+    const float4 zero = f4(0.f);
+    const float4 e_xhbar = zero - r * (eq * epx + ep * eqx);
+    const float4 e_xhbar_xh = zero - r * (eqx * epx) * 2.0f;
+    const float4 e_qdc = r * (eqp - eq * ep - eqx * epx);
+    for (int p = pl; p < HW; p += 32) {
+        const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
+        const float g = A.gamma[p];
+        const float4 vv = *reinterpret_cast<const float4*>(A.v + off + (size_t)p * C);
+        const float4 pp = vv * g;
+        const float4 qq = *reinterpret_cast<const float4*>(A.q + off + (size_t)p * C);
+        const float4 pbar = r * (qq - eq - xh * eqx);
+        const float4 y = xh * g + f4(A.beta[p]);
+        *reinterpret_cast<float4*>(A.ubar + off + (size_t)p * C) = act_grad(y, pbar * g, A.alpha);
+        const float t1 = quad8_sum(hsum(pbar * vv));
+        if (cq == 0) { A.gpart[(slot * 2 + 0) * HW + p] = t1; A.gpart[(slot * 2 + 1) * HW + p] = 0.f; }
+        const float4 xhbar = zero - r * (qq * epx + pp * eqx);
+        *reinterpret_cast<float4*>(A.inj + off + (size_t)p * C) = r * (xhbar - e_xhbar - xh * e_xhbar_xh) - r * e_qdc * xh;
+    }
+}
+
+// ================================================================================================ frozen-stats BN (encoder)
+__global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float rs0, float alpha, size_t total4,
+                                                         int C, float* __restrict__ a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int ch = (int)((i * 4) % C);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + ch) * rs0, b = *reinterpret_cast<const float4*>(beta + ch);
+    const float4 y = reinterpret_cast<const float4*>(c)[i] * g + b;
+    reinterpret_cast<float4*>(a)[i] = act_grad(y, y, alpha);
+}
+// dc = da * act'(y) * gamma * rs0; colpart[blk][0][ch] = sum da*act', [1][ch] = sum da*act'*c
+__global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict__ da, const float* __restrict__ c,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float rs0, float alpha, int rows, int rows_per_block, int C,
+                                                         float* __restrict__ dc, float* __restrict__ colpart) {
+    __shared__ float r1[1024], r2[1024];
+    const int Q = C / 4, RL = 256 / Q;
+    const int cq = threadIdx.x % Q, rl = threadIdx.x / Q, ch = cq * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + ch) * rs0, b = *reinterpret_cast<const float4*>(beta + ch);
+    const int row0 = blockIdx.x * rows_per_block, row1 = min(rows, row0 + rows_per_block);
+    float4 s1 = f4(0.f), s2 = f4(0.f);
+    for (int row = row0 + rl; row < row1; row += RL) {
+        const float4 cv = *reinterpret_cast<const float4*>(c + (size_t)row * C + ch);
+        const float4 dn = act_grad(cv * g + b, *reinterpret_cast<const float4*>(da + (size_t)row * C + ch), alpha);
+        *reinterpret_cast<float4*>(dc + (size_t)row * C + ch) = dn * g;
+        s1 = s1 + dn; s2 = s2 + dn * cv;
+    }
+    *reinterpret_cast<float4*>(r1 + rl * C + ch) = s1;
+    *reinterpret_cast<float4*>(r2 + rl * C + ch) = s2;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int k = 0; k < RL; ++k) { a1 += r1[k * C + threadIdx.x]; a2 += r2[k * C + threadIdx.x]; }
+        colpart[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a1;
+        colpart[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = a2;
+    }
+}
+
+// ================================================================================================ heads
+// d[row] = feat[row,:] . w + b   (critic Dense(1) per feature-map location / generator's final 1x1 conv + sigmoid)
+template <bool SIGMOID>
+__global__ void __launch_bounds__(256) rowdot_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                                     const float* __restrict__ b, int rows, int C, float* __restrict__ out) {
+    const int LPR = C / 4;
+    const int lane = threadIdx.x % LPR;
+    const int row = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) / LPR);
+    float s = 0.f;
+    if (row < rows) s = hsum(*reinterpret_cast<const float4*>(feat + (size_t)row * C + lane * 4) * *reinterpret_cast<const float4*>(w + lane * 4));
+    for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (row < rows && lane == 0) {
+        s += b[0];
+        out[row] = SIGMOID ? 1.0f / (1.0f + expf(-s)) : s;
+    }
+}
+struct Coef4 { float v[4]; };
+// out[row, c] = coef[row / rows_per_group] * w[c]
+__global__ void __launch_bounds__(256) topgrad_kernel(const float* __restrict__ w, int rows_per_group, int C, size_t total4,
+                                                      Coef4 coef, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const size_t row = (i * 4) / C;
+    const int ch = (int)((i * 4) % C);
+    reinterpret_cast<float4*>(out)[i] = *reinterpret_cast<const float4*>(w + ch) * coef.v[row / rows_per_group];
+}
+// partial[blk][c] = sum over the block's rows of coef[row / rows_per_group] * feat[row, c]
+__global__ void __launch_bounds__(256) coef_colsum_kernel(const float* __restrict__ feat, int rows, int rows_per_block,
+                                                          int rows_per_group, int C, Coef4 coef, float* __restrict__ partial) {
+    __shared__ float red[1024];
+    const int Q = C / 4, RL = 256 / Q;
+    const int cq = threadIdx.x % Q, rl = threadIdx.x / Q, ch = cq * 4;
+    const int row0 = blockIdx.x * rows_per_block, row1 = min(rows, row0 + rows_per_block);
+    float4 s = f4(0.f);
+    for (int row = row0 + rl; row < row1; row += RL)
+        s = s + *reinterpret_cast<const float4*>(feat + (size_t)row * C + ch) * coef.v[row / rows_per_group];
+    *reinterpret_cast<float4*>(red + rl * C + ch) = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float a = 0.f;
+        for (int k = 0; k < RL; ++k) a += red[k * C + threadIdx.x];
+        partial[(size_t)blockIdx.x * C + threadIdx.x] = a;
+    }
+}
+// generator output backward: do = dx * x (1 - x); da[row, c] = do * wf[c]; partial[blk][0..C) = sum do * a[row, c], [C] = sum do
+__global__ void __launch_bounds__(256) gfinal_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ x,
+                                                         const float* __restrict__ a, const float* __restrict__ wf, int rows,
+                                                         int rows_per_block, int C, float* __restrict__ da,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[1024], redb[256];
+    const int Q = C / 4, RL = 256 / Q;
+    const int cq = threadIdx.x % Q, rl = threadIdx.x / Q, ch = cq * 4;
+    const float4 w = *reinterpret_cast<const float4*>(wf + ch);
+    const int row0 = blockIdx.x * rows_per_block, row1 = min(rows, row0 + rows_per_block);
+    float4 s = f4(0.f);
+    float sb = 0.f;
+    for (int row = row0 + rl; row < row1; row += RL) {
+        const float xv = x[row];
+        const float dv = dx[row] * xv * (1.0f - xv);
+        *reinterpret_cast<float4*>(da + (size_t)row * C + ch) = w * dv;
+        if (partial) { s = s + *reinterpret_cast<const float4*>(a + (size_t)row * C + ch) * dv; sb += dv; }
+    }
+    if (!partial) return;
+    *reinterpret_cast<float4*>(red + rl * C + ch) = s;
+    redb[threadIdx.x] = cq == 0 ? sb : 0.f;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float acc = 0.f;
+        for (int k = 0; k < RL; ++k) acc += red[k * C + threadIdx.x];
+        partial[(size_t)blockIdx.x * (C + 1) + threadIdx.x] = acc;
+    }
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int k = 0; k < 256; ++k) acc += redb[k];
+        partial[(size_t)blockIdx.x * (C + 1) + C] = acc;
+    }
+}
+
+// ================================================================================================ elementwise / losses
+// din = [xg ; x ; x + alpha[n] (xg - x)]
+__global__ void __launch_bounds__(256) interp_kernel(const float* __restrict__ xg, const float* __restrict__ x,
+                                                     const float* __restrict__ alpha, int HW, size_t total, float* __restrict__ din) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float g = xg[i], r = x[i];
+    din[i] = g; din[total + i] = r; din[2 * total + i] = r + alpha[i / HW] * (g - r);
+}
+__global__ void __launch_bounds__(256) tanh_kernel(const float* __restrict__ zr, size_t n, float* __restrict__ z) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) z[i] = tanhf(zr[i]);
+}
+__global__ void __launch_bounds__(256) tanh_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                       const float* __restrict__ mask, size_t n, float* __restrict__ dzr) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dzr[i] = dz[i] * (1.0f - z[i] * z[i]) * (mask ? mask[i] : 1.0f);
+}
+// out = coef * (a - b)  (+ out_prev when ACC)
+template <bool ACC>
+__global__ void __launch_bounds__(256) diff_scale_kernel(const float* __restrict__ a, const float* __restrict__ b, float coef,
+                                                         size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (ACC ? out[i] : 0.f) + coef * (a[i] - b[i]);
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+// MODE 0: sum a ; 1: sum (a-b)^2 ; 2: sum |a-b| (optionally writing the map).  partial[blk]
+template <int MODE>
+__global__ void __launch_bounds__(256) sum_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                  float* __restrict__ map, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (MODE == 0) s += a[i];
+        else if (MODE == 1) { const float d = a[i] - b[i]; s += d * d; }
+        else { const float d = fabsf(a[i] - b[i]); s += d; if (map) map[i] = d; }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// trainers/fAnoGAN.py:56-57: slopes = sqrt(sum over axis 1 (H) of ddx^2) -> [n, W]; partial sums of (slope - 1)^2
+__global__ void __launch_bounds__(256) pen_col_kernel(const float* __restrict__ g, int n, int H, int W, float* __restrict__ s,
+                                                      float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    float t = 0.f;
+    if (col < n * W) {
+        const int nn = col / W, w = col % W;
+        float acc = 0.f;
+        for (int h = 0; h < H; ++h) { const float v = g[((size_t)nn * H + h) * W + w]; acc = fmaf(v, v, acc); }
+        const float sl = sqrtf(acc);
+        s[col] = sl;
+        t = (sl - 1.0f) * (sl - 1.0f);
+    }
+    t = block_sum(t, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+// d penalty / d ddx = coef * (s - 1) / s * ddx
+__global__ void __launch_bounds__(256) pen_grad_kernel(const float* __restrict__ g, const float* __restrict__ s, float coef, int H,
+                                                       int W, size_t total, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int w = (int)(i % W);
+    const size_t nn = i / ((size_t)H * W);
+    const float sl = s[nn * W + w];
+    out[i] = coef * (sl - 1.0f) / sl * g[i];
+}
+// derived scalars of a phase from the raw means in raw[]
+__global__ void combine_kernel(int phase, const float* __restrict__ raw, float kappa, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    if (phase == UAD_GAN_GENERATOR) {
+        out[UAD_GAN_S_DISC_FAKE] = raw[0]; out[UAD_GAN_S_GEN_LOSS] = -raw[0];
+    } else if (phase == UAD_GAN_DISCRIMINATOR) {
+        out[UAD_GAN_S_DISC_FAKE] = raw[0]; out[UAD_GAN_S_DISC_REAL] = raw[1]; out[UAD_GAN_S_PENALTY] = raw[2];
+        out[UAD_GAN_S_DISC_LOSS] = raw[0] - raw[1] + raw[2]; out[UAD_GAN_S_GEN_LOSS] = -raw[0];
+    } else {
+        out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
+        out[UAD_GAN_S_REC_LOSS] = raw[2];
+    }
+}
+
+// ================================================================================================ handle
+struct Tensor {
+    std::string name;
+    long long off;
+    int rank;
+    int shape[4];
+    long long count() const { return (long long)shape[0] * shape[1] * shape[2] * shape[3]; }
+};
+struct Block {            // conv / convT followed by a norm + (Leaky)ReLU
+    UadConvDesc d;        // geometry at batch 1
+    long long w, b, gamma, beta;
+    int H, W, C;          // output map of the block
+};
+
+}  // namespace
+
+struct uad_gan {
+    uad_gan_config_t cfg;
+    int npool, cenc, cmid, flat;
+    std::vector<Tensor> tensors;
+    long long nparams;
+    long long grp_off[3], grp_cnt[3], step[3];
+    float *params, *grads, *adam_m, *adam_v;
+    float *wpack_f, *wpack_d, *wpack16_f, *wpack16_d;
+    int math;
+    bool packed_valid;
+    UadGemmWs ws;
+    std::vector<Block> E, G, D;
+    long long e_cw, e_cb, e_dw, e_db;                   // Encoder/conv2d, Encoder/dense
+    long long g_dw, g_db, g_cw, g_cb, g_ln0g, g_ln0b;   // Generator/dense, conv2d_1, first LayerNorm
+    long long g_fw, g_fb;                               // dec_Conv2D_final
+    long long d_hw, d_hb;                               // Discriminator/dense
+    // encoder activations
+    std::vector<float*> ec, ea;        // ea[i] = input of block i (ea[0] unused: the caller's x)
+    float *et, *zr, *z;
+    // generator activations
+    float *gdv, *xg;
+    std::vector<float*> gc, ga, gstat; // gc[0] = conv2d_1 output, gc[i+1] = ConvT i output
+    // critic (4n layout where noted)
+    float* din;                        // [4n] input images; tail = pass C's adjoint of the input gradient
+    std::vector<float*> Dc, Dstat;     // [3n]
+    std::vector<float*> Da;            // Da[i] = input of block i (i >= 1), Da[L] = features; [4n], tail = pass C adjoints
+    std::vector<float*> Dg;            // [4n] d loss / d c_i ; tail = pass B's d c_i
+    std::vector<float*> V, inj;        // [n] pass B's d / d norm output ; pass C's d penalty / d c_i
+    std::vector<float*> lnpart;        // per critic level [4n * CG][2][HW]
+    float *Q, *Dd, *Gx, *slopes;
+    float *lnpart_g;                   // generator LayerNorm parameter-gradient partials
+    // gradient ping-pong, small vectors, scratch
+    float *Ga, *Gb, *dxbuf, *dzbuf, *dzr, *dflat, *ddv;
+    float *wpartial, *colscratch, *colpart, *redpart, *raw, *scalars_own, *finpart;
+    std::map<std::string, std::pair<float*, long long>> dbg;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+float* P(uad_gan* m, long long off) { return m->params + off; }
+float* Gr(uad_gan* m, long long off) { return m->grads + off; }
+const float* PKF(uad_gan* m, long long off) { return m->math == UAD_MATH_F32 ? m->wpack_f + off : nullptr; }
+const float* PKD(uad_gan* m, long long off) { return m->math == UAD_MATH_F32 ? m->wpack_d + off : nullptr; }
+const unsigned short* PK16F(uad_gan* m, long long off) { return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_f + 2 * off : nullptr; }
+const unsigned short* PK16D(uad_gan* m, long long off) { return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_d + 2 * off : nullptr; }
+long long PLANE(const Block& L) { return (long long)L.d.KS * L.d.KS * L.d.CB * L.d.CS; }
+UadXform no_xform() { UadXform x; x.scale = nullptr; x.shift = nullptr; x.alpha = 1.f; x.mult = 1.f; return x; }
+UadEpilogue epi_bias(const float* bias, const float* mul = nullptr, const float* add = nullptr) {
+    UadEpilogue e;
+    memset(&e, 0, sizeof e);
+    e.kind = UAD_EPI_BIAS; e.bias = bias; e.mul = mul; e.add = add;
+    return e;
+}
+UadConvDesc dense_desc(int n, int in, int out) { return UadConvDesc{n, 1, 1, in, 1, 1, out, 1, 1, 0}; }
+UadConvDesc conv1x1_desc(int n, int h, int w, int cin, int cout) { return UadConvDesc{n, h, w, cin, h, w, cout, 1, 1, 0}; }
+int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+inline unsigned blocks256(size_t n) { return (unsigned)((n + 255) / 256); }
+
+long long add_tensor(uad_gan* m, const std::string& name, int rank, int s0, int s1, int s2, int s3) {
+    Tensor t;
+    t.name = name; t.off = m->nparams; t.rank = rank;
+    t.shape[0] = s0; t.shape[1] = s1; t.shape[2] = s2; t.shape[3] = s3;
+    m->nparams += t.count();
+    m->tensors.push_back(t);
+    return t.off;
+}
+int dev_alloc(uad_gan* m, float** p, size_t floats, const char* name = nullptr) {
+    void* q = nullptr;
+    if (floats == 0) floats = 4;
+    HIP_TRY(hipMalloc(&q, floats * sizeof(float)));
+    HIP_TRY(hipMemset(q, 0, floats * sizeof(float)));
+    m->allocs.push_back(q);
+    *p = (float*)q;
+    if (name) m->dbg[name] = std::make_pair((float*)q, (long long)floats);
+    return UAD_OK;
+}
+
+// ---- launch helpers ----
+void ln_fwd(const float* c, const float* gamma, const float* beta, float alpha, int N, int HW, int C, float* a, float* stats, hipStream_t st) {
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(C / 32, N), dim3(256), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
+}
+void ln_bwd(const LnBwdArgs& a, int N, hipStream_t st) { hipLaunchKernelGGL(ln_bwd_kernel, dim3(a.C / 32, N), dim3(256), 0, st, a); }
+void ln_bwd2(const LnBwd2Args& a, int N, hipStream_t st) { hipLaunchKernelGGL(ln_bwd2_kernel, dim3(a.C / 32, N), dim3(256), 0, st, a); }
+void bn_act_fwd(uad_gan* m, const Block& L, const float* c, int N, float* a, hipStream_t st) {
+    const size_t total4 = (size_t)N * L.H * L.W * L.C / 4;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks256(total4)), dim3(256), 0, st, c, P(m, L.gamma), P(m, L.beta),
+                       1.0f / sqrtf(1.0f + kBnEps), kLrelu, total4, L.C, a);
+}
+constexpr int kBnBwdBlocks = 512;
+void bn_act_bwd(uad_gan* m, const Block& L, const float* da, const float* c, int N, float* dc, hipStream_t st) {
+    const float rs0 = 1.0f / sqrtf(1.0f + kBnEps);
+    const int rows = N * L.H * L.W;
+    const int rpb = (rows + kBnBwdBlocks - 1) / kBnBwdBlocks;
+    const int blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(blocks), dim3(256), 0, st, da, c, P(m, L.gamma), P(m, L.beta), rs0, kLrelu, rows,
+                       rpb, L.C, dc, m->colpart);
+    uad_launch_bn_grad_finalize(m->colpart, blocks, L.C, P(m, L.gamma), rs0, Gr(m, L.gamma), Gr(m, L.beta), Gr(m, L.b), st);
+}
+// raw[k] = scale * sum(...)
+template <int MODE>
+void reduce_to(uad_gan* m, int k, const float* a, const float* b, size_t n, float scale, float* map, hipStream_t st) {
+    hipLaunchKernelGGL((sum_kernel<MODE>), dim3(256), dim3(256), 0, st, a, b, n, map, m->redpart);
+    uad_launch_reduce_partials(m->redpart, 256, 1, scale, m->raw + k, st);
+}
+
+int refresh_packs(uad_gan* m, hipStream_t st) {
+    if (m->packed_valid) return UAD_OK;
+    long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
+    auto add = [&](const Block& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
+    for (size_t i = 1; i < m->E.size(); ++i) add(m->E[i]);
+    for (auto& L : m->G) add(L);
+    for (size_t i = 1; i < m->D.size(); ++i) add(m->D[i]);
+    if (np > 0) {
+        if (m->math == UAD_MATH_BF16X3)
+            uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
+        else
+            uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
+    }
+    m->packed_valid = true;
+    return UAD_OK;
+}
+
+// Conv2D block forward / data gradient / filter gradient (E and D), ConvT block likewise (G)
+void conv_fwd(uad_gan* m, const Block& L, int N, const float* in, float* out, bool bias, hipStream_t st) {
+    UadConvDesc d = L.d; d.N = N;
+    if (d.CB % 4) uad_launch_conv_first_fwd(d, in, P(m, L.w), bias ? P(m, L.b) : nullptr, out, st);
+    else uad_launch_conv_f(d, in, no_xform(), P(m, L.w), out, epi_bias(bias ? P(m, L.b) : nullptr), st, PKF(m, L.w), m->ws, PK16F(m, L.w), PLANE(L));
+}
+void conv_dgrad(uad_gan* m, const Block& L, int N, const float* g, float* out, hipStream_t st) {
+    UadConvDesc d = L.d; d.N = N;
+    if (d.CB % 4) uad_launch_conv_first_dgrad_plain(d, g, P(m, L.w), out, st);
+    else uad_launch_conv_d(d, g, no_xform(), P(m, L.w), out, epi_bias(nullptr), st, PKD(m, L.w), m->ws, PK16D(m, L.w), PLANE(L));
+}
+void conv_wgrad(uad_gan* m, const Block& L, int N, const float* in, const float* g, hipStream_t st) {
+    UadConvDesc d = L.d; d.N = N;
+    if (d.CB % 4) uad_launch_conv_first_wgrad(d, in, g, Gr(m, L.w), m->wpartial, st);
+    else uad_launch_conv_w(d, in, no_xform(), g, no_xform(), Gr(m, L.w), m->wpartial, st, m->math == UAD_MATH_BF16X3);
+}
+void convT_fwd(uad_gan* m, const Block& L, int N, const float* in, float* out, hipStream_t st) {
+    UadConvDesc d = L.d; d.N = N;
+    uad_launch_conv_d(d, in, no_xform(), P(m, L.w), out, epi_bias(P(m, L.b)), st, PKD(m, L.w), m->ws, PK16D(m, L.w), PLANE(L));
+}
+void convT_dgrad(uad_gan* m, const Block& L, int N, const float* g, float* out, hipStream_t st) {
+    UadConvDesc d = L.d; d.N = N;
+    uad_launch_conv_f(d, g, no_xform(), P(m, L.w), out, epi_bias(nullptr), st, PKF(m, L.w), m->ws, PK16F(m, L.w), PLANE(L));
+}
+void convT_wgrad(uad_gan* m, const Block& L, int N, const float* in, const float* g, hipStream_t st) {
+    UadConvDesc d = L.d; d.N = N;
+    uad_launch_conv_w(d, g, no_xform(), in, no_xform(), Gr(m, L.w), m->wpartial, st, m->math == UAD_MATH_BF16X3);
+}
+size_t asz(const Block& L) { return (size_t)L.H * L.W * L.C; }   // floats per sample of the block's output
+
+// ------------------------------------------------------------------------------------------------ Encoder
+void enc_forward(uad_gan* m, const float* x, const float* mask_z, int n, hipStream_t st) {
+    const int r = m->cfg.inter_res;
+    const float* in = x;
+    for (size_t i = 0; i < m->E.size(); ++i) {
+        conv_fwd(m, m->E[i], n, in, m->ec[i], true, st);
+        bn_act_fwd(m, m->E[i], m->ec[i], n, m->ea[i + 1], st);
+        in = m->ea[i + 1];
+    }
+    uad_launch_conv_f(conv1x1_desc(n, r, r, m->cenc, m->cmid), in, no_xform(), P(m, m->e_cw), m->et, epi_bias(P(m, m->e_cb)), st, nullptr, m->ws);
+    uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), m->et, no_xform(), P(m, m->e_dw), m->zr, epi_bias(P(m, m->e_db), mask_z), st, nullptr, m->ws);
+    const size_t nz = (size_t)n * m->cfg.zdim;
+    hipLaunchKernelGGL(tanh_kernel, dim3(blocks256(nz)), dim3(256), 0, st, m->zr, nz, m->z);
+}
+// dz = d loss / d z_enc in m->dzbuf; writes every Encoder gradient
+void enc_backward(uad_gan* m, const float* x, const float* mask_z, int n, hipStream_t st) {
+    const int r = m->cfg.inter_res, zd = m->cfg.zdim;
+    const size_t nz = (size_t)n * zd;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(blocks256(nz)), dim3(256), 0, st, m->dzbuf, m->z, mask_z, nz, m->dzr);
+    const UadConvDesc dd = dense_desc(n, m->flat, zd), dc1 = conv1x1_desc(n, r, r, m->cenc, m->cmid);
+    uad_launch_conv_w(dd, m->et, no_xform(), m->dzr, no_xform(), Gr(m, m->e_dw), m->wpartial, st);
+    uad_launch_colsum(m->dzr, n, zd, Gr(m, m->e_db), m->colscratch, st);
+    uad_launch_conv_d(dd, m->dzr, no_xform(), P(m, m->e_dw), m->dflat, epi_bias(nullptr), st, nullptr, m->ws);
+    uad_launch_conv_w(dc1, m->ea[m->E.size()], no_xform(), m->dflat, no_xform(), Gr(m, m->e_cw), m->wpartial, st);
+    uad_launch_colsum(m->dflat, n * r * r, m->cmid, Gr(m, m->e_cb), m->colscratch, st);
+    float* g = m->Ga; float* gn = m->Gb;
+    uad_launch_conv_d(dc1, m->dflat, no_xform(), P(m, m->e_cw), g, epi_bias(nullptr), st, nullptr, m->ws);
+    for (int i = (int)m->E.size() - 1; i >= 0; --i) {
+        bn_act_bwd(m, m->E[i], g, m->ec[i], n, gn, st);          // gn = d loss / d c_i ; gamma, beta, bias gradients
+        conv_wgrad(m, m->E[i], n, i == 0 ? x : m->ea[i], gn, st);
+        if (i > 0) conv_dgrad(m, m->E[i], n, gn, g, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Generator
+void gen_forward(uad_gan* m, const float* z, const float* mask_g, int n, hipStream_t st) {
+    const int r = m->cfg.inter_res;
+    uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), z, no_xform(), P(m, m->g_dw), m->gdv, epi_bias(P(m, m->g_db), mask_g), st, nullptr, m->ws);
+    uad_launch_conv_f(conv1x1_desc(n, r, r, m->cmid, m->cenc), m->gdv, no_xform(), P(m, m->g_cw), m->gc[0], epi_bias(P(m, m->g_cb)), st, nullptr, m->ws);
+    ln_fwd(m->gc[0], P(m, m->g_ln0g), P(m, m->g_ln0b), 0.0f, n, r * r, m->cenc, m->ga[0], m->gstat[0], st);
+    for (size_t i = 0; i < m->G.size(); ++i) {
+        const Block& L = m->G[i];
+        convT_fwd(m, L, n, m->ga[i], m->gc[i + 1], st);
+        ln_fwd(m->gc[i + 1], P(m, L.gamma), P(m, L.beta), kLrelu, n, L.H * L.W, L.C, m->ga[i + 1], m->gstat[i + 1], st);
+    }
+    const Block& LL = m->G.back();
+    const int rows = n * LL.H * LL.W;
+    hipLaunchKernelGGL((rowdot_kernel<true>), dim3(blocks256((size_t)rows * (LL.C / 4))), dim3(256), 0, st, m->ga[m->G.size()],
+                       P(m, m->g_fw), P(m, m->g_fb), rows, LL.C, m->xg);
+}
+// dx = d loss / d generator output (post-sigmoid); pg: Generator parameter gradients; dz_out: optional d loss / d z
+void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* dx, int n, bool pg, float* dz_out, hipStream_t st) {
+    const int r = m->cfg.inter_res;
+    const Block& LL = m->G.back();
+    const int rows = n * LL.H * LL.W;
+    float* g = m->Ga; float* gn = m->Gb;
+    {
+        const int rpb = (rows + 1023) / 1024, blocks = (rows + rpb - 1) / rpb;
+        hipLaunchKernelGGL(gfinal_bwd_kernel, dim3(blocks), dim3(256), 0, st, dx, m->xg, m->ga[m->G.size()], P(m, m->g_fw), rows, rpb,
+                           LL.C, g, pg ? m->finpart : nullptr);
+        if (pg) {
+            uad_launch_reduce_partials(m->finpart, blocks, LL.C + 1, 1.0f, m->colscratch, st);
+            hipMemcpyAsync(Gr(m, m->g_fw), m->colscratch, LL.C * sizeof(float), hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(Gr(m, m->g_fb), m->colscratch + LL.C, sizeof(float), hipMemcpyDeviceToDevice, st);
+        }
+    }
+    for (int i = (int)m->G.size() - 1; i >= 0; --i) {
+        const Block& L = m->G[i];
+        LnBwdArgs a;
+        memset(&a, 0, sizeof a);
+        a.da = g; a.c = m->gc[i + 1]; a.stats = m->gstat[i + 1]; a.gamma = P(m, L.gamma); a.beta = P(m, L.beta); a.alpha = kLrelu;
+        a.HW = L.H * L.W; a.C = L.C; a.dc = gn; a.gpart = pg ? m->lnpart_g : nullptr;
+        ln_bwd(a, n, st);
+        if (pg) {
+            uad_launch_reduce_partials(m->lnpart_g, n * (L.C / 32), 2 * a.HW, 1.0f, Gr(m, L.gamma), st);   // gamma | beta adjacent
+            convT_wgrad(m, L, n, m->ga[i], gn, st);
+            // a bias in front of a LayerNorm over (H, W) is removed by the mean subtraction: its gradient is identically zero
+            hipMemsetAsync(Gr(m, L.b), 0, L.C * sizeof(float), st);
+        }
+        convT_dgrad(m, L, n, gn, g, st);
+    }
+    LnBwdArgs a;
+    memset(&a, 0, sizeof a);
+    a.da = g; a.c = m->gc[0]; a.stats = m->gstat[0]; a.gamma = P(m, m->g_ln0g); a.beta = P(m, m->g_ln0b); a.alpha = 0.0f;
+    a.HW = r * r; a.C = m->cenc; a.dc = gn; a.gpart = pg ? m->lnpart_g : nullptr;
+    ln_bwd(a, n, st);
+    const UadConvDesc dc1 = conv1x1_desc(n, r, r, m->cmid, m->cenc), dd = dense_desc(n, m->cfg.zdim, m->flat);
+    if (pg) {
+        uad_launch_reduce_partials(m->lnpart_g, n * (m->cenc / 32), 2 * r * r, 1.0f, Gr(m, m->g_ln0g), st);
+        uad_launch_conv_w(dc1, m->gdv, no_xform(), gn, no_xform(), Gr(m, m->g_cw), m->wpartial, st);
+        hipMemsetAsync(Gr(m, m->g_cb), 0, m->cenc * sizeof(float), st);
+    }
+    uad_launch_conv_d(dc1, gn, no_xform(), P(m, m->g_cw), m->ddv, epi_bias(nullptr, mask_g), st, nullptr, m->ws);
+    if (pg) {
+        uad_launch_conv_w(dd, z, no_xform(), m->ddv, no_xform(), Gr(m, m->g_dw), m->wpartial, st);
+        uad_launch_colsum(m->ddv, n, m->flat, Gr(m, m->g_db), m->colscratch, st);
+    }
+    if (dz_out) uad_launch_conv_d(dd, m->ddv, no_xform(), P(m, m->g_dw), dz_out, epi_bias(nullptr), st, nullptr, m->ws);
+}
+
+// ------------------------------------------------------------------------------------------------ Critic
+// forward of N samples starting at din; head: also d = Dense(1)(features)
+void disc_forward(uad_gan* m, int N, bool head, hipStream_t st) {
+    const float* in = m->din;
+    for (size_t i = 0; i < m->D.size(); ++i) {
+        const Block& L = m->D[i];
+        conv_fwd(m, L, N, in, m->Dc[i], true, st);
+        ln_fwd(m->Dc[i], P(m, L.gamma), P(m, L.beta), kLrelu, N, L.H * L.W, L.C, m->Da[i + 1], m->Dstat[i], st);
+        in = m->Da[i + 1];
+    }
+    if (head) {
+        const Block& LL = m->D.back();
+        const int rows = N * LL.H * LL.W;
+        hipLaunchKernelGGL((rowdot_kernel<false>), dim3(blocks256((size_t)rows * (LL.C / 4))), dim3(256), 0, st, m->Da[m->D.size()],
+                           P(m, m->d_hw), P(m, m->d_hb), rows, LL.C, m->Dd);
+    }
+}
+// ordinary backward of the first N samples; the top gradient (d loss / d features) is in m->Ga.
+//   pg: parameter gradients, with pass C's pairs as an extra `ntail` samples of every filter gradient / LayerNorm partial set
+//   inject_lo >= 0: add m->inj[i] to d c_i of samples [inject_lo, inject_lo + ntail)
+//   dx_out: optional d loss / d input
+void disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float* dx_out, hipStream_t st) {
+    float* g = m->Ga; float* gn = m->Gb;
+    for (int i = (int)m->D.size() - 1; i >= 0; --i) {
+        const Block& L = m->D[i];
+        LnBwdArgs a;
+        memset(&a, 0, sizeof a);
+        a.da = g; a.c = m->Dc[i]; a.stats = m->Dstat[i]; a.gamma = P(m, L.gamma); a.beta = P(m, L.beta); a.alpha = kLrelu;
+        a.HW = L.H * L.W; a.C = L.C; a.dc = m->Dg[i]; a.gpart = pg ? m->lnpart[i] : nullptr;
+        if (inject_lo >= 0) { a.add = m->inj[i]; a.add_lo = inject_lo; a.add_hi = inject_lo + ntail; }
+        ln_bwd(a, N, st);
+        if (pg) {
+            uad_launch_reduce_partials(m->lnpart[i], (N + ntail) * (L.C / 32), 2 * a.HW, 1.0f, Gr(m, L.gamma), st);
+            conv_wgrad(m, L, N + ntail, i == 0 ? m->din : m->Da[i], m->Dg[i], st);
+            hipMemsetAsync(Gr(m, L.b), 0, L.C * sizeof(float), st);      // bias in front of LayerNorm-HW: zero gradient
+        }
+        if (i > 0) { conv_dgrad(m, L, N, m->Dg[i], gn, st); float* t = g; g = gn; gn = t; }
+        else if (dx_out) conv_dgrad(m, L, N, m->Dg[0], dx_out, st);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
+    if (!cfg || !out) return fail(UAD_ERR_INVALID, "null argument");
+    const int H = cfg->height;
+    if (H != cfg->width || H <= 0 || (H & (H - 1))) return fail(UAD_ERR_INVALID, "height/width must be equal powers of two");
+    if (cfg->inter_res <= 0 || (cfg->inter_res & (cfg->inter_res - 1)) || cfg->inter_res >= H)
+        return fail(UAD_ERR_INVALID, "inter_res must be a power of two smaller than height");
+    if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
+    if (cfg->zdim <= 0 || cfg->zdim % 8) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
+    if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
+    const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
+    if (npool < 2 || npool > 5) return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 2..5 blocks supported", npool);
+    if (H < 32) return fail(UAD_ERR_UNSUPPORTED, "height >= 32 needed");
+
+    uad_gan* m = new uad_gan();
+    m->cfg = *cfg;
+    m->npool = npool; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
+    m->step[0] = m->step[1] = m->step[2] = 0;
+    const int ir = cfg->inter_res;
+    char nm[160];
+    // ---- parameter table, TF variable-creation order (fanogan.py:15-58) ----
+    int cin = 1, res = H;
+    for (int i = 0; i < npool; ++i) {
+        const int f = (32 << i) < 128 ? (32 << i) : 128;
+        Block L;
+        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
+        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
+        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        std::string bs = i == 0 ? "Encoder/batch_normalization" : "Encoder/batch_normalization_" + std::to_string(i);
+        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
+        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
+        L.H = L.W = res / 2; L.C = f;
+        m->E.push_back(L);
+        cin = f; res /= 2;
+    }
+    m->cenc = cin; m->cmid = cin / 8; m->flat = ir * ir * m->cmid;
+    m->e_cw = add_tensor(m, "Encoder/conv2d/kernel", 4, 1, 1, m->cenc, m->cmid);
+    m->e_cb = add_tensor(m, "Encoder/conv2d/bias", 1, m->cmid, 1, 1, 1);
+    m->e_dw = add_tensor(m, "Encoder/dense/kernel", 2, m->flat, cfg->zdim, 1, 1);
+    m->e_db = add_tensor(m, "Encoder/dense/bias", 1, cfg->zdim, 1, 1, 1);
+    m->grp_off[UAD_GAN_ENCODER] = 0; m->grp_cnt[UAD_GAN_ENCODER] = m->nparams;
+    m->g_dw = add_tensor(m, "Generator/dense/kernel", 2, cfg->zdim, m->flat, 1, 1);
+    m->g_db = add_tensor(m, "Generator/dense/bias", 1, m->flat, 1, 1, 1);
+    m->g_cw = add_tensor(m, "Generator/conv2d_1/kernel", 4, 1, 1, m->cmid, m->cenc);
+    m->g_cb = add_tensor(m, "Generator/conv2d_1/bias", 1, m->cenc, 1, 1, 1);
+    int ln = 0;
+    auto ln_name = [&](const char* scope) { std::string r = std::string(scope) + (ln == 0 ? "layer_normalization" : "layer_normalization_" + std::to_string(ln)); ++ln; return r; };
+    { const std::string s = ln_name("Generator/"); m->g_ln0g = add_tensor(m, s + "/gamma", 2, ir, ir, 1, 1); m->g_ln0b = add_tensor(m, s + "/beta", 2, ir, ir, 1, 1); }
+    cin = m->cenc; res = ir;
+    for (int i = 0; i < npool; ++i) {
+        const int f = (128 >> i) > 32 ? (128 >> i) : 32;
+        Block L;
+        L.d = UadConvDesc{1, res * 2, res * 2, f, res, res, cin, 5, 2, 1};
+        snprintf(nm, sizeof nm, "Generator/dec_Conv2DT_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, f, cin);
+        snprintf(nm, sizeof nm, "Generator/dec_Conv2DT_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        res *= 2;
+        const std::string s = ln_name("Generator/");
+        L.gamma = add_tensor(m, s + "/gamma", 2, res, res, 1, 1);
+        L.beta = add_tensor(m, s + "/beta", 2, res, res, 1, 1);
+        L.H = L.W = res; L.C = f;
+        m->G.push_back(L);
+        cin = f;
+    }
+    m->g_fw = add_tensor(m, "Generator/dec_Conv2D_final/kernel", 4, 1, 1, cin, 1);
+    m->g_fb = add_tensor(m, "Generator/dec_Conv2D_final/bias", 1, 1, 1, 1, 1);
+    m->grp_off[UAD_GAN_GENERATOR] = m->grp_cnt[UAD_GAN_ENCODER];
+    m->grp_cnt[UAD_GAN_GENERATOR] = m->nparams - m->grp_off[UAD_GAN_GENERATOR];
+    cin = 1; res = H;
+    for (int i = 0; i < npool; ++i) {
+        const int f = (32 << i) < 128 ? (32 << i) : 128;
+        Block L;
+        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
+        snprintf(nm, sizeof nm, "Discriminator/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
+        snprintf(nm, sizeof nm, "Discriminator/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        res /= 2;
+        const std::string s = ln_name("Discriminator/");
+        L.gamma = add_tensor(m, s + "/gamma", 2, res, res, 1, 1);
+        L.beta = add_tensor(m, s + "/beta", 2, res, res, 1, 1);
+        L.H = L.W = res; L.C = f;
+        m->D.push_back(L);
+        cin = f;
+    }
+    m->d_hw = add_tensor(m, "Discriminator/dense/kernel", 2, cin, 1, 1, 1);
+    m->d_hb = add_tensor(m, "Discriminator/dense/bias", 1, 1, 1, 1, 1);
+    m->grp_off[UAD_GAN_DISCRIMINATOR] = m->grp_off[UAD_GAN_GENERATOR] + m->grp_cnt[UAD_GAN_GENERATOR];
+    m->grp_cnt[UAD_GAN_DISCRIMINATOR] = m->nparams - m->grp_off[UAD_GAN_DISCRIMINATOR];
+    if (m->cmid % 8 || m->flat % 8) { delete m; return fail(UAD_ERR_UNSUPPORTED, "bottleneck channels must be a multiple of 8"); }
+
+    // ---- device memory ----
+    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H;
+    int rc = UAD_OK;
+#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
+    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
+    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
+    ALLOC(m->wpack_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack_d, (size_t)m->nparams, nullptr);
+    ALLOC(m->wpack16_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack16_d, (size_t)m->nparams, nullptr);
+    size_t maxact = 3 * NB * HW;
+    m->ec.resize(npool); m->ea.resize(npool + 1, nullptr);
+    for (int i = 0; i < npool; ++i) {
+        const size_t s = NB * asz(m->E[i]);
+        snprintf(nm, sizeof nm, "ec%d", i); ALLOC(m->ec[i], s, nm);
+        snprintf(nm, sizeof nm, "ea%d", i + 1); ALLOC(m->ea[i + 1], s, nm);
+        if (s > maxact) maxact = s;
+    }
+    ALLOC(m->et, NB * m->flat, "et"); ALLOC(m->zr, NB * cfg->zdim, "zr"); ALLOC(m->z, NB * cfg->zdim, "z");
+    ALLOC(m->gdv, NB * m->flat, "gdv"); ALLOC(m->xg, NB * HW, "xg");
+    m->gc.resize(npool + 1); m->ga.resize(npool + 1); m->gstat.resize(npool + 1);
+    size_t lnp_g = 0;
+    for (int i = 0; i <= npool; ++i) {
+        const size_t per = i == 0 ? (size_t)ir * ir * m->cenc : asz(m->G[i - 1]);
+        const int C = i == 0 ? m->cenc : m->G[i - 1].C;
+        snprintf(nm, sizeof nm, "gc%d", i); ALLOC(m->gc[i], NB * per, nm);
+        snprintf(nm, sizeof nm, "ga%d", i); ALLOC(m->ga[i], NB * per, nm);
+        ALLOC(m->gstat[i], NB * 2 * C, nullptr);
+        if (NB * per > maxact) maxact = NB * per;
+        const size_t lp = NB * (C / 32) * 2 * (per / C);
+        if (lp > lnp_g) lnp_g = lp;
+    }
+    ALLOC(m->lnpart_g, lnp_g, nullptr);
+    ALLOC(m->din, 4 * NB * HW, "din");
+    m->Dc.resize(npool); m->Dstat.resize(npool); m->Da.resize(npool + 1, nullptr); m->Dg.resize(npool); m->V.resize(npool);
+    m->inj.resize(npool); m->lnpart.resize(npool);
+    size_t maxc = 0;
+    for (int i = 0; i < npool; ++i) {
+        const Block& L = m->D[i];
+        const size_t per = asz(L);
+        snprintf(nm, sizeof nm, "Dc%d", i); ALLOC(m->Dc[i], 3 * NB * per, nm);
+        ALLOC(m->Dstat[i], 3 * NB * 2 * L.C, nullptr);
+        snprintf(nm, sizeof nm, "Da%d", i + 1); ALLOC(m->Da[i + 1], 4 * NB * per, nm);
+        snprintf(nm, sizeof nm, "Dg%d", i); ALLOC(m->Dg[i], 4 * NB * per, nm);
+        snprintf(nm, sizeof nm, "V%d", i); ALLOC(m->V[i], NB * per, nm);
+        snprintf(nm, sizeof nm, "inj%d", i); ALLOC(m->inj[i], NB * per, nm);
+        ALLOC(m->lnpart[i], 4 * NB * (L.C / 32) * 2 * L.H * L.W, nullptr);
+        if (3 * NB * per > maxact) maxact = 3 * NB * per;
+        if (per > maxc) maxc = per;
+    }
+    ALLOC(m->Q, NB * maxc, "Q");
+    ALLOC(m->Dd, 3 * NB * ir * ir, "Dd"); ALLOC(m->Gx, NB * HW, "Gx"); ALLOC(m->slopes, NB * H, "slopes");
+    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
+    ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->dzbuf, NB * cfg->zdim, "dz"); ALLOC(m->dzr, NB * cfg->zdim, nullptr);
+    ALLOC(m->dflat, NB * m->flat, nullptr); ALLOC(m->ddv, NB * m->flat, nullptr);
+    {
+        size_t wp = 0;
+        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
+        for (size_t i = 1; i < m->E.size(); ++i) wp_need(m->E[i].d, NB);
+        for (auto& L : m->G) wp_need(L.d, NB);
+        for (size_t i = 1; i < m->D.size(); ++i) wp_need(m->D[i].d, 4 * NB);
+        wp_need(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), NB); wp_need(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB);
+        wp_need(dense_desc(1, m->flat, cfg->zdim), NB); wp_need(dense_desc(1, cfg->zdim, m->flat), NB);
+        { UadConvDesc d0 = m->D[0].d; d0.N = (int)(4 * NB); size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
+        ALLOC(m->wpartial, wp, nullptr);
+        size_t need = (size_t)4 << 20;
+        auto want = [&](UadConvDesc d, size_t n, bool f, bool pack) { d.N = (int)n; size_t v = uad_conv_ws_floats(d, f, pack); if (v > need) need = v; };
+        for (size_t i = 1; i < m->E.size(); ++i) { want(m->E[i].d, NB, true, true); want(m->E[i].d, NB, false, true); }
+        for (auto& L : m->G) { want(L.d, NB, true, true); want(L.d, NB, false, true); }
+        for (size_t i = 1; i < m->D.size(); ++i) { want(m->D[i].d, 3 * NB, true, true); want(m->D[i].d, 3 * NB, false, true); want(m->D[i].d, NB, true, true); want(m->D[i].d, NB, false, true); }
+        for (int f = 0; f < 2; ++f) {
+            want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), NB, f, false); want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB, f, false);
+            want(dense_desc(1, m->flat, cfg->zdim), NB, f, false); want(dense_desc(1, cfg->zdim, m->flat), NB, f, false);
+        }
+        m->ws.floats = need; m->ws.ptr = nullptr;
+        ALLOC(m->ws.ptr, need, nullptr);
+    }
+    ALLOC(m->colscratch, 64 * 1024, nullptr); ALLOC(m->colpart, (size_t)kBnBwdBlocks * 2 * 128, nullptr);
+    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
+    ALLOC(m->finpart, (size_t)1024 * 65, nullptr);
+#undef ALLOC
+    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
+    *out = m;
+    return UAD_OK;
+}
+
+int uad_gan_destroy(uad_gan_t* m) {
+    if (!m) return UAD_OK;
+    for (void* p : m->allocs) hipFree(p);
+    delete m;
+    return UAD_OK;
+}
+long long uad_gan_param_count(const uad_gan_t* m) { return m ? m->nparams : 0; }
+int uad_gan_num_tensors(const uad_gan_t* m) { return m ? (int)m->tensors.size() : 0; }
+int uad_gan_tensor_info(const uad_gan_t* m, int idx, char* name, int name_cap, long long* offset, int* rank, int* shape4) {
+    if (!m || idx < 0 || idx >= (int)m->tensors.size()) return fail(UAD_ERR_INVALID, "tensor index out of range");
+    const Tensor& t = m->tensors[idx];
+    if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = t.off;
+    if (rank) *rank = t.rank;
+    if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+    return UAD_OK;
+}
+float* uad_gan_buffer(uad_gan_t* m, int which) {
+    if (!m) return nullptr;
+    switch (which) {
+        case UAD_BUF_PARAMS: return m->params;
+        case UAD_BUF_GRADS: return m->grads;
+        case UAD_BUF_ADAM_M: return m->adam_m;
+        case UAD_BUF_ADAM_V: return m->adam_v;
+    }
+    return nullptr;
+}
+int uad_gan_group(const uad_gan_t* m, int group, long long* offset, long long* count) {
+    if (!m || group < 0 || group > 2) return fail(UAD_ERR_INVALID, "bad group");
+    if (offset) *offset = m->grp_off[group];
+    if (count) *count = m->grp_cnt[group];
+    return UAD_OK;
+}
+int uad_gan_set_buffer(uad_gan_t* m, int which, const float* host, long long count) {
+    float* p = uad_gan_buffer(m, which);
+    if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "gan set_buffer: bad arguments (count=%lld, expected %lld)", count, m ? m->nparams : -1);
+    HIP_TRY(hipMemcpy(p, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+    if (which == UAD_BUF_PARAMS) m->packed_valid = false;
+    return UAD_OK;
+}
+int uad_gan_get_buffer(uad_gan_t* m, int which, float* host, long long count) {
+    float* p = uad_gan_buffer(m, which);
+    if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "gan get_buffer: bad arguments");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return UAD_OK;
+}
+int uad_gan_set_math_mode(uad_gan_t* m, int mode) {
+    if (!m || (mode != UAD_MATH_F32 && mode != UAD_MATH_BF16X3)) return fail(UAD_ERR_INVALID, "bad math mode");
+    m->math = mode; m->packed_valid = false;
+    return UAD_OK;
+}
+long long uad_gan_get_step(const uad_gan_t* m, int group) { return (m && group >= 0 && group < 3) ? m->step[group] : 0; }
+int uad_gan_set_step(uad_gan_t* m, int group, long long t) {
+    if (!m || group < 0 || group > 2 || t < 0) return fail(UAD_ERR_INVALID, "bad group / step");
+    m->step[group] = t;
+    return UAD_OK;
+}
+int uad_gan_debug_buffer(uad_gan_t* m, const char* name, float** ptr, long long* count) {
+    if (!m || !name) return fail(UAD_ERR_INVALID, "null argument");
+    auto it = m->dbg.find(name);
+    if (it == m->dbg.end()) return fail(UAD_ERR_INVALID, "no debug buffer named %s", name);
+    if (ptr) *ptr = it->second.first;
+    if (count) *count = it->second.second;
+    return UAD_OK;
+}
+
+int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int want_backward, void* stream) {
+    if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
+    if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
+    if (phase < 0 || phase > 2) return fail(UAD_ERR_INVALID, "bad phase");
+    hipStream_t st = (hipStream_t)stream;
+    const int H = m->cfg.height, ir = m->cfg.inter_res, L = m->npool;
+    const size_t HW = (size_t)H * H, img = (size_t)n * HW;
+    const int P2 = ir * ir;                        // feature-map locations per sample
+    const Block& DL = m->D.back();
+    float* scal = io->scalars ? io->scalars : m->scalars_own;
+    refresh_packs(m, st);
+
+    if (phase == UAD_GAN_GENERATOR) {
+        // trainers/fAnoGAN.py:52,75: gen_loss = -mean(D(G(z))), gradient w.r.t. the Generator variables
+        if (!io->z) return fail(UAD_ERR_INVALID, "generator phase needs io.z");
+        gen_forward(m, io->z, io->mask_g, n, st);
+        HIP_TRY(hipMemcpyAsync(m->din, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        disc_forward(m, n, true, st);
+        reduce_to<0>(m, 0, m->Dd, nullptr, (size_t)n * P2, 1.0f / (float)(n * P2), nullptr, st);
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, phase, m->raw, m->cfg.kappa, scal);
+        if (want_backward) {
+            Coef4 cf{{-1.0f / (float)(n * P2), 0.f, 0.f, 0.f}};
+            const size_t t4 = (size_t)n * P2 * DL.C / 4;
+            hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, DL.C, t4, cf, m->Ga);
+            disc_backward(m, n, false, 0, -1, m->dxbuf, st);
+            gen_backward(m, io->z, io->mask_g, m->dxbuf, n, true, nullptr, st);
+        }
+        if (io->generated) HIP_TRY(hipMemcpyAsync(io->generated, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (phase == UAD_GAN_DISCRIMINATOR) {
+        // trainers/fAnoGAN.py:50-58,74
+        if (!io->z || !io->x || !io->alpha) return fail(UAD_ERR_INVALID, "critic phase needs io.x, io.z and io.alpha");
+        gen_forward(m, io->z, io->mask_g, n, st);
+        hipLaunchKernelGGL(interp_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, io->alpha, (int)HW, img, m->din);
+        disc_forward(m, 3 * n, true, st);                                                         // pass A
+        reduce_to<0>(m, 0, m->Dd, nullptr, (size_t)n * P2, 1.0f / (float)(n * P2), nullptr, st);
+        reduce_to<0>(m, 1, m->Dd + (size_t)n * P2, nullptr, (size_t)n * P2, 1.0f / (float)(n * P2), nullptr, st);
+        // pass B: ddx = d sum(d_hat) / d x_hat on samples [2n, 3n)
+        {
+            Coef4 one{{1.f, 1.f, 1.f, 1.f}};
+            const size_t t4 = (size_t)n * P2 * DL.C / 4;
+            float* u = m->Ga; float* un = m->Gb;
+            hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, DL.C, t4, one, u);
+            for (int i = L - 1; i >= 0; --i) {
+                const Block& B = m->D[i];
+                const size_t per = asz(B);
+                LnBwdArgs a;
+                memset(&a, 0, sizeof a);
+                a.da = u; a.c = m->Dc[i] + 2 * n * per; a.stats = m->Dstat[i] + (size_t)2 * n * 2 * B.C;
+                a.gamma = P(m, B.gamma); a.beta = P(m, B.beta); a.alpha = kLrelu; a.HW = B.H * B.W; a.C = B.C;
+                a.dc = m->Dg[i] + 3 * n * per; a.v_out = m->V[i];
+                ln_bwd(a, n, st);
+                if (i > 0) { conv_dgrad(m, B, n, a.dc, un, st); float* t = u; u = un; un = t; }
+                else conv_dgrad(m, B, n, a.dc, m->Gx, st);
+            }
+        }
+        const int cols = n * H;
+        hipLaunchKernelGGL(pen_col_kernel, dim3(blocks256(cols)), dim3(256), 0, st, m->Gx, n, H, H, m->slopes, m->redpart);
+        uad_launch_reduce_partials(m->redpart, (int)blocks256(cols), 1, m->cfg.scale / (float)cols, m->raw + 2, st);
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, phase, m->raw, m->cfg.kappa, scal);
+        if (want_backward) {
+            // pass C, bottom-up: adjoint of pass B.  ubar_0 = d penalty / d ddx lives in din's tail.
+            hipLaunchKernelGGL(pen_grad_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->Gx, m->slopes,
+                               m->cfg.scale * 2.0f / (float)cols, H, H, img, m->din + 3 * img);
+            for (int i = 0; i < L; ++i) {
+                const Block& B = m->D[i];
+                const size_t per = asz(B);
+                const float* ubar = i == 0 ? m->din + 3 * img : m->Da[i] + 3 * n * asz(m->D[i - 1]);
+                conv_fwd(m, B, n, ubar, m->Q, false, st);                 // adjoint of the data gradient w.r.t. its input
+                LnBwd2Args a;
+                memset(&a, 0, sizeof a);
+                a.q = m->Q; a.v = m->V[i]; a.c = m->Dc[i] + 2 * n * per; a.stats = m->Dstat[i] + (size_t)2 * n * 2 * B.C;
+                a.gamma = P(m, B.gamma); a.beta = P(m, B.beta); a.alpha = kLrelu; a.HW = B.H * B.W; a.C = B.C;
+                a.ubar = m->Da[i + 1] + 3 * n * per; a.inj = m->inj[i]; a.gpart = m->lnpart[i]; a.slot0 = 3 * n;
+                ln_bwd2(a, n, st);
+            }
+            // pass D: ordinary backward of all 3n samples; top gradient +1/(n P) fake, -1/(n P) real, 0 for x_hat
+            const float k = 1.0f / (float)(n * P2);
+            Coef4 cf{{k, -k, 0.f, 1.f}};
+            const size_t t4 = (size_t)3 * n * P2 * DL.C / 4;
+            hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, DL.C, t4, cf, m->Ga);
+            {   // Dense(1): kernel gradient over the 3n feature rows (coefficient per third) + pass C's adjoint rows (coefficient 1)
+                const int rows = 4 * n * P2, rpb = (rows + 255) / 256, blocks = (rows + rpb - 1) / rpb;
+                hipLaunchKernelGGL(coef_colsum_kernel, dim3(blocks), dim3(256), 0, st, m->Da[L], rows, rpb, n * P2, DL.C, cf, m->finpart);
+                uad_launch_reduce_partials(m->finpart, blocks, DL.C, 1.0f, Gr(m, m->d_hw), st);
+                HIP_TRY(hipMemsetAsync(Gr(m, m->d_hb), 0, sizeof(float), st));   // +1/(nP) over the fake rows, -1/(nP) over the real rows
+            }
+            disc_backward(m, 3 * n, true, n, 2 * n, nullptr, st);
+        }
+        if (io->generated) HIP_TRY(hipMemcpyAsync(io->generated, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        // trainers/fAnoGAN.py:60-66,76: enc_loss = MSE(x, x_enc) + kappa * MSE(features(x_enc), features(x)) w.r.t. the Encoder
+        if (!io->x) return fail(UAD_ERR_INVALID, "encoder phase needs io.x");
+        enc_forward(m, io->x, io->mask_z, n, st);
+        gen_forward(m, m->z, io->mask_g, n, st);
+        HIP_TRY(hipMemcpyAsync(m->din, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(m->din + img, io->x, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        disc_forward(m, 2 * n, false, st);
+        const size_t nf = (size_t)n * P2 * DL.C;
+        const float* f_enc = m->Da[L];
+        const float* f_real = m->Da[L] + nf;
+        reduce_to<1>(m, 0, io->x, m->xg, img, 1.0f / (float)img, nullptr, st);
+        reduce_to<1>(m, 1, f_enc, f_real, nf, 1.0f / (float)nf, nullptr, st);
+        reduce_to<2>(m, 2, io->x, m->xg, img, 1.0f / (float)n, io->l1_map, st);
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, phase, m->raw, m->cfg.kappa, scal);
+        if (want_backward) {
+            hipLaunchKernelGGL((diff_scale_kernel<false>), dim3(blocks256(nf)), dim3(256), 0, st, f_enc, f_real,
+                               m->cfg.kappa * 2.0f / (float)nf, nf, m->Ga);
+            disc_backward(m, n, false, 0, -1, m->dxbuf, st);
+            hipLaunchKernelGGL((diff_scale_kernel<true>), dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, 2.0f / (float)img, img, m->dxbuf);
+            gen_backward(m, m->z, io->mask_g, m->dxbuf, n, false, m->dzbuf, st);
+            enc_backward(m, io->x, io->mask_z, n, st);
+        }
+        if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+int uad_gan_reconstruct(uad_gan_t* m, const uad_gan_io_t* io, int n, void* stream) {
+    if (!m || !io || !io->x) return fail(UAD_ERR_INVALID, "null argument");
+    if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t img = (size_t)n * m->cfg.height * m->cfg.width;
+    refresh_packs(m, st);
+    enc_forward(m, io->x, io->mask_z, n, st);
+    gen_forward(m, m->z, io->mask_g, n, st);
+    if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (io->l1_map) hipLaunchKernelGGL((sum_kernel<2>), dim3(256), dim3(256), 0, st, io->x, m->xg, img, io->l1_map, m->redpart);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+int uad_gan_adam(uad_gan_t* m, int group, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (!m || group < 0 || group > 2) return fail(UAD_ERR_INVALID, "bad group");
+    m->step[group] += 1;
+    const double t = (double)m->step[group];
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    const long long off = m->grp_off[group];
+    m->packed_valid = false;
+    uad_launch_adam(m->params + off, m->grads + off, m->adam_m + off, m->adam_v + off, (size_t)m->grp_cnt[group], lr_t, beta1, beta2,
+                    eps, grad_scale, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+}  // extern "C"

@@ -419,6 +419,7 @@ __device__ __forceinline__ void first_dgrad_store(const FirstDgradEpi& e, size_t
         if (e.x_upd) e.x_upd[pix] -= e.restore_lr * gx;
         return;
     }
+    if (!e.x) { e.dx_out[pix] = acc; return; }      // plain data gradient (f-AnoGAN critic)
     const float diff = e.x[pix] - e.x_hat[pix];
     const float gx = acc + (diff > 0.f ? e.inv_batch : (diff < 0.f ? -e.inv_batch : 0.f));
     if (e.dx_out) e.dx_out[pix] = gx;
@@ -565,6 +566,7 @@ __global__ void __launch_bounds__(256) conv_first_dgrad_kernel(UadConvDesc d, co
         if (x_upd) x_upd[pix] -= restore_lr * gx;
         return;
     }
+    if (!x) { dx_out[pix] = acc; return; }          // plain data gradient
     const float diff = x[pix] - x_hat[pix];
     const float gx = acc + (diff > 0.f ? inv_batch : (diff < 0.f ? -inv_batch : 0.f));
     if (dx_out) dx_out[pix] = gx;
@@ -734,6 +736,9 @@ void uad_launch_conv_first_dgrad_restore(const UadConvDesc& d, const float* g, c
     hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3((total + 255) / 256), dim3(256),
                        (size_t)d.KS * d.KS * d.CS * sizeof(float), st, d, g, W, (const float*)nullptr,
                        (const float*)nullptr, 0.f, (float*)nullptr, dx, dxhat, x_upd, restore_lr);
+}
+void uad_launch_conv_first_dgrad_plain(const UadConvDesc& d, const float* g, const float* W, float* dx, hipStream_t st) {
+    uad_launch_conv_first_dgrad(d, g, W, nullptr, nullptr, 0.f, nullptr, dx, st);
 }
 void uad_launch_mul(const float* x, const float* mask, float* y, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(mul_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, mask, y, n);

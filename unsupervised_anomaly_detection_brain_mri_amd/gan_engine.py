@@ -1,0 +1,179 @@
+"""Host-side handle around the f-AnoGAN C-ABI (include/uad_hip.h, uad_gan_*): what a tf.Session + the fanogan graph hold in
+the reference (trainers/fAnoGAN.py:18-43) -- the three variable groups, their Adam slots and the compiled phases.  PyTorch is
+plumbing only (device buffers, the current HIP stream, zero-copy views for the RCCL all-reduce)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import _DevArray, _ptr
+
+GROUPS = {'Encoder': _lib.GAN_ENCODER, 'Generator': _lib.GAN_GENERATOR, 'Discriminator': _lib.GAN_DISCRIMINATOR}
+
+
+class GanEngine:
+    def __init__(self, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, scale=10.0, kappa=1.0,
+                 device=None, math='bf16x3'):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        torch.cuda.set_device(self.device)
+        self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
+        cfg = _lib.UadGanConfig(height, width, channels, inter_res, zdim, max_batch, float(scale), float(kappa))
+        h = C.c_void_p()
+        _lib.check(self.lib.uad_gan_create(C.byref(cfg), C.byref(h)))
+        self.handle = h
+        self.nparams = int(self.lib.uad_gan_param_count(h))
+        self.spec = []
+        name = C.create_string_buffer(160)
+        off, rank, shape = C.c_longlong(), C.c_int(), (C.c_int * 4)()
+        for i in range(self.lib.uad_gan_num_tensors(h)):
+            _lib.check(self.lib.uad_gan_tensor_info(h, i, name, 160, C.byref(off), C.byref(rank), shape))
+            self.spec.append((name.value.decode(), tuple(shape[:rank.value]), int(off.value)))
+        self.flat = [s for n, s, _ in self.spec if n == 'Generator/dense/kernel'][0][1]
+        self._views = {}
+        self.set_math(math)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            torch.cuda.synchronize(self.device)
+            self.lib.uad_gan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_math(self, math):
+        modes = {'f32': _lib.MATH_F32, 'bf16x3': _lib.MATH_BF16X3}
+        if math not in modes:
+            raise ValueError(f'unknown math mode {math!r}')
+        _lib.check(self.lib.uad_gan_set_math_mode(self.handle, modes[math]))
+        self.math = math
+
+    # ---------------------------------------------------------------- buffers
+    def buffer(self, which=_lib.BUF_PARAMS):
+        if which not in self._views:
+            ptr = self.lib.uad_gan_buffer(self.handle, which)
+            self._views[which] = torch.as_tensor(_DevArray(ptr, self.nparams), device=self.device)
+        return self._views[which]
+
+    def group(self, group):
+        off, cnt = C.c_longlong(), C.c_longlong()
+        _lib.check(self.lib.uad_gan_group(self.handle, GROUPS.get(group, group), C.byref(off), C.byref(cnt)))
+        return int(off.value), int(cnt.value)
+
+    def set_params(self, params):
+        if isinstance(params, dict):
+            flat = np.concatenate([np.asarray(params[n], np.float32).reshape(-1) for n, _, _ in self.spec])
+        else:
+            flat = np.ascontiguousarray(params, np.float32).reshape(-1)
+        _lib.check(self.lib.uad_gan_set_buffer(self.handle, _lib.BUF_PARAMS, flat.ctypes.data_as(C.c_void_p), flat.size))
+
+    def get_buffer_host(self, which=_lib.BUF_PARAMS):
+        torch.cuda.synchronize(self.device)
+        out = np.empty(self.nparams, np.float32)
+        _lib.check(self.lib.uad_gan_get_buffer(self.handle, which, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def set_buffer_host(self, which, flat):
+        flat = np.ascontiguousarray(flat, np.float32).reshape(-1)
+        _lib.check(self.lib.uad_gan_set_buffer(self.handle, which, flat.ctypes.data_as(C.c_void_p), flat.size))
+
+    def unflatten(self, flat):
+        return {n: flat[o:o + int(np.prod(s))].reshape(s) for n, s, o in self.spec}
+
+    def get_params(self):
+        return self.unflatten(self.get_buffer_host(_lib.BUF_PARAMS))
+
+    def get_grads(self):
+        return self.unflatten(self.get_buffer_host(_lib.BUF_GRADS))
+
+    def step_count(self, group):
+        return int(self.lib.uad_gan_get_step(self.handle, GROUPS.get(group, group)))
+
+    def set_step_count(self, group, t):
+        _lib.check(self.lib.uad_gan_set_step(self.handle, GROUPS.get(group, group), int(t)))
+
+    def debug_buffer(self, name):
+        """tests: torch view of a named intermediate of the last phase."""
+        ptr, cnt = C.c_void_p(), C.c_longlong()
+        _lib.check(self.lib.uad_gan_debug_buffer(self.handle, name.encode(), C.byref(ptr), C.byref(cnt)))
+        return torch.as_tensor(_DevArray(ptr.value, cnt.value), device=self.device)
+
+    def _dev(self, a, shape=None):
+        if a is None:
+            return None
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, np.float32))
+        t = t.to(self.device, torch.float32).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f'expected shape {tuple(shape)}, got {tuple(t.shape)}')
+        return t
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---------------------------------------------------------------- phases
+    def phase(self, group, x=None, z=None, alpha=None, mask_z=None, mask_g=None, want_backward=True, want_images=True,
+              want_l1=False):
+        """Run one phase ('Generator' | 'Discriminator' | 'Encoder').  Returns a dict of device tensors: the 0-d losses of the
+        phase (trainers/fAnoGAN.py:50-66 names) and, per phase, 'generated' | 'reconstruction', 'z_enc', 'L1'."""
+        g = GROUPS[group]
+        n = (x if x is not None else z).shape[0]
+        img = (n, self.h, self.w, self.c)
+        x = self._dev(x, img)
+        z = self._dev(z, (n, self.zdim))
+        alpha = self._dev(None if alpha is None else np.asarray(alpha, np.float32).reshape(-1) if not isinstance(alpha, torch.Tensor) else alpha.reshape(-1), (n,))
+        mask_z = self._dev(mask_z, (n, self.zdim))
+        mask_g = self._dev(mask_g, (n, self.flat))
+        out = {}
+        scal = torch.zeros(16, device=self.device)
+        io = _lib.UadGanIO()
+        io.x, io.z, io.alpha, io.mask_z, io.mask_g = _ptr(x), _ptr(z), _ptr(alpha), _ptr(mask_z), _ptr(mask_g)
+        io.scalars = _ptr(scal)
+        if g == _lib.GAN_ENCODER:
+            if want_images:
+                out['reconstruction'] = torch.empty(img, device=self.device)
+                io.reconstruction = _ptr(out['reconstruction'])
+            out['z_enc'] = torch.empty((n, self.zdim), device=self.device)
+            io.z_enc = _ptr(out['z_enc'])
+            if want_l1:
+                out['L1'] = torch.empty(img, device=self.device)
+                io.l1_map = _ptr(out['L1'])
+        elif want_images:
+            out['generated'] = torch.empty(img, device=self.device)
+            io.generated = _ptr(out['generated'])
+        _lib.check(self.lib.uad_gan_phase(self.handle, g, C.byref(io), n, 1 if want_backward else 0, self._stream()))
+        names = {_lib.GAN_GENERATOR: ('gen_loss', 'disc_fake'),
+                 _lib.GAN_DISCRIMINATOR: ('gen_loss', 'disc_fake', 'disc_real', 'penalty', 'disc_loss'),
+                 _lib.GAN_ENCODER: ('loss_img', 'loss_fts', 'enc_loss', 'reconstructionLoss')}[g]
+        for k in names:
+            out[k] = scal[_lib.GAN_SCALARS.index(k)]
+        if g == _lib.GAN_ENCODER:
+            out['loss'] = out['reconstructionLoss']
+        self._keep = (x, z, alpha, mask_z, mask_g, scal, out)
+        return out
+
+    def adam(self, group, lr, beta1=0.5, beta2=0.9, eps=1e-8, grad_scale=1.0):
+        _lib.check(self.lib.uad_gan_adam(self.handle, GROUPS[group], lr, beta1, beta2, eps, grad_scale, self._stream()))
+
+    def reconstruct(self, x, mask_z=None, mask_g=None, want_l1=False):
+        n = x.shape[0]
+        img = (n, self.h, self.w, self.c)
+        x = self._dev(x, img)
+        mask_z = self._dev(mask_z, (n, self.zdim))
+        mask_g = self._dev(mask_g, (n, self.flat))
+        out = {'reconstruction': torch.empty(img, device=self.device), 'z_enc': torch.empty((n, self.zdim), device=self.device)}
+        io = _lib.UadGanIO()
+        io.x, io.mask_z, io.mask_g = _ptr(x), _ptr(mask_z), _ptr(mask_g)
+        io.reconstruction, io.z_enc = _ptr(out['reconstruction']), _ptr(out['z_enc'])
+        if want_l1:
+            out['L1'] = torch.empty(img, device=self.device)
+            io.l1_map = _ptr(out['L1'])
+        _lib.check(self.lib.uad_gan_reconstruct(self.handle, C.byref(io), n, self._stream()))
+        self._keep = (x, mask_z, mask_g, out)
+        return out
