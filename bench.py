@@ -191,6 +191,94 @@ def bench_gmvae(args):
         dist.destroy_process_group()
 
 
+def bench_fanogan(args):
+    """BASELINE.json configs[3] shape (64x64) on the unified f-AnoGAN graph (models/fanogan.py -- the graph north_star names;
+    the ResNet `fanogan_schlegl` variant is not built).  One 'step' = one batch iteration of the reference's WGAN stage
+    (trainers/fAnoGAN.py:97-130): 1 generator step + 5 critic steps (each incl. the second-order gradient-penalty backward) +
+    their Adam updates; value = slices per second through that loop.  The encoder stage (izi_f) is timed beside it."""
+    import torch
+    import torch.distributed as dist
+    from unsupervised_anomaly_detection_brain_mri_amd.gan_engine import GanEngine
+    from unsupervised_anomaly_detection_brain_mri_amd.parallel import GanDataParallel
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import synthetic_slices
+    world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    hh, bs, zd = args.size or 64, BATCH, 128
+    eng = GanEngine(hh, hh, 1, 8, zd, max_batch=bs, device=f'cuda:{local_rank}', math=args.math)
+    rng = np.random.default_rng(3)
+    flat = np.zeros(eng.nparams, np.float32)
+    for name, shape, off in eng.spec:
+        cnt = int(np.prod(shape))
+        if name.endswith('kernel'):
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            lim = np.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf))
+            flat[off:off + cnt] = rng.uniform(-lim, lim, cnt)
+        elif name.endswith('gamma'):
+            flat[off:off + cnt] = 1.0
+    eng.set_params(flat)
+    dp = GanDataParallel(eng, world)
+    dp.broadcast_params(0)
+    x = torch.from_numpy(synthetic_slices(bs, hh, hh, seed=1000 + rank)).cuda()
+    g = torch.Generator(device='cuda').manual_seed(1 + rank)
+    zs = [torch.randn(bs, zd, device='cuda', generator=g) for _ in range(6)]
+    al = [torch.rand(bs, device='cuda', generator=g) for _ in range(5)]
+    lr = 1e-4
+
+    def wgan_step():
+        dp.train_phase('Generator', lr, z=zs[0], want_images=False)
+        for k in range(5):
+            out = dp.train_phase('Discriminator', lr, x=x, z=zs[k + 1], alpha=al[k], want_images=False)
+        return out
+
+    def enc_step():
+        return dp.train_phase('Encoder', lr, x=x, want_images=False)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    dt, out = timed(wgan_step, args.steps, args.warmup)
+    assert bool(torch.isfinite(out['disc_loss']))
+    dt_e, out_e = timed(enc_step, args.steps, max(args.warmup, 1))
+    assert bool(torch.isfinite(out_e['enc_loss']))
+    if rank == 0:
+        value = bs * world * args.steps / dt
+        res = {'metric': f'MRI slices/sec f-AnoGAN WGAN-GP batch iteration (1 G + 5 D steps, {hh}x{hh}, bs={bs}/GPU)',
+               'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': args.math, 'data': 'synthetic',
+               'config': {'workload': f'BASELINE.json configs[3] shape: unified f-AnoGAN graph (models/fanogan.py) {hh}x{hh}x1, zDim {zd}, '
+                                      f'{bs} slices per GPU; step = 1 generator + 5 critic phases with Adam (trainers/fAnoGAN.py:97-130)',
+                          'encoder_stage_ms_per_step': round(dt_e / args.steps * 1e3, 3),
+                          'encoder_stage_slices_per_s': round(bs * world * args.steps / dt_e, 2), 'parallelism': f'dp{world}'}}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -201,16 +289,19 @@ def main():
                     help='bf16x3 (default): split-bf16 products on the bf16 matrix cores, fp32 accumulate, parity 1e-4 vs the '
                          'fp32 oracle; f32: exact fp32 MFMA')
     ap.add_argument('--restore-steps', type=int, default=150, help='GMVAE_spatial: restoration iterations per slice')
-    ap.add_argument('--arch', default='VAE', choices=['VAE', 'ceVAE', 'GMVAE_spatial'],
+    ap.add_argument('--arch', default='VAE', choices=['VAE', 'ceVAE', 'GMVAE_spatial', 'fAnoGAN'],
                     help='VAE = the headline workload (BASELINE.json configs[1]); ceVAE = configs[3] (16 slices per GPU: both '
                          'branches + the input-gradient anomaly map every step), reported for the record')
+    ap.add_argument('--size', type=int, default=0, help='fAnoGAN: slice edge (default 64)')
     ap.add_argument('--batch', type=int, default=0, help='slices per GPU (default 64 for VAE, 16 for ceVAE)')
     args = ap.parse_args()
     global BATCH
-    BATCH = args.batch or (64 if args.arch == 'VAE' else 16)
+    BATCH = args.batch or (64 if args.arch in ('VAE', 'fAnoGAN') else 16)
     cevae = args.arch == 'ceVAE'
     if args.arch == 'GMVAE_spatial':
         return bench_gmvae(args)
+    if args.arch == 'fAnoGAN':
+        return bench_fanogan(args)
 
     import torch
     import torch.distributed as dist

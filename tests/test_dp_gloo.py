@@ -80,3 +80,107 @@ def test_two_rank_dp_equals_big_batch():
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res['grad_err'] < 1e-12
     assert res['replica_diff'] == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# f-AnoGAN phases under DP: parallel.GanDataParallel itself (all-reduce of the trained group's slice, Adam with
+# grad_scale 1/world) driven over gloo with an oracle-backed stand-in for the device engine.
+# ---------------------------------------------------------------------------------------------------------------
+class _OracleGanEngine:
+    def __init__(self, m, p):
+        from oracle import fanogan as ofa
+        self.m, self.ofa = m, ofa
+        self.spec, off = [], 0
+        for name, shape, _ in m.spec:
+            self.spec.append((name, shape, off)); off += int(np.prod(shape))
+        self.params = torch.from_numpy(np.concatenate([p[k].reshape(-1) for k, _, _ in self.spec]).copy())
+        self.grads = torch.zeros_like(self.params)
+        self.m1, self.m2 = np.zeros(off), np.zeros(off)
+        self.t = {'Encoder': 0, 'Generator': 0, 'Discriminator': 0}
+
+    def buffer(self, which):
+        return self.params if which == 0 else self.grads
+
+    def group(self, g):
+        idx = [(o, int(np.prod(s))) for k, s, o in self.spec if self.ofa.group_of(k) == g]
+        return idx[0][0], sum(c for _, c in idx)
+
+    def _p(self):
+        flat = self.params.numpy()
+        return {k: flat[o:o + int(np.prod(s))].reshape(s) for k, s, o in self.spec}
+
+    def phase(self, group, want_backward=True, x=None, z=None, alpha=None, **kw):
+        p = self._p()
+        if group == 'Generator':
+            ls, g = self.m.gen_phase(p, z)
+        elif group == 'Discriminator':
+            ls, g = self.m.disc_phase(p, x, z, alpha)
+        else:
+            ls, g = self.m.enc_phase(p, x)
+        for k, s, o in self.spec:
+            if k in g:
+                self.grads[o:o + int(np.prod(s))] = torch.from_numpy(np.asarray(g[k], np.float64).reshape(-1).copy())
+        return ls
+
+    def adam(self, group, lr, b1, b2, eps, grad_scale):
+        self.t[group] += 1
+        off, cnt = self.group(group)
+        sl = slice(off, off + cnt)
+        pf = self.params.numpy()
+        onn.adam_tf_step(pf[sl], self.grads.numpy()[sl] * grad_scale, self.m1[sl], self.m2[sl], self.t[group], lr, b1, b2, eps)
+
+
+def _gan_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import fanogan as ofa
+        from unsupervised_anomaly_detection_brain_mri_amd.parallel import GanDataParallel
+        h, inter, zdim, n = 32, 8, 16, 4
+        m = ofa.FAnoGAN(h, inter, zdim)
+        p = ovae.init_params(m.spec, seed=4, dtype=np.float64, perturb=True)
+        x = ovae.synthetic_slices(n, h, h, seed=0, dtype=np.float64)
+        rng = np.random.default_rng(2)
+        z = rng.standard_normal((n, zdim)); alpha = rng.uniform(0, 1, (n, 1))
+        per = n // world
+        sl = slice(rank * per, (rank + 1) * per)
+        eng = _OracleGanEngine(m, p)
+        dp = GanDataParallel(eng, world)
+        single = _OracleGanEngine(m, p)
+        for group, kw, kw_full in (('Discriminator', dict(x=x[sl], z=z[sl], alpha=alpha[sl]), dict(x=x, z=z, alpha=alpha)),
+                                   ('Generator', dict(z=z[sl]), dict(z=z)), ('Encoder', dict(x=x[sl]), dict(x=x))):
+            dp.train_phase(group, 1e-3, **kw)
+            single.phase(group, **kw_full)
+            off, cnt = eng.group(group)
+            g_dp = eng.grads[off:off + cnt].numpy() / world
+            g_full = single.grads[off:off + cnt].numpy()
+            single.adam(group, 1e-3, 0.5, 0.9, 1e-8, 1.0)
+            if rank == 0:
+                q.put((group + '_grad_err', float(np.abs(g_dp - g_full).max() / np.abs(g_full).max())))
+                q.put((group + '_param_err', float((eng.params - single.params).abs().max())))
+        t = eng.params.clone()
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        if rank == 0:
+            q.put(('replica_diff', float((gathered[0] - gathered[1]).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gan_phases_equal_big_batch():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gan_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(7))
+    for g in ('Discriminator', 'Generator', 'Encoder'):
+        assert res[g + '_grad_err'] < 1e-10, res
+        assert res[g + '_param_err'] < 1e-9, res
+    assert res['replica_diff'] == 0.0

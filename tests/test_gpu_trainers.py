@@ -205,3 +205,57 @@ def test_gmvae_spatial_trainer_surface(tmp_path):
     model.determine_best_lambda(ds16)
     assert 0.0 <= model.tv_lambda_value <= 1.9
     model.engine.close()
+
+
+def test_fanogan_trainer_surface(tmp_path):
+    """trainers/fAnoGAN.py: Config defaults, the two training stages (WGAN epochs: 1 generator + 5 critic steps per batch;
+    encoder epochs with validation), the fetch keys of the three sess.runs, reconstruct(), checkpoint resume with the three
+    Adam step counters, and the evaluation driver on top."""
+    from oracle import fanogan as ofa
+    from unsupervised_anomaly_detection_brain_mri_amd.models import fanogan
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import fAnoGAN
+    d = fAnoGAN.Config()
+    assert (d.modelname, d.scale, d.kappa) == ('fAnoGAN', 10.0, 1.0)
+    cfg, opt, ds = _config(fAnoGAN, tmp_path, h=64, bs=4, epochs=1)
+    cfg.dropout_rate = 0.0
+    model = fAnoGAN(None, cfg, network=fanogan)
+    assert model.model_dir == 'fAnoGAN_dSyntheticDataset_s64x64_fanogan_b4_z64_'
+    assert [n for n, _, _ in model.engine.spec] == [n for n, _, _ in ofa.param_spec(64, 8, 64)]
+    # one critic step against the oracle with injected z / alpha (before any training)
+    batch = ds.next_batch(4, set='TRAIN')[0]
+    p = {k: v.astype(np.float64) for k, v in model.engine.get_params().items()}
+    z = model.sample_z(4)
+    alpha = np.linspace(0.1, 0.9, 4).astype(np.float32)
+    m = ofa.FAnoGAN(64, 8, 64)
+    ls, _ = m.disc_phase(p, batch.astype(np.float64), z.astype(np.float64), alpha.astype(np.float64))
+    run = model.discriminator_step(batch, z=z, alpha=alpha)
+    assert set(run) == {'generated', 'disc_loss', 'disc_fake', 'disc_real'}
+    for k in ('disc_loss', 'disc_fake', 'disc_real'):
+        assert run[k] == pytest.approx(ls[k], rel=1e-4, abs=1e-5)
+    run = model.generator_step(batch)
+    assert set(run) == {'generated', 'gen_loss'} and tuple(run['generated'].shape) == (4, 64, 64, 1)
+    model.train(ds)
+    nb = ds.num_batches(4, set='TRAIN')
+    assert model.engine.step_count('Generator') == nb + 1 and model.engine.step_count('Discriminator') == 5 * nb + 1
+    assert model.engine.step_count('Encoder') == nb
+    assert {'TRAIN/wgan_gen_loss', 'TRAIN/wgan_disc_loss', 'TRAIN/enc_loss', 'TRAIN/reconstructionLoss', 'VAL/reconstructionLoss'} <= set(model.curves)
+    run = model.step(ds.next_batch(4, set='VAL')[0], Phase.VAL)
+    assert set(run) == {'loss_img', 'loss_fts', 'enc_loss', 'reconstructionLoss', 'loss', 'reconstruction', 'L1', 'z_enc'}
+    assert run['enc_loss'] == pytest.approx(run['loss_img'] + run['loss_fts'], rel=1e-5)
+    x = ds.next_batch(1, set='VAL')[0][0]
+    r = model.reconstruct(x)
+    assert r['reconstruction'].shape == (1, 64, 64, 1) and 0.0 <= r['reconstruction'].min() and r['reconstruction'].max() <= 1.0
+    ck = os.path.join(model.checkpointDir, model.model_dir)
+    assert os.path.isfile(os.path.join(ck, 'fAnoGAN.model-2.npz'))
+    w = model.engine.get_buffer_host(_lib.BUF_PARAMS)
+    steps = [model.engine.step_count(g) for g in ('Encoder', 'Generator', 'Discriminator')]
+    vols = [synthetic_slices(8, 64, 64, seed=60, lesions=True)]
+    ev = Evaluation.evaluate([v[0][..., 0].astype('float64') for v in vols], [v[1] for v in vols], [v[2] for v in vols], model, opt)
+    assert 0.0 <= ev['diff_AUC'] <= 1.0 and 0.0 <= ev['diff_AUPRC'] <= 1.0
+    model.engine.close()
+    cfg2, _, _ = _config(fAnoGAN, tmp_path, h=64, bs=4, epochs=1)
+    m2 = fAnoGAN(None, cfg2, network=fanogan, seed=5)
+    assert m2.load_checkpoint() == 2
+    assert np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w)
+    assert [m2.engine.step_count(g) for g in ('Encoder', 'Generator', 'Discriminator')] == steps
+    m2.engine.close()

@@ -22,7 +22,50 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-class Engine:
+class _EvalOps:
+    """Model-independent device ops of the evaluation path (erosion, 3-D median, residual maps, sort-based metrics); shared by
+    the AE-family Engine and the f-AnoGAN GanEngine.  Needs self.lib, self.device, self._dev, self._stream."""
+
+    # ---------------------------------------------------------------- scoring (SURVEY.md §8 row a14)
+    def erode_cross(self, masks, iterations=12):
+        """Brain-mask erosion on device (utils/Evaluation.py:84-89): masks [n,H,W] (any dtype, nonzero = set) -> fp32 0/1 tensor."""
+        mk = self._dev(np.asarray(masks, np.float32) if not isinstance(masks, torch.Tensor) else masks)
+        if mk.dim() != 3:
+            raise ValueError(f'masks must be [n,H,W], got {tuple(mk.shape)}')
+        out = torch.empty_like(mk)
+        _lib.check(self.lib.uad_erode_cross(_ptr(mk), mk.shape[0], mk.shape[1], mk.shape[2], int(iterations), _ptr(out),
+                                            self._stream()))
+        return out
+
+    def median3d(self, volume, ksize=5):
+        """5x5x5 median filter of a [D,H,W] volume, scipy 'reflect' boundary (utils/Evaluation.py:108-110)."""
+        v = self._dev(np.asarray(volume, np.float32) if not isinstance(volume, torch.Tensor) else volume)
+        if v.dim() != 3:
+            raise ValueError(f'volume must be [D,H,W], got {tuple(v.shape)}')
+        out = torch.empty_like(v)
+        _lib.check(self.lib.uad_median3d(_ptr(v), v.shape[0], v.shape[1], v.shape[2], int(ksize), _ptr(out), self._stream()))
+        return out
+
+    def scores(self, predictions, labels):
+        """One descending device sort of all voxel scores -> Scores object (AUROC, AUPRC, dice at thresholds)."""
+        return Scores(self, predictions, labels)
+
+    def residual(self, x, x_rec, mask=None, pos_only=True, prior_thresh=None):
+        """Residual anomaly map on device (utils/Evaluation.py:282-289).  Returns (map, l1err_per_sample)."""
+        x = self._dev(x)
+        xr = self._dev(x_rec, x.shape)
+        mk = self._dev(mask, x.shape) if mask is not None else None
+        n = x.shape[0]
+        hw = int(np.prod(x.shape[1:]))
+        out = torch.empty_like(x)
+        l1 = torch.empty(n, device=self.device)
+        thr = -math.inf if prior_thresh is None else float(prior_thresh)
+        _lib.check(self.lib.uad_residual(_ptr(x), _ptr(xr), _ptr(mk), n, hw, 1 if pos_only else 0, thr, _ptr(out),
+                                         _ptr(l1), self._stream()))
+        return out, l1
+
+
+class Engine(_EvalOps):
     """One AE / VAE / ceVAE instance on one GPU.  Mirrors what a tf.Session + graph holds in the reference
     (trainers/VAE.py:18-29): variables, optimizer slots and the compiled step."""
 
@@ -282,44 +325,6 @@ class Engine:
             tag, cnt, ms = line.split()
             rep[tag] = (int(cnt), float(ms))
         return rep
-
-    # ---------------------------------------------------------------- scoring
-    def erode_cross(self, masks, iterations=12):
-        """Brain-mask erosion on device (utils/Evaluation.py:84-89): masks [n,H,W] (any dtype, nonzero = set) -> fp32 0/1 tensor."""
-        mk = self._dev(np.asarray(masks, np.float32) if not isinstance(masks, torch.Tensor) else masks)
-        if mk.dim() != 3:
-            raise ValueError(f'masks must be [n,H,W], got {tuple(mk.shape)}')
-        out = torch.empty_like(mk)
-        _lib.check(self.lib.uad_erode_cross(_ptr(mk), mk.shape[0], mk.shape[1], mk.shape[2], int(iterations), _ptr(out),
-                                            self._stream()))
-        return out
-
-    def median3d(self, volume, ksize=5):
-        """5x5x5 median filter of a [D,H,W] volume, scipy 'reflect' boundary (utils/Evaluation.py:108-110)."""
-        v = self._dev(np.asarray(volume, np.float32) if not isinstance(volume, torch.Tensor) else volume)
-        if v.dim() != 3:
-            raise ValueError(f'volume must be [D,H,W], got {tuple(v.shape)}')
-        out = torch.empty_like(v)
-        _lib.check(self.lib.uad_median3d(_ptr(v), v.shape[0], v.shape[1], v.shape[2], int(ksize), _ptr(out), self._stream()))
-        return out
-
-    def scores(self, predictions, labels):
-        """One descending device sort of all voxel scores -> Scores object (AUROC, AUPRC, dice at thresholds)."""
-        return Scores(self, predictions, labels)
-
-    def residual(self, x, x_rec, mask=None, pos_only=True, prior_thresh=None):
-        """Residual anomaly map on device (utils/Evaluation.py:282-289).  Returns (map, l1err_per_sample)."""
-        x = self._dev(x)
-        xr = self._dev(x_rec, x.shape)
-        mk = self._dev(mask, x.shape) if mask is not None else None
-        n = x.shape[0]
-        hw = int(np.prod(x.shape[1:]))
-        out = torch.empty_like(x)
-        l1 = torch.empty(n, device=self.device)
-        thr = -math.inf if prior_thresh is None else float(prior_thresh)
-        _lib.check(self.lib.uad_residual(_ptr(x), _ptr(xr), _ptr(mk), n, hw, 1 if pos_only else 0, thr, _ptr(out),
-                                         _ptr(l1), self._stream()))
-        return out, l1
 
 
 class Scores:

@@ -7,12 +7,12 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import _DevArray, _ptr
+from .engine import _DevArray, _EvalOps, _ptr
 
 GROUPS = {'Encoder': _lib.GAN_ENCODER, 'Generator': _lib.GAN_GENERATOR, 'Discriminator': _lib.GAN_DISCRIMINATOR}
 
 
-class GanEngine:
+class GanEngine(_EvalOps):
     def __init__(self, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, scale=10.0, kappa=1.0,
                  device=None, math='bf16x3'):
         self.lib = _lib.load()
@@ -92,6 +92,13 @@ class GanEngine:
 
     def get_grads(self):
         return self.unflatten(self.get_buffer_host(_lib.BUF_GRADS))
+
+    def reset_optimizer(self):
+        zeros = np.zeros(self.nparams, np.float32)
+        self.set_buffer_host(_lib.BUF_ADAM_M, zeros)
+        self.set_buffer_host(_lib.BUF_ADAM_V, zeros)
+        for g in GROUPS:
+            self.set_step_count(g, 0)
 
     def step_count(self, group):
         return int(self.lib.uad_gan_get_step(self.handle, GROUPS.get(group, group)))

@@ -5,3 +5,4 @@ from .autoencoder import autoencoder  # noqa: F401
 from .variational_autoencoder import variational_autoencoder  # noqa: F401
 from .context_encoder_variational_autoencoder import context_encoder_variational_autoencoder  # noqa: F401
 from .gaussian_mixture_variational_autoencoder_spatial import gaussian_mixture_variational_autoencoder_spatial  # noqa: F401
+from .fanogan import fanogan  # noqa: F401

@@ -52,7 +52,7 @@ class AEMODEL(DLMODEL):
         c = self.config
         self.checkpointDir = os.path.join(c.checkpointDir or 'checkpoints', self.network.__name__)
         self.engine = self._make_engine(device)
-        self.dp = DataParallelStep(self.engine, world)
+        self.dp = self._make_dp(world)
         self.rng = np.random.default_rng(seed)       # host RNG for eps / dropout masks (TF graph RNG is unseeded)
         self.initialize_variables()
         self.get_number_of_trainable_params()
@@ -61,6 +61,9 @@ class AEMODEL(DLMODEL):
         c = self.config
         return Engine(self.ARCH, c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]),
                       c.zDim, max_batch=max(int(c.batchsize), 1), device=device)
+
+    def _make_dp(self, world):
+        return DataParallelStep(self.engine, world)
 
     def initialize_variables(self):
         """tf.global_variables_initializer(): glorot_uniform kernels, zero bias, gamma 1, beta 0 (SURVEY §8a note 3)."""

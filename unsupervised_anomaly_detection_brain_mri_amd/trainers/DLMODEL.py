@@ -49,6 +49,13 @@ class DLMODEL(object):
             raise NotImplementedError(f"optimizer {type!r}: only 'ADAM' (the reference default) is implemented on the HIP path")
         return type
 
+    # Adam step counter(s) stored with a checkpoint (one per optimiser)
+    def _adam_steps(self):
+        return np.int64(self.engine.step_count)
+
+    def _set_adam_steps(self, t):
+        self.engine.step_count = int(t)
+
     def save(self, checkpoint_dir, step):
         model_name = self.config.modelname + ".model"
         checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
@@ -56,7 +63,7 @@ class DLMODEL(object):
         eng = self.engine
         np.savez(os.path.join(checkpoint_dir, f'{model_name}-{step}.npz'),
                  params=eng.get_buffer_host(_lib.BUF_PARAMS), adam_m=eng.get_buffer_host(_lib.BUF_ADAM_M),
-                 adam_v=eng.get_buffer_host(_lib.BUF_ADAM_V), adam_t=np.int64(eng.step_count),
+                 adam_v=eng.get_buffer_host(_lib.BUF_ADAM_V), adam_t=self._adam_steps(),
                  names=np.array([n for n, _, _ in eng.spec]))
         with open(os.path.join(checkpoint_dir, 'checkpoint'), 'w') as f:
             f.write(f'model_checkpoint_path: "{model_name}-{step}"\n')
@@ -86,7 +93,7 @@ class DLMODEL(object):
             self.engine.set_params(z['params'])
             self.engine.set_buffer_host(_lib.BUF_ADAM_M, z['adam_m'])
             self.engine.set_buffer_host(_lib.BUF_ADAM_V, z['adam_v'])
-            self.engine.step_count = int(z['adam_t'])
+            self._set_adam_steps(z['adam_t'])
             counter = int(next(re.finditer(r'(\d+)(?!.*\d)', name)).group(0))
             print(" [*] Success to read {}".format(name))
             return True, counter

@@ -3,3 +3,4 @@ from .VAE import VAE  # noqa: F401
 from .AEMODEL import Phase  # noqa: F401
 from .ceVAE import ceVAE  # noqa: F401
 from .GMVAE_spatial import GMVAE_spatial  # noqa: F401
+from .fAnoGAN import fAnoGAN  # noqa: F401
