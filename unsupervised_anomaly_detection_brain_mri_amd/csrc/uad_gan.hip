@@ -39,13 +39,14 @@ constexpr float kLnEps = 1e-3f;     // keras LayerNormalization default epsilon
 constexpr float kLrelu = 0.3f;      // keras LeakyReLU() default
 
 // ================================================================================================ LayerNorm over (H, W)
-// One workgroup per (sample, 32-channel group): 256 threads = 32 pixel lanes x 8 channel quads (float4 = 16-byte NHWC
-// accesses).  Per-channel sums are folded through LDS in a fixed order.
+// One workgroup per (sample, 32-channel group): PL pixel lanes x 8 channel quads (float4 = 16-byte NHWC accesses); PL = 128
+// (1024 threads) for the large maps, 32 for the small ones.  Per-channel sums are folded through LDS in a fixed order.
+template <int PL>
 __device__ __forceinline__ float4 chan_reduce(float4 v, float (*red)[36], int pl, int cq) {
     red[pl][cq * 4 + 0] = v.x; red[pl][cq * 4 + 1] = v.y; red[pl][cq * 4 + 2] = v.z; red[pl][cq * 4 + 3] = v.w;
     __syncthreads();
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
+    for (int o = PL / 2; o > 0; o >>= 1) {
         if (pl < o) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) red[pl][cq * 4 + k] += red[pl + o][cq * 4 + k];
@@ -67,30 +68,35 @@ __device__ __forceinline__ float quad8_sum(float v) {   // over the 8 channel-qu
     return v;
 }
 
-// a = act(gamma[p] * (c - mean) * rstd + beta[p]); stats[n][0][ch] = mean, stats[n][1][ch] = rstd
-__global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float alpha, int HW, int C,
-                                                     float* __restrict__ a, float* __restrict__ stats) {
-    __shared__ float red[32][36];
+// a = act(gamma[p] * (c - mean) * rstd + beta[p]); stats[n][0][ch] = mean, stats[n][1][ch] = rstd.
+// Mean and variance come from ONE pass: sums of (c - k) and (c - k)^2 about the pivot k = the channel's first pixel, which lies
+// inside the data range, so var = E[(c-k)^2] - E[c-k]^2 loses no more than a few ulp (nn.moments itself is two-pass fp32).
+template <int PL>
+__global__ void __launch_bounds__(PL * 8) ln_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float alpha, int HW, int C,
+                                                        float* __restrict__ a, float* __restrict__ stats) {
+    __shared__ float red[PL][36];
     const int n = blockIdx.y, cq = threadIdx.x & 7, pl = threadIdx.x >> 3, ch0 = blockIdx.x * 32 + cq * 4;
     const size_t off = (size_t)n * HW * C + ch0;
-    float4 s = f4(0.f);
-    for (int p = pl; p < HW; p += 32) s = s + *reinterpret_cast<const float4*>(c + off + (size_t)p * C);
-    const float inv = 1.0f / (float)HW;
-    const float4 mean = chan_reduce(s, red, pl, cq) * inv;
-    float4 q = f4(0.f);
-    for (int p = pl; p < HW; p += 32) {
-        const float4 d = *reinterpret_cast<const float4*>(c + off + (size_t)p * C) - mean;
-        q = q + d * d;
+    const float4 piv = *reinterpret_cast<const float4*>(c + off);
+    float4 s = f4(0.f), q = f4(0.f);
+    for (int p = pl; p < HW; p += PL) {
+        const float4 d = *reinterpret_cast<const float4*>(c + off + (size_t)p * C) - piv;
+        s = s + d; q = q + d * d;
     }
-    const float4 var = chan_reduce(q, red, pl, cq) * inv;
+    const float inv = 1.0f / (float)HW;
+    const float4 m1 = chan_reduce<PL>(s, red, pl, cq) * inv;
+    const float4 m2 = chan_reduce<PL>(q, red, pl, cq) * inv;
+    const float4 mean = piv + m1;
+    const float4 var = make_float4(fmaxf(m2.x - m1.x * m1.x, 0.f), fmaxf(m2.y - m1.y * m1.y, 0.f), fmaxf(m2.z - m1.z * m1.z, 0.f),
+                                   fmaxf(m2.w - m1.w * m1.w, 0.f));
     const float4 r = make_float4(1.0f / sqrtf(var.x + kLnEps), 1.0f / sqrtf(var.y + kLnEps), 1.0f / sqrtf(var.z + kLnEps),
                                  1.0f / sqrtf(var.w + kLnEps));
     if (pl == 0) {
         *reinterpret_cast<float4*>(stats + ((size_t)n * 2 + 0) * C + ch0) = mean;
         *reinterpret_cast<float4*>(stats + ((size_t)n * 2 + 1) * C + ch0) = r;
     }
-    for (int p = pl; p < HW; p += 32) {
+    for (int p = pl; p < HW; p += PL) {
         const float4 xh = (*reinterpret_cast<const float4*>(c + off + (size_t)p * C) - mean) * r;
         const float4 y = xh * gamma[p] + f4(beta[p]);
         *reinterpret_cast<float4*>(a + off + (size_t)p * C) = act_grad(y, y, alpha);
@@ -111,8 +117,9 @@ struct LnBwdArgs {
     float* gpart;           // optional [slot][2][HW]: per-pixel sums over the block's channels of dn*xhat, dn
     int slot0;
 };
-__global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs A) {
-    __shared__ float red[32][36];
+template <int PL>
+__global__ void __launch_bounds__(PL * 8) ln_bwd_kernel(const LnBwdArgs A) {
+    __shared__ float red[PL][36];
     const int n = blockIdx.y, cq = threadIdx.x & 7, pl = threadIdx.x >> 3, ch0 = blockIdx.x * 32 + cq * 4;
     const int HW = A.HW, C = A.C;
     const size_t off = (size_t)n * HW * C + ch0;
@@ -120,7 +127,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs A) {
     const float4 r = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 1) * C + ch0);
     const size_t slot = (size_t)(A.slot0 + n) * gridDim.x + blockIdx.x;
     float4 sp = f4(0.f), spx = f4(0.f);
-    for (int p = pl; p < HW; p += 32) {
+    for (int p = pl; p < HW; p += PL) {
         const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
         const float g = A.gamma[p];
         const float4 y = xh * g + f4(A.beta[p]);
@@ -133,11 +140,11 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs A) {
         }
     }
     const float inv = 1.0f / (float)HW;
-    const float4 ep = chan_reduce(sp, red, pl, cq) * inv;
-    const float4 epx = chan_reduce(spx, red, pl, cq) * inv;
+    const float4 ep = chan_reduce<PL>(sp, red, pl, cq) * inv;
+    const float4 epx = chan_reduce<PL>(spx, red, pl, cq) * inv;
     const bool has_add = A.add && n >= A.add_lo && n < A.add_hi;
     const size_t aoff = has_add ? (size_t)(n - A.add_lo) * HW * C + ch0 : 0;
-    for (int p = pl; p < HW; p += 32) {
+    for (int p = pl; p < HW; p += PL) {
         const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
         const float g = A.gamma[p];
         const float4 y = xh * g + f4(A.beta[p]);
@@ -160,8 +167,9 @@ struct LnBwd2Args {
     float* ubar; float* inj; float* gpart;
     int slot0;
 };
-__global__ void __launch_bounds__(256) ln_bwd2_kernel(const LnBwd2Args A) {
-    __shared__ float red[32][36];
+template <int PL>
+__global__ void __launch_bounds__(PL * 8) ln_bwd2_kernel(const LnBwd2Args A) {
+    __shared__ float red[PL][36];
     const int n = blockIdx.y, cq = threadIdx.x & 7, pl = threadIdx.x >> 3, ch0 = blockIdx.x * 32 + cq * 4;
     const int HW = A.HW, C = A.C;
     const size_t off = (size_t)n * HW * C + ch0;
@@ -169,21 +177,21 @@ __global__ void __launch_bounds__(256) ln_bwd2_kernel(const LnBwd2Args A) {
     const float4 r = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 1) * C + ch0);
     const size_t slot = (size_t)(A.slot0 + n) * gridDim.x + blockIdx.x;
     float4 sp = f4(0.f), spx = f4(0.f), sq = f4(0.f), sqx = f4(0.f), sqp = f4(0.f);
-    for (int p = pl; p < HW; p += 32) {
+    for (int p = pl; p < HW; p += PL) {
         const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
         const float4 pp = *reinterpret_cast<const float4*>(A.v + off + (size_t)p * C) * A.gamma[p];
         const float4 qq = *reinterpret_cast<const float4*>(A.q + off + (size_t)p * C);
         sp = sp + pp; spx = spx + pp * xh; sq = sq + qq; sqx = sqx + qq * xh; sqp = sqp + qq * pp;
     }
     const float inv = 1.0f / (float)HW;
-    const float4 ep = chan_reduce(sp, red, pl, cq) * inv, epx = chan_reduce(spx, red, pl, cq) * inv;
-    const float4 eq = chan_reduce(sq, red, pl, cq) * inv, eqx = chan_reduce(sqx, red, pl, cq) * inv;
-    const float4 eqp = chan_reduce(sqp, red, pl, cq) * inv;
+    const float4 ep = chan_reduce<PL>(sp, red, pl, cq) * inv, epx = chan_reduce<PL>(spx, red, pl, cq) * inv;
+    const float4 eq = chan_reduce<PL>(sq, red, pl, cq) * inv, eqx = chan_reduce<PL>(sqx, red, pl, cq) * inv;
+    const float4 eqp = chan_reduce<PL>(sqp, red, pl, cq) * inv;
     const float4 zero = f4(0.f);
     const float4 e_xhbar = zero - r * (eq * epx + ep * eqx);
     const float4 e_xhbar_xh = zero - r * (eqx * epx) * 2.0f;
     const float4 e_qdc = r * (eqp - eq * ep - eqx * epx);
-    for (int p = pl; p < HW; p += 32) {
+    for (int p = pl; p < HW; p += PL) {
         const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
         const float g = A.gamma[p];
         const float4 vv = *reinterpret_cast<const float4*>(A.v + off + (size_t)p * C);
@@ -501,10 +509,17 @@ int dev_alloc(uad_gan* m, float** p, size_t floats, const char* name = nullptr) 
 
 // ---- launch helpers ----
 void ln_fwd(const float* c, const float* gamma, const float* beta, float alpha, int N, int HW, int C, float* a, float* stats, hipStream_t st) {
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(C / 32, N), dim3(256), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
+    if (HW >= 512) hipLaunchKernelGGL((ln_fwd_kernel<128>), dim3(C / 32, N), dim3(1024), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
+    else hipLaunchKernelGGL((ln_fwd_kernel<32>), dim3(C / 32, N), dim3(256), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
 }
-void ln_bwd(const LnBwdArgs& a, int N, hipStream_t st) { hipLaunchKernelGGL(ln_bwd_kernel, dim3(a.C / 32, N), dim3(256), 0, st, a); }
-void ln_bwd2(const LnBwd2Args& a, int N, hipStream_t st) { hipLaunchKernelGGL(ln_bwd2_kernel, dim3(a.C / 32, N), dim3(256), 0, st, a); }
+void ln_bwd(const LnBwdArgs& a, int N, hipStream_t st) {
+    if (a.HW >= 512) hipLaunchKernelGGL((ln_bwd_kernel<128>), dim3(a.C / 32, N), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<32>), dim3(a.C / 32, N), dim3(256), 0, st, a);
+}
+void ln_bwd2(const LnBwd2Args& a, int N, hipStream_t st) {
+    if (a.HW >= 512) hipLaunchKernelGGL((ln_bwd2_kernel<128>), dim3(a.C / 32, N), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((ln_bwd2_kernel<32>), dim3(a.C / 32, N), dim3(256), 0, st, a);
+}
 void bn_act_fwd(uad_gan* m, const Block& L, const float* c, int N, float* a, hipStream_t st) {
     const size_t total4 = (size_t)N * L.H * L.W * L.C / 4;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks256(total4)), dim3(256), 0, st, c, P(m, L.gamma), P(m, L.beta),
@@ -650,8 +665,8 @@ void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* 
         if (pg) {
             uad_launch_reduce_partials(m->lnpart_g, n * (L.C / 32), 2 * a.HW, 1.0f, Gr(m, L.gamma), st);   // gamma | beta adjacent
             convT_wgrad(m, L, n, m->ga[i], gn, st);
-            // a bias in front of a LayerNorm over (H, W) is removed by the mean subtraction: its gradient is identically zero
-            hipMemsetAsync(Gr(m, L.b), 0, L.C * sizeof(float), st);
+            // a bias in front of a LayerNorm over (H, W) is removed by the mean subtraction: its gradient is identically zero.
+            // The gradient buffer is zero-initialised and nothing writes those entries, so they stay exact zeros.
         }
         convT_dgrad(m, L, n, gn, g, st);
     }
@@ -664,7 +679,6 @@ void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* 
     if (pg) {
         uad_launch_reduce_partials(m->lnpart_g, n * (m->cenc / 32), 2 * r * r, 1.0f, Gr(m, m->g_ln0g), st);
         uad_launch_conv_w(dc1, m->gdv, no_xform(), gn, no_xform(), Gr(m, m->g_cw), m->wpartial, st);
-        hipMemsetAsync(Gr(m, m->g_cb), 0, m->cenc * sizeof(float), st);
     }
     uad_launch_conv_d(dc1, gn, no_xform(), P(m, m->g_cw), m->ddv, epi_bias(nullptr, mask_g), st, nullptr, m->ws);
     if (pg) {
@@ -708,7 +722,6 @@ void disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float* 
         if (pg) {
             uad_launch_reduce_partials(m->lnpart[i], (N + ntail) * (L.C / 32), 2 * a.HW, 1.0f, Gr(m, L.gamma), st);
             conv_wgrad(m, L, N + ntail, i == 0 ? m->din : m->Da[i], m->Dg[i], st);
-            hipMemsetAsync(Gr(m, L.b), 0, L.C * sizeof(float), st);      // bias in front of LayerNorm-HW: zero gradient
         }
         if (i > 0) { conv_dgrad(m, L, N, m->Dg[i], gn, st); float* t = g; g = gn; gn = t; }
         else if (dx_out) conv_dgrad(m, L, N, m->Dg[0], dx_out, st);
@@ -1041,7 +1054,7 @@ int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int wa
                 const int rows = 4 * n * P2, rpb = (rows + 255) / 256, blocks = (rows + rpb - 1) / rpb;
                 hipLaunchKernelGGL(coef_colsum_kernel, dim3(blocks), dim3(256), 0, st, m->Da[L], rows, rpb, n * P2, DL.C, cf, m->finpart);
                 uad_launch_reduce_partials(m->finpart, blocks, DL.C, 1.0f, Gr(m, m->d_hw), st);
-                HIP_TRY(hipMemsetAsync(Gr(m, m->d_hb), 0, sizeof(float), st));   // +1/(nP) over the fake rows, -1/(nP) over the real rows
+                // Dense(1) bias: +1/(nP) over the fake rows, -1/(nP) over the real rows = 0 (stays at its zero initialisation)
             }
             disc_backward(m, 3 * n, true, n, 2 * n, nullptr, st);
         }
