@@ -104,3 +104,59 @@ def test_fanogan_adam_groups():
         # the critic's dense bias sees +1/size from the fake and -1/size from the real half: exactly zero
         assert changed == (ofa.group_of(k) == 'Discriminator' and k in g and np.any(g[k] != 0)), k
     assert opt['t'] == {'Encoder': 0, 'Generator': 0, 'Discriminator': 1}
+
+
+# ------------------------------------------------------------------ ResNet graph (models/fanogan_schlegl.py)
+@pytest.mark.parametrize('h,dim,zdim,n', [(32, 4, 8, 2), (64, 2, 8, 1)])
+def test_fanogan_schlegl_phases_vs_torch(h, dim, zdim, n):
+    from oracle import fanogan_schlegl as ofs
+    inter = h // 8
+    m = ofs.FAnoGANSchlegl(h, inter, zdim, dim, scale=10.0, kappa=0.7)
+    p = ovae.init_params(m.spec, seed=5, dtype=np.float64, perturb=True)
+    rng = np.random.default_rng(8)
+    x = ovae.synthetic_slices(n, h, h, seed=1, dtype=np.float64)
+    z = rng.standard_normal((n, zdim)); alpha = rng.uniform(0, 1, (n, 1))
+    tp = torch_ref.to_torch(p)
+    o = torch_ref.fanogan_schlegl_graph(tp, m.bg, m.bd, m.nm, torch.tensor(x), torch.tensor(z), torch.tensor(alpha), inter, m.scale, m.kappa)
+    groups = {g: [k for k, _, _ in m.spec if ofa.group_of(k) == g] for g in ('Encoder', 'Generator', 'Discriminator')}
+
+    def tgrads(loss, group):
+        gs = torch.autograd.grad(loss, [tp[k] for k in groups[group]], retain_graph=True, allow_unused=True)
+        return {k: (np.zeros(p[k].shape) if g is None else g.numpy()) for k, g in zip(groups[group], gs)}
+
+    def check(mine, ref, group, tag):
+        # residual-stream biases shift every critic score by the same constant: their disc_loss gradient is round-off only
+        gmax = max(np.abs(ref[k]).max() for k in groups[group])
+        for k in groups[group]:
+            a = np.asarray(mine.get(k, np.zeros(p[k].shape))).reshape(p[k].shape)
+            np.testing.assert_allclose(a, ref[k], rtol=2e-7, atol=1e-9 * gmax + 1e-8 * np.abs(ref[k]).max(), err_msg=tag + ':' + k)
+
+    ls, g = m.gen_phase(p, z)
+    np.testing.assert_allclose(ls['gen_loss'], o['gen_loss'].item(), rtol=1e-10)
+    np.testing.assert_allclose(ls['generated'], o['x_'].detach().numpy(), rtol=1e-9, atol=1e-12)
+    check(g, tgrads(o['gen_loss'], 'Generator'), 'Generator', 'gen')
+    ls, g = m.disc_phase(p, x, z, alpha)
+    for k in ('disc_fake', 'disc_real', 'disc_loss', 'penalty'):
+        np.testing.assert_allclose(ls[k], o[k].item(), rtol=1e-9, err_msg=k)
+    check(g, tgrads(o['disc_loss'], 'Discriminator'), 'Discriminator', 'disc')
+    ls, g = m.enc_phase(p, x)
+    for k in ('loss_img', 'loss_fts', 'enc_loss', 'reconstructionLoss'):
+        np.testing.assert_allclose(ls[k], o[k].item(), rtol=1e-9, err_msg=k)
+    np.testing.assert_allclose(ls['reconstruction'], o['x_enc'].detach().numpy(), rtol=1e-9, atol=1e-12)
+    check(g, tgrads(o['enc_loss'], 'Encoder'), 'Encoder', 'enc')
+
+
+def test_fanogan_schlegl_param_table():
+    from oracle import fanogan_schlegl as ofs
+    m = ofs.FAnoGANSchlegl(64, 8, 128, 64)
+    names = [s[0] for s in m.spec]
+    shp = dict((s[0], s[1]) for s in m.spec)
+    assert names.index('Generator/dense/kernel') < names.index('Generator/layer_normalization/gamma') < names.index('Generator/conv2d/kernel')
+    assert shp['Generator/dense/kernel'] == (128, 8 * 8 * 512) and shp['Generator/conv2d/kernel'] == (3, 3, 512, 512)
+    assert shp['Generator/conv2d_transpose_2/kernel'] == (1, 1, 256, 512)          # res2 shortcut: k1 s2 ConvT 512 -> 256
+    assert shp['Generator/conv2d_4/kernel'] == (1, 1, 64, 1) and shp['Generator/layer_normalization_8/gamma'] == (64, 64)
+    assert shp['Discriminator/conv2d/kernel'] == (3, 3, 1, 64) and shp['Discriminator/layer_normalization_9/gamma'] == (64, 64)
+    assert shp['Discriminator/conv2d_3/kernel'] == (1, 1, 64, 128) and names[-2:] == ['Discriminator/dense/kernel', 'Discriminator/dense/bias']
+    n_g = sum(int(np.prod(s)) for k, s, _ in m.spec if k.startswith('Generator'))
+    n_d = sum(int(np.prod(s)) for k, s, _ in m.spec if k.startswith('Discriminator'))
+    assert 11.0e6 < n_g < 12.0e6 and 9.0e6 < n_d < 10.0e6                            # ~11.4 M / ~9.5 M

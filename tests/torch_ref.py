@@ -32,6 +32,9 @@ def _convT_same(x, w_hwoi, b, stride):
     total = max((h - 1) * stride + k - oh, 0)
     pb = total // 2
     y = F.conv_transpose2d(x, w_hwoi.permute(3, 2, 0, 1), None, stride=stride, padding=0)
+    short = pb + oh - y.shape[2]
+    if short > 0:                      # k < stride (k1 s2): TF's output is 2x, the uncovered rows / columns are zero
+        y = F.pad(y, (0, short, 0, short))
     y = y[:, :, pb:pb + oh, pb:pb + oh]
     return y + b.view(1, -1, 1, 1)
 
@@ -292,4 +295,65 @@ def fanogan_graph(P, x_nhwc, z, alpha, n_pool, inter_res, scale=10.0, kappa=1.0,
     o['x_enc'] = xe
     o['x_'] = x_.permute(0, 2, 3, 1)
     o['ddx'] = ddx
+    return o
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# f-AnoGAN, ResNet graph (models/fanogan_schlegl.py:11-161) with autograd; layer names come from the oracle's table.
+# ---------------------------------------------------------------------------------------------------------------
+def fanogan_schlegl_graph(P, blocks_g, blocks_d, names, x_nhwc, z, alpha, inter_res, scale=10.0, kappa=1.0):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    n = x.shape[0]
+
+    def conv(a, name, stride):
+        return _conv_same(a, P[name + '/kernel'], P[name + '/bias'], stride)
+
+    def convT(a, name, stride):
+        return _convT_same(a, P[name + '/kernel'], P[name + '/bias'], stride)
+
+    def ln(a, name):
+        return _ln_hw(a, P[name + '/gamma'], P[name + '/beta'])
+
+    def encoder(a):
+        for i in range(3):
+            a = conv(a, 'Encoder/enc_conv2D_%d' % i, 2)
+            bn = 'Encoder/batch_normalization' + ('' if i == 0 else '_%d' % i)
+            a = F.leaky_relu(a * (P[bn + '/gamma'] / math.sqrt(1.0 + BN_EPS)).view(1, -1, 1, 1) + P[bn + '/beta'].view(1, -1, 1, 1), ALPHA)
+        return torch.tanh(a.permute(0, 2, 3, 1).reshape(n, -1) @ P['Encoder/dense/kernel'] + P['Encoder/dense/bias'])
+
+    def generator(zz):
+        out = (zz @ P['Generator/dense/kernel'] + P['Generator/dense/bias']).reshape(n, inter_res, inter_res, -1).permute(0, 3, 1, 2)
+        for b in blocks_g:
+            t = convT(F.relu(ln(conv(F.relu(ln(out, b.n['ln1'])), b.n['conv1'], 1), b.n['ln2'])), b.n['conv2'], b.stride)
+            out = t + (out if b.n['short'] is None else convT(out, b.n['short'], 2))
+        return torch.tanh(conv(F.relu(ln(out, names['gen_ln'])), names['gen_final'], 1))
+
+    def critic(a):
+        out = conv(a, names['dis_conv'], 1)
+        for b in blocks_d:
+            t = conv(F.relu(ln(conv(F.relu(ln(out, b.n['ln1'])), b.n['conv1'], 1), b.n['ln2'])), b.n['conv2'], b.stride)
+            out = t + (out if b.n['short'] is None else F.avg_pool2d(conv(out, b.n['short'], 1), 2))
+        feat = out.permute(0, 2, 3, 1)
+        return feat, feat @ P['Discriminator/dense/kernel'] + P['Discriminator/dense/bias']
+
+    o = {}
+    o['z_enc'] = z_enc = encoder(x)
+    x_enc = generator(z_enc)
+    x_ = generator(z)
+    o['d_fake_features'], o['d_'] = critic(x_)
+    o['d_features'], o['d'] = critic(x)
+    x_hat = x + alpha.view(n, 1, 1, 1) * (x_ - x)
+    _, o['d_hat'] = critic(x_hat)
+    o['d_enc_features'], _ = critic(x_enc)
+    o['disc_real'], o['disc_fake'] = o['d'].mean(), o['d_'].mean()
+    o['gen_loss'] = -o['disc_fake']
+    ddx = torch.autograd.grad(o['d_hat'].sum(), x_hat, create_graph=True)[0].permute(0, 2, 3, 1)
+    o['penalty'] = ((torch.sqrt((ddx ** 2).sum(dim=1)) - 1.0) ** 2).mean() * scale
+    o['disc_loss'] = o['disc_fake'] - o['disc_real'] + o['penalty']
+    xe = x_enc.permute(0, 2, 3, 1)
+    o['loss_img'] = ((x_nhwc - xe) ** 2).mean()
+    o['loss_fts'] = ((o['d_enc_features'] - o['d_features']) ** 2).mean()
+    o['enc_loss'] = o['loss_img'] + kappa * o['loss_fts']
+    o['reconstructionLoss'] = (x_nhwc - xe).abs().sum(dim=(1, 2, 3)).mean()
+    o['x_enc'], o['x_'] = xe, x_.permute(0, 2, 3, 1)
     return o
