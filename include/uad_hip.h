@@ -183,6 +183,7 @@ int uad_scores_destroy(uad_scores_t* s);
  * the gradient of that loss w.r.t. the phase's variable group into the gradient buffer; uad_gan_adam then applies
  * TF-Adam to that group only (each group keeps its own step counter).  All calls are asynchronous on `stream`. */
 enum { UAD_GAN_ENCODER = 0, UAD_GAN_GENERATOR = 1, UAD_GAN_DISCRIMINATOR = 2 };
+enum { UAD_GAN_UNIFIED = 0, UAD_GAN_RESNET = 1 };
 /* scalars[16] written by uad_gan_phase (entries a phase does not compute are left untouched) */
 enum { UAD_GAN_S_GEN_LOSS = 0, UAD_GAN_S_DISC_FAKE = 1, UAD_GAN_S_DISC_REAL = 2, UAD_GAN_S_PENALTY = 3, UAD_GAN_S_DISC_LOSS = 4,
        UAD_GAN_S_LOSS_IMG = 5, UAD_GAN_S_LOSS_FTS = 6, UAD_GAN_S_ENC_LOSS = 7, UAD_GAN_S_REC_LOSS = 8 };
@@ -193,6 +194,10 @@ typedef struct {
     int zdim;                      /* config.zDim */
     int max_batch;
     float scale, kappa;            /* fAnoGAN.Config :15-16 (gradient-penalty weight, feature-loss weight) */
+    int variant;                   /* UAD_GAN_UNIFIED: models/fanogan.py:11-84; UAD_GAN_RESNET: models/fanogan_schlegl.py:11-161
+                                      (pre-activation residual blocks, k3 convolutions, avg-pool / k1 s2 shortcuts, tanh output;
+                                      height must be 8 * inter_res; no dropout in that graph: mask_z / mask_g are ignored) */
+    int dim;                       /* RESNET only: base width (fanogan_schlegl.py:13: 64); 0 = 64 */
 } uad_gan_config_t;
 typedef struct {
     const float* x;                /* [n,H,W,1] batch (critic and encoder phases, reconstruct) */

@@ -36,7 +36,7 @@ class UadIO(C.Structure):
 
 class UadGanConfig(C.Structure):
     _fields_ = [('height', C.c_int), ('width', C.c_int), ('channels', C.c_int), ('inter_res', C.c_int), ('zdim', C.c_int),
-                ('max_batch', C.c_int), ('scale', C.c_float), ('kappa', C.c_float)]
+                ('max_batch', C.c_int), ('scale', C.c_float), ('kappa', C.c_float), ('variant', C.c_int), ('dim', C.c_int)]
 
 
 class UadGanIO(C.Structure):
@@ -45,6 +45,7 @@ class UadGanIO(C.Structure):
 
 
 GAN_ENCODER, GAN_GENERATOR, GAN_DISCRIMINATOR = 0, 1, 2
+GAN_UNIFIED, GAN_RESNET = 0, 1
 GAN_SCALARS = ('gen_loss', 'disc_fake', 'disc_real', 'penalty', 'disc_loss', 'loss_img', 'loss_fts', 'enc_loss',
                'reconstructionLoss')
 

@@ -112,6 +112,8 @@ struct LnBwdArgs {
     int HW, C;
     const float* add;       // optional extra d / d c for samples [add_lo, add_hi), indexed from add_lo
     int add_lo, add_hi;
+    const float* add2;      // a second one (residual blocks: shortcut gradient + second-order injection)
+    int add2_lo, add2_hi;
     float* dc;
     float* v_out;           // optional: d / d (norm output) = da * act'
     float* gpart;           // optional [slot][2][HW]: per-pixel sums over the block's channels of dn*xhat, dn
@@ -144,6 +146,8 @@ __global__ void __launch_bounds__(PL * 8) ln_bwd_kernel(const LnBwdArgs A) {
     const float4 epx = chan_reduce<PL>(spx, red, pl, cq) * inv;
     const bool has_add = A.add && n >= A.add_lo && n < A.add_hi;
     const size_t aoff = has_add ? (size_t)(n - A.add_lo) * HW * C + ch0 : 0;
+    const bool has_add2 = A.add2 && n >= A.add2_lo && n < A.add2_hi;
+    const size_t aoff2 = has_add2 ? (size_t)(n - A.add2_lo) * HW * C + ch0 : 0;
     for (int p = pl; p < HW; p += PL) {
         const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
         const float g = A.gamma[p];
@@ -151,6 +155,7 @@ __global__ void __launch_bounds__(PL * 8) ln_bwd_kernel(const LnBwdArgs A) {
         const float4 dn = act_grad(y, *reinterpret_cast<const float4*>(A.da + off + (size_t)p * C), A.alpha);
         float4 dc = r * (dn * g - ep - xh * epx);
         if (has_add) dc = dc + *reinterpret_cast<const float4*>(A.add + aoff + (size_t)p * C);
+        if (has_add2) dc = dc + *reinterpret_cast<const float4*>(A.add2 + aoff2 + (size_t)p * C);
         *reinterpret_cast<float4*>(A.dc + off + (size_t)p * C) = dc;
         if (A.v_out) *reinterpret_cast<float4*>(A.v_out + off + (size_t)p * C) = dn;
     }
@@ -247,19 +252,21 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
 }
 
 // ================================================================================================ heads
-// d[row] = feat[row,:] . w + b   (critic Dense(1) per feature-map location / generator's final 1x1 conv + sigmoid)
-template <bool SIGMOID>
+// out[row] = act(feat[row,:] . w + b)   (critic Dense(1) per feature-map location; generator's final 1x1 conv + sigmoid / tanh)
+// ACT: 0 none, 1 sigmoid, 2 tanh.  min(C/4, 64) lanes per row, each striding over the row's float4s.
+template <int ACT>
 __global__ void __launch_bounds__(256) rowdot_kernel(const float* __restrict__ feat, const float* __restrict__ w,
-                                                     const float* __restrict__ b, int rows, int C, float* __restrict__ out) {
-    const int LPR = C / 4;
+                                                     const float* __restrict__ b, int rows, int C, int LPR, float* __restrict__ out) {
     const int lane = threadIdx.x % LPR;
     const int row = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) / LPR);
     float s = 0.f;
-    if (row < rows) s = hsum(*reinterpret_cast<const float4*>(feat + (size_t)row * C + lane * 4) * *reinterpret_cast<const float4*>(w + lane * 4));
+    if (row < rows)
+        for (int c4 = lane; c4 < C / 4; c4 += LPR)
+            s += hsum(*reinterpret_cast<const float4*>(feat + (size_t)row * C + c4 * 4) * *reinterpret_cast<const float4*>(w + c4 * 4));
     for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (row < rows && lane == 0) {
         s += b[0];
-        out[row] = SIGMOID ? 1.0f / (1.0f + expf(-s)) : s;
+        out[row] = ACT == 1 ? 1.0f / (1.0f + expf(-s)) : (ACT == 2 ? tanhf(s) : s);
     }
 }
 struct Coef4 { float v[4]; };
@@ -290,10 +297,11 @@ __global__ void __launch_bounds__(256) coef_colsum_kernel(const float* __restric
         partial[(size_t)blockIdx.x * C + threadIdx.x] = a;
     }
 }
-// generator output backward: do = dx * x (1 - x); da[row, c] = do * wf[c]; partial[blk][0..C) = sum do * a[row, c], [C] = sum do
+// generator output backward: do = dx * x (1 - x) (sigmoid) or dx * (1 - x^2) (tanh); da[row, c] = do * wf[c];
+// partial[blk][0..C) = sum do * a[row, c], [C] = sum do
 __global__ void __launch_bounds__(256) gfinal_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ x,
                                                          const float* __restrict__ a, const float* __restrict__ wf, int rows,
-                                                         int rows_per_block, int C, float* __restrict__ da,
+                                                         int rows_per_block, int C, int tanh_act, float* __restrict__ da,
                                                          float* __restrict__ partial) {
     __shared__ float red[1024], redb[256];
     const int Q = C / 4, RL = 256 / Q;
@@ -304,7 +312,7 @@ __global__ void __launch_bounds__(256) gfinal_bwd_kernel(const float* __restrict
     float sb = 0.f;
     for (int row = row0 + rl; row < row1; row += RL) {
         const float xv = x[row];
-        const float dv = dx[row] * xv * (1.0f - xv);
+        const float dv = dx[row] * (tanh_act ? (1.0f - xv * xv) : xv * (1.0f - xv));
         *reinterpret_cast<float4*>(da + (size_t)row * C + ch) = w * dv;
         if (partial) { s = s + *reinterpret_cast<const float4*>(a + (size_t)row * C + ch) * dv; sb += dv; }
     }
@@ -399,6 +407,34 @@ __global__ void __launch_bounds__(256) pen_grad_kernel(const float* __restrict__
     const float sl = s[nn * W + w];
     out[i] = coef * (sl - 1.0f) / sl * g[i];
 }
+// 2x2 average pooling (keras AvgPool2D()) and its backward, NHWC float4
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float* __restrict__ x, int H, int W, int C, size_t total4,
+                                                          float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int C4 = C / 4, W2 = W / 2, H2 = H / 2;
+    const int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    const int ox = (int)(t % W2); t /= W2;
+    const int oy = (int)(t % H2);
+    const size_t n = t / H2;
+    const float4* xp = reinterpret_cast<const float4*>(x) + ((n * H + 2 * oy) * W + 2 * ox) * C4 + c4;
+    const float4 s = (xp[0] + xp[C4]) + (xp[(size_t)W * C4] + xp[(size_t)W * C4 + C4]);
+    reinterpret_cast<float4*>(y)[i] = s * 0.25f;
+}
+__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const float* __restrict__ g, int H, int W, int C, size_t total4,
+                                                          float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // over the input-resolution tensor [N,H,W,C]
+    if (i >= total4) return;
+    const int C4 = C / 4;
+    const int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const size_t n = t / H;
+    reinterpret_cast<float4*>(dx)[i] = reinterpret_cast<const float4*>(g)[((n * (H / 2) + y / 2) * (W / 2) + x / 2) * C4 + c4] * 0.25f;
+}
+
 // derived scalars of a phase from the raw means in raw[]
 __global__ void combine_kernel(int phase, const float* __restrict__ raw, float kappa, float* __restrict__ out) {
     if (threadIdx.x != 0) return;
@@ -463,6 +499,25 @@ struct uad_gan {
     // gradient ping-pong, small vectors, scratch
     float *Ga, *Gb, *dxbuf, *dzbuf, *dzr, *dflat, *ddv;
     float *wpartial, *colscratch, *colpart, *redpart, *raw, *scalars_own, *finpart;
+    // ---- ResNet variant (models/fanogan_schlegl.py) ----
+    int variant, dim;
+    struct RB {                        // pre-activation residual block: LN -> ReLU -> conv1 (k3 s1) -> LN -> ReLU -> conv2, + shortcut
+        bool gen;                      // generator block: conv2 / shortcut are transposed convolutions
+        int stride, Hin, Hout, Cin, Cout;
+        long long ln1g, ln1b, w1, b1, ln2g, ln2b, w2, b2, ws, bs;   // ws < 0: identity shortcut
+        UadConvDesc d1, d2, ds;
+        float *X, *H1, *C1, *H2, *OUT, *ST1, *ST2;   // X = previous block's OUT; critic: X/H1/H2/OUT hold 4n samples (tail = pass C adjoints)
+        float *DX, *DOUT, *G1, *DSC;                 // gradients w.r.t. X (= previous DOUT), OUT, C1, shortcut-conv output (critic: 4n, tail = pass B)
+        float *V1, *V2, *INJX, *INJC1, *LP1, *LP2;   // critic: pass B's d / d(norm output), pass C's injections, LayerNorm parameter partials
+        size_t sx, sc1, sout;                        // floats per sample of X, C1, OUT
+    };
+    std::vector<RB> GB, DB;
+    long long s_glg, s_glb, s_d0w, s_d0b;            // generator's last LayerNorm; critic's first conv (k3, Cin = 1)
+    UadConvDesc s_d0;
+    float *s_g0, *s_dg0;                             // generator dense output map [n,r,r,8d] and its gradient
+    float *s_hf, *s_stf;                             // relu(LN(last generator block)) + statistics
+    float *s_out0, *s_dout0;                         // critic first conv output [4n] and its gradient [4n]
+    float *s_ta, *s_tb, *s_sp, *s_sct;               // temporaries: conv2 / conv1 data gradients, pooled shortcut, shortcut conv output
     std::map<std::string, std::pair<float*, long long>> dbg;
     std::vector<void*> allocs;
 };
@@ -508,6 +563,12 @@ int dev_alloc(uad_gan* m, float** p, size_t floats, const char* name = nullptr) 
 }
 
 // ---- launch helpers ----
+template <int ACT>
+void rowdot(const float* feat, const float* w, const float* b, int rows, int C, float* out, hipStream_t st) {
+    int lpr = C / 4;
+    if (lpr > 64) lpr = 64;
+    hipLaunchKernelGGL((rowdot_kernel<ACT>), dim3(blocks256((size_t)rows * lpr)), dim3(256), 0, st, feat, w, b, rows, C, lpr, out);
+}
 void ln_fwd(const float* c, const float* gamma, const float* beta, float alpha, int N, int HW, int C, float* a, float* stats, hipStream_t st) {
     if (HW >= 512) hipLaunchKernelGGL((ln_fwd_kernel<128>), dim3(C / 32, N), dim3(1024), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
     else hipLaunchKernelGGL((ln_fwd_kernel<32>), dim3(C / 32, N), dim3(256), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
@@ -636,8 +697,7 @@ void gen_forward(uad_gan* m, const float* z, const float* mask_g, int n, hipStre
     }
     const Block& LL = m->G.back();
     const int rows = n * LL.H * LL.W;
-    hipLaunchKernelGGL((rowdot_kernel<true>), dim3(blocks256((size_t)rows * (LL.C / 4))), dim3(256), 0, st, m->ga[m->G.size()],
-                       P(m, m->g_fw), P(m, m->g_fb), rows, LL.C, m->xg);
+    rowdot<1>(m->ga[m->G.size()], P(m, m->g_fw), P(m, m->g_fb), rows, LL.C, m->xg, st);
 }
 // dx = d loss / d generator output (post-sigmoid); pg: Generator parameter gradients; dz_out: optional d loss / d z
 void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* dx, int n, bool pg, float* dz_out, hipStream_t st) {
@@ -648,7 +708,7 @@ void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* 
     {
         const int rpb = (rows + 1023) / 1024, blocks = (rows + rpb - 1) / rpb;
         hipLaunchKernelGGL(gfinal_bwd_kernel, dim3(blocks), dim3(256), 0, st, dx, m->xg, m->ga[m->G.size()], P(m, m->g_fw), rows, rpb,
-                           LL.C, g, pg ? m->finpart : nullptr);
+                           LL.C, 0, g, pg ? m->finpart : nullptr);
         if (pg) {
             uad_launch_reduce_partials(m->finpart, blocks, LL.C + 1, 1.0f, m->colscratch, st);
             hipMemcpyAsync(Gr(m, m->g_fw), m->colscratch, LL.C * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -701,8 +761,7 @@ void disc_forward(uad_gan* m, int N, bool head, hipStream_t st) {
     if (head) {
         const Block& LL = m->D.back();
         const int rows = N * LL.H * LL.W;
-        hipLaunchKernelGGL((rowdot_kernel<false>), dim3(blocks256((size_t)rows * (LL.C / 4))), dim3(256), 0, st, m->Da[m->D.size()],
-                           P(m, m->d_hw), P(m, m->d_hb), rows, LL.C, m->Dd);
+        rowdot<0>(m->Da[m->D.size()], P(m, m->d_hw), P(m, m->d_hb), rows, LL.C, m->Dd, st);
     }
 }
 // ordinary backward of the first N samples; the top gradient (d loss / d features) is in m->Ga.
@@ -728,9 +787,395 @@ void disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float* 
     }
 }
 
+
+// ================================================================================================ ResNet variant
+// models/fanogan_schlegl.py:119-161.  Every k3 / k1 contraction runs on the generic F / D / W kernels (any KS / S / P).
+typedef uad_gan::RB RB;
+void g_conv_f(uad_gan* m, UadConvDesc d, int N, const float* big_in, long long w, const float* bias, const float* add, float* small_out, hipStream_t st) {
+    d.N = N;
+    uad_launch_conv_f(d, big_in, no_xform(), P(m, w), small_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws);
+}
+void g_conv_d(uad_gan* m, UadConvDesc d, int N, const float* small_in, long long w, const float* bias, const float* add, float* big_out, hipStream_t st) {
+    d.N = N;
+    uad_launch_conv_d(d, small_in, no_xform(), P(m, w), big_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws);
+}
+void g_conv_w(uad_gan* m, UadConvDesc d, int N, const float* big, const float* small_, long long w, hipStream_t st) {
+    d.N = N;
+    uad_launch_conv_w(d, big, no_xform(), small_, no_xform(), Gr(m, w), m->wpartial, st);
+}
+void avgpool_fwd(const float* x, int N, int H, int C, float* y, hipStream_t st) {
+    const size_t t4 = (size_t)N * (H / 2) * (H / 2) * C / 4;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(blocks256(t4)), dim3(256), 0, st, x, H, H, C, t4, y);
+}
+void avgpool_bwd(const float* g, int N, int H, int C, float* dx, hipStream_t st) {
+    const size_t t4 = (size_t)N * H * H * C / 4;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(blocks256(t4)), dim3(256), 0, st, g, H, H, C, t4, dx);
+}
+
+// forward of the first N samples
+void rb_forward(uad_gan* m, RB& B, int N, hipStream_t st) {
+    const int HW = B.Hin * B.Hin;
+    ln_fwd(B.X, P(m, B.ln1g), P(m, B.ln1b), 0.0f, N, HW, B.Cin, B.H1, B.ST1, st);
+    g_conv_f(m, B.d1, N, B.H1, B.w1, P(m, B.b1), nullptr, B.C1, st);
+    ln_fwd(B.C1, P(m, B.ln2g), P(m, B.ln2b), 0.0f, N, HW, B.Cout, B.H2, B.ST2, st);
+    const float* add = B.X;                                   // identity shortcut
+    if (B.ws >= 0) {
+        if (B.gen) g_conv_d(m, B.ds, N, B.X, B.ws, P(m, B.bs), nullptr, m->s_sp, st);
+        else { g_conv_f(m, B.ds, N, B.X, B.ws, P(m, B.bs), nullptr, m->s_sct, st); avgpool_fwd(m->s_sct, N, B.Hin, B.Cout, m->s_sp, st); }
+        add = m->s_sp;
+    }
+    if (B.gen) g_conv_d(m, B.d2, N, B.H2, B.w2, P(m, B.b2), add, B.OUT, st);
+    else g_conv_f(m, B.d2, N, B.H2, B.w2, P(m, B.b2), add, B.OUT, st);
+}
+
+struct RbBwd {
+    int N;
+    size_t in_off, out_off;   // sample offsets of the forward tensors read / of the gradient regions read and written
+    bool pg;                  // parameter gradients (over N + ntail samples from offset 0)
+    int ntail;
+    bool store_v;             // pass B: keep d / d(norm output) for the adjoint pass
+    int inj_lo;               // >= 0: add the second-order injections to samples [inj_lo, inj_lo + ntail)
+};
+void rb_backward(uad_gan* m, RB& B, const RbBwd& a, hipStream_t st) {
+    const int HW = B.Hin * B.Hin, N = a.N;
+    const float* dout = B.DOUT + a.out_off * B.sout;
+    float* g1 = B.G1 + a.out_off * B.sc1;
+    float* dx = B.DX + a.out_off * B.sx;
+    if (B.gen) g_conv_f(m, B.d2, N, dout, B.w2, nullptr, nullptr, m->s_ta, st);      // data gradient of the transposed conv
+    else g_conv_d(m, B.d2, N, dout, B.w2, nullptr, nullptr, m->s_ta, st);
+    LnBwdArgs l;
+    memset(&l, 0, sizeof l);
+    l.da = m->s_ta; l.c = B.C1 + a.in_off * B.sc1; l.stats = B.ST2 + a.in_off * 2 * B.Cout; l.gamma = P(m, B.ln2g); l.beta = P(m, B.ln2b);
+    l.alpha = 0.0f; l.HW = HW; l.C = B.Cout; l.dc = g1; l.v_out = a.store_v ? B.V2 : nullptr; l.gpart = a.pg ? B.LP2 : nullptr;
+    if (a.inj_lo >= 0) { l.add = B.INJC1; l.add_lo = a.inj_lo; l.add_hi = a.inj_lo + a.ntail; }
+    ln_bwd(l, N, st);
+    g_conv_d(m, B.d1, N, g1, B.w1, nullptr, nullptr, m->s_tb, st);
+    const float* addp = dout;                                  // identity shortcut: d / d x gets d / d out
+    if (B.ws >= 0) {
+        if (B.gen) g_conv_f(m, B.ds, N, dout, B.ws, nullptr, nullptr, dx, st);
+        else {
+            float* dsc = B.DSC + a.out_off * B.sc1;
+            avgpool_bwd(dout, N, B.Hin, B.Cout, dsc, st);
+            g_conv_d(m, B.ds, N, dsc, B.ws, nullptr, nullptr, dx, st);
+        }
+        addp = dx;
+    }
+    memset(&l, 0, sizeof l);
+    l.da = m->s_tb; l.c = B.X + a.in_off * B.sx; l.stats = B.ST1 + a.in_off * 2 * B.Cin; l.gamma = P(m, B.ln1g); l.beta = P(m, B.ln1b);
+    l.alpha = 0.0f; l.HW = HW; l.C = B.Cin; l.dc = dx; l.v_out = a.store_v ? B.V1 : nullptr; l.gpart = a.pg ? B.LP1 : nullptr;
+    l.add = addp; l.add_lo = 0; l.add_hi = N;
+    if (a.inj_lo >= 0) { l.add2 = B.INJX; l.add2_lo = a.inj_lo; l.add2_hi = a.inj_lo + a.ntail; }
+    ln_bwd(l, N, st);
+    if (!a.pg) return;
+    const int M = N + a.ntail;
+    uad_launch_reduce_partials(B.LP2, M * (B.Cout / 32), 2 * HW, 1.0f, Gr(m, B.ln2g), st);
+    uad_launch_reduce_partials(B.LP1, M * (B.Cin / 32), 2 * HW, 1.0f, Gr(m, B.ln1g), st);
+    if (B.gen) g_conv_w(m, B.d2, M, B.DOUT, B.H2, B.w2, st); else g_conv_w(m, B.d2, M, B.H2, B.DOUT, B.w2, st);
+    g_conv_w(m, B.d1, M, B.H1, B.G1, B.w1, st);
+    uad_launch_colsum(B.DOUT, N * B.Hout * B.Hout, B.Cout, Gr(m, B.b2), m->colscratch, st);
+    if (B.ws >= 0) {
+        if (B.gen) g_conv_w(m, B.ds, M, B.DOUT, B.X, B.ws, st); else g_conv_w(m, B.ds, M, B.X, B.DSC, B.ws, st);
+        // the shortcut's bias sees the same column sums as conv2's (the pooling / stride-2 scatter only redistributes d / d out)
+        hipMemcpyAsync(Gr(m, B.bs), Gr(m, B.b2), B.Cout * sizeof(float), hipMemcpyDeviceToDevice, st);
+    }
+    // conv1's bias feeds a LayerNorm over (H, W): identically zero gradient (stays at its zero initialisation)
+}
+// adjoint of the data-gradient map of a critic block on the x_hat third (pass C): reads the adjoint of d / d x from X's tail,
+// leaves the adjoint of d / d out in OUT's tail, the pass-C operands of the filter gradients in H1 / H2's tails, the injections
+void rb_adjoint(uad_gan* m, RB& B, int n, hipStream_t st) {
+    const int HW = B.Hin * B.Hin;
+    const size_t hat = (size_t)2 * n, tail = (size_t)3 * n;
+    const float* ubx = B.X + tail * B.sx;
+    LnBwd2Args a;
+    memset(&a, 0, sizeof a);
+    a.q = ubx; a.v = B.V1; a.c = B.X + hat * B.sx; a.stats = B.ST1 + hat * 2 * B.Cin; a.gamma = P(m, B.ln1g); a.beta = P(m, B.ln1b);
+    a.alpha = 0.0f; a.HW = HW; a.C = B.Cin; a.ubar = B.H1 + tail * B.sx; a.inj = B.INJX; a.gpart = B.LP1; a.slot0 = 3 * n;
+    ln_bwd2(a, n, st);
+    g_conv_f(m, B.d1, n, B.H1 + tail * B.sx, B.w1, nullptr, nullptr, m->Q, st);
+    memset(&a, 0, sizeof a);
+    a.q = m->Q; a.v = B.V2; a.c = B.C1 + hat * B.sc1; a.stats = B.ST2 + hat * 2 * B.Cout; a.gamma = P(m, B.ln2g); a.beta = P(m, B.ln2b);
+    a.alpha = 0.0f; a.HW = HW; a.C = B.Cout; a.ubar = B.H2 + tail * B.sc1; a.inj = B.INJC1; a.gpart = B.LP2; a.slot0 = 3 * n;
+    ln_bwd2(a, n, st);
+    const float* add = ubx;
+    if (B.ws >= 0) {
+        g_conv_f(m, B.ds, n, ubx, B.ws, nullptr, nullptr, m->s_sct, st);
+        avgpool_fwd(m->s_sct, n, B.Hin, B.Cout, m->s_sp, st);
+        add = m->s_sp;
+    }
+    g_conv_f(m, B.d2, n, B.H2 + tail * B.sc1, B.w2, nullptr, add, B.OUT + tail * B.sout, st);
+}
+
+void s_enc_forward(uad_gan* m, const float* x, int n, hipStream_t st) {
+    const float* in = x;
+    for (size_t i = 0; i < m->E.size(); ++i) {
+        conv_fwd(m, m->E[i], n, in, m->ec[i], true, st);
+        bn_act_fwd(m, m->E[i], m->ec[i], n, m->ea[i + 1], st);
+        in = m->ea[i + 1];
+    }
+    uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), in, no_xform(), P(m, m->e_dw), m->zr, epi_bias(P(m, m->e_db)), st, nullptr, m->ws);
+    const size_t nz = (size_t)n * m->cfg.zdim;
+    hipLaunchKernelGGL(tanh_kernel, dim3(blocks256(nz)), dim3(256), 0, st, m->zr, nz, m->z);
+}
+void s_enc_backward(uad_gan* m, const float* x, int n, hipStream_t st) {
+    const int zd = m->cfg.zdim;
+    const size_t nz = (size_t)n * zd;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(blocks256(nz)), dim3(256), 0, st, m->dzbuf, m->z, (const float*)nullptr, nz, m->dzr);
+    const UadConvDesc dd = dense_desc(n, m->flat, zd);
+    uad_launch_conv_w(dd, m->ea[m->E.size()], no_xform(), m->dzr, no_xform(), Gr(m, m->e_dw), m->wpartial, st);
+    uad_launch_colsum(m->dzr, n, zd, Gr(m, m->e_db), m->colscratch, st);
+    float* g = m->Ga; float* gn = m->Gb;
+    uad_launch_conv_d(dd, m->dzr, no_xform(), P(m, m->e_dw), g, epi_bias(nullptr), st, nullptr, m->ws);
+    for (int i = (int)m->E.size() - 1; i >= 0; --i) {
+        bn_act_bwd(m, m->E[i], g, m->ec[i], n, gn, st);
+        conv_wgrad(m, m->E[i], n, i == 0 ? x : m->ea[i], gn, st);
+        if (i > 0) conv_dgrad(m, m->E[i], n, gn, g, st);
+    }
+}
+void s_gen_forward(uad_gan* m, const float* z, int n, hipStream_t st) {
+    const int flatg = m->cfg.inter_res * m->cfg.inter_res * 8 * m->dim;
+    uad_launch_conv_f(dense_desc(n, m->cfg.zdim, flatg), z, no_xform(), P(m, m->g_dw), m->s_g0, epi_bias(P(m, m->g_db)), st, nullptr, m->ws);
+    for (auto& B : m->GB) rb_forward(m, B, n, st);
+    const RB& L = m->GB.back();
+    ln_fwd(L.OUT, P(m, m->s_glg), P(m, m->s_glb), 0.0f, n, L.Hout * L.Hout, L.Cout, m->s_hf, m->s_stf, st);
+    rowdot<2>(m->s_hf, P(m, m->g_fw), P(m, m->g_fb), n * L.Hout * L.Hout, L.Cout, m->xg, st);
+}
+void s_gen_backward(uad_gan* m, const float* z, const float* dx, int n, bool pg, float* dz_out, hipStream_t st) {
+    RB& L = m->GB.back();
+    const int rows = n * L.Hout * L.Hout, HW = L.Hout * L.Hout;
+    {
+        const int rpb = (rows + 1023) / 1024, blocks = (rows + rpb - 1) / rpb;
+        hipLaunchKernelGGL(gfinal_bwd_kernel, dim3(blocks), dim3(256), 0, st, dx, m->xg, m->s_hf, P(m, m->g_fw), rows, rpb, L.Cout, 1, m->Ga,
+                           pg ? m->finpart : nullptr);
+        if (pg) {
+            uad_launch_reduce_partials(m->finpart, blocks, L.Cout + 1, 1.0f, m->colscratch, st);
+            hipMemcpyAsync(Gr(m, m->g_fw), m->colscratch, L.Cout * sizeof(float), hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(Gr(m, m->g_fb), m->colscratch + L.Cout, sizeof(float), hipMemcpyDeviceToDevice, st);
+        }
+    }
+    LnBwdArgs l;
+    memset(&l, 0, sizeof l);
+    l.da = m->Ga; l.c = L.OUT; l.stats = m->s_stf; l.gamma = P(m, m->s_glg); l.beta = P(m, m->s_glb); l.alpha = 0.0f; l.HW = HW; l.C = L.Cout;
+    l.dc = L.DOUT; l.gpart = pg ? m->lnpart_g : nullptr;
+    ln_bwd(l, n, st);
+    if (pg) uad_launch_reduce_partials(m->lnpart_g, n * (L.Cout / 32), 2 * HW, 1.0f, Gr(m, m->s_glg), st);
+    RbBwd a{n, 0, 0, pg, 0, false, -1};
+    for (int k = (int)m->GB.size() - 1; k >= 0; --k) rb_backward(m, m->GB[k], a, st);
+    const int flatg = m->cfg.inter_res * m->cfg.inter_res * 8 * m->dim;
+    const UadConvDesc dd = dense_desc(n, m->cfg.zdim, flatg);
+    if (pg) {
+        uad_launch_conv_w(dd, z, no_xform(), m->s_dg0, no_xform(), Gr(m, m->g_dw), m->wpartial, st);
+        uad_launch_colsum(m->s_dg0, n, flatg, Gr(m, m->g_db), m->colscratch, st);
+    }
+    if (dz_out) uad_launch_conv_d(dd, m->s_dg0, no_xform(), P(m, m->g_dw), dz_out, epi_bias(nullptr), st, nullptr, m->ws);
+}
+void s_disc_forward(uad_gan* m, int N, bool head, hipStream_t st) {
+    UadConvDesc d0 = m->s_d0; d0.N = N;
+    uad_launch_conv_first_fwd(d0, m->din, P(m, m->s_d0w), P(m, m->s_d0b), m->s_out0, st);
+    for (auto& B : m->DB) rb_forward(m, B, N, st);
+    if (head) {
+        const RB& L = m->DB.back();
+        rowdot<0>(L.OUT, P(m, m->d_hw), P(m, m->d_hb), N * L.Hout * L.Hout, L.Cout, m->Dd, st);
+    }
+}
+// ordinary backward of the first N samples from DB.back().DOUT (see disc_backward)
+void s_disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float* dx_out, hipStream_t st) {
+    RbBwd a{N, 0, 0, pg, ntail, false, inject_lo};
+    for (int k = (int)m->DB.size() - 1; k >= 0; --k) rb_backward(m, m->DB[k], a, st);
+    UadConvDesc d0 = m->s_d0;
+    if (pg) {
+        d0.N = N + ntail;
+        uad_launch_conv_first_wgrad(d0, m->din, m->s_dout0, Gr(m, m->s_d0w), m->wpartial, st);
+        uad_launch_colsum(m->s_dout0, N * d0.HS * d0.WS, d0.CS, Gr(m, m->s_d0b), m->colscratch, st);
+    }
+    if (dx_out) { d0.N = N; uad_launch_conv_first_dgrad_plain(d0, m->s_dout0, P(m, m->s_d0w), dx_out, st); }
+}
+
 }  // namespace
 
 extern "C" {
+
+// ---- handle of the ResNet variant (models/fanogan_schlegl.py); parameter table in TF first-call order ----
+static int create_resnet(const uad_gan_config_t* cfg, uad_gan_t** out) {
+    const int H = cfg->height, ir = cfg->inter_res, dim = cfg->dim > 0 ? cfg->dim : 64;
+    if (H != 8 * ir) return fail(UAD_ERR_UNSUPPORTED, "ResNet f-AnoGAN: the generator upsamples 8x, height must be 8 * inter_res (fanogan_schlegl.py:28,121-133)");
+    if (dim % 32 || dim > 64) return fail(UAD_ERR_UNSUPPORTED, "ResNet f-AnoGAN: dim must be 32 or 64");
+    if (ir < 2) return fail(UAD_ERR_UNSUPPORTED, "inter_res >= 2 needed");
+    uad_gan* m = new uad_gan();
+    m->cfg = *cfg; m->variant = 1; m->dim = dim;
+    m->npool = 3; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
+    m->step[0] = m->step[1] = m->step[2] = 0;
+    char nm[160];
+    int cin = 1, res = H;
+    for (int i = 0; i < 3; ++i) {
+        const int f = (32 << i) < 128 ? (32 << i) : 128;
+        Block L;
+        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
+        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
+        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        std::string bs = i == 0 ? "Encoder/batch_normalization" : "Encoder/batch_normalization_" + std::to_string(i);
+        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
+        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
+        L.H = L.W = res / 2; L.C = f;
+        m->E.push_back(L);
+        cin = f; res /= 2;
+    }
+    m->cenc = cin; m->cmid = 0; m->flat = ir * ir * cin;
+    m->e_cw = m->e_cb = -1;
+    m->e_dw = add_tensor(m, "Encoder/dense/kernel", 2, m->flat, cfg->zdim, 1, 1);
+    m->e_db = add_tensor(m, "Encoder/dense/bias", 1, cfg->zdim, 1, 1, 1);
+    m->grp_off[UAD_GAN_ENCODER] = 0; m->grp_cnt[UAD_GAN_ENCODER] = m->nparams;
+    int ln = 0;
+    std::map<std::string, int> cnt;
+    auto ln_name = [&](const char* scope) { std::string r = std::string(scope) + (ln == 0 ? "layer_normalization" : "layer_normalization_" + std::to_string(ln)); ++ln; return r; };
+    auto tf_name = [&](const char* scope, const char* base) {
+        const std::string key = std::string(scope) + base;
+        const int k = cnt[key]++;
+        return k == 0 ? key : key + "_" + std::to_string(k);
+    };
+    const int flatg = ir * ir * 8 * dim;
+    m->g_dw = add_tensor(m, "Generator/dense/kernel", 2, cfg->zdim, flatg, 1, 1);
+    m->g_db = add_tensor(m, "Generator/dense/bias", 1, flatg, 1, 1, 1);
+    m->g_cw = m->g_cb = m->g_ln0g = m->g_ln0b = -1;
+    auto make_block = [&](bool gen, const char* scope, int Hin, int Cin, int Cout, int stride) {
+        RB B;
+        memset(&B, 0, sizeof B);
+        B.gen = gen; B.stride = stride; B.Hin = Hin; B.Cin = Cin; B.Cout = Cout;
+        B.Hout = gen ? Hin * stride : Hin / stride;
+        std::string s1 = ln_name(scope);
+        B.ln1g = add_tensor(m, s1 + "/gamma", 2, Hin, Hin, 1, 1); B.ln1b = add_tensor(m, s1 + "/beta", 2, Hin, Hin, 1, 1);
+        std::string c1 = tf_name(scope, "conv2d");
+        B.w1 = add_tensor(m, c1 + "/kernel", 4, 3, 3, Cin, Cout); B.b1 = add_tensor(m, c1 + "/bias", 1, Cout, 1, 1, 1);
+        std::string s2 = ln_name(scope);
+        B.ln2g = add_tensor(m, s2 + "/gamma", 2, Hin, Hin, 1, 1); B.ln2b = add_tensor(m, s2 + "/beta", 2, Hin, Hin, 1, 1);
+        std::string c2 = tf_name(scope, gen ? "conv2d_transpose" : "conv2d");
+        B.w2 = add_tensor(m, c2 + "/kernel", 4, 3, 3, Cout, Cout); B.b2 = add_tensor(m, c2 + "/bias", 1, Cout, 1, 1, 1);
+        B.ws = B.bs = -1;
+        if (stride == 2) {
+            std::string sh = tf_name(scope, gen ? "conv2d_transpose" : "conv2d");
+            if (gen) B.ws = add_tensor(m, sh + "/kernel", 4, 1, 1, Cout, Cin); else B.ws = add_tensor(m, sh + "/kernel", 4, 1, 1, Cin, Cout);
+            B.bs = add_tensor(m, sh + "/bias", 1, Cout, 1, 1, 1);
+        }
+        B.d1 = UadConvDesc{1, Hin, Hin, Cin, Hin, Hin, Cout, 3, 1, 1};
+        const int P2 = stride == 1 ? 1 : 0;                       // TF SAME: k3 s1 pads 1 before; k3 s2 on an even size pads 0 before
+        if (gen) {
+            B.d2 = UadConvDesc{1, B.Hout, B.Hout, Cout, Hin, Hin, Cout, 3, stride, P2};     // big = output of the transposed conv
+            B.ds = UadConvDesc{1, B.Hout, B.Hout, Cout, Hin, Hin, Cin, 1, 2, 0};
+        } else {
+            B.d2 = UadConvDesc{1, Hin, Hin, Cout, B.Hout, B.Hout, Cout, 3, stride, P2};
+            B.ds = UadConvDesc{1, Hin, Hin, Cin, Hin, Hin, Cout, 1, 1, 0};
+        }
+        B.sx = (size_t)Hin * Hin * Cin; B.sc1 = (size_t)Hin * Hin * Cout; B.sout = (size_t)B.Hout * B.Hout * Cout;
+        return B;
+    };
+    {
+        const int chans[4] = {8 * dim, 4 * dim, 2 * dim, dim}, strides[4] = {1, 2, 2, 2};
+        int c = 8 * dim, r = ir;
+        for (int k = 0; k < 4; ++k) { m->GB.push_back(make_block(true, "Generator/", r, c, chans[k], strides[k])); c = chans[k]; r *= strides[k]; }
+        const std::string sl = ln_name("Generator/");
+        m->s_glg = add_tensor(m, sl + "/gamma", 2, r, r, 1, 1); m->s_glb = add_tensor(m, sl + "/beta", 2, r, r, 1, 1);
+        const std::string gf = tf_name("Generator/", "conv2d");
+        m->g_fw = add_tensor(m, gf + "/kernel", 4, 1, 1, c, 1); m->g_fb = add_tensor(m, gf + "/bias", 1, 1, 1, 1, 1);
+    }
+    m->grp_off[UAD_GAN_GENERATOR] = m->grp_cnt[UAD_GAN_ENCODER];
+    m->grp_cnt[UAD_GAN_GENERATOR] = m->nparams - m->grp_off[UAD_GAN_GENERATOR];
+    {
+        const std::string d0 = tf_name("Discriminator/", "conv2d");
+        m->s_d0w = add_tensor(m, d0 + "/kernel", 4, 3, 3, 1, dim); m->s_d0b = add_tensor(m, d0 + "/bias", 1, dim, 1, 1, 1);
+        m->s_d0 = UadConvDesc{1, H, H, 1, H, H, dim, 3, 1, 1};
+        const int chans[4] = {2 * dim, 4 * dim, 8 * dim, 8 * dim}, strides[4] = {2, 2, 2, 1};
+        int c = dim, r = H;
+        for (int k = 0; k < 4; ++k) { m->DB.push_back(make_block(false, "Discriminator/", r, c, chans[k], strides[k])); c = chans[k]; r /= strides[k]; }
+        m->d_hw = add_tensor(m, "Discriminator/dense/kernel", 2, c, 1, 1, 1);
+        m->d_hb = add_tensor(m, "Discriminator/dense/bias", 1, 1, 1, 1, 1);
+    }
+    m->grp_off[UAD_GAN_DISCRIMINATOR] = m->grp_off[UAD_GAN_GENERATOR] + m->grp_cnt[UAD_GAN_GENERATOR];
+    m->grp_cnt[UAD_GAN_DISCRIMINATOR] = m->nparams - m->grp_off[UAD_GAN_DISCRIMINATOR];
+
+    // ---- device memory ----
+    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H;
+    int rc = UAD_OK;
+#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
+    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
+    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
+    ALLOC(m->wpack_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack_d, (size_t)m->nparams, nullptr);
+    ALLOC(m->wpack16_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack16_d, (size_t)m->nparams, nullptr);
+    size_t maxact = 3 * NB * HW, max_ta = 0, max_tb = 0, max_sp = 0, max_q = 0, lnp_g = 0;
+    m->ec.resize(3); m->ea.resize(4, nullptr);
+    for (int i = 0; i < 3; ++i) {
+        const size_t sz = NB * asz(m->E[i]);
+        snprintf(nm, sizeof nm, "ec%d", i); ALLOC(m->ec[i], sz, nm);
+        snprintf(nm, sizeof nm, "ea%d", i + 1); ALLOC(m->ea[i + 1], sz, nm);
+        if (sz > maxact) maxact = sz;
+    }
+    ALLOC(m->zr, NB * cfg->zdim, "zr"); ALLOC(m->z, NB * cfg->zdim, "z"); ALLOC(m->xg, NB * HW, "xg");
+    ALLOC(m->s_g0, NB * flatg, "sg_x0"); ALLOC(m->s_dg0, NB * flatg, nullptr);
+    auto alloc_block = [&](RB& B, float* X, float* DX, size_t cap_act, size_t cap_fwd, bool critic, const char* tag, int k) {
+        B.X = X; B.DX = DX;
+        snprintf(nm, sizeof nm, "%s_h1_%d", tag, k); ALLOC(B.H1, cap_act * B.sx, nm);
+        snprintf(nm, sizeof nm, "%s_c1_%d", tag, k); ALLOC(B.C1, cap_fwd * B.sc1, nm);
+        snprintf(nm, sizeof nm, "%s_h2_%d", tag, k); ALLOC(B.H2, cap_act * B.sc1, nm);
+        snprintf(nm, sizeof nm, "%s_out_%d", tag, k); ALLOC(B.OUT, cap_act * B.sout, nm);
+        ALLOC(B.ST1, cap_fwd * 2 * B.Cin, nullptr); ALLOC(B.ST2, cap_fwd * 2 * B.Cout, nullptr);
+        snprintf(nm, sizeof nm, "%s_dout_%d", tag, k); ALLOC(B.DOUT, cap_act * B.sout, nm);
+        snprintf(nm, sizeof nm, "%s_g1_%d", tag, k); ALLOC(B.G1, cap_act * B.sc1, nm);
+        if (critic && B.ws >= 0) ALLOC(B.DSC, cap_act * B.sc1, nullptr);
+        if (critic) {
+            snprintf(nm, sizeof nm, "%s_v1_%d", tag, k); ALLOC(B.V1, NB * B.sx, nm);
+            snprintf(nm, sizeof nm, "%s_v2_%d", tag, k); ALLOC(B.V2, NB * B.sc1, nm);
+            snprintf(nm, sizeof nm, "%s_injx_%d", tag, k); ALLOC(B.INJX, NB * B.sx, nm);
+            snprintf(nm, sizeof nm, "%s_injc1_%d", tag, k); ALLOC(B.INJC1, NB * B.sc1, nm);
+        }
+        ALLOC(B.LP1, cap_act * (B.Cin / 32) * 2 * B.Hin * B.Hin, nullptr);
+        ALLOC(B.LP2, cap_act * (B.Cout / 32) * 2 * B.Hin * B.Hin, nullptr);
+        if (cap_fwd * B.sc1 > max_ta) max_ta = cap_fwd * B.sc1;
+        if (cap_fwd * B.sx > max_tb) max_tb = cap_fwd * B.sx;
+        if (cap_fwd * B.sout > max_sp) max_sp = cap_fwd * B.sout;
+        if (NB * B.sc1 > max_q) max_q = NB * B.sc1;
+    };
+    {
+        float* X = m->s_g0; float* DX = m->s_dg0;
+        for (size_t k = 0; k < m->GB.size(); ++k) { alloc_block(m->GB[k], X, DX, NB, NB, false, "sg", (int)k); X = m->GB[k].OUT; DX = m->GB[k].DOUT; }
+        const RB& L = m->GB.back();
+        ALLOC(m->s_hf, NB * L.sout, "sg_hf"); ALLOC(m->s_stf, NB * 2 * L.Cout, nullptr);
+        lnp_g = NB * (L.Cout / 32) * 2 * L.Hout * L.Hout;
+        if (NB * L.sout > maxact) maxact = NB * L.sout;
+    }
+    ALLOC(m->lnpart_g, lnp_g, nullptr);
+    ALLOC(m->din, 4 * NB * HW, "din");
+    ALLOC(m->s_out0, 4 * NB * HW * dim, "sd_out0"); ALLOC(m->s_dout0, 4 * NB * HW * dim, "sd_dout0");
+    {
+        float* X = m->s_out0; float* DX = m->s_dout0;
+        for (size_t k = 0; k < m->DB.size(); ++k) { alloc_block(m->DB[k], X, DX, 4 * NB, 3 * NB, true, "sd", (int)k); X = m->DB[k].OUT; DX = m->DB[k].DOUT; }
+    }
+    ALLOC(m->s_ta, max_ta, nullptr); ALLOC(m->s_tb, max_tb, nullptr); ALLOC(m->s_sp, max_sp, nullptr); ALLOC(m->s_sct, max_ta, nullptr);
+    ALLOC(m->Q, max_q, "Q");
+    ALLOC(m->Dd, 3 * NB * ir * ir, "Dd"); ALLOC(m->Gx, NB * HW, "Gx"); ALLOC(m->slopes, NB * H, "slopes");
+    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
+    ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->dzbuf, NB * cfg->zdim, "dz"); ALLOC(m->dzr, NB * cfg->zdim, nullptr);
+    {
+        size_t wp = 0, need = (size_t)4 << 20;
+        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
+        auto want = [&](UadConvDesc d, size_t n) { d.N = (int)n; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, false); if (v > need) need = v; } };
+        for (size_t i = 1; i < m->E.size(); ++i) { wp_need(m->E[i].d, NB); UadConvDesc d = m->E[i].d; d.N = (int)NB; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, true); if (v > need) need = v; } }
+        for (auto& B : m->GB) { wp_need(B.d1, NB); wp_need(B.d2, NB); want(B.d1, NB); want(B.d2, NB); if (B.ws >= 0) { wp_need(B.ds, NB); want(B.ds, NB); } }
+        for (auto& B : m->DB) { wp_need(B.d1, 4 * NB); wp_need(B.d2, 4 * NB); want(B.d1, 3 * NB); want(B.d2, 3 * NB); want(B.d1, NB); want(B.d2, NB);
+                                if (B.ws >= 0) { wp_need(B.ds, 4 * NB); want(B.ds, 3 * NB); want(B.ds, NB); } }
+        wp_need(dense_desc(1, m->flat, cfg->zdim), NB); wp_need(dense_desc(1, cfg->zdim, flatg), NB);
+        want(dense_desc(1, m->flat, cfg->zdim), NB); want(dense_desc(1, cfg->zdim, flatg), NB);
+        { UadConvDesc d0 = m->s_d0; d0.N = (int)(4 * NB); size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
+        { UadConvDesc d0 = m->E[0].d; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
+        ALLOC(m->wpartial, wp, nullptr);
+        m->ws.floats = need; m->ws.ptr = nullptr;
+        ALLOC(m->ws.ptr, need, nullptr);
+    }
+    ALLOC(m->colscratch, 64 * 1024, nullptr); ALLOC(m->colpart, (size_t)kBnBwdBlocks * 2 * 128, nullptr);
+    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
+    ALLOC(m->finpart, (size_t)1024 * 520, nullptr);
+#undef ALLOC
+    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
+    *out = m;
+    return UAD_OK;
+}
 
 int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (!cfg || !out) return fail(UAD_ERR_INVALID, "null argument");
@@ -741,12 +1186,14 @@ int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
     if (cfg->zdim <= 0 || cfg->zdim % 8) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
     if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
+    if (cfg->variant != UAD_GAN_UNIFIED && cfg->variant != UAD_GAN_RESNET) return fail(UAD_ERR_INVALID, "bad variant");
+    if (cfg->variant == UAD_GAN_RESNET) return create_resnet(cfg, out);
     const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
     if (npool < 2 || npool > 5) return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 2..5 blocks supported", npool);
     if (H < 32) return fail(UAD_ERR_UNSUPPORTED, "height >= 32 needed");
 
     uad_gan* m = new uad_gan();
-    m->cfg = *cfg;
+    m->cfg = *cfg; m->variant = 0; m->dim = 0;
     m->npool = npool; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
     m->step[0] = m->step[1] = m->step[2] = 0;
     const int ir = cfg->inter_res;
@@ -975,54 +1422,70 @@ int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int wa
     if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
     if (phase < 0 || phase > 2) return fail(UAD_ERR_INVALID, "bad phase");
     hipStream_t st = (hipStream_t)stream;
+    const bool rn = m->variant == UAD_GAN_RESNET;
     const int H = m->cfg.height, ir = m->cfg.inter_res, L = m->npool;
     const size_t HW = (size_t)H * H, img = (size_t)n * HW;
     const int P2 = ir * ir;                        // feature-map locations per sample
-    const Block& DL = m->D.back();
+    const int FC = rn ? m->DB.back().Cout : m->D.back().C;                 // feature channels
+    float* feat = rn ? m->DB.back().OUT : m->Da[L];                        // critic features, 4n layout
+    float* top = rn ? m->DB.back().DOUT : m->Ga;                           // d loss / d features
     float* scal = io->scalars ? io->scalars : m->scalars_own;
     refresh_packs(m, st);
+    auto gen_fwd = [&](const float* z) { if (rn) s_gen_forward(m, z, n, st); else gen_forward(m, z, io->mask_g, n, st); };
+    auto gen_bwd = [&](const float* z, bool pg, float* dz) { if (rn) s_gen_backward(m, z, m->dxbuf, n, pg, dz, st); else gen_backward(m, z, io->mask_g, m->dxbuf, n, pg, dz, st); };
+    auto disc_fwd = [&](int N, bool head) { if (rn) s_disc_forward(m, N, head, st); else disc_forward(m, N, head, st); };
+    auto disc_bwd = [&](int N, bool pg, int ntail, int inj_lo, float* dx) { if (rn) s_disc_backward(m, N, pg, ntail, inj_lo, dx, st); else disc_backward(m, N, pg, ntail, inj_lo, dx, st); };
 
     if (phase == UAD_GAN_GENERATOR) {
         // trainers/fAnoGAN.py:52,75: gen_loss = -mean(D(G(z))), gradient w.r.t. the Generator variables
         if (!io->z) return fail(UAD_ERR_INVALID, "generator phase needs io.z");
-        gen_forward(m, io->z, io->mask_g, n, st);
+        gen_fwd(io->z);
         HIP_TRY(hipMemcpyAsync(m->din, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
-        disc_forward(m, n, true, st);
+        disc_fwd(n, true);
         reduce_to<0>(m, 0, m->Dd, nullptr, (size_t)n * P2, 1.0f / (float)(n * P2), nullptr, st);
         hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, phase, m->raw, m->cfg.kappa, scal);
         if (want_backward) {
             Coef4 cf{{-1.0f / (float)(n * P2), 0.f, 0.f, 0.f}};
-            const size_t t4 = (size_t)n * P2 * DL.C / 4;
-            hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, DL.C, t4, cf, m->Ga);
-            disc_backward(m, n, false, 0, -1, m->dxbuf, st);
-            gen_backward(m, io->z, io->mask_g, m->dxbuf, n, true, nullptr, st);
+            const size_t t4 = (size_t)n * P2 * FC / 4;
+            hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, FC, t4, cf, top);
+            disc_bwd(n, false, 0, -1, m->dxbuf);
+            gen_bwd(io->z, true, nullptr);
         }
         if (io->generated) HIP_TRY(hipMemcpyAsync(io->generated, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else if (phase == UAD_GAN_DISCRIMINATOR) {
         // trainers/fAnoGAN.py:50-58,74
         if (!io->z || !io->x || !io->alpha) return fail(UAD_ERR_INVALID, "critic phase needs io.x, io.z and io.alpha");
-        gen_forward(m, io->z, io->mask_g, n, st);
+        gen_fwd(io->z);
         hipLaunchKernelGGL(interp_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, io->alpha, (int)HW, img, m->din);
-        disc_forward(m, 3 * n, true, st);                                                         // pass A
+        disc_fwd(3 * n, true);                                                                    // pass A
         reduce_to<0>(m, 0, m->Dd, nullptr, (size_t)n * P2, 1.0f / (float)(n * P2), nullptr, st);
         reduce_to<0>(m, 1, m->Dd + (size_t)n * P2, nullptr, (size_t)n * P2, 1.0f / (float)(n * P2), nullptr, st);
         // pass B: ddx = d sum(d_hat) / d x_hat on samples [2n, 3n)
         {
             Coef4 one{{1.f, 1.f, 1.f, 1.f}};
-            const size_t t4 = (size_t)n * P2 * DL.C / 4;
-            float* u = m->Ga; float* un = m->Gb;
-            hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, DL.C, t4, one, u);
-            for (int i = L - 1; i >= 0; --i) {
-                const Block& B = m->D[i];
-                const size_t per = asz(B);
-                LnBwdArgs a;
-                memset(&a, 0, sizeof a);
-                a.da = u; a.c = m->Dc[i] + 2 * n * per; a.stats = m->Dstat[i] + (size_t)2 * n * 2 * B.C;
-                a.gamma = P(m, B.gamma); a.beta = P(m, B.beta); a.alpha = kLrelu; a.HW = B.H * B.W; a.C = B.C;
-                a.dc = m->Dg[i] + 3 * n * per; a.v_out = m->V[i];
-                ln_bwd(a, n, st);
-                if (i > 0) { conv_dgrad(m, B, n, a.dc, un, st); float* t = u; u = un; un = t; }
-                else conv_dgrad(m, B, n, a.dc, m->Gx, st);
+            const size_t t4 = (size_t)n * P2 * FC / 4;
+            if (rn) {
+                const RB& LB = m->DB.back();
+                hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, FC, t4, one, LB.DOUT + (size_t)3 * n * LB.sout);
+                RbBwd a{n, (size_t)2 * n, (size_t)3 * n, false, 0, true, -1};
+                for (int k = (int)m->DB.size() - 1; k >= 0; --k) rb_backward(m, m->DB[k], a, st);
+                UadConvDesc d0 = m->s_d0; d0.N = n;
+                uad_launch_conv_first_dgrad_plain(d0, m->s_dout0 + (size_t)3 * n * HW * m->dim, P(m, m->s_d0w), m->Gx, st);
+            } else {
+                float* u = m->Ga; float* un = m->Gb;
+                hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, FC, t4, one, u);
+                for (int i = L - 1; i >= 0; --i) {
+                    const Block& B = m->D[i];
+                    const size_t per = asz(B);
+                    LnBwdArgs a;
+                    memset(&a, 0, sizeof a);
+                    a.da = u; a.c = m->Dc[i] + 2 * n * per; a.stats = m->Dstat[i] + (size_t)2 * n * 2 * B.C;
+                    a.gamma = P(m, B.gamma); a.beta = P(m, B.beta); a.alpha = kLrelu; a.HW = B.H * B.W; a.C = B.C;
+                    a.dc = m->Dg[i] + 3 * n * per; a.v_out = m->V[i];
+                    ln_bwd(a, n, st);
+                    if (i > 0) { conv_dgrad(m, B, n, a.dc, un, st); float* t = u; u = un; un = t; }
+                    else conv_dgrad(m, B, n, a.dc, m->Gx, st);
+                }
             }
         }
         const int cols = n * H;
@@ -1033,54 +1496,60 @@ int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int wa
             // pass C, bottom-up: adjoint of pass B.  ubar_0 = d penalty / d ddx lives in din's tail.
             hipLaunchKernelGGL(pen_grad_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->Gx, m->slopes,
                                m->cfg.scale * 2.0f / (float)cols, H, H, img, m->din + 3 * img);
-            for (int i = 0; i < L; ++i) {
-                const Block& B = m->D[i];
-                const size_t per = asz(B);
-                const float* ubar = i == 0 ? m->din + 3 * img : m->Da[i] + 3 * n * asz(m->D[i - 1]);
-                conv_fwd(m, B, n, ubar, m->Q, false, st);                 // adjoint of the data gradient w.r.t. its input
-                LnBwd2Args a;
-                memset(&a, 0, sizeof a);
-                a.q = m->Q; a.v = m->V[i]; a.c = m->Dc[i] + 2 * n * per; a.stats = m->Dstat[i] + (size_t)2 * n * 2 * B.C;
-                a.gamma = P(m, B.gamma); a.beta = P(m, B.beta); a.alpha = kLrelu; a.HW = B.H * B.W; a.C = B.C;
-                a.ubar = m->Da[i + 1] + 3 * n * per; a.inj = m->inj[i]; a.gpart = m->lnpart[i]; a.slot0 = 3 * n;
-                ln_bwd2(a, n, st);
+            if (rn) {
+                UadConvDesc d0 = m->s_d0; d0.N = n;
+                uad_launch_conv_first_fwd(d0, m->din + 3 * img, P(m, m->s_d0w), nullptr, m->s_out0 + (size_t)3 * n * HW * m->dim, st);
+                for (auto& B : m->DB) rb_adjoint(m, B, n, st);
+            } else {
+                for (int i = 0; i < L; ++i) {
+                    const Block& B = m->D[i];
+                    const size_t per = asz(B);
+                    const float* ubar = i == 0 ? m->din + 3 * img : m->Da[i] + 3 * n * asz(m->D[i - 1]);
+                    conv_fwd(m, B, n, ubar, m->Q, false, st);                 // adjoint of the data gradient w.r.t. its input
+                    LnBwd2Args a;
+                    memset(&a, 0, sizeof a);
+                    a.q = m->Q; a.v = m->V[i]; a.c = m->Dc[i] + 2 * n * per; a.stats = m->Dstat[i] + (size_t)2 * n * 2 * B.C;
+                    a.gamma = P(m, B.gamma); a.beta = P(m, B.beta); a.alpha = kLrelu; a.HW = B.H * B.W; a.C = B.C;
+                    a.ubar = m->Da[i + 1] + 3 * n * per; a.inj = m->inj[i]; a.gpart = m->lnpart[i]; a.slot0 = 3 * n;
+                    ln_bwd2(a, n, st);
+                }
             }
             // pass D: ordinary backward of all 3n samples; top gradient +1/(n P) fake, -1/(n P) real, 0 for x_hat
             const float k = 1.0f / (float)(n * P2);
             Coef4 cf{{k, -k, 0.f, 1.f}};
-            const size_t t4 = (size_t)3 * n * P2 * DL.C / 4;
-            hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, DL.C, t4, cf, m->Ga);
+            const size_t t4 = (size_t)3 * n * P2 * FC / 4;
+            hipLaunchKernelGGL(topgrad_kernel, dim3(blocks256(t4)), dim3(256), 0, st, P(m, m->d_hw), n * P2, FC, t4, cf, top);
             {   // Dense(1): kernel gradient over the 3n feature rows (coefficient per third) + pass C's adjoint rows (coefficient 1)
                 const int rows = 4 * n * P2, rpb = (rows + 255) / 256, blocks = (rows + rpb - 1) / rpb;
-                hipLaunchKernelGGL(coef_colsum_kernel, dim3(blocks), dim3(256), 0, st, m->Da[L], rows, rpb, n * P2, DL.C, cf, m->finpart);
-                uad_launch_reduce_partials(m->finpart, blocks, DL.C, 1.0f, Gr(m, m->d_hw), st);
+                hipLaunchKernelGGL(coef_colsum_kernel, dim3(blocks), dim3(256), 0, st, feat, rows, rpb, n * P2, FC, cf, m->finpart);
+                uad_launch_reduce_partials(m->finpart, blocks, FC, 1.0f, Gr(m, m->d_hw), st);
                 // Dense(1) bias: +1/(nP) over the fake rows, -1/(nP) over the real rows = 0 (stays at its zero initialisation)
             }
-            disc_backward(m, 3 * n, true, n, 2 * n, nullptr, st);
+            disc_bwd(3 * n, true, n, 2 * n, nullptr);
         }
         if (io->generated) HIP_TRY(hipMemcpyAsync(io->generated, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
         // trainers/fAnoGAN.py:60-66,76: enc_loss = MSE(x, x_enc) + kappa * MSE(features(x_enc), features(x)) w.r.t. the Encoder
         if (!io->x) return fail(UAD_ERR_INVALID, "encoder phase needs io.x");
-        enc_forward(m, io->x, io->mask_z, n, st);
-        gen_forward(m, m->z, io->mask_g, n, st);
+        if (rn) s_enc_forward(m, io->x, n, st); else enc_forward(m, io->x, io->mask_z, n, st);
+        gen_fwd(m->z);
         HIP_TRY(hipMemcpyAsync(m->din, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(m->din + img, io->x, img * sizeof(float), hipMemcpyDeviceToDevice, st));
-        disc_forward(m, 2 * n, false, st);
-        const size_t nf = (size_t)n * P2 * DL.C;
-        const float* f_enc = m->Da[L];
-        const float* f_real = m->Da[L] + nf;
+        disc_fwd(2 * n, false);
+        const size_t nf = (size_t)n * P2 * FC;
+        const float* f_enc = feat;
+        const float* f_real = feat + nf;
         reduce_to<1>(m, 0, io->x, m->xg, img, 1.0f / (float)img, nullptr, st);
         reduce_to<1>(m, 1, f_enc, f_real, nf, 1.0f / (float)nf, nullptr, st);
         reduce_to<2>(m, 2, io->x, m->xg, img, 1.0f / (float)n, io->l1_map, st);
         hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, phase, m->raw, m->cfg.kappa, scal);
         if (want_backward) {
             hipLaunchKernelGGL((diff_scale_kernel<false>), dim3(blocks256(nf)), dim3(256), 0, st, f_enc, f_real,
-                               m->cfg.kappa * 2.0f / (float)nf, nf, m->Ga);
-            disc_backward(m, n, false, 0, -1, m->dxbuf, st);
+                               m->cfg.kappa * 2.0f / (float)nf, nf, top);
+            disc_bwd(n, false, 0, -1, m->dxbuf);
             hipLaunchKernelGGL((diff_scale_kernel<true>), dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, 2.0f / (float)img, img, m->dxbuf);
-            gen_backward(m, m->z, io->mask_g, m->dxbuf, n, false, m->dzbuf, st);
-            enc_backward(m, io->x, io->mask_z, n, st);
+            gen_bwd(m->z, false, m->dzbuf);
+            if (rn) s_enc_backward(m, io->x, n, st); else enc_backward(m, io->x, io->mask_z, n, st);
         }
         if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
         if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1095,8 +1564,8 @@ int uad_gan_reconstruct(uad_gan_t* m, const uad_gan_io_t* io, int n, void* strea
     hipStream_t st = (hipStream_t)stream;
     const size_t img = (size_t)n * m->cfg.height * m->cfg.width;
     refresh_packs(m, st);
-    enc_forward(m, io->x, io->mask_z, n, st);
-    gen_forward(m, m->z, io->mask_g, n, st);
+    if (m->variant == UAD_GAN_RESNET) { s_enc_forward(m, io->x, n, st); s_gen_forward(m, m->z, n, st); }
+    else { enc_forward(m, io->x, io->mask_z, n, st); gen_forward(m, m->z, io->mask_g, n, st); }
     if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (io->l1_map) hipLaunchKernelGGL((sum_kernel<2>), dim3(256), dim3(256), 0, st, io->x, m->xg, img, io->l1_map, m->redpart);

@@ -1183,7 +1183,8 @@ int uad_op_conv_first_fwd(const uad_conv_desc_t* d, const float* x, const float*
     return UAD_OK;
 }
 int uad_op_conv_first_wgrad(const uad_conv_desc_t* dd, const float* x, const float* g, float* dW, void* stream) {
-    if (!dd || dd->KS != 5 || (dd->CB != 1 && dd->CB != 3) || 256 % dd->CS) return fail(UAD_ERR_UNSUPPORTED, "first wgrad: KS=5, Cin in {1,3}, Cout | 256");
+    if (!dd || !((dd->KS == 5 && (dd->CB == 1 || dd->CB == 3)) || (dd->KS == 3 && dd->CB == 1)) || 256 % dd->CS)
+        return fail(UAD_ERR_UNSUPPORTED, "first wgrad: (KS=5, Cin in {1,3}) or (KS=3, Cin=1), Cout | 256");
     UadConvDesc d = to_desc(dd);
     float* partial = nullptr;
     HIP_TRY(hipMalloc((void**)&partial, uad_conv_first_wgrad_partial_floats(d) * sizeof(float)));

@@ -14,14 +14,19 @@ GROUPS = {'Encoder': _lib.GAN_ENCODER, 'Generator': _lib.GAN_GENERATOR, 'Discrim
 
 class GanEngine(_EvalOps):
     def __init__(self, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, scale=10.0, kappa=1.0,
-                 device=None, math='bf16x3'):
+                 device=None, math='bf16x3', variant='unified', dim=64):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         torch.cuda.set_device(self.device)
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
-        cfg = _lib.UadGanConfig(height, width, channels, inter_res, zdim, max_batch, float(scale), float(kappa))
+        variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET}
+        if variant not in variants:
+            raise ValueError(f'unknown f-AnoGAN variant {variant!r}')
+        self.variant, self.dim = variant, int(dim)
+        cfg = _lib.UadGanConfig(height, width, channels, inter_res, zdim, max_batch, float(scale), float(kappa), variants[variant],
+                                int(dim))
         h = C.c_void_p()
         _lib.check(self.lib.uad_gan_create(C.byref(cfg), C.byref(h)))
         self.handle = h
@@ -135,6 +140,8 @@ class GanEngine(_EvalOps):
         x = self._dev(x, img)
         z = self._dev(z, (n, self.zdim))
         alpha = self._dev(None if alpha is None else np.asarray(alpha, np.float32).reshape(-1) if not isinstance(alpha, torch.Tensor) else alpha.reshape(-1), (n,))
+        if self.variant == 'resnet' and (mask_z is not None or mask_g is not None):
+            raise ValueError('the ResNet f-AnoGAN graph has no dropout layers (models/fanogan_schlegl.py): masks are not accepted')
         mask_z = self._dev(mask_z, (n, self.zdim))
         mask_g = self._dev(mask_g, (n, self.flat))
         out = {}

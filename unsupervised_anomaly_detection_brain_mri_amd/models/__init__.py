@@ -6,3 +6,4 @@ from .variational_autoencoder import variational_autoencoder  # noqa: F401
 from .context_encoder_variational_autoencoder import context_encoder_variational_autoencoder  # noqa: F401
 from .gaussian_mixture_variational_autoencoder_spatial import gaussian_mixture_variational_autoencoder_spatial  # noqa: F401
 from .fanogan import fanogan  # noqa: F401
+from .fanogan_schlegl import fanogan_schlegl  # noqa: F401

@@ -8,6 +8,7 @@ def fanogan(z=None, x=None, dropout_rate=None, dropout=None, config=None):
 
 
 fanogan.arch = 'fAnoGAN'
+fanogan.variant = 'unified'
 # fanogan.py:30,42,47,57-58,64-65,69,75-76,82-83
 fanogan.output_keys = ('z_enc', 'x_enc', 'x_', 'd_fake_features', 'd_', 'd_features', 'd', 'x_hat', 'd_hat_features', 'd_hat',
                        'd_enc_features', 'd_enc')

@@ -28,7 +28,7 @@ class fAnoGAN(AEMODEL):
         c = self.config
         return GanEngine(c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]), c.zDim,
                          max_batch=max(int(c.batchsize), 1), scale=float(getattr(c, 'scale', 10.0)),
-                         kappa=float(getattr(c, 'kappa', 1.0)), device=device)
+                         kappa=float(getattr(c, 'kappa', 1.0)), device=device, variant=getattr(self.network, 'variant', 'unified'))
 
     def _make_dp(self, world):
         return GanDataParallel(self.engine, world)
@@ -39,7 +39,7 @@ class fAnoGAN(AEMODEL):
 
     def _keep(self, shape, train):
         r = float(self.config.dropout_rate)
-        if not train or r <= 0:
+        if not train or r <= 0 or self.engine.variant == 'resnet':      # the ResNet graph has no dropout layers
             return None
         return (self.rng.random(shape) >= r).astype(np.float32) / (1.0 - r)
 
