@@ -192,8 +192,8 @@ def bench_gmvae(args):
 
 
 def bench_fanogan(args):
-    """BASELINE.json configs[3] shape (64x64) on the unified f-AnoGAN graph (models/fanogan.py -- the graph north_star names;
-    the ResNet `fanogan_schlegl` variant is not built).  One 'step' = one batch iteration of the reference's WGAN stage
+    """BASELINE.json configs[3]: f-AnoGAN 64x64 on the ResNet graph (models/fanogan_schlegl.py; --variant unified = models/fanogan.py,
+    the graph north_star names).  One 'step' = one batch iteration of the reference's WGAN stage
     (trainers/fAnoGAN.py:97-130): 1 generator step + 5 critic steps (each incl. the second-order gradient-penalty backward) +
     their Adam updates; value = slices per second through that loop.  The encoder stage (izi_f) is timed beside it."""
     import torch
@@ -210,7 +210,9 @@ def bench_fanogan(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     hh, bs, zd = args.size or 64, BATCH, 128
-    eng = GanEngine(hh, hh, 1, 8, zd, max_batch=bs, device=f'cuda:{local_rank}', math=args.math)
+    eng = GanEngine(hh, hh, 1, hh // 8 if args.variant == 'resnet' else 8, zd, max_batch=bs, device=f'cuda:{local_rank}', math=args.math,
+                    variant=args.variant)
+    graph = 'models/fanogan_schlegl.py (ResNet generator / critic, dim 64)' if args.variant == 'resnet' else 'models/fanogan.py (unified graph)'
     rng = np.random.default_rng(3)
     flat = np.zeros(eng.nparams, np.float32)
     for name, shape, off in eng.spec:
@@ -266,11 +268,12 @@ def bench_fanogan(args):
     assert bool(torch.isfinite(out_e['enc_loss']))
     if rank == 0:
         value = bs * world * args.steps / dt
-        res = {'metric': f'MRI slices/sec f-AnoGAN WGAN-GP batch iteration (1 G + 5 D steps, {hh}x{hh}, bs={bs}/GPU)',
+        res = {'metric': f'MRI slices/sec f-AnoGAN ({args.variant}) WGAN-GP batch iteration (1 G + 5 D steps, {hh}x{hh}, bs={bs}/GPU)',
                'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': args.math, 'data': 'synthetic',
-               'config': {'workload': f'BASELINE.json configs[3] shape: unified f-AnoGAN graph (models/fanogan.py) {hh}x{hh}x1, zDim {zd}, '
+               'dtype': 'f32' if args.variant == 'resnet' else args.math,      # the k3 / k1 contractions run on the generic fp32-MFMA kernels
+               'data': 'synthetic',
+               'config': {'workload': f'BASELINE.json configs[3]: f-AnoGAN {graph} {hh}x{hh}x1, zDim {zd}, '
                                       f'{bs} slices per GPU; step = 1 generator + 5 critic phases with Adam (trainers/fAnoGAN.py:97-130)',
                           'encoder_stage_ms_per_step': round(dt_e / args.steps * 1e3, 3),
                           'encoder_stage_slices_per_s': round(bs * world * args.steps / dt_e, 2), 'parallelism': f'dp{world}'}}
@@ -293,10 +296,14 @@ def main():
                     help='VAE = the headline workload (BASELINE.json configs[1]); ceVAE = configs[3] (16 slices per GPU: both '
                          'branches + the input-gradient anomaly map every step), reported for the record')
     ap.add_argument('--size', type=int, default=0, help='fAnoGAN: slice edge (default 64)')
+    ap.add_argument('--variant', default='resnet', choices=['resnet', 'unified'],
+                    help='fAnoGAN graph: resnet = models/fanogan_schlegl.py (the one BASELINE.json configs[3] names), unified = models/fanogan.py')
     ap.add_argument('--batch', type=int, default=0, help='slices per GPU (default 64 for VAE, 16 for ceVAE)')
     args = ap.parse_args()
     global BATCH
     BATCH = args.batch or (64 if args.arch in ('VAE', 'fAnoGAN') else 16)
+    if args.arch == 'fAnoGAN' and args.variant == 'resnet' and not args.batch:
+        BATCH = 32
     cevae = args.arch == 'ceVAE'
     if args.arch == 'GMVAE_spatial':
         return bench_gmvae(args)

@@ -14,7 +14,8 @@ TOL = 1e-4
 # Gradients when the fp32 device run took the other (Leaky)ReLU branch than the fp64 oracle on some activation whose
 # pre-activation is within round-off of zero: one flipped element moves a filter gradient (a sum of sign-alternating terms) by
 # up to ~1e-2 of its max-norm.  The tests count the flips exactly (activation signs, device vs oracle); with zero flips the
-# gradients are held to TOL.  Forward values and losses are always held to TOL.
+# gradients are held to TOL in the max-norm, otherwise to TOL_KINK in the L2 norm.  Forward values and losses are always
+# held to TOL.
 TOL_KINK = 5e-2
 
 
@@ -72,10 +73,16 @@ def _check_grads(eng, m, g_ref, group, tag, tol=TOL):
             continue
         ref = np.asarray(g_ref.get(k, np.zeros(s)), np.float64).reshape(s)
         dev = g_dev[k].astype(np.float64)
-        # biases feeding a LayerNorm over (H, W) have an identically zero gradient; the device writes exact zeros, the
-        # oracle carries fp64 round-off
-        err = np.abs(dev - ref).max()
-        assert err <= tol * max(np.abs(ref).max(), 1e-2 * scale), f'{tag}:{k} err {err:.3e} ref max {np.abs(ref).max():.3e}'
+        if tol == TOL:
+            # biases feeding a LayerNorm over (H, W) have an identically zero gradient; the device writes exact zeros, the
+            # oracle carries fp64 round-off -- hence the floor on the reference scale
+            err = np.abs(dev - ref).max()
+            assert err <= tol * max(np.abs(ref).max(), 1e-2 * scale), f'{tag}:{k} err {err:.3e} ref max {np.abs(ref).max():.3e}'
+        else:
+            # activation flips present: a flipped element is an O(1) change of the per-pixel LayerNorm gradients at its pixel
+            # and a ~1e-2 change of the filter gradients it feeds, so the bound is on the L2 norm of the difference
+            err = np.linalg.norm(dev - ref)
+            assert err <= tol * max(np.linalg.norm(ref), 1e-2 * scale * np.sqrt(ref.size)), f'{tag}:{k} L2 err {err:.3e} ref {np.linalg.norm(ref):.3e}'
 
 
 CASES = [(32, 8, 16, 2, 'f32', False), (64, 8, 16, 3, 'bf16x3', True), (128, 8, 128, 2, 'bf16x3', False)]

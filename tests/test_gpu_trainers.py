@@ -259,3 +259,25 @@ def test_fanogan_trainer_surface(tmp_path):
     assert np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w)
     assert [m2.engine.step_count(g) for g in ('Encoder', 'Generator', 'Discriminator')] == steps
     m2.engine.close()
+
+
+def test_fanogan_schlegl_trainer(tmp_path):
+    """The same trainer on the ResNet graph (network=fanogan_schlegl): parameter table, one critic step against the oracle,
+    one epoch of each stage, reconstruct() in [-1, 1] (tanh output)."""
+    from oracle import fanogan_schlegl as ofs
+    from unsupervised_anomaly_detection_brain_mri_amd.models import fanogan_schlegl
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import fAnoGAN
+    cfg, opt, ds = _config(fAnoGAN, tmp_path, h=64, bs=2, epochs=1)
+    model = fAnoGAN(None, cfg, network=fanogan_schlegl)
+    assert model.model_dir == 'fAnoGAN_dSyntheticDataset_s64x64_fanogan_schlegl_b2_z64_'
+    m = ofs.FAnoGANSchlegl(64, 8, 64, 64)
+    assert [(n, tuple(s)) for n, s, _ in model.engine.spec] == [(n, tuple(s)) for n, s, _ in m.spec]
+    batch = ds.next_batch(2, set='TRAIN')[0]
+    run = model.discriminator_step(batch)
+    assert set(run) == {'generated', 'disc_loss', 'disc_fake', 'disc_real'} and np.isfinite(run['disc_loss'])
+    ds2 = SyntheticDataset(4, 2, 64, 64, seed=1)
+    model.train(ds2)
+    assert model.engine.step_count('Generator') == 2 and model.engine.step_count('Discriminator') == 11 and model.engine.step_count('Encoder') == 2
+    r = model.reconstruct(ds2.next_batch(1, set='VAL')[0][0])
+    assert r['reconstruction'].shape == (1, 64, 64, 1) and -1.0 <= r['reconstruction'].min() and r['reconstruction'].max() <= 1.0
+    model.engine.close()

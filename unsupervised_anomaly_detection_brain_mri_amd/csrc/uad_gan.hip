@@ -291,10 +291,10 @@ __global__ void __launch_bounds__(256) coef_colsum_kernel(const float* __restric
         s = s + *reinterpret_cast<const float4*>(feat + (size_t)row * C + ch) * coef.v[row / rows_per_group];
     *reinterpret_cast<float4*>(red + rl * C + ch) = s;
     __syncthreads();
-    if (threadIdx.x < C) {
+    for (int c = threadIdx.x; c < C; c += 256) {
         float a = 0.f;
-        for (int k = 0; k < RL; ++k) a += red[k * C + threadIdx.x];
-        partial[(size_t)blockIdx.x * C + threadIdx.x] = a;
+        for (int k = 0; k < RL; ++k) a += red[k * C + c];
+        partial[(size_t)blockIdx.x * C + c] = a;
     }
 }
 // generator output backward: do = dx * x (1 - x) (sigmoid) or dx * (1 - x^2) (tanh); da[row, c] = do * wf[c];
