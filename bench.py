@@ -271,7 +271,8 @@ def bench_fanogan(args):
         res = {'metric': f'MRI slices/sec f-AnoGAN ({args.variant}) WGAN-GP batch iteration (1 G + 5 D steps, {hh}x{hh}, bs={bs}/GPU)',
                'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32' if args.variant == 'resnet' else args.math,      # the k3 / k1 contractions run on the generic fp32-MFMA kernels
+               # the ResNet graph's k3 / k1 contractions run on the generic kernels: fp32 MFMA unless --math bf16x3_all (not parity-rated)
+               'dtype': ('f32' if args.math != 'bf16x3_all' else 'bf16x3_all') if args.variant == 'resnet' else args.math,
                'data': 'synthetic',
                'config': {'workload': f'BASELINE.json configs[3]: f-AnoGAN {graph} {hh}x{hh}x1, zDim {zd}, '
                                       f'{bs} slices per GPU; step = 1 generator + 5 critic phases with Adam (trainers/fAnoGAN.py:97-130)',
@@ -288,7 +289,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'bf16x3'), choices=['f32', 'bf16x3'],
+    ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'bf16x3'), choices=['f32', 'bf16x3', 'bf16x3_all'],
                     help='bf16x3 (default): split-bf16 products on the bf16 matrix cores, fp32 accumulate, parity 1e-4 vs the '
                          'fp32 oracle; f32: exact fp32 MFMA')
     ap.add_argument('--restore-steps', type=int, default=150, help='GMVAE_spatial: restoration iterations per slice')

@@ -44,7 +44,10 @@ enum { UAD_BUF_PARAMS = 0, UAD_BUF_GRADS = 1, UAD_BUF_ADAM_M = 2, UAD_BUF_ADAM_V
 enum { UAD_SEG_DECODER = 0, UAD_SEG_BOTTLENECK = 1, UAD_SEG_ENCODER = 2, UAD_SEG_ALL = -1 };
 /* arithmetic of the k5 s2 forward / data-gradient contractions: exact fp32 MFMA (default), or split-bf16 (x = hi + lo,
  * hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate: ~2^-17 relative error per product) */
-enum { UAD_MATH_F32 = 0, UAD_MATH_BF16X3 = 1 };
+enum { UAD_MATH_F32 = 0, UAD_MATH_BF16X3 = 1,
+       UAD_MATH_BF16X3_ALL = 2 };   /* uad_gan_* only: also the generic k3 / k1 contractions of the ResNet graph in bf16x3.  Each
+                                       contraction stays inside 1e-4, but through the 20-layer ResNet critic the penalty scalar
+                                       drifts to ~3e-4 of its value, so this mode is opt-in and NOT parity-rated */
 
 typedef struct uad_model uad_model_t;
 

@@ -501,6 +501,7 @@ struct uad_gan {
     float *wpartial, *colscratch, *colpart, *redpart, *raw, *scalars_own, *finpart;
     // ---- ResNet variant (models/fanogan_schlegl.py) ----
     int variant, dim;
+    bool generic16;                    // UAD_MATH_BF16X3_ALL: generic contractions in bf16x3 too (opt-in, not parity-rated)
     struct RB {                        // pre-activation residual block: LN -> ReLU -> conv1 (k3 s1) -> LN -> ReLU -> conv2, + shortcut
         bool gen;                      // generator block: conv2 / shortcut are transposed convolutions
         int stride, Hin, Hout, Cin, Cout;
@@ -793,11 +794,13 @@ void disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float* 
 typedef uad_gan::RB RB;
 void g_conv_f(uad_gan* m, UadConvDesc d, int N, const float* big_in, long long w, const float* bias, const float* add, float* small_out, hipStream_t st) {
     d.N = N;
-    uad_launch_conv_f(d, big_in, no_xform(), P(m, w), small_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws);
+    uad_launch_conv_f(d, big_in, no_xform(), P(m, w), small_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, nullptr, 0,
+                      m->generic16);
 }
 void g_conv_d(uad_gan* m, UadConvDesc d, int N, const float* small_in, long long w, const float* bias, const float* add, float* big_out, hipStream_t st) {
     d.N = N;
-    uad_launch_conv_d(d, small_in, no_xform(), P(m, w), big_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws);
+    uad_launch_conv_d(d, small_in, no_xform(), P(m, w), big_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, nullptr, 0,
+                      m->generic16);
 }
 void g_conv_w(uad_gan* m, UadConvDesc d, int N, const float* big, const float* small_, long long w, hipStream_t st) {
     d.N = N;
@@ -1001,7 +1004,7 @@ static int create_resnet(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (dim % 32 || dim > 64) return fail(UAD_ERR_UNSUPPORTED, "ResNet f-AnoGAN: dim must be 32 or 64");
     if (ir < 2) return fail(UAD_ERR_UNSUPPORTED, "inter_res >= 2 needed");
     uad_gan* m = new uad_gan();
-    m->cfg = *cfg; m->variant = 1; m->dim = dim;
+    m->cfg = *cfg; m->variant = 1; m->dim = dim; m->generic16 = false;
     m->npool = 3; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
     m->step[0] = m->step[1] = m->step[2] = 0;
     char nm[160];
@@ -1193,7 +1196,7 @@ int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (H < 32) return fail(UAD_ERR_UNSUPPORTED, "height >= 32 needed");
 
     uad_gan* m = new uad_gan();
-    m->cfg = *cfg; m->variant = 0; m->dim = 0;
+    m->cfg = *cfg; m->variant = 0; m->dim = 0; m->generic16 = false;
     m->npool = npool; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
     m->step[0] = m->step[1] = m->step[2] = 0;
     const int ir = cfg->inter_res;
@@ -1398,8 +1401,8 @@ int uad_gan_get_buffer(uad_gan_t* m, int which, float* host, long long count) {
     return UAD_OK;
 }
 int uad_gan_set_math_mode(uad_gan_t* m, int mode) {
-    if (!m || (mode != UAD_MATH_F32 && mode != UAD_MATH_BF16X3)) return fail(UAD_ERR_INVALID, "bad math mode");
-    m->math = mode; m->packed_valid = false;
+    if (!m || (mode != UAD_MATH_F32 && mode != UAD_MATH_BF16X3 && mode != UAD_MATH_BF16X3_ALL)) return fail(UAD_ERR_INVALID, "bad math mode");
+    m->math = mode == UAD_MATH_F32 ? UAD_MATH_F32 : UAD_MATH_BF16X3; m->generic16 = mode == UAD_MATH_BF16X3_ALL; m->packed_valid = false;
     return UAD_OK;
 }
 long long uad_gan_get_step(const uad_gan_t* m, int group) { return (m && group >= 0 && group < 3) ? m->step[group] : 0; }

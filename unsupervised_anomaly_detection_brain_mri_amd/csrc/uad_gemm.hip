@@ -41,6 +41,7 @@ struct ConvGemmArgs {
     long long out_elems;
     unsigned long long* dbgbuf;   // per-phase clock stamps of a few workgroups (UAD_DBG & 8)
     int dbg;       // ablation switches for kernel tuning (UAD_DBG): 1 = no epilogue stores, 2 = no MFMA loop, 4 = no staging
+    int math16;    // generic kernel: bf16x3 products (conv_gemm16_kernel) where the tile shape allows
 };
 
 __device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int lws, int& n, int& i, int& j) {
@@ -817,6 +818,373 @@ __device__ __forceinline__ void split_bf16(float4 v, uint2& hi, uint2& lo) {
 __device__ __forceinline__ v16f mfma_bf16(uint4 a, uint4 b, v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
 }
+// ---- generic (any KS / S / P) contraction in bf16x3 math: the fp32 tiles are split into bf16 hi | lo planes while they are stored
+// to LDS (same bytes as fp32), both operands K-contiguous, so a fragment is one ds_read_b128 per plane and a K = 16 slice costs
+// three v_mfma_f32_32x32x16_bf16 instead of eight fp32 MFMAs.  Identity activation-on-load only.
+template <int BM, int BN, int BK, int WGM, int WGN, int KIND>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm16_kernel(const ConvGemmArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int FM = WTM / 32, FN = WTN / 32;
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
+    static_assert(BK % 16 == 0, "BK multiple of 16");
+    constexpr int NKK = BK / 16;
+    constexpr int LDK = BK + 8;                        // bf16 row stride (80 B at BK = 32): 16-byte aligned rows
+    constexpr int A_EL = BM * LDK, B_EL = BN * LDK;    // per plane; both operands are stored K-contiguous
+    constexpr int STAGE = 2 * A_EL + 2 * B_EL;         // A hi | A lo | B hi | B lo
+    __shared__ __attribute__((aligned(16))) unsigned short smem16[2 * STAGE];
+    float* const smem = reinterpret_cast<float*>(smem16);   // epilogue scratch
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const UadConvDesc& d = a.d;
+    const int S = d.S, P = d.P, KS = d.KS;
+
+    // ---- tap set: all KS*KS taps (F) or the taps of this output-parity class (D) ----
+    int py = 0, px = 0, ky0 = 0, kx0 = 0, nty = KS, ntx = KS, dy0 = 0, dx0 = 0;
+    const int nsplit = a.nsplit;
+    const int split = (KIND == KIND_D) ? (int)(blockIdx.z % nsplit) : (int)blockIdx.z;
+    if (KIND == KIND_D) {
+        const int cz = blockIdx.z / nsplit;
+        py = (S - 1) - cz / S;
+        px = (S - 1) - cz % S;
+        ky0 = (py + P) % S;
+        kx0 = (px + P) % S;
+        dy0 = (py + P) / S;
+        dx0 = (px + P) / S;
+        nty = ky0 < KS ? (KS - ky0 + S - 1) / S : 0;
+        ntx = kx0 < KS ? (KS - kx0 + S - 1) / S : 0;
+    }
+    const int ntaps = nty * ntx;
+    const int ncc = a.CA / BK;
+    const int nk = ntaps * ncc;
+    // split-K: this workgroup contracts K-steps [ks0, ks1)
+    const int kper = (nk + nsplit - 1) / nsplit;
+    const int ks0 = split * kper;
+    const int ks1 = min(nk, ks0 + kper);
+
+    // (no activation-on-load in this variant: the launcher only selects it for identity transforms)
+
+    // ---- per-thread A rows (positions) ----
+    constexpr int TPR = BK / 4, RPP = NT / TPR, PA = (BM + RPP - 1) / RPP;
+    const int acol = (tid % TPR) * 4;
+    const int arow0 = tid / TPR;
+    int rbase[PA], ry[PA], rx[PA];
+    bool rok[PA];
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+        const int r = arow0 + q * RPP;
+        const int m = m0 + r;
+        rok[q] = (r < BM) && (m < a.M);
+        int n, i, j;
+        decode_pos(rok[q] ? m : 0, d.HS, d.WS, a.lhs, a.lws, n, i, j);
+        if (KIND == KIND_F) {
+            rbase[q] = n * d.HB * d.WB;
+            ry[q] = S * i - P;
+            rx[q] = S * j - P;
+        } else {
+            rbase[q] = n * d.HS * d.WS;
+            ry[q] = i;
+            rx[q] = j;
+        }
+    }
+    const int AH = (KIND == KIND_F) ? d.HB : d.HS;
+    const int AW = (KIND == KIND_F) ? d.WB : d.WS;
+
+    // ---- per-thread B slots (predicates are loop invariant; out-of-range slots read element 0 and are zeroed) ----
+    constexpr int TPRB = (KIND == KIND_F) ? (BN / 4) : (BK / 4);
+    constexpr int RPB = NT / TPRB;
+    constexpr int BROWS = (KIND == KIND_F) ? BK : BN;
+    constexpr int PB = (BROWS + RPB - 1) / RPB;
+    static_assert(KIND != KIND_F || PB == 2, "F-type: each thread owns two adjacent K rows of the weight tile");
+    const int bcol = (tid % TPRB) * 4;
+    const int brow0 = tid / TPRB;
+    // F-type: rows (2*brow0, 2*brow0+1) so that the transposed LDS store writes one 32-bit pair per output column
+    auto brow = [&](int q) { return (KIND == KIND_F) ? (brow0 * PB + q) : (brow0 + q * RPB); };
+    bool bok[PB];
+    int boff[PB];   // loop-invariant part of the weight offset
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int r = brow(q);
+        if (KIND == KIND_F) {
+            bok[q] = (r < BK) && (n0 + bcol) < a.Nn;
+            boff[q] = bok[q] ? (r * d.CS + n0 + bcol) : 0;
+        } else {
+            bok[q] = (r < BN) && (n0 + r) < a.Nn;
+            boff[q] = bok[q] ? ((n0 + r) * d.CS + bcol) : 0;
+        }
+    }
+
+    float4 va[PA], vb[PB];
+    unsigned okbits = 0;
+    int xc0 = 0;
+
+    // branch-free tile fetch: every load is issued unconditionally from a clamped (always valid) address
+    auto load_tiles = [&](int tap, int c0) {
+        int ky, kx, oy, ox;
+        {
+            const int ty = tap / ntx, tx = tap - ty * ntx;
+            if (KIND == KIND_F) { ky = ty; kx = tx; oy = ky; ox = kx; }
+            else { ky = ky0 + S * ty; kx = kx0 + S * tx; oy = dy0 - ty; ox = dx0 - tx; }
+        }
+        xc0 = c0;
+        okbits = 0;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int y = ry[q] + oy, x = rx[q] + ox;
+            const bool ok = rok[q] && (unsigned)y < (unsigned)AH && (unsigned)x < (unsigned)AW;
+            const int pix = ok ? (rbase[q] + y * AW + x) : 0;
+            va[q] = *reinterpret_cast<const float4*>(a.A + (size_t)pix * a.CA + c0 + acol);
+            okbits |= (ok ? 1u : 0u) << q;
+        }
+        const int tapw = ky * KS + kx;
+        const size_t wbase = (KIND == KIND_F) ? ((size_t)tapw * d.CB + c0) * d.CS : ((size_t)tapw * d.CB) * d.CS + c0;
+#pragma unroll
+        for (int q = 0; q < PB; ++q) vb[q] = *reinterpret_cast<const float4*>(a.W + wbase + boff[q]);
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned short* sAh = smem16 + buf * STAGE;
+        unsigned short* sAl = sAh + A_EL;
+        unsigned short* sBh = sAl + A_EL;
+        unsigned short* sBl = sBh + B_EL;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int r = arow0 + q * RPP;
+            // padding pixels stay exactly 0
+            const float4 v = keep4((okbits >> q) & 1u, va[q]);
+            uint2 hi, lo;
+            split_bf16(v, hi, lo);
+            if (r < BM) {
+                *reinterpret_cast<uint2*>(sAh + r * LDK + acol) = hi;
+                *reinterpret_cast<uint2*>(sAl + r * LDK + acol) = lo;
+            }
+        }
+        if (KIND == KIND_F) {
+            // W tile arrives [k][n]; the matrix cores want n-major rows with K contiguous: transposed store, one (k, k+1) pair per n
+            uint2 h0, l0, h1, l1;
+            split_bf16(keep4(bok[0], vb[0]), h0, l0);
+            split_bf16(keep4(bok[PB - 1], vb[PB - 1]), h1, l1);
+            const unsigned hh0[4] = {h0.x & 0xFFFFu, h0.x >> 16, h0.y & 0xFFFFu, h0.y >> 16};
+            const unsigned hh1[4] = {h1.x & 0xFFFFu, h1.x >> 16, h1.y & 0xFFFFu, h1.y >> 16};
+            const unsigned ll0[4] = {l0.x & 0xFFFFu, l0.x >> 16, l0.y & 0xFFFFu, l0.y >> 16};
+            const unsigned ll1[4] = {l1.x & 0xFFFFu, l1.x >> 16, l1.y & 0xFFFFu, l1.y >> 16};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<unsigned*>(sBh + (bcol + i) * LDK + 2 * brow0) = hh0[i] | (hh1[i] << 16);
+                *reinterpret_cast<unsigned*>(sBl + (bcol + i) * LDK + 2 * brow0) = ll0[i] | (ll1[i] << 16);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                const int r = brow0 + q * RPB;
+                uint2 hi, lo;
+                split_bf16(keep4(bok[q], vb[q]), hi, lo);
+                if (r < BROWS) {
+                    *reinterpret_cast<uint2*>(sBh + r * LDK + bcol) = hi;
+                    *reinterpret_cast<uint2*>(sBl + r * LDK + bcol) = lo;
+                }
+            }
+        }
+    };
+
+    v16f acc[FM][FN];
+#pragma unroll
+    for (int im = 0; im < FM; ++im)
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[im][jn][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int tap = ks0 / ncc, cc = ks0 - tap * ncc;
+    if (ks0 < ks1) {
+        load_tiles(tap, cc * BK);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    // fragment double buffer: the ds_reads of k-slice kk+1 are in flight while the MFMAs of kk issue
+    uint4 ah[2][FM], al[2][FM], bh[2][FN], bl[2][FN];
+    auto load_frags = [&](int slot, const unsigned short* sAh, int kk) {
+        const unsigned short* sAl = sAh + A_EL;
+        const unsigned short* sBh = sAl + A_EL;
+        const unsigned short* sBl = sBh + B_EL;
+#pragma unroll
+        for (int im = 0; im < FM; ++im) {
+            const int o = (wm * WTM + im * 32 + l31) * LDK + kk * 16 + 8 * lh;
+            ah[slot][im] = *reinterpret_cast<const uint4*>(sAh + o);
+            al[slot][im] = *reinterpret_cast<const uint4*>(sAl + o);
+        }
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn) {
+            const int o = (wn * WTN + jn * 32 + l31) * LDK + kk * 16 + 8 * lh;
+            bh[slot][jn] = *reinterpret_cast<const uint4*>(sBh + o);
+            bl[slot][jn] = *reinterpret_cast<const uint4*>(sBl + o);
+        }
+    };
+
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int buf = (ks - ks0) & 1;
+        int ntap = tap, ncc_ = cc + 1;
+        if (ncc_ == ncc) { ncc_ = 0; ntap = tap + 1; }
+        const bool more = (ks + 1 < ks1);
+        const unsigned short* sA = smem16 + buf * STAGE;
+        load_frags(0, sA, 0);
+        if (more) load_tiles(ntap, ncc_ * BK);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int cur = kk & 1;
+            if (kk + 1 < NKK) load_frags(cur ^ 1, sA, kk + 1);
+#pragma unroll
+            for (int im = 0; im < FM; ++im)
+#pragma unroll
+                for (int jn = 0; jn < FN; ++jn) {
+                    acc[im][jn] = mfma_bf16(ah[cur][im], bh[cur][jn], acc[im][jn]);
+                    acc[im][jn] = mfma_bf16(ah[cur][im], bl[cur][jn], acc[im][jn]);
+                    acc[im][jn] = mfma_bf16(al[cur][im], bh[cur][jn], acc[im][jn]);
+                }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+        tap = ntap;
+        cc = ncc_;
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    if (nsplit > 1) {
+        // raw partial tile into this split's slab (output layout); bias / activation-backward / column sums are
+        // applied by splitk_epilogue_kernel after the slabs are summed in a fixed order
+        float* slab = a.Out + (size_t)split * a.out_elems;
+#pragma unroll
+        for (int im = 0; im < FM; ++im)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + row;
+                if (m >= a.M) continue;
+                size_t ob;
+                if (KIND == KIND_F) ob = (size_t)m * a.Nn;
+                else {
+                    int n, i, j;
+                    decode_pos(m, d.HS, d.WS, a.lhs, a.lws, n, i, j);
+                    ob = ((size_t)(n * d.HB + S * i + py) * d.WB + (S * j + px)) * a.Nn;
+                }
+#pragma unroll
+                for (int jn = 0; jn < FN; ++jn) {
+                    const int col = n0 + wn * WTN + jn * 32 + l31;
+                    if (col < a.Nn) slab[ob + col] = acc[im][jn][r];
+                }
+            }
+        return;
+    }
+    const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
+    // per-lane column constants
+    bool colok[FN];
+    int colc[FN];
+    float c_a[FN], c_b[FN];   // !bwd: bias, -- ; bwd: escale*emult, eshift
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) {
+        const int col = n0 + wn * WTN + jn * 32 + l31;
+        colok[jn] = col < a.Nn;
+        colc[jn] = colok[jn] ? col : 0;
+        if (!bwd) {
+            c_a[jn] = a.ep.bias ? a.ep.bias[colc[jn]] : 0.f;
+            c_b[jn] = 0.f;
+        } else {
+            c_a[jn] = a.ep.escale[colc[jn]] * a.ep.emult;
+            c_b[jn] = a.ep.eshift[colc[jn]];
+        }
+    }
+    float s1[FN], s2[FN];
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) { s1[jn] = 0.f; s2[jn] = 0.f; }
+
+#pragma unroll
+    for (int im = 0; im < FM; ++im) {
+        // row bases of this fragment's 16 rows
+        size_t obase[16];
+        bool rowok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + row;
+            rowok[r] = m < a.M;
+            const int mc = rowok[r] ? m : 0;
+            if (KIND == KIND_F) {
+                obase[r] = (size_t)mc * a.Nn;
+            } else {
+                int n, i, j;
+                decode_pos(mc, d.HS, d.WS, a.lhs, a.lws, n, i, j);
+                obase[r] = ((size_t)(n * d.HB + S * i + py) * d.WB + (S * j + px)) * a.Nn;
+            }
+        }
+        if (!bwd) {
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (!(rowok[r] && colok[jn])) continue;
+                    const size_t off = obase[r] + colc[jn];
+                    float v = acc[im][jn][r] + c_a[jn];
+                    if (a.ep.mul) v *= a.ep.mul[off];
+                    if (a.ep.add) v += a.ep.add[off];
+                    a.Out[off] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                // all 16 c_prev loads of this fragment are issued before the first one is consumed
+                float cp[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = rowok[r] && colok[jn];
+                    cp[r] = a.ep.cprev[ok ? (obase[r] + colc[jn]) : 0];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = rowok[r] && colok[jn];
+                    const float c = cp[r];
+                    const float bn = fmaf(c_a[jn], c, c_b[jn]);
+                    const float v = acc[im][jn][r];
+                    float dbn = bn > 0.f ? v : v * a.ep.ealpha;
+                    dbn = ok ? dbn : 0.f;
+                    if (ok) a.Out[obase[r] + colc[jn]] = dbn * c_a[jn];
+                    s1[jn] += dbn;
+                    s2[jn] = fmaf(dbn, c, s2[jn]);
+                }
+            }
+        }
+    }
+    if (bwd) {
+        // column sums: lane halves -> waves along M -> one partial row per block tile
+        float* red = smem;  // [WGM][2][BN]
+        __syncthreads();
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn) {
+            float t1 = s1[jn] + __shfl_xor(s1[jn], 32);
+            float t2 = s2[jn] + __shfl_xor(s2[jn], 32);
+            if (lh == 0) {
+                red[(wm * 2 + 0) * BN + wn * WTN + jn * 32 + l31] = t1;
+                red[(wm * 2 + 1) * BN + wn * WTN + jn * 32 + l31] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) t += red[(w * 2 + which) * BN + c];
+            const int col = n0 + c;
+            const size_t tile = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+            if (col < a.Nn) a.ep.colpart[(tile * 2 + which) * a.Nn + col] = t;
+        }
+    }
+}
+
+
 template <int NKS>
 struct BFrag16 { uint4 hi[NKS], lo[NKS]; };
 
@@ -2383,6 +2751,10 @@ template <int KIND>
 void launch_gemm(const ConvGemmArgs& a, int classes, hipStream_t st) {
     const TileChoice t = choose_tile(a.M, a.Nn, a.CA, classes);
     dim3 grid((a.M + t.BM - 1) / t.BM, (a.Nn + t.BN - 1) / t.BN, classes * a.nsplit);
+    if (a.math16 && !a.xf.scale && t.BK == 32 && t.BN == 64 && !getenv("UAD_NO_G16")) {
+        if (t.BM == 128) { hipLaunchKernelGGL((conv_gemm16_kernel<128, 64, 32, 2, 2, KIND>), grid, dim3(256), 0, st, a); return; }
+        if (t.BM == 64) { hipLaunchKernelGGL((conv_gemm16_kernel<64, 64, 32, 2, 2, KIND>), grid, dim3(256), 0, st, a); return; }
+    }
 #define UAD_GEMM_CASE(bm, bn, bk, wgm, wgn)                                                              \
     if (t.BM == bm && t.BN == bn && t.BK == bk) {                                                        \
         hipLaunchKernelGGL((conv_gemm_kernel<bm, bn, bk, wgm, wgn, KIND>), grid, dim3(64 * wgm * wgn), 0, st, a); \
@@ -2561,9 +2933,9 @@ void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, un
 
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W, float* small_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
-                       long long w16_plane) {
+                       long long w16_plane, bool generic_bf16x3) {
     ConvGemmArgs a;
-    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane;
+    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CB; a.Nn = d.CS;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;
@@ -2573,9 +2945,9 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
 
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W, float* big_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
-                       long long w16_plane) {
+                       long long w16_plane, bool generic_bf16x3) {
     ConvGemmArgs a;
-    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane;
+    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CS; a.Nn = d.CB;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;

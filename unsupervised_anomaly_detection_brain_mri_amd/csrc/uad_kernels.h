@@ -70,11 +70,14 @@ struct UadEpilogue {
 // spatial kernel.  The tile count of EPI_BWD_ACT (uad_conv_*_tiles) assumes Wpacked is given whenever it can be used.
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W,
                        float* small_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr,
-                       UadGemmWs ws = UadGemmWs{nullptr, 0}, const unsigned short* Wp16 = nullptr, long long w16_plane = 0);
+                       UadGemmWs ws = UadGemmWs{nullptr, 0}, const unsigned short* Wp16 = nullptr, long long w16_plane = 0,
+                       bool generic_bf16x3 = false);
 // D-type: big_out[n,S*i-P+ky,S*j-P+kx,cb] += xf(small_in)[n,i,j,cs] * W[tap][cb][cs]
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W,
                        float* big_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr,
-                       UadGemmWs ws = UadGemmWs{nullptr, 0}, const unsigned short* Wp16 = nullptr, long long w16_plane = 0);
+                       UadGemmWs ws = UadGemmWs{nullptr, 0}, const unsigned short* Wp16 = nullptr, long long w16_plane = 0,
+                       bool generic_bf16x3 = false);
+// generic_bf16x3: when no specialised kernel applies, let the generic kernel use bf16x3 products (identity xf, BK = 32 tiles)
 // bf16x3 math mode: Wp16 = this tensor's hi plane inside the bf16 pack buffer (ushort index 2*offset), w16_plane = its
 // element count (the lo plane follows the hi plane)
 void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, unsigned short* w16_d, const long long* offs,

@@ -1095,7 +1095,7 @@ static int pack_for_op(const UadConvDesc& d, const float* W, bool f_type, float*
 }
 // launch arguments for the op-level entry points in the selected math mode
 #define OP_PACK_ARGS(pk, d) (op_bf16x3() ? nullptr : (pk)), ws, (op_bf16x3() ? (const unsigned short*)(pk) : nullptr), \
-                            (long long)(d).KS * (d).KS * (d).CB * (d).CS
+                            (long long)(d).KS * (d).KS * (d).CB * (d).CS, op_bf16x3()
 static int finish_op(float* pf, float* pd, hipStream_t st, float* wsp = nullptr) {
     if (pf || pd || wsp) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(pf); (void)hipFree(pd); (void)hipFree(wsp); }
     HIP_TRY(hipGetLastError());

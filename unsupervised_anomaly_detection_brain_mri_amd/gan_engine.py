@@ -54,7 +54,8 @@ class GanEngine(_EvalOps):
             pass
 
     def set_math(self, math):
-        modes = {'f32': _lib.MATH_F32, 'bf16x3': _lib.MATH_BF16X3}
+        # 'bf16x3_all' (ResNet graph): also the generic k3 / k1 contractions in bf16x3 -- faster, but NOT parity-rated (header)
+        modes = {'f32': _lib.MATH_F32, 'bf16x3': _lib.MATH_BF16X3, 'bf16x3_all': _lib.MATH_BF16X3_ALL}
         if math not in modes:
             raise ValueError(f'unknown math mode {math!r}')
         _lib.check(self.lib.uad_gan_set_math_mode(self.handle, modes[math]))
