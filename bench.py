@@ -191,6 +191,80 @@ def bench_gmvae(args):
         dist.destroy_process_group()
 
 
+def gan_macs(variant, h, zdim=128, dim=64):
+    """Multiply-accumulates per sample and forward pass of the encoder, generator and critic."""
+    if variant == 'resnet':
+        r = h // 8
+        enc = sum((h >> (i + 1)) ** 2 * 25 * ci * co for i, (ci, co) in enumerate(((1, 32), (32, 64), (64, 128)))) + r * r * 128 * zdim
+        gen, c, res = zdim * r * r * 8 * dim, 8 * dim, r
+        for f, st in ((8 * dim, 1), (4 * dim, 2), (2 * dim, 2), (dim, 2)):
+            gen += res * res * 9 * c * f                      # conv1 at the input resolution
+            gen += res * res * 9 * f * f                      # transposed conv2: 9 taps per INPUT position
+            if st == 2:
+                gen += res * res * c * f                      # k1 s2 shortcut
+            c, res = f, res * st
+        gen += res * res * c
+        dis, c, res = h * h * 9 * dim, dim, h
+        for f, st in ((2 * dim, 2), (4 * dim, 2), (8 * dim, 2), (8 * dim, 1)):
+            dis += res * res * 9 * c * f + (res // st) ** 2 * 9 * f * f
+            if st == 2:
+                dis += res * res * c * f
+            c, res = f, res // st
+        return enc, gen, dis + res * res * c
+    npool = int(np.log2(h)) - 3
+    chans = [min(128, 32 * 2 ** i) for i in range(npool)]
+    enc = dis = 0
+    c, res = 1, h
+    for f in chans:
+        res //= 2
+        enc += res * res * 25 * c * f
+        c = f
+    dis = enc + 64 * c
+    enc += 64 * c * (c // 8) + 64 * (c // 8) * zdim
+    gen = zdim * 64 * (c // 8) + 64 * (c // 8) * c
+    res = 8
+    for i in range(npool):
+        f = max(32, 128 >> i)
+        gen += res * res * 25 * c * f
+        c, res = f, res * 2
+    return enc, gen + res * res * c, dis
+
+
+def gan_cpu_baseline(variant, hh, zd):
+    """The numpy oracle (kind "port") on a bounded sample: ONE WGAN-GP batch iteration (1 generator + 5 critic phases, gradients
+    only) at batch 1, fp32, BLAS threads capped like cpu_baseline()."""
+    threads = max(1, min(int(os.environ.get('UAD_CPU_THREADS', '32')), os.cpu_count() or 1))
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:
+        limiter = None
+    from oracle import vae as ovae
+    if variant == 'resnet':
+        from oracle import fanogan_schlegl as ofs
+        m = ofs.FAnoGANSchlegl(hh, hh // 8, zd, 64)
+    else:
+        from oracle import fanogan as ofa
+        m = ofa.FAnoGAN(hh, 8, zd)
+    p = ovae.init_params(m.spec, seed=3)
+    x = ovae.synthetic_slices(1, hh, hh, seed=0)
+    rng = np.random.default_rng(1)
+    z = rng.standard_normal((1, zd)).astype(np.float32); alpha = rng.uniform(0, 1, (1, 1)).astype(np.float32)
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 1 or (time.perf_counter() - t0 < 10.0 and iters < 64):      # ~10 s of CPU work
+        m.gen_phase(p, z)
+        for _ in range(5):
+            m.disc_phase(p, x, z, alpha)
+        iters += 1
+    dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
+    return {'value': round(iters / dt, 3), 'unit': 'slices/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{iters} WGAN-GP batch iteration(s) (1 generator + 5 critic phases each) at batch 1 with the numpy oracle, fp32, {dt:.1f} s '
+                      f'(BLAS on {threads} of {os.cpu_count()} host CPUs; TF-CPU itself is not installable)'}
+
+
 def bench_fanogan(args):
     """BASELINE.json configs[3]: f-AnoGAN 64x64 on the ResNet graph (models/fanogan_schlegl.py; --variant unified = models/fanogan.py,
     the graph north_star names).  One 'step' = one batch iteration of the reference's WGAN stage
@@ -278,6 +352,19 @@ def bench_fanogan(args):
                                       f'{bs} slices per GPU; step = 1 generator + 5 critic phases with Adam (trainers/fAnoGAN.py:97-130)',
                           'encoder_stage_ms_per_step': round(dt_e / args.steps * 1e3, 3),
                           'encoder_stage_slices_per_s': round(bs * world * args.steps / dt_e, 2), 'parallelism': f'dp{world}'}}
+        e_m, g_m, d_m = gan_macs(args.variant, hh, zd)
+        # per WGAN iteration and sample: G step = G fwd + bwd (3 passes) + critic fwd + data gradient; each of the 5 critic steps =
+        # G fwd + critic fwd of 3 samples, input gradient, its adjoint, data gradient of 3 and filter gradients of 4 sample-slots
+        macs = (3 * g_m + 2 * d_m) + 5 * (g_m + 12 * d_m)
+        tfl = 2.0 * macs * value / 1e12
+        peak = 157.3 if (args.variant == 'resnet' and args.math != 'bf16x3_all') else 2500.0 / 3.0
+        res['roofline'] = {'bound': 'mfma', 'kernel': 'whole WGAN-GP iteration (this handle has no per-kernel event profiler; per-kernel '
+                           'durations: profiles/r01_h_* / r01_i_* rocprofv3 summaries)', 'achieved': round(tfl, 2), 'peak': round(peak, 1),
+                           'unit': 'TFLOP/s', 'frac': round(tfl / peak, 4), 'traffic': None,
+                           'note': 'algorithmic FLOP of the iteration / wall time; peak = fp32 MFMA (ResNet graph: generic fp32 kernels) or the '
+                                   'bf16 matrix peak / 3 products per fp32 product (bf16x3 kernels)'}
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = gan_cpu_baseline(args.variant, hh, zd)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
