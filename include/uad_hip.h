@@ -172,6 +172,9 @@ int uad_residual(const float* x, const float* xr, const float* mask, int n, int 
 typedef struct uad_scores uad_scores_t;
 int uad_erode_cross(const float* mask, int n, int H, int W, int iterations, float* out, void* stream);
 int uad_median3d(const float* vol, int D, int H, int W, int ksize, float* out, void* stream);
+/* utils/Evaluation.py:113-127 filter_3d_connected_components: out = vol with every 26-connected component of non-zero voxels that has
+ * at most max_voxels (reference: 7) voxels set to 0 (bounded flood fill per voxel, exact; max_voxels < 16; not in place) */
+int uad_cc_filter(const float* vol, int D, int H, int W, int max_voxels, float* out, void* stream);
 int uad_scores_create(const float* pred, const float* label, long long n, uad_scores_t** out, void* stream);
 int uad_scores_auc(const uad_scores_t* s, double* auroc, double* auprc, double* positives);
 int uad_scores_dice(uad_scores_t* s, const double* thresholds_host, int k, double* dice_host, void* stream);

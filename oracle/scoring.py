@@ -127,7 +127,8 @@ def auroc(predictions, labels):
 
 def filter_3d_connected_components(volume, min_filled=7):
     """utils/Evaluation.py:113-127 with scipy: 26-connected components (skimage connectivity=3) whose hole-filled
-    size is <= 7 voxels are removed.  UNPINNED (skimage is not installed here)."""
+    size is <= 7 voxels are removed.  UNPINNED (skimage is not installed here).  regionprops' filled_area fills holes
+    with the FULL 3x3x3 structure (skimage/measure/_regionprops.py: `structure = np.ones((3,) * ndim)`), restated here."""
     import scipy.ndimage as ndi
     vol = np.array(volume, copy=True)
     cc, n = ndi.label(vol, structure=np.ones((3, 3, 3)))
@@ -135,6 +136,6 @@ def filter_3d_connected_components(volume, min_filled=7):
         if sl is None:
             continue
         region = cc[sl] == lbl
-        if ndi.binary_fill_holes(region).sum() <= min_filled:
+        if ndi.binary_fill_holes(region, structure=np.ones((3, 3, 3))).sum() <= min_filled:
             vol[sl][region] = 0
     return vol

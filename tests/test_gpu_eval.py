@@ -116,3 +116,35 @@ def test_scores_edge_cases(eng):
         eng.scores(np.zeros(3, np.float32), np.zeros(4))
     with pytest.raises(ValueError):
         eng.median3d(np.zeros((4, 4), np.float32))
+
+
+def _cc_cases():
+    rng = np.random.default_rng(5)
+    v = (rng.random((12, 20, 24)) < 0.06).astype(np.float32) * rng.uniform(0.5, 2.0, (12, 20, 24)).astype(np.float32)
+    v[2:5, 3:6, 3:6] = 1.5                                  # 27-voxel blob: kept
+    v[8, 10, 10:17] = 0.7                                   # 7-voxel line: removed
+    v[9, 15, 2:10] = 0.9                                    # 8-voxel line: kept
+    v[0, 0, 0] = v[11, 19, 23] = 1.0                        # corners
+    octa = np.zeros((12, 20, 24), np.float32)               # 6 face neighbours of an empty centre + 1: area 7, encloses a 6-connected hole
+    for dz, dy, dx in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (1, 1, 0)):
+        octa[6 + dz, 10 + dy, 12 + dx] = 1.0
+    clean = np.zeros((12, 20, 24), np.float32)
+    clean[2:5, 3:6, 3:6] = 1.5; clean[8, 10, 10:17] = 0.7; clean[9, 15, 2:10] = 0.9; clean[0, 0, 0] = 1.0
+    return [v, octa, np.zeros((3, 8, 8), np.float32), np.ones((4, 8, 8), np.float32), clean]
+
+
+@pytest.mark.parametrize('case', range(5))
+def test_cc_filter_bit_exact(eng, case):
+    """uad_cc_filter vs the scipy labelling of the oracle / the host helper: exact (integer decisions, values passed through)."""
+    from oracle import scoring as osc
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import Evaluation
+    v = _cc_cases()[case]
+    out = eng.cc_filter(v, 7).cpu().numpy()
+    assert np.array_equal(out, osc.filter_3d_connected_components(v))
+    assert np.array_equal(out, Evaluation.filter_3d_connected_components(v))
+    if case == 4:      # 27-voxel blob and 8-voxel line kept with their values, 7-voxel line and the lone corner voxel removed
+        assert out[8, 10, 10:17].sum() == 0 and out[0, 0, 0] == 0 and (out[9, 15, 2:10] == np.float32(0.9)).all() and (out[2:5, 3:6, 3:6] == 1.5).all()
+    if case == 1:      # area 7 with an enclosed (6-connected) hole: filled with the full structure it is still 7 -> removed
+        assert out.sum() == 0
+    for mv in (0, 3, 12):
+        assert np.array_equal(eng.cc_filter(v, mv).cpu().numpy(), Evaluation.filter_3d_connected_components(v, max_voxels=mv))

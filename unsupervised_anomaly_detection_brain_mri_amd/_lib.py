@@ -92,6 +92,7 @@ SYMBOLS = {
                                C.c_void_p, C.c_void_p]),
     'uad_erode_cross': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'uad_median3d': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'uad_cc_filter': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'uad_scores_create': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.POINTER(C.c_void_p), C.c_void_p]),
     'uad_scores_auc': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'uad_scores_dice': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_void_p]),

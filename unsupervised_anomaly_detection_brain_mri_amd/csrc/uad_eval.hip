@@ -161,6 +161,54 @@ __global__ void dice_at_kernel(const float* __restrict__ score, const unsigned l
     out[q] = (2.0 * tps) / (cnt + P);            // 0/0 -> nan like the reference's numpy division
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-component filter (utils/Evaluation.py:113-127: label(volume, connectivity=3) + regionprops, components with
+// filled_area <= 7 are zeroed).  No labelling pass is needed for that rule: a 26-connected component of at most `maxv` voxels is
+// found completely by a flood fill that stops at maxv + 1 voxels.  One thread per voxel runs that bounded fill from its own voxel
+// (list of visited linear indices in LDS, <= maxv + 1 entries, linear membership test) and keeps the voxel iff the fill reaches
+// maxv + 1.  (skimage fills holes with the full 3x3x3 structure, so a component this small has filled_area == area.)
+// Integer work on L2-resident reads; exact.
+// ------------------------------------------------------------------------------------------------
+constexpr int CC_CAP = 16;
+__global__ void __launch_bounds__(256) cc_filter_kernel(const float* __restrict__ vol, int D, int H, int W, int maxv,
+                                                        float* __restrict__ out) {
+    __shared__ int s_list[CC_CAP][256];
+    const size_t total = (size_t)D * H * W;
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= total) return;
+    const float val = vol[v];
+    if (val == 0.f) { out[v] = 0.f; return; }
+    const int t = threadIdx.x;
+    s_list[0][t] = (int)v;
+    int count = 1, head = 0;
+    const int HW = H * W;
+    while (head < count && count <= maxv) {
+        const int cur = s_list[head++][t];
+        const int z = cur / HW, y = (cur - z * HW) / W, x = cur - z * HW - y * W;
+        for (int dz = -1; dz <= 1 && count <= maxv; ++dz) {
+            const int zz = z + dz;
+            if ((unsigned)zz >= (unsigned)D) continue;
+            for (int dy = -1; dy <= 1 && count <= maxv; ++dy) {
+                const int yy = y + dy;
+                if ((unsigned)yy >= (unsigned)H) continue;
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx;
+                    if ((unsigned)xx >= (unsigned)W || (dz == 0 && dy == 0 && dx == 0)) continue;
+                    const int nb = (zz * H + yy) * W + xx;
+                    if (vol[nb] == 0.f) continue;
+                    bool seen = false;
+                    for (int k = 0; k < count; ++k) seen |= (s_list[k][t] == nb);
+                    if (!seen) {
+                        s_list[count++][t] = nb;
+                        if (count > maxv) break;
+                    }
+                }
+            }
+        }
+    }
+    out[v] = count > maxv ? val : 0.f;
+}
+
 }  // namespace
 
 struct uad_scores {
@@ -192,6 +240,17 @@ int uad_median3d(const float* vol, int D, int H, int W, int ksize, float* out, v
     if (vol == out) return fail(UAD_ERR_INVALID, "median3d: in-place is not supported");
     dim3 grid((W + 7) / 8, (H + 7) / 8, (D + 7) / 8);
     hipLaunchKernelGGL(median5_kernel, grid, dim3(512), 0, (hipStream_t)stream, vol, D, H, W, out);
+    EV_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+int uad_cc_filter(const float* vol, int D, int H, int W, int max_voxels, float* out, void* stream) {
+    if (!vol || !out || D <= 0 || H <= 0 || W <= 0) return fail(UAD_ERR_INVALID, "cc_filter: bad arguments");
+    if (max_voxels < 0 || max_voxels >= CC_CAP) return fail(UAD_ERR_UNSUPPORTED, "cc_filter: max_voxels must be in [0, %d)", CC_CAP);
+    if (vol == out) return fail(UAD_ERR_INVALID, "cc_filter: in-place is not supported");
+    const size_t total = (size_t)D * H * W;
+    if (total > 0x7fffffffULL) return fail(UAD_ERR_UNSUPPORTED, "cc_filter: volume too large");
+    hipLaunchKernelGGL(cc_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vol, D, H, W, max_voxels, out);
     EV_TRY(hipGetLastError());
     return UAD_OK;
 }

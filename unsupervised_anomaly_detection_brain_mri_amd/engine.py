@@ -46,6 +46,17 @@ class _EvalOps:
         _lib.check(self.lib.uad_median3d(_ptr(v), v.shape[0], v.shape[1], v.shape[2], int(ksize), _ptr(out), self._stream()))
         return out
 
+    def cc_filter(self, volume, max_voxels=7):
+        """filter_3d_connected_components (utils/Evaluation.py:113-127) of a [D,H,W] volume (bool / float, non-zero = foreground):
+        components of at most `max_voxels` voxels are zeroed.  Returns a float device tensor."""
+        v = volume if isinstance(volume, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(volume))
+        v = v.to(self.device, torch.float32).contiguous()
+        if v.dim() != 3:
+            raise ValueError('cc_filter expects a [D,H,W] volume')
+        out = torch.empty_like(v)
+        _lib.check(self.lib.uad_cc_filter(_ptr(v), v.shape[0], v.shape[1], v.shape[2], int(max_voxels), _ptr(out), self._stream()))
+        return out
+
     def scores(self, predictions, labels):
         """One descending device sort of all voxel scores -> Scores object (AUROC, AUPRC, dice at thresholds)."""
         return Scores(self, predictions, labels)

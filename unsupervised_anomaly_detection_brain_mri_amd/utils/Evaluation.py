@@ -134,7 +134,8 @@ def evaluate_volume(model, volume, brainmasks, options, eps=0.0, device_out=Fals
 
 def evaluate(volumes, labels, brainmasks, model, options, eps=0.0):
     """volumes/labels/brainmasks: lists of [S,H,W] arrays (one per patient).  Returns the reference's evalPC scalars
-    (utils/Evaluation.py:416-461): diff_AUC, diff_AUPRC, bestDiceScore, bestThreshold, per-patient Dice."""
+    (utils/Evaluation.py:416-470): diff_AUC, diff_AUPRC, bestDiceScore, bestThreshold, DiceScore, DiceScorePerPatient,
+    PrecisionPerPatient, RecallPerPatient (after the small-component filter)."""
     _time = {'evaluation': time.time()}
     diffs = [evaluate_volume(model, v, b, options, eps, device_out=True)[0] for v, b in zip(volumes, brainmasks)]
     d_all = torch.cat([d.reshape(-1) for d in diffs])
@@ -144,7 +145,23 @@ def evaluate(volumes, labels, brainmasks, model, options, eps=0.0):
     ev['bestDiceScore'], ev['bestThreshold'] = Metrics.compute_dice_curve_recursive_device(sc, granularity=10)
     sc.close()
     thr = ev['bestThreshold'] if options.get('threshold', 'bestdice') == 'bestdice' else options['threshold']
-    ev['Dice'] = [Metrics.dice((d.cpu().numpy().astype(np.float64) > thr).astype(np.int64), np.asarray(l)) for d, l in zip(diffs, labels)]
+    ev['thresholdType'] = options.get('threshold', 'bestdice')
+    # utils/Evaluation.py:452-470: threshold, drop the <= 7-voxel components of the STACKED patient volume (device flood-fill
+    # filter), then the overall and per-patient Dice / precision / recall
+    stacked = torch.cat(diffs, dim=0)
+    pred = model.engine.cc_filter((stacked > float(thr)).to(torch.float32), 7).cpu().numpy() > 0
+    gts = [np.asarray(l).reshape(d.shape).astype(bool) for d, l in zip(diffs, labels)]
+    ev['DiceScore'] = Metrics.dice(pred, np.concatenate(gts, axis=0))
+    ev['DiceScorePerPatient'], ev['PrecisionPerPatient'], ev['RecallPerPatient'] = [], [], []
+    s0 = 0
+    with np.errstate(divide='ignore', invalid='ignore'):
+        for d, g in zip(diffs, gts):
+            sub = pred[s0:s0 + d.shape[0]]
+            s0 += d.shape[0]
+            ev['DiceScorePerPatient'].append(Metrics.dice(sub, g))
+            ev['PrecisionPerPatient'].append(Metrics.precision(sub, g))
+            ev['RecallPerPatient'].append(Metrics.recall(sub, g))
+    ev['Dice'] = ev['DiceScorePerPatient']
     _time['evaluation'] = time.time() - _time['evaluation']
     ev['time'] = _time
     return ev
