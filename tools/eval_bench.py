@@ -27,6 +27,11 @@ dm, dv = torch.from_numpy(masks).cuda(), torch.from_numpy(vol).cuda()
 res = {}
 res['erode_ms'] = timed(lambda: eng.erode_cross(dm, 12))
 res['median_ms'] = timed(lambda: eng.median3d(dv))
+# thresholded 12-patient stack [1320,128,128] with ~1.5 % foreground (blobs + speckle), like `diffs > bestThreshold`
+thr_mask = (scipy.ndimage.uniform_filter(rng.random((12 * D, H, W)).astype(np.float32), 3) > 0.62).astype(np.float32)
+dt_ = torch.from_numpy(thr_mask).cuda()
+res['cc_filter_ms'] = timed(lambda: eng.cc_filter(dt_, 7))
+res['cc_foreground'] = float(thr_mask.mean())
 n = 12 * D * H * W
 lab = rng.random(n) < 0.02
 pred = (rng.random(n) * (rng.random(n) < 0.4) + 0.3 * lab * rng.random(n)).astype(np.float32)
@@ -41,5 +46,8 @@ res['host_erode_ms'] = (time.perf_counter() - t0) * 1e3
 t0 = time.perf_counter(); scipy.ndimage.median_filter(vol.astype(np.float64), (5, 5, 5)); res['host_median_ms'] = (time.perf_counter() - t0) * 1e3
 t0 = time.perf_counter(); hp = Metrics.compute_prc(pred.astype(np.float64), lab)[0]; hr = Metrics.compute_roc(pred.astype(np.float64), lab)[0]
 res['host_sorted_metrics_ms'] = (time.perf_counter() - t0) * 1e3
+from unsupervised_anomaly_detection_brain_mri_amd.utils import Evaluation
+t0 = time.perf_counter(); href = Evaluation.filter_3d_connected_components(thr_mask); res['host_cc_filter_ms'] = (time.perf_counter() - t0) * 1e3
+res['cc_equal'] = bool(np.array_equal(href, eng.cc_filter(dt_, 7).cpu().numpy()))
 res['host_auprc'], res['host_auroc'] = hp, hr
 print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in res.items()})
