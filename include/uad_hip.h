@@ -180,6 +180,15 @@ int uad_scores_auc(const uad_scores_t* s, double* auroc, double* auprc, double* 
 int uad_scores_dice(uad_scores_t* s, const double* thresholds_host, int k, double* dice_host, void* stream);
 int uad_scores_destroy(uad_scores_t* s);
 
+/* ---- batch assembly from an HBM-resident slice cache ------------------------------------------------------------
+ * Replaces the host-side batch slicing of dataloaders/BRAINWEB.py:411-478 (`next_batch`: images[images_in_set[start:end]], the label
+ * -> brain-mask mapping :466-476) when the whole slice set lives in device memory (288 GB HBM): no H2D copy per step.
+ *   uad_gather_slices: out[b] = src[idx[b]]                      src [N, slice_elems] fp32, idx device int32 [n]
+ *   uad_gather_mask:   out[b][p] = lut256[labels[idx[b]][p]]     labels [N, slice_px] u8; lut256 NULL = the label value as float */
+int uad_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, void* stream);
+int uad_gather_mask(const unsigned char* labels, const int* idx, int n, long long slice_px, const unsigned char* lut256, float* out,
+                    void* stream);
+
 /* ---- f-AnoGAN (unified graph) ------------------------------------------------------------------------------
  * Replaces models/fanogan.py:11-84 (encoder + generator + critic graph) and the three optimisation phases of
  * trainers/fAnoGAN.py:45-77 (losses :50-66, the WGAN-GP penalty's tf.gradients :55-57, three Adams :71-77);

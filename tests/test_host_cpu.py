@@ -135,3 +135,49 @@ def test_evaluation_host_helpers_against_golden_and_oracle():
     x = np.full((8, 8), 0.8); xr = np.full((8, 8), 0.5); x[0, 0] = 0.3
     d = E.postprocess_slice(x, xr)
     assert d[0, 0] == 0 and np.allclose(d[1:, 1:], 0.3)
+
+
+# ------------------------------------------------------------------ slice cache
+def test_slice_cache_roundtrip_and_cursor(tmp_path):
+    """Cache files are plain arrays + JSON; BatchCursor restates the cursor / epoch-wrap / shuffle arithmetic of
+    dataloaders/BRAINWEB.py:411-457 (checked here against a direct restatement on image arrays, same permutation draws)."""
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import slice_cache as sc
+    rng = np.random.default_rng(0)
+    imgs = rng.random((23, 8, 8, 1)).astype(np.float32)
+    labs = rng.integers(0, 11, (23, 8, 8)).astype(np.uint8)
+    sets = np.array([0] * 13 + [1] * 6 + [2] * 4)
+    rng.shuffle(sets)
+    sc.write_cache(str(tmp_path / 'c'), imgs, sets, labs, patients=['p0', 'p1'], options={'sliceStart': 20})
+    im2, lb2, index = sc.read_cache(str(tmp_path / 'c'))
+    assert np.array_equal(np.asarray(im2), imgs) and np.array_equal(np.asarray(lb2), labs)
+    assert index['sets'] == sets.tolist() and index['patients'] == ['p0', 'p1'] and index['options'] == {'sliceStart': 20}
+    assert os.path.getsize(tmp_path / 'c' / 'slices.f32') == imgs.size * 4
+    lut = sc.brainmask_lut()
+    assert [int(lut[v]) for v in range(11)] == [0, 1, 1, 1, 0, 0, 0, 0, 1, 0, 1]          # BRAINWEB.py:466-476
+
+    # reference arithmetic on arrays (the images of one split), same RNG stream
+    def ref_batches(data, bs, nb, seed):
+        r = np.random.default_rng(seed)
+        cur, start, out = data.copy(), 0, []
+        for _ in range(nb):
+            if start + bs > len(cur):
+                rest = cur[start:]
+                cur = cur[r.permutation(len(cur))]
+                start = bs - len(rest)
+                out.append(np.concatenate([rest, cur[:start]]))
+            else:
+                out.append(cur[start:start + bs]); start += bs
+        return out
+
+    data = np.arange(13)
+    cur = sc.BatchCursor(13, np.random.default_rng(5))
+    got = [data[cur.next(4)] for _ in range(11)]
+    for a, b in zip(got, ref_batches(data, 4, 11, 5)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(np.concatenate(got[:3]), np.arange(12))        # first epoch is never shuffled (BRAINWEB.py:419 quirk)
+    assert cur.epochs_completed == 3
+    for b in got:                                                         # every wrapped batch is complete and in range
+        assert len(b) == 4 and b.min() >= 0 and b.max() < 13
+    # no shuffle: plain wrap-around
+    c2 = sc.BatchCursor(5, np.random.default_rng(1))
+    assert [c2.next(2, shuffle=False).tolist() for _ in range(4)] == [[0, 1], [2, 3], [4, 0], [1, 2]]

@@ -218,6 +218,10 @@ void uad_launch_gm_loss_finalize(const float* rec_partial, int n, int bps, const
                                  float inv_batch, float* rec_per_sample, float* scalars, hipStream_t st);
 // dx = data gradient of the first conv, nothing else (f-AnoGAN critic input gradient)
 void uad_launch_conv_first_dgrad_plain(const UadConvDesc& d, const float* g, const float* W, float* dx, hipStream_t st);
+// batch assembly from the HBM-resident slice cache: out[b] = src[idx[b]]; mask[b][p] = lut[labels[idx[b]][p]] (lut null: the label value)
+void uad_launch_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, hipStream_t st);
+void uad_launch_gather_mask(const unsigned char* labels, const int* idx, int n, long long slice_px, const unsigned char* lut,
+                            float* out, hipStream_t st);
 // y = x * mask (mask may be null -> copy)
 void uad_launch_mul(const float* x, const float* mask, float* y, size_t n, hipStream_t st);
 // scalars[8] = {reconstructionLoss, kl, loss, 0, Rec_vae, Rec_ce, loss_vae, 0}; samples [n_vae, n) = ceVAE context branch

@@ -609,9 +609,40 @@ __global__ void __launch_bounds__(256) residual_kernel(const float* __restrict__
     if (threadIdx.x == 0 && l1part) l1part[(size_t)n * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Batch assembly from an HBM-resident slice cache: out[b] = src[idx[b]] (fp32 slices, 16-byte copies) and
+// mask[b][p] = lut[labels[idx[b]][p]] (u8 label maps -> 0/1 brain masks, dataloaders/BRAINWEB.py:466-476).
+__global__ void __launch_bounds__(256) gather_slices_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                            long long slice_f4, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const float4* s = reinterpret_cast<const float4*>(src) + (size_t)idx[b] * slice_f4;
+    float4* o = reinterpret_cast<float4*>(out) + (size_t)b * slice_f4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < slice_f4; i += (long long)gridDim.x * 256) o[i] = s[i];
+}
+__global__ void __launch_bounds__(256) gather_mask_kernel(const unsigned char* __restrict__ labels, const int* __restrict__ idx,
+                                                          long long slice_px, const unsigned char* __restrict__ lut,
+                                                          float* __restrict__ out) {
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut ? (float)lut[threadIdx.x] : (float)threadIdx.x;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const unsigned char* l = labels + (size_t)idx[b] * slice_px;
+    float* o = out + (size_t)b * slice_px;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < slice_px; i += (long long)gridDim.x * 256) o[i] = s_lut[l[i]];
+}
+
 }  // namespace
 
 // ================================================================================================
+void uad_launch_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, hipStream_t st) {
+    const long long f4 = slice_elems / 4;
+    int bx = (int)((f4 + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(gather_slices_kernel, dim3(bx, n), dim3(256), 0, st, src, idx, f4, out);
+}
+void uad_launch_gather_mask(const unsigned char* labels, const int* idx, int n, long long slice_px, const unsigned char* lut,
+                            float* out, hipStream_t st) {
+    int bx = (int)((slice_px + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(gather_mask_kernel, dim3(bx, n), dim3(256), 0, st, labels, idx, slice_px, lut, out);
+}
 void uad_launch_reduce_partials(const float* partial, int S, int L, float scale, float* out, hipStream_t st) {
     const int blocks = (L + 63) / 64;
     if (blocks >= 256 || S <= 8)

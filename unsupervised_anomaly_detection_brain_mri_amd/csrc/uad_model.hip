@@ -1062,6 +1062,21 @@ int uad_residual(const float* x, const float* xr, const float* mask, int n, int 
     return UAD_OK;
 }
 
+int uad_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, void* stream) {
+    if (!src || !idx || !out || n <= 0 || slice_elems <= 0 || slice_elems % 4) return fail(UAD_ERR_INVALID, "gather_slices: bad arguments (slice elements must be a multiple of 4)");
+    if (n > 65535) return fail(UAD_ERR_UNSUPPORTED, "gather_slices: at most 65535 slices per call");
+    uad_launch_gather_slices(src, idx, n, slice_elems, out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+int uad_gather_mask(const unsigned char* labels, const int* idx, int n, long long slice_px, const unsigned char* lut256, float* out, void* stream) {
+    if (!labels || !idx || !out || n <= 0 || slice_px <= 0) return fail(UAD_ERR_INVALID, "gather_mask: bad arguments");
+    if (n > 65535) return fail(UAD_ERR_UNSUPPORTED, "gather_mask: at most 65535 slices per call");
+    uad_launch_gather_mask(labels, idx, n, slice_px, lut256, out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ op-level entry points
 static UadConvDesc to_desc(const uad_conv_desc_t* d) { return UadConvDesc{d->N, d->HB, d->WB, d->CB, d->HS, d->WS, d->CS, d->KS, d->S, d->P}; }
 static UadXform to_xf(const uad_xform_t* x) {

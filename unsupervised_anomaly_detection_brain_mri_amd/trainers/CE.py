@@ -13,6 +13,10 @@ def retrieve_masked_batch(batch, brainmasks, rng=None):
     (the earlier samples' squares are drawn -- consuming RNG -- and then discarded).
     rng: object with randint(a, b), both ends inclusive; default the `random` module like the reference."""
     rng = _random if rng is None else rng
+    if hasattr(batch, 'cpu'):            # device tensors of utils.slice_cache.DeviceDataset: the masking RNG and geometry are host-side
+        batch = batch.cpu().numpy()
+    if hasattr(brainmasks, 'cpu'):
+        brainmasks = brainmasks.cpu().numpy()
     batch = np.asarray(batch)
     boxes = []
     for bm in brainmasks:
