@@ -39,7 +39,9 @@ extern "C" {
 #endif
 
 enum { UAD_OK = 0, UAD_ERR_INVALID = 1, UAD_ERR_HIP = 2, UAD_ERR_UNSUPPORTED = 3 };
-enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1, UAD_ARCH_CEVAE = 2, UAD_ARCH_GMVAE_SPATIAL = 3 };
+enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1, UAD_ARCH_CEVAE = 2, UAD_ARCH_GMVAE_SPATIAL = 3,
+       UAD_ARCH_AE_SPATIAL = 4 };   /* models/autoencoder_spatial.py:7-27: no dense bottleneck; the latent is the encoder feature map
+                                       [n,r,r,C]: io.mask_mu is its dropout keep-mask and io.z_mu receives it (both that shape) */
 enum { UAD_BUF_PARAMS = 0, UAD_BUF_GRADS = 1, UAD_BUF_ADAM_M = 2, UAD_BUF_ADAM_V = 3 };
 enum { UAD_SEG_DECODER = 0, UAD_SEG_BOTTLENECK = 1, UAD_SEG_ENCODER = 2, UAD_SEG_ALL = -1 };
 /* arithmetic of the k5 s2 forward / data-gradient contractions: exact fp32 MFMA (default), or split-bf16 (x = hi + lo,

@@ -406,3 +406,85 @@ def synthetic_slices(n, h=128, w=128, seed=0, dtype=np.float32):
         img = np.clip(f + rng.normal(0, 0.03, f.shape), 0.0, 1.0)
         out[i, :, :, 0] = (img * mask).astype(dtype)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Spatial autoencoder (models/autoencoder_spatial.py:7-27): the unified encoder's feature map is the latent code -- dropout on
+# it, then straight into the unified decoder (whose first layers are BN + ReLU, customlayers.py:30-31).  Trained by trainers/AE.py.
+# ---------------------------------------------------------------------------------------------------------------
+def param_spec_spatial(height, width, channels, inter_res):
+    assert height == width
+    n_pool = int(math.log(height, 2) - math.log(float(inter_res), 2))
+    spec, cin = [], channels
+    for i in range(n_pool):
+        f = int(min(128, 32 * (2 ** i)))
+        spec += [(f'Encoder/enc_conv2D_{i}/kernel', (5, 5, cin, f), 'conv_w'), (f'Encoder/enc_conv2D_{i}/bias', (f,), 'bias'),
+                 (f'Encoder/batch_normalization_{i}/gamma', (f,), 'gamma'), (f'Encoder/batch_normalization_{i}/beta', (f,), 'beta')]
+        cin = f
+    spec += [('Decoder/batch_normalization/gamma', (cin,), 'gamma'), ('Decoder/batch_normalization/beta', (cin,), 'beta')]
+    for i in range(n_pool):
+        f = int(max(32, 128 / (2 ** i)))
+        spec += [(f'Decoder/dec_Conv2DT_{i}/kernel', (5, 5, f, cin), 'conv_w'), (f'Decoder/dec_Conv2DT_{i}/bias', (f,), 'bias'),
+                 (f'Decoder/batch_normalization_{i + 1}/gamma', (f,), 'gamma'), (f'Decoder/batch_normalization_{i + 1}/beta', (f,), 'beta')]
+        cin = f
+    spec += [('Decoder/dec_Conv2D_final/kernel', (1, 1, cin, channels), 'conv_w'), ('Decoder/dec_Conv2D_final/bias', (channels,), 'bias')]
+    return spec
+
+
+class SpatialAE:
+    def __init__(self, height=128, width=128, channels=1, inter_res=8):
+        self.h, self.w, self.c, self.inter = height, width, channels, inter_res
+        self.spec = param_spec_spatial(height, width, channels, inter_res)
+        self.n_pool = int(math.log(height, 2) - math.log(float(inter_res), 2))
+
+    def forward(self, p, x, masks=None):
+        """masks: {'z': pre-scaled keep mask [N, r, r, C]} (autoencoder_spatial.py:16)."""
+        masks = masks or {}
+        cache = {'x': x}
+        a = x
+        for i in range(self.n_pool):
+            c = nn.conv2d_fwd(a, p[f'Encoder/enc_conv2D_{i}/kernel'], p[f'Encoder/enc_conv2D_{i}/bias'], 2)
+            bn = nn.bn_frozen_fwd(c, p[f'Encoder/batch_normalization_{i}/gamma'], p[f'Encoder/batch_normalization_{i}/beta'])
+            cache[f'enc_in{i}'], cache[f'enc_c{i}'], cache[f'enc_bn{i}'] = a, c, bn
+            a = nn.leaky_relu_fwd(bn, LRELU_ALPHA)
+        z = a * masks['z'] if 'z' in masks else a
+        bn = nn.bn_frozen_fwd(z, p['Decoder/batch_normalization/gamma'], p['Decoder/batch_normalization/beta'])
+        cache['z'], cache['dec_bn_in'] = z, bn
+        a = nn.leaky_relu_fwd(bn, 0.0)
+        for i in range(self.n_pool):
+            c = nn.conv2d_transpose_fwd(a, p[f'Decoder/dec_Conv2DT_{i}/kernel'], p[f'Decoder/dec_Conv2DT_{i}/bias'], 2)
+            bn = nn.bn_frozen_fwd(c, p[f'Decoder/batch_normalization_{i + 1}/gamma'], p[f'Decoder/batch_normalization_{i + 1}/beta'])
+            cache[f'dec_in{i}'], cache[f'dec_c{i}'], cache[f'dec_bn{i}'] = a, c, bn
+            a = nn.leaky_relu_fwd(bn, LRELU_ALPHA)
+        cache['dec_out'] = a
+        xh = nn.conv2d_fwd(a, p['Decoder/dec_Conv2D_final/kernel'], p['Decoder/dec_Conv2D_final/bias'], 1)
+        return {'z': z, 'x_hat': xh}, cache
+
+    def losses(self, x, out):
+        l1 = np.abs(out['x_hat'] - x)
+        rec = l1.reshape(x.shape[0], -1).sum(axis=1).mean()
+        return {'L1': l1, 'reconstructionLoss': rec, 'loss': rec}
+
+    def backward(self, p, x, out, cache, masks=None):
+        masks = masks or {}
+        n, g = x.shape[0], {}
+        gx = np.sign(out['x_hat'] - x) * x.dtype.type(1.0 / n)
+        da, g['Decoder/dec_Conv2D_final/kernel'], g['Decoder/dec_Conv2D_final/bias'] = \
+            nn.conv2d_bwd(cache['dec_out'], p['Decoder/dec_Conv2D_final/kernel'], gx, 1)
+        for i in reversed(range(self.n_pool)):
+            bnp = f'Decoder/batch_normalization_{i + 1}'
+            dbn = nn.leaky_relu_bwd(cache[f'dec_bn{i}'], da, LRELU_ALPHA)
+            dc, g[bnp + '/gamma'], g[bnp + '/beta'] = nn.bn_frozen_bwd(cache[f'dec_c{i}'], p[bnp + '/gamma'], dbn)
+            da, g[f'Decoder/dec_Conv2DT_{i}/kernel'], g[f'Decoder/dec_Conv2DT_{i}/bias'] = \
+                nn.conv2d_transpose_bwd(cache[f'dec_in{i}'], p[f'Decoder/dec_Conv2DT_{i}/kernel'], dc, 2)
+        dbn = nn.leaky_relu_bwd(cache['dec_bn_in'], da, 0.0)
+        dz, g['Decoder/batch_normalization/gamma'], g['Decoder/batch_normalization/beta'] = \
+            nn.bn_frozen_bwd(cache['z'], p['Decoder/batch_normalization/gamma'], dbn)
+        da = dz * masks['z'] if 'z' in masks else dz
+        for i in reversed(range(self.n_pool)):
+            bnp = f'Encoder/batch_normalization_{i}'
+            dbn = nn.leaky_relu_bwd(cache[f'enc_bn{i}'], da, LRELU_ALPHA)
+            dc, g[bnp + '/gamma'], g[bnp + '/beta'] = nn.bn_frozen_bwd(cache[f'enc_c{i}'], p[bnp + '/gamma'], dbn)
+            da, g[f'Encoder/enc_conv2D_{i}/kernel'], g[f'Encoder/enc_conv2D_{i}/bias'] = \
+                nn.conv2d_bwd(cache[f'enc_in{i}'], p[f'Encoder/enc_conv2D_{i}/kernel'], dc, 2)
+        return g

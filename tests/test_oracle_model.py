@@ -169,3 +169,38 @@ def test_retrieve_masked_batch_replays_reference_defect():
     # holes are unions of 20x20 squares inside the brain bounding box
     ys, xs = np.nonzero(holes[0, :, :, 0])
     assert ys.min() >= 8 and ys.max() <= 55 and xs.min() >= 10 and xs.max() <= 49
+
+
+def test_spatial_ae_vs_torch():
+    """models/autoencoder_spatial.py: oracle forward / backward vs an autograd graph (fp64)."""
+    import torch
+    import torch.nn.functional as F
+    from tests import torch_ref
+    m = ovae.SpatialAE(32, 32, 1, 8)
+    p = ovae.init_params(m.spec, seed=2, dtype=np.float64, perturb=True)
+    x = ovae.synthetic_slices(3, 32, 32, seed=1, dtype=np.float64)
+    rng = np.random.default_rng(0)
+    mask = (rng.random((3, 8, 8, 64)) > 0.2) / 0.8
+    out, cache = m.forward(p, x, {'z': mask})
+    g = m.backward(p, x, out, cache, {'z': mask})
+    tp = torch_ref.to_torch(p)
+    a = torch.tensor(x).permute(0, 3, 1, 2)
+
+    def bn(t, name):
+        return t * (tp[name + '/gamma'] / np.sqrt(1.0 + 1e-3)).view(1, -1, 1, 1) + tp[name + '/beta'].view(1, -1, 1, 1)
+
+    for i in range(2):
+        a = F.leaky_relu(bn(torch_ref._conv_same(a, tp[f'Encoder/enc_conv2D_{i}/kernel'], tp[f'Encoder/enc_conv2D_{i}/bias'], 2),
+                            f'Encoder/batch_normalization_{i}'), 0.3)
+    z = a * torch.tensor(mask).permute(0, 3, 1, 2)
+    a = F.relu(bn(z, 'Decoder/batch_normalization'))
+    for i in range(2):
+        a = F.leaky_relu(bn(torch_ref._convT_same(a, tp[f'Decoder/dec_Conv2DT_{i}/kernel'], tp[f'Decoder/dec_Conv2DT_{i}/bias'], 2),
+                            f'Decoder/batch_normalization_{i + 1}'), 0.3)
+    xh = torch_ref._conv_same(a, tp['Decoder/dec_Conv2D_final/kernel'], tp['Decoder/dec_Conv2D_final/bias'], 1).permute(0, 2, 3, 1)
+    loss = (xh - torch.tensor(x)).abs().sum(dim=(1, 2, 3)).mean()
+    loss.backward()
+    np.testing.assert_allclose(out['x_hat'], xh.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(m.losses(x, out)['loss'], loss.item(), rtol=1e-12)
+    for name, _, _ in m.spec:
+        np.testing.assert_allclose(g[name], tp[name].grad.numpy(), rtol=1e-7, atol=1e-12, err_msg=name)

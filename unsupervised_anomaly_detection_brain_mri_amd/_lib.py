@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('UAD_LIB') or os.path.join(_HERE, 'libuad_hip.so')   # UAD_LIB: A/B builds for kernel tuning
 
 UAD_OK = 0
-ARCH_AE, ARCH_VAE, ARCH_CEVAE, ARCH_GMVAE_SPATIAL = 0, 1, 2, 3
+ARCH_AE, ARCH_VAE, ARCH_CEVAE, ARCH_GMVAE_SPATIAL, ARCH_AE_SPATIAL = 0, 1, 2, 3, 4
 BUF_PARAMS, BUF_GRADS, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
 SEG_DECODER, SEG_BOTTLENECK, SEG_ENCODER, SEG_ALL = 0, 1, 2, -1
 MATH_F32, MATH_BF16X3, MATH_BF16X3_ALL = 0, 1, 2

@@ -218,6 +218,12 @@ void uad_launch_gm_loss_finalize(const float* rec_partial, int n, int bps, const
                                  float inv_batch, float* rec_per_sample, float* scalars, hipStream_t st);
 // dx = data gradient of the first conv, nothing else (f-AnoGAN critic input gradient)
 void uad_launch_conv_first_dgrad_plain(const UadConvDesc& d, const float* g, const float* W, float* dx, hipStream_t st);
+// spatial autoencoder latent: z = mask * lrelu(gamma * rs0 * c + beta) and its backward (colpart [blocks][2][C], blocks as returned)
+void uad_launch_spatial_z_fwd(const float* c, const float* gamma, const float* beta, float rs0, float alpha, const float* mask, int rows,
+                              int C, float* z, hipStream_t st);
+int uad_spatial_z_bwd_blocks(int rows);
+void uad_launch_spatial_z_bwd(const float* dz, const float* c, const float* gamma, const float* beta, float rs0, float alpha,
+                              const float* mask, int rows, int C, float* dc, float* colpart, hipStream_t st);
 // batch assembly from the HBM-resident slice cache: out[b] = src[idx[b]]; mask[b][p] = lut[labels[idx[b]][p]] (lut null: the label value)
 void uad_launch_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, hipStream_t st);
 void uad_launch_gather_mask(const unsigned char* labels, const int* idx, int n, long long slice_px, const unsigned char* lut,

@@ -609,6 +609,55 @@ __global__ void __launch_bounds__(256) residual_kernel(const float* __restrict__
     if (threadIdx.x == 0 && l1part) l1part[(size_t)n * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Spatial autoencoder latent (models/autoencoder_spatial.py:13-17): z = mask * lrelu(gamma' c + beta) of the last encoder block,
+// materialised because it is a graph output and the decoder input; backward: d c = d z * mask * lrelu' * gamma', with the
+// per-block column sums the BN-gradient finalize expects (colpart[blk][0][ch] = sum d_bn, [1][ch] = sum d_bn * c).
+__global__ void __launch_bounds__(256) spatial_z_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float rs0, float alpha,
+                                                            const float* __restrict__ mask, size_t total4, int C, float* __restrict__ z) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int ch = (int)((i * 4) % C);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + ch), b = *reinterpret_cast<const float4*>(beta + ch);
+    const float4 v = reinterpret_cast<const float4*>(c)[i];
+    float4 y = make_float4(fmaf(v.x, g.x * rs0, b.x), fmaf(v.y, g.y * rs0, b.y), fmaf(v.z, g.z * rs0, b.z), fmaf(v.w, g.w * rs0, b.w));
+    y = make_float4(y.x > 0.f ? y.x : alpha * y.x, y.y > 0.f ? y.y : alpha * y.y, y.z > 0.f ? y.z : alpha * y.z, y.w > 0.f ? y.w : alpha * y.w);
+    if (mask) { const float4 m = reinterpret_cast<const float4*>(mask)[i]; y = make_float4(y.x * m.x, y.y * m.y, y.z * m.z, y.w * m.w); }
+    reinterpret_cast<float4*>(z)[i] = y;
+}
+__global__ void __launch_bounds__(256) spatial_z_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ c,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float rs0,
+                                                            float alpha, const float* __restrict__ mask, int rows, int rows_per_block,
+                                                            int C, float* __restrict__ dc, float* __restrict__ colpart) {
+    __shared__ float r1[1024], r2[1024];
+    const int Q = C / 4, RL = 256 / Q;
+    const int cq = threadIdx.x % Q, rl = threadIdx.x / Q, ch = cq * 4;
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch), b = *reinterpret_cast<const float4*>(beta + ch);
+    const float4 g = make_float4(g0.x * rs0, g0.y * rs0, g0.z * rs0, g0.w * rs0);
+    const int row0 = blockIdx.x * rows_per_block, row1 = min(rows, row0 + rows_per_block);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (int row = row0 + rl; row < row1; row += RL) {
+        const size_t o = (size_t)row * C + ch;
+        const float4 cv = *reinterpret_cast<const float4*>(c + o);
+        float4 d = *reinterpret_cast<const float4*>(dz + o);
+        if (mask) { const float4 m = *reinterpret_cast<const float4*>(mask + o); d = make_float4(d.x * m.x, d.y * m.y, d.z * m.z, d.w * m.w); }
+        const float4 dn = make_float4(fmaf(cv.x, g.x, b.x) > 0.f ? d.x : alpha * d.x, fmaf(cv.y, g.y, b.y) > 0.f ? d.y : alpha * d.y,
+                                      fmaf(cv.z, g.z, b.z) > 0.f ? d.z : alpha * d.z, fmaf(cv.w, g.w, b.w) > 0.f ? d.w : alpha * d.w);
+        *reinterpret_cast<float4*>(dc + o) = make_float4(dn.x * g.x, dn.y * g.y, dn.z * g.z, dn.w * g.w);
+        s1 = make_float4(s1.x + dn.x, s1.y + dn.y, s1.z + dn.z, s1.w + dn.w);
+        s2 = make_float4(fmaf(dn.x, cv.x, s2.x), fmaf(dn.y, cv.y, s2.y), fmaf(dn.z, cv.z, s2.z), fmaf(dn.w, cv.w, s2.w));
+    }
+    *reinterpret_cast<float4*>(r1 + rl * C + ch) = s1;
+    *reinterpret_cast<float4*>(r2 + rl * C + ch) = s2;
+    __syncthreads();
+    for (int k = threadIdx.x; k < C; k += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int j = 0; j < RL; ++j) { a1 += r1[j * C + k]; a2 += r2[j * C + k]; }
+        colpart[((size_t)blockIdx.x * 2 + 0) * C + k] = a1;
+        colpart[((size_t)blockIdx.x * 2 + 1) * C + k] = a2;
+    }
+}
+
 // Batch assembly from an HBM-resident slice cache: out[b] = src[idx[b]] (fp32 slices, 16-byte copies) and
 // mask[b][p] = lut[labels[idx[b]][p]] (u8 label maps -> 0/1 brain masks, dataloaders/BRAINWEB.py:466-476).
 __global__ void __launch_bounds__(256) gather_slices_kernel(const float* __restrict__ src, const int* __restrict__ idx,
@@ -633,6 +682,22 @@ __global__ void __launch_bounds__(256) gather_mask_kernel(const unsigned char* _
 }  // namespace
 
 // ================================================================================================
+void uad_launch_spatial_z_fwd(const float* c, const float* gamma, const float* beta, float rs0, float alpha, const float* mask, int rows,
+                              int C, float* z, hipStream_t st) {
+    const size_t total4 = (size_t)rows * C / 4;
+    hipLaunchKernelGGL(spatial_z_fwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, c, gamma, beta, rs0, alpha, mask, total4, C, z);
+}
+int uad_spatial_z_bwd_blocks(int rows) {      // blocks the backward launches (= colpart rows it writes)
+    const int nb = rows < 512 ? rows : 512;
+    const int rpb = (rows + nb - 1) / nb;
+    return (rows + rpb - 1) / rpb;
+}
+void uad_launch_spatial_z_bwd(const float* dz, const float* c, const float* gamma, const float* beta, float rs0, float alpha,
+                              const float* mask, int rows, int C, float* dc, float* colpart, hipStream_t st) {
+    const int nb = uad_spatial_z_bwd_blocks(rows);
+    const int rpb = (rows + nb - 1) / nb;
+    hipLaunchKernelGGL(spatial_z_bwd_kernel, dim3(nb), dim3(256), 0, st, dz, c, gamma, beta, rs0, alpha, mask, rows, rpb, C, dc, colpart);
+}
 void uad_launch_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, hipStream_t st) {
     const long long f4 = slice_elems / 4;
     int bx = (int)((f4 + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;

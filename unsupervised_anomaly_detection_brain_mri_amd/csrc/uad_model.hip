@@ -250,11 +250,12 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     if (cfg->inter_res <= 0 || (cfg->inter_res & (cfg->inter_res - 1)) || cfg->inter_res >= H)
         return fail(UAD_ERR_INVALID, "inter_res must be a power of two smaller than height");
     if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
-    if (cfg->arch < UAD_ARCH_AE || cfg->arch > UAD_ARCH_GMVAE_SPATIAL) return fail(UAD_ERR_INVALID, "bad arch");
+    if (cfg->arch < UAD_ARCH_AE || cfg->arch > UAD_ARCH_AE_SPATIAL) return fail(UAD_ERR_INVALID, "bad arch");
     const bool gm = cfg->arch == UAD_ARCH_GMVAE_SPATIAL;
+    const bool sp = cfg->arch == UAD_ARCH_AE_SPATIAL;        // spatial AE: encoder feature map -> decoder, nothing in between
     if (gm && (cfg->dim_c < 1 || cfg->dim_c > 64 || cfg->dim_z < 1 || cfg->dim_w < 1 || cfg->dim_z * cfg->dim_c > 4096 || cfg->dim_w > 64))
         return fail(UAD_ERR_UNSUPPORTED, "GMVAE: need 1 <= dim_c <= 64, dim_z*dim_c <= 4096, 1 <= dim_w <= 64");
-    if (!gm && (cfg->zdim <= 0 || cfg->zdim % 8)) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
+    if (!gm && !sp && (cfg->zdim <= 0 || cfg->zdim % 8)) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
     if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
 
     uad_model* m = new uad_model();
@@ -322,6 +323,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
         m->gm_off[13] = add_tensor(m, "p_z_wc/z_wc_log_sigma/bias", 1, Q, 1, 1, 1);
         m->gm_off[14] = add_tensor(m, "Variable", 1, Q, 1, 1, 1);
         m->gm_total = m->nparams - m->gm_off[0];
+    } else if (sp) {
+        // no bottleneck variables (autoencoder_spatial.py:11-17)
     } else {
     m->bw = add_tensor(m, "Bottleneck/conv2d/kernel", 4, 1, 1, m->cenc, m->cmid);
     m->bb = add_tensor(m, "Bottleneck/conv2d/bias", 1, m->cmid, 1, 1, 1);
@@ -385,12 +388,12 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     size_t maxact = 0;
     for (auto& L : m->enc) { size_t n = NB * L.d.HS * L.d.WS * L.d.CS; ALLOC(L.c, n); if (n > maxact) maxact = n; }
     for (auto& L : m->dec) { size_t n = NB * L.d.HB * L.d.WB * L.d.CB; ALLOC(L.c, n); if (n > maxact) maxact = n; }
-    const size_t nz = NB * (gm ? 8 : cfg->zdim), nflat = NB * m->flat, ncb = NB * ir * ir * m->cenc;
+    const size_t nz = NB * ((gm || sp) ? 8 : cfg->zdim), nflat = NB * m->flat, ncb = NB * ir * ir * m->cenc;
     ALLOC(m->t, nflat); ALLOC(m->mu_raw, nz); ALLOC(m->ls_raw, nz); ALLOC(m->mu, nz); ALLOC(m->ls, nz);
     ALLOC(m->sigma, nz); ALLOC(m->z, nz); ALLOC(m->dvec, nflat); ALLOC(m->cb, ncb); ALLOC(m->kl, NB);
     ALLOC(m->xhat_own, NB * H * Wd * cfg->channels);
     m->wT_d = m->wT_mu = m->wT_sg = nullptr;
-    if (!gm) { const size_t fz = (size_t)m->flat * cfg->zdim; ALLOC(m->wT_d, fz); ALLOC(m->wT_mu, fz); ALLOC(m->wT_sg, fz); }
+    if (!gm && !sp) { const size_t fz = (size_t)m->flat * cfg->zdim; ALLOC(m->wT_d, fz); ALLOC(m->wT_mu, fz); ALLOC(m->wT_sg, fz); }
     m->xcat = m->mdec_cat = m->l1_own = nullptr;
     if (cevae) { ALLOC(m->xcat, NB * H * Wd * cfg->channels); ALLOC(m->mdec_cat, nflat); ALLOC(m->l1_own, NB * H * Wd * cfg->channels); }
     m->gm_h = m->gm_loc_loss = m->gm_dheads = m->gm_da7 = m->gm_mid = m->gm_dM = m->gm_dLq = m->gm_ws = m->gm_partial = m->gm_dxhat = nullptr;
@@ -400,7 +403,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
         ALLOC(m->gm_mid, L * 64); ALLOC(m->gm_dM, L * Q); ALLOC(m->gm_dLq, L * Q); ALLOC(m->gm_ws, L * cfg->dim_w);
         ALLOC(m->gm_partial, (size_t)64 * m->gm_total); ALLOC(m->gm_dxhat, NB * H * Wd * cfg->channels);
     }
-    m->dec_in0 = gm ? m->gm_h : m->cb;
+    if (sp) ALLOC(m->gm_h, NB * ir * ir * m->cenc);           // the latent feature map z
+    m->dec_in0 = (gm || sp) ? m->gm_h : m->cb;
     ALLOC(m->G0, maxact); ALLOC(m->G1, maxact);
     ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
     ALLOC(m->g_small[4], nflat); ALLOC(m->g_small[5], nflat);
@@ -411,6 +415,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     for (auto& L : m->dec) cp_need(NB * L.d.HS * L.d.WS, 1, L.d.CS);
     cp_need(NB * ir * ir, 1, m->cenc);
     if (gm) { size_t v = NB * ir * ir * 2 * m->cenc; if (v > cp) cp = v; }
+    if (sp) { size_t v = (size_t)512 * 2 * m->cenc; if (v > cp) cp = v; }
     m->colpart_cap = cp; ALLOC(m->colpart, cp);
     for (int k = 0; k < 16; ++k) { m->cp_slot[k] = nullptr; ALLOC(m->cp_slot[k], cp); }
     m->ev_next = 0; m->side = nullptr;
@@ -419,7 +424,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     auto wp_need = [&](UadConvDesc d) { d.N = (int)NB; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
     for (size_t i = 1; i < m->enc.size(); ++i) wp_need(m->enc[i].d);
     for (auto& L : m->dec) wp_need(L.d);
-    if (!gm) {
+    if (!gm && !sp) {
         wp_need(conv1x1_desc(1, ir, ir, m->cenc, m->cmid)); wp_need(conv1x1_desc(1, ir, ir, m->cmid, m->cenc));
         wp_need(dense_desc(1, m->flat, cfg->zdim)); wp_need(dense_desc(1, cfg->zdim, m->flat));
     }
@@ -431,7 +436,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
         auto want = [&](UadConvDesc d, bool f, bool pack) { d.N = (int)NB; size_t v = uad_conv_ws_floats(d, f, pack); if (v > need) need = v; };
         for (size_t i = 1; i < m->enc.size(); ++i) { want(m->enc[i].d, true, true); want(m->enc[i].d, false, true); }
         for (auto& L : m->dec) { want(L.d, true, true); want(L.d, false, true); }
-        if (!gm) {
+        if (!gm && !sp) {
         want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), true, false); want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), false, false);
         want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), true, false); want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), false, false);
         want(dense_desc(1, m->flat, cfg->zdim), true, false); want(dense_desc(1, m->flat, cfg->zdim), false, false);
@@ -526,6 +531,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     const bool vae = m->cfg.arch == UAD_ARCH_VAE || m->cfg.arch == UAD_ARCH_CEVAE;
     const bool cevae = m->cfg.arch == UAD_ARCH_CEVAE;
     const bool gm = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL;
+    const bool sp = m->cfg.arch == UAD_ARCH_AE_SPATIAL;
     const int ir = m->cfg.inter_res;
     const int nu = n;                 // samples the caller passed
     const float* xin = io->x;
@@ -560,7 +566,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
             else
                 uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
         }
-        if (!gm) {
+        if (!gm && !sp) {
             // transposed copies of the dense kernels for the fused bottleneck backward
             const float* tin[3] = {P(m, m->dw), P(m, m->muw), m->sgw >= 0 ? P(m, m->sgw) : nullptr};
             float* tout[3] = {m->wT_d, m->wT_mu, m->wT_sg};
@@ -590,6 +596,10 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         UadGmArgs ga = gm_args(m, io->eps_w, io->eps_z, 1.0f / (float)nu);
         ga.w_mu = io->w_mu; ga.w_ls = io->w_log_sigma; ga.z_mu = io->z_mu; ga.z_ls = io->z_log_sigma; ga.pc = io->pc;
         uad_launch_gm_heads_fwd(ga, n * ir * ir, st);
+    } else if (sp) {
+        PROF("spatial.z.fwd");
+        uad_launch_spatial_z_fwd(EL.c, P(m, EL.gamma), P(m, EL.beta), 1.0f / sqrtf(1.0f + kBnEps), kLrelu, io->mask_mu, n * ir * ir, m->cenc,
+                                 m->gm_h, st);
     } else if (uad_bottleneck_fused_ok(bott_args(m, *io, mask_dec, nu))) {
         PROF("bott.fwd");
         uad_launch_bottleneck_fwd(bott_args(m, *io, mask_dec, nu), n, st);
@@ -689,8 +699,9 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         if (io->l1_map_ce) HIP_TRY(hipMemcpyAsync(io->l1_map_ce, m->l1_own + xe, xb, hipMemcpyDeviceToDevice, st));
     }
     // optional latent outputs (VAE-branch samples)
-    const size_t zb = gm ? 0 : (size_t)nu * m->cfg.zdim * sizeof(float);
-    if (!gm && io->z_mu) hipMemcpyAsync(io->z_mu, vae ? m->mu : m->z, zb, hipMemcpyDeviceToDevice, st);
+    const size_t zb = (gm || sp) ? 0 : (size_t)nu * m->cfg.zdim * sizeof(float);
+    if (sp && io->z_mu) hipMemcpyAsync(io->z_mu, m->gm_h, (size_t)nu * ir * ir * m->cenc * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (!gm && !sp && io->z_mu) hipMemcpyAsync(io->z_mu, vae ? m->mu : m->z, zb, hipMemcpyDeviceToDevice, st);
     if (vae && io->z_log_sigma) hipMemcpyAsync(io->z_log_sigma, m->ls, zb, hipMemcpyDeviceToDevice, st);
     if (vae && io->z_sigma) hipMemcpyAsync(io->z_sigma, m->sigma, zb, hipMemcpyDeviceToDevice, st);
     m->last_n = n; m->last_nuser = nu; m->last_io = *io; m->have_fwd = want_backward != 0;
@@ -922,6 +933,21 @@ static int backward_gm_heads(uad_model* m, hipStream_t st) {
     return UAD_OK;
 }
 
+// spatial AE: the "bottleneck" segment is the dropout mask + the last encoder block's activation backward
+static int backward_spatial_z(uad_model* m, hipStream_t st) {
+    const int n = m->last_n, ir = m->cfg.inter_res, rows = n * ir * ir;
+    const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
+    const ConvLayer& EL = m->enc.back();
+    hipStream_t sd = m->side;
+    float* cp = m->cp_slot[15];
+    { PROF("spatial.z.bwd"); uad_launch_spatial_z_bwd(m->G0, EL.c, P(m, EL.gamma), P(m, EL.beta), rstd, kLrelu, m->last_io.mask_mu, rows, m->cenc, m->G1, cp, st); }
+    edge(m, st, sd);
+    if (!m->data_only) { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_spatial_z_bwd_blocks(rows), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma), Gr(m, EL.beta), Gr(m, EL.b), sd); }
+    float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;   // G0 = d loss / d c of the last encoder conv
+    edge(m, sd, st);
+    return UAD_OK;
+}
+
 static int backward_encoder(uad_model* m, hipStream_t st) {
     const int n = m->last_n;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
@@ -972,7 +998,8 @@ int uad_backward(uad_model_t* m, int segment, void* stream) {
     int rc = UAD_OK;
     if (segment == UAD_SEG_ALL || segment == UAD_SEG_DECODER) rc = backward_decoder(m, st);
     if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_BOTTLENECK))
-        rc = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL ? backward_gm_heads(m, st) : backward_bottleneck(m, st, segment == UAD_SEG_BOTTLENECK);
+        rc = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL ? backward_gm_heads(m, st)
+             : m->cfg.arch == UAD_ARCH_AE_SPATIAL ? backward_spatial_z(m, st) : backward_bottleneck(m, st, segment == UAD_SEG_BOTTLENECK);
     if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_ENCODER)) {
         rc = backward_encoder(m, st);
         m->have_fwd = false;

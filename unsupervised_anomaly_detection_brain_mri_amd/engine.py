@@ -90,7 +90,7 @@ class Engine(_EvalOps):
         self.arch = arch
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
         archs = {'AE': _lib.ARCH_AE, 'VAE': _lib.ARCH_VAE, 'ceVAE': _lib.ARCH_CEVAE,
-                 'GMVAE_spatial': _lib.ARCH_GMVAE_SPATIAL}
+                 'GMVAE_spatial': _lib.ARCH_GMVAE_SPATIAL, 'AE_spatial': _lib.ARCH_AE_SPATIAL}
         if arch not in archs:
             raise ValueError(f'unknown arch {arch!r}')
         self.dim_c, self.dim_z, self.dim_w = int(dim_c), int(dim_z), int(dim_w)
@@ -211,10 +211,11 @@ class Engine(_EvalOps):
         ce = self.arch == 'ceVAE'
         if x_ce is not None and not ce:
             raise ValueError('x_ce is a ceVAE input')
-        zs = (n, self.zdim)
+        # spatial AE: the latent (and its dropout mask) is the encoder feature map
+        zs = (n, self.inter, self.inter, self._cenc()) if self.arch == 'AE_spatial' else (n, self.zdim)
         eps = self._dev(eps, zs)
         m_mu_ce = m_dec_ce = None
-        if self.arch != 'AE':
+        if self.arch not in ('AE', 'AE_spatial'):
             m_mu, m_sg = self._dev(masks.get('mu'), zs), self._dev(masks.get('sigma'), zs)
             m_dec = self._dev(masks.get('dec'), (n, self.flat))
             if ce:
@@ -234,7 +235,7 @@ class Engine(_EvalOps):
                 out['anomaly'] = torch.empty_like(x)
         lat = {}
         if want_latents:
-            if self.arch != 'AE':
+            if self.arch not in ('AE', 'AE_spatial'):
                 lat = {k: torch.empty(zs, device=self.device) for k in ('z_mu', 'z_log_sigma', 'z_sigma')}
             else:
                 lat = {'z': torch.empty(zs, device=self.device)}

@@ -7,3 +7,4 @@ from .context_encoder_variational_autoencoder import context_encoder_variational
 from .gaussian_mixture_variational_autoencoder_spatial import gaussian_mixture_variational_autoencoder_spatial  # noqa: F401
 from .fanogan import fanogan  # noqa: F401
 from .fanogan_schlegl import fanogan_schlegl  # noqa: F401
+from .autoencoder_spatial import autoencoder_spatial  # noqa: F401

@@ -48,7 +48,8 @@ class DataParallelStep:
         for seg in SEGMENT_ORDER:
             eng.backward(seg)
             off, cnt = self.segs[seg]
-            works.append(dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
+            if cnt > 0:          # the spatial AE has no bottleneck variables
+                works.append(dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
         # local grads are d(mean over the local batch); sum / world = d(mean over the global batch)

@@ -41,12 +41,17 @@ class AEMODEL(DLMODEL):
     ARCH = 'AE'
     SCALAR_KEYS = ('reconstructionLoss', 'loss')
 
+    @property
+    def ARCHS(self):                  # network families this trainer class accepts
+        return (self.ARCH,)
+
     def __init__(self, sess, config=None, network=None, seed=0, world=None, device=None):
         super().__init__(sess, config if config is not None else self.Config())
         if network is None or not hasattr(network, 'arch'):
             raise ValueError('network= must be one of unsupervised_anomaly_detection_brain_mri_amd.models.*')
-        if network.arch != self.ARCH:
-            raise ValueError(f'trainer {type(self).__name__} expects a {self.ARCH} network, got {network.__name__}')
+        if network.arch not in self.ARCHS:
+            raise ValueError(f'trainer {type(self).__name__} expects a {" / ".join(self.ARCHS)} network, got {network.__name__}')
+        self.arch = network.arch
         self.network = network
         self.losses = {}
         c = self.config
@@ -59,7 +64,7 @@ class AEMODEL(DLMODEL):
 
     def _make_engine(self, device):
         c = self.config
-        return Engine(self.ARCH, c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]),
+        return Engine(self.arch, c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]),
                       c.zDim, max_batch=max(int(c.batchsize), 1), device=device)
 
     def _make_dp(self, world):
