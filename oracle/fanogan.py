@@ -136,6 +136,7 @@ class FAnoGAN:
         self.ln_g = [n[:-len('/gamma')] for n, _, _ in self.spec if n.startswith('Generator/layer_norm') and n.endswith('gamma')]
         self.ln_d = [n[:-len('/gamma')] for n, _, _ in self.spec if n.startswith('Discriminator/layer_norm') and n.endswith('gamma')]
         self.bn_e = [n[:-len('/gamma')] for n, _, _ in self.spec if n.startswith('Encoder/batch_norm') and n.endswith('gamma')]
+        self.final_act = 'sigmoid'        # fanogan.py:42,47; AnoVAEGAN's generator output is linear
 
     # ------------------------------------------------------------------ Encoder
     def enc_forward(self, p, x, mask_z=None):
@@ -190,7 +191,7 @@ class FAnoGAN:
             a = nn.leaky_relu_fwd(y, LRELU)
             cache['c'].append(c); cache['ln'].append((y, lc)); cache['a'].append(a)
         o = nn.conv2d_fwd(a, p['Generator/dec_Conv2D_final/kernel'], p['Generator/dec_Conv2D_final/bias'], 1)
-        xg = sigmoid(o)
+        xg = sigmoid(o) if self.final_act == 'sigmoid' else o
         cache['x'] = xg
         return xg, cache
 
@@ -198,7 +199,7 @@ class FAnoGAN:
         """dx = dL/d(sigmoid output).  Returns (parameter grads, dL/dz)."""
         g = {}
         xg = cache['x']
-        do = dx * xg * (1.0 - xg)
+        do = dx * xg * (1.0 - xg) if self.final_act == 'sigmoid' else dx
         da, g['Generator/dec_Conv2D_final/kernel'], g['Generator/dec_Conv2D_final/bias'] = \
             nn.conv2d_bwd(cache['a'][-1], p['Generator/dec_Conv2D_final/kernel'], do, 1)
         for i in reversed(range(self.npool)):
@@ -360,3 +361,120 @@ class FAnoGAN:
             if group_of(k) == group:
                 nn.adam_tf_step(p[k], np.asarray(gk, p[k].dtype).reshape(p[k].shape), opt['m'][k], opt['v'][k], opt['t'][group],
                                 lr, beta1=0.5, beta2=0.9)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# AnoVAE-GAN (models/anovaegan.py:10-80, trainers/AnoVAEGAN.py:45-86): the same encoder / generator / critic blocks as the
+# unified f-AnoGAN, but the encoder ends in mu / log-sigma heads (z = mu + eps * exp(log_sigma)), the generator decodes z_vae and
+# has a linear output, and the critic judges the RECONSTRUCTION G(E(x)) against x.  Three Adams (beta1 .5, beta2 .9):
+#   optim_vae: enc_loss = mean_n sum|x - out| + kl_weight * mean_n KL      over Encoder + Generator variables
+#   optim_gen: gen_loss = -mean D(out)                                        over Generator variables
+#   optim_dis: disc_loss = mean D(out) - mean D(x) + scale * penalty          over Discriminator variables
+# ---------------------------------------------------------------------------------------------------------------
+def param_spec_anovaegan(height=128, inter_res=8, zdim=128, channels=1):
+    spec = param_spec(height, inter_res, zdim, channels)
+    i = [k for k, (n, _, _) in enumerate(spec) if n == 'Encoder/dense/bias'][0]
+    flat = spec[i - 1][1][0]
+    return spec[:i + 1] + [('Encoder/dense_1/kernel', (flat, zdim), 'dense_w'), ('Encoder/dense_1/bias', (zdim,), 'bias')] + spec[i + 1:]
+
+
+class AnoVAEGAN(FAnoGAN):
+    def __init__(self, height=128, inter_res=8, zdim=128, channels=1, scale=10.0, kl_weight=1.0):
+        super().__init__(height, inter_res, zdim, channels, scale, 1.0)
+        self.kl_weight = kl_weight
+        self.spec = param_spec_anovaegan(height, inter_res, zdim, channels)
+        self.final_act = 'none'
+
+    def vae_enc_forward(self, p, x, eps, mask_mu=None, mask_sg=None):
+        cache = {'a': [x], 'c': []}
+        a = x
+        for i in range(self.npool):
+            c = nn.conv2d_fwd(a, p['Encoder/enc_conv2D_%d/kernel' % i], p['Encoder/enc_conv2D_%d/bias' % i], 2)
+            a = nn.leaky_relu_fwd(nn.bn_frozen_fwd(c, p[self.bn_e[i] + '/gamma'], p[self.bn_e[i] + '/beta']), LRELU)
+            cache['c'].append(c); cache['a'].append(a)
+        t = nn.conv2d_fwd(a, p['Encoder/conv2d/kernel'], p['Encoder/conv2d/bias'], 1)
+        flat = t.reshape(t.shape[0], -1)
+        mu = nn.dense_fwd(flat, p['Encoder/dense/kernel'], p['Encoder/dense/bias'])
+        ls = nn.dense_fwd(flat, p['Encoder/dense_1/kernel'], p['Encoder/dense_1/bias'])
+        if mask_mu is not None:
+            mu = mu * mask_mu
+        if mask_sg is not None:
+            ls = ls * mask_sg
+        sg = np.exp(ls)
+        z = mu + eps * sg
+        kl = 0.5 * (mu * mu + sg * sg - 2.0 * ls - 1.0).sum(axis=1)           # tf.log(tf.square(sigma)) = 2 log_sigma
+        cache.update(t=t, flat=flat, mu=mu, ls=ls, sg=sg, eps=eps, mask_mu=mask_mu, mask_sg=mask_sg)
+        return z, kl, cache
+
+    def vae_enc_backward(self, p, cache, dz, klw):
+        g = {}
+        mu, sg, eps = cache['mu'], cache['sg'], cache['eps']
+        dmu = dz + mu * klw
+        dls = dz * eps * sg + (sg * sg - 1.0) * klw
+        if cache['mask_mu'] is not None:
+            dmu = dmu * cache['mask_mu']
+        if cache['mask_sg'] is not None:
+            dls = dls * cache['mask_sg']
+        d1, g['Encoder/dense/kernel'], g['Encoder/dense/bias'] = nn.dense_bwd(cache['flat'], p['Encoder/dense/kernel'], dmu)
+        d2, g['Encoder/dense_1/kernel'], g['Encoder/dense_1/bias'] = nn.dense_bwd(cache['flat'], p['Encoder/dense_1/kernel'], dls)
+        da, g['Encoder/conv2d/kernel'], g['Encoder/conv2d/bias'] = nn.conv2d_bwd(cache['a'][-1], p['Encoder/conv2d/kernel'],
+                                                                               (d1 + d2).reshape(cache['t'].shape), 1)
+        for i in reversed(range(self.npool)):
+            c = cache['c'][i]
+            bnv = nn.bn_frozen_fwd(c, p[self.bn_e[i] + '/gamma'], p[self.bn_e[i] + '/beta'])
+            dc, g[self.bn_e[i] + '/gamma'], g[self.bn_e[i] + '/beta'] = nn.bn_frozen_bwd(c, p[self.bn_e[i] + '/gamma'], nn.leaky_relu_bwd(bnv, da, LRELU))
+            da, g['Encoder/enc_conv2D_%d/kernel' % i], g['Encoder/enc_conv2D_%d/bias' % i] = \
+                nn.conv2d_bwd(cache['a'][i], p['Encoder/enc_conv2D_%d/kernel' % i], dc, 2)
+        return g
+
+    def vae_phase(self, p, x, eps, mask_mu=None, mask_sg=None, caches=None):
+        n = x.shape[0]
+        z, kl, ec = self.vae_enc_forward(p, x, eps, mask_mu, mask_sg)
+        out, gc = self.gen_forward(p, z)
+        if caches is not None:
+            caches.update(enc=ec, gen=gc, disc=[])
+        l1 = np.abs(x - out)
+        rec = l1.reshape(n, -1).sum(axis=1).mean()
+        losses = {'reconstructionLoss': rec, 'loss': rec, 'kl': kl.mean(), 'enc_loss': rec + self.kl_weight * kl.mean(), 'L1': l1,
+                  'reconstruction': out, 'z_mu': ec['mu'], 'z_sigma': ec['sg']}
+        g_gen, dz = self.gen_backward(p, gc, np.sign(out - x) / n)
+        grads = self.vae_enc_backward(p, ec, dz, self.kl_weight / n)
+        grads.update(g_gen)
+        return losses, grads
+
+    def gen_phase(self, p, x, eps, mask_mu=None, mask_sg=None, caches=None):
+        z, _, ec = self.vae_enc_forward(p, x, eps, mask_mu, mask_sg)
+        out, gc = self.gen_forward(p, z)
+        _, d, dcache = self.disc_forward(p, out)
+        if caches is not None:
+            caches.update(enc=ec, gen=gc, disc=[dcache])
+        _, dx = self.disc_backward(p, dcache, dd=np.full_like(d, -1.0 / d.size), want_params=False)
+        grads, _ = self.gen_backward(p, gc, dx)
+        return {'gen_loss': -d.mean(), 'reconstruction': out}, grads
+
+    def disc_phase(self, p, x, eps, alpha, mask_mu=None, mask_sg=None, caches=None):
+        z, _, ec = self.vae_enc_forward(p, x, eps, mask_mu, mask_sg)
+        out, gcache = self.gen_forward(p, z)
+        _, d_fake, c_fake = self.disc_forward(p, out)
+        _, d_real, c_real = self.disc_forward(p, x)
+        x_hat = x + alpha.reshape(-1, 1, 1, 1).astype(x.dtype) * (out - x)
+        _, _, c_hat = self.disc_forward(p, x_hat)
+        if caches is not None:
+            caches.update(enc=ec, gen=gcache, disc=[c_fake, c_real, c_hat])
+        ddx, tape = self.disc_input_grad(p, c_hat)
+        pen, gbar = self.gradient_penalty(ddx)
+        losses = {'disc_fake': d_fake.mean(), 'disc_real': d_real.mean(), 'penalty': pen}
+        losses['disc_loss'] = losses['disc_fake'] - losses['disc_real'] + pen
+        g_f, _ = self.disc_backward(p, c_fake, dd=np.full_like(d_fake, 1.0 / d_fake.size))
+        g_r, _ = self.disc_backward(p, c_real, dd=np.full_like(d_real, -1.0 / d_real.size))
+        g_2, inject = self.disc_penalty_grads(p, c_hat, tape, gbar)
+        g_3, _ = self.disc_backward(p, c_hat, inject=inject)
+        grads = {}
+        for part in (g_f, g_r, g_2, g_3):
+            for k, v in part.items():
+                grads[k] = grads.get(k, 0) + v
+        return losses, grads
+
+    def reconstruct(self, p, x, eps=None):
+        z, _, _ = self.vae_enc_forward(p, x, np.zeros((x.shape[0], self.zdim), x.dtype) if eps is None else eps)
+        return self.gen_forward(p, z)[0]

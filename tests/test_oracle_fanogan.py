@@ -160,3 +160,83 @@ def test_fanogan_schlegl_param_table():
     n_g = sum(int(np.prod(s)) for k, s, _ in m.spec if k.startswith('Generator'))
     n_d = sum(int(np.prod(s)) for k, s, _ in m.spec if k.startswith('Discriminator'))
     assert 11.0e6 < n_g < 12.0e6 and 9.0e6 < n_d < 10.0e6                            # ~11.4 M / ~9.5 M
+
+
+# ------------------------------------------------------------------ AnoVAE-GAN (models/anovaegan.py, trainers/AnoVAEGAN.py)
+@pytest.mark.parametrize('h,inter,zdim,n,drop', [(32, 8, 16, 2, True), (64, 8, 8, 1, False)])
+def test_anovaegan_phases_vs_torch(h, inter, zdim, n, drop):
+    import math
+    import torch.nn.functional as F
+    m = ofa.AnoVAEGAN(h, inter, zdim, scale=10.0, kl_weight=0.7)
+    p = ovae.init_params(m.spec, seed=9, dtype=np.float64, perturb=True)
+    rng = np.random.default_rng(3)
+    x = ovae.synthetic_slices(n, h, h, seed=2, dtype=np.float64)
+    eps = rng.standard_normal((n, zdim)); alpha = rng.uniform(0, 1, (n, 1))
+    mm = (rng.random((n, zdim)) > 0.2) / 0.8 if drop else None
+    ms = (rng.random((n, zdim)) > 0.2) / 0.8 if drop else None
+    tp = torch_ref.to_torch(p)
+    xt = torch.tensor(x).permute(0, 3, 1, 2)
+    ln_g = [k for k in m.ln_g]; ln_d = [k for k in m.ln_d]
+
+    a = xt
+    for i in range(m.npool):
+        a = torch_ref._conv_same(a, tp['Encoder/enc_conv2D_%d/kernel' % i], tp['Encoder/enc_conv2D_%d/bias' % i], 2)
+        a = F.leaky_relu(a * (tp[m.bn_e[i] + '/gamma'] / math.sqrt(1.001)).view(1, -1, 1, 1) + tp[m.bn_e[i] + '/beta'].view(1, -1, 1, 1), 0.3)
+    t = torch_ref._conv_same(a, tp['Encoder/conv2d/kernel'], tp['Encoder/conv2d/bias'], 1)
+    flat = t.permute(0, 2, 3, 1).reshape(n, -1)
+    mu = flat @ tp['Encoder/dense/kernel'] + tp['Encoder/dense/bias']
+    ls = flat @ tp['Encoder/dense_1/kernel'] + tp['Encoder/dense_1/bias']
+    if drop:
+        mu = mu * torch.tensor(mm); ls = ls * torch.tensor(ms)
+    sg = torch.exp(ls)
+    z = mu + torch.tensor(eps) * sg
+    dv = z @ tp['Generator/dense/kernel'] + tp['Generator/dense/bias']
+    g = dv.reshape(n, inter, inter, -1).permute(0, 3, 1, 2)
+    g = torch_ref._conv_same(g, tp['Generator/conv2d_1/kernel'], tp['Generator/conv2d_1/bias'], 1)
+    g = F.relu(torch_ref._ln_hw(g, tp[ln_g[0] + '/gamma'], tp[ln_g[0] + '/beta']))
+    for i in range(m.npool):
+        g = torch_ref._convT_same(g, tp['Generator/dec_Conv2DT_%d/kernel' % i], tp['Generator/dec_Conv2DT_%d/bias' % i], 2)
+        g = F.leaky_relu(torch_ref._ln_hw(g, tp[ln_g[i + 1] + '/gamma'], tp[ln_g[i + 1] + '/beta']), 0.3)
+    out = torch_ref._conv_same(g, tp['Generator/dec_Conv2D_final/kernel'], tp['Generator/dec_Conv2D_final/bias'], 1)
+
+    def critic(v):
+        for i in range(m.npool):
+            v = torch_ref._conv_same(v, tp['Discriminator/enc_conv2D_%d/kernel' % i], tp['Discriminator/enc_conv2D_%d/bias' % i], 2)
+            v = F.leaky_relu(torch_ref._ln_hw(v, tp[ln_d[i] + '/gamma'], tp[ln_d[i] + '/beta']), 0.3)
+        return v.permute(0, 2, 3, 1) @ tp['Discriminator/dense/kernel'] + tp['Discriminator/dense/bias']
+
+    d_fake, d_real = critic(out), critic(xt)
+    x_hat = xt + torch.tensor(alpha).view(n, 1, 1, 1) * (out - xt)
+    ddx = torch.autograd.grad(critic(x_hat).sum(), x_hat, create_graph=True)[0].permute(0, 2, 3, 1)
+    pen = ((torch.sqrt((ddx ** 2).sum(dim=1)) - 1.0) ** 2).mean() * m.scale
+    disc_loss = d_fake.mean() - d_real.mean() + pen
+    gen_loss = -d_fake.mean()
+    rec = (xt - out).abs().sum(dim=(1, 2, 3)).mean()
+    kl = (0.5 * (mu ** 2 + sg ** 2 - torch.log(sg ** 2) - 1).sum(dim=1)).mean()
+    enc_loss = rec + m.kl_weight * kl
+    groups = {gname: [k for k, _, _ in m.spec if ofa.group_of(k) == gname] for gname in ('Encoder', 'Generator', 'Discriminator')}
+
+    def tgrads(loss, names):
+        gs = torch.autograd.grad(loss, [tp[k] for k in names], retain_graph=True, allow_unused=True)
+        return {k: (np.zeros(p[k].shape) if gg is None else gg.numpy()) for k, gg in zip(names, gs)}
+
+    def check(mine, ref, tag):
+        gmax = max(np.abs(v).max() for v in ref.values())
+        for k, r in ref.items():
+            a_ = np.asarray(mine.get(k, np.zeros(p[k].shape))).reshape(p[k].shape)
+            np.testing.assert_allclose(a_, r, rtol=2e-7, atol=1e-9 * gmax + 1e-8 * np.abs(r).max(), err_msg=tag + ':' + k)
+
+    lsd, gr = m.vae_phase(p, x, eps, mm, ms)
+    for k, v in (('reconstructionLoss', rec), ('kl', kl), ('enc_loss', enc_loss)):
+        np.testing.assert_allclose(lsd[k], v.item(), rtol=1e-10, err_msg=k)
+    np.testing.assert_allclose(lsd['reconstruction'], out.permute(0, 2, 3, 1).detach().numpy(), rtol=1e-9, atol=1e-12)
+    check(gr, tgrads(enc_loss, groups['Encoder'] + groups['Generator']), 'vae')
+    assert not any(k.startswith('Discriminator') for k in gr)
+    lsd, gr = m.gen_phase(p, x, eps, mm, ms)
+    np.testing.assert_allclose(lsd['gen_loss'], gen_loss.item(), rtol=1e-10)
+    check(gr, tgrads(gen_loss, groups['Generator']), 'gen')
+    assert all(k.startswith('Generator') for k in gr)
+    lsd, gr = m.disc_phase(p, x, eps, alpha, mm, ms)
+    for k, v in (('disc_fake', d_fake.mean()), ('disc_real', d_real.mean()), ('penalty', pen), ('disc_loss', disc_loss)):
+        np.testing.assert_allclose(lsd[k], v.item(), rtol=1e-9, err_msg=k)
+    check(gr, tgrads(disc_loss, groups['Discriminator']), 'disc')
