@@ -283,10 +283,11 @@ def bench_fanogan(args):
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    hh, bs, zd = args.size or 64, BATCH, 128
+    hh, bs, zd = args.size or (128 if args.variant == 'anovaegan' else 64), BATCH, 128
     eng = GanEngine(hh, hh, 1, hh // 8 if args.variant == 'resnet' else 8, zd, max_batch=bs, device=f'cuda:{local_rank}', math=args.math,
                     variant=args.variant)
-    graph = 'models/fanogan_schlegl.py (ResNet generator / critic, dim 64)' if args.variant == 'resnet' else 'models/fanogan.py (unified graph)'
+    graph = {'resnet': 'models/fanogan_schlegl.py (ResNet generator / critic, dim 64)', 'unified': 'models/fanogan.py (unified graph)',
+             'anovaegan': 'models/anovaegan.py (AnoVAE-GAN on the unified blocks)'}[args.variant]
     rng = np.random.default_rng(3)
     flat = np.zeros(eng.nparams, np.float32)
     for name, shape, off in eng.spec:
@@ -306,13 +307,23 @@ def bench_fanogan(args):
     al = [torch.rand(bs, device='cuda', generator=g) for _ in range(5)]
     lr = 1e-4
 
+    av = args.variant == 'anovaegan'
+
     def wgan_step():
+        if av:      # trainers/AnoVAEGAN.py:97-150: VAE step, generator step, 5 critic steps
+            dp.train_phase('Encoder', lr, x=x, eps=zs[0], want_images=False)
+            dp.train_phase('Generator', lr, x=x, eps=zs[0], want_images=False)
+            for k in range(5):
+                out = dp.train_phase('Discriminator', lr, x=x, eps=zs[k + 1], alpha=al[k], want_images=False)
+            return out
         dp.train_phase('Generator', lr, z=zs[0], want_images=False)
         for k in range(5):
             out = dp.train_phase('Discriminator', lr, x=x, z=zs[k + 1], alpha=al[k], want_images=False)
         return out
 
     def enc_step():
+        if av:
+            return dp.train_phase('Encoder', lr, x=x, eps=zs[0], want_images=False)
         return dp.train_phase('Encoder', lr, x=x, want_images=False)
 
     def timed(fn, steps, warmup):
@@ -342,20 +353,23 @@ def bench_fanogan(args):
     assert bool(torch.isfinite(out_e['enc_loss']))
     if rank == 0:
         value = bs * world * args.steps / dt
-        res = {'metric': f'MRI slices/sec f-AnoGAN ({args.variant}) WGAN-GP batch iteration (1 G + 5 D steps, {hh}x{hh}, bs={bs}/GPU)',
+        name = 'AnoVAE-GAN batch iteration (1 VAE + 1 G + 5 D steps' if av else f'f-AnoGAN ({args.variant}) WGAN-GP batch iteration (1 G + 5 D steps'
+        res = {'metric': f'MRI slices/sec {name}, {hh}x{hh}, bs={bs}/GPU)',
                'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                # the ResNet graph's k3 / k1 contractions run on the generic kernels: fp32 MFMA unless --math bf16x3_all (not parity-rated)
                'dtype': ('f32' if args.math != 'bf16x3_all' else 'bf16x3_all') if args.variant == 'resnet' else args.math,
                'data': 'synthetic',
                'config': {'workload': f'BASELINE.json configs[3]: f-AnoGAN {graph} {hh}x{hh}x1, zDim {zd}, '
-                                      f'{bs} slices per GPU; step = 1 generator + 5 critic phases with Adam (trainers/fAnoGAN.py:97-130)',
+                                      f'{bs} slices per GPU; step = ' + ('1 VAE + 1 generator + 5 critic phases with Adam (trainers/AnoVAEGAN.py:97-150)' if av else '1 generator + 5 critic phases with Adam (trainers/fAnoGAN.py:97-130)'),
                           'encoder_stage_ms_per_step': round(dt_e / args.steps * 1e3, 3),
                           'encoder_stage_slices_per_s': round(bs * world * args.steps / dt_e, 2), 'parallelism': f'dp{world}'}}
-        e_m, g_m, d_m = gan_macs(args.variant, hh, zd)
+        e_m, g_m, d_m = gan_macs('unified' if av else args.variant, hh, zd)
         # per WGAN iteration and sample: G step = G fwd + bwd (3 passes) + critic fwd + data gradient; each of the 5 critic steps =
         # G fwd + critic fwd of 3 samples, input gradient, its adjoint, data gradient of 3 and filter gradients of 4 sample-slots
         macs = (3 * g_m + 2 * d_m) + 5 * (g_m + 12 * d_m)
+        if av:       # the encoder runs in front of every generator pass; plus the VAE step (E and G forward + backward)
+            macs += 7 * e_m + 3 * (e_m + g_m)
         tfl = 2.0 * macs * value / 1e12
         peak = 157.3 if (args.variant == 'resnet' and args.math != 'bf16x3_all') else 2500.0 / 3.0
         res['roofline'] = {'bound': 'mfma', 'kernel': 'whole WGAN-GP iteration (this handle has no per-kernel event profiler; per-kernel '
@@ -363,7 +377,7 @@ def bench_fanogan(args):
                            'unit': 'TFLOP/s', 'frac': round(tfl / peak, 4), 'traffic': None,
                            'note': 'algorithmic FLOP of the iteration / wall time; peak = fp32 MFMA (ResNet graph: generic fp32 kernels) or the '
                                    'bf16 matrix peak / 3 products per fp32 product (bf16x3 kernels)'}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not av:
             res['cpu_baseline'] = gan_cpu_baseline(args.variant, hh, zd)
         print(json.dumps(res))
     if world > 1:
@@ -384,7 +398,7 @@ def main():
                     help='VAE = the headline workload (BASELINE.json configs[1]); ceVAE = configs[3] (16 slices per GPU: both '
                          'branches + the input-gradient anomaly map every step), reported for the record')
     ap.add_argument('--size', type=int, default=0, help='fAnoGAN: slice edge (default 64)')
-    ap.add_argument('--variant', default='resnet', choices=['resnet', 'unified'],
+    ap.add_argument('--variant', default='resnet', choices=['resnet', 'unified', 'anovaegan'],
                     help='fAnoGAN graph: resnet = models/fanogan_schlegl.py (the one BASELINE.json configs[3] names), unified = models/fanogan.py')
     ap.add_argument('--batch', type=int, default=0, help='slices per GPU (default 64 for VAE, 16 for ceVAE)')
     args = ap.parse_args()

@@ -200,10 +200,18 @@ int uad_gather_mask(const unsigned char* labels, const int* idx, int n, long lon
  * the gradient of that loss w.r.t. the phase's variable group into the gradient buffer; uad_gan_adam then applies
  * TF-Adam to that group only (each group keeps its own step counter).  All calls are asynchronous on `stream`. */
 enum { UAD_GAN_ENCODER = 0, UAD_GAN_GENERATOR = 1, UAD_GAN_DISCRIMINATOR = 2 };
-enum { UAD_GAN_UNIFIED = 0, UAD_GAN_RESNET = 1 };
+enum { UAD_GAN_UNIFIED = 0, UAD_GAN_RESNET = 1,
+       UAD_GAN_ANOVAEGAN = 2 };   /* models/anovaegan.py:10-80 + trainers/AnoVAEGAN.py:45-86 on the unified blocks: the encoder ends in mu /
+                                     log-sigma heads (io.mask_z / io.mask_sigma, io.eps), the generator decodes z_vae with a linear output and
+                                     the critic judges the reconstruction.  Phases: UAD_GAN_ENCODER = optim_vae (reconstructionLoss +
+                                     kl_weight * kl over Encoder + Generator variables; uad_gan_adam(UAD_GAN_ENCODER) steps both, the
+                                     Generator with its own second pair of slots, UAD_BUF_ADAM_M2 / _V2), UAD_GAN_GENERATOR = optim_gen,
+                                     UAD_GAN_DISCRIMINATOR = optim_dis; io.z is unused */
+enum { UAD_GAN_GROUP_VAE = 3 };   /* uad_gan_group only: the contiguous Encoder + Generator slice (AnoVAE-GAN's optim_vae) */
+enum { UAD_BUF_ADAM_M2 = 4, UAD_BUF_ADAM_V2 = 5 };
 /* scalars[16] written by uad_gan_phase (entries a phase does not compute are left untouched) */
 enum { UAD_GAN_S_GEN_LOSS = 0, UAD_GAN_S_DISC_FAKE = 1, UAD_GAN_S_DISC_REAL = 2, UAD_GAN_S_PENALTY = 3, UAD_GAN_S_DISC_LOSS = 4,
-       UAD_GAN_S_LOSS_IMG = 5, UAD_GAN_S_LOSS_FTS = 6, UAD_GAN_S_ENC_LOSS = 7, UAD_GAN_S_REC_LOSS = 8 };
+       UAD_GAN_S_LOSS_IMG = 5, UAD_GAN_S_LOSS_FTS = 6, UAD_GAN_S_ENC_LOSS = 7, UAD_GAN_S_REC_LOSS = 8, UAD_GAN_S_KL = 9 };
 typedef struct uad_gan uad_gan_t;
 typedef struct {
     int height, width, channels;   /* square power-of-two slices, 1 channel */
@@ -215,6 +223,7 @@ typedef struct {
                                       (pre-activation residual blocks, k3 convolutions, avg-pool / k1 s2 shortcuts, tanh output;
                                       height must be 8 * inter_res; no dropout in that graph: mask_z / mask_g are ignored) */
     int dim;                       /* RESNET only: base width (fanogan_schlegl.py:13: 64); 0 = 64 */
+    float kl_weight;               /* ANOVAEGAN only: AnoVAEGAN.Config.kl_weight (:17) */
 } uad_gan_config_t;
 typedef struct {
     const float* x;                /* [n,H,W,1] batch (critic and encoder phases, reconstruct) */
@@ -227,6 +236,8 @@ typedef struct {
     float* z_enc;                  /* optional out [n,zDim] */
     float* l1_map;                 /* optional out [n,H,W,1]: |x - x_enc| (losses['L1']) */
     float* scalars;                /* optional out [16], UAD_GAN_S_* */
+    const float* eps;              /* ANOVAEGAN: [n,zDim] N(0,1) reparameterisation noise (NULL = 0) */
+    const float* mask_sigma;       /* ANOVAEGAN: optional keep mask of the log-sigma head (mask_z is the mu head's) */
 } uad_gan_io_t;
 int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out);
 int uad_gan_destroy(uad_gan_t* g);

@@ -32,7 +32,7 @@ def _flips(eng, m, caches):
             cnt(f'ea{i + 1}', caches['enc']['a'][i + 1])
     for i in range(m.npool + 1):
         cnt(f'ga{i}', caches['gen']['a'][i])
-    for i in range(m.npool):
+    for i in range(m.npool if caches['disc'] else 0):
         cnt(f'Da{i + 1}', np.concatenate([c['a'][i + 1] for c in caches['disc']]))
     return total
 
@@ -259,3 +259,81 @@ def test_resnet_bf16x3_all_mode_is_close_but_not_parity_rated():
     for k in ('disc_fake', 'disc_real', 'penalty', 'disc_loss'):
         assert abs(out[k].item() - ls[k]) < 2e-3 * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
     _check_grads(eng, m, g, 'Discriminator', 'disc', TOL_KINK)
+
+
+# ------------------------------------------------------------------ AnoVAE-GAN (models/anovaegan.py, trainers/AnoVAEGAN.py)
+def _setup_av(h, zdim, n, seed=0, drop=False):
+    m = ofa.AnoVAEGAN(h, 8, zdim, scale=10.0, kl_weight=0.8)
+    p = ovae.init_params(m.spec, seed=41 + seed, dtype=np.float64, perturb=True)
+    rng = np.random.default_rng(290 + seed)
+    x = ovae.synthetic_slices(n, h, h, seed=seed, dtype=np.float64)
+    eps = rng.standard_normal((n, zdim)); alpha = rng.uniform(0, 1, (n, 1))
+    mm = (rng.random((n, zdim)) > 0.2) / 0.8 if drop else None
+    ms = (rng.random((n, zdim)) > 0.2) / 0.8 if drop else None
+    return m, p, x, eps, alpha, mm, ms
+
+
+def _engine_av(m, p, n, math):
+    from unsupervised_anomaly_detection_brain_mri_amd.gan_engine import GanEngine
+    eng = GanEngine(m.height, m.height, 1, 8, m.zdim, max_batch=n, scale=m.scale, math=math, variant='anovaegan', kl_weight=m.kl_weight)
+    assert [(k, tuple(s)) for k, s, _ in eng.spec] == [(k, tuple(s)) for k, s, _ in m.spec]
+    eng.set_params(p)
+    return eng
+
+
+AV_CASES = [(32, 16, 2, 'f32', True), (64, 16, 3, 'bf16x3', False), (128, 128, 2, 'bf16x3', True)]
+
+
+@pytest.mark.parametrize('h,zdim,n,math,drop', AV_CASES)
+def test_anovaegan_phases(h, zdim, n, math, drop):
+    m, p, x, eps, alpha, mm, ms = _setup_av(h, zdim, n, drop=drop)
+    eng = _engine_av(m, p, n, math)
+    # VAE phase: Encoder + Generator gradients
+    out = eng.phase('Encoder', x=x, eps=eps, mask_z=mm, mask_sigma=ms, want_l1=True)
+    caches = {}
+    ls, g = m.vae_phase(p, x, eps, mm, ms, caches)
+    for k in ('reconstructionLoss', 'kl', 'enc_loss'):
+        assert abs(out[k].item() - ls[k]) < TOL * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
+    assert _rel(out['reconstruction'].cpu().numpy(), ls['reconstruction']) < TOL
+    assert _rel(out['L1'].cpu().numpy(), ls['L1']) < TOL
+    tol = TOL if _flips(eng, m, caches) == 0 else TOL_KINK
+    _check_grads(eng, m, g, 'Encoder', 'vae', tol)
+    _check_grads(eng, m, g, 'Generator', 'vae', tol)
+    # generator phase
+    out = eng.phase('Generator', x=x, eps=eps, mask_z=mm, mask_sigma=ms)
+    caches = {}
+    ls, g = m.gen_phase(p, x, eps, mm, ms, caches)
+    assert abs(out['gen_loss'].item() - ls['gen_loss']) < TOL * max(1.0, abs(ls['gen_loss']))
+    assert _rel(out['reconstruction'].cpu().numpy(), ls['reconstruction']) < TOL
+    _check_grads(eng, m, g, 'Generator', 'gen', TOL if _flips(eng, m, caches) == 0 else TOL_KINK)
+    # critic phase
+    out = eng.phase('Discriminator', x=x, eps=eps, alpha=alpha, mask_z=mm, mask_sigma=ms)
+    caches = {}
+    ls, g = m.disc_phase(p, x, eps, alpha, mm, ms, caches)
+    for k in ('disc_fake', 'disc_real', 'penalty', 'disc_loss'):
+        assert abs(out[k].item() - ls[k]) < TOL * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
+    _check_grads(eng, m, g, 'Discriminator', 'disc', TOL if _flips(eng, m, caches) == 0 else TOL_KINK)
+    assert _rel(eng.reconstruct(x, eps=eps)['reconstruction'].cpu().numpy(), m.reconstruct(p, x, eps)) < TOL
+
+
+def test_anovaegan_adam_slots():
+    """optim_vae steps Encoder AND Generator variables (its own Generator slots); optim_gen keeps separate Generator slots."""
+    from unsupervised_anomaly_detection_brain_mri_amd import _lib
+    m, p, x, eps, alpha, mm, ms = _setup_av(32, 16, 2, seed=5)
+    eng = _engine_av(m, p, 2, 'f32')
+    before = eng.get_params()
+    eng.phase('Encoder', x=x, eps=eps)
+    eng.adam('Encoder', 1e-3)
+    after = eng.get_params()
+    for k in after:
+        moved = not np.array_equal(before[k], after[k])
+        assert moved == (ofa.group_of(k) in ('Encoder', 'Generator')) or np.all(eng.get_grads()[k] == 0), k
+    assert eng.step_count('Encoder') == 1 and eng.step_count('Generator') == 0
+    m2 = eng.unflatten(eng.get_buffer_host(_lib.BUF_ADAM_M2)); m1 = eng.unflatten(eng.get_buffer_host(_lib.BUF_ADAM_M))
+    assert np.abs(m2['Generator/dense/kernel']).max() > 0 and np.abs(m1['Generator/dense/kernel']).max() == 0
+    assert np.abs(m1['Encoder/dense/kernel']).max() > 0
+    eng.phase('Generator', x=x, eps=eps)
+    eng.adam('Generator', 1e-3)
+    assert np.abs(eng.unflatten(eng.get_buffer_host(_lib.BUF_ADAM_M))['Generator/dense/kernel']).max() > 0 and eng.step_count('Generator') == 1
+    off, cnt = eng.group('VAE')
+    assert off == 0 and cnt == eng.group('Encoder')[1] + eng.group('Generator')[1]

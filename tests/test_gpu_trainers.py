@@ -281,3 +281,31 @@ def test_fanogan_schlegl_trainer(tmp_path):
     r = model.reconstruct(ds2.next_batch(1, set='VAL')[0][0])
     assert r['reconstruction'].shape == (1, 64, 64, 1) and -1.0 <= r['reconstruction'].min() and r['reconstruction'].max() <= 1.0
     model.engine.close()
+
+
+def test_anovaegan_trainer(tmp_path):
+    """trainers/AnoVAEGAN.py surface: Config defaults, one epoch (VAE + generator + 5 critic steps per batch, then VAL), fetch keys,
+    reconstruct(), checkpoint resume."""
+    from unsupervised_anomaly_detection_brain_mri_amd.models import anovaegan
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import AnoVAEGAN
+    d = AnoVAEGAN.Config()
+    assert (d.modelname, d.scale, d.kappa, d.kl_weight) == ('AnoVAEGAN', 10.0, 1.0, 1.0)
+    cfg, opt, ds = _config(AnoVAEGAN, tmp_path, h=64, bs=4, epochs=1)
+    model = AnoVAEGAN(None, cfg, network=anovaegan)
+    assert model.model_dir == 'AnoVAEGAN_dSyntheticDataset_s64x64_anovaegan_b4_z64_'
+    model.train(ds)
+    nb = ds.num_batches(4, set='TRAIN')
+    assert [model.engine.step_count(g) for g in ('Encoder', 'Generator', 'Discriminator')] == [nb, nb, 5 * nb]
+    assert {'TRAIN/gen_loss', 'TRAIN/disc_loss', 'TRAIN/reconstructionLoss', 'TRAIN/kl', 'VAL/reconstructionLoss'} <= set(model.curves)
+    run = model.step(ds.next_batch(4, set='VAL')[0], Phase.VAL)
+    assert set(run) == {'reconstructionLoss', 'kl', 'enc_loss', 'loss', 'reconstruction', 'L1'}
+    assert run['enc_loss'] == pytest.approx(run['reconstructionLoss'] + run['kl'], rel=1e-5)
+    r = model.reconstruct(ds.next_batch(1, set='VAL')[0][0], eps=0.0)
+    assert r['reconstruction'].shape == (1, 64, 64, 1) and np.isfinite(r['l1err'])
+    w = model.engine.get_buffer_host(_lib.BUF_PARAMS)
+    model.engine.close()
+    cfg2, _, _ = _config(AnoVAEGAN, tmp_path, h=64, bs=4, epochs=1)
+    m2 = AnoVAEGAN(None, cfg2, network=anovaegan, seed=9)
+    assert m2.load_checkpoint() == 1 and np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w)
+    assert [m2.engine.step_count(g) for g in ('Encoder', 'Generator', 'Discriminator')] == [nb, nb, 5 * nb]
+    m2.engine.close()

@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) gfinal_bwd_kernel(const float* __restrict
     float sb = 0.f;
     for (int row = row0 + rl; row < row1; row += RL) {
         const float xv = x[row];
-        const float dv = dx[row] * (tanh_act ? (1.0f - xv * xv) : xv * (1.0f - xv));
+        const float dv = dx[row] * (tanh_act == 2 ? 1.0f : (tanh_act ? (1.0f - xv * xv) : xv * (1.0f - xv)));   // 0 sigmoid, 1 tanh, 2 linear
         *reinterpret_cast<float4*>(da + (size_t)row * C + ch) = w * dv;
         if (partial) { s = s + *reinterpret_cast<const float4*>(a + (size_t)row * C + ch) * dv; sb += dv; }
     }
@@ -356,6 +356,14 @@ __global__ void __launch_bounds__(256) diff_scale_kernel(const float* __restrict
                                                          size_t n, float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = (ACC ? out[i] : 0.f) + coef * (a[i] - b[i]);
+}
+// d (mean_n sum |a - b|) / d a = sign(a - b) * coef
+__global__ void __launch_bounds__(256) sign_scale_kernel(const float* __restrict__ a, const float* __restrict__ b, float coef, size_t n,
+                                                         float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float d = a[i] - b[i];
+    out[i] = d > 0.f ? coef : (d < 0.f ? -coef : 0.f);
 }
 __device__ __forceinline__ float block_sum(float v, float* red) {
 #pragma unroll
@@ -443,6 +451,8 @@ __global__ void combine_kernel(int phase, const float* __restrict__ raw, float k
     } else if (phase == UAD_GAN_DISCRIMINATOR) {
         out[UAD_GAN_S_DISC_FAKE] = raw[0]; out[UAD_GAN_S_DISC_REAL] = raw[1]; out[UAD_GAN_S_PENALTY] = raw[2];
         out[UAD_GAN_S_DISC_LOSS] = raw[0] - raw[1] + raw[2]; out[UAD_GAN_S_GEN_LOSS] = -raw[0];
+    } else if (phase == 3) {      // AnoVAE-GAN's VAE phase: raw = {reconstructionLoss, kl}, kappa = kl_weight
+        out[UAD_GAN_S_REC_LOSS] = raw[0]; out[UAD_GAN_S_KL] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
     } else {
         out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
         out[UAD_GAN_S_REC_LOSS] = raw[2];
@@ -472,12 +482,15 @@ struct uad_gan {
     long long nparams;
     long long grp_off[3], grp_cnt[3], step[3];
     float *params, *grads, *adam_m, *adam_v;
+    float *adam_m2, *adam_v2;          // AnoVAE-GAN: the Generator's slots inside optim_vae (its optim_gen slots are adam_m / adam_v)
     float *wpack_f, *wpack_d, *wpack16_f, *wpack16_d;
     int math;
     bool packed_valid;
     UadGemmWs ws;
     std::vector<Block> E, G, D;
     long long e_cw, e_cb, e_dw, e_db;                   // Encoder/conv2d, Encoder/dense
+    long long e_sw, e_sb;                               // AnoVAE-GAN: Encoder/dense_1 (log-sigma head; Encoder/dense is mu)
+    float *v_mu_raw, *v_ls_raw, *v_mu, *v_ls, *v_sigma, *v_kl, *v_dmu, *v_dls, *v_dflat2;
     long long g_dw, g_db, g_cw, g_cb, g_ln0g, g_ln0b;   // Generator/dense, conv2d_1, first LayerNorm
     long long g_fw, g_fb;                               // dec_Conv2D_final
     long long d_hw, d_hb;                               // Discriminator/dense
@@ -685,6 +698,44 @@ void enc_backward(uad_gan* m, const float* x, const float* mask_z, int n, hipStr
     }
 }
 
+// AnoVAE-GAN encoder (models/anovaegan.py:14-35): mu / log-sigma heads with their own dropout masks, z = mu + eps * exp(log_sigma)
+void v_enc_forward(uad_gan* m, const uad_gan_io_t* io, int n, hipStream_t st) {
+    const int r = m->cfg.inter_res, zd = m->cfg.zdim;
+    const float* in = io->x;
+    for (size_t i = 0; i < m->E.size(); ++i) {
+        conv_fwd(m, m->E[i], n, in, m->ec[i], true, st);
+        bn_act_fwd(m, m->E[i], m->ec[i], n, m->ea[i + 1], st);
+        in = m->ea[i + 1];
+    }
+    uad_launch_conv_f(conv1x1_desc(n, r, r, m->cenc, m->cmid), in, no_xform(), P(m, m->e_cw), m->et, epi_bias(P(m, m->e_cb)), st, nullptr, m->ws);
+    const UadConvDesc dd = dense_desc(n, m->flat, zd);
+    uad_launch_conv_f(dd, m->et, no_xform(), P(m, m->e_dw), m->v_mu_raw, epi_bias(P(m, m->e_db)), st, nullptr, m->ws);
+    uad_launch_conv_f(dd, m->et, no_xform(), P(m, m->e_sw), m->v_ls_raw, epi_bias(P(m, m->e_sb)), st, nullptr, m->ws);
+    uad_launch_reparam_fwd(n, n, zd, m->v_mu_raw, m->v_ls_raw, io->mask_z, io->mask_sigma, nullptr, io->eps, m->v_mu, m->v_ls, m->v_sigma,
+                           m->z, m->v_kl, st);
+}
+// dz in m->dzbuf; klw = kl_weight / n; writes every Encoder gradient
+void v_enc_backward(uad_gan* m, const uad_gan_io_t* io, int n, float klw, hipStream_t st) {
+    const int r = m->cfg.inter_res, zd = m->cfg.zdim;
+    uad_launch_reparam_bwd(n, n, zd, m->dzbuf, m->v_mu, m->v_sigma, io->eps, io->mask_z, io->mask_sigma, nullptr, klw, m->v_dmu, m->v_dls, st);
+    const UadConvDesc dd = dense_desc(n, m->flat, zd), dc1 = conv1x1_desc(n, r, r, m->cenc, m->cmid);
+    uad_launch_conv_w(dd, m->et, no_xform(), m->v_dmu, no_xform(), Gr(m, m->e_dw), m->wpartial, st);
+    uad_launch_colsum(m->v_dmu, n, zd, Gr(m, m->e_db), m->colscratch, st);
+    uad_launch_conv_w(dd, m->et, no_xform(), m->v_dls, no_xform(), Gr(m, m->e_sw), m->wpartial, st);
+    uad_launch_colsum(m->v_dls, n, zd, Gr(m, m->e_sb), m->colscratch, st);
+    uad_launch_conv_d(dd, m->v_dmu, no_xform(), P(m, m->e_dw), m->v_dflat2, epi_bias(nullptr), st, nullptr, m->ws);
+    uad_launch_conv_d(dd, m->v_dls, no_xform(), P(m, m->e_sw), m->dflat, epi_bias(nullptr, nullptr, m->v_dflat2), st, nullptr, m->ws);
+    uad_launch_conv_w(dc1, m->ea[m->E.size()], no_xform(), m->dflat, no_xform(), Gr(m, m->e_cw), m->wpartial, st);
+    uad_launch_colsum(m->dflat, n * r * r, m->cmid, Gr(m, m->e_cb), m->colscratch, st);
+    float* g = m->Ga; float* gn = m->Gb;
+    uad_launch_conv_d(dc1, m->dflat, no_xform(), P(m, m->e_cw), g, epi_bias(nullptr), st, nullptr, m->ws);
+    for (int i = (int)m->E.size() - 1; i >= 0; --i) {
+        bn_act_bwd(m, m->E[i], g, m->ec[i], n, gn, st);
+        conv_wgrad(m, m->E[i], n, i == 0 ? io->x : m->ea[i], gn, st);
+        if (i > 0) conv_dgrad(m, m->E[i], n, gn, g, st);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Generator
 void gen_forward(uad_gan* m, const float* z, const float* mask_g, int n, hipStream_t st) {
     const int r = m->cfg.inter_res;
@@ -698,7 +749,8 @@ void gen_forward(uad_gan* m, const float* z, const float* mask_g, int n, hipStre
     }
     const Block& LL = m->G.back();
     const int rows = n * LL.H * LL.W;
-    rowdot<1>(m->ga[m->G.size()], P(m, m->g_fw), P(m, m->g_fb), rows, LL.C, m->xg, st);
+    if (m->variant == UAD_GAN_ANOVAEGAN) rowdot<0>(m->ga[m->G.size()], P(m, m->g_fw), P(m, m->g_fb), rows, LL.C, m->xg, st);   // linear output
+    else rowdot<1>(m->ga[m->G.size()], P(m, m->g_fw), P(m, m->g_fb), rows, LL.C, m->xg, st);
 }
 // dx = d loss / d generator output (post-sigmoid); pg: Generator parameter gradients; dz_out: optional d loss / d z
 void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* dx, int n, bool pg, float* dz_out, hipStream_t st) {
@@ -709,7 +761,7 @@ void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* 
     {
         const int rpb = (rows + 1023) / 1024, blocks = (rows + rpb - 1) / rpb;
         hipLaunchKernelGGL(gfinal_bwd_kernel, dim3(blocks), dim3(256), 0, st, dx, m->xg, m->ga[m->G.size()], P(m, m->g_fw), rows, rpb,
-                           LL.C, 0, g, pg ? m->finpart : nullptr);
+                           LL.C, m->variant == UAD_GAN_ANOVAEGAN ? 2 : 0, g, pg ? m->finpart : nullptr);
         if (pg) {
             uad_launch_reduce_partials(m->finpart, blocks, LL.C + 1, 1.0f, m->colscratch, st);
             hipMemcpyAsync(Gr(m, m->g_fw), m->colscratch, LL.C * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1004,7 +1056,7 @@ static int create_resnet(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (dim % 32 || dim > 64) return fail(UAD_ERR_UNSUPPORTED, "ResNet f-AnoGAN: dim must be 32 or 64");
     if (ir < 2) return fail(UAD_ERR_UNSUPPORTED, "inter_res >= 2 needed");
     uad_gan* m = new uad_gan();
-    m->cfg = *cfg; m->variant = 1; m->dim = dim; m->generic16 = false;
+    m->cfg = *cfg; m->variant = 1; m->dim = dim; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1;
     m->npool = 3; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
     m->step[0] = m->step[1] = m->step[2] = 0;
     char nm[160];
@@ -1189,14 +1241,15 @@ int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
     if (cfg->zdim <= 0 || cfg->zdim % 8) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
     if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
-    if (cfg->variant != UAD_GAN_UNIFIED && cfg->variant != UAD_GAN_RESNET) return fail(UAD_ERR_INVALID, "bad variant");
+    if (cfg->variant != UAD_GAN_UNIFIED && cfg->variant != UAD_GAN_RESNET && cfg->variant != UAD_GAN_ANOVAEGAN) return fail(UAD_ERR_INVALID, "bad variant");
     if (cfg->variant == UAD_GAN_RESNET) return create_resnet(cfg, out);
     const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
     if (npool < 2 || npool > 5) return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 2..5 blocks supported", npool);
     if (H < 32) return fail(UAD_ERR_UNSUPPORTED, "height >= 32 needed");
 
     uad_gan* m = new uad_gan();
-    m->cfg = *cfg; m->variant = 0; m->dim = 0; m->generic16 = false;
+    m->cfg = *cfg; m->variant = cfg->variant; m->dim = 0; m->generic16 = false;
+    const bool av = cfg->variant == UAD_GAN_ANOVAEGAN;
     m->npool = npool; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
     m->step[0] = m->step[1] = m->step[2] = 0;
     const int ir = cfg->inter_res;
@@ -1221,6 +1274,11 @@ int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     m->e_cb = add_tensor(m, "Encoder/conv2d/bias", 1, m->cmid, 1, 1, 1);
     m->e_dw = add_tensor(m, "Encoder/dense/kernel", 2, m->flat, cfg->zdim, 1, 1);
     m->e_db = add_tensor(m, "Encoder/dense/bias", 1, cfg->zdim, 1, 1, 1);
+    m->e_sw = m->e_sb = -1;
+    if (av) {
+        m->e_sw = add_tensor(m, "Encoder/dense_1/kernel", 2, m->flat, cfg->zdim, 1, 1);
+        m->e_sb = add_tensor(m, "Encoder/dense_1/bias", 1, cfg->zdim, 1, 1, 1);
+    }
     m->grp_off[UAD_GAN_ENCODER] = 0; m->grp_cnt[UAD_GAN_ENCODER] = m->nparams;
     m->g_dw = add_tensor(m, "Generator/dense/kernel", 2, cfg->zdim, m->flat, 1, 1);
     m->g_db = add_tensor(m, "Generator/dense/bias", 1, m->flat, 1, 1, 1);
@@ -1287,6 +1345,14 @@ int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     }
     ALLOC(m->et, NB * m->flat, "et"); ALLOC(m->zr, NB * cfg->zdim, "zr"); ALLOC(m->z, NB * cfg->zdim, "z");
     ALLOC(m->gdv, NB * m->flat, "gdv"); ALLOC(m->xg, NB * HW, "xg");
+    m->adam_m2 = m->adam_v2 = nullptr;
+    if (av) {
+        const size_t nz = NB * cfg->zdim;
+        ALLOC(m->adam_m2, (size_t)m->nparams, nullptr); ALLOC(m->adam_v2, (size_t)m->nparams, nullptr);
+        ALLOC(m->v_mu_raw, nz, nullptr); ALLOC(m->v_ls_raw, nz, nullptr); ALLOC(m->v_mu, nz, "v_mu"); ALLOC(m->v_ls, nz, nullptr);
+        ALLOC(m->v_sigma, nz, "v_sigma"); ALLOC(m->v_kl, NB, nullptr); ALLOC(m->v_dmu, nz, nullptr); ALLOC(m->v_dls, nz, nullptr);
+        ALLOC(m->v_dflat2, NB * m->flat, nullptr);
+    }
     m->gc.resize(npool + 1); m->ga.resize(npool + 1); m->gstat.resize(npool + 1);
     size_t lnp_g = 0;
     for (int i = 0; i <= npool; ++i) {
@@ -1377,10 +1443,17 @@ float* uad_gan_buffer(uad_gan_t* m, int which) {
         case UAD_BUF_GRADS: return m->grads;
         case UAD_BUF_ADAM_M: return m->adam_m;
         case UAD_BUF_ADAM_V: return m->adam_v;
+        case UAD_BUF_ADAM_M2: return m->adam_m2;
+        case UAD_BUF_ADAM_V2: return m->adam_v2;
     }
     return nullptr;
 }
 int uad_gan_group(const uad_gan_t* m, int group, long long* offset, long long* count) {
+    if (m && group == UAD_GAN_GROUP_VAE) {       // Encoder | Generator are adjacent in the flat buffers
+        if (offset) *offset = 0;
+        if (count) *count = m->grp_cnt[UAD_GAN_ENCODER] + m->grp_cnt[UAD_GAN_GENERATOR];
+        return UAD_OK;
+    }
     if (!m || group < 0 || group > 2) return fail(UAD_ERR_INVALID, "bad group");
     if (offset) *offset = m->grp_off[group];
     if (count) *count = m->grp_cnt[group];
@@ -1426,6 +1499,8 @@ int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int wa
     if (phase < 0 || phase > 2) return fail(UAD_ERR_INVALID, "bad phase");
     hipStream_t st = (hipStream_t)stream;
     const bool rn = m->variant == UAD_GAN_RESNET;
+    const bool av = m->variant == UAD_GAN_ANOVAEGAN;      // the generator's input is the encoder's z_vae, never io->z
+    if (av && !io->x) return fail(UAD_ERR_INVALID, "AnoVAE-GAN phases need io.x");
     const int H = m->cfg.height, ir = m->cfg.inter_res, L = m->npool;
     const size_t HW = (size_t)H * H, img = (size_t)n * HW;
     const int P2 = ir * ir;                        // feature-map locations per sample
@@ -1434,14 +1509,21 @@ int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int wa
     float* top = rn ? m->DB.back().DOUT : m->Ga;                           // d loss / d features
     float* scal = io->scalars ? io->scalars : m->scalars_own;
     refresh_packs(m, st);
-    auto gen_fwd = [&](const float* z) { if (rn) s_gen_forward(m, z, n, st); else gen_forward(m, z, io->mask_g, n, st); };
-    auto gen_bwd = [&](const float* z, bool pg, float* dz) { if (rn) s_gen_backward(m, z, m->dxbuf, n, pg, dz, st); else gen_backward(m, z, io->mask_g, m->dxbuf, n, pg, dz, st); };
+    auto gen_fwd = [&](const float* z) {
+        if (rn) s_gen_forward(m, z, n, st);
+        else if (av) { v_enc_forward(m, io, n, st); gen_forward(m, m->z, nullptr, n, st); }
+        else gen_forward(m, z, io->mask_g, n, st);
+    };
+    auto gen_bwd = [&](const float* z, bool pg, float* dz) {
+        if (rn) s_gen_backward(m, z, m->dxbuf, n, pg, dz, st);
+        else gen_backward(m, av ? m->z : z, av ? nullptr : io->mask_g, m->dxbuf, n, pg, dz, st);
+    };
     auto disc_fwd = [&](int N, bool head) { if (rn) s_disc_forward(m, N, head, st); else disc_forward(m, N, head, st); };
     auto disc_bwd = [&](int N, bool pg, int ntail, int inj_lo, float* dx) { if (rn) s_disc_backward(m, N, pg, ntail, inj_lo, dx, st); else disc_backward(m, N, pg, ntail, inj_lo, dx, st); };
 
     if (phase == UAD_GAN_GENERATOR) {
         // trainers/fAnoGAN.py:52,75: gen_loss = -mean(D(G(z))), gradient w.r.t. the Generator variables
-        if (!io->z) return fail(UAD_ERR_INVALID, "generator phase needs io.z");
+        if (!av && !io->z) return fail(UAD_ERR_INVALID, "generator phase needs io.z");
         gen_fwd(io->z);
         HIP_TRY(hipMemcpyAsync(m->din, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
         disc_fwd(n, true);
@@ -1457,7 +1539,7 @@ int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int wa
         if (io->generated) HIP_TRY(hipMemcpyAsync(io->generated, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else if (phase == UAD_GAN_DISCRIMINATOR) {
         // trainers/fAnoGAN.py:50-58,74
-        if (!io->z || !io->x || !io->alpha) return fail(UAD_ERR_INVALID, "critic phase needs io.x, io.z and io.alpha");
+        if ((!av && !io->z) || !io->x || !io->alpha) return fail(UAD_ERR_INVALID, "critic phase needs io.x, io.z and io.alpha");
         gen_fwd(io->z);
         hipLaunchKernelGGL(interp_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, io->alpha, (int)HW, img, m->din);
         disc_fwd(3 * n, true);                                                                    // pass A
@@ -1531,6 +1613,19 @@ int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int wa
             disc_bwd(3 * n, true, n, 2 * n, nullptr);
         }
         if (io->generated) HIP_TRY(hipMemcpyAsync(io->generated, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (av) {
+        // trainers/AnoVAEGAN.py:61-71,84: enc_loss = mean_n sum|x - out| + kl_weight * mean_n KL over Encoder + Generator variables
+        gen_fwd(nullptr);
+        reduce_to<2>(m, 0, io->x, m->xg, img, 1.0f / (float)n, io->l1_map, st);
+        reduce_to<0>(m, 1, m->v_kl, nullptr, (size_t)n, 1.0f / (float)n, nullptr, st);
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, 3, m->raw, m->cfg.kl_weight, scal);
+        if (want_backward) {
+            hipLaunchKernelGGL(sign_scale_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, 1.0f / (float)n, img, m->dxbuf);
+            gen_bwd(nullptr, true, m->dzbuf);
+            v_enc_backward(m, io, n, m->cfg.kl_weight / (float)n, st);
+        }
+        if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
         // trainers/fAnoGAN.py:60-66,76: enc_loss = MSE(x, x_enc) + kappa * MSE(features(x_enc), features(x)) w.r.t. the Encoder
         if (!io->x) return fail(UAD_ERR_INVALID, "encoder phase needs io.x");
@@ -1568,6 +1663,7 @@ int uad_gan_reconstruct(uad_gan_t* m, const uad_gan_io_t* io, int n, void* strea
     const size_t img = (size_t)n * m->cfg.height * m->cfg.width;
     refresh_packs(m, st);
     if (m->variant == UAD_GAN_RESNET) { s_enc_forward(m, io->x, n, st); s_gen_forward(m, m->z, n, st); }
+    else if (m->variant == UAD_GAN_ANOVAEGAN) { v_enc_forward(m, io, n, st); gen_forward(m, m->z, nullptr, n, st); }
     else { enc_forward(m, io->x, io->mask_z, n, st); gen_forward(m, m->z, io->mask_g, n, st); }
     if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1585,6 +1681,12 @@ int uad_gan_adam(uad_gan_t* m, int group, float lr, float beta1, float beta2, fl
     m->packed_valid = false;
     uad_launch_adam(m->params + off, m->grads + off, m->adam_m + off, m->adam_v + off, (size_t)m->grp_cnt[group], lr_t, beta1, beta2,
                     eps, grad_scale, (hipStream_t)stream);
+    if (m->variant == UAD_GAN_ANOVAEGAN && group == UAD_GAN_ENCODER) {
+        // optim_vae also owns the Generator variables (trainers/AnoVAEGAN.py:84), with slots of its own and the same step count
+        const long long go = m->grp_off[UAD_GAN_GENERATOR];
+        uad_launch_adam(m->params + go, m->grads + go, m->adam_m2 + go, m->adam_v2 + go, (size_t)m->grp_cnt[UAD_GAN_GENERATOR], lr_t, beta1,
+                        beta2, eps, grad_scale, (hipStream_t)stream);
+    }
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }

@@ -9,24 +9,25 @@ import torch
 from . import _lib
 from .engine import _DevArray, _EvalOps, _ptr
 
-GROUPS = {'Encoder': _lib.GAN_ENCODER, 'Generator': _lib.GAN_GENERATOR, 'Discriminator': _lib.GAN_DISCRIMINATOR}
+GROUPS = {'Encoder': _lib.GAN_ENCODER, 'Generator': _lib.GAN_GENERATOR, 'Discriminator': _lib.GAN_DISCRIMINATOR,
+          'VAE': _lib.GAN_GROUP_VAE}       # 'VAE': the Encoder + Generator slice (AnoVAE-GAN's optim_vae), buffers / all-reduce only
 
 
 class GanEngine(_EvalOps):
     def __init__(self, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, scale=10.0, kappa=1.0,
-                 device=None, math='bf16x3', variant='unified', dim=64):
+                 device=None, math='bf16x3', variant='unified', dim=64, kl_weight=1.0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         torch.cuda.set_device(self.device)
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
-        variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET}
+        variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET, 'anovaegan': _lib.GAN_ANOVAEGAN}
         if variant not in variants:
             raise ValueError(f'unknown f-AnoGAN variant {variant!r}')
         self.variant, self.dim = variant, int(dim)
         cfg = _lib.UadGanConfig(height, width, channels, inter_res, zdim, max_batch, float(scale), float(kappa), variants[variant],
-                                int(dim))
+                                int(dim), float(kl_weight))
         h = C.c_void_p()
         _lib.check(self.lib.uad_gan_create(C.byref(cfg), C.byref(h)))
         self.handle = h
@@ -103,7 +104,10 @@ class GanEngine(_EvalOps):
         zeros = np.zeros(self.nparams, np.float32)
         self.set_buffer_host(_lib.BUF_ADAM_M, zeros)
         self.set_buffer_host(_lib.BUF_ADAM_V, zeros)
-        for g in GROUPS:
+        if self.variant == 'anovaegan':
+            self.set_buffer_host(_lib.BUF_ADAM_M2, zeros)
+            self.set_buffer_host(_lib.BUF_ADAM_V2, zeros)
+        for g in ('Encoder', 'Generator', 'Discriminator'):
             self.set_step_count(g, 0)
 
     def step_count(self, group):
@@ -132,7 +136,7 @@ class GanEngine(_EvalOps):
 
     # ---------------------------------------------------------------- phases
     def phase(self, group, x=None, z=None, alpha=None, mask_z=None, mask_g=None, want_backward=True, want_images=True,
-              want_l1=False):
+              want_l1=False, eps=None, mask_sigma=None):
         """Run one phase ('Generator' | 'Discriminator' | 'Encoder').  Returns a dict of device tensors: the 0-d losses of the
         phase (trainers/fAnoGAN.py:50-66 names) and, per phase, 'generated' | 'reconstruction', 'z_enc', 'L1'."""
         g = GROUPS[group]
@@ -145,11 +149,21 @@ class GanEngine(_EvalOps):
             raise ValueError('the ResNet f-AnoGAN graph has no dropout layers (models/fanogan_schlegl.py): masks are not accepted')
         mask_z = self._dev(mask_z, (n, self.zdim))
         mask_g = self._dev(mask_g, (n, self.flat))
+        av = self.variant == 'anovaegan'        # AnoVAE-GAN: 'Encoder' = the VAE phase; eps / mask_z (mu head) / mask_sigma; no z, no mask_g
+        if not av and (eps is not None or mask_sigma is not None):
+            raise ValueError('eps / mask_sigma are AnoVAE-GAN inputs')
+        eps = self._dev(eps, (n, self.zdim))
+        mask_sigma = self._dev(mask_sigma, (n, self.zdim))
         out = {}
         scal = torch.zeros(16, device=self.device)
         io = _lib.UadGanIO()
         io.x, io.z, io.alpha, io.mask_z, io.mask_g = _ptr(x), _ptr(z), _ptr(alpha), _ptr(mask_z), _ptr(mask_g)
         io.scalars = _ptr(scal)
+        io.eps, io.mask_sigma = _ptr(eps), _ptr(mask_sigma)
+        if av and g != _lib.GAN_ENCODER and want_images:
+            out['reconstruction'] = torch.empty(img, device=self.device)     # the critic's "fake" is the reconstruction
+            io.generated = _ptr(out['reconstruction'])
+            want_images = False
         if g == _lib.GAN_ENCODER:
             if want_images:
                 out['reconstruction'] = torch.empty(img, device=self.device)
@@ -165,18 +179,18 @@ class GanEngine(_EvalOps):
         _lib.check(self.lib.uad_gan_phase(self.handle, g, C.byref(io), n, 1 if want_backward else 0, self._stream()))
         names = {_lib.GAN_GENERATOR: ('gen_loss', 'disc_fake'),
                  _lib.GAN_DISCRIMINATOR: ('gen_loss', 'disc_fake', 'disc_real', 'penalty', 'disc_loss'),
-                 _lib.GAN_ENCODER: ('loss_img', 'loss_fts', 'enc_loss', 'reconstructionLoss')}[g]
+                 _lib.GAN_ENCODER: ('reconstructionLoss', 'kl', 'enc_loss') if av else ('loss_img', 'loss_fts', 'enc_loss', 'reconstructionLoss')}[g]
         for k in names:
             out[k] = scal[_lib.GAN_SCALARS.index(k)]
         if g == _lib.GAN_ENCODER:
             out['loss'] = out['reconstructionLoss']
-        self._keep = (x, z, alpha, mask_z, mask_g, scal, out)
+        self._keep = (x, z, alpha, mask_z, mask_g, scal, out, eps, mask_sigma)
         return out
 
     def adam(self, group, lr, beta1=0.5, beta2=0.9, eps=1e-8, grad_scale=1.0):
         _lib.check(self.lib.uad_gan_adam(self.handle, GROUPS[group], lr, beta1, beta2, eps, grad_scale, self._stream()))
 
-    def reconstruct(self, x, mask_z=None, mask_g=None, want_l1=False):
+    def reconstruct(self, x, mask_z=None, mask_g=None, want_l1=False, eps=None, mask_sigma=None):
         n = x.shape[0]
         img = (n, self.h, self.w, self.c)
         x = self._dev(x, img)
@@ -185,10 +199,12 @@ class GanEngine(_EvalOps):
         out = {'reconstruction': torch.empty(img, device=self.device), 'z_enc': torch.empty((n, self.zdim), device=self.device)}
         io = _lib.UadGanIO()
         io.x, io.mask_z, io.mask_g = _ptr(x), _ptr(mask_z), _ptr(mask_g)
+        eps, mask_sigma = self._dev(eps, (n, self.zdim)), self._dev(mask_sigma, (n, self.zdim))
+        io.eps, io.mask_sigma = _ptr(eps), _ptr(mask_sigma)
         io.reconstruction, io.z_enc = _ptr(out['reconstruction']), _ptr(out['z_enc'])
         if want_l1:
             out['L1'] = torch.empty(img, device=self.device)
             io.l1_map = _ptr(out['L1'])
         _lib.check(self.lib.uad_gan_reconstruct(self.handle, C.byref(io), n, self._stream()))
-        self._keep = (x, mask_z, mask_g, out)
+        self._keep = (x, mask_z, mask_g, out, eps, mask_sigma)
         return out

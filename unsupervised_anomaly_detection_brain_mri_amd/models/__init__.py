@@ -8,3 +8,4 @@ from .gaussian_mixture_variational_autoencoder_spatial import gaussian_mixture_v
 from .fanogan import fanogan  # noqa: F401
 from .fanogan_schlegl import fanogan_schlegl  # noqa: F401
 from .autoencoder_spatial import autoencoder_spatial  # noqa: F401
+from .anovaegan import anovaegan  # noqa: F401

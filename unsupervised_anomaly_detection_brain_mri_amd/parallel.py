@@ -81,7 +81,9 @@ class GanDataParallel:
     def train_phase(self, group, lr, beta1=0.5, beta2=0.9, adam_eps=1e-8, **kw):
         out = self.eng.phase(group, want_backward=True, **kw)
         if self.world > 1:
-            off, cnt = self.eng.group(group)
+            # AnoVAE-GAN's 'Encoder' phase is optim_vae: Encoder + Generator variables (one contiguous slice)
+            red = 'VAE' if (getattr(self.eng, 'variant', '') == 'anovaegan' and group == 'Encoder') else group
+            off, cnt = self.eng.group(red)
             dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM)
         self.eng.adam(group, lr, beta1, beta2, adam_eps, 1.0 / self.world)
         return out
