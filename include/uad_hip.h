@@ -145,7 +145,9 @@ int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float be
 /* spatial GMVAE restoration (trainers/GMVAE_spatial.py:178-190): one `sess.run(grads)` + host update, on device.
  * grads = d( loss + sum_n tv_lambda * TV_n(x - xz_mu) ) / d x  at the current x_restored; then
  * x_restored -= restore_lr * grads in place.  grads_out (may be NULL) receives the gradient.  No parameter gradient is
- * computed and no host synchronisation happens: the caller enqueues restore_steps calls back to back. */
+ * computed and no host synchronisation happens: the caller enqueues restore_steps calls back to back.
+ * On a UAD_ARCH_VAE handle this is trainers/VAE_You.py:52-53,133-144 instead: grads = d( rec_n + kl_n + tv_lambda * TV_n(x - x_hat) ) / d x
+ * per sample (no 1/n: `pixel_loss` is not averaged), eps_z is the [n,zDim] reparameterisation noise, eps_w is ignored. */
 int uad_restore_step(uad_model_t* m, float* x_restored, const float* eps_w, const float* eps_z, int n, float tv_lambda,
                      float restore_lr, float* grads_out, void* stream);
 

@@ -203,15 +203,17 @@ class Model:
         return res
 
     # ------------------------------------------------------------------
-    def backward(self, p, x, out, cache, masks=None, kl=True):
+    def backward(self, p, x, out, cache, masks=None, kl=True, gx=None, klw=None):
         """Gradient of losses()['loss'] w.r.t. every parameter (dict by name).  kl=False drops the KL term
-        (the ceVAE context branch, whose loss is the reconstruction sum only: trainers/ceVAE.py:43,49)."""
+        (the ceVAE context branch, whose loss is the reconstruction sum only: trainers/ceVAE.py:43,49).
+        gx / klw override d objective / d x_hat and the KL weight (default sign(x_hat - x) / N and 1 / N): restoration objectives."""
         masks = masks or {}
         n = x.shape[0]
         dt = x.dtype.type
         g = {}
         # d loss / d x_hat = sign(x_hat - x) / N   (tf.abs gradient: sign, 0 at 0)
-        gx = np.sign(out['x_hat'] - x) * dt(1.0 / n)
+        if gx is None:
+            gx = np.sign(out['x_hat'] - x) * dt(1.0 / n)
         a = cache['dec_out']
         da, g['Decoder/dec_Conv2D_final/kernel'], g['Decoder/dec_Conv2D_final/bias'] = \
             nn.conv2d_bwd(a, p['Decoder/dec_Conv2D_final/kernel'], gx, 1)
@@ -235,7 +237,7 @@ class Model:
         if self.variational:
             mu, ls, sg, eps = cache['mu'], cache['ls'], cache['sigma'], cache['eps']
             # z = mu + eps*exp(ls); kl_n = 0.5*sum(mu^2 + exp(2 ls) - 2 ls - 1); loss += mean_n kl_n
-            klw = dt(1.0 / n) if kl else dt(0.0)
+            klw = (dt(1.0 / n) if klw is None else dt(klw)) if kl else dt(0.0)
             dmu = dz + mu * klw
             dls = dz * eps * sg + (sg * sg - dt(1.0)) * klw
             if 'mu' in masks:
@@ -280,6 +282,21 @@ class Model:
     def new_opt(self, p):
         return {'t': 0, 'm': {k: np.zeros_like(v) for k, v in p.items()},
                 'v': {k: np.zeros_like(v) for k, v in p.items()}}
+
+    def restore_grads(self, p, x, eps, tv_lambda):
+        """trainers/VAE_You.py:52-53: tf.gradients(pixel_loss + restore, x) with pixel_loss = rec_n + kl_n PER SAMPLE (no mean) and
+        restore = tv_lambda * total_variation(x - x_hat): x enters through the encoder and, directly, through r = x - x_hat."""
+        from .gmvae import total_variation_grad
+        out, cache = self.forward(p, x, eps)
+        dxhat = np.sign(out['x_hat'] - x) - x.dtype.type(tv_lambda) * total_variation_grad(x - out['x_hat'])
+        return self.backward(p, x, out, cache, gx=dxhat, klw=1.0)['__dx'] - dxhat
+
+    def restore(self, p, x, noise, restore_steps=150, restore_lr=1e-3, tv_lambda=1.8):
+        """trainers/VAE_You.py:133-144; noise: callable step -> eps (the graph samples z on every sess.run)."""
+        rec = x.copy()
+        for step in range(restore_steps):
+            rec = rec - x.dtype.type(restore_lr) * self.restore_grads(p, rec, noise(step), tv_lambda)
+        return rec
 
     def reconstruct(self, p, x, eps=None, masks=None):
         """trainers/VAE.py:105-123 / AE.py:92-110 (l2err == l1err, sic; A4)."""

@@ -136,7 +136,7 @@ def test_gmvae_train_trajectory():
 def test_gmvae_error_paths():
     with pytest.raises(ValueError):
         Engine('GMVAE_spatial', 64, 64, 1, 8, max_batch=1, dim_c=100)       # dim_c > 64
-    eng = Engine('VAE', 32, 32, 1, 8, 16, max_batch=1)
+    eng = Engine('AE', 32, 32, 1, 8, 16, max_batch=1)
     with pytest.raises(ValueError):
-        eng.restore_step(torch.zeros(1, 32, 32, 1, device='cuda'))          # not a GMVAE handle
+        eng.restore_step(torch.zeros(1, 32, 32, 1, device='cuda'))          # restoration needs a GMVAE or a VAE handle
     eng.close()

@@ -204,3 +204,21 @@ def test_spatial_ae_vs_torch():
     np.testing.assert_allclose(m.losses(x, out)['loss'], loss.item(), rtol=1e-12)
     for name, _, _ in m.spec:
         np.testing.assert_allclose(g[name], tp[name].grad.numpy(), rtol=1e-7, atol=1e-12, err_msg=name)
+
+
+def test_vae_restore_grads_vs_torch():
+    """trainers/VAE_You.py:52-53: d (rec_n + kl_n + tv * TV_n(x - x_hat)) / d x, oracle vs autograd (fp64)."""
+    m = ovae.Model('VAE', 32, 32, 1, 8, 16)
+    p = ovae.init_params(m.spec, seed=4, dtype=np.float64, perturb=True)
+    x = ovae.synthetic_slices(2, 32, 32, seed=3, dtype=np.float64)
+    eps = np.random.default_rng(2).standard_normal((2, 16))
+    tv = 1.8
+    g = m.restore_grads(p, x, eps, tv)
+    tp = torch_ref.to_torch(p, requires_grad=False)
+    xt = torch.tensor(x, requires_grad=True)
+    L, xh, _ = torch_ref.forward_loss('VAE', m.spec, tp, xt, torch.tensor(eps), {}, 8, m.n_pool)
+    r = xt - xh
+    tvn = (r[:, 1:] - r[:, :-1]).abs().sum() + (r[:, :, 1:] - r[:, :, :-1]).abs().sum()
+    obj = x.shape[0] * L['loss'] + tv * tvn          # sum over samples of (rec_n + kl_n) = N * mean
+    obj.backward()
+    np.testing.assert_allclose(g, xt.grad.numpy(), rtol=1e-7, atol=1e-10)

@@ -94,6 +94,7 @@ struct uad_model {
     bool restore;                      // last forward was a restoration pass (TV term in the objective)
     bool fb_on_load;                   // ... whose d loss / d c of the last block is formed inside dec.back()'s data-gradient kernel
     float restore_tv, restore_lr;
+    float restore_scale;               // weight of the reconstruction / KL terms in the restore objective: 1/n (GMVAE: mean loss) or 1 (VAE_You: per-sample pixel_loss)
     float* restore_x;                  // x_restored (updated in place by the backward) or null
     float* restore_grads;              // optional gradient output
     // gradient ping-pong + small grads
@@ -272,6 +273,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     m->nmul = cevae ? 2 : 1;
     m->data_only = false;
     m->restore = false; m->fb_on_load = false; m->restore_x = nullptr; m->restore_grads = nullptr; m->restore_tv = 0.f; m->restore_lr = 0.f;
+    m->restore_scale = 1.0f;
     m->gm_total = 0;
     char nm[128];
     // the GMVAE graph opens no variable scope: plain layer names, BN layers numbered across encoder and decoder
@@ -404,6 +406,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
         ALLOC(m->gm_partial, (size_t)64 * m->gm_total); ALLOC(m->gm_dxhat, NB * H * Wd * cfg->channels);
     }
     if (sp) ALLOC(m->gm_h, NB * ir * ir * m->cenc);           // the latent feature map z
+    if (cfg->arch == UAD_ARCH_VAE) ALLOC(m->gm_dxhat, NB * H * Wd * cfg->channels);     // restoration mode (trainers/VAE_You.py)
     m->dec_in0 = (gm || sp) ? m->gm_h : m->cb;
     ALLOC(m->G0, maxact); ALLOC(m->G1, maxact);
     ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
@@ -671,7 +674,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         PROF("final.fwd+tv+bwd");
         float* dc = fa.d_c; fa.d_c = nullptr;
         if (!fused_final) uad_launch_final_fwd_bwd(fa, st);
-        uad_launch_tv_dxhat(xin, fa.x_hat, n, fa.H, fa.W, fa.inv_batch, m->restore_tv, m->gm_dxhat, st);
+        uad_launch_tv_dxhat(xin, fa.x_hat, n, fa.H, fa.W, m->restore_scale, m->restore_tv, m->gm_dxhat, st);
         fa.d_c = dc; fa.dxhat_in = m->gm_dxhat;
         m->fb_on_load = fused_final && restore_fb_on_load(m, n);
         if (!m->fb_on_load) uad_launch_final_fwd_bwd(fa, st);   // else: folded into dec.back()'s data gradient
@@ -808,6 +811,7 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
     const ConvLayer& EL = m->enc.back();
     {
         UadBottArgs ba = bott_args(m, io, m->mask_dec_eff, nu);
+        if (m->restore) ba.inv_batch = m->restore_scale;          // VAE_You: d (rec_n + kl_n) / d x per sample, no 1/n
         if (uad_bottleneck_fused_ok(ba)) {
             // MAIN: one workgroup per sample does the whole data-gradient chain.  SIDE: the parameter-gradient GEMMs -- conv2d_1's
             // (it needs only dcb / dvec) before that kernel, the others from the vectors it leaves behind.
@@ -856,7 +860,7 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
         uad_launch_conv_d(d_dec, dd, no_xform(), P(m, m->dw), dz, epi_bias(nullptr, vae ? nullptr : io.mask_mu), st, nullptr, m->ws);
         if (vae) {
             uad_launch_reparam_bwd(n, nu, zd, dz, m->mu, m->sigma, io.eps, io.mask_mu, io.mask_sigma,
-                                   cevae ? io.mask_mu_ce : nullptr, 1.0f / (float)nu, dmu, dls, st);
+                                   cevae ? io.mask_mu_ce : nullptr, m->restore ? m->restore_scale : 1.0f / (float)nu, dmu, dls, st);
             edge(m, st, sd);
             if (pg) { PROF_ON("bott.wgrad", sd);
               uad_launch_conv_w(d_in, m->t, no_xform(), dmu, no_xform(), Gr(m, m->muw), wp, sd);
@@ -1030,11 +1034,15 @@ int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float be
 int uad_restore_step(uad_model_t* m, float* x_restored, const float* eps_w, const float* eps_z, int n, float tv_lambda,
                      float restore_lr, float* grads_out, void* stream) {
     if (!m || !x_restored) return fail(UAD_ERR_INVALID, "null argument");
-    if (m->cfg.arch != UAD_ARCH_GMVAE_SPATIAL) return fail(UAD_ERR_INVALID, "uad_restore_step needs a spatial GMVAE handle");
+    const bool vae = m->cfg.arch == UAD_ARCH_VAE;
+    if (m->cfg.arch != UAD_ARCH_GMVAE_SPATIAL && !vae) return fail(UAD_ERR_INVALID, "uad_restore_step needs a spatial GMVAE or a VAE handle");
+    if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
     uad_io_t io;
     memset(&io, 0, sizeof io);
     io.x = x_restored; io.eps_w = eps_w; io.eps_z = eps_z;
+    if (vae) io.eps = eps_z;                     // trainers/VAE_You.py:52-53: grads = d (rec_n + kl_n + tv * TV_n) / d x, per sample
     m->restore = true; m->restore_tv = tv_lambda; m->restore_lr = restore_lr;
+    m->restore_scale = vae ? 1.0f : 1.0f / (float)n;
     m->restore_x = x_restored; m->restore_grads = grads_out;
     int rc = uad_forward(m, &io, n, 2, stream);
     if (rc == UAD_OK) rc = uad_backward(m, UAD_SEG_ALL, stream);

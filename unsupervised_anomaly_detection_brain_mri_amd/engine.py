@@ -296,8 +296,11 @@ class Engine(_EvalOps):
         n, r = x_restored.shape[0], self.inter
         if tuple(x_restored.shape[1:]) != (self.h, self.w, self.c) or n > self.max_batch:
             raise ValueError(f'x_restored must be [n<={self.max_batch},{self.h},{self.w},{self.c}]')
-        eps_w = self._dev(eps_w, (n, r, r, self.dim_w))
-        eps_z = self._dev(eps_z, (n, r, r, self.dim_z))
+        if self.arch == 'VAE':      # trainers/VAE_You.py: eps_z is the [n,zDim] reparameterisation noise, the objective is per sample
+            eps_w, eps_z = None, self._dev(eps_z, (n, self.zdim))
+        else:
+            eps_w = self._dev(eps_w, (n, r, r, self.dim_w))
+            eps_z = self._dev(eps_z, (n, r, r, self.dim_z))
         grads = torch.empty_like(x_restored) if want_grads else None
         self._keep = (x_restored, eps_w, eps_z, grads)
         _lib.check(self.lib.uad_restore_step(self.handle, _ptr(x_restored), _ptr(eps_w), _ptr(eps_z), n, float(tv_lambda),
