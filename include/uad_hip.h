@@ -176,6 +176,10 @@ int uad_residual(const float* x, const float* xr, const float* mask, int n, int 
 typedef struct uad_scores uad_scores_t;
 int uad_erode_cross(const float* mask, int n, int H, int W, int iterations, float* out, void* stream);
 int uad_median3d(const float* vol, int D, int H, int W, int ksize, float* out, void* stream);
+/* Monte-Carlo dropout statistics of K reconstructions (utils/Evaluation.py:238-266 with numMonteCarloSamples > 1): recs [K, total],
+ * optional mask [total] (the eroded brain mask is applied to every sample first, as the reference does); mean [total] = E[mask*rec],
+ * var [total] (may be NULL) = E[(mask*rec)^2] - E[mask*rec]^2 = Metrics.combined_predictive_uncertainty(x_recs, 0) (:170-173) */
+int uad_mc_stats(const float* recs, const float* mask, int K, long long total, float* mean, float* var, void* stream);
 /* utils/Evaluation.py:113-127 filter_3d_connected_components: out = vol with every 26-connected component of non-zero voxels that has
  * at most max_voxels (reference: 7) voxels set to 0 (bounded flood fill per voxel, exact; max_voxels < 16; not in place) */
 int uad_cc_filter(const float* vol, int D, int H, int W, int max_voxels, float* out, void* stream);

@@ -46,7 +46,8 @@ def main(args):
     if args.threshold:
         options['threshold'] = args.threshold
     ev = Evaluation.evaluate(vols, labs, masks, model, options)
-    print(json.dumps({k: (v if isinstance(v, (list, dict, str)) else float(v)) for k, v in ev.items() if k != 'time'}, default=float))
+    print(json.dumps({k: (v if isinstance(v, (list, dict, str)) else float(v)) for k, v in ev.items()
+                      if k not in ('time', 'epistemic_variance')}, default=float))
 
 
 if __name__ == '__main__':

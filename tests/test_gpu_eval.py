@@ -148,3 +148,40 @@ def test_cc_filter_bit_exact(eng, case):
         assert out.sum() == 0
     for mv in (0, 3, 12):
         assert np.array_equal(eng.cc_filter(v, mv).cpu().numpy(), Evaluation.filter_3d_connected_components(v, max_voxels=mv))
+
+
+def test_mc_stats_matches_metrics(eng):
+    """uad_mc_stats vs Metrics.combined_predictive_uncertainty(x_recs, 0) and the mean of the masked reconstructions."""
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import Metrics
+    rng = np.random.default_rng(2)
+    recs = rng.random((7, 3, 16, 16, 1)).astype(np.float32)
+    mask = (rng.random((3, 16, 16, 1)) > 0.3).astype(np.float32)
+    mean, var = eng.mc_stats(recs, mask)
+    p = recs.astype(np.float64) * mask
+    np.testing.assert_allclose(mean.cpu().numpy(), p.mean(axis=0), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(var.cpu().numpy(), Metrics.combined_predictive_uncertainty(p, np.zeros_like(p), axis=0), rtol=1e-4, atol=1e-7)
+    m2, _ = eng.mc_stats(recs)
+    np.testing.assert_allclose(m2.cpu().numpy(), recs.mean(axis=0), rtol=1e-6, atol=1e-7)
+
+
+def test_evaluate_with_monte_carlo_dropout(tmp_path):
+    """numMonteCarloSamples > 1 (the "Bayesian" AE / VAE of the comparison): K dropout passes per batch, residual against their mean,
+    epistemic variance + its histogram in the result (utils/Evaluation.py:238-266, 404-408)."""
+    from unsupervised_anomaly_detection_brain_mri_amd.models import autoencoder
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import AE
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import Evaluation
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_config, get_options
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset, synthetic_slices
+    opt = get_options(batchsize=8, learningrate=2e-4, numEpochs=1, zDim=64, outputWidth=64, outputHeight=64, numMonteCarloSamples=4,
+                      config={'CHECKPOINTDIR': str(tmp_path / 'ck'), 'SAMPLEDIR': str(tmp_path / 'smp')})
+    ds = SyntheticDataset(16, 8, 64, 64, seed=0)
+    model = AE(None, get_config(AE, opt, 'ADAM', [8, 8], 0.2, ds), network=autoencoder)
+    model.train(ds)
+    x, lab, msk = synthetic_slices(10, 64, 64, seed=33, lesions=True)
+    ev = Evaluation.evaluate([x[..., 0].astype(np.float64)], [lab], [msk], model, opt)
+    assert ev['epistemic_variance'].shape == (10, 64, 64) and (ev['epistemic_variance'] >= -1e-6).all() and ev['epistemic_variance'].max() > 0
+    assert len(ev['uncertaintyHistogram']) == 50 and 0.0 <= ev['diff_AUC'] <= 1.0
+    opt1 = dict(opt, numMonteCarloSamples=0)
+    ev1 = Evaluation.evaluate([x[..., 0].astype(np.float64)], [lab], [msk], model, opt1)
+    assert 'epistemic_variance' not in ev1
+    model.engine.close()

@@ -169,6 +169,23 @@ __global__ void dice_at_kernel(const float* __restrict__ score, const unsigned l
 // maxv + 1.  (skimage fills holes with the full 3x3x3 structure, so a component this small has filled_area == area.)
 // Integer work on L2-resident reads; exact.
 // ------------------------------------------------------------------------------------------------
+// Monte-Carlo dropout statistics (utils/Evaluation.py:238-266, Metrics.combined_predictive_uncertainty :170-173): per pixel, over the K
+// brain-masked reconstructions p_k = mask * rec_k:  mean = E[p],  var = E[p^2] - E[p]^2  (the epistemic term; no aleatoric input here).
+__global__ void __launch_bounds__(256) mc_stats_kernel(const float* __restrict__ recs, const float* __restrict__ mask, int K, size_t total,
+                                                       float* __restrict__ mean, float* __restrict__ var) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float m = mask ? mask[i] : 1.0f;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float p = recs[(size_t)k * total + i] * m;
+        s += p; q = fmaf(p, p, q);
+    }
+    const float mu = s / (float)K;
+    mean[i] = mu;
+    if (var) var[i] = q / (float)K - mu * mu;
+}
+
 constexpr int CC_CAP = 16;
 __global__ void __launch_bounds__(256) cc_filter_kernel(const float* __restrict__ vol, int D, int H, int W, int maxv,
                                                         float* __restrict__ out) {
@@ -240,6 +257,13 @@ int uad_median3d(const float* vol, int D, int H, int W, int ksize, float* out, v
     if (vol == out) return fail(UAD_ERR_INVALID, "median3d: in-place is not supported");
     dim3 grid((W + 7) / 8, (H + 7) / 8, (D + 7) / 8);
     hipLaunchKernelGGL(median5_kernel, grid, dim3(512), 0, (hipStream_t)stream, vol, D, H, W, out);
+    EV_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+int uad_mc_stats(const float* recs, const float* mask, int K, long long total, float* mean, float* var, void* stream) {
+    if (!recs || !mean || K <= 0 || total <= 0) return fail(UAD_ERR_INVALID, "mc_stats: bad arguments");
+    hipLaunchKernelGGL(mc_stats_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, recs, mask, K, (size_t)total, mean, var);
     EV_TRY(hipGetLastError());
     return UAD_OK;
 }

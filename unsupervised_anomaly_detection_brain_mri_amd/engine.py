@@ -46,6 +46,20 @@ class _EvalOps:
         _lib.check(self.lib.uad_median3d(_ptr(v), v.shape[0], v.shape[1], v.shape[2], int(ksize), _ptr(out), self._stream()))
         return out
 
+    def mc_stats(self, recs, mask=None):
+        """Monte-Carlo dropout statistics (utils/Evaluation.py:238-266): recs [K, ...] device / host array of K reconstructions, mask
+        broadcastable to one sample.  Returns (mean, epistemic variance) of the masked reconstructions as device tensors."""
+        r = recs if isinstance(recs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(recs, np.float32))
+        r = r.to(self.device, torch.float32).contiguous()
+        K, total = r.shape[0], r[0].numel()
+        m = None
+        if mask is not None:
+            m = mask if isinstance(mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mask, np.float32))
+            m = m.to(self.device, torch.float32).expand(r.shape[1:]).contiguous()
+        mean, var = torch.empty_like(r[0]), torch.empty_like(r[0])
+        _lib.check(self.lib.uad_mc_stats(_ptr(r), _ptr(m), K, total, _ptr(mean), _ptr(var), self._stream()))
+        return mean, var
+
     def cc_filter(self, volume, max_voxels=7):
         """filter_3d_connected_components (utils/Evaluation.py:113-127) of a [D,H,W] volume (bool / float, non-zero = foreground):
         components of at most `max_voxels` voxels are zeroed.  Returns a float device tensor."""

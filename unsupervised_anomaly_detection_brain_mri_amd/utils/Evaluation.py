@@ -120,13 +120,24 @@ def evaluate_volume(model, volume, brainmasks, options, eps=0.0, device_out=Fals
     bs = model.config.batchsize
     diffs = torch.empty((S,) + volume.shape[1:], device=eng.device, dtype=torch.float32)
     l1 = np.zeros(S)
+    K = int(options.get('numMonteCarloSamples') or 0)
+    var = torch.empty_like(diffs) if K > 1 else None
     for s0 in range(0, S, bs):
         xb = x[s0:s0 + bs]
-        rec = model.reconstruct(xb, eps=eps)['reconstruction']
+        if K > 1:
+            # Monte-Carlo dropout (utils/Evaluation.py:238-266): K stochastic passes, the residual is taken against the mean of the
+            # brain-masked reconstructions, their per-pixel variance is the epistemic uncertainty
+            recs = torch.stack([torch.from_numpy(model.reconstruct(xb, dropout=True)['reconstruction']).to(eng.device) for _ in range(K)])
+            rec, v = eng.mc_stats(recs, masks[s0:s0 + bs, ..., None])
+            var[s0:s0 + bs] = v[..., 0]
+        else:
+            rec = model.reconstruct(xb, eps=eps)['reconstruction']
         d, e = eng.residual(xb, rec, masks[s0:s0 + bs, ..., None], pos_only=should(options, 'keepOnlyPositiveResiduals'),
                             prior_thresh=prior)
         diffs[s0:s0 + bs] = d[..., 0]
         l1[s0:s0 + bs] = e.cpu().numpy()
+    if var is not None:
+        model.last_epistemic_variance = var
     if should(options, 'medianFiltering'):
         diffs = eng.median3d(diffs, 5)
     return (diffs if device_out else diffs.cpu().numpy().astype(np.float64)), l1
@@ -137,7 +148,11 @@ def evaluate(volumes, labels, brainmasks, model, options, eps=0.0):
     (utils/Evaluation.py:416-470): diff_AUC, diff_AUPRC, bestDiceScore, bestThreshold, DiceScore, DiceScorePerPatient,
     PrecisionPerPatient, RecallPerPatient (after the small-component filter)."""
     _time = {'evaluation': time.time()}
-    diffs = [evaluate_volume(model, v, b, options, eps, device_out=True)[0] for v, b in zip(volumes, brainmasks)]
+    diffs, variances = [], []
+    for v, b in zip(volumes, brainmasks):
+        diffs.append(evaluate_volume(model, v, b, options, eps, device_out=True)[0])
+        if int(options.get('numMonteCarloSamples') or 0) > 1:
+            variances.append(model.last_epistemic_variance.cpu().numpy())
     d_all = torch.cat([d.reshape(-1) for d in diffs])
     l_all = np.concatenate([np.asarray(l).flatten() for l in labels])
     sc = model.engine.scores(d_all, l_all)
@@ -162,6 +177,13 @@ def evaluate(volumes, labels, brainmasks, model, options, eps=0.0):
             ev['PrecisionPerPatient'].append(Metrics.precision(sub, g))
             ev['RecallPerPatient'].append(Metrics.recall(sub, g))
     ev['Dice'] = ev['DiceScorePerPatient']
+    if variances:
+        # utils/Evaluation.py:404-408: histogram of the epistemic variances (50 bins, 1e-5 .. their 99.8th percentile)
+        ev['epistemic_variance'] = np.concatenate(variances, axis=0)
+        pos = ev['epistemic_variance'][ev['epistemic_variance'] >= 0]
+        hi = float(np.percentile(pos, 99.8))
+        # (the reference's np.histogram raises when every variance is below 1e-5; an empty histogram is returned here instead)
+        ev['uncertaintyHistogram'] = (np.histogram(ev['epistemic_variance'], bins=50, range=(1e-5, hi))[0] if hi > 1e-5 else np.zeros(50, np.int64)).tolist()
     _time['evaluation'] = time.time() - _time['evaluation']
     ev['time'] = _time
     return ev
