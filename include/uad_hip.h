@@ -213,6 +213,14 @@ enum { UAD_GAN_UNIFIED = 0, UAD_GAN_RESNET = 1,
                                      kl_weight * kl over Encoder + Generator variables; uad_gan_adam(UAD_GAN_ENCODER) steps both, the
                                      Generator with its own second pair of slots, UAD_BUF_ADAM_M2 / _V2), UAD_GAN_GENERATOR = optim_gen,
                                      UAD_GAN_DISCRIMINATOR = optim_dis; io.z is unused */
+enum { UAD_GAN_AAE = 3 };        /* dense-bottleneck BN autoencoder + re-encoding constraint and / or latent WGAN-GP critic; cfg.aae_kind:
+                                     0 = models/constrained_autoencoder.py:9-48 + trainers/ConstrainedAE.py:36-45,
+                                     1 = models/adversarial_autoencoder.py:10-72 + trainers/AAE.py:40-67,
+                                     2 = models/constrained_adversarial_autoencoder.py:10-79 + trainers/ConstrainedAAE.py:44-70.
+                                     Phases / groups: UAD_GAN_GENERATOR (1) = optim_ae (loss = mean(L2 [+ rho Rec_z]), every autoencoder variable),
+                                     UAD_GAN_DISCRIMINATOR (2) = optim_dis (io.z = prior sample, io.alpha = eps of z_hat = z + eps (z - z_)),
+                                     UAD_GAN_ENCODER (0) = optim_gen (-mean d_, the variables named 'Encoder/...', own Adam slots);
+                                     io.mask_z / mask_g / mask_sigma = dropout masks of z_, dec_dense, z_rec */
 enum { UAD_GAN_GROUP_VAE = 3 };   /* uad_gan_group only: the contiguous Encoder + Generator slice (AnoVAE-GAN's optim_vae) */
 enum { UAD_BUF_ADAM_M2 = 4, UAD_BUF_ADAM_V2 = 5 };
 /* scalars[16] written by uad_gan_phase (entries a phase does not compute are left untouched) */
@@ -230,6 +238,8 @@ typedef struct {
                                       height must be 8 * inter_res; no dropout in that graph: mask_z / mask_g are ignored) */
     int dim;                       /* RESNET only: base width (fanogan_schlegl.py:13: 64); 0 = 64 */
     float kl_weight;               /* ANOVAEGAN only: AnoVAEGAN.Config.kl_weight (:17) */
+    int aae_kind;                  /* AAE only: 0 constrained AE, 1 AAE, 2 constrained AAE */
+    float rho;                     /* AAE only: weight of the latent re-encoding term (ConstrainedAE.Config.rho :15) */
 } uad_gan_config_t;
 typedef struct {
     const float* x;                /* [n,H,W,1] batch (critic and encoder phases, reconstruct) */

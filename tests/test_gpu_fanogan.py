@@ -369,3 +369,55 @@ def test_resnet_critic_phase_batch4_dim64():
     flips = _flips_rn(eng, m, caches)
     _check_critic_scalars(out, ls, flips)
     _check_grads(eng, m, g, 'Discriminator', 'disc', TOL if flips == 0 else TOL_KINK)
+
+
+# ------------------------------------------------------------------ AAE family (ConstrainedAE / AAE / ConstrainedAAE)
+@pytest.mark.parametrize('kind,h,zdim,n,math,drop', [('constrained_ae', 32, 16, 3, 'f32', True), ('aae', 64, 32, 2, 'bf16x3', True),
+                                                    ('constrained_aae', 64, 128, 2, 'bf16x3', False), ('constrained_ae', 128, 128, 2, 'bf16x3', True)])
+def test_aae_family_phases(kind, h, zdim, n, math, drop):
+    from oracle import aae as oaae
+    from unsupervised_anomaly_detection_brain_mri_amd.gan_engine import GanEngine
+    m = oaae.AAE(kind, h, 8, zdim, rho=0.8, scale=10.0)
+    p = ovae.init_params(m.spec, seed=51, dtype=np.float64, perturb=True)
+    rng = np.random.default_rng(61)
+    x = ovae.synthetic_slices(n, h, h, seed=3, dtype=np.float64)
+    z_prior = rng.standard_normal((n, zdim)); eps = rng.uniform(0, 1, n)
+    eng = GanEngine(h, h, 1, 8, zdim, max_batch=n, scale=m.scale, math=math, variant='aae', aae_kind=kind, rho=m.rho)
+    assert [(k, tuple(s)) for k, s, _ in eng.spec] == [(k, tuple(s)) for k, s, _ in m.spec]
+    eng.set_params(p)
+    keep = lambda shape: (rng.random(shape) > 0.2) / 0.8
+    mz = keep((n, zdim)) if drop else None
+    md = keep((n, eng.flat)) if drop else None
+    mr = keep((n, zdim)) if (drop and m.constrained) else None
+
+    def check(g_ref, names, tag, tol=5e-4):
+        # L1-free losses (L2 / MSE / critic scores): no sign ties; activation flips are bounded through the L2 norm (TOL_KINK discussion)
+        g_dev = eng.get_grads()
+        scale = max(np.abs(np.asarray(g_ref[k])).max() for k in names)
+        for k in names:
+            ref = np.asarray(g_ref.get(k, 0) * np.ones(g_dev[k].shape)).reshape(g_dev[k].shape)
+            err = np.linalg.norm(g_dev[k].astype(np.float64) - ref)
+            assert err <= tol * max(np.linalg.norm(ref), 1e-2 * scale * np.sqrt(ref.size)), f'{tag}:{k} L2 err {err:.3e} ref {np.linalg.norm(ref):.3e}'
+
+    ae_names = [k for k, _, _ in m.spec if not k.startswith('Discriminator')]
+    out = eng.aae_phase('AE', x, mask_z=mz, mask_dec=md, mask_rec=mr, want_l1=True)
+    ls, g = m.ae_phase(p, x, mz, md, mr)
+    assert abs(out['loss'].item() - ls['loss']) < TOL * max(1.0, abs(ls['loss']))
+    assert abs(out['reconstructionLoss'].item() - ls['reconstructionLoss']) < TOL * ls['reconstructionLoss']
+    assert _rel(out['reconstruction'].cpu().numpy(), ls['reconstruction']) < TOL
+    assert _rel(out['z'].cpu().numpy(), ls['z']) < TOL and _rel(out['L1'].cpu().numpy(), ls['L1']) < TOL
+    check(g, ae_names, 'ae')
+    if m.has_critic:
+        out = eng.aae_phase('Discriminator', x, z=z_prior, eps=eps, mask_z=mz)
+        ls, g = m.disc_phase(p, x, z_prior, eps, mz)
+        for k in ('disc_fake', 'disc_real', 'penalty', 'disc_loss'):
+            assert abs(out[k].item() - ls[k]) < TOL * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
+        check(g, [k for k, _, _ in m.spec if k.startswith('Discriminator')], 'disc', tol=TOL)
+        out = eng.aae_phase('Encoder', x, mask_z=mz)
+        ls, g = m.gen_phase(p, x, mz)
+        assert abs(out['gen_loss'].item() - ls['gen_loss']) < TOL * max(1.0, abs(ls['gen_loss']))
+        check(g, [k for k, _, _ in m.spec if 'Encoder' in k], 'gen')
+        off, cnt = eng.group('Encoder')
+        assert off == 0 and cnt == sum(int(np.prod(s)) for k, s, _ in m.spec if 'Encoder' in k)
+    assert _rel(eng.reconstruct(x)['reconstruction'].cpu().numpy(), m.reconstruct(p, x)) < TOL
+    eng.close()

@@ -309,3 +309,38 @@ def test_anovaegan_trainer(tmp_path):
     assert m2.load_checkpoint() == 1 and np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w)
     assert [m2.engine.step_count(g) for g in ('Encoder', 'Generator', 'Discriminator')] == [nb, nb, 5 * nb]
     m2.engine.close()
+
+
+@pytest.mark.parametrize('tname,mname', [('ConstrainedAE', 'constrained_autoencoder'), ('AAE', 'adversarial_autoencoder'),
+                                         ('ConstrainedAAE', 'constrained_adversarial_autoencoder')])
+def test_latent_ae_trainers(tmp_path, tname, mname):
+    """trainers/ConstrainedAE.py, AAE.py, ConstrainedAAE.py: Config defaults, one epoch of the reference loop (shortened critic
+    iterations), fetch keys, reconstruct(), resume with the three Adam step counters."""
+    import importlib
+    T = getattr(importlib.import_module('unsupervised_anomaly_detection_brain_mri_amd.trainers'), tname)
+    net = getattr(importlib.import_module('unsupervised_anomaly_detection_brain_mri_amd.models'), mname)
+    cfg, opt, ds = _config(T, tmp_path, h=64, bs=4, epochs=1)
+    assert cfg.modelname == tname and (tname == 'AAE' or cfg.rho == 1) and (tname == 'ConstrainedAE' or cfg.scale == 10.0)
+    model = T(None, cfg, network=net)
+    model.D_ITERS = 2
+    assert model.model_dir == f'{tname}_dSyntheticDataset_s64x64_{mname}_b4_z64_'
+    model.train(ds)
+    nb = ds.num_batches(4, set='TRAIN')
+    steps = [model.engine.step_count(g) for g in ('Encoder', 'AE', 'Discriminator')]
+    assert steps == ([0, nb, 0] if tname == 'ConstrainedAE' else [nb, 2 * nb, 2 * nb])
+    run = model.step(ds.next_batch(4, set='VAL')[0], Phase.VAL)
+    want = {'loss', 'L2', 'reconstructionLoss', 'reconstruction', 'L1'} | (set() if tname == 'AAE' else {'Rec_z'})
+    assert set(run) == want
+    if tname == 'AAE':
+        assert run['loss'] == pytest.approx(run['L2'], rel=1e-6)
+    else:
+        assert run['loss'] == pytest.approx(run['L2'] + run['Rec_z'], rel=1e-5)
+    r = model.reconstruct(ds.next_batch(1, set='VAL')[0][0])
+    assert r['reconstruction'].shape == (1, 64, 64, 1) and np.isfinite(r['l1err'])
+    w = model.engine.get_buffer_host(_lib.BUF_PARAMS)
+    model.engine.close()
+    cfg2, _, _ = _config(T, tmp_path, h=64, bs=4, epochs=1)
+    m2 = T(None, cfg2, network=net, seed=3)
+    assert m2.load_checkpoint() == 1 and np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w)
+    assert [m2.engine.step_count(g) for g in ('Encoder', 'AE', 'Discriminator')] == steps
+    m2.engine.close()

@@ -37,7 +37,7 @@ class UadIO(C.Structure):
 class UadGanConfig(C.Structure):
     _fields_ = [('height', C.c_int), ('width', C.c_int), ('channels', C.c_int), ('inter_res', C.c_int), ('zdim', C.c_int),
                 ('max_batch', C.c_int), ('scale', C.c_float), ('kappa', C.c_float), ('variant', C.c_int), ('dim', C.c_int),
-                ('kl_weight', C.c_float)]
+                ('kl_weight', C.c_float), ('aae_kind', C.c_int), ('rho', C.c_float)]
 
 
 class UadGanIO(C.Structure):
@@ -46,7 +46,7 @@ class UadGanIO(C.Structure):
 
 
 GAN_ENCODER, GAN_GENERATOR, GAN_DISCRIMINATOR = 0, 1, 2
-GAN_UNIFIED, GAN_RESNET, GAN_ANOVAEGAN = 0, 1, 2
+GAN_UNIFIED, GAN_RESNET, GAN_ANOVAEGAN, GAN_AAE = 0, 1, 2, 3
 GAN_GROUP_VAE = 3
 BUF_ADAM_M2, BUF_ADAM_V2 = 4, 5
 GAN_SCALARS = ('gen_loss', 'disc_fake', 'disc_real', 'penalty', 'disc_loss', 'loss_img', 'loss_fts', 'enc_loss',

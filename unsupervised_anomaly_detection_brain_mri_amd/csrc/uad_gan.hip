@@ -365,6 +365,10 @@ __global__ void __launch_bounds__(256) sign_scale_kernel(const float* __restrict
     const float d = a[i] - b[i];
     out[i] = d > 0.f ? coef : (d < 0.f ? -coef : 0.f);
 }
+__global__ void __launch_bounds__(256) add_kernel(float* __restrict__ out, const float* __restrict__ a, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] += a[i];
+}
 __device__ __forceinline__ float block_sum(float v, float* red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -451,12 +455,141 @@ __global__ void combine_kernel(int phase, const float* __restrict__ raw, float k
     } else if (phase == UAD_GAN_DISCRIMINATOR) {
         out[UAD_GAN_S_DISC_FAKE] = raw[0]; out[UAD_GAN_S_DISC_REAL] = raw[1]; out[UAD_GAN_S_PENALTY] = raw[2];
         out[UAD_GAN_S_DISC_LOSS] = raw[0] - raw[1] + raw[2]; out[UAD_GAN_S_GEN_LOSS] = -raw[0];
+    } else if (phase == 4) {      // AAE family, autoencoder phase: raw = {mean L2, mean Rec_z, reconstructionLoss}, kappa = rho
+        out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
+        out[UAD_GAN_S_REC_LOSS] = raw[2];
     } else if (phase == 3) {      // AnoVAE-GAN's VAE phase: raw = {reconstructionLoss, kl}, kappa = kl_weight
         out[UAD_GAN_S_REC_LOSS] = raw[0]; out[UAD_GAN_S_KL] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
     } else {
         out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
         out[UAD_GAN_S_REC_LOSS] = raw[2];
     }
+}
+
+// ================================================================================================ latent critic (AAE family)
+// MLP zDim -> h1 -> h2 -> 1 with tf.nn.leaky_relu (alpha 0.2): models/adversarial_autoencoder.py:44-64, trainers/AAE.py:41-49.
+// One workgroup (128 threads) per sample does everything that sample contributes: the three critic evaluations (fake z_, real z,
+// z_hat = z + eps (z - z_)), the first-order backward of  +d_/n - d/n,  the penalty scale/n (||d d_hat / d z_hat|| - 1)^2 and its
+// second-order gradient (masks are constant a.e.), and writes the sample's parameter-gradient slab [nD] (reduced over samples
+// afterwards in a fixed order).  mode 1 (generator step): only the fake evaluation and dz_fake = -1/n * d d_ / d z_.
+struct CriticArgs {
+    int zd, h1, h2, mode;                 // mode 0 = critic step, 1 = generator step
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    const float *zf, *zr, *eps;           // fake [n,zd], real [n,zd], eps [n]
+    float inv_n, scale;
+    float *d_fake, *d_real, *pen;         // [n] each
+    float *slab;                          // [n][nD]: dW1 | db1 | dW2 | db2 | dW3 | db3
+    float *dz_fake;                       // [n,zd] (mode 1)
+};
+constexpr int kCritMaxZ = 512, kCritMaxH = 128;
+__global__ void __launch_bounds__(128) critic_kernel(const CriticArgs A) {
+    __shared__ float v[3][kCritMaxZ];                 // fake, real, hat
+    __shared__ float m1[3][kCritMaxH], hh1[3][kCritMaxH], m2[3][kCritMaxH], hh2[3][kCritMaxH];
+    __shared__ float da1[2][kCritMaxH], da2[2][kCritMaxH], u1[kCritMaxH], u2[kCritMaxH], tb1[kCritMaxH], ub2[kCritMaxH];
+    __shared__ float gz[kCritMaxZ], red[128];
+    __shared__ float s_d[3], s_coef;
+    const int n = blockIdx.x, t = threadIdx.x, zd = A.zd, h1 = A.h1, h2 = A.h2;
+    const float alpha = 0.2f;
+    const int nin = A.mode == 0 ? 3 : 1;
+    for (int k = t; k < zd; k += 128) {
+        const float f = A.zf[(size_t)n * zd + k];
+        v[0][k] = f;
+        if (A.mode == 0) { const float r = A.zr[(size_t)n * zd + k]; v[1][k] = r; v[2][k] = r + A.eps[n] * (r - f); }
+    }
+    __syncthreads();
+    // forward of the inputs
+    for (int i = 0; i < nin; ++i) {
+        if (t < h1) {
+            float a = A.b1[t];
+            for (int k = 0; k < zd; ++k) a = fmaf(v[i][k], A.W1[(size_t)k * h1 + t], a);
+            m1[i][t] = a > 0.f ? 1.f : alpha; hh1[i][t] = a > 0.f ? a : alpha * a;
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < nin; ++i) {
+        if (t < h2) {
+            float a = A.b2[t];
+            for (int j = 0; j < h1; ++j) a = fmaf(hh1[i][j], A.W2[(size_t)j * h2 + t], a);
+            m2[i][t] = a > 0.f ? 1.f : alpha; hh2[i][t] = a > 0.f ? a : alpha * a;
+        }
+    }
+    __syncthreads();
+    if (t < nin) {
+        float d = A.b3[0];
+        for (int l = 0; l < h2; ++l) d = fmaf(hh2[t][l], A.W3[l], d);
+        s_d[t] = d;
+    }
+    __syncthreads();
+    if (t == 0) { A.d_fake[n] = s_d[0]; if (A.mode == 0) A.d_real[n] = s_d[1]; }
+    // u2 = m2 * w3, t1 = W2 u2, u1 = m1 * t1, gz = W1 u1 on the input whose input-gradient is needed (hat: mode 0, fake: mode 1)
+    const int gi = A.mode == 0 ? 2 : 0;
+    if (t < h2) u2[t] = m2[gi][t] * A.W3[t];
+    __syncthreads();
+    if (t < h1) {
+        float a = 0.f;
+        for (int l = 0; l < h2; ++l) a = fmaf(A.W2[(size_t)t * h2 + l], u2[l], a);
+        u1[t] = m1[gi][t] * a;
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int k = t; k < zd; k += 128) {
+        float a = 0.f;
+        for (int j = 0; j < h1; ++j) a = fmaf(A.W1[(size_t)k * h1 + j], u1[j], a);
+        gz[k] = a;
+        part = fmaf(a, a, part);
+    }
+    if (A.mode == 1) {
+        for (int k = t; k < zd; k += 128) A.dz_fake[(size_t)n * zd + k] = -A.inv_n * gz[k];
+        return;
+    }
+    red[t] = part;
+    __syncthreads();
+    if (t == 0) {
+        float ss = 0.f;
+        for (int i = 0; i < 128; ++i) ss += red[i];
+        const float sl = sqrtf(ss);
+        A.pen[n] = A.scale * A.inv_n * (sl - 1.f) * (sl - 1.f);
+        s_coef = A.scale * 2.f * (sl - 1.f) / sl * A.inv_n;
+    }
+    __syncthreads();
+    const float coef = s_coef;                       // gbar = coef * gz
+    // first-order backward of +d_/n (fake, i = 0) and -d/n (real, i = 1)
+    if (t < h2) { da2[0][t] = A.inv_n * A.W3[t] * m2[0][t]; da2[1][t] = -A.inv_n * A.W3[t] * m2[1][t]; }
+    __syncthreads();
+    if (t < h1) {
+        float a0 = 0.f, a1 = 0.f, ub = 0.f;
+        for (int l = 0; l < h2; ++l) { const float w = A.W2[(size_t)t * h2 + l]; a0 = fmaf(w, da2[0][l], a0); a1 = fmaf(w, da2[1][l], a1); }
+        da1[0][t] = a0 * m1[0][t]; da1[1][t] = a1 * m1[1][t];
+        for (int k = 0; k < zd; ++k) ub = fmaf(gz[k], A.W1[(size_t)k * h1 + t], ub);      // adjoint of u1 (times coef)
+        tb1[t] = coef * ub * m1[2][t];
+    }
+    __syncthreads();
+    if (t < h2) {
+        float a = 0.f;
+        for (int j = 0; j < h1; ++j) a = fmaf(tb1[j], A.W2[(size_t)j * h2 + t], a);
+        ub2[t] = a;
+    }
+    __syncthreads();
+    // the sample's gradient slab
+    const size_t nD = (size_t)zd * h1 + h1 + (size_t)h1 * h2 + h2 + h2 + 1;
+    float* S = A.slab + (size_t)n * nD;
+    for (int idx = t; idx < zd * h1; idx += 128) {
+        const int k = idx / h1, j = idx - k * h1;
+        S[idx] = v[0][k] * da1[0][j] + v[1][k] * da1[1][j] + coef * gz[k] * u1[j];
+    }
+    float* S1 = S + (size_t)zd * h1;
+    if (t < h1) S1[t] = da1[0][t] + da1[1][t];
+    float* S2 = S1 + h1;
+    for (int idx = t; idx < h1 * h2; idx += 128) {
+        const int j = idx / h2, l = idx - j * h2;
+        S2[idx] = hh1[0][j] * da2[0][l] + hh1[1][j] * da2[1][l] + tb1[j] * u2[l];
+    }
+    float* S3 = S2 + (size_t)h1 * h2;
+    if (t < h2) {
+        S3[t] = da2[0][t] + da2[1][t];
+        S3[h2 + t] = A.inv_n * (hh2[0][t] - hh2[1][t]) + ub2[t] * m2[2][t];
+    }
+    if (t == 0) S3[2 * h2] = 0.f;                    // db3: +1/n - 1/n
 }
 
 // ================================================================================================ handle
@@ -514,6 +647,14 @@ struct uad_gan {
     float *wpartial, *colscratch, *colpart, *redpart, *raw, *scalars_own, *finpart;
     // ---- ResNet variant (models/fanogan_schlegl.py) ----
     int variant, dim;
+    // ---- AAE family (UAD_GAN_AAE): dense-bottleneck BN autoencoder + optional re-encoding constraint + optional latent critic ----
+    int aae_kind;                      // 0 constrained AE, 1 AAE, 2 constrained AAE
+    bool a_constrained, a_critic;
+    int a_h1, a_h2;
+    long long a_cw, a_cb, a_zw, a_zb, a_dw, a_db, a_rw, a_rb, a_dbng, a_dbnb;   // conv2d, dense (z), dense (dec), conv2d_1, decoder input BN
+    long long a_w1, a_b1, a_w2, a_b2, a_w3, a_b3, a_nd;                          // critic tensors, their total size
+    std::vector<float*> a_eg, a_cp;    // per encoder level: d loss / d c_i [2n] and BN column partials (both encoder passes)
+    float *a_xcat, *a_zm, *a_dzm, *a_dflat, *a_slab, *a_crit[3];                 // [x ; x_hat], z_ | z_rec, masked d z, d flat, critic slabs, d_fake / d_real / pen
     bool generic16;                    // UAD_MATH_BF16X3_ALL: generic contractions in bf16x3 too (opt-in, not parity-rated)
     struct RB {                        // pre-activation residual block: LN -> ReLU -> conv1 (k3 s1) -> LN -> ReLU -> conv2, + shortcut
         bool gen;                      // generator block: conv2 / shortcut are transposed convolutions
@@ -840,6 +981,199 @@ void disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float* 
     }
 }
 
+
+// ================================================================================================ AAE family
+// models/constrained_autoencoder.py, adversarial_autoencoder.py, constrained_adversarial_autoencoder.py on materialised activations.
+void bn_fwd(uad_gan* m, long long gamma, long long beta, float alpha, const float* c, size_t rows, int C, float* a, hipStream_t st) {
+    const size_t total4 = rows * C / 4;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks256(total4)), dim3(256), 0, st, c, P(m, gamma), P(m, beta), 1.0f / sqrtf(1.0f + kBnEps),
+                       alpha, total4, C, a);
+}
+// dc = da * act' * gamma'; column partials into `colpart`; returns the number of partial rows written
+int bn_bwd_partial(uad_gan* m, long long gamma, long long beta, float alpha, const float* da, const float* c, int rows, int C, float* dc,
+                   float* colpart, hipStream_t st) {
+    const int rpb = (rows + kBnBwdBlocks - 1) / kBnBwdBlocks;
+    const int blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(blocks), dim3(256), 0, st, da, c, P(m, gamma), P(m, beta), 1.0f / sqrtf(1.0f + kBnEps), alpha, rows,
+                       rpb, C, dc, colpart);
+    return blocks;
+}
+void bn_finalize(uad_gan* m, const float* colpart, int T, int C, long long gamma, long long beta, long long bias, hipStream_t st) {
+    uad_launch_bn_grad_finalize(colpart, T, C, P(m, gamma), 1.0f / sqrtf(1.0f + kBnEps), Gr(m, gamma), Gr(m, beta), bias >= 0 ? Gr(m, bias) : nullptr, st);
+}
+// encoder pass of n samples at sample offset `off` (0: x, n: x_hat); z (post dropout) lands in a_zm + off * zdim
+void a_encode(uad_gan* m, const float* x, const float* mask, int n, int off, hipStream_t st) {
+    const int r = m->cfg.inter_res, zd = m->cfg.zdim;
+    const float* in = x;
+    for (size_t i = 0; i < m->E.size(); ++i) {
+        const Block& L = m->E[i];
+        float* c = m->ec[i] + (size_t)off * asz(L);
+        float* a = m->ea[i + 1] + (size_t)off * asz(L);
+        conv_fwd(m, L, n, in, c, true, st);
+        bn_fwd(m, L.gamma, L.beta, kLrelu, c, (size_t)n * L.H * L.W, L.C, a, st);
+        in = a;
+    }
+    float* t = m->et + (size_t)off * m->flat;
+    uad_launch_conv_f(conv1x1_desc(n, r, r, m->cenc, m->cmid), in, no_xform(), P(m, m->a_cw), t, epi_bias(P(m, m->a_cb)), st, nullptr, m->ws);
+    uad_launch_conv_f(dense_desc(n, m->flat, zd), t, no_xform(), P(m, m->a_zw), m->a_zm + (size_t)off * zd, epi_bias(P(m, m->a_zb), mask), st, nullptr, m->ws);
+}
+// data-gradient chain of one encoder pass from d / d z (post dropout) in `dz`: leaves d c_i in a_eg[i] (+off) and the BN column
+// partials in a_cp[i] (rows [cp_row0, ...)); returns the partial-row count (identical for every level is NOT assumed: see cp_rows)
+void a_encode_backward(uad_gan* m, const float* dz, const float* mask, int n, int off, int* cp_rows, float* dx_out, hipStream_t st) {
+    const int r = m->cfg.inter_res, zd = m->cfg.zdim;
+    float* dzm = m->a_dzm + (size_t)off * zd;
+    uad_launch_mul(dz, mask, dzm, (size_t)n * zd, st);
+    float* dfl = m->a_dflat + (size_t)off * m->flat;
+    uad_launch_conv_d(dense_desc(n, m->flat, zd), dzm, no_xform(), P(m, m->a_zw), dfl, epi_bias(nullptr), st, nullptr, m->ws);
+    float* g = m->Ga; float* gn = m->Gb;
+    uad_launch_conv_d(conv1x1_desc(n, r, r, m->cenc, m->cmid), dfl, no_xform(), P(m, m->a_cw), g, epi_bias(nullptr), st, nullptr, m->ws);
+    for (int i = (int)m->E.size() - 1; i >= 0; --i) {
+        const Block& L = m->E[i];
+        float* dc = m->a_eg[i] + (size_t)off * asz(L);
+        const int T = bn_bwd_partial(m, L.gamma, L.beta, kLrelu, g, m->ec[i] + (size_t)off * asz(L), n * L.H * L.W, L.C, dc,
+                                     m->a_cp[i] + (size_t)cp_rows[i] * 2 * L.C, st);
+        cp_rows[i] += T;
+        if (i > 0) conv_dgrad(m, L, n, dc, g, st);
+        else if (dx_out) conv_dgrad(m, L, n, dc, dx_out, st);
+    }
+    (void)gn;
+}
+// parameter gradients of the encoder path over `rows_n` samples (both passes when constrained)
+void a_encode_wgrads(uad_gan* m, const float* x_all, int nall, const int* cp_rows, hipStream_t st) {
+    const int r = m->cfg.inter_res, zd = m->cfg.zdim;
+    uad_launch_conv_w(dense_desc(nall, m->flat, zd), m->et, no_xform(), m->a_dzm, no_xform(), Gr(m, m->a_zw), m->wpartial, st);
+    uad_launch_colsum(m->a_dzm, nall, zd, Gr(m, m->a_zb), m->colscratch, st);
+    uad_launch_conv_w(conv1x1_desc(nall, r, r, m->cenc, m->cmid), m->ea[m->E.size()], no_xform(), m->a_dflat, no_xform(), Gr(m, m->a_cw), m->wpartial, st);
+    uad_launch_colsum(m->a_dflat, nall * r * r, m->cmid, Gr(m, m->a_cb), m->colscratch, st);
+    for (size_t i = 0; i < m->E.size(); ++i) {
+        const Block& L = m->E[i];
+        bn_finalize(m, m->a_cp[i], cp_rows[i], L.C, L.gamma, L.beta, L.b, st);
+        conv_wgrad(m, L, nall, i == 0 ? x_all : m->ea[i], m->a_eg[i], st);
+    }
+}
+void a_decode(uad_gan* m, const float* z, const float* mask_dec, int n, hipStream_t st) {
+    const int r = m->cfg.inter_res;
+    uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), z, no_xform(), P(m, m->a_dw), m->gdv, epi_bias(P(m, m->a_db), mask_dec), st, nullptr, m->ws);
+    uad_launch_conv_f(conv1x1_desc(n, r, r, m->cmid, m->cenc), m->gdv, no_xform(), P(m, m->a_rw), m->gc[0], epi_bias(P(m, m->a_rb)), st, nullptr, m->ws);
+    bn_fwd(m, m->a_dbng, m->a_dbnb, 0.0f, m->gc[0], (size_t)n * r * r, m->cenc, m->ga[0], st);
+    for (size_t i = 0; i < m->G.size(); ++i) {
+        const Block& L = m->G[i];
+        convT_fwd(m, L, n, m->ga[i], m->gc[i + 1], st);
+        bn_fwd(m, L.gamma, L.beta, kLrelu, m->gc[i + 1], (size_t)n * L.H * L.W, L.C, m->ga[i + 1], st);
+    }
+    const Block& LL = m->G.back();
+    rowdot<0>(m->ga[m->G.size()], P(m, m->g_fw), P(m, m->g_fb), n * LL.H * LL.W, LL.C, m->xg, st);
+}
+// dxh = d loss / d x_hat; writes every decoder-path gradient and d / d z into dz_out
+void a_decode_backward(uad_gan* m, const float* z, const float* mask_dec, const float* dxh, int n, float* dz_out, hipStream_t st) {
+    const int r = m->cfg.inter_res;
+    const Block& LL = m->G.back();
+    const int rows = n * LL.H * LL.W;
+    float* g = m->Ga; float* gn = m->Gb;
+    {
+        const int rpb = (rows + 1023) / 1024, blocks = (rows + rpb - 1) / rpb;
+        hipLaunchKernelGGL(gfinal_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxh, m->xg, m->ga[m->G.size()], P(m, m->g_fw), rows, rpb, LL.C, 2, g, m->finpart);
+        uad_launch_reduce_partials(m->finpart, blocks, LL.C + 1, 1.0f, m->colscratch, st);
+        hipMemcpyAsync(Gr(m, m->g_fw), m->colscratch, LL.C * sizeof(float), hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(Gr(m, m->g_fb), m->colscratch + LL.C, sizeof(float), hipMemcpyDeviceToDevice, st);
+    }
+    for (int i = (int)m->G.size() - 1; i >= 0; --i) {
+        const Block& L = m->G[i];
+        const int T = bn_bwd_partial(m, L.gamma, L.beta, kLrelu, g, m->gc[i + 1], n * L.H * L.W, L.C, gn, m->colpart, st);
+        bn_finalize(m, m->colpart, T, L.C, L.gamma, L.beta, L.b, st);
+        convT_wgrad(m, L, n, m->ga[i], gn, st);
+        convT_dgrad(m, L, n, gn, g, st);
+    }
+    const int T = bn_bwd_partial(m, m->a_dbng, m->a_dbnb, 0.0f, g, m->gc[0], n * r * r, m->cenc, gn, m->colpart, st);
+    bn_finalize(m, m->colpart, T, m->cenc, m->a_dbng, m->a_dbnb, m->a_rb, st);
+    const UadConvDesc dc1 = conv1x1_desc(n, r, r, m->cmid, m->cenc), dd = dense_desc(n, m->cfg.zdim, m->flat);
+    uad_launch_conv_w(dc1, m->gdv, no_xform(), gn, no_xform(), Gr(m, m->a_rw), m->wpartial, st);
+    uad_launch_conv_d(dc1, gn, no_xform(), P(m, m->a_rw), m->ddv, epi_bias(nullptr, mask_dec), st, nullptr, m->ws);
+    uad_launch_conv_w(dd, z, no_xform(), m->ddv, no_xform(), Gr(m, m->a_dw), m->wpartial, st);
+    uad_launch_colsum(m->ddv, n, m->flat, Gr(m, m->a_db), m->colscratch, st);
+    uad_launch_conv_d(dd, m->ddv, no_xform(), P(m, m->a_dw), dz_out, epi_bias(nullptr), st, nullptr, m->ws);
+}
+void a_critic(uad_gan* m, int mode, const float* zf, const float* zr, const float* eps, int n, hipStream_t st) {
+    CriticArgs a;
+    memset(&a, 0, sizeof a);
+    a.zd = m->cfg.zdim; a.h1 = m->a_h1; a.h2 = m->a_h2; a.mode = mode;
+    a.W1 = P(m, m->a_w1); a.b1 = P(m, m->a_b1); a.W2 = P(m, m->a_w2); a.b2 = P(m, m->a_b2); a.W3 = P(m, m->a_w3); a.b3 = P(m, m->a_b3);
+    a.zf = zf; a.zr = zr; a.eps = eps; a.inv_n = 1.0f / (float)n; a.scale = m->cfg.scale;
+    a.d_fake = m->a_crit[0]; a.d_real = m->a_crit[1]; a.pen = m->a_crit[2]; a.slab = m->a_slab; a.dz_fake = m->dzbuf;
+    hipLaunchKernelGGL(critic_kernel, dim3(n), dim3(128), 0, st, a);
+}
+
+int aae_phase(uad_gan* m, int phase, const uad_gan_io_t* io, int n, int want_backward, hipStream_t st) {
+    if (!io->x) return fail(UAD_ERR_INVALID, "AAE-family phases need io.x");
+    const int H = m->cfg.height, zd = m->cfg.zdim;
+    const size_t img = (size_t)n * H * H;
+    float* scal = io->scalars ? io->scalars : m->scalars_own;
+    refresh_packs(m, st);
+    int cp_rows[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (phase == UAD_GAN_GENERATOR) {
+        // optim_ae (trainers/ConstrainedAE.py:42-45, AAE.py:54-56, ConstrainedAAE.py:59-62): loss = mean_n(L2_n [+ rho * Rec_z_n]) over every AE variable
+        a_encode(m, io->x, io->mask_z, n, 0, st);
+        a_decode(m, m->a_zm, io->mask_g, n, st);
+        reduce_to<1>(m, 0, io->x, m->xg, img, 1.0f / (float)img, nullptr, st);                   // mean_n L2_n
+        reduce_to<2>(m, 2, io->x, m->xg, img, 1.0f / (float)n, io->l1_map, st);                  // reconstructionLoss
+        if (m->a_constrained) {
+            a_encode(m, m->xg, io->mask_sigma, n, n, st);                                         // z_rec (mask_sigma = its dropout mask)
+            reduce_to<1>(m, 1, m->a_zm, m->a_zm + (size_t)n * zd, (size_t)n * zd, 1.0f / (float)((size_t)n * zd), nullptr, st);
+        } else {
+            HIP_TRY(hipMemsetAsync(m->raw + 1, 0, sizeof(float), st));
+        }
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, 4, m->raw, m->a_constrained ? m->cfg.rho : 0.0f, scal);
+        if (want_backward) {
+            hipLaunchKernelGGL((diff_scale_kernel<false>), dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, 2.0f / (float)img, img, m->dxbuf);
+            const float* x_all = io->x;
+            int nall = n;
+            if (m->a_constrained) {
+                // second encoder pass first: d Rec_z / d z_rec = -2 rho (z - z_rec) / (n zd), through the shared layers down to x_hat
+                const size_t nz = (size_t)n * zd;
+                const float cz = 2.0f * m->cfg.rho / (float)nz;
+                hipLaunchKernelGGL((diff_scale_kernel<false>), dim3(blocks256(nz)), dim3(256), 0, st, m->a_zm + nz, m->a_zm, cz, nz, m->dzr);       // cz (z_rec - z)
+                a_encode_backward(m, m->dzr, io->mask_sigma, n, n, cp_rows, m->Gx, st);
+                hipLaunchKernelGGL(add_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->dxbuf, m->Gx, img);      // + the path through z_rec
+                HIP_TRY(hipMemcpyAsync(m->a_xcat, io->x, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(m->a_xcat + img, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+                x_all = m->a_xcat; nall = 2 * n;
+            }
+            a_decode_backward(m, m->a_zm, io->mask_g, m->dxbuf, n, m->dzbuf, st);
+            if (m->a_constrained) {
+                const size_t nz = (size_t)n * zd;
+                hipLaunchKernelGGL((diff_scale_kernel<true>), dim3(blocks256(nz)), dim3(256), 0, st, m->a_zm, m->a_zm + nz, 2.0f * m->cfg.rho / (float)nz, nz, m->dzbuf);   // + 2 rho (z - z_rec)/(n zd)
+            }
+            a_encode_backward(m, m->dzbuf, io->mask_z, n, 0, cp_rows, nullptr, st);
+            a_encode_wgrads(m, x_all, nall, cp_rows, st);
+        }
+        if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->a_zm, (size_t)n * zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return UAD_OK;
+    }
+    if (!m->a_critic) return fail(UAD_ERR_INVALID, "this model has no latent critic: only the autoencoder phase exists");
+    a_encode(m, io->x, io->mask_z, n, 0, st);
+    if (phase == UAD_GAN_DISCRIMINATOR) {
+        // optim_dis (trainers/AAE.py:41-49,64): mean d_ - mean d + mean((||d d_hat/d z_hat|| - 1)^2 scale) over the Discriminator variables
+        if (!io->z || !io->alpha) return fail(UAD_ERR_INVALID, "critic phase needs io.z (prior sample) and io.alpha (eps)");
+        a_critic(m, 0, m->a_zm, io->z, io->alpha, n, st);
+        reduce_to<0>(m, 0, m->a_crit[0], nullptr, (size_t)n, 1.0f / (float)n, nullptr, st);
+        reduce_to<0>(m, 1, m->a_crit[1], nullptr, (size_t)n, 1.0f / (float)n, nullptr, st);
+        reduce_to<0>(m, 2, m->a_crit[2], nullptr, (size_t)n, 1.0f, nullptr, st);
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, UAD_GAN_DISCRIMINATOR, m->raw, 0.0f, scal);
+        if (want_backward) uad_launch_reduce_partials(m->a_slab, n, (int)m->a_nd, 1.0f, Gr(m, m->a_w1), st);
+    } else {
+        // optim_gen (:43,65): -mean d_ over the variables whose name contains 'Encoder'
+        a_critic(m, 1, m->a_zm, nullptr, nullptr, n, st);
+        reduce_to<0>(m, 0, m->a_crit[0], nullptr, (size_t)n, 1.0f / (float)n, nullptr, st);
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, UAD_GAN_GENERATOR, m->raw, 0.0f, scal);
+        if (want_backward) {
+            a_encode_backward(m, m->dzbuf, io->mask_z, n, 0, cp_rows, nullptr, st);
+            a_encode_wgrads(m, io->x, n, cp_rows, st);
+        }
+    }
+    if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->a_zm, (size_t)n * zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return UAD_OK;
+}
 
 // ================================================================================================ ResNet variant
 // models/fanogan_schlegl.py:119-161.  Every k3 / k1 contraction runs on the generic F / D / W kernels (any KS / S / P).
@@ -1232,6 +1566,133 @@ static int create_resnet(const uad_gan_config_t* cfg, uad_gan_t** out) {
     return UAD_OK;
 }
 
+// ---- handle of the AAE family (ConstrainedAE / AAE / ConstrainedAAE); parameter table in TF first-call order ----
+static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
+    const int H = cfg->height, ir = cfg->inter_res;
+    if (cfg->aae_kind < 0 || cfg->aae_kind > 2) return fail(UAD_ERR_INVALID, "bad aae_kind");
+    const int npool = ilog2i(H) - ilog2i(ir);
+    if (npool < 2 || npool > 5) return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 2..5 blocks supported", npool);
+    if (cfg->zdim > kCritMaxZ) return fail(UAD_ERR_UNSUPPORTED, "zDim <= %d", kCritMaxZ);
+    uad_gan* m = new uad_gan();
+    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->dim = 0; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1;
+    m->aae_kind = cfg->aae_kind; m->a_constrained = cfg->aae_kind != 1; m->a_critic = cfg->aae_kind != 0;
+    m->a_h1 = cfg->aae_kind == 2 ? 100 : 50; m->a_h2 = 50;
+    m->npool = npool; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
+    m->step[0] = m->step[1] = m->step[2] = 0;
+    char nm[160];
+    int cin = 1, res = H;
+    for (int i = 0; i < npool; ++i) {
+        const int f = (32 << i) < 128 ? (32 << i) : 128;
+        Block L;
+        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
+        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
+        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        std::string bs = i == 0 ? "Encoder/batch_normalization" : "Encoder/batch_normalization_" + std::to_string(i);
+        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
+        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
+        L.H = L.W = res / 2; L.C = f;
+        m->E.push_back(L);
+        cin = f; res /= 2;
+    }
+    m->cenc = cin; m->cmid = cin / 8; m->flat = ir * ir * m->cmid;
+    if (m->cmid % 8 || m->flat % 8) { delete m; return fail(UAD_ERR_UNSUPPORTED, "bottleneck channels must be a multiple of 8"); }
+    const bool caae = cfg->aae_kind == 2;       // constrained_adversarial_autoencoder.py: conv2d / dense live in 'Encoder', dense (dec) / conv2d_1 in 'Decoder'
+    const std::string n_conv = caae ? "Encoder/conv2d" : "Bottleneck/conv2d", n_z = caae ? "Encoder/dense" : "Bottleneck/dense";
+    const std::string n_dec = caae ? "Decoder/dense" : "Bottleneck/dense_1", n_rev = caae ? "Decoder/conv2d_1" : "Bottleneck/conv2d_1";
+    m->a_cw = add_tensor(m, n_conv + "/kernel", 4, 1, 1, m->cenc, m->cmid); m->a_cb = add_tensor(m, n_conv + "/bias", 1, m->cmid, 1, 1, 1);
+    m->a_zw = add_tensor(m, n_z + "/kernel", 2, m->flat, cfg->zdim, 1, 1); m->a_zb = add_tensor(m, n_z + "/bias", 1, cfg->zdim, 1, 1, 1);
+    const long long gen_end_caae = m->nparams;        // 'Encoder' in name: blocks + conv2d + dense
+    long long gen_end = caae ? gen_end_caae : m->a_cw;  // AAE: the encoder blocks only (the bottleneck lives in 'Bottleneck')
+    m->a_dw = add_tensor(m, n_dec + "/kernel", 2, cfg->zdim, m->flat, 1, 1); m->a_db = add_tensor(m, n_dec + "/bias", 1, m->flat, 1, 1, 1);
+    m->a_rw = add_tensor(m, n_rev + "/kernel", 4, 1, 1, m->cmid, m->cenc); m->a_rb = add_tensor(m, n_rev + "/bias", 1, m->cenc, 1, 1, 1);
+    m->a_dbng = add_tensor(m, "Decoder/batch_normalization/gamma", 1, m->cenc, 1, 1, 1);
+    m->a_dbnb = add_tensor(m, "Decoder/batch_normalization/beta", 1, m->cenc, 1, 1, 1);
+    cin = m->cenc; res = ir;
+    for (int i = 0; i < npool; ++i) {
+        const int f = (128 >> i) > 32 ? (128 >> i) : 32;
+        Block L;
+        L.d = UadConvDesc{1, res * 2, res * 2, f, res, res, cin, 5, 2, 1};
+        snprintf(nm, sizeof nm, "Decoder/dec_Conv2DT_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, f, cin);
+        snprintf(nm, sizeof nm, "Decoder/dec_Conv2DT_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
+        res *= 2;
+        const std::string bs = "Decoder/batch_normalization_" + std::to_string(i + 1);
+        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
+        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
+        L.H = L.W = res; L.C = f;
+        m->G.push_back(L);
+        cin = f;
+    }
+    m->g_fw = add_tensor(m, "Decoder/dec_Conv2D_final/kernel", 4, 1, 1, cin, 1);
+    m->g_fb = add_tensor(m, "Decoder/dec_Conv2D_final/bias", 1, 1, 1, 1, 1);
+    const long long ae_end = m->nparams;
+    m->a_w1 = m->a_b1 = m->a_w2 = m->a_b2 = m->a_w3 = m->a_b3 = -1; m->a_nd = 0;
+    if (m->a_critic) {
+        m->a_w1 = add_tensor(m, "Discriminator/dense/kernel", 2, cfg->zdim, m->a_h1, 1, 1); m->a_b1 = add_tensor(m, "Discriminator/dense/bias", 1, m->a_h1, 1, 1, 1);
+        m->a_w2 = add_tensor(m, "Discriminator/dense_1/kernel", 2, m->a_h1, m->a_h2, 1, 1); m->a_b2 = add_tensor(m, "Discriminator/dense_1/bias", 1, m->a_h2, 1, 1, 1);
+        m->a_w3 = add_tensor(m, "Discriminator/dense_2/kernel", 2, m->a_h2, 1, 1, 1); m->a_b3 = add_tensor(m, "Discriminator/dense_2/bias", 1, 1, 1, 1, 1);
+        m->a_nd = m->nparams - ae_end;
+    }
+    // groups: 0 = optim_gen ('Encoder' variables, a prefix), 1 = optim_ae (every autoencoder variable), 2 = optim_dis
+    m->grp_off[0] = 0; m->grp_cnt[0] = gen_end;
+    m->grp_off[1] = 0; m->grp_cnt[1] = ae_end;
+    m->grp_off[2] = ae_end; m->grp_cnt[2] = m->nparams - ae_end;
+
+    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H, E2 = m->a_constrained ? 2 * NB : NB;
+    int rc = UAD_OK;
+#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
+    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
+    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
+    ALLOC(m->adam_m2, (size_t)m->nparams, nullptr); ALLOC(m->adam_v2, (size_t)m->nparams, nullptr);
+    ALLOC(m->wpack_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack_d, (size_t)m->nparams, nullptr);
+    ALLOC(m->wpack16_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack16_d, (size_t)m->nparams, nullptr);
+    size_t maxact = NB * HW;
+    m->ec.resize(npool); m->ea.resize(npool + 1, nullptr); m->a_eg.resize(npool); m->a_cp.resize(npool);
+    for (int i = 0; i < npool; ++i) {
+        const size_t sz = E2 * asz(m->E[i]);
+        snprintf(nm, sizeof nm, "ec%d", i); ALLOC(m->ec[i], sz, nm);
+        snprintf(nm, sizeof nm, "ea%d", i + 1); ALLOC(m->ea[i + 1], sz, nm);
+        ALLOC(m->a_eg[i], sz, nullptr);
+        ALLOC(m->a_cp[i], (size_t)2 * kBnBwdBlocks * 2 * m->E[i].C, nullptr);
+        if (NB * asz(m->E[i]) > maxact) maxact = NB * asz(m->E[i]);
+    }
+    ALLOC(m->et, E2 * m->flat, "et"); ALLOC(m->a_zm, E2 * cfg->zdim, "z"); ALLOC(m->a_dzm, E2 * cfg->zdim, nullptr);
+    ALLOC(m->a_dflat, E2 * m->flat, nullptr); ALLOC(m->a_xcat, E2 * HW, nullptr);
+    ALLOC(m->gdv, NB * m->flat, "gdv"); ALLOC(m->xg, NB * HW, "xg"); ALLOC(m->ddv, NB * m->flat, nullptr);
+    m->gc.resize(npool + 1); m->ga.resize(npool + 1);
+    for (int i = 0; i <= npool; ++i) {
+        const size_t per = i == 0 ? (size_t)ir * ir * m->cenc : asz(m->G[i - 1]);
+        snprintf(nm, sizeof nm, "gc%d", i); ALLOC(m->gc[i], NB * per, nm);
+        snprintf(nm, sizeof nm, "ga%d", i); ALLOC(m->ga[i], NB * per, nm);
+        if (NB * per > maxact) maxact = NB * per;
+    }
+    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
+    ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->Gx, NB * HW, "Gx"); ALLOC(m->dzbuf, NB * cfg->zdim, "dz"); ALLOC(m->dzr, NB * cfg->zdim, nullptr);
+    m->a_slab = nullptr; m->a_crit[0] = m->a_crit[1] = m->a_crit[2] = nullptr;
+    if (m->a_critic) { ALLOC(m->a_slab, NB * (size_t)m->a_nd, nullptr); for (int k = 0; k < 3; ++k) ALLOC(m->a_crit[k], NB, nullptr); }
+    {
+        size_t wp = 0, need = (size_t)4 << 20;
+        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
+        auto want = [&](UadConvDesc d, size_t n, bool pack) { d.N = (int)n; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, pack); if (v > need) need = v; } };
+        for (size_t i = 1; i < m->E.size(); ++i) { wp_need(m->E[i].d, E2); want(m->E[i].d, NB, true); }
+        for (auto& L : m->G) { wp_need(L.d, NB); want(L.d, NB, true); }
+        wp_need(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), E2); wp_need(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB);
+        wp_need(dense_desc(1, m->flat, cfg->zdim), E2); wp_need(dense_desc(1, cfg->zdim, m->flat), NB);
+        want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), NB, false); want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB, false);
+        want(dense_desc(1, m->flat, cfg->zdim), NB, false); want(dense_desc(1, cfg->zdim, m->flat), NB, false);
+        { UadConvDesc d0 = m->E[0].d; d0.N = (int)E2; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
+        ALLOC(m->wpartial, wp, nullptr);
+        m->ws.floats = need; m->ws.ptr = nullptr;
+        ALLOC(m->ws.ptr, need, nullptr);
+    }
+    ALLOC(m->colscratch, 64 * 1024, nullptr); ALLOC(m->colpart, (size_t)kBnBwdBlocks * 2 * 128, nullptr);
+    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
+    ALLOC(m->finpart, (size_t)1024 * 65, nullptr);
+#undef ALLOC
+    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
+    *out = m;
+    return UAD_OK;
+}
+
 int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (!cfg || !out) return fail(UAD_ERR_INVALID, "null argument");
     const int H = cfg->height;
@@ -1241,7 +1702,9 @@ int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
     if (cfg->zdim <= 0 || cfg->zdim % 8) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
     if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
-    if (cfg->variant != UAD_GAN_UNIFIED && cfg->variant != UAD_GAN_RESNET && cfg->variant != UAD_GAN_ANOVAEGAN) return fail(UAD_ERR_INVALID, "bad variant");
+    if (cfg->variant != UAD_GAN_UNIFIED && cfg->variant != UAD_GAN_RESNET && cfg->variant != UAD_GAN_ANOVAEGAN && cfg->variant != UAD_GAN_AAE)
+        return fail(UAD_ERR_INVALID, "bad variant");
+    if (cfg->variant == UAD_GAN_AAE) return create_aae(cfg, out);
     if (cfg->variant == UAD_GAN_RESNET) return create_resnet(cfg, out);
     const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
     if (npool < 2 || npool > 5) return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 2..5 blocks supported", npool);
@@ -1498,6 +1961,12 @@ int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int wa
     if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
     if (phase < 0 || phase > 2) return fail(UAD_ERR_INVALID, "bad phase");
     hipStream_t st = (hipStream_t)stream;
+    if (m->variant == UAD_GAN_AAE) {
+        const int rc = aae_phase(m, phase, io, n, want_backward, st);
+        if (rc != UAD_OK) return rc;
+        HIP_TRY(hipGetLastError());
+        return UAD_OK;
+    }
     const bool rn = m->variant == UAD_GAN_RESNET;
     const bool av = m->variant == UAD_GAN_ANOVAEGAN;      // the generator's input is the encoder's z_vae, never io->z
     if (av && !io->x) return fail(UAD_ERR_INVALID, "AnoVAE-GAN phases need io.x");
@@ -1662,11 +2131,12 @@ int uad_gan_reconstruct(uad_gan_t* m, const uad_gan_io_t* io, int n, void* strea
     hipStream_t st = (hipStream_t)stream;
     const size_t img = (size_t)n * m->cfg.height * m->cfg.width;
     refresh_packs(m, st);
-    if (m->variant == UAD_GAN_RESNET) { s_enc_forward(m, io->x, n, st); s_gen_forward(m, m->z, n, st); }
+    if (m->variant == UAD_GAN_AAE) { a_encode(m, io->x, io->mask_z, n, 0, st); a_decode(m, m->a_zm, io->mask_g, n, st); }
+    else if (m->variant == UAD_GAN_RESNET) { s_enc_forward(m, io->x, n, st); s_gen_forward(m, m->z, n, st); }
     else if (m->variant == UAD_GAN_ANOVAEGAN) { v_enc_forward(m, io, n, st); gen_forward(m, m->z, nullptr, n, st); }
     else { enc_forward(m, io->x, io->mask_z, n, st); gen_forward(m, m->z, io->mask_g, n, st); }
     if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->variant == UAD_GAN_AAE ? m->a_zm : m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (io->l1_map) hipLaunchKernelGGL((sum_kernel<2>), dim3(256), dim3(256), 0, st, io->x, m->xg, img, io->l1_map, m->redpart);
     HIP_TRY(hipGetLastError());
     return UAD_OK;
@@ -1679,7 +2149,10 @@ int uad_gan_adam(uad_gan_t* m, int group, float lr, float beta1, float beta2, fl
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
     const long long off = m->grp_off[group];
     m->packed_valid = false;
-    uad_launch_adam(m->params + off, m->grads + off, m->adam_m + off, m->adam_v + off, (size_t)m->grp_cnt[group], lr_t, beta1, beta2,
+    // AAE family: optim_gen (group 0) shares its variables with optim_ae (group 1) and keeps slots of its own
+    float* am = (m->variant == UAD_GAN_AAE && group == 0) ? m->adam_m2 : m->adam_m;
+    float* avv = (m->variant == UAD_GAN_AAE && group == 0) ? m->adam_v2 : m->adam_v;
+    uad_launch_adam(m->params + off, m->grads + off, am + off, avv + off, (size_t)m->grp_cnt[group], lr_t, beta1, beta2,
                     eps, grad_scale, (hipStream_t)stream);
     if (m->variant == UAD_GAN_ANOVAEGAN && group == UAD_GAN_ENCODER) {
         // optim_vae also owns the Generator variables (trainers/AnoVAEGAN.py:84), with slots of its own and the same step count

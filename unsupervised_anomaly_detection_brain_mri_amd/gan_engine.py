@@ -15,19 +15,23 @@ GROUPS = {'Encoder': _lib.GAN_ENCODER, 'Generator': _lib.GAN_GENERATOR, 'Discrim
 
 class GanEngine(_EvalOps):
     def __init__(self, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, scale=10.0, kappa=1.0,
-                 device=None, math='bf16x3', variant='unified', dim=64, kl_weight=1.0):
+                 device=None, math='bf16x3', variant='unified', dim=64, kl_weight=1.0, aae_kind='aae', rho=1.0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         torch.cuda.set_device(self.device)
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
-        variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET, 'anovaegan': _lib.GAN_ANOVAEGAN}
+        variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET, 'anovaegan': _lib.GAN_ANOVAEGAN, 'aae': _lib.GAN_AAE}
+        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2}
+        if variant == 'aae' and aae_kind not in kinds:
+            raise ValueError(f'unknown aae_kind {aae_kind!r}')
+        self.aae_kind = aae_kind if variant == 'aae' else None
         if variant not in variants:
             raise ValueError(f'unknown f-AnoGAN variant {variant!r}')
         self.variant, self.dim = variant, int(dim)
         cfg = _lib.UadGanConfig(height, width, channels, inter_res, zdim, max_batch, float(scale), float(kappa), variants[variant],
-                                int(dim), float(kl_weight))
+                                int(dim), float(kl_weight), kinds.get(aae_kind, 1), float(rho))
         h = C.c_void_p()
         _lib.check(self.lib.uad_gan_create(C.byref(cfg), C.byref(h)))
         self.handle = h
@@ -38,7 +42,8 @@ class GanEngine(_EvalOps):
         for i in range(self.lib.uad_gan_num_tensors(h)):
             _lib.check(self.lib.uad_gan_tensor_info(h, i, name, 160, C.byref(off), C.byref(rank), shape))
             self.spec.append((name.value.decode(), tuple(shape[:rank.value]), int(off.value)))
-        self.flat = [s for n, s, _ in self.spec if n == 'Generator/dense/kernel'][0][1]
+        dec_dense = {'constrained_ae': 'Bottleneck/dense_1/kernel', 'aae': 'Bottleneck/dense_1/kernel', 'constrained_aae': 'Decoder/dense/kernel'}
+        self.flat = [s for n, s, _ in self.spec if n == (dec_dense[aae_kind] if variant == 'aae' else 'Generator/dense/kernel')][0][1]
         self._views = {}
         self.set_math(math)
 
@@ -71,7 +76,8 @@ class GanEngine(_EvalOps):
 
     def group(self, group):
         off, cnt = C.c_longlong(), C.c_longlong()
-        _lib.check(self.lib.uad_gan_group(self.handle, GROUPS.get(group, group), C.byref(off), C.byref(cnt)))
+        gid = _lib.GAN_GENERATOR if (self.variant == 'aae' and group == 'AE') else GROUPS.get(group, group)
+        _lib.check(self.lib.uad_gan_group(self.handle, gid, C.byref(off), C.byref(cnt)))
         return int(off.value), int(cnt.value)
 
     def set_params(self, params):
@@ -104,17 +110,20 @@ class GanEngine(_EvalOps):
         zeros = np.zeros(self.nparams, np.float32)
         self.set_buffer_host(_lib.BUF_ADAM_M, zeros)
         self.set_buffer_host(_lib.BUF_ADAM_V, zeros)
-        if self.variant == 'anovaegan':
+        if self.variant in ('anovaegan', 'aae'):
             self.set_buffer_host(_lib.BUF_ADAM_M2, zeros)
             self.set_buffer_host(_lib.BUF_ADAM_V2, zeros)
         for g in ('Encoder', 'Generator', 'Discriminator'):
             self.set_step_count(g, 0)
 
+    def _gid(self, group):
+        return _lib.GAN_GENERATOR if (self.variant == 'aae' and group == 'AE') else GROUPS.get(group, group)
+
     def step_count(self, group):
-        return int(self.lib.uad_gan_get_step(self.handle, GROUPS.get(group, group)))
+        return int(self.lib.uad_gan_get_step(self.handle, self._gid(group)))
 
     def set_step_count(self, group, t):
-        _lib.check(self.lib.uad_gan_set_step(self.handle, GROUPS.get(group, group), int(t)))
+        _lib.check(self.lib.uad_gan_set_step(self.handle, self._gid(group), int(t)))
 
     def debug_buffer(self, name):
         """tests: torch view of a named intermediate of the last phase."""
@@ -135,6 +144,43 @@ class GanEngine(_EvalOps):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---------------------------------------------------------------- phases
+    def aae_phase(self, which, x, z=None, eps=None, mask_z=None, mask_dec=None, mask_rec=None, want_backward=True, want_images=True,
+                  want_l1=False):
+        """AAE family (variant 'aae').  which: 'AE' (optim_ae: loss = mean(L2 [+ rho Rec_z]) over every autoencoder variable) |
+        'Discriminator' (optim_dis; z = prior sample [n,zDim], eps [n] of z_hat = z + eps (z - z_)) | 'Encoder' (optim_gen: -mean d_).
+        Returns device tensors: AE -> loss, L2, Rec_z, reconstructionLoss, reconstruction, z, L1; critic -> disc_loss, disc_fake,
+        disc_real, penalty; generator -> gen_loss."""
+        if self.variant != 'aae':
+            raise ValueError('aae_phase needs an AAE-family engine')
+        g = {'AE': _lib.GAN_GENERATOR, 'Discriminator': _lib.GAN_DISCRIMINATOR, 'Encoder': _lib.GAN_ENCODER}[which]
+        n = x.shape[0]
+        img = (n, self.h, self.w, self.c)
+        x = self._dev(x, img)
+        z = self._dev(z, (n, self.zdim))
+        eps = self._dev(None if eps is None else (eps.reshape(-1) if isinstance(eps, torch.Tensor) else np.asarray(eps, np.float32).reshape(-1)), (n,))
+        mask_z, mask_rec = self._dev(mask_z, (n, self.zdim)), self._dev(mask_rec, (n, self.zdim))
+        mask_dec = self._dev(mask_dec, (n, self.flat))
+        out, scal = {}, torch.zeros(16, device=self.device)
+        io = _lib.UadGanIO()
+        io.x, io.z, io.alpha, io.mask_z, io.mask_g, io.mask_sigma, io.scalars = _ptr(x), _ptr(z), _ptr(eps), _ptr(mask_z), _ptr(mask_dec), _ptr(mask_rec), _ptr(scal)
+        if g == _lib.GAN_GENERATOR:
+            if want_images:
+                out['reconstruction'] = torch.empty(img, device=self.device); io.reconstruction = _ptr(out['reconstruction'])
+            out['z'] = torch.empty((n, self.zdim), device=self.device); io.z_enc = _ptr(out['z'])
+            if want_l1:
+                out['L1'] = torch.empty(img, device=self.device); io.l1_map = _ptr(out['L1'])
+        _lib.check(self.lib.uad_gan_phase(self.handle, g, C.byref(io), n, 1 if want_backward else 0, self._stream()))
+        S = _lib.GAN_SCALARS
+        if g == _lib.GAN_GENERATOR:
+            out.update(L2=scal[S.index('loss_img')], Rec_z=scal[S.index('loss_fts')], loss=scal[S.index('enc_loss')],
+                       reconstructionLoss=scal[S.index('reconstructionLoss')])
+        elif g == _lib.GAN_DISCRIMINATOR:
+            out.update({k: scal[S.index(k)] for k in ('disc_fake', 'disc_real', 'penalty', 'disc_loss')})
+        else:
+            out['gen_loss'] = scal[S.index('gen_loss')]
+        self._keep = (x, z, eps, mask_z, mask_dec, mask_rec, scal, out)
+        return out
+
     def phase(self, group, x=None, z=None, alpha=None, mask_z=None, mask_g=None, want_backward=True, want_images=True,
               want_l1=False, eps=None, mask_sigma=None):
         """Run one phase ('Generator' | 'Discriminator' | 'Encoder').  Returns a dict of device tensors: the 0-d losses of the
@@ -188,7 +234,9 @@ class GanEngine(_EvalOps):
         return out
 
     def adam(self, group, lr, beta1=0.5, beta2=0.9, eps=1e-8, grad_scale=1.0):
-        _lib.check(self.lib.uad_gan_adam(self.handle, GROUPS[group], lr, beta1, beta2, eps, grad_scale, self._stream()))
+        """group: 'Encoder' | 'Generator' | 'Discriminator'; for the AAE family 'AE' (= optim_ae), 'Discriminator', 'Encoder' (= optim_gen)."""
+        gid = _lib.GAN_GENERATOR if (self.variant == 'aae' and group == 'AE') else GROUPS[group]
+        _lib.check(self.lib.uad_gan_adam(self.handle, gid, lr, beta1, beta2, eps, grad_scale, self._stream()))
 
     def reconstruct(self, x, mask_z=None, mask_g=None, want_l1=False, eps=None, mask_sigma=None):
         n = x.shape[0]

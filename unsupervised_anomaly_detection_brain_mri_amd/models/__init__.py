@@ -9,3 +9,6 @@ from .fanogan import fanogan  # noqa: F401
 from .fanogan_schlegl import fanogan_schlegl  # noqa: F401
 from .autoencoder_spatial import autoencoder_spatial  # noqa: F401
 from .anovaegan import anovaegan  # noqa: F401
+from .constrained_autoencoder import constrained_autoencoder  # noqa: F401
+from .adversarial_autoencoder import adversarial_autoencoder  # noqa: F401
+from .constrained_adversarial_autoencoder import constrained_adversarial_autoencoder  # noqa: F401
