@@ -1,0 +1,56 @@
+"""Times the phases of the materialised-graph handles (AAE family, AnoVAE-GAN, f-AnoGAN) at 128x128 (64x64 for the ResNet graph),
+batch 64 (32): ms per phase incl. its Adam step, HIP-event timed over 20 repetitions."""
+import json, sys
+import numpy as np, torch
+sys.path.insert(0, '.')
+from unsupervised_anomaly_detection_brain_mri_amd.gan_engine import GanEngine
+from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import synthetic_slices
+
+
+def init(eng):
+    rng = np.random.default_rng(3)
+    flat = np.zeros(eng.nparams, np.float32)
+    for name, shape, off in eng.spec:
+        cnt = int(np.prod(shape))
+        if name.endswith('kernel'):
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            lim = np.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf)); flat[off:off + cnt] = rng.uniform(-lim, lim, cnt)
+        elif name.endswith('gamma'):
+            flat[off:off + cnt] = 1.0
+    eng.set_params(flat)
+
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return round(a.elapsed_time(b) / reps, 3)
+
+
+res = {}
+g = torch.Generator(device='cuda').manual_seed(1)
+for kind in ('constrained_ae', 'aae', 'constrained_aae'):
+    h, bs, zd = 128, 64, 128
+    eng = GanEngine(h, h, 1, 8, zd, max_batch=bs, variant='aae', aae_kind=kind)
+    init(eng)
+    x = torch.from_numpy(synthetic_slices(bs, h, h, seed=1)).cuda()
+    z = torch.randn(bs, zd, device='cuda', generator=g); e = torch.rand(bs, device='cuda', generator=g)
+    r = {'AE': timed(lambda: (eng.aae_phase('AE', x, want_images=False), eng.adam('AE', 1e-4)))}
+    if kind != 'constrained_ae':
+        r['Discriminator'] = timed(lambda: (eng.aae_phase('Discriminator', x, z=z, eps=e), eng.adam('Discriminator', 1e-4)))
+        r['Encoder(gen)'] = timed(lambda: (eng.aae_phase('Encoder', x), eng.adam('Encoder', 1e-4)))
+    res[kind + '_128_b64_ms'] = r
+    eng.close()
+eng = GanEngine(128, 128, 1, 8, 128, max_batch=64, variant='anovaegan')
+init(eng)
+x = torch.from_numpy(synthetic_slices(64, 128, 128, seed=1)).cuda()
+z = torch.randn(64, 128, device='cuda', generator=g); e = torch.rand(64, device='cuda', generator=g)
+res['anovaegan_128_b64_ms'] = {'VAE': timed(lambda: (eng.phase('Encoder', x=x, eps=z, want_images=False), eng.adam('Encoder', 1e-4))),
+                               'Generator': timed(lambda: (eng.phase('Generator', x=x, eps=z, want_images=False), eng.adam('Generator', 1e-4))),
+                               'Discriminator': timed(lambda: (eng.phase('Discriminator', x=x, eps=z, alpha=e, want_images=False), eng.adam('Discriminator', 1e-4)))}
+eng.close()
+print(json.dumps(res))
