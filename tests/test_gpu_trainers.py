@@ -344,3 +344,31 @@ def test_latent_ae_trainers(tmp_path, tname, mname):
     assert m2.load_checkpoint() == 1 and np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w)
     assert [m2.engine.step_count(g) for g in ('Encoder', 'AE', 'Discriminator')] == steps
     m2.engine.close()
+
+
+def test_tf_checkpoint_export_and_resume(tmp_path):
+    """save_tf() writes a TF-V2 tensor bundle under the reference's variable names; a fresh trainer's load() reads it back (weights,
+    Adam slots and the step count recovered from beta1_power), and the next train step is bit-identical to continuing in place."""
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import tf_checkpoint
+    cfg, opt, ds = _config(VAE, tmp_path, epochs=1)
+    model = VAE(None, cfg, network=variational_autoencoder)
+    model.train(ds)
+    prefix = model.save_tf(model.checkpointDir, 1)
+    names = set(tf_checkpoint.read_index(prefix + '.index')[1])
+    assert {'Encoder/enc_conv2D_0/kernel', 'Encoder/enc_conv2D_0/kernel/Adam', 'Encoder/enc_conv2D_0/kernel/Adam_1', 'beta1_power'} <= names
+    w, m, v = (model.engine.get_buffer_host(b) for b in (_lib.BUF_PARAMS, _lib.BUF_ADAM_M, _lib.BUF_ADAM_V))
+    t = model.engine.step_count
+    ck = os.path.join(model.checkpointDir, model.model_dir)
+    os.remove(os.path.join(ck, 'VAE.model-1.npz'))                # leave only the TF bundle
+    cfg2, _, _ = _config(VAE, tmp_path, epochs=1)
+    m2 = VAE(None, cfg2, network=variational_autoencoder, seed=5)
+    ok, counter = m2.load(m2.checkpointDir)
+    assert ok and counter == 1 and m2.engine.step_count == t
+    for b, ref in ((_lib.BUF_PARAMS, w), (_lib.BUF_ADAM_M, m), (_lib.BUF_ADAM_V, v)):
+        assert np.array_equal(m2.engine.get_buffer_host(b), ref)
+    x = synthetic_slices(8, 64, 64, seed=3)
+    eps = np.random.default_rng(0).standard_normal((8, 64)).astype(np.float32)
+    for mod in (model, m2):
+        mod.engine.train_step(x, eps=eps, masks=None, lr=1e-3)
+    assert np.array_equal(model.engine.get_buffer_host(_lib.BUF_PARAMS), m2.engine.get_buffer_host(_lib.BUF_PARAMS))
+    model.engine.close(); m2.engine.close()

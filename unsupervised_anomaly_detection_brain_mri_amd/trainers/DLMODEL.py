@@ -1,5 +1,5 @@
 """trainers/DLMODEL.py — base class: Config, save/load, optimizer validation.  The TF session / Saver are replaced by
-the HIP engine handle and a flat-fp32 .npz checkpoint (the TF checkpoint FORMAT is out of scope, SURVEY.md §2 row 6;
+the HIP engine handle and a flat-fp32 .npz checkpoint (TF tensor-bundle checkpoints are read / exported via utils/tf_checkpoint.py;
 the directory layout, file names and resume-by-epoch behaviour are kept: DLMODEL.py:63-110)."""
 import json
 import os
@@ -97,8 +97,38 @@ class DLMODEL(object):
             counter = int(next(re.finditer(r'(\d+)(?!.*\d)', name)).group(0))
             print(" [*] Success to read {}".format(name))
             return True, counter
+        if name and os.path.isfile(os.path.join(checkpoint_dir, name + '.index')):
+            # a TensorFlow V2 checkpoint written by the reference's tf.train.Saver (DLMODEL.py:63-83): same variable names as the spec
+            from ..utils import tf_checkpoint
+            got = tf_checkpoint.bundle_to_flat(self.engine.spec, tf_checkpoint.read_checkpoint(os.path.join(checkpoint_dir, name)),
+                                               beta1=getattr(self.config, 'beta1', 0.5))
+            if got['missing']:
+                raise ValueError(f"TF checkpoint {name} lacks variables of this model: {got['missing'][:4]} ...")
+            self.engine.set_params(got['params'])
+            if got['adam_m'] is not None:
+                self.engine.set_buffer_host(_lib.BUF_ADAM_M, got['adam_m'])
+                self.engine.set_buffer_host(_lib.BUF_ADAM_V, got['adam_v'])
+                if got['adam_t'] is not None:
+                    self._set_adam_steps(np.full(np.shape(self._adam_steps()), got['adam_t'], np.int64))
+            counter = int(next(re.finditer(r'(\d+)(?!.*\d)', name)).group(0))
+            print(" [*] Success to read TF checkpoint {}".format(name))
+            return True, counter
         print(" [*] Failed to find a checkpoint")
         return False, 0
+
+    def save_tf(self, checkpoint_dir, step):
+        """Exports the model as a TensorFlow V2 tensor bundle (<modelname>.model-<step>.index / .data-00000-of-00001) under the
+        reference's variable names, for tf.train.Saver().restore on the reference side."""
+        from ..utils import tf_checkpoint
+        checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        eng = self.engine
+        t = int(np.atleast_1d(self._adam_steps())[0])
+        prefix = os.path.join(checkpoint_dir, f'{self.config.modelname}.model-{step}')
+        tf_checkpoint.write_checkpoint(prefix, tf_checkpoint.flat_to_bundle(
+            eng.spec, eng.get_buffer_host(_lib.BUF_PARAMS), eng.get_buffer_host(_lib.BUF_ADAM_M), eng.get_buffer_host(_lib.BUF_ADAM_V),
+            t, beta1=getattr(self.config, 'beta1', 0.5), beta2=getattr(self.config, 'beta2', 0.999)))
+        return prefix
 
     def get_number_of_trainable_params(self):
         scopes = {}
