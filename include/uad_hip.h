@@ -143,7 +143,8 @@ int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float be
                    void* stream);
 
 /* spatial GMVAE restoration (trainers/GMVAE_spatial.py:178-190): one `sess.run(grads)` + host update, on device.
- * grads = d( loss + sum_n tv_lambda * TV_n(x - xz_mu) ) / d x  at the current x_restored; then
+ * grads = d( n * loss + sum_n tv_lambda * TV_n(x - xz_mu) ) / d x  at the current x_restored (tf.gradients of the [n]-shaped
+ * `loss + restore` sums its elements: each slice sees its own loss terms with weight 1, as if restored alone); then
  * x_restored -= restore_lr * grads in place.  grads_out (may be NULL) receives the gradient.  No parameter gradient is
  * computed and no host synchronisation happens: the caller enqueues restore_steps calls back to back.
  * On a UAD_ARCH_VAE handle this is trainers/VAE_You.py:52-53,133-144 instead: grads = d( rec_n + kl_n + tv_lambda * TV_n(x - x_hat) ) / d x

@@ -176,7 +176,9 @@ class GMVAE:
         only g['__dx'] is meaningful for the caller then (parameter entries hold the gradient of that other objective)."""
         n = x.shape[0]
         dt = x.dtype.type
-        inv = dt(1.0 / n)
+        # `grads` = tf.gradients(loss + restore, x): `loss + restore` has shape [n] (scalar + per-image TV) and tf.gradients differentiates the
+        # SUM of its elements = n * loss + sum_n restore_n, i.e. every sample's own loss terms enter with weight 1 (not 1/n)
+        inv = dt(1.0 / n) if tv_lambda is None else dt(1.0)
         g = {}
         C = self.dim_c
         # ---- decoder ----

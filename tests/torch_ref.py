@@ -211,7 +211,7 @@ def gmvae_losses(params, bn_names, x, e_w, e_z, n_pool, dim_c, dim_z, c_lambda, 
     r = x - xh
     tv = (r[:, 1:] - r[:, :-1]).abs().sum(dim=(1, 2, 3)) + (r[:, :, 1:] - r[:, :, :-1]).abs().sum(dim=(1, 2, 3))
     L['restore'] = tv_lambda * tv
-    L['grads'], = torch.autograd.grad(L['loss'] + L['restore'].sum(), x, retain_graph=True)
+    L['grads'], = torch.autograd.grad((L['loss'] + L['restore']).sum(), x, retain_graph=True)      # tf.gradients sums the [n]-shaped ys
     L['dx_loss'], = torch.autograd.grad(L['loss'], x, retain_graph=True)
     return L, xh, {'pc': pc, 'z_wc_mus': M, 'z_wc_log_sigma_invs': Lq, 'w_sampled': w_s, 'z_sampled': z_s}
 

@@ -94,7 +94,7 @@ struct uad_model {
     bool restore;                      // last forward was a restoration pass (TV term in the objective)
     bool fb_on_load;                   // ... whose d loss / d c of the last block is formed inside dec.back()'s data-gradient kernel
     float restore_tv, restore_lr;
-    float restore_scale;               // weight of the reconstruction / KL terms in the restore objective: 1/n (GMVAE: mean loss) or 1 (VAE_You: per-sample pixel_loss)
+    float restore_scale;               // weight of every sample's loss terms in the restore objective (1: tf.gradients sums the [n]-shaped ys)
     float* restore_x;                  // x_restored (updated in place by the backward) or null
     float* restore_grads;              // optional gradient output
     // gradient ping-pong + small grads
@@ -903,7 +903,7 @@ static int backward_gm_heads(uad_model* m, hipStream_t st) {
     hipStream_t sd = m->side;
     const ConvLayer& EL = m->enc.back();
     float* cp = m->cp_slot[15];
-    UadGmArgs ga = gm_args(m, m->last_io.eps_w, m->last_io.eps_z, 1.0f / (float)m->last_nuser);
+    UadGmArgs ga = gm_args(m, m->last_io.eps_w, m->last_io.eps_z, m->restore ? m->restore_scale : 1.0f / (float)m->last_nuser);
     ga.h_out = nullptr;
     ga.dh_dec = m->G0; ga.g_out = m->G1; ga.colpart = cp;
     ga.dvec_heads = m->gm_dheads; ga.dvec_a7 = m->gm_da7; ga.dvec_M = m->gm_dM; ga.dvec_Lq = m->gm_dLq;
@@ -1042,7 +1042,9 @@ int uad_restore_step(uad_model_t* m, float* x_restored, const float* eps_w, cons
     io.x = x_restored; io.eps_w = eps_w; io.eps_z = eps_z;
     if (vae) io.eps = eps_z;                     // trainers/VAE_You.py:52-53: grads = d (rec_n + kl_n + tv * TV_n) / d x, per sample
     m->restore = true; m->restore_tv = tv_lambda; m->restore_lr = restore_lr;
-    m->restore_scale = vae ? 1.0f : 1.0f / (float)n;
+    // both trainers: tf.gradients of an [n]-shaped objective (per-sample pixel_loss, or scalar loss + per-image restore broadcast to [n])
+    // differentiates the SUM of its elements -> every sample's own loss terms carry weight 1
+    m->restore_scale = 1.0f;
     m->restore_x = x_restored; m->restore_grads = grads_out;
     int rc = uad_forward(m, &io, n, 2, stream);
     if (rc == UAD_OK) rc = uad_backward(m, UAD_SEG_ALL, stream);
