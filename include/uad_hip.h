@@ -221,12 +221,19 @@ enum { UAD_GAN_AAE = 3 };        /* dense-bottleneck BN autoencoder + re-encodin
                                      Phases / groups: UAD_GAN_GENERATOR (1) = optim_ae (loss = mean(L2 [+ rho Rec_z]), every autoencoder variable),
                                      UAD_GAN_DISCRIMINATOR (2) = optim_dis (io.z = prior sample, io.alpha = eps of z_hat = z + eps (z - z_)),
                                      UAD_GAN_ENCODER (0) = optim_gen (-mean d_, the variables named 'Encoder/...', own Adam slots);
-                                     io.mask_z / mask_g / mask_sigma = dropout masks of z_, dec_dense, z_rec */
+                                     io.mask_z / mask_g / mask_sigma = dropout masks of z_, dec_dense, z_rec.
+                                     3 = the dense GMVAE, models/gaussian_mixture_variational_autoencoder.py:11-76 + trainers/GMVAE.py:56-101:
+                                     cfg.zdim = dim_z, cfg.dim = dim_c, cfg.dim_w, cfg.c_lambda; one phase, UAD_GAN_GENERATOR = the optimizer over every
+                                     variable (group 1); io.eps_w [n,dim_w] / io.eps [n,dim_z] = reparameterisation noise, io.mask_w_mu / mask_w_ls [n,dim_w],
+                                     io.mask_z [n,dim_z] (z_mu; z_log_sigma has no dropout, model :42), io.mask_g [n,flat] (dec_dense);
+                                     scalars: UAD_GAN_S_GM_*; restoration through uad_gan_restore_step */
 enum { UAD_GAN_GROUP_VAE = 3 };   /* uad_gan_group only: the contiguous Encoder + Generator slice (AnoVAE-GAN's optim_vae) */
 enum { UAD_BUF_ADAM_M2 = 4, UAD_BUF_ADAM_V2 = 5 };
 /* scalars[16] written by uad_gan_phase (entries a phase does not compute are left untouched) */
 enum { UAD_GAN_S_GEN_LOSS = 0, UAD_GAN_S_DISC_FAKE = 1, UAD_GAN_S_DISC_REAL = 2, UAD_GAN_S_PENALTY = 3, UAD_GAN_S_DISC_LOSS = 4,
-       UAD_GAN_S_LOSS_IMG = 5, UAD_GAN_S_LOSS_FTS = 6, UAD_GAN_S_ENC_LOSS = 7, UAD_GAN_S_REC_LOSS = 8, UAD_GAN_S_KL = 9 };
+       UAD_GAN_S_LOSS_IMG = 5, UAD_GAN_S_LOSS_FTS = 6, UAD_GAN_S_ENC_LOSS = 7, UAD_GAN_S_REC_LOSS = 8, UAD_GAN_S_KL = 9,
+       UAD_GAN_S_GM_LOSS = 10, UAD_GAN_S_GM_CON = 11, UAD_GAN_S_GM_W = 12, UAD_GAN_S_GM_C = 13 };   /* dense GMVAE: loss, conditional_prior_loss,
+                                                                                                       w_prior_loss, c_prior_loss (mean_p_loss = S_REC_LOSS) */
 typedef struct uad_gan uad_gan_t;
 typedef struct {
     int height, width, channels;   /* square power-of-two slices, 1 channel */
@@ -239,8 +246,10 @@ typedef struct {
                                       height must be 8 * inter_res; no dropout in that graph: mask_z / mask_g are ignored) */
     int dim;                       /* RESNET only: base width (fanogan_schlegl.py:13: 64); 0 = 64 */
     float kl_weight;               /* ANOVAEGAN only: AnoVAEGAN.Config.kl_weight (:17) */
-    int aae_kind;                  /* AAE only: 0 constrained AE, 1 AAE, 2 constrained AAE */
+    int aae_kind;                  /* AAE only: 0 constrained AE, 1 AAE, 2 constrained AAE, 3 dense GMVAE */
     float rho;                     /* AAE only: weight of the latent re-encoding term (ConstrainedAE.Config.rho :15) */
+    int dim_w;                     /* dense GMVAE only: GMVAE.Config.dim_w (:17); dim_z = zdim, dim_c = dim */
+    float c_lambda;                /* dense GMVAE only: GMVAE.Config.c_lambda (:18) */
 } uad_gan_config_t;
 typedef struct {
     const float* x;                /* [n,H,W,1] batch (critic and encoder phases, reconstruct) */
@@ -255,6 +264,9 @@ typedef struct {
     float* scalars;                /* optional out [16], UAD_GAN_S_* */
     const float* eps;              /* ANOVAEGAN: [n,zDim] N(0,1) reparameterisation noise (NULL = 0) */
     const float* mask_sigma;       /* ANOVAEGAN: optional keep mask of the log-sigma head (mask_z is the mu head's) */
+    const float* eps_w;            /* dense GMVAE: [n,dim_w] N(0,1) noise of w_sampled (NULL = 0); io.eps is z_sampled's */
+    const float* mask_w_mu;        /* dense GMVAE: optional [n,dim_w] keep masks of the w_mu / w_log_sigma heads */
+    const float* mask_w_ls;
 } uad_gan_io_t;
 int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out);
 int uad_gan_destroy(uad_gan_t* g);
@@ -272,6 +284,12 @@ int uad_gan_set_step(uad_gan_t* g, int group, long long t);
 int uad_gan_phase(uad_gan_t* g, int phase, const uad_gan_io_t* io, int n, int want_backward, void* stream);
 int uad_gan_adam(uad_gan_t* g, int group, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int uad_gan_reconstruct(uad_gan_t* g, const uad_gan_io_t* io, int n, void* stream);
+/* dense GMVAE restoration (trainers/GMVAE.py:172-184): one `sess.run(grads)` + the host update, on device.  grads = d( n * loss +
+ * sum_n tv_lambda * TV_n(x - xz_mu) ) / d x at the current x_restored (= io->x is ignored; tf.gradients sums the [n]-shaped `loss + restore`,
+ * so every slice sees its own loss terms with weight 1); then x_restored -= restore_lr * grads in place.  grads_out may be NULL.
+ * io supplies the noise / dropout masks of this run.  No parameter gradient is produced. */
+int uad_gan_restore_step(uad_gan_t* g, float* x_restored, const uad_gan_io_t* io, int n, float tv_lambda, float restore_lr, float* grads_out,
+                         void* stream);
 /* tests: device pointer + element count of a named intermediate of the last phase (NULL name table entry -> error) */
 int uad_gan_debug_buffer(uad_gan_t* g, const char* name, float** ptr, long long* count);
 

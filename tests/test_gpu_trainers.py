@@ -372,3 +372,64 @@ def test_tf_checkpoint_export_and_resume(tmp_path):
         mod.engine.train_step(x, eps=eps, masks=None, lr=1e-3)
     assert np.array_equal(model.engine.get_buffer_host(_lib.BUF_PARAMS), m2.engine.get_buffer_host(_lib.BUF_PARAMS))
     model.engine.close(); m2.engine.close()
+
+
+def test_gmvae_dense_trainer_surface(tmp_path):
+    """trainers/GMVAE.py on models/gaussian_mixture_variational_autoencoder.py: Config defaults, fetch keys, an oracle-checked TRAIN
+    step with injected noise / dropout masks, training progress, restoration-mode reconstruct(), resume."""
+    from oracle import gmvae_dense as ogd
+    from unsupervised_anomaly_detection_brain_mri_amd.models import gaussian_mixture_variational_autoencoder as net
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import GMVAE
+    assert (GMVAE.Config().dim_c, GMVAE.Config().dim_z, GMVAE.Config().dim_w, GMVAE.Config().c_lambda,
+            GMVAE.Config().restore_lr, GMVAE.Config().restore_steps, GMVAE.Config().tv_lambda) == (6, 1, 1, 1, 1e-3, 150, 1.8)
+    h, bs = 64, 4
+    opt = get_options(batchsize=bs, learningrate=1e-3, numEpochs=2, zDim=64, outputWidth=h, outputHeight=h,
+                      config={'CHECKPOINTDIR': str(tmp_path / 'ck'), 'SAMPLEDIR': str(tmp_path / 'smp')})
+    ds = SyntheticDataset(16, 8, h, h, seed=0)
+    cfg = get_config(GMVAE, opt, 'ADAM', [8, 8], 0.2, ds)
+    cfg.dim_c, cfg.dim_z, cfg.dim_w, cfg.restore_steps = 5, 2, 3, 4
+    model = GMVAE(None, cfg, network=net)
+    assert model.model_dir.startswith('GMVAE_dSyntheticDataset')
+    m = ogd.GMVAEDense(h, 8, 5, 2, 3, 1.0)
+    assert [n for n, _, _ in model.engine.spec] == [n for n, _, _ in m.spec]
+    p = {k: v.astype(np.float64) for k, v in model.engine.get_params().items()}
+    x = ds.next_batch(bs, set='TRAIN')[0]
+    rng = np.random.default_rng(3)
+    e_w, e_z = rng.standard_normal((bs, 3)).astype(np.float32), rng.standard_normal((bs, 2)).astype(np.float32)
+    masks = model._masks(bs, True)
+    assert set(masks) == {'w_mu', 'w_ls', 'z_mu', 'dec'} and masks['dec'].shape == (bs, model.engine.flat)
+    run = model.step(x, Phase.TRAIN, eps=(e_w, e_z), masks=masks)
+    assert set(run) == {'reconstruction', 'L1', 'L2', 'L1_sum', 'L2_sum', 'reconstructionLoss', 'mean_p_loss', 'conditional_prior_loss',
+                        'w_prior_loss', 'c_prior_loss', 'loss'}
+    o = m.new_opt(p)
+    _, ls, _ = m.train_step(p, o, x.astype(np.float64), e_w.astype(np.float64), e_z.astype(np.float64), {k: v.astype(np.float64) for k, v in masks.items()},
+                            lr=1e-3, beta1=cfg.beta1)
+    for k in ('mean_p_loss', 'conditional_prior_loss', 'w_prior_loss', 'c_prior_loss', 'loss'):
+        assert run[k] == pytest.approx(ls[k], rel=3e-4), k
+    ref = np.concatenate([p[nm].reshape(-1) for nm, _, _ in m.spec])
+    got = model.engine.get_buffer_host(_lib.BUF_PARAMS)
+    # one Adam step moves every touched weight by ~lr * sign(g): a weight whose gradient is rounding noise may step the other way
+    assert np.abs(got - ref).max() <= 2.5e-3 and np.mean(np.abs(got - ref)) <= 2e-5
+    model.train(ds)
+    tr = model.curves['TRAIN/loss']
+    assert len(tr) == 2 and tr[1] < tr[0]
+    # restoration-mode reconstruct: deterministic mode equals the oracle's loop
+    xs = ds.next_batch(2, set='VAL')[0]
+    r = model.reconstruct(xs, eps=0.0)
+    p2 = {k: v.astype(np.float64) for k, v in model.engine.get_params().items()}
+    zero = lambda s: (np.zeros((2, 3)), np.zeros((2, 2)))
+    rref = m.reconstruct(p2, xs.astype(np.float64), zero, restore_steps=4, restore_lr=cfg.restore_lr, tv_lambda=cfg.tv_lambda)
+    assert np.mean(np.abs(r['reconstruction'] - rref['reconstruction'])) <= 2e-5
+    assert np.abs(r['reconstruction'] - rref['reconstruction']).max() <= 8 * cfg.restore_lr * cfg.tv_lambda + 1e-4
+    assert r['l1err'] == pytest.approx(r['l2err'], rel=1e-6)
+    g = model.restore_gradients(xs, eps=(np.zeros((2, 3), np.float32), np.zeros((2, 2), np.float32)))
+    assert g.shape == xs.shape and np.isfinite(g).all()
+    model.restore_steps = 0
+    assert model.reconstruct(xs[0], dropout=True)['reconstruction'].shape == (1, h, h, 1)
+    w = model.engine.get_buffer_host(_lib.BUF_PARAMS)
+    t = model.engine.step_count('AE')
+    model.engine.close()
+    m2 = GMVAE(None, cfg, network=net, seed=9)
+    assert m2.load_checkpoint() == 2 and m2.engine.step_count('AE') == t
+    assert np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w)
+    m2.engine.close()

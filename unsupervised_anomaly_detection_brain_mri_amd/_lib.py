@@ -37,12 +37,12 @@ class UadIO(C.Structure):
 class UadGanConfig(C.Structure):
     _fields_ = [('height', C.c_int), ('width', C.c_int), ('channels', C.c_int), ('inter_res', C.c_int), ('zdim', C.c_int),
                 ('max_batch', C.c_int), ('scale', C.c_float), ('kappa', C.c_float), ('variant', C.c_int), ('dim', C.c_int),
-                ('kl_weight', C.c_float), ('aae_kind', C.c_int), ('rho', C.c_float)]
+                ('kl_weight', C.c_float), ('aae_kind', C.c_int), ('rho', C.c_float), ('dim_w', C.c_int), ('c_lambda', C.c_float)]
 
 
 class UadGanIO(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('x', 'z', 'alpha', 'mask_z', 'mask_g', 'generated', 'reconstruction', 'z_enc',
-                                          'l1_map', 'scalars', 'eps', 'mask_sigma')]
+                                          'l1_map', 'scalars', 'eps', 'mask_sigma', 'eps_w', 'mask_w_mu', 'mask_w_ls')]
 
 
 GAN_ENCODER, GAN_GENERATOR, GAN_DISCRIMINATOR = 0, 1, 2
@@ -50,7 +50,7 @@ GAN_UNIFIED, GAN_RESNET, GAN_ANOVAEGAN, GAN_AAE = 0, 1, 2, 3
 GAN_GROUP_VAE = 3
 BUF_ADAM_M2, BUF_ADAM_V2 = 4, 5
 GAN_SCALARS = ('gen_loss', 'disc_fake', 'disc_real', 'penalty', 'disc_loss', 'loss_img', 'loss_fts', 'enc_loss',
-               'reconstructionLoss', 'kl')
+               'reconstructionLoss', 'kl', 'gm_loss', 'gm_con', 'gm_w', 'gm_c')
 
 
 class UadConvDesc(C.Structure):
@@ -119,6 +119,7 @@ SYMBOLS = {
     'uad_gan_phase': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(UadGanIO), C.c_int, C.c_int, C.c_void_p]),
     'uad_gan_adam': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_gan_reconstruct': (C.c_int, [C.c_void_p, C.POINTER(UadGanIO), C.c_int, C.c_void_p]),
+    'uad_gan_restore_step': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(UadGanIO), C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     'uad_gan_debug_buffer': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     'uad_op_conv_f': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, 'libuad_hip.so')
-SOURCES = ['uad_gemm.hip', 'uad_misc.hip', 'uad_gmvae.hip', 'uad_bott.hip', 'uad_eval.hip', 'uad_gan.hip', 'uad_model.hip']
+SOURCES = ['uad_gemm.hip', 'uad_misc.hip', 'uad_gmvae.hip', 'uad_gmd.hip', 'uad_bott.hip', 'uad_eval.hip', 'uad_gan.hip', 'uad_model.hip']
 ARCH = 'gfx950'
 
 

@@ -458,6 +458,9 @@ __global__ void combine_kernel(int phase, const float* __restrict__ raw, float k
     } else if (phase == 4) {      // AAE family, autoencoder phase: raw = {mean L2, mean Rec_z, reconstructionLoss}, kappa = rho
         out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
         out[UAD_GAN_S_REC_LOSS] = raw[2];
+    } else if (phase == 5) {      // dense GMVAE: raw = {mean_p_loss, conditional_prior_loss, w_prior_loss, c_prior_loss}
+        out[UAD_GAN_S_REC_LOSS] = raw[0]; out[UAD_GAN_S_GM_CON] = raw[1]; out[UAD_GAN_S_GM_W] = raw[2]; out[UAD_GAN_S_GM_C] = raw[3];
+        out[UAD_GAN_S_GM_LOSS] = ((raw[0] + raw[1]) + raw[2]) + raw[3];
     } else if (phase == 3) {      // AnoVAE-GAN's VAE phase: raw = {reconstructionLoss, kl}, kappa = kl_weight
         out[UAD_GAN_S_REC_LOSS] = raw[0]; out[UAD_GAN_S_KL] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
     } else {
@@ -655,6 +658,12 @@ struct uad_gan {
     long long a_w1, a_b1, a_w2, a_b2, a_w3, a_b3, a_nd;                          // critic tensors, their total size
     std::vector<float*> a_eg, a_cp;    // per encoder level: d loss / d c_i [2n] and BN column partials (both encoder passes)
     float *a_xcat, *a_zm, *a_dzm, *a_dflat, *a_slab, *a_crit[3];                 // [x ; x_hat], z_ | z_rec, masked d z, d flat, critic slabs, d_fake / d_real / pen
+    // dense GMVAE (aae_kind 3): four Dense heads on the flattened bottleneck, p(z|w,c) = two Dense layers on w_sampled + the 0.1 Variable
+    bool gmv;
+    int gm_W, gm_Z, gm_C, gm_J;        // dim_w, dim_z, dim_c, 2W + 2Z (row of head values: w_mu | w_log_sigma | z_mu | z_log_sigma)
+    long long gm_hw[4], gm_hb[4], gm_mw, gm_mb, gm_lw, gm_lb, gm_var;
+    int gm_hd[4], gm_ho[4];            // head widths and column offsets inside a row
+    float *gm_hv, *gm_hvm, *gm_ws, *gm_M, *gm_Lq, *gm_pc, *gm_loss3, *gm_dhv, *gm_dM, *gm_dLq, *gm_dxhat;
     bool generic16;                    // UAD_MATH_BF16X3_ALL: generic contractions in bf16x3 too (opt-in, not parity-rated)
     struct RB {                        // pre-activation residual block: LN -> ReLU -> conv1 (k3 s1) -> LN -> ReLU -> conv2, + shortcut
         bool gen;                      // generator block: conv2 / shortcut are transposed convolutions
@@ -1015,16 +1024,38 @@ void a_encode(uad_gan* m, const float* x, const float* mask, int n, int off, hip
     }
     float* t = m->et + (size_t)off * m->flat;
     uad_launch_conv_f(conv1x1_desc(n, r, r, m->cenc, m->cmid), in, no_xform(), P(m, m->a_cw), t, epi_bias(P(m, m->a_cb)), st, nullptr, m->ws);
+    if (m->gmv) {
+        // the four Dense heads (model :27-42): raw values (bias added) into one row per sample; dropout is applied by the latent kernel
+        for (int h = 0; h < 4; ++h) {
+            UadSdArgs a;
+            memset(&a, 0, sizeof a);
+            a.a = t; a.lda = m->flat; a.B = P(m, m->gm_hw[h]); a.sBi = m->gm_hd[h]; a.sBo = 1; a.bias = P(m, m->gm_hb[h]);
+            a.R = n; a.I = m->flat; a.O = m->gm_hd[h]; a.out = m->gm_hv + m->gm_ho[h]; a.ldo = m->gm_J;
+            uad_launch_sd(a, st);
+        }
+        return;
+    }
     uad_launch_conv_f(dense_desc(n, m->flat, zd), t, no_xform(), P(m, m->a_zw), m->a_zm + (size_t)off * zd, epi_bias(P(m, m->a_zb), mask), st, nullptr, m->ws);
 }
 // data-gradient chain of one encoder pass from d / d z (post dropout) in `dz`: leaves d c_i in a_eg[i] (+off) and the BN column
 // partials in a_cp[i] (rows [cp_row0, ...)); returns the partial-row count (identical for every level is NOT assumed: see cp_rows)
 void a_encode_backward(uad_gan* m, const float* dz, const float* mask, int n, int off, int* cp_rows, float* dx_out, hipStream_t st) {
     const int r = m->cfg.inter_res, zd = m->cfg.zdim;
-    float* dzm = m->a_dzm + (size_t)off * zd;
-    uad_launch_mul(dz, mask, dzm, (size_t)n * zd, st);
     float* dfl = m->a_dflat + (size_t)off * m->flat;
-    uad_launch_conv_d(dense_desc(n, m->flat, zd), dzm, no_xform(), P(m, m->a_zw), dfl, epi_bias(nullptr), st, nullptr, m->ws);
+    if (m->gmv) {
+        // dz = d / d raw head values [n, 2W+2Z]: d flat = sum over the four heads of dhead . kernel^T
+        for (int h = 0; h < 4; ++h) {
+            UadSdArgs a;
+            memset(&a, 0, sizeof a);
+            a.a = dz + m->gm_ho[h]; a.lda = m->gm_J; a.B = P(m, m->gm_hw[h]); a.sBi = 1; a.sBo = m->gm_hd[h];
+            a.R = n; a.I = m->gm_hd[h]; a.O = m->flat; a.out = dfl; a.ldo = m->flat; a.accumulate = h > 0;
+            uad_launch_sd(a, st);
+        }
+    } else {
+        float* dzm = m->a_dzm + (size_t)off * zd;
+        uad_launch_mul(dz, mask, dzm, (size_t)n * zd, st);
+        uad_launch_conv_d(dense_desc(n, m->flat, zd), dzm, no_xform(), P(m, m->a_zw), dfl, epi_bias(nullptr), st, nullptr, m->ws);
+    }
     float* g = m->Ga; float* gn = m->Gb;
     uad_launch_conv_d(conv1x1_desc(n, r, r, m->cenc, m->cmid), dfl, no_xform(), P(m, m->a_cw), g, epi_bias(nullptr), st, nullptr, m->ws);
     for (int i = (int)m->E.size() - 1; i >= 0; --i) {
@@ -1041,8 +1072,13 @@ void a_encode_backward(uad_gan* m, const float* dz, const float* mask, int n, in
 // parameter gradients of the encoder path over `rows_n` samples (both passes when constrained)
 void a_encode_wgrads(uad_gan* m, const float* x_all, int nall, const int* cp_rows, hipStream_t st) {
     const int r = m->cfg.inter_res, zd = m->cfg.zdim;
-    uad_launch_conv_w(dense_desc(nall, m->flat, zd), m->et, no_xform(), m->a_dzm, no_xform(), Gr(m, m->a_zw), m->wpartial, st);
-    uad_launch_colsum(m->a_dzm, nall, zd, Gr(m, m->a_zb), m->colscratch, st);
+    if (m->gmv) {
+        for (int h = 0; h < 4; ++h)
+            uad_launch_sd_wgrad(m->et, m->flat, m->gm_dhv + m->gm_ho[h], m->gm_J, nall, m->flat, m->gm_hd[h], Gr(m, m->gm_hw[h]), Gr(m, m->gm_hb[h]), st);
+    } else {
+        uad_launch_conv_w(dense_desc(nall, m->flat, zd), m->et, no_xform(), m->a_dzm, no_xform(), Gr(m, m->a_zw), m->wpartial, st);
+        uad_launch_colsum(m->a_dzm, nall, zd, Gr(m, m->a_zb), m->colscratch, st);
+    }
     uad_launch_conv_w(conv1x1_desc(nall, r, r, m->cenc, m->cmid), m->ea[m->E.size()], no_xform(), m->a_dflat, no_xform(), Gr(m, m->a_cw), m->wpartial, st);
     uad_launch_colsum(m->a_dflat, nall * r * r, m->cmid, Gr(m, m->a_cb), m->colscratch, st);
     for (size_t i = 0; i < m->E.size(); ++i) {
@@ -1053,7 +1089,15 @@ void a_encode_wgrads(uad_gan* m, const float* x_all, int nall, const int* cp_row
 }
 void a_decode(uad_gan* m, const float* z, const float* mask_dec, int n, hipStream_t st) {
     const int r = m->cfg.inter_res;
-    uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), z, no_xform(), P(m, m->a_dw), m->gdv, epi_bias(P(m, m->a_db), mask_dec), st, nullptr, m->ws);
+    if (m->gmv) {          // dec_dense on z_sampled [n, dim_z] (dim_z may be 1: a skinny product)
+        UadSdArgs a;
+        memset(&a, 0, sizeof a);
+        a.a = z; a.lda = m->gm_Z; a.B = P(m, m->a_dw); a.sBi = m->flat; a.sBo = 1; a.bias = P(m, m->a_db); a.mask = mask_dec; a.ldm = m->flat;
+        a.R = n; a.I = m->gm_Z; a.O = m->flat; a.out = m->gdv; a.ldo = m->flat;
+        uad_launch_sd(a, st);
+    } else {
+        uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), z, no_xform(), P(m, m->a_dw), m->gdv, epi_bias(P(m, m->a_db), mask_dec), st, nullptr, m->ws);
+    }
     uad_launch_conv_f(conv1x1_desc(n, r, r, m->cmid, m->cenc), m->gdv, no_xform(), P(m, m->a_rw), m->gc[0], epi_bias(P(m, m->a_rb)), st, nullptr, m->ws);
     bn_fwd(m, m->a_dbng, m->a_dbnb, 0.0f, m->gc[0], (size_t)n * r * r, m->cenc, m->ga[0], st);
     for (size_t i = 0; i < m->G.size(); ++i) {
@@ -1065,30 +1109,43 @@ void a_decode(uad_gan* m, const float* z, const float* mask_dec, int n, hipStrea
     rowdot<0>(m->ga[m->G.size()], P(m, m->g_fw), P(m, m->g_fb), n * LL.H * LL.W, LL.C, m->xg, st);
 }
 // dxh = d loss / d x_hat; writes every decoder-path gradient and d / d z into dz_out
-void a_decode_backward(uad_gan* m, const float* z, const float* mask_dec, const float* dxh, int n, float* dz_out, hipStream_t st) {
+void a_decode_backward(uad_gan* m, const float* z, const float* mask_dec, const float* dxh, int n, float* dz_out, hipStream_t st, bool pg = true) {
     const int r = m->cfg.inter_res;
     const Block& LL = m->G.back();
     const int rows = n * LL.H * LL.W;
     float* g = m->Ga; float* gn = m->Gb;
     {
         const int rpb = (rows + 1023) / 1024, blocks = (rows + rpb - 1) / rpb;
-        hipLaunchKernelGGL(gfinal_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxh, m->xg, m->ga[m->G.size()], P(m, m->g_fw), rows, rpb, LL.C, 2, g, m->finpart);
-        uad_launch_reduce_partials(m->finpart, blocks, LL.C + 1, 1.0f, m->colscratch, st);
-        hipMemcpyAsync(Gr(m, m->g_fw), m->colscratch, LL.C * sizeof(float), hipMemcpyDeviceToDevice, st);
-        hipMemcpyAsync(Gr(m, m->g_fb), m->colscratch + LL.C, sizeof(float), hipMemcpyDeviceToDevice, st);
+        hipLaunchKernelGGL(gfinal_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxh, m->xg, m->ga[m->G.size()], P(m, m->g_fw), rows, rpb, LL.C, 2, g,
+                           pg ? m->finpart : nullptr);
+        if (pg) {
+            uad_launch_reduce_partials(m->finpart, blocks, LL.C + 1, 1.0f, m->colscratch, st);
+            hipMemcpyAsync(Gr(m, m->g_fw), m->colscratch, LL.C * sizeof(float), hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(Gr(m, m->g_fb), m->colscratch + LL.C, sizeof(float), hipMemcpyDeviceToDevice, st);
+        }
     }
     for (int i = (int)m->G.size() - 1; i >= 0; --i) {
         const Block& L = m->G[i];
         const int T = bn_bwd_partial(m, L.gamma, L.beta, kLrelu, g, m->gc[i + 1], n * L.H * L.W, L.C, gn, m->colpart, st);
-        bn_finalize(m, m->colpart, T, L.C, L.gamma, L.beta, L.b, st);
-        convT_wgrad(m, L, n, m->ga[i], gn, st);
+        if (pg) {
+            bn_finalize(m, m->colpart, T, L.C, L.gamma, L.beta, L.b, st);
+            convT_wgrad(m, L, n, m->ga[i], gn, st);
+        }
         convT_dgrad(m, L, n, gn, g, st);
     }
     const int T = bn_bwd_partial(m, m->a_dbng, m->a_dbnb, 0.0f, g, m->gc[0], n * r * r, m->cenc, gn, m->colpart, st);
-    bn_finalize(m, m->colpart, T, m->cenc, m->a_dbng, m->a_dbnb, m->a_rb, st);
+    if (pg) bn_finalize(m, m->colpart, T, m->cenc, m->a_dbng, m->a_dbnb, m->a_rb, st);
     const UadConvDesc dc1 = conv1x1_desc(n, r, r, m->cmid, m->cenc), dd = dense_desc(n, m->cfg.zdim, m->flat);
-    uad_launch_conv_w(dc1, m->gdv, no_xform(), gn, no_xform(), Gr(m, m->a_rw), m->wpartial, st);
+    if (pg) uad_launch_conv_w(dc1, m->gdv, no_xform(), gn, no_xform(), Gr(m, m->a_rw), m->wpartial, st);
     uad_launch_conv_d(dc1, gn, no_xform(), P(m, m->a_rw), m->ddv, epi_bias(nullptr, mask_dec), st, nullptr, m->ws);
+    if (m->gmv) {
+        if (pg) uad_launch_sd_wgrad(z, m->gm_Z, m->ddv, m->flat, n, m->gm_Z, m->flat, Gr(m, m->a_dw), Gr(m, m->a_db), st);
+        UadSdArgs a;
+        memset(&a, 0, sizeof a);
+        a.a = m->ddv; a.lda = m->flat; a.B = P(m, m->a_dw); a.sBi = 1; a.sBo = m->flat; a.R = n; a.I = m->flat; a.O = m->gm_Z; a.out = dz_out; a.ldo = m->gm_Z;
+        uad_launch_sd(a, st);
+        return;
+    }
     uad_launch_conv_w(dd, z, no_xform(), m->ddv, no_xform(), Gr(m, m->a_dw), m->wpartial, st);
     uad_launch_colsum(m->ddv, n, m->flat, Gr(m, m->a_db), m->colscratch, st);
     uad_launch_conv_d(dd, m->ddv, no_xform(), P(m, m->a_dw), dz_out, epi_bias(nullptr), st, nullptr, m->ws);
@@ -1103,7 +1160,73 @@ void a_critic(uad_gan* m, int mode, const float* zf, const float* zr, const floa
     hipLaunchKernelGGL(critic_kernel, dim3(n), dim3(128), 0, st, a);
 }
 
+
+// ---- dense GMVAE (aae_kind 3) ----
+UadGmdArgs gmd_args(uad_gan* m, const uad_gan_io_t* io, float inv) {
+    UadGmdArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = m->gm_W; a.Z = m->gm_Z; a.C = m->gm_C; a.nmax = m->cfg.max_batch; a.c_lambda = m->cfg.c_lambda; a.inv = inv;
+    a.hv = m->gm_hv; a.mask_wmu = io->mask_w_mu; a.mask_wls = io->mask_w_ls; a.mask_zmu = io->mask_z; a.e_w = io->eps_w; a.e_z = io->eps;
+    a.Wm = P(m, m->gm_mw); a.bm = P(m, m->gm_mb); a.Wl = P(m, m->gm_lw); a.bl = P(m, m->gm_lb); a.var = P(m, m->gm_var);
+    a.hvm = m->gm_hvm; a.w_s = m->gm_ws; a.z_s = m->a_zm; a.M = m->gm_M; a.Lq = m->gm_Lq; a.pc = m->gm_pc; a.loss3 = m->gm_loss3;
+    a.dhv = m->gm_dhv; a.dM = m->gm_dM; a.dLq = m->gm_dLq;
+    return a;
+}
+void gmv_forward(uad_gan* m, const uad_gan_io_t* io, const float* x, int n, float inv, hipStream_t st) {
+    a_encode(m, x, nullptr, n, 0, st);
+    uad_launch_gmd_fwd(gmd_args(m, io, inv), n, st);
+    a_decode(m, m->a_zm, io->mask_g, n, st);
+}
+// one sess.run of trainers/GMVAE.py:122-139 (train / validation) or, with restore, of :172-184 (the `grads` fetch + the update)
+int gmv_phase(uad_gan* m, const uad_gan_io_t* io, const float* x, int n, int want_backward, bool restore, float tv, float rlr, float* x_upd,
+              float* grads_out, hipStream_t st) {
+    const int H = m->cfg.height, Q = m->gm_Z * m->gm_C;
+    const size_t img = (size_t)n * H * H;
+    const float inv = restore ? 1.0f : 1.0f / (float)n;
+    refresh_packs(m, st);
+    gmv_forward(m, io, x, n, inv, st);
+    if (!restore) {
+        float* scal = io->scalars ? io->scalars : m->scalars_own;
+        reduce_to<2>(m, 0, x, m->xg, img, 1.0f / (float)n, io->l1_map, st);                         // mean_p_loss (:58-60)
+        for (int k = 0; k < 3; ++k) reduce_to<0>(m, 1 + k, m->gm_loss3 + (size_t)k * m->cfg.max_batch, nullptr, (size_t)n, 1.0f / (float)n, nullptr, st);
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, 5, m->raw, 0.0f, scal);
+        if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->a_zm, (size_t)n * m->gm_Z * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (!want_backward) return UAD_OK;
+    const float* dxh;
+    if (restore) {
+        uad_launch_tv_dxhat(x, m->xg, n, H, H, 1.0f, tv, m->gm_dxhat, st);                          // sign(x_hat - x) - tv * dTV/dr, r = x - x_hat
+        dxh = m->gm_dxhat;
+    } else {
+        hipLaunchKernelGGL(sign_scale_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, x, 1.0f / (float)n, img, m->dxbuf);
+        dxh = m->dxbuf;
+    }
+    a_decode_backward(m, m->a_zm, io->mask_g, dxh, n, m->dzbuf, st, !restore);
+    UadGmdArgs ga = gmd_args(m, io, inv);
+    ga.dz_dec = m->dzbuf;
+    uad_launch_gmd_bwd(ga, n, st);
+    int cp_rows[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    a_encode_backward(m, m->gm_dhv, nullptr, n, 0, cp_rows, nullptr, st);
+    if (restore) {
+        UadConvDesc d0 = m->E[0].d; d0.N = n;
+        uad_launch_conv_first_dgrad_restore(d0, m->a_eg[0], P(m, m->E[0].w), m->gm_dxhat, grads_out, x_upd, rlr, st);
+        return UAD_OK;
+    }
+    // p(z|w,c): dense (mu), dense_1 (log sigma inv) on w_sampled; the Variable's gradient is dense_1's bias gradient
+    uad_launch_sd_wgrad(m->gm_ws, m->gm_W, m->gm_dM, Q, n, m->gm_W, Q, Gr(m, m->gm_mw), Gr(m, m->gm_mb), st);
+    uad_launch_sd_wgrad(m->gm_ws, m->gm_W, m->gm_dLq, Q, n, m->gm_W, Q, Gr(m, m->gm_lw), Gr(m, m->gm_lb), st);
+    HIP_TRY(hipMemcpyAsync(Gr(m, m->gm_var), Gr(m, m->gm_lb), (size_t)Q * sizeof(float), hipMemcpyDeviceToDevice, st));
+    a_encode_wgrads(m, x, n, cp_rows, st);
+    return UAD_OK;
+}
+
 int aae_phase(uad_gan* m, int phase, const uad_gan_io_t* io, int n, int want_backward, hipStream_t st) {
+    if (m->gmv) {
+        if (phase != UAD_GAN_GENERATOR) return fail(UAD_ERR_INVALID, "the dense GMVAE has one phase (UAD_GAN_GENERATOR): its optimizer covers every variable");
+        if (!io->x) return fail(UAD_ERR_INVALID, "GMVAE phase needs io.x");
+        return gmv_phase(m, io, io->x, n, want_backward, false, 0.f, 0.f, nullptr, nullptr, st);
+    }
     if (!io->x) return fail(UAD_ERR_INVALID, "AAE-family phases need io.x");
     const int H = m->cfg.height, zd = m->cfg.zdim;
     const size_t img = (size_t)n * H * H;
@@ -1569,13 +1692,20 @@ static int create_resnet(const uad_gan_config_t* cfg, uad_gan_t** out) {
 // ---- handle of the AAE family (ConstrainedAE / AAE / ConstrainedAAE); parameter table in TF first-call order ----
 static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
     const int H = cfg->height, ir = cfg->inter_res;
-    if (cfg->aae_kind < 0 || cfg->aae_kind > 2) return fail(UAD_ERR_INVALID, "bad aae_kind");
+    if (cfg->aae_kind < 0 || cfg->aae_kind > 3) return fail(UAD_ERR_INVALID, "bad aae_kind");
+    const bool gmv = cfg->aae_kind == 3;
+    if (gmv) {
+        const long long q = (long long)cfg->zdim * cfg->dim;
+        if (cfg->dim_w < 1 || cfg->dim_w > 1024 || cfg->zdim < 1 || cfg->zdim > 1024 || cfg->dim < 1 || cfg->dim > 64 || q > 4096)
+            return fail(UAD_ERR_UNSUPPORTED, "dense GMVAE: 1 <= dim_w, dim_z <= 1024, 1 <= dim_c <= 64, dim_z * dim_c <= 4096");
+    }
     const int npool = ilog2i(H) - ilog2i(ir);
     if (npool < 2 || npool > 5) return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 2..5 blocks supported", npool);
-    if (cfg->zdim > kCritMaxZ) return fail(UAD_ERR_UNSUPPORTED, "zDim <= %d", kCritMaxZ);
+    if (!gmv && cfg->zdim > kCritMaxZ) return fail(UAD_ERR_UNSUPPORTED, "zDim <= %d", kCritMaxZ);
     uad_gan* m = new uad_gan();
+    m->gmv = gmv; m->gm_W = cfg->dim_w; m->gm_Z = cfg->zdim; m->gm_C = cfg->dim; m->gm_J = 2 * cfg->dim_w + 2 * cfg->zdim;
     m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->dim = 0; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1;
-    m->aae_kind = cfg->aae_kind; m->a_constrained = cfg->aae_kind != 1; m->a_critic = cfg->aae_kind != 0;
+    m->aae_kind = cfg->aae_kind; m->a_constrained = cfg->aae_kind == 0 || cfg->aae_kind == 2; m->a_critic = cfg->aae_kind == 1 || cfg->aae_kind == 2;
     m->a_h1 = cfg->aae_kind == 2 ? 100 : 50; m->a_h2 = 50;
     m->npool = npool; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
     m->step[0] = m->step[1] = m->step[2] = 0;
@@ -1600,11 +1730,31 @@ static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
     const std::string n_conv = caae ? "Encoder/conv2d" : "Bottleneck/conv2d", n_z = caae ? "Encoder/dense" : "Bottleneck/dense";
     const std::string n_dec = caae ? "Decoder/dense" : "Bottleneck/dense_1", n_rev = caae ? "Decoder/conv2d_1" : "Bottleneck/conv2d_1";
     m->a_cw = add_tensor(m, n_conv + "/kernel", 4, 1, 1, m->cenc, m->cmid); m->a_cb = add_tensor(m, n_conv + "/bias", 1, m->cmid, 1, 1, 1);
-    m->a_zw = add_tensor(m, n_z + "/kernel", 2, m->flat, cfg->zdim, 1, 1); m->a_zb = add_tensor(m, n_z + "/bias", 1, cfg->zdim, 1, 1, 1);
+    m->a_zw = m->a_zb = -1;
+    if (gmv) {
+        // layers take their scope name at first call (model :22-45): conv2d, dense .. dense_3 (w_mu, w_log_sigma, z_mu, z_log_sigma), dense_4 (dec_dense),
+        // conv2d_1; then, outside any scope, dense / dense_1 (p(z|w,c)) and the 0.1 Variable (:48-53)
+        const int hd[4] = {cfg->dim_w, cfg->dim_w, cfg->zdim, cfg->zdim};
+        int ofs = 0;
+        for (int h = 0; h < 4; ++h) {
+            const std::string nmh = h == 0 ? "Bottleneck/dense" : "Bottleneck/dense_" + std::to_string(h);
+            m->gm_hw[h] = add_tensor(m, nmh + "/kernel", 2, m->flat, hd[h], 1, 1); m->gm_hb[h] = add_tensor(m, nmh + "/bias", 1, hd[h], 1, 1, 1);
+            m->gm_hd[h] = hd[h]; m->gm_ho[h] = ofs; ofs += hd[h];
+        }
+    } else {
+        m->a_zw = add_tensor(m, n_z + "/kernel", 2, m->flat, cfg->zdim, 1, 1); m->a_zb = add_tensor(m, n_z + "/bias", 1, cfg->zdim, 1, 1, 1);
+    }
     const long long gen_end_caae = m->nparams;        // 'Encoder' in name: blocks + conv2d + dense
     long long gen_end = caae ? gen_end_caae : m->a_cw;  // AAE: the encoder blocks only (the bottleneck lives in 'Bottleneck')
-    m->a_dw = add_tensor(m, n_dec + "/kernel", 2, cfg->zdim, m->flat, 1, 1); m->a_db = add_tensor(m, n_dec + "/bias", 1, m->flat, 1, 1, 1);
+    const std::string n_dec2 = gmv ? "Bottleneck/dense_4" : n_dec;
+    m->a_dw = add_tensor(m, n_dec2 + "/kernel", 2, cfg->zdim, m->flat, 1, 1); m->a_db = add_tensor(m, n_dec2 + "/bias", 1, m->flat, 1, 1, 1);
     m->a_rw = add_tensor(m, n_rev + "/kernel", 4, 1, 1, m->cmid, m->cenc); m->a_rb = add_tensor(m, n_rev + "/bias", 1, m->cenc, 1, 1, 1);
+    if (gmv) {
+        const int q = cfg->zdim * cfg->dim;
+        m->gm_mw = add_tensor(m, "dense/kernel", 2, cfg->dim_w, q, 1, 1); m->gm_mb = add_tensor(m, "dense/bias", 1, q, 1, 1, 1);
+        m->gm_lw = add_tensor(m, "dense_1/kernel", 2, cfg->dim_w, q, 1, 1); m->gm_lb = add_tensor(m, "dense_1/bias", 1, q, 1, 1, 1);
+        m->gm_var = add_tensor(m, "Variable", 1, q, 1, 1, 1);
+    }
     m->a_dbng = add_tensor(m, "Decoder/batch_normalization/gamma", 1, m->cenc, 1, 1, 1);
     m->a_dbnb = add_tensor(m, "Decoder/batch_normalization/beta", 1, m->cenc, 1, 1, 1);
     cin = m->cenc; res = ir;
@@ -1669,6 +1819,13 @@ static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
     ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->Gx, NB * HW, "Gx"); ALLOC(m->dzbuf, NB * cfg->zdim, "dz"); ALLOC(m->dzr, NB * cfg->zdim, nullptr);
     m->a_slab = nullptr; m->a_crit[0] = m->a_crit[1] = m->a_crit[2] = nullptr;
     if (m->a_critic) { ALLOC(m->a_slab, NB * (size_t)m->a_nd, nullptr); for (int k = 0; k < 3; ++k) ALLOC(m->a_crit[k], NB, nullptr); }
+    m->gm_hv = m->gm_hvm = m->gm_ws = m->gm_M = m->gm_Lq = m->gm_pc = m->gm_loss3 = m->gm_dhv = m->gm_dM = m->gm_dLq = m->gm_dxhat = nullptr;
+    if (gmv) {
+        const size_t q = (size_t)cfg->zdim * cfg->dim;
+        ALLOC(m->gm_hv, NB * m->gm_J, "hv"); ALLOC(m->gm_hvm, NB * m->gm_J, "hvm"); ALLOC(m->gm_ws, NB * cfg->dim_w, "w_s");
+        ALLOC(m->gm_M, NB * q, "M"); ALLOC(m->gm_Lq, NB * q, "Lq"); ALLOC(m->gm_pc, NB * cfg->dim, "pc"); ALLOC(m->gm_loss3, 3 * NB, nullptr);
+        ALLOC(m->gm_dhv, NB * m->gm_J, "dhv"); ALLOC(m->gm_dM, NB * q, nullptr); ALLOC(m->gm_dLq, NB * q, nullptr); ALLOC(m->gm_dxhat, NB * HW, nullptr);
+    }
     {
         size_t wp = 0, need = (size_t)4 << 20;
         auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
@@ -1676,9 +1833,11 @@ static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
         for (size_t i = 1; i < m->E.size(); ++i) { wp_need(m->E[i].d, E2); want(m->E[i].d, NB, true); }
         for (auto& L : m->G) { wp_need(L.d, NB); want(L.d, NB, true); }
         wp_need(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), E2); wp_need(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB);
-        wp_need(dense_desc(1, m->flat, cfg->zdim), E2); wp_need(dense_desc(1, cfg->zdim, m->flat), NB);
         want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), NB, false); want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB, false);
-        want(dense_desc(1, m->flat, cfg->zdim), NB, false); want(dense_desc(1, cfg->zdim, m->flat), NB, false);
+        if (!gmv) {
+            wp_need(dense_desc(1, m->flat, cfg->zdim), E2); wp_need(dense_desc(1, cfg->zdim, m->flat), NB);
+            want(dense_desc(1, m->flat, cfg->zdim), NB, false); want(dense_desc(1, cfg->zdim, m->flat), NB, false);
+        }
         { UadConvDesc d0 = m->E[0].d; d0.N = (int)E2; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
         ALLOC(m->wpartial, wp, nullptr);
         m->ws.floats = need; m->ws.ptr = nullptr;
@@ -2131,13 +2290,25 @@ int uad_gan_reconstruct(uad_gan_t* m, const uad_gan_io_t* io, int n, void* strea
     hipStream_t st = (hipStream_t)stream;
     const size_t img = (size_t)n * m->cfg.height * m->cfg.width;
     refresh_packs(m, st);
-    if (m->variant == UAD_GAN_AAE) { a_encode(m, io->x, io->mask_z, n, 0, st); a_decode(m, m->a_zm, io->mask_g, n, st); }
+    if (m->variant == UAD_GAN_AAE && m->gmv) gmv_forward(m, io, io->x, n, 1.0f / (float)n, st);
+    else if (m->variant == UAD_GAN_AAE) { a_encode(m, io->x, io->mask_z, n, 0, st); a_decode(m, m->a_zm, io->mask_g, n, st); }
     else if (m->variant == UAD_GAN_RESNET) { s_enc_forward(m, io->x, n, st); s_gen_forward(m, m->z, n, st); }
     else if (m->variant == UAD_GAN_ANOVAEGAN) { v_enc_forward(m, io, n, st); gen_forward(m, m->z, nullptr, n, st); }
     else { enc_forward(m, io->x, io->mask_z, n, st); gen_forward(m, m->z, io->mask_g, n, st); }
     if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->variant == UAD_GAN_AAE ? m->a_zm : m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (io->l1_map) hipLaunchKernelGGL((sum_kernel<2>), dim3(256), dim3(256), 0, st, io->x, m->xg, img, io->l1_map, m->redpart);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
+int uad_gan_restore_step(uad_gan_t* m, float* x_restored, const uad_gan_io_t* io, int n, float tv_lambda, float restore_lr, float* grads_out,
+                         void* stream) {
+    if (!m || !io || !x_restored) return fail(UAD_ERR_INVALID, "null argument");
+    if (m->variant != UAD_GAN_AAE || !m->gmv) return fail(UAD_ERR_INVALID, "uad_gan_restore_step needs a dense GMVAE handle");
+    if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
+    const int rc = gmv_phase(m, io, x_restored, n, 1, true, tv_lambda, restore_lr, x_restored, grads_out, (hipStream_t)stream);
+    if (rc != UAD_OK) return rc;
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }

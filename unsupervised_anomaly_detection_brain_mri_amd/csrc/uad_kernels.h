@@ -216,6 +216,35 @@ void uad_launch_tv_dxhat(const float* x, const float* xh, int N, int H, int W, f
                          float* dxhat, hipStream_t st);
 void uad_launch_gm_loss_finalize(const float* rec_partial, int n, int bps, const float* loc_loss, int lps,
                                  float inv_batch, float* rec_per_sample, float* scalars, hipStream_t st);
+// ---- dense GMVAE latent (uad_gmd.hip) ----
+// skinny dense contraction: out[r*ldo + o] (=|+=) mask[r*ldm + o] * (bias[o] + sum_{i<I} a[r*lda + i] * B[i*sBi + o*sBo])
+struct UadSdArgs {
+    const float* a; int lda;
+    const float* B; long long sBi, sBo;
+    const float* bias;          // [O] or null
+    const float* mask; int ldm; // [R, ldm] or null
+    int R, I, O;
+    float* out; int ldo;
+    int accumulate;
+};
+void uad_launch_sd(const UadSdArgs& a, hipStream_t st);
+// dW[k*J + j] = sum_r a[r*lda + k] * g[r*ldg + j], db[j] = sum_r g[r*ldg + j] (db may be null); fixed summation order
+void uad_launch_sd_wgrad(const float* a, int lda, const float* g, int ldg, int R, int K, int J, float* dW, float* db, hipStream_t st);
+struct UadGmdArgs {
+    int W, Z, C, nmax;
+    float c_lambda, inv;                                  // inv: weight of a sample's prior terms in the objective (1/n; 1 when restoring)
+    const float* hv;                                      // [n, 2W+2Z] raw head outputs (bias added, before dropout)
+    const float *mask_wmu, *mask_wls, *mask_zmu;          // [n,W], [n,W], [n,Z] keep/(1-rate) or null
+    const float *e_w, *e_z;                               // [n,W], [n,Z] N(0,1) or null (= 0)
+    const float *Wm, *bm, *Wl, *bl, *var;                 // p(z|w,c): dense [W,Q], [Q], dense_1 [W,Q], [Q], Variable [Q]; Q = Z*C
+    float *hvm, *w_s, *z_s, *M, *Lq, *pc;                 // saved forward state ([n,2W+2Z], [n,W], [n,Z], [n,Q], [n,Q], [n,C])
+    float* loss3;                                         // [3][nmax]: per-sample conditional-prior, w-prior, c-prior terms
+    const float* dz_dec;                                  // [n,Z] decoder-side d / d z_sampled (backward)
+    float *dhv, *dM, *dLq;                                // [n,2W+2Z] d / d raw heads, [n,Q], [n,Q]
+};
+size_t uad_gmd_lds_bytes(int W, int Z, int C);
+void uad_launch_gmd_fwd(const UadGmdArgs& a, int n, hipStream_t st);
+void uad_launch_gmd_bwd(const UadGmdArgs& a, int n, hipStream_t st);
 // dx = data gradient of the first conv, nothing else (f-AnoGAN critic input gradient)
 void uad_launch_conv_first_dgrad_plain(const UadConvDesc& d, const float* g, const float* W, float* dx, hipStream_t st);
 // spatial autoencoder latent: z = mask * lrelu(gamma * rs0 * c + beta) and its backward (colpart [blocks][2][C], blocks as returned)

@@ -15,7 +15,7 @@ GROUPS = {'Encoder': _lib.GAN_ENCODER, 'Generator': _lib.GAN_GENERATOR, 'Discrim
 
 class GanEngine(_EvalOps):
     def __init__(self, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, scale=10.0, kappa=1.0,
-                 device=None, math='bf16x3', variant='unified', dim=64, kl_weight=1.0, aae_kind='aae', rho=1.0):
+                 device=None, math='bf16x3', variant='unified', dim=64, kl_weight=1.0, aae_kind='aae', rho=1.0, dim_w=1, c_lambda=1.0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
@@ -23,7 +23,7 @@ class GanEngine(_EvalOps):
         torch.cuda.set_device(self.device)
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
         variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET, 'anovaegan': _lib.GAN_ANOVAEGAN, 'aae': _lib.GAN_AAE}
-        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2}
+        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2, 'gmvae': 3}     # 'gmvae': zdim = dim_z, dim = dim_c, dim_w, c_lambda
         if variant == 'aae' and aae_kind not in kinds:
             raise ValueError(f'unknown aae_kind {aae_kind!r}')
         self.aae_kind = aae_kind if variant == 'aae' else None
@@ -31,7 +31,8 @@ class GanEngine(_EvalOps):
             raise ValueError(f'unknown f-AnoGAN variant {variant!r}')
         self.variant, self.dim = variant, int(dim)
         cfg = _lib.UadGanConfig(height, width, channels, inter_res, zdim, max_batch, float(scale), float(kappa), variants[variant],
-                                int(dim), float(kl_weight), kinds.get(aae_kind, 1), float(rho))
+                                int(dim), float(kl_weight), kinds.get(aae_kind, 1), float(rho), int(dim_w), float(c_lambda))
+        self.dim_w, self.dim_c = int(dim_w), int(dim)
         h = C.c_void_p()
         _lib.check(self.lib.uad_gan_create(C.byref(cfg), C.byref(h)))
         self.handle = h
@@ -42,7 +43,8 @@ class GanEngine(_EvalOps):
         for i in range(self.lib.uad_gan_num_tensors(h)):
             _lib.check(self.lib.uad_gan_tensor_info(h, i, name, 160, C.byref(off), C.byref(rank), shape))
             self.spec.append((name.value.decode(), tuple(shape[:rank.value]), int(off.value)))
-        dec_dense = {'constrained_ae': 'Bottleneck/dense_1/kernel', 'aae': 'Bottleneck/dense_1/kernel', 'constrained_aae': 'Decoder/dense/kernel'}
+        dec_dense = {'constrained_ae': 'Bottleneck/dense_1/kernel', 'aae': 'Bottleneck/dense_1/kernel', 'constrained_aae': 'Decoder/dense/kernel',
+                     'gmvae': 'Bottleneck/dense_4/kernel'}
         self.flat = [s for n, s, _ in self.spec if n == (dec_dense[aae_kind] if variant == 'aae' else 'Generator/dense/kernel')][0][1]
         self._views = {}
         self.set_math(math)
@@ -180,6 +182,54 @@ class GanEngine(_EvalOps):
             out['gen_loss'] = scal[S.index('gen_loss')]
         self._keep = (x, z, eps, mask_z, mask_dec, mask_rec, scal, out)
         return out
+
+    # ---------------------------------------------------------------- dense GMVAE (variant 'aae', aae_kind 'gmvae')
+    def _gm_io(self, n, eps_w, eps_z, masks):
+        masks = masks or {}
+        t = dict(eps_w=self._dev(eps_w, (n, self.dim_w)), eps=self._dev(eps_z, (n, self.zdim)),
+                 mask_w_mu=self._dev(masks.get('w_mu'), (n, self.dim_w)), mask_w_ls=self._dev(masks.get('w_ls'), (n, self.dim_w)),
+                 mask_z=self._dev(masks.get('z_mu'), (n, self.zdim)), mask_g=self._dev(masks.get('dec'), (n, self.flat)))
+        io = _lib.UadGanIO()
+        for k, v in t.items():
+            setattr(io, k, _ptr(v))
+        return io, t
+
+    def gm_phase(self, x, eps_w=None, eps_z=None, masks=None, want_backward=True, want_l1=True):
+        """One sess.run of trainers/GMVAE.py:122-139: forward + the four loss terms (+ the gradient of `loss` w.r.t. every variable).
+        masks: dict with optional 'w_mu', 'w_ls' [n,dim_w], 'z_mu' [n,dim_z], 'dec' [n,flat] keep masks (already / (1 - rate))."""
+        if self.aae_kind != 'gmvae':
+            raise ValueError('gm_phase needs a dense-GMVAE engine')
+        n = x.shape[0]
+        img = (n, self.h, self.w, self.c)
+        x = self._dev(x, img)
+        io, keep = self._gm_io(n, eps_w, eps_z, masks)
+        scal = torch.zeros(16, device=self.device)
+        out = {'reconstruction': torch.empty(img, device=self.device), 'z_sampled': torch.empty((n, self.zdim), device=self.device)}
+        io.x, io.scalars, io.reconstruction, io.z_enc = _ptr(x), _ptr(scal), _ptr(out['reconstruction']), _ptr(out['z_sampled'])
+        if want_l1:
+            out['L1'] = torch.empty(img, device=self.device); io.l1_map = _ptr(out['L1'])
+        _lib.check(self.lib.uad_gan_phase(self.handle, _lib.GAN_GENERATOR, C.byref(io), n, 1 if want_backward else 0, self._stream()))
+        S = _lib.GAN_SCALARS
+        out.update(loss=scal[S.index('gm_loss')], mean_p_loss=scal[S.index('reconstructionLoss')], reconstructionLoss=scal[S.index('reconstructionLoss')],
+                   conditional_prior_loss=scal[S.index('gm_con')], w_prior_loss=scal[S.index('gm_w')], c_prior_loss=scal[S.index('gm_c')])
+        self._keep = (x, keep, scal, out)
+        return out
+
+    def gm_restore_step(self, x_restored, eps_w=None, eps_z=None, masks=None, tv_lambda=1.8, restore_lr=1e-3, want_grads=False):
+        """trainers/GMVAE.py:172-184 on device: x_restored (a DEVICE tensor, updated in place) -= restore_lr * d(n loss + sum tv TV_n)/dx."""
+        if self.aae_kind != 'gmvae':
+            raise ValueError('gm_restore_step needs a dense-GMVAE engine')
+        if not isinstance(x_restored, torch.Tensor) or x_restored.device != self.device or x_restored.dtype != torch.float32 or not x_restored.is_contiguous():
+            raise ValueError('x_restored must be a contiguous fp32 tensor on the engine device (it is updated in place)')
+        n = x_restored.shape[0]
+        if tuple(x_restored.shape) != (n, self.h, self.w, self.c):
+            raise ValueError('x_restored must be [n,H,W,C]')
+        io, keep = self._gm_io(n, eps_w, eps_z, masks)
+        grads = torch.empty_like(x_restored) if want_grads else None
+        _lib.check(self.lib.uad_gan_restore_step(self.handle, _ptr(x_restored), C.byref(io), n, float(tv_lambda), float(restore_lr),
+                                                 _ptr(grads), self._stream()))
+        self._keep = (keep, grads)
+        return grads
 
     def phase(self, group, x=None, z=None, alpha=None, mask_z=None, mask_g=None, want_backward=True, want_images=True,
               want_l1=False, eps=None, mask_sigma=None):
