@@ -63,7 +63,7 @@ def init_params(spec, seed=3, dtype=np.float64, perturb=True):
             lim = np.sqrt(6.0 / (fan_in + fan_out))
             p[name] = rng.uniform(-lim, lim, shape)
         elif kind == 'gamma':
-            p[name] = 1.0 + (0.1 * rng.standard_normal(shape) if perturb else 0)
+            p[name] = np.ones(shape) + (0.1 * rng.standard_normal(shape) if perturb else 0)
         elif kind == 'const0.1':
             p[name] = np.full(shape, 0.1) + (0.05 * rng.standard_normal(shape) if perturb else 0)
         else:

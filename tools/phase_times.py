@@ -53,4 +53,14 @@ res['anovaegan_128_b64_ms'] = {'VAE': timed(lambda: (eng.phase('Encoder', x=x, e
                                'Generator': timed(lambda: (eng.phase('Generator', x=x, eps=z, want_images=False), eng.adam('Generator', 1e-4))),
                                'Discriminator': timed(lambda: (eng.phase('Discriminator', x=x, eps=z, alpha=e, want_images=False), eng.adam('Discriminator', 1e-4)))}
 eng.close()
+for (dc, dz, dw) in ((6, 1, 1), (9, 128, 64)):
+    eng = GanEngine(128, 128, 1, 8, zdim=dz, max_batch=64, variant='aae', aae_kind='gmvae', dim=dc, dim_w=dw)
+    init(eng)
+    ew = torch.randn(64, dw, device='cuda', generator=g); ez = torch.randn(64, dz, device='cuda', generator=g)
+    xr = x.clone()
+    res[f'gmvae_dense_c{dc}_z{dz}_w{dw}_128_b64_ms'] = {
+        'train': timed(lambda: (eng.gm_phase(x, ew, ez, want_l1=False), eng.adam('AE', 1e-4, 0.5, 0.999))),
+        'forward': timed(lambda: eng.gm_phase(x, ew, ez, want_backward=False, want_l1=False)),
+        'restore_step': timed(lambda: eng.gm_restore_step(xr, ew, ez))}
+    eng.close()
 print(json.dumps(res))

@@ -1859,7 +1859,8 @@ int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (cfg->inter_res <= 0 || (cfg->inter_res & (cfg->inter_res - 1)) || cfg->inter_res >= H)
         return fail(UAD_ERR_INVALID, "inter_res must be a power of two smaller than height");
     if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
-    if (cfg->zdim <= 0 || cfg->zdim % 8) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
+    const bool dense_gmvae = cfg->variant == UAD_GAN_AAE && cfg->aae_kind == 3;      // its latent widths are free (skinny-dense kernels)
+    if (!dense_gmvae && (cfg->zdim <= 0 || cfg->zdim % 8)) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
     if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
     if (cfg->variant != UAD_GAN_UNIFIED && cfg->variant != UAD_GAN_RESNET && cfg->variant != UAD_GAN_ANOVAEGAN && cfg->variant != UAD_GAN_AAE)
         return fail(UAD_ERR_INVALID, "bad variant");
