@@ -84,7 +84,9 @@ typedef struct {
                                      (means over the n samples; [4..6] are written for ceVAE only)       */
     float* rec_per_sample;   /* out [n] sum_hwc L1 (ceVAE: [2n], VAE branch then context branch), may be NULL */
     /* ---- ceVAE only (models/context_encoder_variational_autoencoder.py:9-59); NULL / ignored otherwise ---- */
-    const float* x_ce;       /* in  [n,H,W,C] context-masked input (trainers/CE.py:123-139); NULL = x */
+    const float* x_ce;       /* in  [n,H,W,C] context-masked input (trainers/CE.py:123-139); NULL = x.  ceVAE: the second branch's input.
+                                AE handles (dense / spatial): context-encoder training (trainers/CE.py:19-21,87-92): the network reads x_ce, the L1
+                                term compares x_hat with x */
     const float* mask_mu_ce; /* in  [n,zdim] keep-mask on z_mu_ce (:37); given iff mask_mu is         */
     const float* mask_dec_ce;/* in  [n,flat] keep-mask on dec_dense(z_mu_ce) (:43); given iff mask_dec is */
     float* x_hat_ce;         /* out [n,H,W,C] reconstruction of the context branch, may be NULL      */

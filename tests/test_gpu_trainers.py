@@ -432,3 +432,50 @@ def test_gmvae_dense_trainer_surface(tmp_path):
     assert m2.load_checkpoint() == 2 and m2.engine.step_count('AE') == t
     assert np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w)
     m2.engine.close()
+
+
+@pytest.mark.parametrize('mname', ['autoencoder', 'autoencoder_spatial'])
+def test_context_encoder_trainer(tmp_path, mname):
+    """trainers/CE.py: the network reads the masked batch, the L1 term compares with the clean one; TRAIN step vs the oracle (forward on
+    x_ce, loss / backward against x), VAL = plain AE forward, reconstruct() feeds x_ce = x."""
+    import importlib
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import CE
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers.CE import retrieve_masked_batch
+    net = getattr(importlib.import_module(f'unsupervised_anomaly_detection_brain_mri_amd.models.{mname}'), mname)
+    cfg, opt, ds = _config(CE, tmp_path, h=64, bs=4, epochs=2)
+    model = CE(None, cfg, network=net)
+    assert model.model_dir.startswith('CE_dSyntheticDataset')
+    x, _, bm = ds.next_batch(4, set='TRAIN', return_brainmask=True)
+    x_ce = retrieve_masked_batch(x, bm)
+    assert x_ce.shape == x.shape and (x_ce != x).any()
+    m = ovae.SpatialAE(64, 64, 1, 8) if mname == 'autoencoder_spatial' else ovae.Model('AE', 64, 64, 1, 8, 64)
+    p = {k: v.astype(np.float64) for k, v in model.engine.get_params().items()}
+    masks = model._draw(4, True)[1]
+    m64 = {k: v.astype(np.float64) for k, v in masks.items()}
+    args = (p, x_ce.astype(np.float64), m64) if mname == 'autoencoder_spatial' else (p, x_ce.astype(np.float64), None, m64)
+    out, cache = m.forward(*args)
+    ls = m.losses(x.astype(np.float64), out)
+    g = m.backward(p, x.astype(np.float64), out, cache, m64)
+    got = model.engine.forward(x, None, masks, want_backward=True, x_ce=x_ce)
+    model.engine.backward()
+    assert float(got['scalars'][0]) == pytest.approx(ls['reconstructionLoss'], rel=2e-4)
+    assert np.abs(got['x_hat'].cpu().numpy() - out['x_hat']).max() <= 1e-4 * np.abs(out['x_hat']).max()
+    assert np.abs(got['L1'].cpu().numpy() - ls['L1']).max() <= 2e-4 * np.abs(ls['L1']).max()
+    grads = model.engine.get_grads()
+    for name in ('Encoder/enc_conv2D_0/kernel', 'Encoder/enc_conv2D_1/kernel', 'Decoder/dec_Conv2DT_0/kernel', 'Decoder/dec_Conv2D_final/kernel'):
+        assert np.abs(grads[name] - g[name]).max() <= 1e-4 * np.abs(g[name]).max(), name
+    run = model.step(x, Phase.TRAIN, x_ce=x_ce, dropout_masks=masks)
+    assert set(run) == {'reconstruction', 'L1', 'reconstructionLoss', 'loss'} and run['loss'] == run['reconstructionLoss']
+    assert run['loss'] == pytest.approx(ls['loss'], rel=2e-4)
+    # VAL: x_ce = x
+    v = model.step(x, Phase.VAL)
+    ref = model.engine.forward(x, None, None, want_backward=False)
+    assert v['loss'] == pytest.approx(float(ref['scalars'][0]), rel=1e-6)
+    model.train(ds)
+    assert len(model.curves['TRAIN/loss']) == 2 and model.curves['VAL/loss'][1] < model.curves['VAL/loss'][0]
+    r = model.reconstruct(x[0])
+    assert r['reconstruction'].shape == (1, 64, 64, 1)
+    with pytest.raises(ValueError):
+        from unsupervised_anomaly_detection_brain_mri_amd.models import variational_autoencoder as vnet
+        CE(None, cfg, network=vnet)                                           # the context encoder's loss has no KL term
+    model.engine.close()

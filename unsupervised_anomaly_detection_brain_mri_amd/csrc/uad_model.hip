@@ -538,7 +538,14 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     const int ir = m->cfg.inter_res;
     const int nu = n;                 // samples the caller passed
     const float* xin = io->x;
+    const float* xtgt = io->x;        // what the L1 term compares the reconstruction with
     const float* mask_dec = io->mask_dec;
+    if (!cevae && io->x_ce) {
+        // context-encoder training (trainers/CE.py:19-21,87-92): the network reads the masked batch, the loss compares with the clean one
+        if (m->cfg.arch != UAD_ARCH_AE && m->cfg.arch != UAD_ARCH_AE_SPATIAL)
+            return fail(UAD_ERR_INVALID, "io.x_ce is the ceVAE's second input or an AE handle's context-encoder input");
+        xin = io->x_ce;
+    }
     if (cevae) {
         // both branches as ONE pass over 2n samples through the shared layers: [x ; x_ce]
         if ((io->mask_mu == nullptr) != (io->mask_mu_ce == nullptr) || (io->mask_dec == nullptr) != (io->mask_dec_ce == nullptr))
@@ -644,7 +651,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
             const bool restore_bwd = m->restore && want_backward;
             ep.kind = UAD_EPI_FINAL;
             ep.escale = P(m, DL.gamma); ep.eshift = P(m, DL.beta); ep.ealpha = kLrelu; ep.emult = 1.0f / sqrtf(1.0f + kBnEps);
-            ep.fin_wf = P(m, m->fw); ep.fin_bf = P(m, m->fb); ep.fin_x = xin;
+            ep.fin_wf = P(m, m->fw); ep.fin_bf = P(m, m->fb); ep.fin_x = cevae ? xin : xtgt;
             ep.fin_xhat = (io->x_hat && !cevae) ? io->x_hat : m->xhat_own;
             ep.fin_l1 = cevae ? ((io->l1_map || io->l1_map_ce) ? m->l1_own : nullptr) : io->l1_map;
             ep.fin_rec_partial = m->rec_partial; ep.fin_red_partial = m->red_partial;
@@ -659,7 +666,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     fa.N = n; fa.H = m->cfg.height; fa.W = m->cfg.width; fa.C = DL.d.CB;
     fa.c_last = DL.c; fa.scale = P(m, DL.gamma); fa.shift = P(m, DL.beta); fa.alpha = kLrelu;
     fa.mult = 1.0f / sqrtf(1.0f + kBnEps);
-    fa.wf = P(m, m->fw); fa.bf = P(m, m->fb); fa.x = xin;
+    fa.wf = P(m, m->fw); fa.bf = P(m, m->fb); fa.x = cevae ? xin : xtgt;
     fa.x_hat = (io->x_hat && !cevae) ? io->x_hat : m->xhat_own;
     fa.l1_map = cevae ? ((io->l1_map || io->l1_map_ce) ? m->l1_own : nullptr) : io->l1_map;
     fa.rec_partial = m->rec_partial;

@@ -212,6 +212,7 @@ class Engine(_EvalOps):
                 want_anomaly=True):
         """Returns a dict of DEVICE tensors: x_hat, L1 (opt), z_mu/z_log_sigma/z_sigma or z (opt), scalars [8]
         (reconstructionLoss, kl, loss, 0, Rec_vae, Rec_ce, loss_vae, 0), rec_per_sample [n] ([2n] for ceVAE).
+        AE: x_ce (optional) = context-encoder training, the network reads x_ce and the L1 term compares with x (trainers/CE.py).
         ceVAE additionally takes x_ce (None = x) and masks 'mu_ce'/'dec_ce', and returns x_hat_ce, L1_vae / L1_ce
         (instead of L1) and -- filled in by backward() -- 'anomaly'.  want_backward: False | True | 'data' (data-gradient
         chain only: the ceVAE anomaly map without parameter gradients).  Asynchronous on the current stream."""
@@ -223,8 +224,8 @@ class Engine(_EvalOps):
         if n > self.max_batch:
             raise ValueError(f'batch {n} > max_batch {self.max_batch}')
         ce = self.arch == 'ceVAE'
-        if x_ce is not None and not ce:
-            raise ValueError('x_ce is a ceVAE input')
+        if x_ce is not None and self.arch not in ('ceVAE', 'AE', 'AE_spatial'):
+            raise ValueError('x_ce is a ceVAE input, or the network input of a context-encoder step on an AE engine')
         # spatial AE: the latent (and its dropout mask) is the encoder feature map
         zs = (n, self.inter, self.inter, self._cenc()) if self.arch == 'AE_spatial' else (n, self.zdim)
         eps = self._dev(eps, zs)
