@@ -292,6 +292,13 @@ int uad_gan_reconstruct(uad_gan_t* g, const uad_gan_io_t* io, int n, void* strea
  * io supplies the noise / dropout masks of this run.  No parameter gradient is produced. */
 int uad_gan_restore_step(uad_gan_t* g, float* x_restored, const uad_gan_io_t* io, int n, float tv_lambda, float restore_lr, float* grads_out,
                          void* stream);
+/* hipGraph replay of whole phases (they are 60-250 launches of mostly tiny kernels): on = 1 makes uad_gan_phase / uad_gan_reconstruct /
+ * uad_gan_restore_step capture their launch sequence the second time a (phase, n, want_backward, io pointer set, math mode) combination
+ * is seen and replay it with one hipGraphLaunch afterwards (48 cached graphs, least-recently-used eviction).  The caller must keep the io
+ * pointers stable across calls to benefit; results are identical to the plain path (same kernels, same order).  Work runs on a stream
+ * owned by the handle, fenced against `stream` with events on both sides. */
+int uad_gan_set_graph_mode(uad_gan_t* g, int on);
+int uad_gan_graph_stats(const uad_gan_t* g, long long* captures, long long* replays, int* enabled);
 /* tests: device pointer + element count of a named intermediate of the last phase (NULL name table entry -> error) */
 int uad_gan_debug_buffer(uad_gan_t* g, const char* name, float** ptr, long long* count);
 
