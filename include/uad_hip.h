@@ -228,7 +228,10 @@ enum { UAD_GAN_AAE = 3 };        /* dense-bottleneck BN autoencoder + re-encodin
                                      cfg.zdim = dim_z, cfg.dim = dim_c, cfg.dim_w, cfg.c_lambda; one phase, UAD_GAN_GENERATOR = the optimizer over every
                                      variable (group 1); io.eps_w [n,dim_w] / io.eps [n,dim_z] = reparameterisation noise, io.mask_w_mu / mask_w_ls [n,dim_w],
                                      io.mask_z [n,dim_z] (z_mu; z_log_sigma has no dropout, model :42), io.mask_g [n,flat] (dec_dense);
-                                     scalars: UAD_GAN_S_GM_*; restoration through uad_gan_restore_step */
+                                     scalars: UAD_GAN_S_GM_*; restoration through uad_gan_restore_step.
+                                     4 = the Zimmerer VAE, models/variational_autoencoder_Zimmerer.py:7-32 under trainers/VAE.py:36-42 (k4 s2 convolutions
+                                     16-64-256-1024 + leaky_relu 0.2, no normalisation / dropout; inter_res must be height / 16); one phase,
+                                     UAD_GAN_GENERATOR; io.eps [n,zDim]; scalars UAD_GAN_S_REC_LOSS, UAD_GAN_S_KL, UAD_GAN_S_ENC_LOSS (= loss) */
 enum { UAD_GAN_GROUP_VAE = 3 };   /* uad_gan_group only: the contiguous Encoder + Generator slice (AnoVAE-GAN's optim_vae) */
 enum { UAD_BUF_ADAM_M2 = 4, UAD_BUF_ADAM_V2 = 5 };
 /* scalars[16] written by uad_gan_phase (entries a phase does not compute are left untouched) */
@@ -248,7 +251,7 @@ typedef struct {
                                       height must be 8 * inter_res; no dropout in that graph: mask_z / mask_g are ignored) */
     int dim;                       /* RESNET only: base width (fanogan_schlegl.py:13: 64); 0 = 64 */
     float kl_weight;               /* ANOVAEGAN only: AnoVAEGAN.Config.kl_weight (:17) */
-    int aae_kind;                  /* AAE only: 0 constrained AE, 1 AAE, 2 constrained AAE, 3 dense GMVAE */
+    int aae_kind;                  /* AAE only: 0 constrained AE, 1 AAE, 2 constrained AAE, 3 dense GMVAE, 4 Zimmerer VAE */
     float rho;                     /* AAE only: weight of the latent re-encoding term (ConstrainedAE.Config.rho :15) */
     int dim_w;                     /* dense GMVAE only: GMVAE.Config.dim_w (:17); dim_z = zdim, dim_c = dim */
     float c_lambda;                /* dense GMVAE only: GMVAE.Config.c_lambda (:18) */

@@ -1,0 +1,112 @@
+"""GPU parity of the Zimmerer VAE (models/variational_autoencoder_Zimmerer.py under trainers/VAE.py) through the C-ABI (uad_gan_* with
+UAD_GAN_AAE / aae_kind 4) vs the fp64 oracle: reconstruction, latents, losses, every parameter gradient, Adam trajectory, trainer surface.
+Tolerance 1e-4 max-norm relative (north_star) on the kernels' gradients, 5e-4 on the long bias sums; activation-kink flips (a
+leaky_relu input within rounding of 0 taking the other branch on the device) are counted exactly and loosen the bound as in the GAN tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vae as ovae
+from oracle import zimmerer as oz
+
+pytestmark = pytest.mark.gpu
+
+try:
+    from unsupervised_anomaly_detection_brain_mri_amd import _lib
+    from unsupervised_anomaly_detection_brain_mri_amd.gan_engine import GanEngine, ZimmererEngine
+    from tests.gpu_util import assert_close
+except Exception:
+    GanEngine = None
+
+
+def _f64(d):
+    return {k: np.asarray(v, np.float64) for k, v in d.items()}
+
+
+def _flips(eng, cache, n):
+    """number of leaky_relu inputs whose sign differs between the device run and the oracle."""
+    cnt = 0
+    for i in range(4):
+        for name, ref in ((f'ec{i}', cache['c'][i]), (f'gc{i + 1}', cache['gc'][i])):
+            dev = eng.debug_buffer(name).cpu().numpy()[:ref.size].reshape(ref.shape)
+            cnt += int(((dev > 0) != (ref > 0)).sum())
+    return cnt
+
+
+@pytest.mark.parametrize('h,zd,n', [(32, 16, 2), (64, 32, 3), (128, 128, 2)])
+def test_zimmerer_forward_backward_parity(h, zd, n):
+    m = oz.VAEZimmerer(h, zd)
+    p32 = oz.init_params(m.spec, seed=5, dtype=np.float32)
+    x = ovae.synthetic_slices(n, h, h, seed=1, dtype=np.float32)
+    eps = np.random.default_rng(2).standard_normal((n, zd)).astype(np.float32)
+    p64, x64 = _f64(p32), x.astype(np.float64)
+    out, cache = m.forward(p64, x64, eps.astype(np.float64))
+    ls = m.losses(x64, out)
+    g = m.backward(p64, x64, out, cache)
+    eng = GanEngine(h, h, 1, h // 16, zd, max_batch=n, variant='aae', aae_kind='vae_zimmerer', math='f32')
+    assert [(a, tuple(b)) for a, b, _ in eng.spec] == [(a, tuple(b)) for a, b, _ in m.spec]
+    eng.set_params(p32)
+    got = eng.zim_phase(x, eps)
+    torch.cuda.synchronize()
+    assert_close(got['reconstruction'].cpu().numpy(), out['x_hat'], name='x_hat')
+    assert_close(got['L1'].cpu().numpy(), ls['L1'], tol=2e-4, name='L1')
+    assert_close(got['z'].cpu().numpy(), out['z'], tol=2e-4, name='z')
+    for k in ('reconstructionLoss', 'kl', 'loss'):
+        assert abs(float(got[k]) - ls[k]) <= 2e-4 * max(abs(ls[k]), 1e-3), (k, float(got[k]), ls[k])
+    flips = _flips(eng, cache, n)
+    grads = eng.get_grads()
+    for name, _, _ in m.spec:
+        a, b = grads[name].astype(np.float64), g[name]
+        if flips == 0:
+            assert_close(a, b, tol=1e-4 if name.endswith('kernel') else 5e-4, name=name)
+        else:           # a flipped element changes the gradient by O(its own contribution): bound in the L2 norm
+            assert np.linalg.norm(a - b) <= 5e-2 * max(np.linalg.norm(b), 1e-12), (name, flips)
+    eng.close()
+    with pytest.raises(ValueError):
+        GanEngine(h, h, 1, 8 if h != 128 else 4, zd, max_batch=1, variant='aae', aae_kind='vae_zimmerer')      # inter_res must be height / 16
+
+
+def test_zimmerer_adam_trajectory_and_trainer(tmp_path):
+    h, zd, n = 32, 16, 4
+    m = oz.VAEZimmerer(h, zd)
+    p32 = oz.init_params(m.spec, seed=9, dtype=np.float32, perturb=False)
+    x = ovae.synthetic_slices(n, h, h, seed=3, dtype=np.float32)
+    eps = np.random.default_rng(4).standard_normal((n, zd)).astype(np.float32)
+    p64 = _f64(p32)
+    opt = m.new_opt(p64)
+    eng = ZimmererEngine(h, h, 1, 2, zd, max_batch=n)
+    eng.set_params(p32)
+    ref_l, got_l = [], []
+    for _ in range(6):
+        _, ls, _ = m.train_step(p64, opt, x.astype(np.float64), eps.astype(np.float64), lr=1e-4)
+        ref_l.append(ls['loss'])
+        got_l.append(float(eng.train_step(x, eps, lr=1e-4)['scalars'][2]))
+    np.testing.assert_allclose(got_l, ref_l, rtol=3e-4)
+    assert eng.step_count == 6
+    eng.close()
+
+    from unsupervised_anomaly_detection_brain_mri_amd.models import variational_autoencoder_Zimmerer as net
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import VAE, VAE_You, Phase
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_config, get_options
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset
+    opt_ = get_options(batchsize=4, learningrate=2e-4, numEpochs=2, zDim=16, outputWidth=32, outputHeight=32,
+                       config={'CHECKPOINTDIR': str(tmp_path / 'ck'), 'SAMPLEDIR': str(tmp_path / 'smp')})
+    ds = SyntheticDataset(16, 8, 32, 32, seed=0)
+    cfg = get_config(VAE, opt_, 'ADAM', [2, 2], 0.2, ds)
+    model = VAE(None, cfg, network=net)
+    assert 'variational_autoencoder_Zimmerer' in model.model_dir
+    run = model.step(ds.next_batch(4, set='VAL')[0], Phase.VAL)
+    assert set(run) == {'reconstruction', 'L1', 'reconstructionLoss', 'kl', 'loss'}
+    assert run['loss'] == pytest.approx(run['reconstructionLoss'] + run['kl'], rel=1e-5)
+    model.train(ds)
+    assert len(model.curves['TRAIN/loss']) == 2 and model.curves['VAL/loss'][1] < model.curves['VAL/loss'][0]
+    r = model.reconstruct(ds.next_batch(1, set='VAL')[0][0], eps=0.0)
+    assert r['reconstruction'].shape == (1, 32, 32, 1)
+    w, t = model.engine.get_buffer_host(_lib.BUF_PARAMS), model.engine.step_count
+    model.engine.close()
+    m2 = VAE(None, cfg, network=net, seed=11)
+    assert m2.load_checkpoint() == 2 and m2.engine.step_count == t
+    assert np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w)
+    m2.engine.close()
+    with pytest.raises(ValueError):
+        VAE_You(None, cfg, network=net)

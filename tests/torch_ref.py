@@ -21,7 +21,7 @@ def _conv_same(x, w_hwio, b, stride):
     total = max((out - 1) * stride + k - h, 0)
     pb, pa = total // 2, total - total // 2
     xp = F.pad(x, (pb, pa, pb, pa))
-    return F.conv2d(xp, w_hwio.permute(3, 2, 0, 1), b, stride=stride)
+    return F.conv2d(xp, w_hwio.permute(3, 2, 0, 1).contiguous(), b, stride=stride)
 
 
 def _convT_same(x, w_hwoi, b, stride):

@@ -63,6 +63,13 @@ for (dc, dz, dw) in ((6, 1, 1), (9, 128, 64)):
         'forward': timed(lambda: eng.gm_phase(x, ew, ez, want_backward=False, want_l1=False)),
         'restore_step': timed(lambda: eng.gm_restore_step(xr, ew, ez))}
     eng.close()
+for math in ('f32', 'bf16x3_all'):
+    eng = GanEngine(128, 128, 1, 8, 128, max_batch=64, variant='aae', aae_kind='vae_zimmerer', math=math)
+    init(eng)
+    ez = torch.randn(64, 128, device='cuda', generator=g)
+    res[f'vae_zimmerer_128_b64_{math}_ms'] = {'train': timed(lambda: (eng.zim_phase(x, ez, want_l1=False), eng.adam('AE', 1e-4, 0.5, 0.999)), reps=10),
+                                             'forward': timed(lambda: eng.zim_phase(x, ez, want_backward=False, want_l1=False), reps=10)}
+    eng.close()
 # hipGraph replay (uad_gan_set_graph_mode) vs plain launches: one f-AnoGAN WGAN iteration (1 generator + 5 critic phases) + encoder step
 for (variant, h, bs) in (('unified', 64, 64), ('unified', 128, 64)):
     row = {}

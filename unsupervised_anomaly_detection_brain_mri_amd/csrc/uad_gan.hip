@@ -469,6 +469,35 @@ __global__ void combine_kernel(int phase, const float* __restrict__ raw, float k
     }
 }
 
+
+// ---- Zimmerer VAE elementwise ----
+__global__ void __launch_bounds__(256) lrelu_fwd_kernel(const float* __restrict__ c, float alpha, size_t total4, float* __restrict__ a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const float4 v = reinterpret_cast<const float4*>(c)[i];
+    reinterpret_cast<float4*>(a)[i] = make_float4(v.x > 0.f ? v.x : alpha * v.x, v.y > 0.f ? v.y : alpha * v.y, v.z > 0.f ? v.z : alpha * v.z,
+                                                  v.w > 0.f ? v.w : alpha * v.w);
+}
+__global__ void __launch_bounds__(256) lrelu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ c, float alpha, size_t total4,
+                                                        float* __restrict__ dc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const float4 v = reinterpret_cast<const float4*>(c)[i], g = reinterpret_cast<const float4*>(da)[i];
+    reinterpret_cast<float4*>(dc)[i] = make_float4(v.x > 0.f ? g.x : alpha * g.x, v.y > 0.f ? g.y : alpha * g.y, v.z > 0.f ? g.z : alpha * g.z,
+                                                   v.w > 0.f ? g.w : alpha * g.w);
+}
+// out[(T-1-t)*C + c] = w[t*C + c]
+__global__ void __launch_bounds__(256) flip_taps_kernel(const float* __restrict__ w, int T, int C, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * C) return;
+    const int t = i / C, c = i % C;
+    out[(T - 1 - t) * C + c] = w[i];
+}
+__global__ void __launch_bounds__(256) add_scalar_kernel(float* __restrict__ x, const float* __restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] += b[0];
+}
+
 // ================================================================================================ latent critic (AAE family)
 // MLP zDim -> h1 -> h2 -> 1 with tf.nn.leaky_relu (alpha 0.2): models/adversarial_autoencoder.py:44-64, trainers/AAE.py:41-49.
 // One workgroup (128 threads) per sample does everything that sample contributes: the three critic evaluations (fake z_, real z,
@@ -664,6 +693,11 @@ struct uad_gan {
     long long gm_hw[4], gm_hb[4], gm_mw, gm_mb, gm_lw, gm_lb, gm_var;
     int gm_hd[4], gm_ho[4];            // head widths and column offsets inside a row
     float *gm_hv, *gm_hvm, *gm_ws, *gm_M, *gm_Lq, *gm_pc, *gm_loss3, *gm_dhv, *gm_dM, *gm_dLq, *gm_dxhat;
+    // Zimmerer VAE (aae_kind 4): k4 convolutions + bias + leaky_relu(0.2), no normalisation; E / G hold the blocks (gamma = beta = -1)
+    bool zim;
+    long long z_muw, z_mub, z_lsw, z_lsb, z_dw, z_db, z_fw, z_fb;
+    UadConvDesc z_fd;                  // final k4 s1 conv as the image-side (1-channel "big") relation: S 1, P 2, taps reversed
+    float *z_wflip, *z_dwflip;         // [16 taps][16] reversed final-conv kernel and its gradient
     bool generic16;                    // UAD_MATH_BF16X3_ALL: generic contractions in bf16x3 too (opt-in, not parity-rated)
     struct RB {                        // pre-activation residual block: LN -> ReLU -> conv1 (k3 s1) -> LN -> ReLU -> conv2, + shortcut
         bool gen;                      // generator block: conv2 / shortcut are transposed convolutions
@@ -783,6 +817,7 @@ void reduce_to(uad_gan* m, int k, const float* a, const float* b, size_t n, floa
 
 int refresh_packs(uad_gan* m, hipStream_t st) {
     if (m->packed_valid) return UAD_OK;
+    if (m->zim) { m->packed_valid = true; return UAD_OK; }       // no k5 layers: nothing is packed
     long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
     auto add = [&](const Block& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
     for (size_t i = 1; i < m->E.size(); ++i) add(m->E[i]);
@@ -1175,6 +1210,8 @@ void a_critic(uad_gan* m, int mode, const float* zf, const float* zr, const floa
 }
 
 
+int zim_phase(uad_gan* m, const uad_gan_io_t* io, int n, int want_backward, hipStream_t st);      // Zimmerer VAE, defined with the generic-conv helpers below
+
 // ---- dense GMVAE (aae_kind 3) ----
 UadGmdArgs gmd_args(uad_gan* m, const uad_gan_io_t* io, float inv) {
     UadGmdArgs a;
@@ -1236,6 +1273,10 @@ int gmv_phase(uad_gan* m, const uad_gan_io_t* io, const float* x, int n, int wan
 }
 
 int aae_phase(uad_gan* m, int phase, const uad_gan_io_t* io, int n, int want_backward, hipStream_t st) {
+    if (m->zim) {
+        if (phase != UAD_GAN_GENERATOR) return fail(UAD_ERR_INVALID, "the Zimmerer VAE has one phase (UAD_GAN_GENERATOR): its optimizer covers every variable");
+        return zim_phase(m, io, n, want_backward, st);
+    }
     if (m->gmv) {
         if (phase != UAD_GAN_GENERATOR) return fail(UAD_ERR_INVALID, "the dense GMVAE has one phase (UAD_GAN_GENERATOR): its optimizer covers every variable");
         if (!io->x) return fail(UAD_ERR_INVALID, "GMVAE phase needs io.x");
@@ -1517,6 +1558,105 @@ void s_disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float
 }
 
 
+// ================================================================================================ Zimmerer VAE (aae_kind 4)
+// models/variational_autoencoder_Zimmerer.py:7-32 under trainers/VAE.py:36-42.  Every k4 contraction with >= 4 channels on both sides runs
+// on the generic F / D / W kernels; the two single-channel ends (first conv 1 -> 16, final conv 16 -> 1) run on the image-side kernels:
+// the final k4 s1 convolution is their "data gradient" relation (big = the 1-channel output, S 1, P 2) with the taps reversed.
+constexpr float kZimAlpha = 0.2f;          // tf.nn.leaky_relu default
+void z_act_fwd(const float* c, size_t total, float* a, hipStream_t st) {
+    hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(blocks256(total / 4)), dim3(256), 0, st, c, kZimAlpha, total / 4, a);
+}
+void z_act_bwd(const float* da, const float* c, size_t total, float* dc, hipStream_t st) {
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks256(total / 4)), dim3(256), 0, st, da, c, kZimAlpha, total / 4, dc);
+}
+void zim_forward(uad_gan* m, const uad_gan_io_t* io, int n, hipStream_t st) {
+    const int zd = m->cfg.zdim, H = m->cfg.height;
+    const float* in = io->x;
+    for (size_t i = 0; i < m->E.size(); ++i) {
+        const Block& L = m->E[i];
+        UadConvDesc d = L.d; d.N = n;
+        if (i == 0) uad_launch_conv_first_fwd(d, in, P(m, L.w), P(m, L.b), m->ec[i], st);
+        else g_conv_f(m, L.d, n, in, L.w, P(m, L.b), nullptr, m->ec[i], st);
+        z_act_fwd(m->ec[i], (size_t)n * asz(L), m->ea[i + 1], st);
+        in = m->ea[i + 1];
+    }
+    const UadConvDesc dd = dense_desc(n, m->flat, zd);
+    uad_launch_conv_f(dd, in, no_xform(), P(m, m->z_muw), m->v_mu_raw, epi_bias(P(m, m->z_mub)), st, nullptr, m->ws);
+    uad_launch_conv_f(dd, in, no_xform(), P(m, m->z_lsw), m->v_ls_raw, epi_bias(P(m, m->z_lsb)), st, nullptr, m->ws);
+    uad_launch_reparam_fwd(n, n, zd, m->v_mu_raw, m->v_ls_raw, nullptr, nullptr, nullptr, io->eps, m->v_mu, m->v_ls, m->v_sigma, m->z, m->v_kl, st);
+    uad_launch_conv_f(dense_desc(n, zd, m->flat), m->z, no_xform(), P(m, m->z_dw), m->ga[0], epi_bias(P(m, m->z_db)), st, nullptr, m->ws);
+    for (size_t i = 0; i < m->G.size(); ++i) {
+        const Block& L = m->G[i];
+        g_conv_d(m, L.d, n, m->ga[i], L.w, P(m, L.b), nullptr, m->gc[i + 1], st);
+        z_act_fwd(m->gc[i + 1], (size_t)n * asz(L), m->ga[i + 1], st);
+    }
+    hipLaunchKernelGGL(flip_taps_kernel, dim3(1), dim3(256), 0, st, P(m, m->z_fw), 16, 16, m->z_wflip);
+    UadConvDesc df = m->z_fd; df.N = n;
+    uad_launch_conv_first_dgrad_plain(df, m->ga[m->G.size()], m->z_wflip, m->xg, st);
+    const size_t img = (size_t)n * H * H;
+    hipLaunchKernelGGL(add_scalar_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, P(m, m->z_fb), img);
+}
+// dxh = d loss / d x_hat in m->dxbuf; klw = weight of a sample's KL term; writes every gradient
+void zim_backward(uad_gan* m, const uad_gan_io_t* io, int n, float klw, hipStream_t st) {
+    const int zd = m->cfg.zdim, H = m->cfg.height;
+    UadConvDesc df = m->z_fd; df.N = n;
+    float* g = m->Ga; float* gn = m->Gb;
+    // final conv: kernel gradient in the reversed-tap layout, then un-reversed; bias; data gradient = the "forward" of the image-side relation
+    uad_launch_conv_first_wgrad(df, m->dxbuf, m->ga[m->G.size()], m->z_dwflip, m->wpartial, st);
+    hipLaunchKernelGGL(flip_taps_kernel, dim3(1), dim3(256), 0, st, m->z_dwflip, 16, 16, Gr(m, m->z_fw));
+    uad_launch_colsum(m->dxbuf, n * H * H, 1, Gr(m, m->z_fb), m->colscratch, st);
+    uad_launch_conv_first_fwd(df, m->dxbuf, m->z_wflip, nullptr, g, st);
+    for (int i = (int)m->G.size() - 1; i >= 0; --i) {
+        const Block& L = m->G[i];
+        z_act_bwd(g, m->gc[i + 1], (size_t)n * asz(L), gn, st);                          // gn = d loss / d c
+        uad_launch_colsum(gn, n * L.H * L.W, L.C, Gr(m, L.b), m->colscratch, st);
+        g_conv_w(m, L.d, n, gn, m->ga[i], L.w, st);
+        g_conv_f(m, L.d, n, gn, L.w, nullptr, nullptr, g, st);                           // d / d (block input)
+    }
+    // dec_dense (no activation on its output)
+    const UadConvDesc ddec = dense_desc(n, zd, m->flat), dd = dense_desc(n, m->flat, zd);
+    uad_launch_conv_w(ddec, m->z, no_xform(), g, no_xform(), Gr(m, m->z_dw), m->wpartial, st);
+    uad_launch_colsum(g, n, m->flat, Gr(m, m->z_db), m->colscratch, st);
+    uad_launch_conv_d(ddec, g, no_xform(), P(m, m->z_dw), m->dzbuf, epi_bias(nullptr), st, nullptr, m->ws);
+    uad_launch_reparam_bwd(n, n, zd, m->dzbuf, m->v_mu, m->v_sigma, io->eps, nullptr, nullptr, nullptr, klw, m->v_dmu, m->v_dls, st);
+    const float* flat = m->ea[m->E.size()];
+    uad_launch_conv_w(dd, flat, no_xform(), m->v_dmu, no_xform(), Gr(m, m->z_muw), m->wpartial, st);
+    uad_launch_colsum(m->v_dmu, n, zd, Gr(m, m->z_mub), m->colscratch, st);
+    uad_launch_conv_w(dd, flat, no_xform(), m->v_dls, no_xform(), Gr(m, m->z_lsw), m->wpartial, st);
+    uad_launch_colsum(m->v_dls, n, zd, Gr(m, m->z_lsb), m->colscratch, st);
+    uad_launch_conv_d(dd, m->v_dmu, no_xform(), P(m, m->z_muw), gn, epi_bias(nullptr), st, nullptr, m->ws);
+    uad_launch_conv_d(dd, m->v_dls, no_xform(), P(m, m->z_lsw), g, epi_bias(nullptr, nullptr, gn), st, nullptr, m->ws);   // g = d loss / d a_4
+    for (int i = (int)m->E.size() - 1; i >= 0; --i) {
+        const Block& L = m->E[i];
+        z_act_bwd(g, m->ec[i], (size_t)n * asz(L), gn, st);
+        uad_launch_colsum(gn, n * L.H * L.W, L.C, Gr(m, L.b), m->colscratch, st);
+        if (i == 0) {
+            UadConvDesc d0 = L.d; d0.N = n;
+            uad_launch_conv_first_wgrad(d0, io->x, gn, Gr(m, L.w), m->wpartial, st);
+        } else {
+            g_conv_w(m, L.d, n, m->ea[i], gn, L.w, st);
+            g_conv_d(m, L.d, n, gn, L.w, nullptr, nullptr, g, st);
+        }
+    }
+}
+int zim_phase(uad_gan* m, const uad_gan_io_t* io, int n, int want_backward, hipStream_t st) {
+    if (!io->x) return fail(UAD_ERR_INVALID, "Zimmerer VAE phase needs io.x");
+    const int H = m->cfg.height;
+    const size_t img = (size_t)n * H * H;
+    float* scal = io->scalars ? io->scalars : m->scalars_own;
+    zim_forward(m, io, n, st);
+    reduce_to<2>(m, 0, io->x, m->xg, img, 1.0f / (float)n, io->l1_map, st);                       // reconstructionLoss (trainers/VAE.py:36-38)
+    reduce_to<0>(m, 1, m->v_kl, nullptr, (size_t)n, 1.0f / (float)n, nullptr, st);                 // kl (:39-41)
+    hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, 3, m->raw, 1.0f, scal);
+    if (want_backward) {
+        hipLaunchKernelGGL(sign_scale_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, 1.0f / (float)n, img, m->dxbuf);
+        zim_backward(m, io, n, 1.0f / (float)n, st);
+    }
+    if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return UAD_OK;
+}
+
 // ---- hipGraph replay ----
 // A phase is 60-250 launches of mostly tiny kernels (LayerNorm statistics, reductions, skinny products): launch-bound.  In graph mode
 // the launch sequence of a phase is captured once per distinct (phase, batch, flags, io pointers) and replayed with one hipGraphLaunch.
@@ -1772,9 +1912,104 @@ static int create_resnet(const uad_gan_config_t* cfg, uad_gan_t** out) {
 }
 
 // ---- handle of the AAE family (ConstrainedAE / AAE / ConstrainedAAE); parameter table in TF first-call order ----
+
+static int create_zimmerer(const uad_gan_config_t* cfg, uad_gan_t** out) {
+    const int H = cfg->height, zd = cfg->zdim;
+    if (H < 32 || H % 16) return fail(UAD_ERR_UNSUPPORTED, "Zimmerer VAE: height must be a power of two >= 32");
+    if (cfg->inter_res != H / 16) return fail(UAD_ERR_INVALID, "Zimmerer VAE: intermediateResolutions must be height / 16 (four stride-2 stages)");
+    uad_gan* m = new uad_gan();
+    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->aae_kind = 4; m->zim = true; m->gmv = false; m->a_constrained = m->a_critic = false;
+    m->dim = 0; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1; m->a_zw = m->a_zb = -1;
+    m->npool = 4; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = true;        // nothing is packed: no k5 layers
+    m->step[0] = m->step[1] = m->step[2] = 0;
+    static const int ef[4] = {16, 64, 256, 1024}, gf[4] = {1024, 256, 64, 16};
+    char nm[160];
+    int cin = 1, res = H;
+    for (int i = 0; i < 4; ++i) {
+        Block L;
+        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, ef[i], 4, 2, 1};
+        snprintf(nm, sizeof nm, "enc_conv2D_%d/kernel", i + 1); L.w = add_tensor(m, nm, 4, 4, 4, cin, ef[i]);
+        snprintf(nm, sizeof nm, "enc_conv2D_%d/bias", i + 1); L.b = add_tensor(m, nm, 1, ef[i], 1, 1, 1);
+        L.gamma = L.beta = -1; L.H = L.W = res / 2; L.C = ef[i];
+        m->E.push_back(L);
+        cin = ef[i]; res /= 2;
+    }
+    const int r = res;
+    m->cenc = 1024; m->cmid = 1024; m->flat = r * r * 1024;
+    m->z_muw = add_tensor(m, "dense/kernel", 2, m->flat, zd, 1, 1); m->z_mub = add_tensor(m, "dense/bias", 1, zd, 1, 1, 1);
+    m->z_lsw = add_tensor(m, "dense_1/kernel", 2, m->flat, zd, 1, 1); m->z_lsb = add_tensor(m, "dense_1/bias", 1, zd, 1, 1, 1);
+    m->z_dw = add_tensor(m, "dense_2/kernel", 2, zd, m->flat, 1, 1); m->z_db = add_tensor(m, "dense_2/bias", 1, m->flat, 1, 1, 1);
+    cin = 1024;
+    for (int i = 0; i < 4; ++i) {
+        Block L;
+        L.d = UadConvDesc{1, res * 2, res * 2, gf[i], res, res, cin, 4, 2, 1};
+        snprintf(nm, sizeof nm, "dec_Conv2DT_%d/kernel", i + 1); L.w = add_tensor(m, nm, 4, 4, 4, gf[i], cin);
+        snprintf(nm, sizeof nm, "dec_Conv2DT_%d/bias", i + 1); L.b = add_tensor(m, nm, 1, gf[i], 1, 1, 1);
+        res *= 2;
+        L.gamma = L.beta = -1; L.H = L.W = res; L.C = gf[i];
+        m->G.push_back(L);
+        cin = gf[i];
+    }
+    m->z_fw = add_tensor(m, "dec_Conv2D_final/kernel", 4, 4, 4, 16, 1); m->z_fb = add_tensor(m, "dec_Conv2D_final/bias", 1, 1, 1, 1, 1);
+    m->z_fd = UadConvDesc{1, H, H, 1, H, H, 16, 4, 1, 2};
+    m->g_fw = m->z_fw; m->g_fb = m->z_fb;
+    for (int k = 0; k < 3; ++k) { m->grp_off[k] = 0; m->grp_cnt[k] = m->nparams; }      // one optimizer over every variable
+
+    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H;
+    int rc = UAD_OK;
+#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
+    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
+    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
+    m->wpack_f = m->wpack_d = m->wpack16_f = m->wpack16_d = nullptr;
+    size_t maxact = NB * HW * 16;
+    m->ec.resize(4); m->ea.resize(5, nullptr);
+    for (int i = 0; i < 4; ++i) {
+        const size_t sz = NB * asz(m->E[i]);
+        snprintf(nm, sizeof nm, "ec%d", i); ALLOC(m->ec[i], sz, nm);
+        snprintf(nm, sizeof nm, "ea%d", i + 1); ALLOC(m->ea[i + 1], sz, nm);
+        if (sz > maxact) maxact = sz;
+    }
+    m->gc.resize(5, nullptr); m->ga.resize(5, nullptr);
+    ALLOC(m->ga[0], NB * m->flat, "ga0");
+    for (int i = 0; i < 4; ++i) {
+        const size_t sz = NB * asz(m->G[i]);
+        snprintf(nm, sizeof nm, "gc%d", i + 1); ALLOC(m->gc[i + 1], sz, nm);
+        snprintf(nm, sizeof nm, "ga%d", i + 1); ALLOC(m->ga[i + 1], sz, nm);
+        if (sz > maxact) maxact = sz;
+    }
+    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
+    ALLOC(m->xg, NB * HW, "xg"); ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->z, NB * zd, "z"); ALLOC(m->dzbuf, NB * zd, "dz");
+    ALLOC(m->v_mu_raw, NB * zd, nullptr); ALLOC(m->v_ls_raw, NB * zd, nullptr); ALLOC(m->v_mu, NB * zd, "mu"); ALLOC(m->v_ls, NB * zd, "ls");
+    ALLOC(m->v_sigma, NB * zd, "sigma"); ALLOC(m->v_kl, NB, nullptr); ALLOC(m->v_dmu, NB * zd, nullptr); ALLOC(m->v_dls, NB * zd, nullptr);
+    ALLOC(m->z_wflip, 256, nullptr); ALLOC(m->z_dwflip, 256, nullptr);
+    {
+        size_t wp = 0, need = (size_t)4 << 20;
+        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
+        auto want = [&](UadConvDesc d, size_t n) { d.N = (int)n; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, false); if (v > need) need = v; } };
+        for (size_t i = 1; i < m->E.size(); ++i) { wp_need(m->E[i].d, NB); want(m->E[i].d, NB); }
+        for (auto& L : m->G) { wp_need(L.d, NB); want(L.d, NB); }
+        wp_need(dense_desc(1, m->flat, zd), NB); wp_need(dense_desc(1, zd, m->flat), NB);
+        want(dense_desc(1, m->flat, zd), NB); want(dense_desc(1, zd, m->flat), NB);
+        { UadConvDesc d0 = m->E[0].d; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
+        { UadConvDesc d0 = m->z_fd; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
+        ALLOC(m->wpartial, wp, nullptr);
+        m->ws.floats = need; m->ws.ptr = nullptr;
+        ALLOC(m->ws.ptr, need, nullptr);
+    }
+    size_t cs = 64 * 1024;
+    { const size_t v = uad_colsum_scratch_floats((int)NB, m->flat); if (v > cs) cs = v; }
+    ALLOC(m->colscratch, cs, nullptr);
+    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
+#undef ALLOC
+    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
+    *out = m;
+    return UAD_OK;
+}
+
 static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
     const int H = cfg->height, ir = cfg->inter_res;
-    if (cfg->aae_kind < 0 || cfg->aae_kind > 3) return fail(UAD_ERR_INVALID, "bad aae_kind");
+    if (cfg->aae_kind == 4) return create_zimmerer(cfg, out);
+    if (cfg->aae_kind < 0 || cfg->aae_kind > 4) return fail(UAD_ERR_INVALID, "bad aae_kind");
     const bool gmv = cfg->aae_kind == 3;
     if (gmv) {
         const long long q = (long long)cfg->zdim * cfg->dim;
@@ -2375,7 +2610,8 @@ static int gan_reconstruct_body(uad_gan_t* m, const uad_gan_io_t* io, int n, voi
     hipStream_t st = (hipStream_t)stream;
     const size_t img = (size_t)n * m->cfg.height * m->cfg.width;
     refresh_packs(m, st);
-    if (m->variant == UAD_GAN_AAE && m->gmv) gmv_forward(m, io, io->x, n, 1.0f / (float)n, st);
+    if (m->variant == UAD_GAN_AAE && m->zim) zim_forward(m, io, n, st);
+    else if (m->variant == UAD_GAN_AAE && m->gmv) gmv_forward(m, io, io->x, n, 1.0f / (float)n, st);
     else if (m->variant == UAD_GAN_AAE) { a_encode(m, io->x, io->mask_z, n, 0, st); a_decode(m, m->a_zm, io->mask_g, n, st); }
     else if (m->variant == UAD_GAN_RESNET) { s_enc_forward(m, io->x, n, st); s_gen_forward(m, m->z, n, st); }
     else if (m->variant == UAD_GAN_ANOVAEGAN) { v_enc_forward(m, io, n, st); gen_forward(m, m->z, nullptr, n, st); }

@@ -774,6 +774,8 @@ void uad_launch_conv_first_wgrad(const UadConvDesc& d, const float* x, const flo
         hipLaunchKernelGGL((conv_first_wgrad_kernel<5, 3>), dim3(blocks), dim3(256), lds, st, d, x, g, rpb, partial);
     else if (d.KS == 3 && d.CB == 1)
         hipLaunchKernelGGL((conv_first_wgrad_kernel<3, 1>), dim3(blocks), dim3(256), lds, st, d, x, g, rpb, partial);
+    else if (d.KS == 4 && d.CB == 1)
+        hipLaunchKernelGGL((conv_first_wgrad_kernel<4, 1>), dim3(blocks), dim3(256), lds, st, d, x, g, rpb, partial);
     else
         return;  // validated by the caller (uad_model.hip)
     uad_launch_reduce_partials(partial, blocks, ntap * d.CS, 1.0f, dW, st);

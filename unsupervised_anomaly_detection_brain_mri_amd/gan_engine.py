@@ -24,7 +24,7 @@ class GanEngine(_EvalOps):
         torch.cuda.set_device(self.device)
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
         variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET, 'anovaegan': _lib.GAN_ANOVAEGAN, 'aae': _lib.GAN_AAE}
-        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2, 'gmvae': 3}     # 'gmvae': zdim = dim_z, dim = dim_c, dim_w, c_lambda
+        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2, 'gmvae': 3, 'vae_zimmerer': 4}     # 'gmvae': zdim = dim_z, dim = dim_c, dim_w, c_lambda
         if variant == 'aae' and aae_kind not in kinds:
             raise ValueError(f'unknown aae_kind {aae_kind!r}')
         self.aae_kind = aae_kind if variant == 'aae' else None
@@ -45,7 +45,7 @@ class GanEngine(_EvalOps):
             _lib.check(self.lib.uad_gan_tensor_info(h, i, name, 160, C.byref(off), C.byref(rank), shape))
             self.spec.append((name.value.decode(), tuple(shape[:rank.value]), int(off.value)))
         dec_dense = {'constrained_ae': 'Bottleneck/dense_1/kernel', 'aae': 'Bottleneck/dense_1/kernel', 'constrained_aae': 'Decoder/dense/kernel',
-                     'gmvae': 'Bottleneck/dense_4/kernel'}
+                     'gmvae': 'Bottleneck/dense_4/kernel', 'vae_zimmerer': 'dense_2/kernel'}
         self.flat = [s for n, s, _ in self.spec if n == (dec_dense[aae_kind] if variant == 'aae' else 'Generator/dense/kernel')][0][1]
         self._views = {}
         self.graph, self._pool, self._slot = False, {}, None
@@ -116,7 +116,7 @@ class GanEngine(_EvalOps):
         zeros = np.zeros(self.nparams, np.float32)
         self.set_buffer_host(_lib.BUF_ADAM_M, zeros)
         self.set_buffer_host(_lib.BUF_ADAM_V, zeros)
-        if self.variant in ('anovaegan', 'aae'):
+        if self.variant in ('anovaegan', 'aae') and self.aae_kind != 'vae_zimmerer':      # the Zimmerer VAE has one optimizer, one pair of slots
             self.set_buffer_host(_lib.BUF_ADAM_M2, zeros)
             self.set_buffer_host(_lib.BUF_ADAM_V2, zeros)
         for g in ('Encoder', 'Generator', 'Discriminator'):
@@ -227,6 +227,30 @@ class GanEngine(_EvalOps):
         else:
             out['gen_loss'] = scal[S.index('gen_loss')]
         self._keep = (x, z, eps, mask_z, mask_dec, mask_rec, scal, out)
+        self._slot = None
+        return out
+
+    # ---------------------------------------------------------------- Zimmerer VAE (variant 'aae', aae_kind 'vae_zimmerer')
+    def zim_phase(self, x, eps=None, want_backward=True, want_l1=True):
+        """One sess.run of trainers/VAE.py:83-96 on models/variational_autoencoder_Zimmerer.py: forward, reconstructionLoss / kl / loss and
+        (want_backward) the gradient of `loss` w.r.t. every variable."""
+        if self.aae_kind != 'vae_zimmerer':
+            raise ValueError('zim_phase needs a Zimmerer-VAE engine')
+        self._begin('zim_phase')
+        n = x.shape[0]
+        img = (n, self.h, self.w, self.c)
+        x = self._dev(x, img)
+        eps = self._dev(eps, (n, self.zdim))
+        scal = self._new(16, zero=True)
+        out = {'reconstruction': self._new(img), 'z': self._new((n, self.zdim))}
+        io = _lib.UadGanIO()
+        io.x, io.eps, io.scalars, io.reconstruction, io.z_enc = _ptr(x), _ptr(eps), _ptr(scal), _ptr(out['reconstruction']), _ptr(out['z'])
+        if want_l1:
+            out['L1'] = self._new(img); io.l1_map = _ptr(out['L1'])
+        _lib.check(self.lib.uad_gan_phase(self.handle, _lib.GAN_GENERATOR, C.byref(io), n, 1 if want_backward else 0, self._stream()))
+        S = _lib.GAN_SCALARS
+        out.update(reconstructionLoss=scal[S.index('reconstructionLoss')], kl=scal[S.index('kl')], loss=scal[S.index('enc_loss')])
+        self._keep = (x, eps, scal, out)
         self._slot = None
         return out
 
@@ -361,3 +385,45 @@ class GanEngine(_EvalOps):
         self._keep = (x, mask_z, mask_g, out, eps, mask_sigma)
         self._slot = None
         return out
+
+
+class ZimmererEngine(GanEngine):
+    """The Zimmerer VAE behind the `Engine` surface the AE-family trainers and `parallel.DataParallelStep` drive (forward / backward /
+    adam_step / grad_segment): forward(want_backward=True) already produces every gradient, so backward() has nothing left to do and the
+    whole flat buffer is reported as ONE segment (the last one in `parallel.SEGMENT_ORDER`), all-reduced once."""
+
+    def __init__(self, height, width, channels, inter_res, zdim, max_batch=64, device=None, math='f32'):
+        super().__init__(height, width, channels, inter_res, zdim, max_batch=max_batch, device=device, math=math, variant='aae',
+                         aae_kind='vae_zimmerer')
+        self.arch = 'VAE_Zimmerer'
+
+    def forward(self, x, eps=None, masks=None, want_backward=False, want_l1=True, want_latents=True, **kw):
+        if masks:
+            raise ValueError('models/variational_autoencoder_Zimmerer.py has no dropout layers: masks are not accepted')
+        o = self.zim_phase(x, eps, want_backward=bool(want_backward), want_l1=want_l1)
+        out = {'x_hat': o['reconstruction'], 'z': o['z'], 'scalars': torch.stack([o['reconstructionLoss'], o['kl'], o['loss']])}
+        if want_l1:
+            out['L1'] = o['L1']
+        return out
+
+    def backward(self, segment=_lib.SEG_ALL):
+        return None
+
+    def grad_segment(self, seg):
+        return (0, self.nparams) if seg == _lib.SEG_ENCODER else (0, 0)
+
+    def adam_step(self, lr, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        self.adam('AE', lr, beta1, beta2, eps, grad_scale)
+
+    def train_step(self, x, eps=None, masks=None, lr=1e-4, beta1=0.5, beta2=0.999, adam_eps=1e-8, **kw):
+        out = self.forward(x, eps, masks, want_backward=True, **kw)
+        self.adam_step(lr, beta1, beta2, adam_eps)
+        return out
+
+    @property
+    def step_count(self):
+        return int(self.lib.uad_gan_get_step(self.handle, _lib.GAN_GENERATOR))
+
+    @step_count.setter
+    def step_count(self, t):
+        _lib.check(self.lib.uad_gan_set_step(self.handle, _lib.GAN_GENERATOR, int(t)))

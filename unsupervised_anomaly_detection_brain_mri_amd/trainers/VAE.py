@@ -11,12 +11,21 @@ class VAE(AEMODEL):
             super().__init__('VAE')
 
     ARCH = 'VAE'
+    ARCHS = ('VAE', 'VAE_Zimmerer')          # models/variational_autoencoder.py | models/variational_autoencoder_Zimmerer.py (no dropout layers)
     SCALAR_KEYS = ('reconstructionLoss', 'kl', 'loss')
+
+    def _make_engine(self, device):
+        if self.arch != 'VAE_Zimmerer':
+            return super()._make_engine(device)
+        from ..gan_engine import ZimmererEngine
+        c = self.config
+        return ZimmererEngine(c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]), c.zDim,
+                              max_batch=max(int(c.batchsize), 1), device=device)
 
     def _draw(self, n, dropout):
         z = self.config.zDim
         eps = self.rng.standard_normal((n, z)).astype(np.float32)
-        if not dropout or self.config.dropout_rate <= 0:
+        if not dropout or self.config.dropout_rate <= 0 or self.arch == 'VAE_Zimmerer':
             return eps, None
         r = float(self.config.dropout_rate)
         keep = lambda shape: (self.rng.random(shape) >= r).astype(np.float32) / (1.0 - r)

@@ -10,6 +10,7 @@ from .VAE import VAE
 
 
 class VAE_You(VAE):
+    ARCHS = ('VAE',)                  # restoration runs on the fused VAE handle (uad_restore_step)
     class Config(VAE.Config):
         def __init__(self):          # trainers/VAE_You.py:12-17
             super().__init__()
