@@ -117,12 +117,15 @@ def bench_gmvae(args):
     from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import synthetic_slices
     world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))    # single-GPU rehearsal of the multi-process path: every rank on cuda:0, gloo instead of RCCL
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        dist.init_process_group('gloo', rank=rank, world_size=world) if rehearsal else dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     hh, bs, rs = 256, BATCH, args.restore_steps
     eng = Engine('GMVAE_spatial', hh, hh, 1, 8, max_batch=bs, device=f'cuda:{local_rank}', math=args.math, dim_c=9, dim_z=1, dim_w=1)
     rng = np.random.default_rng(3)
@@ -277,12 +280,15 @@ def bench_fanogan(args):
     from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import synthetic_slices
     world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))    # single-GPU rehearsal of the multi-process path: every rank on cuda:0, gloo instead of RCCL
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        dist.init_process_group('gloo', rank=rank, world_size=world) if rehearsal else dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     hh, bs, zd = args.size or (128 if args.variant == 'anovaegan' else 64), BATCH, 128
     eng = GanEngine(hh, hh, 1, hh // 8 if args.variant == 'resnet' else 8, zd, max_batch=bs, device=f'cuda:{local_rank}', math=args.math,
                     variant=args.variant)
@@ -422,12 +428,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))    # single-GPU rehearsal of the multi-process path: every rank on cuda:0, gloo instead of RCCL
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        dist.init_process_group('gloo', rank=rank, world_size=world) if rehearsal else dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     eng = Engine(args.arch, H, W, 1, INTER, ZDIM, max_batch=BATCH, device=f'cuda:{local_rank}', math=args.math)
     # identical glorot-uniform init on every rank (seed 3), zero bias, gamma 1, beta 0
