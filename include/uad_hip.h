@@ -231,7 +231,11 @@ enum { UAD_GAN_AAE = 3 };        /* dense-bottleneck BN autoencoder + re-encodin
                                      scalars: UAD_GAN_S_GM_*; restoration through uad_gan_restore_step.
                                      4 = the Zimmerer VAE, models/variational_autoencoder_Zimmerer.py:7-32 under trainers/VAE.py:36-42 (k4 s2 convolutions
                                      16-64-256-1024 + leaky_relu 0.2, no normalisation / dropout; inter_res must be height / 16); one phase,
-                                     UAD_GAN_GENERATOR; io.eps [n,zDim]; scalars UAD_GAN_S_REC_LOSS, UAD_GAN_S_KL, UAD_GAN_S_ENC_LOSS (= loss) */
+                                     UAD_GAN_GENERATOR; io.eps [n,zDim]; scalars UAD_GAN_S_REC_LOSS, UAD_GAN_S_KL, UAD_GAN_S_ENC_LOSS (= loss).
+                                     5 = the context-encoding VAE on the same stack, models/context_encoder_variational_autoencoder_Zimmerer.py:8-45 under
+                                     trainers/ceVAE.py:38-51: io.x_ce, both branches as one 2n-sample pass; want_backward 2 = data-gradient chain only
+                                     (io.anomaly without parameter gradients); scalars UAD_GAN_S_LOSS_IMG = Rec_vae, UAD_GAN_S_LOSS_FTS = Rec_ce, UAD_GAN_S_KL,
+                                     UAD_GAN_S_REC_LOSS, UAD_GAN_S_ENC_LOSS = loss, UAD_GAN_S_GM_LOSS = loss_vae */
 enum { UAD_GAN_GROUP_VAE = 3 };   /* uad_gan_group only: the contiguous Encoder + Generator slice (AnoVAE-GAN's optim_vae) */
 enum { UAD_BUF_ADAM_M2 = 4, UAD_BUF_ADAM_V2 = 5 };
 /* scalars[16] written by uad_gan_phase (entries a phase does not compute are left untouched) */
@@ -251,7 +255,7 @@ typedef struct {
                                       height must be 8 * inter_res; no dropout in that graph: mask_z / mask_g are ignored) */
     int dim;                       /* RESNET only: base width (fanogan_schlegl.py:13: 64); 0 = 64 */
     float kl_weight;               /* ANOVAEGAN only: AnoVAEGAN.Config.kl_weight (:17) */
-    int aae_kind;                  /* AAE only: 0 constrained AE, 1 AAE, 2 constrained AAE, 3 dense GMVAE, 4 Zimmerer VAE */
+    int aae_kind;                  /* AAE only: 0 constrained AE, 1 AAE, 2 constrained AAE, 3 dense GMVAE, 4 Zimmerer VAE, 5 Zimmerer ceVAE */
     float rho;                     /* AAE only: weight of the latent re-encoding term (ConstrainedAE.Config.rho :15) */
     int dim_w;                     /* dense GMVAE only: GMVAE.Config.dim_w (:17); dim_z = zdim, dim_c = dim */
     float c_lambda;                /* dense GMVAE only: GMVAE.Config.c_lambda (:18) */
@@ -272,6 +276,9 @@ typedef struct {
     const float* eps_w;            /* dense GMVAE: [n,dim_w] N(0,1) noise of w_sampled (NULL = 0); io.eps is z_sampled's */
     const float* mask_w_mu;        /* dense GMVAE: optional [n,dim_w] keep masks of the w_mu / w_log_sigma heads */
     const float* mask_w_ls;
+    const float* x_ce;             /* ceVAE on the Zimmerer stack (aae_kind 5): [n,H,W,1] context-masked input (NULL = x) */
+    float* l1_map_ce;              /* ... optional out [n,H,W,1]: |x_ce - x_hat_ce| (io.l1_map is the VAE branch's, io.generated = x_hat_ce) */
+    float* anomaly;                /* ... optional out [n,H,W,1]: L1_vae * |d loss_vae / d x| (written when want_backward != 0) */
 } uad_gan_io_t;
 int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out);
 int uad_gan_destroy(uad_gan_t* g);

@@ -110,3 +110,84 @@ def test_zimmerer_adam_trajectory_and_trainer(tmp_path):
     m2.engine.close()
     with pytest.raises(ValueError):
         VAE_You(None, cfg, network=net)
+
+
+@pytest.mark.parametrize('h,zd,n', [(32, 16, 2), (64, 32, 2)])
+def test_zimmerer_cevae_parity(h, zd, n):
+    """models/context_encoder_variational_autoencoder_Zimmerer.py under trainers/ceVAE.py:38-51: both branches, every loss scalar, every
+    parameter gradient of `loss`, the anomaly map, and the data-only mode (anomaly without parameter gradients)."""
+    m = oz.CeVAEZimmerer(h, zd)
+    p32 = oz.init_params(m.spec, seed=6, dtype=np.float32)
+    x = ovae.synthetic_slices(n, h, h, seed=2, dtype=np.float32)
+    x_ce = x.copy(); x_ce[:, h // 4:h // 4 + 10, h // 3:h // 3 + 10] = 0
+    eps = np.random.default_rng(3).standard_normal((n, zd)).astype(np.float32)
+    p64 = _f64(p32)
+    out, caches = m.ce_forward(p64, x.astype(np.float64), x_ce.astype(np.float64), eps.astype(np.float64))
+    ls = m.ce_losses(x.astype(np.float64), x_ce.astype(np.float64), out)
+    g = m.ce_backward(p64, x.astype(np.float64), x_ce.astype(np.float64), out, caches)
+    eng = GanEngine(h, h, 1, h // 16, zd, max_batch=n, variant='aae', aae_kind='cevae_zimmerer', math='f32')
+    assert [(a, tuple(b)) for a, b, _ in eng.spec] == [(a, tuple(b)) for a, b, _ in m.spec]
+    eng.set_params(p32)
+    sentinel = np.full(eng.nparams, 2.0, np.float32)
+    eng.set_buffer_host(_lib.BUF_GRADS, sentinel)
+    d = eng.zim_phase(x, eps, want_backward='data', x_ce=x_ce)
+    torch.cuda.synchronize()
+    anomaly_data = d['anomaly'].clone()
+    assert np.array_equal(eng.get_buffer_host(_lib.BUF_GRADS), sentinel)          # data mode writes no parameter gradient
+    got = eng.zim_phase(x, eps, x_ce=x_ce)
+    torch.cuda.synchronize()
+    assert torch.equal(got['anomaly'], anomaly_data)
+    assert_close(got['reconstruction'].cpu().numpy(), out['x_hat'], name='x_hat')
+    assert_close(got['reconstruction_ce'].cpu().numpy(), out['x_hat_ce'], name='x_hat_ce')
+    assert_close(got['L1'].cpu().numpy(), ls['L1_vae'], tol=2e-4, name='L1_vae')
+    assert_close(got['L1_ce'].cpu().numpy(), ls['L1_ce'], tol=2e-4, name='L1_ce')
+    for k in ('reconstructionLoss', 'kl', 'loss', 'Rec_vae', 'Rec_ce', 'loss_vae'):
+        assert abs(float(got[k]) - ls[k]) <= 2e-4 * max(abs(ls[k]), 1e-3), (k, float(got[k]), ls[k])
+    # kink flips over both branches (device buffers hold [x ; x_ce] rows)
+    flips = 0
+    for i in range(4):
+        for name, a, b in ((f'ec{i}', caches[0]['c'][i], caches[1]['c'][i]), (f'gc{i + 1}', caches[0]['gc'][i], caches[1]['gc'][i])):
+            ref = np.concatenate([a, b], axis=0)
+            dev = eng.debug_buffer(name).cpu().numpy()[:ref.size].reshape(ref.shape)
+            flips += int(((dev > 0) != (ref > 0)).sum())
+    grads = eng.get_grads()
+    for name, _, _ in m.spec:
+        a, b = grads[name].astype(np.float64), g[name]
+        if flips == 0:
+            assert_close(a, b, tol=1e-4 if name.endswith('kernel') else 5e-4, name=name)
+        else:
+            assert np.linalg.norm(a - b) <= 5e-2 * max(np.linalg.norm(b), 1e-12), (name, flips)
+    an, ar = got['anomaly'].cpu().numpy().astype(np.float64), g['__anomaly']
+    if flips == 0:
+        # |dx| has a kink of its own at 0 (sign of the L1 term): pixels whose residual is within rounding of 0 may differ by 2/n * |x - x_hat| ~ 0
+        assert np.abs(an - ar).max() <= 3e-4 * np.abs(ar).max()
+    else:
+        assert np.linalg.norm(an - ar) <= 5e-2 * np.linalg.norm(ar)
+    eng.close()
+
+
+def test_zimmerer_cevae_trainer(tmp_path):
+    from unsupervised_anomaly_detection_brain_mri_amd.models import context_encoder_variational_autoencoder_Zimmerer as net
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import ceVAE, Phase
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_config, get_options
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset
+    opt_ = get_options(batchsize=4, learningrate=2e-4, numEpochs=2, zDim=16, outputWidth=32, outputHeight=32,
+                       config={'CHECKPOINTDIR': str(tmp_path / 'ck'), 'SAMPLEDIR': str(tmp_path / 'smp')})
+    ds = SyntheticDataset(16, 8, 32, 32, seed=0)
+    cfg = get_config(ceVAE, opt_, 'ADAM', [2, 2], 0.2, ds)
+    model = ceVAE(None, cfg, network=net)
+    x = ds.next_batch(4, set='VAL')[0]
+    run = model.step(x, Phase.VAL)
+    assert set(run) == {'Rec_ce', 'Rec_vae', 'reconstructionLoss', 'kl', 'loss', 'loss_vae', 'reconstruction', 'reconstruction_ce', 'L1_vae', 'L1_ce',
+                        'L1', 'anomaly'}
+    assert run['loss'] == pytest.approx(run['Rec_vae'] + run['kl'] + run['Rec_ce'], rel=1e-5)
+    assert run['loss_vae'] == pytest.approx(run['Rec_vae'] + run['kl'], rel=1e-5)
+    # VAL feeds x_ce = x, but the context branch decodes mu (no sampling): the two reconstructions differ unless eps = 0
+    r0 = model.step(x, Phase.VAL, eps=np.zeros((4, 16), np.float32))
+    assert np.allclose(r0['reconstruction'], r0['reconstruction_ce'], atol=1e-6) and r0['Rec_vae'] == pytest.approx(r0['Rec_ce'], rel=1e-6)
+    model.train(ds)
+    assert len(model.curves['TRAIN/loss']) == 2 and model.curves['VAL/loss'][1] < model.curves['VAL/loss'][0]
+    rec = model.reconstruct(x[:2], eps=0.0)
+    assert rec['reconstruction'].shape == (2, 32, 32, 1) and rec['anomaly'].shape == (2, 32, 32, 1)
+    assert np.allclose(rec['reconstruction'], x[:2] - rec['anomaly'])               # use_gradient_based_restoration (ceVAE.py:138-141)
+    model.engine.close()

@@ -42,7 +42,7 @@ class UadGanConfig(C.Structure):
 
 class UadGanIO(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('x', 'z', 'alpha', 'mask_z', 'mask_g', 'generated', 'reconstruction', 'z_enc',
-                                          'l1_map', 'scalars', 'eps', 'mask_sigma', 'eps_w', 'mask_w_mu', 'mask_w_ls')]
+                                          'l1_map', 'scalars', 'eps', 'mask_sigma', 'eps_w', 'mask_w_mu', 'mask_w_ls', 'x_ce', 'l1_map_ce', 'anomaly')]
 
 
 GAN_ENCODER, GAN_GENERATOR, GAN_DISCRIMINATOR = 0, 1, 2

@@ -458,6 +458,9 @@ __global__ void combine_kernel(int phase, const float* __restrict__ raw, float k
     } else if (phase == 4) {      // AAE family, autoencoder phase: raw = {mean L2, mean Rec_z, reconstructionLoss}, kappa = rho
         out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
         out[UAD_GAN_S_REC_LOSS] = raw[2];
+    } else if (phase == 6) {      // ceVAE (Zimmerer stack): raw = {Rec_vae, Rec_ce, kl}
+        out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_KL] = raw[2];
+        out[UAD_GAN_S_REC_LOSS] = 0.5f * (raw[0] + raw[1]); out[UAD_GAN_S_ENC_LOSS] = (raw[0] + raw[2]) + raw[1]; out[UAD_GAN_S_GM_LOSS] = raw[0] + raw[2];
     } else if (phase == 5) {      // dense GMVAE: raw = {mean_p_loss, conditional_prior_loss, w_prior_loss, c_prior_loss}
         out[UAD_GAN_S_REC_LOSS] = raw[0]; out[UAD_GAN_S_GM_CON] = raw[1]; out[UAD_GAN_S_GM_W] = raw[2]; out[UAD_GAN_S_GM_C] = raw[3];
         out[UAD_GAN_S_GM_LOSS] = ((raw[0] + raw[1]) + raw[2]) + raw[3];
@@ -694,7 +697,8 @@ struct uad_gan {
     int gm_hd[4], gm_ho[4];            // head widths and column offsets inside a row
     float *gm_hv, *gm_hvm, *gm_ws, *gm_M, *gm_Lq, *gm_pc, *gm_loss3, *gm_dhv, *gm_dM, *gm_dLq, *gm_dxhat;
     // Zimmerer VAE (aae_kind 4): k4 convolutions + bias + leaky_relu(0.2), no normalisation; E / G hold the blocks (gamma = beta = -1)
-    bool zim;
+    bool zim, zim_ce;                  // zim_ce (aae_kind 5): the context-encoding VAE on the same stack, both branches as one 2n-sample pass
+    float* z_l1;                       // [2n] L1 maps of both branches
     long long z_muw, z_mub, z_lsw, z_lsb, z_dw, z_db, z_fw, z_fb;
     UadConvDesc z_fd;                  // final k4 s1 conv as the image-side (1-channel "big") relation: S 1, P 2, taps reversed
     float *z_wflip, *z_dwflip;         // [16 taps][16] reversed final-conv kernel and its gradient
@@ -1569,9 +1573,10 @@ void z_act_fwd(const float* c, size_t total, float* a, hipStream_t st) {
 void z_act_bwd(const float* da, const float* c, size_t total, float* dc, hipStream_t st) {
     hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks256(total / 4)), dim3(256), 0, st, da, c, kZimAlpha, total / 4, dc);
 }
-void zim_forward(uad_gan* m, const uad_gan_io_t* io, int n, hipStream_t st) {
+// n samples, the first n_vae of them sampled (z = mu + eps sigma, KL), the rest decode z = mu (the ceVAE's context branch)
+void zim_forward(uad_gan* m, const float* xin, const float* eps, int n, int n_vae, hipStream_t st) {
     const int zd = m->cfg.zdim, H = m->cfg.height;
-    const float* in = io->x;
+    const float* in = xin;
     for (size_t i = 0; i < m->E.size(); ++i) {
         const Block& L = m->E[i];
         UadConvDesc d = L.d; d.N = n;
@@ -1583,7 +1588,7 @@ void zim_forward(uad_gan* m, const uad_gan_io_t* io, int n, hipStream_t st) {
     const UadConvDesc dd = dense_desc(n, m->flat, zd);
     uad_launch_conv_f(dd, in, no_xform(), P(m, m->z_muw), m->v_mu_raw, epi_bias(P(m, m->z_mub)), st, nullptr, m->ws);
     uad_launch_conv_f(dd, in, no_xform(), P(m, m->z_lsw), m->v_ls_raw, epi_bias(P(m, m->z_lsb)), st, nullptr, m->ws);
-    uad_launch_reparam_fwd(n, n, zd, m->v_mu_raw, m->v_ls_raw, nullptr, nullptr, nullptr, io->eps, m->v_mu, m->v_ls, m->v_sigma, m->z, m->v_kl, st);
+    uad_launch_reparam_fwd(n, n_vae, zd, m->v_mu_raw, m->v_ls_raw, nullptr, nullptr, nullptr, eps, m->v_mu, m->v_ls, m->v_sigma, m->z, m->v_kl, st);
     uad_launch_conv_f(dense_desc(n, zd, m->flat), m->z, no_xform(), P(m, m->z_dw), m->ga[0], epi_bias(P(m, m->z_db)), st, nullptr, m->ws);
     for (size_t i = 0; i < m->G.size(); ++i) {
         const Block& L = m->G[i];
@@ -1596,45 +1601,58 @@ void zim_forward(uad_gan* m, const uad_gan_io_t* io, int n, hipStream_t st) {
     const size_t img = (size_t)n * H * H;
     hipLaunchKernelGGL(add_scalar_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, P(m, m->z_fb), img);
 }
-// dxh = d loss / d x_hat in m->dxbuf; klw = weight of a sample's KL term; writes every gradient
-void zim_backward(uad_gan* m, const uad_gan_io_t* io, int n, float klw, hipStream_t st) {
+// dxh = d loss / d x_hat in m->dxbuf; klw = weight of a sample's KL term; pg: also every parameter gradient; anomaly (optional, [n_vae]):
+// |x - x_hat| * |d loss_vae / d x| of the sampled branch (trainers/ceVAE.py:51)
+void zim_backward(uad_gan* m, const float* xin, const float* eps, int n, int n_vae, float klw, bool pg, float* anomaly, hipStream_t st) {
     const int zd = m->cfg.zdim, H = m->cfg.height;
     UadConvDesc df = m->z_fd; df.N = n;
     float* g = m->Ga; float* gn = m->Gb;
     // final conv: kernel gradient in the reversed-tap layout, then un-reversed; bias; data gradient = the "forward" of the image-side relation
-    uad_launch_conv_first_wgrad(df, m->dxbuf, m->ga[m->G.size()], m->z_dwflip, m->wpartial, st);
-    hipLaunchKernelGGL(flip_taps_kernel, dim3(1), dim3(256), 0, st, m->z_dwflip, 16, 16, Gr(m, m->z_fw));
-    uad_launch_colsum(m->dxbuf, n * H * H, 1, Gr(m, m->z_fb), m->colscratch, st);
+    if (pg) {
+        uad_launch_conv_first_wgrad(df, m->dxbuf, m->ga[m->G.size()], m->z_dwflip, m->wpartial, st);
+        hipLaunchKernelGGL(flip_taps_kernel, dim3(1), dim3(256), 0, st, m->z_dwflip, 16, 16, Gr(m, m->z_fw));
+        uad_launch_colsum(m->dxbuf, n * H * H, 1, Gr(m, m->z_fb), m->colscratch, st);
+    }
     uad_launch_conv_first_fwd(df, m->dxbuf, m->z_wflip, nullptr, g, st);
     for (int i = (int)m->G.size() - 1; i >= 0; --i) {
         const Block& L = m->G[i];
         z_act_bwd(g, m->gc[i + 1], (size_t)n * asz(L), gn, st);                          // gn = d loss / d c
-        uad_launch_colsum(gn, n * L.H * L.W, L.C, Gr(m, L.b), m->colscratch, st);
-        g_conv_w(m, L.d, n, gn, m->ga[i], L.w, st);
+        if (pg) {
+            uad_launch_colsum(gn, n * L.H * L.W, L.C, Gr(m, L.b), m->colscratch, st);
+            g_conv_w(m, L.d, n, gn, m->ga[i], L.w, st);
+        }
         g_conv_f(m, L.d, n, gn, L.w, nullptr, nullptr, g, st);                           // d / d (block input)
     }
     // dec_dense (no activation on its output)
     const UadConvDesc ddec = dense_desc(n, zd, m->flat), dd = dense_desc(n, m->flat, zd);
-    uad_launch_conv_w(ddec, m->z, no_xform(), g, no_xform(), Gr(m, m->z_dw), m->wpartial, st);
-    uad_launch_colsum(g, n, m->flat, Gr(m, m->z_db), m->colscratch, st);
+    if (pg) {
+        uad_launch_conv_w(ddec, m->z, no_xform(), g, no_xform(), Gr(m, m->z_dw), m->wpartial, st);
+        uad_launch_colsum(g, n, m->flat, Gr(m, m->z_db), m->colscratch, st);
+    }
     uad_launch_conv_d(ddec, g, no_xform(), P(m, m->z_dw), m->dzbuf, epi_bias(nullptr), st, nullptr, m->ws);
-    uad_launch_reparam_bwd(n, n, zd, m->dzbuf, m->v_mu, m->v_sigma, io->eps, nullptr, nullptr, nullptr, klw, m->v_dmu, m->v_dls, st);
+    uad_launch_reparam_bwd(n, n_vae, zd, m->dzbuf, m->v_mu, m->v_sigma, eps, nullptr, nullptr, nullptr, klw, m->v_dmu, m->v_dls, st);
     const float* flat = m->ea[m->E.size()];
-    uad_launch_conv_w(dd, flat, no_xform(), m->v_dmu, no_xform(), Gr(m, m->z_muw), m->wpartial, st);
-    uad_launch_colsum(m->v_dmu, n, zd, Gr(m, m->z_mub), m->colscratch, st);
-    uad_launch_conv_w(dd, flat, no_xform(), m->v_dls, no_xform(), Gr(m, m->z_lsw), m->wpartial, st);
-    uad_launch_colsum(m->v_dls, n, zd, Gr(m, m->z_lsb), m->colscratch, st);
+    if (pg) {
+        uad_launch_conv_w(dd, flat, no_xform(), m->v_dmu, no_xform(), Gr(m, m->z_muw), m->wpartial, st);
+        uad_launch_colsum(m->v_dmu, n, zd, Gr(m, m->z_mub), m->colscratch, st);
+        uad_launch_conv_w(dd, flat, no_xform(), m->v_dls, no_xform(), Gr(m, m->z_lsw), m->wpartial, st);
+        uad_launch_colsum(m->v_dls, n, zd, Gr(m, m->z_lsb), m->colscratch, st);
+    }
     uad_launch_conv_d(dd, m->v_dmu, no_xform(), P(m, m->z_muw), gn, epi_bias(nullptr), st, nullptr, m->ws);
     uad_launch_conv_d(dd, m->v_dls, no_xform(), P(m, m->z_lsw), g, epi_bias(nullptr, nullptr, gn), st, nullptr, m->ws);   // g = d loss / d a_4
     for (int i = (int)m->E.size() - 1; i >= 0; --i) {
         const Block& L = m->E[i];
         z_act_bwd(g, m->ec[i], (size_t)n * asz(L), gn, st);
-        uad_launch_colsum(gn, n * L.H * L.W, L.C, Gr(m, L.b), m->colscratch, st);
+        if (pg) uad_launch_colsum(gn, n * L.H * L.W, L.C, Gr(m, L.b), m->colscratch, st);
         if (i == 0) {
             UadConvDesc d0 = L.d; d0.N = n;
-            uad_launch_conv_first_wgrad(d0, io->x, gn, Gr(m, L.w), m->wpartial, st);
+            if (pg) uad_launch_conv_first_wgrad(d0, xin, gn, Gr(m, L.w), m->wpartial, st);
+            if (anomaly) {
+                d0.N = n_vae;
+                uad_launch_conv_first_dgrad(d0, gn, P(m, L.w), xin, m->xg, 1.0f / (float)n_vae, anomaly, nullptr, st);
+            }
         } else {
-            g_conv_w(m, L.d, n, m->ea[i], gn, L.w, st);
+            if (pg) g_conv_w(m, L.d, n, m->ea[i], gn, L.w, st);
             g_conv_d(m, L.d, n, gn, L.w, nullptr, nullptr, g, st);
         }
     }
@@ -1644,13 +1662,34 @@ int zim_phase(uad_gan* m, const uad_gan_io_t* io, int n, int want_backward, hipS
     const int H = m->cfg.height;
     const size_t img = (size_t)n * H * H;
     float* scal = io->scalars ? io->scalars : m->scalars_own;
-    zim_forward(m, io, n, st);
+    if (m->zim_ce) {
+        // trainers/ceVAE.py:38-51 on models/context_encoder_variational_autoencoder_Zimmerer.py: [x ; x_ce] as one 2n-sample pass through the
+        // shared layers; the context rows decode z = mu and carry no KL term; each branch is scored against ITS OWN input (:39)
+        HIP_TRY(hipMemcpyAsync(m->a_xcat, io->x, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(m->a_xcat + img, io->x_ce ? io->x_ce : io->x, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        zim_forward(m, m->a_xcat, io->eps, 2 * n, n, st);
+        reduce_to<2>(m, 0, m->a_xcat, m->xg, img, 1.0f / (float)n, m->z_l1, st);                         // Rec_vae
+        reduce_to<2>(m, 1, m->a_xcat + img, m->xg + img, img, 1.0f / (float)n, m->z_l1 + img, st);       // Rec_ce
+        reduce_to<0>(m, 2, m->v_kl, nullptr, (size_t)n, 1.0f / (float)n, nullptr, st);                   // kl
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, 6, m->raw, 0.0f, scal);
+        if (want_backward) {
+            hipLaunchKernelGGL(sign_scale_kernel, dim3(blocks256(2 * img)), dim3(256), 0, st, m->xg, m->a_xcat, 1.0f / (float)n, 2 * img, m->dxbuf);
+            zim_backward(m, m->a_xcat, io->eps, 2 * n, n, 1.0f / (float)n, want_backward == 1, io->anomaly, st);
+        }
+        if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (io->generated) HIP_TRY(hipMemcpyAsync(io->generated, m->xg + img, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (io->l1_map) HIP_TRY(hipMemcpyAsync(io->l1_map, m->z_l1, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (io->l1_map_ce) HIP_TRY(hipMemcpyAsync(io->l1_map_ce, m->z_l1 + img, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return UAD_OK;
+    }
+    zim_forward(m, io->x, io->eps, n, n, st);
     reduce_to<2>(m, 0, io->x, m->xg, img, 1.0f / (float)n, io->l1_map, st);                       // reconstructionLoss (trainers/VAE.py:36-38)
     reduce_to<0>(m, 1, m->v_kl, nullptr, (size_t)n, 1.0f / (float)n, nullptr, st);                 // kl (:39-41)
     hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, 3, m->raw, 1.0f, scal);
     if (want_backward) {
         hipLaunchKernelGGL(sign_scale_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, 1.0f / (float)n, img, m->dxbuf);
-        zim_backward(m, io, n, 1.0f / (float)n, st);
+        zim_backward(m, io->x, io->eps, n, n, 1.0f / (float)n, true, nullptr, st);
     }
     if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1918,7 +1957,9 @@ static int create_zimmerer(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (H < 32 || H % 16) return fail(UAD_ERR_UNSUPPORTED, "Zimmerer VAE: height must be a power of two >= 32");
     if (cfg->inter_res != H / 16) return fail(UAD_ERR_INVALID, "Zimmerer VAE: intermediateResolutions must be height / 16 (four stride-2 stages)");
     uad_gan* m = new uad_gan();
-    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->aae_kind = 4; m->zim = true; m->gmv = false; m->a_constrained = m->a_critic = false;
+    const bool ce = cfg->aae_kind == 5;
+    const std::string se = ce ? "Encoder/" : "", sb = ce ? "Bottleneck/" : "", sdc = ce ? "Decoder/" : "";
+    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->aae_kind = cfg->aae_kind; m->zim = true; m->zim_ce = ce; m->gmv = false; m->a_constrained = m->a_critic = false;
     m->dim = 0; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1; m->a_zw = m->a_zb = -1;
     m->npool = 4; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = true;        // nothing is packed: no k5 layers
     m->step[0] = m->step[1] = m->step[2] = 0;
@@ -1928,39 +1969,41 @@ static int create_zimmerer(const uad_gan_config_t* cfg, uad_gan_t** out) {
     for (int i = 0; i < 4; ++i) {
         Block L;
         L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, ef[i], 4, 2, 1};
-        snprintf(nm, sizeof nm, "enc_conv2D_%d/kernel", i + 1); L.w = add_tensor(m, nm, 4, 4, 4, cin, ef[i]);
-        snprintf(nm, sizeof nm, "enc_conv2D_%d/bias", i + 1); L.b = add_tensor(m, nm, 1, ef[i], 1, 1, 1);
+        snprintf(nm, sizeof nm, "enc_conv2D_%d/kernel", i + 1); L.w = add_tensor(m, se + nm, 4, 4, 4, cin, ef[i]);
+        snprintf(nm, sizeof nm, "enc_conv2D_%d/bias", i + 1); L.b = add_tensor(m, se + nm, 1, ef[i], 1, 1, 1);
         L.gamma = L.beta = -1; L.H = L.W = res / 2; L.C = ef[i];
         m->E.push_back(L);
         cin = ef[i]; res /= 2;
     }
     const int r = res;
     m->cenc = 1024; m->cmid = 1024; m->flat = r * r * 1024;
-    m->z_muw = add_tensor(m, "dense/kernel", 2, m->flat, zd, 1, 1); m->z_mub = add_tensor(m, "dense/bias", 1, zd, 1, 1, 1);
-    m->z_lsw = add_tensor(m, "dense_1/kernel", 2, m->flat, zd, 1, 1); m->z_lsb = add_tensor(m, "dense_1/bias", 1, zd, 1, 1, 1);
-    m->z_dw = add_tensor(m, "dense_2/kernel", 2, zd, m->flat, 1, 1); m->z_db = add_tensor(m, "dense_2/bias", 1, m->flat, 1, 1, 1);
+    m->z_muw = add_tensor(m, sb + "dense/kernel", 2, m->flat, zd, 1, 1); m->z_mub = add_tensor(m, sb + "dense/bias", 1, zd, 1, 1, 1);
+    m->z_lsw = add_tensor(m, sb + "dense_1/kernel", 2, m->flat, zd, 1, 1); m->z_lsb = add_tensor(m, sb + "dense_1/bias", 1, zd, 1, 1, 1);
+    m->z_dw = add_tensor(m, sb + "dense_2/kernel", 2, zd, m->flat, 1, 1); m->z_db = add_tensor(m, sb + "dense_2/bias", 1, m->flat, 1, 1, 1);
     cin = 1024;
     for (int i = 0; i < 4; ++i) {
         Block L;
         L.d = UadConvDesc{1, res * 2, res * 2, gf[i], res, res, cin, 4, 2, 1};
-        snprintf(nm, sizeof nm, "dec_Conv2DT_%d/kernel", i + 1); L.w = add_tensor(m, nm, 4, 4, 4, gf[i], cin);
-        snprintf(nm, sizeof nm, "dec_Conv2DT_%d/bias", i + 1); L.b = add_tensor(m, nm, 1, gf[i], 1, 1, 1);
+        snprintf(nm, sizeof nm, "dec_Conv2DT_%d/kernel", i + 1); L.w = add_tensor(m, sdc + nm, 4, 4, 4, gf[i], cin);
+        snprintf(nm, sizeof nm, "dec_Conv2DT_%d/bias", i + 1); L.b = add_tensor(m, sdc + nm, 1, gf[i], 1, 1, 1);
         res *= 2;
         L.gamma = L.beta = -1; L.H = L.W = res; L.C = gf[i];
         m->G.push_back(L);
         cin = gf[i];
     }
-    m->z_fw = add_tensor(m, "dec_Conv2D_final/kernel", 4, 4, 4, 16, 1); m->z_fb = add_tensor(m, "dec_Conv2D_final/bias", 1, 1, 1, 1, 1);
+    m->z_fw = add_tensor(m, sdc + "dec_Conv2D_final/kernel", 4, 4, 4, 16, 1); m->z_fb = add_tensor(m, sdc + "dec_Conv2D_final/bias", 1, 1, 1, 1, 1);
     m->z_fd = UadConvDesc{1, H, H, 1, H, H, 16, 4, 1, 2};
     m->g_fw = m->z_fw; m->g_fb = m->z_fb;
     for (int k = 0; k < 3; ++k) { m->grp_off[k] = 0; m->grp_cnt[k] = m->nparams; }      // one optimizer over every variable
 
-    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H;
+    const size_t NB = (size_t)cfg->max_batch * (ce ? 2 : 1), HW = (size_t)H * H;      // ceVAE: both branches in one pass
     int rc = UAD_OK;
 #define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
     ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
     ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
     m->wpack_f = m->wpack_d = m->wpack16_f = m->wpack16_d = nullptr;
+    m->a_xcat = m->z_l1 = nullptr;
+    if (ce) { ALLOC(m->a_xcat, NB * HW, nullptr); ALLOC(m->z_l1, NB * HW, nullptr); }
     size_t maxact = NB * HW * 16;
     m->ec.resize(4); m->ea.resize(5, nullptr);
     for (int i = 0; i < 4; ++i) {
@@ -2008,8 +2051,8 @@ static int create_zimmerer(const uad_gan_config_t* cfg, uad_gan_t** out) {
 
 static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
     const int H = cfg->height, ir = cfg->inter_res;
-    if (cfg->aae_kind == 4) return create_zimmerer(cfg, out);
-    if (cfg->aae_kind < 0 || cfg->aae_kind > 4) return fail(UAD_ERR_INVALID, "bad aae_kind");
+    if (cfg->aae_kind == 4 || cfg->aae_kind == 5) return create_zimmerer(cfg, out);
+    if (cfg->aae_kind < 0 || cfg->aae_kind > 5) return fail(UAD_ERR_INVALID, "bad aae_kind");
     const bool gmv = cfg->aae_kind == 3;
     if (gmv) {
         const long long q = (long long)cfg->zdim * cfg->dim;
@@ -2610,7 +2653,7 @@ static int gan_reconstruct_body(uad_gan_t* m, const uad_gan_io_t* io, int n, voi
     hipStream_t st = (hipStream_t)stream;
     const size_t img = (size_t)n * m->cfg.height * m->cfg.width;
     refresh_packs(m, st);
-    if (m->variant == UAD_GAN_AAE && m->zim) zim_forward(m, io, n, st);
+    if (m->variant == UAD_GAN_AAE && m->zim) zim_forward(m, io->x, io->eps, n, n, st);
     else if (m->variant == UAD_GAN_AAE && m->gmv) gmv_forward(m, io, io->x, n, 1.0f / (float)n, st);
     else if (m->variant == UAD_GAN_AAE) { a_encode(m, io->x, io->mask_z, n, 0, st); a_decode(m, m->a_zm, io->mask_g, n, st); }
     else if (m->variant == UAD_GAN_RESNET) { s_enc_forward(m, io->x, n, st); s_gen_forward(m, m->z, n, st); }

@@ -24,7 +24,7 @@ class GanEngine(_EvalOps):
         torch.cuda.set_device(self.device)
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
         variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET, 'anovaegan': _lib.GAN_ANOVAEGAN, 'aae': _lib.GAN_AAE}
-        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2, 'gmvae': 3, 'vae_zimmerer': 4}     # 'gmvae': zdim = dim_z, dim = dim_c, dim_w, c_lambda
+        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2, 'gmvae': 3, 'vae_zimmerer': 4, 'cevae_zimmerer': 5}     # 'gmvae': zdim = dim_z, dim = dim_c, dim_w, c_lambda
         if variant == 'aae' and aae_kind not in kinds:
             raise ValueError(f'unknown aae_kind {aae_kind!r}')
         self.aae_kind = aae_kind if variant == 'aae' else None
@@ -45,7 +45,7 @@ class GanEngine(_EvalOps):
             _lib.check(self.lib.uad_gan_tensor_info(h, i, name, 160, C.byref(off), C.byref(rank), shape))
             self.spec.append((name.value.decode(), tuple(shape[:rank.value]), int(off.value)))
         dec_dense = {'constrained_ae': 'Bottleneck/dense_1/kernel', 'aae': 'Bottleneck/dense_1/kernel', 'constrained_aae': 'Decoder/dense/kernel',
-                     'gmvae': 'Bottleneck/dense_4/kernel', 'vae_zimmerer': 'dense_2/kernel'}
+                     'gmvae': 'Bottleneck/dense_4/kernel', 'vae_zimmerer': 'dense_2/kernel', 'cevae_zimmerer': 'Bottleneck/dense_2/kernel'}
         self.flat = [s for n, s, _ in self.spec if n == (dec_dense[aae_kind] if variant == 'aae' else 'Generator/dense/kernel')][0][1]
         self._views = {}
         self.graph, self._pool, self._slot = False, {}, None
@@ -116,7 +116,7 @@ class GanEngine(_EvalOps):
         zeros = np.zeros(self.nparams, np.float32)
         self.set_buffer_host(_lib.BUF_ADAM_M, zeros)
         self.set_buffer_host(_lib.BUF_ADAM_V, zeros)
-        if self.variant in ('anovaegan', 'aae') and self.aae_kind != 'vae_zimmerer':      # the Zimmerer VAE has one optimizer, one pair of slots
+        if self.variant in ('anovaegan', 'aae') and self.aae_kind not in ('vae_zimmerer', 'cevae_zimmerer'):      # the Zimmerer VAE has one optimizer, one pair of slots
             self.set_buffer_host(_lib.BUF_ADAM_M2, zeros)
             self.set_buffer_host(_lib.BUF_ADAM_V2, zeros)
         for g in ('Encoder', 'Generator', 'Discriminator'):
@@ -231,26 +231,44 @@ class GanEngine(_EvalOps):
         return out
 
     # ---------------------------------------------------------------- Zimmerer VAE (variant 'aae', aae_kind 'vae_zimmerer')
-    def zim_phase(self, x, eps=None, want_backward=True, want_l1=True):
+    def zim_phase(self, x, eps=None, want_backward=True, want_l1=True, x_ce=None, want_anomaly=True):
         """One sess.run of trainers/VAE.py:83-96 on models/variational_autoencoder_Zimmerer.py: forward, reconstructionLoss / kl / loss and
-        (want_backward) the gradient of `loss` w.r.t. every variable."""
-        if self.aae_kind != 'vae_zimmerer':
-            raise ValueError('zim_phase needs a Zimmerer-VAE engine')
+        (want_backward) the gradient of `loss` w.r.t. every variable.  On a 'cevae_zimmerer' engine: one sess.run of trainers/ceVAE.py:95-110
+        (x_ce: the context-masked batch, None = x; want_backward True | False | 'data' = the input-gradient chain only) returning in addition
+        reconstruction_ce, L1_ce, anomaly, Rec_vae, Rec_ce, loss_vae."""
+        if self.aae_kind not in ('vae_zimmerer', 'cevae_zimmerer'):
+            raise ValueError('zim_phase needs a Zimmerer-stack engine')
+        ce = self.aae_kind == 'cevae_zimmerer'
+        if x_ce is not None and not ce:
+            raise ValueError('x_ce is an input of the context-encoding VAE')
         self._begin('zim_phase')
         n = x.shape[0]
         img = (n, self.h, self.w, self.c)
         x = self._dev(x, img)
         eps = self._dev(eps, (n, self.zdim))
+        x_ce = self._dev(x_ce, img)
         scal = self._new(16, zero=True)
         out = {'reconstruction': self._new(img), 'z': self._new((n, self.zdim))}
         io = _lib.UadGanIO()
         io.x, io.eps, io.scalars, io.reconstruction, io.z_enc = _ptr(x), _ptr(eps), _ptr(scal), _ptr(out['reconstruction']), _ptr(out['z'])
+        io.x_ce = _ptr(x_ce)
         if want_l1:
             out['L1'] = self._new(img); io.l1_map = _ptr(out['L1'])
-        _lib.check(self.lib.uad_gan_phase(self.handle, _lib.GAN_GENERATOR, C.byref(io), n, 1 if want_backward else 0, self._stream()))
+        if ce:
+            out['reconstruction_ce'] = self._new(img); io.generated = _ptr(out['reconstruction_ce'])
+            if want_l1:
+                out['L1_ce'] = self._new(img); io.l1_map_ce = _ptr(out['L1_ce'])
+            if want_backward and want_anomaly:
+                out['anomaly'] = self._new(img); io.anomaly = _ptr(out['anomaly'])
+        wb = 2 if want_backward == 'data' else (1 if want_backward else 0)
+        if wb == 2 and not ce:
+            raise ValueError("want_backward='data' is the ceVAE's anomaly-map mode")
+        _lib.check(self.lib.uad_gan_phase(self.handle, _lib.GAN_GENERATOR, C.byref(io), n, wb, self._stream()))
         S = _lib.GAN_SCALARS
         out.update(reconstructionLoss=scal[S.index('reconstructionLoss')], kl=scal[S.index('kl')], loss=scal[S.index('enc_loss')])
-        self._keep = (x, eps, scal, out)
+        if ce:
+            out.update(Rec_vae=scal[S.index('loss_img')], Rec_ce=scal[S.index('loss_fts')], loss_vae=scal[S.index('gm_loss')])
+        self._keep = (x, eps, x_ce, scal, out)
         self._slot = None
         return out
 
@@ -388,19 +406,29 @@ class GanEngine(_EvalOps):
 
 
 class ZimmererEngine(GanEngine):
-    """The Zimmerer VAE behind the `Engine` surface the AE-family trainers and `parallel.DataParallelStep` drive (forward / backward /
-    adam_step / grad_segment): forward(want_backward=True) already produces every gradient, so backward() has nothing left to do and the
-    whole flat buffer is reported as ONE segment (the last one in `parallel.SEGMENT_ORDER`), all-reduced once."""
+    """The Zimmerer VAE / ceVAE behind the `Engine` surface the AE-family trainers and `parallel.DataParallelStep` drive (forward / backward
+    / adam_step / grad_segment): forward(want_backward=...) already produces every gradient (and the ceVAE's anomaly map), so backward() has
+    nothing left to do and the whole flat buffer is reported as ONE segment (the last one in `parallel.SEGMENT_ORDER`), all-reduced once."""
 
-    def __init__(self, height, width, channels, inter_res, zdim, max_batch=64, device=None, math='f32'):
+    def __init__(self, height, width, channels, inter_res, zdim, max_batch=64, device=None, math='f32', cevae=False):
         super().__init__(height, width, channels, inter_res, zdim, max_batch=max_batch, device=device, math=math, variant='aae',
-                         aae_kind='vae_zimmerer')
-        self.arch = 'VAE_Zimmerer'
+                         aae_kind='cevae_zimmerer' if cevae else 'vae_zimmerer')
+        self.arch = 'ceVAE_Zimmerer' if cevae else 'VAE_Zimmerer'
+        self.cevae = bool(cevae)
 
-    def forward(self, x, eps=None, masks=None, want_backward=False, want_l1=True, want_latents=True, **kw):
+    def forward(self, x, eps=None, masks=None, want_backward=False, want_l1=True, want_latents=True, x_ce=None, want_anomaly=True, **kw):
         if masks:
-            raise ValueError('models/variational_autoencoder_Zimmerer.py has no dropout layers: masks are not accepted')
-        o = self.zim_phase(x, eps, want_backward=bool(want_backward), want_l1=want_l1)
+            raise ValueError('the Zimmerer models have no dropout layers: masks are not accepted')
+        o = self.zim_phase(x, eps, want_backward=want_backward, want_l1=want_l1, x_ce=x_ce, want_anomaly=want_anomaly)
+        zero = torch.zeros((), device=self.device)
+        if self.cevae:      # scalars in the fused ceVAE handle's layout: reconstructionLoss, kl, loss, -, Rec_vae, Rec_ce, loss_vae, -
+            out = {'x_hat': o['reconstruction'], 'x_hat_ce': o['reconstruction_ce'], 'z': o['z'],
+                   'scalars': torch.stack([o['reconstructionLoss'], o['kl'], o['loss'], zero, o['Rec_vae'], o['Rec_ce'], o['loss_vae'], zero])}
+            if want_l1:
+                out['L1_vae'], out['L1_ce'] = o['L1'], o['L1_ce']
+            if 'anomaly' in o:
+                out['anomaly'] = o['anomaly']
+            return out
         out = {'x_hat': o['reconstruction'], 'z': o['z'], 'scalars': torch.stack([o['reconstructionLoss'], o['kl'], o['loss']])}
         if want_l1:
             out['L1'] = o['L1']

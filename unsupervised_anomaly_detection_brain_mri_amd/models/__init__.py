@@ -14,3 +14,4 @@ from .adversarial_autoencoder import adversarial_autoencoder  # noqa: F401
 from .constrained_adversarial_autoencoder import constrained_adversarial_autoencoder  # noqa: F401
 from .gaussian_mixture_variational_autoencoder import gaussian_mixture_variational_autoencoder  # noqa: F401
 from .variational_autoencoder_Zimmerer import variational_autoencoder_Zimmerer  # noqa: F401
+from .context_encoder_variational_autoencoder_Zimmerer import context_encoder_variational_autoencoder_Zimmerer  # noqa: F401

@@ -19,15 +19,24 @@ class ceVAE(AEMODEL):
             self.use_gradient_based_restoration = True      # ceVAE.py:16
 
     ARCH = 'ceVAE'
+    ARCHS = ('ceVAE', 'ceVAE_Zimmerer')      # models/context_encoder_variational_autoencoder.py | ..._Zimmerer.py (no dropout layers)
     SCALAR_KEYS = ('Rec_ce', 'Rec_vae', 'reconstructionLoss', 'kl', 'loss', 'loss_vae')
     _SCALAR_SLOT = {'reconstructionLoss': 0, 'kl': 1, 'loss': 2, 'Rec_vae': 4, 'Rec_ce': 5, 'loss_vae': 6}
+
+    def _make_engine(self, device):
+        if self.arch != 'ceVAE_Zimmerer':
+            return super()._make_engine(device)
+        from ..gan_engine import ZimmererEngine
+        c = self.config
+        return ZimmererEngine(c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]), c.zDim,
+                              max_batch=max(int(c.batchsize), 1), device=device, cevae=True)
 
     def _draw(self, n, dropout):
         """eps + the five independent dropout masks of one sess.run: the single Dropout layer object is called on z_mu,
         z_mu_ce, z_log_sigma and on both dec_dense outputs (context_encoder_variational_autoencoder.py:36-43)."""
         z = self.config.zDim
         eps = self.rng.standard_normal((n, z)).astype(np.float32)
-        if not dropout or self.config.dropout_rate <= 0:
+        if not dropout or self.config.dropout_rate <= 0 or self.arch == 'ceVAE_Zimmerer':
             return eps, None
         r = float(self.config.dropout_rate)
         keep = lambda shape: (self.rng.random(shape) >= r).astype(np.float32) / (1.0 - r)
