@@ -458,6 +458,9 @@ __global__ void combine_kernel(int phase, const float* __restrict__ raw, float k
     } else if (phase == 4) {      // AAE family, autoencoder phase: raw = {mean L2, mean Rec_z, reconstructionLoss}, kappa = rho
         out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
         out[UAD_GAN_S_REC_LOSS] = raw[2];
+    } else if (phase == 7) {      // spatial GMVAE (You): raw = {mean_p_loss, sum con, sum w, sum c}, kappa = 1/n
+        out[UAD_GAN_S_REC_LOSS] = raw[0]; out[UAD_GAN_S_GM_CON] = raw[1] * kappa; out[UAD_GAN_S_GM_W] = raw[2] * kappa; out[UAD_GAN_S_GM_C] = raw[3] * kappa;
+        out[UAD_GAN_S_GM_LOSS] = ((raw[0] + raw[1] * kappa) + raw[2] * kappa) + raw[3] * kappa;
     } else if (phase == 6) {      // ceVAE (Zimmerer stack): raw = {Rec_vae, Rec_ce, kl}
         out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_KL] = raw[2];
         out[UAD_GAN_S_REC_LOSS] = 0.5f * (raw[0] + raw[1]); out[UAD_GAN_S_ENC_LOSS] = (raw[0] + raw[2]) + raw[1]; out[UAD_GAN_S_GM_LOSS] = raw[0] + raw[2];
@@ -499,6 +502,34 @@ __global__ void __launch_bounds__(256) flip_taps_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) add_scalar_kernel(float* __restrict__ x, const float* __restrict__ b, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) x[i] += b[0];
+}
+
+
+// nearest-neighbour x2 (tf.image.resize_images NEAREST_NEIGHBOR, align_corners False: out[i] = in[i / 2]) and its adjoint
+__global__ void __launch_bounds__(256) up2_fwd_kernel(const float* __restrict__ x, int H, int W, int C, size_t total4, float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int C4 = C / 4;
+    const int c = (int)(i % C4);
+    size_t t = i / C4;
+    const int ox = (int)(t % (2 * W)); t /= 2 * W;
+    const int oy = (int)(t % (2 * H));
+    const size_t n = t / (2 * H);
+    reinterpret_cast<float4*>(y)[i] = reinterpret_cast<const float4*>(x)[((n * H + oy / 2) * W + ox / 2) * C4 + c];
+}
+__global__ void __launch_bounds__(256) up2_bwd_kernel(const float* __restrict__ g, int H, int W, int C, size_t total4, float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int C4 = C / 4;
+    const int c = (int)(i % C4);
+    size_t t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const size_t n = t / H;
+    const float4* gp = reinterpret_cast<const float4*>(g);
+    const size_t r0 = ((n * 2 * H + 2 * y) * 2 * W + 2 * x) * C4 + c, r1 = r0 + (size_t)2 * W * C4;
+    const float4 a = gp[r0], b = gp[r0 + C4], cc = gp[r1], d = gp[r1 + C4];
+    reinterpret_cast<float4*>(dx)[i] = make_float4((a.x + b.x) + (cc.x + d.x), (a.y + b.y) + (cc.y + d.y), (a.z + b.z) + (cc.z + d.z), (a.w + b.w) + (cc.w + d.w));
 }
 
 // ================================================================================================ latent critic (AAE family)
@@ -702,6 +733,13 @@ struct uad_gan {
     long long z_muw, z_mub, z_lsw, z_lsb, z_dw, z_db, z_fw, z_fb;
     UadConvDesc z_fd;                  // final k4 s1 conv as the image-side (1-channel "big") relation: S 1, P 2, taps reversed
     float *z_wflip, *z_dwflip;         // [16 taps][16] reversed final-conv kernel and its gradient
+    // original-architecture spatial GMVAE (aae_kind 6, models/gaussian_mixture_variational_autoencoder_You.py): a program of k3 layers
+    struct YOp { int kind; Block L; bool relu; float *c, *a; int Hout, Cout; };   // kind 0 conv, 1 transposed conv, 2 nearest-neighbour x2
+    bool you;
+    std::vector<YOp> y_enc, y_dec;
+    long long y_off[15], y_total;      // the 15 latent-head tensors (contiguous), their total size
+    UadConvDesc y_fd;                  // p_x_z/y_mu (k3, 64 -> 1) as the image-side relation, taps reversed
+    float *y_ones, *y_zeros, *y_loc, *y_colpart, *y_dheads, *y_da7, *y_dM, *y_dLq, *y_ws, *y_mid, *y_partial, *y_dzdec, *y_h;
     bool generic16;                    // UAD_MATH_BF16X3_ALL: generic contractions in bf16x3 too (opt-in, not parity-rated)
     struct RB {                        // pre-activation residual block: LN -> ReLU -> conv1 (k3 s1) -> LN -> ReLU -> conv2, + shortcut
         bool gen;                      // generator block: conv2 / shortcut are transposed convolutions
@@ -821,7 +859,7 @@ void reduce_to(uad_gan* m, int k, const float* a, const float* b, size_t n, floa
 
 int refresh_packs(uad_gan* m, hipStream_t st) {
     if (m->packed_valid) return UAD_OK;
-    if (m->zim) { m->packed_valid = true; return UAD_OK; }       // no k5 layers: nothing is packed
+    if (m->zim || m->you) { m->packed_valid = true; return UAD_OK; }       // no k5 layers: nothing is packed
     long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
     auto add = [&](const Block& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
     for (size_t i = 1; i < m->E.size(); ++i) add(m->E[i]);
@@ -1214,6 +1252,8 @@ void a_critic(uad_gan* m, int mode, const float* zf, const float* zr, const floa
 }
 
 
+int you_phase(uad_gan* m, const uad_gan_io_t* io, const float* x, int n, int want_backward, bool restore, float tv, float rlr, float* x_upd,
+              float* grads_out, hipStream_t st);
 int zim_phase(uad_gan* m, const uad_gan_io_t* io, int n, int want_backward, hipStream_t st);      // Zimmerer VAE, defined with the generic-conv helpers below
 
 // ---- dense GMVAE (aae_kind 3) ----
@@ -1277,6 +1317,11 @@ int gmv_phase(uad_gan* m, const uad_gan_io_t* io, const float* x, int n, int wan
 }
 
 int aae_phase(uad_gan* m, int phase, const uad_gan_io_t* io, int n, int want_backward, hipStream_t st) {
+    if (m->you) {
+        if (phase != UAD_GAN_GENERATOR) return fail(UAD_ERR_INVALID, "the GMVAE has one phase (UAD_GAN_GENERATOR): its optimizer covers every variable");
+        if (!io->x) return fail(UAD_ERR_INVALID, "GMVAE phase needs io.x");
+        return you_phase(m, io, io->x, n, want_backward, false, 0.f, 0.f, nullptr, nullptr, st);
+    }
     if (m->zim) {
         if (phase != UAD_GAN_GENERATOR) return fail(UAD_ERR_INVALID, "the Zimmerer VAE has one phase (UAD_GAN_GENERATOR): its optimizer covers every variable");
         return zim_phase(m, io, n, want_backward, st);
@@ -1567,11 +1612,11 @@ void s_disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float
 // on the generic F / D / W kernels; the two single-channel ends (first conv 1 -> 16, final conv 16 -> 1) run on the image-side kernels:
 // the final k4 s1 convolution is their "data gradient" relation (big = the 1-channel output, S 1, P 2) with the taps reversed.
 constexpr float kZimAlpha = 0.2f;          // tf.nn.leaky_relu default
-void z_act_fwd(const float* c, size_t total, float* a, hipStream_t st) {
-    hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(blocks256(total / 4)), dim3(256), 0, st, c, kZimAlpha, total / 4, a);
+void z_act_fwd(const float* c, size_t total, float* a, hipStream_t st, float alpha = kZimAlpha) {
+    hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(blocks256(total / 4)), dim3(256), 0, st, c, alpha, total / 4, a);
 }
-void z_act_bwd(const float* da, const float* c, size_t total, float* dc, hipStream_t st) {
-    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks256(total / 4)), dim3(256), 0, st, da, c, kZimAlpha, total / 4, dc);
+void z_act_bwd(const float* da, const float* c, size_t total, float* dc, hipStream_t st, float alpha = kZimAlpha) {
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks256(total / 4)), dim3(256), 0, st, da, c, alpha, total / 4, dc);
 }
 // n samples, the first n_vae of them sampled (z = mu + eps sigma, KL), the rest decode z = mu (the ceVAE's context branch)
 void zim_forward(uad_gan* m, const float* xin, const float* eps, int n, int n_vae, hipStream_t st) {
@@ -1693,6 +1738,169 @@ int zim_phase(uad_gan* m, const uad_gan_io_t* io, int n, int want_backward, hipS
     }
     if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->z, (size_t)n * m->cfg.zdim * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return UAD_OK;
+}
+
+// ================================================================================================ spatial GMVAE, original architecture (aae_kind 6)
+// models/gaussian_mixture_variational_autoencoder_You.py:8-85 under trainers/GMVAE_spatial.py:61-97,168-199.  k3 layers on the generic F / D / W
+// kernels (SAME: P 0 at stride 2, P 1 at stride 1), the single-channel ends on the image-side kernels (y_mu as their data-gradient relation with
+// reversed taps), the latent heads on the spatial GMVAE's per-location kernels (uad_gmvae.hip) with z_sampled handed to / from the decoder.
+typedef uad_gan::YOp YOp;
+size_t yop_out(const YOp& o) { return (size_t)o.Hout * o.Hout * o.Cout; }
+UadGmArgs you_gm_args(uad_gan* m, const uad_gan_io_t* io, float inv) {
+    UadGmArgs a;
+    memset(&a, 0, sizeof a);
+    a.cenc = 64; a.W = m->gm_W; a.Z = m->gm_Z; a.C = m->gm_C; a.c_lambda = m->cfg.c_lambda; a.inv_batch = inv;
+    a.c_enc = m->y_enc.back().c; a.scale = m->y_ones; a.shift = m->y_zeros; a.alpha = 0.0f; a.mult = 1.0f;      // h = relu(conv + bias)
+    const float** slots[15] = {&a.wmu_k, &a.wmu_b, &a.wls_k, &a.wls_b, &a.zmu_k, &a.zmu_b, &a.zls_k, &a.zls_b, &a.c7_k, &a.c7_b, &a.m_k, &a.m_b, &a.l_k,
+                               &a.l_b, &a.var};
+    for (int k = 0; k < 15; ++k) *slots[k] = P(m, m->y_off[k]);
+    a.eps_w = io->eps_w; a.eps_z = io->eps;
+    a.h_out = m->y_h; a.loc_loss = m->y_loc; a.zs_out = m->a_zm;
+    return a;
+}
+void you_forward(uad_gan* m, const uad_gan_io_t* io, const float* x, int n, float inv, hipStream_t st) {
+    const int H = m->cfg.height, r = H / 4;
+    const float* in = x;
+    for (size_t i = 0; i < m->y_enc.size(); ++i) {
+        YOp& o = m->y_enc[i];
+        UadConvDesc d = o.L.d; d.N = n;
+        if (d.CB % 4) uad_launch_conv_first_fwd(d, in, P(m, o.L.w), P(m, o.L.b), o.c, st);
+        else g_conv_f(m, o.L.d, n, in, o.L.w, P(m, o.L.b), nullptr, o.c, st);
+        if (i + 1 < m->y_enc.size()) { z_act_fwd(o.c, (size_t)n * yop_out(o), o.a, st, 0.0f); in = o.a; }
+    }
+    uad_launch_gm_heads_fwd(you_gm_args(m, io, inv), n * r * r, st);
+    in = m->a_zm;
+    int hin = r, cin = m->gm_Z;
+    for (size_t i = 0; i + 1 < m->y_dec.size(); ++i) {
+        YOp& o = m->y_dec[i];
+        if (o.kind == 2) {
+            const size_t t4 = (size_t)n * o.Hout * o.Hout * cin / 4;
+            hipLaunchKernelGGL(up2_fwd_kernel, dim3(blocks256(t4)), dim3(256), 0, st, in, hin, hin, cin, t4, o.a);
+        } else {
+            UadConvDesc d = o.L.d; d.N = n;
+            if (o.kind == 0 && d.CB % 4) uad_launch_conv_first_fwd(d, in, P(m, o.L.w), P(m, o.L.b), o.c, st);
+            else if (o.kind == 0) g_conv_f(m, o.L.d, n, in, o.L.w, P(m, o.L.b), nullptr, o.c, st);
+            else g_conv_d(m, o.L.d, n, in, o.L.w, P(m, o.L.b), nullptr, o.c, st);
+            if (o.relu) z_act_fwd(o.c, (size_t)n * yop_out(o), o.a, st, 0.0f);
+        }
+        in = o.a; hin = o.Hout; cin = o.Cout;
+    }
+    // y_mu
+    const YOp& F = m->y_dec.back();
+    hipLaunchKernelGGL(flip_taps_kernel, dim3(3), dim3(256), 0, st, P(m, F.L.w), 9, 64, m->z_wflip);
+    UadConvDesc df = m->y_fd; df.N = n;
+    uad_launch_conv_first_dgrad_plain(df, in, m->z_wflip, m->xg, st);
+    const size_t img = (size_t)n * H * H;
+    hipLaunchKernelGGL(add_scalar_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, P(m, F.L.b), img);
+}
+// dxh = d objective / d x_hat; leaves d objective / d c of the FIRST encoder conv in *g_first (for the caller's input gradient)
+void you_backward(uad_gan* m, const uad_gan_io_t* io, const float* x, const float* dxh, int n, float inv, bool pg, float** g_first, hipStream_t st) {
+    const int H = m->cfg.height, r = H / 4, L = n * r * r;
+    float* g = m->Ga; float* gn = m->Gb;
+    const YOp& F = m->y_dec.back();
+    const size_t nd = m->y_dec.size();
+    const float* fin = m->y_dec[nd - 2].a;
+    UadConvDesc df = m->y_fd; df.N = n;
+    if (pg) {
+        uad_launch_conv_first_wgrad(df, dxh, fin, m->z_dwflip, m->wpartial, st);
+        hipLaunchKernelGGL(flip_taps_kernel, dim3(3), dim3(256), 0, st, m->z_dwflip, 9, 64, Gr(m, F.L.w));
+        uad_launch_colsum(dxh, n * H * H, 1, Gr(m, F.L.b), m->colscratch, st);
+    }
+    uad_launch_conv_first_fwd(df, dxh, m->z_wflip, nullptr, g, st);
+    for (int i = (int)nd - 2; i >= 0; --i) {
+        YOp& o = m->y_dec[i];
+        const float* in = i == 0 ? m->a_zm : m->y_dec[i - 1].a;
+        const int hin = i == 0 ? r : m->y_dec[i - 1].Hout, cin = i == 0 ? m->gm_Z : m->y_dec[i - 1].Cout;
+        if (o.kind == 2) {
+            const size_t t4 = (size_t)n * hin * hin * cin / 4;
+            hipLaunchKernelGGL(up2_bwd_kernel, dim3(blocks256(t4)), dim3(256), 0, st, g, hin, hin, cin, t4, gn);
+            float* t = g; g = gn; gn = t;
+            continue;
+        }
+        const float* dc = g;
+        if (o.relu) { z_act_bwd(g, o.c, (size_t)n * yop_out(o), gn, st, 0.0f); dc = gn; }
+        if (pg) uad_launch_colsum(dc, n * o.Hout * o.Hout, o.Cout, Gr(m, o.L.b), m->colscratch, st);
+        float* dst = (dc == g) ? gn : g;
+        UadConvDesc d = o.L.d; d.N = n;
+        if (o.kind == 0 && d.CB % 4) {            // first decoder conv on a 1-channel z_sampled
+            if (pg) uad_launch_conv_first_wgrad(d, in, dc, Gr(m, o.L.w), m->wpartial, st);
+            uad_launch_conv_first_dgrad_plain(d, dc, P(m, o.L.w), m->y_dzdec, st);
+        } else if (o.kind == 0) {
+            if (pg) g_conv_w(m, o.L.d, n, in, dc, o.L.w, st);
+            g_conv_d(m, o.L.d, n, dc, o.L.w, nullptr, nullptr, i == 0 ? m->y_dzdec : dst, st);
+        } else {
+            if (pg) g_conv_w(m, o.L.d, n, dc, in, o.L.w, st);
+            g_conv_f(m, o.L.d, n, dc, o.L.w, nullptr, nullptr, dst, st);
+        }
+        if (dst != g) { float* t = g; g = gn; gn = t; }
+    }
+    // latent heads: per-location backward (recomputes its forward), z_sampled's decoder gradient added in
+    UadGmArgs ga = you_gm_args(m, io, inv);
+    ga.h_out = nullptr; ga.zs_out = nullptr;
+    ga.dz_dec = m->y_dzdec; ga.g_out = g; ga.colpart = m->y_colpart;
+    ga.dvec_heads = m->y_dheads; ga.dvec_a7 = m->y_da7; ga.dvec_M = m->y_dM; ga.dvec_Lq = m->y_dLq; ga.ws_out = m->y_ws; ga.mid_out = m->y_mid;
+    uad_launch_gm_heads_bwd(ga, L, st);
+    if (pg) {
+        const int W = ga.W, Z = ga.Z, Q = ga.Z * ga.C, O = 2 * W + 2 * Z, CE = 64;
+        UadGmWgradArgs wa;
+        memset(&wa, 0, sizeof wa);
+        const long long base = m->y_off[0];
+        auto job = [&](int k, const float* A, int lda, const float* B, int ldb, int b) {
+            wa.job[k] = UadGmWgradArgs::Job{A, lda, B, ldb, b, (int)(m->y_off[k] - base)};
+        };
+        const float* dh = m->y_dheads;
+        job(0, m->y_h, CE, dh, O, W);              job(1, nullptr, 0, dh, O, W);
+        job(2, m->y_h, CE, dh + W, O, W);          job(3, nullptr, 0, dh + W, O, W);
+        job(4, m->y_h, CE, dh + 2 * W, O, Z);      job(5, nullptr, 0, dh + 2 * W, O, Z);
+        job(6, m->y_h, CE, dh + 2 * W + Z, O, Z);  job(7, nullptr, 0, dh + 2 * W + Z, O, Z);
+        job(8, m->y_ws, W, m->y_da7, 64, 64);      job(9, nullptr, 0, m->y_da7, 64, 64);
+        job(10, m->y_mid, 64, m->y_dM, Q, Q);      job(11, nullptr, 0, m->y_dM, Q, Q);
+        job(12, m->y_mid, 64, m->y_dLq, Q, Q);     job(13, nullptr, 0, m->y_dLq, Q, Q);
+        job(14, nullptr, 0, m->y_dLq, Q, Q);
+        wa.njobs = 15; wa.total = (int)m->y_total; wa.L = L; wa.partial = m->y_partial;
+        uad_launch_gm_heads_wgrad(wa, Gr(m, base), st);
+    }
+    // encoder: g = d objective / d c of the last conv
+    for (int i = (int)m->y_enc.size() - 1; i >= 0; --i) {
+        YOp& o = m->y_enc[i];
+        const float* in = i == 0 ? x : m->y_enc[i - 1].a;
+        if (pg) uad_launch_colsum(g, n * o.Hout * o.Hout, o.Cout, Gr(m, o.L.b), m->colscratch, st);
+        UadConvDesc d = o.L.d; d.N = n;
+        if (i == 0) {
+            if (pg) uad_launch_conv_first_wgrad(d, in, g, Gr(m, o.L.w), m->wpartial, st);
+            break;
+        }
+        if (pg) g_conv_w(m, o.L.d, n, in, g, o.L.w, st);
+        g_conv_d(m, o.L.d, n, g, o.L.w, nullptr, nullptr, gn, st);
+        z_act_bwd(gn, m->y_enc[i - 1].c, (size_t)n * yop_out(m->y_enc[i - 1]), g, st, 0.0f);
+    }
+    *g_first = g;
+}
+int you_phase(uad_gan* m, const uad_gan_io_t* io, const float* x, int n, int want_backward, bool restore, float tv, float rlr, float* x_upd,
+              float* grads_out, hipStream_t st) {
+    const int H = m->cfg.height, r = H / 4, L = n * r * r;
+    const size_t img = (size_t)n * H * H;
+    const float inv = restore ? 1.0f : 1.0f / (float)n;
+    you_forward(m, io, x, n, inv, st);
+    if (!restore) {
+        float* scal = io->scalars ? io->scalars : m->scalars_own;
+        reduce_to<2>(m, 0, x, m->xg, img, 1.0f / (float)n, io->l1_map, st);
+        uad_launch_colsum(m->y_loc, L, 3, m->raw + 1, m->colscratch, st);            // sums over locations of con, w-prior, c-prior
+        hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, 7, m->raw, 1.0f / (float)n, scal);
+        if (io->reconstruction) HIP_TRY(hipMemcpyAsync(io->reconstruction, m->xg, img * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (io->z_enc) HIP_TRY(hipMemcpyAsync(io->z_enc, m->a_zm, (size_t)L * m->gm_Z * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (!want_backward) return UAD_OK;
+    const float* dxh;
+    if (restore) { uad_launch_tv_dxhat(x, m->xg, n, H, H, 1.0f, tv, m->gm_dxhat, st); dxh = m->gm_dxhat; }
+    else { hipLaunchKernelGGL(sign_scale_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, x, 1.0f / (float)n, img, m->dxbuf); dxh = m->dxbuf; }
+    float* g0 = nullptr;
+    you_backward(m, io, x, dxh, n, inv, !restore, &g0, st);
+    if (restore) {
+        UadConvDesc d0 = m->y_enc[0].L.d; d0.N = n;
+        uad_launch_conv_first_dgrad_restore(d0, g0, P(m, m->y_enc[0].L.w), m->gm_dxhat, grads_out, x_upd, rlr, st);
+    }
     return UAD_OK;
 }
 
@@ -2049,10 +2257,133 @@ static int create_zimmerer(const uad_gan_config_t* cfg, uad_gan_t** out) {
     return UAD_OK;
 }
 
+
+static int create_you(const uad_gan_config_t* cfg, uad_gan_t** out) {
+    const int H = cfg->height, Z = cfg->zdim, W = cfg->dim_w, C = cfg->dim;
+    if (H < 16 || H % 16) return fail(UAD_ERR_UNSUPPORTED, "GMVAE (You): height must be a power of two >= 16");
+    if (cfg->inter_res != H / 4) return fail(UAD_ERR_INVALID, "GMVAE (You): the latent map is height / 4 (two stride-2 convolutions): set intermediateResolutions accordingly");
+    // the first decoder convolution contracts over dim_z channels: 1 (image-side kernel) or a multiple of 8 (generic kernels' K step)
+    if (!(Z == 1 || Z % 8 == 0) || Z > 64 || W < 1 || W > 64 || C < 1 || C > 64 || (long long)Z * C > 1024)
+        return fail(UAD_ERR_UNSUPPORTED, "GMVAE (You): dim_z 1 or a multiple of 8 (<= 64), dim_w <= 64, dim_c <= 64, dim_z * dim_c <= 1024");
+    uad_gan* m = new uad_gan();
+    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->aae_kind = 6; m->you = true; m->zim = m->zim_ce = m->gmv = false; m->a_constrained = m->a_critic = false;
+    m->gm_W = W; m->gm_Z = Z; m->gm_C = C;
+    m->dim = C; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1; m->a_zw = m->a_zb = -1;
+    m->npool = 2; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = true;
+    m->step[0] = m->step[1] = m->step[2] = 0;
+    auto conv_op = [&](const std::string& name, int kind, int hin, int cin, int cout, int stride, bool relu) {
+        YOp o;
+        o.kind = kind; o.relu = relu; o.c = o.a = nullptr;
+        const int hout = hin / stride;
+        if (kind == 0) {
+            o.L.d = UadConvDesc{1, hin, hin, cin, hout, hout, cout, 3, stride, stride == 2 ? 0 : 1};
+            o.L.w = add_tensor(m, name + "/kernel", 4, 3, 3, cin, cout);
+        } else {
+            o.L.d = UadConvDesc{1, hout, hout, cout, hin, hin, cin, 3, 1, 1};
+            o.L.w = add_tensor(m, name + "/kernel", 4, 3, 3, cout, cin);
+        }
+        o.L.b = add_tensor(m, name + "/bias", 1, cout, 1, 1, 1);
+        o.L.gamma = o.L.beta = -1; o.L.H = o.L.W = hout; o.L.C = cout;
+        o.Hout = hout; o.Cout = cout;
+        return o;
+    };
+    static const char* en[6] = {"q_wz_x/3x3convlayer", "q_wz_x/3x3convlayer1", "q_wz_x/3x3convlayer2", "q_wz_x/3x3convlayer3", "q_wz_x/3x3convlayer4",
+                                "q_wz_x/3x3convlayer5"};
+    static const int es[6] = {2, 1, 1, 2, 1, 1};
+    int h = H, cin = 1;
+    for (int i = 0; i < 6; ++i) { m->y_enc.push_back(conv_op(en[i], 0, h, cin, 64, es[i], true)); h /= es[i]; cin = 64; }
+    const int r = h, Q = Z * C;
+    {
+        int k = 0;
+        const char* hn[4] = {"q_wz_x/w_mu", "q_wz_x/w_log_sigma", "q_wz_x/z_mu", "q_wz_x/z_log_sigma"};
+        const int hd[4] = {W, W, Z, Z};
+        for (int j = 0; j < 4; ++j) {
+            m->y_off[k++] = add_tensor(m, std::string(hn[j]) + "/kernel", 4, 1, 1, 64, hd[j]);
+            m->y_off[k++] = add_tensor(m, std::string(hn[j]) + "/bias", 1, hd[j], 1, 1, 1);
+        }
+        m->y_off[k++] = add_tensor(m, "p_z_wc/1x1convlayer/kernel", 4, 1, 1, W, 64); m->y_off[k++] = add_tensor(m, "p_z_wc/1x1convlayer/bias", 1, 64, 1, 1, 1);
+        m->y_off[k++] = add_tensor(m, "p_z_wc/z_wc_mu/kernel", 4, 1, 1, 64, Q); m->y_off[k++] = add_tensor(m, "p_z_wc/z_wc_mu/bias", 1, Q, 1, 1, 1);
+        m->y_off[k++] = add_tensor(m, "p_z_wc/z_wc_log_sigma/kernel", 4, 1, 1, 64, Q); m->y_off[k++] = add_tensor(m, "p_z_wc/z_wc_log_sigma/bias", 1, Q, 1, 1, 1);
+        m->y_off[k++] = add_tensor(m, "Variable", 1, Q, 1, 1, 1);
+        m->y_total = m->nparams - m->y_off[0];
+    }
+    auto up_op = [&](int hin, int c) { YOp o; o.kind = 2; o.relu = false; o.c = o.a = nullptr; o.Hout = 2 * hin; o.Cout = c; o.L.w = o.L.b = o.L.gamma = o.L.beta = -1; return o; };
+    h = r;
+    m->y_dec.push_back(conv_op("p_x_z/3x3convlayer1", 0, h, Z, 64, 1, true));
+    m->y_dec.push_back(conv_op("p_x_z/3x3upconvlayer1", 1, h, 64, 64, 1, true));
+    m->y_dec.push_back(conv_op("p_x_z/3x3upconvlayer2", 1, h, 64, 64, 1, true));
+    m->y_dec.push_back(up_op(h, 64)); h *= 2;
+    m->y_dec.push_back(conv_op("p_x_z/3x3convlayer2", 0, h, 64, 64, 1, true));
+    m->y_dec.push_back(conv_op("p_x_z/3x3upconvlayer3", 1, h, 64, 64, 1, true));
+    m->y_dec.push_back(conv_op("p_x_z/3x3upconvlayer4", 1, h, 64, 64, 1, true));
+    m->y_dec.push_back(up_op(h, 64)); h *= 2;
+    m->y_dec.push_back(conv_op("p_x_z/3x3convlayer3", 0, h, 64, 64, 1, false));
+    m->y_dec.push_back(conv_op("p_x_z/y_mu", 0, h, 64, 1, 1, false));
+    m->y_fd = UadConvDesc{1, H, H, 1, H, H, 64, 3, 1, 1};
+    m->g_fw = m->y_dec.back().L.w; m->g_fb = m->y_dec.back().L.b;
+    for (int k = 0; k < 3; ++k) { m->grp_off[k] = 0; m->grp_cnt[k] = m->nparams; }
+    m->flat = r * r * Z; m->cenc = 64; m->cmid = 64;
+
+    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H, Lm = NB * r * r;
+    int rc = UAD_OK;
+    char nm[64];
+#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
+    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
+    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
+    m->wpack_f = m->wpack_d = m->wpack16_f = m->wpack16_d = nullptr;
+    size_t maxact = NB * HW * 64;
+    for (size_t i = 0; i < m->y_enc.size(); ++i) {
+        YOp& o = m->y_enc[i];
+        snprintf(nm, sizeof nm, "yec%d", (int)i); ALLOC(o.c, NB * yop_out(o), nm);
+        if (i + 1 < m->y_enc.size()) { ALLOC(o.a, NB * yop_out(o), nullptr); }
+    }
+    for (size_t i = 0; i + 1 < m->y_dec.size(); ++i) {
+        YOp& o = m->y_dec[i];
+        if (o.kind != 2) { snprintf(nm, sizeof nm, "ydc%d", (int)i); ALLOC(o.c, NB * yop_out(o), nm); }
+        if (o.kind == 2 || o.relu) { ALLOC(o.a, NB * yop_out(o), nullptr); } else o.a = o.c;
+    }
+    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
+    ALLOC(m->xg, NB * HW, "xg"); ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->gm_dxhat, NB * HW, nullptr);
+    ALLOC(m->a_zm, Lm * Z, "z_s"); ALLOC(m->y_dzdec, Lm * Z, nullptr); ALLOC(m->y_h, Lm * 64, "h");
+    ALLOC(m->y_ones, 64, nullptr); ALLOC(m->y_zeros, 64, nullptr);
+    ALLOC(m->y_loc, Lm * 3, "loc"); ALLOC(m->y_colpart, Lm * 2 * 64, nullptr);
+    ALLOC(m->y_dheads, Lm * (2 * W + 2 * Z), nullptr); ALLOC(m->y_da7, Lm * 64, nullptr); ALLOC(m->y_dM, Lm * Q, nullptr); ALLOC(m->y_dLq, Lm * Q, nullptr);
+    ALLOC(m->y_ws, Lm * W, nullptr); ALLOC(m->y_mid, Lm * 64, nullptr);
+    ALLOC(m->y_partial, (size_t)uad_gm_wgrad_chunks((int)Lm) * (size_t)m->y_total, nullptr);
+    ALLOC(m->z_wflip, 1024, nullptr); ALLOC(m->z_dwflip, 1024, nullptr);
+    if (rc == UAD_OK) {
+        std::vector<float> ones(64, 1.0f);
+        HIP_TRY(hipMemcpy(m->y_ones, ones.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    {
+        size_t wp = 0, need = (size_t)4 << 20;
+        auto wp_need = [&](UadConvDesc d) { d.N = (int)NB; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
+        auto want = [&](UadConvDesc d) { d.N = (int)NB; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, false); if (v > need) need = v; } };
+        auto first = [&](UadConvDesc d) { d.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d); if (v > wp) wp = v; };
+        for (auto& o : m->y_enc) { if (o.L.d.CB % 4) first(o.L.d); else { wp_need(o.L.d); want(o.L.d); } }
+        for (size_t i = 0; i + 1 < m->y_dec.size(); ++i) {
+            auto& o = m->y_dec[i];
+            if (o.kind == 2) continue;
+            if (o.L.d.CB % 4) first(o.L.d); else { wp_need(o.L.d); want(o.L.d); }
+        }
+        first(m->y_fd);
+        ALLOC(m->wpartial, wp, nullptr);
+        m->ws.floats = need; m->ws.ptr = nullptr;
+        ALLOC(m->ws.ptr, need, nullptr);
+    }
+    ALLOC(m->colscratch, 64 * 1024, nullptr);
+    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
+#undef ALLOC
+    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
+    *out = m;
+    return UAD_OK;
+}
+
 static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
     const int H = cfg->height, ir = cfg->inter_res;
     if (cfg->aae_kind == 4 || cfg->aae_kind == 5) return create_zimmerer(cfg, out);
-    if (cfg->aae_kind < 0 || cfg->aae_kind > 5) return fail(UAD_ERR_INVALID, "bad aae_kind");
+    if (cfg->aae_kind == 6) return create_you(cfg, out);
+    if (cfg->aae_kind < 0 || cfg->aae_kind > 6) return fail(UAD_ERR_INVALID, "bad aae_kind");
     const bool gmv = cfg->aae_kind == 3;
     if (gmv) {
         const long long q = (long long)cfg->zdim * cfg->dim;
@@ -2219,7 +2550,7 @@ int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
     if (cfg->inter_res <= 0 || (cfg->inter_res & (cfg->inter_res - 1)) || cfg->inter_res >= H)
         return fail(UAD_ERR_INVALID, "inter_res must be a power of two smaller than height");
     if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
-    const bool dense_gmvae = cfg->variant == UAD_GAN_AAE && cfg->aae_kind == 3;      // its latent widths are free (skinny-dense kernels)
+    const bool dense_gmvae = cfg->variant == UAD_GAN_AAE && (cfg->aae_kind == 3 || cfg->aae_kind == 6);      // its latent widths are free (skinny-dense kernels)
     if (!dense_gmvae && (cfg->zdim <= 0 || cfg->zdim % 8)) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
     if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
     if (cfg->variant != UAD_GAN_UNIFIED && cfg->variant != UAD_GAN_RESNET && cfg->variant != UAD_GAN_ANOVAEGAN && cfg->variant != UAD_GAN_AAE)
@@ -2653,7 +2984,8 @@ static int gan_reconstruct_body(uad_gan_t* m, const uad_gan_io_t* io, int n, voi
     hipStream_t st = (hipStream_t)stream;
     const size_t img = (size_t)n * m->cfg.height * m->cfg.width;
     refresh_packs(m, st);
-    if (m->variant == UAD_GAN_AAE && m->zim) zim_forward(m, io->x, io->eps, n, n, st);
+    if (m->variant == UAD_GAN_AAE && m->you) you_forward(m, io, io->x, n, 1.0f / (float)n, st);
+    else if (m->variant == UAD_GAN_AAE && m->zim) zim_forward(m, io->x, io->eps, n, n, st);
     else if (m->variant == UAD_GAN_AAE && m->gmv) gmv_forward(m, io, io->x, n, 1.0f / (float)n, st);
     else if (m->variant == UAD_GAN_AAE) { a_encode(m, io->x, io->mask_z, n, 0, st); a_decode(m, m->a_zm, io->mask_g, n, st); }
     else if (m->variant == UAD_GAN_RESNET) { s_enc_forward(m, io->x, n, st); s_gen_forward(m, m->z, n, st); }
@@ -2669,10 +3001,11 @@ static int gan_reconstruct_body(uad_gan_t* m, const uad_gan_io_t* io, int n, voi
 int uad_gan_restore_step(uad_gan_t* m, float* x_restored, const uad_gan_io_t* io, int n, float tv_lambda, float restore_lr, float* grads_out,
                          void* stream) {
     if (!m || !io || !x_restored) return fail(UAD_ERR_INVALID, "null argument");
-    if (m->variant != UAD_GAN_AAE || !m->gmv) return fail(UAD_ERR_INVALID, "uad_gan_restore_step needs a dense GMVAE handle");
+    if (m->variant != UAD_GAN_AAE || !(m->gmv || m->you)) return fail(UAD_ERR_INVALID, "uad_gan_restore_step needs a GMVAE handle (aae_kind 3 or 6)");
     if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
     auto body = [&](hipStream_t st) {
-        const int rc = gmv_phase(m, io, x_restored, n, 1, true, tv_lambda, restore_lr, x_restored, grads_out, st);
+        const int rc = m->you ? you_phase(m, io, x_restored, n, 1, true, tv_lambda, restore_lr, x_restored, grads_out, st)
+                              : gmv_phase(m, io, x_restored, n, 1, true, tv_lambda, restore_lr, x_restored, grads_out, st);
         if (rc != UAD_OK) return rc;
         HIP_TRY(hipGetLastError());
         return (int)UAD_OK;

@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(256) gm_heads_fwd_kernel(const UadGmArgs a) {
     if (a.z_mu) for (int z = tid; z < Z; z += nt) a.z_mu[(size_t)loc * Z + z] = s[L.heads + 2 * W + z];
     if (a.z_ls) for (int z = tid; z < Z; z += nt) a.z_ls[(size_t)loc * Z + z] = s[L.heads + 2 * W + Z + z];
     if (a.pc) for (int c = tid; c < C; c += nt) a.pc[(size_t)loc * C + c] = s[L.pc + c];
+    if (a.zs_out) for (int z = tid; z < Z; z += nt) a.zs_out[(size_t)loc * Z + z] = s[L.zs + z];
 }
 
 // Backward of one location (recomputes its forward), fused with the activation backward of the last encoder block:
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(256) gm_heads_bwd_kernel(const UadGmArgs a) {
     // d z_mu / d z_log_sigma (heads slots 2W.., 2W+Z..)
     for (int z = tid; z < Z; z += nt) {
         const float zls = s[L.heads + 2 * W + Z + z], V = expf(zls);
-        float dzs = 0.f, dzmu = 0.f, dzls = 0.f;
+        float dzs = a.dz_dec ? a.dz_dec[(size_t)loc * Z + z] : 0.f, dzmu = 0.f, dzls = 0.f;
         for (int c = 0; c < C; ++c) {
             const int q = z * C + c;
             const float lq = s[L.Lq + q], E = expf(lq), E6 = E + 1e-6f;

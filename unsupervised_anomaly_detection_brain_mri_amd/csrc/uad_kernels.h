@@ -200,6 +200,9 @@ struct UadGmArgs {
     float* g_out;                       // [L,cenc] d loss / d c_enc
     float* colpart;                     // [L][2][cenc]
     float *dvec_heads, *dvec_a7, *dvec_M, *dvec_Lq, *ws_out, *mid_out;   // per-location vectors for the weight gradients
+    // decoders that consume z_sampled instead of h (models/gaussian_mixture_variational_autoencoder_You.py:54-68)
+    float* zs_out;                      // forward, optional: [L,Z] z_sampled
+    const float* dz_dec;                // backward, optional: [L,Z] d loss / d z_sampled through the decoder
 };
 struct UadGmWgradArgs {
     struct Job { const float* A; int lda; const float* B; int ldb; int b; int off; };

@@ -24,7 +24,7 @@ class GanEngine(_EvalOps):
         torch.cuda.set_device(self.device)
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
         variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET, 'anovaegan': _lib.GAN_ANOVAEGAN, 'aae': _lib.GAN_AAE}
-        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2, 'gmvae': 3, 'vae_zimmerer': 4, 'cevae_zimmerer': 5}     # 'gmvae': zdim = dim_z, dim = dim_c, dim_w, c_lambda
+        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2, 'gmvae': 3, 'vae_zimmerer': 4, 'cevae_zimmerer': 5, 'gmvae_you': 6}     # 'gmvae': zdim = dim_z, dim = dim_c, dim_w, c_lambda
         if variant == 'aae' and aae_kind not in kinds:
             raise ValueError(f'unknown aae_kind {aae_kind!r}')
         self.aae_kind = aae_kind if variant == 'aae' else None
@@ -46,7 +46,10 @@ class GanEngine(_EvalOps):
             self.spec.append((name.value.decode(), tuple(shape[:rank.value]), int(off.value)))
         dec_dense = {'constrained_ae': 'Bottleneck/dense_1/kernel', 'aae': 'Bottleneck/dense_1/kernel', 'constrained_aae': 'Decoder/dense/kernel',
                      'gmvae': 'Bottleneck/dense_4/kernel', 'vae_zimmerer': 'dense_2/kernel', 'cevae_zimmerer': 'Bottleneck/dense_2/kernel'}
-        self.flat = [s for n, s, _ in self.spec if n == (dec_dense[aae_kind] if variant == 'aae' else 'Generator/dense/kernel')][0][1]
+        if variant == 'aae' and aae_kind == 'gmvae_you':        # fully convolutional: no dense decoder input
+            self.flat = None
+        else:
+            self.flat = [s for n, s, _ in self.spec if n == (dec_dense[aae_kind] if variant == 'aae' else 'Generator/dense/kernel')][0][1]
         self._views = {}
         self.graph, self._pool, self._slot = False, {}, None
         self.set_math(math)
@@ -116,7 +119,7 @@ class GanEngine(_EvalOps):
         zeros = np.zeros(self.nparams, np.float32)
         self.set_buffer_host(_lib.BUF_ADAM_M, zeros)
         self.set_buffer_host(_lib.BUF_ADAM_V, zeros)
-        if self.variant in ('anovaegan', 'aae') and self.aae_kind not in ('vae_zimmerer', 'cevae_zimmerer'):      # the Zimmerer VAE has one optimizer, one pair of slots
+        if self.variant in ('anovaegan', 'aae') and self.aae_kind not in ('vae_zimmerer', 'cevae_zimmerer', 'gmvae_you'):      # the Zimmerer VAE has one optimizer, one pair of slots
             self.set_buffer_host(_lib.BUF_ADAM_M2, zeros)
             self.set_buffer_host(_lib.BUF_ADAM_V2, zeros)
         for g in ('Encoder', 'Generator', 'Discriminator'):
@@ -275,6 +278,15 @@ class GanEngine(_EvalOps):
     # ---------------------------------------------------------------- dense GMVAE (variant 'aae', aae_kind 'gmvae')
     def _gm_io(self, n, eps_w, eps_z, masks):
         masks = masks or {}
+        if self.aae_kind == 'gmvae_you':        # spatial latents on the H/4 map; the graph has no dropout layer
+            if any(v is not None for v in masks.values()):
+                raise ValueError('models/gaussian_mixture_variational_autoencoder_You.py has no dropout layers: masks are not accepted')
+            r = self.inter
+            t = dict(eps_w=self._dev(eps_w, (n, r, r, self.dim_w)), eps=self._dev(eps_z, (n, r, r, self.zdim)))
+            io = _lib.UadGanIO()
+            for k, v in t.items():
+                setattr(io, k, _ptr(v))
+            return io, t
         t = dict(eps_w=self._dev(eps_w, (n, self.dim_w)), eps=self._dev(eps_z, (n, self.zdim)),
                  mask_w_mu=self._dev(masks.get('w_mu'), (n, self.dim_w)), mask_w_ls=self._dev(masks.get('w_ls'), (n, self.dim_w)),
                  mask_z=self._dev(masks.get('z_mu'), (n, self.zdim)), mask_g=self._dev(masks.get('dec'), (n, self.flat)))
@@ -287,14 +299,15 @@ class GanEngine(_EvalOps):
         """One sess.run of trainers/GMVAE.py:122-139: forward + the four loss terms (+ the gradient of `loss` w.r.t. every variable).
         masks: dict with optional 'w_mu', 'w_ls' [n,dim_w], 'z_mu' [n,dim_z], 'dec' [n,flat] keep masks (already / (1 - rate))."""
         self._begin('gm_phase')
-        if self.aae_kind != 'gmvae':
-            raise ValueError('gm_phase needs a dense-GMVAE engine')
+        if self.aae_kind not in ('gmvae', 'gmvae_you'):
+            raise ValueError('gm_phase needs a GMVAE engine (aae_kind gmvae | gmvae_you)')
         n = x.shape[0]
         img = (n, self.h, self.w, self.c)
         x = self._dev(x, img)
         io, keep = self._gm_io(n, eps_w, eps_z, masks)
         scal = self._new(16, zero=True)
-        out = {'reconstruction': self._new(img), 'z_sampled': self._new((n, self.zdim))}
+        zshape = (n, self.inter, self.inter, self.zdim) if self.aae_kind == 'gmvae_you' else (n, self.zdim)
+        out = {'reconstruction': self._new(img), 'z_sampled': self._new(zshape)}
         io.x, io.scalars, io.reconstruction, io.z_enc = _ptr(x), _ptr(scal), _ptr(out['reconstruction']), _ptr(out['z_sampled'])
         if want_l1:
             out['L1'] = self._new(img); io.l1_map = _ptr(out['L1'])
@@ -309,8 +322,8 @@ class GanEngine(_EvalOps):
     def gm_restore_step(self, x_restored, eps_w=None, eps_z=None, masks=None, tv_lambda=1.8, restore_lr=1e-3, want_grads=False):
         """trainers/GMVAE.py:172-184 on device: x_restored (a DEVICE tensor, updated in place) -= restore_lr * d(n loss + sum tv TV_n)/dx."""
         self._begin('gm_restore_step')
-        if self.aae_kind != 'gmvae':
-            raise ValueError('gm_restore_step needs a dense-GMVAE engine')
+        if self.aae_kind not in ('gmvae', 'gmvae_you'):
+            raise ValueError('gm_restore_step needs a GMVAE engine (aae_kind gmvae | gmvae_you)')
         if not isinstance(x_restored, torch.Tensor) or x_restored.device != self.device or x_restored.dtype != torch.float32 or not x_restored.is_contiguous():
             raise ValueError('x_restored must be a contiguous fp32 tensor on the engine device (it is updated in place)')
         n = x_restored.shape[0]

@@ -15,3 +15,4 @@ from .constrained_adversarial_autoencoder import constrained_adversarial_autoenc
 from .gaussian_mixture_variational_autoencoder import gaussian_mixture_variational_autoencoder  # noqa: F401
 from .variational_autoencoder_Zimmerer import variational_autoencoder_Zimmerer  # noqa: F401
 from .context_encoder_variational_autoencoder_Zimmerer import context_encoder_variational_autoencoder_Zimmerer  # noqa: F401
+from .gaussian_mixture_variational_autoencoder_You import gaussian_mixture_variational_autoencoder_You  # noqa: F401

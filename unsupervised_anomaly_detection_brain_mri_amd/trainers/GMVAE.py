@@ -20,6 +20,7 @@ class GMVAE(GMVAE_spatial):
 
     ARCH = 'GMVAE'
     ARCHS = ('GMVAE',)
+    HAS_DROPOUT = True
     SCALAR_KEYS = ('reconstructionLoss', 'mean_p_loss', 'conditional_prior_loss', 'w_prior_loss', 'c_prior_loss', 'loss')
     GROUPS = ('AE',)
 
@@ -32,9 +33,12 @@ class GMVAE(GMVAE_spatial):
     def _make_dp(self, world):
         return GanDataParallel(self.engine, world)
 
+    def _eps_shapes(self, n):
+        return (n, self.config.dim_w), (n, self.config.dim_z)
+
     def _draw(self, n, dropout=False):
-        c = self.config
-        return (self.rng.standard_normal((n, c.dim_w)).astype(np.float32), self.rng.standard_normal((n, c.dim_z)).astype(np.float32))
+        sw, sz = self._eps_shapes(n)
+        return self.rng.standard_normal(sw).astype(np.float32), self.rng.standard_normal(sz).astype(np.float32)
 
     def _masks(self, n, on):
         r = float(self.config.dropout_rate)
@@ -84,12 +88,13 @@ class GMVAE(GMVAE_spatial):
         r = float(c.dropout_rate)
         for step in range(steps):
             if eps is None:
-                e_w = torch.randn((n, c.dim_w), device=dev, generator=g)
-                e_z = torch.randn((n, c.dim_z), device=dev, generator=g)
+                sw, sz = self._eps_shapes(n)
+                e_w = torch.randn(sw, device=dev, generator=g)
+                e_z = torch.randn(sz, device=dev, generator=g)
             else:
                 e_w, e_z = eps(step) if callable(eps) else eps
             masks = None
-            if dropout and r > 0:        # `dropout` is fed on every restoration run (:176): fresh masks per step, drawn on the device
+            if dropout and r > 0 and self.HAS_DROPOUT:        # `dropout` is fed on every restoration run (:176): fresh masks per step, drawn on the device
                 keep = lambda shape: (torch.rand(shape, device=dev, generator=g) >= r).float() / (1.0 - r)
                 masks = {'w_mu': keep((n, c.dim_w)), 'w_ls': keep((n, c.dim_w)), 'z_mu': keep((n, c.dim_z)), 'dec': keep((n, self.engine.flat))}
             self.engine.gm_restore_step(xr, e_w, e_z, masks, tv_lambda=tv_lambda, restore_lr=self.restore_lr)
@@ -119,3 +124,28 @@ class GMVAE(GMVAE_spatial):
 
     def _set_adam_steps(self, t):
         self.engine.set_step_count('AE', int(np.atleast_1d(t)[0]))
+
+
+class GMVAE_You(GMVAE):
+    """models/gaussian_mixture_variational_autoencoder_You.py under trainers/GMVAE_spatial.py (what `GMVAE_spatial(sess, config, network=
+    gaussian_mixture_variational_autoencoder_You)` instantiates): the spatial trainer's losses / restoration on the original architecture
+    (k3 layers, latent maps on the H/4 grid, decoder on z_sampled, no dropout layer).  Handle: uad_gan_* with aae_kind 6."""
+    Config = GMVAE_spatial.Config
+    ARCH = 'GMVAE_You'
+    ARCHS = ('GMVAE_You',)
+    HAS_DROPOUT = False
+
+    def _make_engine(self, device):
+        c = self.config
+        if int(c.intermediateResolutions[0]) * 4 != int(c.outputHeight):
+            raise ValueError('gaussian_mixture_variational_autoencoder_You: the latent map is outputHeight / 4; set intermediateResolutions accordingly')
+        return GanEngine(c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]), zdim=int(c.dim_z),
+                         max_batch=max(int(c.batchsize), 1), device=device, variant='aae', aae_kind='gmvae_you', dim=int(c.dim_c),
+                         dim_w=int(c.dim_w), c_lambda=float(c.c_lambda), math='f32')
+
+    def _eps_shapes(self, n):
+        r = self.engine.inter
+        return (n, r, r, self.config.dim_w), (n, r, r, self.config.dim_z)
+
+    def _masks(self, n, on):
+        return None

@@ -29,6 +29,15 @@ class GMVAE_spatial(AEMODEL):
             self.tv_lambda = 1.8
 
     ARCH = 'GMVAE_spatial'
+    ARCHS = ('GMVAE_spatial', 'GMVAE_You')
+
+    def __new__(cls, sess=None, config=None, network=None, **kw):
+        # the reference pairs this trainer with two spatial models; the original-architecture one runs on the materialised-graph handle
+        if cls is GMVAE_spatial and getattr(network, 'arch', None) == 'GMVAE_You':
+            from .GMVAE import GMVAE_You
+            return object.__new__(GMVAE_You)
+        return object.__new__(cls)
+
     SCALAR_KEYS = ('reconstructionLoss', 'mean_p_loss', 'conditional_prior_loss', 'w_prior_loss', 'c_prior_loss', 'loss')
     _SCALAR_SLOT = {'reconstructionLoss': 0, 'mean_p_loss': 0, 'conditional_prior_loss': 1, 'loss': 2, 'w_prior_loss': 3,
                     'c_prior_loss': 4}
