@@ -34,9 +34,9 @@ def _setup(h, dim_c, dim_z, dim_w, n, seed=0, c_lambda=1.0, perturb=True):
     return m, p32, x, rng.standard_normal((n, r, r, dim_w)).astype(np.float32), rng.standard_normal((n, r, r, dim_z)).astype(np.float32)
 
 
-def _engine(m, n):
+def _engine(m, n, math='f32'):
     return GanEngine(m.h, m.h, 1, m.h // 4, zdim=m.dim_z, max_batch=n, variant='aae', aae_kind='gmvae_you', dim=m.dim_c, dim_w=m.dim_w,
-                     c_lambda=m.c_lambda, math='f32')
+                     c_lambda=m.c_lambda, math=math)
 
 
 def _flips(eng, cache):
@@ -54,14 +54,15 @@ def _flips(eng, cache):
     return cnt
 
 
+@pytest.mark.parametrize('math', ['f32', 'bf16x3_all'])
 @pytest.mark.parametrize('h,dim_c,dim_z,dim_w,n,c_lambda', [(32, 6, 1, 1, 2, 1.0), (64, 5, 8, 2, 2, 0.001), (128, 9, 1, 1, 2, 0.01)])
-def test_gmvae_you_forward_backward_parity(h, dim_c, dim_z, dim_w, n, c_lambda):
+def test_gmvae_you_forward_backward_parity(h, dim_c, dim_z, dim_w, n, c_lambda, math):
     m, p32, x, e_w, e_z = _setup(h, dim_c, dim_z, dim_w, n, c_lambda=c_lambda)
     p64, x64 = _f64(p32), x.astype(np.float64)
     out, cache = m.forward(p64, x64, e_w.astype(np.float64), e_z.astype(np.float64))
     ls = m.losses(x64, out)
     g = m.backward(p64, x64, out, cache)
-    eng = _engine(m, n)
+    eng = _engine(m, n, math)
     assert [(a, tuple(b)) for a, b, _ in eng.spec] == [(a, tuple(b)) for a, b, _ in m.spec]
     eng.set_params(p32)
     got = eng.gm_phase(x, e_w, e_z)

@@ -33,8 +33,9 @@ def _flips(eng, cache, n):
     return cnt
 
 
+@pytest.mark.parametrize('math', ['f32', 'bf16x3_all'])
 @pytest.mark.parametrize('h,zd,n', [(32, 16, 2), (64, 32, 3), (128, 128, 2)])
-def test_zimmerer_forward_backward_parity(h, zd, n):
+def test_zimmerer_forward_backward_parity(h, zd, n, math):
     m = oz.VAEZimmerer(h, zd)
     p32 = oz.init_params(m.spec, seed=5, dtype=np.float32)
     x = ovae.synthetic_slices(n, h, h, seed=1, dtype=np.float32)
@@ -43,7 +44,7 @@ def test_zimmerer_forward_backward_parity(h, zd, n):
     out, cache = m.forward(p64, x64, eps.astype(np.float64))
     ls = m.losses(x64, out)
     g = m.backward(p64, x64, out, cache)
-    eng = GanEngine(h, h, 1, h // 16, zd, max_batch=n, variant='aae', aae_kind='vae_zimmerer', math='f32')
+    eng = GanEngine(h, h, 1, h // 16, zd, max_batch=n, variant='aae', aae_kind='vae_zimmerer', math=math)
     assert [(a, tuple(b)) for a, b, _ in eng.spec] == [(a, tuple(b)) for a, b, _ in m.spec]
     eng.set_params(p32)
     got = eng.zim_phase(x, eps)

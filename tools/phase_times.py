@@ -70,14 +70,15 @@ for math in ('f32', 'bf16x3_all'):
     res[f'vae_zimmerer_128_b64_{math}_ms'] = {'train': timed(lambda: (eng.zim_phase(x, ez, want_l1=False), eng.adam('AE', 1e-4, 0.5, 0.999)), reps=10),
                                              'forward': timed(lambda: eng.zim_phase(x, ez, want_backward=False, want_l1=False), reps=10)}
     eng.close()
-eng = GanEngine(128, 128, 1, 32, zdim=1, max_batch=64, variant='aae', aae_kind='gmvae_you', dim=9, dim_w=1, math='f32')
-init(eng)
-ew = torch.randn(64, 32, 32, 1, device='cuda', generator=g); ez = torch.randn(64, 32, 32, 1, device='cuda', generator=g)
-xr = x.clone()
-res['gmvae_you_128_b64_f32_ms'] = {'train': timed(lambda: (eng.gm_phase(x, ew, ez, want_l1=False), eng.adam('AE', 5e-5, 0.5, 0.999)), reps=10),
-                                   'forward': timed(lambda: eng.gm_phase(x, ew, ez, want_backward=False, want_l1=False), reps=10),
-                                   'restore_step': timed(lambda: eng.gm_restore_step(xr, ew, ez), reps=10)}
-eng.close()
+for math in ('f32', 'bf16x3_all'):
+    eng = GanEngine(128, 128, 1, 32, zdim=1, max_batch=64, variant='aae', aae_kind='gmvae_you', dim=9, dim_w=1, math=math)
+    init(eng)
+    ew = torch.randn(64, 32, 32, 1, device='cuda', generator=g); ez = torch.randn(64, 32, 32, 1, device='cuda', generator=g)
+    xr = x.clone()
+    res[f'gmvae_you_128_b64_{math}_ms'] = {'train': timed(lambda: (eng.gm_phase(x, ew, ez, want_l1=False), eng.adam('AE', 5e-5, 0.5, 0.999)), reps=10),
+                                          'forward': timed(lambda: eng.gm_phase(x, ew, ez, want_backward=False, want_l1=False), reps=10),
+                                          'restore_step': timed(lambda: eng.gm_restore_step(xr, ew, ez), reps=10)}
+    eng.close()
 # hipGraph replay (uad_gan_set_graph_mode) vs plain launches: one f-AnoGAN WGAN iteration (1 generator + 5 critic phases) + encoder step
 for (variant, h, bs) in (('unified', 64, 64), ('unified', 128, 64)):
     row = {}

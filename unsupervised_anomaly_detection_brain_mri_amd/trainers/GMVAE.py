@@ -141,7 +141,7 @@ class GMVAE_You(GMVAE):
             raise ValueError('gaussian_mixture_variational_autoencoder_You: the latent map is outputHeight / 4; set intermediateResolutions accordingly')
         return GanEngine(c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]), zdim=int(c.dim_z),
                          max_batch=max(int(c.batchsize), 1), device=device, variant='aae', aae_kind='gmvae_you', dim=int(c.dim_c),
-                         dim_w=int(c.dim_w), c_lambda=float(c.c_lambda), math='f32')
+                         dim_w=int(c.dim_w), c_lambda=float(c.c_lambda), math='bf16x3_all')      # parity-rated for this stack: tests/test_gpu_gmvae_you.py, both modes
 
     def _eps_shapes(self, n):
         r = self.engine.inter
