@@ -213,12 +213,15 @@ class AAE:
         self.encode_backward(p, ec, dz, g)
         return losses, g
 
+    def _z_hat(self, z_prior, z_, eps):
+        return z_prior + eps * (z_prior - z_)            # (sic) adversarial_autoencoder.py:60, constrained_adversarial_autoencoder.py:67
+
     def disc_phase(self, p, x, z_prior, eps, mask_z=None):
         """optim_dis: disc_loss (+ penalty) w.r.t. the Discriminator variables."""
         z_, _ = self.encode(p, x, mask_z)
         d_fake, cf = self.critic(p, z_)
         d_real, cr = self.critic(p, z_prior)
-        z_hat = z_prior + eps.reshape(-1, 1) * (z_prior - z_)
+        z_hat = self._z_hat(z_prior, z_, eps.reshape(-1, 1))
         _, ch = self.critic(p, z_hat)
         g = {}
         n = x.shape[0]
