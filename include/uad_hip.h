@@ -237,7 +237,13 @@ enum { UAD_GAN_AAE = 3 };        /* dense-bottleneck BN autoencoder + re-encodin
                                      5 = the context-encoding VAE on the same stack, models/context_encoder_variational_autoencoder_Zimmerer.py:8-45 under
                                      trainers/ceVAE.py:38-51: io.x_ce, both branches as one 2n-sample pass; want_backward 2 = data-gradient chain only
                                      (io.anomaly without parameter gradients); scalars UAD_GAN_S_LOSS_IMG = Rec_vae, UAD_GAN_S_LOSS_FTS = Rec_ce, UAD_GAN_S_KL,
-                                     UAD_GAN_S_REC_LOSS, UAD_GAN_S_ENC_LOSS = loss, UAD_GAN_S_GM_LOSS = loss_vae */
+                                     UAD_GAN_S_REC_LOSS, UAD_GAN_S_ENC_LOSS = loss, UAD_GAN_S_GM_LOSS = loss_vae.
+                                     6 = the original-architecture spatial GMVAE, models/gaussian_mixture_variational_autoencoder_You.py:8-85 under
+                                     trainers/GMVAE_spatial.py: inter_res = height / 4 (the latent map), cfg as for kind 3, io.eps_w / io.eps =
+                                     [n,r,r,dim_w] / [n,r,r,dim_z], no masks; scalars UAD_GAN_S_GM_*; uad_gan_restore_step.
+                                     7 = the constrained adversarial autoencoder on residual blocks, models/constrained_adversarial_autoencoder_Chen.py:11-162
+                                     under trainers/ConstrainedAAE.py:44-70: cfg.dim (32 | 64), height = 8 * inter_res; phases / groups / io as kind 2
+                                     (no dropout masks; io.alpha = the run's scalar eps repeated n times, z_hat = eps z + (1 - eps) z_) */
 enum { UAD_GAN_GROUP_VAE = 3 };   /* uad_gan_group only: the contiguous Encoder + Generator slice (AnoVAE-GAN's optim_vae) */
 enum { UAD_BUF_ADAM_M2 = 4, UAD_BUF_ADAM_V2 = 5 };
 /* scalars[16] written by uad_gan_phase (entries a phase does not compute are left untouched) */
@@ -257,7 +263,7 @@ typedef struct {
                                       height must be 8 * inter_res; no dropout in that graph: mask_z / mask_g are ignored) */
     int dim;                       /* RESNET only: base width (fanogan_schlegl.py:13: 64); 0 = 64 */
     float kl_weight;               /* ANOVAEGAN only: AnoVAEGAN.Config.kl_weight (:17) */
-    int aae_kind;                  /* AAE only: 0 constrained AE, 1 AAE, 2 constrained AAE, 3 dense GMVAE, 4 Zimmerer VAE, 5 Zimmerer ceVAE */
+    int aae_kind;                  /* AAE only: 0 constrained AE, 1 AAE, 2 constrained AAE, 3 dense GMVAE, 4 Zimmerer VAE, 5 Zimmerer ceVAE, 6 GMVAE (You), 7 constrained AAE (Chen) */
     float rho;                     /* AAE only: weight of the latent re-encoding term (ConstrainedAE.Config.rho :15) */
     int dim_w;                     /* dense GMVAE only: GMVAE.Config.dim_w (:17); dim_z = zdim, dim_c = dim */
     float c_lambda;                /* dense GMVAE only: GMVAE.Config.c_lambda (:18) */

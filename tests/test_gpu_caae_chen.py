@@ -1,0 +1,104 @@
+"""GPU parity of the residual-block constrained adversarial autoencoder (models/constrained_adversarial_autoencoder_Chen.py under
+trainers/ConstrainedAAE.py) through the C-ABI (uad_gan_* with UAD_GAN_AAE / aae_kind 7) vs the fp64 oracle: the three phases' scalars and
+gradients.  The autoencoder phase's gradient runs x -> encoder -> decoder -> encoder again (24 LayerNorms deep): its fp32 round-off reaches
+1.2e-4 of a kernel gradient's max-norm on the smallest case, so the bound here is 2e-4 (1e-4 in the shallower graphs) when no activation sign differs between the device run and the oracle (counted
+exactly over every LayerNorm+ReLU output); with flips, 5e-2 in the L2 norm (one flipped element is an O(1) change of that pixel's
+LayerNorm parameter gradients), as in tests/test_gpu_fanogan.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import caae_chen as oc
+from oracle import gmvae as og
+from oracle import vae as ovae
+
+pytestmark = pytest.mark.gpu
+
+try:
+    from unsupervised_anomaly_detection_brain_mri_amd import _lib
+    from unsupervised_anomaly_detection_brain_mri_amd.gan_engine import GanEngine
+    from tests.gpu_util import assert_close
+except Exception:
+    GanEngine = None
+
+
+def _setup(h, zd, dim, n, seed=0):
+    m = oc.CAAEChen(h, zd, dim=dim, rho=0.8)
+    p32 = og.init_params(m.spec, seed=3 + seed, dtype=np.float32, perturb=True)
+    x = ovae.synthetic_slices(n, h, h, seed=seed, dtype=np.float32)
+    rng = np.random.default_rng(7 + seed)
+    return m, p32, x, rng.standard_normal((n, zd)).astype(np.float32), np.full(n, 0.41, np.float32)
+
+
+def _engine(m, n):
+    return GanEngine(m.height, m.height, 1, m.inter_res, m.zdim, max_batch=n, variant='aae', aae_kind='caae_chen', dim=m.dim, rho=m.rho, scale=m.scale,
+                     math='f32')
+
+
+def _check(eng, m, g, groups, flips):
+    grads = eng.get_grads()
+    for name, _, _ in m.spec:
+        if not name.startswith(groups):
+            continue
+        a, b = grads[name].astype(np.float64), np.asarray(g.get(name, np.zeros_like(grads[name])), np.float64)
+        scale = max(np.abs(b).max(), 1e-30)
+        if np.abs(b).max() <= 1e-9:                      # conv biases in front of a LayerNorm-HW: identically zero
+            assert np.abs(a).max() <= 1e-5, name
+        elif flips == 0:
+            assert np.abs(a - b).max() <= (2e-4 if 'kernel' in name else 5e-4) * scale, (name, np.abs(a - b).max() / scale)
+        else:
+            assert np.linalg.norm(a - b) <= 5e-2 * np.linalg.norm(b), (name, flips)
+
+
+def _flips(eng, caches):
+    """caches: list of (prefix, block caches, sample offset) -- sign differences of every ReLU input (LayerNorm output)."""
+    cnt = 0
+    for tag, blocks, off in caches:
+        for k, c in enumerate(blocks):
+            for key, dev_name in (('y1', f'{tag}_h1_{k}'), ('y2', f'{tag}_h2_{k}')):
+                ref = c[key]
+                dev = eng.debug_buffer(dev_name).cpu().numpy()
+                per = ref[0].size
+                dev = dev[off * per:(off + ref.shape[0]) * per].reshape(ref.shape)
+                cnt += int(((dev > 0) != (ref > 0)).sum())
+    return cnt
+
+
+@pytest.mark.parametrize('h,zd,dim,n', [(32, 16, 32, 3), (32, 32, 32, 2), (64, 128, 64, 1)])
+def test_caae_chen_phases(h, zd, dim, n):
+    m, p32, x, zp, eps = _setup(h, zd, dim, n)
+    p64, x64 = {k: v.astype(np.float64) for k, v in p32.items()}, x.astype(np.float64)
+    eng = _engine(m, n)
+    assert [(a, tuple(b)) for a, b, _ in eng.spec] == [(a, tuple(b)) for a, b, _ in m.spec]
+    assert eng.group('Encoder')[1] == sum(int(np.prod(s)) for nm, s, _ in m.spec if nm.startswith('Encoder'))
+    eng.set_params(p32)
+    # autoencoder phase (optim_ae)
+    ls, g = m.ae_phase(p64, x64)
+    got = eng.aae_phase('AE', x, want_l1=True)
+    torch.cuda.synchronize()
+    assert_close(got['reconstruction'].cpu().numpy(), ls['reconstruction'], tol=2e-4, name='x_hat')
+    assert_close(got['z'].cpu().numpy(), ls['z'], tol=2e-4, name='z_')
+    for k, ref in (('loss', ls['loss']), ('L2', ls['L2'].mean()), ('Rec_z', ls['Rec_z'].mean()), ('reconstructionLoss', ls['reconstructionLoss'])):
+        assert abs(float(got[k]) - ref) <= 3e-4 * max(abs(ref), 1e-6), (k, float(got[k]), ref)
+    z_, ec = m.encode(p64, x64)
+    xh, dc = m.decode(p64, z_)
+    _, ec2 = m.encode(p64, xh)
+    flips = _flips(eng, [('sd', ec['blocks'], 0), ('sd', ec2['blocks'], n), ('sg', dc['blocks'], 0)])
+    _check(eng, m, g, ('Encoder', 'Decoder'), flips)
+    # critic phase (optim_dis)
+    ls, g = m.disc_phase(p64, x64, zp.astype(np.float64), eps.astype(np.float64))
+    got = eng.aae_phase('Discriminator', x, z=zp, eps=eps)
+    torch.cuda.synchronize()
+    for k in ('disc_fake', 'disc_real', 'penalty', 'disc_loss'):
+        assert abs(float(got[k]) - ls[k]) <= 5e-4 * max(abs(ls[k]), 1e-3), (k, float(got[k]), ls[k])
+    _check(eng, m, g, ('Discriminator',), 0)
+    # generator phase (optim_gen): -mean d_ w.r.t. the Encoder variables
+    ls, g = m.gen_phase(p64, x64)
+    got = eng.aae_phase('Encoder', x)
+    torch.cuda.synchronize()
+    assert abs(float(got['gen_loss']) - ls['gen_loss']) <= 3e-4 * max(abs(ls['gen_loss']), 1e-3)
+    flips = _flips(eng, [('sd', ec['blocks'], 0)])
+    _check(eng, m, g, ('Encoder',), flips)
+    rec = eng.reconstruct(x)['reconstruction'].cpu().numpy()
+    assert_close(rec, m.reconstruct(p64, x64), tol=2e-4, name='reconstruct')
+    eng.close()

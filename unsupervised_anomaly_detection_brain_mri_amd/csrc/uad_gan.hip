@@ -540,6 +540,7 @@ __global__ void __launch_bounds__(256) up2_bwd_kernel(const float* __restrict__ 
 // afterwards in a fixed order).  mode 1 (generator step): only the fake evaluation and dz_fake = -1/n * d d_ / d z_.
 struct CriticArgs {
     int zd, h1, h2, mode;                 // mode 0 = critic step, 1 = generator step
+    int hat_mode;                         // 0: z_hat = z + eps (z - z_) (sic, the unified models); 1: z_hat = eps z + (1 - eps) z_ (..._Chen.py:119)
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     const float *zf, *zr, *eps;           // fake [n,zd], real [n,zd], eps [n]
     float inv_n, scale;
@@ -547,7 +548,7 @@ struct CriticArgs {
     float *slab;                          // [n][nD]: dW1 | db1 | dW2 | db2 | dW3 | db3
     float *dz_fake;                       // [n,zd] (mode 1)
 };
-constexpr int kCritMaxZ = 512, kCritMaxH = 128;
+constexpr int kCritMaxZ = 512, kCritMaxH = 400;
 __global__ void __launch_bounds__(128) critic_kernel(const CriticArgs A) {
     __shared__ float v[3][kCritMaxZ];                 // fake, real, hat
     __shared__ float m1[3][kCritMaxH], hh1[3][kCritMaxH], m2[3][kCritMaxH], hh2[3][kCritMaxH];
@@ -560,23 +561,23 @@ __global__ void __launch_bounds__(128) critic_kernel(const CriticArgs A) {
     for (int k = t; k < zd; k += 128) {
         const float f = A.zf[(size_t)n * zd + k];
         v[0][k] = f;
-        if (A.mode == 0) { const float r = A.zr[(size_t)n * zd + k]; v[1][k] = r; v[2][k] = r + A.eps[n] * (r - f); }
+        if (A.mode == 0) { const float r = A.zr[(size_t)n * zd + k]; v[1][k] = r; v[2][k] = A.hat_mode ? f + A.eps[n] * (r - f) : r + A.eps[n] * (r - f); }
     }
     __syncthreads();
     // forward of the inputs
     for (int i = 0; i < nin; ++i) {
-        if (t < h1) {
-            float a = A.b1[t];
-            for (int k = 0; k < zd; ++k) a = fmaf(v[i][k], A.W1[(size_t)k * h1 + t], a);
-            m1[i][t] = a > 0.f ? 1.f : alpha; hh1[i][t] = a > 0.f ? a : alpha * a;
+        for (int q = t; q < h1; q += 128) {
+            float a = A.b1[q];
+            for (int k = 0; k < zd; ++k) a = fmaf(v[i][k], A.W1[(size_t)k * h1 + q], a);
+            m1[i][q] = a > 0.f ? 1.f : alpha; hh1[i][q] = a > 0.f ? a : alpha * a;
         }
     }
     __syncthreads();
     for (int i = 0; i < nin; ++i) {
-        if (t < h2) {
-            float a = A.b2[t];
-            for (int j = 0; j < h1; ++j) a = fmaf(hh1[i][j], A.W2[(size_t)j * h2 + t], a);
-            m2[i][t] = a > 0.f ? 1.f : alpha; hh2[i][t] = a > 0.f ? a : alpha * a;
+        for (int q = t; q < h2; q += 128) {
+            float a = A.b2[q];
+            for (int j = 0; j < h1; ++j) a = fmaf(hh1[i][j], A.W2[(size_t)j * h2 + q], a);
+            m2[i][q] = a > 0.f ? 1.f : alpha; hh2[i][q] = a > 0.f ? a : alpha * a;
         }
     }
     __syncthreads();
@@ -589,12 +590,12 @@ __global__ void __launch_bounds__(128) critic_kernel(const CriticArgs A) {
     if (t == 0) { A.d_fake[n] = s_d[0]; if (A.mode == 0) A.d_real[n] = s_d[1]; }
     // u2 = m2 * w3, t1 = W2 u2, u1 = m1 * t1, gz = W1 u1 on the input whose input-gradient is needed (hat: mode 0, fake: mode 1)
     const int gi = A.mode == 0 ? 2 : 0;
-    if (t < h2) u2[t] = m2[gi][t] * A.W3[t];
+    for (int q = t; q < h2; q += 128) u2[q] = m2[gi][q] * A.W3[q];
     __syncthreads();
-    if (t < h1) {
+    for (int q = t; q < h1; q += 128) {
         float a = 0.f;
-        for (int l = 0; l < h2; ++l) a = fmaf(A.W2[(size_t)t * h2 + l], u2[l], a);
-        u1[t] = m1[gi][t] * a;
+        for (int l = 0; l < h2; ++l) a = fmaf(A.W2[(size_t)q * h2 + l], u2[l], a);
+        u1[q] = m1[gi][q] * a;
     }
     __syncthreads();
     float part = 0.f;
@@ -620,20 +621,20 @@ __global__ void __launch_bounds__(128) critic_kernel(const CriticArgs A) {
     __syncthreads();
     const float coef = s_coef;                       // gbar = coef * gz
     // first-order backward of +d_/n (fake, i = 0) and -d/n (real, i = 1)
-    if (t < h2) { da2[0][t] = A.inv_n * A.W3[t] * m2[0][t]; da2[1][t] = -A.inv_n * A.W3[t] * m2[1][t]; }
+    for (int q = t; q < h2; q += 128) { da2[0][q] = A.inv_n * A.W3[q] * m2[0][q]; da2[1][q] = -A.inv_n * A.W3[q] * m2[1][q]; }
     __syncthreads();
-    if (t < h1) {
+    for (int q = t; q < h1; q += 128) {
         float a0 = 0.f, a1 = 0.f, ub = 0.f;
-        for (int l = 0; l < h2; ++l) { const float w = A.W2[(size_t)t * h2 + l]; a0 = fmaf(w, da2[0][l], a0); a1 = fmaf(w, da2[1][l], a1); }
-        da1[0][t] = a0 * m1[0][t]; da1[1][t] = a1 * m1[1][t];
-        for (int k = 0; k < zd; ++k) ub = fmaf(gz[k], A.W1[(size_t)k * h1 + t], ub);      // adjoint of u1 (times coef)
-        tb1[t] = coef * ub * m1[2][t];
+        for (int l = 0; l < h2; ++l) { const float w = A.W2[(size_t)q * h2 + l]; a0 = fmaf(w, da2[0][l], a0); a1 = fmaf(w, da2[1][l], a1); }
+        da1[0][q] = a0 * m1[0][q]; da1[1][q] = a1 * m1[1][q];
+        for (int k = 0; k < zd; ++k) ub = fmaf(gz[k], A.W1[(size_t)k * h1 + q], ub);      // adjoint of u1 (times coef)
+        tb1[q] = coef * ub * m1[2][q];
     }
     __syncthreads();
-    if (t < h2) {
+    for (int q = t; q < h2; q += 128) {
         float a = 0.f;
-        for (int j = 0; j < h1; ++j) a = fmaf(tb1[j], A.W2[(size_t)j * h2 + t], a);
-        ub2[t] = a;
+        for (int j = 0; j < h1; ++j) a = fmaf(tb1[j], A.W2[(size_t)j * h2 + q], a);
+        ub2[q] = a;
     }
     __syncthreads();
     // the sample's gradient slab
@@ -644,16 +645,16 @@ __global__ void __launch_bounds__(128) critic_kernel(const CriticArgs A) {
         S[idx] = v[0][k] * da1[0][j] + v[1][k] * da1[1][j] + coef * gz[k] * u1[j];
     }
     float* S1 = S + (size_t)zd * h1;
-    if (t < h1) S1[t] = da1[0][t] + da1[1][t];
+    for (int q = t; q < h1; q += 128) S1[q] = da1[0][q] + da1[1][q];
     float* S2 = S1 + h1;
     for (int idx = t; idx < h1 * h2; idx += 128) {
         const int j = idx / h2, l = idx - j * h2;
         S2[idx] = hh1[0][j] * da2[0][l] + hh1[1][j] * da2[1][l] + tb1[j] * u2[l];
     }
     float* S3 = S2 + (size_t)h1 * h2;
-    if (t < h2) {
-        S3[t] = da2[0][t] + da2[1][t];
-        S3[h2 + t] = A.inv_n * (hh2[0][t] - hh2[1][t]) + ub2[t] * m2[2][t];
+    for (int q = t; q < h2; q += 128) {
+        S3[q] = da2[0][q] + da2[1][q];
+        S3[h2 + q] = A.inv_n * (hh2[0][q] - hh2[1][q]) + ub2[q] * m2[2][q];
     }
     if (t == 0) S3[2 * h2] = 0.f;                    // db3: +1/n - 1/n
 }
@@ -728,6 +729,7 @@ struct uad_gan {
     int gm_hd[4], gm_ho[4];            // head widths and column offsets inside a row
     float *gm_hv, *gm_hvm, *gm_ws, *gm_M, *gm_Lq, *gm_pc, *gm_loss3, *gm_dhv, *gm_dM, *gm_dLq, *gm_dxhat;
     // Zimmerer VAE (aae_kind 4): k4 convolutions + bias + leaky_relu(0.2), no normalisation; E / G hold the blocks (gamma = beta = -1)
+    bool chen;                         // aae_kind 7: constrained adversarial autoencoder on residual blocks (encoder = DB, decoder = GB)
     bool zim, zim_ce;                  // zim_ce (aae_kind 5): the context-encoding VAE on the same stack, both branches as one 2n-sample pass
     float* z_l1;                       // [2n] L1 maps of both branches
     long long z_muw, z_mub, z_lsw, z_lsb, z_dw, z_db, z_fw, z_fb;
@@ -859,7 +861,7 @@ void reduce_to(uad_gan* m, int k, const float* a, const float* b, size_t n, floa
 
 int refresh_packs(uad_gan* m, hipStream_t st) {
     if (m->packed_valid) return UAD_OK;
-    if (m->zim || m->you) { m->packed_valid = true; return UAD_OK; }       // no k5 layers: nothing is packed
+    if (m->zim || m->you || m->chen) { m->packed_valid = true; return UAD_OK; }       // no k5 layers: nothing is packed
     long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
     auto add = [&](const Block& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
     for (size_t i = 1; i < m->E.size(); ++i) add(m->E[i]);
@@ -1082,6 +1084,14 @@ void disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float* 
 }
 
 
+
+// residual-block constrained AAE (aae_kind 7): the AAE-family phases on the ResNet-graph blocks (defined after them)
+void c_encode(uad_gan* m, const float* x, int n, int off, hipStream_t st);
+void c_encode_backward(uad_gan* m, const float* dz, int n, int off, float* dx_out, hipStream_t st);
+void c_encode_wgrads(uad_gan* m, int nall, hipStream_t st);
+void c_decode(uad_gan* m, const float* z, int n, hipStream_t st);
+void c_decode_backward(uad_gan* m, const float* z, const float* dxh, int n, float* dz_out, bool pg, hipStream_t st);
+
 // ================================================================================================ AAE family
 // models/constrained_autoencoder.py, adversarial_autoencoder.py, constrained_adversarial_autoencoder.py on materialised activations.
 void bn_fwd(uad_gan* m, long long gamma, long long beta, float alpha, const float* c, size_t rows, int C, float* a, hipStream_t st) {
@@ -1103,6 +1113,7 @@ void bn_finalize(uad_gan* m, const float* colpart, int T, int C, long long gamma
 }
 // encoder pass of n samples at sample offset `off` (0: x, n: x_hat); z (post dropout) lands in a_zm + off * zdim
 void a_encode(uad_gan* m, const float* x, const float* mask, int n, int off, hipStream_t st) {
+    if (m->chen) { c_encode(m, x, n, off, st); return; }
     const int r = m->cfg.inter_res, zd = m->cfg.zdim;
     const float* in = x;
     for (size_t i = 0; i < m->E.size(); ++i) {
@@ -1131,6 +1142,7 @@ void a_encode(uad_gan* m, const float* x, const float* mask, int n, int off, hip
 // data-gradient chain of one encoder pass from d / d z (post dropout) in `dz`: leaves d c_i in a_eg[i] (+off) and the BN column
 // partials in a_cp[i] (rows [cp_row0, ...)); returns the partial-row count (identical for every level is NOT assumed: see cp_rows)
 void a_encode_backward(uad_gan* m, const float* dz, const float* mask, int n, int off, int* cp_rows, float* dx_out, hipStream_t st) {
+    if (m->chen) { c_encode_backward(m, dz, n, off, dx_out, st); return; }
     const int r = m->cfg.inter_res, zd = m->cfg.zdim;
     float* dfl = m->a_dflat + (size_t)off * m->flat;
     if (m->gmv) {
@@ -1162,6 +1174,7 @@ void a_encode_backward(uad_gan* m, const float* dz, const float* mask, int n, in
 }
 // parameter gradients of the encoder path over `rows_n` samples (both passes when constrained)
 void a_encode_wgrads(uad_gan* m, const float* x_all, int nall, const int* cp_rows, hipStream_t st) {
+    if (m->chen) { c_encode_wgrads(m, nall, st); return; }
     const int r = m->cfg.inter_res, zd = m->cfg.zdim;
     if (m->gmv) {
         for (int h = 0; h < 4; ++h)
@@ -1179,6 +1192,7 @@ void a_encode_wgrads(uad_gan* m, const float* x_all, int nall, const int* cp_row
     }
 }
 void a_decode(uad_gan* m, const float* z, const float* mask_dec, int n, hipStream_t st) {
+    if (m->chen) { c_decode(m, z, n, st); return; }
     const int r = m->cfg.inter_res;
     if (m->gmv) {          // dec_dense on z_sampled [n, dim_z] (dim_z may be 1: a skinny product)
         UadSdArgs a;
@@ -1201,6 +1215,7 @@ void a_decode(uad_gan* m, const float* z, const float* mask_dec, int n, hipStrea
 }
 // dxh = d loss / d x_hat; writes every decoder-path gradient and d / d z into dz_out
 void a_decode_backward(uad_gan* m, const float* z, const float* mask_dec, const float* dxh, int n, float* dz_out, hipStream_t st, bool pg = true) {
+    if (m->chen) { c_decode_backward(m, z, dxh, n, dz_out, pg, st); return; }
     const int r = m->cfg.inter_res;
     const Block& LL = m->G.back();
     const int rows = n * LL.H * LL.W;
@@ -1244,7 +1259,7 @@ void a_decode_backward(uad_gan* m, const float* z, const float* mask_dec, const 
 void a_critic(uad_gan* m, int mode, const float* zf, const float* zr, const float* eps, int n, hipStream_t st) {
     CriticArgs a;
     memset(&a, 0, sizeof a);
-    a.zd = m->cfg.zdim; a.h1 = m->a_h1; a.h2 = m->a_h2; a.mode = mode;
+    a.zd = m->cfg.zdim; a.h1 = m->a_h1; a.h2 = m->a_h2; a.mode = mode; a.hat_mode = m->chen ? 1 : 0;
     a.W1 = P(m, m->a_w1); a.b1 = P(m, m->a_b1); a.W2 = P(m, m->a_w2); a.b2 = P(m, m->a_b2); a.W3 = P(m, m->a_w3); a.b3 = P(m, m->a_b3);
     a.zf = zf; a.zr = zr; a.eps = eps; a.inv_n = 1.0f / (float)n; a.scale = m->cfg.scale;
     a.d_fake = m->a_crit[0]; a.d_real = m->a_crit[1]; a.pen = m->a_crit[2]; a.slab = m->a_slab; a.dz_fake = m->dzbuf;
@@ -1429,19 +1444,21 @@ void avgpool_bwd(const float* g, int N, int H, int C, float* dx, hipStream_t st)
 }
 
 // forward of the first N samples
-void rb_forward(uad_gan* m, RB& B, int N, hipStream_t st) {
+void rb_forward(uad_gan* m, RB& B, int N, hipStream_t st, size_t off = 0) {      // off: first sample (the buffers hold several passes)
     const int HW = B.Hin * B.Hin;
-    ln_fwd(B.X, P(m, B.ln1g), P(m, B.ln1b), 0.0f, N, HW, B.Cin, B.H1, B.ST1, st);
-    g_conv_f(m, B.d1, N, B.H1, B.w1, P(m, B.b1), nullptr, B.C1, st);
-    ln_fwd(B.C1, P(m, B.ln2g), P(m, B.ln2b), 0.0f, N, HW, B.Cout, B.H2, B.ST2, st);
-    const float* add = B.X;                                   // identity shortcut
+    const float* X = B.X + off * B.sx;
+    float* H1 = B.H1 + off * B.sx; float* C1 = B.C1 + off * B.sc1; float* H2 = B.H2 + off * B.sc1; float* OUT = B.OUT + off * B.sout;
+    ln_fwd(X, P(m, B.ln1g), P(m, B.ln1b), 0.0f, N, HW, B.Cin, H1, B.ST1 + off * 2 * B.Cin, st);
+    g_conv_f(m, B.d1, N, H1, B.w1, P(m, B.b1), nullptr, C1, st);
+    ln_fwd(C1, P(m, B.ln2g), P(m, B.ln2b), 0.0f, N, HW, B.Cout, H2, B.ST2 + off * 2 * B.Cout, st);
+    const float* add = X;                                     // identity shortcut
     if (B.ws >= 0) {
-        if (B.gen) g_conv_d(m, B.ds, N, B.X, B.ws, P(m, B.bs), nullptr, m->s_sp, st);
-        else { g_conv_f(m, B.ds, N, B.X, B.ws, P(m, B.bs), nullptr, m->s_sct, st); avgpool_fwd(m->s_sct, N, B.Hin, B.Cout, m->s_sp, st); }
+        if (B.gen) g_conv_d(m, B.ds, N, X, B.ws, P(m, B.bs), nullptr, m->s_sp, st);
+        else { g_conv_f(m, B.ds, N, X, B.ws, P(m, B.bs), nullptr, m->s_sct, st); avgpool_fwd(m->s_sct, N, B.Hin, B.Cout, m->s_sp, st); }
         add = m->s_sp;
     }
-    if (B.gen) g_conv_d(m, B.d2, N, B.H2, B.w2, P(m, B.b2), add, B.OUT, st);
-    else g_conv_f(m, B.d2, N, B.H2, B.w2, P(m, B.b2), add, B.OUT, st);
+    if (B.gen) g_conv_d(m, B.d2, N, H2, B.w2, P(m, B.b2), add, OUT, st);
+    else g_conv_f(m, B.d2, N, H2, B.w2, P(m, B.b2), add, OUT, st);
 }
 
 struct RbBwd {
@@ -1451,7 +1468,9 @@ struct RbBwd {
     int ntail;
     bool store_v;             // pass B: keep d / d(norm output) for the adjoint pass
     int inj_lo;               // >= 0: add the second-order injections to samples [inj_lo, inj_lo + ntail)
+    bool lnpart;              // data chain of one pass at out_off that still leaves its LayerNorm parameter partials (slots from out_off)
 };
+void rb_param_grads(uad_gan* m, RB& B, int M, int Nb, hipStream_t st);
 void rb_backward(uad_gan* m, RB& B, const RbBwd& a, hipStream_t st) {
     const int HW = B.Hin * B.Hin, N = a.N;
     const float* dout = B.DOUT + a.out_off * B.sout;
@@ -1462,7 +1481,7 @@ void rb_backward(uad_gan* m, RB& B, const RbBwd& a, hipStream_t st) {
     LnBwdArgs l;
     memset(&l, 0, sizeof l);
     l.da = m->s_ta; l.c = B.C1 + a.in_off * B.sc1; l.stats = B.ST2 + a.in_off * 2 * B.Cout; l.gamma = P(m, B.ln2g); l.beta = P(m, B.ln2b);
-    l.alpha = 0.0f; l.HW = HW; l.C = B.Cout; l.dc = g1; l.v_out = a.store_v ? B.V2 : nullptr; l.gpart = a.pg ? B.LP2 : nullptr;
+    l.alpha = 0.0f; l.HW = HW; l.C = B.Cout; l.dc = g1; l.v_out = a.store_v ? B.V2 : nullptr; l.gpart = (a.pg || a.lnpart) ? B.LP2 : nullptr; l.slot0 = a.lnpart ? (int)a.out_off : 0;
     if (a.inj_lo >= 0) { l.add = B.INJC1; l.add_lo = a.inj_lo; l.add_hi = a.inj_lo + a.ntail; }
     ln_bwd(l, N, st);
     g_conv_d(m, B.d1, N, g1, B.w1, nullptr, nullptr, m->s_tb, st);
@@ -1478,12 +1497,16 @@ void rb_backward(uad_gan* m, RB& B, const RbBwd& a, hipStream_t st) {
     }
     memset(&l, 0, sizeof l);
     l.da = m->s_tb; l.c = B.X + a.in_off * B.sx; l.stats = B.ST1 + a.in_off * 2 * B.Cin; l.gamma = P(m, B.ln1g); l.beta = P(m, B.ln1b);
-    l.alpha = 0.0f; l.HW = HW; l.C = B.Cin; l.dc = dx; l.v_out = a.store_v ? B.V1 : nullptr; l.gpart = a.pg ? B.LP1 : nullptr;
+    l.alpha = 0.0f; l.HW = HW; l.C = B.Cin; l.dc = dx; l.v_out = a.store_v ? B.V1 : nullptr; l.gpart = (a.pg || a.lnpart) ? B.LP1 : nullptr; l.slot0 = a.lnpart ? (int)a.out_off : 0;
     l.add = addp; l.add_lo = 0; l.add_hi = N;
     if (a.inj_lo >= 0) { l.add2 = B.INJX; l.add2_lo = a.inj_lo; l.add2_hi = a.inj_lo + a.ntail; }
     ln_bwd(l, N, st);
     if (!a.pg) return;
-    const int M = N + a.ntail;
+    rb_param_grads(m, B, N + a.ntail, N, st);
+}
+// parameter gradients of a block over the first M samples of its buffers (bias column sums over the first Nb)
+void rb_param_grads(uad_gan* m, RB& B, int M, int Nb, hipStream_t st) {
+    const int HW = B.Hin * B.Hin, N = Nb;
     uad_launch_reduce_partials(B.LP2, M * (B.Cout / 32), 2 * HW, 1.0f, Gr(m, B.ln2g), st);
     uad_launch_reduce_partials(B.LP1, M * (B.Cin / 32), 2 * HW, 1.0f, Gr(m, B.ln1g), st);
     if (B.gen) g_conv_w(m, B.d2, M, B.DOUT, B.H2, B.w2, st); else g_conv_w(m, B.d2, M, B.H2, B.DOUT, B.w2, st);
@@ -1547,20 +1570,21 @@ void s_enc_backward(uad_gan* m, const float* x, int n, hipStream_t st) {
         if (i > 0) conv_dgrad(m, m->E[i], n, gn, g, st);
     }
 }
-void s_gen_forward(uad_gan* m, const float* z, int n, hipStream_t st) {
+void s_gen_forward(uad_gan* m, const float* z, int n, hipStream_t st, bool linear = false) {
     const int flatg = m->cfg.inter_res * m->cfg.inter_res * 8 * m->dim;
     uad_launch_conv_f(dense_desc(n, m->cfg.zdim, flatg), z, no_xform(), P(m, m->g_dw), m->s_g0, epi_bias(P(m, m->g_db)), st, nullptr, m->ws);
     for (auto& B : m->GB) rb_forward(m, B, n, st);
     const RB& L = m->GB.back();
     ln_fwd(L.OUT, P(m, m->s_glg), P(m, m->s_glb), 0.0f, n, L.Hout * L.Hout, L.Cout, m->s_hf, m->s_stf, st);
-    rowdot<2>(m->s_hf, P(m, m->g_fw), P(m, m->g_fb), n * L.Hout * L.Hout, L.Cout, m->xg, st);
+    if (linear) rowdot<0>(m->s_hf, P(m, m->g_fw), P(m, m->g_fb), n * L.Hout * L.Hout, L.Cout, m->xg, st);
+    else rowdot<2>(m->s_hf, P(m, m->g_fw), P(m, m->g_fb), n * L.Hout * L.Hout, L.Cout, m->xg, st);
 }
-void s_gen_backward(uad_gan* m, const float* z, const float* dx, int n, bool pg, float* dz_out, hipStream_t st) {
+void s_gen_backward(uad_gan* m, const float* z, const float* dx, int n, bool pg, float* dz_out, hipStream_t st, bool linear = false) {
     RB& L = m->GB.back();
     const int rows = n * L.Hout * L.Hout, HW = L.Hout * L.Hout;
     {
         const int rpb = (rows + 1023) / 1024, blocks = (rows + rpb - 1) / rpb;
-        hipLaunchKernelGGL(gfinal_bwd_kernel, dim3(blocks), dim3(256), 0, st, dx, m->xg, m->s_hf, P(m, m->g_fw), rows, rpb, L.Cout, 1, m->Ga,
+        hipLaunchKernelGGL(gfinal_bwd_kernel, dim3(blocks), dim3(256), 0, st, dx, m->xg, m->s_hf, P(m, m->g_fw), rows, rpb, L.Cout, linear ? 2 : 1, m->Ga,
                            pg ? m->finpart : nullptr);
         if (pg) {
             uad_launch_reduce_partials(m->finpart, blocks, L.Cout + 1, 1.0f, m->colscratch, st);
@@ -1606,6 +1630,50 @@ void s_disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float
     if (dx_out) { d0.N = N; uad_launch_conv_first_dgrad_plain(d0, m->s_dout0, P(m, m->s_d0w), dx_out, st); }
 }
 
+
+// ================================================================================================ constrained AAE on residual blocks (aae_kind 7)
+// models/constrained_adversarial_autoencoder_Chen.py:11-162 under trainers/ConstrainedAAE.py:44-70.  Encoder = the ResNet graph's critic
+// stack (k3 conv + four blocks, DB) + Dense(zDim); decoder = its generator stack (Dense + four blocks, GB) with a linear 1x1 output; the
+// phases are the AAE family's (aae_phase): these five functions are its encoder / decoder hooks.  The encoder buffers hold both passes
+// ([x ; x_hat], 2n samples); each pass runs its own data-gradient chain, the parameter gradients are ONE launch per tensor over both.
+void c_encode(uad_gan* m, const float* x, int n, int off, hipStream_t st) {
+    const size_t HW = (size_t)m->cfg.height * m->cfg.height;
+    float* din = m->din + (size_t)off * HW;
+    (void)hipMemcpyAsync(din, x, (size_t)n * HW * sizeof(float), hipMemcpyDeviceToDevice, st);
+    UadConvDesc d0 = m->s_d0; d0.N = n;
+    uad_launch_conv_first_fwd(d0, din, P(m, m->s_d0w), P(m, m->s_d0b), m->s_out0 + (size_t)off * HW * m->dim, st);
+    for (auto& B : m->DB) rb_forward(m, B, n, st, (size_t)off);
+    const RB& L = m->DB.back();
+    uad_launch_conv_f(dense_desc(n, m->flat, m->cfg.zdim), L.OUT + (size_t)off * L.sout, no_xform(), P(m, m->e_dw), m->a_zm + (size_t)off * m->cfg.zdim,
+                      epi_bias(P(m, m->e_db)), st, nullptr, m->ws);
+}
+void c_encode_backward(uad_gan* m, const float* dz, int n, int off, float* dx_out, hipStream_t st) {
+    const int zd = m->cfg.zdim;
+    const size_t HW = (size_t)m->cfg.height * m->cfg.height;
+    (void)hipMemcpyAsync(m->a_dzm + (size_t)off * zd, dz, (size_t)n * zd * sizeof(float), hipMemcpyDeviceToDevice, st);
+    RB& L = m->DB.back();
+    uad_launch_conv_d(dense_desc(n, m->flat, zd), dz, no_xform(), P(m, m->e_dw), L.DOUT + (size_t)off * L.sout, epi_bias(nullptr), st, nullptr, m->ws);
+    RbBwd a{n, (size_t)off, (size_t)off, false, 0, false, -1, true};
+    for (int k = (int)m->DB.size() - 1; k >= 0; --k) rb_backward(m, m->DB[k], a, st);
+    if (dx_out) {
+        UadConvDesc d0 = m->s_d0; d0.N = n;
+        uad_launch_conv_first_dgrad_plain(d0, m->s_dout0 + (size_t)off * HW * m->dim, P(m, m->s_d0w), dx_out, st);
+    }
+}
+void c_encode_wgrads(uad_gan* m, int nall, hipStream_t st) {
+    const int zd = m->cfg.zdim;
+    RB& L = m->DB.back();
+    uad_launch_conv_w(dense_desc(nall, m->flat, zd), L.OUT, no_xform(), m->a_dzm, no_xform(), Gr(m, m->e_dw), m->wpartial, st);
+    uad_launch_colsum(m->a_dzm, nall, zd, Gr(m, m->e_db), m->colscratch, st);
+    for (auto& B : m->DB) rb_param_grads(m, B, nall, nall, st);
+    UadConvDesc d0 = m->s_d0; d0.N = nall;
+    uad_launch_conv_first_wgrad(d0, m->din, m->s_dout0, Gr(m, m->s_d0w), m->wpartial, st);
+    uad_launch_colsum(m->s_dout0, nall * d0.HS * d0.WS, d0.CS, Gr(m, m->s_d0b), m->colscratch, st);
+}
+void c_decode(uad_gan* m, const float* z, int n, hipStream_t st) { s_gen_forward(m, z, n, st, true); }
+void c_decode_backward(uad_gan* m, const float* z, const float* dxh, int n, float* dz_out, bool pg, hipStream_t st) {
+    s_gen_backward(m, z, dxh, n, pg, dz_out, st, true);
+}
 
 // ================================================================================================ Zimmerer VAE (aae_kind 4)
 // models/variational_autoencoder_Zimmerer.py:7-32 under trainers/VAE.py:36-42.  Every k4 contraction with >= 4 channels on both sides runs
@@ -2379,11 +2447,166 @@ static int create_you(const uad_gan_config_t* cfg, uad_gan_t** out) {
     return UAD_OK;
 }
 
+
+static int create_chen(const uad_gan_config_t* cfg, uad_gan_t** out) {
+    const int H = cfg->height, ir = cfg->inter_res, dim = cfg->dim > 0 ? cfg->dim : 64, zd = cfg->zdim;
+    if (H != 8 * ir) return fail(UAD_ERR_UNSUPPORTED, "constrained AAE (Chen): three stride-2 blocks, height must be 8 * inter_res");
+    if (dim % 32 || dim > 64) return fail(UAD_ERR_UNSUPPORTED, "constrained AAE (Chen): dim must be 32 or 64");
+    if (ir < 2) return fail(UAD_ERR_UNSUPPORTED, "inter_res >= 2 needed");
+    if (zd > kCritMaxZ) return fail(UAD_ERR_UNSUPPORTED, "zDim <= %d", kCritMaxZ);
+    uad_gan* m = new uad_gan();
+    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->aae_kind = 7; m->chen = true; m->dim = dim; m->generic16 = false; m->e_sw = m->e_sb = -1;
+    m->a_constrained = true; m->a_critic = true; m->a_h1 = 400; m->a_h2 = 200;
+    m->npool = 3; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = true;
+    m->step[0] = m->step[1] = m->step[2] = 0;
+    char nm[160];
+    int ln = 0;
+    std::map<std::string, int> cnt;
+    auto ln_name = [&](const char* scope) { std::string r = std::string(scope) + (ln == 0 ? "layer_normalization" : "layer_normalization_" + std::to_string(ln)); ++ln; return r; };
+    auto tf_name = [&](const char* scope, const char* base) {
+        const std::string key = std::string(scope) + base;
+        const int k = cnt[key]++;
+        return k == 0 ? key : key + "_" + std::to_string(k);
+    };
+    auto make_block = [&](bool gen, const char* scope, int Hin, int Cin, int Cout, int stride) {
+        RB B;
+        memset(&B, 0, sizeof B);
+        B.gen = gen; B.stride = stride; B.Hin = Hin; B.Cin = Cin; B.Cout = Cout;
+        B.Hout = gen ? Hin * stride : Hin / stride;
+        std::string s1 = ln_name(scope);
+        B.ln1g = add_tensor(m, s1 + "/gamma", 2, Hin, Hin, 1, 1); B.ln1b = add_tensor(m, s1 + "/beta", 2, Hin, Hin, 1, 1);
+        std::string c1 = tf_name(scope, "conv2d");
+        B.w1 = add_tensor(m, c1 + "/kernel", 4, 3, 3, Cin, Cout); B.b1 = add_tensor(m, c1 + "/bias", 1, Cout, 1, 1, 1);
+        std::string s2 = ln_name(scope);
+        B.ln2g = add_tensor(m, s2 + "/gamma", 2, Hin, Hin, 1, 1); B.ln2b = add_tensor(m, s2 + "/beta", 2, Hin, Hin, 1, 1);
+        std::string c2 = tf_name(scope, gen ? "conv2d_transpose" : "conv2d");
+        B.w2 = add_tensor(m, c2 + "/kernel", 4, 3, 3, Cout, Cout); B.b2 = add_tensor(m, c2 + "/bias", 1, Cout, 1, 1, 1);
+        B.ws = B.bs = -1;
+        if (stride == 2) {
+            std::string sh = tf_name(scope, gen ? "conv2d_transpose" : "conv2d");
+            if (gen) B.ws = add_tensor(m, sh + "/kernel", 4, 1, 1, Cout, Cin); else B.ws = add_tensor(m, sh + "/kernel", 4, 1, 1, Cin, Cout);
+            B.bs = add_tensor(m, sh + "/bias", 1, Cout, 1, 1, 1);
+        }
+        B.d1 = UadConvDesc{1, Hin, Hin, Cin, Hin, Hin, Cout, 3, 1, 1};
+        const int P2 = stride == 1 ? 1 : 0;
+        if (gen) {
+            B.d2 = UadConvDesc{1, B.Hout, B.Hout, Cout, Hin, Hin, Cout, 3, stride, P2};
+            B.ds = UadConvDesc{1, B.Hout, B.Hout, Cout, Hin, Hin, Cin, 1, 2, 0};
+        } else {
+            B.d2 = UadConvDesc{1, Hin, Hin, Cout, B.Hout, B.Hout, Cout, 3, stride, P2};
+            B.ds = UadConvDesc{1, Hin, Hin, Cin, Hin, Hin, Cout, 1, 1, 0};
+        }
+        B.sx = (size_t)Hin * Hin * Cin; B.sc1 = (size_t)Hin * Hin * Cout; B.sout = (size_t)B.Hout * B.Hout * Cout;
+        return B;
+    };
+    // Encoder (:15-47, evaluate_encoder :128-151): conv2d, four blocks, dense
+    {
+        const std::string e0 = tf_name("Encoder/", "conv2d");
+        m->s_d0w = add_tensor(m, e0 + "/kernel", 4, 3, 3, 1, dim); m->s_d0b = add_tensor(m, e0 + "/bias", 1, dim, 1, 1, 1);
+        m->s_d0 = UadConvDesc{1, H, H, 1, H, H, dim, 3, 1, 1};
+        const int chans[4] = {2 * dim, 4 * dim, 8 * dim, 8 * dim}, strides[4] = {2, 2, 2, 1};
+        int c = dim, r = H;
+        for (int k = 0; k < 4; ++k) { m->DB.push_back(make_block(false, "Encoder/", r, c, chans[k], strides[k])); c = chans[k]; r /= strides[k]; }
+    }
+    const int flatg = ir * ir * 8 * dim;
+    m->flat = flatg; m->cenc = 8 * dim; m->cmid = 0;
+    m->e_cw = m->e_cb = -1;
+    m->e_dw = add_tensor(m, "Encoder/dense/kernel", 2, flatg, zd, 1, 1); m->e_db = add_tensor(m, "Encoder/dense/bias", 1, zd, 1, 1, 1);
+    const long long enc_end = m->nparams;
+    // Decoder (:49-83, evaluate_decoder :154-170)
+    m->g_dw = add_tensor(m, "Decoder/dense/kernel", 2, zd, flatg, 1, 1); m->g_db = add_tensor(m, "Decoder/dense/bias", 1, flatg, 1, 1, 1);
+    m->g_cw = m->g_cb = m->g_ln0g = m->g_ln0b = -1;
+    {
+        const int chans[4] = {8 * dim, 4 * dim, 2 * dim, dim}, strides[4] = {1, 2, 2, 2};
+        int c = 8 * dim, r = ir;
+        for (int k = 0; k < 4; ++k) { m->GB.push_back(make_block(true, "Decoder/", r, c, chans[k], strides[k])); c = chans[k]; r *= strides[k]; }
+        const std::string sl = ln_name("Decoder/");
+        m->s_glg = add_tensor(m, sl + "/gamma", 2, r, r, 1, 1); m->s_glb = add_tensor(m, sl + "/beta", 2, r, r, 1, 1);
+        const std::string gf = tf_name("Decoder/", "conv2d");
+        m->g_fw = add_tensor(m, gf + "/kernel", 4, 1, 1, c, 1); m->g_fb = add_tensor(m, gf + "/bias", 1, 1, 1, 1, 1);
+    }
+    const long long ae_end = m->nparams;
+    m->a_w1 = add_tensor(m, "Discriminator/dense/kernel", 2, zd, m->a_h1, 1, 1); m->a_b1 = add_tensor(m, "Discriminator/dense/bias", 1, m->a_h1, 1, 1, 1);
+    m->a_w2 = add_tensor(m, "Discriminator/dense_1/kernel", 2, m->a_h1, m->a_h2, 1, 1); m->a_b2 = add_tensor(m, "Discriminator/dense_1/bias", 1, m->a_h2, 1, 1, 1);
+    m->a_w3 = add_tensor(m, "Discriminator/dense_2/kernel", 2, m->a_h2, 1, 1, 1); m->a_b3 = add_tensor(m, "Discriminator/dense_2/bias", 1, 1, 1, 1, 1);
+    m->a_nd = m->nparams - ae_end;
+    m->grp_off[0] = 0; m->grp_cnt[0] = enc_end;          // optim_gen: 'Encoder' in var.name
+    m->grp_off[1] = 0; m->grp_cnt[1] = ae_end;           // optim_ae
+    m->grp_off[2] = ae_end; m->grp_cnt[2] = m->nparams - ae_end;
+
+    const size_t NB = (size_t)cfg->max_batch, E2 = 2 * NB, HW = (size_t)H * H;
+    int rc = UAD_OK;
+#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
+    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
+    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
+    ALLOC(m->adam_m2, (size_t)m->nparams, nullptr); ALLOC(m->adam_v2, (size_t)m->nparams, nullptr);
+    m->wpack_f = m->wpack_d = m->wpack16_f = m->wpack16_d = nullptr;
+    size_t maxact = NB * HW * dim, max_ta = 0, max_tb = 0, max_sp = 0;
+    auto alloc_block = [&](RB& B, float* X, float* DX, size_t cap, const char* tag, int k) {
+        B.X = X; B.DX = DX;
+        snprintf(nm, sizeof nm, "%s_h1_%d", tag, k); ALLOC(B.H1, cap * B.sx, nm);
+        snprintf(nm, sizeof nm, "%s_c1_%d", tag, k); ALLOC(B.C1, cap * B.sc1, nm);
+        snprintf(nm, sizeof nm, "%s_h2_%d", tag, k); ALLOC(B.H2, cap * B.sc1, nm);
+        snprintf(nm, sizeof nm, "%s_out_%d", tag, k); ALLOC(B.OUT, cap * B.sout, nm);
+        ALLOC(B.ST1, cap * 2 * B.Cin, nullptr); ALLOC(B.ST2, cap * 2 * B.Cout, nullptr);
+        ALLOC(B.DOUT, cap * B.sout, nullptr); ALLOC(B.G1, cap * B.sc1, nullptr);
+        if (!B.gen && B.ws >= 0) ALLOC(B.DSC, cap * B.sc1, nullptr);
+        ALLOC(B.LP1, cap * (B.Cin / 32) * 2 * B.Hin * B.Hin, nullptr);
+        ALLOC(B.LP2, cap * (B.Cout / 32) * 2 * B.Hin * B.Hin, nullptr);
+        if (NB * B.sc1 > max_ta) max_ta = NB * B.sc1;
+        if (NB * B.sx > max_tb) max_tb = NB * B.sx;
+        if (NB * B.sout > max_sp) max_sp = NB * B.sout;
+    };
+    ALLOC(m->din, E2 * HW, "din");
+    ALLOC(m->s_out0, E2 * HW * dim, "sd_out0"); ALLOC(m->s_dout0, E2 * HW * dim, nullptr);
+    {
+        float* X = m->s_out0; float* DX = m->s_dout0;
+        for (size_t k = 0; k < m->DB.size(); ++k) { alloc_block(m->DB[k], X, DX, E2, "sd", (int)k); X = m->DB[k].OUT; DX = m->DB[k].DOUT; }
+    }
+    ALLOC(m->s_g0, NB * flatg, "sg_x0"); ALLOC(m->s_dg0, NB * flatg, nullptr);
+    size_t lnp_g = 0;
+    {
+        float* X = m->s_g0; float* DX = m->s_dg0;
+        for (size_t k = 0; k < m->GB.size(); ++k) { alloc_block(m->GB[k], X, DX, NB, "sg", (int)k); X = m->GB[k].OUT; DX = m->GB[k].DOUT; }
+        const RB& L = m->GB.back();
+        ALLOC(m->s_hf, NB * L.sout, "sg_hf"); ALLOC(m->s_stf, NB * 2 * L.Cout, nullptr);
+        lnp_g = NB * (L.Cout / 32) * 2 * L.Hout * L.Hout;
+        if (NB * L.sout > maxact) maxact = NB * L.sout;
+    }
+    ALLOC(m->lnpart_g, lnp_g, nullptr);
+    ALLOC(m->s_ta, max_ta, nullptr); ALLOC(m->s_tb, max_tb, nullptr); ALLOC(m->s_sp, max_sp, nullptr); ALLOC(m->s_sct, max_ta, nullptr);
+    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
+    ALLOC(m->xg, NB * HW, "xg"); ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->Gx, NB * HW, "Gx"); ALLOC(m->a_xcat, E2 * HW, nullptr);
+    ALLOC(m->a_zm, E2 * zd, "z"); ALLOC(m->a_dzm, E2 * zd, nullptr); ALLOC(m->dzbuf, NB * zd, "dz"); ALLOC(m->dzr, NB * zd, nullptr);
+    ALLOC(m->a_slab, NB * (size_t)m->a_nd, nullptr); for (int k = 0; k < 3; ++k) ALLOC(m->a_crit[k], NB, nullptr);
+    {
+        size_t wp = 0, need = (size_t)4 << 20;
+        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
+        auto want = [&](UadConvDesc d, size_t n) { d.N = (int)n; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, false); if (v > need) need = v; } };
+        for (auto& B : m->GB) { wp_need(B.d1, NB); wp_need(B.d2, NB); want(B.d1, NB); want(B.d2, NB); if (B.ws >= 0) { wp_need(B.ds, NB); want(B.ds, NB); } }
+        for (auto& B : m->DB) { wp_need(B.d1, E2); wp_need(B.d2, E2); want(B.d1, NB); want(B.d2, NB); if (B.ws >= 0) { wp_need(B.ds, E2); want(B.ds, NB); } }
+        wp_need(dense_desc(1, flatg, zd), E2); wp_need(dense_desc(1, zd, flatg), NB);
+        want(dense_desc(1, flatg, zd), NB); want(dense_desc(1, zd, flatg), NB);
+        { UadConvDesc d0 = m->s_d0; d0.N = (int)E2; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
+        ALLOC(m->wpartial, wp, nullptr);
+        m->ws.floats = need; m->ws.ptr = nullptr;
+        ALLOC(m->ws.ptr, need, nullptr);
+    }
+    ALLOC(m->colscratch, 64 * 1024, nullptr); ALLOC(m->colpart, (size_t)kBnBwdBlocks * 2 * 128, nullptr);
+    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
+    ALLOC(m->finpart, (size_t)1024 * 520, nullptr);
+#undef ALLOC
+    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
+    *out = m;
+    return UAD_OK;
+}
+
 static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
     const int H = cfg->height, ir = cfg->inter_res;
     if (cfg->aae_kind == 4 || cfg->aae_kind == 5) return create_zimmerer(cfg, out);
     if (cfg->aae_kind == 6) return create_you(cfg, out);
-    if (cfg->aae_kind < 0 || cfg->aae_kind > 6) return fail(UAD_ERR_INVALID, "bad aae_kind");
+    if (cfg->aae_kind == 7) return create_chen(cfg, out);
+    if (cfg->aae_kind < 0 || cfg->aae_kind > 7) return fail(UAD_ERR_INVALID, "bad aae_kind");
     const bool gmv = cfg->aae_kind == 3;
     if (gmv) {
         const long long q = (long long)cfg->zdim * cfg->dim;

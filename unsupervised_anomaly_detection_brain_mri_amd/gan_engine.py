@@ -24,7 +24,7 @@ class GanEngine(_EvalOps):
         torch.cuda.set_device(self.device)
         self.h, self.w, self.c, self.inter, self.zdim, self.max_batch = height, width, channels, inter_res, zdim, max_batch
         variants = {'unified': _lib.GAN_UNIFIED, 'resnet': _lib.GAN_RESNET, 'anovaegan': _lib.GAN_ANOVAEGAN, 'aae': _lib.GAN_AAE}
-        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2, 'gmvae': 3, 'vae_zimmerer': 4, 'cevae_zimmerer': 5, 'gmvae_you': 6}     # 'gmvae': zdim = dim_z, dim = dim_c, dim_w, c_lambda
+        kinds = {'constrained_ae': 0, 'aae': 1, 'constrained_aae': 2, 'gmvae': 3, 'vae_zimmerer': 4, 'cevae_zimmerer': 5, 'gmvae_you': 6, 'caae_chen': 7}     # 'gmvae': zdim = dim_z, dim = dim_c, dim_w, c_lambda
         if variant == 'aae' and aae_kind not in kinds:
             raise ValueError(f'unknown aae_kind {aae_kind!r}')
         self.aae_kind = aae_kind if variant == 'aae' else None
@@ -45,7 +45,7 @@ class GanEngine(_EvalOps):
             _lib.check(self.lib.uad_gan_tensor_info(h, i, name, 160, C.byref(off), C.byref(rank), shape))
             self.spec.append((name.value.decode(), tuple(shape[:rank.value]), int(off.value)))
         dec_dense = {'constrained_ae': 'Bottleneck/dense_1/kernel', 'aae': 'Bottleneck/dense_1/kernel', 'constrained_aae': 'Decoder/dense/kernel',
-                     'gmvae': 'Bottleneck/dense_4/kernel', 'vae_zimmerer': 'dense_2/kernel', 'cevae_zimmerer': 'Bottleneck/dense_2/kernel'}
+                     'gmvae': 'Bottleneck/dense_4/kernel', 'vae_zimmerer': 'dense_2/kernel', 'cevae_zimmerer': 'Bottleneck/dense_2/kernel', 'caae_chen': 'Decoder/dense/kernel'}
         if variant == 'aae' and aae_kind == 'gmvae_you':        # fully convolutional: no dense decoder input
             self.flat = None
         else:
