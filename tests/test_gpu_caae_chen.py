@@ -102,3 +102,41 @@ def test_caae_chen_phases(h, zd, dim, n):
     rec = eng.reconstruct(x)['reconstruction'].cpu().numpy()
     assert_close(rec, m.reconstruct(p64, x64), tol=2e-4, name='reconstruct')
     eng.close()
+
+
+def test_caae_chen_trainer(tmp_path):
+    """`ConstrainedAAE(sess, config, network=constrained_adversarial_autoencoder_Chen)`: fetch keys, the three optimisers' loop, resume."""
+    from unsupervised_anomaly_detection_brain_mri_amd.models import constrained_adversarial_autoencoder_Chen as net
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import ConstrainedAAE, Phase
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_config, get_options
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset
+    h = 32
+    opt_ = get_options(batchsize=4, learningrate=1e-4, numEpochs=2, zDim=16, outputWidth=h, outputHeight=h,
+                       config={'CHECKPOINTDIR': str(tmp_path / 'ck'), 'SAMPLEDIR': str(tmp_path / 'smp')})
+    ds = SyntheticDataset(8, 8, h, h, seed=0)
+    cfg = get_config(ConstrainedAAE, opt_, 'ADAM', [4, 4], 0.2, ds)
+    model = ConstrainedAAE(None, cfg, network=net)
+    model.D_ITERS = 2
+    assert model.KIND == 'caae_chen' and 'constrained_adversarial_autoencoder_Chen' in model.model_dir
+    names = [nm for nm, _, _ in model.engine.spec]
+    assert names[0] == 'Encoder/conv2d/kernel' and 'Decoder/layer_normalization_16/gamma' in names and names[-1] == 'Discriminator/dense_2/bias'
+    x = ds.next_batch(4, set='VAL')[0]
+    run = model.step(x, Phase.VAL)
+    assert set(run) == {'loss', 'L2', 'Rec_z', 'reconstructionLoss', 'reconstruction', 'L1'}
+    d = model.discriminator_step(x)
+    assert set(d) == {'disc_loss', 'disc_fake', 'disc_real'} and np.isfinite(list(d.values())).all()
+    g = model.generator_step(x)
+    assert set(g) == {'gen_loss'} and np.isfinite(g['gen_loss'])
+    model.train(ds)
+    assert len(model.curves['TRAIN/reconstructionLoss']) == 2 and np.isfinite(model.curves['VAL/reconstructionLoss']).all()
+    w = model.engine.get_buffer_host(_lib.BUF_PARAMS)                       # what the epoch-2 checkpoint holds
+    steps = [model.engine.step_count(gname) for gname in model.GROUPS]
+    losses = [float(model.step(x, Phase.TRAIN, fetch_maps=False)['loss']) for _ in range(15)]      # optim_ae alone brings its objective down
+    assert losses[-1] < losses[0]
+    r = model.reconstruct(x[0])
+    assert r['reconstruction'].shape == (1, h, h, 1)
+    model.engine.close()
+    m2 = ConstrainedAAE(None, cfg, network=net, seed=5)
+    assert m2.load_checkpoint() == 2
+    assert np.array_equal(m2.engine.get_buffer_host(_lib.BUF_PARAMS), w) and [m2.engine.step_count(gname) for gname in m2.GROUPS] == steps
+    m2.engine.close()

@@ -79,6 +79,14 @@ for math in ('f32', 'bf16x3_all'):
                                           'forward': timed(lambda: eng.gm_phase(x, ew, ez, want_backward=False, want_l1=False), reps=10),
                                           'restore_step': timed(lambda: eng.gm_restore_step(xr, ew, ez), reps=10)}
     eng.close()
+eng = GanEngine(64, 64, 1, 8, 128, max_batch=32, variant='aae', aae_kind='caae_chen', dim=64, math='f32')
+init(eng)
+x64 = torch.from_numpy(synthetic_slices(32, 64, 64, seed=1)).cuda()
+z32 = torch.randn(32, 128, device='cuda', generator=g); e32 = torch.full((32,), 0.3, device='cuda')
+res['caae_chen_64_b32_f32_ms'] = {'AE': timed(lambda: (eng.aae_phase('AE', x64, want_images=False), eng.adam('AE', 1e-4)), reps=5),
+                                  'Discriminator': timed(lambda: (eng.aae_phase('Discriminator', x64, z=z32, eps=e32), eng.adam('Discriminator', 1e-4)), reps=5),
+                                  'Encoder(gen)': timed(lambda: (eng.aae_phase('Encoder', x64), eng.adam('Encoder', 1e-4)), reps=5)}
+eng.close()
 # hipGraph replay (uad_gan_set_graph_mode) vs plain launches: one f-AnoGAN WGAN iteration (1 generator + 5 critic phases) + encoder step
 for (variant, h, bs) in (('unified', 64, 64), ('unified', 128, 64)):
     row = {}

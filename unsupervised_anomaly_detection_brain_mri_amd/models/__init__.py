@@ -16,3 +16,4 @@ from .gaussian_mixture_variational_autoencoder import gaussian_mixture_variation
 from .variational_autoencoder_Zimmerer import variational_autoencoder_Zimmerer  # noqa: F401
 from .context_encoder_variational_autoencoder_Zimmerer import context_encoder_variational_autoencoder_Zimmerer  # noqa: F401
 from .gaussian_mixture_variational_autoencoder_You import gaussian_mixture_variational_autoencoder_You  # noqa: F401
+from .constrained_adversarial_autoencoder_Chen import constrained_adversarial_autoencoder_Chen  # noqa: F401

@@ -42,6 +42,8 @@ class _LatentAE(AEMODEL):
     def _masks(self, n, train):
         """dropout masks of z_, dec_dense and z_rec.  In constrained_adversarial_autoencoder.py the last two Dropout calls carry no
         `training=` (:35,47) and are therefore never active."""
+        if self.KIND == 'caae_chen':                 # models/constrained_adversarial_autoencoder_Chen.py has no Dropout layer
+            return dict(mask_z=None, mask_dec=None, mask_rec=None)
         both = self.KIND != 'constrained_aae'
         return dict(mask_z=self._keep((n, self.config.zDim), train), mask_dec=self._keep((n, self.engine.flat), train and both),
                     mask_rec=self._keep((n, self.config.zDim), train and both and self.KIND == 'constrained_ae'))
@@ -76,13 +78,17 @@ class _LatentAE(AEMODEL):
     def discriminator_step(self, batch, z=None, eps=None, mask_z=None):
         n = len(batch)
         z = self.sample_z(n) if z is None else z
-        eps = self.rng.uniform(0.0, 1.0, (n,)).astype(np.float32) if eps is None else eps
+        if eps is None:      # one coefficient per sample; ..._Chen.py:118 draws ONE scalar per run (tf.random_uniform([]))
+            eps = (np.full((n,), self.rng.uniform(0.0, 1.0), np.float32) if self.KIND == 'caae_chen'
+                   else self.rng.uniform(0.0, 1.0, (n,)).astype(np.float32))
+        chen = self.KIND == 'caae_chen'
         out = self._phase('Discriminator', self.config.learningrate, x=batch, z=z, eps=eps,
-                          mask_z=self._keep((n, self.config.zDim), True) if mask_z is None else mask_z)
+                          mask_z=None if chen else (self._keep((n, self.config.zDim), True) if mask_z is None else mask_z))
         return {k: np.float32(out[k].item()) for k in ('disc_loss', 'disc_fake', 'disc_real')}
 
     def generator_step(self, batch, mask_z=None):
-        out = self._phase('Encoder', self.config.learningrate, x=batch, mask_z=self._keep((len(batch), self.config.zDim), True) if mask_z is None else mask_z)
+        out = self._phase('Encoder', self.config.learningrate, x=batch,
+                          mask_z=None if self.KIND == 'caae_chen' else (self._keep((len(batch), self.config.zDim), True) if mask_z is None else mask_z))
         return {'gen_loss': np.float32(out['gen_loss'].item())}
 
     # ------------------------------------------------------------------ epoch loops
