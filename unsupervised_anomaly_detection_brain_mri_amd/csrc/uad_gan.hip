@@ -38,626 +38,7 @@ constexpr float kBnEps = 1e-3f;     // tf.layers.BatchNormalization default epsi
 constexpr float kLnEps = 1e-3f;     // keras LayerNormalization default epsilon
 constexpr float kLrelu = 0.3f;      // keras LeakyReLU() default
 
-// ================================================================================================ LayerNorm over (H, W)
-// One workgroup per (sample, 32-channel group): PL pixel lanes x 8 channel quads (float4 = 16-byte NHWC accesses); PL = 128
-// (1024 threads) for the large maps, 32 for the small ones.  Per-channel sums are folded through LDS in a fixed order.
-template <int PL>
-__device__ __forceinline__ float4 chan_reduce(float4 v, float (*red)[36], int pl, int cq) {
-    red[pl][cq * 4 + 0] = v.x; red[pl][cq * 4 + 1] = v.y; red[pl][cq * 4 + 2] = v.z; red[pl][cq * 4 + 3] = v.w;
-    __syncthreads();
-#pragma unroll
-    for (int o = PL / 2; o > 0; o >>= 1) {
-        if (pl < o) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) red[pl][cq * 4 + k] += red[pl + o][cq * 4 + k];
-        }
-        __syncthreads();
-    }
-    const float4 r = make_float4(red[0][cq * 4 + 0], red[0][cq * 4 + 1], red[0][cq * 4 + 2], red[0][cq * 4 + 3]);
-    __syncthreads();
-    return r;
-}
-__device__ __forceinline__ float4 f4(float s) { return make_float4(s, s, s, s); }
-__device__ __forceinline__ float4 act_grad(float4 y, float4 g, float alpha) {
-    return make_float4(y.x > 0.f ? g.x : alpha * g.x, y.y > 0.f ? g.y : alpha * g.y, y.z > 0.f ? g.z : alpha * g.z,
-                       y.w > 0.f ? g.w : alpha * g.w);
-}
-__device__ __forceinline__ float hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
-__device__ __forceinline__ float quad8_sum(float v) {   // over the 8 channel-quad lanes of one pixel
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-    return v;
-}
-
-// a = act(gamma[p] * (c - mean) * rstd + beta[p]); stats[n][0][ch] = mean, stats[n][1][ch] = rstd.
-// Mean and variance come from ONE pass: sums of (c - k) and (c - k)^2 about the pivot k = the channel's first pixel, which lies
-// inside the data range, so var = E[(c-k)^2] - E[c-k]^2 loses no more than a few ulp (nn.moments itself is two-pass fp32).
-template <int PL>
-__global__ void __launch_bounds__(PL * 8) ln_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float alpha, int HW, int C,
-                                                        float* __restrict__ a, float* __restrict__ stats) {
-    __shared__ float red[PL][36];
-    const int n = blockIdx.y, cq = threadIdx.x & 7, pl = threadIdx.x >> 3, ch0 = blockIdx.x * 32 + cq * 4;
-    const size_t off = (size_t)n * HW * C + ch0;
-    const float4 piv = *reinterpret_cast<const float4*>(c + off);
-    float4 s = f4(0.f), q = f4(0.f);
-    for (int p = pl; p < HW; p += PL) {
-        const float4 d = *reinterpret_cast<const float4*>(c + off + (size_t)p * C) - piv;
-        s = s + d; q = q + d * d;
-    }
-    const float inv = 1.0f / (float)HW;
-    const float4 m1 = chan_reduce<PL>(s, red, pl, cq) * inv;
-    const float4 m2 = chan_reduce<PL>(q, red, pl, cq) * inv;
-    const float4 mean = piv + m1;
-    const float4 var = make_float4(fmaxf(m2.x - m1.x * m1.x, 0.f), fmaxf(m2.y - m1.y * m1.y, 0.f), fmaxf(m2.z - m1.z * m1.z, 0.f),
-                                   fmaxf(m2.w - m1.w * m1.w, 0.f));
-    const float4 r = make_float4(1.0f / sqrtf(var.x + kLnEps), 1.0f / sqrtf(var.y + kLnEps), 1.0f / sqrtf(var.z + kLnEps),
-                                 1.0f / sqrtf(var.w + kLnEps));
-    if (pl == 0) {
-        *reinterpret_cast<float4*>(stats + ((size_t)n * 2 + 0) * C + ch0) = mean;
-        *reinterpret_cast<float4*>(stats + ((size_t)n * 2 + 1) * C + ch0) = r;
-    }
-    for (int p = pl; p < HW; p += PL) {
-        const float4 xh = (*reinterpret_cast<const float4*>(c + off + (size_t)p * C) - mean) * r;
-        const float4 y = xh * gamma[p] + f4(beta[p]);
-        *reinterpret_cast<float4*>(a + off + (size_t)p * C) = act_grad(y, y, alpha);
-    }
-}
-
-struct LnBwdArgs {
-    const float* da;        // d / d activation output
-    const float* c;         // pre-norm tensor
-    const float* stats;
-    const float* gamma; const float* beta;
-    float alpha;
-    int HW, C;
-    const float* add;       // optional extra d / d c for samples [add_lo, add_hi), indexed from add_lo
-    int add_lo, add_hi;
-    const float* add2;      // a second one (residual blocks: shortcut gradient + second-order injection)
-    int add2_lo, add2_hi;
-    float* dc;
-    float* v_out;           // optional: d / d (norm output) = da * act'
-    float* gpart;           // optional [slot][2][HW]: per-pixel sums over the block's channels of dn*xhat, dn
-    int slot0;
-};
-template <int PL>
-__global__ void __launch_bounds__(PL * 8) ln_bwd_kernel(const LnBwdArgs A) {
-    __shared__ float red[PL][36];
-    const int n = blockIdx.y, cq = threadIdx.x & 7, pl = threadIdx.x >> 3, ch0 = blockIdx.x * 32 + cq * 4;
-    const int HW = A.HW, C = A.C;
-    const size_t off = (size_t)n * HW * C + ch0;
-    const float4 mean = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 0) * C + ch0);
-    const float4 r = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 1) * C + ch0);
-    const size_t slot = (size_t)(A.slot0 + n) * gridDim.x + blockIdx.x;
-    float4 sp = f4(0.f), spx = f4(0.f);
-    for (int p = pl; p < HW; p += PL) {
-        const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
-        const float g = A.gamma[p];
-        const float4 y = xh * g + f4(A.beta[p]);
-        const float4 dn = act_grad(y, *reinterpret_cast<const float4*>(A.da + off + (size_t)p * C), A.alpha);
-        const float4 pp = dn * g;
-        sp = sp + pp; spx = spx + pp * xh;
-        if (A.gpart) {
-            const float t1 = quad8_sum(hsum(dn * xh)), t2 = quad8_sum(hsum(dn));
-            if (cq == 0) { A.gpart[(slot * 2 + 0) * HW + p] = t1; A.gpart[(slot * 2 + 1) * HW + p] = t2; }
-        }
-    }
-    const float inv = 1.0f / (float)HW;
-    const float4 ep = chan_reduce<PL>(sp, red, pl, cq) * inv;
-    const float4 epx = chan_reduce<PL>(spx, red, pl, cq) * inv;
-    const bool has_add = A.add && n >= A.add_lo && n < A.add_hi;
-    const size_t aoff = has_add ? (size_t)(n - A.add_lo) * HW * C + ch0 : 0;
-    const bool has_add2 = A.add2 && n >= A.add2_lo && n < A.add2_hi;
-    const size_t aoff2 = has_add2 ? (size_t)(n - A.add2_lo) * HW * C + ch0 : 0;
-    for (int p = pl; p < HW; p += PL) {
-        const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
-        const float g = A.gamma[p];
-        const float4 y = xh * g + f4(A.beta[p]);
-        const float4 dn = act_grad(y, *reinterpret_cast<const float4*>(A.da + off + (size_t)p * C), A.alpha);
-        float4 dc = r * (dn * g - ep - xh * epx);
-        if (has_add) dc = dc + *reinterpret_cast<const float4*>(A.add + aoff + (size_t)p * C);
-        if (has_add2) dc = dc + *reinterpret_cast<const float4*>(A.add2 + aoff2 + (size_t)p * C);
-        *reinterpret_cast<float4*>(A.dc + off + (size_t)p * C) = dc;
-        if (A.v_out) *reinterpret_cast<float4*>(A.v_out + off + (size_t)p * C) = dn;
-    }
-}
-
-// Adjoint of (v, gamma, c) -> dc = r (p - E[p] - xh E[p xh]), p = v gamma:  given q = d P / d dc
-//   pbar  = r (q - E[q] - xh E[q xh])                       -> ubar = pbar * gamma * act'(y),  dgamma[p] += sum_ch pbar * v
-//   xhbar = -r (q E[p xh] + p E[q xh])
-//   cbar  = r (xhbar - E[xhbar] - xh E[xhbar xh]) - r E[q dc] xh
-struct LnBwd2Args {
-    const float* q; const float* v; const float* c; const float* stats; const float* gamma; const float* beta;
-    float alpha;
-    int HW, C;
-    float* ubar; float* inj; float* gpart;
-    int slot0;
-};
-template <int PL>
-__global__ void __launch_bounds__(PL * 8) ln_bwd2_kernel(const LnBwd2Args A) {
-    __shared__ float red[PL][36];
-    const int n = blockIdx.y, cq = threadIdx.x & 7, pl = threadIdx.x >> 3, ch0 = blockIdx.x * 32 + cq * 4;
-    const int HW = A.HW, C = A.C;
-    const size_t off = (size_t)n * HW * C + ch0;
-    const float4 mean = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 0) * C + ch0);
-    const float4 r = *reinterpret_cast<const float4*>(A.stats + ((size_t)n * 2 + 1) * C + ch0);
-    const size_t slot = (size_t)(A.slot0 + n) * gridDim.x + blockIdx.x;
-    float4 sp = f4(0.f), spx = f4(0.f), sq = f4(0.f), sqx = f4(0.f), sqp = f4(0.f);
-    for (int p = pl; p < HW; p += PL) {
-        const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
-        const float4 pp = *reinterpret_cast<const float4*>(A.v + off + (size_t)p * C) * A.gamma[p];
-        const float4 qq = *reinterpret_cast<const float4*>(A.q + off + (size_t)p * C);
-        sp = sp + pp; spx = spx + pp * xh; sq = sq + qq; sqx = sqx + qq * xh; sqp = sqp + qq * pp;
-    }
-    const float inv = 1.0f / (float)HW;
-    const float4 ep = chan_reduce<PL>(sp, red, pl, cq) * inv, epx = chan_reduce<PL>(spx, red, pl, cq) * inv;
-    const float4 eq = chan_reduce<PL>(sq, red, pl, cq) * inv, eqx = chan_reduce<PL>(sqx, red, pl, cq) * inv;
-    const float4 eqp = chan_reduce<PL>(sqp, red, pl, cq) * inv;
-    const float4 zero = f4(0.f);
-    const float4 e_xhbar = zero - r * (eq * epx + ep * eqx);
-    const float4 e_xhbar_xh = zero - r * (eqx * epx) * 2.0f;
-    const float4 e_qdc = r * (eqp - eq * ep - eqx * epx);
-    for (int p = pl; p < HW; p += PL) {
-        const float4 xh = (*reinterpret_cast<const float4*>(A.c + off + (size_t)p * C) - mean) * r;
-        const float g = A.gamma[p];
-        const float4 vv = *reinterpret_cast<const float4*>(A.v + off + (size_t)p * C);
-        const float4 pp = vv * g;
-        const float4 qq = *reinterpret_cast<const float4*>(A.q + off + (size_t)p * C);
-        const float4 pbar = r * (qq - eq - xh * eqx);
-        const float4 y = xh * g + f4(A.beta[p]);
-        *reinterpret_cast<float4*>(A.ubar + off + (size_t)p * C) = act_grad(y, pbar * g, A.alpha);
-        const float t1 = quad8_sum(hsum(pbar * vv));
-        if (cq == 0) { A.gpart[(slot * 2 + 0) * HW + p] = t1; A.gpart[(slot * 2 + 1) * HW + p] = 0.f; }
-        const float4 xhbar = zero - r * (qq * epx + pp * eqx);
-        *reinterpret_cast<float4*>(A.inj + off + (size_t)p * C) = r * (xhbar - e_xhbar - xh * e_xhbar_xh) - r * e_qdc * xh;
-    }
-}
-
-// ================================================================================================ frozen-stats BN (encoder)
-__global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float rs0, float alpha, size_t total4,
-                                                         int C, float* __restrict__ a) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const int ch = (int)((i * 4) % C);
-    const float4 g = *reinterpret_cast<const float4*>(gamma + ch) * rs0, b = *reinterpret_cast<const float4*>(beta + ch);
-    const float4 y = reinterpret_cast<const float4*>(c)[i] * g + b;
-    reinterpret_cast<float4*>(a)[i] = act_grad(y, y, alpha);
-}
-// dc = da * act'(y) * gamma * rs0; colpart[blk][0][ch] = sum da*act', [1][ch] = sum da*act'*c
-__global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict__ da, const float* __restrict__ c,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float rs0, float alpha, int rows, int rows_per_block, int C,
-                                                         float* __restrict__ dc, float* __restrict__ colpart) {
-    __shared__ float r1[1024], r2[1024];
-    const int Q = C / 4, RL = 256 / Q;
-    const int cq = threadIdx.x % Q, rl = threadIdx.x / Q, ch = cq * 4;
-    const float4 g = *reinterpret_cast<const float4*>(gamma + ch) * rs0, b = *reinterpret_cast<const float4*>(beta + ch);
-    const int row0 = blockIdx.x * rows_per_block, row1 = min(rows, row0 + rows_per_block);
-    float4 s1 = f4(0.f), s2 = f4(0.f);
-    for (int row = row0 + rl; row < row1; row += RL) {
-        const float4 cv = *reinterpret_cast<const float4*>(c + (size_t)row * C + ch);
-        const float4 dn = act_grad(cv * g + b, *reinterpret_cast<const float4*>(da + (size_t)row * C + ch), alpha);
-        *reinterpret_cast<float4*>(dc + (size_t)row * C + ch) = dn * g;
-        s1 = s1 + dn; s2 = s2 + dn * cv;
-    }
-    *reinterpret_cast<float4*>(r1 + rl * C + ch) = s1;
-    *reinterpret_cast<float4*>(r2 + rl * C + ch) = s2;
-    __syncthreads();
-    if (threadIdx.x < C) {
-        float a1 = 0.f, a2 = 0.f;
-        for (int k = 0; k < RL; ++k) { a1 += r1[k * C + threadIdx.x]; a2 += r2[k * C + threadIdx.x]; }
-        colpart[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a1;
-        colpart[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = a2;
-    }
-}
-
-// ================================================================================================ heads
-// out[row] = act(feat[row,:] . w + b)   (critic Dense(1) per feature-map location; generator's final 1x1 conv + sigmoid / tanh)
-// ACT: 0 none, 1 sigmoid, 2 tanh.  min(C/4, 64) lanes per row, each striding over the row's float4s.
-template <int ACT>
-__global__ void __launch_bounds__(256) rowdot_kernel(const float* __restrict__ feat, const float* __restrict__ w,
-                                                     const float* __restrict__ b, int rows, int C, int LPR, float* __restrict__ out) {
-    const int lane = threadIdx.x % LPR;
-    const int row = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) / LPR);
-    float s = 0.f;
-    if (row < rows)
-        for (int c4 = lane; c4 < C / 4; c4 += LPR)
-            s += hsum(*reinterpret_cast<const float4*>(feat + (size_t)row * C + c4 * 4) * *reinterpret_cast<const float4*>(w + c4 * 4));
-    for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (row < rows && lane == 0) {
-        s += b[0];
-        out[row] = ACT == 1 ? 1.0f / (1.0f + expf(-s)) : (ACT == 2 ? tanhf(s) : s);
-    }
-}
-struct Coef4 { float v[4]; };
-// out[row, c] = coef[row / rows_per_group] * w[c]
-__global__ void __launch_bounds__(256) topgrad_kernel(const float* __restrict__ w, int rows_per_group, int C, size_t total4,
-                                                      Coef4 coef, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const size_t row = (i * 4) / C;
-    const int ch = (int)((i * 4) % C);
-    reinterpret_cast<float4*>(out)[i] = *reinterpret_cast<const float4*>(w + ch) * coef.v[row / rows_per_group];
-}
-// partial[blk][c] = sum over the block's rows of coef[row / rows_per_group] * feat[row, c]
-__global__ void __launch_bounds__(256) coef_colsum_kernel(const float* __restrict__ feat, int rows, int rows_per_block,
-                                                          int rows_per_group, int C, Coef4 coef, float* __restrict__ partial) {
-    __shared__ float red[1024];
-    const int Q = C / 4, RL = 256 / Q;
-    const int cq = threadIdx.x % Q, rl = threadIdx.x / Q, ch = cq * 4;
-    const int row0 = blockIdx.x * rows_per_block, row1 = min(rows, row0 + rows_per_block);
-    float4 s = f4(0.f);
-    for (int row = row0 + rl; row < row1; row += RL)
-        s = s + *reinterpret_cast<const float4*>(feat + (size_t)row * C + ch) * coef.v[row / rows_per_group];
-    *reinterpret_cast<float4*>(red + rl * C + ch) = s;
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = 0.f;
-        for (int k = 0; k < RL; ++k) a += red[k * C + c];
-        partial[(size_t)blockIdx.x * C + c] = a;
-    }
-}
-// generator output backward: do = dx * x (1 - x) (sigmoid) or dx * (1 - x^2) (tanh); da[row, c] = do * wf[c];
-// partial[blk][0..C) = sum do * a[row, c], [C] = sum do
-__global__ void __launch_bounds__(256) gfinal_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ x,
-                                                         const float* __restrict__ a, const float* __restrict__ wf, int rows,
-                                                         int rows_per_block, int C, int tanh_act, float* __restrict__ da,
-                                                         float* __restrict__ partial) {
-    __shared__ float red[1024], redb[256];
-    const int Q = C / 4, RL = 256 / Q;
-    const int cq = threadIdx.x % Q, rl = threadIdx.x / Q, ch = cq * 4;
-    const float4 w = *reinterpret_cast<const float4*>(wf + ch);
-    const int row0 = blockIdx.x * rows_per_block, row1 = min(rows, row0 + rows_per_block);
-    float4 s = f4(0.f);
-    float sb = 0.f;
-    for (int row = row0 + rl; row < row1; row += RL) {
-        const float xv = x[row];
-        const float dv = dx[row] * (tanh_act == 2 ? 1.0f : (tanh_act ? (1.0f - xv * xv) : xv * (1.0f - xv)));   // 0 sigmoid, 1 tanh, 2 linear
-        *reinterpret_cast<float4*>(da + (size_t)row * C + ch) = w * dv;
-        if (partial) { s = s + *reinterpret_cast<const float4*>(a + (size_t)row * C + ch) * dv; sb += dv; }
-    }
-    if (!partial) return;
-    *reinterpret_cast<float4*>(red + rl * C + ch) = s;
-    redb[threadIdx.x] = cq == 0 ? sb : 0.f;
-    __syncthreads();
-    if (threadIdx.x < C) {
-        float acc = 0.f;
-        for (int k = 0; k < RL; ++k) acc += red[k * C + threadIdx.x];
-        partial[(size_t)blockIdx.x * (C + 1) + threadIdx.x] = acc;
-    }
-    if (threadIdx.x == 0) {
-        float acc = 0.f;
-        for (int k = 0; k < 256; ++k) acc += redb[k];
-        partial[(size_t)blockIdx.x * (C + 1) + C] = acc;
-    }
-}
-
-// ================================================================================================ elementwise / losses
-// din = [xg ; x ; x + alpha[n] (xg - x)]
-__global__ void __launch_bounds__(256) interp_kernel(const float* __restrict__ xg, const float* __restrict__ x,
-                                                     const float* __restrict__ alpha, int HW, size_t total, float* __restrict__ din) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const float g = xg[i], r = x[i];
-    din[i] = g; din[total + i] = r; din[2 * total + i] = r + alpha[i / HW] * (g - r);
-}
-__global__ void __launch_bounds__(256) tanh_kernel(const float* __restrict__ zr, size_t n, float* __restrict__ z) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) z[i] = tanhf(zr[i]);
-}
-__global__ void __launch_bounds__(256) tanh_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z,
-                                                       const float* __restrict__ mask, size_t n, float* __restrict__ dzr) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dzr[i] = dz[i] * (1.0f - z[i] * z[i]) * (mask ? mask[i] : 1.0f);
-}
-// out = coef * (a - b)  (+ out_prev when ACC)
-template <bool ACC>
-__global__ void __launch_bounds__(256) diff_scale_kernel(const float* __restrict__ a, const float* __restrict__ b, float coef,
-                                                         size_t n, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = (ACC ? out[i] : 0.f) + coef * (a[i] - b[i]);
-}
-// d (mean_n sum |a - b|) / d a = sign(a - b) * coef
-__global__ void __launch_bounds__(256) sign_scale_kernel(const float* __restrict__ a, const float* __restrict__ b, float coef, size_t n,
-                                                         float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float d = a[i] - b[i];
-    out[i] = d > 0.f ? coef : (d < 0.f ? -coef : 0.f);
-}
-__global__ void __launch_bounds__(256) add_kernel(float* __restrict__ out, const float* __restrict__ a, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] += a[i];
-}
-__device__ __forceinline__ float block_sum(float v, float* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float r = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
-    return r;
-}
-// MODE 0: sum a ; 1: sum (a-b)^2 ; 2: sum |a-b| (optionally writing the map).  partial[blk]
-template <int MODE>
-__global__ void __launch_bounds__(256) sum_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
-                                                  float* __restrict__ map, float* __restrict__ partial) {
-    __shared__ float red[4];
-    float s = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        if (MODE == 0) s += a[i];
-        else if (MODE == 1) { const float d = a[i] - b[i]; s += d * d; }
-        else { const float d = fabsf(a[i] - b[i]); s += d; if (map) map[i] = d; }
-    }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-// trainers/fAnoGAN.py:56-57: slopes = sqrt(sum over axis 1 (H) of ddx^2) -> [n, W]; partial sums of (slope - 1)^2
-__global__ void __launch_bounds__(256) pen_col_kernel(const float* __restrict__ g, int n, int H, int W, float* __restrict__ s,
-                                                      float* __restrict__ partial) {
-    __shared__ float red[4];
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    float t = 0.f;
-    if (col < n * W) {
-        const int nn = col / W, w = col % W;
-        float acc = 0.f;
-        for (int h = 0; h < H; ++h) { const float v = g[((size_t)nn * H + h) * W + w]; acc = fmaf(v, v, acc); }
-        const float sl = sqrtf(acc);
-        s[col] = sl;
-        t = (sl - 1.0f) * (sl - 1.0f);
-    }
-    t = block_sum(t, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = t;
-}
-// d penalty / d ddx = coef * (s - 1) / s * ddx
-__global__ void __launch_bounds__(256) pen_grad_kernel(const float* __restrict__ g, const float* __restrict__ s, float coef, int H,
-                                                       int W, size_t total, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int w = (int)(i % W);
-    const size_t nn = i / ((size_t)H * W);
-    const float sl = s[nn * W + w];
-    out[i] = coef * (sl - 1.0f) / sl * g[i];
-}
-// 2x2 average pooling (keras AvgPool2D()) and its backward, NHWC float4
-__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float* __restrict__ x, int H, int W, int C, size_t total4,
-                                                          float* __restrict__ y) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const int C4 = C / 4, W2 = W / 2, H2 = H / 2;
-    const int c4 = (int)(i % C4);
-    size_t t = i / C4;
-    const int ox = (int)(t % W2); t /= W2;
-    const int oy = (int)(t % H2);
-    const size_t n = t / H2;
-    const float4* xp = reinterpret_cast<const float4*>(x) + ((n * H + 2 * oy) * W + 2 * ox) * C4 + c4;
-    const float4 s = (xp[0] + xp[C4]) + (xp[(size_t)W * C4] + xp[(size_t)W * C4 + C4]);
-    reinterpret_cast<float4*>(y)[i] = s * 0.25f;
-}
-__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const float* __restrict__ g, int H, int W, int C, size_t total4,
-                                                          float* __restrict__ dx) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // over the input-resolution tensor [N,H,W,C]
-    if (i >= total4) return;
-    const int C4 = C / 4;
-    const int c4 = (int)(i % C4);
-    size_t t = i / C4;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const size_t n = t / H;
-    reinterpret_cast<float4*>(dx)[i] = reinterpret_cast<const float4*>(g)[((n * (H / 2) + y / 2) * (W / 2) + x / 2) * C4 + c4] * 0.25f;
-}
-
-// derived scalars of a phase from the raw means in raw[]
-__global__ void combine_kernel(int phase, const float* __restrict__ raw, float kappa, float* __restrict__ out) {
-    if (threadIdx.x != 0) return;
-    if (phase == UAD_GAN_GENERATOR) {
-        out[UAD_GAN_S_DISC_FAKE] = raw[0]; out[UAD_GAN_S_GEN_LOSS] = -raw[0];
-    } else if (phase == UAD_GAN_DISCRIMINATOR) {
-        out[UAD_GAN_S_DISC_FAKE] = raw[0]; out[UAD_GAN_S_DISC_REAL] = raw[1]; out[UAD_GAN_S_PENALTY] = raw[2];
-        out[UAD_GAN_S_DISC_LOSS] = raw[0] - raw[1] + raw[2]; out[UAD_GAN_S_GEN_LOSS] = -raw[0];
-    } else if (phase == 4) {      // AAE family, autoencoder phase: raw = {mean L2, mean Rec_z, reconstructionLoss}, kappa = rho
-        out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
-        out[UAD_GAN_S_REC_LOSS] = raw[2];
-    } else if (phase == 7) {      // spatial GMVAE (You): raw = {mean_p_loss, sum con, sum w, sum c}, kappa = 1/n
-        out[UAD_GAN_S_REC_LOSS] = raw[0]; out[UAD_GAN_S_GM_CON] = raw[1] * kappa; out[UAD_GAN_S_GM_W] = raw[2] * kappa; out[UAD_GAN_S_GM_C] = raw[3] * kappa;
-        out[UAD_GAN_S_GM_LOSS] = ((raw[0] + raw[1] * kappa) + raw[2] * kappa) + raw[3] * kappa;
-    } else if (phase == 6) {      // ceVAE (Zimmerer stack): raw = {Rec_vae, Rec_ce, kl}
-        out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_KL] = raw[2];
-        out[UAD_GAN_S_REC_LOSS] = 0.5f * (raw[0] + raw[1]); out[UAD_GAN_S_ENC_LOSS] = (raw[0] + raw[2]) + raw[1]; out[UAD_GAN_S_GM_LOSS] = raw[0] + raw[2];
-    } else if (phase == 5) {      // dense GMVAE: raw = {mean_p_loss, conditional_prior_loss, w_prior_loss, c_prior_loss}
-        out[UAD_GAN_S_REC_LOSS] = raw[0]; out[UAD_GAN_S_GM_CON] = raw[1]; out[UAD_GAN_S_GM_W] = raw[2]; out[UAD_GAN_S_GM_C] = raw[3];
-        out[UAD_GAN_S_GM_LOSS] = ((raw[0] + raw[1]) + raw[2]) + raw[3];
-    } else if (phase == 3) {      // AnoVAE-GAN's VAE phase: raw = {reconstructionLoss, kl}, kappa = kl_weight
-        out[UAD_GAN_S_REC_LOSS] = raw[0]; out[UAD_GAN_S_KL] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
-    } else {
-        out[UAD_GAN_S_LOSS_IMG] = raw[0]; out[UAD_GAN_S_LOSS_FTS] = raw[1]; out[UAD_GAN_S_ENC_LOSS] = raw[0] + kappa * raw[1];
-        out[UAD_GAN_S_REC_LOSS] = raw[2];
-    }
-}
-
-
-// ---- Zimmerer VAE elementwise ----
-__global__ void __launch_bounds__(256) lrelu_fwd_kernel(const float* __restrict__ c, float alpha, size_t total4, float* __restrict__ a) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const float4 v = reinterpret_cast<const float4*>(c)[i];
-    reinterpret_cast<float4*>(a)[i] = make_float4(v.x > 0.f ? v.x : alpha * v.x, v.y > 0.f ? v.y : alpha * v.y, v.z > 0.f ? v.z : alpha * v.z,
-                                                  v.w > 0.f ? v.w : alpha * v.w);
-}
-__global__ void __launch_bounds__(256) lrelu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ c, float alpha, size_t total4,
-                                                        float* __restrict__ dc) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const float4 v = reinterpret_cast<const float4*>(c)[i], g = reinterpret_cast<const float4*>(da)[i];
-    reinterpret_cast<float4*>(dc)[i] = make_float4(v.x > 0.f ? g.x : alpha * g.x, v.y > 0.f ? g.y : alpha * g.y, v.z > 0.f ? g.z : alpha * g.z,
-                                                   v.w > 0.f ? g.w : alpha * g.w);
-}
-// out[(T-1-t)*C + c] = w[t*C + c]
-__global__ void __launch_bounds__(256) flip_taps_kernel(const float* __restrict__ w, int T, int C, float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * C) return;
-    const int t = i / C, c = i % C;
-    out[(T - 1 - t) * C + c] = w[i];
-}
-__global__ void __launch_bounds__(256) add_scalar_kernel(float* __restrict__ x, const float* __restrict__ b, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) x[i] += b[0];
-}
-
-
-// nearest-neighbour x2 (tf.image.resize_images NEAREST_NEIGHBOR, align_corners False: out[i] = in[i / 2]) and its adjoint
-__global__ void __launch_bounds__(256) up2_fwd_kernel(const float* __restrict__ x, int H, int W, int C, size_t total4, float* __restrict__ y) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const int C4 = C / 4;
-    const int c = (int)(i % C4);
-    size_t t = i / C4;
-    const int ox = (int)(t % (2 * W)); t /= 2 * W;
-    const int oy = (int)(t % (2 * H));
-    const size_t n = t / (2 * H);
-    reinterpret_cast<float4*>(y)[i] = reinterpret_cast<const float4*>(x)[((n * H + oy / 2) * W + ox / 2) * C4 + c];
-}
-__global__ void __launch_bounds__(256) up2_bwd_kernel(const float* __restrict__ g, int H, int W, int C, size_t total4, float* __restrict__ dx) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const int C4 = C / 4;
-    const int c = (int)(i % C4);
-    size_t t = i / C4;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const size_t n = t / H;
-    const float4* gp = reinterpret_cast<const float4*>(g);
-    const size_t r0 = ((n * 2 * H + 2 * y) * 2 * W + 2 * x) * C4 + c, r1 = r0 + (size_t)2 * W * C4;
-    const float4 a = gp[r0], b = gp[r0 + C4], cc = gp[r1], d = gp[r1 + C4];
-    reinterpret_cast<float4*>(dx)[i] = make_float4((a.x + b.x) + (cc.x + d.x), (a.y + b.y) + (cc.y + d.y), (a.z + b.z) + (cc.z + d.z), (a.w + b.w) + (cc.w + d.w));
-}
-
-// ================================================================================================ latent critic (AAE family)
-// MLP zDim -> h1 -> h2 -> 1 with tf.nn.leaky_relu (alpha 0.2): models/adversarial_autoencoder.py:44-64, trainers/AAE.py:41-49.
-// One workgroup (128 threads) per sample does everything that sample contributes: the three critic evaluations (fake z_, real z,
-// z_hat = z + eps (z - z_)), the first-order backward of  +d_/n - d/n,  the penalty scale/n (||d d_hat / d z_hat|| - 1)^2 and its
-// second-order gradient (masks are constant a.e.), and writes the sample's parameter-gradient slab [nD] (reduced over samples
-// afterwards in a fixed order).  mode 1 (generator step): only the fake evaluation and dz_fake = -1/n * d d_ / d z_.
-struct CriticArgs {
-    int zd, h1, h2, mode;                 // mode 0 = critic step, 1 = generator step
-    int hat_mode;                         // 0: z_hat = z + eps (z - z_) (sic, the unified models); 1: z_hat = eps z + (1 - eps) z_ (..._Chen.py:119)
-    const float *W1, *b1, *W2, *b2, *W3, *b3;
-    const float *zf, *zr, *eps;           // fake [n,zd], real [n,zd], eps [n]
-    float inv_n, scale;
-    float *d_fake, *d_real, *pen;         // [n] each
-    float *slab;                          // [n][nD]: dW1 | db1 | dW2 | db2 | dW3 | db3
-    float *dz_fake;                       // [n,zd] (mode 1)
-};
-constexpr int kCritMaxZ = 512, kCritMaxH = 400;
-__global__ void __launch_bounds__(128) critic_kernel(const CriticArgs A) {
-    __shared__ float v[3][kCritMaxZ];                 // fake, real, hat
-    __shared__ float m1[3][kCritMaxH], hh1[3][kCritMaxH], m2[3][kCritMaxH], hh2[3][kCritMaxH];
-    __shared__ float da1[2][kCritMaxH], da2[2][kCritMaxH], u1[kCritMaxH], u2[kCritMaxH], tb1[kCritMaxH], ub2[kCritMaxH];
-    __shared__ float gz[kCritMaxZ], red[128];
-    __shared__ float s_d[3], s_coef;
-    const int n = blockIdx.x, t = threadIdx.x, zd = A.zd, h1 = A.h1, h2 = A.h2;
-    const float alpha = 0.2f;
-    const int nin = A.mode == 0 ? 3 : 1;
-    for (int k = t; k < zd; k += 128) {
-        const float f = A.zf[(size_t)n * zd + k];
-        v[0][k] = f;
-        if (A.mode == 0) { const float r = A.zr[(size_t)n * zd + k]; v[1][k] = r; v[2][k] = A.hat_mode ? f + A.eps[n] * (r - f) : r + A.eps[n] * (r - f); }
-    }
-    __syncthreads();
-    // forward of the inputs
-    for (int i = 0; i < nin; ++i) {
-        for (int q = t; q < h1; q += 128) {
-            float a = A.b1[q];
-            for (int k = 0; k < zd; ++k) a = fmaf(v[i][k], A.W1[(size_t)k * h1 + q], a);
-            m1[i][q] = a > 0.f ? 1.f : alpha; hh1[i][q] = a > 0.f ? a : alpha * a;
-        }
-    }
-    __syncthreads();
-    for (int i = 0; i < nin; ++i) {
-        for (int q = t; q < h2; q += 128) {
-            float a = A.b2[q];
-            for (int j = 0; j < h1; ++j) a = fmaf(hh1[i][j], A.W2[(size_t)j * h2 + q], a);
-            m2[i][q] = a > 0.f ? 1.f : alpha; hh2[i][q] = a > 0.f ? a : alpha * a;
-        }
-    }
-    __syncthreads();
-    if (t < nin) {
-        float d = A.b3[0];
-        for (int l = 0; l < h2; ++l) d = fmaf(hh2[t][l], A.W3[l], d);
-        s_d[t] = d;
-    }
-    __syncthreads();
-    if (t == 0) { A.d_fake[n] = s_d[0]; if (A.mode == 0) A.d_real[n] = s_d[1]; }
-    // u2 = m2 * w3, t1 = W2 u2, u1 = m1 * t1, gz = W1 u1 on the input whose input-gradient is needed (hat: mode 0, fake: mode 1)
-    const int gi = A.mode == 0 ? 2 : 0;
-    for (int q = t; q < h2; q += 128) u2[q] = m2[gi][q] * A.W3[q];
-    __syncthreads();
-    for (int q = t; q < h1; q += 128) {
-        float a = 0.f;
-        for (int l = 0; l < h2; ++l) a = fmaf(A.W2[(size_t)q * h2 + l], u2[l], a);
-        u1[q] = m1[gi][q] * a;
-    }
-    __syncthreads();
-    float part = 0.f;
-    for (int k = t; k < zd; k += 128) {
-        float a = 0.f;
-        for (int j = 0; j < h1; ++j) a = fmaf(A.W1[(size_t)k * h1 + j], u1[j], a);
-        gz[k] = a;
-        part = fmaf(a, a, part);
-    }
-    if (A.mode == 1) {
-        for (int k = t; k < zd; k += 128) A.dz_fake[(size_t)n * zd + k] = -A.inv_n * gz[k];
-        return;
-    }
-    red[t] = part;
-    __syncthreads();
-    if (t == 0) {
-        float ss = 0.f;
-        for (int i = 0; i < 128; ++i) ss += red[i];
-        const float sl = sqrtf(ss);
-        A.pen[n] = A.scale * A.inv_n * (sl - 1.f) * (sl - 1.f);
-        s_coef = A.scale * 2.f * (sl - 1.f) / sl * A.inv_n;
-    }
-    __syncthreads();
-    const float coef = s_coef;                       // gbar = coef * gz
-    // first-order backward of +d_/n (fake, i = 0) and -d/n (real, i = 1)
-    for (int q = t; q < h2; q += 128) { da2[0][q] = A.inv_n * A.W3[q] * m2[0][q]; da2[1][q] = -A.inv_n * A.W3[q] * m2[1][q]; }
-    __syncthreads();
-    for (int q = t; q < h1; q += 128) {
-        float a0 = 0.f, a1 = 0.f, ub = 0.f;
-        for (int l = 0; l < h2; ++l) { const float w = A.W2[(size_t)q * h2 + l]; a0 = fmaf(w, da2[0][l], a0); a1 = fmaf(w, da2[1][l], a1); }
-        da1[0][q] = a0 * m1[0][q]; da1[1][q] = a1 * m1[1][q];
-        for (int k = 0; k < zd; ++k) ub = fmaf(gz[k], A.W1[(size_t)k * h1 + q], ub);      // adjoint of u1 (times coef)
-        tb1[q] = coef * ub * m1[2][q];
-    }
-    __syncthreads();
-    for (int q = t; q < h2; q += 128) {
-        float a = 0.f;
-        for (int j = 0; j < h1; ++j) a = fmaf(tb1[j], A.W2[(size_t)j * h2 + q], a);
-        ub2[q] = a;
-    }
-    __syncthreads();
-    // the sample's gradient slab
-    const size_t nD = (size_t)zd * h1 + h1 + (size_t)h1 * h2 + h2 + h2 + 1;
-    float* S = A.slab + (size_t)n * nD;
-    for (int idx = t; idx < zd * h1; idx += 128) {
-        const int k = idx / h1, j = idx - k * h1;
-        S[idx] = v[0][k] * da1[0][j] + v[1][k] * da1[1][j] + coef * gz[k] * u1[j];
-    }
-    float* S1 = S + (size_t)zd * h1;
-    for (int q = t; q < h1; q += 128) S1[q] = da1[0][q] + da1[1][q];
-    float* S2 = S1 + h1;
-    for (int idx = t; idx < h1 * h2; idx += 128) {
-        const int j = idx / h2, l = idx - j * h2;
-        S2[idx] = hh1[0][j] * da2[0][l] + hh1[1][j] * da2[1][l] + tb1[j] * u2[l];
-    }
-    float* S3 = S2 + (size_t)h1 * h2;
-    for (int q = t; q < h2; q += 128) {
-        S3[q] = da2[0][q] + da2[1][q];
-        S3[h2 + q] = A.inv_n * (hh2[0][q] - hh2[1][q]) + ub2[q] * m2[2][q];
-    }
-    if (t == 0) S3[2 * h2] = 0.f;                    // db3: +1/n - 1/n
-}
+#include "uad_gan_kernels.inc"
 
 // ================================================================================================ handle
 struct Tensor {
@@ -2043,918 +1424,7 @@ uad_gan::GraphKey graph_key(int kind, int phase, const uad_gan_io_t* io, int n, 
 
 extern "C" {
 
-// ---- handle of the ResNet variant (models/fanogan_schlegl.py); parameter table in TF first-call order ----
-static int create_resnet(const uad_gan_config_t* cfg, uad_gan_t** out) {
-    const int H = cfg->height, ir = cfg->inter_res, dim = cfg->dim > 0 ? cfg->dim : 64;
-    if (H != 8 * ir) return fail(UAD_ERR_UNSUPPORTED, "ResNet f-AnoGAN: the generator upsamples 8x, height must be 8 * inter_res (fanogan_schlegl.py:28,121-133)");
-    if (dim % 32 || dim > 64) return fail(UAD_ERR_UNSUPPORTED, "ResNet f-AnoGAN: dim must be 32 or 64");
-    if (ir < 2) return fail(UAD_ERR_UNSUPPORTED, "inter_res >= 2 needed");
-    uad_gan* m = new uad_gan();
-    m->cfg = *cfg; m->variant = 1; m->dim = dim; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1;
-    m->npool = 3; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
-    m->step[0] = m->step[1] = m->step[2] = 0;
-    char nm[160];
-    int cin = 1, res = H;
-    for (int i = 0; i < 3; ++i) {
-        const int f = (32 << i) < 128 ? (32 << i) : 128;
-        Block L;
-        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
-        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
-        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
-        std::string bs = i == 0 ? "Encoder/batch_normalization" : "Encoder/batch_normalization_" + std::to_string(i);
-        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
-        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
-        L.H = L.W = res / 2; L.C = f;
-        m->E.push_back(L);
-        cin = f; res /= 2;
-    }
-    m->cenc = cin; m->cmid = 0; m->flat = ir * ir * cin;
-    m->e_cw = m->e_cb = -1;
-    m->e_dw = add_tensor(m, "Encoder/dense/kernel", 2, m->flat, cfg->zdim, 1, 1);
-    m->e_db = add_tensor(m, "Encoder/dense/bias", 1, cfg->zdim, 1, 1, 1);
-    m->grp_off[UAD_GAN_ENCODER] = 0; m->grp_cnt[UAD_GAN_ENCODER] = m->nparams;
-    int ln = 0;
-    std::map<std::string, int> cnt;
-    auto ln_name = [&](const char* scope) { std::string r = std::string(scope) + (ln == 0 ? "layer_normalization" : "layer_normalization_" + std::to_string(ln)); ++ln; return r; };
-    auto tf_name = [&](const char* scope, const char* base) {
-        const std::string key = std::string(scope) + base;
-        const int k = cnt[key]++;
-        return k == 0 ? key : key + "_" + std::to_string(k);
-    };
-    const int flatg = ir * ir * 8 * dim;
-    m->g_dw = add_tensor(m, "Generator/dense/kernel", 2, cfg->zdim, flatg, 1, 1);
-    m->g_db = add_tensor(m, "Generator/dense/bias", 1, flatg, 1, 1, 1);
-    m->g_cw = m->g_cb = m->g_ln0g = m->g_ln0b = -1;
-    auto make_block = [&](bool gen, const char* scope, int Hin, int Cin, int Cout, int stride) {
-        RB B;
-        memset(&B, 0, sizeof B);
-        B.gen = gen; B.stride = stride; B.Hin = Hin; B.Cin = Cin; B.Cout = Cout;
-        B.Hout = gen ? Hin * stride : Hin / stride;
-        std::string s1 = ln_name(scope);
-        B.ln1g = add_tensor(m, s1 + "/gamma", 2, Hin, Hin, 1, 1); B.ln1b = add_tensor(m, s1 + "/beta", 2, Hin, Hin, 1, 1);
-        std::string c1 = tf_name(scope, "conv2d");
-        B.w1 = add_tensor(m, c1 + "/kernel", 4, 3, 3, Cin, Cout); B.b1 = add_tensor(m, c1 + "/bias", 1, Cout, 1, 1, 1);
-        std::string s2 = ln_name(scope);
-        B.ln2g = add_tensor(m, s2 + "/gamma", 2, Hin, Hin, 1, 1); B.ln2b = add_tensor(m, s2 + "/beta", 2, Hin, Hin, 1, 1);
-        std::string c2 = tf_name(scope, gen ? "conv2d_transpose" : "conv2d");
-        B.w2 = add_tensor(m, c2 + "/kernel", 4, 3, 3, Cout, Cout); B.b2 = add_tensor(m, c2 + "/bias", 1, Cout, 1, 1, 1);
-        B.ws = B.bs = -1;
-        if (stride == 2) {
-            std::string sh = tf_name(scope, gen ? "conv2d_transpose" : "conv2d");
-            if (gen) B.ws = add_tensor(m, sh + "/kernel", 4, 1, 1, Cout, Cin); else B.ws = add_tensor(m, sh + "/kernel", 4, 1, 1, Cin, Cout);
-            B.bs = add_tensor(m, sh + "/bias", 1, Cout, 1, 1, 1);
-        }
-        B.d1 = UadConvDesc{1, Hin, Hin, Cin, Hin, Hin, Cout, 3, 1, 1};
-        const int P2 = stride == 1 ? 1 : 0;                       // TF SAME: k3 s1 pads 1 before; k3 s2 on an even size pads 0 before
-        if (gen) {
-            B.d2 = UadConvDesc{1, B.Hout, B.Hout, Cout, Hin, Hin, Cout, 3, stride, P2};     // big = output of the transposed conv
-            B.ds = UadConvDesc{1, B.Hout, B.Hout, Cout, Hin, Hin, Cin, 1, 2, 0};
-        } else {
-            B.d2 = UadConvDesc{1, Hin, Hin, Cout, B.Hout, B.Hout, Cout, 3, stride, P2};
-            B.ds = UadConvDesc{1, Hin, Hin, Cin, Hin, Hin, Cout, 1, 1, 0};
-        }
-        B.sx = (size_t)Hin * Hin * Cin; B.sc1 = (size_t)Hin * Hin * Cout; B.sout = (size_t)B.Hout * B.Hout * Cout;
-        return B;
-    };
-    {
-        const int chans[4] = {8 * dim, 4 * dim, 2 * dim, dim}, strides[4] = {1, 2, 2, 2};
-        int c = 8 * dim, r = ir;
-        for (int k = 0; k < 4; ++k) { m->GB.push_back(make_block(true, "Generator/", r, c, chans[k], strides[k])); c = chans[k]; r *= strides[k]; }
-        const std::string sl = ln_name("Generator/");
-        m->s_glg = add_tensor(m, sl + "/gamma", 2, r, r, 1, 1); m->s_glb = add_tensor(m, sl + "/beta", 2, r, r, 1, 1);
-        const std::string gf = tf_name("Generator/", "conv2d");
-        m->g_fw = add_tensor(m, gf + "/kernel", 4, 1, 1, c, 1); m->g_fb = add_tensor(m, gf + "/bias", 1, 1, 1, 1, 1);
-    }
-    m->grp_off[UAD_GAN_GENERATOR] = m->grp_cnt[UAD_GAN_ENCODER];
-    m->grp_cnt[UAD_GAN_GENERATOR] = m->nparams - m->grp_off[UAD_GAN_GENERATOR];
-    {
-        const std::string d0 = tf_name("Discriminator/", "conv2d");
-        m->s_d0w = add_tensor(m, d0 + "/kernel", 4, 3, 3, 1, dim); m->s_d0b = add_tensor(m, d0 + "/bias", 1, dim, 1, 1, 1);
-        m->s_d0 = UadConvDesc{1, H, H, 1, H, H, dim, 3, 1, 1};
-        const int chans[4] = {2 * dim, 4 * dim, 8 * dim, 8 * dim}, strides[4] = {2, 2, 2, 1};
-        int c = dim, r = H;
-        for (int k = 0; k < 4; ++k) { m->DB.push_back(make_block(false, "Discriminator/", r, c, chans[k], strides[k])); c = chans[k]; r /= strides[k]; }
-        m->d_hw = add_tensor(m, "Discriminator/dense/kernel", 2, c, 1, 1, 1);
-        m->d_hb = add_tensor(m, "Discriminator/dense/bias", 1, 1, 1, 1, 1);
-    }
-    m->grp_off[UAD_GAN_DISCRIMINATOR] = m->grp_off[UAD_GAN_GENERATOR] + m->grp_cnt[UAD_GAN_GENERATOR];
-    m->grp_cnt[UAD_GAN_DISCRIMINATOR] = m->nparams - m->grp_off[UAD_GAN_DISCRIMINATOR];
-
-    // ---- device memory ----
-    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H;
-    int rc = UAD_OK;
-#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
-    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
-    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
-    ALLOC(m->wpack_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack_d, (size_t)m->nparams, nullptr);
-    ALLOC(m->wpack16_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack16_d, (size_t)m->nparams, nullptr);
-    size_t maxact = 3 * NB * HW, max_ta = 0, max_tb = 0, max_sp = 0, max_q = 0, lnp_g = 0;
-    m->ec.resize(3); m->ea.resize(4, nullptr);
-    for (int i = 0; i < 3; ++i) {
-        const size_t sz = NB * asz(m->E[i]);
-        snprintf(nm, sizeof nm, "ec%d", i); ALLOC(m->ec[i], sz, nm);
-        snprintf(nm, sizeof nm, "ea%d", i + 1); ALLOC(m->ea[i + 1], sz, nm);
-        if (sz > maxact) maxact = sz;
-    }
-    ALLOC(m->zr, NB * cfg->zdim, "zr"); ALLOC(m->z, NB * cfg->zdim, "z"); ALLOC(m->xg, NB * HW, "xg");
-    ALLOC(m->s_g0, NB * flatg, "sg_x0"); ALLOC(m->s_dg0, NB * flatg, nullptr);
-    auto alloc_block = [&](RB& B, float* X, float* DX, size_t cap_act, size_t cap_fwd, bool critic, const char* tag, int k) {
-        B.X = X; B.DX = DX;
-        snprintf(nm, sizeof nm, "%s_h1_%d", tag, k); ALLOC(B.H1, cap_act * B.sx, nm);
-        snprintf(nm, sizeof nm, "%s_c1_%d", tag, k); ALLOC(B.C1, cap_fwd * B.sc1, nm);
-        snprintf(nm, sizeof nm, "%s_h2_%d", tag, k); ALLOC(B.H2, cap_act * B.sc1, nm);
-        snprintf(nm, sizeof nm, "%s_out_%d", tag, k); ALLOC(B.OUT, cap_act * B.sout, nm);
-        ALLOC(B.ST1, cap_fwd * 2 * B.Cin, nullptr); ALLOC(B.ST2, cap_fwd * 2 * B.Cout, nullptr);
-        snprintf(nm, sizeof nm, "%s_dout_%d", tag, k); ALLOC(B.DOUT, cap_act * B.sout, nm);
-        snprintf(nm, sizeof nm, "%s_g1_%d", tag, k); ALLOC(B.G1, cap_act * B.sc1, nm);
-        if (critic && B.ws >= 0) ALLOC(B.DSC, cap_act * B.sc1, nullptr);
-        if (critic) {
-            snprintf(nm, sizeof nm, "%s_v1_%d", tag, k); ALLOC(B.V1, NB * B.sx, nm);
-            snprintf(nm, sizeof nm, "%s_v2_%d", tag, k); ALLOC(B.V2, NB * B.sc1, nm);
-            snprintf(nm, sizeof nm, "%s_injx_%d", tag, k); ALLOC(B.INJX, NB * B.sx, nm);
-            snprintf(nm, sizeof nm, "%s_injc1_%d", tag, k); ALLOC(B.INJC1, NB * B.sc1, nm);
-        }
-        ALLOC(B.LP1, cap_act * (B.Cin / 32) * 2 * B.Hin * B.Hin, nullptr);
-        ALLOC(B.LP2, cap_act * (B.Cout / 32) * 2 * B.Hin * B.Hin, nullptr);
-        if (cap_fwd * B.sc1 > max_ta) max_ta = cap_fwd * B.sc1;
-        if (cap_fwd * B.sx > max_tb) max_tb = cap_fwd * B.sx;
-        if (cap_fwd * B.sout > max_sp) max_sp = cap_fwd * B.sout;
-        if (NB * B.sc1 > max_q) max_q = NB * B.sc1;
-    };
-    {
-        float* X = m->s_g0; float* DX = m->s_dg0;
-        for (size_t k = 0; k < m->GB.size(); ++k) { alloc_block(m->GB[k], X, DX, NB, NB, false, "sg", (int)k); X = m->GB[k].OUT; DX = m->GB[k].DOUT; }
-        const RB& L = m->GB.back();
-        ALLOC(m->s_hf, NB * L.sout, "sg_hf"); ALLOC(m->s_stf, NB * 2 * L.Cout, nullptr);
-        lnp_g = NB * (L.Cout / 32) * 2 * L.Hout * L.Hout;
-        if (NB * L.sout > maxact) maxact = NB * L.sout;
-    }
-    ALLOC(m->lnpart_g, lnp_g, nullptr);
-    ALLOC(m->din, 4 * NB * HW, "din");
-    ALLOC(m->s_out0, 4 * NB * HW * dim, "sd_out0"); ALLOC(m->s_dout0, 4 * NB * HW * dim, "sd_dout0");
-    {
-        float* X = m->s_out0; float* DX = m->s_dout0;
-        for (size_t k = 0; k < m->DB.size(); ++k) { alloc_block(m->DB[k], X, DX, 4 * NB, 3 * NB, true, "sd", (int)k); X = m->DB[k].OUT; DX = m->DB[k].DOUT; }
-    }
-    ALLOC(m->s_ta, max_ta, nullptr); ALLOC(m->s_tb, max_tb, nullptr); ALLOC(m->s_sp, max_sp, nullptr); ALLOC(m->s_sct, max_ta, nullptr);
-    ALLOC(m->Q, max_q, "Q");
-    ALLOC(m->Dd, 3 * NB * ir * ir, "Dd"); ALLOC(m->Gx, NB * HW, "Gx"); ALLOC(m->slopes, NB * H, "slopes");
-    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
-    ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->dzbuf, NB * cfg->zdim, "dz"); ALLOC(m->dzr, NB * cfg->zdim, nullptr);
-    {
-        size_t wp = 0, need = (size_t)4 << 20;
-        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
-        auto want = [&](UadConvDesc d, size_t n) { d.N = (int)n; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, false); if (v > need) need = v; } };
-        for (size_t i = 1; i < m->E.size(); ++i) { wp_need(m->E[i].d, NB); UadConvDesc d = m->E[i].d; d.N = (int)NB; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, true); if (v > need) need = v; } }
-        for (auto& B : m->GB) { wp_need(B.d1, NB); wp_need(B.d2, NB); want(B.d1, NB); want(B.d2, NB); if (B.ws >= 0) { wp_need(B.ds, NB); want(B.ds, NB); } }
-        for (auto& B : m->DB) { wp_need(B.d1, 4 * NB); wp_need(B.d2, 4 * NB); want(B.d1, 3 * NB); want(B.d2, 3 * NB); want(B.d1, NB); want(B.d2, NB);
-                                if (B.ws >= 0) { wp_need(B.ds, 4 * NB); want(B.ds, 3 * NB); want(B.ds, NB); } }
-        wp_need(dense_desc(1, m->flat, cfg->zdim), NB); wp_need(dense_desc(1, cfg->zdim, flatg), NB);
-        want(dense_desc(1, m->flat, cfg->zdim), NB); want(dense_desc(1, cfg->zdim, flatg), NB);
-        { UadConvDesc d0 = m->s_d0; d0.N = (int)(4 * NB); size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
-        { UadConvDesc d0 = m->E[0].d; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
-        ALLOC(m->wpartial, wp, nullptr);
-        m->ws.floats = need; m->ws.ptr = nullptr;
-        ALLOC(m->ws.ptr, need, nullptr);
-    }
-    ALLOC(m->colscratch, 64 * 1024, nullptr); ALLOC(m->colpart, (size_t)kBnBwdBlocks * 2 * 128, nullptr);
-    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
-    ALLOC(m->finpart, (size_t)1024 * 520, nullptr);
-#undef ALLOC
-    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
-    *out = m;
-    return UAD_OK;
-}
-
-// ---- handle of the AAE family (ConstrainedAE / AAE / ConstrainedAAE); parameter table in TF first-call order ----
-
-static int create_zimmerer(const uad_gan_config_t* cfg, uad_gan_t** out) {
-    const int H = cfg->height, zd = cfg->zdim;
-    if (H < 32 || H % 16) return fail(UAD_ERR_UNSUPPORTED, "Zimmerer VAE: height must be a power of two >= 32");
-    if (cfg->inter_res != H / 16) return fail(UAD_ERR_INVALID, "Zimmerer VAE: intermediateResolutions must be height / 16 (four stride-2 stages)");
-    uad_gan* m = new uad_gan();
-    const bool ce = cfg->aae_kind == 5;
-    const std::string se = ce ? "Encoder/" : "", sb = ce ? "Bottleneck/" : "", sdc = ce ? "Decoder/" : "";
-    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->aae_kind = cfg->aae_kind; m->zim = true; m->zim_ce = ce; m->gmv = false; m->a_constrained = m->a_critic = false;
-    m->dim = 0; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1; m->a_zw = m->a_zb = -1;
-    m->npool = 4; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = true;        // nothing is packed: no k5 layers
-    m->step[0] = m->step[1] = m->step[2] = 0;
-    static const int ef[4] = {16, 64, 256, 1024}, gf[4] = {1024, 256, 64, 16};
-    char nm[160];
-    int cin = 1, res = H;
-    for (int i = 0; i < 4; ++i) {
-        Block L;
-        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, ef[i], 4, 2, 1};
-        snprintf(nm, sizeof nm, "enc_conv2D_%d/kernel", i + 1); L.w = add_tensor(m, se + nm, 4, 4, 4, cin, ef[i]);
-        snprintf(nm, sizeof nm, "enc_conv2D_%d/bias", i + 1); L.b = add_tensor(m, se + nm, 1, ef[i], 1, 1, 1);
-        L.gamma = L.beta = -1; L.H = L.W = res / 2; L.C = ef[i];
-        m->E.push_back(L);
-        cin = ef[i]; res /= 2;
-    }
-    const int r = res;
-    m->cenc = 1024; m->cmid = 1024; m->flat = r * r * 1024;
-    m->z_muw = add_tensor(m, sb + "dense/kernel", 2, m->flat, zd, 1, 1); m->z_mub = add_tensor(m, sb + "dense/bias", 1, zd, 1, 1, 1);
-    m->z_lsw = add_tensor(m, sb + "dense_1/kernel", 2, m->flat, zd, 1, 1); m->z_lsb = add_tensor(m, sb + "dense_1/bias", 1, zd, 1, 1, 1);
-    m->z_dw = add_tensor(m, sb + "dense_2/kernel", 2, zd, m->flat, 1, 1); m->z_db = add_tensor(m, sb + "dense_2/bias", 1, m->flat, 1, 1, 1);
-    cin = 1024;
-    for (int i = 0; i < 4; ++i) {
-        Block L;
-        L.d = UadConvDesc{1, res * 2, res * 2, gf[i], res, res, cin, 4, 2, 1};
-        snprintf(nm, sizeof nm, "dec_Conv2DT_%d/kernel", i + 1); L.w = add_tensor(m, sdc + nm, 4, 4, 4, gf[i], cin);
-        snprintf(nm, sizeof nm, "dec_Conv2DT_%d/bias", i + 1); L.b = add_tensor(m, sdc + nm, 1, gf[i], 1, 1, 1);
-        res *= 2;
-        L.gamma = L.beta = -1; L.H = L.W = res; L.C = gf[i];
-        m->G.push_back(L);
-        cin = gf[i];
-    }
-    m->z_fw = add_tensor(m, sdc + "dec_Conv2D_final/kernel", 4, 4, 4, 16, 1); m->z_fb = add_tensor(m, sdc + "dec_Conv2D_final/bias", 1, 1, 1, 1, 1);
-    m->z_fd = UadConvDesc{1, H, H, 1, H, H, 16, 4, 1, 2};
-    m->g_fw = m->z_fw; m->g_fb = m->z_fb;
-    for (int k = 0; k < 3; ++k) { m->grp_off[k] = 0; m->grp_cnt[k] = m->nparams; }      // one optimizer over every variable
-
-    const size_t NB = (size_t)cfg->max_batch * (ce ? 2 : 1), HW = (size_t)H * H;      // ceVAE: both branches in one pass
-    int rc = UAD_OK;
-#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
-    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
-    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
-    m->wpack_f = m->wpack_d = m->wpack16_f = m->wpack16_d = nullptr;
-    m->a_xcat = m->z_l1 = nullptr;
-    if (ce) { ALLOC(m->a_xcat, NB * HW, nullptr); ALLOC(m->z_l1, NB * HW, nullptr); }
-    size_t maxact = NB * HW * 16;
-    m->ec.resize(4); m->ea.resize(5, nullptr);
-    for (int i = 0; i < 4; ++i) {
-        const size_t sz = NB * asz(m->E[i]);
-        snprintf(nm, sizeof nm, "ec%d", i); ALLOC(m->ec[i], sz, nm);
-        snprintf(nm, sizeof nm, "ea%d", i + 1); ALLOC(m->ea[i + 1], sz, nm);
-        if (sz > maxact) maxact = sz;
-    }
-    m->gc.resize(5, nullptr); m->ga.resize(5, nullptr);
-    ALLOC(m->ga[0], NB * m->flat, "ga0");
-    for (int i = 0; i < 4; ++i) {
-        const size_t sz = NB * asz(m->G[i]);
-        snprintf(nm, sizeof nm, "gc%d", i + 1); ALLOC(m->gc[i + 1], sz, nm);
-        snprintf(nm, sizeof nm, "ga%d", i + 1); ALLOC(m->ga[i + 1], sz, nm);
-        if (sz > maxact) maxact = sz;
-    }
-    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
-    ALLOC(m->xg, NB * HW, "xg"); ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->z, NB * zd, "z"); ALLOC(m->dzbuf, NB * zd, "dz");
-    ALLOC(m->v_mu_raw, NB * zd, nullptr); ALLOC(m->v_ls_raw, NB * zd, nullptr); ALLOC(m->v_mu, NB * zd, "mu"); ALLOC(m->v_ls, NB * zd, "ls");
-    ALLOC(m->v_sigma, NB * zd, "sigma"); ALLOC(m->v_kl, NB, nullptr); ALLOC(m->v_dmu, NB * zd, nullptr); ALLOC(m->v_dls, NB * zd, nullptr);
-    ALLOC(m->z_wflip, 256, nullptr); ALLOC(m->z_dwflip, 256, nullptr);
-    {
-        size_t wp = 0, need = (size_t)4 << 20;
-        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
-        auto want = [&](UadConvDesc d, size_t n) { d.N = (int)n; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, false); if (v > need) need = v; } };
-        for (size_t i = 1; i < m->E.size(); ++i) { wp_need(m->E[i].d, NB); want(m->E[i].d, NB); }
-        for (auto& L : m->G) { wp_need(L.d, NB); want(L.d, NB); }
-        wp_need(dense_desc(1, m->flat, zd), NB); wp_need(dense_desc(1, zd, m->flat), NB);
-        want(dense_desc(1, m->flat, zd), NB); want(dense_desc(1, zd, m->flat), NB);
-        { UadConvDesc d0 = m->E[0].d; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
-        { UadConvDesc d0 = m->z_fd; d0.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
-        ALLOC(m->wpartial, wp, nullptr);
-        m->ws.floats = need; m->ws.ptr = nullptr;
-        ALLOC(m->ws.ptr, need, nullptr);
-    }
-    size_t cs = 64 * 1024;
-    { const size_t v = uad_colsum_scratch_floats((int)NB, m->flat); if (v > cs) cs = v; }
-    ALLOC(m->colscratch, cs, nullptr);
-    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
-#undef ALLOC
-    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
-    *out = m;
-    return UAD_OK;
-}
-
-
-static int create_you(const uad_gan_config_t* cfg, uad_gan_t** out) {
-    const int H = cfg->height, Z = cfg->zdim, W = cfg->dim_w, C = cfg->dim;
-    if (H < 16 || H % 16) return fail(UAD_ERR_UNSUPPORTED, "GMVAE (You): height must be a power of two >= 16");
-    if (cfg->inter_res != H / 4) return fail(UAD_ERR_INVALID, "GMVAE (You): the latent map is height / 4 (two stride-2 convolutions): set intermediateResolutions accordingly");
-    // the first decoder convolution contracts over dim_z channels: 1 (image-side kernel) or a multiple of 8 (generic kernels' K step)
-    if (!(Z == 1 || Z % 8 == 0) || Z > 64 || W < 1 || W > 64 || C < 1 || C > 64 || (long long)Z * C > 1024)
-        return fail(UAD_ERR_UNSUPPORTED, "GMVAE (You): dim_z 1 or a multiple of 8 (<= 64), dim_w <= 64, dim_c <= 64, dim_z * dim_c <= 1024");
-    uad_gan* m = new uad_gan();
-    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->aae_kind = 6; m->you = true; m->zim = m->zim_ce = m->gmv = false; m->a_constrained = m->a_critic = false;
-    m->gm_W = W; m->gm_Z = Z; m->gm_C = C;
-    m->dim = C; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1; m->a_zw = m->a_zb = -1;
-    m->npool = 2; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = true;
-    m->step[0] = m->step[1] = m->step[2] = 0;
-    auto conv_op = [&](const std::string& name, int kind, int hin, int cin, int cout, int stride, bool relu) {
-        YOp o;
-        o.kind = kind; o.relu = relu; o.c = o.a = nullptr;
-        const int hout = hin / stride;
-        if (kind == 0) {
-            o.L.d = UadConvDesc{1, hin, hin, cin, hout, hout, cout, 3, stride, stride == 2 ? 0 : 1};
-            o.L.w = add_tensor(m, name + "/kernel", 4, 3, 3, cin, cout);
-        } else {
-            o.L.d = UadConvDesc{1, hout, hout, cout, hin, hin, cin, 3, 1, 1};
-            o.L.w = add_tensor(m, name + "/kernel", 4, 3, 3, cout, cin);
-        }
-        o.L.b = add_tensor(m, name + "/bias", 1, cout, 1, 1, 1);
-        o.L.gamma = o.L.beta = -1; o.L.H = o.L.W = hout; o.L.C = cout;
-        o.Hout = hout; o.Cout = cout;
-        return o;
-    };
-    static const char* en[6] = {"q_wz_x/3x3convlayer", "q_wz_x/3x3convlayer1", "q_wz_x/3x3convlayer2", "q_wz_x/3x3convlayer3", "q_wz_x/3x3convlayer4",
-                                "q_wz_x/3x3convlayer5"};
-    static const int es[6] = {2, 1, 1, 2, 1, 1};
-    int h = H, cin = 1;
-    for (int i = 0; i < 6; ++i) { m->y_enc.push_back(conv_op(en[i], 0, h, cin, 64, es[i], true)); h /= es[i]; cin = 64; }
-    const int r = h, Q = Z * C;
-    {
-        int k = 0;
-        const char* hn[4] = {"q_wz_x/w_mu", "q_wz_x/w_log_sigma", "q_wz_x/z_mu", "q_wz_x/z_log_sigma"};
-        const int hd[4] = {W, W, Z, Z};
-        for (int j = 0; j < 4; ++j) {
-            m->y_off[k++] = add_tensor(m, std::string(hn[j]) + "/kernel", 4, 1, 1, 64, hd[j]);
-            m->y_off[k++] = add_tensor(m, std::string(hn[j]) + "/bias", 1, hd[j], 1, 1, 1);
-        }
-        m->y_off[k++] = add_tensor(m, "p_z_wc/1x1convlayer/kernel", 4, 1, 1, W, 64); m->y_off[k++] = add_tensor(m, "p_z_wc/1x1convlayer/bias", 1, 64, 1, 1, 1);
-        m->y_off[k++] = add_tensor(m, "p_z_wc/z_wc_mu/kernel", 4, 1, 1, 64, Q); m->y_off[k++] = add_tensor(m, "p_z_wc/z_wc_mu/bias", 1, Q, 1, 1, 1);
-        m->y_off[k++] = add_tensor(m, "p_z_wc/z_wc_log_sigma/kernel", 4, 1, 1, 64, Q); m->y_off[k++] = add_tensor(m, "p_z_wc/z_wc_log_sigma/bias", 1, Q, 1, 1, 1);
-        m->y_off[k++] = add_tensor(m, "Variable", 1, Q, 1, 1, 1);
-        m->y_total = m->nparams - m->y_off[0];
-    }
-    auto up_op = [&](int hin, int c) { YOp o; o.kind = 2; o.relu = false; o.c = o.a = nullptr; o.Hout = 2 * hin; o.Cout = c; o.L.w = o.L.b = o.L.gamma = o.L.beta = -1; return o; };
-    h = r;
-    m->y_dec.push_back(conv_op("p_x_z/3x3convlayer1", 0, h, Z, 64, 1, true));
-    m->y_dec.push_back(conv_op("p_x_z/3x3upconvlayer1", 1, h, 64, 64, 1, true));
-    m->y_dec.push_back(conv_op("p_x_z/3x3upconvlayer2", 1, h, 64, 64, 1, true));
-    m->y_dec.push_back(up_op(h, 64)); h *= 2;
-    m->y_dec.push_back(conv_op("p_x_z/3x3convlayer2", 0, h, 64, 64, 1, true));
-    m->y_dec.push_back(conv_op("p_x_z/3x3upconvlayer3", 1, h, 64, 64, 1, true));
-    m->y_dec.push_back(conv_op("p_x_z/3x3upconvlayer4", 1, h, 64, 64, 1, true));
-    m->y_dec.push_back(up_op(h, 64)); h *= 2;
-    m->y_dec.push_back(conv_op("p_x_z/3x3convlayer3", 0, h, 64, 64, 1, false));
-    m->y_dec.push_back(conv_op("p_x_z/y_mu", 0, h, 64, 1, 1, false));
-    m->y_fd = UadConvDesc{1, H, H, 1, H, H, 64, 3, 1, 1};
-    m->g_fw = m->y_dec.back().L.w; m->g_fb = m->y_dec.back().L.b;
-    for (int k = 0; k < 3; ++k) { m->grp_off[k] = 0; m->grp_cnt[k] = m->nparams; }
-    m->flat = r * r * Z; m->cenc = 64; m->cmid = 64;
-
-    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H, Lm = NB * r * r;
-    int rc = UAD_OK;
-    char nm[64];
-#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
-    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
-    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
-    m->wpack_f = m->wpack_d = m->wpack16_f = m->wpack16_d = nullptr;
-    size_t maxact = NB * HW * 64;
-    for (size_t i = 0; i < m->y_enc.size(); ++i) {
-        YOp& o = m->y_enc[i];
-        snprintf(nm, sizeof nm, "yec%d", (int)i); ALLOC(o.c, NB * yop_out(o), nm);
-        if (i + 1 < m->y_enc.size()) { ALLOC(o.a, NB * yop_out(o), nullptr); }
-    }
-    for (size_t i = 0; i + 1 < m->y_dec.size(); ++i) {
-        YOp& o = m->y_dec[i];
-        if (o.kind != 2) { snprintf(nm, sizeof nm, "ydc%d", (int)i); ALLOC(o.c, NB * yop_out(o), nm); }
-        if (o.kind == 2 || o.relu) { ALLOC(o.a, NB * yop_out(o), nullptr); } else o.a = o.c;
-    }
-    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
-    ALLOC(m->xg, NB * HW, "xg"); ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->gm_dxhat, NB * HW, nullptr);
-    ALLOC(m->a_zm, Lm * Z, "z_s"); ALLOC(m->y_dzdec, Lm * Z, nullptr); ALLOC(m->y_h, Lm * 64, "h");
-    ALLOC(m->y_ones, 64, nullptr); ALLOC(m->y_zeros, 64, nullptr);
-    ALLOC(m->y_loc, Lm * 3, "loc"); ALLOC(m->y_colpart, Lm * 2 * 64, nullptr);
-    ALLOC(m->y_dheads, Lm * (2 * W + 2 * Z), nullptr); ALLOC(m->y_da7, Lm * 64, nullptr); ALLOC(m->y_dM, Lm * Q, nullptr); ALLOC(m->y_dLq, Lm * Q, nullptr);
-    ALLOC(m->y_ws, Lm * W, nullptr); ALLOC(m->y_mid, Lm * 64, nullptr);
-    ALLOC(m->y_partial, (size_t)uad_gm_wgrad_chunks((int)Lm) * (size_t)m->y_total, nullptr);
-    ALLOC(m->z_wflip, 1024, nullptr); ALLOC(m->z_dwflip, 1024, nullptr);
-    if (rc == UAD_OK) {
-        std::vector<float> ones(64, 1.0f);
-        HIP_TRY(hipMemcpy(m->y_ones, ones.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
-    }
-    {
-        size_t wp = 0, need = (size_t)4 << 20;
-        auto wp_need = [&](UadConvDesc d) { d.N = (int)NB; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
-        auto want = [&](UadConvDesc d) { d.N = (int)NB; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, false); if (v > need) need = v; } };
-        auto first = [&](UadConvDesc d) { d.N = (int)NB; size_t v = uad_conv_first_wgrad_partial_floats(d); if (v > wp) wp = v; };
-        for (auto& o : m->y_enc) { if (o.L.d.CB % 4) first(o.L.d); else { wp_need(o.L.d); want(o.L.d); } }
-        for (size_t i = 0; i + 1 < m->y_dec.size(); ++i) {
-            auto& o = m->y_dec[i];
-            if (o.kind == 2) continue;
-            if (o.L.d.CB % 4) first(o.L.d); else { wp_need(o.L.d); want(o.L.d); }
-        }
-        first(m->y_fd);
-        ALLOC(m->wpartial, wp, nullptr);
-        m->ws.floats = need; m->ws.ptr = nullptr;
-        ALLOC(m->ws.ptr, need, nullptr);
-    }
-    ALLOC(m->colscratch, 64 * 1024, nullptr);
-    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
-#undef ALLOC
-    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
-    *out = m;
-    return UAD_OK;
-}
-
-
-static int create_chen(const uad_gan_config_t* cfg, uad_gan_t** out) {
-    const int H = cfg->height, ir = cfg->inter_res, dim = cfg->dim > 0 ? cfg->dim : 64, zd = cfg->zdim;
-    if (H != 8 * ir) return fail(UAD_ERR_UNSUPPORTED, "constrained AAE (Chen): three stride-2 blocks, height must be 8 * inter_res");
-    if (dim % 32 || dim > 64) return fail(UAD_ERR_UNSUPPORTED, "constrained AAE (Chen): dim must be 32 or 64");
-    if (ir < 2) return fail(UAD_ERR_UNSUPPORTED, "inter_res >= 2 needed");
-    if (zd > kCritMaxZ) return fail(UAD_ERR_UNSUPPORTED, "zDim <= %d", kCritMaxZ);
-    uad_gan* m = new uad_gan();
-    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->aae_kind = 7; m->chen = true; m->dim = dim; m->generic16 = false; m->e_sw = m->e_sb = -1;
-    m->a_constrained = true; m->a_critic = true; m->a_h1 = 400; m->a_h2 = 200;
-    m->npool = 3; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = true;
-    m->step[0] = m->step[1] = m->step[2] = 0;
-    char nm[160];
-    int ln = 0;
-    std::map<std::string, int> cnt;
-    auto ln_name = [&](const char* scope) { std::string r = std::string(scope) + (ln == 0 ? "layer_normalization" : "layer_normalization_" + std::to_string(ln)); ++ln; return r; };
-    auto tf_name = [&](const char* scope, const char* base) {
-        const std::string key = std::string(scope) + base;
-        const int k = cnt[key]++;
-        return k == 0 ? key : key + "_" + std::to_string(k);
-    };
-    auto make_block = [&](bool gen, const char* scope, int Hin, int Cin, int Cout, int stride) {
-        RB B;
-        memset(&B, 0, sizeof B);
-        B.gen = gen; B.stride = stride; B.Hin = Hin; B.Cin = Cin; B.Cout = Cout;
-        B.Hout = gen ? Hin * stride : Hin / stride;
-        std::string s1 = ln_name(scope);
-        B.ln1g = add_tensor(m, s1 + "/gamma", 2, Hin, Hin, 1, 1); B.ln1b = add_tensor(m, s1 + "/beta", 2, Hin, Hin, 1, 1);
-        std::string c1 = tf_name(scope, "conv2d");
-        B.w1 = add_tensor(m, c1 + "/kernel", 4, 3, 3, Cin, Cout); B.b1 = add_tensor(m, c1 + "/bias", 1, Cout, 1, 1, 1);
-        std::string s2 = ln_name(scope);
-        B.ln2g = add_tensor(m, s2 + "/gamma", 2, Hin, Hin, 1, 1); B.ln2b = add_tensor(m, s2 + "/beta", 2, Hin, Hin, 1, 1);
-        std::string c2 = tf_name(scope, gen ? "conv2d_transpose" : "conv2d");
-        B.w2 = add_tensor(m, c2 + "/kernel", 4, 3, 3, Cout, Cout); B.b2 = add_tensor(m, c2 + "/bias", 1, Cout, 1, 1, 1);
-        B.ws = B.bs = -1;
-        if (stride == 2) {
-            std::string sh = tf_name(scope, gen ? "conv2d_transpose" : "conv2d");
-            if (gen) B.ws = add_tensor(m, sh + "/kernel", 4, 1, 1, Cout, Cin); else B.ws = add_tensor(m, sh + "/kernel", 4, 1, 1, Cin, Cout);
-            B.bs = add_tensor(m, sh + "/bias", 1, Cout, 1, 1, 1);
-        }
-        B.d1 = UadConvDesc{1, Hin, Hin, Cin, Hin, Hin, Cout, 3, 1, 1};
-        const int P2 = stride == 1 ? 1 : 0;
-        if (gen) {
-            B.d2 = UadConvDesc{1, B.Hout, B.Hout, Cout, Hin, Hin, Cout, 3, stride, P2};
-            B.ds = UadConvDesc{1, B.Hout, B.Hout, Cout, Hin, Hin, Cin, 1, 2, 0};
-        } else {
-            B.d2 = UadConvDesc{1, Hin, Hin, Cout, B.Hout, B.Hout, Cout, 3, stride, P2};
-            B.ds = UadConvDesc{1, Hin, Hin, Cin, Hin, Hin, Cout, 1, 1, 0};
-        }
-        B.sx = (size_t)Hin * Hin * Cin; B.sc1 = (size_t)Hin * Hin * Cout; B.sout = (size_t)B.Hout * B.Hout * Cout;
-        return B;
-    };
-    // Encoder (:15-47, evaluate_encoder :128-151): conv2d, four blocks, dense
-    {
-        const std::string e0 = tf_name("Encoder/", "conv2d");
-        m->s_d0w = add_tensor(m, e0 + "/kernel", 4, 3, 3, 1, dim); m->s_d0b = add_tensor(m, e0 + "/bias", 1, dim, 1, 1, 1);
-        m->s_d0 = UadConvDesc{1, H, H, 1, H, H, dim, 3, 1, 1};
-        const int chans[4] = {2 * dim, 4 * dim, 8 * dim, 8 * dim}, strides[4] = {2, 2, 2, 1};
-        int c = dim, r = H;
-        for (int k = 0; k < 4; ++k) { m->DB.push_back(make_block(false, "Encoder/", r, c, chans[k], strides[k])); c = chans[k]; r /= strides[k]; }
-    }
-    const int flatg = ir * ir * 8 * dim;
-    m->flat = flatg; m->cenc = 8 * dim; m->cmid = 0;
-    m->e_cw = m->e_cb = -1;
-    m->e_dw = add_tensor(m, "Encoder/dense/kernel", 2, flatg, zd, 1, 1); m->e_db = add_tensor(m, "Encoder/dense/bias", 1, zd, 1, 1, 1);
-    const long long enc_end = m->nparams;
-    // Decoder (:49-83, evaluate_decoder :154-170)
-    m->g_dw = add_tensor(m, "Decoder/dense/kernel", 2, zd, flatg, 1, 1); m->g_db = add_tensor(m, "Decoder/dense/bias", 1, flatg, 1, 1, 1);
-    m->g_cw = m->g_cb = m->g_ln0g = m->g_ln0b = -1;
-    {
-        const int chans[4] = {8 * dim, 4 * dim, 2 * dim, dim}, strides[4] = {1, 2, 2, 2};
-        int c = 8 * dim, r = ir;
-        for (int k = 0; k < 4; ++k) { m->GB.push_back(make_block(true, "Decoder/", r, c, chans[k], strides[k])); c = chans[k]; r *= strides[k]; }
-        const std::string sl = ln_name("Decoder/");
-        m->s_glg = add_tensor(m, sl + "/gamma", 2, r, r, 1, 1); m->s_glb = add_tensor(m, sl + "/beta", 2, r, r, 1, 1);
-        const std::string gf = tf_name("Decoder/", "conv2d");
-        m->g_fw = add_tensor(m, gf + "/kernel", 4, 1, 1, c, 1); m->g_fb = add_tensor(m, gf + "/bias", 1, 1, 1, 1, 1);
-    }
-    const long long ae_end = m->nparams;
-    m->a_w1 = add_tensor(m, "Discriminator/dense/kernel", 2, zd, m->a_h1, 1, 1); m->a_b1 = add_tensor(m, "Discriminator/dense/bias", 1, m->a_h1, 1, 1, 1);
-    m->a_w2 = add_tensor(m, "Discriminator/dense_1/kernel", 2, m->a_h1, m->a_h2, 1, 1); m->a_b2 = add_tensor(m, "Discriminator/dense_1/bias", 1, m->a_h2, 1, 1, 1);
-    m->a_w3 = add_tensor(m, "Discriminator/dense_2/kernel", 2, m->a_h2, 1, 1, 1); m->a_b3 = add_tensor(m, "Discriminator/dense_2/bias", 1, 1, 1, 1, 1);
-    m->a_nd = m->nparams - ae_end;
-    m->grp_off[0] = 0; m->grp_cnt[0] = enc_end;          // optim_gen: 'Encoder' in var.name
-    m->grp_off[1] = 0; m->grp_cnt[1] = ae_end;           // optim_ae
-    m->grp_off[2] = ae_end; m->grp_cnt[2] = m->nparams - ae_end;
-
-    const size_t NB = (size_t)cfg->max_batch, E2 = 2 * NB, HW = (size_t)H * H;
-    int rc = UAD_OK;
-#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
-    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
-    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
-    ALLOC(m->adam_m2, (size_t)m->nparams, nullptr); ALLOC(m->adam_v2, (size_t)m->nparams, nullptr);
-    m->wpack_f = m->wpack_d = m->wpack16_f = m->wpack16_d = nullptr;
-    size_t maxact = NB * HW * dim, max_ta = 0, max_tb = 0, max_sp = 0;
-    auto alloc_block = [&](RB& B, float* X, float* DX, size_t cap, const char* tag, int k) {
-        B.X = X; B.DX = DX;
-        snprintf(nm, sizeof nm, "%s_h1_%d", tag, k); ALLOC(B.H1, cap * B.sx, nm);
-        snprintf(nm, sizeof nm, "%s_c1_%d", tag, k); ALLOC(B.C1, cap * B.sc1, nm);
-        snprintf(nm, sizeof nm, "%s_h2_%d", tag, k); ALLOC(B.H2, cap * B.sc1, nm);
-        snprintf(nm, sizeof nm, "%s_out_%d", tag, k); ALLOC(B.OUT, cap * B.sout, nm);
-        ALLOC(B.ST1, cap * 2 * B.Cin, nullptr); ALLOC(B.ST2, cap * 2 * B.Cout, nullptr);
-        ALLOC(B.DOUT, cap * B.sout, nullptr); ALLOC(B.G1, cap * B.sc1, nullptr);
-        if (!B.gen && B.ws >= 0) ALLOC(B.DSC, cap * B.sc1, nullptr);
-        ALLOC(B.LP1, cap * (B.Cin / 32) * 2 * B.Hin * B.Hin, nullptr);
-        ALLOC(B.LP2, cap * (B.Cout / 32) * 2 * B.Hin * B.Hin, nullptr);
-        if (NB * B.sc1 > max_ta) max_ta = NB * B.sc1;
-        if (NB * B.sx > max_tb) max_tb = NB * B.sx;
-        if (NB * B.sout > max_sp) max_sp = NB * B.sout;
-    };
-    ALLOC(m->din, E2 * HW, "din");
-    ALLOC(m->s_out0, E2 * HW * dim, "sd_out0"); ALLOC(m->s_dout0, E2 * HW * dim, nullptr);
-    {
-        float* X = m->s_out0; float* DX = m->s_dout0;
-        for (size_t k = 0; k < m->DB.size(); ++k) { alloc_block(m->DB[k], X, DX, E2, "sd", (int)k); X = m->DB[k].OUT; DX = m->DB[k].DOUT; }
-    }
-    ALLOC(m->s_g0, NB * flatg, "sg_x0"); ALLOC(m->s_dg0, NB * flatg, nullptr);
-    size_t lnp_g = 0;
-    {
-        float* X = m->s_g0; float* DX = m->s_dg0;
-        for (size_t k = 0; k < m->GB.size(); ++k) { alloc_block(m->GB[k], X, DX, NB, "sg", (int)k); X = m->GB[k].OUT; DX = m->GB[k].DOUT; }
-        const RB& L = m->GB.back();
-        ALLOC(m->s_hf, NB * L.sout, "sg_hf"); ALLOC(m->s_stf, NB * 2 * L.Cout, nullptr);
-        lnp_g = NB * (L.Cout / 32) * 2 * L.Hout * L.Hout;
-        if (NB * L.sout > maxact) maxact = NB * L.sout;
-    }
-    ALLOC(m->lnpart_g, lnp_g, nullptr);
-    ALLOC(m->s_ta, max_ta, nullptr); ALLOC(m->s_tb, max_tb, nullptr); ALLOC(m->s_sp, max_sp, nullptr); ALLOC(m->s_sct, max_ta, nullptr);
-    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
-    ALLOC(m->xg, NB * HW, "xg"); ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->Gx, NB * HW, "Gx"); ALLOC(m->a_xcat, E2 * HW, nullptr);
-    ALLOC(m->a_zm, E2 * zd, "z"); ALLOC(m->a_dzm, E2 * zd, nullptr); ALLOC(m->dzbuf, NB * zd, "dz"); ALLOC(m->dzr, NB * zd, nullptr);
-    ALLOC(m->a_slab, NB * (size_t)m->a_nd, nullptr); for (int k = 0; k < 3; ++k) ALLOC(m->a_crit[k], NB, nullptr);
-    {
-        size_t wp = 0, need = (size_t)4 << 20;
-        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
-        auto want = [&](UadConvDesc d, size_t n) { d.N = (int)n; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, false); if (v > need) need = v; } };
-        for (auto& B : m->GB) { wp_need(B.d1, NB); wp_need(B.d2, NB); want(B.d1, NB); want(B.d2, NB); if (B.ws >= 0) { wp_need(B.ds, NB); want(B.ds, NB); } }
-        for (auto& B : m->DB) { wp_need(B.d1, E2); wp_need(B.d2, E2); want(B.d1, NB); want(B.d2, NB); if (B.ws >= 0) { wp_need(B.ds, E2); want(B.ds, NB); } }
-        wp_need(dense_desc(1, flatg, zd), E2); wp_need(dense_desc(1, zd, flatg), NB);
-        want(dense_desc(1, flatg, zd), NB); want(dense_desc(1, zd, flatg), NB);
-        { UadConvDesc d0 = m->s_d0; d0.N = (int)E2; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
-        ALLOC(m->wpartial, wp, nullptr);
-        m->ws.floats = need; m->ws.ptr = nullptr;
-        ALLOC(m->ws.ptr, need, nullptr);
-    }
-    ALLOC(m->colscratch, 64 * 1024, nullptr); ALLOC(m->colpart, (size_t)kBnBwdBlocks * 2 * 128, nullptr);
-    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
-    ALLOC(m->finpart, (size_t)1024 * 520, nullptr);
-#undef ALLOC
-    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
-    *out = m;
-    return UAD_OK;
-}
-
-static int create_aae(const uad_gan_config_t* cfg, uad_gan_t** out) {
-    const int H = cfg->height, ir = cfg->inter_res;
-    if (cfg->aae_kind == 4 || cfg->aae_kind == 5) return create_zimmerer(cfg, out);
-    if (cfg->aae_kind == 6) return create_you(cfg, out);
-    if (cfg->aae_kind == 7) return create_chen(cfg, out);
-    if (cfg->aae_kind < 0 || cfg->aae_kind > 7) return fail(UAD_ERR_INVALID, "bad aae_kind");
-    const bool gmv = cfg->aae_kind == 3;
-    if (gmv) {
-        const long long q = (long long)cfg->zdim * cfg->dim;
-        if (cfg->dim_w < 1 || cfg->dim_w > 1024 || cfg->zdim < 1 || cfg->zdim > 1024 || cfg->dim < 1 || cfg->dim > 64 || q > 4096)
-            return fail(UAD_ERR_UNSUPPORTED, "dense GMVAE: 1 <= dim_w, dim_z <= 1024, 1 <= dim_c <= 64, dim_z * dim_c <= 4096");
-    }
-    const int npool = ilog2i(H) - ilog2i(ir);
-    if (npool < 2 || npool > 5) return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 2..5 blocks supported", npool);
-    if (!gmv && cfg->zdim > kCritMaxZ) return fail(UAD_ERR_UNSUPPORTED, "zDim <= %d", kCritMaxZ);
-    uad_gan* m = new uad_gan();
-    m->gmv = gmv; m->gm_W = cfg->dim_w; m->gm_Z = cfg->zdim; m->gm_C = cfg->dim; m->gm_J = 2 * cfg->dim_w + 2 * cfg->zdim;
-    m->cfg = *cfg; m->variant = UAD_GAN_AAE; m->dim = 0; m->generic16 = false; m->adam_m2 = m->adam_v2 = nullptr; m->e_sw = m->e_sb = -1;
-    m->aae_kind = cfg->aae_kind; m->a_constrained = cfg->aae_kind == 0 || cfg->aae_kind == 2; m->a_critic = cfg->aae_kind == 1 || cfg->aae_kind == 2;
-    m->a_h1 = cfg->aae_kind == 2 ? 100 : 50; m->a_h2 = 50;
-    m->npool = npool; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
-    m->step[0] = m->step[1] = m->step[2] = 0;
-    char nm[160];
-    int cin = 1, res = H;
-    for (int i = 0; i < npool; ++i) {
-        const int f = (32 << i) < 128 ? (32 << i) : 128;
-        Block L;
-        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
-        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
-        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
-        std::string bs = i == 0 ? "Encoder/batch_normalization" : "Encoder/batch_normalization_" + std::to_string(i);
-        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
-        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
-        L.H = L.W = res / 2; L.C = f;
-        m->E.push_back(L);
-        cin = f; res /= 2;
-    }
-    m->cenc = cin; m->cmid = cin / 8; m->flat = ir * ir * m->cmid;
-    if (m->cmid % 8 || m->flat % 8) { delete m; return fail(UAD_ERR_UNSUPPORTED, "bottleneck channels must be a multiple of 8"); }
-    const bool caae = cfg->aae_kind == 2;       // constrained_adversarial_autoencoder.py: conv2d / dense live in 'Encoder', dense (dec) / conv2d_1 in 'Decoder'
-    const std::string n_conv = caae ? "Encoder/conv2d" : "Bottleneck/conv2d", n_z = caae ? "Encoder/dense" : "Bottleneck/dense";
-    const std::string n_dec = caae ? "Decoder/dense" : "Bottleneck/dense_1", n_rev = caae ? "Decoder/conv2d_1" : "Bottleneck/conv2d_1";
-    m->a_cw = add_tensor(m, n_conv + "/kernel", 4, 1, 1, m->cenc, m->cmid); m->a_cb = add_tensor(m, n_conv + "/bias", 1, m->cmid, 1, 1, 1);
-    m->a_zw = m->a_zb = -1;
-    if (gmv) {
-        // layers take their scope name at first call (model :22-45): conv2d, dense .. dense_3 (w_mu, w_log_sigma, z_mu, z_log_sigma), dense_4 (dec_dense),
-        // conv2d_1; then, outside any scope, dense / dense_1 (p(z|w,c)) and the 0.1 Variable (:48-53)
-        const int hd[4] = {cfg->dim_w, cfg->dim_w, cfg->zdim, cfg->zdim};
-        int ofs = 0;
-        for (int h = 0; h < 4; ++h) {
-            const std::string nmh = h == 0 ? "Bottleneck/dense" : "Bottleneck/dense_" + std::to_string(h);
-            m->gm_hw[h] = add_tensor(m, nmh + "/kernel", 2, m->flat, hd[h], 1, 1); m->gm_hb[h] = add_tensor(m, nmh + "/bias", 1, hd[h], 1, 1, 1);
-            m->gm_hd[h] = hd[h]; m->gm_ho[h] = ofs; ofs += hd[h];
-        }
-    } else {
-        m->a_zw = add_tensor(m, n_z + "/kernel", 2, m->flat, cfg->zdim, 1, 1); m->a_zb = add_tensor(m, n_z + "/bias", 1, cfg->zdim, 1, 1, 1);
-    }
-    const long long gen_end_caae = m->nparams;        // 'Encoder' in name: blocks + conv2d + dense
-    long long gen_end = caae ? gen_end_caae : m->a_cw;  // AAE: the encoder blocks only (the bottleneck lives in 'Bottleneck')
-    const std::string n_dec2 = gmv ? "Bottleneck/dense_4" : n_dec;
-    m->a_dw = add_tensor(m, n_dec2 + "/kernel", 2, cfg->zdim, m->flat, 1, 1); m->a_db = add_tensor(m, n_dec2 + "/bias", 1, m->flat, 1, 1, 1);
-    m->a_rw = add_tensor(m, n_rev + "/kernel", 4, 1, 1, m->cmid, m->cenc); m->a_rb = add_tensor(m, n_rev + "/bias", 1, m->cenc, 1, 1, 1);
-    if (gmv) {
-        const int q = cfg->zdim * cfg->dim;
-        m->gm_mw = add_tensor(m, "dense/kernel", 2, cfg->dim_w, q, 1, 1); m->gm_mb = add_tensor(m, "dense/bias", 1, q, 1, 1, 1);
-        m->gm_lw = add_tensor(m, "dense_1/kernel", 2, cfg->dim_w, q, 1, 1); m->gm_lb = add_tensor(m, "dense_1/bias", 1, q, 1, 1, 1);
-        m->gm_var = add_tensor(m, "Variable", 1, q, 1, 1, 1);
-    }
-    m->a_dbng = add_tensor(m, "Decoder/batch_normalization/gamma", 1, m->cenc, 1, 1, 1);
-    m->a_dbnb = add_tensor(m, "Decoder/batch_normalization/beta", 1, m->cenc, 1, 1, 1);
-    cin = m->cenc; res = ir;
-    for (int i = 0; i < npool; ++i) {
-        const int f = (128 >> i) > 32 ? (128 >> i) : 32;
-        Block L;
-        L.d = UadConvDesc{1, res * 2, res * 2, f, res, res, cin, 5, 2, 1};
-        snprintf(nm, sizeof nm, "Decoder/dec_Conv2DT_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, f, cin);
-        snprintf(nm, sizeof nm, "Decoder/dec_Conv2DT_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
-        res *= 2;
-        const std::string bs = "Decoder/batch_normalization_" + std::to_string(i + 1);
-        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
-        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
-        L.H = L.W = res; L.C = f;
-        m->G.push_back(L);
-        cin = f;
-    }
-    m->g_fw = add_tensor(m, "Decoder/dec_Conv2D_final/kernel", 4, 1, 1, cin, 1);
-    m->g_fb = add_tensor(m, "Decoder/dec_Conv2D_final/bias", 1, 1, 1, 1, 1);
-    const long long ae_end = m->nparams;
-    m->a_w1 = m->a_b1 = m->a_w2 = m->a_b2 = m->a_w3 = m->a_b3 = -1; m->a_nd = 0;
-    if (m->a_critic) {
-        m->a_w1 = add_tensor(m, "Discriminator/dense/kernel", 2, cfg->zdim, m->a_h1, 1, 1); m->a_b1 = add_tensor(m, "Discriminator/dense/bias", 1, m->a_h1, 1, 1, 1);
-        m->a_w2 = add_tensor(m, "Discriminator/dense_1/kernel", 2, m->a_h1, m->a_h2, 1, 1); m->a_b2 = add_tensor(m, "Discriminator/dense_1/bias", 1, m->a_h2, 1, 1, 1);
-        m->a_w3 = add_tensor(m, "Discriminator/dense_2/kernel", 2, m->a_h2, 1, 1, 1); m->a_b3 = add_tensor(m, "Discriminator/dense_2/bias", 1, 1, 1, 1, 1);
-        m->a_nd = m->nparams - ae_end;
-    }
-    // groups: 0 = optim_gen ('Encoder' variables, a prefix), 1 = optim_ae (every autoencoder variable), 2 = optim_dis
-    m->grp_off[0] = 0; m->grp_cnt[0] = gen_end;
-    m->grp_off[1] = 0; m->grp_cnt[1] = ae_end;
-    m->grp_off[2] = ae_end; m->grp_cnt[2] = m->nparams - ae_end;
-
-    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H, E2 = m->a_constrained ? 2 * NB : NB;
-    int rc = UAD_OK;
-#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
-    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
-    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
-    ALLOC(m->adam_m2, (size_t)m->nparams, nullptr); ALLOC(m->adam_v2, (size_t)m->nparams, nullptr);
-    ALLOC(m->wpack_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack_d, (size_t)m->nparams, nullptr);
-    ALLOC(m->wpack16_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack16_d, (size_t)m->nparams, nullptr);
-    size_t maxact = NB * HW;
-    m->ec.resize(npool); m->ea.resize(npool + 1, nullptr); m->a_eg.resize(npool); m->a_cp.resize(npool);
-    for (int i = 0; i < npool; ++i) {
-        const size_t sz = E2 * asz(m->E[i]);
-        snprintf(nm, sizeof nm, "ec%d", i); ALLOC(m->ec[i], sz, nm);
-        snprintf(nm, sizeof nm, "ea%d", i + 1); ALLOC(m->ea[i + 1], sz, nm);
-        ALLOC(m->a_eg[i], sz, nullptr);
-        ALLOC(m->a_cp[i], (size_t)2 * kBnBwdBlocks * 2 * m->E[i].C, nullptr);
-        if (NB * asz(m->E[i]) > maxact) maxact = NB * asz(m->E[i]);
-    }
-    ALLOC(m->et, E2 * m->flat, "et"); ALLOC(m->a_zm, E2 * cfg->zdim, "z"); ALLOC(m->a_dzm, E2 * cfg->zdim, nullptr);
-    ALLOC(m->a_dflat, E2 * m->flat, nullptr); ALLOC(m->a_xcat, E2 * HW, nullptr);
-    ALLOC(m->gdv, NB * m->flat, "gdv"); ALLOC(m->xg, NB * HW, "xg"); ALLOC(m->ddv, NB * m->flat, nullptr);
-    m->gc.resize(npool + 1); m->ga.resize(npool + 1);
-    for (int i = 0; i <= npool; ++i) {
-        const size_t per = i == 0 ? (size_t)ir * ir * m->cenc : asz(m->G[i - 1]);
-        snprintf(nm, sizeof nm, "gc%d", i); ALLOC(m->gc[i], NB * per, nm);
-        snprintf(nm, sizeof nm, "ga%d", i); ALLOC(m->ga[i], NB * per, nm);
-        if (NB * per > maxact) maxact = NB * per;
-    }
-    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
-    ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->Gx, NB * HW, "Gx"); ALLOC(m->dzbuf, NB * cfg->zdim, "dz"); ALLOC(m->dzr, NB * cfg->zdim, nullptr);
-    m->a_slab = nullptr; m->a_crit[0] = m->a_crit[1] = m->a_crit[2] = nullptr;
-    if (m->a_critic) { ALLOC(m->a_slab, NB * (size_t)m->a_nd, nullptr); for (int k = 0; k < 3; ++k) ALLOC(m->a_crit[k], NB, nullptr); }
-    m->gm_hv = m->gm_hvm = m->gm_ws = m->gm_M = m->gm_Lq = m->gm_pc = m->gm_loss3 = m->gm_dhv = m->gm_dM = m->gm_dLq = m->gm_dxhat = nullptr;
-    if (gmv) {
-        const size_t q = (size_t)cfg->zdim * cfg->dim;
-        ALLOC(m->gm_hv, NB * m->gm_J, "hv"); ALLOC(m->gm_hvm, NB * m->gm_J, "hvm"); ALLOC(m->gm_ws, NB * cfg->dim_w, "w_s");
-        ALLOC(m->gm_M, NB * q, "M"); ALLOC(m->gm_Lq, NB * q, "Lq"); ALLOC(m->gm_pc, NB * cfg->dim, "pc"); ALLOC(m->gm_loss3, 3 * NB, nullptr);
-        ALLOC(m->gm_dhv, NB * m->gm_J, "dhv"); ALLOC(m->gm_dM, NB * q, nullptr); ALLOC(m->gm_dLq, NB * q, nullptr); ALLOC(m->gm_dxhat, NB * HW, nullptr);
-    }
-    {
-        size_t wp = 0, need = (size_t)4 << 20;
-        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
-        auto want = [&](UadConvDesc d, size_t n, bool pack) { d.N = (int)n; for (int f = 0; f < 2; ++f) { size_t v = uad_conv_ws_floats(d, f != 0, pack); if (v > need) need = v; } };
-        for (size_t i = 1; i < m->E.size(); ++i) { wp_need(m->E[i].d, E2); want(m->E[i].d, NB, true); }
-        for (auto& L : m->G) { wp_need(L.d, NB); want(L.d, NB, true); }
-        wp_need(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), E2); wp_need(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB);
-        want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), NB, false); want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB, false);
-        if (!gmv) {
-            wp_need(dense_desc(1, m->flat, cfg->zdim), E2); wp_need(dense_desc(1, cfg->zdim, m->flat), NB);
-            want(dense_desc(1, m->flat, cfg->zdim), NB, false); want(dense_desc(1, cfg->zdim, m->flat), NB, false);
-        }
-        { UadConvDesc d0 = m->E[0].d; d0.N = (int)E2; size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
-        ALLOC(m->wpartial, wp, nullptr);
-        m->ws.floats = need; m->ws.ptr = nullptr;
-        ALLOC(m->ws.ptr, need, nullptr);
-    }
-    ALLOC(m->colscratch, 64 * 1024, nullptr); ALLOC(m->colpart, (size_t)kBnBwdBlocks * 2 * 128, nullptr);
-    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
-    ALLOC(m->finpart, (size_t)1024 * 65, nullptr);
-#undef ALLOC
-    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
-    *out = m;
-    return UAD_OK;
-}
-
-int uad_gan_create(const uad_gan_config_t* cfg, uad_gan_t** out) {
-    if (!cfg || !out) return fail(UAD_ERR_INVALID, "null argument");
-    const int H = cfg->height;
-    if (H != cfg->width || H <= 0 || (H & (H - 1))) return fail(UAD_ERR_INVALID, "height/width must be equal powers of two");
-    if (cfg->inter_res <= 0 || (cfg->inter_res & (cfg->inter_res - 1)) || cfg->inter_res >= H)
-        return fail(UAD_ERR_INVALID, "inter_res must be a power of two smaller than height");
-    if (cfg->channels != 1) return fail(UAD_ERR_UNSUPPORTED, "numChannels=%d: only 1 is supported", cfg->channels);
-    const bool dense_gmvae = cfg->variant == UAD_GAN_AAE && (cfg->aae_kind == 3 || cfg->aae_kind == 6);      // its latent widths are free (skinny-dense kernels)
-    if (!dense_gmvae && (cfg->zdim <= 0 || cfg->zdim % 8)) return fail(UAD_ERR_UNSUPPORTED, "zDim must be a positive multiple of 8");
-    if (cfg->max_batch <= 0) return fail(UAD_ERR_INVALID, "max_batch must be positive");
-    if (cfg->variant != UAD_GAN_UNIFIED && cfg->variant != UAD_GAN_RESNET && cfg->variant != UAD_GAN_ANOVAEGAN && cfg->variant != UAD_GAN_AAE)
-        return fail(UAD_ERR_INVALID, "bad variant");
-    if (cfg->variant == UAD_GAN_AAE) return create_aae(cfg, out);
-    if (cfg->variant == UAD_GAN_RESNET) return create_resnet(cfg, out);
-    const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
-    if (npool < 2 || npool > 5) return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 2..5 blocks supported", npool);
-    if (H < 32) return fail(UAD_ERR_UNSUPPORTED, "height >= 32 needed");
-
-    uad_gan* m = new uad_gan();
-    m->cfg = *cfg; m->variant = cfg->variant; m->dim = 0; m->generic16 = false;
-    const bool av = cfg->variant == UAD_GAN_ANOVAEGAN;
-    m->npool = npool; m->nparams = 0; m->math = UAD_MATH_F32; m->packed_valid = false;
-    m->step[0] = m->step[1] = m->step[2] = 0;
-    const int ir = cfg->inter_res;
-    char nm[160];
-    // ---- parameter table, TF variable-creation order (fanogan.py:15-58) ----
-    int cin = 1, res = H;
-    for (int i = 0; i < npool; ++i) {
-        const int f = (32 << i) < 128 ? (32 << i) : 128;
-        Block L;
-        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
-        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
-        snprintf(nm, sizeof nm, "Encoder/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
-        std::string bs = i == 0 ? "Encoder/batch_normalization" : "Encoder/batch_normalization_" + std::to_string(i);
-        L.gamma = add_tensor(m, bs + "/gamma", 1, f, 1, 1, 1);
-        L.beta = add_tensor(m, bs + "/beta", 1, f, 1, 1, 1);
-        L.H = L.W = res / 2; L.C = f;
-        m->E.push_back(L);
-        cin = f; res /= 2;
-    }
-    m->cenc = cin; m->cmid = cin / 8; m->flat = ir * ir * m->cmid;
-    m->e_cw = add_tensor(m, "Encoder/conv2d/kernel", 4, 1, 1, m->cenc, m->cmid);
-    m->e_cb = add_tensor(m, "Encoder/conv2d/bias", 1, m->cmid, 1, 1, 1);
-    m->e_dw = add_tensor(m, "Encoder/dense/kernel", 2, m->flat, cfg->zdim, 1, 1);
-    m->e_db = add_tensor(m, "Encoder/dense/bias", 1, cfg->zdim, 1, 1, 1);
-    m->e_sw = m->e_sb = -1;
-    if (av) {
-        m->e_sw = add_tensor(m, "Encoder/dense_1/kernel", 2, m->flat, cfg->zdim, 1, 1);
-        m->e_sb = add_tensor(m, "Encoder/dense_1/bias", 1, cfg->zdim, 1, 1, 1);
-    }
-    m->grp_off[UAD_GAN_ENCODER] = 0; m->grp_cnt[UAD_GAN_ENCODER] = m->nparams;
-    m->g_dw = add_tensor(m, "Generator/dense/kernel", 2, cfg->zdim, m->flat, 1, 1);
-    m->g_db = add_tensor(m, "Generator/dense/bias", 1, m->flat, 1, 1, 1);
-    m->g_cw = add_tensor(m, "Generator/conv2d_1/kernel", 4, 1, 1, m->cmid, m->cenc);
-    m->g_cb = add_tensor(m, "Generator/conv2d_1/bias", 1, m->cenc, 1, 1, 1);
-    int ln = 0;
-    auto ln_name = [&](const char* scope) { std::string r = std::string(scope) + (ln == 0 ? "layer_normalization" : "layer_normalization_" + std::to_string(ln)); ++ln; return r; };
-    { const std::string s = ln_name("Generator/"); m->g_ln0g = add_tensor(m, s + "/gamma", 2, ir, ir, 1, 1); m->g_ln0b = add_tensor(m, s + "/beta", 2, ir, ir, 1, 1); }
-    cin = m->cenc; res = ir;
-    for (int i = 0; i < npool; ++i) {
-        const int f = (128 >> i) > 32 ? (128 >> i) : 32;
-        Block L;
-        L.d = UadConvDesc{1, res * 2, res * 2, f, res, res, cin, 5, 2, 1};
-        snprintf(nm, sizeof nm, "Generator/dec_Conv2DT_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, f, cin);
-        snprintf(nm, sizeof nm, "Generator/dec_Conv2DT_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
-        res *= 2;
-        const std::string s = ln_name("Generator/");
-        L.gamma = add_tensor(m, s + "/gamma", 2, res, res, 1, 1);
-        L.beta = add_tensor(m, s + "/beta", 2, res, res, 1, 1);
-        L.H = L.W = res; L.C = f;
-        m->G.push_back(L);
-        cin = f;
-    }
-    m->g_fw = add_tensor(m, "Generator/dec_Conv2D_final/kernel", 4, 1, 1, cin, 1);
-    m->g_fb = add_tensor(m, "Generator/dec_Conv2D_final/bias", 1, 1, 1, 1, 1);
-    m->grp_off[UAD_GAN_GENERATOR] = m->grp_cnt[UAD_GAN_ENCODER];
-    m->grp_cnt[UAD_GAN_GENERATOR] = m->nparams - m->grp_off[UAD_GAN_GENERATOR];
-    cin = 1; res = H;
-    for (int i = 0; i < npool; ++i) {
-        const int f = (32 << i) < 128 ? (32 << i) : 128;
-        Block L;
-        L.d = UadConvDesc{1, res, res, cin, res / 2, res / 2, f, 5, 2, 1};
-        snprintf(nm, sizeof nm, "Discriminator/enc_conv2D_%d/kernel", i); L.w = add_tensor(m, nm, 4, 5, 5, cin, f);
-        snprintf(nm, sizeof nm, "Discriminator/enc_conv2D_%d/bias", i); L.b = add_tensor(m, nm, 1, f, 1, 1, 1);
-        res /= 2;
-        const std::string s = ln_name("Discriminator/");
-        L.gamma = add_tensor(m, s + "/gamma", 2, res, res, 1, 1);
-        L.beta = add_tensor(m, s + "/beta", 2, res, res, 1, 1);
-        L.H = L.W = res; L.C = f;
-        m->D.push_back(L);
-        cin = f;
-    }
-    m->d_hw = add_tensor(m, "Discriminator/dense/kernel", 2, cin, 1, 1, 1);
-    m->d_hb = add_tensor(m, "Discriminator/dense/bias", 1, 1, 1, 1, 1);
-    m->grp_off[UAD_GAN_DISCRIMINATOR] = m->grp_off[UAD_GAN_GENERATOR] + m->grp_cnt[UAD_GAN_GENERATOR];
-    m->grp_cnt[UAD_GAN_DISCRIMINATOR] = m->nparams - m->grp_off[UAD_GAN_DISCRIMINATOR];
-    if (m->cmid % 8 || m->flat % 8) { delete m; return fail(UAD_ERR_UNSUPPORTED, "bottleneck channels must be a multiple of 8"); }
-
-    // ---- device memory ----
-    const size_t NB = (size_t)cfg->max_batch, HW = (size_t)H * H;
-    int rc = UAD_OK;
-#define ALLOC(ptr, n, name) if (rc == UAD_OK) rc = dev_alloc(m, &(ptr), (n), name)
-    ALLOC(m->params, (size_t)m->nparams, "params"); ALLOC(m->grads, (size_t)m->nparams, "grads");
-    ALLOC(m->adam_m, (size_t)m->nparams, nullptr); ALLOC(m->adam_v, (size_t)m->nparams, nullptr);
-    ALLOC(m->wpack_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack_d, (size_t)m->nparams, nullptr);
-    ALLOC(m->wpack16_f, (size_t)m->nparams, nullptr); ALLOC(m->wpack16_d, (size_t)m->nparams, nullptr);
-    size_t maxact = 3 * NB * HW;
-    m->ec.resize(npool); m->ea.resize(npool + 1, nullptr);
-    for (int i = 0; i < npool; ++i) {
-        const size_t s = NB * asz(m->E[i]);
-        snprintf(nm, sizeof nm, "ec%d", i); ALLOC(m->ec[i], s, nm);
-        snprintf(nm, sizeof nm, "ea%d", i + 1); ALLOC(m->ea[i + 1], s, nm);
-        if (s > maxact) maxact = s;
-    }
-    ALLOC(m->et, NB * m->flat, "et"); ALLOC(m->zr, NB * cfg->zdim, "zr"); ALLOC(m->z, NB * cfg->zdim, "z");
-    ALLOC(m->gdv, NB * m->flat, "gdv"); ALLOC(m->xg, NB * HW, "xg");
-    m->adam_m2 = m->adam_v2 = nullptr;
-    if (av) {
-        const size_t nz = NB * cfg->zdim;
-        ALLOC(m->adam_m2, (size_t)m->nparams, nullptr); ALLOC(m->adam_v2, (size_t)m->nparams, nullptr);
-        ALLOC(m->v_mu_raw, nz, nullptr); ALLOC(m->v_ls_raw, nz, nullptr); ALLOC(m->v_mu, nz, "v_mu"); ALLOC(m->v_ls, nz, nullptr);
-        ALLOC(m->v_sigma, nz, "v_sigma"); ALLOC(m->v_kl, NB, nullptr); ALLOC(m->v_dmu, nz, nullptr); ALLOC(m->v_dls, nz, nullptr);
-        ALLOC(m->v_dflat2, NB * m->flat, nullptr);
-    }
-    m->gc.resize(npool + 1); m->ga.resize(npool + 1); m->gstat.resize(npool + 1);
-    size_t lnp_g = 0;
-    for (int i = 0; i <= npool; ++i) {
-        const size_t per = i == 0 ? (size_t)ir * ir * m->cenc : asz(m->G[i - 1]);
-        const int C = i == 0 ? m->cenc : m->G[i - 1].C;
-        snprintf(nm, sizeof nm, "gc%d", i); ALLOC(m->gc[i], NB * per, nm);
-        snprintf(nm, sizeof nm, "ga%d", i); ALLOC(m->ga[i], NB * per, nm);
-        ALLOC(m->gstat[i], NB * 2 * C, nullptr);
-        if (NB * per > maxact) maxact = NB * per;
-        const size_t lp = NB * (C / 32) * 2 * (per / C);
-        if (lp > lnp_g) lnp_g = lp;
-    }
-    ALLOC(m->lnpart_g, lnp_g, nullptr);
-    ALLOC(m->din, 4 * NB * HW, "din");
-    m->Dc.resize(npool); m->Dstat.resize(npool); m->Da.resize(npool + 1, nullptr); m->Dg.resize(npool); m->V.resize(npool);
-    m->inj.resize(npool); m->lnpart.resize(npool);
-    size_t maxc = 0;
-    for (int i = 0; i < npool; ++i) {
-        const Block& L = m->D[i];
-        const size_t per = asz(L);
-        snprintf(nm, sizeof nm, "Dc%d", i); ALLOC(m->Dc[i], 3 * NB * per, nm);
-        ALLOC(m->Dstat[i], 3 * NB * 2 * L.C, nullptr);
-        snprintf(nm, sizeof nm, "Da%d", i + 1); ALLOC(m->Da[i + 1], 4 * NB * per, nm);
-        snprintf(nm, sizeof nm, "Dg%d", i); ALLOC(m->Dg[i], 4 * NB * per, nm);
-        snprintf(nm, sizeof nm, "V%d", i); ALLOC(m->V[i], NB * per, nm);
-        snprintf(nm, sizeof nm, "inj%d", i); ALLOC(m->inj[i], NB * per, nm);
-        ALLOC(m->lnpart[i], 4 * NB * (L.C / 32) * 2 * L.H * L.W, nullptr);
-        if (3 * NB * per > maxact) maxact = 3 * NB * per;
-        if (per > maxc) maxc = per;
-    }
-    ALLOC(m->Q, NB * maxc, "Q");
-    ALLOC(m->Dd, 3 * NB * ir * ir, "Dd"); ALLOC(m->Gx, NB * HW, "Gx"); ALLOC(m->slopes, NB * H, "slopes");
-    ALLOC(m->Ga, maxact, "Ga"); ALLOC(m->Gb, maxact, "Gb");
-    ALLOC(m->dxbuf, NB * HW, "dx"); ALLOC(m->dzbuf, NB * cfg->zdim, "dz"); ALLOC(m->dzr, NB * cfg->zdim, nullptr);
-    ALLOC(m->dflat, NB * m->flat, nullptr); ALLOC(m->ddv, NB * m->flat, nullptr);
-    {
-        size_t wp = 0;
-        auto wp_need = [&](UadConvDesc d, size_t n) { d.N = (int)n; size_t v = uad_conv_w_partial_floats(d); if (v > wp) wp = v; };
-        for (size_t i = 1; i < m->E.size(); ++i) wp_need(m->E[i].d, NB);
-        for (auto& L : m->G) wp_need(L.d, NB);
-        for (size_t i = 1; i < m->D.size(); ++i) wp_need(m->D[i].d, 4 * NB);
-        wp_need(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), NB); wp_need(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB);
-        wp_need(dense_desc(1, m->flat, cfg->zdim), NB); wp_need(dense_desc(1, cfg->zdim, m->flat), NB);
-        { UadConvDesc d0 = m->D[0].d; d0.N = (int)(4 * NB); size_t v = uad_conv_first_wgrad_partial_floats(d0); if (v > wp) wp = v; }
-        ALLOC(m->wpartial, wp, nullptr);
-        size_t need = (size_t)4 << 20;
-        auto want = [&](UadConvDesc d, size_t n, bool f, bool pack) { d.N = (int)n; size_t v = uad_conv_ws_floats(d, f, pack); if (v > need) need = v; };
-        for (size_t i = 1; i < m->E.size(); ++i) { want(m->E[i].d, NB, true, true); want(m->E[i].d, NB, false, true); }
-        for (auto& L : m->G) { want(L.d, NB, true, true); want(L.d, NB, false, true); }
-        for (size_t i = 1; i < m->D.size(); ++i) { want(m->D[i].d, 3 * NB, true, true); want(m->D[i].d, 3 * NB, false, true); want(m->D[i].d, NB, true, true); want(m->D[i].d, NB, false, true); }
-        for (int f = 0; f < 2; ++f) {
-            want(conv1x1_desc(1, ir, ir, m->cenc, m->cmid), NB, f, false); want(conv1x1_desc(1, ir, ir, m->cmid, m->cenc), NB, f, false);
-            want(dense_desc(1, m->flat, cfg->zdim), NB, f, false); want(dense_desc(1, cfg->zdim, m->flat), NB, f, false);
-        }
-        m->ws.floats = need; m->ws.ptr = nullptr;
-        ALLOC(m->ws.ptr, need, nullptr);
-    }
-    ALLOC(m->colscratch, 64 * 1024, nullptr); ALLOC(m->colpart, (size_t)kBnBwdBlocks * 2 * 128, nullptr);
-    ALLOC(m->redpart, 1024, nullptr); ALLOC(m->raw, 16, "raw"); ALLOC(m->scalars_own, 16, nullptr);
-    ALLOC(m->finpart, (size_t)1024 * 65, nullptr);
-#undef ALLOC
-    if (rc != UAD_OK) { uad_gan_destroy(m); return rc; }
-    *out = m;
-    return UAD_OK;
-}
+#include "uad_gan_create.inc"
 
 int uad_gan_destroy(uad_gan_t* m) {
     if (!m) return UAD_OK;
