@@ -813,7 +813,7 @@ void g_conv_d(uad_gan* m, UadConvDesc d, int N, const float* small_in, long long
 }
 void g_conv_w(uad_gan* m, UadConvDesc d, int N, const float* big, const float* small_, long long w, hipStream_t st) {
     d.N = N;
-    uad_launch_conv_w(d, big, no_xform(), small_, no_xform(), Gr(m, w), m->wpartial, st);
+    uad_launch_conv_w(d, big, no_xform(), small_, no_xform(), Gr(m, w), m->wpartial, st, false, nullptr, nullptr, m->generic16);
 }
 void avgpool_fwd(const float* x, int N, int H, int C, float* y, hipStream_t st) {
     const size_t t4 = (size_t)N * (H / 2) * (H / 2) * C / 4;

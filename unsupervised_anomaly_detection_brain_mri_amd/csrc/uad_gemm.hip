@@ -2373,6 +2373,157 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_w_kernel(const ConvWArgs 
         }
 }
 
+
+// ---- generic filter gradient in bf16x3 math (UAD_MATH_BF16X3_ALL): both operands arrive position-major ([k = position][channels]) and the
+// matrix cores want channel-major rows with K contiguous, so each thread owns PAIRS of adjacent positions and stores (k, k+1) as one
+// 32-bit word per channel into the hi | lo bf16 planes; a K = 16 slice is three v_mfma_f32_32x32x16_bf16.  Identity activation-on-load only.
+template <int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv_w16_kernel(const ConvWArgs a) {
+    constexpr int BK = 32, NT = 64 * WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int FM = WTM / 32, FN = WTN / 32;
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+    constexpr int LDK = BK + 8;
+    constexpr int A_EL = BM * LDK, B_EL = BN * LDK, STAGE = 2 * A_EL + 2 * B_EL;     // A hi | A lo | B hi | B lo
+    __shared__ __attribute__((aligned(16))) unsigned short smem16[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const UadConvDesc& d = a.d;
+    const int kbeg = blockIdx.z * a.kper;
+    const int kend = min(kbeg + a.kper, a.Kt);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    constexpr int TPRA = BM / 4, RPA = NT / TPRA, PA = BK / RPA;
+    constexpr int TPRB = BN / 4, RPB = NT / TPRB, PB = BK / RPB;
+    static_assert(PA % 2 == 0 && PB % 2 == 0 && PA * RPA == BK && PB * RPB == BK, "each thread owns pairs of adjacent positions");
+    const int acol = (tid % TPRA) * 4, arow0 = tid / TPRA;
+    const int bcol = (tid % TPRB) * 4, brow0 = tid / TPRB;
+    auto arow = [&](int q) { return 2 * arow0 + (q & 1) + 2 * RPA * (q >> 1); };
+    auto brow = [&](int q) { return 2 * brow0 + (q & 1) + 2 * RPB * (q >> 1); };
+    const int mcol = m0 + acol;
+    const bool acolok = mcol < a.Mtot;
+    const int tapA = acolok ? mcol / d.CB : 0;
+    const int cbA = acolok ? mcol - tapA * d.CB : 0;
+    const int kyA = tapA / d.KS, kxA = tapA - kyA * d.KS;
+    const int ncol = n0 + bcol;
+    const bool bcolok = ncol < d.CS;
+
+    float4 va[PA], vb[PB];
+    auto load_tiles = [&](int kpos) {
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int pos = kpos + arow(q);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos < kend && acolok) {
+                int n, i, j;
+                decode_pos(pos, d.HS, d.WS, a.lhs, a.lws, n, i, j);
+                const int y = d.S * i - d.P + kyA, x = d.S * j - d.P + kxA;
+                if ((unsigned)y < (unsigned)d.HB && (unsigned)x < (unsigned)d.WB)
+                    v = *reinterpret_cast<const float4*>(a.big + ((size_t)(n * d.HB + y) * d.WB + x) * d.CB + cbA);
+            }
+            va[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int pos = kpos + brow(q);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos < kend && bcolok) v = *reinterpret_cast<const float4*>(a.small_ + (size_t)pos * d.CS + ncol);
+            vb[q] = v;
+        }
+    };
+    // (k, k+1) of four channels -> four 32-bit words per plane
+    auto store_pair = [&](unsigned short* ph, unsigned short* pl, int col, int k, const float4 v0, const float4 v1) {
+        uint2 h0, l0, h1, l1;
+        split_bf16(v0, h0, l0);
+        split_bf16(v1, h1, l1);
+        const unsigned hh0[4] = {h0.x & 0xFFFFu, h0.x >> 16, h0.y & 0xFFFFu, h0.y >> 16};
+        const unsigned hh1[4] = {h1.x & 0xFFFFu, h1.x >> 16, h1.y & 0xFFFFu, h1.y >> 16};
+        const unsigned ll0[4] = {l0.x & 0xFFFFu, l0.x >> 16, l0.y & 0xFFFFu, l0.y >> 16};
+        const unsigned ll1[4] = {l1.x & 0xFFFFu, l1.x >> 16, l1.y & 0xFFFFu, l1.y >> 16};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<unsigned*>(ph + (col + i) * LDK + k) = hh0[i] | (hh1[i] << 16);
+            *reinterpret_cast<unsigned*>(pl + (col + i) * LDK + k) = ll0[i] | (ll1[i] << 16);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned short* sAh = smem16 + buf * STAGE;
+        unsigned short* sAl = sAh + A_EL;
+        unsigned short* sBh = sAl + A_EL;
+        unsigned short* sBl = sBh + B_EL;
+#pragma unroll
+        for (int q = 0; q < PA; q += 2) store_pair(sAh, sAl, acol, arow(q), va[q], va[q + 1]);
+#pragma unroll
+        for (int q = 0; q < PB; q += 2) store_pair(sBh, sBl, bcol, brow(q), vb[q], vb[q + 1]);
+    };
+
+    v16f acc[FM][FN];
+#pragma unroll
+    for (int im = 0; im < FM; ++im)
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[im][jn][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (nk > 0) {
+        load_tiles(kbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        const bool more = ks + 1 < nk;
+        if (more) load_tiles(kbeg + (ks + 1) * BK);
+        const unsigned short* sAh = smem16 + buf * STAGE;
+        const unsigned short* sAl = sAh + A_EL;
+        const unsigned short* sBh = sAl + A_EL;
+        const unsigned short* sBl = sBh + B_EL;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            uint4 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+            for (int im = 0; im < FM; ++im) {
+                const int o = (wm * WTM + im * 32 + l31) * LDK + kk * 16 + 8 * lh;
+                ah[im] = *reinterpret_cast<const uint4*>(sAh + o);
+                al[im] = *reinterpret_cast<const uint4*>(sAl + o);
+            }
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                const int o = (wn * WTN + jn * 32 + l31) * LDK + kk * 16 + 8 * lh;
+                bh[jn] = *reinterpret_cast<const uint4*>(sBh + o);
+                bl[jn] = *reinterpret_cast<const uint4*>(sBl + o);
+            }
+#pragma unroll
+            for (int im = 0; im < FM; ++im)
+#pragma unroll
+                for (int jn = 0; jn < FN; ++jn) {
+                    acc[im][jn] = mfma_bf16(ah[im], bh[jn], acc[im][jn]);
+                    acc[im][jn] = mfma_bf16(ah[im], bl[jn], acc[im][jn]);
+                    acc[im][jn] = mfma_bf16(al[im], bh[jn], acc[im][jn]);
+                }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.partial + (size_t)blockIdx.z * a.Mtot * d.CS;
+#pragma unroll
+    for (int im = 0; im < FM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= a.Mtot) continue;
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                const int col = n0 + wn * WTN + jn * 32 + l31;
+                if (col < d.CS) out[(size_t)m * d.CS + col] = acc[im][jn][r];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k5 s2 SAME filter gradient, spatial form: one workgroup owns a 32(cb) x 32(cs) channel block and walks a list of
 // 8x8 tiles of the small image.  Per tile the big halo tile [19x19][32] and the small tile [64][32] are staged in LDS
@@ -2985,7 +3136,7 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
 }
 
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
-                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev) {
+                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev, bool generic_bf16x3) {
     // reduce_st/ev (optional): run the split-K slab reduction on a second stream, ordered after the main kernel by `ev`
     auto hop = [&]() -> hipStream_t {
         if (!reduce_st) return st;
@@ -3040,7 +3191,13 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
     a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = c.kper;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;
     dim3 grid((a.Mtot + c.BM - 1) / c.BM, (d.CS + c.BN - 1) / c.BN, c.splits);
-    if (c.BM == 128 && c.BN == 64)
+    static const bool w16_ok = !getenv("UAD_NO_W16");
+    const bool w16 = generic_bf16x3 && w16_ok && !xfb.scale && !xfs.scale && c.BN == 64 && d.CB % 4 == 0 && d.CS % 4 == 0;
+    if (w16 && c.BM == 128)
+        hipLaunchKernelGGL((conv_w16_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, a);
+    else if (w16 && c.BM == 64)
+        hipLaunchKernelGGL((conv_w16_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
+    else if (c.BM == 128 && c.BN == 64)
         hipLaunchKernelGGL((conv_w_kernel<128, 64, 32, 2, 2>), grid, dim3(256), 0, st, a);
     else if (c.BM == 128 && c.BN == 32)
         hipLaunchKernelGGL((conv_w_kernel<128, 32, 32, 4, 1>), grid, dim3(256), 0, st, a);

@@ -102,7 +102,7 @@ size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack);
 size_t uad_conv_w_partial_floats(const UadConvDesc& d);
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
                        float* dW, float* partial, hipStream_t st, bool math_bf16x3 = false,
-                       hipStream_t reduce_st = nullptr, hipEvent_t ev = nullptr);
+                       hipStream_t reduce_st = nullptr, hipEvent_t ev = nullptr, bool generic_bf16x3 = false);
 
 // out[j] = scale * sum_{s<S} partial[s*L + j]
 void uad_launch_reduce_partials(const float* partial, int S, int L, float scale, float* out, hipStream_t st);

@@ -1228,7 +1228,7 @@ int uad_op_conv_w(const uad_conv_desc_t* dd, const float* big, const uad_xform_t
     float* partial = nullptr;
     HIP_TRY(hipMalloc((void**)&partial, uad_conv_w_partial_floats(d) * sizeof(float)));
     hipStream_t st = (hipStream_t)stream;
-    uad_launch_conv_w(d, big, to_xf(xfb), small_, to_xf(xfs), dW, partial, st, op_bf16x3());
+    uad_launch_conv_w(d, big, to_xf(xfb), small_, to_xf(xfs), dW, partial, st, op_bf16x3(), nullptr, nullptr, op_bf16x3());
     HIP_TRY(hipStreamSynchronize(st));
     hipFree(partial);
     HIP_TRY(hipGetLastError());
