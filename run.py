@@ -30,7 +30,14 @@ def main(args):
     options = get_options(batchsize=args.batchsize, learningrate=args.lr, numEpochs=args.numEpochs, zDim=args.zDim,
                           outputWidth=args.outputWidth, outputHeight=args.outputHeight, slices_start=args.slices_start,
                           slices_end=args.slices_end, numMonteCarloSamples=args.numMonteCarloSamples, config=json_config)
-    dataset_hc, dataset_pc = get_datasets(options, dataset=Dataset.BRAINWEB)
+    if args.cache:
+        # a slice cache built from real volumes (tools/build_cache.py, utils/nifti.py): HBM-resident training set, per-patient TEST volumes
+        from unsupervised_anomaly_detection_brain_mri_amd.utils.slice_cache import DeviceDataset
+        dataset_hc = DeviceDataset.from_cache(args.cache)
+        if tuple(dataset_hc.shape[1:3]) != (args.outputHeight, args.outputWidth):
+            raise SystemExit(f'cache slices are {dataset_hc.shape[1]}x{dataset_hc.shape[2]}, but -g/-w ask for {args.outputHeight}x{args.outputWidth}')
+    else:
+        dataset_hc, dataset_pc = get_datasets(options, dataset=Dataset.BRAINWEB)
     config = get_config(trainer=trainer, options=options, optimizer=args.optimizer,
                         intermediateResolutions=args.intermediateResolutions, dropout_rate=0.2, dataset=dataset_hc)
     for arg in vars(args):
@@ -40,7 +47,10 @@ def main(args):
     model.train(dataset_hc)
     # evaluation on synthetic lesion volumes (Evaluation.evaluate; Brainweb/MSLUB/MSISBI2015 need the real data)
     vols, labs, masks = [], [], []
-    for p in range(2):
+    if args.cache:
+        from unsupervised_anomaly_detection_brain_mri_amd.utils.slice_cache import volumes_from_cache
+        vols, labs, masks, _ = volumes_from_cache(args.cache, 'TEST')
+    for p in range(0 if args.cache else 2):
         x, lab, msk = synthetic_slices(16, args.outputHeight, args.outputWidth, seed=50 + p, lesions=True)
         vols.append(x[..., 0].astype('float64')); labs.append(lab); masks.append(msk)
     if args.threshold:
@@ -68,6 +78,7 @@ if __name__ == '__main__':
     ap.add_argument('-O', '--threshold', default=None, type=float)
     ap.add_argument('-d', '--ds', default=None, type=str)
     ap.add_argument('-n', '--numMonteCarloSamples', default=0, type=int)
+    ap.add_argument('--cache', default=None, type=str, help='slice-cache directory (tools/build_cache.py) to train / evaluate on instead of the synthetic set')
     # GMVAE-only flags (reference run.py:144-150, same defaults)
     ap.add_argument('-C', '--dim_c', default=9, type=int, help='only for GMVAE')
     ap.add_argument('-Z', '--dim_z', default=128, type=int, help='only for GMVAE')

@@ -103,3 +103,22 @@ def test_build_cache_patient_split(tmp_path):
     assert set(np.unique(labels)) <= {0, 2, 10} and (labels == 10).any() and (labels == 2).any()
     s = nifti.partition_patients(10, {'TRAIN': 0.7, 'VAL': 0.2, 'TEST': 0.1}, np.random.default_rng(0))
     assert [len(s[k]) for k in ('TRAIN', 'VAL', 'TEST')] == [7, 2, 1] and len(set(np.concatenate(list(s.values())))) == 10
+
+
+def test_volumes_from_cache(tmp_path):
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.slice_cache import volumes_from_cache, write_cache
+    rng = np.random.default_rng(0)
+    images = rng.random((10, 8, 8, 1)).astype(np.float32)
+    labels = rng.choice([0, 2, 3, 7, 10], size=(10, 8, 8)).astype(np.uint8)
+    sets = [0, 0, 2, 2, 2, 1, 2, 2, 0, 2]
+    pats = ['a', 'a', 'b', 'b', 'c', 'c', 'b', 'c', 'd', 'c']
+    write_cache(str(tmp_path / 'c'), images, sets, labels, patients=pats)
+    vols, labs, masks, names = volumes_from_cache(str(tmp_path / 'c'), 'TEST')
+    assert names == ['b', 'c'] and [v.shape for v in vols] == [(3, 8, 8), (3, 8, 8)]
+    np.testing.assert_array_equal(vols[0], images[[2, 3, 6], ..., 0].astype(np.float64))
+    np.testing.assert_array_equal(labs[1], (labels[[4, 7, 9]] == 10).astype(np.float64))
+    # brain mask = every label the LUT keeps (GM 2, WM 3, LESION 10 are brain; BACKGROUND 0 and SKULL 7 are not)
+    np.testing.assert_array_equal(masks[0], np.isin(labels[[2, 3, 6]], [2, 3, 10]).astype(np.float64))
+    write_cache(str(tmp_path / 'nolab'), images, sets)
+    with pytest.raises(ValueError):
+        volumes_from_cache(str(tmp_path / 'nolab'))

@@ -65,6 +65,30 @@ def read_cache(directory):
     return images, labels, index
 
 
+def volumes_from_cache(directory, set_name='TEST'):
+    """Per-patient volumes of one split for utils/Evaluation.evaluate (the reference evaluates patient by patient, Evaluation.py:205-262):
+    -> (volumes [z,H,W] float64 list, lesion maps [z,H,W] {0,1} list, brain masks [z,H,W] {0,1} list, patient names).  Slices keep their cache
+    order inside a patient; lesion = label LESION, brain = every label the brain-mask LUT keeps."""
+    images, labels, index = read_cache(directory)
+    if labels is None:
+        raise ValueError('the cache holds no label maps: nothing to evaluate against')
+    sets = np.asarray(index['sets'])
+    pats = index.get('patients') or []
+    if len(pats) != len(sets):
+        raise ValueError('the cache does not record which patient a slice belongs to')
+    sel = np.where(sets == SET_TYPES.index(set_name))[0]
+    lut = brainmask_lut()
+    vols, labs, masks, names = [], [], [], []
+    for name in dict.fromkeys(pats[i] for i in sel):          # first-seen order
+        idx = [i for i in sel if pats[i] == name]
+        lab = np.asarray(labels[idx])
+        vols.append(np.asarray(images[idx])[..., 0].astype(np.float64))
+        labs.append((lab == LABELS['LESION']).astype(np.float64))
+        masks.append(lut[lab].astype(np.float64))
+        names.append(name)
+    return vols, labs, masks, names
+
+
 class BatchCursor:
     """The index arithmetic of BRAINWEB.next_batch (:411-457) for one split, on index vectors instead of image arrays: returns the
     positions (into the split's slice list) of the next batch."""
