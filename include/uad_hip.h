@@ -142,6 +142,11 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
 int uad_backward(uad_model_t* m, int segment, void* stream);
 /* TF-1.15 Adam: t += 1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps); grads scaled by grad_scale first */
 int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* the other optimizers of DLMODEL.create_optimizer (trainers/DLMODEL.py:113-123) with TF-1.15's update rules; the two slot buffers are the
+ * Adam slots' storage (UAD_BUF_ADAM_M = Momentum's accumulator / RMSProp's `momentum` slot, UAD_BUF_ADAM_V = RMSProp's `rms` slot, which
+ * TensorFlow initialises to ONE: set it before the first UAD_OPT_RMS step).  RMSProp: decay 0.9, eps 1e-10 are TF's defaults. */
+enum { UAD_OPT_SGD = 1, UAD_OPT_MOMENTUM = 2, UAD_OPT_RMS = 3 };
+int uad_optimizer_step(uad_model_t* m, int kind, float lr, float momentum, float decay, float eps, float grad_scale, void* stream);
 /* uad_forward(want_backward=1) + uad_backward(ALL) + uad_adam_step */
 int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float beta1, float beta2, float eps,
                    void* stream);

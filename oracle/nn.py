@@ -180,6 +180,28 @@ def adam_tf_step(p, g, m, v, t, lr, beta1=0.5, beta2=0.999, eps=1e-8):
     return p, m, v
 
 
+def sgd_tf_step(p, g, lr):
+    """tf.train.GradientDescentOptimizer (trainers/DLMODEL.py:116-117), in place."""
+    p -= lr * g
+
+
+def momentum_tf_step(p, g, accum, lr, momentum=0.9):
+    """tf.train.MomentumOptimizer (use_nesterov False, :118-119): accum = momentum accum + g ; p -= lr accum.  In place."""
+    accum *= momentum
+    accum += g
+    p -= lr * accum
+
+
+def rmsprop_tf_step(p, g, ms, mom, lr, momentum=0.9, decay=0.9, eps=1e-10):
+    """tf.train.RMSPropOptimizer(learning_rate, momentum=momentum) (:120-121; decay 0.9, epsilon 1e-10, centered False; the `rms` slot
+    starts at ONE): ms = decay ms + (1 - decay) g^2 ; mom = momentum mom + lr g / sqrt(ms + eps) ; p -= mom.  In place."""
+    ms *= decay
+    ms += (1.0 - decay) * g * g
+    mom *= momentum
+    mom += lr * g / np.sqrt(ms + eps)
+    p -= mom
+
+
 def glorot_uniform(rng, shape, dtype=np.float32):
     """keras glorot_uniform: fan_in/out computed with the receptive field
     (prod(shape[:-2])) for conv kernels; limit = sqrt(6/(fan_in+fan_out))."""

@@ -83,6 +83,7 @@ SYMBOLS = {
     'uad_forward': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_int, C.c_void_p]),
     'uad_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'uad_adam_step': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'uad_optimizer_step': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_train_step': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),
     'uad_restore_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,

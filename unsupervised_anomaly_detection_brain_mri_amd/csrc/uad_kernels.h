@@ -267,6 +267,8 @@ void uad_launch_loss_finalize(const float* rec_partial, int n, int n_vae, int bp
                               float inv_batch, float rec_scale, float* rec_per_sample, float* scalars, hipStream_t st);
 
 // TF-form Adam over a flat parameter buffer: g is multiplied by gscale first
+void uad_launch_optim(int kind, float* p, const float* g, float* s1, float* s2, size_t n, float lr, float momentum, float decay, float eps,
+                      float gscale, hipStream_t st);
 void uad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2,
                      float eps, float gscale, hipStream_t st);
 

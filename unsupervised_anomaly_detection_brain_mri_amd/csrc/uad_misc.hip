@@ -586,6 +586,24 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
 }
 
+// The other optimizers of DLMODEL.create_optimizer (trainers/DLMODEL.py:113-123), TF-1.15 update rules:
+//   kind 1 GradientDescentOptimizer            p -= lr g
+//   kind 2 MomentumOptimizer(momentum)         a = momentum a + g ; p -= lr a                        (slot a = s1, zero-initialised)
+//   kind 3 RMSPropOptimizer(decay .9, momentum, eps 1e-10)   ms = decay ms + (1 - decay) g^2 ; mom = momentum mom + lr g / sqrt(ms + eps) ; p -= mom
+//                                                            (slots ms = s2, ONE-initialised by TF, mom = s1)
+__global__ void optim_kernel(int kind, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1, float* __restrict__ s2, size_t n,
+                             float lr, float momentum, float decay, float eps, float gscale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    if (kind == 1) { p[i] -= lr * gi; return; }
+    if (kind == 2) { const float a = momentum * s1[i] + gi; s1[i] = a; p[i] -= lr * a; return; }
+    const float ms = decay * s2[i] + (1.f - decay) * gi * gi;
+    const float mom = momentum * s1[i] + lr * gi / sqrtf(ms + eps);
+    s2[i] = ms; s1[i] = mom;
+    p[i] -= mom;
+}
+
 // residual anomaly map, one block row per sample (utils/Evaluation.py:282-289)
 __global__ void __launch_bounds__(256) residual_kernel(const float* __restrict__ x, const float* __restrict__ xr,
                                                        const float* __restrict__ mask, int hw, int pos_only,
@@ -847,6 +865,10 @@ void uad_launch_loss_finalize(const float* rec_partial, int n, int n_vae, int bp
                               float inv_batch, float rec_scale, float* rec_per_sample, float* scalars, hipStream_t st) {
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, rec_partial, n, n_vae, bps, kl_per_sample,
                        inv_batch, rec_scale, rec_per_sample, scalars);
+}
+void uad_launch_optim(int kind, float* p, const float* g, float* s1, float* s2, size_t n, float lr, float momentum, float decay, float eps,
+                      float gscale, hipStream_t st) {
+    hipLaunchKernelGGL(optim_kernel, dim3((n + 255) / 256), dim3(256), 0, st, kind, p, g, s1, s2, n, lr, momentum, decay, eps, gscale);
 }
 void uad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2,
                      float eps, float gscale, hipStream_t st) {

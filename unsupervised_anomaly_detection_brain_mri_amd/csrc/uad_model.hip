@@ -1031,6 +1031,17 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
     return UAD_OK;
 }
 
+int uad_optimizer_step(uad_model_t* m, int kind, float lr, float momentum, float decay, float eps, float grad_scale, void* stream) {
+    if (!m) return fail(UAD_ERR_INVALID, "null model");
+    if (kind < UAD_OPT_SGD || kind > UAD_OPT_RMS) return fail(UAD_ERR_INVALID, "optimizer kind %d: UAD_OPT_SGD | UAD_OPT_MOMENTUM | UAD_OPT_RMS (Adam is uad_adam_step)", kind);
+    m->step += 1;
+    m->packed_valid = false;
+    hipStream_t st = (hipStream_t)stream;
+    { PROF("optim"); uad_launch_optim(kind, m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr, momentum, decay, eps, grad_scale, st); }
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
 int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float beta1, float beta2, float eps, void* stream) {
     int rc = uad_forward(m, io, n, 1, stream);
     if (rc == UAD_OK) rc = uad_backward(m, UAD_SEG_ALL, stream);

@@ -325,8 +325,24 @@ class Engine(_EvalOps):
     def backward(self, segment=_lib.SEG_ALL):
         _lib.check(self.lib.uad_backward(self.handle, segment, self._stream()))
 
+    OPTIMIZERS = {'ADAM': 0, 'SGD': 1, 'MOMENTUM': 2, 'RMS': 3}
+
+    def set_optimizer(self, kind='ADAM', momentum=0.9):
+        """Selects what adam_step() applies (DLMODEL.create_optimizer, trainers/DLMODEL.py:113-123).  A fresh RMSProp run gets TF's slot
+        initialisation (`rms` = 1); Adam / Momentum slots start at 0."""
+        if kind not in self.OPTIMIZERS:
+            raise ValueError('Invalid optimizer type')
+        self.optimizer, self.momentum = kind, float(momentum)
+        if kind == 'RMS' and self.step_count == 0:
+            self.set_buffer_host(_lib.BUF_ADAM_V, np.ones(self.nparams, np.float32))
+
     def adam_step(self, lr, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0):
-        _lib.check(self.lib.uad_adam_step(self.handle, lr, beta1, beta2, eps, grad_scale, self._stream()))
+        """The optimizer step of the trainers (TF-Adam unless set_optimizer() chose SGD / MOMENTUM / RMS)."""
+        kind = getattr(self, 'optimizer', 'ADAM')
+        if kind == 'ADAM':
+            _lib.check(self.lib.uad_adam_step(self.handle, lr, beta1, beta2, eps, grad_scale, self._stream()))
+        else:
+            _lib.check(self.lib.uad_optimizer_step(self.handle, self.OPTIMIZERS[kind], lr, self.momentum, 0.9, 1e-10, grad_scale, self._stream()))
 
     def train_step(self, x, eps=None, masks=None, lr=1e-4, beta1=0.5, beta2=0.999, adam_eps=1e-8, **kw):
         """forward + backward + Adam; ceVAE: pass x_ce=... (its 'anomaly' output is filled by the backward)."""

@@ -40,13 +40,20 @@ class DLMODEL(object):
     def model_dir(self):
         return "{}_d{}_b{}_{}".format(self.config.modelname, self.config.dataset, self.config.batchsize, self.config.description)
 
-    @staticmethod
-    def create_optimizer(type='ADAM'):
-        """Validates the optimizer string like DLMODEL.create_optimizer (:112-123).  Only ADAM has a HIP kernel."""
+    def create_optimizer(self=None, type='ADAM', momentum=0.9):
+        """DLMODEL.create_optimizer (:112-123): validates the optimizer string and selects the engine's update rule.  ADAM everywhere; SGD /
+        MOMENTUM / RMS (TF-1.15 rules) on the fused AE-family handle, which is where the reference's trainers pass config.optimizer through."""
+        if isinstance(self, str):                    # called as the reference's staticmethod: create_optimizer('ADAM')
+            self, type = None, self
         if type not in OPTIMIZERS:
             raise ValueError('Invalid optimizer type')
+        eng = getattr(self, 'engine', None)
         if type != 'ADAM':
-            raise NotImplementedError(f"optimizer {type!r}: only 'ADAM' (the reference default) is implemented on the HIP path")
+            if eng is None or not hasattr(eng, 'set_optimizer'):
+                raise NotImplementedError(f"optimizer {type!r}: implemented on the fused AE-family handle only (this trainer's handle applies ADAM)")
+            eng.set_optimizer(type, momentum)
+        elif eng is not None and hasattr(eng, 'set_optimizer'):
+            eng.set_optimizer('ADAM')
         return type
 
     # Adam step counter(s) stored with a checkpoint (one per optimiser)
