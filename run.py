@@ -69,7 +69,7 @@ if __name__ == '__main__':
     ap.add_argument('-z', '--zDim', default=128, type=int)
     ap.add_argument('-w', '--outputWidth', default=128, type=int)
     ap.add_argument('-g', '--outputHeight', default=128, type=int)
-    ap.add_argument('-o', '--optimizer', default='ADAM', type=str, help='ADAM (SGD / MOMENTUM / RMS are validated but not implemented)')
+    ap.add_argument('-o', '--optimizer', default='ADAM', type=str, help='ADAM | SGD | MOMENTUM | RMS (the non-Adam rules run on the fused AE-family handle; the WGAN trainers build their own Adams)')
     ap.add_argument('-i', '--intermediateResolutions', default=(8, 8), type=lambda s: tuple(int(v) for v in s.split(',')))
     ap.add_argument('-s', '--slices_start', default=20, type=int)
     ap.add_argument('-e', '--slices_end', default=130, type=int)
