@@ -94,6 +94,22 @@ class AEMODEL(DLMODEL):
         return "{}_d{}_s{}x{}_{}_b{}_z{}_{}".format(c.modelname, c.dataset, c.outputWidth, c.outputHeight,
                                                     self.network.__name__, c.batchsize, c.zDim, c.description)
 
+    def log_to_tensorboard(self, epoch, scalars, visuals, phase, name='x'):      # trainers/AEMODEL.py:37-42
+        """Epoch means of the scalar fetches (+ up to 50 image rows when `visuals` is given) into <logDir>/{TRAIN,VAL,TEST} event files
+        (utils/logger.py, TensorBoard's format, no TensorFlow).  The reference only summarises when visuals were collected; the scalars are
+        written here in either case.  Off with config.useTensorboard = False."""
+        if not getattr(self.config, 'useTensorboard', False):
+            return
+        if getattr(self, 'logger', None) is None:
+            from ..utils.logger import Logger
+            base = getattr(self.config, 'logDir', None) or os.path.join(os.path.dirname(os.path.abspath(self.checkpointDir)), 'logs')
+            self.logDir = os.path.join(base, self.network.__name__, self.model_dir)
+            self.logger = Logger(None, self.logDir)
+        summ = {k: np.float32(np.mean(v)) for k, v in scalars.items()}
+        if visuals:
+            summ[name] = np.vstack(visuals)[:50]
+        self.logger.summarize(epoch, phase=phase, summaries_dict=summ)
+
     def load_checkpoint(self):      # trainers/AEMODEL.py:44-52
         could_load, counter = self.load(self.checkpointDir)
         print(" [*] Load SUCCESS" if could_load else " [!] Load failed...")
@@ -144,6 +160,7 @@ class AEMODEL(DLMODEL):
         out = {k: np.mean(v) for k, v in scalars.items()}
         for k, v in out.items():
             self.curves.setdefault(f'{phase.value}/{k}', []).append(float(v))
+        self.log_to_tensorboard(epoch, out, None, phase)
         return out
 
     def train(self, dataset):       # trainers/VAE.py:31-74

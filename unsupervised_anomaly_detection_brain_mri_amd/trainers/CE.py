@@ -80,4 +80,5 @@ class CE(AE):
         out = {k: np.mean(v) for k, v in scalars.items()}
         for k, v in out.items():
             self.curves.setdefault(f'{phase.value}/{k}', []).append(float(v))
+        self.log_to_tensorboard(epoch, out, None, phase)
         return out
