@@ -67,3 +67,27 @@ def test_image_scaling_rule_and_rgb_png():
     assert u.tolist() == [[1, 128], [191, 255]]
     rgb = (np.arange(2 * 3 * 3) * 10 % 256).astype(np.uint8).reshape(2, 3, 3)
     assert np.array_equal(_decode_png(lg.encode_png(rgb)), rgb)
+
+
+def test_trainer_log_hook_without_engine(tmp_path):
+    """AEMODEL.log_to_tensorboard: lazily creates the per-phase writers next to the checkpoint directory, honours config.useTensorboard."""
+    import glob as _glob
+    from unsupervised_anomaly_detection_brain_mri_amd.models import variational_autoencoder
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import VAE, Phase
+    t = object.__new__(VAE)                                   # no engine: host logic only
+    t.config = VAE.Config()
+    t.config.dataset, t.config.description, t.config.batchsize = 'Synthetic', '', 4
+    t.network = variational_autoencoder
+    t.checkpointDir = str(tmp_path / 'ck' / 'variational_autoencoder')
+    t.logger = None
+    t.config.useTensorboard = False
+    t.log_to_tensorboard(0, {'loss': 1.0}, None, Phase.TRAIN)
+    assert not (tmp_path / 'ck' / 'logs').exists()
+    t.config.useTensorboard = True
+    t.log_to_tensorboard(0, {'loss': [1.0, 3.0], 'kl': np.float32(0.5)}, None, Phase.TRAIN)
+    t.log_to_tensorboard(1, {'loss': 1.5}, [np.ones((2, 4, 4, 1), np.float32)], Phase.VAL)
+    d = tmp_path / 'ck' / 'logs' / 'variational_autoencoder' / t.model_dir
+    tr = lg.read_events(_glob.glob(str(d / 'TRAIN' / 'events*'))[0])
+    assert tr[1] == (0, {'loss': 2.0, 'kl': 0.5})
+    va = lg.read_events(_glob.glob(str(d / 'VAL' / 'events*'))[0])
+    assert va[1][0] == 1 and va[1][1]['loss'] == 1.5 and {'x/image/0', 'x/image/1'} <= set(va[1][1])
