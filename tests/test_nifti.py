@@ -122,3 +122,15 @@ def test_volumes_from_cache(tmp_path):
     write_cache(str(tmp_path / 'nolab'), images, sets)
     with pytest.raises(ValueError):
         volumes_from_cache(str(tmp_path / 'nolab'))
+
+
+def test_rotations_and_center_crop():
+    from scipy.ndimage import rotate
+    vol, seg, brain = _phantom(2)
+    base, lb, kept = nifti.volume_to_slices(vol, seg, brain, slice_start=3, slice_end=9, slice_resolution=(40, 40))
+    imgs, labs, k2 = nifti.volume_to_slices(vol, seg, brain, slice_start=3, slice_end=9, slice_resolution=(40, 40), rotations=(0, 15), center_crop=(24, 32))
+    assert k2 == [s for s in kept for _ in range(2)] and imgs.shape == (2 * len(kept), 32, 24)
+    np.testing.assert_allclose(imgs[0], nifti.crop_center(base[0], 24, 32))
+    np.testing.assert_allclose(imgs[1], nifti.crop_center(rotate(base[0], 15, reshape=False), 24, 32), rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(labs[1], nifti.crop_center(rotate(lb[0], 15, reshape=False, mode='nearest'), 24, 32))
+    assert nifti.crop_center(np.arange(100).reshape(10, 10), 4, 6).shape == (6, 4)

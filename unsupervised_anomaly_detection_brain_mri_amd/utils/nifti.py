@@ -91,10 +91,19 @@ def normalize_scaling(vol, lower=0, upper=99.8):
     return v
 
 
+def crop_center(img, cropx, cropy):
+    """utils/image_utils.py:4-12."""
+    y, x = img.shape[:2]
+    sx, sy = x // 2 - cropx // 2, y // 2 - cropy // 2
+    return img[sy:sy + cropy, sx:sx + cropx]
+
+
 def volume_to_slices(vol, seg=None, brainmask=None, axis='axial', slice_start=0, slice_end=155, slice_resolution=None, skull_stripping=True,
-                     view_mapping=None, empty_percentile=90, empty_thresh=0.2, denoise=False):
-    """-> (images [k,H,W] float32 in [0,1], labels [k,H,W] float32 in {0,1}, slice indices kept)."""
-    from scipy.ndimage import zoom
+                     view_mapping=None, empty_percentile=90, empty_thresh=0.2, denoise=False, rotations=(0,), center_crop=None):
+    """-> (images [k,H,W] float32 in [0,1], labels [k,H,W] float32 in {0,1}, slice indices kept).
+    rotations: angles in degrees, one output per angle and slice (dataloaders/BRAINWEB.py:156-162: scipy.ndimage.rotate, reshape False, the label
+    map with mode 'nearest'); center_crop (width, height): the `useCrops` / cropType 'center' option (MSLUB.py:206-210)."""
+    from scipy.ndimage import rotate, zoom
     if denoise:
         raise NotImplementedError("nii.denoise() is SimpleITK's CurvatureFlow filter (MSLUB.py:257); it is not restated here")
     vm = view_mapping or VIEW_MAPPING
@@ -124,7 +133,11 @@ def volume_to_slices(vol, seg=None, brainmask=None, axis='axial', slice_start=0,
             sd = zoom(sd, f)
             ss = zoom(ss, f, mode='nearest')
             ss = (ss >= 0.9).astype(np.float64)
-        imgs.append(sd.astype(np.float32)); labs.append(ss.astype(np.float32)); kept.append(s)
+        for angle in rotations:
+            sdr, ssr = (sd, ss) if angle == 0 else (rotate(sd, angle, reshape=False), rotate(ss, angle, reshape=False, mode='nearest'))
+            if center_crop is not None:
+                sdr, ssr = crop_center(sdr, center_crop[0], center_crop[1]), crop_center(ssr, center_crop[0], center_crop[1])
+            imgs.append(np.asarray(sdr, np.float32)); labs.append(np.asarray(ssr, np.float32)); kept.append(s)
     if not imgs:
         return np.zeros((0, 0, 0), np.float32), np.zeros((0, 0, 0), np.float32), []
     return np.stack(imgs), np.stack(labs), kept
