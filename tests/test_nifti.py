@@ -134,3 +134,21 @@ def test_rotations_and_center_crop():
     np.testing.assert_allclose(imgs[1], nifti.crop_center(rotate(base[0], 15, reshape=False), 24, 32), rtol=1e-6, atol=1e-6)
     np.testing.assert_array_equal(labs[1], nifti.crop_center(rotate(lb[0], 15, reshape=False, mode='nearest'), 24, 32))
     assert nifti.crop_center(np.arange(100).reshape(10, 10), 4, 6).shape == (6, 4)
+
+
+def test_read_nrrd(tmp_path):
+    import gzip as _gz
+    rng = np.random.default_rng(0)
+    vol = rng.integers(-500, 500, (4, 5, 6)).astype(np.int16)               # [x, y, z], x fastest in the file
+    head = b'NRRD0004\n# a comment\ntype: short\ndimension: 3\nsizes: 4 5 6\nendian: little\nencoding: raw\nspace: left-posterior-superior\n\n'
+    (tmp_path / 'a.nrrd').write_bytes(head + vol.tobytes(order='F'))
+    d, h = nifti.read_nrrd(str(tmp_path / 'a.nrrd'))
+    assert d.shape == (4, 5, 6) and np.array_equal(d, vol) and h['dimension'] == '3'
+    big = b'NRRD0005\r\ntype: float\r\ndimension: 2\r\nsizes: 3 2\r\nendian: big\r\nencoding: gzip\r\n\r\n'
+    fv = rng.random((3, 2)).astype('>f4')
+    (tmp_path / 'b.nrrd').write_bytes(big + _gz.compress(fv.tobytes(order='F')))
+    d2, _ = nifti.read_nrrd(str(tmp_path / 'b.nrrd'))
+    assert np.array_equal(d2, fv)
+    (tmp_path / 'c.nrrd').write_bytes(b'NRRD0004\ntype: short\nsizes: 2 2\ndata file: x.raw\n\n')
+    with pytest.raises(ValueError):
+        nifti.read_nrrd(str(tmp_path / 'c.nrrd'))

@@ -79,6 +79,51 @@ def write_nifti(path, data_zyx, dtype='f4', pixdim=(1.0, 1.0, 1.0)):
         f.write(payload)
 
 
+_NRRD_TYPES = {'signed char': 'i1', 'int8': 'i1', 'int8_t': 'i1', 'uchar': 'u1', 'unsigned char': 'u1', 'uint8': 'u1', 'uint8_t': 'u1',
+               'short': 'i2', 'short int': 'i2', 'signed short': 'i2', 'int16': 'i2', 'int16_t': 'i2', 'ushort': 'u2', 'unsigned short': 'u2',
+               'uint16': 'u2', 'uint16_t': 'u2', 'int': 'i4', 'signed int': 'i4', 'int32': 'i4', 'int32_t': 'i4', 'uint': 'u4', 'unsigned int': 'u4',
+               'uint32': 'u4', 'uint32_t': 'u4', 'longlong': 'i8', 'long long': 'i8', 'int64': 'i8', 'int64_t': 'i8', 'ulonglong': 'u8',
+               'unsigned long long': 'u8', 'uint64': 'u8', 'uint64_t': 'u8', 'float': 'f4', 'double': 'f8'}
+
+
+def read_nrrd(path):
+    """NRRD (attached header; encodings raw / gzip) -> (data, header dict) in the index order of `nrrd.read` that dataloaders/NRRD.py:11 relies
+    on: shape = the header's `sizes` (first axis fastest, i.e. Fortran order)."""
+    raw = open(path, 'rb').read()
+    if not raw.startswith(b'NRRD'):
+        raise ValueError(f'{path}: not an NRRD file')
+    end = raw.find(b'\n\n')
+    crlf = raw.find(b'\r\n\r\n')
+    if crlf != -1 and (end == -1 or crlf < end):
+        head, body = raw[:crlf], raw[crlf + 4:]
+    elif end != -1:
+        head, body = raw[:end], raw[end + 2:]
+    else:
+        raise ValueError(f'{path}: no header terminator')
+    hdr = {}
+    for line in head.decode('ascii', 'replace').splitlines()[1:]:
+        if line.startswith('#') or ':' not in line:
+            continue
+        k, v = line.split(':', 1)
+        hdr[k.strip().lower()] = v.lstrip('=').strip()
+    if 'data file' in hdr or 'datafile' in hdr:
+        raise ValueError(f'{path}: detached NRRD data files are not supported')
+    t = hdr.get('type', '').lower()
+    if t not in _NRRD_TYPES:
+        raise ValueError(f'{path}: unsupported NRRD type {t!r}')
+    sizes = [int(v) for v in hdr['sizes'].split()]
+    enc = hdr.get('encoding', 'raw').lower()
+    if enc in ('gzip', 'gz'):
+        body = gzip.decompress(body)
+    elif enc != 'raw':
+        raise ValueError(f'{path}: unsupported NRRD encoding {enc!r}')
+    dt = np.dtype(('>' if hdr.get('endian', 'little').lower() == 'big' else '<') + _NRRD_TYPES[t])
+    cnt = int(np.prod(sizes))
+    if len(body) < cnt * dt.itemsize:
+        raise ValueError(f'{path}: NRRD data is truncated')
+    return np.frombuffer(body, dt, cnt).reshape(sizes, order='F'), hdr
+
+
 def normalize_scaling(vol, lower=0, upper=99.8):
     """NII.normalize(method='scaling', lowerpercentile, upperpercentile) (NII.py:50-66)."""
     v = vol.astype(np.float32)
