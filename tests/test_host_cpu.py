@@ -181,3 +181,18 @@ def test_slice_cache_roundtrip_and_cursor(tmp_path):
     # no shuffle: plain wrap-around
     c2 = sc.BatchCursor(5, np.random.default_rng(1))
     assert [c2.next(2, shuffle=False).tolist() for _ in range(4)] == [[0, 1], [2, 3], [4, 0], [1, 2]]
+
+
+def test_trainer_utils_summary_dict():
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import trainer_utils as tu
+    rng = np.random.default_rng(0)
+    batch = rng.random((3, 8, 8, 1)).astype(np.float32)
+    run = {'reconstruction': rng.random((3, 8, 8, 1)).astype(np.float32), 'L1': rng.random((3, 8, 8, 1)).astype(np.float32),
+           'loss': np.float32(2.0), 'kl': np.float32(0.5), 'optimizer': None, 'nan': float('nan')}
+    scalars, visuals = tu.get_summary_dict(batch, run)
+    assert set(scalars) == {'loss', 'kl'} and visuals.shape == (3, 8, 24, 1)
+    assert visuals.min() == 0.0 and visuals.max() == 255.0
+    np.testing.assert_allclose(visuals[1, :, :8, 0], 255 * (batch[1, ..., 0] - batch[1].min()) / (batch[1].max() - batch[1].min()), rtol=1e-5)
+    assert tu.normalize(np.full((4, 4), 3.0)).max() == 0.0                   # constant image -> 0 (cv2.NORM_MINMAX)
+    _, v2 = tu.get_summary_dict(batch, run, ['L1'], batch)
+    assert v2.shape == (3, 8, 24, 1)
