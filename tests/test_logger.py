@@ -91,3 +91,33 @@ def test_trainer_log_hook_without_engine(tmp_path):
     assert tr[1] == (0, {'loss': 2.0, 'kl': 0.5})
     va = lg.read_events(_glob.glob(str(d / 'VAL' / 'events*'))[0])
     assert va[1][0] == 1 and va[1][1]['loss'] == 1.5 and {'x/image/0', 'x/image/1'} <= set(va[1][1])
+
+
+def test_process_collects_image_strip_when_asked(tmp_path):
+    """AEMODEL.process with config.tfSummaryImages: the per-step maps go through trainer_utils.get_summary_dict into one image summary."""
+    import glob as _glob
+    from unsupervised_anomaly_detection_brain_mri_amd.models import variational_autoencoder
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import VAE, Phase
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset
+    t = object.__new__(VAE)
+    t.config = VAE.Config()
+    t.config.dataset, t.config.description, t.config.batchsize, t.config.useTensorboard, t.config.tfSummaryImages = 'Synthetic', '', 4, True, True
+    t.network, t.checkpointDir, t.logger, t.curves = variational_autoencoder, str(tmp_path / 'ck' / 'net'), None, {}
+    calls = []
+
+    def fake_step(batch, phase, fetch_maps=True, **kw):
+        calls.append(fetch_maps)
+        b = np.asarray(batch)
+        return {'loss': np.float32(1.0 + len(calls)), 'kl': np.float32(0.1), 'reconstruction': b * 0.5, 'L1': np.abs(b - b * 0.5)}
+    t.step = fake_step
+    ds = SyntheticDataset(8, 8, 16, 16, seed=0)
+    out = t.process(ds, 3, Phase.VAL)
+    assert calls == [True, True] and out['loss'] == 2.5 and t.curves['VAL/loss'] == [2.5]
+    ev = lg.read_events(_glob.glob(str(tmp_path / 'ck' / 'logs' / 'variational_autoencoder' / t.model_dir / 'VAL' / 'events*'))[0])
+    step, vals = ev[1]
+    imgs = [k for k in vals if k.startswith('x/image')]
+    assert step == 3 and vals['loss'] == 2.5 and len(imgs) == 8 and vals[imgs[0]][1:3] == (16, 48)       # input | reconstruction | L1 side by side
+    t.config.tfSummaryImages = False
+    calls.clear()
+    t.process(ds, 4, Phase.VAL)
+    assert calls == [False, False]

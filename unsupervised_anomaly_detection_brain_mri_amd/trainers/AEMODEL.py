@@ -149,18 +149,26 @@ class AEMODEL(DLMODEL):
     def process(self, dataset, epoch, phase, optim=None):       # trainers/VAE.py:76-103
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
         scalars = defaultdict(list)
+        visuals = []
+        # the reference fetches the maps of EVERY step for its TensorBoard image strip (trainer_utils.get_summary_dict); here that is opt-in
+        # (config.tfSummaryImages): the maps are 4 MB of D2H per step
+        want_images = bool(getattr(self.config, 'tfSummaryImages', False)) and bool(getattr(self.config, 'useTensorboard', False))
         num_batches = dataset.num_batches(self.config.batchsize, set=phase.value)
         for idx in range(num_batches):
             batch, _, _ = dataset.next_batch(self.config.batchsize, set=phase.value)
-            run = self.step(batch, phase, fetch_maps=False)    # maps are opt-in (4 MB D2H per step otherwise)
+            run = self.step(batch, phase, fetch_maps=want_images)
             print(f'Epoch ({phase.value}): [{epoch:2d}] [{idx:4d}/{num_batches:4d}] loss: {run["loss"]:.8f}')
             for k, v in run.items():
                 if np.ndim(v) == 0:
                     scalars[k].append(v)
+            if want_images:
+                from .trainer_utils import get_summary_dict
+                b = batch.cpu().numpy() if hasattr(batch, 'cpu') else np.asarray(batch)
+                visuals.append(get_summary_dict(b, run)[1])
         out = {k: np.mean(v) for k, v in scalars.items()}
         for k, v in out.items():
             self.curves.setdefault(f'{phase.value}/{k}', []).append(float(v))
-        self.log_to_tensorboard(epoch, out, None, phase)
+        self.log_to_tensorboard(epoch, out, visuals, phase)
         return out
 
     def train(self, dataset):       # trainers/VAE.py:31-74
