@@ -1,0 +1,16 @@
+"""mains/main_GMVAE_You.py of the reference: the `GMVAE_spatial` trainer on `models/gaussian_mixture_variational_autoencoder_You.py` -- here the same pairing through run.py's driver
+(all of run.py's flags apply; `python mains/main_GMVAE_You.py -E 10 -b 64`)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from run import build_parser, main  # noqa: E402
+
+if __name__ == '__main__':
+    ap = build_parser()
+    ap.set_defaults(trainer='GMVAE_spatial', model='gaussian_mixture_variational_autoencoder_You', dim_z=1)
+    args = ap.parse_args()
+    if args.intermediateResolutions == (8, 8) and args.outputHeight // 4 != 8:      # this graph's latent map is height / 4
+        args.intermediateResolutions = (args.outputHeight // 4, args.outputWidth // 4)
+    main(args)

@@ -1,0 +1,16 @@
+"""mains/main_VAE_Zimmerer.py of the reference: the `VAE` trainer on `models/variational_autoencoder_Zimmerer.py` -- here the same pairing through run.py's driver
+(all of run.py's flags apply; `python mains/main_VAE_Zimmerer.py -E 10 -b 64`)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from run import build_parser, main  # noqa: E402
+
+if __name__ == '__main__':
+    ap = build_parser()
+    ap.set_defaults(trainer='VAE', model='variational_autoencoder_Zimmerer')
+    args = ap.parse_args()
+    if args.intermediateResolutions == (8, 8) and args.outputHeight // 16 != 8:      # this graph's latent map is height / 16
+        args.intermediateResolutions = (args.outputHeight // 16, args.outputWidth // 16)
+    main(args)

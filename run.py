@@ -60,7 +60,7 @@ def main(args):
                       if k not in ('time', 'epistemic_variance')}, default=float))
 
 
-if __name__ == '__main__':
+def build_parser():
     ap = argparse.ArgumentParser(description='Framework')
     ap.add_argument('-c', '--config', default='config.default.json', type=str, help='config-path')
     ap.add_argument('-b', '--batchsize', default=8, type=int)
@@ -87,4 +87,8 @@ if __name__ == '__main__':
     ap.add_argument('-L', '--restore_lr', default=1e-3, type=float, help='only for GMVAE')
     ap.add_argument('-S', '--restore_steps', default=150, type=int, help='only for GMVAE')
     ap.add_argument('-T', '--tv_lambda', default=-1.0, type=float, help='only for GMVAE')
-    main(ap.parse_args())
+    return ap
+
+
+if __name__ == '__main__':
+    main(build_parser().parse_args())

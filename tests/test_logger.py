@@ -87,9 +87,9 @@ def test_trainer_log_hook_without_engine(tmp_path):
     t.log_to_tensorboard(0, {'loss': [1.0, 3.0], 'kl': np.float32(0.5)}, None, Phase.TRAIN)
     t.log_to_tensorboard(1, {'loss': 1.5}, [np.ones((2, 4, 4, 1), np.float32)], Phase.VAL)
     d = tmp_path / 'ck' / 'logs' / 'variational_autoencoder' / t.model_dir
-    tr = lg.read_events(_glob.glob(str(d / 'TRAIN' / 'events*'))[0])
+    tr = lg.read_events(_glob.glob(str(d / '*' / 'TRAIN' / 'events*'))[0])          # <logs>/<network>/<model_dir>/<YYYYmmdd_HHMMSS>/TRAIN
     assert tr[1] == (0, {'loss': 2.0, 'kl': 0.5})
-    va = lg.read_events(_glob.glob(str(d / 'VAL' / 'events*'))[0])
+    va = lg.read_events(_glob.glob(str(d / '*' / 'VAL' / 'events*'))[0])
     assert va[1][0] == 1 and va[1][1]['loss'] == 1.5 and {'x/image/0', 'x/image/1'} <= set(va[1][1])
 
 
@@ -113,7 +113,7 @@ def test_process_collects_image_strip_when_asked(tmp_path):
     ds = SyntheticDataset(8, 8, 16, 16, seed=0)
     out = t.process(ds, 3, Phase.VAL)
     assert calls == [True, True] and out['loss'] == 2.5 and t.curves['VAL/loss'] == [2.5]
-    ev = lg.read_events(_glob.glob(str(tmp_path / 'ck' / 'logs' / 'variational_autoencoder' / t.model_dir / 'VAL' / 'events*'))[0])
+    ev = lg.read_events(_glob.glob(str(tmp_path / 'ck' / 'logs' / 'variational_autoencoder' / t.model_dir / '*' / 'VAL' / 'events*'))[0])
     step, vals = ev[1]
     imgs = [k for k in vals if k.startswith('x/image')]
     assert step == 3 and vals['loss'] == 2.5 and len(imgs) == 8 and vals[imgs[0]][1:3] == (16, 48)       # input | reconstruction | L1 side by side

@@ -103,7 +103,8 @@ class AEMODEL(DLMODEL):
         if getattr(self, 'logger', None) is None:
             from ..utils.logger import Logger
             base = getattr(self.config, 'logDir', None) or os.path.join(os.path.dirname(os.path.abspath(self.checkpointDir)), 'logs')
-            self.logDir = os.path.join(base, self.network.__name__, self.model_dir)
+            import time
+            self.logDir = os.path.join(base, self.network.__name__, self.model_dir, time.strftime('%Y%m%d_%H%M%S'))      # AEMODEL.py:33-34
             self.logger = Logger(None, self.logDir)
         summ = {k: np.float32(np.mean(v)) for k, v in scalars.items()}
         if visuals:
