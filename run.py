@@ -56,8 +56,20 @@ def main(args):
     if args.threshold:
         options['threshold'] = args.threshold
     ev = Evaluation.evaluate(vols, labs, masks, model, options)
-    print(json.dumps({k: (v if isinstance(v, (list, dict, str)) else float(v)) for k, v in ev.items()
-                      if k not in ('time', 'epistemic_variance')}, default=float))
+    summary = {k: (v if isinstance(v, (list, dict, str)) else float(v)) for k, v in ev.items() if k not in ('time', 'epistemic_variance')}
+    # evalPC.npy / evalPC.txt under <SAMPLEDIR>/<network>/<model_dir>/eval-<epoch>-<timestamp>/ (utils/Evaluation.py:380-395,519-526)
+    try:
+        import time
+        import numpy as np
+        epoch = len(model.curves.get('TRAIN/loss', model.curves.get('TRAIN/reconstructionLoss', [])))
+        out_dir = os.path.join(options['train']['samplesDir'], network.__name__, model.model_dir, f"eval-{epoch}-{time.strftime('%Y%m%d_%H%M%S')}")
+        os.makedirs(out_dir, exist_ok=True)
+        np.save(os.path.join(out_dir, 'evalPC.npy'), summary)
+        with open(os.path.join(out_dir, 'evalPC.txt'), 'w') as f:
+            json.dump(summary, f, default=float)
+    except Exception as e:      # the summary on stdout is the contract; the files are a convenience
+        print(f'could not write the evaluation summary: {e}')
+    print(json.dumps(summary, default=float))
 
 
 def build_parser():
