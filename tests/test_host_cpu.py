@@ -196,3 +196,24 @@ def test_trainer_utils_summary_dict():
     assert tu.normalize(np.full((4, 4), 3.0)).max() == 0.0                   # constant image -> 0 (cv2.NORM_MINMAX)
     _, v2 = tu.get_summary_dict(batch, run, ['L1'], batch)
     assert v2.shape == (3, 8, 24, 1)
+
+
+def test_mains_pairings_resolve():
+    """every mains/main_*.py names a trainer / model pair that exists and that the trainer accepts (the reference's 17 entry points)."""
+    import glob
+    import importlib
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, 'mains', 'main_*.py')))
+    assert len(files) == 17
+    pkg = 'unsupervised_anomaly_detection_brain_mri_amd'
+    for f in files:
+        src = open(f).read()
+        m = re.search(r"set_defaults\(trainer='(\w+)', model='(\w+)'", src)
+        assert m, f
+        T = getattr(importlib.import_module(f'{pkg}.trainers.{m.group(1)}'), m.group(1))
+        net = getattr(importlib.import_module(f'{pkg}.models.{m.group(2)}'), m.group(2))
+        archs = T.ARCHS if isinstance(T.ARCHS, tuple) else (T.ARCH,)
+        assert net.arch in archs, (os.path.basename(f), net.arch, archs)
+        assert net.__name__ == m.group(2)
