@@ -163,6 +163,11 @@ int uad_restore_step(uad_model_t* m, float* x_restored, const float* eps_w, cons
 
 int uad_set_math_mode(uad_model_t* m, int mode);   /* UAD_MATH_* ; takes effect at the next uad_forward */
 int uad_get_math_mode(const uad_model_t* m);
+/* tests: device pointer + element count (for the batch of the last uad_forward; 2n rows inside a ceVAE handle) of a named
+ * intermediate: "enc_c<i>" / "dec_c<i>" = pre-BN output of encoder / decoder block i (the activation pattern of the step is
+ * sign(gamma' c + beta); the last decoder block's is not written when its epilogue is fused -- read "G0" = d loss / d c of that block
+ * right after a want_backward forward instead), "dec_in" = the decoder's pre-BN input, "G0" / "G1" = gradient ping-pong buffers. */
+int uad_debug_buffer(uad_model_t* m, const char* name, float** ptr, long long* count);
 
 /* per-launch-group HIP-event profiler (bench.py's roofline leg).  While enabled, every launch group of
  * uad_forward / uad_backward / uad_adam_step is bracketed by hipEventRecord on the caller's stream.

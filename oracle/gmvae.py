@@ -18,6 +18,7 @@ import math
 import numpy as np
 
 from . import nn
+from .vae import act_bwd
 
 LRELU_ALPHA = 0.3
 
@@ -170,10 +171,11 @@ class GMVAE:
         return res
 
     # ------------------------------------------------------------------ backward
-    def backward(self, p, x, out, cache, tv_lambda=None):
+    def backward(self, p, x, out, cache, tv_lambda=None, act=None):
         """tv_lambda None: d loss / d params (the optimizer's objective, :94-97) and g['__dx'] = d loss / d x.
         tv_lambda given: the same backward of  loss + sum_n tv_lambda * TV_n(x - xz_mu)  (the `grads` fetch, :91-92);
-        only g['__dx'] is meaningful for the caller then (parameter entries hold the gradient of that other objective)."""
+        only g['__dx'] is meaningful for the caller then (parameter entries hold the gradient of that other objective).
+        act: activation pattern of another fp32 implementation for the trunk's kinks (oracle/vae.py: act_bwd)."""
         n = x.shape[0]
         dt = x.dtype.type
         # `grads` = tf.gradients(loss + restore, x): `loss + restore` has shape [n] (scalar + per-image TV) and tf.gradients differentiates the
@@ -182,7 +184,7 @@ class GMVAE:
         g = {}
         C = self.dim_c
         # ---- decoder ----
-        gx = np.sign(out['xz_mu'] - x) * inv
+        gx = (act['l1_sign'].astype(x.dtype) if act is not None and 'l1_sign' in act else np.sign(out['xz_mu'] - x)) * inv
         dx_direct = -gx
         if tv_lambda is not None:
             tvg = total_variation_grad(x - out['xz_mu']) * dt(tv_lambda)
@@ -193,11 +195,11 @@ class GMVAE:
         d = self.n_pool
         for i in reversed(range(self.n_pool)):
             b = self.bn[d + 1 + i]
-            dbn = nn.leaky_relu_bwd(cache[f'dec_bn{i}'], da, LRELU_ALPHA)
+            dbn = act_bwd(cache, f'dec_bn{i}', da, LRELU_ALPHA, act)
             dc, g[b + '/gamma'], g[b + '/beta'] = nn.bn_frozen_bwd(cache[f'dec_c{i}'], p[b + '/gamma'], dbn)
             da, g[f'dec_Conv2DT_{i}/kernel'], g[f'dec_Conv2DT_{i}/bias'] = \
                 nn.conv2d_transpose_bwd(cache[f'dec_in{i}'], p[f'dec_Conv2DT_{i}/kernel'], dc, 2)
-        dbn = nn.leaky_relu_bwd(cache['dec_bn_in'], da, 0.0)
+        dbn = act_bwd(cache, 'dec_bn_in', da, 0.0, act)
         dh, g[self.bn[d] + '/gamma'], g[self.bn[d] + '/beta'] = nn.bn_frozen_bwd(cache['h'], p[self.bn[d] + '/gamma'], dbn)
         # ---- latent heads (per location) ----
         c = cache
@@ -211,8 +213,8 @@ class GMVAE:
         dkl = inv * np.broadcast_to(pc[:, :, :, None, :], kl.shape)
         dpc = inv * kl.sum(axis=3)
         cl1 = (pc * np.log(pc * C + 1e-8)).sum(axis=3)
-        act = (cl1 >= self.c_lambda)[..., None]          # tf.maximum routes the gradient to x where x >= y
-        dpc = dpc + inv * act * (np.log(pc * C + 1e-8) + pc * C / (pc * C + 1e-8))
+        c_on = (cl1 >= self.c_lambda)[..., None]          # tf.maximum routes the gradient to x where x >= y
+        dpc = dpc + inv * c_on * (np.log(pc * C + 1e-8) + pc * C / (pc * C + 1e-8))
         dlogit = pc * (dpc - (dpc * pc).sum(axis=-1, keepdims=True))
         dll = np.broadcast_to(dlogit[:, :, :, None, :], kl.shape)
         D = z_s[..., None] - M
@@ -241,7 +243,7 @@ class GMVAE:
         da = dh
         for i in reversed(range(self.n_pool)):
             b = self.bn[i]
-            dbn = nn.leaky_relu_bwd(cache[f'enc_bn{i}'], da, LRELU_ALPHA)
+            dbn = act_bwd(cache, f'enc_bn{i}', da, LRELU_ALPHA, act)
             dc, g[b + '/gamma'], g[b + '/beta'] = nn.bn_frozen_bwd(cache[f'enc_c{i}'], p[b + '/gamma'], dbn)
             da, g[f'enc_conv2D_{i}/kernel'], g[f'enc_conv2D_{i}/bias'] = \
                 nn.conv2d_bwd(cache[f'enc_in{i}'], p[f'enc_conv2D_{i}/kernel'], dc, 2)

@@ -27,36 +27,52 @@ def same_pads(size, k, s):
 #   models/customlayers.py:21 (k5 s2), :37 (1x1), variational_autoencoder.py:20-21
 #   kernel layout HWIO = [kh, kw, Cin, Cout]
 # --------------------------------------------------------------------------
-def conv2d_fwd(x, w, b, stride):
+def _geom(size, k, s, padding):
+    """(out, pad_before, pad_after) of one spatial dim: 'SAME' as same_pads(); 'VALID' = no padding, out = (size - k)//s + 1
+    (only the TF unit-test vectors of tests/golden/tf_published.json use VALID; every layer of the reference is 'same')."""
+    if padding == 'SAME':
+        return same_pads(size, k, s)
+    if padding != 'VALID':
+        raise ValueError(padding)
+    return (size - k) // s + 1, 0, 0
+
+
+def _strides(stride):
+    return (stride, stride) if np.isscalar(stride) else tuple(stride)
+
+
+def conv2d_fwd(x, w, b, stride, padding='SAME'):
     n, h, wd, cin = x.shape
     kh, kw, _, cout = w.shape
-    oh, pt, pb = same_pads(h, kh, stride)
-    ow, pl, pr = same_pads(wd, kw, stride)
+    sh, sw = _strides(stride)
+    oh, pt, pb = _geom(h, kh, sh, padding)
+    ow, pl, pr = _geom(wd, kw, sw, padding)
     xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
     out = np.zeros((n, oh, ow, cout), dtype=x.dtype)
     for ky in range(kh):
         for kx in range(kw):
-            patch = xp[:, ky:ky + stride * oh:stride, kx:kx + stride * ow:stride, :]
+            patch = xp[:, ky:ky + sh * oh:sh, kx:kx + sw * ow:sw, :]
             out += (patch.reshape(-1, cin) @ w[ky, kx]).reshape(n, oh, ow, cout)
     if b is not None:
         out += b
     return out
 
 
-def conv2d_bwd(x, w, g, stride):
+def conv2d_bwd(x, w, g, stride, padding='SAME'):
     """Returns (dx, dw, db) for out = conv2d_fwd(x, w, b, stride), g = dL/dout."""
     n, h, wd, cin = x.shape
     kh, kw, _, cout = w.shape
-    oh, pt, pb = same_pads(h, kh, stride)
-    ow, pl, pr = same_pads(wd, kw, stride)
+    sh, sw = _strides(stride)
+    oh, pt, pb = _geom(h, kh, sh, padding)
+    ow, pl, pr = _geom(wd, kw, sw, padding)
     xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
     dxp = np.zeros_like(xp)
     dw = np.zeros_like(w)
     g2 = g.reshape(-1, cout)
     for ky in range(kh):
         for kx in range(kw):
-            sl = (slice(None), slice(ky, ky + stride * oh, stride),
-                  slice(kx, kx + stride * ow, stride), slice(None))
+            sl = (slice(None), slice(ky, ky + sh * oh, sh),
+                  slice(kx, kx + sw * ow, sw), slice(None))
             dw[ky, kx] = xp[sl].reshape(-1, cin).T @ g2
             dxp[sl] += (g2 @ w[ky, kx].T).reshape(n, oh, ow, cin)
     dx = dxp[:, pt:pt + h, pl:pl + wd, :]

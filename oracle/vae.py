@@ -114,6 +114,16 @@ def unflatten_params(spec, flat):
     return p
 
 
+def act_bwd(cache, key, da, alpha, act=None):
+    """(Leaky)ReLU backward at cache[key].  `act` (tests) optionally carries, per key, the boolean "pre-activation counted as positive"
+    pattern of ANOTHER fp32 implementation of the same step: a pre-activation within round-off of 0 lands on either side of the kink
+    depending on summation order, and its derivative (alpha or 1) is then a legitimate property of that implementation, not an error
+    (tests/gpu_util.py: device_activation_pattern)."""
+    if act is not None and key in act:
+        return np.where(act[key], da, da * da.dtype.type(alpha))
+    return nn.leaky_relu_bwd(cache[key], da, alpha)
+
+
 class Model:
     def __init__(self, arch, height=128, width=128, channels=1, inter_res=8, zdim=128):
         self.arch, self.h, self.w, self.c = arch, height, width, channels
@@ -203,8 +213,9 @@ class Model:
         return res
 
     # ------------------------------------------------------------------
-    def backward(self, p, x, out, cache, masks=None, kl=True, gx=None, klw=None):
-        """Gradient of losses()['loss'] w.r.t. every parameter (dict by name).  kl=False drops the KL term
+    def backward(self, p, x, out, cache, masks=None, kl=True, gx=None, klw=None, act=None):
+        """Gradient of losses()['loss'] w.r.t. every parameter (dict by name).  act: see act_bwd() (adds key 'l1_sign' = the other
+        implementation's sign(x_hat - x)).  kl=False drops the KL term
         (the ceVAE context branch, whose loss is the reconstruction sum only: trainers/ceVAE.py:43,49).
         gx / klw override d objective / d x_hat and the KL weight (default sign(x_hat - x) / N and 1 / N): restoration objectives."""
         masks = masks or {}
@@ -213,18 +224,18 @@ class Model:
         g = {}
         # d loss / d x_hat = sign(x_hat - x) / N   (tf.abs gradient: sign, 0 at 0)
         if gx is None:
-            gx = np.sign(out['x_hat'] - x) * dt(1.0 / n)
+            gx = (act['l1_sign'].astype(x.dtype) if act is not None and 'l1_sign' in act else np.sign(out['x_hat'] - x)) * dt(1.0 / n)
         a = cache['dec_out']
         da, g['Decoder/dec_Conv2D_final/kernel'], g['Decoder/dec_Conv2D_final/bias'] = \
             nn.conv2d_bwd(a, p['Decoder/dec_Conv2D_final/kernel'], gx, 1)
         for i in reversed(range(self.n_pool)):
             pre = f'Decoder/dec_Conv2DT_{i}'
             bnp = f'Decoder/batch_normalization_{i + 1}'
-            dbn = nn.leaky_relu_bwd(cache[f'dec_bn{i}'], da, LRELU_ALPHA)
+            dbn = act_bwd(cache, f'dec_bn{i}', da, LRELU_ALPHA, act)
             dc, g[bnp + '/gamma'], g[bnp + '/beta'] = nn.bn_frozen_bwd(cache[f'dec_c{i}'], p[bnp + '/gamma'], dbn)
             da, g[pre + '/kernel'], g[pre + '/bias'] = \
                 nn.conv2d_transpose_bwd(cache[f'dec_in{i}'], p[pre + '/kernel'], dc, 2)
-        dbn = nn.leaky_relu_bwd(cache['dec_bn_in'], da, 0.0)
+        dbn = act_bwd(cache, 'dec_bn_in', da, 0.0, act)
         dc, g['Decoder/batch_normalization/gamma'], g['Decoder/batch_normalization/beta'] = \
             nn.bn_frozen_bwd(cache['dec_c_in'], p['Decoder/batch_normalization/gamma'], dbn)
         dd4, g['Bottleneck/conv2d_1/kernel'], g['Bottleneck/conv2d_1/bias'] = \
@@ -260,7 +271,7 @@ class Model:
         for i in reversed(range(self.n_pool)):
             pre = f'Encoder/enc_conv2D_{i}'
             bnp = f'Encoder/batch_normalization_{i}'
-            dbn = nn.leaky_relu_bwd(cache[f'enc_bn{i}'], da, LRELU_ALPHA)
+            dbn = act_bwd(cache, f'enc_bn{i}', da, LRELU_ALPHA, act)
             dc, g[bnp + '/gamma'], g[bnp + '/beta'] = nn.bn_frozen_bwd(cache[f'enc_c{i}'], p[bnp + '/gamma'], dbn)
             da, g[pre + '/kernel'], g[pre + '/bias'] = \
                 nn.conv2d_bwd(cache[f'enc_in{i}'], p[pre + '/kernel'], dc, 2)
@@ -344,17 +355,18 @@ class CeVAE(Model):
                 'reconstructionLoss': 0.5 * (rv + rc).mean(), 'kl': kl.mean(), 'loss': (rv + kl + rc).mean(),
                 'loss_vae': (rv + kl).mean()}
 
-    def ce_backward(self, p, x, x_ce, out, caches, masks=None):
+    def ce_backward(self, p, x, x_ce, out, caches, masks=None, act_v=None, act_c=None):
         """d loss / d params (sum of both branches through the shared variables) and
         anomaly = L1_vae * |d loss_vae / d x| (trainers/ceVAE.py:51; x enters loss_vae through the encoder AND
         directly as the L1 label, whose tf.abs gradient is sign(x - x_hat)/N)."""
         mv, mc = self._split(masks)
         out_v, cache_v, out_c, cache_c = caches
-        gv = self.backward(p, x, out_v, cache_v, mv, kl=True)
-        gc = self.backward(p, x_ce, out_c, cache_c, mc, kl=False)
+        gv = self.backward(p, x, out_v, cache_v, mv, kl=True, act=act_v)
+        gc = self.backward(p, x_ce, out_c, cache_c, mc, kl=False, act=act_c)
         g = {name: gv[name] + gc[name] for name, _, _ in self.spec}
         n = x.shape[0]
-        dx = gv['__dx'] + np.sign(x - out['x_hat']) * x.dtype.type(1.0 / n)
+        sg = -act_v['l1_sign'].astype(x.dtype) if act_v is not None and 'l1_sign' in act_v else np.sign(x - out['x_hat'])
+        dx = gv['__dx'] + sg * x.dtype.type(1.0 / n)
         g['__dx_vae'] = dx
         g['anomaly'] = np.abs(out['x_hat'] - x) * np.abs(dx)
         return g
@@ -482,25 +494,25 @@ class SpatialAE:
         rec = l1.reshape(x.shape[0], -1).sum(axis=1).mean()
         return {'L1': l1, 'reconstructionLoss': rec, 'loss': rec}
 
-    def backward(self, p, x, out, cache, masks=None):
+    def backward(self, p, x, out, cache, masks=None, act=None):
         masks = masks or {}
         n, g = x.shape[0], {}
-        gx = np.sign(out['x_hat'] - x) * x.dtype.type(1.0 / n)
+        gx = (act['l1_sign'].astype(x.dtype) if act is not None and 'l1_sign' in act else np.sign(out['x_hat'] - x)) * x.dtype.type(1.0 / n)
         da, g['Decoder/dec_Conv2D_final/kernel'], g['Decoder/dec_Conv2D_final/bias'] = \
             nn.conv2d_bwd(cache['dec_out'], p['Decoder/dec_Conv2D_final/kernel'], gx, 1)
         for i in reversed(range(self.n_pool)):
             bnp = f'Decoder/batch_normalization_{i + 1}'
-            dbn = nn.leaky_relu_bwd(cache[f'dec_bn{i}'], da, LRELU_ALPHA)
+            dbn = act_bwd(cache, f'dec_bn{i}', da, LRELU_ALPHA, act)
             dc, g[bnp + '/gamma'], g[bnp + '/beta'] = nn.bn_frozen_bwd(cache[f'dec_c{i}'], p[bnp + '/gamma'], dbn)
             da, g[f'Decoder/dec_Conv2DT_{i}/kernel'], g[f'Decoder/dec_Conv2DT_{i}/bias'] = \
                 nn.conv2d_transpose_bwd(cache[f'dec_in{i}'], p[f'Decoder/dec_Conv2DT_{i}/kernel'], dc, 2)
-        dbn = nn.leaky_relu_bwd(cache['dec_bn_in'], da, 0.0)
+        dbn = act_bwd(cache, 'dec_bn_in', da, 0.0, act)
         dz, g['Decoder/batch_normalization/gamma'], g['Decoder/batch_normalization/beta'] = \
             nn.bn_frozen_bwd(cache['z'], p['Decoder/batch_normalization/gamma'], dbn)
         da = dz * masks['z'] if 'z' in masks else dz
         for i in reversed(range(self.n_pool)):
             bnp = f'Encoder/batch_normalization_{i}'
-            dbn = nn.leaky_relu_bwd(cache[f'enc_bn{i}'], da, LRELU_ALPHA)
+            dbn = act_bwd(cache, f'enc_bn{i}', da, LRELU_ALPHA, act)
             dc, g[bnp + '/gamma'], g[bnp + '/beta'] = nn.bn_frozen_bwd(cache[f'enc_c{i}'], p[bnp + '/gamma'], dbn)
             da, g[f'Encoder/enc_conv2D_{i}/kernel'], g[f'Encoder/enc_conv2D_{i}/bias'] = \
                 nn.conv2d_bwd(cache[f'enc_in{i}'], p[f'Encoder/enc_conv2D_{i}/kernel'], dc, 2)

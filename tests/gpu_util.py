@@ -42,3 +42,83 @@ def assert_close(actual, expected, tol=REL_TOL, name=''):
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Activation pattern of a device step (flip-aware gradient parity).
+# A pre-activation within fp32 round-off of 0 lands on either side of the (Leaky)ReLU kink depending on summation order; its
+# derivative (alpha or 1) then differs between ANY two fp32 implementations (TF-CPU vs TF-GPU included), and one such element moves
+# the small downstream gradient tensors by 1e-3 of their max.  The parity tests therefore read the pattern the device actually used
+# (sign of gamma' c + beta on its stored pre-BN outputs, sign(x_hat - x) of its reconstruction), count the disagreements with the
+# fp64 oracle ("flips") and differentiate the oracle with the device's pattern: every gradient tensor is then held to the 1e-4 bar
+# regardless of flips, and with zero flips this is exactly the plain oracle gradient.
+# ------------------------------------------------------------------------------------------------------------------
+BN_MULT = np.float32(1.0) / np.sqrt(np.float32(1.0) + np.float32(1e-3))
+
+
+def _bn_positive(c, gamma, beta):
+    """sign of fmaf(c, gamma * mult, beta) as the kernels evaluate it (fp32 product gamma*mult, fused multiply-add)."""
+    a = (np.asarray(gamma, np.float32) * BN_MULT).astype(np.float64)
+    return (c.astype(np.float64) * a + np.asarray(beta, np.float32).astype(np.float64)) > 0
+
+
+def device_activation_pattern(eng, params, x_target, xhat_dev, cache, n_pool, bn_names, rows=None,
+                              final_kernel='Decoder/dec_Conv2D_final/kernel'):
+    """Call right after eng.forward(..., want_backward=True) and BEFORE eng.backward() (the fused last block leaves its d loss / d c
+    in the ping-pong buffer the backward reuses).  params: dict name -> fp32 array (the engine's); x_target / xhat_dev: [n,H,W,1]
+    L1 target and the DEVICE reconstruction; cache: the oracle's forward cache (shapes + its own pattern for the flip count);
+    bn_names: {'enc': [prefix per block], 'dec_in': prefix, 'dec': [prefix per block]} of the BatchNormalization layers;
+    rows: slice of the handle's sample rows to read (ceVAE handles hold [x ; x_ce]).
+    Returns (act, flips): act feeds oracle backward(act=...), flips = {key: count of disagreements with the oracle}."""
+    n = x_target.shape[0]
+    rows = rows if rows is not None else slice(0, n)
+    act, flips = {}, {}
+
+    def grab(name, like):
+        buf = eng.debug_buffer(name).cpu().numpy()
+        per = int(np.prod(like.shape[1:]))
+        return buf.reshape(-1, per)[rows].reshape(like.shape)
+
+    def put(key, pos):
+        ref = cache[key] > 0
+        act[key] = pos
+        flips[key] = int((pos != ref).sum())
+
+    for i in range(n_pool):
+        c = grab(f'enc_c{i}', cache[f'enc_bn{i}'])
+        put(f'enc_bn{i}', _bn_positive(c, params[bn_names['enc'][i] + '/gamma'], params[bn_names['enc'][i] + '/beta']))
+    c = grab('dec_in', cache['dec_bn_in'])
+    put('dec_bn_in', _bn_positive(c, params[bn_names['dec_in'] + '/gamma'], params[bn_names['dec_in'] + '/beta']))
+    xh = xhat_dev.astype(np.float32) if isinstance(xhat_dev, np.ndarray) else xhat_dev.cpu().numpy()
+    sg = np.sign(xh - np.asarray(x_target, np.float32)).astype(np.float64)          # fp32 subtraction, as the loss kernel does
+    fused = eng.debug_buffer('fused_final')
+    for i in range(n_pool):
+        key = f'dec_bn{i}'
+        g_, b_ = params[bn_names['dec'][i] + '/gamma'], params[bn_names['dec'][i] + '/beta']
+        if i == n_pool - 1 and fused:
+            # c of the last block was never written: d loss / d c = sign/N * w_f[ch] * lrelu'(bn) * gamma'[ch] sits in G0
+            dc = grab('G0', cache[key]).astype(np.float64)
+            wf = np.asarray(params[final_kernel], np.float32).reshape(-1).astype(np.float64)
+            a = (np.asarray(g_, np.float32) * BN_MULT).astype(np.float64)
+            base = sg * (1.0 / n) * (wf * a)[None, None, None, :]
+            pos = cache[key] > 0
+            known = base != 0
+            ratio = np.divide(dc, base, out=np.ones_like(dc), where=known)
+            assert (np.abs(ratio[known] - 1.0) < 1e-3).__or__(np.abs(ratio[known] - 0.3) < 1e-3).all(), 'fused d_c is not sign/N*w_f*lrelu\'*gamma\''
+            pos = np.where(known, ratio > 0.65, pos)
+            put(key, pos)
+        else:
+            put(key, _bn_positive(grab(f'dec_c{i}', cache[key]), g_, b_))
+    act['l1_sign'] = sg
+    return act, flips
+
+
+def assert_grads_close(got, want, names, tol=REL_TOL, flips=None):
+    """max-norm relative bar on every named gradient tensor; the message carries the flip census."""
+    worst = {}
+    for name in names:
+        scale = max(np.abs(want[name]).max(), 1e-30)
+        worst[name] = np.abs(np.asarray(got[name], np.float64) - want[name]).max() / scale
+    bad = {k: f'{v:.2e}' for k, v in worst.items() if not v <= tol}
+    assert not bad, f'gradient tensors over {tol:g}: {bad}; flips {flips}'
+    return worst

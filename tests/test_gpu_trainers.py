@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import vae as ovae
+from tests.gpu_util import assert_grads_close, device_activation_pattern
 
 pytestmark = pytest.mark.gpu
 
@@ -448,24 +449,34 @@ def test_context_encoder_trainer(tmp_path, mname):
     model.mask_rng = random.Random(0)            # the reference draws the squares from the unseeded `random` module
     assert model.model_dir.startswith('CE_dSyntheticDataset')
     x, _, bm = ds.next_batch(4, set='TRAIN', return_brainmask=True)
-    x_ce = retrieve_masked_batch(x, bm)
+    x_ce = retrieve_masked_batch(x, bm, rng=random.Random(1))          # seeded: every input of this test is reproducible
     assert x_ce.shape == x.shape and (x_ce != x).any()
     m = ovae.SpatialAE(64, 64, 1, 8) if mname == 'autoencoder_spatial' else ovae.Model('AE', 64, 64, 1, 8, 64)
-    p = {k: v.astype(np.float64) for k, v in model.engine.get_params().items()}
+    p32 = model.engine.get_params()
+    p = {k: v.astype(np.float64) for k, v in p32.items()}
     masks = model._draw(4, True)[1]
     m64 = {k: v.astype(np.float64) for k, v in masks.items()}
     args = (p, x_ce.astype(np.float64), m64) if mname == 'autoencoder_spatial' else (p, x_ce.astype(np.float64), None, m64)
     out, cache = m.forward(*args)
     ls = m.losses(x.astype(np.float64), out)
-    g = m.backward(p, x.astype(np.float64), out, cache, m64)
-    got = model.engine.forward(x, None, masks, want_backward=True, x_ce=x_ce)
-    model.engine.backward()
-    assert float(got['scalars'][0]) == pytest.approx(ls['reconstructionLoss'], rel=2e-4)
-    assert np.abs(got['x_hat'].cpu().numpy() - out['x_hat']).max() <= 1e-4 * np.abs(out['x_hat']).max()
-    assert np.abs(got['L1'].cpu().numpy() - ls['L1']).max() <= 2e-4 * np.abs(ls['L1']).max()
-    grads = model.engine.get_grads()
-    for name in ('Encoder/enc_conv2D_0/kernel', 'Encoder/enc_conv2D_1/kernel', 'Decoder/dec_Conv2DT_0/kernel', 'Decoder/dec_Conv2D_final/kernel'):
-        assert np.abs(grads[name] - g[name]).max() <= 1e-4 * np.abs(g[name]).max(), name
+    bn_names = {'enc': [f'Encoder/batch_normalization_{i}' for i in range(3)], 'dec_in': 'Decoder/batch_normalization',
+                'dec': [f'Decoder/batch_normalization_{i + 1}' for i in range(3)]}
+    for math in ('f32', 'bf16x3'):
+        # round 1's red run of this test (enc0 filter gradient 1.9e-4 off) was activation-kink flips, not arithmetic: with freshly
+        # initialised weights the decoder pre-activations are ~1e-2 and hundreds of them lie within 1e-6 of zero
+        # (tests/debug/ce_spatial_rootcause.py), and the masked batch was drawn from the unseeded `random` module, so the flip set changed
+        # from run to run.  The oracle is therefore differentiated with the device's activation pattern and EVERY tensor is held to 1e-4.
+        model.engine.set_math(math)
+        got = model.engine.forward(x, None, masks, want_backward=True, x_ce=x_ce)
+        act, flips = device_activation_pattern(model.engine, p32, x, got['x_hat'], cache, 3, bn_names)
+        model.engine.backward()
+        assert float(got['scalars'][0]) == pytest.approx(ls['reconstructionLoss'], rel=1e-4)
+        assert np.abs(got['x_hat'].cpu().numpy() - out['x_hat']).max() <= 1e-4 * np.abs(out['x_hat']).max()
+        assert np.abs(got['L1'].cpu().numpy() - ls['L1']).max() <= 1e-4 * np.abs(ls['L1']).max()
+        g = m.backward(p, x.astype(np.float64), out, cache, m64, act=act)
+        assert_grads_close(model.engine.get_grads(), g, [nm for nm, _, _ in model.engine.spec], flips=flips)
+        assert sum(flips.values()) <= 64, flips          # a handful of round-off flips, not a different function
+    model.engine.set_math('bf16x3')
     run = model.step(x, Phase.TRAIN, x_ce=x_ce, dropout_masks=masks)
     assert set(run) == {'reconstruction', 'L1', 'reconstructionLoss', 'loss'} and run['loss'] == run['reconstructionLoss']
     assert run['loss'] == pytest.approx(ls['loss'], rel=2e-4)

@@ -123,6 +123,7 @@ SYMBOLS = {
     'uad_gan_set_graph_mode': (C.c_int, [C.c_void_p, C.c_int]),
     'uad_gan_graph_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     'uad_gan_restore_step': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(UadGanIO), C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'uad_debug_buffer': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     'uad_gan_debug_buffer': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     'uad_op_conv_f': (C.c_int, [C.POINTER(UadConvDesc), C.c_void_p, C.POINTER(UadXform), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -110,6 +110,7 @@ struct uad_model {
     const float* mask_dec_eff;         // [last_n, flat] or null
     bool have_fwd;
     bool data_only;                    // uad_forward(want_backward = 2): no parameter gradients
+    bool last_fused_final;             // the last forward ran the last block's BN / final conv / loss inside the ConvT epilogue (its c is not written)
     std::vector<void*> allocs;
     // second stream + events of the backward pass; per-layer scratch touched by that stream
     hipStream_t side;
@@ -716,6 +717,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     if (vae && io->z_sigma) hipMemcpyAsync(io->z_sigma, m->sigma, zb, hipMemcpyDeviceToDevice, st);
     m->last_n = n; m->last_nuser = nu; m->last_io = *io; m->have_fwd = want_backward != 0;
     m->x_eff = xin; m->mask_dec_eff = mask_dec; m->data_only = want_backward == 2;
+    m->last_fused_final = fused_final && !(m->restore && want_backward);
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
@@ -1077,6 +1079,31 @@ int uad_set_math_mode(uad_model_t* m, int mode) {
     return UAD_OK;
 }
 int uad_get_math_mode(const uad_model_t* m) { return m ? m->math : -1; }
+
+// tests: named intermediates of the last uad_forward (pre-BN conv outputs, the decoder's input, the gradient ping-pong buffers).
+// Counts are for the sample count of the last forward (2n rows inside a ceVAE handle).
+int uad_debug_buffer(uad_model_t* m, const char* name, float** ptr, long long* count) {
+    if (!m || !name) return fail(UAD_ERR_INVALID, "null argument");
+    const long long n = m->last_n;
+    float* p = nullptr; long long c = 0;
+    int idx = -1;
+    if (sscanf(name, "enc_c%d", &idx) == 1 && idx >= 0 && idx < (int)m->enc.size()) {
+        const UadConvDesc& d = m->enc[idx].d; p = m->enc[idx].c; c = n * d.HS * d.WS * d.CS;
+    } else if (sscanf(name, "dec_c%d", &idx) == 1 && idx >= 0 && idx < (int)m->dec.size()) {
+        const UadConvDesc& d = m->dec[idx].d; p = m->dec[idx].c; c = n * d.HB * d.WB * d.CB;
+    } else if (!strcmp(name, "dec_in")) {
+        p = (float*)m->dec_in0; c = n * m->cfg.inter_res * m->cfg.inter_res * m->cenc;
+    } else if (!strcmp(name, "fused_final")) {
+        p = nullptr; c = m->last_fused_final ? 1 : 0;
+    } else if (!strcmp(name, "G0") || !strcmp(name, "G1")) {
+        const UadConvDesc& d = m->dec.back().d; p = name[1] == '0' ? m->G0 : m->G1; c = n * d.HB * d.WB * d.CB;
+    } else {
+        return fail(UAD_ERR_INVALID, "no debug buffer named %s", name);
+    }
+    if (ptr) *ptr = p;
+    if (count) *count = c;
+    return UAD_OK;
+}
 
 int uad_profile_enable(uad_model_t* m, int on) {
     if (!m) return fail(UAD_ERR_INVALID, "null model");

@@ -351,6 +351,14 @@ class Engine(_EvalOps):
         self.adam_step(lr, beta1, beta2, adam_eps)
         return out
 
+    def debug_buffer(self, name):
+        """tests: torch view of a named intermediate of the last forward (include/uad_hip.h: uad_debug_buffer)."""
+        ptr, cnt = C.c_void_p(), C.c_longlong()
+        _lib.check(self.lib.uad_debug_buffer(self.handle, name.encode(), C.byref(ptr), C.byref(cnt)))
+        if not ptr.value:
+            return int(cnt.value)           # flag entries ("fused_final")
+        return torch.as_tensor(_DevArray(ptr.value, cnt.value), device=self.device)
+
     def set_math(self, math):
         """'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 on the bf16 matrix cores, ~2^-17 relative product error)."""
         modes = {'f32': _lib.MATH_F32, 'bf16x3': _lib.MATH_BF16X3}
