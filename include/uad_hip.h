@@ -166,7 +166,10 @@ int uad_get_math_mode(const uad_model_t* m);
 /* tests: device pointer + element count (for the batch of the last uad_forward; 2n rows inside a ceVAE handle) of a named
  * intermediate: "enc_c<i>" / "dec_c<i>" = pre-BN output of encoder / decoder block i (the activation pattern of the step is
  * sign(gamma' c + beta); the last decoder block's is not written when its epilogue is fused -- read "G0" = d loss / d c of that block
- * right after a want_backward forward instead), "dec_in" = the decoder's pre-BN input, "G0" / "G1" = gradient ping-pong buffers. */
+ * right after a want_backward forward instead -- or, when the step keeps that gradient in its compressed form, "fin_bits" = one
+ * 32-bit word per output pixel (bit ch = channel ch's BN output > 0; read the floats' bit patterns) and "fin_dxhat" =
+ * sign(x_hat - x) / n per pixel; both report count 0 otherwise), "dec_in" = the decoder's pre-BN input, "G0" / "G1" = gradient
+ * ping-pong buffers, "fused_final" = flag in *count. */
 int uad_debug_buffer(uad_model_t* m, const char* name, float** ptr, long long* count);
 
 /* per-launch-group HIP-event profiler (bench.py's roofline leg).  While enabled, every launch group of

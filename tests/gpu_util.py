@@ -95,7 +95,18 @@ def device_activation_pattern(eng, params, x_target, xhat_dev, cache, n_pool, bn
     for i in range(n_pool):
         key = f'dec_bn{i}'
         g_, b_ = params[bn_names['dec'][i] + '/gamma'], params[bn_names['dec'][i] + '/beta']
-        if i == n_pool - 1 and fused:
+        bits = eng.debug_buffer('fin_bits') if (i == n_pool - 1 and fused) else 0
+        if i == n_pool - 1 and fused and not isinstance(bits, int):
+            # training step with the compressed loss gradient: the pattern IS what the device stored (one word per output pixel),
+            # next to sign(x_hat - x) / n
+            import torch
+            words = bits.view(torch.int32).cpu().numpy().view(np.uint32).reshape(-1, int(np.prod(cache[key].shape[1:3])))[rows]
+            words = words.reshape(cache[key].shape[:3])
+            pos = ((words[..., None] >> np.arange(cache[key].shape[3], dtype=np.uint32)) & 1).astype(bool)
+            dxh = eng.debug_buffer('fin_dxhat').cpu().numpy().reshape(-1, int(np.prod(cache[key].shape[1:3])))[rows].reshape(sg.shape)
+            assert np.array_equal(np.sign(dxh), sg) and np.allclose(np.abs(dxh[dxh != 0]), 1.0 / n, rtol=1e-6), 'fin_dxhat != sign(x_hat - x) / n'
+            put(key, pos)
+        elif i == n_pool - 1 and fused:
             # c of the last block was never written: d loss / d c = sign/N * w_f[ch] * lrelu'(bn) * gamma'[ch] sits in G0
             dc = grab('G0', cache[key]).astype(np.float64)
             wf = np.asarray(params[final_kernel], np.float32).reshape(-1).astype(np.float64)

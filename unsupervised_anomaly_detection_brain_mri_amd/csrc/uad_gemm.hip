@@ -1428,6 +1428,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     float* s_fx = s_epi + WGM * WGN * 32 * 36;  // EPI_FINAL: target / reconstruction / L1 tiles of the 2TH x 2TW output block
     float* s_fo = s_fx + 4 * TH * TW;
     float* s_fl = s_fo + 4 * TH * TW;
+    unsigned* s_fb = reinterpret_cast<unsigned*>(s_fl + 4 * TH * TW);   // EPI_FINAL + fin_bits: pattern word / d objective / d x_hat per pixel
+    float* s_fg = reinterpret_cast<float*>(s_fb + 4 * TH * TW);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -1623,19 +1625,28 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
                     rec += fabsf(diff);
                 }
                 if (a.Out) *reinterpret_cast<float4*>(a.Out + off[k]) = make_float4(cc[0], cc[1], cc[2], cc[3]);
-                if (a.ep.fin_dc) {
+                if (a.ep.fin_dc || a.ep.fin_bits) {
                     const float sgn = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * a.ep.fin_inv_batch;
                     float dc[4];
+                    unsigned nib = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float da = sgn * wv[e];
-                        const float dbn = bn[e] > 0.f ? da : da * a.ep.ealpha;
+                        const bool pos = bn[e] > 0.f;
+                        const float dbn = pos ? da : da * a.ep.ealpha;
                         dc[e] = dbn * scv[e];
                         dwf[e] = fmaf(sgn, av[e], dwf[e]);
                         s1[e] += dbn;
                         s2[e] = fmaf(dbn, cc[e], s2[e]);
+                        nib |= (pos ? 1u : 0u) << e;
                     }
-                    *reinterpret_cast<float4*>(a.ep.fin_dc + off[k]) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+                    if (a.ep.fin_dc) *reinterpret_cast<float4*>(a.ep.fin_dc + off[k]) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+                    if (a.ep.fin_bits) {
+                        // d loss / d c of this pixel = sgn * w_f[ch] * (bit ? 1 : alpha) * scale[ch]: one word + one float instead of 32 floats
+                        unsigned w = nib << ecol;
+                        w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
+                        if ((lane & 7) == 0) { s_fb[lidx[k]] = w; s_fg[lidx[k]] = sgn; }
+                    }
                     if ((lane & 7) == 0) dbf += sgn;
                 }
             }
@@ -1720,6 +1731,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             const size_t pix = ((size_t)n * d.HB + 2 * ty0 + yl) * d.WB + 2 * tx0 + xl;
             a.ep.fin_xhat[pix] = s_fo[idx];
             if (a.ep.fin_l1) a.ep.fin_l1[pix] = s_fl[idx];
+            if (a.ep.fin_bits) { a.ep.fin_bits[pix] = s_fb[idx]; a.ep.fin_dxhat[pix] = s_fg[idx]; }
         }
         float* fr = s_epi;                      // [waves][3*BN + 2]
         constexpr int FL = 3 * BN + 2;
@@ -1746,7 +1758,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 #pragma unroll
             for (int w = 0; w < WGM * WGN; ++w) t += fr[w * FL + tid];
             if (tid == 3 * BN + 1) a.ep.fin_rec_partial[tile] = t;
-            else if (a.ep.fin_dc) a.ep.fin_red_partial[tile * (3 * BN + 1) + tid] = t;
+            else if (a.ep.fin_dc || a.ep.fin_bits) a.ep.fin_red_partial[tile * (3 * BN + 1) + tid] = t;
         }
         return;
     }
@@ -1780,7 +1792,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 // too large to hold every channel at once, so channels are walked in CK-wide chunks (restaged per chunk, accumulators live
 // across chunks); the weight ring runs through the chunk boundary.
 // ------------------------------------------------------------------------------------------------
-template <int TH, int TW, int CK, int WGM, int WGN, bool FB>
+template <int TH, int TW, int CK, int WGM, int WGN, int FB>      // FB: 0 plain | 1 final-backward on load from c | 2 ... from the pattern bits
 __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_per_eu(2))) conv5_f16_kernel(const ConvGemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int IH = 2 * TH + 3, IW = 2 * TW + 3;
@@ -1809,8 +1821,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     const int AH = d.HB, AW = d.WB;
 
     const bool xf = a.xf.scale != nullptr;
-    constexpr bool fb = FB;                  // final-backward on load (UadXform::fb_*): its own instantiation, the extra
+    constexpr bool fb = FB != 0;             // final-backward on load (UadXform::fb_*): its own instantiation, the extra
                                              // prefetch registers would otherwise spill the 64-column variant
+    constexpr bool fbb = FB == 2;            // ... from one pattern word per pixel instead of the 32 pre-BN values (UadXform::fb_bits)
     if (xf)
         for (int c = tid; c < CA; c += NT) {
             s_xf[c] = a.xf.scale[c] * a.xf.mult;
@@ -1863,8 +1876,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     // HBM/L2 latencies were ~60 % of a workgroup's lifetime); conversion + LDS store happen once every wave has left chunk ch.
     constexpr int TOT = IH * IW * CQ;
     constexpr int PER = (TOT + NT - 1) / NT;
-    float4 pf[PER];
-    float pg[FB ? PER : 1];                  // fb mode: the pixel's d objective / d x_hat, fetched with the tile
+    float4 pf[fbb ? 1 : PER];
+    float pg[fb ? PER : 1];                  // fb mode: the pixel's d objective / d x_hat, fetched with the tile
+    unsigned pb[fbb ? PER : 1];              // bits mode: the pixel's activation-pattern word
     auto issue_stage = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -1874,7 +1888,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             const int gy = gy0 + iy, gx = gx0 + ix;
             const bool ok = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
             const int gp = ok ? (gy * AW + gx) : 0;
-            pf[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok ? cq * 4 : 0));
+            if (fbb) pb[u] = a.xf.fb_bits[(size_t)n * AH * AW + gp];
+            else pf[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok ? cq * 4 : 0));
             if (fb) pg[u] = a.xf.fb_dxhat[(size_t)n * AH * AW + gp];
         }
     };
@@ -1887,8 +1902,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             const int iy = pix / IW, ix = pix % IW;
             const int gy = gy0 + iy, gx = gx0 + ix;
             const bool ok = (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
-            float4 t = pf[u];
-            if (fb) {
+            float4 t = pf[fbb ? 0 : u];
+            if (fbb) {
+                // the same from the pattern word the fused forward epilogue left: the derivative side of every channel is one bit
+                const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
+                const float4 wf = *reinterpret_cast<const float4*>(s_xf + 2 * XF_LDS_CH + c0 + cq * 4);
+                const float g = ok ? pg[u] : 0.f;
+                const unsigned b = pb[u] >> (c0 + cq * 4);
+                t.x = g * wf.x * ((b & 1u) ? sc.x : sc.x * a.xf.alpha);
+                t.y = g * wf.y * ((b & 2u) ? sc.y : sc.y * a.xf.alpha);
+                t.z = g * wf.z * ((b & 4u) ? sc.z : sc.z * a.xf.alpha);
+                t.w = g * wf.w * ((b & 8u) ? sc.w : sc.w * a.xf.alpha);
+            } else if (fb) {
                 // final-backward on load: t = dxhat[pixel] * wf * lrelu'(bn(c)) * scale  (see UadXform::fb_*)
                 const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
                 const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
@@ -2031,7 +2056,7 @@ template <int TH, int TW, int CK, int WGM, int WGN>
 constexpr size_t conv5_f16_lds_bytes() {
     return (size_t)2 * (2 * TH + 3) * (2 * TW + 3) * (CK + 8) * 2 + (size_t)3 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
 }
-template <int TH, int TW, int CK, int WGM, int WGN, bool FB>
+template <int TH, int TW, int CK, int WGM, int WGN, int FB>
 void launch_conv5_f16_v(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = conv5_f16_lds_bytes<TH, TW, CK, WGM, WGN>();
     static bool attr_set = false;
@@ -2044,14 +2069,15 @@ void launch_conv5_f16_v(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
 }
 template <int TH, int TW, int CK, int WGM, int WGN>
 void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
-    if (a.xf.fb_dxhat) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, true>(a, grid, st);
-    else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, false>(a, grid, st);
+    if (a.xf.fb_bits) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 2>(a, grid, st);
+    else if (a.xf.fb_dxhat) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 1>(a, grid, st);
+    else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0>(a, grid, st);
 }
 
 template <int TH, int TW, int CST, int WGM, int WGN>
 constexpr size_t conv5_d16_lds_bytes() {
     return (size_t)2 * (TH + 2) * (TW + 2) * (CST + 8) * 2 + (size_t)2 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4 +
-           (size_t)WGM * WGN * 32 * 36 * 4 + (size_t)3 * 4 * TH * TW * 4;
+           (size_t)WGM * WGN * 32 * 36 * 4 + (size_t)5 * 4 * TH * TW * 4;
 }
 template <int TH, int TW, int CST, int WGM, int WGN>
 void launch_conv5_d16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
@@ -2675,7 +2701,9 @@ __global__ void __launch_bounds__(256) conv5_w_kernel(const ConvWArgs a, int til
 // NCSB = 1: one 32-cb x 32-cs block per 4-wave workgroup.  NCSB = 2: two cs blocks share ONE staged big tile in an 8-wave
 // workgroup (waves 0-3 / 4-7): the big tile (46 KB of fp32 per 8x8 positions, the kernel's dominant cost) is staged once for
 // twice the MFMA work and by twice the threads (one round of loads instead of two).
-template <int NCSB>
+// FBB: `big` is the last decoder block's d loss / d c in its compressed form (UadXform::fb_bits: pattern word + d objective / d x_hat
+// per pixel, CB == 32): the 46 KB fp32 halo tile becomes 2.9 KB of loads, expanded while it is written to LDS.
+template <int NCSB, bool FBB = false>
 __global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
 conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256 * NCSB, CSQ = 8 * NCSB;
@@ -2700,7 +2728,7 @@ conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     const int t_end = min(t_begin + tiles_per_split, total_tiles);
 
     const int cq = tid % CQ;
-    const bool xfa = a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
+    const bool xfa = !FBB && a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
     // activation-on-load tables in LDS
     if (tid < 32) {
         sXf[tid] = xfa ? a.xfb.scale[cb0 + tid] * a.xfb.mult : 1.f;
@@ -2709,6 +2737,16 @@ conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     if (tid < 32 * NCSB) {
         sXf[64 + tid] = xfs ? a.xfs.scale[cs0 + tid] * a.xfs.mult : 1.f;
         sXf[128 + tid] = xfs ? a.xfs.shift[cs0 + tid] : 0.f;
+    }
+
+    float fb_wf[4] = {0.f, 0.f, 0.f, 0.f}, fb_s1[4] = {0.f, 0.f, 0.f, 0.f}, fb_s0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FBB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            fb_wf[e] = a.xfb.fb_wf[cb0 + cq * 4 + e];
+            fb_s1[e] = a.xfb.scale[cb0 + cq * 4 + e] * a.xfb.mult;
+            fb_s0[e] = fb_s1[e] * a.xfb.alpha;
+        }
     }
 
     constexpr int MAXT = 7;
@@ -2748,7 +2786,9 @@ conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
             constexpr int TOT = IH * IW * CQ;
             constexpr int BATCH = 6;
             for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
-                float4 v[BATCH];
+                float4 v[FBB ? 1 : BATCH];
+                unsigned vb[FBB ? BATCH : 1];
+                float vg[FBB ? BATCH : 1];
                 bool ok[BATCH];
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u) {
@@ -2758,14 +2798,26 @@ conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
                     const int gy = gy0 + iy, gx = gx0 + ix;
                     ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
                     const int gp = ok[u] ? (gy * d.WB + gx) : 0;
-                    v[u] = *reinterpret_cast<const float4*>(bigb + (size_t)gp * d.CB + cq * 4);
+                    if (FBB) {
+                        vb[u] = a.xfb.fb_bits[(size_t)n * d.HB * d.WB + gp];
+                        vg[u] = a.xfb.fb_dxhat[(size_t)n * d.HB * d.WB + gp];
+                    } else {
+                        v[u] = *reinterpret_cast<const float4*>(bigb + (size_t)gp * d.CB + cq * 4);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u) {
                     const int f = f0 + u * NT;
                     if (f >= TOT) continue;
-                    float4 tv = v[u];
-                    if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
+                    float4 tv = v[FBB ? 0 : u];
+                    if (FBB) {
+                        const unsigned b = vb[u] >> (cb0 + cq * 4);
+                        const float gq = vg[u];
+                        tv.x = gq * fb_wf[0] * ((b & 1u) ? fb_s1[0] : fb_s0[0]);
+                        tv.y = gq * fb_wf[1] * ((b & 2u) ? fb_s1[1] : fb_s0[1]);
+                        tv.z = gq * fb_wf[2] * ((b & 4u) ? fb_s1[2] : fb_s0[2]);
+                        tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
+                    } else if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
                     tv = keep4(ok[u], tv);
                     uint2 hi, lo;
                     split_bf16(tv, hi, lo);
@@ -3128,6 +3180,10 @@ inline WChoice choose_w(const UadConvDesc& d) {
 }
 }  // namespace
 
+bool uad_conv_w_supports_fb_bits(const UadConvDesc& d, bool math_bf16x3) {
+    return math_bf16x3 && choose_w5(d).ok && d.CB == 32 && !getenv("UAD_NO_FB_BITS");
+}
+
 size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
     const W5Choice w5 = choose_w5(d);
     if (w5.ok) return (size_t)w5.splits * d.KS * d.KS * d.CB * d.CS;
@@ -3172,7 +3228,20 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                     fprintf(stderr, "[w5 CB=%d CS=%d HS=%d grid=%d,%d,%d] span=%llu (100MHz ticks) wg dur min=%llu avg=%llu max=%llu latest start=%llu\n", d.CB, d.CS, d.HS, g->x, g->y, g->z,
                             t1 - t0, dmin, dsum / nb, dmax, smax); } } dump{dbg_this, st, wbuf, &grid, &wcalls, d};
             static const bool pair_ok = !getenv("UAD_NO_W2");
-            if (pair_ok && d.CS % 64 == 0) {
+            if (xfb.fb_bits) {          // compressed d loss / d c of the last decoder block (callers check uad_conv_w_supports_fb_bits)
+                static bool fb_attr = false;
+                if (!fb_attr) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_lds_bytes(1));
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_lds_bytes(2));
+                    fb_attr = true;
+                }
+                if (pair_ok && d.CS % 64 == 0) {
+                    grid.y = d.CS / 64;
+                    hipLaunchKernelGGL((conv5_w_bf16_kernel<2, true>), grid, dim3(512), conv5_w_bf16_lds_bytes(2), st, a, w5.tiles_per_split, w5.total_tiles);
+                } else {
+                    hipLaunchKernelGGL((conv5_w_bf16_kernel<1, true>), grid, dim3(256), conv5_w_bf16_lds_bytes(1), st, a, w5.tiles_per_split, w5.total_tiles);
+                }
+            } else if (pair_ok && d.CS % 64 == 0) {
                 grid.y = d.CS / 64;
                 hipLaunchKernelGGL(conv5_w_bf16_kernel<2>, grid, dim3(512), conv5_w_bf16_lds_bytes(2), st, a, w5.tiles_per_split, w5.total_tiles);
             } else {

@@ -31,6 +31,11 @@ struct UadXform {
     // i.e. the big operand is the last block's PRE-BN output and the loss gradient is never materialised.
     const float* fb_dxhat = nullptr;   // [N, HB, WB]
     const float* fb_wf = nullptr;      // [CB]
+    // ... and the same without reading c at all (training step): fb_bits[N, HB, WB] holds one word per pixel whose bit ch is
+    // (scale*c + shift > 0) as the last block's fused epilogue saw it (UadEpilogue::fin_bits).  The big operand pointer is then unused:
+    // the 128 B / pixel of d loss / d c shrink to 8 B / pixel (bits + dxhat).  Understood by the F-kind bf16x3 kernel and by the k5 s2
+    // bf16x3 filter-gradient kernel (there as the transform of `big`); CB <= 32.
+    const unsigned* fb_bits = nullptr;
 };
 
 enum { UAD_EPI_BIAS = 0, UAD_EPI_BWD_ACT = 1, UAD_EPI_FINAL = 2 };
@@ -61,7 +66,9 @@ struct UadEpilogue {
     float* fin_l1;              // [N,H,W,1] or null
     float* fin_rec_partial;     // [tiles]               (tile = blockIdx.y * gridDim.x + blockIdx.x)
     float* fin_red_partial;     // [tiles][3C+1]: dwf[C], S1[C], S2[C], dbf   (backward only)
-    float* fin_dc;              // [N,H,W,C] d loss / d c, or null (forward only)
+    float* fin_dc;              // [N,H,W,C] d loss / d c, or null
+    unsigned* fin_bits;         // [N,H,W] activation-pattern word per pixel (bit ch = BN output > 0) + fin_dxhat[N,H,W] = sign(x_hat - x) *
+    float* fin_dxhat;           // fin_inv_batch: the compressed form of d loss / d c (UadXform::fb_bits); both or neither
     float fin_inv_batch;
 };
 
@@ -100,6 +107,8 @@ size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack);
 // W-type: dW[tap][cb][cs] = sum_{n,i,j} xfb(big)[..tap..,cb] * xfs(small)[n,i,j,cs]
 // `partial` must hold uad_conv_w_partial_floats(d) floats.
 size_t uad_conv_w_partial_floats(const UadConvDesc& d);
+// true when uad_launch_conv_w(d, ..., math_bf16x3) runs the kernel that understands xfb.fb_bits (compressed d loss / d c as `big`)
+bool uad_conv_w_supports_fb_bits(const UadConvDesc& d, bool math_bf16x3);
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
                        float* dW, float* partial, hipStream_t st, bool math_bf16x3 = false,
                        hipStream_t reduce_st = nullptr, hipEvent_t ev = nullptr, bool generic_bf16x3 = false);

@@ -110,6 +110,9 @@ struct uad_model {
     const float* mask_dec_eff;         // [last_n, flat] or null
     bool have_fwd;
     bool data_only;                    // uad_forward(want_backward = 2): no parameter gradients
+    unsigned* fin_bits;                // training step: the last block's d loss / d c in compressed form -- activation-pattern word per output
+    float* fin_dxh;                    //   pixel + sign(x_hat - x) / n per pixel (UadEpilogue::fin_bits, UadXform::fb_bits)
+    bool last_fin_bits;                // the last forward left its loss gradient in that form (G0 was not written)
     bool last_fused_final;             // the last forward ran the last block's BN / final conv / loss inside the ConvT epilogue (its c is not written)
     std::vector<void*> allocs;
     // second stream + events of the backward pass; per-layer scratch touched by that stream
@@ -410,6 +413,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     if (cfg->arch == UAD_ARCH_VAE) ALLOC(m->gm_dxhat, NB * H * Wd * cfg->channels);     // restoration mode (trainers/VAE_You.py)
     m->dec_in0 = (gm || sp) ? m->gm_h : m->cb;
     ALLOC(m->G0, maxact); ALLOC(m->G1, maxact);
+    { float* fbw = nullptr; ALLOC(fbw, NB * H * Wd); m->fin_bits = reinterpret_cast<unsigned*>(fbw); ALLOC(m->fin_dxh, NB * H * Wd); }
+    m->last_fin_bits = false;
     ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
     ALLOC(m->g_small[4], nflat); ALLOC(m->g_small[5], nflat);
     // column-partial scratch: worst case 64-row tiles
@@ -635,7 +640,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     // decoder
     const ConvLayer& DL = m->dec.back();
     const int bps = uad_final_blocks_per_sample(m->cfg.height, m->cfg.width);
-    bool fused_final = false;
+    bool fused_final = false, fin_bits_mode = false;
     for (size_t i = 0; i < m->dec.size(); ++i) {
         PROF(kDecF[i & 7]);
         UadConvDesc d = m->dec[i].d; d.N = n;
@@ -657,6 +662,14 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
             ep.fin_l1 = cevae ? ((io->l1_map || io->l1_map_ce) ? m->l1_own : nullptr) : io->l1_map;
             ep.fin_rec_partial = m->rec_partial; ep.fin_red_partial = m->red_partial;
             ep.fin_dc = (want_backward && !restore_bwd) ? m->G0 : nullptr;
+            ep.fin_bits = nullptr; ep.fin_dxhat = nullptr;
+            if (ep.fin_dc && d.CB <= 32 && uad_conv_f_supports_final_bwd(d, true, m->ws.floats) &&
+                (want_backward == 2 || uad_conv_w_supports_fb_bits(d, true))) {
+                // both consumers of d loss / d c (this layer's data- and filter-gradient kernels) can expand it from one pattern word +
+                // one float per pixel: 8 B instead of 128 B per pixel written here and read twice in the backward
+                ep.fin_dc = nullptr; ep.fin_bits = m->fin_bits; ep.fin_dxhat = m->fin_dxh;
+                fin_bits_mode = true;
+            }
             ep.fin_inv_batch = 1.0f / (float)nu;
             out = restore_bwd ? DL.c : nullptr;
         }
@@ -718,6 +731,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     m->last_n = n; m->last_nuser = nu; m->last_io = *io; m->have_fwd = want_backward != 0;
     m->x_eff = xin; m->mask_dec_eff = mask_dec; m->data_only = want_backward == 2;
     m->last_fused_final = fused_final && !(m->restore && want_backward);
+    m->last_fin_bits = fin_bits_mode;
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
@@ -778,11 +792,15 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         const long long ibias = (i == 0) ? m->rb : m->dec[i - 1].b;
         float* cp = m->cp_slot[i];
         // filter gradient on MAIN (big = d c raw, small = layer input with activation on load); slab reduce on SIDE
-        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, sd, next_event(m)); }
+        const bool last = i + 1 == (int)m->dec.size();
+        const bool fbb = last && m->last_fin_bits;      // d loss / d c of the last block exists only as pattern bits + d objective / d x_hat
+        UadXform gbits = no_xform();
+        if (fbb) { gbits = bn_xform(m, DL.gamma, DL.beta, kLrelu); gbits.fb_dxhat = m->fin_dxh; gbits.fb_wf = P(m, m->fw); gbits.fb_bits = m->fin_bits; }
+        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, sd, next_event(m)); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
         { PROF(kDecD[i & 7]); UadEpilogue e = epi_bwd(m, in, ig, ib, ia); e.colpart = cp;
-          const bool fb = m->restore && m->fb_on_load && i + 1 == (int)m->dec.size();
-          UadXform gx = no_xform();
+          const bool fb = m->restore && m->fb_on_load && last;
+          UadXform gx = fbb ? gbits : no_xform();
           if (fb) { gx = bn_xform(m, DL.gamma, DL.beta, kLrelu); gx.fb_dxhat = m->gm_dxhat; gx.fb_wf = P(m, m->fw); }
           uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
         edge(m, st, sd);   // column partials of this layer are ready
@@ -1093,6 +1111,10 @@ int uad_debug_buffer(uad_model_t* m, const char* name, float** ptr, long long* c
         const UadConvDesc& d = m->dec[idx].d; p = m->dec[idx].c; c = n * d.HB * d.WB * d.CB;
     } else if (!strcmp(name, "dec_in")) {
         p = (float*)m->dec_in0; c = n * m->cfg.inter_res * m->cfg.inter_res * m->cenc;
+    } else if (!strcmp(name, "fin_bits")) {       // one word per output pixel; null unless the last forward used the compressed form
+        p = m->last_fin_bits ? reinterpret_cast<float*>(m->fin_bits) : nullptr; c = m->last_fin_bits ? n * m->cfg.height * m->cfg.width : 0;
+    } else if (!strcmp(name, "fin_dxhat")) {
+        p = m->last_fin_bits ? m->fin_dxh : nullptr; c = m->last_fin_bits ? n * m->cfg.height * m->cfg.width : 0;
     } else if (!strcmp(name, "fused_final")) {
         p = nullptr; c = m->last_fused_final ? 1 : 0;
     } else if (!strcmp(name, "G0") || !strcmp(name, "G1")) {
