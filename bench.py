@@ -9,8 +9,11 @@ Workload = BASELINE.json configs[1]: VAE (variational_autoencoder) 128x128 "bf16
 arithmetic cannot meet the north_star parity bar (1e-4 rel vs fp32), so the default math mode is bf16x3: every fp32
 operand is split hi+lo into two bf16 values and a product is hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32
 accumulation (~2^-17 relative error per product; tests/test_gpu_model.py holds it to the same 1e-4 bar as --math f32,
-the exact-fp32-MFMA mode, whose number is reported alongside on 1 GPU).  Inputs (x, eps, dropout masks) are
-resident in HBM before the timed region.  N>1: slice-batch data parallel, weak scaling (64 slices per GPU), the three
+the exact-fp32-MFMA mode, whose number is reported alongside on 1 GPU).  The slice batch x is resident in HBM before the
+timed region; eps and the three dropout masks are drawn FRESH every timed step on the device (counter-based generator, one launch, inside
+the timed region).  Also reported: `trainer_loop_slices_per_s` = one process() epoch of trainers.VAE (the reference's unit of work), the
+roofline of the dominant kernel against BOTH bounds (mfma_fraction, hbm_fraction), the CPU baseline (torch-CPU oneDNN port, all physical
+cores).  N>1: slice-batch data parallel, weak scaling (64 slices per GPU), the three
 gradient segments are all-reduced over RCCL as soon as each is complete, overlapped with the rest of the backward.
 Prints ONE JSON line on rank 0.
 """
@@ -60,6 +63,38 @@ def flops_per_tag(n):
     return fl
 
 
+def bytes_per_tag(n, fin_bits=True):
+    """Algorithmic HBM bytes of one launch of every conv launch group: fp32 activations read / written once per
+    kernel; weights (<= 1.6 MB) ignored.  fwd: input + output; dgrad: d_out + the producer's pre-BN output (activation backward in the
+    epilogue) + d_in; wgrad: layer input + d_out.  The last decoder block keeps its d loss / d c as one pattern word + one float per
+    output pixel (fin_bits): its forward writes x_hat, L1 and those 8 bytes per pixel instead of 32 floats."""
+    by = {}
+    cin, res = 1, H
+    layers = []
+    i = 0
+    while res > INTER:
+        f = min(128, 32 * 2 ** i)
+        layers.append((f'enc{i}', res * res * cin, (res // 2) ** 2 * f))       # floats per slice: layer input, layer output
+        cin, res, i = f, res // 2, i + 1
+    i = 0
+    while res < H:
+        f = max(32, 128 // 2 ** i)
+        layers.append((f'dec{i}', res * res * cin, (2 * res) ** 2 * f))
+        cin, res, i = f, res * 2, i + 1
+    last = layers[-1][0]
+    for name, fin, fout in layers:
+        b_in, b_out = 4.0 * n * fin, 4.0 * n * fout
+        d_out = b_out
+        if name == last and fin_bits:
+            d_out = 8.0 * n * H * W
+            by[f'{name}.fwd'] = b_in + d_out + 12.0 * n * H * W        # + target read, x_hat and L1 written
+        else:
+            by[f'{name}.fwd'] = b_in + b_out
+        by[f'{name}.dgrad'] = d_out + 2.0 * b_in
+        by[f'{name}.wgrad'] = b_in + d_out
+    return by
+
+
 def train_flops_per_slice():
     """371.5 M MAC fwd -> 0.743 GFLOP; train step = 3x fwd minus the enc0 data-grad."""
     fwd_macs = sum(pos * k for _, pos, k in conv_layers())
@@ -67,43 +102,70 @@ def train_flops_per_slice():
     return 2.0 * (3 * (fwd_macs + small) - conv_layers()[0][1] * conv_layers()[0][2])
 
 
-def cpu_baseline(sample_batch=16, steps=4):
-    """The numpy oracle (a PORT of the reference semantics, not TF — TF 1.15 cannot be installed here) timed on this
-    host's cores on a bounded sample: `steps` VAE train steps at batch `sample_batch`, fp32.  BLAS threads are capped
-    (UAD_CPU_THREADS, default 32): the per-tap matmuls are small and oversubscribing a 256-thread host is slower."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _physical_cores():
+    try:
+        import psutil
+        return int(psutil.cpu_count(logical=False) or os.cpu_count() or 1)
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline(batch=64, steps=20, warmup=5):
+    """SURVEY.md section 8d's CPU baseline: the reference's TF-CPU path cannot be run (tensorflow==1.15.2 is not installable here and reference
+    Python may not travel to the GPU box), so the SAME step -- VAE forward + losses + backward + TF-Adam, fp32, explicit TF-SAME padding,
+    dropout masks and eps as inputs -- is timed as a torch-CPU graph (oneDNN convolutions, autograd; the formulation of tests/torch_ref.py,
+    which the tests hold against the oracle) on all physical cores of this host: median of `steps` steps after `warmup`, batch 64.
+    kind = "port"; cores and the CPU model are stated."""
+    import torch
     from oracle import nn as onn, vae as ovae
-    threads = int(os.environ.get('UAD_CPU_THREADS', '32'))
-    threads = max(1, min(threads, os.cpu_count() or 1))
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=threads)
-    except Exception:
-        limiter = None
+    from tests import torch_ref as tr
+    cores = _physical_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
     m = ovae.Model('VAE', H, W, 1, INTER, ZDIM)
-    p = ovae.init_params(m.spec, seed=3)
-    opt = m.new_opt(p)
-    x = ovae.synthetic_slices(sample_batch, H, W, seed=0)
+    p_np = ovae.init_params(m.spec, seed=3)
+    params = tr.to_torch(p_np, dtype=torch.float32, requires_grad=True)
+    names = [n for n, _, _ in m.spec]
+    slots_m = {n: torch.zeros_like(params[n]) for n in names}
+    slots_v = {n: torch.zeros_like(params[n]) for n in names}
+    x = torch.from_numpy(ovae.synthetic_slices(batch, H, W, seed=0))
     rng = np.random.default_rng(1)
-    eps = rng.standard_normal((sample_batch, ZDIM)).astype(np.float32)
-    masks = {'mu': onn.make_dropout_mask(rng, (sample_batch, ZDIM), 0.2),
-             'sigma': onn.make_dropout_mask(rng, (sample_batch, ZDIM), 0.2),
-             'dec': onn.make_dropout_mask(rng, (sample_batch, INTER * INTER * 16), 0.2)}
-    m.train_step(p, opt, x, eps, masks)          # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        m.train_step(p, opt, x, eps, masks)
-    dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([d.get('num_threads', 1) for d in threadpool_info()] or [1])
-    except Exception:
-        cores = threads
-    if limiter is not None:
-        limiter.restore_original_limits()
-    return {'value': round(sample_batch * steps / dt, 2), 'unit': 'slices/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'{steps} fp32 VAE train steps at batch {sample_batch} with the numpy oracle '
-                      f'(BLAS matmuls on {cores} threads of {os.cpu_count()} host CPUs; TF-CPU itself is not '
-                      f'installable), {dt:.1f} s'}
+    lr, b1, b2, eps_adam = 1e-4, 0.5, 0.999, 1e-8
+    n_pool = int(np.log2(H) - np.log2(INTER))
+    times = []
+    for t in range(1, warmup + steps + 1):
+        eps = torch.from_numpy(rng.standard_normal((batch, ZDIM)).astype(np.float32))
+        masks = {k: torch.from_numpy(onn.make_dropout_mask(rng, shp, 0.2)) for k, shp in
+                 (('mu', (batch, ZDIM)), ('sigma', (batch, ZDIM)), ('dec', (batch, INTER * INTER * 16)))}
+        t0 = time.perf_counter()
+        losses, _, _ = tr.forward_loss('VAE', m.spec, params, x, eps, masks, INTER, n_pool)
+        grads = torch.autograd.grad(losses['loss'], [params[n] for n in names])
+        with torch.no_grad():
+            lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            for n, g in zip(names, grads):
+                slots_m[n].mul_(b1).add_(g, alpha=1.0 - b1)
+                slots_v[n].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                params[n].sub_(lr_t * slots_m[n] / (slots_v[n].sqrt() + eps_adam))
+        dt = time.perf_counter() - t0
+        if t > warmup:
+            times.append(dt)
+    torch.set_num_threads(prev)
+    med = float(np.median(times))
+    return {'value': round(batch / med, 2), 'unit': 'slices/s', 'cores': cores, 'kind': 'port', 'cpu_model': _cpu_model(),
+            'ms_per_step': round(med * 1e3, 2),
+            'sample': f'median of {steps} fp32 VAE train steps (after {warmup} warm-up) at batch {batch} as a torch-CPU oneDNN graph with '
+                      f'explicit TF-SAME padding (tests/torch_ref.py), {cores} threads = all physical cores of {os.cpu_count()} logical CPUs; '
+                      f'TF-CPU 1.15 itself is not installable here; {sum(times):.1f} s of CPU work'}
 
 
 def bench_gmvae(args):
@@ -452,20 +514,28 @@ def main():
             flat[off:off + cnt] = 1.0
     eng.set_params(flat)
     # per-rank shard of the global synthetic batch, resident in HBM
+    from unsupervised_anomaly_detection_brain_mri_amd.engine import rng_fill
     x = torch.from_numpy(synthetic_slices(BATCH, H, W, seed=1000 + rank)).cuda()
-    g = torch.Generator(device='cuda').manual_seed(1 + rank)
-    eps = torch.randn(BATCH, ZDIM, device='cuda', generator=g)
-    keep = lambda shape: (torch.rand(shape, device='cuda', generator=g) >= 0.2).float() / 0.8   # rate 0.2, run.py:40
-    masks = {'mu': keep((BATCH, ZDIM)), 'sigma': keep((BATCH, ZDIM)), 'dec': keep((BATCH, INTER * INTER * 16))}
+    FLAT = INTER * INTER * 16
+    noise_jobs = [('eps', ZDIM, 'normal', 0.0), ('mu', ZDIM, 'keep', 0.2), ('sigma', ZDIM, 'keep', 0.2), ('dec', FLAT, 'keep', 0.2)]   # rate 0.2, run.py:40
     extra = {}
     if cevae:
         x_ce = x.clone()
         x_ce[:, 40:60, 50:70] = 0          # one 20x20 context hole, the same for every slice (trainers/CE.py:130-139, A3)
-        masks.update(mu_ce=keep((BATCH, ZDIM)), dec_ce=keep((BATCH, INTER * INTER * 16)))
+        noise_jobs += [('mu_ce', ZDIM, 'keep', 0.2), ('dec_ce', FLAT, 'keep', 0.2)]
         extra = {'x_ce': x_ce}
+    step_no = [0]
+
+    def draw():
+        """FRESH eps / dropout masks of this step, drawn on the device inside the timed region (one launch; the counter-based generator is
+        keyed by (step, global sample index), so every rank count draws the same global batch)."""
+        got = rng_fill(noise_jobs, BATCH, 1, step_no[0], rank * BATCH)
+        step_no[0] += 1
+        return got.pop('eps'), got
     dp = DataParallelStep(eng, world)
 
     def step():
+        eps, masks = draw()
         return dp.train_step(x, eps, masks, lr=1e-4, beta1=0.5, want_l1=True, want_latents=False, **extra)
 
     def timed(steps, warmup):
@@ -503,25 +573,36 @@ def main():
         dom = max(gemm, key=lambda t: gemm[t][1])
         dom_ms = gemm[dom][1] / gemm[dom][0]
         alg = fl[dom] / (dom_ms * 1e-3) / 1e12            # algorithmic (fp32-equivalent) TFLOP/s
+        # MFMA roofline on ALGORITHMIC flops: exact-fp32 MFMA peak in f32 mode; in bf16x3 every fp32 product costs three bf16 MFMA products,
+        # so the ceiling of algorithmic throughput is the dense bf16 peak / 3
         if math == 'f32':
-            achieved, peak, note = alg, PEAK_F32_MFMA_TFLOPS, 'v_mfma_f32_32x32x2_f32 (exact fp32)'
+            peak, note = PEAK_F32_MFMA_TFLOPS, 'v_mfma_f32_32x32x2_f32 (exact fp32); peak = dense fp32 MFMA'
         else:
-            achieved, peak, note = 3.0 * alg, PEAK_BF16_MFMA_TFLOPS, ('3 x v_mfma_f32_32x32x16_bf16 per fp32 product '
-                                                                       '(achieved = executed bf16 FLOP/s = 3 x algorithmic)')
+            peak, note = PEAK_BF16_MFMA_TFLOPS / 3.0, ('3 x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = dense bf16 MFMA 2500 TFLOP/s / 3 products '
+                                                       '(executed bf16 FLOP/s = 3 x achieved)')
+        by = bytes_per_tag(BATCH * (2 if cevae else 1), fin_bits=(math != 'f32'))
+        gbs = by[dom] / (dom_ms * 1e-3) / 1e9
         traffic = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, 'profiles', f'r01_traffic_{math}.json'))).get(dom)
-            if tr:
-                traffic = {'bytes': int(tr['fetch_bytes'] + tr['write_bytes']), 'fetch_bytes': int(tr['fetch_bytes']),
-                           'write_bytes': int(tr['write_bytes']),
-                           'source': f'profiles/r01_traffic_{math}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)'}
-        except Exception:
-            traffic = None
-        kernels = {t: {'ms': round(ms / c, 4), 'tflops': round(fl[t] / (ms / c * 1e-3) / 1e12, 2) if t in fl else None}
+        for cand in (f'r02_traffic_{math}.json', f'r01_traffic_{math}.json'):
+            try:
+                doc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
+                tr = doc.get(dom)
+                if tr:
+                    traffic = {'bytes': int(tr['fetch_bytes'] + tr['write_bytes']), 'fetch_bytes': int(tr['fetch_bytes']), 'write_bytes': int(tr['write_bytes']),
+                               'source': f'profiles/{cand}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH x2 gfx950 correction), '
+                                         f'measured at commit {doc.get("_commit", "(round 1 build: before the fin_bits change, dec3 kernels differ)")}; '
+                                         'not re-measured in this run (PMC counters need the profiler)'}
+                    break
+            except Exception:
+                continue
+        kernels = {t: {'ms': round(ms / c, 4), 'tflops': round(fl[t] / (ms / c * 1e-3) / 1e12, 2) if t in fl else None,
+                       'gbs': round(by[t] / (ms / c * 1e-3) / 1e9, 1) if t in by else None}
                    for t, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
-        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(achieved / peak, 4), 'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4),
-                'algorithmic_tflops': round(alg, 2), 'instruction': note}
+        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(alg, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                'frac': round(alg / peak, 4), 'mfma_fraction': round(alg / peak, 4),
+                'hbm_fraction': round(gbs / PEAK_HBM_GBS, 4), 'hbm_achieved_gbs': round(gbs, 1), 'hbm_peak_gbs': PEAK_HBM_GBS,
+                'algorithmic_bytes_per_launch': int(by[dom]), 'algorithmic_flop_per_launch': int(fl[dom]),
+                'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'instruction': note}
         return roof, kernels
 
     dt, loss = timed(args.steps, args.warmup)
@@ -536,6 +617,58 @@ def main():
         other = {'math': om, 'value': round(BATCH * args.steps / odt, 1), 'ms_per_step': round(odt / args.steps * 1e3, 4),
                  'roofline': oroof}
         eng.set_math(args.math)
+
+    # per-segment gradient all-reduce, timed on its own after the timed region (N > 1): what the backward has to hide
+    allreduce = None
+    if world > 1:
+        names = {_lib.SEG_DECODER: 'decoder', _lib.SEG_BOTTLENECK: 'bottleneck', _lib.SEG_ENCODER: 'encoder'}
+        allreduce = {'ranks': dist.get_world_size(), 'backend': dist.get_backend() + (' (RCCL over xGMI)' if not rehearsal else ' (single-GPU rehearsal)'),
+                     'segments': {}}
+        for seg, (off, cnt) in dp.segs.items():
+            if cnt == 0:
+                continue
+            buf = dp.grads[off:off + cnt]
+            for _ in range(3):
+                dist.all_reduce(buf)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); dist.barrier()
+            e0.record()
+            for _ in range(10):
+                dist.all_reduce(buf)
+            e1.record(); torch.cuda.synchronize()
+            allreduce['segments'][names[seg]] = {'bytes': int(cnt * 4), 'ms': round(e0.elapsed_time(e1) / 10, 4)}
+
+    # the reference's unit of work is the process() loop (trainers/VAE.py:76-103): one TRAIN epoch of trainers.VAE on an HBM-resident
+    # slice set -- batch gather, noise and scalar bookkeeping included -- next to the bare step above
+    loop = None
+    if world == 1 and not cevae and args.arch == 'VAE':
+        from unsupervised_anomaly_detection_brain_mri_amd.models import variational_autoencoder
+        from unsupervised_anomaly_detection_brain_mri_amd.trainers import VAE, Phase
+        from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_config, get_options
+        from unsupervised_anomaly_detection_brain_mri_amd.utils.slice_cache import DeviceDataset
+        eng.close()
+        nb = max(args.steps, 20)
+        base = synthetic_slices(256, H, W, seed=77)
+        imgs = np.concatenate([base] * ((BATCH * nb + 255) // 256))[:BATCH * nb]
+        dsd = DeviceDataset(imgs, np.zeros(len(imgs), np.int64), seed=0)
+        opt = get_options(batchsize=BATCH, learningrate=1e-4, numEpochs=1, zDim=ZDIM, outputWidth=W, outputHeight=H,
+                          config={'CHECKPOINTDIR': '/tmp/uad_bench_ck', 'SAMPLEDIR': '/tmp/uad_bench_smp'})
+        cfg = get_config(VAE, opt, 'ADAM', [INTER, INTER], 0.2, dsd)
+        cfg.quiet = True; cfg.useTensorboard = False
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            tm = VAE(None, cfg, network=variational_autoencoder)
+            tm.engine.set_math(args.math)
+            tm.process(dsd, 0, Phase.TRAIN)              # warm-up epoch
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sc = tm.process(dsd, 1, Phase.TRAIN)
+            torch.cuda.synchronize()
+            ldt = time.perf_counter() - t0
+        loop = {'value': round(BATCH * nb / ldt, 1), 'unit': 'slices/s', 'ms_per_step': round(ldt / nb * 1e3, 4), 'steps': nb,
+                'what': 'trainers.VAE.process(dataset, epoch, TRAIN): DeviceDataset.next_batch gather + device noise + train step per batch, '
+                        'one host synchronisation per epoch', 'epoch_loss': float(sc['loss'])}
+        tm.engine.close()
 
     if rank == 0:
         slices = BATCH * world * args.steps
@@ -560,9 +693,19 @@ def main():
             'kernels': kernels,
         }
         res['roofline'] = roof
-        res['roofline']['whole_step_algorithmic_tflops'] = res['config']['step_tflops']
+        step_bytes = sum(bytes_per_tag(BATCH * (2 if cevae else 1), fin_bits=(args.math != 'f32')).values())
+        res['roofline']['whole_step'] = {
+            'algorithmic_tflops': res['config']['step_tflops'], 'mfma_fraction': round(res['config']['step_tflops'] / roof['peak'], 4),
+            'algorithmic_gbytes': round(step_bytes / 1e9, 3),
+            'hbm_fraction': round(step_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 4),
+            'note': 'conv launch groups only (the first / final single-channel kernels, the bottleneck and Adam add < 8 % of the bytes)'}
         if other:
             res['other_math_mode'] = other
+        if loop:
+            res['trainer_loop_slices_per_s'] = loop['value']
+            res['trainer_loop'] = loop
+        if allreduce:
+            res['allreduce'] = allreduce
         if world == 1 and not args.no_cpu_baseline and not cevae:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))

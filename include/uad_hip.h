@@ -206,6 +206,18 @@ int uad_scores_auc(const uad_scores_t* s, double* auroc, double* auprc, double* 
 int uad_scores_dice(uad_scores_t* s, const double* thresholds_host, int k, double* dice_host, void* stream);
 int uad_scores_destroy(uad_scores_t* s);
 
+/* ---- noise of one step, drawn on the device --------------------------------------------------------------------
+ * The reference draws eps (tf.random_normal, models/variational_autoencoder.py:34) and the dropout masks (keras Dropout(rate)(x, training),
+ * e.g. :28-30) inside the graph on every sess.run; here they are explicit inputs of uad_forward, and this call fills them without a host
+ * round trip.  Philox4x32-10, key = seed, counter = (element / 4, GLOBAL sample index sample0 + i, step, stream id): sample i of the
+ * call gets the same numbers whichever rank / batch split draws it (data-parallel runs reproduce the single-process run).
+ *   kind UAD_RNG_NORMAL:    out[i][e] ~ N(0, 1) (Box-Muller on 24-bit uniforms)
+ *   kind UAD_RNG_KEEP_MASK: out[i][e] = u >= rate ? 1 / (1 - rate) : 0        (nn.dropout's rule, pre-scaled)
+ * jobs: up to 8 arrays [n, per_sample] filled by ONE launch; `stream` tells independent arrays of a step apart (mu / sigma / dec masks). */
+enum { UAD_RNG_NORMAL = 0, UAD_RNG_KEEP_MASK = 1 };
+typedef struct { float* out; int per_sample; int kind; float rate; int stream; } uad_rng_job_t;
+int uad_rng_fill(const uad_rng_job_t* jobs, int njobs, int n, unsigned long long seed, unsigned long long step, long long sample0, void* stream);
+
 /* ---- batch assembly from an HBM-resident slice cache ------------------------------------------------------------
  * Replaces the host-side batch slicing of dataloaders/BRAINWEB.py:411-478 (`next_batch`: images[images_in_set[start:end]], the label
  * -> brain-mask mapping :466-476) when the whole slice set lives in device memory (288 GB HBM): no H2D copy per step.

@@ -45,31 +45,77 @@ def main(args):
             setattr(config, arg, getattr(args, arg))
     model = trainer(None, config, network=network)
     model.train(dataset_hc)
-    # evaluation on synthetic lesion volumes (Evaluation.evaluate; Brainweb/MSLUB/MSISBI2015 need the real data)
-    vols, labs, masks = [], [], []
-    if args.cache:
-        from unsupervised_anomaly_detection_brain_mri_amd.utils.slice_cache import volumes_from_cache
-        vols, labs, masks, _ = volumes_from_cache(args.cache, 'TEST')
-    for p in range(0 if args.cache else 2):
-        x, lab, msk = synthetic_slices(16, args.outputHeight, args.outputWidth, seed=50 + p, lesions=True)
-        vols.append(x[..., 0].astype('float64')); labs.append(lab); masks.append(msk)
     if args.threshold:
         options['threshold'] = args.threshold
-    ev = Evaluation.evaluate(vols, labs, masks, model, options)
-    summary = {k: (v if isinstance(v, (list, dict, str)) else float(v)) for k, v in ev.items() if k not in ('time', 'epistemic_variance')}
-    # evalPC.npy / evalPC.txt under <SAMPLEDIR>/<network>/<model_dir>/eval-<epoch>-<timestamp>/ (utils/Evaluation.py:380-395,519-526)
-    try:
-        import time
-        import numpy as np
-        epoch = len(model.curves.get('TRAIN/loss', model.curves.get('TRAIN/reconstructionLoss', [])))
-        out_dir = os.path.join(options['train']['samplesDir'], network.__name__, model.model_dir, f"eval-{epoch}-{time.strftime('%Y%m%d_%H%M%S')}")
-        os.makedirs(out_dir, exist_ok=True)
-        np.save(os.path.join(out_dir, 'evalPC.npy'), summary)
-        with open(os.path.join(out_dir, 'evalPC.txt'), 'w') as f:
-            json.dump(summary, f, default=float)
-    except Exception as e:      # the summary on stdout is the contract; the files are a convenience
-        print(f'could not write the evaluation summary: {e}')
-    print(json.dumps(summary, default=float))
+    if args.cache:
+        # a real-data slice cache has no per-dataset loaders behind it: score its TEST patients once (array-level core)
+        from unsupervised_anomaly_detection_brain_mri_amd.utils.slice_cache import volumes_from_cache
+        vols, labs, masks, _ = volumes_from_cache(args.cache, 'TEST')
+        ev = Evaluation.evaluate_arrays(vols, labs, masks, model, options)
+        print(json.dumps(_summary(ev), default=float))
+        return
+
+    def ds_of(name):
+        if isinstance(name, Dataset):
+            return name
+        try:
+            return Dataset[str(name).upper()]            # the reference passes the raw -d string on, which cannot work (run.py:67); accept the member's name
+        except KeyError:
+            raise SystemExit(f'-d {name!r}: expected one of {[d.name for d in Dataset]}')
+
+    results = []
+    ########################
+    #  Evaluate best dice  #  (run.py:58-80)
+    ########################
+    if not args.threshold:
+        if args.ds:
+            results.append(evaluate_optimal(model, options, ds_of(args.ds)))
+            print(json.dumps(_summary(results[-1]), default=float))
+            return
+        for prior in (False, True):     # all datasets for best dice without, then with, the hyper-intensity prior
+            options['applyHyperIntensityPrior'] = prior
+            for d in (Dataset.BRAINWEB, Dataset.MSLUB, Dataset.MSISBI2015):
+                results.append(evaluate_optimal(model, options, d))
+    ###############################################
+    #  Evaluate generalization to other datasets  #  (run.py:82-97)
+    ###############################################
+    if args.threshold and args.ds:  # only threshold is invalid
+        results.append(evaluate_with_threshold(model, options, args.threshold, ds_of(args.ds)))
+    else:
+        options['applyHyperIntensityPrior'] = False
+        dataset_brainweb = get_evaluation_dataset(options, Dataset.BRAINWEB)
+        best_dice_val, thresh_val = Evaluation.determine_threshold_on_labeled_patients([dataset_brainweb], model, options, description='VAL')
+        print(f"Optimal threshold on MS Lesion Validation Set without optimal postprocessing: {thresh_val} (Dice-Score {best_dice_val})")
+        for d in (Dataset.BRAINWEB, Dataset.MSLUB, Dataset.MSISBI2015):      # re-evaluate with the previously determined threshold
+            results.append(evaluate_with_threshold(model, options, thresh_val, d))
+    print(json.dumps(_summary(results[-1]), default=float))
+
+
+def _summary(ev):
+    return {k: (v if isinstance(v, (list, dict, str)) else float(v)) for k, v in ev.items() if k not in ('time', 'epistemic_variance')}
+
+
+def get_evaluation_dataset(options, dataset):          # run.py:115-117
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_datasets
+    options['data']['dir'] = options["globals"].get(dataset.value, '')
+    return get_datasets(options, dataset=dataset)[1]
+
+
+def evaluate_with_threshold(model, options, threshold, dataset):          # run.py:100-105
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import Evaluation
+    options['applyHyperIntensityPrior'] = False
+    options['threshold'] = threshold
+    evaluation_dataset = get_evaluation_dataset(options, dataset)
+    description = f'{type(evaluation_dataset).__name__}-{dataset.name}-VALthresh_{options["threshold"]}'
+    return Evaluation.evaluate(evaluation_dataset, model, options, description=description, epoch=str(options['train']['numEpochs']))
+
+
+def evaluate_optimal(model, options, dataset):          # run.py:108-116
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import Evaluation
+    prior_str = "_wPrior" if options['applyHyperIntensityPrior'] else ''
+    evaluation_dataset = get_evaluation_dataset(options, dataset)
+    description = f'{type(evaluation_dataset).__name__}-{dataset.name}_upperbound_{options["threshold"]}{prior_str}'
+    return Evaluation.evaluate(evaluation_dataset, model, options, description=description, epoch=str(options['train']['numEpochs']))
 
 
 def build_parser():

@@ -178,10 +178,10 @@ def test_evaluate_with_monte_carlo_dropout(tmp_path):
     model = AE(None, get_config(AE, opt, 'ADAM', [8, 8], 0.2, ds), network=autoencoder)
     model.train(ds)
     x, lab, msk = synthetic_slices(10, 64, 64, seed=33, lesions=True)
-    ev = Evaluation.evaluate([x[..., 0].astype(np.float64)], [lab], [msk], model, opt)
+    ev = Evaluation.evaluate_arrays([x[..., 0].astype(np.float64)], [lab], [msk], model, opt)
     assert ev['epistemic_variance'].shape == (10, 64, 64) and (ev['epistemic_variance'] >= -1e-6).all() and ev['epistemic_variance'].max() > 0
     assert len(ev['uncertaintyHistogram']) == 50 and 0.0 <= ev['diff_AUC'] <= 1.0
     opt1 = dict(opt, numMonteCarloSamples=0)
-    ev1 = Evaluation.evaluate([x[..., 0].astype(np.float64)], [lab], [msk], model, opt1)
+    ev1 = Evaluation.evaluate_arrays([x[..., 0].astype(np.float64)], [lab], [msk], model, opt1)
     assert 'epistemic_variance' not in ev1
     model.engine.close()

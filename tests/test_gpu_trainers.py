@@ -33,9 +33,12 @@ def test_vae_train_process_reconstruct_resume(tmp_path):
     model = VAE(None, cfg, network=variational_autoencoder)
     assert model.network.__name__ == 'variational_autoencoder'
     assert model.model_dir == 'VAE_dSyntheticDataset_s64x64_variational_autoencoder_b8_z64_'
+    xv = ds.next_batch(8, set='VAL')[0]
+    before = model.step(xv, Phase.VAL, eps=np.zeros((8, 64), np.float32))['loss']
     model.train(ds)
     tr = model.curves['TRAIN/loss']
-    assert len(tr) == 2 and tr[1] < tr[0]
+    # (the epoch means carry the step's own noise -- eps and dropout are drawn on the device; the objective is judged on a fixed batch with eps = 0)
+    assert len(tr) == 2 and model.step(xv, Phase.VAL, eps=np.zeros((8, 64), np.float32))['loss'] < before
     assert set(model.curves) >= {'TRAIN/loss', 'TRAIN/kl', 'TRAIN/reconstructionLoss', 'VAL/loss'}
     ck = os.path.join(model.checkpointDir, model.model_dir)
     assert os.path.isfile(os.path.join(ck, 'VAE.model-2.npz')) and os.path.isfile(os.path.join(ck, 'Config-2.json'))
@@ -83,7 +86,7 @@ def test_evaluation_driver_runs_and_scores(tmp_path):
     for pth in range(2):
         x, lab, msk = synthetic_slices(12, 64, 64, seed=70 + pth, lesions=True)
         vols.append(x[..., 0].astype(np.float64)); labs.append(lab); masks.append(msk)
-    ev = Evaluation.evaluate(vols, labs, masks, model, opt)
+    ev = Evaluation.evaluate_arrays(vols, labs, masks, model, opt, eps=0.0)
     assert 0.0 <= ev['diff_AUPRC'] <= 1.0 and 0.0 <= ev['diff_AUC'] <= 1.0 and len(ev['Dice']) == 2
     # residual volume of one patient vs the numpy formula on the same reconstructions
     d, l1 = Evaluation.evaluate_volume(model, vols[0], masks[0], {**opt, 'medianFiltering': False})
@@ -251,7 +254,7 @@ def test_fanogan_trainer_surface(tmp_path):
     w = model.engine.get_buffer_host(_lib.BUF_PARAMS)
     steps = [model.engine.step_count(g) for g in ('Encoder', 'Generator', 'Discriminator')]
     vols = [synthetic_slices(8, 64, 64, seed=60, lesions=True)]
-    ev = Evaluation.evaluate([v[0][..., 0].astype('float64') for v in vols], [v[1] for v in vols], [v[2] for v in vols], model, opt)
+    ev = Evaluation.evaluate_arrays([v[0][..., 0].astype('float64') for v in vols], [v[1] for v in vols], [v[2] for v in vols], model, opt)
     assert 0.0 <= ev['diff_AUC'] <= 1.0 and 0.0 <= ev['diff_AUPRC'] <= 1.0
     model.engine.close()
     cfg2, _, _ = _config(fAnoGAN, tmp_path, h=64, bs=4, epochs=1)

@@ -109,3 +109,25 @@ def test_spec_mapping(tmp_path):
     assert got['missing'] == ['Decoder/dense/bias']
     with pytest.raises(ValueError, match='shape'):
         tfc.bundle_to_flat([('Encoder/conv/bias', (4,), 0)], tfc.read_checkpoint(str(tmp_path / 'w')))
+
+
+def test_adam_step_survives_beta1_power_underflow_and_bn_statistics_are_exported(tmp_path):
+    """with the reference's beta1 = 0.5 the fp32 beta1_power is 0 after 149 steps (less than an epoch), so the step count must come
+    from beta2_power; and a reference-side tf.train.Saver() restores every global variable, the BatchNormalization moving statistics
+    (never updated there: zeros / ones) included."""
+    rng = np.random.default_rng(2)
+    spec = [('Encoder/enc_conv2D_0/kernel', (5, 5, 1, 8), 0), ('Encoder/batch_normalization_0/gamma', (8,), 200),
+            ('Encoder/batch_normalization_0/beta', (8,), 208), ('Decoder/batch_normalization/gamma', (4,), 216), ('Decoder/batch_normalization/beta', (4,), 220)]
+    params, m, v = (rng.standard_normal(224).astype(np.float32) for _ in range(3))
+    for t in (1, 148, 150, 2000, 50000):
+        tensors = tfc.flat_to_bundle(spec, params, m, np.abs(v), adam_t=t)
+        if t >= 150:
+            assert float(tensors['beta1_power']) == 0.0          # what a long reference run leaves behind
+        tfc.write_checkpoint(str(tmp_path / f'ck{t}'), tensors)
+        assert tfc.bundle_to_flat(spec, tfc.read_checkpoint(str(tmp_path / f'ck{t}')))['adam_t'] == t
+    np.testing.assert_array_equal(tensors['Encoder/batch_normalization_0/moving_mean'], np.zeros(8, np.float32))
+    np.testing.assert_array_equal(tensors['Encoder/batch_normalization_0/moving_variance'], np.ones(8, np.float32))
+    np.testing.assert_array_equal(tensors['Decoder/batch_normalization/moving_variance'], np.ones(4, np.float32))
+    # a bundle with only an underflowed beta1_power gives no step (the caller keeps its own counter) instead of a wrong one
+    only_b1 = {k: val for k, val in tensors.items() if k != 'beta2_power'}
+    assert tfc.bundle_to_flat(spec, only_b1)['adam_t'] is None

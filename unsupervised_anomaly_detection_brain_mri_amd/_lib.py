@@ -21,6 +21,13 @@ class UadConfig(C.Structure):
                 ('dim_c', C.c_int), ('dim_z', C.c_int), ('dim_w', C.c_int), ('c_lambda', C.c_float)]
 
 
+class UadRngJob(C.Structure):
+    _fields_ = [('out', C.c_void_p), ('per_sample', C.c_int), ('kind', C.c_int), ('rate', C.c_float), ('stream', C.c_int)]
+
+
+RNG_NORMAL, RNG_KEEP_MASK = 0, 1
+
+
 class UadIO(C.Structure):
     _fields_ = [('x', C.c_void_p), ('eps', C.c_void_p), ('mask_mu', C.c_void_p), ('mask_sigma', C.c_void_p),
                 ('mask_dec', C.c_void_p), ('x_hat', C.c_void_p), ('l1_map', C.c_void_p), ('z_mu', C.c_void_p),
@@ -104,6 +111,7 @@ SYMBOLS = {
     'uad_scores_auc': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'uad_scores_dice': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     'uad_scores_destroy': (C.c_int, [C.c_void_p]),
+    'uad_rng_fill': (C.c_int, [C.POINTER(UadRngJob), C.c_int, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_longlong, C.c_void_p]),
     'uad_gan_create': (C.c_int, [C.POINTER(UadGanConfig), C.POINTER(C.c_void_p)]),
     'uad_gan_destroy': (C.c_int, [C.c_void_p]),
     'uad_gan_param_count': (C.c_longlong, [C.c_void_p]),

@@ -266,6 +266,10 @@ int uad_spatial_z_bwd_blocks(int rows);
 void uad_launch_spatial_z_bwd(const float* dz, const float* c, const float* gamma, const float* beta, float rs0, float alpha,
                               const float* mask, int rows, int C, float* dc, float* colpart, hipStream_t st);
 // batch assembly from the HBM-resident slice cache: out[b] = src[idx[b]]; mask[b][p] = lut[labels[idx[b]][p]] (lut null: the label value)
+// counter-based noise of one step (uad_misc.hip: rng_fill_kernel); at most 8 jobs
+struct UadRngJob { float* out; int per_sample; int kind; float rate; int stream; };
+void uad_launch_rng_fill(const UadRngJob* jobs, int njobs, int n, unsigned long long seed, unsigned long long step, long long sample0,
+                         hipStream_t st);
 void uad_launch_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, hipStream_t st);
 void uad_launch_gather_mask(const unsigned char* labels, const int* idx, int n, long long slice_px, const unsigned char* lut,
                             float* out, hipStream_t st);

@@ -716,6 +716,70 @@ void uad_launch_spatial_z_bwd(const float* dz, const float* c, const float* gamm
     const int rpb = (rows + nb - 1) / nb;
     hipLaunchKernelGGL(spatial_z_bwd_kernel, dim3(nb), dim3(256), 0, st, dz, c, gamma, beta, rs0, alpha, mask, rows, rpb, C, dc, colpart);
 }
+// ------------------------------------------------------------------------------------------------
+// Counter-based noise of one step (the reference draws eps / dropout masks inside the TF graph: tf.random_normal,
+// keras Dropout; models/variational_autoencoder.py:34, customlayers.py / autoencoder.py dropout layers).  Philox4x32-10 keyed by
+// the run seed; the counter is (element quad within the sample, GLOBAL sample index, step, stream id): a sample's noise does not
+// depend on which rank draws it or on how the global batch is split, so data-parallel runs reproduce the single-process run
+// (SURVEY.md section 8e).  kind 0: N(0,1) by Box-Muller on two 24-bit uniforms; kind 1: inverted-dropout keep mask
+// (u >= rate ? 1/(1-rate) : 0, nn.dropout's rule).  One launch fills every array of the step (grid.y = job).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+struct RngJobs { UadRngJob j[8]; };
+__global__ void __launch_bounds__(256) rng_fill_kernel(RngJobs jobs, int n, unsigned k0, unsigned k1, unsigned step_lo, unsigned step_hi,
+                                                       long long sample0) {
+    const UadRngJob jb = jobs.j[blockIdx.y];
+    const int quads = (jb.per_sample + 3) / 4;
+    const long long total = (long long)n * quads;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(q / quads), e4 = (int)(q % quads);
+        const unsigned long long gs = (unsigned long long)(sample0 + s);
+        unsigned r[4];
+        philox4x32_10((unsigned)e4, (unsigned)gs, step_lo, (step_hi << 8) ^ ((unsigned)(gs >> 32) << 16) ^ (unsigned)jb.stream, k0, k1, r);
+        float v[4];
+        if (jb.kind == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * 5.9604644775390625e-8f;       // (0, 1]
+                const float u2 = (float)(r[2 * h + 1] >> 8) * 5.9604644775390625e-8f;            // [0, 1)
+                const float rad = sqrtf(-2.0f * logf(u1));
+                float sn, cs;
+                sincosf(6.283185307179586f * u2, &sn, &cs);
+                v[2 * h] = rad * cs; v[2 * h + 1] = rad * sn;
+            }
+        } else {
+            const float keep = 1.0f / (1.0f - jb.rate);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) v[h] = ((float)(r[h] >> 8) * 5.9604644775390625e-8f >= jb.rate) ? keep : 0.0f;
+        }
+        float* o = jb.out + (size_t)s * jb.per_sample + (size_t)e4 * 4;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) if (e4 * 4 + h < jb.per_sample) o[h] = v[h];
+    }
+}
+}  // namespace
+
+void uad_launch_rng_fill(const UadRngJob* jobs, int njobs, int n, unsigned long long seed, unsigned long long step, long long sample0,
+                         hipStream_t st) {
+    RngJobs js;
+    int maxq = 1;
+    for (int i = 0; i < njobs; ++i) { js.j[i] = jobs[i]; const int q = (jobs[i].per_sample + 3) / 4; if (q > maxq) maxq = q; }
+    long long blocks = ((long long)n * maxq + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)blocks, njobs), dim3(256), 0, st, js, n, (unsigned)seed, (unsigned)(seed >> 32),
+                       (unsigned)step, (unsigned)(step >> 32), sample0);
+}
+
 void uad_launch_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, hipStream_t st) {
     const long long f4 = slice_elems / 4;
     int bx = (int)((f4 + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;

@@ -1166,6 +1166,20 @@ int uad_residual(const float* x, const float* xr, const float* mask, int n, int 
     return UAD_OK;
 }
 
+int uad_rng_fill(const uad_rng_job_t* jobs, int njobs, int n, unsigned long long seed, unsigned long long step, long long sample0, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > 8 || n <= 0 || sample0 < 0) return fail(UAD_ERR_INVALID, "rng_fill: 1..8 jobs, n > 0, sample0 >= 0");
+    UadRngJob js[8];
+    for (int i = 0; i < njobs; ++i) {
+        if (!jobs[i].out || jobs[i].per_sample <= 0 || (jobs[i].kind != UAD_RNG_NORMAL && jobs[i].kind != UAD_RNG_KEEP_MASK))
+            return fail(UAD_ERR_INVALID, "rng_fill: job %d: null output, empty sample or unknown kind", i);
+        if (jobs[i].kind == UAD_RNG_KEEP_MASK && !(jobs[i].rate >= 0.f && jobs[i].rate < 1.f)) return fail(UAD_ERR_INVALID, "rng_fill: dropout rate must be in [0, 1)");
+        js[i] = UadRngJob{jobs[i].out, jobs[i].per_sample, jobs[i].kind, jobs[i].rate, jobs[i].stream};
+    }
+    uad_launch_rng_fill(js, njobs, n, seed, step, sample0, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
 int uad_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, void* stream) {
     if (!src || !idx || !out || n <= 0 || slice_elems <= 0 || slice_elems % 4) return fail(UAD_ERR_INVALID, "gather_slices: bad arguments (slice elements must be a multiple of 4)");
     if (n > 65535) return fail(UAD_ERR_UNSUPPORTED, "gather_slices: at most 65535 slices per call");

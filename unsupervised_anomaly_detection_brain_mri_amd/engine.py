@@ -22,6 +22,25 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def rng_fill(jobs, n, seed, step, sample0=0, device=None, stream=None):
+    """One launch of the device noise generator (include/uad_hip.h: uad_rng_fill).  jobs: list of (name, per_sample shape tuple or int,
+    kind 'normal' | 'keep', rate); returns {name: device tensor [n, *shape]}.  Sample i gets the numbers of GLOBAL sample sample0 + i
+    at this step: the same whichever rank draws them."""
+    lib = _lib.load()
+    dev = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+    arr = (_lib.UadRngJob * len(jobs))()
+    out = {}
+    for k, (name, shape, kind, rate) in enumerate(jobs):
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        t = torch.empty((n,) + shape, device=dev, dtype=torch.float32)
+        out[name] = t
+        arr[k] = _lib.UadRngJob(t.data_ptr(), int(np.prod(shape)), _lib.RNG_NORMAL if kind == 'normal' else _lib.RNG_KEEP_MASK,
+                                float(rate), k)
+    st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.uad_rng_fill(arr, len(jobs), int(n), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), int(sample0), st))
+    return out
+
+
 class _EvalOps:
     """Model-independent device ops of the evaluation path (erosion, 3-D median, residual maps, sort-based metrics); shared by
     the AE-family Engine and the f-AnoGAN GanEngine.  Needs self.lib, self.device, self._dev, self._stream."""

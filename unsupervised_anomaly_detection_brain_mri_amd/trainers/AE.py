@@ -10,6 +10,12 @@ class AE(AEMODEL):
     ARCHS = ('AE', 'AE_spatial')
     SCALAR_KEYS = ('reconstructionLoss', 'loss')
 
+    def _noise_layout(self, dropout):
+        if not dropout or self.config.dropout_rate <= 0:
+            return []
+        e = self.engine
+        return [('z', (e.inter, e.inter, e._cenc()) if self.arch == 'AE_spatial' else self.config.zDim, 'keep')]      # autoencoder.py:29-30
+
     def _draw(self, n, dropout):
         if not dropout or self.config.dropout_rate <= 0:
             return None, None

@@ -58,7 +58,12 @@ class AEMODEL(DLMODEL):
         self.checkpointDir = os.path.join(c.checkpointDir or 'checkpoints', self.network.__name__)
         self.engine = self._make_engine(device)
         self.dp = self._make_dp(world)
-        self.rng = np.random.default_rng(seed)       # host RNG for eps / dropout masks (TF graph RNG is unseeded)
+        self.rng = np.random.default_rng(seed)       # host RNG: variable initialisation, and eps / masks when device_noise is off
+        # eps / dropout masks of a step are drawn ON THE DEVICE by a counter-based generator keyed (seed, step, global sample index):
+        # no host RNG, no H2D copy per step, and the same noise whichever rank holds the sample
+        self.device_noise = True
+        self.noise_seed = int(seed)
+        self.noise_step = 0
         self.initialize_variables()
         self.get_number_of_trainable_params()
 
@@ -118,41 +123,126 @@ class AEMODEL(DLMODEL):
 
     # ------------------------------------------------------------------ RNG inputs of one sess.run
     def _draw(self, n, dropout):
+        """Host draw (numpy) of (eps, masks): tests that inject noise, and device_noise = False."""
         raise NotImplementedError
 
+    def _noise_layout(self, dropout):
+        """[(name, per-sample shape, 'normal' | 'keep')] of the arrays one sess.run draws ('eps' + the dropout masks by io name)."""
+        raise NotImplementedError
+
+    @property
+    def rank(self):
+        import torch.distributed as dist
+        return dist.get_rank() if (self.dp.world > 1 and dist.is_initialized()) else 0
+
+    def _noise(self, n, dropout):
+        """(eps, masks) of the next sess.run.  Device path: one launch of the counter-based generator; sample i of this rank is global
+        sample rank * n + i of step noise_step (contiguous partitioning of the global batch, parallel.py)."""
+        if not self.device_noise:
+            return self._draw(n, dropout)
+        from ..engine import rng_fill
+        layout = self._noise_layout(dropout)
+        step = self.noise_step
+        self.noise_step += 1
+        if not layout:
+            return None, None
+        r = float(self.config.dropout_rate)
+        got = rng_fill([(name, shape, kind, r) for name, shape, kind in layout], n, self.noise_seed, step, self.rank * n,
+                       device=self.engine.device)
+        eps = got.pop('eps', None)
+        return eps, (got or None)
+
     # ------------------------------------------------------------------ one sess.run
-    def step(self, batch, phase, *, eps=None, dropout_masks=None, fetch_maps=True):
-        """The body of the reference's process() loop (= one sess.run, VAE.py:83-96): returns the same fetch keys.
-        TRAIN runs fwd + bwd + Adam; VAL/TEST run the forward + losses only (dropout False).
-        eps / dropout_masks may be injected (parity tests); otherwise they are drawn from the trainer's host RNG."""
-        phase = Phase(phase) if not isinstance(phase, Phase) else phase
+    def _run(self, batch, phase, eps=None, dropout_masks=None, fetch_maps=True, **kw):
+        """Enqueues one sess.run on the device and returns the engine's dict of DEVICE tensors (no host synchronisation)."""
         train = phase == Phase.TRAIN
         n = len(batch)
-        d_eps, d_masks = self._draw(n, dropout=train)
-        eps = d_eps if eps is None else eps
-        masks = d_masks if dropout_masks is None else dropout_masks
+        if eps is None and dropout_masks is None:
+            eps, masks = self._noise(n, dropout=train)
+        else:
+            d_eps, d_masks = self._draw(n, dropout=train)
+            eps = d_eps if eps is None else eps
+            masks = d_masks if dropout_masks is None else dropout_masks
         c = self.config
         if train:
-            out = self.dp.train_step(batch, eps, masks, lr=c.learningrate, beta1=c.beta1, want_l1=fetch_maps)
-        else:
-            out = self.engine.forward(batch, eps, masks, want_backward=False, want_l1=fetch_maps)
-        sc = self.dp.allreduce_scalars(out['scalars'].clone()).cpu().numpy()       # the only host sync of the step
+            return self.dp.train_step(batch, eps, masks, lr=c.learningrate, beta1=c.beta1, want_l1=fetch_maps, **kw)
+        return self.engine.forward(batch, eps, masks, want_backward=False, want_l1=fetch_maps, **kw)
+
+    def _scalars_to_run(self, sc):
         run = {'reconstructionLoss': np.float32(sc[0]), 'loss': np.float32(sc[2])}
         if 'kl' in self.SCALAR_KEYS:
             run['kl'] = np.float32(sc[1])
         else:
             run['loss'] = run['reconstructionLoss']
+        return run
+
+    def step(self, batch, phase, *, eps=None, dropout_masks=None, fetch_maps=True):
+        """The body of the reference's process() loop (= one sess.run, VAE.py:83-96): returns the same fetch keys as host values.
+        TRAIN runs fwd + bwd + Adam; VAL/TEST run the forward + losses only (dropout False).
+        eps / dropout_masks may be injected (parity tests); otherwise they are drawn on the device (see _noise)."""
+        phase = Phase(phase) if not isinstance(phase, Phase) else phase
+        out = self._run(batch, phase, eps, dropout_masks, fetch_maps)
+        sc = self.dp.allreduce_scalars(out['scalars'].clone()).cpu().numpy()       # the only host sync of the step
+        run = self._scalars_to_run(sc)
         if fetch_maps:
             run['reconstruction'] = out['x_hat'].cpu().numpy()
             run['L1'] = out['L1'].cpu().numpy()
         return run
 
+    def _shard(self, dataset, phase, **kw):
+        """This rank's slice of the next GLOBAL batch (config.batchsize slices per rank, contiguous partitioning): every rank advances the
+        same dataset cursor over batchsize * world slices and keeps rows [rank * bs, (rank + 1) * bs)."""
+        bs, w = self.config.batchsize, self.dp.world
+        got = dataset.next_batch(bs * w, set=phase.value, **kw)
+        if w == 1:
+            return got
+        lo = self.rank * bs
+        return tuple(None if a is None else a[lo:lo + bs] for a in got)
+
     def process(self, dataset, epoch, phase, optim=None):       # trainers/VAE.py:76-103
+        """One epoch.  The loop body only ENQUEUES work: the batch comes from the dataset (device tensors when it is an HBM-resident
+        utils.slice_cache.DeviceDataset), the noise is drawn on the device, and every step's scalar fetches are copied into one row of a
+        device table; the table is read back once per epoch (the reference's per-step console line is printed then, same text).
+        config.tfSummaryImages restores the reference's per-step map fetch for its TensorBoard image strip."""
+        import torch
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
-        scalars = defaultdict(list)
+        if getattr(self.step, '__func__', None) is not AEMODEL.step:
+            return self._process_via_step(dataset, epoch, phase)
         visuals = []
         # the reference fetches the maps of EVERY step for its TensorBoard image strip (trainer_utils.get_summary_dict); here that is opt-in
         # (config.tfSummaryImages): the maps are 4 MB of D2H per step (SURVEY.md §3.2)
+        want_images = bool(getattr(self.config, 'tfSummaryImages', False)) and bool(getattr(self.config, 'useTensorboard', False))
+        num_batches = dataset.num_batches(self.config.batchsize * self.dp.world, set=phase.value)
+        table = torch.zeros((max(num_batches, 1), 8), device=self.engine.device)
+        for idx in range(num_batches):
+            batch, _, _ = self._shard(dataset, phase)
+            out = self._run(batch, phase, fetch_maps=want_images)
+            table[idx].copy_(out['scalars'])
+            if want_images:
+                from .trainer_utils import get_summary_dict
+                b = batch.cpu().numpy() if hasattr(batch, 'cpu') else np.asarray(batch)
+                run = self._scalars_to_run(out['scalars'].cpu().numpy())
+                run['reconstruction'], run['L1'] = out['x_hat'].cpu().numpy(), out['L1'].cpu().numpy()
+                visuals.append(get_summary_dict(b, run)[1])
+        rows = self.dp.allreduce_scalars(table).cpu().numpy()[:num_batches]          # the epoch's one host synchronisation
+        scalars = defaultdict(list)
+        quiet = bool(getattr(self.config, 'quiet', False))
+        for idx, sc in enumerate(rows):
+            run = self._scalars_to_run(sc)
+            if not quiet:
+                print(f'Epoch ({phase.value}): [{epoch:2d}] [{idx:4d}/{num_batches:4d}] loss: {run["loss"]:.8f}')
+            for k, v in run.items():
+                scalars[k].append(v)
+        out = {k: np.mean(v) for k, v in scalars.items()}
+        for k, v in out.items():
+            self.curves.setdefault(f'{phase.value}/{k}', []).append(float(v))
+        self.log_to_tensorboard(epoch, out, visuals, phase)
+        return out
+
+    def _process_via_step(self, dataset, epoch, phase):
+        """The epoch loop of trainers whose step() is their own (multi-phase GAN trainers): one step() -- with its host fetch -- per batch."""
+        scalars = defaultdict(list)
+        visuals = []
         want_images = bool(getattr(self.config, 'tfSummaryImages', False)) and bool(getattr(self.config, 'useTensorboard', False))
         num_batches = dataset.num_batches(self.config.batchsize, set=phase.value)
         for idx in range(num_batches):
@@ -179,7 +269,8 @@ class AEMODEL(DLMODEL):
         for epoch in range(last_epoch, self.config.numEpochs):
             self.process(dataset, epoch, Phase.TRAIN, optim=True)
             last_epoch += 1
-            self.save(self.checkpointDir, last_epoch)
+            if self.rank == 0:                      # replicas are identical: one writer
+                self.save(self.checkpointDir, last_epoch)
             val_scalars = self.process(dataset, epoch, Phase.VAL)
             best_cost, last_improvement, stop = indicate_early_stopping(val_scalars['loss'], best_cost, last_improvement)
             if stop:
@@ -192,7 +283,7 @@ class AEMODEL(DLMODEL):
         x = np.asarray(x, np.float32)
         if x.ndim < 4:
             x = np.expand_dims(x, 0)
-        d_eps, masks = self._draw(len(x), dropout=bool(dropout))
+        d_eps, masks = self._noise(len(x), dropout=bool(dropout))
         if eps is None:
             eps = d_eps
         elif np.isscalar(eps):

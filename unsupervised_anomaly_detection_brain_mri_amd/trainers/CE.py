@@ -51,8 +51,7 @@ class CE(AE):
     def step(self, batch, phase, *, x_ce=None, eps=None, dropout_masks=None, fetch_maps=True):
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
         train = phase == Phase.TRAIN
-        _, d_masks = self._draw(len(batch), dropout=train)
-        masks = d_masks if dropout_masks is None else dropout_masks
+        masks = self._noise(len(batch), dropout=train)[1] if dropout_masks is None else dropout_masks
         c = self.config
         if train:
             out = self.dp.train_step(batch, None, masks, lr=c.learningrate, beta1=c.beta1, want_l1=fetch_maps, x_ce=x_ce)

@@ -22,6 +22,13 @@ class VAE(AEMODEL):
         return ZimmererEngine(c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]), c.zDim,
                               max_batch=max(int(c.batchsize), 1), device=device)
 
+    def _noise_layout(self, dropout):
+        z = self.config.zDim
+        lay = [('eps', z, 'normal')]
+        if dropout and self.config.dropout_rate > 0 and self.arch != 'VAE_Zimmerer':
+            lay += [('mu', z, 'keep'), ('sigma', z, 'keep'), ('dec', self.engine.flat, 'keep')]      # variational_autoencoder.py:31-35
+        return lay
+
     def _draw(self, n, dropout):
         z = self.config.zDim
         eps = self.rng.standard_normal((n, z)).astype(np.float32)

@@ -31,6 +31,13 @@ class ceVAE(AEMODEL):
         return ZimmererEngine(c.outputHeight, c.outputWidth, c.numChannels, int(c.intermediateResolutions[0]), c.zDim,
                               max_batch=max(int(c.batchsize), 1), device=device, cevae=True)
 
+    def _noise_layout(self, dropout):
+        z, f = self.config.zDim, self.engine.flat
+        lay = [('eps', z, 'normal')]
+        if dropout and self.config.dropout_rate > 0 and self.arch != 'ceVAE_Zimmerer':
+            lay += [('mu', z, 'keep'), ('mu_ce', z, 'keep'), ('sigma', z, 'keep'), ('dec', f, 'keep'), ('dec_ce', f, 'keep')]
+        return lay
+
     def _draw(self, n, dropout):
         """eps + the five independent dropout masks of one sess.run: the single Dropout layer object is called on z_mu,
         z_mu_ce, z_log_sigma and on both dec_dense outputs (context_encoder_variational_autoencoder.py:36-43)."""
@@ -51,9 +58,12 @@ class ceVAE(AEMODEL):
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
         train = phase == Phase.TRAIN
         n = len(batch)
-        d_eps, d_masks = self._draw(n, dropout=train)
-        eps = d_eps if eps is None else eps
-        masks = d_masks if dropout_masks is None else dropout_masks
+        if eps is None and dropout_masks is None:
+            eps, masks = self._noise(n, dropout=train)           # drawn on the device (AEMODEL._noise)
+        else:
+            d_eps, d_masks = self._draw(n, dropout=train)
+            eps = d_eps if eps is None else eps
+            masks = d_masks if dropout_masks is None else dropout_masks
         x_ce = masked_batch if (train and masked_batch is not None) else None
         c = self.config
         if train:
@@ -108,14 +118,20 @@ class ceVAE(AEMODEL):
                 print('Early stopping was triggered due to no improvement over the last 5 epochs')
                 break
 
-    def reconstruct(self, x, dropout=False, eps=None):
+    RECONSTRUCT_PER_SLICE = True          # utils/Evaluation.evaluate_volume passes per_slice=True
+
+    def reconstruct(self, x, dropout=False, eps=None, per_slice=False):
         """ceVAE.py:119-144: x_ce = x; fetches the reconstruction and every loss incl. `anomaly`; when
         config.use_gradient_based_restoration is truthy the returned 'reconstruction' is x - c * anomaly (sic: 'not the
-        real reconstruction but treated like it', :138-141).  eps as in AEMODEL.reconstruct."""
+        real reconstruction but treated like it', :138-141).  eps as in AEMODEL.reconstruct.
+        `anomaly` = L1_vae * |d mean_n(rec_vae + kl) / d x| carries the 1/n of the batch mean: a batch of n slices gives every slice's
+        map scaled by 1/n relative to n single-slice calls.  That is what the reference's graph returns for a batch too, but its evaluation
+        only ever feeds one slice (Evaluation.py:246-250); per_slice=True rescales by n so that a batched call equals the slice-by-slice
+        calls (row i of reconstruct(x[:k], per_slice=True) == reconstruct(x[i:i+1]) for the same noise)."""
         x = np.asarray(x, np.float32)
         if x.ndim < 4:
             x = np.expand_dims(x, 0)
-        d_eps, masks = self._draw(len(x), dropout=bool(dropout))
+        d_eps, masks = self._noise(len(x), dropout=bool(dropout))
         if eps is None:
             eps = d_eps
         elif np.isscalar(eps):
@@ -128,6 +144,8 @@ class ceVAE(AEMODEL):
         results['L1_ce'] = out['L1_ce'].cpu().numpy()
         results['L1'] = 0.5 * (results['L1_vae'] + results['L1_ce'])
         results['anomaly'] = out['anomaly'].cpu().numpy()
+        if per_slice:
+            results['anomaly'] = results['anomaly'] * np.float32(len(x))
         rec = out['x_hat'].cpu().numpy()
         c = self.config.use_gradient_based_restoration
         if c:

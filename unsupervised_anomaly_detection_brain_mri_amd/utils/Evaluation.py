@@ -1,5 +1,8 @@
-"""utils/Evaluation.py — residual-map scoring driver (the numeric core of _evaluate :183-365 and evaluate :372-526;
-PNG / PDF / NIfTI export dropped).  Everything between the reconstruction and the scalar metrics stays on the device:
+"""utils/Evaluation.py — residual-map scoring driver: the reference's entry points `evaluate(datasetPC, model, options, epoch,
+description)` (:372-526), `_evaluate(datasetObj, modelObj, sampleDir, options, split)` (:183-365) and
+`determine_threshold_on_labeled_patients(dataset_pc, model, options, epoch, description)` (:529-570) on the dataset duck-type
+(`patients`, `get_patient_idx`, `load_volume_and_groundtruth`, `options.{sliceStart, sliceEnd, axis, sliceResolution}`), over the
+array-level core `evaluate_arrays` / `evaluate_volume` (PNG / PDF / NIfTI export dropped).  Everything between the reconstruction and the scalar metrics stays on the device:
 slices of a volume are reconstructed in ONE batched call (the reference runs one sess.run per slice, :246-250), the brain
 masks are eroded (uad_erode_cross), residual map + mask + hyper-intensity prior come from uad_residual, the 5x5x5 median is
 uad_median3d, and AUROC / AUPRC / the Dice threshold sweep read one device sort of all voxels (uad_scores_*).
@@ -98,22 +101,34 @@ def compute_detection_rate(predicted_volume, groundtruth_volume):
     return tps, fps, fns
 
 
-def determine_threshold_on_labeled_patients(volumes, labels, brainmasks, model, options, eps=0.0):
+def determine_threshold_on_arrays(volumes, labels, brainmasks, model, options, eps=None):
     """utils/Evaluation.py:529-570: the Dice-optimal threshold of the residual maps of labelled VALIDATION patients
     (granularity-10 sweep), on the device path.  Returns (bestDiceScore, bestThreshold)."""
     diffs = [evaluate_volume(model, v, b, options, eps, device_out=True)[0] for v, b in zip(volumes, brainmasks)]
+    return _best_dice_of(model, diffs, labels)
+
+
+def _best_dice_of(model, diffs, labels):
     sc = model.engine.scores(torch.cat([d.reshape(-1) for d in diffs]), np.concatenate([np.asarray(l).flatten() for l in labels]))
     best = Metrics.compute_dice_curve_recursive_device(sc, granularity=10)
     sc.close()
     return best
 
 
-def evaluate_volume(model, volume, brainmasks, options, eps=0.0, device_out=False):
+def evaluate_volume(model, volume, brainmasks, options, eps=None, device_out=False, prior=None):
     """volume [S,H,W] in [0,1]; brainmasks [S,H,W].  Returns the post-processed residual sub-volume [S,H,W] (numpy, or the
-    device tensor with device_out=True) and per-slice l1 reconstruction errors (utils/Evaluation.py:223-312)."""
+    device tensor with device_out=True) and per-slice l1 reconstruction errors (utils/Evaluation.py:223-312).
+    eps: None = z is sampled as the reference's graph does at evaluation too; 0.0 = the deterministic mode.
+    prior: the hyper-intensity threshold (the reference takes the 0.9 quantile of the WHOLE loaded volume, :207); default: of `volume`."""
     S = volume.shape[0]
     eng = model.engine
-    prior = np.quantile(volume, 0.9) if should(options, 'applyHyperIntensityPrior') else None
+    if not should(options, 'applyHyperIntensityPrior'):
+        prior = None
+    elif prior is None:
+        prior = np.quantile(volume, 0.9)
+    # a batched reconstruct() must equal the reference's slice-by-slice calls (:246-250): trainers whose reconstruct() is a batch mean
+    # (ceVAE's input-gradient restoration) take per_slice=True
+    rkw = {'per_slice': True} if getattr(model, 'RECONSTRUCT_PER_SLICE', False) else {}
     bm = np.stack([np.squeeze(b) for b in brainmasks]).astype(np.float32)
     masks = eng.erode_cross(bm, 12) if should(options, 'erodeBrainmask') else eng._dev(bm)
     x = volume[..., None].astype(np.float32)
@@ -127,11 +142,11 @@ def evaluate_volume(model, volume, brainmasks, options, eps=0.0, device_out=Fals
         if K > 1:
             # Monte-Carlo dropout (utils/Evaluation.py:238-266): K stochastic passes, the residual is taken against the mean of the
             # brain-masked reconstructions, their per-pixel variance is the epistemic uncertainty
-            recs = torch.stack([torch.from_numpy(model.reconstruct(xb, dropout=True)['reconstruction']).to(eng.device) for _ in range(K)])
+            recs = torch.stack([torch.from_numpy(model.reconstruct(xb, dropout=True, **rkw)['reconstruction']).to(eng.device) for _ in range(K)])
             rec, v = eng.mc_stats(recs, masks[s0:s0 + bs, ..., None])
             var[s0:s0 + bs] = v[..., 0]
         else:
-            rec = model.reconstruct(xb, eps=eps)['reconstruction']
+            rec = model.reconstruct(xb, eps=eps, **rkw)['reconstruction']
         d, e = eng.residual(xb, rec, masks[s0:s0 + bs, ..., None], pos_only=should(options, 'keepOnlyPositiveResiduals'),
                             prior_thresh=prior)
         diffs[s0:s0 + bs] = d[..., 0]
@@ -143,16 +158,31 @@ def evaluate_volume(model, volume, brainmasks, options, eps=0.0, device_out=Fals
     return (diffs if device_out else diffs.cpu().numpy().astype(np.float64)), l1
 
 
-def evaluate(volumes, labels, brainmasks, model, options, eps=0.0):
+def evaluate_arrays(volumes, labels, brainmasks, model, options, eps=None, priors=None):
     """volumes/labels/brainmasks: lists of [S,H,W] arrays (one per patient).  Returns the reference's evalPC scalars
     (utils/Evaluation.py:416-470): diff_AUC, diff_AUPRC, bestDiceScore, bestThreshold, DiceScore, DiceScorePerPatient,
     PrecisionPerPatient, RecallPerPatient (after the small-component filter)."""
     _time = {'evaluation': time.time()}
     diffs, variances = [], []
-    for v, b in zip(volumes, brainmasks):
-        diffs.append(evaluate_volume(model, v, b, options, eps, device_out=True)[0])
+    l1s = []
+    for k, (v, b) in enumerate(zip(volumes, brainmasks)):
+        d, l1 = evaluate_volume(model, v, b, options, eps, device_out=True, prior=None if priors is None else priors[k])
+        diffs.append(d)
+        l1s.append(l1)
         if int(options.get('numMonteCarloSamples') or 0) > 1:
             variances.append(model.last_epistemic_variance.cpu().numpy())
+    ev = _score_diffs(model, diffs, labels, options, variances)
+    l1all = np.concatenate(l1s) if l1s else np.zeros(0)
+    # (trainers' l2err == l1err, sic: SURVEY.md A4)
+    ev['l1reconstructionErrorMean'] = ev['l2reconstructionErrorMean'] = float(np.mean(l1all)) if l1all.size else 0.0
+    ev['l1reconstructionErrorVariance'] = ev['l2reconstructionErrorVariance'] = float(np.var(l1all)) if l1all.size else 0.0
+    _time['evaluation'] = time.time() - _time['evaluation']
+    ev['time'] = _time
+    return ev
+
+
+def _score_diffs(model, diffs, labels, options, variances=None):
+    """The metric tail of utils/Evaluation.py:416-500 on per-patient residual volumes (device tensors [S,H,W]) and label maps."""
     d_all = torch.cat([d.reshape(-1) for d in diffs])
     l_all = np.concatenate([np.asarray(l).flatten() for l in labels])
     sc = model.engine.scores(d_all, l_all)
@@ -184,6 +214,140 @@ def evaluate(volumes, labels, brainmasks, model, options, eps=0.0):
         hi = float(np.percentile(pos, 99.8))
         # (the reference's np.histogram raises when every variance is below 1e-5; an empty histogram is returned here instead)
         ev['uncertaintyHistogram'] = (np.histogram(ev['epistemic_variance'], bins=50, range=(1e-5, hi))[0] if hi > 1e-5 else np.zeros(50, np.int64)).tolist()
-    _time['evaluation'] = time.time() - _time['evaluation']
-    ev['time'] = _time
     return ev
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The reference's entry points on the dataset duck-type
+# ------------------------------------------------------------------------------------------------------------------------------
+def _zoom_factor(resolution, shape):
+    return tuple(i / j for (i, j) in zip(resolution, shape))
+
+
+def collect_patient_volume(datasetObj, patient, nii_filename, options):
+    """utils/Evaluation.py:205-232: load the volume, its ground truth and skull map; take slices sliceStart .. min(sliceEnd, #slices) along
+    options.axis; zoom every slice to options.sliceResolution -- cubic spline for the image (scipy.ndimage.zoom default order 3), the same
+    call with mode='nearest' for the integer label / skull maps, exactly as written there.  Returns (x [S,H,W] float64, seg [S,H,W] int,
+    skullmap [S,H,W] int, prior_quantile of the whole loaded volume, slice indices) or None when the volume is too thin (:210-211)."""
+    o = datasetObj.options
+    nii, nii_seg, nii_skullmap = datasetObj.load_volume_and_groundtruth(nii_filename, patient)
+    prior_quantile = np.quantile(nii.data, 0.9)
+    if min(nii.shape()) < (o.sliceEnd - o.sliceStart):
+        return None
+    slice_start = o.sliceStart if o.sliceStart else 0
+    n_ax = nii.num_slices_along_axis(o.axis)
+    slice_end = min(o.sliceEnd, n_ax) if o.sliceEnd else n_ax
+    xs, segs, skulls, idx = [], [], [], []
+    for s in range(slice_start, slice_end):
+        slice_data = nii.get_slice(s, o.axis)
+        slice_seg = nii_seg.get_slice(s, o.axis).astype(int)
+        slice_skullmap = nii_skullmap.get_slice(s, o.axis).astype(int)
+        if o.sliceResolution is not None:
+            zf = _zoom_factor(o.sliceResolution, slice_data.shape)
+            slice_data = scipy.ndimage.zoom(slice_data, zf)
+            slice_seg = scipy.ndimage.zoom(slice_seg, zf, mode="nearest")
+            slice_skullmap = scipy.ndimage.zoom(slice_skullmap, zf, mode="nearest")
+        xs.append(slice_data); segs.append(slice_seg); skulls.append(slice_skullmap); idx.append(s)
+    return np.asarray(xs, np.float64), np.asarray(segs), np.asarray(skulls), float(prior_quantile), idx
+
+
+def _evaluate(datasetObj, modelObj, sampleDir, options, split="TEST", eps=None):
+    """utils/Evaluation.py:183-365.  Walks the split's patients through the dataset duck-type, reconstructs every patient's slice stack in
+    batched device calls and returns (eval_dict, patients): eval_dict['diffs'] [P*S,H,W] post-processed residuals (device tensor under
+    '_diffs_device' as well), 'labelmaps', 'x', 'l1reconstructionErrors' and their mean / variance.  The per-slice PNG dumps are not
+    written (sampleDir is created like the reference does)."""
+    import os
+    os.makedirs(sampleDir, exist_ok=True)
+    print("Testing {} samples...".format(datasetObj.num_batches(1, set=split)))
+    patients = [datasetObj.patients[i] for i in datasetObj.get_patient_idx(split=split)]
+    ev = {'x': [], 'labelmaps': [], 'l1reconstructionErrors': [], 'reconstructionTimes': []}
+    diffs_dev = []
+    used = []
+    for p, patient in enumerate(patients):
+        files = patient['filtered_files']
+        if type(files) is not list:
+            files = [files]
+        done = False
+        for nii_filename in files:
+            if done:                                             # `if len(_eval_dict['diffs']) == 0` (:203): the first usable file of a patient
+                break
+            got = collect_patient_volume(datasetObj, patient, nii_filename, options)
+            if got is None:
+                continue
+            done = True
+            x, seg, skull, prior_q, _ = got
+            t0 = time.time()
+            d, l1 = evaluate_volume(modelObj, x, skull, options, eps, device_out=True, prior=prior_q)
+            ev['reconstructionTimes'].append((time.time() - t0) / max(len(x), 1))
+            diffs_dev.append(d)
+            ev['x'].append(x); ev['labelmaps'].append(seg); ev['l1reconstructionErrors'] += list(l1)
+            used.append(patient)
+    print("Done.")
+    ev['_diffs_device'] = diffs_dev
+    ev['diffs'] = np.concatenate([d.cpu().numpy().astype(np.float64) for d in diffs_dev], axis=0) if diffs_dev else np.zeros((0,))
+    ev['x'] = np.concatenate(ev['x'], axis=0) if ev['x'] else np.zeros((0,))
+    ev['labelmaps'] = np.concatenate(ev['labelmaps'], axis=0) if ev['labelmaps'] else np.zeros((0,))
+    e = np.asarray(ev['l1reconstructionErrors'], np.float64)
+    ev['l1reconstructionErrorMean'] = ev['l2reconstructionErrorMean'] = float(e.mean()) if e.size else 0.0
+    ev['l1reconstructionErrorVariance'] = ev['l2reconstructionErrorVariance'] = float(e.var()) if e.size else 0.0
+    ev['reconstructionTimes'] = float(np.mean(ev['reconstructionTimes'])) if ev['reconstructionTimes'] else 0.0
+    return ev, used
+
+
+def _eval_dir(model, options, epoch, description):
+    import os
+    d = os.path.join(options['train']['samplesDir'], model.network.__name__, model.model_dir,
+                     'eval-' + str(epoch) + '-' + time.strftime('%Y-%m-%d_%H-%M-%S'))
+    if description is not None:
+        d += "-" + str(description)
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def evaluate(datasetPC, gan, options, epoch='last', description=None, eps=None):
+    """utils/Evaluation.py:372-526 with the reference's signature: evaluates the TEST patients of `datasetPC`, writes evalPC.npy / evalPC.txt
+    (+ rocPC.npy / prcPC.npy when options['exportROC'] / ['exportPRC']) under <SAMPLEDIR>/<network>/<model_dir>/eval-<epoch>-<timestamp>[-
+    <description>]/ and -- unlike the reference, which returns None -- hands the scalar dictionary back."""
+    import os
+    t_all = time.time()
+    eval_dir = _eval_dir(gan, options, epoch, description)
+    sample_dir = os.path.join(eval_dir, 'samples_test_PC')
+    eval_pc, patients_pc = _evaluate(datasetPC, gan, sample_dir, options, split="TEST", eps=eps)
+    diffs = eval_pc.pop('_diffs_device')
+    labels = [eval_pc['labelmaps'][sum(d.shape[0] for d in diffs[:k]):sum(d.shape[0] for d in diffs[:k + 1])] for k in range(len(diffs))]
+    ev = _score_diffs(gan, diffs, labels, options)
+    for k in ('l1reconstructionErrorMean', 'l1reconstructionErrorVariance', 'l2reconstructionErrorMean', 'l2reconstructionErrorVariance',
+              'reconstructionTimes'):
+        ev[k] = eval_pc[k]
+    if should(options, 'exportROC') or should(options, 'exportPRC'):
+        flat_l = eval_pc['labelmaps'].astype(bool).flatten()
+        if should(options, 'exportROC'):
+            _, fpr, tpr, th = Metrics.compute_roc(eval_pc['diffs'].flatten(), flat_l)
+            np.save(os.path.join(eval_dir, 'rocPC.npy'), {"fpr": fpr, "tpr": tpr, "threshs": th}, allow_pickle=True)
+        if should(options, 'exportPRC'):
+            _, pr, rc, th = Metrics.compute_prc(eval_pc['diffs'].flatten(), flat_l)
+            np.save(os.path.join(eval_dir, 'prcPC.npy'), {"precisions": pr, "recalls": rc, "threshs": th}, allow_pickle=True)
+    ev['time'] = {'evaluation': time.time() - t_all}
+    out = {k: v for k, v in ev.items() if k not in ('epistemic_variance',)}
+    np.save(os.path.join(eval_dir, 'evalPC.npy'), out)
+    with open(os.path.join(eval_dir, 'evalPC.txt'), "w") as f:
+        f.write(str(out))
+    ev['eval_dir'] = eval_dir
+    return ev
+
+
+def determine_threshold_on_labeled_patients(dataset_pc, model, options, epoch='last', description=None, eps=None):
+    """utils/Evaluation.py:529-570: the Dice-optimal threshold (granularity-10 sweep) of the residual maps of the VAL patients of one
+    dataset or a list of datasets.  Returns (bestDiceScore, bestThreshold)."""
+    import os
+    eval_dir = _eval_dir(model, options, epoch, description)
+    sample_dir = os.path.join(eval_dir, 'samples_val_PC')
+    if not isinstance(dataset_pc, list):
+        dataset_pc = [dataset_pc]
+    diffs, labels = [], []
+    for ds in dataset_pc:
+        e, _ = _evaluate(ds, model, sample_dir, options, split="VAL", eps=eps)
+        diffs += e['_diffs_device']
+        labels.append(e['labelmaps'])
+    print("Computing DICE curve for Lesion Validation samples")
+    return _best_dice_of(model, diffs, labels)

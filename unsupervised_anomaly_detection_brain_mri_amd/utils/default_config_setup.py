@@ -5,7 +5,7 @@ import json
 import os
 from enum import Enum
 
-from .synthetic import SyntheticDataset
+from .synthetic import SyntheticDataset, SyntheticPatientDataset
 
 base_path = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -53,7 +53,12 @@ def get_datasets(options, dataset=Dataset.BRAINWEB, loader=None):
     if loader is not None:
         return loader(options, dataset)
     h, w = options['train']['outputHeight'], options['train']['outputWidth']
-    return SyntheticDataset(256, 64, h, w, seed=0), SyntheticDataset(16, 16, h, w, seed=5)
+    # (dataset_hc, dataset_pc) like the reference (:59-242): healthy training set, patient-structured lesion set for the evaluation.  The
+    # stand-in lesion set differs per Dataset member (seed, native resolution) so that run.py's per-dataset evaluations are not copies.
+    k = list(Dataset).index(dataset)
+    sl = max(4, min(16, options['sliceEnd'] - options['sliceStart']))
+    pc = SyntheticPatientDataset(n_val=2, n_test=2, slices=sl, native=h + 16 * (k % 2), h=h, w=w, seed=5 + 11 * k, slice_start=0, slice_end=sl)
+    return SyntheticDataset(256, 64, h, w, seed=0), pc
 
 
 def get_config(trainer, options, optimizer, intermediateResolutions, dropout_rate, dataset):

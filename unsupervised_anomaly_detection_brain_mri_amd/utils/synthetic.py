@@ -64,3 +64,61 @@ class SyntheticDataset:
         if return_brainmask:
             return batch, labels, (batch[..., 0] > 0).astype(np.int32)
         return batch, labels, None
+
+
+class _Volume:
+    """The slice accessors the reference's utils/NII.py wrapper offers to utils/Evaluation._evaluate (:205-220): data [z,y,x],
+    shape(), num_slices_along_axis(axis), get_slice(s, axis)."""
+    _AX = {'axial': 0, 'coronal': 1, 'sagittal': 2, 0: 0, 1: 1, 2: 2}
+
+    def __init__(self, data):
+        self.data = np.asarray(data)
+
+    def shape(self):
+        return self.data.shape
+
+    def num_slices_along_axis(self, axis):
+        return self.data.shape[self._AX[axis]]
+
+    def get_slice(self, s, axis):
+        return np.take(self.data, s, axis=self._AX[axis])
+
+
+class _Options:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class SyntheticPatientDataset(SyntheticDataset):
+    """A patient-structured stand-in for the reference's lesion datasets (dataloaders/BRAINWEB.py & co.) with exactly the members
+    utils/Evaluation.py reads: `patients` (dicts with 'name', 'filtered_files', 'groundtruth_filename'),
+    `get_patient_idx(split)`, `load_volume_and_groundtruth(nii_filename, patient) -> (volume, segmentation, skullmap)`,
+    `options.{sliceStart, sliceEnd, axis, sliceResolution}`, plus the training duck-type of SyntheticDataset.
+    Volumes are [slices, native, native] with planted hyper-intense lesions; native != sliceResolution exercises the zoom step."""
+
+    def __init__(self, n_val=2, n_test=2, slices=16, native=None, h=128, w=128, seed=0, slice_start=0, slice_end=None, axis='axial'):
+        super().__init__(max(8, slices), 8, h, w, seed)
+        native = native or h
+        self.options = _Options(sliceStart=slice_start, sliceEnd=slice_end if slice_end is not None else slices, axis=axis,
+                                sliceResolution=(h, w), format='raw')
+        self.patients, self._vols = [], {}
+        self._split = {'TRAIN': [], 'VAL': [], 'TEST': []}
+        for k in range(n_val + n_test):
+            name = f'synthetic_patient_{k}'
+            x, lab, msk = synthetic_slices(slices, native, native, seed=seed + 100 + k, lesions=True)
+            self._vols[name] = (x[..., 0].astype(np.float64), lab.astype(np.int32), msk.astype(np.int32))
+            self._split['VAL' if k < n_val else 'TEST'].append(k)
+            self.patients.append({'name': name, 'fullpath': name, 'filtered_files': [name + '.raw'], 'groundtruth_filename': name + '_seg.raw',
+                                  'split': 'VAL' if k < n_val else 'TEST'})
+
+    def get_patient_idx(self, split='TEST'):
+        return list(self._split[split])
+
+    def load_volume_and_groundtruth(self, nii_filename, patient):
+        x, lab, msk = self._vols[patient['name']]
+        return _Volume(x), _Volume(lab), _Volume(msk)
+
+    def num_batches(self, batchsize, set='TRAIN'):
+        if set in ('VAL', 'TEST') and self._split[set] and batchsize == 1:
+            return sum(self._vols[self.patients[i]['name']][0].shape[0] for i in self._split[set])
+        return super().num_batches(batchsize, set)

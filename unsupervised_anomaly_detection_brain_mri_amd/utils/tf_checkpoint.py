@@ -230,11 +230,13 @@ def write_checkpoint(prefix, tensors, entries_per_block=64):
 
 
 # ------------------------------------------------------------------ spec (flat buffers) <-> bundle
-def bundle_to_flat(spec, tensors, beta1=0.5):
+def bundle_to_flat(spec, tensors, beta1=0.5, beta2=0.999):
     """spec: [(name, shape, offset)] of an engine.  -> dict(params, adam_m, adam_v, adam_t, missing): flat fp32 buffers filled from
-    the bundle's variables; adam_* are None unless every variable has its `<name>/Adam` (m) and `<name>/Adam_1` (v) slots; adam_t
-    follows from beta1_power = beta1^t (AdamOptimizer's non-slot variable).  Tensors the spec does not name (BN moving averages,
-    which the reference never updates, global_step, ...) are ignored."""
+    the bundle's variables; adam_* are None unless every variable has its `<name>/Adam` (m) and `<name>/Adam_1` (v) slots.  adam_t is
+    recovered from AdamOptimizer's non-slot variables: beta2_power = beta2^t first (0.999^t stays a normal fp32 up to t ~ 8.7e4), beta1_power
+    = beta1^t as the fallback -- with the reference's beta1 = 0.5 that one underflows to 0 after 149 steps, less than one epoch, and a
+    resume from it would restart Adam's bias correction at t = 1.  Tensors the spec does not name (BN moving averages, which the
+    reference never updates, global_step, ...) are ignored."""
     total = max(off + int(np.prod(shape)) for _, shape, off in spec)
     params, m, v = (np.zeros(total, np.float32) for _ in range(3))
     missing, slots = [], True
@@ -253,19 +255,33 @@ def bundle_to_flat(spec, tensors, beta1=0.5):
         else:
             slots = False
     t = None
-    if 'beta1_power' in tensors:
-        b1p = float(np.asarray(tensors['beta1_power']).reshape(-1)[0])
-        if 0.0 < b1p <= 1.0:
-            t = int(round(math.log(b1p) / math.log(beta1)))
+    for key, beta in (('beta2_power', beta2), ('beta1_power', beta1)):
+        if key in tensors:
+            bp = float(np.asarray(tensors[key]).reshape(-1)[0])
+            if bp == 1.0:
+                t = 0
+                break
+            # fp32 normal range only: a denormal / zero power carries no usable step count
+            if 1.2e-38 < bp < 1.0:
+                t = int(round(math.log(bp) / math.log(beta)))
+                break
     ok = slots and not missing
     return {'params': params, 'adam_m': m if ok else None, 'adam_v': v if ok else None, 'adam_t': t if ok else None, 'missing': missing}
 
 
 def flat_to_bundle(spec, params, adam_m=None, adam_v=None, adam_t=0, beta1=0.5, beta2=0.999):
+    """The variables a tf.train.Saver() built on the reference's graph expects (DLMODEL.py:63-83 saves ALL global variables): the spec's
+    trainables, every BatchNormalization scope's moving_mean (zeros) / moving_variance (ones) -- the reference never updates them
+    (SURVEY.md A1), so their initial values are what any of its checkpoints holds -- and, when slots are given, the Adam slots and
+    beta powers.  UNVERIFIED against a real TensorFlow restore (none in the image)."""
     tensors = {}
     for name, shape, off in spec:
         cnt = int(np.prod(shape))
         tensors[name] = params[off:off + cnt].reshape(shape)
+        if name.endswith('/gamma') and 'batch_normalization' in name.rsplit('/', 2)[-2]:
+            scope = name[:-len('/gamma')]
+            tensors[scope + '/moving_mean'] = np.zeros(shape, np.float32)
+            tensors[scope + '/moving_variance'] = np.ones(shape, np.float32)
         if adam_m is not None and adam_v is not None:
             tensors[name + '/Adam'] = adam_m[off:off + cnt].reshape(shape)
             tensors[name + '/Adam_1'] = adam_v[off:off + cnt].reshape(shape)
