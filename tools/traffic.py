@@ -1,7 +1,7 @@
 """Post-processes two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; each with --kernel-trace only) of
 `bench.py --steps 2 --warmup 1 --no-cpu-baseline` into
   * a per-(kernel, grid) table (stdout / profiles/*.md), and
-  * profiles/r01_traffic_<math>.json, keyed by bench.py's launch-group tags for the big conv kernels
+  * profiles/r0N_traffic_<math>.json, keyed by bench.py's launch-group tags for the big conv kernels
     (tag <-> (kernel template, grid) at the BASELINE configs[1] shapes, N = 64).
 FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH is doubled per MI355X_MICROARCH.md (gfx950 counts 128-B read requests
 at 64 B; calibrated here on final_kernel: 134 MB algorithmic read)."""
@@ -37,12 +37,12 @@ for (name, grid, wg), n, f, w in rows[:40]:
 
 # tag -> (kernel substring, grid threads) at N=64, 128x128 (grid = blocks * threads)
 TAGS = {
-    'dec3.fwd': ('conv5_d16_kernel<8, 16, 32, 4, 1>', 32 * 64 * 256),
-    'dec2.fwd': ('conv5_d16_kernel<8, 16, 64, 4, 1>', 8 * 64 * 256),
-    'enc1.dgrad': ('conv5_d16_kernel<8, 16, 64, 4, 1>', 32 * 64 * 256),
-    'dec3.dgrad': ('conv5_f16_kernel<8, 16, 16, 4, 1>', 32 * 64 * 256),
-    'dec2.dgrad': ('conv5_f16_kernel<8, 8, 32, 2, 2>', 16 * 64 * 256),
-    'enc1.fwd': ('conv5_f16_kernel<8, 8, 32, 2, 2>', 16 * 64 * 256),
+    'dec3.fwd': ('conv5_d16_kernel<8, 16, 32, 4, 1', 32 * 64 * 256),
+    'dec2.fwd': ('conv5_d16_kernel<8, 16, 64, 4, 1', 8 * 64 * 256),
+    'enc1.dgrad': ('conv5_d16_kernel<8, 16, 64, 4, 1', 32 * 64 * 256),
+    'dec3.dgrad': ('conv5_f16_kernel<8, 16, 16, 4, 1', 32 * 64 * 256),
+    'dec2.dgrad': ('conv5_f16_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
+    'enc1.fwd': ('conv5_f16_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
     'dec3.wgrad': ('conv5_w_bf16_kernel', 512 * 256),
     'final.fwd+bwd': ('final_kernel<true>', 32 * 64 * 256),
 }
@@ -52,6 +52,7 @@ for tag, (sub, grid) in TAGS.items():
     if cands:
         k, n, f, w = max(cands, key=lambda c: c[2] + c[3])
         out[tag] = {'kernel': sub, 'fetch_bytes': f, 'write_bytes': w, 'launches': n}
+out['_commit'] = sys.argv[4] if len(sys.argv) > 4 else 'unknown'
 out['_note'] = ('HBM bytes per launch from rocprofv3 PMC on MI355X (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes with '
                 '--kernel-trace only); FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated on final_kernel). enc1.fwd and '
                 'dec2.dgrad share a kernel template and grid: the entry is the larger of the two.')
