@@ -30,6 +30,7 @@ def _config(trainer, tmp_path, h=64, bs=8, epochs=2):
 
 def test_vae_train_process_reconstruct_resume(tmp_path):
     cfg, opt, ds = _config(VAE, tmp_path)
+    cfg.learningrate = 3e-4          # (1e-3 makes Adam's first steps on the freshly initialised net spike: not a premise for "the objective falls")
     model = VAE(None, cfg, network=variational_autoencoder)
     assert model.network.__name__ == 'variational_autoencoder'
     assert model.model_dir == 'VAE_dSyntheticDataset_s64x64_variational_autoencoder_b8_z64_'
@@ -489,8 +490,9 @@ def test_context_encoder_trainer(tmp_path, mname):
     assert v['loss'] == pytest.approx(float(ref['scalars'][0]), rel=1e-6)
     model.train(ds)
     assert len(model.curves['TRAIN/loss']) == 3 and np.isfinite(model.curves['VAL/loss']).all()
-    fixed = [float(model.step(x, Phase.TRAIN, x_ce=x_ce, fetch_maps=False)['loss']) for _ in range(12)]      # same batch, same holes: the objective falls
-    assert fixed[-1] < fixed[0]
+    model.config.learningrate = 2e-4
+    fixed = [float(model.step(x, Phase.TRAIN, x_ce=x_ce, dropout_masks=masks, fetch_maps=False)['loss']) for _ in range(16)]      # same batch, holes and masks: the objective falls
+    assert np.mean(fixed[-3:]) < fixed[0]
     r = model.reconstruct(x[0])
     assert r['reconstruction'].shape == (1, 64, 64, 1)
     with pytest.raises(ValueError):

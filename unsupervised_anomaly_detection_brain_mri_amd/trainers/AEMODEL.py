@@ -217,7 +217,8 @@ class AEMODEL(DLMODEL):
         for idx in range(num_batches):
             batch, _, _ = self._shard(dataset, phase)
             out = self._run(batch, phase, fetch_maps=want_images)
-            table[idx].copy_(out['scalars'])
+            sc = out['scalars'].reshape(-1)          # 8 slots on the fused handle, fewer on the materialised-graph engines
+            table[idx, :sc.numel()].copy_(sc)
             if want_images:
                 from .trainer_utils import get_summary_dict
                 b = batch.cpu().numpy() if hasattr(batch, 'cpu') else np.asarray(batch)
