@@ -1,8 +1,9 @@
 """Oracle primitives: TF-1.15 layer semantics restated in numpy (NHWC).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED for these
-ops (no TF here); every function cites the reference call site it restates and
-the TF semantic it fixes (SURVEY.md §8a notes 1-8).
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PINNED against the expectations
+published in TensorFlow r1.15's own unit tests (tests/golden/tf_published.json,
+tests/test_oracle_tf_published.py); every function cites the reference call site it
+restates and the TF semantic it fixes (SURVEY.md §8a notes 1-8).
 
 All functions are dtype-preserving: pass float64 arrays for the "truth" run,
 float32 for the timed CPU baseline.

@@ -1,6 +1,6 @@
 """Oracle for the dense-bottleneck AE / VAE / ceVAE train step and reconstruct().
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED (no TF).
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Primitives pinned by TF's published unit-test vectors (oracle/nn.py); the graph wiring is PARITY UNPINNED against TF output (no TF).
 
 Restates, with hand-written backward passes:
   models/customlayers.py:16-38          unified encoder / decoder
