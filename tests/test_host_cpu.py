@@ -217,3 +217,24 @@ def test_mains_pairings_resolve():
         archs = T.ARCHS if isinstance(T.ARCHS, tuple) else (T.ARCH,)
         assert net.arch in archs, (os.path.basename(f), net.arch, archs)
         assert net.__name__ == m.group(2)
+
+
+def test_trainer_rank_sharding_of_the_global_batch():
+    """AEMODEL._shard: under slice-batch DP every rank advances the SAME dataset cursor over batchsize * world slices and keeps its
+    contiguous share (the partitioning parallel.py's big-batch equivalence and the rank-invariant noise assume)."""
+    import types
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import VAE, Phase
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset
+    got = []
+    for rank in range(2):
+        t = object.__new__(VAE)
+        t.config = types.SimpleNamespace(batchsize=4)
+        t.dp = types.SimpleNamespace(world=2)
+        type(t).rank = property(lambda self, r=rank: r)
+        ds = SyntheticDataset(16, 8, 16, 16, seed=0)
+        b, _, m = t._shard(ds, Phase.TRAIN, return_brainmask=True)
+        assert b.shape == (4, 16, 16, 1) and m.shape == (4, 16, 16)
+        got.append(b)
+        del type(t).rank
+    ref = SyntheticDataset(16, 8, 16, 16, seed=0).next_batch(8, set='TRAIN')[0]
+    assert np.array_equal(np.concatenate(got), ref)
