@@ -238,3 +238,36 @@ def test_trainer_rank_sharding_of_the_global_batch():
         del type(t).rank
     ref = SyntheticDataset(16, 8, 16, 16, seed=0).next_batch(8, set='TRAIN')[0]
     assert np.array_equal(np.concatenate(got), ref)
+
+
+def test_batch_cursor_reproduces_the_reference_next_batch():
+    """utils/slice_cache.BatchCursor against what the REFERENCE's BRAINWEB.next_batch returned on the same split vectors and seeds
+    (tests/golden/cursor_golden.npz, written by tests/golden/make_cursor_golden.py from dataloaders/BRAINWEB.py:406-478 run in this container):
+    no shuffle before the first epoch (:419 compares a dict with 0), the epoch wrap takes the rest of the old arrangement + the head of the
+    freshly permuted one, the permutation acts on the CURRENT arrangement, TRAIN and VAL share one random stream; brain-mask label mapping."""
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import slice_cache as sc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cursor_golden.npz'))
+
+    class GlobalShuffle:            # numpy.random.shuffle(arange(n)) on the global stream, as the reference draws its permutations
+        def permutation(self, n):
+            p = np.arange(n)
+            np.random.shuffle(p)
+            return p
+
+    for case in range(4):
+        sets = g[f'sets{case}']
+        bs, calls, seed, shuffle, nb_train, nb_val = (int(v) for v in g[f'cfg{case}'])
+        idx = {k: np.where(sets == k)[0] for k in (0, 1)}
+        assert len(idx[0]) // bs == nb_train and len(idx[1]) // 2 == nb_val
+        np.random.seed(seed)
+        rng = GlobalShuffle()
+        cur = {k: sc.BatchCursor(len(idx[k]), rng) for k in (0, 1)}
+        vi = 0
+        for c in range(calls):
+            got = idx[0][cur[0].next(bs, bool(shuffle))]
+            assert np.array_equal(got, g[f'train{case}'][c]), (case, c)
+            if len(idx[1]) and c % 2 == 0:
+                assert np.array_equal(idx[1][cur[1].next(2, bool(shuffle))], g[f'val{case}'][vi]), (case, c)
+                vi += 1
+        lut = sc.brainmask_lut()
+        assert np.array_equal(lut[g[f'bm_labels{case}'].astype(np.uint8)], g[f'bm{case}'].astype(np.uint8))
