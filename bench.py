@@ -455,8 +455,8 @@ def bench_fanogan(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'bf16x3'), choices=['f32', 'bf16x3', 'bf16x3_all'],
                     help='bf16x3 (default): split-bf16 products on the bf16 matrix cores, fp32 accumulate, parity 1e-4 vs the '

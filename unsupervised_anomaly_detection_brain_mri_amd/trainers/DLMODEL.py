@@ -64,6 +64,12 @@ class DLMODEL(object):
         self.engine.step_count = int(t)
 
     def save(self, checkpoint_dir, step):
+        try:                                    # data-parallel replicas hold identical weights: one writer
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+                return
+        except ImportError:
+            pass
         model_name = self.config.modelname + ".model"
         checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
         os.makedirs(checkpoint_dir, exist_ok=True)
