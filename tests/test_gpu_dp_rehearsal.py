@@ -85,6 +85,33 @@ def _worker(rank, world, port, tmp, q):
                                   mean_diff=float(np.abs(w_dp - w_1).mean()), mean_step=float(moved.mean()),
                                   frac_far=float((np.abs(w_dp - w_1) > 0.5 * 1e-3).mean()))))
                 single.engine.close()
+            if name == 'VAE':
+                # trainer level: one TRAIN epoch of process() with dropout 0.2 -- the batch is rank-sharded (AEMODEL._shard) and eps / the masks
+                # are drawn on the device keyed by the GLOBAL sample index, so two ranks of 4 see what one process of 8 sees
+                from unsupervised_anomaly_detection_brain_mri_amd.trainers import Phase
+                from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_config, get_options
+                from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset
+
+                def mk(world_, bs_):
+                    opt = get_options(batchsize=bs_, learningrate=1e-3, numEpochs=1, outputWidth=32, outputHeight=32, zDim=16,
+                                      config={'CHECKPOINTDIR': os.path.join(tmp, 'ck2'), 'SAMPLEDIR': os.path.join(tmp, 'smp2')})
+                    ds_ = SyntheticDataset(16, 8, 32, 32, seed=4)
+                    cfg_ = get_config(case[1], opt, 'ADAM', [8, 8], 0.2, ds_)
+                    cfg_.quiet = True
+                    return case[1](None, cfg_, network=case[2], seed=9, world=world_, device='cuda:0'), ds_
+                tm, tds = mk(world, 4)
+                tw0 = tm.engine.get_buffer_host(_lib.BUF_PARAMS)
+                sc_dp = tm.process(tds, 0, Phase.TRAIN)
+                tw_dp = tm.engine.get_buffer_host(_lib.BUF_PARAMS)
+                if rank == 0:
+                    sm, sds = mk(1, 8)
+                    sm.engine.set_params(tw0); sm.engine.reset_optimizer()
+                    sc_1 = sm.process(sds, 0, Phase.TRAIN)
+                    tw_1 = sm.engine.get_buffer_host(_lib.BUF_PARAMS)
+                    q.put(('VAE_process', dict(loss_dp=float(sc_dp['loss']), loss_1=float(sc_1['loss']), kl_dp=float(sc_dp['kl']), kl_1=float(sc_1['kl']),
+                                               mean_diff=float(np.abs(tw_dp - tw_1).mean()), mean_step=float(np.abs(tw_1 - tw0).mean()))))
+                    sm.engine.close()
+                tm.engine.close()
             t = torch.from_numpy(w_dp)
             both = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(both, t)
@@ -110,6 +137,9 @@ def test_two_rank_train_step_equals_big_batch(tmp_path):
     while not q.empty():
         k, v = q.get()
         res[k] = v
+    r = res['VAE_process']
+    assert r['loss_dp'] == pytest.approx(r['loss_1'], rel=2e-4) and r['kl_dp'] == pytest.approx(r['kl_1'], rel=2e-4), r     # same batches, same noise
+    assert r['mean_diff'] <= 0.05 * r['mean_step'], r
     for name in ('VAE', 'GMVAE', 'VAE_Zimmerer', 'CAAE_Chen'):
         r = res[name]
         assert res[name + '_replicas'] == 0.0, name                       # both replicas applied the identical update
