@@ -2902,6 +2902,236 @@ conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
         a.dbgbuf[2 * b + 1] = wall_clock64();
     }
 }
+// Channel-major form of conv5_w_bf16_kernel.  The MFMA wants, per lane, 8 consecutive POSITIONS of one channel; in the [pixel][channel] tile
+// that is eight strided 16-bit LDS reads + four packing instructions per fragment and plane (448 reads + 448 VALU per wave and tile -- the
+// round-2 counters show this kernel bound by instruction issue, not by a pipe).  Here the big tile is stored [channel][row][column parity][x/2]:
+// the 8 positions a k5 s2 tap touches along x (columns 2 tx + kx) are 8 CONSECUTIVE 16-bit slots of one (row, parity) segment starting at slot
+// kx >> 1, so one segment read (2 x ds_read_b64 + 1 x ds_read_b32 per plane) serves every tap of that row and parity: offsets 0 and 2 are
+// register selections, offset 1 four v_alignbit.  Taps are dealt to the four waves by kernel ROW (wave w: the five taps of row w, tap (4, w), and
+// its quarter of tap (4, 4)) so that a wave's taps share its segment reads: ~20 LDS reads and <= 24 VALU per 16-position step instead of ~100 each.
+template <int NCSB, bool FBB = false>
+__global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
+conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
+    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256 * NCSB, CSQ = 8 * NCSB;
+    constexpr int XHP = 12;                       // 16-bit slots per (channel, row, parity) segment: columns 0,2,..,18 / 1,3,..,17 (+ slack)
+    constexpr int CSTP = IH * 2 * XHP + 4;        // channel stride (ushorts): 920 B = an odd number of 8-byte units -> the lanes' b64 reads spread over all banks
+    constexpr int BIGP = CK * CSTP;               // ushorts per plane
+    constexpr int LDP = TH * TW + 8;  // ushorts per channel row of the transposed small tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned short* bHi = reinterpret_cast<unsigned short*>(dsm);
+    unsigned short* bLo = bHi + BIGP;
+    unsigned short* sHiT = bLo + BIGP;
+    unsigned short* sLoT = sHiT + NCSB * CK * LDP;
+    float* sXf = reinterpret_cast<float*>(sLoT + NCSB * CK * LDP);   // [32] big scale, [32] big shift, [64] small scale, [64] small shift
+    float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
+
+    const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+    const int wave = wave_all & 3, csb = wave_all >> 2;   // tap group / cs block of this wave
+    const int l31 = lane & 31, lh = lane >> 5;
+    const UadConvDesc& d = a.d;
+    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32 * NCSB;
+    const int tilesx = d.WS / TW, tilesy = d.HS / TH;
+    const int t_begin = blockIdx.z * tiles_per_split;
+    const int t_end = min(t_begin + tiles_per_split, total_tiles);
+
+    const int cq = tid % CQ;
+    const bool xfa = !FBB && a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
+    // activation-on-load tables in LDS
+    if (tid < 32) {
+        sXf[tid] = xfa ? a.xfb.scale[cb0 + tid] * a.xfb.mult : 1.f;
+        sXf[32 + tid] = xfa ? a.xfb.shift[cb0 + tid] : 0.f;
+    }
+    if (tid < 32 * NCSB) {
+        sXf[64 + tid] = xfs ? a.xfs.scale[cs0 + tid] * a.xfs.mult : 1.f;
+        sXf[128 + tid] = xfs ? a.xfs.shift[cs0 + tid] : 0.f;
+    }
+
+    float fb_wf[4] = {0.f, 0.f, 0.f, 0.f}, fb_s1[4] = {0.f, 0.f, 0.f, 0.f}, fb_s0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FBB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            fb_wf[e] = a.xfb.fb_wf[cb0 + cq * 4 + e];
+            fb_s1[e] = a.xfb.scale[cb0 + cq * 4 + e] * a.xfb.mult;
+            fb_s0[e] = fb_s1[e] * a.xfb.alpha;
+        }
+    }
+
+    constexpr int MAXT = 7;
+    // segment base of this lane's channel for kernel row ky at tile-row half lh (ushorts): row y = 4 js + 2 lh + ky
+    const int seg_own = l31 * CSTP + ((2 * lh + wave) * 2) * XHP;          // ky = wave, parity 0; parity 1 at + XHP; step js at + 8 js XHP
+    const int seg_k4 = l31 * CSTP + ((2 * lh + 4) * 2) * XHP;              // ky = 4
+    const int baddr = (csb * 32 + l31) * LDP + 8 * lh;
+
+    v16f acc[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    struct Seg { unsigned d0, d1, d2, d3, d4; };
+    auto read_seg = [&](const unsigned short* plane, int addr) {           // 10 consecutive 16-bit slots (8-byte aligned)
+        Seg r;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(plane + addr);
+        const uint2 a1 = *reinterpret_cast<const uint2*>(plane + addr + 4);
+        r.d0 = a0.x; r.d1 = a0.y; r.d2 = a1.x; r.d3 = a1.y;
+        r.d4 = *reinterpret_cast<const unsigned*>(plane + addr + 8);
+        return r;
+    };
+    auto frag = [&](const Seg& r, int xh0) {                               // slots xh0 .. xh0 + 7
+        if (xh0 == 0) return make_uint4(r.d0, r.d1, r.d2, r.d3);
+        if (xh0 == 2) return make_uint4(r.d1, r.d2, r.d3, r.d4);
+        return make_uint4(__builtin_amdgcn_alignbit(r.d1, r.d0, 16), __builtin_amdgcn_alignbit(r.d2, r.d1, 16),
+                          __builtin_amdgcn_alignbit(r.d3, r.d2, 16), __builtin_amdgcn_alignbit(r.d4, r.d3, 16));
+    };
+    auto mma3 = [&](v16f& c, uint4 ah, uint4 al, uint4 bh, uint4 bl) {
+        c = mfma_bf16(ah, bh, c);
+        c = mfma_bf16(ah, bl, c);
+        c = mfma_bf16(al, bh, c);
+    };
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int tx0 = (t % tilesx) * TW;
+        const int ty0 = ((t / tilesx) % tilesy) * TH;
+        const int n = t / (tilesx * tilesy);
+        const float* bigb = a.big + (size_t)n * d.HB * d.WB * d.CB + cb0;
+        const float* smb = a.small_ + ((size_t)(n * d.HS + ty0) * d.WS + tx0) * d.CS + cs0;
+        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
+        __syncthreads();
+        {
+            constexpr int TOT = IH * IW * CQ;
+            constexpr int BATCH = 6;
+            for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
+                float4 v[FBB ? 1 : BATCH];
+                unsigned vb[FBB ? BATCH : 1];
+                float vg[FBB ? BATCH : 1];
+                bool ok[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int f = f0 + u * NT;
+                    const int pix = f / CQ;
+                    const int iy = pix / IW, ix = pix % IW;
+                    const int gy = gy0 + iy, gx = gx0 + ix;
+                    ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
+                    const int gp = ok[u] ? (gy * d.WB + gx) : 0;
+                    if (FBB) {
+                        vb[u] = a.xfb.fb_bits[(size_t)n * d.HB * d.WB + gp];
+                        vg[u] = a.xfb.fb_dxhat[(size_t)n * d.HB * d.WB + gp];
+                    } else {
+                        v[u] = *reinterpret_cast<const float4*>(bigb + (size_t)gp * d.CB + cq * 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int f = f0 + u * NT;
+                    if (f >= TOT) continue;
+                    float4 tv = v[FBB ? 0 : u];
+                    if (FBB) {
+                        const unsigned b = vb[u] >> (cb0 + cq * 4);
+                        const float gq = vg[u];
+                        tv.x = gq * fb_wf[0] * ((b & 1u) ? fb_s1[0] : fb_s0[0]);
+                        tv.y = gq * fb_wf[1] * ((b & 2u) ? fb_s1[1] : fb_s0[1]);
+                        tv.z = gq * fb_wf[2] * ((b & 4u) ? fb_s1[2] : fb_s0[2]);
+                        tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
+                    } else if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
+                    tv = keep4(ok[u], tv);
+                    uint2 hi, lo;
+                    split_bf16(tv, hi, lo);
+                    {   // channel-major scatter: 4 channels x (hi, lo) 16-bit stores
+                        const int pix = f / CQ;
+                        const int iy = pix / IW, ix = pix % IW;
+                        const int o = (cq * 4) * CSTP + (iy * 2 + (ix & 1)) * XHP + (ix >> 1);
+                        bHi[o] = (unsigned short)hi.x; bHi[o + CSTP] = (unsigned short)(hi.x >> 16);
+                        bHi[o + 2 * CSTP] = (unsigned short)hi.y; bHi[o + 3 * CSTP] = (unsigned short)(hi.y >> 16);
+                        bLo[o] = (unsigned short)lo.x; bLo[o + CSTP] = (unsigned short)(lo.x >> 16);
+                        bLo[o + 2 * CSTP] = (unsigned short)lo.y; bLo[o + 3 * CSTP] = (unsigned short)(lo.y >> 16);
+                    }
+                }
+            }
+            float4 sv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + u * NT;
+                const int pos = idx / CSQ, csq = idx % CSQ;
+                sv[u] = *reinterpret_cast<const float4*>(smb + (size_t)((pos / TW) * d.WS + (pos % TW)) * d.CS + csq * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + u * NT;
+                const int pos = idx / CSQ, csq = idx % CSQ;
+                float4 tv = sv[u];
+                if (xfs) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + 64 + csq * 4), *reinterpret_cast<const float4*>(sXf + 128 + csq * 4), a.xfs.alpha);
+                uint2 hi, lo;
+                split_bf16(tv, hi, lo);
+                unsigned short* ph = sHiT + (csq * 4) * LDP + pos;
+                unsigned short* pl = sLoT + (csq * 4) * LDP + pos;
+                ph[0] = (unsigned short)hi.x; ph[LDP] = (unsigned short)(hi.x >> 16);
+                ph[2 * LDP] = (unsigned short)hi.y; ph[3 * LDP] = (unsigned short)(hi.y >> 16);
+                pl[0] = (unsigned short)lo.x; pl[LDP] = (unsigned short)(lo.x >> 16);
+                pl[2 * LDP] = (unsigned short)lo.y; pl[3 * LDP] = (unsigned short)(lo.y >> 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int js = 0; js < TH * TW / 16; ++js) {
+            // positions 16*js .. 16*js+15 = tile rows 2*js (lanes 0-31) and 2*js+1 (lanes 32-63), tx = element index
+            const uint4 bh = *reinterpret_cast<const uint4*>(sHiT + baddr + 16 * js);
+            const uint4 bl = *reinterpret_cast<const uint4*>(sLoT + baddr + 16 * js);
+            const int so = seg_own + (8 * js) * XHP, sk = seg_k4 + (8 * js) * XHP;
+            {   // own kernel row, even columns: taps kx = 0, 2, 4
+                const Seg h = read_seg(bHi, so), l = read_seg(bLo, so);
+                mma3(acc[0], frag(h, 0), frag(l, 0), bh, bl);
+                mma3(acc[2], frag(h, 1), frag(l, 1), bh, bl);
+                mma3(acc[4], frag(h, 2), frag(l, 2), bh, bl);
+            }
+            {   // odd columns: taps kx = 1, 3
+                const Seg h = read_seg(bHi, so + XHP), l = read_seg(bLo, so + XHP);
+                mma3(acc[1], frag(h, 0), frag(l, 0), bh, bl);
+                mma3(acc[3], frag(h, 1), frag(l, 1), bh, bl);
+            }
+            {   // kernel row 4: tap (4, wave)
+                const int a4 = sk + (wave & 1) * XHP;
+                const Seg h = read_seg(bHi, a4), l = read_seg(bLo, a4);
+                const bool one = (wave >> 1) != 0;                      // slots from (wave >> 1): wave-uniform
+                mma3(acc[5], one ? frag(h, 1) : frag(h, 0), one ? frag(l, 1) : frag(l, 0), bh, bl);
+            }
+            if (js == wave) {   // wave-uniform: this wave's quarter of tap (4, 4)
+                const Seg h = read_seg(bHi, sk), l = read_seg(bLo, sk);
+                mma3(acc[6], frag(h, 2), frag(l, 2), bh, bl);
+            }
+        }
+    }
+
+    // Accumulator block -> slab.  One 64-bit address per lane; everything else is a wave-uniform 32-bit offset (the plain form
+    // `out[((size_t)tap * CB + cb) * CS + col]` cost ~400 quarter-rate 64-bit multiply-adds per wave: 8 of this kernel's ~47 us).
+    const int CSi = d.CS;
+    float* ob = a.partial + (size_t)blockIdx.z * a.Mtot * CSi + (size_t)(cb0 + 4 * lh) * CSi + cs0 + csb * 32 + l31;
+    const int tapstride = d.CB * CSi;
+#pragma unroll
+    for (int j = 0; j < MAXT - 1; ++j) {
+        const int tap = j < 5 ? 5 * wave + j : 20 + wave;
+        float* ot = ob + tap * tapstride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2)) * CSi] = acc[j][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[(wave_all * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
+    __syncthreads();
+    if (wave == 0) {
+        float* ot = ob + 24 * tapstride;
+        const float* q = sRed + (size_t)csb * 64 * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ot[((r & 3) + 8 * (r >> 2)) * CSi] = (q[r * 64 + lane] + q[(16 + r) * 64 + lane]) + (q[(32 + r) * 64 + lane] + q[(48 + r) * 64 + lane]);
+    }
+    if (a.dbgbuf && tid == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        a.dbgbuf[2 * b] = dbg_t0;
+        a.dbgbuf[2 * b + 1] = wall_clock64();
+    }
+}
+constexpr size_t conv5_w_bf16_t_lds_bytes(int ncsb) { return (size_t)2 * 32 * (19 * 2 * 12 + 4) * 2 + (size_t)ncsb * 2 * 32 * 72 * 2 + 192 * 4; }
 constexpr size_t conv5_w_bf16_lds_bytes(int ncsb) { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)ncsb * 2 * 32 * 72 * 2 + 192 * 4; }
 
 struct W5Choice { bool ok; int splits, tiles_per_split, total_tiles; };
@@ -3228,6 +3458,27 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                     fprintf(stderr, "[w5 CB=%d CS=%d HS=%d grid=%d,%d,%d] span=%llu (100MHz ticks) wg dur min=%llu avg=%llu max=%llu latest start=%llu\n", d.CB, d.CS, d.HS, g->x, g->y, g->z,
                             t1 - t0, dmin, dsum / nb, dmax, smax); } } dump{dbg_this, st, wbuf, &grid, &wcalls, d};
             static const bool pair_ok = !getenv("UAD_NO_W2");
+            static const bool tlay = !getenv("UAD_NO_W_T");          // channel-major big tile (conv5_w_bf16_t_kernel); UAD_NO_W_T=1: the pixel-major kernel
+            if (tlay) {
+                static bool t_attr = false;
+                if (!t_attr) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(1));
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(2));
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(1));
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(2));
+                    t_attr = true;
+                }
+                const bool two = pair_ok && d.CS % 64 == 0;
+                if (two) grid.y = d.CS / 64;
+                const size_t lds = conv5_w_bf16_t_lds_bytes(two ? 2 : 1);
+                if (xfb.fb_bits) {
+                    if (two) hipLaunchKernelGGL((conv5_w_bf16_t_kernel<2, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                    else hipLaunchKernelGGL((conv5_w_bf16_t_kernel<1, true>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                } else {
+                    if (two) hipLaunchKernelGGL((conv5_w_bf16_t_kernel<2, false>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                    else hipLaunchKernelGGL((conv5_w_bf16_t_kernel<1, false>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                }
+            } else
             if (xfb.fb_bits) {          // compressed d loss / d c of the last decoder block (callers check uad_conv_w_supports_fb_bits)
                 static bool fb_attr = false;
                 if (!fb_attr) {
