@@ -24,15 +24,16 @@ def main():
     start = next(i for i, l in enumerate(lines) if re.match(r'^_Z\w+:', l) and key in l)
     counts = collections.defaultdict(collections.Counter)
     mnems = collections.defaultdict(collections.Counter)
-    cur = 0
+    cur = ('?', 0)
+    files = {int(m.group(1)): m.group(2).split('/')[-1] for m in re.finditer(r'\.file\s+(\d+)\s+(?:"[^"]*"\s+)?"([^"]*)"', '\n'.join(lines))}
     tot = collections.Counter()
     for l in lines[start + 1:]:
         if l.startswith('.Lfunc_end'):
             break
         s = l.strip()
-        m = re.match(r'\.loc\s+\d+\s+(\d+)', s)
+        m = re.match(r'\.loc\s+(\d+)\s+(\d+)', s)
         if m:
-            cur = int(m.group(1))
+            cur = (files.get(int(m.group(1)), m.group(1)), int(m.group(2)))
             continue
         if not s or s.startswith(('.', ';')) or s.endswith(':'):
             continue
@@ -45,7 +46,7 @@ def main():
     rows = sorted(counts.items(), key=lambda kv: -sum(kv[1].values()))[:top]
     for line, c in rows:
         best = ' '.join(f'{m}:{n}' for m, n in mnems[line].most_common(5))
-        print(f'L{line:5d} n={sum(c.values()):5d} ' + ' '.join(f'{k}={c[k]}' for k in ('mfma', 'valu', 'salu', 'lds', 'vmem', 'wait') if c[k]) + '   | ' + best)
+        print(f'{line[0][-24:]:>24s}:{line[1]:<5d} n={sum(c.values()):5d} ' + ' '.join(f'{k}={c[k]}' for k in ('mfma', 'valu', 'salu', 'lds', 'vmem', 'wait') if c[k]) + '   | ' + best)
 
 
 if __name__ == '__main__':

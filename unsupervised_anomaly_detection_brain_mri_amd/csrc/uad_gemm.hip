@@ -3432,8 +3432,10 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
 }
 
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
-                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev, bool generic_bf16x3) {
-    // reduce_st/ev (optional): run the split-K slab reduction on a second stream, ordered after the main kernel by `ev`
+                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev, bool generic_bf16x3, bool defer_reduce) {
+    // reduce_st/ev (optional): run the split-K slab reduction on a second stream, ordered after the main kernel by `ev`.
+    // defer_reduce: leave the reduction to a later uad_launch_conv_w_reduce (the caller orders it after this kernel with ONE event per layer:
+    // every event recorded on the main stream costs a ~6 us bubble before its next kernel)
     auto hop = [&]() -> hipStream_t {
         if (!reduce_st) return st;
         (void)hipEventRecord(ev, st);
@@ -3511,7 +3513,7 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         } else {
             hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
         }
-        if (w5.splits > 1) uad_launch_reduce_partials(partial, w5.splits, a.Mtot * d.CS, 1.0f, dW, hop());
+        if (w5.splits > 1 && !defer_reduce) uad_launch_reduce_partials(partial, w5.splits, a.Mtot * d.CS, 1.0f, dW, hop());
         return;
     }
     const WChoice c = choose_w(d);
@@ -3535,5 +3537,11 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         hipLaunchKernelGGL((conv_w_kernel<64, 64, 32, 2, 2>), grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((conv_w_kernel<64, 32, 32, 2, 1>), grid, dim3(128), 0, st, a);
-    if (c.splits > 1) uad_launch_reduce_partials(partial, c.splits, a.Mtot * d.CS, 1.0f, dW, hop());
+    if (c.splits > 1 && !defer_reduce) uad_launch_reduce_partials(partial, c.splits, a.Mtot * d.CS, 1.0f, dW, hop());
+}
+
+void uad_launch_conv_w_reduce(const UadConvDesc& d, float* dW, float* partial, hipStream_t st) {
+    const W5Choice w5 = choose_w5(d);
+    const int splits = w5.ok ? w5.splits : choose_w(d).splits;
+    if (splits > 1) uad_launch_reduce_partials(partial, splits, d.KS * d.KS * d.CB * d.CS, 1.0f, dW, st);
 }

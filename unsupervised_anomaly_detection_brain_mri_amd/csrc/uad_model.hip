@@ -746,7 +746,9 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
 static hipEvent_t next_event(uad_model* m) {
     if (m->ev_next == m->sync_events.size()) {
         hipEvent_t e;
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        // same-device stream ordering only: no system-scope fence (cache writeback) at the record
+        if (getenv("UAD_EVENT_SYSFENCE") || hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
+            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
         m->sync_events.push_back(e);
     }
     return m->sync_events[m->ev_next++];
@@ -796,15 +798,15 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
         const bool fbb = last && m->last_fin_bits;      // d loss / d c of the last block exists only as pattern bits + d objective / d x_hat
         UadXform gbits = no_xform();
         if (fbb) { gbits = bn_xform(m, DL.gamma, DL.beta, kLrelu); gbits.fb_dxhat = m->fin_dxh; gbits.fb_wf = P(m, m->fw); gbits.fb_bits = m->fin_bits; }
-        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, sd, next_event(m)); }
+        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, nullptr, nullptr, false, true); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
         { PROF(kDecD[i & 7]); UadEpilogue e = epi_bwd(m, in, ig, ib, ia); e.colpart = cp;
           const bool fb = m->restore && m->fb_on_load && last;
           UadXform gx = fbb ? gbits : no_xform();
           if (fb) { gx = bn_xform(m, DL.gamma, DL.beta, kLrelu); gx.fb_dxhat = m->gm_dxhat; gx.fb_wf = P(m, m->fw); }
           uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
-        edge(m, st, sd);   // column partials of this layer are ready
-        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd); }
+        edge(m, st, sd);   // ONE edge per layer: its filter-gradient slabs and column partials are ready
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd); }
         float* tsw = g; g = gn; gn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
@@ -993,11 +995,12 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
         UadConvDesc d = m->enc[i].d; d.N = n;
         const ConvLayer& PL = m->enc[i - 1];
         float* cp = m->cp_slot[8 + (i & 7)];
-        if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, sd, next_event(m)); }
+        if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true); }
         { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
           uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i])); }
         edge(m, st, sd);
-        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd);
+                  uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd); }
         float* tsw = g; g = gn; gn = tsw;
     }

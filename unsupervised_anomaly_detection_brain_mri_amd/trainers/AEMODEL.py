@@ -164,6 +164,7 @@ class AEMODEL(DLMODEL):
             eps = d_eps if eps is None else eps
             masks = d_masks if dropout_masks is None else dropout_masks
         c = self.config
+        kw.setdefault('want_latents', False)      # the reference's process() fetches no latent (VAE.py:83-96); reconstruct() does
         if train:
             return self.dp.train_step(batch, eps, masks, lr=c.learningrate, beta1=c.beta1, want_l1=fetch_maps, **kw)
         return self.engine.forward(batch, eps, masks, want_backward=False, want_l1=fetch_maps, **kw)
