@@ -183,7 +183,11 @@ __global__ void __launch_bounds__(NT) bottleneck_bwd_kernel(const UadBottArgs a)
     float* s_df = s_dz + 2 * Z;      // [F]      dflat
     float* s_w = s_df + F;           // [C*M]
     float* s_part = s_w + C * M;     // [NT]
-    for (int i = tid; i < P * C; i += NT) s_g[i] = a.dcb[(size_t)n * P * C + i];
+    for (int i = tid; i < P * C; i += NT) {
+        const float v = a.dcb[(size_t)n * P * C + i];
+        s_g[i] = v;
+        if (a.dcb_copy) a.dcb_copy[(size_t)n * P * C + i] = v;
+    }
     // conv2d_1 kernel [M][C] staged transposed ([C][M]) so that it is the [K][O] operand of the data gradient
     for (int i = tid; i < C * M; i += NT) s_w[(i % C) * M + i / C] = a.Wr[i];
     __syncthreads();

@@ -184,6 +184,7 @@ struct UadBottArgs {
     float *t, *mu, *ls, *sigma, *z, *kl, *dvec, *cb;
     // backward
     const float* dcb;                    // [n, npos, cenc] d loss / d cb
+    float* dcb_copy;                     // optional: the backward kernel leaves a copy of dcb here
     float *dd, *dmu, *dls, *dflat, *g_out, *colpart;   // colpart [n][2][cenc]
 };
 size_t uad_bottleneck_lds_bytes(const UadBottArgs& a, bool bwd);

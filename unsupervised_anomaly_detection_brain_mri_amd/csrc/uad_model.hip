@@ -99,6 +99,7 @@ struct uad_model {
     float* restore_grads;              // optional gradient output
     // gradient ping-pong + small grads
     float *G0, *G1;
+    float* dcb_keep;                  // copy of d loss / d cb for conv2d_1's kernel gradient (SIDE)
     float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
     // scratch
     float *colpart, *wpartial, *colscratch, *red_partial, *rec_partial, *rec_ps, *scalars_own;
@@ -417,6 +418,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     m->last_fin_bits = false;
     ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
     ALLOC(m->g_small[4], nflat); ALLOC(m->g_small[5], nflat);
+    ALLOC(m->dcb_keep, NB * ir * ir * m->cenc);
     // column-partial scratch: worst case 64-row tiles
     size_t cp = 0;
     auto cp_need = [&](size_t rows, int classes, int C) { size_t v = ((rows + 63) / 64) * classes * 2 * C; if (v > cp) cp = v; };
@@ -760,7 +762,7 @@ static void edge(uad_model* m, hipStream_t from, hipStream_t to) {
 }
 #define PROF_ON(tag, stream) ProfScope prof_scope_s_##__LINE__(m, tag, stream)
 
-static int backward_decoder(uad_model* m, hipStream_t st) {
+static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
     const int n = m->last_n;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
     hipStream_t sd = m->side;
@@ -773,16 +775,6 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
     static const char* kDecD[] = {"dec0.dgrad", "dec1.dgrad", "dec2.dgrad", "dec3.dgrad", "dec4.dgrad", "dec5.dgrad", "dec6.dgrad", "dec7.dgrad"};
     const bool pg = !m->data_only;   // parameter gradients wanted
     m->ev_next = 0;
-    edge(m, st, sd);   // forward (d c of the last block, loss partials) is complete
-    if (pg) {
-        // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials:
-        // red_partial[T][3C+1] = {dwf[C], S1[C], S2[C], dbf}
-        PROF_ON("final.gradfin", sd);
-        uad_launch_reduce_partials(m->red_partial, T, L, 1.0f, m->colscratch, sd);
-        hipMemcpyAsync(Gr(m, m->fw), m->colscratch, C * sizeof(float), hipMemcpyDeviceToDevice, sd);
-        hipMemcpyAsync(Gr(m, m->fb), m->colscratch + 3 * C, sizeof(float), hipMemcpyDeviceToDevice, sd);
-        uad_launch_bn_grad_finalize(m->colscratch + C, 1, C, P(m, DL.gamma), rstd, Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), sd);
-    }
     float* g = m->G0;      // d loss / d c of dec[i]
     float* gn = m->G1;
     for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
@@ -806,11 +798,20 @@ static int backward_decoder(uad_model* m, hipStream_t st) {
           if (fb) { gx = bn_xform(m, DL.gamma, DL.beta, kLrelu); gx.fb_dxhat = m->gm_dxhat; gx.fb_wf = P(m, m->fw); }
           uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
         edge(m, st, sd);   // ONE edge per layer: its filter-gradient slabs and column partials are ready
+        if (pg && last) {
+            // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials (forward results; riding on
+            // this layer's edge instead of one of their own): red_partial[T][3C+1] = {dwf[C], S1[C], S2[C], dbf}
+            PROF_ON("final.gradfin", sd);
+            uad_launch_reduce_partials(m->red_partial, T, L, 1.0f, m->colscratch, sd);
+            hipMemcpyAsync(Gr(m, m->fw), m->colscratch, C * sizeof(float), hipMemcpyDeviceToDevice, sd);
+            hipMemcpyAsync(Gr(m, m->fb), m->colscratch + 3 * C, sizeof(float), hipMemcpyDeviceToDevice, sd);
+            uad_launch_bn_grad_finalize(m->colscratch + C, 1, C, P(m, DL.gamma), rstd, Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), sd);
+        }
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd); }
         float* tsw = g; g = gn; gn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
-    edge(m, sd, st);         // join: decoder gradients complete
+    if (join_now) edge(m, sd, st);         // join: decoder gradients complete (inside UAD_SEG_ALL the join is the encoder segment's)
     return UAD_OK;
 }
 
@@ -842,21 +843,15 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
         UadBottArgs ba = bott_args(m, io, m->mask_dec_eff, nu);
         if (m->restore) ba.inv_batch = m->restore_scale;          // VAE_You: d (rec_n + kl_n) / d x per sample, no 1/n
         if (uad_bottleneck_fused_ok(ba)) {
-            // MAIN: one workgroup per sample does the whole data-gradient chain.  SIDE: the parameter-gradient GEMMs -- conv2d_1's
-            // (it needs only dcb / dvec) before that kernel, the others from the vectors it leaves behind.
-            hipEvent_t ev_r = nullptr;
-            edge(m, st, sd);
-            if (pg) {
-                PROF_ON("bott.wgrad", sd);
-                uad_launch_conv_w(d_r, m->dvec, no_xform(), dcb, no_xform(), Gr(m, m->rw), wp, sd);
-                ev_r = next_event(m);
-                (void)hipEventRecord(ev_r, sd);
-            }
+            // MAIN: one workgroup per sample does the whole data-gradient chain.  SIDE: the parameter-gradient GEMMs, from the vectors
+            // it leaves behind (one edge, no wait of MAIN on SIDE).
             ba.dcb = dcb; ba.dd = dd; ba.dmu = vae ? dmu : dz; ba.dls = dls; ba.dflat = dflat; ba.g_out = m->G1; ba.colpart = cp;
+            ba.dcb_copy = pg ? m->dcb_keep : nullptr;     // conv2d_1's kernel gradient reads this copy on SIDE: dcb's buffer becomes encoder scratch
             { PROF("bott.bwd"); uad_launch_bottleneck_bwd(ba, n, st); }
             edge(m, st, sd);
             if (pg) {
                 PROF_ON("bott.wgrad", sd);
+                uad_launch_conv_w(d_r, m->dvec, no_xform(), m->dcb_keep, no_xform(), Gr(m, m->rw), wp, sd);
                 uad_launch_conv_w(d_dec, m->z, no_xform(), dd, no_xform(), Gr(m, m->dw), wp, sd);
                 uad_launch_colsum(dd, n, m->flat, Gr(m, m->db), m->colscratch, sd);
                 uad_launch_conv_w(d_in, m->t, no_xform(), vae ? dmu : dz, no_xform(), Gr(m, m->muw), wp, sd);
@@ -870,8 +865,6 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
                 uad_launch_bn_grad_finalize(cp, n, m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma), Gr(m, EL.beta), Gr(m, EL.b), sd);
             }
             float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;
-            // dcb (now G1) becomes the encoder chain's scratch: SIDE must be done reading it (only conv2d_1's gradient does)
-            if (ev_r) (void)hipStreamWaitEvent(st, ev_r, 0);
             if (join_now) edge(m, sd, st);
             return UAD_OK;
         }
@@ -1030,7 +1023,7 @@ int uad_backward(uad_model_t* m, int segment, void* stream) {
     if (segment < UAD_SEG_ALL || segment > UAD_SEG_ENCODER) return fail(UAD_ERR_INVALID, "bad segment %d", segment);
     hipStream_t st = (hipStream_t)stream;
     int rc = UAD_OK;
-    if (segment == UAD_SEG_ALL || segment == UAD_SEG_DECODER) rc = backward_decoder(m, st);
+    if (segment == UAD_SEG_ALL || segment == UAD_SEG_DECODER) rc = backward_decoder(m, st, segment == UAD_SEG_DECODER);
     if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_BOTTLENECK))
         rc = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL ? backward_gm_heads(m, st)
              : m->cfg.arch == UAD_ARCH_AE_SPATIAL ? backward_spatial_z(m, st) : backward_bottleneck(m, st, segment == UAD_SEG_BOTTLENECK);
