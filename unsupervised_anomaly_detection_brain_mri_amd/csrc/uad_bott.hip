@@ -1,4 +1,5 @@
-// Dense bottleneck of the AE / VAE / ceVAE graphs as ONE workgroup per sample (1024 threads), forward and data-gradient backward
+// Dense bottleneck of the AE / VAE / ceVAE graphs as ONE group of workgroups per sample (4 x 1024 threads, or one workgroup when the
+// shapes do not split), forward and data-gradient backward
 // (models/autoencoder.py:20-33, variational_autoencoder.py:20-40, context_encoder_variational_autoencoder.py:23-47).
 // As a chain of batched GEMMs this part is ~16 dependent launches of tiny kernels (M = batch = 64 rows): 79 + 87 us of a 1.3 ms
 // step with almost no arithmetic in it.  Per sample everything fits in LDS; the only real traffic is streaming the three
@@ -10,6 +11,9 @@
 namespace {
 
 constexpr int NT = 1024;
+
+// UAD_BOTT_DBG=1: phase stamps (100 MHz wall clock) of workgroup 0, printed by the launcher for its first calls
+#define STAMP(i) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -60,61 +64,140 @@ __device__ __forceinline__ void gemv_cols_partial(const float* __restrict__ W, c
     __syncthreads();
 }
 
+// ---- exchange between the Q workgroups that share one sample ----
+// Every workgroup owns 1/Q of the positions (and so of the flattened features); the two reductions that run over ALL features
+// (dense heads forward, dec_dense data gradient backward) are computed as Q partial vectors and combined in a fixed order
+// (deterministic) after ONE exchange through global memory: xch[(n*Q + q) * xw + i], flags[n*Q + q] = epoch of this launch.
+// The Q workgroups of a sample have adjacent block ids, so whenever one of them is resident its siblings are the next to be
+// dispatched: the spin cannot starve them (resident complete groups finish on their own and free their slots).
+template <int Q>
+__device__ __forceinline__ void group_exchange(const UadBottArgs& a, int n, int q, int tid, int count, float mine, float* s_tot) {
+    if (Q == 1) {
+        if (tid < count) s_tot[tid] = mine;
+        __syncthreads();
+        return;
+    }
+    // Agent-scope RELAXED atomics move the data and the flag: they are performed at the device's coherence point (the workgroups of a
+    // group sit on different XCDs, i.e. behind different L2s), and "data before flag" is enforced by draining the stores (s_waitcnt)
+    // before the barrier that precedes the flag store.  A release fence instead writes back the whole dirty L2 of the XCD: 20 us here.
+    if (tid < count) {
+        __hip_atomic_store(a.xch + ((size_t)n * Q + q) * a.xw + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.flags + n * Q + q, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < Q)
+        while (__hip_atomic_load(a.flags + n * Q + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __syncthreads();
+    if (tid < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < Q; ++qq) t += __hip_atomic_load(a.xch + ((size_t)n * Q + qq) * a.xw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_tot[tid] = t;
+    }
+    __syncthreads();
+}
+
+// out[col] (col in this workgroup's slice [c0, c0 + NC) of a row-major [K][ld] matrix, coalesced over col) = sum_k x[k] * W[k][c0 + col]:
+// NT threads = G k-groups x CP columns per pass (G > 1 when the slice is narrower than the workgroup), 16 independent row loads in
+// flight per thread, group partials through s_part.  fin(col, sum) runs on the k-group-0 thread of each column.
+template <typename Fin>
+__device__ __forceinline__ void gemv_slice(const float* __restrict__ W, size_t ld, int c0, int NC, const float* x, int K, float* s_part, int tid, Fin fin) {
+    const int G = NC < NT ? NT / NC : 1;
+    const int CP = NT / G;
+    const int kg = tid / CP, cl = tid % CP;
+    const int kper = K / G;
+    for (int cb = 0; cb < NC; cb += CP) {
+        const int col = cb + cl;
+        float acc = 0.f;
+        if (col < NC)
+            for (int k = kg * kper; k < (kg + 1) * kper; k += 16) {
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = W[(size_t)(k + u) * ld + c0 + col];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = fmaf(x[k + u], w[u], acc);
+            }
+        if (G > 1) {
+            s_part[tid] = acc;
+            __syncthreads();
+            if (kg == 0 && col < NC)
+                for (int g = 1; g < G; ++g) acc += s_part[g * CP + cl];
+        }
+        if (kg == 0 && col < NC) fin(col, acc);
+        if (G > 1) __syncthreads();
+    }
+}
+
+template <int Q>
 __global__ void __launch_bounds__(NT) bottleneck_fwd_kernel(const UadBottArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int tid = threadIdx.x, n = blockIdx.x;
+    const int tid = threadIdx.x, n = blockIdx.x / Q, q = blockIdx.x % Q;
     const int C = a.cenc, M = a.cmid, P = a.npos, F = a.npos * a.cmid, Z = a.zdim;
-    float* s_h = sm;                 // [P][C]   activated encoder features
-    float* s_t = s_h + P * C;        // [F]      flattened conv2d output
-    float* s_part = s_t + F;         // [NT]
+    const int Pq = P / Q, Fq = Pq * M, p0 = q * Pq, f0 = q * Fq;     // this workgroup's positions / flattened features
+    float* s_h = sm;                 // [Pq][C]  activated encoder features
+    float* s_t = s_h + Pq * C;       // [Fq]     flattened conv2d output
+    float* s_part = s_t + Fq;        // [NT]
     float* s_z = s_part + NT;        // [Z]
-    float* s_d = s_z + Z;            // [F]      dec_dense output (after dropout)
-    float* s_w = s_d + F;            // [C*M]    1x1 kernels (conv2d, then conv2d_1)
+    float* s_d = s_z + Z;            // [Fq]     dec_dense output (after dropout)
+    float* s_w = s_d + Fq;           // [C*M]    1x1 kernels (conv2d, then conv2d_1)
+    STAMP(0);
     // stage h = lrelu(bn(c_enc)) and the conv2d kernel
-    for (int i = tid; i < P * C; i += NT) {
+    const size_t hb = ((size_t)n * P + p0) * C;
+    for (int i = tid; i < Pq * C; i += NT) {
         const int c = i % C;
-        const float bn = fmaf(a.c_enc[(size_t)n * P * C + i], a.scale[c] * a.mult, a.shift[c]);
+        const float bn = fmaf(a.c_enc[hb + i], a.scale[c] * a.mult, a.shift[c]);
         s_h[i] = bn > 0.f ? bn : bn * a.alpha;
     }
     for (int i = tid; i < C * M; i += NT) s_w[i] = a.Wb[i];
     __syncthreads();
+    STAMP(1);
     // conv2d 1x1: t[p*M + j] = sum_c h[p][c] * Wb[c][j] + bb[j]
-    conv1x1_tiled(s_h, s_w, P, C, M, tid, [&](int p, int o, const float4& v) {
+    conv1x1_tiled(s_h, s_w, Pq, C, M, tid, [&](int p, int o, const float4& v) {
         const float4 b = *reinterpret_cast<const float4*>(a.bb + o);
         const float4 r = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
         *reinterpret_cast<float4*>(s_t + p * M + o) = r;
-        *reinterpret_cast<float4*>(a.t + (size_t)n * F + p * M + o) = r;
+        *reinterpret_cast<float4*>(a.t + (size_t)n * F + f0 + p * M + o) = r;
     });
     __syncthreads();
+    STAMP(2);
     const bool ctx = n >= a.n_vae;          // ceVAE context branch: z = z_mu_ce, no sampling / KL
-    // dense heads: NO columns (2Z: mu | log-sigma from two [F][Z] kernels; AE: Z columns of dense_z), K = F split over NT/NO groups
+    // dense heads: NO columns (2Z: mu | log-sigma from two [F][Z] kernels; AE: Z columns of dense_z); this workgroup contracts its
+    // Fq features (split over NT/NO groups), the group's partial vectors are exchanged
     {
         const int NO = a.Wsg ? 2 * Z : Z;
         const int G = NT / NO;
         const int o2 = tid % NO, kg = tid / NO;
         const float* W = (o2 < Z) ? a.Wmu : a.Wsg;
         const int o = (o2 < Z) ? o2 : o2 - Z;
-        const int kper = (F + G - 1) / G, k0 = kg * kper, k1 = min(k0 + kper, F);
+        const int kper = (Fq + G - 1) / G, k0 = kg * kper, k1 = min(k0 + kper, Fq);
         float acc = 0.f;
         int k = k0;
         for (; k + 32 <= k1; k += 32) {
             float w[32];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) w[u] = W[(size_t)(k + u) * Z + o];
+            for (int u = 0; u < 32; ++u) w[u] = W[(size_t)(f0 + k + u) * Z + o];
 #pragma unroll
             for (int u = 0; u < 32; ++u) acc = fmaf(s_t[k + u], w[u], acc);
         }
-        for (; k < k1; ++k) acc = fmaf(s_t[k], W[(size_t)k * Z + o], acc);
+        for (; k < k1; ++k) acc = fmaf(s_t[k], W[(size_t)(f0 + k) * Z + o], acc);
         s_part[tid] = acc;
         __syncthreads();
+        float mine = 0.f;
+        if (tid < NO)
+            for (int g = 0; g < G; ++g) mine += s_part[g * NO + tid];
+        __syncthreads();
+        STAMP(3);
+        group_exchange<Q>(a, n, q, tid, NO, mine, s_part);
+        STAMP(4);      // s_part[0 .. NO) = head pre-activations without bias
         float klv = 0.f;
         if (tid < Z) {
             const size_t i = (size_t)n * Z + tid;
-            float mr = a.bmu[tid];
-            for (int g = 0; g < G; ++g) mr += s_part[g * NO + tid];
+            const float mr = a.bmu[tid] + s_part[tid];
             if (a.Wsg) {
-                float lr = a.bsg[tid];
-                for (int g = 0; g < G; ++g) lr += s_part[g * NO + Z + tid];
+                const float lr = a.bsg[tid] + s_part[Z + tid];
                 float mval = mr, l = 0.f, s = 1.f, zv;
                 if (ctx) {
                     if (a.mask_mu_ce) mval *= a.mask_mu_ce[(size_t)(n - a.n_vae) * Z + tid];
@@ -128,12 +211,12 @@ __global__ void __launch_bounds__(NT) bottleneck_fwd_kernel(const UadBottArgs a)
                     zv = fmaf(e, s, mval);
                     klv = mval * mval + s * s - 2.f * l - 1.f;
                 }
-                a.mu[i] = mval; a.ls[i] = l; a.sigma[i] = s; a.z[i] = zv;
+                if (q == 0) { a.mu[i] = mval; a.ls[i] = l; a.sigma[i] = s; a.z[i] = zv; }
                 s_z[tid] = zv;
             } else {
                 float zv = mr;
                 if (a.mask_mu) zv *= a.mask_mu[i];
-                a.z[i] = zv;
+                if (q == 0) a.z[i] = zv;
                 s_z[tid] = zv;
             }
         }
@@ -143,73 +226,75 @@ __global__ void __launch_bounds__(NT) bottleneck_fwd_kernel(const UadBottArgs a)
             __syncthreads();
             if ((tid & 63) == 0 && tid < Z) s_part[tid >> 6] = klv;
             __syncthreads();
-            if (tid == 0) { float t = 0.f; for (int w = 0; w < (Z + 63) / 64; ++w) t += s_part[w]; a.kl[n] = 0.5f * t; }
+            if (tid == 0 && q == 0) { float t = 0.f; for (int w = 0; w < (Z + 63) / 64; ++w) t += s_part[w]; a.kl[n] = 0.5f * t; }
         }
         __syncthreads();
     }
-    // dec_dense: d[f] = (sum_k z[k] * Wd[k][f] + bd[f]) * mask_dec[f]      (F columns, K = Z)
-    for (int f0 = 0; f0 < F; f0 += NT) {
-        const int f = f0 + tid;
-        if (f < F) {
-            float acc = a.bd[f];
-            for (int k = 0; k < Z; k += 16) {
-                float w[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) w[u] = a.Wd[(size_t)(k + u) * F + f];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) acc = fmaf(s_z[k + u], w[u], acc);
-            }
-            if (a.mask_dec) acc *= a.mask_dec[(size_t)n * F + f];
-            s_d[f] = acc;
-            a.dvec[(size_t)n * F + f] = acc;
-        }
-    }
+    STAMP(5);
+    // dec_dense: d[f] = (sum_k z[k] * Wd[k][f] + bd[f]) * mask_dec[f]      (this workgroup's Fq columns, K = Z)
+    gemv_slice(a.Wd, (size_t)F, f0, Fq, s_z, Z, s_part, tid, [&](int fl, float acc) {
+        acc += a.bd[f0 + fl];
+        if (a.mask_dec) acc *= a.mask_dec[(size_t)n * F + f0 + fl];
+        s_d[fl] = acc;
+        a.dvec[(size_t)n * F + f0 + fl] = acc;
+    });
+    STAMP(6);
     for (int i = tid; i < C * M; i += NT) s_w[i] = a.Wr[i];      // conv2d_1 kernel [M][C]
     __syncthreads();
+    STAMP(7);
     // conv2d_1 1x1: cb[p][c] = sum_j d[p*M + j] * Wr[j][c] + br[c]
-    conv1x1_tiled(s_d, s_w, P, M, C, tid, [&](int p, int c0, const float4& v) {
+    conv1x1_tiled(s_d, s_w, Pq, M, C, tid, [&](int p, int c0, const float4& v) {
         const float4 b = *reinterpret_cast<const float4*>(a.br + c0);
-        *reinterpret_cast<float4*>(a.cb + (size_t)n * P * C + p * C + c0) = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+        *reinterpret_cast<float4*>(a.cb + ((size_t)n * P + p0 + p) * C + c0) = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
     });
+    __syncthreads();
+    STAMP(8);
 }
 
+template <int Q>
 __global__ void __launch_bounds__(NT) bottleneck_bwd_kernel(const UadBottArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int tid = threadIdx.x, n = blockIdx.x;
+    const int tid = threadIdx.x, n = blockIdx.x / Q, q = blockIdx.x % Q;
     const int C = a.cenc, M = a.cmid, P = a.npos, F = a.npos * a.cmid, Z = a.zdim;
-    float* s_g = sm;                 // [P][C]   d loss / d cb, later d_bn of the last encoder block
-    float* s_dd = s_g + P * C;       // [F]
-    float* s_dz = s_dd + F;          // [2Z]     dmu | dls
-    float* s_df = s_dz + 2 * Z;      // [F]      dflat
-    float* s_w = s_df + F;           // [C*M]
+    const int Pq = P / Q, Fq = Pq * M, p0 = q * Pq, f0 = q * Fq;
+    float* s_g = sm;                 // [Pq][C]  d loss / d cb, later d_bn of the last encoder block
+    float* s_dd = s_g + Pq * C;      // [Fq]
+    float* s_dz = s_dd + Fq;         // [2Z]     dmu | dls
+    float* s_df = s_dz + 2 * Z;      // [Fq]     dflat
+    float* s_w = s_df + Fq;          // [C*M]
     float* s_part = s_w + C * M;     // [NT]
-    for (int i = tid; i < P * C; i += NT) {
-        const float v = a.dcb[(size_t)n * P * C + i];
+    const size_t gb = ((size_t)n * P + p0) * C;
+    for (int i = tid; i < Pq * C; i += NT) {
+        const float v = a.dcb[gb + i];
         s_g[i] = v;
-        if (a.dcb_copy) a.dcb_copy[(size_t)n * P * C + i] = v;
+        if (a.dcb_copy) a.dcb_copy[gb + i] = v;
     }
     // conv2d_1 kernel [M][C] staged transposed ([C][M]) so that it is the [K][O] operand of the data gradient
     for (int i = tid; i < C * M; i += NT) s_w[(i % C) * M + i / C] = a.Wr[i];
     __syncthreads();
     // d dec_dense output: dd[p*M + j] = (sum_c dcb[p][c] * Wr[j][c]) * mask_dec
-    conv1x1_tiled(s_g, s_w, P, C, M, tid, [&](int p, int o, const float4& v) {
-        const int f = p * M + o;
+    conv1x1_tiled(s_g, s_w, Pq, C, M, tid, [&](int p, int o, const float4& v) {
+        const int fl = p * M + o;
         float4 r = v;
         if (a.mask_dec) {
-            const float4 mk = *reinterpret_cast<const float4*>(a.mask_dec + (size_t)n * F + f);
+            const float4 mk = *reinterpret_cast<const float4*>(a.mask_dec + (size_t)n * F + f0 + fl);
             r.x *= mk.x; r.y *= mk.y; r.z *= mk.z; r.w *= mk.w;
         }
-        *reinterpret_cast<float4*>(s_dd + f) = r;
-        *reinterpret_cast<float4*>(a.dd + (size_t)n * F + f) = r;
+        *reinterpret_cast<float4*>(s_dd + fl) = r;
+        *reinterpret_cast<float4*>(a.dd + (size_t)n * F + f0 + fl) = r;
     });
     __syncthreads();
-    // dz[k] = sum_f dd[f] * Wd^T[f][k]   (transposed copy: coalesced over k)
-    gemv_cols_partial(a.WdT, s_dd, F, Z, s_part, tid);
+    // dz[k] = sum_f dd[f] * Wd^T[f][k]   (transposed copy: coalesced over k); this workgroup's Fq rows, then the exchange
+    gemv_cols_partial(a.WdT + (size_t)f0 * Z, s_dd, Fq, Z, s_part, tid);
+    float mine = 0.f;
+    if (tid < Z)
+        for (int g = 0; g < NT / Z; ++g) mine += s_part[g * Z + tid];
+    __syncthreads();
+    group_exchange<Q>(a, n, q, tid, Z, mine, s_part);
     const bool ctx = n >= a.n_vae;
     if (tid < Z) {
         const size_t i = (size_t)n * Z + tid;
-        float g = 0.f;
-        for (int q = 0; q < NT / Z; ++q) g += s_part[q * Z + tid];
+        const float g = s_part[tid];
         float dm, dl = 0.f;
         if (a.Wsg) {
             if (ctx) {
@@ -221,43 +306,27 @@ __global__ void __launch_bounds__(NT) bottleneck_bwd_kernel(const UadBottArgs a)
                 if (a.mask_mu) dm *= a.mask_mu[i];
                 if (a.mask_ls) dl *= a.mask_ls[i];
             }
-            a.dmu[i] = dm; a.dls[i] = dl;
+            if (q == 0) { a.dmu[i] = dm; a.dls[i] = dl; }
         } else {
             dm = a.mask_mu ? g * a.mask_mu[i] : g;
-            a.dmu[i] = dm;
+            if (q == 0) a.dmu[i] = dm;
         }
         s_dz[tid] = dm; s_dz[Z + tid] = dl;
     }
     __syncthreads();
-    // dflat[r] = sum_o dmu[o] * Wmu^T[o][r] (+ dls[o] * Wsg^T[o][r])   (transposed copies: coalesced over r)
-    for (int r0 = 0; r0 < F; r0 += NT) {
-        const int r = r0 + tid;
-        if (r < F) {
-            float acc = 0.f;
-            for (int o = 0; o < Z; o += 16) {
-                float w[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) w[u] = a.WmuT[(size_t)(o + u) * F + r];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) acc = fmaf(s_dz[o + u], w[u], acc);
-            }
-            if (a.Wsg)
-                for (int o = 0; o < Z; o += 16) {
-                    float w[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) w[u] = a.WsgT[(size_t)(o + u) * F + r];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) acc = fmaf(s_dz[Z + o + u], w[u], acc);
-                }
-            s_df[r] = acc;
-            a.dflat[(size_t)n * F + r] = acc;
-        }
+    // dflat[r] = sum_o dmu[o] * Wmu^T[o][r] (+ dls[o] * Wsg^T[o][r])   (transposed copies: coalesced over r); this workgroup's Fq columns
+    gemv_slice(a.WmuT, (size_t)F, f0, Fq, s_dz, Z, s_part, tid, [&](int fl, float acc) { s_df[fl] = acc; });
+    if (a.Wsg) {
+        __syncthreads();
+        gemv_slice(a.WsgT, (size_t)F, f0, Fq, s_dz + Z, Z, s_part, tid, [&](int fl, float acc) { s_df[fl] += acc; });
     }
+    __syncthreads();
+    for (int fl = tid; fl < Fq; fl += NT) a.dflat[(size_t)n * F + f0 + fl] = s_df[fl];
     for (int i = tid; i < C * M; i += NT) s_w[(i % M) * C + i / M] = a.Wb[i];      // conv2d kernel [C][M] staged as [M][C] = [K][O]
     __syncthreads();
-    // d h[p][c] = sum_j dflat[p*M + j] * Wb[c][j]; activation backward of the last encoder block; per-sample BN partials
-    conv1x1_tiled(s_df, s_w, P, M, C, tid, [&](int p, int c0, const float4& v) {
-        const size_t gi = (size_t)n * P * C + p * C + c0;
+    // d h[p][c] = sum_j dflat[p*M + j] * Wb[c][j]; activation backward of the last encoder block; per-workgroup BN partials
+    conv1x1_tiled(s_df, s_w, Pq, M, C, tid, [&](int p, int c0, const float4& v) {
+        const size_t gi = gb + p * C + c0;
         const float4 cv = *reinterpret_cast<const float4*>(a.c_enc + gi);
         const float dh[4] = {v.x, v.y, v.z, v.w}, cc[4] = {cv.x, cv.y, cv.z, cv.w};
         float dbn[4], out[4];
@@ -274,13 +343,13 @@ __global__ void __launch_bounds__(NT) bottleneck_bwd_kernel(const UadBottArgs a)
     __syncthreads();
     if (tid < C) {
         float t1 = 0.f, t2 = 0.f;
-        for (int p = 0; p < P; ++p) {
+        for (int p = 0; p < Pq; ++p) {
             const float dbn = s_g[p * C + tid];
             t1 += dbn;
-            t2 = fmaf(dbn, a.c_enc[(size_t)n * P * C + p * C + tid], t2);
+            t2 = fmaf(dbn, a.c_enc[gb + p * C + tid], t2);
         }
-        a.colpart[((size_t)n * 2 + 0) * C + tid] = t1;
-        a.colpart[((size_t)n * 2 + 1) * C + tid] = t2;
+        a.colpart[((size_t)blockIdx.x * 2 + 0) * C + tid] = t1;      // rows: one per workgroup (uad_bottleneck_colpart_rows)
+        a.colpart[((size_t)blockIdx.x * 2 + 1) * C + tid] = t2;
     }
 }
 
@@ -302,30 +371,61 @@ __global__ void __launch_bounds__(256) transpose_kernel(const TransposeJobs jb) 
 
 }  // namespace
 
+// workgroups per sample: 4 when the shapes split evenly (one exchange per kernel, weights streamed by 4x as many CUs), else 1
+int uad_bottleneck_group(const UadBottArgs& a) {
+    static const bool q1 = getenv("UAD_BOTT_Q1") != nullptr;
+    const int Q = 4;
+    if (q1 || !a.xch || !a.flags || a.npos % Q) return 1;
+    const int Fq = a.npos / Q * a.cmid;
+    const bool slice_ok = (Fq >= NT ? Fq % NT == 0 : NT % Fq == 0) && a.zdim % (16 * (Fq < NT ? NT / Fq : 1)) == 0;
+    return slice_ok ? Q : 1;
+}
+int uad_bottleneck_colpart_rows(const UadBottArgs& a, int n) { return n * uad_bottleneck_group(a); }
 size_t uad_bottleneck_lds_bytes(const UadBottArgs& a, bool bwd) {
-    const size_t PC = (size_t)a.npos * a.cenc, F = (size_t)a.npos * a.cmid, CM = (size_t)a.cenc * a.cmid;
+    const int Q = uad_bottleneck_group(a);
+    const size_t PC = (size_t)a.npos / Q * a.cenc, F = (size_t)a.npos / Q * a.cmid, CM = (size_t)a.cenc * a.cmid;
     return (bwd ? PC + F + 2 * a.zdim + F + CM + NT : PC + F + NT + a.zdim + F + CM) * sizeof(float);
 }
 bool uad_bottleneck_fused_ok(const UadBottArgs& a) {
     if (getenv("UAD_NO_FUSED_BOTT")) return false;
     const int NO = a.Wsg ? 2 * a.zdim : a.zdim;
-    if (a.zdim % 16 || NO > NT || NT % NO || NT % a.zdim || a.cmid % 4 || a.cenc % 16 || (a.npos * a.cmid) % 4) return false;
+    const int F = a.npos * a.cmid;
+    if (a.zdim % 16 || NO > NT || NT % NO || NT % a.zdim || a.cmid % 4 || a.cenc % 16 || F % 4) return false;
+    if (uad_bottleneck_group(a) == 1 && !((F >= NT ? F % NT == 0 : NT % F == 0) && a.zdim % (16 * (F < NT ? NT / F : 1)) == 0)) return false;
     return uad_bottleneck_lds_bytes(a, false) <= 150 * 1024 && uad_bottleneck_lds_bytes(a, true) <= 150 * 1024;
 }
 static void bott_attrs() {
     static bool attr = false;
     if (attr) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
 }
 void uad_launch_bottleneck_fwd(const UadBottArgs& a, int n, hipStream_t st) {
     bott_attrs();
-    hipLaunchKernelGGL(bottleneck_fwd_kernel, dim3(n), dim3(NT), uad_bottleneck_lds_bytes(a, false), st, a);
+    static const bool dbg = getenv("UAD_BOTT_DBG") != nullptr;
+    static unsigned long long* sbuf = nullptr;
+    static int calls = 0;
+    UadBottArgs b = a;
+    const bool on = dbg && ++calls > 20 && calls <= 24;
+    if (on) { if (!sbuf) (void)hipMalloc((void**)&sbuf, 16 * 8); b.stamps = sbuf; }
+    if (uad_bottleneck_group(a) == 4) hipLaunchKernelGGL(bottleneck_fwd_kernel<4>, dim3(4 * n), dim3(NT), uad_bottleneck_lds_bytes(a, false), st, b);
+    else hipLaunchKernelGGL(bottleneck_fwd_kernel<1>, dim3(n), dim3(NT), uad_bottleneck_lds_bytes(a, false), st, b);
+    if (on) {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, sbuf, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[bott.fwd Q=%d] phases (x10 ns):", uad_bottleneck_group(a));
+        for (int i = 1; i <= 8; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+        fprintf(stderr, " | total %llu\n", h[8] - h[0]);
+    }
 }
 void uad_launch_bottleneck_bwd(const UadBottArgs& a, int n, hipStream_t st) {
     bott_attrs();
-    hipLaunchKernelGGL(bottleneck_bwd_kernel, dim3(n), dim3(NT), uad_bottleneck_lds_bytes(a, true), st, a);
+    if (uad_bottleneck_group(a) == 4) hipLaunchKernelGGL(bottleneck_bwd_kernel<4>, dim3(4 * n), dim3(NT), uad_bottleneck_lds_bytes(a, true), st, a);
+    else hipLaunchKernelGGL(bottleneck_bwd_kernel<1>, dim3(n), dim3(NT), uad_bottleneck_lds_bytes(a, true), st, a);
 }
 void uad_launch_transpose(const float* const* in, const int* R, const int* C, float* const* out, int njobs, hipStream_t st) {
     TransposeJobs jb;

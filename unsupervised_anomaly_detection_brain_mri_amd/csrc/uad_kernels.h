@@ -185,10 +185,15 @@ struct UadBottArgs {
     // backward
     const float* dcb;                    // [n, npos, cenc] d loss / d cb
     float* dcb_copy;                     // optional: the backward kernel leaves a copy of dcb here
+    // exchange between the workgroups of one sample (uad_bott.hip): partial vectors, completion flags, this launch's epoch
+    float* xch; unsigned* flags; unsigned epoch; int xw;
+    unsigned long long* stamps;          // debug (UAD_BOTT_DBG): phase clocks of workgroup 0
     float *dd, *dmu, *dls, *dflat, *g_out, *colpart;   // colpart [n][2][cenc]
 };
 size_t uad_bottleneck_lds_bytes(const UadBottArgs& a, bool bwd);
 bool uad_bottleneck_fused_ok(const UadBottArgs& a);
+int uad_bottleneck_group(const UadBottArgs& a);                  // workgroups per sample (1 or 4)
+int uad_bottleneck_colpart_rows(const UadBottArgs& a, int n);    // rows of colpart [rows][2][cenc] the backward writes
 void uad_launch_bottleneck_fwd(const UadBottArgs& a, int n, hipStream_t st);
 void uad_launch_bottleneck_bwd(const UadBottArgs& a, int n, hipStream_t st);
 // out_i[c][r] = in_i[r][c] for up to 3 matrices in one launch

@@ -100,6 +100,7 @@ struct uad_model {
     // gradient ping-pong + small grads
     float *G0, *G1;
     float* dcb_keep;                  // copy of d loss / d cb for conv2d_1's kernel gradient (SIDE)
+    float* bott_xch; unsigned* bott_flags; unsigned bott_epoch;      // exchange of the fused bottleneck's workgroup groups
     float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
     // scratch
     float *colpart, *wpartial, *colscratch, *red_partial, *rec_partial, *rec_ps, *scalars_own;
@@ -234,6 +235,7 @@ UadBottArgs bott_args(uad_model* m, const uad_io_t& io, const float* mask_dec, i
     a.mask_mu_ce = m->cfg.arch == UAD_ARCH_CEVAE ? io.mask_mu_ce : nullptr;
     a.mask_dec = vae ? mask_dec : nullptr;        // AE: the dec_dense dropout is never active (autoencoder.py:30)
     a.t = m->t; a.mu = m->mu; a.ls = m->ls; a.sigma = m->sigma; a.z = m->z; a.kl = m->kl; a.dvec = m->dvec; a.cb = m->cb;
+    a.xch = m->bott_xch; a.flags = m->bott_flags; a.xw = 2 * m->cfg.zdim; a.epoch = 0;      // epoch: set at each launch
     return a;
 }
 
@@ -419,12 +421,15 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
     ALLOC(m->g_small[4], nflat); ALLOC(m->g_small[5], nflat);
     ALLOC(m->dcb_keep, NB * ir * ir * m->cenc);
+    ALLOC(m->bott_xch, NB * 4 * 2 * (size_t)cfg->zdim);
+    { float* fl = nullptr; ALLOC(fl, NB * 4); m->bott_flags = reinterpret_cast<unsigned*>(fl); m->bott_epoch = 0; }
     // column-partial scratch: worst case 64-row tiles
     size_t cp = 0;
     auto cp_need = [&](size_t rows, int classes, int C) { size_t v = ((rows + 63) / 64) * classes * 2 * C; if (v > cp) cp = v; };
     for (auto& L : m->enc) cp_need(NB * L.d.HS * L.d.WS, 4, L.d.CB);
     for (auto& L : m->dec) cp_need(NB * L.d.HS * L.d.WS, 1, L.d.CS);
     cp_need(NB * ir * ir, 1, m->cenc);
+    if (NB * 4 * 2 * m->cenc > cp) cp = NB * 4 * 2 * m->cenc;      // fused bottleneck backward: one row pair per workgroup, 4 per sample
     if (gm) { size_t v = NB * ir * ir * 2 * m->cenc; if (v > cp) cp = v; }
     if (sp) { size_t v = (size_t)512 * 2 * m->cenc; if (v > cp) cp = v; }
     m->colpart_cap = cp; ALLOC(m->colpart, cp);
@@ -620,7 +625,9 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
                                  m->gm_h, st);
     } else if (uad_bottleneck_fused_ok(bott_args(m, *io, mask_dec, nu))) {
         PROF("bott.fwd");
-        uad_launch_bottleneck_fwd(bott_args(m, *io, mask_dec, nu), n, st);
+        UadBottArgs ba = bott_args(m, *io, mask_dec, nu);
+        ba.epoch = ++m->bott_epoch;
+        uad_launch_bottleneck_fwd(ba, n, st);
     } else {
     PROF("bott.fwd");
     uad_launch_conv_f(conv1x1_desc(n, ir, ir, m->cenc, m->cmid), EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu),
@@ -847,9 +854,11 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
             // it leaves behind (one edge, no wait of MAIN on SIDE).
             ba.dcb = dcb; ba.dd = dd; ba.dmu = vae ? dmu : dz; ba.dls = dls; ba.dflat = dflat; ba.g_out = m->G1; ba.colpart = cp;
             ba.dcb_copy = pg ? m->dcb_keep : nullptr;     // conv2d_1's kernel gradient reads this copy on SIDE: dcb's buffer becomes encoder scratch
+            ba.epoch = ++m->bott_epoch;
             { PROF("bott.bwd"); uad_launch_bottleneck_bwd(ba, n, st); }
             edge(m, st, sd);
-            if (pg) {
+            static const bool skipw = getenv("UAD_DBG_SKIP_BOTT_WGRAD") != nullptr;      // timing experiment only
+            if (pg && !skipw) {
                 PROF_ON("bott.wgrad", sd);
                 uad_launch_conv_w(d_r, m->dvec, no_xform(), m->dcb_keep, no_xform(), Gr(m, m->rw), wp, sd);
                 uad_launch_conv_w(d_dec, m->z, no_xform(), dd, no_xform(), Gr(m, m->dw), wp, sd);
@@ -862,7 +871,7 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
                 }
                 uad_launch_conv_w(d_b, EL.c, bn_xform(m, EL.gamma, EL.beta, kLrelu), dflat, no_xform(), Gr(m, m->bw), wp, sd);
                 uad_launch_colsum(dflat, n * ir * ir, m->cmid, Gr(m, m->bb), m->colscratch, sd);
-                uad_launch_bn_grad_finalize(cp, n, m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma), Gr(m, EL.beta), Gr(m, EL.b), sd);
+                uad_launch_bn_grad_finalize(cp, uad_bottleneck_colpart_rows(ba, n), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma), Gr(m, EL.beta), Gr(m, EL.b), sd);
             }
             float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;
             if (join_now) edge(m, sd, st);
