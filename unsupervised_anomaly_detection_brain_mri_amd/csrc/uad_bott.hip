@@ -261,8 +261,8 @@ __global__ void __launch_bounds__(NT) bottleneck_bwd_kernel(const UadBottArgs a)
     float* s_dd = s_g + Pq * C;      // [Fq]
     float* s_dz = s_dd + Fq;         // [2Z]     dmu | dls
     float* s_df = s_dz + 2 * Z;      // [Fq]     dflat
-    float* s_w = s_df + Fq;          // [C*M]
-    float* s_part = s_w + C * M;     // [NT]
+    float* s_w = s_df + Fq;          // [max(C*M, Pq*C)]
+    float* s_part = s_w + max(C * M, Pq * C);     // [NT]
     const size_t gb = ((size_t)n * P + p0) * C;
     for (int i = tid; i < Pq * C; i += NT) {
         const float v = a.dcb[gb + i];
@@ -271,7 +271,19 @@ __global__ void __launch_bounds__(NT) bottleneck_bwd_kernel(const UadBottArgs a)
     }
     // conv2d_1 kernel [M][C] staged transposed ([C][M]) so that it is the [K][O] operand of the data gradient
     for (int i = tid; i < C * M; i += NT) s_w[(i % C) * M + i / C] = a.Wr[i];
+    float* wp = a.wpart ? a.wpart + (size_t)blockIdx.x * (2 * C * M + M) : nullptr;      // [dWb (C x M) | dWr (M x C) | db_b (M)]
+    if (wp) for (int i = tid; i < Fq; i += NT) s_df[i] = a.dvec[(size_t)n * F + f0 + i];
     __syncthreads();
+    if (wp) {
+        // this workgroup's share of conv2d_1's kernel gradient: dWr[j][c] = sum_p dvec[p*M + j] * dcb[p][c] over its positions
+        for (int o = tid; o < M * C; o += NT) {
+            const int j = o / C, c = o % C;
+            float acc = 0.f;
+            for (int p = 0; p < Pq; ++p) acc = fmaf(s_df[p * M + j], s_g[p * C + c], acc);
+            wp[C * M + o] = acc;
+        }
+        __syncthreads();      // s_df is rewritten below
+    }
     // d dec_dense output: dd[p*M + j] = (sum_c dcb[p][c] * Wr[j][c]) * mask_dec
     conv1x1_tiled(s_g, s_w, Pq, C, M, tid, [&](int p, int o, const float4& v) {
         const int fl = p * M + o;
@@ -351,6 +363,125 @@ __global__ void __launch_bounds__(NT) bottleneck_bwd_kernel(const UadBottArgs a)
         a.colpart[((size_t)blockIdx.x * 2 + 0) * C + tid] = t1;      // rows: one per workgroup (uad_bottleneck_colpart_rows)
         a.colpart[((size_t)blockIdx.x * 2 + 1) * C + tid] = t2;
     }
+    if (wp) {
+        // this workgroup's share of conv2d's kernel / bias gradient: dWb[c][j] = sum_p h[p][c] * dflat[p*M + j], db_b[j] = sum_p dflat[p*M + j]
+        __syncthreads();
+        for (int i = tid; i < Pq * C; i += NT) {
+            const int c = i % C;
+            const float bn = fmaf(a.c_enc[gb + i], a.scale[c] * a.mult, a.shift[c]);
+            s_w[i] = bn > 0.f ? bn : bn * a.alpha;      // h (s_w holds max(C*M, Pq*C) floats: uad_bottleneck_lds_bytes)
+        }
+        __syncthreads();
+        for (int o = tid; o < C * M; o += NT) {
+            const int c = o / M, j = o % M;
+            float acc = 0.f;
+            for (int p = 0; p < Pq; ++p) acc = fmaf(s_w[p * C + c], s_df[p * M + j], acc);
+            wp[o] = acc;
+        }
+        if (tid < M) {
+            float acc = 0.f;
+            for (int p = 0; p < Pq; ++p) acc += s_df[p * M + tid];
+            wp[2 * C * M + tid] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// All parameter gradients of the dense bottleneck in ONE launch (they used to be 5 split-K GEMM launches + 4 column sums + their
+// reductions on the side stream: ~175 us there while it overlaps the encoder backward, and the critical path of that phase).
+//   part A  (K = batch):      dWd [Z][F] = z^T dd,  dWmu [F][Z] = t^T dmu,  dWsg [F][Z] = t^T dls,  bias gradients = column sums of
+//                             dd / dmu / dls; 32 x 64 output tiles, the whole batch staged in LDS in chunks of 64 samples
+//   part B  (K = batch * P):  dWb [C][M] = h^T dflat,  dWr [M][C] = dvec^T dcb,  db_b = column sums of dflat: every workgroup of the
+//                             backward kernel leaves its positions' share (it has dcb, dflat and the c_enc rows at hand), this kernel
+//                             sums the shares.
+// Deterministic: every sum runs in a fixed order.
+constexpr int WG_NT = 256, WG_TI = 32, WG_TJ = 64;
+
+__device__ __forceinline__ void wgrad_dense_tile(const float* __restrict__ A, int I, const float* __restrict__ B, int J, int n, int ti, int tj,
+                                                 float* __restrict__ out, float* __restrict__ dbias, float* sm) {
+    // out[i][j] = sum_s A[s][i] * B[s][j] for the tile (ti, tj); dbias[j] = sum_s B[s][j] (written by the ti == 0 tiles)
+    float* sA = sm;                      // [64][WG_TI]
+    float* sB = sm + 64 * WG_TI;         // [64][WG_TJ]
+    const int tid = threadIdx.x;
+    const int i0 = ti * WG_TI, j0 = tj * WG_TJ;
+    const int ip = tid / 16, jq = tid % 16;            // this thread: rows 2*ip, 2*ip+1; columns 4*jq .. 4*jq+3
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float bsum = 0.f;
+    for (int s0 = 0; s0 < n; s0 += 64) {
+        const int ns = min(64, n - s0);
+        __syncthreads();
+        for (int e = tid; e < 64 * WG_TI / 4; e += WG_NT) {
+            const int r = e / (WG_TI / 4), c4 = e % (WG_TI / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < ns) v = *reinterpret_cast<const float4*>(A + (size_t)(s0 + r) * I + i0 + c4 * 4);
+            *reinterpret_cast<float4*>(sA + r * WG_TI + c4 * 4) = v;
+        }
+        for (int e = tid; e < 64 * WG_TJ / 4; e += WG_NT) {
+            const int r = e / (WG_TJ / 4), c4 = e % (WG_TJ / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < ns) v = *reinterpret_cast<const float4*>(B + (size_t)(s0 + r) * J + j0 + c4 * 4);
+            *reinterpret_cast<float4*>(sB + r * WG_TJ + c4 * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
+            const float2 a2 = *reinterpret_cast<const float2*>(sA + r * WG_TI + 2 * ip);
+            const float4 b4 = *reinterpret_cast<const float4*>(sB + r * WG_TJ + 4 * jq);
+            acc[0][0] = fmaf(a2.x, b4.x, acc[0][0]); acc[0][1] = fmaf(a2.x, b4.y, acc[0][1]);
+            acc[0][2] = fmaf(a2.x, b4.z, acc[0][2]); acc[0][3] = fmaf(a2.x, b4.w, acc[0][3]);
+            acc[1][0] = fmaf(a2.y, b4.x, acc[1][0]); acc[1][1] = fmaf(a2.y, b4.y, acc[1][1]);
+            acc[1][2] = fmaf(a2.y, b4.z, acc[1][2]); acc[1][3] = fmaf(a2.y, b4.w, acc[1][3]);
+        }
+        if (ti == 0 && dbias && tid < WG_TJ)
+            for (int r = 0; r < 64; ++r) bsum += sB[r * WG_TJ + tid];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        *reinterpret_cast<float4*>(out + (size_t)(i0 + 2 * ip + e) * J + j0 + 4 * jq) = make_float4(acc[e][0], acc[e][1], acc[e][2], acc[e][3]);
+    if (ti == 0 && dbias && tid < WG_TJ) dbias[j0 + tid] = bsum;
+}
+
+__global__ void __launch_bounds__(WG_NT) bottleneck_wgrad_kernel(const UadBottWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x;
+    const int Z = a.zdim, F = a.npos * a.cmid, C = a.cenc, M = a.cmid;
+    int b = blockIdx.x;
+    // ---- part A ----
+    const int tiles_d = (Z / WG_TI) * (F / WG_TJ), tiles_h = (F / WG_TI) * (Z / WG_TJ);
+    if (b < tiles_d) { wgrad_dense_tile(a.z, Z, a.dd, F, a.n, b / (F / WG_TJ), b % (F / WG_TJ), a.gWd, a.gbd, sm); return; }
+    b -= tiles_d;
+    if (b < tiles_h) { wgrad_dense_tile(a.t, F, a.dmu, Z, a.n, b / (Z / WG_TJ), b % (Z / WG_TJ), a.gWmu, a.gbmu, sm); return; }
+    b -= tiles_h;
+    if (a.dls) {
+        if (b < tiles_h) { wgrad_dense_tile(a.t, F, a.dls, Z, a.n, b / (Z / WG_TJ), b % (Z / WG_TJ), a.gWsg, a.gbsg, sm); return; }
+        b -= tiles_h;
+    }
+    // ---- part B: out[o] = sum_w wpart[w][o] over the W partials the backward kernel left (fixed order): 64 outputs x 4 w-groups ----
+    const int PW = 2 * C * M + M;
+    const int ol = tid % 64, wg = tid / 64;
+    const int o = b * 64 + ol;
+    const int wper = (a.nparts + 3) / 4, w0 = wg * wper, w1 = min(w0 + wper, a.nparts);
+    float acc = 0.f;
+    if (o < PW) {
+        int w = w0;
+        for (; w + 16 <= w1; w += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = a.part[(size_t)(w + u) * PW + o];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; w < w1; ++w) acc += a.part[(size_t)w * PW + o];
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    if (wg == 0 && o < PW) {
+        const float t = (sm[ol] + sm[64 + ol]) + (sm[128 + ol] + sm[192 + ol]);
+        const int NOUT = C * M;
+        if (o < NOUT) a.gWb[o] = t;
+        else if (o < 2 * NOUT) a.gWr[o - NOUT] = t;
+        else a.gbb[o - 2 * NOUT] = t;
+    }
 }
 
 // out[c][r] = in[r][c]  (32x32 LDS tiles): transposed copies of the dense kernels for the backward's coalesced GEMVs
@@ -384,7 +515,7 @@ int uad_bottleneck_colpart_rows(const UadBottArgs& a, int n) { return n * uad_bo
 size_t uad_bottleneck_lds_bytes(const UadBottArgs& a, bool bwd) {
     const int Q = uad_bottleneck_group(a);
     const size_t PC = (size_t)a.npos / Q * a.cenc, F = (size_t)a.npos / Q * a.cmid, CM = (size_t)a.cenc * a.cmid;
-    return (bwd ? PC + F + 2 * a.zdim + F + CM + NT : PC + F + NT + a.zdim + F + CM) * sizeof(float);
+    return (bwd ? PC + F + 2 * a.zdim + F + (CM > PC ? CM : PC) + NT : PC + F + NT + a.zdim + F + CM) * sizeof(float);
 }
 bool uad_bottleneck_fused_ok(const UadBottArgs& a) {
     if (getenv("UAD_NO_FUSED_BOTT")) return false;
@@ -426,6 +557,19 @@ void uad_launch_bottleneck_bwd(const UadBottArgs& a, int n, hipStream_t st) {
     bott_attrs();
     if (uad_bottleneck_group(a) == 4) hipLaunchKernelGGL(bottleneck_bwd_kernel<4>, dim3(4 * n), dim3(NT), uad_bottleneck_lds_bytes(a, true), st, a);
     else hipLaunchKernelGGL(bottleneck_bwd_kernel<1>, dim3(n), dim3(NT), uad_bottleneck_lds_bytes(a, true), st, a);
+}
+bool uad_bottleneck_wgrad_ok(const UadBottWgradArgs& a) {
+    if (getenv("UAD_NO_FUSED_BOTT_WGRAD")) return false;
+    const int F = a.npos * a.cmid;
+    return a.part && a.nparts > 0 && a.zdim % WG_TJ == 0 && F % WG_TJ == 0;
+}
+size_t uad_bottleneck_wgrad_part_floats(const UadBottWgradArgs& a) { return (size_t)2 * a.cenc * a.cmid + a.cmid; }
+void uad_launch_bottleneck_wgrad(const UadBottWgradArgs& a, hipStream_t st) {
+    const int Z = a.zdim, F = a.npos * a.cmid;
+    const int tiles_d = (Z / WG_TI) * (F / WG_TJ), tiles_h = (F / WG_TI) * (Z / WG_TJ);
+    const int PW = (int)uad_bottleneck_wgrad_part_floats(a);
+    const int grid = tiles_d + tiles_h * (a.dls ? 2 : 1) + (PW + 63) / 64;
+    hipLaunchKernelGGL(bottleneck_wgrad_kernel, dim3(grid), dim3(WG_NT), (size_t)64 * (WG_TI + WG_TJ) * sizeof(float), st, a);
 }
 void uad_launch_transpose(const float* const* in, const int* R, const int* C, float* const* out, int njobs, hipStream_t st) {
     TransposeJobs jb;

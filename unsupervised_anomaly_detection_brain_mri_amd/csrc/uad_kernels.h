@@ -185,6 +185,7 @@ struct UadBottArgs {
     // backward
     const float* dcb;                    // [n, npos, cenc] d loss / d cb
     float* dcb_copy;                     // optional: the backward kernel leaves a copy of dcb here
+    float* wpart;                        // optional: per-workgroup shares of conv2d / conv2d_1's parameter gradients, [wg][2*C*M + M]
     // exchange between the workgroups of one sample (uad_bott.hip): partial vectors, completion flags, this launch's epoch
     float* xch; unsigned* flags; unsigned epoch; int xw;
     unsigned long long* stamps;          // debug (UAD_BOTT_DBG): phase clocks of workgroup 0
@@ -196,6 +197,19 @@ int uad_bottleneck_group(const UadBottArgs& a);                  // workgroups p
 int uad_bottleneck_colpart_rows(const UadBottArgs& a, int n);    // rows of colpart [rows][2][cenc] the backward writes
 void uad_launch_bottleneck_fwd(const UadBottArgs& a, int n, hipStream_t st);
 void uad_launch_bottleneck_bwd(const UadBottArgs& a, int n, hipStream_t st);
+// every parameter gradient of the dense bottleneck in one launch (uad_bott.hip); dls / gWsg / gbsg null: AE
+struct UadBottWgradArgs {
+    int n, cenc, cmid, npos, zdim;
+    float alpha, mult;
+    const float *z, *dd, *t, *dmu, *dls;                 // [n][Z], [n][F], [n][F], [n][Z], [n][Z]
+    const float *c_enc, *scale, *shift;                  // last encoder block (pre-BN) + its BN: h = lrelu(bn(c_enc)) on load
+    const float *dflat, *dvec, *dcb;                     // [n][F], [n][F], [n][P][C]
+    float *gWd, *gbd, *gWmu, *gbmu, *gWsg, *gbsg, *gWb, *gbb, *gWr;
+    const float* part; int nparts;                       // [nparts][2*C*M + M] shares of dWb | dWr | db_b left by the backward kernel
+};
+bool uad_bottleneck_wgrad_ok(const UadBottWgradArgs& a);
+size_t uad_bottleneck_wgrad_part_floats(const UadBottWgradArgs& a);
+void uad_launch_bottleneck_wgrad(const UadBottWgradArgs& a, hipStream_t st);
 // out_i[c][r] = in_i[r][c] for up to 3 matrices in one launch
 void uad_launch_transpose(const float* const* in, const int* R, const int* C, float* const* out, int njobs, hipStream_t st);
 

@@ -100,7 +100,8 @@ struct uad_model {
     // gradient ping-pong + small grads
     float *G0, *G1;
     float* dcb_keep;                  // copy of d loss / d cb for conv2d_1's kernel gradient (SIDE)
-    float* bott_xch; unsigned* bott_flags; unsigned bott_epoch;      // exchange of the fused bottleneck's workgroup groups
+    float* bott_xch; unsigned* bott_flags; unsigned bott_epoch;
+    float* bott_wpart;                // [4 * max_batch][2*cenc*cmid + cmid] shares of conv2d / conv2d_1's parameter gradients
     float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
     // scratch
     float *colpart, *wpartial, *colscratch, *red_partial, *rec_partial, *rec_ps, *scalars_own;
@@ -423,6 +424,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->dcb_keep, NB * ir * ir * m->cenc);
     ALLOC(m->bott_xch, NB * 4 * 2 * (size_t)cfg->zdim);
     { float* fl = nullptr; ALLOC(fl, NB * 4); m->bott_flags = reinterpret_cast<unsigned*>(fl); m->bott_epoch = 0; }
+    ALLOC(m->bott_wpart, NB * 4 * (2 * (size_t)m->cenc * m->cmid + m->cmid));
     // column-partial scratch: worst case 64-row tiles
     size_t cp = 0;
     auto cp_need = [&](size_t rows, int classes, int C) { size_t v = ((rows + 63) / 64) * classes * 2 * C; if (v > cp) cp = v; };
@@ -853,12 +855,27 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
             // MAIN: one workgroup per sample does the whole data-gradient chain.  SIDE: the parameter-gradient GEMMs, from the vectors
             // it leaves behind (one edge, no wait of MAIN on SIDE).
             ba.dcb = dcb; ba.dd = dd; ba.dmu = vae ? dmu : dz; ba.dls = dls; ba.dflat = dflat; ba.g_out = m->G1; ba.colpart = cp;
+            ba.wpart = pg ? m->bott_wpart : nullptr;      // shares of conv2d / conv2d_1's parameter gradients, summed by the SIDE kernel
             ba.dcb_copy = pg ? m->dcb_keep : nullptr;     // conv2d_1's kernel gradient reads this copy on SIDE: dcb's buffer becomes encoder scratch
             ba.epoch = ++m->bott_epoch;
             { PROF("bott.bwd"); uad_launch_bottleneck_bwd(ba, n, st); }
             edge(m, st, sd);
-            static const bool skipw = getenv("UAD_DBG_SKIP_BOTT_WGRAD") != nullptr;      // timing experiment only
-            if (pg && !skipw) {
+            UadBottWgradArgs wa;
+            memset(&wa, 0, sizeof wa);
+            wa.n = n; wa.cenc = m->cenc; wa.cmid = m->cmid; wa.npos = ir * ir; wa.zdim = zd; wa.alpha = kLrelu; wa.mult = rstd;
+            wa.z = m->z; wa.dd = dd; wa.t = m->t; wa.dmu = vae ? dmu : dz; wa.dls = vae ? dls : nullptr;
+            wa.c_enc = EL.c; wa.scale = P(m, EL.gamma); wa.shift = P(m, EL.beta);
+            wa.dflat = dflat; wa.dvec = m->dvec; wa.dcb = m->dcb_keep;
+            wa.gWd = Gr(m, m->dw); wa.gbd = Gr(m, m->db); wa.gWmu = Gr(m, m->muw); wa.gbmu = Gr(m, m->mub);
+            if (vae) { wa.gWsg = Gr(m, m->sgw); wa.gbsg = Gr(m, m->sgb); }
+            wa.gWb = Gr(m, m->bw); wa.gbb = Gr(m, m->bb); wa.gWr = Gr(m, m->rw);
+            wa.part = m->bott_wpart; wa.nparts = uad_bottleneck_colpart_rows(ba, n);
+            if (pg && uad_bottleneck_wgrad_ok(wa)) {
+                // SIDE: every parameter gradient of the segment in one launch (+ the last encoder block's BN finalize)
+                PROF_ON("bott.wgrad", sd);
+                uad_launch_bottleneck_wgrad(wa, sd);
+                uad_launch_bn_grad_finalize(cp, uad_bottleneck_colpart_rows(ba, n), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma), Gr(m, EL.beta), Gr(m, EL.b), sd);
+            } else if (pg) {
                 PROF_ON("bott.wgrad", sd);
                 uad_launch_conv_w(d_r, m->dvec, no_xform(), m->dcb_keep, no_xform(), Gr(m, m->rw), wp, sd);
                 uad_launch_conv_w(d_dec, m->z, no_xform(), dd, no_xform(), Gr(m, m->dw), wp, sd);
