@@ -118,8 +118,10 @@ void uad_launch_conv_w_reduce(const UadConvDesc& d, float* dW, float* partial, h
 // out[j] = scale * sum_{s<S} partial[s*L + j]
 void uad_launch_reduce_partials(const float* partial, int S, int L, float scale, float* out, hipStream_t st);
 // dbeta = S1, dgamma = rstd*S2, dbias = gamma*rstd*S1 with S1,S2 = sum over T tiles of colpart[t][0/1][c]
+// scratch (optional, uad_bn_grad_finalize_scratch_floats(C) zero-initialised floats, one per stream): tile ranges in parallel
 void uad_launch_bn_grad_finalize(const float* colpart, int T, int C, const float* gamma, float rstd,
-                                 float* dgamma, float* dbeta, float* dbias, hipStream_t st);
+                                 float* dgamma, float* dbeta, float* dbias, hipStream_t st, float* scratch = nullptr);
+size_t uad_bn_grad_finalize_scratch_floats(int C);
 // out[c] = sum_rows g[row][c]
 void uad_launch_colsum(const float* g, int rows, int C, float* out, float* scratch, hipStream_t st);
 size_t uad_colsum_scratch_floats(int rows, int C);

@@ -69,6 +69,55 @@ __global__ void __launch_bounds__(1024) bn_grad_finalize_kernel(const float* __r
     }
 }
 
+// The same over a 2-D grid: block (bx, by) sums the tile range `by` of 32 channels, the last block to arrive per channel group (agent-scope
+// counter) adds the NB partials in a fixed order and finalizes.  One block walking T = 2048 tiles took 8 us alone and 20-60 us squeezed
+// between the heavy kernels on the side stream.  scratch: [64 counters | (C/32) x NB x 64 partials]; partials and counter move through
+// relaxed agent-scope atomics (the blocks sit on different XCDs; a release fence would write back the whole L2).
+__global__ void __launch_bounds__(1024) bn_grad_finalize2_kernel(const float* __restrict__ colpart, int T, int C,
+                                                                 const float* __restrict__ gamma, float rstd,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ dbias, float* scratch) {
+    __shared__ float red[2][32][33];
+    __shared__ int s_last;
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int NB = gridDim.y, by = blockIdx.y;
+    const int tper = (T + NB - 1) / NB, t0 = by * tper, t1 = min(t0 + tper, T);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C)
+        for (int t = t0 + g; t < t1; t += 32) {
+            s1 += colpart[((size_t)t * 2 + 0) * C + c];
+            s2 += colpart[((size_t)t * 2 + 1) * C + c];
+        }
+    red[0][g][cl] = s1;
+    red[1][g][cl] = s2;
+    __syncthreads();
+    unsigned* cnt = reinterpret_cast<unsigned*>(scratch) + blockIdx.x;
+    float* part = scratch + 64 + ((size_t)blockIdx.x * NB) * 64;
+    if (g < 2) {
+        float a = 0.f;
+        for (int k = 0; k < 32; ++k) a += red[g][k][cl];
+        __hip_atomic_store(part + by * 64 + g * 32 + cl, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(NB - 1));
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    if (g == 0 && c < C) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int k = 0; k < NB; ++k) {
+            a1 += __hip_atomic_load(part + k * 64 + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a2 += __hip_atomic_load(part + k * 64 + 32 + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (dbeta) dbeta[c] = a1;
+        if (dgamma) dgamma[c] = a2 * rstd;
+        if (dbias) dbias[c] = gamma[c] * rstd * a1;
+    }
+}
+
 // scratch[rchunk][C] partial column sums; block = 32 channels x 8 row-lanes
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g, int rows, int C, int rows_per_chunk,
                                                      float* __restrict__ out) {
@@ -798,8 +847,14 @@ void uad_launch_reduce_partials(const float* partial, int S, int L, float scale,
         hipLaunchKernelGGL((reduce_partials_kernel<16>), dim3(blocks), dim3(1024), 0, st, partial, S, L, scale, out);
 }
 
+size_t uad_bn_grad_finalize_scratch_floats(int C) { return 64 + (size_t)((C + 31) / 32) * 32 * 64; }
 void uad_launch_bn_grad_finalize(const float* colpart, int T, int C, const float* gamma, float rstd, float* dgamma,
-                                 float* dbeta, float* dbias, hipStream_t st) {
+                                 float* dbeta, float* dbias, hipStream_t st, float* scratch) {
+    const int NB = T >= 2048 ? 32 : T >= 512 ? 16 : T >= 128 ? 8 : 1;
+    if (scratch && NB > 1 && (C + 31) / 32 <= 64) {
+        hipLaunchKernelGGL(bn_grad_finalize2_kernel, dim3((C + 31) / 32, NB), dim3(1024), 0, st, colpart, T, C, gamma, rstd, dgamma, dbeta, dbias, scratch);
+        return;
+    }
     hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, colpart, T, C, gamma, rstd,
                        dgamma, dbeta, dbias);
 }

@@ -101,6 +101,7 @@ struct uad_model {
     float *G0, *G1;
     float* dcb_keep;                  // copy of d loss / d cb for conv2d_1's kernel gradient (SIDE)
     float* bott_xch; unsigned* bott_flags; unsigned bott_epoch;
+    float* bnfin_scratch;             // counters + partials of the 2-D BN-gradient finalize (SIDE stream only)
     float* bott_wpart;                // [4 * max_batch][2*cenc*cmid + cmid] shares of conv2d / conv2d_1's parameter gradients
     float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
     // scratch
@@ -424,6 +425,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->dcb_keep, NB * ir * ir * m->cenc);
     ALLOC(m->bott_xch, NB * 4 * 2 * (size_t)cfg->zdim);
     { float* fl = nullptr; ALLOC(fl, NB * 4); m->bott_flags = reinterpret_cast<unsigned*>(fl); m->bott_epoch = 0; }
+    ALLOC(m->bnfin_scratch, uad_bn_grad_finalize_scratch_floats(512));
     ALLOC(m->bott_wpart, NB * 4 * (2 * (size_t)m->cenc * m->cmid + m->cmid));
     // column-partial scratch: worst case 64-row tiles
     size_t cp = 0;
@@ -816,7 +818,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
             hipMemcpyAsync(Gr(m, m->fb), m->colscratch + 3 * C, sizeof(float), hipMemcpyDeviceToDevice, sd);
             uad_launch_bn_grad_finalize(m->colscratch + C, 1, C, P(m, DL.gamma), rstd, Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), sd);
         }
-        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd); }
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
@@ -1020,7 +1022,7 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
         edge(m, st, sd);
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd);
                   uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
-                                    Gr(m, PL.beta), Gr(m, PL.b), sd); }
+                                    Gr(m, PL.beta), Gr(m, PL.b), sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
     }
     UadConvDesc d0 = m->enc[0].d; d0.N = n;
