@@ -178,7 +178,7 @@ def test_dense_and_1x1_all_three_kernels(rows, K, Nout):
     assert_close(dw.cpu().numpy(), x.T @ g, name='dense wgrad')
 
 
-@pytest.mark.parametrize('N,H,Cout', [(2, 16, 32), (3, 128, 32), (1, 10, 64)])
+@pytest.mark.parametrize('N,H,Cout', [(2, 16, 32), (3, 128, 32), (1, 10, 64), (5, 64, 32), (2, 256, 32), (64, 128, 32)])
 def test_conv_first_fwd_and_wgrad(N, H, Cout):
     rng = np.random.default_rng(8)
     x = rng.uniform(0, 1, (N, H, H, 1)); w = rng.standard_normal((5, 5, 1, Cout)) / 5; b = rng.standard_normal(Cout)

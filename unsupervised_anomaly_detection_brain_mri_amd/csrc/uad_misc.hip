@@ -275,6 +275,143 @@ __global__ void __launch_bounds__(256) conv_first_wgrad_kernel(UadConvDesc d, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// First layer in the shape every graph of the reference has: 1 input channel, k5 s2 SAME (pad 1 before, 2 after), 32 filters
+// (models/autoencoder.py:13-14 via customlayers.build_unified_encoder :8-17).  The generic kernels above are LDS-issue-bound there
+// (forward: 15 LDS reads per 40 FMAs, 24 us; filter gradient: 1 LDS read per FMA, 26 us -- for 37 MB of traffic each).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// forward: block = OR output rows x WS pixels x 32 channels; thread = 4 adjacent pixels x 8 channels of one row.  Per kernel row three
+// 16-byte reads fetch the 12 input columns the 4 pixels touch and ten fetch the 5 x 8 weights: 13 reads per 160 FMAs (packed pairs).
+template <int WS>
+__global__ void __launch_bounds__(256) conv_first_fwd32_kernel(UadConvDesc d, const float* __restrict__ x, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, float* __restrict__ out) {
+    constexpr int OR = 256 / WS, IR = 2 * OR + 3, XW = 2 * WS + 4;
+    __shared__ __attribute__((aligned(16))) float ws[25 * 32];
+    __shared__ __attribute__((aligned(16))) float xs[IR * XW];      // column xx holds input column xx - 1
+    const int tid = threadIdx.x;
+    const int q = tid & 3, pg = (tid >> 2) % (WS / 4), rl = tid / WS;
+    const int bpi = d.HS / OR;
+    const int n = blockIdx.x / bpi, oy0 = (blockIdx.x % bpi) * OR;
+    for (int i = tid; i < 25 * 32; i += 256) ws[i] = W[i];
+    for (int i = tid; i < IR * XW; i += 256) {
+        const int r = i / XW, xx = i % XW;
+        const int iy = 2 * oy0 - 1 + r, ix = xx - 1;
+        xs[i] = ((unsigned)iy < (unsigned)d.HB && (unsigned)ix < (unsigned)d.WB) ? x[((size_t)n * d.HB + iy) * d.WB + ix] : 0.f;
+    }
+    __syncthreads();
+    v2f acc[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const v2f b = bias ? v2f{bias[q * 8 + 2 * e], bias[q * 8 + 2 * e + 1]} : v2f{0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][e] = b;
+    }
+    const float* xr0 = xs + (2 * rl) * XW + 8 * pg;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        float xv[12];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(xv + 4 * k) = *reinterpret_cast<const float4*>(xr0 + ky * XW + 4 * k);
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const float4 w0 = *reinterpret_cast<const float4*>(ws + (ky * 5 + kx) * 32 + q * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(ws + (ky * 5 + kx) * 32 + q * 8 + 4);
+            const v2f w[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v2f xx = {xv[2 * j + kx], xv[2 * j + kx]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_elementwise_fma(xx, w[e], acc[j][e]);
+            }
+        }
+    }
+    float* o = out + (((size_t)n * d.HS + oy0 + rl) * WS + 4 * pg) * 32 + q * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<float4*>(o + j * 32) = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+        *reinterpret_cast<float4*>(o + j * 32 + 4) = make_float4(acc[j][2].x, acc[j][2].y, acc[j][3].x, acc[j][3].y);
+    }
+}
+
+// filter gradient: thread = 4 channels x one of 32 pixel lanes, 25 x 4 accumulators: one 16-byte gradient load and 25 LDS reads per
+// 100 FMAs (packed pairs).  A block takes RPB consecutive output rows of ONE sample (RPB divides HS): their 2 RPB + 3 input rows are
+// staged once, the gradient loads of the next row pair are in flight while the current pair is accumulated.  The pixel lanes are
+// folded with shuffles inside the wave, then across the 4 waves through LDS, in a fixed order; one partial [25][32] per block, summed
+// by reduce_partials.
+template <int WS>
+__global__ void __launch_bounds__(256) conv_first_wgrad32_kernel(UadConvDesc d, const float* __restrict__ x, const float* __restrict__ g,
+                                                                 int RPB, float* __restrict__ partial) {
+    constexpr int XW = 2 * WS + 4, NP = WS / 32, MAXR = 16;
+    __shared__ __attribute__((aligned(16))) float xs[(2 * MAXR + 3) * XW];
+    __shared__ __attribute__((aligned(16))) float red[4][25 * 32];
+    const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
+    const int row0 = blockIdx.x * RPB;                 // n * HS + oy0
+    const int n = row0 / d.HS, oy0 = row0 % d.HS;
+    for (int i = tid; i < (2 * RPB + 3) * XW; i += 256) {
+        const int r = i / XW, xx = i % XW;
+        const int iy = 2 * oy0 - 1 + r, ix = xx - 1;
+        xs[i] = ((unsigned)iy < (unsigned)d.HB && (unsigned)ix < (unsigned)d.WB) ? x[((size_t)n * d.HB + iy) * d.WB + ix] : 0.f;
+    }
+    v2f acc[25][2];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) { acc[t][0] = v2f{0.f, 0.f}; acc[t][1] = v2f{0.f, 0.f}; }
+    const float* gb = g + ((size_t)row0 * WS + pl) * 32 + cq * 4;
+    float4 cur[2][NP], nxt[2][NP];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) cur[r][k] = *reinterpret_cast<const float4*>(gb + ((size_t)r * WS + k * 32) * 32);
+    __syncthreads();
+    for (int rp = 0; rp < RPB; rp += 2) {
+        if (rp + 2 < RPB) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < NP; ++k) nxt[r][k] = *reinterpret_cast<const float4*>(gb + ((size_t)(rp + 2 + r) * WS + k * 32) * 32);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const float* xr = xs + 2 * (rp + r) * XW + 2 * (k * 32 + pl);
+                const v2f g0 = {cur[r][k].x, cur[r][k].y}, g1 = {cur[r][k].z, cur[r][k].w};
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const float xv = xr[ky * XW + kx];
+                        const v2f xx = {xv, xv};
+                        acc[ky * 5 + kx][0] = __builtin_elementwise_fma(xx, g0, acc[ky * 5 + kx][0]);
+                        acc[ky * 5 + kx][1] = __builtin_elementwise_fma(xx, g1, acc[ky * 5 + kx][1]);
+                    }
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) cur[r][k] = nxt[r][k];
+    }
+    // fold the 8 pixel lanes of this wave (lane = cq + 8 * (pl & 7)), then the 4 waves
+#pragma unroll
+    for (int t = 0; t < 25; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float a = acc[t][h].x, b = acc[t][h].y;
+            a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
+            a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+            a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+            acc[t][h] = v2f{a, b};
+        }
+    const int wave = tid >> 6;
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int t = 0; t < 25; ++t)
+            *reinterpret_cast<float4*>(&red[wave][t * 32 + cq * 4]) = make_float4(acc[t][0].x, acc[t][0].y, acc[t][1].x, acc[t][1].y);
+    }
+    __syncthreads();
+    for (int i = tid; i < 25 * 32; i += 256) partial[(size_t)blockIdx.x * 800 + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Final 1x1 conv (C -> 1) + L1 loss, fused with its backward.  C/4 lanes per pixel (float4 of channels each).
 // reference: models/customlayers.py:37 (dec_Conv2D_final), trainers/VAE.py:36-37,40
 // ------------------------------------------------------------------------------------------------
@@ -877,17 +1014,33 @@ void uad_launch_colsum(const float* g, int rows, int C, float* out, float* scrat
     }
 }
 
+// the specialised first-layer kernels: 1 -> 32 channels, k5 s2 SAME on an even square-ish grid
+static inline bool first32_ok(const UadConvDesc& d) {
+    static const bool off = getenv("UAD_NO_FIRST32") != nullptr;
+    return !off && d.CB == 1 && d.CS == 32 && d.KS == 5 && d.S == 2 && d.P == 1 && d.HB == 2 * d.HS && d.WB == 2 * d.WS &&
+           (d.WS == 32 || d.WS == 64 || d.WS == 128) && d.HS % 8 == 0;
+}
 void uad_launch_conv_first_fwd(const UadConvDesc& d, const float* x, const float* W, const float* bias, float* out,
                                hipStream_t st) {
     const int tpp = d.CS / 8, ppb = 256 / tpp;
     const int xw = d.S * ppb + d.KS;
     const size_t lds = ((size_t)d.KS * d.KS * d.CB * d.CS + (size_t)d.KS * xw * d.CB) * sizeof(float);
     const int bpr = (d.WS + ppb - 1) / ppb;
+    if (first32_ok(d)) {
+        if (d.WS == 32) hipLaunchKernelGGL(conv_first_fwd32_kernel<32>, dim3(d.N * d.HS / 8), dim3(256), 0, st, d, x, W, bias, out);
+        else if (d.WS == 64) hipLaunchKernelGGL(conv_first_fwd32_kernel<64>, dim3(d.N * d.HS / 4), dim3(256), 0, st, d, x, W, bias, out);
+        else hipLaunchKernelGGL(conv_first_fwd32_kernel<128>, dim3(d.N * d.HS / 2), dim3(256), 0, st, d, x, W, bias, out);
+        return;
+    }
     hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(d.N * d.HS * bpr), dim3(256), lds, st, d, x, W, bias, out);
 }
 
 static inline int first_wgrad_rows_per_block(const UadConvDesc& d) {
     const int total = d.N * d.HS;
+    if (first32_ok(d)) {              // 4, 8 or 16 rows of one sample per block (the fold of the pixel lanes costs as much as ~3 rows)
+        const int want = (total + 511) / 512;
+        return (want > 8 && d.HS % 16 == 0) ? 16 : want > 4 ? 8 : 4;
+    }
     int rpb = (total + 1023) / 1024;
     return rpb < 1 ? 1 : rpb;
 }
@@ -905,7 +1058,11 @@ void uad_launch_conv_first_wgrad(const UadConvDesc& d, const float* x, const flo
     const int xw = d.WB + d.KS + d.S;
     size_t lds_x = (size_t)4 * d.KS * xw * d.CB, lds_r = (size_t)G * ntap * d.CS;
     const size_t lds = (lds_x > lds_r ? lds_x : lds_r) * sizeof(float);
-    if (d.KS == 5 && d.CB == 1)
+    if (first32_ok(d)) {
+        if (d.WS == 32) hipLaunchKernelGGL(conv_first_wgrad32_kernel<32>, dim3(blocks), dim3(256), 0, st, d, x, g, rpb, partial);
+        else if (d.WS == 64) hipLaunchKernelGGL(conv_first_wgrad32_kernel<64>, dim3(blocks), dim3(256), 0, st, d, x, g, rpb, partial);
+        else hipLaunchKernelGGL(conv_first_wgrad32_kernel<128>, dim3(blocks), dim3(256), 0, st, d, x, g, rpb, partial);
+    } else if (d.KS == 5 && d.CB == 1)
         hipLaunchKernelGGL((conv_first_wgrad_kernel<5, 1>), dim3(blocks), dim3(256), lds, st, d, x, g, rpb, partial);
     else if (d.KS == 5 && d.CB == 3)
         hipLaunchKernelGGL((conv_first_wgrad_kernel<5, 3>), dim3(blocks), dim3(256), lds, st, d, x, g, rpb, partial);
