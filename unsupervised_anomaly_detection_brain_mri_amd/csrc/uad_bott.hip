@@ -31,8 +31,9 @@ __device__ __forceinline__ void conv1x1_tiled(const float* s_in, const float* s_
     for (int it = tid >> 2; it < P * OQ; it += NT / 4) {
         const int p = it / OQ, oq = it % OQ;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int kper = K / 4, k0 = kq * kper;
-        for (int k = k0; k < k0 + kper; ++k) {
+        // the 4 lanes of a quad take k = kq, kq + 4, ...: their s_in words sit in adjacent banks and their s_w rows in different ones
+        // (contiguous K quarters put all 64 lanes of a wave on one bank: a 16-way conflict on every read)
+        for (int k = kq; k < K; k += 4) {
             const float x = s_in[p * K + k];
             const float4 w = *reinterpret_cast<const float4*>(s_w + k * O + oq * 4);
             acc.x = fmaf(x, w.x, acc.x); acc.y = fmaf(x, w.y, acc.y); acc.z = fmaf(x, w.z, acc.z); acc.w = fmaf(x, w.w, acc.w);

@@ -816,6 +816,32 @@ __device__ __forceinline__ void split_bf16(float4 v, uint2& hi, uint2& lo) {
     lo.x = cvt_pk_bf16(rx, ry);
     lo.y = cvt_pk_bf16(rz, rw);
 }
+// 16-byte load through a buffer descriptor: wave-uniform base (descriptor) + wave-uniform byte offset (SGPR) + 32-bit per-lane byte
+// offset.  The flat form spends a 64-bit VALU add per load on the same address.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_bytes, (int)uniform_bytes, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Butterfly over 8 consecutive lanes with DPP (one VALU op per step instead of a ds_bpermute round trip through the LDS unit): swap
+// inside pairs, swap pairs inside quads, mirror the half row.  Every lane ends with the same value as the xor-shuffle butterfly (the
+// operands of each add / or are the same pair, the operations commute).
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += __uint_as_float(dpp_u32<0xB1>(__float_as_uint(v)));       // quad_perm [1,0,3,2]
+    v += __uint_as_float(dpp_u32<0x4E>(__float_as_uint(v)));       // quad_perm [2,3,0,1]
+    v += __uint_as_float(dpp_u32<0x141>(__float_as_uint(v)));      // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ unsigned or8_dpp(unsigned v) {
+    v |= dpp_u32<0xB1>(v);
+    v |= dpp_u32<0x4E>(v);
+    v |= dpp_u32<0x141>(v);
+    return v;
+}
+
 // Compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
 template <int I0, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -1483,13 +1509,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     constexpr int NUNIT = 25 * NCH;
     const uint4* wq = reinterpret_cast<const uint4*>(a.Wp16) + (size_t)lh * Nn + colc;
     BFrag16<2> b0, b1, b2, b3;
+    // wave-uniform base (SGPR pair, scalar arithmetic) + one 32-bit per-lane offset: no 64-bit VALU add per load
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.Wp16), 0, 0xffffffff, 0x00020000);
+    const unsigned lb = (unsigned)(lh * Nn + colc) * 16u;      // byte offsets, 32 bits: the packed weights of a layer are < 4 GB
+    const unsigned plane_b = (unsigned)plane_q * 16u;
     auto loadB = [&](BFrag16<2>& b, int unit) __attribute__((always_inline)) {
         const int tap = kTapOrderD.tap[unit / NCH], c0 = cbase + (unit % NCH) * 32;
-        const uint4* w = wq + ((size_t)tap * (CA / 8) + c0 / 8) * Nn;
+        const unsigned u = (unsigned)((tap * (CA / 8) + c0 / 8) * Nn) * 16u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            b.hi[j] = w[(size_t)(2 * j) * Nn];
-            b.lo[j] = w[(size_t)(2 * j) * Nn + plane_q];
+            b.hi[j] = buf_load16(wrs, lb, u + (unsigned)(2 * j * Nn) * 16u);
+            b.lo[j] = buf_load16(wrs, lb, u + (unsigned)(2 * j * Nn) * 16u + plane_b);
         }
     };
     auto loadA = [&](BFrag16<2>& f, int unit) __attribute__((always_inline)) {
@@ -1621,17 +1651,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
                     av[e] = bn[e] > 0.f ? bn[e] : bn[e] * a.ep.ealpha;
                     dot = fmaf(av[e], wv[e], dot);
                 }
-                dot += __shfl_xor(dot, 1);
-                dot += __shfl_xor(dot, 2);
-                dot += __shfl_xor(dot, 4);
+                dot = sum8_dpp(dot);
                 const float xh = dot + f_bf;
                 const float diff = xh - xin[k];
-                if ((lane & 7) == 0) {
-                    s_fo[lidx[k]] = xh;                 // written to HBM as coalesced rows after the last class
-                    s_fl[lidx[k]] = fabsf(diff);
-                    rec += fabsf(diff);
-                }
+                // all 8 lanes of the pixel hold the same xh / diff: lanes 0..3 of the group each store one of the four per-pixel values
+                // (x_hat, |diff|, pattern word, sign), the running sums are kept in every lane and read from lane 0 of the group
+                rec += fabsf(diff);
                 if (a.Out) *reinterpret_cast<float4*>(a.Out + off[k]) = make_float4(cc[0], cc[1], cc[2], cc[3]);
+                unsigned pw = 0u;
+                float sg = 0.f;
                 if (a.ep.fin_dc || a.ep.fin_bits) {
                     const float sgn = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * a.ep.fin_inv_batch;
                     float dc[4];
@@ -1648,13 +1676,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
                         nib |= (pos ? 1u : 0u) << e;
                     }
                     if (a.ep.fin_dc) *reinterpret_cast<float4*>(a.ep.fin_dc + off[k]) = make_float4(dc[0], dc[1], dc[2], dc[3]);
-                    if (a.ep.fin_bits) {
-                        // d loss / d c of this pixel = sgn * w_f[ch] * (bit ? 1 : alpha) * scale[ch]: one word + one float instead of 32 floats
-                        unsigned w = nib << ecol;
-                        w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
-                        if ((lane & 7) == 0) { s_fb[lidx[k]] = w; s_fg[lidx[k]] = sgn; }
-                    }
-                    if ((lane & 7) == 0) dbf += sgn;
+                    // d loss / d c of this pixel = sgn * w_f[ch] * (bit ? 1 : alpha) * scale[ch]: one word + one float instead of 32 floats
+                    pw = or8_dpp(nib << ecol);
+                    sg = sgn;
+                    dbf += sgn;
+                }
+                {
+                    const int role = lane & 3;
+                    const float val = role == 0 ? xh : role == 1 ? fabsf(diff) : role == 2 ? __uint_as_float(pw) : sg;
+                    if ((lane & 4) == 0) s_fo[role * (4 * TH * TW) + lidx[k]] = val;      // s_fo | s_fl | s_fb | s_fg are adjacent
                 }
             }
         } else if (!bwd) {
@@ -1854,14 +1884,19 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     const int nchunks = min(CA / CK, ch0 + cper);
 
     BFrag16<NKS> b0, b1, b2, b3, a0, a1;
+    // wave-uniform base (SGPR pair, scalar arithmetic) + one 32-bit per-lane offset: no 64-bit VALU add per load
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.Wp16), 0, 0xffffffff, 0x00020000);
+    const unsigned lb = (unsigned)(wq - reinterpret_cast<const uint4*>(a.Wp16)) * 16u;      // byte offsets, 32 bits: the packed weights of a layer are < 4 GB
+    const unsigned plane_b = (unsigned)plane_q * 16u;
     auto loadB = [&](BFrag16<NKS>& b, int tap, int c0) {
-        const uint4* w = wq + ((size_t)tap * (CA / 8) + c0 / 8) * Nn;
+        const unsigned u = (unsigned)((tap * (CA / 8) + c0 / 8) * Nn) * 16u;
 #pragma unroll
         for (int j = 0; j < NKS; ++j) {
-            b.hi[j] = w[(size_t)(2 * j) * Nn];
-            b.lo[j] = w[(size_t)(2 * j) * Nn + plane_q];
+            b.hi[j] = buf_load16(wrs, lb, u + (unsigned)(2 * j * Nn) * 16u);
+            b.lo[j] = buf_load16(wrs, lb, u + (unsigned)(2 * j * Nn) * 16u + plane_b);
         }
     };
+
     auto loadA = [&](BFrag16<NKS>& f, int tap) {
         const int toff = ((tap / 5) * IW + (tap % 5)) * LDH;
 #pragma unroll
@@ -1945,13 +1980,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             *reinterpret_cast<uint2*>(sLo + pix * LDH + cq * 4) = lo;
         }
     };
+    unsigned long long* stp = (a.dbgbuf && lane == 0 && blockIdx.y == 1 && blockIdx.z == 0 && blockIdx.x < 8) ? a.dbgbuf + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
+    if (stp) stp[0] = wall_clock64();
     issue_stage(ch0 * CK);
     for (int ch = ch0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
         if (ch > ch0) __syncthreads();
         convert_stage(c0);
+        if (stp && ch == ch0) stp[1] = wall_clock64();
         if (ch + 1 < nchunks) issue_stage(c0 + CK);
         __syncthreads();
+        if (stp && ch == ch0) stp[2] = wall_clock64();
         loadA(a0, 0);
         const bool more = ch + 1 < nchunks;
         auto unit = [&](const BFrag16<NKS>& bc, BFrag16<NKS>& bpf, const BFrag16<NKS>& ac, BFrag16<NKS>& an, const int t) {
@@ -1977,8 +2016,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         b0 = b1; b1 = b2; b2 = b3;
     }
 
+    if (stp) stp[3] = wall_clock64();
     // ---- epilogue: transpose through a wave-private LDS tile, 16-byte accesses (see conv5_d16_kernel) ----
-    __syncthreads();                                   // every wave is done with the activation tile
+    __syncthreads();
+    if (stp) stp[4] = wall_clock64();                                   // every wave is done with the activation tile
     constexpr int EPI_LD = 36;
     static_assert((size_t)WGM * WGN * 32 * EPI_LD * 4 <= (size_t)2 * IH * IW * LDH * 2, "epilogue tile fits in the activation tile");
     const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
@@ -2004,7 +2045,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         float* slab = a.Out + (size_t)split * a.out_elems;
 #pragma unroll
         for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(slab + off[k]) = v[k];
-        return;
+        { if (stp) stp[5] = wall_clock64(); return; }
     }
     if (!bwd) {
         float4 e_a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2017,7 +2058,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             if (a.ep.add) { const float4 q = *reinterpret_cast<const float4*>(a.ep.add + off[k]); t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
             *reinterpret_cast<float4*>(a.Out + off[k]) = t;
         }
-        return;
+        { if (stp) stp[5] = wall_clock64(); return; }
     }
     float4 e_a = *reinterpret_cast<const float4*>(a.ep.escale + ecol);
     e_a.x *= a.ep.emult; e_a.y *= a.ep.emult; e_a.z *= a.ep.emult; e_a.w *= a.ep.emult;
@@ -2060,12 +2101,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
         if (n0 + c < Nn) a.ep.colpart[(tile * 2 + which) * Nn + n0 + c] = t;
     }
+    if (stp) stp[5] = wall_clock64();
 }
 
 template <int TH, int TW, int CK, int WGM, int WGN>
 constexpr size_t conv5_f16_lds_bytes() {
     return (size_t)2 * (2 * TH + 3) * (2 * TW + 3) * (CK + 8) * 2 + (size_t)3 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
 }
+
 template <int TH, int TW, int CK, int WGM, int WGN, int FB>
 void launch_conv5_f16_v(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = conv5_f16_lds_bytes<TH, TW, CK, WGM, WGN>();
@@ -3298,7 +3341,9 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
     { static const int dbg = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0; a.dbg = dbg; a.dbgbuf = nullptr; }
     static unsigned long long* dbgbuf = nullptr;
     static int dbg_calls = 0;
-    const bool dbg_this = (a.dbg & 8) && !f_type && a.Wp16 && a.Nn == 32 && a.CA == 32 && dbg_calls < 3;
+    const bool dbg_f = (a.dbg & 16) && f_type && a.Wp16 && a.Nn == 64 && a.CA == 32 && dbg_calls >= 40 && dbg_calls < 44;
+    if ((a.dbg & 16) && f_type && a.Wp16 && a.Nn == 64 && a.CA == 32 && !dbg_f) ++dbg_calls;
+    const bool dbg_this = dbg_f || ((a.dbg & 8) && !f_type && a.Wp16 && a.Nn == 32 && a.CA == 32 && dbg_calls < 3);
     if (dbg_this) {
         if (!dbgbuf) (void)hipMalloc((void**)&dbgbuf, 8 * 4 * 16 * sizeof(unsigned long long));
         (void)hipMemsetAsync(dbgbuf, 0, 8 * 4 * 16 * sizeof(unsigned long long), st);
@@ -3308,6 +3353,7 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
         ~DbgDump() { if (!on) return; (void)hipStreamSynchronize(st); unsigned long long h[8 * 4 * 16];
             (void)hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost); ++*calls;
             for (int b = 0; b < 8; b += 3) for (int w = 0; w < 4; w += 3) { const unsigned long long* p = h + (b * 4 + w) * 16;
+                if (p[5]) { fprintf(stderr, "[f16 wg%d w%d] (x10ns) load+convert=%llu barrier=%llu mma=%llu barrier=%llu epilogue=%llu | total=%llu\n", b, w, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[5] - p[0]); continue; }
                 fprintf(stderr, "[d16 wg%d w%d] stage=%llu bstore+bar=%llu", b, w, p[1] - p[0], p[2] - p[1]);
                 unsigned long long prev = p[2];
                 for (int c = 0; c < 4; ++c) { fprintf(stderr, " | cls%d mma=%llu epi=%llu", c, p[3 + 2 * c] - prev, p[4 + 2 * c] - p[3 + 2 * c]); prev = p[4 + 2 * c]; }

@@ -70,6 +70,8 @@ struct uad_model {
     int math;                          // UAD_MATH_F32 | UAD_MATH_BF16X3
     UadGemmWs ws;                      // split-K slabs for the GEMMs that cannot fill the chip on their own
     bool packed_valid;
+    bool pack_inflight;               // the repack of the updated parameters was launched on SIDE by the optimizer step (ev_pack)
+    hipEvent_t ev_opt, ev_pack;
     long long step;
     // layers
     std::vector<ConvLayer> enc, dec;
@@ -395,7 +397,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->wpack_f, (size_t)m->nparams); ALLOC(m->wpack_d, (size_t)m->nparams);
     ALLOC(m->wpack16_f, (size_t)m->nparams); ALLOC(m->wpack16_d, (size_t)m->nparams);
     m->math = UAD_MATH_F32;
-    m->packed_valid = false;
+    m->packed_valid = false; m->pack_inflight = false; m->ev_opt = m->ev_pack = nullptr;
     size_t maxact = 0;
     for (auto& L : m->enc) { size_t n = NB * L.d.HS * L.d.WS * L.d.CS; ALLOC(L.c, n); if (n > maxact) maxact = n; }
     for (auto& L : m->dec) { size_t n = NB * L.d.HB * L.d.WB * L.d.CB; ALLOC(L.c, n); if (n > maxact) maxact = n; }
@@ -497,10 +499,11 @@ int uad_tensor_info(const uad_model_t* m, int idx, char* name, int name_cap, lon
     return UAD_OK;
 }
 
+static void invalidate_pack(uad_model* m);
 float* uad_buffer(uad_model_t* m, int which) {
     if (!m) return nullptr;
     switch (which) {
-        case UAD_BUF_PARAMS: return m->params;
+        case UAD_BUF_PARAMS: invalidate_pack(m); return m->params;      // the caller may write through the pointer (DP broadcast, checkpoint restore)
         case UAD_BUF_GRADS: return m->grads;
         case UAD_BUF_ADAM_M: return m->adam_m;
         case UAD_BUF_ADAM_V: return m->adam_v;
@@ -518,8 +521,8 @@ int uad_grad_segment(const uad_model_t* m, int segment, long long* offset, long 
 int uad_set_buffer(uad_model_t* m, int which, const float* host, long long count) {
     float* p = uad_buffer(m, which);
     if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "set_buffer: bad arguments (count=%lld, expected %lld)", count, m ? m->nparams : -1);
+    if (which == UAD_BUF_PARAMS) invalidate_pack(m);
     HIP_TRY(hipMemcpy(p, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
-    if (which == UAD_BUF_PARAMS) m->packed_valid = false;
     return UAD_OK;
 }
 int uad_get_buffer(uad_model_t* m, int which, float* host, long long count) {
@@ -541,6 +544,49 @@ int uad_reset_optimizer(uad_model_t* m) {
 }
 long long uad_get_step(const uad_model_t* m) { return m ? m->step : 0; }
 int uad_set_step(uad_model_t* m, long long t) { if (!m || t < 0) return fail(UAD_ERR_INVALID, "bad step"); m->step = t; return UAD_OK; }
+
+// packed (bf16 hi|lo or fp32) copies of the 5x5 kernels + transposed dense kernels: the forms the conv / fused bottleneck kernels read
+static void pack_weights(uad_model* m, hipStream_t st) {
+    const bool gm = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL, sp = m->cfg.arch == UAD_ARCH_AE_SPATIAL;
+    long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
+    auto add = [&](const ConvLayer& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
+    for (size_t i = 1; i < m->enc.size(); ++i) add(m->enc[i]);
+    for (auto& L : m->dec) add(L);
+    if (np > 0) {
+        if (m->math == UAD_MATH_BF16X3)
+            uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
+        else
+            uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
+    }
+    if (!gm && !sp) {
+        // transposed copies of the dense kernels for the fused bottleneck backward
+        const float* tin[3] = {P(m, m->dw), P(m, m->muw), m->sgw >= 0 ? P(m, m->sgw) : nullptr};
+        float* tout[3] = {m->wT_d, m->wT_mu, m->wT_sg};
+        const int tr[3] = {m->cfg.zdim, m->flat, m->flat}, tc[3] = {m->flat, m->cfg.zdim, m->cfg.zdim};
+        uad_launch_transpose(tin, tr, tc, tout, m->sgw >= 0 ? 3 : 2, st);
+    }
+}
+// parameters changed (optimizer step): repack on SIDE, overlapped with whatever the caller enqueues before the next forward's first
+// packed-weight consumer (noise draw, batch gather, the first layer)
+static void repack_on_side(uad_model* m, hipStream_t st) {
+    static const bool off = getenv("UAD_NO_SIDE_PACK") != nullptr;
+    m->packed_valid = false;
+    if (off) { m->pack_inflight = false; return; }
+    if (!m->ev_opt) {
+        if (hipEventCreateWithFlags(&m->ev_opt, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) (void)hipEventCreateWithFlags(&m->ev_opt, hipEventDisableTiming);
+        if (hipEventCreateWithFlags(&m->ev_pack, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) (void)hipEventCreateWithFlags(&m->ev_pack, hipEventDisableTiming);
+    }
+    (void)hipEventRecord(m->ev_opt, st);
+    (void)hipStreamWaitEvent(m->side, m->ev_opt, 0);
+    pack_weights(m, m->side);
+    (void)hipEventRecord(m->ev_pack, m->side);
+    m->pack_inflight = true;
+}
+// parameters are about to change from the host side: an in-flight repack must not race with it or with the repack that follows
+static void invalidate_pack(uad_model* m) {
+    if (m->pack_inflight) (void)hipStreamSynchronize(m->side);
+    m->packed_valid = false; m->pack_inflight = false;
+}
 
 // ------------------------------------------------------------------------------------------------ forward
 int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, void* stream) {
@@ -580,27 +626,13 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         n = 2 * nu;
     }
 
-    // refresh the packed 5x5 kernels if the parameters changed since the last pack
+    // refresh the packed 5x5 kernels if the parameters changed since the last pack; after an optimizer step the repack already runs
+    // on SIDE (uad_adam_step) and only has to be waited for before the first kernel that reads packed weights
+    bool wait_pack = false;
     if (!m->packed_valid) {
-        PROF("pack.weights");
-        long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
-        auto add = [&](const ConvLayer& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
-        for (size_t i = 1; i < m->enc.size(); ++i) add(m->enc[i]);
-        for (auto& L : m->dec) add(L);
-        if (np > 0) {
-            if (m->math == UAD_MATH_BF16X3)
-                uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
-            else
-                uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
-        }
-        if (!gm && !sp) {
-            // transposed copies of the dense kernels for the fused bottleneck backward
-            const float* tin[3] = {P(m, m->dw), P(m, m->muw), m->sgw >= 0 ? P(m, m->sgw) : nullptr};
-            float* tout[3] = {m->wT_d, m->wT_mu, m->wT_sg};
-            const int tr[3] = {m->cfg.zdim, m->flat, m->flat}, tc[3] = {m->flat, m->cfg.zdim, m->cfg.zdim};
-            uad_launch_transpose(tin, tr, tc, tout, m->sgw >= 0 ? 3 : 2, st);
-        }
-        m->packed_valid = true;
+        if (m->pack_inflight) wait_pack = true;
+        else { PROF("pack.weights"); pack_weights(m, st); }
+        m->packed_valid = true; m->pack_inflight = false;
     }
     // encoder
     static const char* kEncF[] = {"enc0.fwd", "enc1.fwd", "enc2.fwd", "enc3.fwd", "enc4.fwd", "enc5.fwd", "enc6.fwd", "enc7.fwd"};
@@ -610,6 +642,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         UadConvDesc d = m->enc[0].d; d.N = n;
         uad_launch_conv_first_fwd(d, xin, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st);
     }
+    if (wait_pack) (void)hipStreamWaitEvent(st, m->ev_pack, 0);
     for (size_t i = 1; i < m->enc.size(); ++i) {
         PROF(kEncF[i & 7]);
         UadConvDesc d = m->enc[i].d; d.N = n;
@@ -1069,8 +1102,9 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
     const double t = (double)m->step;
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
     hipStream_t st = (hipStream_t)stream;
-    m->packed_valid = false;
+    invalidate_pack(m);
     { PROF("adam"); uad_launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr_t, beta1, beta2, eps, grad_scale, st); }
+    repack_on_side(m, st);
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
@@ -1079,9 +1113,10 @@ int uad_optimizer_step(uad_model_t* m, int kind, float lr, float momentum, float
     if (!m) return fail(UAD_ERR_INVALID, "null model");
     if (kind < UAD_OPT_SGD || kind > UAD_OPT_RMS) return fail(UAD_ERR_INVALID, "optimizer kind %d: UAD_OPT_SGD | UAD_OPT_MOMENTUM | UAD_OPT_RMS (Adam is uad_adam_step)", kind);
     m->step += 1;
-    m->packed_valid = false;
+    invalidate_pack(m);
     hipStream_t st = (hipStream_t)stream;
     { PROF("optim"); uad_launch_optim(kind, m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr, momentum, decay, eps, grad_scale, st); }
+    repack_on_side(m, st);
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
@@ -1117,7 +1152,7 @@ int uad_restore_step(uad_model_t* m, float* x_restored, const float* eps_w, cons
 int uad_set_math_mode(uad_model_t* m, int mode) {
     if (!m || (mode != UAD_MATH_F32 && mode != UAD_MATH_BF16X3)) return fail(UAD_ERR_INVALID, "bad math mode");
     m->math = mode;
-    m->packed_valid = false;
+    invalidate_pack(m);
     return UAD_OK;
 }
 int uad_get_math_mode(const uad_model_t* m) { return m ? m->math : -1; }
