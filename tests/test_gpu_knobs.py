@@ -1,0 +1,27 @@
+"""GPU: the fallback paths behind the library's environment switches stay correct.  The switches are read once per process, so each case
+runs the whole-model parity tests of tests/test_gpu_model.py (forward, every gradient tensor, Adam trajectory vs the oracle) in a fresh
+interpreter with the switch set:
+  UAD_BOTT_Q1              one workgroup per sample in the fused bottleneck kernels instead of a group of four
+  UAD_NO_FUSED_BOTT_WGRAD  bottleneck parameter gradients as batched GEMMs + column sums instead of bottleneck_wgrad_kernel
+  UAD_NO_FIRST32           generic first-layer kernels instead of conv_first_fwd32 / conv_first_wgrad32
+  UAD_NO_SIDE_PACK         weight repack on the caller's stream inside the next forward instead of on the side stream after the optimizer step
+  UAD_EVENT_SYSFENCE       stream-ordering events with the default system-scope fence
+  UAD_NO_W_T               pixel-major filter-gradient kernel instead of the channel-major one"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_EVENT_SYSFENCE', 'UAD_NO_W_T'])
+def test_model_parity_with_switch(knob):
+    env = dict(os.environ, **{knob: '1'})
+    sel = 'test_forward_backward_parity or test_train_trajectory_vae_matches_oracle'
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_model.py', '-q', '-x', '-m', 'gpu', '-k', sel, '-p', 'no:cacheprovider'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (knob, r.stdout[-2000:], r.stderr[-1000:])
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
