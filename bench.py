@@ -621,7 +621,7 @@ def main():
     # per-segment gradient all-reduce, timed on its own after the timed region (N > 1): what the backward has to hide
     allreduce = None
     if world > 1:
-        names = {_lib.SEG_DECODER: 'decoder', _lib.SEG_BOTTLENECK: 'bottleneck', _lib.SEG_ENCODER: 'encoder'}
+        names = {_lib.SEG_DECODER: 'decoder', _lib.SEG_BOTTLENECK: 'bottleneck', _lib.SEG_ENCODER_HI: 'encoder_deep', _lib.SEG_ENCODER_LO: 'encoder_first_blocks'}
         allreduce = {'ranks': dist.get_world_size(), 'backend': dist.get_backend() + (' (RCCL over xGMI)' if not rehearsal else ' (single-GPU rehearsal)'),
                      'segments': {}}
         for seg, (off, cnt) in dp.segs.items():

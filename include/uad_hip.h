@@ -43,7 +43,10 @@ enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1, UAD_ARCH_CEVAE = 2, UAD_ARCH_GMVAE_SPA
        UAD_ARCH_AE_SPATIAL = 4 };   /* models/autoencoder_spatial.py:7-27: no dense bottleneck; the latent is the encoder feature map
                                        [n,r,r,C]: io.mask_mu is its dropout keep-mask and io.z_mu receives it (both that shape) */
 enum { UAD_BUF_PARAMS = 0, UAD_BUF_GRADS = 1, UAD_BUF_ADAM_M = 2, UAD_BUF_ADAM_V = 3 };
-enum { UAD_SEG_DECODER = 0, UAD_SEG_BOTTLENECK = 1, UAD_SEG_ENCODER = 2, UAD_SEG_ALL = -1 };
+/* ENCODER_HI + ENCODER_LO partition ENCODER: HI = the deep blocks' variables (complete after the blocks >= 2 are back-propagated: ~93 % of the
+ * segment at the default depth), LO = the first two blocks' kernels -- the data-parallel layer's last, exposed all-reduce then moves 0.2 MB
+ * instead of 2.7 MB */
+enum { UAD_SEG_DECODER = 0, UAD_SEG_BOTTLENECK = 1, UAD_SEG_ENCODER = 2, UAD_SEG_ENCODER_HI = 3, UAD_SEG_ENCODER_LO = 4, UAD_SEG_ALL = -1 };
 /* arithmetic of the k5 s2 forward / data-gradient contractions: exact fp32 MFMA (default), or split-bf16 (x = hi + lo,
  * hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate: ~2^-17 relative error per product) */
 enum { UAD_MATH_F32 = 0, UAD_MATH_BF16X3 = 1,
@@ -119,7 +122,8 @@ int uad_tensor_info(const uad_model_t* m, int idx, char* name, int name_cap, lon
 /* device pointer to a handle-owned flat fp32 buffer of uad_param_count() elements (UAD_BUF_*) */
 float* uad_buffer(uad_model_t* m, int which);
 /* flat [offset, offset+count) range of one gradient segment; segments complete in the order DECODER, BOTTLENECK,
- * ENCODER during uad_backward — the data-parallel layer all-reduces each as soon as it is done. */
+ * ENCODER (= ENCODER_HI, then ENCODER_LO) during uad_backward — the data-parallel layer all-reduces each as soon as it is done.
+ * A segment may be empty (count 0). */
 int uad_grad_segment(const uad_model_t* m, int segment, long long* offset, long long* count);
 
 /* synchronous host<->device copies of the flat parameter vector */
@@ -138,7 +142,7 @@ int uad_set_step(uad_model_t* m, long long t);
  * ceVAE runs both branches as one 2n-sample pass through the shared layers (VAE-branch samples first). */
 int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, void* stream);
 /* gradient of `loss` w.r.t. every parameter into the UAD_BUF_GRADS buffer; segment = UAD_SEG_* (call DECODER,
- * BOTTLENECK, ENCODER in that order, or UAD_SEG_ALL). */
+ * BOTTLENECK, ENCODER in that order -- ENCODER may be given as ENCODER_HI followed by ENCODER_LO -- or UAD_SEG_ALL). */
 int uad_backward(uad_model_t* m, int segment, void* stream);
 /* TF-1.15 Adam: t += 1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps); grads scaled by grad_scale first */
 int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);

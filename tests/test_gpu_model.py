@@ -81,6 +81,36 @@ def test_forward_backward_parity(arch, h, inter, zdim, n, math):
     eng.close()
 
 
+@pytest.mark.parametrize('arch,h,zdim,n', [('VAE', 64, 64, 5), ('AE', 32, 32, 3)])
+def test_segmented_backward_equals_the_whole_one(arch, h, zdim, n):
+    """uad_backward by segments (what parallel.DataParallelStep issues: DECODER, BOTTLENECK, ENCODER_HI, ENCODER_LO) leaves the same bits as
+    UAD_SEG_ALL, every segment's slice is final when its call returns (the all-reduce reads it then), and ENCODER_HI | ENCODER_LO tile ENCODER."""
+    from unsupervised_anomaly_detection_brain_mri_amd.parallel import SEGMENT_ORDER
+    m, p32, x, eps, masks = _setup(arch, h, 8, zdim, n)
+    eng = Engine(arch, h, h, 1, 8, zdim, max_batch=n)
+    eng.set_params(p32)
+    e = eps if arch == 'VAE' else None
+    eng.forward(x, e, masks, want_backward=True)
+    eng.backward()
+    whole = eng.buffer(_lib.BUF_GRADS).clone()
+    eng.buffer(_lib.BUF_GRADS).zero_()
+    segs = {s: eng.grad_segment(s) for s in SEGMENT_ORDER}
+    (o_enc, c_enc), (o_hi, c_hi), (o_lo, c_lo) = eng.grad_segment(_lib.SEG_ENCODER), segs[_lib.SEG_ENCODER_HI], segs[_lib.SEG_ENCODER_LO]
+    assert (o_lo, o_lo + c_lo, o_hi + c_hi) == (o_enc, o_hi, o_enc + c_enc) and c_lo > 0
+    assert (c_hi > c_lo) if h >= 64 else (c_hi == 0)        # a two-block encoder (32 x 32) has no deep part: ENCODER_HI is empty there
+    assert sum(c for _, c in segs.values()) == eng.nparams
+    eng.forward(x, e, masks, want_backward=True)
+    for s in SEGMENT_ORDER:
+        eng.backward(s)
+        off, cnt = segs[s]
+        torch.cuda.current_stream().synchronize()          # only the caller's stream: the segment must have been joined into it
+        assert torch.equal(eng.buffer(_lib.BUF_GRADS)[off:off + cnt], whole[off:off + cnt]), s
+    assert torch.equal(eng.buffer(_lib.BUF_GRADS), whole)
+    with pytest.raises(Exception):
+        eng.backward(_lib.SEG_ENCODER_LO)                   # the forward state was consumed
+    eng.close()
+
+
 def test_train_trajectory_vae_matches_oracle():
     """12 Adam steps from fixed init + fixed eps/masks (SURVEY.md §4 build-side plan): loss trajectory and final
     weights track the fp64 oracle.  lr is kept small enough for a monotone descent: with lr=1e-3 this problem overshoots

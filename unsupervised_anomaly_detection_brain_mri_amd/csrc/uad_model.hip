@@ -63,7 +63,7 @@ struct uad_model {
     int n_pool, cenc, cmid, flat;
     std::vector<Tensor> tensors;
     long long nparams;
-    long long seg_off[3], seg_cnt[3];
+    long long seg_off[5], seg_cnt[5];
     float *params, *grads, *adam_m, *adam_v;
     float *wpack_f, *wpack_d;          // k-quad-interleaved copies of the 5x5 kernels (refreshed once per forward)
     float *wpack16_f, *wpack16_d;      // bf16 hi|lo planes of the same kernels (bf16x3 math mode); 2*nparams ushorts each
@@ -314,6 +314,12 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
         cin = f; res /= 2;
     }
     m->seg_off[UAD_SEG_ENCODER] = 0; m->seg_cnt[UAD_SEG_ENCODER] = m->nparams;
+    {   // ENCODER_LO = [enc0.kernel .. enc1.kernel] (finished by the last two blocks' backward), ENCODER_HI = the rest (enc1.bias ..): within a
+        // block the order is kernel, bias, gamma, beta, and block i's backward finishes enc[i].kernel and enc[i-1].{bias, gamma, beta}
+        const long long split = m->enc.size() >= 3 ? m->enc[1].b : m->nparams;
+        m->seg_off[UAD_SEG_ENCODER_LO] = 0; m->seg_cnt[UAD_SEG_ENCODER_LO] = split;
+        m->seg_off[UAD_SEG_ENCODER_HI] = split; m->seg_cnt[UAD_SEG_ENCODER_HI] = m->nparams - split;
+    }
     m->cenc = cin; m->cmid = cin / 8;
     const int ir = cfg->inter_res;
     m->flat = ir * ir * m->cmid;
@@ -512,7 +518,7 @@ float* uad_buffer(uad_model_t* m, int which) {
 }
 
 int uad_grad_segment(const uad_model_t* m, int segment, long long* offset, long long* count) {
-    if (!m || segment < 0 || segment > 2) return fail(UAD_ERR_INVALID, "bad segment");
+    if (!m || segment < 0 || segment > UAD_SEG_ENCODER_LO) return fail(UAD_ERR_INVALID, "bad segment");
     if (offset) *offset = m->seg_off[segment];
     if (count) *count = m->seg_cnt[segment];
     return UAD_OK;
@@ -1035,7 +1041,8 @@ static int backward_spatial_z(uad_model* m, hipStream_t st) {
     return UAD_OK;
 }
 
-static int backward_encoder(uad_model* m, hipStream_t st) {
+// part: 0 = the whole segment; 1 = ENCODER_HI (blocks >= 2, joined: their variables are complete); 2 = ENCODER_LO (the rest)
+static int backward_encoder(uad_model* m, hipStream_t st, int part) {
     const int n = m->last_n;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
     hipStream_t sd = m->side;
@@ -1045,7 +1052,9 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
     float* gn = m->G1;
     static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
     static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
-    for (int i = (int)m->enc.size() - 1; i >= 1; --i) {
+    const int hi_from = (int)m->enc.size() - 1, hi_to = m->enc.size() >= 3 ? 2 : hi_from + 1;      // ENCODER_HI runs blocks hi_from .. hi_to
+    const int i_first = part == 2 ? hi_to - 1 : hi_from, i_last = part == 1 ? hi_to : 1;
+    for (int i = i_first; i >= i_last; --i) {
         UadConvDesc d = m->enc[i].d; d.N = n;
         const ConvLayer& PL = m->enc[i - 1];
         float* cp = m->cp_slot[8 + (i & 7)];
@@ -1057,6 +1066,11 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
                   uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
+    }
+    if (part == 1) {
+        m->G0 = g; m->G1 = gn;
+        edge(m, sd, st);   // join: the deep blocks' gradients are complete
+        return UAD_OK;
     }
     UadConvDesc d0 = m->enc[0].d; d0.N = n;
     if (pg) { PROF("enc0.wgrad"); uad_launch_conv_first_wgrad(d0, m->x_eff, g, Gr(m, m->enc[0].w), m->wp_slot[8], st); }
@@ -1081,15 +1095,16 @@ static int backward_encoder(uad_model* m, hipStream_t st) {
 int uad_backward(uad_model_t* m, int segment, void* stream) {
     if (!m) return fail(UAD_ERR_INVALID, "null model");
     if (!m->have_fwd) return fail(UAD_ERR_INVALID, "uad_backward without a preceding uad_forward(want_backward=1)");
-    if (segment < UAD_SEG_ALL || segment > UAD_SEG_ENCODER) return fail(UAD_ERR_INVALID, "bad segment %d", segment);
+    if (segment < UAD_SEG_ALL || segment > UAD_SEG_ENCODER_LO) return fail(UAD_ERR_INVALID, "bad segment %d", segment);
     hipStream_t st = (hipStream_t)stream;
     int rc = UAD_OK;
     if (segment == UAD_SEG_ALL || segment == UAD_SEG_DECODER) rc = backward_decoder(m, st, segment == UAD_SEG_DECODER);
     if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_BOTTLENECK))
         rc = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL ? backward_gm_heads(m, st)
              : m->cfg.arch == UAD_ARCH_AE_SPATIAL ? backward_spatial_z(m, st) : backward_bottleneck(m, st, segment == UAD_SEG_BOTTLENECK);
-    if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_ENCODER)) {
-        rc = backward_encoder(m, st);
+    if (rc == UAD_OK && segment == UAD_SEG_ENCODER_HI) rc = backward_encoder(m, st, 1);
+    if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_ENCODER || segment == UAD_SEG_ENCODER_LO)) {
+        rc = backward_encoder(m, st, segment == UAD_SEG_ENCODER_LO ? 2 : 0);
         m->have_fwd = false;
     }
     HIP_TRY(hipGetLastError());

@@ -453,7 +453,7 @@ class ZimmererEngine(GanEngine):
         return None
 
     def grad_segment(self, seg):
-        return (0, self.nparams) if seg == _lib.SEG_ENCODER else (0, 0)
+        return (0, self.nparams) if seg in (_lib.SEG_ENCODER, _lib.SEG_ENCODER_LO) else (0, 0)
 
     def adam_step(self, lr, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0):
         self.adam('AE', lr, beta1, beta2, eps, grad_scale)
