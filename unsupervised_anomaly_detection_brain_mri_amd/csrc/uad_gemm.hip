@@ -40,6 +40,8 @@ struct ConvGemmArgs {
     int lws, lhs;  // log2(WS), log2(HS) or -1 when not a power of two
     int nsplit;    // split-K factor (>1: raw partial tiles go to Out + split*out_elems, see splitk_epilogue_kernel)
     long long out_elems;
+    unsigned* sk_counter;   // split-K with in-kernel reduction: arrival counters, one per (spatial tile, column block); null = splitk_epilogue_kernel
+    float* out_final;       // ... and the real output (Out points at the slabs)
     unsigned long long* dbgbuf;   // per-phase clock stamps of a few workgroups (UAD_DBG & 8)
     int dbg;       // ablation switches for kernel tuning (UAD_DBG): 1 = no epilogue stores, 2 = no MFMA loop, 4 = no staging
     int math16;    // generic kernel: bf16x3 products (conv_gemm16_kernel) where the tile shape allows
@@ -842,6 +844,34 @@ __device__ __forceinline__ unsigned or8_dpp(unsigned v) {
     return v;
 }
 
+// Split-K with in-kernel reduction (guide: cross-workgroup hand-off, counter form).  The slabs are written with sc1 (write-through) 16-byte
+// buffer stores and read back by the reducer with sc1 loads: performed at the device's coherence point, whichever XCD the contributors of a
+// tile ran on, without a release fence (= write-back of the XCD's whole L2).  Order: slab stores -> every wave drains them (s_waitcnt) ->
+// barrier -> one relaxed agent-scope ticket per workgroup; the workgroup that draws nsplit - 1 sums the slabs in split order (the order
+// splitk_epilogue_kernel uses) and runs the normal epilogue.  The counter is reset by the reducer (zero-initialised at allocation).
+__device__ __forceinline__ void sk_store16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float4 v) {
+    const v4u u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ float4 sk_load16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    const v4u u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+// true in exactly one of the nsplit workgroups of a tile: the last to arrive.  flag: one int of LDS nobody else touches around the call.
+__device__ __forceinline__ bool sk_last_arriver(unsigned* counter, int nsplit, int* flag, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const bool last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
+        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    const bool r = *flag != 0;
+    __syncthreads();          // the flag's LDS word may be reused right away
+    return r;
+}
+
 // Compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
 template <int I0, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -1608,25 +1638,50 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         f_w = *reinterpret_cast<const float4*>(a.ep.fin_wf + ecol);
         f_bf = a.ep.fin_bf[0];
     }
-    auto class_epilogue = [&](const v16f& o, int py, int px) __attribute__((always_inline)) {
+    // reduce = false: the accumulators of one parity class; reduce = true (split-K, last workgroup of the tile): the class's sum over the slabs
+    auto class_epilogue = [&](const v16f& o, int py, int px, const bool reduce) __attribute__((always_inline)) {
+        if (!reduce) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) etile[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + l31] = o[r];
+            for (int r = 0; r < 16; ++r) etile[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + l31] = o[r];
+        }
         __builtin_amdgcn_wave_barrier();
         float4 v[4];
         size_t off[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int row = erow + 8 * k;
-            v[k] = *reinterpret_cast<const float4*>(etile + row * EPI_LD + ec4);
+            v[k] = reduce ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(etile + row * EPI_LD + ec4);
             const int mm = wm * 32 + row;
             const int Y = 2 * (ty0 + mm / TW) + py, X = 2 * (tx0 + mm % TW) + px;
             off[k] = ((size_t)(n * d.HB + Y) * d.WB + X) * Nn + ecol;
         }
         __builtin_amdgcn_wave_barrier();
-        if (nsplit > 1) {
-            float* slab = a.Out + (size_t)split * a.out_elems;
+        float* outp = a.Out;
+        if (nsplit > 1 && reduce) {
+            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, 0xffffffff, 0x00020000);
+            for (int sp = 0; sp < nsplit; sp += 2) {          // split order, two slabs (8 loads) in flight
+                float4 t[4][2];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(slab + off[k]) = v[k];
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) t[k][h] = sk_load16(srs, (unsigned)(((size_t)(sp + h) * a.out_elems + off[k]) * 4));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { v[k].x += t[k][h].x; v[k].y += t[k][h].y; v[k].z += t[k][h].z; v[k].w += t[k][h].w; }
+            }
+            outp = a.out_final;
+        }
+        if (nsplit > 1 && !reduce) {
+            if (a.sk_counter) {
+                const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sk_store16(srs, (unsigned)(((size_t)split * a.out_elems + off[k]) * 4), v[k]);
+            } else {
+                float* slab = a.Out + (size_t)split * a.out_elems;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(slab + off[k]) = v[k];
+            }
         } else if (fin) {
             // last decoder block: BN + LeakyReLU, final 1x1 conv (C -> 1, reduced over the 8 lanes that share a pixel), L1 loss
             // and, if wanted, its gradient back to this layer's pre-BN output (models/customlayers.py:35-37, trainers/VAE.py:36-40)
@@ -1694,7 +1749,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
                 t.x += e_a.x; t.y += e_a.y; t.z += e_a.z; t.w += e_a.w;
                 if (a.ep.mul) { const float4 q = *reinterpret_cast<const float4*>(a.ep.mul + off[k]); t.x *= q.x; t.y *= q.y; t.z *= q.z; t.w *= q.w; }
                 if (a.ep.add) { const float4 q = *reinterpret_cast<const float4*>(a.ep.add + off[k]); t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
-                *reinterpret_cast<float4*>(a.Out + off[k]) = t;
+                *reinterpret_cast<float4*>(outp + off[k]) = t;
             }
         } else {
             float4 cp[4];
@@ -1713,7 +1768,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
                     s1[e] += dbn;
                     s2[e] = fmaf(dbn, cc[e], s2[e]);
                 }
-                *reinterpret_cast<float4*>(a.Out + off[k]) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+                *reinterpret_cast<float4*>(outp + off[k]) = make_float4(oo[0], oo[1], oo[2], oo[3]);
             }
         }
     };
@@ -1753,7 +1808,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             v16f o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = acc0[r] + (acc1[r] + acc2[r]);
-            class_epilogue(o, py, px);
+            class_epilogue(o, py, px, false);
         }
     };
     static_for<0, (NUNIT + 3) / 4>([&](auto G) __attribute__((always_inline)) {
@@ -1802,7 +1857,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         }
         return;
     }
-    if (nsplit > 1) return;
+    if (nsplit > 1) {
+        if (!a.sk_counter) return;            // splitk_epilogue_kernel finishes the job
+        const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) * (gridDim.z / nsplit) + blockIdx.z / nsplit;
+        if (!sk_last_arriver(a.sk_counter + slot, nsplit, reinterpret_cast<int*>(s_red), tid)) return;
+        const v16f none = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        class_epilogue(none, 0, 0, true); class_epilogue(none, 0, 1, true); class_epilogue(none, 1, 0, true); class_epilogue(none, 1, 1, true);
+    }
     if (bwd) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -2041,11 +2102,34 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         const int mm = wm * 32 + row;
         off[k] = ((size_t)(n * d.HS + ty0 + mm / TW) * d.WS + tx0 + mm % TW) * Nn + ecol;
     }
+    float* outp = a.Out;
     if (nsplit > 1) {
-        float* slab = a.Out + (size_t)split * a.out_elems;
+        if (!a.sk_counter) {
+            float* slab = a.Out + (size_t)split * a.out_elems;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(slab + off[k]) = v[k];
-        { if (stp) stp[5] = wall_clock64(); return; }
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(slab + off[k]) = v[k];
+            { if (stp) stp[5] = wall_clock64(); return; }
+        }
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sk_store16(srs, (unsigned)(((size_t)split * a.out_elems + off[k]) * 4), v[k]);
+        const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) * (gridDim.z / nsplit) + blockIdx.z / nsplit;
+        if (!sk_last_arriver(a.sk_counter + slot, nsplit, reinterpret_cast<int*>(s_red), tid)) { if (stp) stp[5] = wall_clock64(); return; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < nsplit; sp += 2) {          // nsplit is a power of two >= 2; two slabs (8 loads) in flight
+            float4 t[4][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) t[k][h] = sk_load16(srs, (unsigned)(((size_t)(sp + h) * a.out_elems + off[k]) * 4));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { v[k].x += t[k][h].x; v[k].y += t[k][h].y; v[k].z += t[k][h].z; v[k].w += t[k][h].w; }
+        }
+        outp = a.out_final;
+        __syncthreads();      // s_red[0] carried the flag; it is reused below
     }
     if (!bwd) {
         float4 e_a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2056,7 +2140,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             t.x += e_a.x; t.y += e_a.y; t.z += e_a.z; t.w += e_a.w;
             if (a.ep.mul) { const float4 q = *reinterpret_cast<const float4*>(a.ep.mul + off[k]); t.x *= q.x; t.y *= q.y; t.z *= q.z; t.w *= q.w; }
             if (a.ep.add) { const float4 q = *reinterpret_cast<const float4*>(a.ep.add + off[k]); t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
-            *reinterpret_cast<float4*>(a.Out + off[k]) = t;
+            *reinterpret_cast<float4*>(outp + off[k]) = t;
         }
         { if (stp) stp[5] = wall_clock64(); return; }
     }
@@ -2080,7 +2164,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             s1[e] += dbn;
             s2[e] = fmaf(dbn, cc[e], s2[e]);
         }
-        *reinterpret_cast<float4*>(a.Out + off[k]) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+        *reinterpret_cast<float4*>(outp + off[k]) = make_float4(oo[0], oo[1], oo[2], oo[3]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -3261,11 +3345,14 @@ void launch_gemm(const ConvGemmArgs& a, int classes, hipStream_t st) {
 
 namespace {
 enum { PATH_GENERIC = 0, PATH_SPATIAL = 1, PATH_SPLITK = 2 };
-struct GemmPlan { int path; SpatialChoice sc; int nsplit; int tiles; size_t ws_floats; long long out_elems; int out_rows; };
+struct GemmPlan { int path; SpatialChoice sc; int nsplit; int tiles; size_t ws_floats; long long out_elems; int out_rows; bool inkernel; };
 
 // One decision procedure for launchers and for the colpart-tile / workspace queries.
-inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, size_t ws_cap) {
+// ncounters > 0: the caller runs the split-bf16 spatial kernels and owns that many arrival counters -> a split launch reduces its slabs in the
+// kernel (last workgroup per tile) when the instance that will run supports it
+inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, size_t ws_cap, int ncounters = 0) {
     GemmPlan p;
+    p.inkernel = false;
     const int CA = f_type ? d.CB : d.CS, Nn = f_type ? d.CS : d.CB;
     const long M = (long)d.N * d.HS * d.WS;
     const int classes = f_type ? 1 : d.S * d.S;
@@ -3289,7 +3376,13 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
             p.path = PATH_SPATIAL;
             p.nsplit = sp;
             p.ws_floats = sp > 1 ? (size_t)sp * p.out_elems : 0;
-            p.tiles = sp > 1 ? (p.out_rows + 63) / 64 : d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW);
+            if (sp > 1 && ncounters > 0 && wgs <= ncounters && (size_t)sp * p.out_elems * 4 < ((size_t)1 << 32)) {
+                static const bool off = getenv("UAD_NO_INKERNEL_SPLITK") != nullptr, no_f16 = getenv("UAD_NO_F16") != nullptr, no_d16 = getenv("UAD_NO_D16") != nullptr;
+                const int cst = CA / sp;
+                const bool inst = f_type ? !no_f16 : (!no_d16 && CA % sp == 0 && (cst == 32 || cst == 64 || (cst == 128 && p.sc.BN == 64)));
+                p.inkernel = !off && inst;
+            }
+            p.tiles = (sp > 1 && !p.inkernel) ? (p.out_rows + 63) / 64 : d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW);
             return p;
         }
     }
@@ -3307,8 +3400,8 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
 bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
     return f_type ? choose_spatial(d, d.CB, d.CS, true).ok : choose_spatial(d, d.CS, d.CB, false).ok;
 }
-int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, true, have_pack, ws_floats).tiles; }
-int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats) { return plan_gemm(d, false, have_pack, ws_floats).tiles; }
+int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats, int ncounters) { return plan_gemm(d, true, have_pack, ws_floats, ncounters).tiles; }
+int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats, int ncounters) { return plan_gemm(d, false, have_pack, ws_floats, ncounters).tiles; }
 bool uad_conv_f_supports_final_bwd(const UadConvDesc& d, bool have_pack16, size_t ws_floats) {
     if (!have_pack16 || getenv("UAD_NO_F16") || getenv("UAD_NO_FB_ON_LOAD")) return false;
     const GemmPlan p = plan_gemm(d, true, true, ws_floats);
@@ -3360,7 +3453,8 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
                 fprintf(stderr, " | total=%llu\n", prev - p[0]); } } } dbg_dump{dbg_this, st, dbgbuf, &dbg_calls};
     if (p.path == PATH_SPATIAL) {
         float* out = a.Out;
-        if (p.nsplit > 1) { a.Out = ws; a.nsplit = p.nsplit; }
+        if (p.nsplit > 1) { a.Out = ws; a.nsplit = p.nsplit; a.out_final = out; }
+        if (!(p.nsplit > 1 && p.inkernel && a.Wp16)) a.sk_counter = nullptr;
         dim3 grid((d.HS / p.sc.TH) * (d.WS / p.sc.TW), d.N, (a.Nn / p.sc.BN) * p.nsplit);
         if (a.Wp16) {   // bf16x3 math mode
             if (f_type) {
@@ -3389,7 +3483,7 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
             else if (p.sc.CK == 32) hipLaunchKernelGGL((conv5_d_kernel<8, 16, 32, 4, 1>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv5_d_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
         }
-        if (p.nsplit > 1) {
+        if (p.nsplit > 1 && !a.sk_counter) {
             dim3 g2((p.out_rows + 63) / 64, (a.Nn + 63) / 64);
             hipLaunchKernelGGL(splitk_epilogue_kernel, g2, dim3(256), 0, st, ws, p.nsplit, p.out_elems, p.out_rows, a.Nn, a.ep, out);
         }
@@ -3428,7 +3522,9 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CB; a.Nn = d.CS;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;
-    const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0);
+    a.sk_counter = nullptr; a.out_final = nullptr;
+    const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
+    if (p.inkernel) a.sk_counter = ws.counters;
     run_plan(p, a, true, ws.ptr, st);
 }
 
@@ -3440,7 +3536,9 @@ void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf,
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CS; a.Nn = d.CB;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;
-    const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0);
+    a.sk_counter = nullptr; a.out_final = nullptr;
+    const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
+    if (p.inkernel) a.sk_counter = ws.counters;
     run_plan(p, a, false, ws.ptr, st);
 }
 

@@ -41,7 +41,9 @@ struct UadXform {
 enum { UAD_EPI_BIAS = 0, UAD_EPI_BWD_ACT = 1, UAD_EPI_FINAL = 2 };
 
 // optional split-K workspace of the generic kernels (slabs of raw partial outputs)
-struct UadGemmWs { float* ptr; size_t floats; };
+// split-K workspace: slabs + (optional) zero-initialised arrival counters, one per output tile of a split launch: with counters the last
+// workgroup to arrive at a tile sums the slabs and applies the epilogue inside the conv kernel (no splitk_epilogue launch)
+struct UadGemmWs { float* ptr; size_t floats; unsigned* counters; int ncounters; };
 
 struct UadEpilogue {
     int kind;             // UAD_EPI_*
@@ -95,13 +97,13 @@ void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d
 bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type);
 // number of colpart tiles the above launches write for EPI_BWD_ACT
 // (the same have_pack / workspace capacity as the launch must be passed: they select the kernel path)
-int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0);
+int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0, int ncounters = 0);      // ncounters: UadGemmWs::ncounters when the launch will run in the split-bf16 mode, else 0
 // true when uad_launch_conv_d(d, ..., UAD_EPI_FINAL) is available: bf16x3 planes given, class-sequential spatial kernel, all
 // output channels (32) in one workgroup, no split
 bool uad_conv_d_can_fuse_final(const UadConvDesc& d, bool have_pack16, size_t ws_floats);
 // true when uad_launch_conv_f would run the bf16x3 spatial kernel that understands UadXform::fb_* (see there)
 bool uad_conv_f_supports_final_bwd(const UadConvDesc& d, bool have_pack16, size_t ws_floats);
-int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0);
+int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0, int ncounters = 0);
 // workspace floats the split-K path would like for this op (0 = it would not split)
 size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack);
 // W-type: dW[tap][cb][cs] = sum_{n,i,j} xfb(big)[..tap..,cb] * xfs(small)[n,i,j,cs]

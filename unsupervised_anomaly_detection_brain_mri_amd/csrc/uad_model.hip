@@ -472,6 +472,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
         }
         m->ws.floats = need; m->ws.ptr = nullptr;
         ALLOC(m->ws.ptr, need);
+        // arrival counters of the in-kernel split-K reduction: one per (spatial tile, column block) of a split launch
+        { float* c = nullptr; m->ws.ncounters = 16384; ALLOC(c, m->ws.ncounters); m->ws.counters = reinterpret_cast<unsigned*>(c); }
     }
     ALLOC(m->colscratch, 64 * 1024);
     const int bps = uad_final_blocks_per_sample(H, Wd);
@@ -795,6 +797,8 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
 // the next heavy kernel instead of each costing a serialized 4-10 us.  Edges are hipEvents; every segment ends with MAIN
 // waiting for SIDE, so the caller (Adam, or the DP all-reduce of that gradient segment) sees complete gradients.
 // Scratch touched by SIDE is per layer (column partials, split-K slabs), so MAIN never overwrites what SIDE still reads.
+// counters the split launches of this handle may use for the in-kernel reduction (split-bf16 mode only: the fp32 kernels have no such path)
+static int sk_counters(const uad_model* m) { return (m->math == UAD_MATH_BF16X3 && m->ws.counters) ? m->ws.ncounters : 0; }
 static hipEvent_t next_event(uad_model* m) {
     if (m->ev_next == m->sync_events.size()) {
         hipEvent_t e;
@@ -857,7 +861,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
             hipMemcpyAsync(Gr(m, m->fb), m->colscratch + 3 * C, sizeof(float), hipMemcpyDeviceToDevice, sd);
             uad_launch_bn_grad_finalize(m->colscratch + C, 1, C, P(m, DL.gamma), rstd, Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), sd);
         }
-        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats, sk_counters(m)), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
@@ -1063,7 +1067,7 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
           uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i])); }
         edge(m, st, sd);
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd);
-                  uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
+                  uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats, sk_counters(m)), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
     }
@@ -1285,7 +1289,15 @@ static int check_gemm_desc(const uad_conv_desc_t* d, bool f_type) {
 // op-level helpers: the spatial kernels need the packed weight copy; build it on the fly (synchronous, tests only)
 static int ws_for_op(const UadConvDesc& d, bool f_type, bool have_pack, UadGemmWs* ws) {
     ws->ptr = nullptr; ws->floats = uad_conv_ws_floats(d, f_type, have_pack);
-    if (ws->floats) HIP_TRY(hipMalloc((void**)&ws->ptr, ws->floats * sizeof(float)));
+    ws->counters = nullptr; ws->ncounters = 0;
+    if (ws->floats) {
+        // slabs + (behind them) the arrival counters of the in-kernel reduction, zeroed: the op-level entry points exercise the same path
+        // as the model handle
+        const int nc = 16384;
+        HIP_TRY(hipMalloc((void**)&ws->ptr, (ws->floats + nc) * sizeof(float)));
+        HIP_TRY(hipMemset(ws->ptr + ws->floats, 0, nc * sizeof(float)));
+        ws->counters = reinterpret_cast<unsigned*>(ws->ptr + ws->floats); ws->ncounters = nc;
+    }
     return UAD_OK;
 }
 static bool op_bf16x3() { const char* e = getenv("UAD_MATH"); return e && !strcmp(e, "bf16x3"); }
@@ -1339,7 +1351,8 @@ static int bwdact_common(bool f_type, const uad_conv_desc_t* dd, const float* in
     const bool can_pack = uad_conv_spatial_ok(d, f_type);
     UadGemmWs ws;
     if (int rc = ws_for_op(d, f_type, can_pack, &ws)) return rc;
-    const int T = f_type ? uad_conv_f_tiles(d, can_pack, ws.floats) : uad_conv_d_tiles(d, can_pack, ws.floats);
+    const int nc = (op_bf16x3() && ws.counters) ? ws.ncounters : 0;
+    const int T = f_type ? uad_conv_f_tiles(d, can_pack, ws.floats, nc) : uad_conv_d_tiles(d, can_pack, ws.floats, nc);
     float *colpart = nullptr, *tmp = nullptr;
     HIP_TRY(hipMalloc((void**)&colpart, (size_t)T * 2 * C * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&tmp, (size_t)3 * C * sizeof(float)));
