@@ -6,7 +6,8 @@ interpreter with the switch set:
   UAD_NO_FIRST32           generic first-layer kernels instead of conv_first_fwd32 / conv_first_wgrad32
   UAD_NO_SIDE_PACK         weight repack on the caller's stream inside the next forward instead of on the side stream after the optimizer step
   UAD_EVENT_SYSFENCE       stream-ordering events with the default system-scope fence
-  UAD_NO_W_T               pixel-major filter-gradient kernel instead of the channel-major one"""
+  UAD_NO_W_T               pixel-major filter-gradient kernel instead of the channel-major one
+  UAD_NO_INKERNEL_SPLITK   split-K slabs summed by splitk_epilogue_kernel launches instead of the conv kernels' last-arriver reduction"""
 import os
 import subprocess
 import sys
@@ -17,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_EVENT_SYSFENCE', 'UAD_NO_W_T'])
+@pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_EVENT_SYSFENCE', 'UAD_NO_W_T', 'UAD_NO_INKERNEL_SPLITK'])
 def test_model_parity_with_switch(knob):
     env = dict(os.environ, **{knob: '1'})
     sel = 'test_forward_backward_parity or test_train_trajectory_vae_matches_oracle'
