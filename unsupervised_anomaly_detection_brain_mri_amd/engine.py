@@ -112,6 +112,7 @@ class _EvalOps:
 class Engine(_EvalOps):
     """One AE / VAE / ceVAE instance on one GPU.  Mirrors what a tf.Session + graph holds in the reference
     (trainers/VAE.py:18-29): variables, optimizer slots and the compiled step."""
+    SCALARS_IN_PLACE = True          # forward(scalars_out=...) is honoured (trainers.AEMODEL.process)
 
     def __init__(self, arch, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, device=None,
                  math='bf16x3', dim_c=9, dim_z=1, dim_w=1, c_lambda=1.0):
@@ -228,13 +229,14 @@ class Engine(_EvalOps):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def forward(self, x, eps=None, masks=None, want_backward=False, want_l1=True, want_latents=True, x_ce=None,
-                want_anomaly=True):
+                want_anomaly=True, scalars_out=None):
         """Returns a dict of DEVICE tensors: x_hat, L1 (opt), z_mu/z_log_sigma/z_sigma or z (opt), scalars [8]
         (reconstructionLoss, kl, loss, 0, Rec_vae, Rec_ce, loss_vae, 0), rec_per_sample [n] ([2n] for ceVAE).
         AE: x_ce (optional) = context-encoder training, the network reads x_ce and the L1 term compares with x (trainers/CE.py).
         ceVAE additionally takes x_ce (None = x) and masks 'mu_ce'/'dec_ce', and returns x_hat_ce, L1_vae / L1_ce
         (instead of L1) and -- filled in by backward() -- 'anomaly'.  want_backward: False | True | 'data' (data-gradient
-        chain only: the ceVAE anomaly map without parameter gradients).  Asynchronous on the current stream."""
+        chain only: the ceVAE anomaly map without parameter gradients).  scalars_out: a contiguous fp32 device tensor of >= 8 elements that
+        receives the scalars in place (the trainers' per-epoch table row: no copy per step).  Asynchronous on the current stream."""
         masks = masks or {}
         x = self._dev(x)
         if x.dim() != 4 or tuple(x.shape[1:]) != (self.h, self.w, self.c):
@@ -257,7 +259,10 @@ class Engine(_EvalOps):
         else:
             m_mu, m_sg, m_dec = self._dev(masks.get('z'), zs), None, None
         x_ce = self._dev(x_ce, x.shape)
-        out = {'x_hat': torch.empty_like(x), 'scalars': torch.empty(8, device=self.device),
+        if scalars_out is not None and not (isinstance(scalars_out, torch.Tensor) and scalars_out.is_cuda and scalars_out.dtype == torch.float32
+                                            and scalars_out.is_contiguous() and scalars_out.numel() >= 8):
+            raise ValueError('scalars_out must be a contiguous fp32 CUDA tensor of at least 8 elements')
+        out = {'x_hat': torch.empty_like(x), 'scalars': torch.empty(8, device=self.device) if scalars_out is None else scalars_out,
                'rec_per_sample': torch.empty(2 * n if ce else n, device=self.device)}
         if want_l1:
             out['L1_vae' if ce else 'L1'] = torch.empty_like(x)

@@ -217,9 +217,12 @@ class AEMODEL(DLMODEL):
         table = torch.zeros((max(num_batches, 1), 8), device=self.engine.device)
         for idx in range(num_batches):
             batch, _, _ = self._shard(dataset, phase)
-            out = self._run(batch, phase, fetch_maps=want_images)
-            sc = out['scalars'].reshape(-1)          # 8 slots on the fused handle, fewer on the materialised-graph engines
-            table[idx, :sc.numel()].copy_(sc)
+            # the fused handle writes its 8 scalars straight into this step's table row; the materialised-graph engines return their own (fewer)
+            kw = {'scalars_out': table[idx]} if getattr(self.engine, 'SCALARS_IN_PLACE', False) else {}
+            out = self._run(batch, phase, fetch_maps=want_images, **kw)
+            sc = out['scalars'].reshape(-1)
+            if sc.data_ptr() != table[idx].data_ptr():
+                table[idx, :sc.numel()].copy_(sc)
             if want_images:
                 from .trainer_utils import get_summary_dict
                 b = batch.cpu().numpy() if hasattr(batch, 'cpu') else np.asarray(batch)
