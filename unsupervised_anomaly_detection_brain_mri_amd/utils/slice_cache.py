@@ -139,6 +139,10 @@ class DeviceDataset:
         self._set_idx = {name: np.where(sets == k)[0].astype(np.int32) for k, name in enumerate(SET_TYPES)}
         rng = np.random.default_rng(seed)
         self._cursor = {name: BatchCursor(len(ix), rng) for name, ix in self._set_idx.items()}
+        # batch indices travel host -> device through a ring of pinned staging buffers with non-blocking copies: `.to(device)` of a pageable
+        # array synchronises the stream, i.e. the host could never run ahead of the GPU and every step paid its launch latency again
+        self._ring, self._ring_n = [], 64
+        self._ring_i = 0
 
     @classmethod
     def from_cache(cls, directory, **kw):
@@ -151,11 +155,33 @@ class DeviceDataset:
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _indices_to_device(self, arr):
+        torch = self._torch
+        arr = np.ascontiguousarray(arr, np.int32)
+        n = int(arr.size)
+        k = self._ring_i % self._ring_n
+        self._ring_i += 1
+        if len(self._ring) <= k or self._ring[k][0].numel() < n:
+            slot = (torch.empty(max(n, 256), dtype=torch.int32).pin_memory(), torch.empty(max(n, 256), dtype=torch.int32, device=self.device),
+                    torch.cuda.Event())
+            if len(self._ring) <= k:
+                self._ring.append(slot)
+            else:
+                self._ring[k][2].synchronize()
+                self._ring[k] = slot
+        else:
+            self._ring[k][2].synchronize()          # the copy that used this slot ring_n batches ago has long completed
+        pin, dev, ev = self._ring[k]
+        pin[:n].copy_(torch.from_numpy(arr))
+        dev[:n].copy_(pin[:n], non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return dev[:n]
+
     def next_batch(self, batch_size, shuffle=True, set='TRAIN', return_brainmask=False):
         torch, _lib = self._torch, self._lib
         pos = self._cursor[set].next(batch_size, shuffle)
         assert pos.size, "The batch is empty!"
-        idx = torch.from_numpy(self._set_idx[set][pos]).to(self.device)
+        idx = self._indices_to_device(self._set_idx[set][pos])
         n = int(idx.numel())
         N, H, W, Cc = self.shape
         out = torch.empty((n, H, W, Cc), device=self.device, dtype=torch.float32)
