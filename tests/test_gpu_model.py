@@ -46,10 +46,18 @@ def test_param_table_matches_oracle_spec():
 
 @pytest.mark.parametrize('math', ['f32', 'bf16x3'])
 @pytest.mark.parametrize('arch,h,inter,zdim,n', [('VAE', 32, 8, 16, 2), ('AE', 32, 8, 32, 3), ('VAE', 64, 8, 64, 5),
-                                                  ('VAE', 128, 8, 128, 2), ('AE', 128, 8, 128, 1), ('VAE', 64, 16, 128, 2)])
+                                                  ('VAE', 128, 8, 128, 2), ('AE', 128, 8, 128, 1), ('VAE', 64, 16, 128, 2),
+                                                  # 80 = one full 64-sample chunk + a ragged one in the fused bottleneck gradient kernel; this width splits
+                                                  # no further than one workgroup per sample
+                                                  ('VAE', 32, 8, 64, 80)])
 def test_forward_backward_parity(arch, h, inter, zdim, n, math):
     """Both math modes must meet the same 1e-4 bar: 'f32' = exact fp32 MFMA, 'bf16x3' = split-bf16 products on the
     bf16 matrix cores with fp32 accumulation (forward and data-gradient k5 s2 contractions)."""
+    if n > 16 and math == 'bf16x3':
+        # 80 x 64 x 64 ReLU inputs: a few sit within the split-bf16 round-off of the kink and take the other derivative (measured: dense_dec/kernel
+        # 1.3e-3 off at n = 64 and 80 alike, seed-independent, with and without the fused gradient kernel, 6e-7 in f32 mode:
+        # tests/debug/n80_bottleneck_grad.py); the flip-aware comparison at these sample counts is tests/test_gpu_scale_parity.py
+        pytest.skip('needs the flip-aware comparison (tests/test_gpu_scale_parity.py); the ragged-chunk logic under test is math-mode independent')
     m, p32, x, eps, masks = _setup(arch, h, inter, zdim, n)
     p64 = _f64(p32)
     out, cache = m.forward(p64, x.astype(np.float64), eps.astype(np.float64) if arch == 'VAE' else None, _f64(masks))
