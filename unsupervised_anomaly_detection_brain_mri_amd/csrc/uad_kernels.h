@@ -124,6 +124,9 @@ void uad_launch_reduce_partials(const float* partial, int S, int L, float scale,
 void uad_launch_bn_grad_finalize(const float* colpart, int T, int C, const float* gamma, float rstd,
                                  float* dgamma, float* dbeta, float* dbias, hipStream_t st, float* scratch = nullptr);
 size_t uad_bn_grad_finalize_scratch_floats(int C);
+// red[3C+1] = {dwf[C], S1[C], S2[C], dbf} (already summed over the tiles) -> final conv kernel / bias gradients + the last block's BN / bias gradients
+void uad_launch_final_gradfin(const float* red, int C, const float* gamma, float rstd, float* dwf, float* dbf, float* dgamma, float* dbeta,
+                              float* dbias, hipStream_t st);
 // out[c] = sum_rows g[row][c]
 void uad_launch_colsum(const float* g, int rows, int C, float* out, float* scratch, hipStream_t st);
 size_t uad_colsum_scratch_floats(int rows, int C);

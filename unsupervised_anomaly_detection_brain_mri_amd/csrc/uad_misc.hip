@@ -118,6 +118,22 @@ __global__ void __launch_bounds__(1024) bn_grad_finalize2_kernel(const float* __
     }
 }
 
+// Last decoder block's parameter gradients from the summed partials of the fused loss epilogue, red[3C+1] = {dwf[C], S1[C], S2[C], dbf}:
+// final conv kernel / bias gradients are copies, the block's BN / bias gradients follow bn_grad_finalize's formulas (one launch instead of two
+// device copies + a finalize on the side stream).
+__global__ void __launch_bounds__(256) final_gradfin_kernel(const float* __restrict__ red, int C, const float* __restrict__ gamma, float rstd,
+                                                            float* __restrict__ dwf, float* __restrict__ dbf, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dbias) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float s1 = red[C + c], s2 = red[2 * C + c];
+        dwf[c] = red[c];
+        if (dbeta) dbeta[c] = s1;
+        if (dgamma) dgamma[c] = s2 * rstd;
+        if (dbias) dbias[c] = gamma[c] * rstd * s1;
+    }
+    if (threadIdx.x == 0) dbf[0] = red[3 * C];
+}
+
 // scratch[rchunk][C] partial column sums; block = 32 channels x 8 row-lanes
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g, int rows, int C, int rows_per_chunk,
                                                      float* __restrict__ out) {
@@ -984,6 +1000,10 @@ void uad_launch_reduce_partials(const float* partial, int S, int L, float scale,
         hipLaunchKernelGGL((reduce_partials_kernel<16>), dim3(blocks), dim3(1024), 0, st, partial, S, L, scale, out);
 }
 
+void uad_launch_final_gradfin(const float* red, int C, const float* gamma, float rstd, float* dwf, float* dbf, float* dgamma, float* dbeta,
+                              float* dbias, hipStream_t st) {
+    hipLaunchKernelGGL(final_gradfin_kernel, dim3(1), dim3(256), 0, st, red, C, gamma, rstd, dwf, dbf, dgamma, dbeta, dbias);
+}
 size_t uad_bn_grad_finalize_scratch_floats(int C) { return 64 + (size_t)((C + 31) / 32) * 32 * 64; }
 void uad_launch_bn_grad_finalize(const float* colpart, int T, int C, const float* gamma, float rstd, float* dgamma,
                                  float* dbeta, float* dbias, hipStream_t st, float* scratch) {

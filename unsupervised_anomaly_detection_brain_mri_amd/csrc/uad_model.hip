@@ -857,9 +857,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
             // this layer's edge instead of one of their own): red_partial[T][3C+1] = {dwf[C], S1[C], S2[C], dbf}
             PROF_ON("final.gradfin", sd);
             uad_launch_reduce_partials(m->red_partial, T, L, 1.0f, m->colscratch, sd);
-            hipMemcpyAsync(Gr(m, m->fw), m->colscratch, C * sizeof(float), hipMemcpyDeviceToDevice, sd);
-            hipMemcpyAsync(Gr(m, m->fb), m->colscratch + 3 * C, sizeof(float), hipMemcpyDeviceToDevice, sd);
-            uad_launch_bn_grad_finalize(m->colscratch + C, 1, C, P(m, DL.gamma), rstd, Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), sd);
+            uad_launch_final_gradfin(m->colscratch, C, P(m, DL.gamma), rstd, Gr(m, m->fw), Gr(m, m->fb), Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), sd);
         }
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats, sk_counters(m)), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
