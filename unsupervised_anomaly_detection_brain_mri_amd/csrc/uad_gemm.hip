@@ -3436,7 +3436,7 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
     static int dbg_calls = 0;
     const bool dbg_f = (a.dbg & 16) && f_type && a.Wp16 && a.Nn == 64 && a.CA == 32 && dbg_calls >= 40 && dbg_calls < 44;
     if ((a.dbg & 16) && f_type && a.Wp16 && a.Nn == 64 && a.CA == 32 && !dbg_f) ++dbg_calls;
-    const bool dbg_this = dbg_f || ((a.dbg & 8) && !f_type && a.Wp16 && a.Nn == 32 && a.CA == 32 && dbg_calls < 3);
+    const bool dbg_this = dbg_f;
     if (dbg_this) {
         if (!dbgbuf) (void)hipMalloc((void**)&dbgbuf, 8 * 4 * 16 * sizeof(unsigned long long));
         (void)hipMemsetAsync(dbgbuf, 0, 8 * 4 * 16 * sizeof(unsigned long long), st);
