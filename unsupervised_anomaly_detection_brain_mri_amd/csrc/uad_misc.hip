@@ -1004,11 +1004,12 @@ void uad_launch_final_gradfin(const float* red, int C, const float* gamma, float
                               float* dbias, hipStream_t st) {
     hipLaunchKernelGGL(final_gradfin_kernel, dim3(1), dim3(256), 0, st, red, C, gamma, rstd, dwf, dbf, dgamma, dbeta, dbias);
 }
+// one workspace serves every launch of a stream: size it for the widest layer it will see (counters: first 64 words)
 size_t uad_bn_grad_finalize_scratch_floats(int C) { return 64 + (size_t)((C + 31) / 32) * 32 * 64; }
 void uad_launch_bn_grad_finalize(const float* colpart, int T, int C, const float* gamma, float rstd, float* dgamma,
                                  float* dbeta, float* dbias, hipStream_t st, float* scratch) {
     const int NB = T >= 2048 ? 32 : T >= 512 ? 16 : T >= 128 ? 8 : 1;
-    if (scratch && NB > 1 && (C + 31) / 32 <= 64) {
+    if (scratch && NB > 1 && C <= 512) {          // callers size the scratch with uad_bn_grad_finalize_scratch_floats(512)
         hipLaunchKernelGGL(bn_grad_finalize2_kernel, dim3((C + 31) / 32, NB), dim3(1024), 0, st, colpart, T, C, gamma, rstd, dgamma, dbeta, dbias, scratch);
         return;
     }
