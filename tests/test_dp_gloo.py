@@ -82,6 +82,120 @@ def test_two_rank_dp_equals_big_batch():
     assert res['replica_diff'] == 0.0
 
 
+class _OracleEngine:
+    """The Engine surface parallel.DataParallelStep drives (forward / backward(segment) / grad_segment / buffer / adam_step), computed by the
+    oracle on CPU: backward(segment) fills ONLY that segment's slice of the flat gradient buffer (in the handle's order DECODER, BOTTLENECK,
+    ENCODER_HI, ENCODER_LO; include/uad_hip.h), so an all-reduce issued too early, on the wrong slice, or a slice left out shows up as a wrong
+    gradient.  The flat layout is the handle's: Encoder | Bottleneck | Decoder, ENCODER_LO = [enc0.kernel .. enc1.kernel]."""
+
+    def __init__(self, model, params64):
+        from unsupervised_anomaly_detection_brain_mri_amd import _lib
+        self._lib, self.m, self.p = _lib, model, params64
+        self.spec = model.spec
+        self.nparams = sum(int(np.prod(sh)) for _, sh, _ in self.spec)
+        self.grads = torch.zeros(self.nparams, dtype=torch.float64)
+        self.flat = ovae.flatten_params(self.spec, params64).copy()
+        self.mm, self.vv, self.t = np.zeros_like(self.flat), np.zeros_like(self.flat), 0
+        off, acc = {}, 0
+        for name, sh, _ in self.spec:            # flatten_params order = spec order
+            off[name] = acc
+            acc += int(np.prod(sh))
+        size = {'Encoder': 0, 'Bottleneck': 0, 'Decoder': 0}
+        for name, sh, _ in self.spec:
+            size[name.split('/')[0]] += int(np.prod(sh))
+        e, b, d = size['Encoder'], size['Bottleneck'], size['Decoder']
+        n_enc = sum(1 for name, _, _ in self.spec if name.startswith('Encoder/enc_conv2D_') and name.endswith('kernel'))
+        split = off['Encoder/enc_conv2D_1/bias'] if n_enc >= 3 else e
+        self.segs = {_lib.SEG_DECODER: (e + b, d), _lib.SEG_BOTTLENECK: (e, b), _lib.SEG_ENCODER: (0, e),
+                     _lib.SEG_ENCODER_LO: (0, split), _lib.SEG_ENCODER_HI: (split, e - split)}
+        self.calls = []
+
+    def grad_segment(self, seg):
+        return self.segs[seg]
+
+    def buffer(self, which):
+        assert which == self._lib.BUF_GRADS
+        return self.grads
+
+    def forward(self, x, eps=None, masks=None, want_backward=False, **kw):
+        out, cache = self.m.forward(self.p, x, eps, masks)
+        self._full = torch.from_numpy(ovae.flatten_params(self.spec, self.m.backward(self.p, x, out, cache, masks)).copy())
+        self.grads.fill_(float('nan'))            # nothing is valid until its segment's backward ran
+        return {'scalars': torch.zeros(8)}
+
+    def backward(self, seg):
+        self.calls.append(seg)
+        off, cnt = self.segs[seg]
+        self.grads[off:off + cnt] = self._full[off:off + cnt]
+
+    def adam_step(self, lr, beta1, beta2, eps, grad_scale):
+        self.t += 1
+        onn.adam_tf_step(self.flat, self.grads.numpy() * grad_scale, self.mm, self.vv, self.t, lr, beta1, beta2, eps)
+
+
+def _dp_worker(rank, world, port, q, h):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from unsupervised_anomaly_detection_brain_mri_amd import _lib
+        from unsupervised_anomaly_detection_brain_mri_amd.parallel import SEGMENT_ORDER, DataParallelStep
+        inter, zdim, n = 8, 16, 4
+        m = ovae.Model('VAE', h, h, 1, inter, zdim)
+        p = ovae.init_params(m.spec, seed=3, dtype=np.float64, perturb=True)
+        x = ovae.synthetic_slices(n, h, h, seed=0, dtype=np.float64)
+        rng = np.random.default_rng(1)
+        eps = rng.standard_normal((n, zdim))
+        flat_dim = 8 * 8 * p['Bottleneck/conv2d/kernel'].shape[-1]
+        masks = {'mu': onn.make_dropout_mask(rng, (n, zdim), 0.2, np.float64), 'sigma': onn.make_dropout_mask(rng, (n, zdim), 0.2, np.float64),
+                 'dec': onn.make_dropout_mask(rng, (n, flat_dim), 0.2, np.float64)}
+        per = n // world
+        sl = slice(rank * per, (rank + 1) * per)
+        eng = _OracleEngine(m, p)
+        dp = DataParallelStep(eng, world)
+        dp.train_step(x[sl], eps[sl], {k: v[sl] for k, v in masks.items()}, lr=1e-3, beta1=0.5)
+        assert tuple(eng.calls) == SEGMENT_ORDER == (_lib.SEG_DECODER, _lib.SEG_BOTTLENECK, _lib.SEG_ENCODER_HI, _lib.SEG_ENCODER_LO)
+        assert sorted(dp.segs) == sorted(SEGMENT_ORDER) and sum(c for _, c in dp.segs.values()) == eng.nparams
+        if rank == 0:
+            ref = _OracleEngine(m, p)
+            ref.forward(x, eps, masks)
+            g_f = ref._full.numpy()
+            got = eng.grads.numpy() / world
+            q.put(('grad_err', float(np.abs(got - g_f).max() / np.abs(g_f).max())))
+            q.put(('hi_share', float(dp.segs[_lib.SEG_ENCODER_HI][1]) / max(1, eng.segs[_lib.SEG_ENCODER][1])))
+        t = torch.from_numpy(eng.flat.copy())
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        if rank == 0:
+            q.put(('replica_diff', float((gathered[0] - gathered[1]).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_dp(h):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, h)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    return dict(q.get(timeout=5) for _ in range(3))
+
+
+def test_data_parallel_step_issues_the_four_segments():
+    """parallel.DataParallelStep.train_step itself, two ranks over gloo, on an oracle-backed engine: DECODER, BOTTLENECK, ENCODER_HI,
+    ENCODER_LO in that order, each all-reduced after its backward; the all-reduced sum / world is the big-batch gradient and the replicas stay
+    identical after Adam.  64 x 64 has three encoder blocks (ENCODER_HI non-empty), 32 x 32 two (ENCODER_HI empty: skipped)."""
+    res = _run_dp(64)
+    assert res['grad_err'] < 1e-12 and res['replica_diff'] == 0.0 and 0.5 < res['hi_share'] < 1.0
+    res = _run_dp(32)
+    assert res['grad_err'] < 1e-12 and res['replica_diff'] == 0.0 and res['hi_share'] == 0.0
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # f-AnoGAN phases under DP: parallel.GanDataParallel itself (all-reduce of the trained group's slice, Adam with
 # grad_scale 1/world) driven over gloo with an oracle-backed stand-in for the device engine.
