@@ -2,7 +2,7 @@ import time, torch, numpy as np, sys
 sys.path.insert(0, '.')
 from unsupervised_anomaly_detection_brain_mri_amd.engine import Engine, rng_fill
 from unsupervised_anomaly_detection_brain_mri_amd.parallel import DataParallelStep
-from oracle.vae import synthetic_slices
+from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import synthetic_slices
 B=64
 eng = Engine('VAE', 128, 128, 1, 8, 128, max_batch=B, device='cuda:0', math='bf16x3')
 x = torch.from_numpy(synthetic_slices(B, 128, 128, seed=1)).cuda()
