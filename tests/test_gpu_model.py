@@ -119,6 +119,33 @@ def test_segmented_backward_equals_the_whole_one(arch, h, zdim, n):
     eng.close()
 
 
+def test_committed_model_fixture():
+    """The handle against tests/golden/model_golden.npz (the oracle frozen at VAE 32 x 32, 2 slices; tests/golden/make_model_golden.py holds the
+    inputs' recipe): x_hat, the scalars and every gradient tensor's sum, in both math modes."""
+    import os
+    from tests.golden import make_model_golden as mk
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'model_golden.npz'))
+    m, p, x = mk.case()
+    flat = mk.INTER * mk.INTER * p['Bottleneck/conv2d/kernel'].shape[-1]
+    eps, masks = mk.noise(np.random.default_rng(100), flat)
+    p32 = {k: v.astype(np.float32) for k, v in p.items()}
+    for math in ('f32', 'bf16x3'):
+        eng = Engine('VAE', mk.H, mk.H, 1, mk.INTER, mk.ZDIM, max_batch=mk.N, math=math)
+        eng.set_params(p32)
+        got = eng.forward(x.astype(np.float32), eps.astype(np.float32), {k: v.astype(np.float32) for k, v in masks.items()}, want_backward=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        assert_close(got['x_hat'].cpu().numpy(), G['x_hat'], name='x_hat')
+        sc = got['scalars'].cpu().numpy()
+        np.testing.assert_allclose(sc[:3], G['scalars'], rtol=1e-4)
+        grads = eng.get_grads()
+        for name, s_ref, a_ref in zip(G['grad_names'], G['grad_sum'], G['grad_abs_sum']):
+            g = grads[str(name)].astype(np.float64)
+            assert abs(g.sum() - s_ref) <= 5e-4 * a_ref + 1e-9, (math, name)
+            assert abs(np.abs(g).sum() - a_ref) <= 5e-4 * a_ref + 1e-9, (math, name)
+        eng.close()
+
+
 def test_train_trajectory_vae_matches_oracle():
     """12 Adam steps from fixed init + fixed eps/masks (SURVEY.md §4 build-side plan): loss trajectory and final
     weights track the fp64 oracle.  lr is kept small enough for a monotone descent: with lr=1e-3 this problem overshoots
