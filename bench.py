@@ -458,6 +458,7 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--quick', action='store_true', help='A/B runs: skip the CPU baseline, the other math mode and the trainer-loop leg')
     ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'bf16x3'), choices=['f32', 'bf16x3', 'bf16x3_all'],
                     help='bf16x3 (default): split-bf16 products on the bf16 matrix cores, fp32 accumulate, parity 1e-4 vs the '
                          'fp32 oracle; f32: exact fp32 MFMA')
@@ -609,7 +610,7 @@ def main():
     roof, kernels = profiled(args.math)
     # the other math mode, same handle, for the record (rank 0 / single GPU only; not the headline value)
     other = None
-    if world == 1:
+    if world == 1 and not args.quick:
         om = 'f32' if args.math == 'bf16x3' else 'bf16x3'
         eng.set_math(om)
         odt, _ = timed(args.steps, max(2, args.warmup))
@@ -641,7 +642,7 @@ def main():
     # the reference's unit of work is the process() loop (trainers/VAE.py:76-103): one TRAIN epoch of trainers.VAE on an HBM-resident
     # slice set -- batch gather, noise and scalar bookkeeping included -- next to the bare step above
     loop = None
-    if world == 1 and not cevae and args.arch == 'VAE':
+    if world == 1 and not cevae and args.arch == 'VAE' and not args.quick:
         from unsupervised_anomaly_detection_brain_mri_amd.models import variational_autoencoder
         from unsupervised_anomaly_detection_brain_mri_amd.trainers import VAE, Phase
         from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_config, get_options
@@ -706,7 +707,7 @@ def main():
             res['trainer_loop'] = loop
         if allreduce:
             res['allreduce'] = allreduce
-        if world == 1 and not args.no_cpu_baseline and not cevae:
+        if world == 1 and not args.no_cpu_baseline and not args.quick and not cevae:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))
     if world > 1:

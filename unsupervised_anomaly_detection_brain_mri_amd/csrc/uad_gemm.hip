@@ -45,6 +45,11 @@ struct ConvGemmArgs {
     unsigned long long* dbgbuf;   // per-phase clock stamps of a few workgroups (UAD_DBG & 8)
     int dbg;       // ablation switches for kernel tuning (UAD_DBG): 1 = no epilogue stores, 2 = no MFMA loop, 4 = no staging
     int math16;    // generic kernel: bf16x3 products (conv_gemm16_kernel) where the tile shape allows
+    // plane-group tensors (uad_conv16s.inc): the A operand already activated and split into bf16 hi | lo groups (replaces A + xf), and an
+    // optional second output in that form -- the activated value under oxf (EPI_BIAS) or the raw gradient (EPI_BWD_ACT)
+    const uint4* Apg = nullptr;
+    uint4* OutPg = nullptr;
+    UadXform oxf;
 };
 
 __device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int lws, int& n, int& i, int& j) {
@@ -2188,6 +2193,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     if (stp) stp[5] = wall_clock64();
 }
 
+#include "uad_conv16s.inc"
+
 template <int TH, int TW, int CK, int WGM, int WGN>
 constexpr size_t conv5_f16_lds_bytes() {
     return (size_t)2 * (2 * TH + 3) * (2 * TW + 3) * (CK + 8) * 2 + (size_t)3 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
@@ -3465,6 +3472,13 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
                 // class-sequential kernel whenever the workgroup's whole channel range fits in LDS (CA == cst * nsplit)
                 const int cst = (a.CA % p.nsplit == 0) ? a.CA / p.nsplit : 0;
                 const bool seq = !getenv("UAD_NO_D16");
+                const bool lp = seq && conv5_d16s_takes(a);      // lane = pixel generation (uad_conv16s.inc)
+                if (lp && p.sc.BN == 64 && cst == 128) launch_conv5_d16s<8, 8, 128, 2, 2>(a, grid, st);
+                else if (lp && p.sc.BN == 64 && cst == 64) launch_conv5_d16s<8, 8, 64, 2, 2>(a, grid, st);
+                else if (lp && p.sc.BN == 64 && cst == 32) launch_conv5_d16s<8, 8, 32, 2, 2>(a, grid, st);
+                else if (lp && p.sc.BN == 32 && cst == 64) launch_conv5_d16s<8, 16, 64, 4, 1>(a, grid, st);
+                else if (lp && p.sc.BN == 32 && cst == 32) launch_conv5_d16s<8, 16, 32, 4, 1>(a, grid, st);
+                else
                 if (p.sc.BN == 64) {
                     if (seq && cst == 128) launch_conv5_d16<8, 8, 128, 2, 2>(a, grid, st);
                     else if (seq && cst == 64) launch_conv5_d16<8, 8, 64, 2, 2>(a, grid, st);

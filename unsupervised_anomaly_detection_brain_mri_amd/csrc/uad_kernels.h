@@ -22,10 +22,10 @@ struct UadConvDesc {
 // LeakyReLU/ReLU of the producer layer, applied by the consumer).  scale == nullptr
 // means identity.
 struct UadXform {
-    const float* scale;   // gamma (or a ready-made scale when mult == 1)
-    const float* shift;   // beta
-    float alpha;
-    float mult;           // scale multiplier: 1/sqrt(1+eps) of the frozen-stats BN
+    const float* scale = nullptr;   // gamma (or a ready-made scale when mult == 1)
+    const float* shift = nullptr;   // beta
+    float alpha = 1.f;
+    float mult = 1.f;     // scale multiplier: 1/sqrt(1+eps) of the frozen-stats BN
     // F-kind bf16x3 kernel only ("final-backward on load", GMVAE restoration): the staged value becomes
     //   d loss / d c = dxhat[pixel] * wf[ch] * lrelu'(scale*c + shift) * scale     instead of lrelu(scale*c + shift),
     // i.e. the big operand is the last block's PRE-BN output and the loss gradient is never materialised.
