@@ -458,6 +458,7 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rounds', type=int, default=5, help='timed regions of --steps steps each; the MEDIAN round is reported (ms_per_step, value)')
     ap.add_argument('--quick', action='store_true', help='A/B runs: skip the CPU baseline, the other math mode and the trainer-loop leg')
     ap.add_argument('--math', default=os.environ.get('UAD_BENCH_MATH', 'bf16x3'), choices=['f32', 'bf16x3', 'bf16x3_all'],
                     help='bf16x3 (default): split-bf16 products on the bf16 matrix cores, fp32 accumulate, parity 1e-4 vs the '
@@ -539,28 +540,34 @@ def main():
         eps, masks = draw()
         return dp.train_step(x, eps, masks, lr=1e-4, beta1=0.5, want_l1=True, want_latents=False, **extra)
 
-    def timed(steps, warmup):
+    def timed(steps, warmup, rounds=1):
+        """`rounds` back-to-back timed regions of exactly `steps` steps each, every one bracketed by barrier + synchronize on both sides
+        and reduced with MAX over the ranks; returns (seconds of the MEDIAN round, last loss, [ms per step of every round])."""
         for _ in range(warmup):
             out = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        per_round = []
+        for _ in range(max(1, rounds)):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            per_round.append(dt)
+        dt = float(np.median(per_round))
         loss = float(out['scalars'][2].item())
         assert np.isfinite(loss) or os.environ.get('UAD_BENCH_ALLOW_NAN'), 'loss diverged'
-        return dt, loss
+        return dt, loss, [round(t / steps * 1e3, 4) for t in per_round]
 
     def profiled(math):
         """Roofline leg: per-launch-group HIP-event timing of the same step (profiling pass after the timed region)."""
@@ -606,24 +613,34 @@ def main():
                 'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'instruction': note}
         return roof, kernels
 
-    dt, loss = timed(args.steps, args.warmup)
+    dt, loss, round_ms = timed(args.steps, args.warmup, args.rounds)
     roof, kernels = profiled(args.math)
     # the other math mode, same handle, for the record (rank 0 / single GPU only; not the headline value)
     other = None
     if world == 1 and not args.quick:
         om = 'f32' if args.math == 'bf16x3' else 'bf16x3'
         eng.set_math(om)
-        odt, _ = timed(args.steps, max(2, args.warmup))
+        odt, _, oround_ms = timed(args.steps, max(2, args.warmup), args.rounds)
         oroof, _ = profiled(om)
         other = {'math': om, 'value': round(BATCH * args.steps / odt, 1), 'ms_per_step': round(odt / args.steps * 1e3, 4),
-                 'roofline': oroof}
+                 'round_ms_per_step': oround_ms, 'roofline': oroof}
         eng.set_math(args.math)
 
     # per-segment gradient all-reduce, timed on its own after the timed region (N > 1): what the backward has to hide
     allreduce = None
     if world > 1:
+        # communication the backward did NOT hide = (step with the gradient all-reduces) - (same step without them), same ranks, same run
+        dp.no_allreduce = True
+        ndt, _, nround_ms = timed(args.steps, 2, args.rounds)
+        dp.no_allreduce = False
+        exposed_ms = (dt - ndt) / args.steps * 1e3
         names = {_lib.SEG_DECODER: 'decoder', _lib.SEG_BOTTLENECK: 'bottleneck', _lib.SEG_ENCODER_HI: 'encoder_deep', _lib.SEG_ENCODER_LO: 'encoder_first_blocks'}
         allreduce = {'ranks': dist.get_world_size(), 'backend': dist.get_backend() + (' (RCCL over xGMI)' if not rehearsal else ' (single-GPU rehearsal)'),
+                     'buckets': dp.buckets, 'bucket_bytes': [int(c * 4) for _, _, c in dp.plan],
+                     'exposed_comm_ms': round(exposed_ms, 4), 'ms_per_step_without_allreduce': round(ndt / args.steps * 1e3, 4),
+                     'round_ms_per_step_without_allreduce': nround_ms,
+                     'env': {k: os.environ.get(k) for k in ('NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS', 'RCCL_MSCCL_ENABLE',
+                                                            'UAD_DP_BUCKETS', 'HSA_ENABLE_IPC_MODE_LEGACY')},
                      'segments': {}}
         for seg, (off, cnt) in dp.segs.items():
             if cnt == 0:
@@ -678,6 +695,7 @@ def main():
             'metric': 'MRI slices/sec VAE train step (128x128, bs=64)' if not cevae else
                       f'MRI slices/sec ceVAE train step (128x128, bs={BATCH}/GPU)',
             'value': round(value, 1), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'rounds': args.rounds, 'round_ms_per_step': round_ms,      # every round times exactly `steps` steps; value / ms_per_step = the median round
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
             'config': {'workload': ('BASELINE.json configs[1]: VAE 128x128x1 slices, batch 64 per GPU, '

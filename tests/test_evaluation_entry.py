@@ -55,6 +55,12 @@ class HostEvalEngine:
     def scores(self, predictions, labels):
         return _HostScores(predictions.numpy() if isinstance(predictions, torch.Tensor) else predictions, labels)
 
+    def mc_stats(self, recs, mask=None):
+        r = recs.numpy().astype(np.float64)
+        if mask is not None:
+            r = r * mask.numpy()
+        return torch.from_numpy(r.mean(axis=0).astype(np.float32)), torch.from_numpy(r.var(axis=0).astype(np.float32))
+
     def cc_filter(self, volume, max_voxels=7):
         return torch.from_numpy(Evaluation.filter_3d_connected_components(volume.numpy(), max_voxels).astype(np.float32))
 
@@ -135,6 +141,33 @@ def test_evaluate_with_the_reference_signature(tmp_path):
     pred = Evaluation.filter_3d_connected_components(np.squeeze(dd > thr))
     assert ev['DiceScore'] == pytest.approx(Metrics.dice(pred, ll), abs=1e-9)
     assert 0.0 < ev['diff_AUPRC'] <= 1.0 and 0.0 < ev['diff_AUC'] <= 1.0
+
+
+def test_evaluate_keeps_the_monte_carlo_dropout_outputs(tmp_path):
+    """numMonteCarloSamples > 1 through the reference-signature entry point: K dropout passes per batch, and the epistemic variance + its
+    50-bin histogram (utils/Evaluation.py:238-266, 404-408) reach the result exactly as they do through evaluate_arrays."""
+    class NoisyBlur(BlurModel):
+        def __init__(self, tmp, bs=5):
+            super().__init__(tmp, bs)
+            self.rng = np.random.default_rng(5)
+
+        def reconstruct(self, x, dropout=False, eps=None):
+            out = super().reconstruct(x, dropout, eps)
+            if dropout:
+                out['reconstruction'] = out['reconstruction'] + self.rng.normal(0, 0.05, out['reconstruction'].shape).astype(np.float32)
+            return out
+
+    opt = dict(_opts(tmp_path), numMonteCarloSamples=3)
+    ds = SyntheticPatientDataset(n_val=1, n_test=2, slices=12, native=80, h=64, w=64, seed=1, slice_start=0, slice_end=12)
+    model = NoisyBlur(tmp_path)
+    ev = Evaluation.evaluate(ds, model, opt, epoch='1')
+    assert ev['epistemic_variance'].shape == (24, 64, 64) and ev['epistemic_variance'].max() > 0
+    assert len(ev['uncertaintyHistogram']) == 50 and sum(ev['uncertaintyHistogram']) > 0
+    assert len(model.calls) == 3 * 3 * 2                      # K passes x 3 batches x 2 patients
+    saved = np.load(os.path.join(ev['eval_dir'], 'evalPC.npy'), allow_pickle=True).item()
+    assert saved['uncertaintyHistogram'] == ev['uncertaintyHistogram'] and 'epistemic_variance' not in saved
+    ev0 = Evaluation.evaluate(ds, BlurModel(tmp_path), _opts(tmp_path), epoch='1')
+    assert 'epistemic_variance' not in ev0 and 'uncertaintyHistogram' not in ev0
 
 
 def test_threshold_on_validation_patients_and_fixed_threshold_evaluation(tmp_path):

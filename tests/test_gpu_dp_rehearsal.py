@@ -112,6 +112,34 @@ def _worker(rank, world, port, tmp, q):
                                                mean_diff=float(np.abs(tw_dp - tw_1).mean()), mean_step=float(np.abs(tw_1 - tw0).mean()))))
                     sm.engine.close()
                 tm.engine.close()
+                # UAD_DP_BUCKETS: the same step with the four gradient segments merged into 3 / 2 / 1 collectives (parallel.bucket_plan) and with
+                # the all-reduces skipped (bench.py's exposed-communication leg): merged or not, two ranks add the same two numbers per element,
+                # so every bucketing ends on the bits of the default one, on both replicas
+                from unsupervised_anomaly_detection_brain_mri_amd.parallel import DataParallelStep
+                from unsupervised_anomaly_detection_brain_mri_amd.trainers import Phase as _Ph
+                ends = {}
+                for bk in (4, 3, 2, 1):
+                    bm = _make(case, world, os.path.join(tmp, f'bk{bk}_{rank}'), n // world)
+                    bm.engine.set_params(w0); bm.engine.reset_optimizer()
+                    bm.dp = DataParallelStep(bm.engine, world, buckets=bk)
+                    assert len(bm.dp.plan) == bk
+                    bm.step(x[sl], _Ph.TRAIN, eps=e_loc, fetch_maps=False)
+                    ends[bk] = bm.engine.get_buffer_host(_lib.BUF_PARAMS)
+                    bm.engine.close()
+                nm = _make(case, world, os.path.join(tmp, f'noar_{rank}'), n // world)
+                nm.engine.set_params(w0); nm.engine.reset_optimizer()
+                nm.dp = DataParallelStep(nm.engine, world, no_allreduce=True)
+                nm.step(x[sl], _Ph.TRAIN, eps=e_loc, fetch_maps=False)
+                w_local = nm.engine.get_buffer_host(_lib.BUF_PARAMS)
+                nm.engine.close()
+                tb = torch.from_numpy(np.stack([ends[b] for b in (4, 3, 2, 1)]))
+                gb = [torch.zeros_like(tb) for _ in range(world)]
+                dist.all_gather(gb, tb)
+                if rank == 0:
+                    q.put(('VAE_buckets', dict(same_as_default=[bool(np.array_equal(ends[4], ends[b])) for b in (3, 2, 1)],
+                                               replicas=float((gb[0] - gb[1]).abs().max()),
+                                               default_is_dp=bool(np.array_equal(ends[4], w_dp)),
+                                               local_differs=bool(not np.array_equal(w_local, w_dp)))))
             t = torch.from_numpy(w_dp)
             both = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(both, t)
@@ -137,6 +165,8 @@ def test_two_rank_train_step_equals_big_batch(tmp_path):
     while not q.empty():
         k, v = q.get()
         res[k] = v
+    b = res['VAE_buckets']
+    assert b['same_as_default'] == [True, True, True] and b['replicas'] == 0.0 and b['default_is_dp'] and b['local_differs'], b
     r = res['VAE_process']
     assert r['loss_dp'] == pytest.approx(r['loss_1'], rel=2e-4) and r['kl_dp'] == pytest.approx(r['kl_1'], rel=2e-4), r     # same batches, same noise
     assert r['mean_diff'] <= 0.05 * r['mean_step'], r

@@ -1448,7 +1448,7 @@ int uad_gan_tensor_info(const uad_gan_t* m, int idx, char* name, int name_cap, l
 float* uad_gan_buffer(uad_gan_t* m, int which) {
     if (!m) return nullptr;
     switch (which) {
-        case UAD_BUF_PARAMS: return m->params;
+        case UAD_BUF_PARAMS: m->packed_valid = false; return m->params;      // the caller may write through the pointer (DP broadcast): repack before the next phase
         case UAD_BUF_GRADS: return m->grads;
         case UAD_BUF_ADAM_M: return m->adam_m;
         case UAD_BUF_ADAM_V: return m->adam_v;

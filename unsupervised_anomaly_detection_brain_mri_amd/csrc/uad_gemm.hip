@@ -50,6 +50,8 @@ struct ConvGemmArgs {
     const uint4* Apg = nullptr;
     uint4* OutPg = nullptr;
     UadXform oxf;
+    int stagger = 0;   // UAD_STAGGER: the second wave of workgroups (linear ids [256, 512)) sleeps this many x 8k cycles before it starts, so that
+                       // the two workgroups resident on a CU do not walk through their staging / MFMA / epilogue phases in lockstep
 };
 
 __device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int lws, int& n, int& i, int& j) {
@@ -3439,25 +3441,40 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
     const UadConvDesc& d = a.d;
     a.nsplit = 1; a.out_elems = p.out_elems;
     { static const int dbg = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0; a.dbg = dbg; a.dbgbuf = nullptr; }
+    { static const int stg = getenv("UAD_STAGGER") ? atoi(getenv("UAD_STAGGER")) : 0; a.stagger = stg; }
     static unsigned long long* dbgbuf = nullptr;
     static int dbg_calls = 0;
     const bool dbg_f = (a.dbg & 16) && f_type && a.Wp16 && a.Nn == 64 && a.CA == 32 && dbg_calls >= 40 && dbg_calls < 44;
     if ((a.dbg & 16) && f_type && a.Wp16 && a.Nn == 64 && a.CA == 32 && !dbg_f) ++dbg_calls;
-    const bool dbg_this = dbg_f;
+    // UAD_DBG & 64: phase clocks of the lane = pixel D-kind kernel; UAD_DBG_SHAPE="Nn,CA,kind" picks the launch (default 32,32,2 = dec3.fwd)
+    static int dq_nn = 32, dq_ca = 32, dq_kind = 2, dq_init = 0;
+    if (!dq_init) { dq_init = 1; if (const char* e = getenv("UAD_DBG_SHAPE")) sscanf(e, "%d,%d,%d", &dq_nn, &dq_ca, &dq_kind); }
+    const bool dq_match = (a.dbg & 64) && !f_type && a.Wp16 && a.Nn == dq_nn && a.CA == dq_ca && a.ep.kind == dq_kind;
+    const bool dbg_d = dq_match && dbg_calls >= 40 && dbg_calls < 43;
+    if (dq_match && !dbg_d) ++dbg_calls;
+    const bool dbg_this = dbg_f || dbg_d;
     if (dbg_this) {
-        if (!dbgbuf) (void)hipMalloc((void**)&dbgbuf, 8 * 4 * 16 * sizeof(unsigned long long));
-        (void)hipMemsetAsync(dbgbuf, 0, 8 * 4 * 16 * sizeof(unsigned long long), st);
+        if (!dbgbuf) (void)hipMalloc((void**)&dbgbuf, 8 * 4 * 32 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbgbuf, 0, 8 * 4 * 32 * sizeof(unsigned long long), st);
         a.dbgbuf = dbgbuf;
     }
-    struct DbgDump { bool on; hipStream_t st; unsigned long long* buf; int* calls;
-        ~DbgDump() { if (!on) return; (void)hipStreamSynchronize(st); unsigned long long h[8 * 4 * 16];
+    struct DbgDump { bool on; hipStream_t st; unsigned long long* buf; int* calls; int dstride;
+        ~DbgDump() { if (!on) return; (void)hipStreamSynchronize(st); unsigned long long h[8 * 4 * 32];
             (void)hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost); ++*calls;
-            for (int b = 0; b < 8; b += 3) for (int w = 0; w < 4; w += 3) { const unsigned long long* p = h + (b * 4 + w) * 16;
+            for (int b = 0; b < 8; b += 3) for (int w = 0; w < 4; w += 3) { const unsigned long long* p = h + (b * 4 + w) * (dstride);
+                if (!p[0]) continue;
+                if (p[11]) { fprintf(stderr, "[d16s wg%d w%d] (x10ns) stage=%llu bar=%llu", b, w, p[1] - p[0], p[2] - p[1]);
+                    unsigned long long prev = p[2];
+                    for (int c = 0; c < 4; ++c) { fprintf(stderr, " | cls%d mma=%llu epi=%llu", c, p[3 + 2 * c] - prev, p[4 + 2 * c] - p[3 + 2 * c]); prev = p[4 + 2 * c]; }
+                    fprintf(stderr, " | tail=%llu end=%llu total=%llu", p[11] - prev, p[12] ? p[12] - p[11] : 0ull, (p[12] ? p[12] : p[11]) - p[0]);
+                    fprintf(stderr, " || pre=%llu issue=%llu params=%llu bar=%llu conv=%llu", p[16] - p[0], p[17] - p[16], p[18] - p[17], p[19] - p[18], p[1] - p[19]);
+                    if (p[22]) fprintf(stderr, " || e.out=%llu e.sum=%llu e.bar=%llu e.fin=%llu", p[20] - p[11], p[21] - p[20], p[22] - p[21], p[12] - p[22]);
+                    fprintf(stderr, "\n"); continue; }
                 if (p[5]) { fprintf(stderr, "[f16 wg%d w%d] (x10ns) load+convert=%llu barrier=%llu mma=%llu barrier=%llu epilogue=%llu | total=%llu\n", b, w, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[5] - p[0]); continue; }
                 fprintf(stderr, "[d16 wg%d w%d] stage=%llu bstore+bar=%llu", b, w, p[1] - p[0], p[2] - p[1]);
                 unsigned long long prev = p[2];
                 for (int c = 0; c < 4; ++c) { fprintf(stderr, " | cls%d mma=%llu epi=%llu", c, p[3 + 2 * c] - prev, p[4 + 2 * c] - p[3 + 2 * c]); prev = p[4 + 2 * c]; }
-                fprintf(stderr, " | total=%llu\n", prev - p[0]); } } } dbg_dump{dbg_this, st, dbgbuf, &dbg_calls};
+                fprintf(stderr, " | total=%llu\n", prev - p[0]); } } } dbg_dump{dbg_this, st, dbgbuf, &dbg_calls, dbg_d ? 32 : 16};
     if (p.path == PATH_SPATIAL) {
         float* out = a.Out;
         if (p.nsplit > 1) { a.Out = ws; a.nsplit = p.nsplit; a.out_final = out; }
@@ -3473,11 +3490,11 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
                 const int cst = (a.CA % p.nsplit == 0) ? a.CA / p.nsplit : 0;
                 const bool seq = !getenv("UAD_NO_D16");
                 const bool lp = seq && conv5_d16s_takes(a);      // lane = pixel generation (uad_conv16s.inc)
-                if (lp && p.sc.BN == 64 && cst == 128) launch_conv5_d16s<8, 8, 128, 2, 2>(a, grid, st);
-                else if (lp && p.sc.BN == 64 && cst == 64) launch_conv5_d16s<8, 8, 64, 2, 2>(a, grid, st);
-                else if (lp && p.sc.BN == 64 && cst == 32) launch_conv5_d16s<8, 8, 32, 2, 2>(a, grid, st);
-                else if (lp && p.sc.BN == 32 && cst == 64) launch_conv5_d16s<8, 16, 64, 4, 1>(a, grid, st);
-                else if (lp && p.sc.BN == 32 && cst == 32) launch_conv5_d16s<8, 16, 32, 4, 1>(a, grid, st);
+                if (lp && p.sc.BN == 64 && cst == 128) launch_conv5_d16s_bn64<128>(a, grid, st);
+                else if (lp && p.sc.BN == 64 && cst == 64) launch_conv5_d16s_bn64<64>(a, grid, st);
+                else if (lp && p.sc.BN == 64 && cst == 32) launch_conv5_d16s_bn64<32>(a, grid, st);
+                else if (lp && p.sc.BN == 32 && cst == 64) launch_conv5_d16s_bn32<64>(a, grid, st);
+                else if (lp && p.sc.BN == 32 && cst == 32) launch_conv5_d16s_bn32<32>(a, grid, st);
                 else
                 if (p.sc.BN == 64) {
                     if (seq && cst == 128) launch_conv5_d16<8, 8, 128, 2, 2>(a, grid, st);

@@ -165,9 +165,13 @@ class Engine(_EvalOps):
     # ---------------------------------------------------------------- buffers
     def buffer(self, which=_lib.BUF_PARAMS):
         """Zero-copy torch view (1-D fp32) of a handle-owned flat buffer."""
-        if which not in self._views:
+        # Every access of the parameter buffer goes through the library: uad_buffer(PARAMS) waits for a weight repack still running on the
+        # handle's side stream and marks the packed copies stale, so a write through the (cached) view -- a second DP broadcast, a checkpoint
+        # restore -- can neither race with the repack nor leave the next forward on old packed kernels.
+        if which not in self._views or which == _lib.BUF_PARAMS:
             ptr = self.lib.uad_buffer(self.handle, which)
-            self._views[which] = torch.as_tensor(_DevArray(ptr, self.nparams), device=self.device)
+            if which not in self._views:
+                self._views[which] = torch.as_tensor(_DevArray(ptr, self.nparams), device=self.device)
         return self._views[which]
 
     def grad_segment(self, seg):

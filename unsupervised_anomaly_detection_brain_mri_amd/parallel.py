@@ -7,6 +7,8 @@ the single-device big batch up to fp32 summation order.  The flat fp32 gradient 
 Decoder; the backward finishes the segments in the order Decoder, Bottleneck, Encoder and each segment's all-reduce
 is issued (async, on RCCL's stream) as soon as its kernels are enqueued, overlapping with the remaining backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -26,14 +28,49 @@ def allreduce_segments(grads_flat, segments, world, async_op=True):
     return works
 
 
-class DataParallelStep:
-    """train_step() for rank-local shards; equal per-rank batch sizes are assumed (weak scaling)."""
+def bucket_plan(segs, buckets):
+    """Which contiguous slice of the flat gradient buffer is all-reduced after which backward segment.
+    segs: {segment: (offset, count)}; buckets 4 = one all-reduce per segment (DECODER, BOTTLENECK, ENCODER_HI, ENCODER_LO: the most overlap,
+    four collective latencies), 3 = Decoder | Encoder-deep + Bottleneck | first encoder blocks, 2 = everything but the first two encoder
+    blocks' kernels in ONE collective issued two layers before the backward ends (6.8 MB hidden behind the last two layers) + the 0.2 MB rest,
+    1 = the whole buffer after the last backward kernel (one latency, no overlap).  The buffer is laid out Encoder(LO | HI) | Bottleneck |
+    Decoder, so every merged bucket is one contiguous slice.  Returns [(segment after which to issue, offset, count)]."""
+    def span(parts):
+        parts = [segs[p] for p in parts if segs[p][1] > 0]
+        if not parts:
+            return 0, 0
+        lo = min(o for o, _ in parts)
+        hi = max(o + c for o, c in parts)
+        assert hi - lo == sum(c for _, c in parts), 'merged gradient segments must be contiguous'
+        return lo, hi - lo
+    if buckets == 4:
+        groups = [(s, (s,)) for s in SEGMENT_ORDER]
+    elif buckets == 3:
+        groups = [(_lib.SEG_DECODER, (_lib.SEG_DECODER,)), (_lib.SEG_ENCODER_HI, (_lib.SEG_ENCODER_HI, _lib.SEG_BOTTLENECK)),
+                  (_lib.SEG_ENCODER_LO, (_lib.SEG_ENCODER_LO,))]
+    elif buckets == 2:
+        groups = [(_lib.SEG_ENCODER_HI, (_lib.SEG_ENCODER_HI, _lib.SEG_BOTTLENECK, _lib.SEG_DECODER)), (_lib.SEG_ENCODER_LO, (_lib.SEG_ENCODER_LO,))]
+    elif buckets == 1:
+        groups = [(_lib.SEG_ENCODER_LO, SEGMENT_ORDER)]
+    else:
+        raise ValueError('UAD_DP_BUCKETS must be 4, 3, 2 or 1')
+    return [(after,) + span(parts) for after, parts in groups]
 
-    def __init__(self, engine, world=None):
+
+class DataParallelStep:
+    """train_step() for rank-local shards; equal per-rank batch sizes are assumed (weak scaling).
+    buckets (default: env UAD_DP_BUCKETS, else 4): how the four gradient segments are merged into all-reduce calls (bucket_plan).
+    no_allreduce (default: env UAD_DP_NO_ALLREDUCE): skip the collectives -- the step then trains on the local gradient; bench.py uses the
+    difference of the two step times as the communication the backward did not hide."""
+
+    def __init__(self, engine, world=None, buckets=None, no_allreduce=None):
         self.eng = engine
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.grads = engine.buffer(_lib.BUF_GRADS) if self.world > 1 else None
         self.segs = {s: engine.grad_segment(s) for s in SEGMENT_ORDER}
+        self.buckets = int(buckets if buckets is not None else os.environ.get('UAD_DP_BUCKETS', '4'))
+        self.plan = bucket_plan(self.segs, self.buckets)
+        self.no_allreduce = bool(int(os.environ.get('UAD_DP_NO_ALLREDUCE', '0'))) if no_allreduce is None else bool(no_allreduce)
 
     def broadcast_params(self, src=0):
         if self.world > 1:
@@ -47,10 +84,11 @@ class DataParallelStep:
             eng.adam_step(lr, beta1, beta2, adam_eps, 1.0)
             return out
         works = []
+        issue = {after: (off, cnt) for after, off, cnt in self.plan}
         for seg in SEGMENT_ORDER:
             eng.backward(seg)
-            off, cnt = self.segs[seg]
-            if cnt > 0:          # the spatial AE has no bottleneck variables
+            off, cnt = issue.get(seg, (0, 0))
+            if cnt > 0 and not self.no_allreduce:          # (the spatial AE has no bottleneck variables)
                 works.append(dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()

@@ -200,6 +200,11 @@ class AEMODEL(DLMODEL):
         lo = self.rank * bs
         return tuple(None if a is None else a[lo:lo + bs] for a in got)
 
+    def _num_batches(self, dataset, phase):
+        """Steps of one epoch: the dataset is walked in GLOBAL batches of config.batchsize * world slices (every rank takes its share, _shard)."""
+        phase = Phase(phase) if not isinstance(phase, Phase) else phase
+        return dataset.num_batches(self.config.batchsize * self.dp.world, set=phase.value)
+
     def process(self, dataset, epoch, phase, optim=None):       # trainers/VAE.py:76-103
         """One epoch.  The loop body only ENQUEUES work: the batch comes from the dataset (device tensors when it is an HBM-resident
         utils.slice_cache.DeviceDataset), the noise is drawn on the device, and every step's scalar fetches are copied into one row of a
@@ -213,7 +218,7 @@ class AEMODEL(DLMODEL):
         # the reference fetches the maps of EVERY step for its TensorBoard image strip (trainer_utils.get_summary_dict); here that is opt-in
         # (config.tfSummaryImages): the maps are 4 MB of D2H per step
         want_images = bool(getattr(self.config, 'tfSummaryImages', False)) and bool(getattr(self.config, 'useTensorboard', False))
-        num_batches = dataset.num_batches(self.config.batchsize * self.dp.world, set=phase.value)
+        num_batches = self._num_batches(dataset, phase)
         table = torch.zeros((max(num_batches, 1), 8), device=self.engine.device)
         for idx in range(num_batches):
             batch, _, _ = self._shard(dataset, phase)
@@ -249,9 +254,9 @@ class AEMODEL(DLMODEL):
         scalars = defaultdict(list)
         visuals = []
         want_images = bool(getattr(self.config, 'tfSummaryImages', False)) and bool(getattr(self.config, 'useTensorboard', False))
-        num_batches = dataset.num_batches(self.config.batchsize, set=phase.value)
+        num_batches = self._num_batches(dataset, phase)
         for idx in range(num_batches):
-            batch, _, _ = dataset.next_batch(self.config.batchsize, set=phase.value)
+            batch, _, _ = self._shard(dataset, phase)
             run = self.step(batch, phase, fetch_maps=want_images)
             print(f'Epoch ({phase.value}): [{epoch:2d}] [{idx:4d}/{num_batches:4d}] loss: {run["loss"]:.8f}')
             for k, v in run.items():
@@ -277,6 +282,10 @@ class AEMODEL(DLMODEL):
             if self.rank == 0:                      # replicas are identical: one writer
                 self.save(self.checkpointDir, last_epoch)
             val_scalars = self.process(dataset, epoch, Phase.VAL)
+            if 'loss' not in val_scalars:
+                # no full validation batch (num_batches floors, dataloaders/BRAINWEB.py:406-409: e.g. fewer VAL slices than batchsize * world):
+                # nothing to stop early on -- the reference would raise KeyError here
+                continue
             best_cost, last_improvement, stop = indicate_early_stopping(val_scalars['loss'], best_cost, last_improvement)
             if stop:
                 print('Early stopping was triggered due to no improvement over the last 5 epochs')

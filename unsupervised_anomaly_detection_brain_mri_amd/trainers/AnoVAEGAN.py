@@ -84,9 +84,9 @@ class AnoVAEGAN(AEMODEL):
         last_epoch = self.load_checkpoint()
         for epoch in range(last_epoch, c.numEpochs):
             scalars = defaultdict(list)
-            num_batches = dataset.num_batches(c.batchsize, set=Phase.TRAIN.value)
+            num_batches = self._num_batches(dataset, Phase.TRAIN)
             for idx in range(num_batches):
-                batch, _, _ = dataset.next_batch(c.batchsize, set=Phase.TRAIN.value)
+                batch, _, _ = self._shard(dataset, Phase.TRAIN)
                 run = self.step(batch, Phase.TRAIN, fetch_maps=False)
                 run = {**run, **self.generator_step(batch)}
                 for _ in range(self.D_ITERS):

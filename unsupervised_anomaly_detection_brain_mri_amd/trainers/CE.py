@@ -67,9 +67,9 @@ class CE(AE):
     def process(self, dataset, epoch, phase, optim=None):       # CE.py:70-101
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
         scalars = defaultdict(list)
-        num_batches = dataset.num_batches(self.config.batchsize, set=phase.value)
+        num_batches = self._num_batches(dataset, phase)
         for idx in range(num_batches):
-            batch, _, brainmasks = dataset.next_batch(self.config.batchsize, return_brainmask=True, set=phase.value)
+            batch, _, brainmasks = self._shard(dataset, phase, return_brainmask=True)
             masked_batch = retrieve_masked_batch(batch, brainmasks, rng=getattr(self, 'mask_rng', None))    # drawn in every phase (:77), fed in TRAIN only (:91)
             run = self.step(batch, phase, x_ce=masked_batch if phase == Phase.TRAIN else None, fetch_maps=False)
             print(f'Epoch ({phase.value}): [{epoch:2d}] [{idx:4d}/{num_batches:4d}] loss: {run["loss"]:.8f}')

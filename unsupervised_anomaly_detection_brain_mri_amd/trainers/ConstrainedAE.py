@@ -103,9 +103,9 @@ class _LatentAE(AEMODEL):
                 self.process(dataset, epoch, Phase.TRAIN, optim=True)
             else:
                 scalars = defaultdict(list)
-                num_batches = dataset.num_batches(c.batchsize, set=Phase.TRAIN.value)
+                num_batches = self._num_batches(dataset, Phase.TRAIN)
                 for idx in range(num_batches):
-                    batch, _, _ = dataset.next_batch(c.batchsize, set=Phase.TRAIN.value)
+                    batch, _, _ = self._shard(dataset, Phase.TRAIN)
                     run = {}
                     for _ in range(self.D_ITERS if epoch <= 5 else 1):
                         run = self.step(batch, Phase.TRAIN, fetch_maps=False)

@@ -77,6 +77,7 @@ class DLMODEL(object):
         np.savez(os.path.join(checkpoint_dir, f'{model_name}-{step}.npz'),
                  params=eng.get_buffer_host(_lib.BUF_PARAMS), adam_m=eng.get_buffer_host(_lib.BUF_ADAM_M),
                  adam_v=eng.get_buffer_host(_lib.BUF_ADAM_V), adam_t=self._adam_steps(),
+                 noise_step=np.int64(getattr(self, 'noise_step', 0)),        # counter of the device noise generator: a resumed run continues the eps / mask sequence
                  names=np.array([n for n, _, _ in eng.spec]))
         with open(os.path.join(checkpoint_dir, 'checkpoint'), 'w') as f:
             f.write(f'model_checkpoint_path: "{model_name}-{step}"\n')
@@ -107,6 +108,9 @@ class DLMODEL(object):
             self.engine.set_buffer_host(_lib.BUF_ADAM_M, z['adam_m'])
             self.engine.set_buffer_host(_lib.BUF_ADAM_V, z['adam_v'])
             self._set_adam_steps(z['adam_t'])
+            if hasattr(self, 'noise_step'):
+                # older checkpoints carry no counter: the optimizer's step count is the number of TRAIN draws so far
+                self.noise_step = int(z['noise_step']) if 'noise_step' in z.files else int(np.max(z['adam_t']))
             counter = int(next(re.finditer(r'(\d+)(?!.*\d)', name)).group(0))
             print(" [*] Success to read {}".format(name))
             return True, counter

@@ -105,9 +105,9 @@ class GMVAE_spatial(AEMODEL):
     def process(self, dataset, epoch, phase, optim=None, visualization_keys=None):     # GMVAE_spatial.py:135-166
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
         scalars = defaultdict(list)
-        num_batches = dataset.num_batches(self.config.batchsize, set=phase.value)
+        num_batches = self._num_batches(dataset, phase)
         for idx in range(num_batches):
-            batch, _, _ = dataset.next_batch(self.config.batchsize, set=phase.value)
+            batch, _, _ = self._shard(dataset, phase)
             run = self.step(batch, phase, fetch_maps=False)
             print(f'Epoch ({phase.value}): [{epoch:2d}] [{idx:4d}/{num_batches:4d}] loss: {run["loss"]:.8f}')
             for k, v in run.items():

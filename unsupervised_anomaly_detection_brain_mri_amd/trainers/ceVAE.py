@@ -88,9 +88,9 @@ class ceVAE(AEMODEL):
     def process(self, dataset, epoch, phase, optim=None, visualization_keys=None):       # ceVAE.py:86-117
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
         scalars = defaultdict(list)
-        num_batches = dataset.num_batches(self.config.batchsize, set=phase.value)
+        num_batches = self._num_batches(dataset, phase)
         for idx in range(num_batches):
-            batch, _, brainmasks = dataset.next_batch(self.config.batchsize, return_brainmask=True, set=phase.value)
+            batch, _, brainmasks = self._shard(dataset, phase, return_brainmask=True)
             masked_batch = retrieve_masked_batch(batch, brainmasks)        # drawn in every phase, used in TRAIN only
             run = self.step(batch, phase, masked_batch=masked_batch, fetch_maps=False)
             print(f'Epoch ({phase.value}): [{epoch:2d}] [{idx:4d}/{num_batches:4d}] loss: {run["loss"]:.8f}')

@@ -262,6 +262,8 @@ def _evaluate(datasetObj, modelObj, sampleDir, options, split="TEST", eps=None):
     patients = [datasetObj.patients[i] for i in datasetObj.get_patient_idx(split=split)]
     ev = {'x': [], 'labelmaps': [], 'l1reconstructionErrors': [], 'reconstructionTimes': []}
     diffs_dev = []
+    variances = []               # numMonteCarloSamples > 1: every patient's epistemic-variance volume (utils/Evaluation.py:238-266,404-408)
+    mc = int(options.get('numMonteCarloSamples') or 0) > 1
     used = []
     for p, patient in enumerate(patients):
         files = patient['filtered_files']
@@ -280,10 +282,13 @@ def _evaluate(datasetObj, modelObj, sampleDir, options, split="TEST", eps=None):
             d, l1 = evaluate_volume(modelObj, x, skull, options, eps, device_out=True, prior=prior_q)
             ev['reconstructionTimes'].append((time.time() - t0) / max(len(x), 1))
             diffs_dev.append(d)
+            if mc:
+                variances.append(modelObj.last_epistemic_variance.cpu().numpy())
             ev['x'].append(x); ev['labelmaps'].append(seg); ev['l1reconstructionErrors'] += list(l1)
             used.append(patient)
     print("Done.")
     ev['_diffs_device'] = diffs_dev
+    ev['_variances'] = variances
     ev['diffs'] = np.concatenate([d.cpu().numpy().astype(np.float64) for d in diffs_dev], axis=0) if diffs_dev else np.zeros((0,))
     ev['x'] = np.concatenate(ev['x'], axis=0) if ev['x'] else np.zeros((0,))
     ev['labelmaps'] = np.concatenate(ev['labelmaps'], axis=0) if ev['labelmaps'] else np.zeros((0,))
@@ -314,8 +319,9 @@ def evaluate(datasetPC, gan, options, epoch='last', description=None, eps=None):
     sample_dir = os.path.join(eval_dir, 'samples_test_PC')
     eval_pc, patients_pc = _evaluate(datasetPC, gan, sample_dir, options, split="TEST", eps=eps)
     diffs = eval_pc.pop('_diffs_device')
+    variances = eval_pc.pop('_variances')
     labels = [eval_pc['labelmaps'][sum(d.shape[0] for d in diffs[:k]):sum(d.shape[0] for d in diffs[:k + 1])] for k in range(len(diffs))]
-    ev = _score_diffs(gan, diffs, labels, options)
+    ev = _score_diffs(gan, diffs, labels, options, variances)
     for k in ('l1reconstructionErrorMean', 'l1reconstructionErrorVariance', 'l2reconstructionErrorMean', 'l2reconstructionErrorVariance',
               'reconstructionTimes'):
         ev[k] = eval_pc[k]
