@@ -1,11 +1,12 @@
 #!/bin/bash
 mkdir -p gpurun_out/r3
-for cfg in "UAD_DBG=$((64+256*40)) UAD_STAGGER=512"; do
-  echo "== $cfg"; env $cfg python bench.py --steps 60 --warmup 3 --quick --rounds 1 2>&1 >/dev/null | grep d16s | head -2
-done
-T="dec0.fwd dec1.fwd dec2.fwd dec3.fwd enc3.dgrad enc2.dgrad enc1.dgrad"
-for round in 1 2; do
-for cfg in "UAD_X=1" "UAD_STAGGER=512" "UAD_NO_PP=1"; do
-  env $cfg python bench.py --steps 40 --warmup 5 --quick > gpurun_out/r3/p.json 2>/dev/null
-  echo -n "[$cfg]: "; python tools/kshow.py gpurun_out/r3/p.json $T
+UAD_MATH=bf16x3 timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_scale_parity.py tests/test_gpu_cevae.py -x -q 2>&1 | tail -5
+T="enc1.fwd enc2.fwd enc3.fwd dec3.dgrad dec2.dgrad dec1.dgrad dec0.dgrad"
+for round in 1 2; do for v in A B; do
+  UAD_LIB=$PWD/ablibs/lib$v.so python bench.py --steps 40 --warmup 5 --quick > gpurun_out/r3/ab_$v.json 2>/dev/null
+  echo -n "$v: "; python tools/kshow.py gpurun_out/r3/ab_$v.json $T
 done; done
+for tp in 1 2 4 8; do
+  UAD_F16_TPW=$tp python bench.py --steps 40 --warmup 5 --quick > gpurun_out/r3/p.json 2>/dev/null
+  echo -n "[tpw $tp]: "; python tools/kshow.py gpurun_out/r3/p.json $T
+done

@@ -1900,7 +1900,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 // too large to hold every channel at once, so channels are walked in CK-wide chunks (restaged per chunk, accumulators live
 // across chunks); the weight ring runs through the chunk boundary.
 // ------------------------------------------------------------------------------------------------
-template <int TH, int TW, int CK, int WGM, int WGN, int FB>      // FB: 0 plain | 1 final-backward on load from c | 2 ... from the pattern bits
+template <int TH, int TW, int CK, int WGM, int WGN, int FB>      // FB: 0 plain | 1 final-backward on load from c | 2 ... from the pattern bits | 3 plain, plane-group input (ConvGemmArgs::Apg)
 __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_per_eu(2))) conv5_f16_kernel(const ConvGemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int IH = 2 * TH + 3, IW = 2 * TW + 3;
@@ -1928,10 +1928,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     const int CA = a.CA, Nn = a.Nn;
     const int AH = d.HB, AW = d.WB;
 
-    const bool xf = a.xf.scale != nullptr;
-    constexpr bool fb = FB != 0;             // final-backward on load (UadXform::fb_*): its own instantiation, the extra
+    const bool xf = a.xf.scale != nullptr && !(FB == 3);
+    constexpr bool fb = FB == 1 || FB == 2;  // final-backward on load (UadXform::fb_*): its own instantiation, the extra
                                              // prefetch registers would otherwise spill the 64-column variant
     constexpr bool fbb = FB == 2;            // ... from one pattern word per pixel instead of the 32 pre-BN values (UadXform::fb_bits)
+    constexpr bool pin = FB == 3;            // the input is a plane-group tensor: staging is a copy (no activation, no split)
     if (xf)
         for (int c = tid; c < CA; c += NT) {
             s_xf[c] = a.xf.scale[c] * a.xf.mult;
@@ -1983,6 +1984,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 
     const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
     const float* inb = a.A + (size_t)n * AH * AW * CA;
+    const size_t sample_q = (size_t)AH * AW * (CA / 4);
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(pin ? (void*)(const_cast<uint4*>(a.Apg) + (size_t)n * sample_q) : (void*)const_cast<float*>(inb),
+                                                                          0, (unsigned)(sample_q * 16), 0x00020000);
     __syncthreads();
 
     // The activation tile of chunk ch+1 is fetched into registers while chunk ch is contracted (the tile's two dependent
@@ -2002,7 +2006,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             const bool ok = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
             const int gp = ok ? (gy * AW + gx) : 0;
             if (fbb) pb[u] = a.xf.fb_bits[(size_t)n * AH * AW + gp];
-            else pf[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok ? cq * 4 : 0));
+            else if (pin) {         // out-of-image pixels read through the buffer's bounds check: zeros
+                const uint4 q = buf_load16(irs, ok ? (unsigned)((gp * (CA / 4) + (c0 >> 2) + cq) * 16) : 0x80000000u, 0);
+                pf[u] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+            } else pf[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok ? cq * 4 : 0));
             if (fb) pg[u] = a.xf.fb_dxhat[(size_t)n * AH * AW + gp];
         }
     };
@@ -2016,6 +2023,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             const int gy = gy0 + iy, gx = gx0 + ix;
             const bool ok = (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
             float4 t = pf[fbb ? 0 : u];
+            if (pin) {
+                *reinterpret_cast<uint2*>(sHi + pix * LDH + cq * 4) = make_uint2(__float_as_uint(t.x), __float_as_uint(t.y));
+                *reinterpret_cast<uint2*>(sLo + pix * LDH + cq * 4) = make_uint2(__float_as_uint(t.z), __float_as_uint(t.w));
+                continue;
+            }
             if (fbb) {
                 // the same from the pattern word the fused forward epilogue left: the derivative side of every channel is one bit
                 const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
@@ -2141,13 +2153,28 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     if (!bwd) {
         float4 e_a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.ep.bias) e_a = *reinterpret_cast<const float4*>(a.ep.bias + ecol);
+        float4 o_sc = make_float4(1.f, 1.f, 1.f, 1.f), o_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.OutPg && a.oxf.scale) {
+            o_sc = *reinterpret_cast<const float4*>(a.oxf.scale + ecol);
+            o_sc.x *= a.oxf.mult; o_sc.y *= a.oxf.mult; o_sc.z *= a.oxf.mult; o_sc.w *= a.oxf.mult;
+            o_sh = *reinterpret_cast<const float4*>(a.oxf.shift + ecol);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float4 t = v[k];
             t.x += e_a.x; t.y += e_a.y; t.z += e_a.z; t.w += e_a.w;
             if (a.ep.mul) { const float4 q = *reinterpret_cast<const float4*>(a.ep.mul + off[k]); t.x *= q.x; t.y *= q.y; t.z *= q.z; t.w *= q.w; }
             if (a.ep.add) { const float4 q = *reinterpret_cast<const float4*>(a.ep.add + off[k]); t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
-            *reinterpret_cast<float4*>(outp + off[k]) = t;
+            if (outp) *reinterpret_cast<float4*>(outp + off[k]) = t;
+            if (a.OutPg) {          // the activated output, split for the next contraction (UadPgIO)
+                float4 q;
+                q.x = fmaf(t.x, o_sc.x, o_sh.x); q.y = fmaf(t.y, o_sc.y, o_sh.y); q.z = fmaf(t.z, o_sc.z, o_sh.z); q.w = fmaf(t.w, o_sc.w, o_sh.w);
+                q.x = q.x > 0.f ? q.x : q.x * a.oxf.alpha; q.y = q.y > 0.f ? q.y : q.y * a.oxf.alpha;
+                q.z = q.z > 0.f ? q.z : q.z * a.oxf.alpha; q.w = q.w > 0.f ? q.w : q.w * a.oxf.alpha;
+                uint2 hi, lo;
+                split_bf16(q, hi, lo);
+                a.OutPg[off[k] >> 2] = make_uint4(hi.x, hi.y, lo.x, lo.y);
+            }
         }
         { if (stp) stp[5] = wall_clock64(); return; }
     }
@@ -2171,7 +2198,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             s1[e] += dbn;
             s2[e] = fmaf(dbn, cc[e], s2[e]);
         }
-        *reinterpret_cast<float4*>(outp + off[k]) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+        const float4 o4 = make_float4(oo[0], oo[1], oo[2], oo[3]);
+        if (outp) *reinterpret_cast<float4*>(outp + off[k]) = o4;
+        if (a.OutPg) {              // the gradient, split for its consumers (next data-gradient kernel, filter-gradient kernel)
+            uint2 hi, lo;
+            split_bf16(o4, hi, lo);
+            a.OutPg[off[k] >> 2] = make_uint4(hi.x, hi.y, lo.x, lo.y);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -2217,6 +2250,7 @@ template <int TH, int TW, int CK, int WGM, int WGN>
 void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
     if (a.xf.fb_bits) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 2>(a, grid, st);
     else if (a.xf.fb_dxhat) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 1>(a, grid, st);
+    else if (a.Apg) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 3>(a, grid, st);
     else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0>(a, grid, st);
 }
 
@@ -2392,6 +2426,10 @@ struct ConvWArgs {
     int kper;  // positions per split (multiple of BK)
     int lws, lhs;
     unsigned long long* dbgbuf;   // UAD_DBG & 32: per-workgroup start / end clocks
+    // plane-group operands (conv5_w_bf16_t_kernel): the operand already activated and split (UadPgIO) -- replaces the pointer and its transform
+    const uint4* big_pg = nullptr;
+    const uint4* small_pg = nullptr;
+    int abl = 0;   // UAD_W_ABL, kernel-tuning ablations (results are wrong): 1 no big-tile LDS stores | 2 no MFMAs | 4 no big-tile global loads | 8 no slab stores
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN>
@@ -3082,7 +3120,9 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     const int t_end = min(t_begin + tiles_per_split, total_tiles);
 
     const int cq = tid % CQ;
-    const bool xfa = !FBB && a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
+    const uint4* bpg = FBB ? nullptr : a.big_pg;
+    const uint4* spg = a.small_pg;
+    const bool xfa = !FBB && !bpg && a.xfb.scale != nullptr, xfs = !spg && a.xfs.scale != nullptr;
     // activation-on-load tables in LDS
     if (tid < 32) {
         sXf[tid] = xfa ? a.xfb.scale[cb0 + tid] * a.xfb.mult : 1.f;
@@ -3136,88 +3176,122 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
         c = mfma_bf16(al, bh, c);
     };
 
-    for (int t = t_begin; t < t_end; ++t) {
-        const int tx0 = (t % tilesx) * TW;
-        const int ty0 = ((t / tilesx) % tilesy) * TH;
-        const int n = t / (tilesx * tilesy);
-        const float* bigb = a.big + (size_t)n * d.HB * d.WB * d.CB + cb0;
-        const float* smb = a.small_ + ((size_t)(n * d.HS + ty0) * d.WS + tx0) * d.CS + cs0;
+    // ---- tile loop, software-pipelined: the global loads of tile t + 1 are in flight while tile t is contracted (round 3: with the loads, the
+    // LDS stores and the MFMAs all ablated the kernel still ran at 55 % of its time -- per-tile load latency that nothing covered, and
+    // per-element index arithmetic: three divisions by non-powers of two and 64-bit address products per 16 bytes staged) ----
+    constexpr int TOT = IH * IW * CQ;
+    constexpr int PER = (TOT + NT - 1) / NT;          // 16-byte elements of the big tile per thread: 12 (NT 256) or 6 (NT 512)
+    constexpr int DP = NT / CQ, DIY = DP / IW, DIX = DP % IW;      // element u + 1 of a thread is DP pixels further: (iy, ix) += (DIY, DIX), one wrap
+    const int pix0 = tid / CQ, iy0 = pix0 / IW, ix0 = pix0 % IW;
+    float4 v[FBB ? 1 : PER];
+    unsigned vb[FBB ? PER : 1];
+    float vg[FBB ? PER : 1];
+    float4 sv[2];
+    auto tile_origin = [&](int t, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
+        tx0 = (t % tilesx) * TW;
+        ty0 = ((t / tilesx) % tilesy) * TH;
+        n = t / (tilesx * tilesy);
+    };
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        int n, ty0, tx0;
+        tile_origin(t, n, ty0, tx0);
         const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-        __syncthreads();
-        {
-            constexpr int TOT = IH * IW * CQ;
-            constexpr int BATCH = 6;
-            for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
-                float4 v[FBB ? 1 : BATCH];
-                unsigned vb[FBB ? BATCH : 1];
-                float vg[FBB ? BATCH : 1];
-                bool ok[BATCH];
+        const size_t pixbase = (size_t)n * d.HB * d.WB;
+        const float* bigb = a.big + pixbase * d.CB + cb0 + cq * 4;
+        int iy = iy0, ix = ix0;
 #pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    const int f = f0 + u * NT;
-                    const int pix = f / CQ;
-                    const int iy = pix / IW, ix = pix % IW;
-                    const int gy = gy0 + iy, gx = gx0 + ix;
-                    ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
-                    const int gp = ok[u] ? (gy * d.WB + gx) : 0;
-                    if (FBB) {
-                        vb[u] = a.xfb.fb_bits[(size_t)n * d.HB * d.WB + gp];
-                        vg[u] = a.xfb.fb_dxhat[(size_t)n * d.HB * d.WB + gp];
-                    } else {
-                        v[u] = *reinterpret_cast<const float4*>(bigb + (size_t)gp * d.CB + cq * 4);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    const int f = f0 + u * NT;
-                    if (f >= TOT) continue;
-                    float4 tv = v[FBB ? 0 : u];
-                    if (FBB) {
-                        const unsigned b = vb[u] >> (cb0 + cq * 4);
-                        const float gq = vg[u];
-                        tv.x = gq * fb_wf[0] * ((b & 1u) ? fb_s1[0] : fb_s0[0]);
-                        tv.y = gq * fb_wf[1] * ((b & 2u) ? fb_s1[1] : fb_s0[1]);
-                        tv.z = gq * fb_wf[2] * ((b & 4u) ? fb_s1[2] : fb_s0[2]);
-                        tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
-                    } else if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
-                    tv = keep4(ok[u], tv);
-                    uint2 hi, lo;
-                    split_bf16(tv, hi, lo);
-                    {   // channel-major scatter: 4 channels x (hi, lo) 16-bit stores
-                        const int pix = f / CQ;
-                        const int iy = pix / IW, ix = pix % IW;
-                        const int o = (cq * 4) * CSTP + (iy * 2 + (ix & 1)) * XHP + (ix >> 1);
-                        bHi[o] = (unsigned short)hi.x; bHi[o + CSTP] = (unsigned short)(hi.x >> 16);
-                        bHi[o + 2 * CSTP] = (unsigned short)hi.y; bHi[o + 3 * CSTP] = (unsigned short)(hi.y >> 16);
-                        bLo[o] = (unsigned short)lo.x; bLo[o + CSTP] = (unsigned short)(lo.x >> 16);
-                        bLo[o + 2 * CSTP] = (unsigned short)lo.y; bLo[o + 3 * CSTP] = (unsigned short)(lo.y >> 16);
-                    }
-                }
+        for (int u = 0; u < PER; ++u) {
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            const bool ok = (u + 1 < PER || tid + u * NT < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
+            const int gp = ok ? (gy * d.WB + gx) : 0;
+            if (FBB) {
+                vb[FBB ? u : 0] = a.xfb.fb_bits[pixbase + gp];
+                vg[FBB ? u : 0] = a.xfb.fb_dxhat[pixbase + gp];
+            } else if (bpg) {
+                const uint4 q = bpg[(pixbase + gp) * (d.CB / 4) + (cb0 >> 2) + cq];
+                v[FBB ? 0 : u] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+            } else if (a.abl & 4) {
+                v[FBB ? 0 : u] = make_float4(1.f, 2.f, 3.f, 4.f);
+            } else {
+                v[FBB ? 0 : u] = *reinterpret_cast<const float4*>(bigb + (unsigned)(gp * d.CB));
             }
-            float4 sv[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + u * NT;
-                const int pos = idx / CSQ, csq = idx % CSQ;
-                sv[u] = *reinterpret_cast<const float4*>(smb + (size_t)((pos / TW) * d.WS + (pos % TW)) * d.CS + csq * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + u * NT;
-                const int pos = idx / CSQ, csq = idx % CSQ;
-                float4 tv = sv[u];
-                if (xfs) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + 64 + csq * 4), *reinterpret_cast<const float4*>(sXf + 128 + csq * 4), a.xfs.alpha);
-                uint2 hi, lo;
-                split_bf16(tv, hi, lo);
-                unsigned short* ph = sHiT + (csq * 4) * LDP + pos;
-                unsigned short* pl = sLoT + (csq * 4) * LDP + pos;
-                ph[0] = (unsigned short)hi.x; ph[LDP] = (unsigned short)(hi.x >> 16);
-                ph[2 * LDP] = (unsigned short)hi.y; ph[3 * LDP] = (unsigned short)(hi.y >> 16);
-                pl[0] = (unsigned short)lo.x; pl[LDP] = (unsigned short)(lo.x >> 16);
-                pl[2 * LDP] = (unsigned short)lo.y; pl[3 * LDP] = (unsigned short)(lo.y >> 16);
-            }
+            ix += DIX; iy += DIY;
+            if (ix >= IW) { ix -= IW; ++iy; }
         }
+        const size_t spix = ((size_t)(n * d.HS + ty0) * d.WS + tx0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * NT;
+            const int pos = idx / CSQ, csq = idx % CSQ;
+            const unsigned po = (unsigned)((pos / TW) * d.WS + (pos % TW));
+            if (spg) {
+                const uint4 q = spg[(spix + po) * (d.CS / 4) + (cs0 >> 2) + csq];
+                sv[u] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+            } else sv[u] = *reinterpret_cast<const float4*>(a.small_ + (spix + po) * d.CS + cs0 + csq * 4);
+        }
+    };
+    auto commit = [&](int t) __attribute__((always_inline)) {
+        int n, ty0, tx0;
+        tile_origin(t, n, ty0, tx0);
+        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
+        int iy = iy0, ix = ix0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const bool valid = u + 1 < PER || tid + u * NT < TOT;
+            const bool ok = valid && (unsigned)(gy0 + iy) < (unsigned)d.HB && (unsigned)(gx0 + ix) < (unsigned)d.WB;
+            if (valid) {
+                float4 tv = v[FBB ? 0 : u];
+                if (FBB) {
+                    const unsigned b = vb[FBB ? u : 0] >> (cb0 + cq * 4);
+                    const float gq = vg[FBB ? u : 0];
+                    tv.x = gq * fb_wf[0] * ((b & 1u) ? fb_s1[0] : fb_s0[0]);
+                    tv.y = gq * fb_wf[1] * ((b & 2u) ? fb_s1[1] : fb_s0[1]);
+                    tv.z = gq * fb_wf[2] * ((b & 4u) ? fb_s1[2] : fb_s0[2]);
+                    tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
+                } else if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
+                uint2 hi, lo;
+                if (!FBB && bpg) {      // plane-group operand: the words are the planes' (padding: zeros)
+                    hi = make_uint2(ok ? __float_as_uint(tv.x) : 0u, ok ? __float_as_uint(tv.y) : 0u);
+                    lo = make_uint2(ok ? __float_as_uint(tv.z) : 0u, ok ? __float_as_uint(tv.w) : 0u);
+                } else {
+                    tv = keep4(ok, tv);
+                    split_bf16(tv, hi, lo);
+                }
+                if (!(a.abl & 1)) {   // channel-major scatter: 4 channels x (hi, lo) 16-bit stores
+                    const int o = (cq * 4) * CSTP + (iy * 2 + (ix & 1)) * XHP + (ix >> 1);
+                    bHi[o] = (unsigned short)hi.x; bHi[o + CSTP] = (unsigned short)(hi.x >> 16);
+                    bHi[o + 2 * CSTP] = (unsigned short)hi.y; bHi[o + 3 * CSTP] = (unsigned short)(hi.y >> 16);
+                    bLo[o] = (unsigned short)lo.x; bLo[o + CSTP] = (unsigned short)(lo.x >> 16);
+                    bLo[o + 2 * CSTP] = (unsigned short)lo.y; bLo[o + 3 * CSTP] = (unsigned short)(lo.y >> 16);
+                }
+            }
+            ix += DIX; iy += DIY;
+            if (ix >= IW) { ix -= IW; ++iy; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * NT;
+            const int pos = idx / CSQ, csq = idx % CSQ;
+            float4 tv = sv[u];
+            if (xfs) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + 64 + csq * 4), *reinterpret_cast<const float4*>(sXf + 128 + csq * 4), a.xfs.alpha);
+            uint2 hi, lo;
+            if (spg) { hi = make_uint2(__float_as_uint(tv.x), __float_as_uint(tv.y)); lo = make_uint2(__float_as_uint(tv.z), __float_as_uint(tv.w)); }
+            else split_bf16(tv, hi, lo);
+            unsigned short* ph = sHiT + (csq * 4) * LDP + pos;
+            unsigned short* pl = sLoT + (csq * 4) * LDP + pos;
+            ph[0] = (unsigned short)hi.x; ph[LDP] = (unsigned short)(hi.x >> 16);
+            ph[2 * LDP] = (unsigned short)hi.y; ph[3 * LDP] = (unsigned short)(hi.y >> 16);
+            pl[0] = (unsigned short)lo.x; pl[LDP] = (unsigned short)(lo.x >> 16);
+            pl[2 * LDP] = (unsigned short)lo.y; pl[3 * LDP] = (unsigned short)(lo.y >> 16);
+        }
+    };
+    if (t_begin < t_end) issue(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();                   // the previous tile's fragments are consumed (first pass: the sXf tables are written)
+        commit(t);
+        if (t + 1 < t_end) issue(t + 1);   // in flight across the barrier and the MFMA loop below
         __syncthreads();
+        if (!(a.abl & 2))
 #pragma unroll
         for (int js = 0; js < TH * TW / 16; ++js) {
             // positions 16*js .. 16*js+15 = tile rows 2*js (lanes 0-31) and 2*js+1 (lanes 32-63), tx = element index
@@ -3253,6 +3327,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     const int CSi = d.CS;
     float* ob = a.partial + (size_t)blockIdx.z * a.Mtot * CSi + (size_t)(cb0 + 4 * lh) * CSi + cs0 + csb * 32 + l31;
     const int tapstride = d.CB * CSi;
+    if (!(a.abl & 8))
 #pragma unroll
     for (int j = 0; j < MAXT - 1; ++j) {
         const int tap = j < 5 ? 5 * wave + j : 20 + wave;
@@ -3545,9 +3620,33 @@ void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, un
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w16_f, w16_d, pd);
 }
 
+namespace {
+// the kernel that will run understands ConvGemmArgs::Apg / OutPg: bf16x3 spatial path, lane = pixel D-kind kernel (uad_conv16s.inc) or the
+// F-kind conv5_f16_kernel, split launches only with the in-kernel reducer
+bool plan_takes_pg(const GemmPlan& p, const UadConvDesc& d, bool f_type) {
+    if (p.path != PATH_SPATIAL) return false;
+    if (p.nsplit > 1 && !p.inkernel) return false;
+    const int CA = f_type ? d.CB : d.CS, Nn = f_type ? d.CS : d.CB;
+    if (f_type) return getenv("UAD_NO_F16") == nullptr && CA % 4 == 0;
+    if (getenv("UAD_NO_D16") || getenv("UAD_NO_D16S") || Nn % 32 || CA % p.nsplit) return false;
+    const int cst = CA / p.nsplit;
+    return p.sc.BN == 64 ? (cst == 128 || cst == 64 || cst == 32) : (cst == 64 || cst == 32);
+}
+void apply_pg(ConvGemmArgs& a, const UadPgIO& pg, bool ok) {
+    if (!ok) return;
+    a.Apg = reinterpret_cast<const uint4*>(pg.in_pg);
+    a.OutPg = reinterpret_cast<uint4*>(pg.out_pg);
+    a.oxf = pg.oxf;
+    if (pg.skip_f32 && pg.out_pg) a.Out = nullptr;
+}
+}  // namespace
+bool uad_conv_pg_ok(const UadConvDesc& d, bool f_type, size_t ws_floats, int ncounters) {
+    return plan_takes_pg(plan_gemm(d, f_type, true, ws_floats, ncounters), d, f_type);
+}
+
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W, float* small_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
-                       long long w16_plane, bool generic_bf16x3) {
+                       long long w16_plane, bool generic_bf16x3, UadPgIO pg) {
     ConvGemmArgs a;
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
@@ -3556,12 +3655,13 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
     a.sk_counter = nullptr; a.out_final = nullptr;
     const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
     if (p.inkernel) a.sk_counter = ws.counters;
+    apply_pg(a, pg, Wp16 != nullptr && plan_takes_pg(p, d, true));
     run_plan(p, a, true, ws.ptr, st);
 }
 
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W, float* big_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
-                       long long w16_plane, bool generic_bf16x3) {
+                       long long w16_plane, bool generic_bf16x3, UadPgIO pg) {
     ConvGemmArgs a;
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
@@ -3570,6 +3670,7 @@ void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf,
     a.sk_counter = nullptr; a.out_final = nullptr;
     const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
     if (p.inkernel) a.sk_counter = ws.counters;
+    apply_pg(a, pg, Wp16 != nullptr && plan_takes_pg(p, d, false));
     run_plan(p, a, false, ws.ptr, st);
 }
 
@@ -3606,8 +3707,13 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
     return (size_t)c.splits * d.KS * d.KS * d.CB * d.CS;
 }
 
+bool uad_conv_w_pg_ok(const UadConvDesc& d, bool math_bf16x3) {
+    return math_bf16x3 && choose_w5(d).ok && !getenv("UAD_NO_W_T");
+}
+
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
-                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev, bool generic_bf16x3, bool defer_reduce) {
+                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev, bool generic_bf16x3, bool defer_reduce,
+                       const void* big_pg, const void* small_pg) {
     // reduce_st/ev (optional): run the split-K slab reduction on a second stream, ordered after the main kernel by `ev`.
     // defer_reduce: leave the reduction to a later uad_launch_conv_w_reduce (the caller orders it after this kernel with ONE event per layer:
     // every event recorded on the main stream costs a ~6 us bubble before its next kernel)
@@ -3623,6 +3729,8 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         a.big = big; a.small_ = small; a.partial = (w5.splits == 1) ? dW : partial;
         a.xfb = xfb; a.xfs = xfs; a.d = d;
         a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = 0; a.lws = a.lhs = -1; a.dbgbuf = nullptr;
+        { static const int abl = getenv("UAD_W_ABL") ? atoi(getenv("UAD_W_ABL")) : 0; a.abl = abl; }
+        if (uad_conv_w_pg_ok(d, math_bf16x3)) { a.big_pg = reinterpret_cast<const uint4*>(big_pg); a.small_pg = reinterpret_cast<const uint4*>(small_pg); }
         dim3 grid(d.CB / 32, d.CS / 32, w5.splits);
         if (math_bf16x3) {
             static bool attr_set = false;

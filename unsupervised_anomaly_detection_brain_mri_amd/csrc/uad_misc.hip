@@ -300,7 +300,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // 16-byte reads fetch the 12 input columns the 4 pixels touch and ten fetch the 5 x 8 weights: 13 reads per 160 FMAs (packed pairs).
 template <int WS>
 __global__ void __launch_bounds__(256) conv_first_fwd32_kernel(UadConvDesc d, const float* __restrict__ x, const float* __restrict__ W,
-                                                               const float* __restrict__ bias, float* __restrict__ out) {
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               uint4* __restrict__ out_pg, UadXform oxf) {
     constexpr int OR = 256 / WS, IR = 2 * OR + 3, XW = 2 * WS + 4;
     __shared__ __attribute__((aligned(16))) float ws[25 * 32];
     __shared__ __attribute__((aligned(16))) float xs[IR * XW];      // column xx holds input column xx - 1
@@ -341,11 +342,37 @@ __global__ void __launch_bounds__(256) conv_first_fwd32_kernel(UadConvDesc d, co
             }
         }
     }
-    float* o = out + (((size_t)n * d.HS + oy0 + rl) * WS + 4 * pg) * 32 + q * 8;
+    const size_t oe = (((size_t)n * d.HS + oy0 + rl) * WS + 4 * pg) * 32 + q * 8;
+    float* o = out + oe;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         *reinterpret_cast<float4*>(o + j * 32) = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
         *reinterpret_cast<float4*>(o + j * 32 + 4) = make_float4(acc[j][2].x, acc[j][2].y, acc[j][3].x, acc[j][3].y);
+    }
+    if (out_pg) {
+        // plane-group copy of the ACTIVATED output (this block's frozen BN + LeakyReLU), already split into bf16 hi | lo for the next
+        // contraction (uad_kernels.h: UadPgIO): 16 bytes per (pixel, channel quad), next to the pre-BN fp32 the backward needs
+        float sc[8], sh[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { sc[c] = oxf.scale[q * 8 + c] * oxf.mult; sh[c] = oxf.shift[q * 8 + c]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v[8] = {acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y, acc[j][2].x, acc[j][2].y, acc[j][3].x, acc[j][3].y};
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                float a0 = fmaf(v[c], sc[c], sh[c]), a1 = fmaf(v[c + 1], sc[c + 1], sh[c + 1]);
+                a0 = a0 > 0.f ? a0 : a0 * oxf.alpha; a1 = a1 > 0.f ? a1 : a1 * oxf.alpha;
+                unsigned h;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(a0), "v"(a1));
+                const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xFFFF0000u);
+                unsigned l;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
+                hi[c / 2] = h; lo[c / 2] = l;
+            }
+            out_pg[(oe + (size_t)j * 32) / 4] = make_uint4(hi[0], hi[1], lo[0], lo[1]);
+            out_pg[(oe + (size_t)j * 32) / 4 + 1] = make_uint4(hi[2], hi[3], lo[2], lo[3]);
+        }
     }
 }
 
@@ -1041,16 +1068,18 @@ static inline bool first32_ok(const UadConvDesc& d) {
     return !off && d.CB == 1 && d.CS == 32 && d.KS == 5 && d.S == 2 && d.P == 1 && d.HB == 2 * d.HS && d.WB == 2 * d.WS &&
            (d.WS == 32 || d.WS == 64 || d.WS == 128) && d.HS % 8 == 0;
 }
+bool uad_conv_first_pg_ok(const UadConvDesc& d) { return first32_ok(d); }
 void uad_launch_conv_first_fwd(const UadConvDesc& d, const float* x, const float* W, const float* bias, float* out,
-                               hipStream_t st) {
+                               hipStream_t st, void* out_pg, UadXform oxf) {
+    uint4* opg = first32_ok(d) ? reinterpret_cast<uint4*>(out_pg) : nullptr;
     const int tpp = d.CS / 8, ppb = 256 / tpp;
     const int xw = d.S * ppb + d.KS;
     const size_t lds = ((size_t)d.KS * d.KS * d.CB * d.CS + (size_t)d.KS * xw * d.CB) * sizeof(float);
     const int bpr = (d.WS + ppb - 1) / ppb;
     if (first32_ok(d)) {
-        if (d.WS == 32) hipLaunchKernelGGL(conv_first_fwd32_kernel<32>, dim3(d.N * d.HS / 8), dim3(256), 0, st, d, x, W, bias, out);
-        else if (d.WS == 64) hipLaunchKernelGGL(conv_first_fwd32_kernel<64>, dim3(d.N * d.HS / 4), dim3(256), 0, st, d, x, W, bias, out);
-        else hipLaunchKernelGGL(conv_first_fwd32_kernel<128>, dim3(d.N * d.HS / 2), dim3(256), 0, st, d, x, W, bias, out);
+        if (d.WS == 32) hipLaunchKernelGGL(conv_first_fwd32_kernel<32>, dim3(d.N * d.HS / 8), dim3(256), 0, st, d, x, W, bias, out, opg, oxf);
+        else if (d.WS == 64) hipLaunchKernelGGL(conv_first_fwd32_kernel<64>, dim3(d.N * d.HS / 4), dim3(256), 0, st, d, x, W, bias, out, opg, oxf);
+        else hipLaunchKernelGGL(conv_first_fwd32_kernel<128>, dim3(d.N * d.HS / 2), dim3(256), 0, st, d, x, W, bias, out, opg, oxf);
         return;
     }
     hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(d.N * d.HS * bpr), dim3(256), lds, st, d, x, W, bias, out);

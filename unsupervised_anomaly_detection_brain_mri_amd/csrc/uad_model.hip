@@ -54,6 +54,8 @@ struct ConvLayer {        // conv / convT block followed by BN + (Leaky)ReLU
     UadConvDesc d;        // geometry at batch 1 (N filled per call)
     long long w, b, gamma, beta;   // flat offsets
     float* c;             // pre-BN output [N, ., ., C]
+    float* pg = nullptr;  // plane-group copy of the ACTIVATED output (UadPgIO; bf16x3 mode): what the next block and the filter gradients stage
+    bool pg_valid = false;   // ... written by the last forward
 };
 
 }  // namespace
@@ -101,6 +103,9 @@ struct uad_model {
     float* restore_grads;              // optional gradient output
     // gradient ping-pong + small grads
     float *G0, *G1;
+    float *GP0 = nullptr, *GP1 = nullptr;   // plane-group forms of the gradients that only bf16x3 kernels read (swap together with G0 / G1)
+    bool g_f32 = true, g_pg = false;   // what the current d loss / d c (G0 / GP0) exists as
+    bool pg_on = false;                // bf16x3 mode and UAD_NO_PG unset
     float* dcb_keep;                  // copy of d loss / d cb for conv2d_1's kernel gradient (SIDE)
     float* bott_xch; unsigned* bott_flags; unsigned bott_epoch;
     float* bnfin_scratch;             // counters + partials of the 2-D BN-gradient finalize (SIDE stream only)
@@ -426,6 +431,12 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     if (cfg->arch == UAD_ARCH_VAE) ALLOC(m->gm_dxhat, NB * H * Wd * cfg->channels);     // restoration mode (trainers/VAE_You.py)
     m->dec_in0 = (gm || sp) ? m->gm_h : m->cb;
     ALLOC(m->G0, maxact); ALLOC(m->G1, maxact);
+    {   // plane-group tensors (same bytes per element as fp32): activations every k5 block hands to the next one, gradients below the last block
+        size_t maxpg = 4;
+        for (size_t i = 0; i + 1 < m->enc.size(); ++i) { auto& L = m->enc[i]; size_t n = NB * L.d.HS * L.d.WS * L.d.CS; ALLOC(L.pg, n); if (i >= 1 && n > maxpg) maxpg = n; }
+        for (size_t i = 0; i + 1 < m->dec.size(); ++i) { auto& L = m->dec[i]; size_t n = NB * L.d.HB * L.d.WB * L.d.CB; ALLOC(L.pg, n); if (n > maxpg) maxpg = n; }
+        ALLOC(m->GP0, maxpg); ALLOC(m->GP1, maxpg);
+    }
     { float* fbw = nullptr; ALLOC(fbw, NB * H * Wd); m->fin_bits = reinterpret_cast<unsigned*>(fbw); ALLOC(m->fin_dxh, NB * H * Wd); }
     m->last_fin_bits = false;
     ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
@@ -597,6 +608,12 @@ static void invalidate_pack(uad_model* m) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+static int sk_counters(const uad_model* m);
+// plane-group tensors: opt-in (UAD_PG=1), split-bf16 mode only.  Measured in round 3 (profiles/README.md): every consumer stages them with plain
+// copies and all parity tests hold, but the step is 2 % SLOWER -- the producers' second 16-byte-per-quad store stream costs more than the
+// conversions it saves, because the staging phases are bound by memory / LDS latency at two waves per SIMD, not by VALU issue.
+static bool pg_mode(const uad_model* m) { static const bool on = getenv("UAD_PG") != nullptr; return on && m->math == UAD_MATH_BF16X3; }
+static bool conv_pg_ok(const uad_model* m, const UadConvDesc& d, bool f_type) { return pg_mode(m) && uad_conv_pg_ok(d, f_type, m->ws.floats, sk_counters(m)); }
 int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, void* stream) {
     if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
     if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
@@ -645,17 +662,30 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     // encoder
     static const char* kEncF[] = {"enc0.fwd", "enc1.fwd", "enc2.fwd", "enc3.fwd", "enc4.fwd", "enc5.fwd", "enc6.fwd", "enc7.fwd"};
     static const char* kDecF[] = {"dec0.fwd", "dec1.fwd", "dec2.fwd", "dec3.fwd", "dec4.fwd", "dec5.fwd", "dec6.fwd", "dec7.fwd"};
+    for (auto& L : m->enc) L.pg_valid = false;
+    for (auto& L : m->dec) L.pg_valid = false;
     {
         PROF(kEncF[0]);
         UadConvDesc d = m->enc[0].d; d.N = n;
-        uad_launch_conv_first_fwd(d, xin, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st);
+        // next to the pre-BN fp32 output every block leaves its ACTIVATED output as a plane-group tensor (UadPgIO): the next block and the
+        // filter gradients stage that with plain copies
+        const bool opg = pg_mode(m) && m->enc[0].pg && uad_conv_first_pg_ok(d);
+        uad_launch_conv_first_fwd(d, xin, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st, opg ? m->enc[0].pg : nullptr,
+                                  bn_xform(m, m->enc[0].gamma, m->enc[0].beta, kLrelu));
+        m->enc[0].pg_valid = opg;
     }
     if (wait_pack) (void)hipStreamWaitEvent(st, m->ev_pack, 0);
     for (size_t i = 1; i < m->enc.size(); ++i) {
         PROF(kEncF[i & 7]);
         UadConvDesc d = m->enc[i].d; d.N = n;
+        UadPgIO io;
+        if (conv_pg_ok(m, d, true)) {
+            if (m->enc[i - 1].pg_valid) io.in_pg = m->enc[i - 1].pg;
+            if (m->enc[i].pg) { io.out_pg = m->enc[i].pg; io.oxf = bn_xform(m, m->enc[i].gamma, m->enc[i].beta, kLrelu); m->enc[i].pg_valid = true; }
+        }
         uad_launch_conv_f(d, m->enc[i - 1].c, bn_xform(m, m->enc[i - 1].gamma, m->enc[i - 1].beta, kLrelu),
-                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, PKF(m, m->enc[i].w), m->ws, PK16F(m, m->enc[i].w), PLANE(m->enc[i]));
+                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, PKF(m, m->enc[i].w), m->ws, PK16F(m, m->enc[i].w), PLANE(m->enc[i]),
+                          false, io);
     }
     const ConvLayer& EL = m->enc.back();
     // bottleneck
@@ -727,7 +757,12 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
             ep.fin_inv_batch = 1.0f / (float)nu;
             out = restore_bwd ? DL.c : nullptr;
         }
-        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), out, ep, st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]));
+        UadPgIO io;
+        if (conv_pg_ok(m, d, false)) {
+            if (i >= 1 && m->dec[i - 1].pg_valid) io.in_pg = m->dec[i - 1].pg;
+            if (m->dec[i].pg && ep.kind == UAD_EPI_BIAS) { io.out_pg = m->dec[i].pg; io.oxf = bn_xform(m, m->dec[i].gamma, m->dec[i].beta, kLrelu); m->dec[i].pg_valid = true; }
+        }
+        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), out, ep, st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]), false, io);
     }
     // final 1x1 conv + L1 loss (+ start of the backward)
     UadFinalArgs fa;
@@ -831,6 +866,11 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
     m->ev_next = 0;
     float* g = m->G0;      // d loss / d c of dec[i]
     float* gn = m->G1;
+    // Gradients that only the bf16x3 kernels read travel as plane-group tensors (GP0 / GP1, UadPgIO): the data-gradient epilogue that produces
+    // d loss / d c of block i - 1 writes it split, and block i - 1's filter- and data-gradient kernels stage it with copies.  The gradient of the
+    // first block goes to the bottleneck kernels and stays fp32.
+    bool g_f32 = true, g_pg = false;
+    float *gp = m->GP0, *gpn = m->GP1;
     for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
         UadConvDesc d = m->dec[i].d; d.N = n;
         const float* in = (i == 0) ? m->dec_in0 : m->dec[i - 1].c;
@@ -844,13 +884,26 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
         const bool fbb = last && m->last_fin_bits;      // d loss / d c of the last block exists only as pattern bits + d objective / d x_hat
         UadXform gbits = no_xform();
         if (fbb) { gbits = bn_xform(m, DL.gamma, DL.beta, kLrelu); gbits.fb_dxhat = m->fin_dxh; gbits.fb_wf = P(m, m->fw); gbits.fb_bits = m->fin_bits; }
-        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, nullptr, nullptr, false, true); }
+        const bool w_pg = pg_mode(m) && uad_conv_w_pg_ok(d, bf);
+        const void* in_act_pg = (w_pg && i >= 1 && m->dec[i - 1].pg_valid) ? m->dec[i - 1].pg : nullptr;
+        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, nullptr, nullptr, false, true,
+                                                          (w_pg && g_pg && !fbb) ? gp : nullptr, in_act_pg); }
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
         { PROF(kDecD[i & 7]); UadEpilogue e = epi_bwd(m, in, ig, ib, ia); e.colpart = cp;
           const bool fb = m->restore && m->fb_on_load && last;
           UadXform gx = fbb ? gbits : no_xform();
           if (fb) { gx = bn_xform(m, DL.gamma, DL.beta, kLrelu); gx.fb_dxhat = m->gm_dxhat; gx.fb_wf = P(m, m->fw); }
-          uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i])); }
+          UadPgIO io;
+          bool gn_pg = false;
+          if (conv_pg_ok(m, d, true)) {
+              if (g_pg && !fbb && !fb) io.in_pg = gp;
+              if (i >= 1) {     // both consumers of d loss / d c of block i - 1 take the plane-group form: write only that
+                  UadConvDesc d1 = m->dec[i - 1].d; d1.N = n;
+                  if (uad_conv_w_pg_ok(d1, bf) && conv_pg_ok(m, d1, true)) { io.out_pg = gpn; io.skip_f32 = true; gn_pg = true; }
+              }
+          }
+          uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i]), false, io);
+          g_pg = gn_pg; g_f32 = !gn_pg; }
         edge(m, st, sd);   // ONE edge per layer: its filter-gradient slabs and column partials are ready
         if (pg && last) {
             // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials (forward results; riding on
@@ -861,8 +914,10 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
         }
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats, sk_counters(m)), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
+        tsw = gp; gp = gpn; gpn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
+    m->GP0 = gp; m->GP1 = gpn; m->g_f32 = g_f32; m->g_pg = g_pg;      // (block 0's gradient is always fp32)
     if (join_now) edge(m, sd, st);         // join: decoder gradients complete (inside UAD_SEG_ALL the join is the encoder segment's)
     return UAD_OK;
 }
@@ -1052,6 +1107,8 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
     const bool pg = !m->data_only;
     float* g = m->G0;
     float* gn = m->G1;
+    float *gp = m->GP0, *gpn = m->GP1;
+    bool g_pg = m->g_pg;          // d loss / d c of the block about to be back-propagated exists as a plane-group tensor (then ONLY as that)
     static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
     static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
     const int hi_from = (int)m->enc.size() - 1, hi_to = m->enc.size() >= 3 ? 2 : hi_from + 1;      // ENCODER_HI runs blocks hi_from .. hi_to
@@ -1060,15 +1117,29 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
         UadConvDesc d = m->enc[i].d; d.N = n;
         const ConvLayer& PL = m->enc[i - 1];
         float* cp = m->cp_slot[8 + (i & 7)];
-        if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true); }
+        const bool w_pg = pg_mode(m) && uad_conv_w_pg_ok(d, bf);
+        if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true,
+                                                          (w_pg && PL.pg_valid) ? PL.pg : nullptr, (w_pg && g_pg) ? gp : nullptr); }
         { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
-          uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i])); }
+          UadPgIO io;
+          bool gn_pg = false;
+          if (conv_pg_ok(m, d, false)) {
+              if (g_pg) io.in_pg = gp;
+              if (i >= 2) {     // d loss / d c of block i - 1 is read by that block's filter- and data-gradient kernels only
+                  UadConvDesc d1 = m->enc[i - 1].d; d1.N = n;
+                  if (uad_conv_w_pg_ok(d1, bf) && conv_pg_ok(m, d1, false)) { io.out_pg = gpn; io.skip_f32 = true; gn_pg = true; }
+              }
+          }
+          uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i]), false, io);
+          g_pg = gn_pg; }
         edge(m, st, sd);
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd);
                   uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats, sk_counters(m)), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
+        tsw = gp; gp = gpn; gpn = tsw;
     }
+    m->GP0 = gp; m->GP1 = gpn; m->g_pg = g_pg; m->g_f32 = !g_pg;
     if (part == 1) {
         m->G0 = g; m->G1 = gn;
         edge(m, sd, st);   // join: the deep blocks' gradients are complete
