@@ -209,7 +209,7 @@ class FAnoGAN:
             da, g['Generator/dec_Conv2DT_%d/kernel' % i], g['Generator/dec_Conv2DT_%d/bias' % i] = \
                 nn.conv2d_transpose_bwd(cache['a'][i], p['Generator/dec_Conv2DT_%d/kernel' % i], dc, 2)
         y, lc = cache['ln'][0]
-        dy = np.where(y > 0, da, 0.0).astype(da.dtype)
+        dy = nn.leaky_relu_bwd(y, da, 0.0)
         dc, g[self.ln_g[0] + '/gamma'], g[self.ln_g[0] + '/beta'] = ln_bwd(dy, p[self.ln_g[0] + '/gamma'], lc)
         dmap, g['Generator/conv2d_1/kernel'], g['Generator/conv2d_1/bias'] = nn.conv2d_bwd(cache['dmap'], p['Generator/conv2d_1/kernel'], dc, 1)
         dv = dmap.reshape(dmap.shape[0], -1)

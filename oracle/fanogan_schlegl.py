@@ -31,7 +31,7 @@ def avgpool_bwd(g):
 
 
 def relu_bwd(y, g):
-    return np.where(y > 0, g, 0.0).astype(g.dtype)
+    return nn.leaky_relu_bwd(y, g, 0.0)
 
 
 class _Block:

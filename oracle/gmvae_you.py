@@ -119,7 +119,7 @@ class GMVAEYou:
             if kind == 'up':
                 da = _up_bwd(da)
                 continue
-            dc = da * (c > 0) if relu else da
+            dc = nn.leaky_relu_bwd(c, da, 0.0) if relu else da
             da, g[name + '/kernel'], g[name + '/bias'] = (nn.conv2d_bwd if kind == 'conv' else nn.conv2d_transpose_bwd)(a_in, p[name + '/kernel'], dc, 1)
         dz_dec = da
         c = cache
@@ -147,7 +147,7 @@ class GMVAEYou:
         g['Variable'] = dLqf.sum(axis=(0, 1, 2))
         dmid1, g['p_z_wc/z_wc_mu/kernel'], g['p_z_wc/z_wc_mu/bias'] = nn.conv2d_bwd(c['mid'], p['p_z_wc/z_wc_mu/kernel'], dMf, 1)
         dmid2, g['p_z_wc/z_wc_log_sigma/kernel'], g['p_z_wc/z_wc_log_sigma/bias'] = nn.conv2d_bwd(c['mid'], p['p_z_wc/z_wc_log_sigma/kernel'], dLqf, 1)
-        da7 = (dmid1 + dmid2) * (c['a7'] > 0)
+        da7 = nn.leaky_relu_bwd(c['a7'], dmid1 + dmid2, 0.0)
         dw_s, g['p_z_wc/1x1convlayer/kernel'], g['p_z_wc/1x1convlayer/bias'] = nn.conv2d_bwd(c['w_s'], p['p_z_wc/1x1convlayer/kernel'], da7, 1)
         dw_mu = inv * w_mu + dw_s
         dw_ls = inv * 0.5 * (np.exp(w_ls) - 1) + dw_s * c['e_w'] * 0.5 * np.exp(0.5 * w_ls)
@@ -158,7 +158,7 @@ class GMVAEYou:
         da = dh
         for i in reversed(range(len(ENC))):
             name, s = ENC[i]
-            dc = da * (cache['ec'][i] > 0)
+            dc = nn.leaky_relu_bwd(cache['ec'][i], da, 0.0)
             da, g[name + '/kernel'], g[name + '/bias'] = nn.conv2d_bwd(cache['ea'][i], p[name + '/kernel'], dc, s)
         g['__dx'] = da + dx_direct
         return g

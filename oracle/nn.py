@@ -157,8 +157,50 @@ def leaky_relu_fwd(x, alpha):
     return np.where(x > 0, x, x * x.dtype.type(alpha))
 
 
+# Derivative side of a (Leaky)ReLU as ANOTHER fp32 implementation of the same step took it (tests only).  A pre-activation within round-off of
+# 0 lands on either side of the kink depending on summation order; its derivative (alpha or 1) is then a property of that implementation, not
+# an error, and one such element moves the small downstream gradient tensors by 1e-3..1e-2 of their max.  The GPU parity tests read the
+# pattern the device used (sign of its stored activations), check that every disagreement with this oracle sits within round-off of the
+# kink (tests/gpu_util.py: kink_overrides), and differentiate the oracle with the device's pattern: every gradient is then held to the
+# 1e-4 bar whether or not flips occur.  The override is keyed by a fingerprint of the site's POST-activation array as this oracle computes
+# it (bit-reproducible: the second run of a phase recomputes the same arrays), so no oracle needs per-site plumbing.
+_ACT_OVERRIDE = None
+
+
+def act_fingerprint(post):
+    import hashlib
+    a = np.ascontiguousarray(post + post.dtype.type(0))          # (+0 folds -0.0 into +0.0: relu as maximum(y, 0) and as where(y > 0, y, 0 * y) agree)
+    return (a.shape, str(a.dtype), hashlib.blake2b(a.tobytes(), digest_size=16).digest())
+
+
+class act_override:
+    """with act_override({act_fingerprint(oracle post-activation): bool pattern}): ... -- leaky_relu_bwd uses the given patterns."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def __enter__(self):
+        global _ACT_OVERRIDE
+        self.prev, _ACT_OVERRIDE = _ACT_OVERRIDE, self.table
+        self.used = set()
+        self.table['_used'] = self.used
+        return self
+
+    def __exit__(self, *exc):
+        global _ACT_OVERRIDE
+        _ACT_OVERRIDE = self.prev
+        return False
+
+
 def leaky_relu_bwd(x, g, alpha):
-    return np.where(x > 0, g, g * x.dtype.type(alpha))
+    pos = x > 0
+    if _ACT_OVERRIDE is not None:
+        key = act_fingerprint(leaky_relu_fwd(x, alpha))
+        o = _ACT_OVERRIDE.get(key)
+        if o is not None:
+            pos = o.reshape(x.shape)
+            _ACT_OVERRIDE['_used'].add(key)
+    return np.where(pos, g, g * x.dtype.type(alpha))
 
 
 # --------------------------------------------------------------------------

@@ -63,7 +63,7 @@ def _bn_positive(c, gamma, beta):
 
 
 def device_activation_pattern(eng, params, x_target, xhat_dev, cache, n_pool, bn_names, rows=None,
-                              final_kernel='Decoder/dec_Conv2D_final/kernel'):
+                              final_kernel='Decoder/dec_Conv2D_final/kernel', math='bf16x3', xhat_oracle=None):
     """Call right after eng.forward(..., want_backward=True) and BEFORE eng.backward() (the fused last block leaves its d loss / d c
     in the ping-pong buffer the backward reuses).  params: dict name -> fp32 array (the engine's); x_target / xhat_dev: [n,H,W,1]
     L1 target and the DEVICE reconstruction; cache: the oracle's forward cache (shapes + its own pattern for the flip count);
@@ -72,7 +72,8 @@ def device_activation_pattern(eng, params, x_target, xhat_dev, cache, n_pool, bn
     Returns (act, flips): act feeds oracle backward(act=...), flips = {key: count of disagreements with the oracle}."""
     n = x_target.shape[0]
     rows = rows if rows is not None else slice(0, n)
-    act, flips = {}, {}
+    act, flips, mags = {}, _Flips(), {}
+    flips.mag = mags
 
     def grab(name, like):
         buf = eng.debug_buffer(name).cpu().numpy()
@@ -80,9 +81,16 @@ def device_activation_pattern(eng, params, x_target, xhat_dev, cache, n_pool, bn
         return buf.reshape(-1, per)[rows].reshape(like.shape)
 
     def put(key, pos):
+        # every disagreement with the oracle has to be a rounding tie: the oracle's pre-activation within the round-off bound of the kink
         ref = cache[key] > 0
         act[key] = pos
-        flips[key] = int((pos != ref).sum())
+        diff = pos != ref
+        flips[key] = int(diff.sum())
+        if flips[key]:
+            mag = float(np.abs(cache[key][diff]).max()) / max(float(np.abs(cache[key]).max()), 1e-30)
+            mags[key] = mag
+            assert mag <= FLIP_BOUND[math], (f'{key}: {flips[key]} flipped activation(s) with oracle |pre-activation| up to {mag:.2e} of the tensor max '
+                                             f'(round-off bound of {math}: {FLIP_BOUND[math]:.2e}) -- not a rounding tie')
 
     for i in range(n_pool):
         c = grab(f'enc_c{i}', cache[f'enc_bn{i}'])
@@ -121,7 +129,57 @@ def device_activation_pattern(eng, params, x_target, xhat_dev, cache, n_pool, bn
         else:
             put(key, _bn_positive(grab(f'dec_c{i}', cache[key]), g_, b_))
     act['l1_sign'] = sg
+    if xhat_oracle is not None:
+        # the L1 term's sign(x_hat - x) as the device took it vs the oracle's: a disagreement needs |x_hat - x| within round-off of 0
+        r = np.asarray(xhat_oracle, np.float64) - np.asarray(x_target, np.float64)
+        diff = np.sign(r) != sg
+        flips.l1_sign = int(diff.sum())
+        if flips.l1_sign:
+            mag = float(np.abs(r[diff]).max()) / max(float(np.abs(np.asarray(xhat_oracle)).max()), 1e-30)
+            mags['l1_sign'] = mag
+            assert mag <= FLIP_BOUND[math], f'l1_sign: {flips.l1_sign} sign disagreements with |x_hat - x| up to {mag:.2e} (bound {FLIP_BOUND[math]:.2e})'
     return act, flips
+
+
+class _Flips(dict):
+    """{site: count} + .mag {site: largest oracle |pre-activation| among the flipped elements, relative to the tensor max} + .l1_sign"""
+    mag = None
+    l1_sign = 0
+
+
+# Round-off bound of a pre-activation in units of its tensor's max: a (Leaky)ReLU whose derivative side differs between the device and the fp64
+# oracle must sit this close to the kink, else the disagreement is a bug, not a rounding tie.  f32: 64 ulp of the largest value; bf16x3: 2^-15
+# (three bf16 products per fp32 product, ~2^-17 each, accumulated over the contraction); bf16x3_all (opt-in, every contraction of a 20-layer
+# residual stack in bf16x3, documented drift 1e-4 .. 3e-4): 2^-12.
+FLIP_BOUND = {'f32': 64.0 * 2.0 ** -24, 'bf16x3': 2.0 ** -15, 'bf16x3_all': 2.0 ** -12}
+
+
+def kink_overrides(pairs, math='bf16x3', bound=None, tag=''):
+    """pairs: iterable of (device activation, oracle POST-activation) or (device activation, oracle PRE-activation, alpha) for every
+    (Leaky)ReLU site of a step (the device array may be pre- or post-activation: only its sign is read).
+    Returns (table, flips, worst): `table` feeds oracle.nn.act_override (the oracle then differentiates with the DEVICE's derivative
+    sides), flips = number of elements whose side differs, worst = the largest |activation| (either implementation's, relative to the
+    site's max) among them -- asserted to be within the round-off bound of the math mode."""
+    from oracle import nn as onn
+    bound = FLIP_BOUND[math] if bound is None else bound
+    table, flips, worst = {}, 0, 0.0
+    for k, item in enumerate(pairs):
+        dev, ref = np.asarray(item[0]), np.asarray(item[1])
+        post = ref if len(item) == 2 else onn.leaky_relu_fwd(ref, item[2])
+        assert dev.size == ref.size, (tag, k, dev.shape, ref.shape)
+        dev = dev.reshape(ref.shape)
+        pd, pr = dev > 0, ref > 0
+        diff = pd != pr
+        nf = int(diff.sum())
+        if nf:
+            scale = max(float(np.abs(ref).max()), 1e-30)
+            mag = float(np.maximum(np.abs(dev[diff].astype(np.float64)), np.abs(ref[diff].astype(np.float64))).max()) / scale
+            worst = max(worst, mag)
+            assert mag <= bound, (f'{tag} site {k}: {nf} activation(s) on different sides of the kink with |value| up to {mag:.2e} of the '
+                                  f'site max (round-off bound of {math}: {bound:.2e}) -- not a rounding tie')
+            flips += nf
+        table[onn.act_fingerprint(post)] = pd
+    return table, flips, worst
 
 
 def assert_grads_close(got, want, names, tol=REL_TOL, flips=None):

@@ -12,6 +12,9 @@ from oracle import caae_chen as oc
 from oracle import gmvae as og
 from oracle import vae as ovae
 
+from oracle import nn as onn  # noqa: E402
+from tests.gpu_util import kink_overrides  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 try:
@@ -35,7 +38,7 @@ def _engine(m, n):
                      math='f32')
 
 
-def _check(eng, m, g, groups, flips):
+def _check(eng, m, g, groups):
     grads = eng.get_grads()
     for name, _, _ in m.spec:
         if not name.startswith(groups):
@@ -44,24 +47,30 @@ def _check(eng, m, g, groups, flips):
         scale = max(np.abs(b).max(), 1e-30)
         if np.abs(b).max() <= 1e-9:                      # conv biases in front of a LayerNorm-HW: identically zero
             assert np.abs(a).max() <= 1e-5, name
-        elif flips == 0:
-            assert np.abs(a - b).max() <= (2e-4 if 'kernel' in name else 5e-4) * scale, (name, np.abs(a - b).max() / scale)
         else:
-            assert np.linalg.norm(a - b) <= 5e-2 * np.linalg.norm(b), (name, flips)
+            assert np.abs(a - b).max() <= (2e-4 if 'kernel' in name else 5e-4) * scale, (name, np.abs(a - b).max() / scale)
 
 
-def _flips(eng, caches):
-    """caches: list of (prefix, block caches, sample offset) -- sign differences of every ReLU input (LayerNorm output)."""
-    cnt = 0
+def _pairs(eng, caches):
+    """caches: list of (prefix, block caches, sample offset) -- (device ReLU input, oracle ReLU input = LayerNorm output, alpha 0) of every
+    ReLU site."""
     for tag, blocks, off in caches:
         for k, c in enumerate(blocks):
             for key, dev_name in (('y1', f'{tag}_h1_{k}'), ('y2', f'{tag}_h2_{k}')):
                 ref = c[key]
                 dev = eng.debug_buffer(dev_name).cpu().numpy()
                 per = ref[0].size
-                dev = dev[off * per:(off + ref.shape[0]) * per].reshape(ref.shape)
-                cnt += int(((dev > 0) != (ref > 0)).sum())
-    return cnt
+                yield dev[off * per:(off + ref.shape[0]) * per].reshape(ref.shape), ref, 0.0
+
+
+def _with_device_pattern(eng, caches, phase, g, tag):
+    """the oracle gradients differentiated with the derivative sides the device took (tests/gpu_util.py: kink_overrides)"""
+    table, flips, worst = kink_overrides(_pairs(eng, caches), 'f32', tag=tag)
+    if flips:
+        with onn.act_override(table):
+            g = phase()[1]
+        print(f'\n[{tag}] {flips} ReLU flips, largest |LayerNorm output| {worst:.2e} of its site max')
+    return g
 
 
 @pytest.mark.parametrize('h,zd,dim,n', [(32, 16, 32, 3), (32, 32, 32, 2), (64, 128, 64, 1)])
@@ -83,22 +92,22 @@ def test_caae_chen_phases(h, zd, dim, n):
     z_, ec = m.encode(p64, x64)
     xh, dc = m.decode(p64, z_)
     _, ec2 = m.encode(p64, xh)
-    flips = _flips(eng, [('sd', ec['blocks'], 0), ('sd', ec2['blocks'], n), ('sg', dc['blocks'], 0)])
-    _check(eng, m, g, ('Encoder', 'Decoder'), flips)
+    g = _with_device_pattern(eng, [('sd', ec['blocks'], 0), ('sd', ec2['blocks'], n), ('sg', dc['blocks'], 0)], lambda: m.ae_phase(p64, x64), g, 'caae.ae')
+    _check(eng, m, g, ('Encoder', 'Decoder'))
     # critic phase (optim_dis)
     ls, g = m.disc_phase(p64, x64, zp.astype(np.float64), eps.astype(np.float64))
     got = eng.aae_phase('Discriminator', x, z=zp, eps=eps)
     torch.cuda.synchronize()
     for k in ('disc_fake', 'disc_real', 'penalty', 'disc_loss'):
         assert abs(float(got[k]) - ls[k]) <= 5e-4 * max(abs(ls[k]), 1e-3), (k, float(got[k]), ls[k])
-    _check(eng, m, g, ('Discriminator',), 0)
+    _check(eng, m, g, ('Discriminator',))
     # generator phase (optim_gen): -mean d_ w.r.t. the Encoder variables
     ls, g = m.gen_phase(p64, x64)
     got = eng.aae_phase('Encoder', x)
     torch.cuda.synchronize()
     assert abs(float(got['gen_loss']) - ls['gen_loss']) <= 3e-4 * max(abs(ls['gen_loss']), 1e-3)
-    flips = _flips(eng, [('sd', ec['blocks'], 0)])
-    _check(eng, m, g, ('Encoder',), flips)
+    g = _with_device_pattern(eng, [('sd', ec['blocks'], 0)], lambda: m.gen_phase(p64, x64), g, 'caae.gen')
+    _check(eng, m, g, ('Encoder',))
     rec = eng.reconstruct(x)['reconstruction'].cpu().numpy()
     assert_close(rec, m.reconstruct(p64, x64), tol=2e-4, name='reconstruct')
     eng.close()

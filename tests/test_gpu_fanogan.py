@@ -11,30 +11,47 @@ from oracle import vae as ovae
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-# Gradients when the fp32 device run took the other (Leaky)ReLU branch than the fp64 oracle on some activation whose
-# pre-activation is within round-off of zero: one flipped element moves a filter gradient (a sum of sign-alternating terms) by
-# up to ~1e-2 of its max-norm.  The tests count the flips exactly (activation signs, device vs oracle); with zero flips the
-# gradients are held to TOL in the max-norm, otherwise to TOL_KINK in the L2 norm.  Forward values and losses are always
-# held to TOL.
-TOL_KINK = 5e-2
+# Gradients when the fp32 device run took the other (Leaky)ReLU branch than the fp64 oracle on some activation whose pre-activation is
+# within round-off of zero: one flipped element moves a filter gradient (a sum of sign-alternating terms) by up to ~1e-2 of its max-norm.
+# The tests read the derivative sides the device took (signs of its stored activations), require every disagreement with the oracle to
+# be a rounding tie (|activation| within the math mode's round-off bound, tests/gpu_util.py: kink_overrides) and differentiate the oracle
+# with the DEVICE's pattern (oracle.nn.act_override): gradients, the penalty and its second-order term are then held to TOL in the
+# max-norm whether or not flips occur.  Forward values and losses are held to TOL as well.
+from oracle import nn as onn
+from tests.gpu_util import kink_overrides
 
 
-def _flips(eng, m, caches):
-    total = 0
-
-    def cnt(name, ref):
-        nonlocal total
-        dev = eng.debug_buffer(name)[:ref.size].cpu().numpy().reshape(ref.shape)
-        total += int(((dev > 0) != (ref > 0)).sum())
+def _pairs(eng, m, caches):
+    """(device activation, oracle activation) of every (Leaky)ReLU site of a unified-graph phase."""
+    def grab(name, ref):
+        return eng.debug_buffer(name)[:ref.size].cpu().numpy().reshape(ref.shape), ref
 
     if 'enc' in caches:
         for i in range(m.npool):
-            cnt(f'ea{i + 1}', caches['enc']['a'][i + 1])
+            yield grab(f'ea{i + 1}', caches['enc']['a'][i + 1])
     for i in range(m.npool + 1):
-        cnt(f'ga{i}', caches['gen']['a'][i])
+        yield grab(f'ga{i}', caches['gen']['a'][i])
     for i in range(m.npool if caches['disc'] else 0):
-        cnt(f'Da{i + 1}', np.concatenate([c['a'][i + 1] for c in caches['disc']]))
-    return total
+        dev, _ = grab(f'Da{i + 1}', np.concatenate([c['a'][i + 1] for c in caches['disc']]))
+        off = 0
+        for c in caches['disc']:                     # one site per critic pass (each pass has its own post-activation array)
+            ref = c['a'][i + 1]
+            yield dev[off:off + ref.shape[0]], ref
+            off += ref.shape[0]
+
+
+def _oracle_with_device_pattern(pairs, math, phase, tag=''):
+    """phase(caches) -> (losses, grads).  Runs the oracle, reads the device's derivative sides against its caches and, when they differ
+    anywhere, runs the oracle again with the device's pattern.  Returns (losses, grads, flips)."""
+    caches = {}
+    ls, g = phase(caches)
+    table, flips, worst = kink_overrides(pairs(caches), math, tag=tag)
+    if flips:
+        with onn.act_override(table) as ov:
+            ls, g = phase({})
+        assert len(ov.used) > 0, 'the override table matched no activation site of the oracle'
+        print(f'\n[{tag} {math}] {flips} activation flips, largest |value| {worst:.2e} of its site max: oracle differentiated with the device pattern')
+    return ls, g, flips
 
 
 def _rel(a, b):
@@ -73,25 +90,16 @@ def _check_grads(eng, m, g_ref, group, tag, tol=TOL):
             continue
         ref = np.asarray(g_ref.get(k, np.zeros(s)), np.float64).reshape(s)
         dev = g_dev[k].astype(np.float64)
-        if tol == TOL:
-            # biases feeding a LayerNorm over (H, W) have an identically zero gradient; the device writes exact zeros, the
-            # oracle carries fp64 round-off -- hence the floor on the reference scale
-            err = np.abs(dev - ref).max()
-            assert err <= tol * max(np.abs(ref).max(), 1e-2 * scale), f'{tag}:{k} err {err:.3e} ref max {np.abs(ref).max():.3e}'
-        else:
-            # activation flips present: a flipped element is an O(1) change of the per-pixel LayerNorm gradients at its pixel
-            # and a ~1e-2 change of the filter gradients it feeds, so the bound is on the L2 norm of the difference
-            err = np.linalg.norm(dev - ref)
-            assert err <= tol * max(np.linalg.norm(ref), 1e-2 * scale * np.sqrt(ref.size)), f'{tag}:{k} L2 err {err:.3e} ref {np.linalg.norm(ref):.3e}'
+        # biases feeding a LayerNorm over (H, W) have an identically zero gradient; the device writes exact zeros, the
+        # oracle carries fp64 round-off -- hence the floor on the reference scale
+        err = np.abs(dev - ref).max()
+        assert err <= tol * max(np.abs(ref).max(), 1e-2 * scale), f'{tag}:{k} err {err:.3e} ref max {np.abs(ref).max():.3e}'
 
 
-def _check_critic_scalars(out, ls, flips):
-    """disc_fake / disc_real are forward values (TOL).  The penalty is a function of the critic's INPUT GRADIENT: with activation flips
-    present (see TOL_KINK) it is held to 2e-3 instead."""
-    for k in ('disc_fake', 'disc_real'):
-        assert abs(out[k].item() - ls[k]) < TOL * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
-    tol = TOL if flips == 0 else 2e-3
-    for k in ('penalty', 'disc_loss'):
+def _check_critic_scalars(out, ls, flips=0, tol=TOL):
+    """disc_fake / disc_real are forward values; the penalty is a function of the critic's INPUT GRADIENT -- with the device's activation
+    pattern injected into the oracle all four are held to the same bar."""
+    for k in ('disc_fake', 'disc_real', 'penalty', 'disc_loss'):
         assert abs(out[k].item() - ls[k]) < tol * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k], flips)
 
 
@@ -103,13 +111,10 @@ def test_generator_phase(h, inter, zdim, n, math, drop):
     m, p, x, z, alpha, mz, mg = _setup(h, inter, zdim, n, drop=drop)
     eng = _engine(m, p, n, math)
     out = eng.phase('Generator', z=z, mask_g=mg)
-    caches = {}
-    ls, g = m.gen_phase(p, z, mg, caches)
+    ls, g, flips = _oracle_with_device_pattern(lambda c: _pairs(eng, m, c), math, lambda c: m.gen_phase(p, z, mg, c), 'gen')
     assert _rel(out['generated'].cpu().numpy(), ls['generated']) < TOL
     assert abs(out['gen_loss'].item() - ls['gen_loss']) < TOL * max(1.0, abs(ls['gen_loss']))
-    flips = _flips(eng, m, caches)
-    _check_grads(eng, m, g, 'Generator', 'gen', TOL if flips == 0 else TOL_KINK)
-    assert h > 32 or flips == 0      # the small case must exercise the tight tolerance
+    _check_grads(eng, m, g, 'Generator', 'gen')
 
 
 @pytest.mark.parametrize('h,inter,zdim,n,math,drop', CASES)
@@ -117,12 +122,9 @@ def test_critic_phase(h, inter, zdim, n, math, drop):
     m, p, x, z, alpha, mz, mg = _setup(h, inter, zdim, n, seed=1, drop=drop)
     eng = _engine(m, p, n, math)
     out = eng.phase('Discriminator', x=x, z=z, alpha=alpha, mask_g=mg)
-    caches = {}
-    ls, g = m.disc_phase(p, x, z, alpha, mg, caches)
-    flips = _flips(eng, m, caches)
+    ls, g, flips = _oracle_with_device_pattern(lambda c: _pairs(eng, m, c), math, lambda c: m.disc_phase(p, x, z, alpha, mg, c), 'disc')
     _check_critic_scalars(out, ls, flips)
-    _check_grads(eng, m, g, 'Discriminator', 'disc', TOL if flips == 0 else TOL_KINK)
-    assert h > 32 or flips == 0
+    _check_grads(eng, m, g, 'Discriminator', 'disc')
 
 
 @pytest.mark.parametrize('h,inter,zdim,n,math,drop', CASES)
@@ -130,16 +132,13 @@ def test_encoder_phase_and_reconstruct(h, inter, zdim, n, math, drop):
     m, p, x, z, alpha, mz, mg = _setup(h, inter, zdim, n, seed=2, drop=drop)
     eng = _engine(m, p, n, math)
     out = eng.phase('Encoder', x=x, mask_z=mz, mask_g=mg, want_l1=True)
-    caches = {}
-    ls, g = m.enc_phase(p, x, mz, mg, caches)
+    ls, g, flips = _oracle_with_device_pattern(lambda c: _pairs(eng, m, c), math, lambda c: m.enc_phase(p, x, mz, mg, c), 'enc')
     for k in ('loss_img', 'loss_fts', 'enc_loss', 'reconstructionLoss'):
         assert abs(out[k].item() - ls[k]) < TOL * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
     assert _rel(out['z_enc'].cpu().numpy(), ls['z_enc']) < TOL
     assert _rel(out['reconstruction'].cpu().numpy(), ls['reconstruction']) < TOL
     assert _rel(out['L1'].cpu().numpy(), ls['L1']) < TOL
-    flips = _flips(eng, m, caches)
-    _check_grads(eng, m, g, 'Encoder', 'enc', TOL if flips == 0 else TOL_KINK)
-    assert h > 32 or flips == 0
+    _check_grads(eng, m, g, 'Encoder', 'enc')
     rec = eng.reconstruct(x)
     assert _rel(rec['reconstruction'].cpu().numpy(), m.reconstruct(p, x)) < TOL
 
@@ -195,26 +194,31 @@ def _engine_rn(m, p, n, math):
     return eng
 
 
-def _flips_rn(eng, m, caches):
-    total = 0
+def _pairs_rn(eng, m, caches):
+    """(device activation, oracle activation) of every LayerNorm + ReLU output of a ResNet-graph phase."""
+    def grab(name, ref):
+        return eng.debug_buffer(name)[:ref.size].cpu().numpy().reshape(ref.shape), ref
 
-    def cnt(name, ref):
-        nonlocal total
-        dev = eng.debug_buffer(name)[:ref.size].cpu().numpy().reshape(ref.shape)
-        total += int(((dev > 0) != (ref > 0)).sum())
+    def per_pass(name, refs):
+        dev, _ = grab(name, np.concatenate(refs))
+        off = 0
+        for ref in refs:
+            yield dev[off:off + ref.shape[0]], ref
+            off += ref.shape[0]
 
     if 'enc' in caches:
         for i in range(3):
-            cnt(f'ea{i + 1}', caches['enc']['a'][i + 1])
+            yield grab(f'ea{i + 1}', caches['enc']['a'][i + 1])
     for k in range(4):
-        cnt(f'sg_h1_{k}', caches['gen']['blocks'][k]['h1']); cnt(f'sg_h2_{k}', caches['gen']['blocks'][k]['h2'])
-        cnt(f'sd_h1_{k}', np.concatenate([c['blocks'][k]['h1'] for c in caches['disc']]))
-        cnt(f'sd_h2_{k}', np.concatenate([c['blocks'][k]['h2'] for c in caches['disc']]))
-    cnt('sg_hf', caches['gen']['h'])
-    return total
+        yield grab(f'sg_h1_{k}', caches['gen']['blocks'][k]['h1'])
+        yield grab(f'sg_h2_{k}', caches['gen']['blocks'][k]['h2'])
+        yield from per_pass(f'sd_h1_{k}', [c['blocks'][k]['h1'] for c in caches['disc']])
+        yield from per_pass(f'sd_h2_{k}', [c['blocks'][k]['h2'] for c in caches['disc']])
+    yield grab('sg_hf', caches['gen']['h'])
 
 
 RN_CASES = [(32, 16, 32, 2, 'f32'), (64, 32, 32, 2, 'bf16x3'), (64, 128, 64, 1, 'bf16x3')]
+RN = lambda eng, m: (lambda c: _pairs_rn(eng, m, c))
 
 
 @pytest.mark.parametrize('h,zdim,dim,n,math', RN_CASES)
@@ -222,11 +226,10 @@ def test_resnet_generator_phase(h, zdim, dim, n, math):
     m, p, x, z, alpha = _setup_rn(h, zdim, dim, n)
     eng = _engine_rn(m, p, n, math)
     out = eng.phase('Generator', z=z)
-    caches = {}
-    ls, g = m.gen_phase(p, z, caches)
+    ls, g, flips = _oracle_with_device_pattern(RN(eng, m), math, lambda c: m.gen_phase(p, z, c), 'rn.gen')
     assert _rel(out['generated'].cpu().numpy(), ls['generated']) < TOL
     assert abs(out['gen_loss'].item() - ls['gen_loss']) < TOL * max(1.0, abs(ls['gen_loss']))
-    _check_grads(eng, m, g, 'Generator', 'gen', TOL if _flips_rn(eng, m, caches) == 0 else TOL_KINK)
+    _check_grads(eng, m, g, 'Generator', 'gen')
 
 
 @pytest.mark.parametrize('h,zdim,dim,n,math', RN_CASES)
@@ -234,13 +237,10 @@ def test_resnet_critic_phase(h, zdim, dim, n, math):
     m, p, x, z, alpha = _setup_rn(h, zdim, dim, n, seed=1)
     eng = _engine_rn(m, p, n, math)
     out = eng.phase('Discriminator', x=x, z=z, alpha=alpha)
-    caches = {}
-    ls, g = m.disc_phase(p, x, z, alpha, caches)
-    flips = _flips_rn(eng, m, caches)
+    ls, g, flips = _oracle_with_device_pattern(RN(eng, m), math, lambda c: m.disc_phase(p, x, z, alpha, c), 'rn.disc')
     _check_critic_scalars(out, ls, flips)
-    tol = TOL if flips == 0 else TOL_KINK
-    assert _rel(eng.debug_buffer('Gx')[:ls['ddx'].size].cpu().numpy().reshape(ls['ddx'].shape), ls['ddx']) < tol
-    _check_grads(eng, m, g, 'Discriminator', 'disc', tol)
+    assert _rel(eng.debug_buffer('Gx')[:ls['ddx'].size].cpu().numpy().reshape(ls['ddx'].shape), ls['ddx']) < TOL
+    _check_grads(eng, m, g, 'Discriminator', 'disc')
 
 
 @pytest.mark.parametrize('h,zdim,dim,n,math', RN_CASES)
@@ -248,26 +248,25 @@ def test_resnet_encoder_phase_and_reconstruct(h, zdim, dim, n, math):
     m, p, x, z, alpha = _setup_rn(h, zdim, dim, n, seed=2)
     eng = _engine_rn(m, p, n, math)
     out = eng.phase('Encoder', x=x, want_l1=True)
-    caches = {}
-    ls, g = m.enc_phase(p, x, caches)
+    ls, g, flips = _oracle_with_device_pattern(RN(eng, m), math, lambda c: m.enc_phase(p, x, c), 'rn.enc')
     for k in ('loss_img', 'loss_fts', 'enc_loss', 'reconstructionLoss'):
         assert abs(out[k].item() - ls[k]) < TOL * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
     assert _rel(out['z_enc'].cpu().numpy(), ls['z_enc']) < TOL
     assert _rel(out['reconstruction'].cpu().numpy(), ls['reconstruction']) < TOL
-    _check_grads(eng, m, g, 'Encoder', 'enc', TOL if _flips_rn(eng, m, caches) == 0 else TOL_KINK)
+    _check_grads(eng, m, g, 'Encoder', 'enc')
     assert _rel(eng.reconstruct(x)['reconstruction'].cpu().numpy(), m.reconstruct(p, x)) < TOL
 
 
 def test_resnet_bf16x3_all_mode_is_close_but_not_parity_rated():
     """UAD_MATH_BF16X3_ALL (opt-in): every contraction in bf16x3.  Single contractions stay inside 1e-4 (tests/test_gpu_ops_resnet.py
-    under UAD_MATH=bf16x3); through the 20-layer critic the scalars drift -- this test pins the drift below 2e-3."""
+    under UAD_MATH=bf16x3); through the 20-layer critic the scalars drift past 1e-4 -- this test pins the drift (scalars and, with the device's
+    activation pattern, every gradient tensor) below 5e-4."""
     m, p, x, z, alpha = _setup_rn(64, 32, 32, 2, seed=1)
     eng = _engine_rn(m, p, 2, 'bf16x3_all')
     out = eng.phase('Discriminator', x=x, z=z, alpha=alpha)
-    ls, g = m.disc_phase(p, x, z, alpha)
-    for k in ('disc_fake', 'disc_real', 'penalty', 'disc_loss'):
-        assert abs(out[k].item() - ls[k]) < 2e-3 * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
-    _check_grads(eng, m, g, 'Discriminator', 'disc', TOL_KINK)
+    ls, g, flips = _oracle_with_device_pattern(RN(eng, m), 'bf16x3_all', lambda c: m.disc_phase(p, x, z, alpha, c), 'rn.all')
+    _check_critic_scalars(out, ls, flips, tol=5e-4)
+    _check_grads(eng, m, g, 'Discriminator', 'disc', 5e-4)
 
 
 # ------------------------------------------------------------------ AnoVAE-GAN (models/anovaegan.py, trainers/AnoVAEGAN.py)
@@ -299,29 +298,25 @@ def test_anovaegan_phases(h, zdim, n, math, drop):
     eng = _engine_av(m, p, n, math)
     # VAE phase: Encoder + Generator gradients
     out = eng.phase('Encoder', x=x, eps=eps, mask_z=mm, mask_sigma=ms, want_l1=True)
-    caches = {}
-    ls, g = m.vae_phase(p, x, eps, mm, ms, caches)
+    UN = lambda c: _pairs(eng, m, c)
+    ls, g, flips = _oracle_with_device_pattern(UN, math, lambda c: m.vae_phase(p, x, eps, mm, ms, c), 'av.vae')
     for k in ('reconstructionLoss', 'kl', 'enc_loss'):
         assert abs(out[k].item() - ls[k]) < TOL * max(1.0, abs(ls[k])), (k, out[k].item(), ls[k])
     assert _rel(out['reconstruction'].cpu().numpy(), ls['reconstruction']) < TOL
     assert _rel(out['L1'].cpu().numpy(), ls['L1']) < TOL
-    tol = TOL if _flips(eng, m, caches) == 0 else TOL_KINK
-    _check_grads(eng, m, g, 'Encoder', 'vae', tol)
-    _check_grads(eng, m, g, 'Generator', 'vae', tol)
+    _check_grads(eng, m, g, 'Encoder', 'vae')
+    _check_grads(eng, m, g, 'Generator', 'vae')
     # generator phase
     out = eng.phase('Generator', x=x, eps=eps, mask_z=mm, mask_sigma=ms)
-    caches = {}
-    ls, g = m.gen_phase(p, x, eps, mm, ms, caches)
+    ls, g, flips = _oracle_with_device_pattern(UN, math, lambda c: m.gen_phase(p, x, eps, mm, ms, c), 'av.gen')
     assert abs(out['gen_loss'].item() - ls['gen_loss']) < TOL * max(1.0, abs(ls['gen_loss']))
     assert _rel(out['reconstruction'].cpu().numpy(), ls['reconstruction']) < TOL
-    _check_grads(eng, m, g, 'Generator', 'gen', TOL if _flips(eng, m, caches) == 0 else TOL_KINK)
+    _check_grads(eng, m, g, 'Generator', 'gen')
     # critic phase
     out = eng.phase('Discriminator', x=x, eps=eps, alpha=alpha, mask_z=mm, mask_sigma=ms)
-    caches = {}
-    ls, g = m.disc_phase(p, x, eps, alpha, mm, ms, caches)
-    flips = _flips(eng, m, caches)
+    ls, g, flips = _oracle_with_device_pattern(UN, math, lambda c: m.disc_phase(p, x, eps, alpha, mm, ms, c), 'av.disc')
     _check_critic_scalars(out, ls, flips)
-    _check_grads(eng, m, g, 'Discriminator', 'disc', TOL if flips == 0 else TOL_KINK)
+    _check_grads(eng, m, g, 'Discriminator', 'disc')
     assert _rel(eng.reconstruct(x, eps=eps)['reconstruction'].cpu().numpy(), m.reconstruct(p, x, eps)) < TOL
 
 
@@ -353,22 +348,28 @@ def test_unified_critic_phase_batch16():
     m, p, x, z, alpha, mz, mg = _setup(64, 8, 32, 16, seed=7)
     eng = _engine(m, p, 16, 'bf16x3')
     out = eng.phase('Discriminator', x=x, z=z, alpha=alpha)
-    caches = {}
-    ls, g = m.disc_phase(p, x, z, alpha, None, caches)
-    flips = _flips(eng, m, caches)
+    ls, g, flips = _oracle_with_device_pattern(lambda c: _pairs(eng, m, c), 'bf16x3', lambda c: m.disc_phase(p, x, z, alpha, None, c), 'disc16')
     _check_critic_scalars(out, ls, flips)
-    _check_grads(eng, m, g, 'Discriminator', 'disc', TOL if flips == 0 else TOL_KINK)
+    _check_grads(eng, m, g, 'Discriminator', 'disc')
 
 
 def test_resnet_critic_phase_batch4_dim64():
     m, p, x, z, alpha = _setup_rn(64, 64, 64, 4, seed=9)
     eng = _engine_rn(m, p, 4, 'f32')
     out = eng.phase('Discriminator', x=x, z=z, alpha=alpha)
-    caches = {}
-    ls, g = m.disc_phase(p, x, z, alpha, caches)
-    flips = _flips_rn(eng, m, caches)
+    ls, g, flips = _oracle_with_device_pattern(RN(eng, m), 'f32', lambda c: m.disc_phase(p, x, z, alpha, c), 'rn.disc4')
     _check_critic_scalars(out, ls, flips)
-    _check_grads(eng, m, g, 'Discriminator', 'disc', TOL if flips == 0 else TOL_KINK)
+    _check_grads(eng, m, g, 'Discriminator', 'disc')
+
+
+def test_resnet_critic_phase_at_the_bench_batch():
+    """BASELINE.json configs[3] at the batch `bench.py --arch fAnoGAN --variant resnet` times: 64 x 64, dim 64, 32 slices per GPU, split-bf16."""
+    m, p, x, z, alpha = _setup_rn(64, 128, 64, 32, seed=11)
+    eng = _engine_rn(m, p, 32, 'bf16x3')
+    out = eng.phase('Discriminator', x=x, z=z, alpha=alpha)
+    ls, g, flips = _oracle_with_device_pattern(RN(eng, m), 'bf16x3', lambda c: m.disc_phase(p, x, z, alpha, c), 'rn.disc32')
+    _check_critic_scalars(out, ls, flips)
+    _check_grads(eng, m, g, 'Discriminator', 'disc')
 
 
 # ------------------------------------------------------------------ AAE family (ConstrainedAE / AAE / ConstrainedAAE)

@@ -45,7 +45,9 @@ def _masks(rng, n, zdim, flat, keys):
 def _report(tag, math, flips, worst):
     tot = sum(flips.values())
     w = max(worst, key=worst.get)
-    print(f'\n[{tag} {math}] activation flips vs fp64 oracle: {tot} {dict((k, v) for k, v in flips.items() if v)}; '
+    mags = getattr(flips, 'mag', None) or {}
+    print(f'\n[{tag} {math}] activation flips vs fp64 oracle: {tot} {dict((k, v) for k, v in flips.items() if v)}; largest oracle |pre-activation| among '
+          f'them (of the tensor max): {dict((k, float(f"{v:.1e}")) for k, v in mags.items())}; L1-sign disagreements: {getattr(flips, "l1_sign", 0)}; '
           f'worst gradient tensor {w}: {worst[w]:.2e}')
     return tot
 
@@ -69,7 +71,7 @@ def test_ae_vae_gradients_at_baseline_batch(arch, n):
     for math in MODES:
         eng.set_math(math)
         got = eng.forward(x, eps, masks, want_backward=True)
-        act, flips = device_activation_pattern(eng, p32, x, got['x_hat'], cache, 4, VAE_BN)
+        act, flips = device_activation_pattern(eng, p32, x, got['x_hat'], cache, 4, VAE_BN, math=math, xhat_oracle=out['x_hat'])
         eng.backward()
         torch.cuda.synchronize()
         assert_close(got['x_hat'].cpu().numpy(), out['x_hat'], name='x_hat')
@@ -106,7 +108,7 @@ def test_vae_small_width_ragged_batch():
     for math in MODES:
         eng.set_math(math)
         got = eng.forward(x, eps, masks, want_backward=True)
-        act, flips = device_activation_pattern(eng, p32, x, got['x_hat'], cache, 2, bn)
+        act, flips = device_activation_pattern(eng, p32, x, got['x_hat'], cache, 2, bn, math=math, xhat_oracle=out['x_hat'])
         eng.backward()
         torch.cuda.synchronize()
         g = m.backward(p64, x64, out, cache, m64, act=act)
@@ -141,8 +143,8 @@ def test_cevae_gradients_at_baseline_batch(n):
     for math in MODES:
         eng.set_math(math)
         got = eng.forward(x, eps, masks, want_backward=True, x_ce=x_ce)
-        act_v, fl_v = device_activation_pattern(eng, p32, x, got['x_hat'], caches[1], 4, VAE_BN, rows=slice(0, n))
-        act_c, fl_c = device_activation_pattern(eng, p32, x_ce, got['x_hat_ce'], caches[3], 4, VAE_BN, rows=slice(n, 2 * n))
+        act_v, fl_v = device_activation_pattern(eng, p32, x, got['x_hat'], caches[1], 4, VAE_BN, rows=slice(0, n), math=math)
+        act_c, fl_c = device_activation_pattern(eng, p32, x_ce, got['x_hat_ce'], caches[3], 4, VAE_BN, rows=slice(n, 2 * n), math=math)
         eng.backward()
         torch.cuda.synchronize()
         assert_close(got['x_hat'].cpu().numpy(), out['x_hat'], name='x_hat')
@@ -181,7 +183,7 @@ def test_gmvae_spatial_gradients_at_baseline_batch():
     for math in MODES:
         eng.set_math(math)
         got = eng.gm_forward(x, e_w, e_z, want_backward=True)
-        act, flips = device_activation_pattern(eng, p32, x, got['x_hat'], cache, 5, bn, final_kernel='dec_Conv2D_final/kernel')
+        act, flips = device_activation_pattern(eng, p32, x, got['x_hat'], cache, 5, bn, final_kernel='dec_Conv2D_final/kernel', math=math)
         eng.backward()
         torch.cuda.synchronize()
         assert_close(got['x_hat'].cpu().numpy(), out['xz_mu'], name='xz_mu')

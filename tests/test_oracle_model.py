@@ -222,3 +222,28 @@ def test_vae_restore_grads_vs_torch():
     obj = x.shape[0] * L['loss'] + tv * tvn          # sum over samples of (rec_n + kl_n) = N * mean
     obj.backward()
     np.testing.assert_allclose(g, xt.grad.numpy(), rtol=1e-7, atol=1e-10)
+
+
+def test_act_override_differentiates_with_a_foreign_activation_pattern():
+    """oracle.nn.act_override (the hook behind tests/gpu_util.py: kink_overrides): with a pattern table keyed by the fingerprint of a site's
+    post-activation array, leaky_relu_bwd takes the derivative sides of the table instead of its own; sites without an entry and runs outside
+    the context are untouched; the second run of the same forward reproduces the fingerprints bit for bit."""
+    from oracle import nn as onn
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal((2, 4, 4, 8))
+    g = rng.standard_normal(y.shape)
+    post = onn.leaky_relu_fwd(y, 0.3)
+    own = onn.leaky_relu_bwd(y, g, 0.3)
+    np.testing.assert_array_equal(own, np.where(y > 0, g, 0.3 * g))
+    pat = y > 0
+    pat[0, 0, 0, :3] ^= True                                    # three elements taken on the other side
+    table = {onn.act_fingerprint(post): pat}
+    with onn.act_override(table) as ov:
+        got = onn.leaky_relu_bwd(y.copy(), g, 0.3)              # a recomputed (bit-identical) pre-activation finds its entry
+        other = onn.leaky_relu_bwd(y + 1.0, g, 0.3)             # another site: no entry
+        assert len(ov.used) == 1
+    np.testing.assert_array_equal(got, np.where(pat, g, 0.3 * g))
+    np.testing.assert_array_equal(other, np.where(y + 1.0 > 0, g, 0.3 * g))
+    np.testing.assert_array_equal(onn.leaky_relu_bwd(y, g, 0.3), own)          # outside the context: the oracle's own pattern
+    # relu written as maximum(y, 0) and as where(y > 0, y, 0 * y) share a fingerprint (-0.0 folded)
+    assert onn.act_fingerprint(np.maximum(y, 0)) == onn.act_fingerprint(onn.leaky_relu_fwd(y, 0.0))
