@@ -2014,6 +2014,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         }
     };
     auto convert_stage = [&](int c0) {
+        // this thread's channel quad is the same for every element (NT % CQ == 0): its table rows are read once per chunk, not once per element
+        const int cq_t = tid % CQ;
+        const float4 t_sc = (xf || fb) ? *reinterpret_cast<const float4*>(s_xf + c0 + cq_t * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 t_sh = (xf || FB == 1) ? *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq_t * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 t_wf = fb ? *reinterpret_cast<const float4*>(s_xf + 2 * XF_LDS_CH + c0 + cq_t * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int f = tid + u * NT;
@@ -2030,8 +2035,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             }
             if (fbb) {
                 // the same from the pattern word the fused forward epilogue left: the derivative side of every channel is one bit
-                const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
-                const float4 wf = *reinterpret_cast<const float4*>(s_xf + 2 * XF_LDS_CH + c0 + cq * 4);
+                const float4 sc = t_sc, wf = t_wf;
                 const float g = ok ? pg[u] : 0.f;
                 const unsigned b = pb[u] >> (c0 + cq * 4);
                 t.x = g * wf.x * ((b & 1u) ? sc.x : sc.x * a.xf.alpha);
@@ -2040,18 +2044,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
                 t.w = g * wf.w * ((b & 8u) ? sc.w : sc.w * a.xf.alpha);
             } else if (fb) {
                 // final-backward on load: t = dxhat[pixel] * wf * lrelu'(bn(c)) * scale  (see UadXform::fb_*)
-                const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
-                const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
-                const float4 wf = *reinterpret_cast<const float4*>(s_xf + 2 * XF_LDS_CH + c0 + cq * 4);
+                const float4 sc = t_sc, sh = t_sh, wf = t_wf;
                 const float g = ok ? pg[u] : 0.f;
                 t.x = g * wf.x * (fmaf(t.x, sc.x, sh.x) > 0.f ? sc.x : sc.x * a.xf.alpha);
                 t.y = g * wf.y * (fmaf(t.y, sc.y, sh.y) > 0.f ? sc.y : sc.y * a.xf.alpha);
                 t.z = g * wf.z * (fmaf(t.z, sc.z, sh.z) > 0.f ? sc.z : sc.z * a.xf.alpha);
                 t.w = g * wf.w * (fmaf(t.w, sc.w, sh.w) > 0.f ? sc.w : sc.w * a.xf.alpha);
             } else if (xf) {
-                const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
-                const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
-                t = xform4(t, sc, sh, a.xf.alpha);
+                t = xform4(t, t_sc, t_sh, a.xf.alpha);
             }
             t = keep4(ok, t);
             uint2 hi, lo;
@@ -3102,11 +3102,13 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     constexpr int BIGP = CK * CSTP;               // ushorts per plane
     constexpr int LDP = TH * TW + 8;  // ushorts per channel row of the transposed small tile
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    unsigned short* bHi = reinterpret_cast<unsigned short*>(dsm);
-    unsigned short* bLo = bHi + BIGP;
-    unsigned short* sHiT = bLo + BIGP;
-    unsigned short* sLoT = sHiT + NCSB * CK * LDP;
-    float* sXf = reinterpret_cast<float*>(sLoT + NCSB * CK * LDP);   // [32] big scale, [32] big shift, [64] small scale, [64] small shift
+    // DB: two tile buffers (NCSB = 2: one 8-wave workgroup per CU, 2 x 77 KB of its 160 KB): tile t + 1 is converted and scattered into one
+    // buffer while tile t is contracted out of the other, ONE barrier per tile.  Measured in round 3: neutral (+- 1 us on every layer) -- the
+    // tile loop is not waiting at its barriers -- so it stays off (the second buffer would cost the LDS of a second resident workgroup).
+    constexpr bool DB = false;
+    constexpr int BUFP = 2 * BIGP + 2 * NCSB * CK * LDP;         // ushorts of one tile buffer
+    unsigned short* bHi0 = reinterpret_cast<unsigned short*>(dsm);
+    float* sXf = reinterpret_cast<float*>(bHi0 + (DB ? 2 : 1) * BUFP);   // [32] big scale, [32] big shift, [64] small scale, [64] small shift
     float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
 
     const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
@@ -3230,7 +3232,11 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
             } else sv[u] = *reinterpret_cast<const float4*>(a.small_ + (spix + po) * d.CS + cs0 + csq * 4);
         }
     };
-    auto commit = [&](int t) __attribute__((always_inline)) {
+    auto commit = [&](int t, int buf) __attribute__((always_inline)) {
+        unsigned short* bHi = bHi0 + buf * BUFP;
+        unsigned short* bLo = bHi + BIGP;
+        unsigned short* sHiT = bLo + BIGP;
+        unsigned short* sLoT = sHiT + NCSB * CK * LDP;
         int n, ty0, tx0;
         tile_origin(t, n, ty0, tx0);
         const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
@@ -3286,11 +3292,26 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
         }
     };
     if (t_begin < t_end) issue(t_begin);
-    for (int t = t_begin; t < t_end; ++t) {
-        __syncthreads();                   // the previous tile's fragments are consumed (first pass: the sXf tables are written)
-        commit(t);
-        if (t + 1 < t_end) issue(t + 1);   // in flight across the barrier and the MFMA loop below
+    if (DB) {
+        __syncthreads();                       // the sXf tables are written
+        if (t_begin < t_end) commit(t_begin, 0);
+        if (t_begin + 1 < t_end) issue(t_begin + 1);
         __syncthreads();
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = DB ? ((t - t_begin) & 1) : 0;
+        if (DB) {
+            if (t + 1 < t_end) { commit(t + 1, cur ^ 1); if (t + 2 < t_end) issue(t + 2); }
+        } else {
+            __syncthreads();                   // the previous tile's fragments are consumed (first pass: the sXf tables are written)
+            commit(t, 0);
+            if (t + 1 < t_end) issue(t + 1);   // in flight across the barrier and the MFMA loop below
+            __syncthreads();
+        }
+        const unsigned short* bHi = bHi0 + cur * BUFP;
+        const unsigned short* bLo = bHi + BIGP;
+        const unsigned short* sHiT = bLo + BIGP;
+        const unsigned short* sLoT = sHiT + NCSB * CK * LDP;
         if (!(a.abl & 2))
 #pragma unroll
         for (int js = 0; js < TH * TW / 16; ++js) {
@@ -3320,6 +3341,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
                 mma3(acc[6], frag(h, 2), frag(l, 2), bh, bl);
             }
         }
+        if (DB) __syncthreads();               // buffer `cur` is consumed, buffer `cur ^ 1` is written
     }
 
     // Accumulator block -> slab.  One 64-bit address per lane; everything else is a wave-uniform 32-bit offset (the plain form
