@@ -3093,10 +3093,17 @@ conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
 // kx >> 1, so one segment read (2 x ds_read_b64 + 1 x ds_read_b32 per plane) serves every tap of that row and parity: offsets 0 and 2 are
 // register selections, offset 1 four v_alignbit.  Taps are dealt to the four waves by kernel ROW (wave w: the five taps of row w, tap (4, w), and
 // its quarter of tap (4, 4)) so that a wave's taps share its segment reads: ~20 LDS reads and <= 24 VALU per 16-position step instead of ~100 each.
-template <int NCSB, bool FBB = false>
-__global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
+// TW8: EIGHT tap-waves per cs block instead of four (512 threads per cs block).  The round-3 ablations (profiles/README.md) put ~45 % of this
+// kernel's time in staging work that neither the loads, the LDS stores nor the MFMAs account for -- a latency-bound conversion / scatter loop
+// at two waves per SIMD.  With the taps dealt to eight waves (three or four 32 x 32 accumulators each instead of seven) a wave needs < 128
+// registers: four waves per SIMD, twice the threads staging every tile, the same MFMA work per tile.
+//   tap group 2 r     (r = kernel row 0..3): taps (r, 0), (r, 2), (r, 4) -- one even-column segment read serves all three -- and, at step
+//                     js == r, its share of tap (4, 4);
+//   tap group 2 r + 1: taps (r, 1), (r, 3) -- one odd-column segment read -- and tap (4, r).
+template <int NCSB, bool FBB = false, bool TW8 = false>
+__global__ void __launch_bounds__((TW8 ? 512 : 256) * NCSB) __attribute__((amdgpu_waves_per_eu(TW8 ? 4 : 2)))
 conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
-    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256 * NCSB, CSQ = 8 * NCSB;
+    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = (TW8 ? 512 : 256) * NCSB, CSQ = 8 * NCSB;
     constexpr int XHP = 12;                       // 16-bit slots per (channel, row, parity) segment: columns 0,2,..,18 / 1,3,..,17 (+ slack)
     constexpr int CSTP = IH * 2 * XHP + 4;        // channel stride (ushorts): 920 B = an odd number of 8-byte units -> the lanes' b64 reads spread over all banks
     constexpr int BIGP = CK * CSTP;               // ushorts per plane
@@ -3113,7 +3120,9 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
 
     const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
-    const int wave = wave_all & 3, csb = wave_all >> 2;   // tap group / cs block of this wave
+    const int wave = TW8 ? ((wave_all & 7) >> 1) : (wave_all & 3);   // kernel row of this wave's taps
+    const int csb = TW8 ? (wave_all >> 3) : (wave_all >> 2);          // its cs block
+    const bool todd = TW8 && (wave_all & 1);                          // TW8: the odd-column tap group of the row
     const int l31 = lane & 31, lh = lane >> 5;
     const UadConvDesc& d = a.d;
     const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32 * NCSB;
@@ -3145,7 +3154,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
         }
     }
 
-    constexpr int MAXT = 7;
+    constexpr int MAXT = TW8 ? 4 : 7;
     // segment base of this lane's channel for kernel row ky at tile-row half lh (ushorts): row y = 4 js + 2 lh + ky
     const int seg_own = l31 * CSTP + ((2 * lh + wave) * 2) * XHP;          // ky = wave, parity 0; parity 1 at + XHP; step js at + 8 js XHP
     const int seg_k4 = l31 * CSTP + ((2 * lh + 4) * 2) * XHP;              // ky = 4
@@ -3188,7 +3197,8 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     float4 v[FBB ? 1 : PER];
     unsigned vb[FBB ? PER : 1];
     float vg[FBB ? PER : 1];
-    float4 sv[2];
+    constexpr int SPER = TH * TW * CSQ / NT;          // 16-byte elements of the small tile per thread (2, or 1 with TW8)
+    float4 sv[SPER];
     auto tile_origin = [&](int t, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
         tx0 = (t % tilesx) * TW;
         ty0 = ((t / tilesx) % tilesy) * TH;
@@ -3222,7 +3232,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
         }
         const size_t spix = ((size_t)(n * d.HS + ty0) * d.WS + tx0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SPER; ++u) {
             const int idx = tid + u * NT;
             const int pos = idx / CSQ, csq = idx % CSQ;
             const unsigned po = (unsigned)((pos / TW) * d.WS + (pos % TW));
@@ -3275,7 +3285,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
             if (ix >= IW) { ix -= IW; ++iy; }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SPER; ++u) {
             const int idx = tid + u * NT;
             const int pos = idx / CSQ, csq = idx % CSQ;
             float4 tv = sv[u];
@@ -3319,6 +3329,26 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
             const uint4 bh = *reinterpret_cast<const uint4*>(sHiT + baddr + 16 * js);
             const uint4 bl = *reinterpret_cast<const uint4*>(sLoT + baddr + 16 * js);
             const int so = seg_own + (8 * js) * XHP, sk = seg_k4 + (8 * js) * XHP;
+            if constexpr (TW8) {
+                if (!todd) {   // even columns of the own row: taps kx = 0, 2, 4
+                    const Seg h = read_seg(bHi, so), l = read_seg(bLo, so);
+                    mma3(acc[0], frag(h, 0), frag(l, 0), bh, bl);
+                    mma3(acc[1], frag(h, 1), frag(l, 1), bh, bl);
+                    mma3(acc[2], frag(h, 2), frag(l, 2), bh, bl);
+                    if (js == wave) {   // this row's share of tap (4, 4)
+                        const Seg h4 = read_seg(bHi, sk), l4 = read_seg(bLo, sk);
+                        mma3(acc[3], frag(h4, 2), frag(l4, 2), bh, bl);
+                    }
+                } else {       // odd columns: taps kx = 1, 3, and tap (4, row)
+                    const Seg h = read_seg(bHi, so + XHP), l = read_seg(bLo, so + XHP);
+                    mma3(acc[0], frag(h, 0), frag(l, 0), bh, bl);
+                    mma3(acc[1], frag(h, 1), frag(l, 1), bh, bl);
+                    const int a4 = sk + (wave & 1) * XHP;
+                    const Seg h4 = read_seg(bHi, a4), l4 = read_seg(bLo, a4);
+                    const bool one = (wave >> 1) != 0;
+                    mma3(acc[2], one ? frag(h4, 1) : frag(h4, 0), one ? frag(l4, 1) : frag(l4, 0), bh, bl);
+                }
+            } else {
             {   // own kernel row, even columns: taps kx = 0, 2, 4
                 const Seg h = read_seg(bHi, so), l = read_seg(bLo, so);
                 mma3(acc[0], frag(h, 0), frag(l, 0), bh, bl);
@@ -3340,6 +3370,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
                 const Seg h = read_seg(bHi, sk), l = read_seg(bLo, sk);
                 mma3(acc[6], frag(h, 2), frag(l, 2), bh, bl);
             }
+            }
         }
         if (DB) __syncthreads();               // buffer `cur` is consumed, buffer `cur ^ 1` is written
     }
@@ -3352,16 +3383,20 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     if (!(a.abl & 8))
 #pragma unroll
     for (int j = 0; j < MAXT - 1; ++j) {
-        const int tap = j < 5 ? 5 * wave + j : 20 + wave;
+        // TW8: even group -> taps (row, 0 / 2 / 4); odd group -> (row, 1), (row, 3), (4, row).  Else: (row, 0..4), (4, row).
+        const int tap = TW8 ? (todd ? (j < 2 ? 5 * wave + 2 * j + 1 : 20 + wave) : 5 * wave + 2 * j) : (j < 5 ? 5 * wave + j : 20 + wave);
         float* ot = ob + tap * tapstride;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2)) * CSi] = acc[j][r];
     }
+    // tap (4, 4): the four rows' shares are folded through LDS in a fixed order
     __syncthreads();
+    if (!TW8 || !todd) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sRed[(wave_all * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
+        for (int r = 0; r < 16; ++r) sRed[((csb * 4 + wave) * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
+    }
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && !todd) {
         float* ot = ob + 24 * tapstride;
         const float* q = sRed + (size_t)csb * 64 * 64;
 #pragma unroll
@@ -3788,6 +3823,26 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                 const bool two = pair_ok && d.CS % 64 == 0;
                 if (two) grid.y = d.CS / 64;
                 const size_t lds = conv5_w_bf16_t_lds_bytes(two ? 2 : 1);
+                // eight tap-waves per cs block (four waves per SIMD): measured 15-50 % SLOWER in round 3 (spills at 128 registers, twice the
+                // small-tile fragment reads) -- opt-in experiment
+                static const bool tw8 = getenv("UAD_W_TW8") != nullptr;
+                if (tw8) {
+                    static bool t8_attr = false;
+                    if (!t8_attr) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(1));
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(2));
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(1));
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(2));
+                        t8_attr = true;
+                    }
+                    if (xfb.fb_bits) {
+                        if (two) hipLaunchKernelGGL((conv5_w_bf16_t_kernel<2, true, true>), grid, dim3(1024), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                        else hipLaunchKernelGGL((conv5_w_bf16_t_kernel<1, true, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                    } else {
+                        if (two) hipLaunchKernelGGL((conv5_w_bf16_t_kernel<2, false, true>), grid, dim3(1024), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                        else hipLaunchKernelGGL((conv5_w_bf16_t_kernel<1, false, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                    }
+                } else
                 if (xfb.fb_bits) {
                     if (two) hipLaunchKernelGGL((conv5_w_bf16_t_kernel<2, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
                     else hipLaunchKernelGGL((conv5_w_bf16_t_kernel<1, true>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
