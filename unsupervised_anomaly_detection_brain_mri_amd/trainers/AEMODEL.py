@@ -193,7 +193,7 @@ class AEMODEL(DLMODEL):
     def _shard(self, dataset, phase, **kw):
         """This rank's slice of the next GLOBAL batch (config.batchsize slices per rank, contiguous partitioning): every rank advances the
         same dataset cursor over batchsize * world slices and keeps rows [rank * bs, (rank + 1) * bs)."""
-        bs, w = self.config.batchsize, self.dp.world
+        bs, w = self.config.batchsize, getattr(getattr(self, 'dp', None), 'world', 1)
         got = dataset.next_batch(bs * w, set=phase.value, **kw)
         if w == 1:
             return got
@@ -203,7 +203,7 @@ class AEMODEL(DLMODEL):
     def _num_batches(self, dataset, phase):
         """Steps of one epoch: the dataset is walked in GLOBAL batches of config.batchsize * world slices (every rank takes its share, _shard)."""
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
-        return dataset.num_batches(self.config.batchsize * self.dp.world, set=phase.value)
+        return dataset.num_batches(self.config.batchsize * getattr(getattr(self, 'dp', None), 'world', 1), set=phase.value)
 
     def process(self, dataset, epoch, phase, optim=None):       # trainers/VAE.py:76-103
         """One epoch.  The loop body only ENQUEUES work: the batch comes from the dataset (device tensors when it is an HBM-resident
