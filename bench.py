@@ -591,7 +591,7 @@ def main():
         by = bytes_per_tag(BATCH * (2 if cevae else 1), fin_bits=(math != 'f32'))
         gbs = by[dom] / (dom_ms * 1e-3) / 1e9
         traffic = None
-        for cand in (f'r02_traffic_{math}.json', f'r01_traffic_{math}.json'):
+        for cand in (f'r03_traffic_{math}.json', f'r02_traffic_{math}.json', f'r01_traffic_{math}.json'):
             try:
                 doc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
                 tr = doc.get(dom)

@@ -36,15 +36,25 @@ for (name, grid, wg), n, f, w in rows[:40]:
     print(f'| `{name[:80]}` | {grid} | {n} | {f / 1e6:.1f} | {w / 1e6:.1f} |')
 
 # tag -> (kernel substring, grid threads) at N=64, 128x128 (grid = blocks * threads)
+MATH = sys.argv[5] if len(sys.argv) > 5 else 'bf16x3'
 TAGS = {
-    'dec3.fwd': ('conv5_d16_kernel<8, 16, 32, 4, 1', 32 * 64 * 256),
-    'dec2.fwd': ('conv5_d16_kernel<8, 16, 64, 4, 1', 8 * 64 * 256),
-    'enc1.dgrad': ('conv5_d16_kernel<8, 16, 64, 4, 1', 32 * 64 * 256),
+    # round 3: the ConvT-class launches run the lane = pixel kernel (uad_conv16s.inc): <TH, TW, CST, WGM, WGN, MF, EPI, PP>
+    'dec3.fwd': ('conv5_d16s_kernel<8, 16, 32, 4, 1, 1, 2', 32 * 64 * 256),
+    'dec2.fwd': ('conv5_d16s_kernel<8, 16, 64, 4, 1, 1, 0', 8 * 64 * 256),
+    'enc1.dgrad': ('conv5_d16s_kernel<8, 16, 64, 4, 1, 1, 1', 8 * 64 * 256),
     'dec3.dgrad': ('conv5_f16_kernel<8, 16, 16, 4, 1', 32 * 64 * 256),
     'dec2.dgrad': ('conv5_f16_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
     'enc1.fwd': ('conv5_f16_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
     'dec3.wgrad': ('conv5_w_bf16_t_kernel<1, true', 512 * 256),
     'enc1.wgrad': ('conv5_w_bf16_t_kernel<2, false', 256 * 512),
+    'final.fwd+bwd': ('final_kernel<true>', 32 * 64 * 256),
+} if MATH != 'f32' else {
+    # exact-fp32 mode (v_mfma_f32_32x32x2_f32 kernels)
+    'dec3.fwd': ('conv5_d_kernel<8, 16, 32, 4, 1', 32 * 64 * 256),
+    'dec3.dgrad': ('conv5_f_kernel<8, 16, 16, 4, 1', 32 * 64 * 256),
+    'dec2.dgrad': ('conv5_f_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
+    'enc1.fwd': ('conv5_f_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
+    'dec3.wgrad': ('conv5_w_kernel', 512 * 256),
     'final.fwd+bwd': ('final_kernel<true>', 32 * 64 * 256),
 }
 out = {}
@@ -54,6 +64,7 @@ for tag, (sub, grid) in TAGS.items():
         k, n, f, w = max(cands, key=lambda c: c[2] + c[3])
         out[tag] = {'kernel': sub, 'fetch_bytes': f, 'write_bytes': w, 'launches': n}
 out['_commit'] = sys.argv[4] if len(sys.argv) > 4 else 'unknown'
+out['_math'] = MATH
 out['_note'] = ('HBM bytes per launch from rocprofv3 PMC on MI355X (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes with '
                 '--kernel-trace only); FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated on final_kernel). enc1.fwd and '
                 'dec2.dgrad share a kernel template and grid: the entry is the larger of the two.')
