@@ -38,6 +38,7 @@ def build(force=False, verbose=False):
                os.path.join(CSRC, 'uad_gan_create.inc'), os.path.join(CSRC, 'uad_conv16s.inc')]      # the .inc files are textual parts of uad_gan.hip
     objs = []
     flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
+    jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace('.hip', '.o'))
@@ -45,8 +46,13 @@ def build(force=False, verbose=False):
             cmd = [hipcc] + flags + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
         objs.append(obj)
+    # the translation units are independent: compile them side by side (uad_gemm.hip alone takes minutes)
+    procs = [subprocess.Popen(cmd) for cmd in jobs]
+    failed = [cmd for cmd, pr in zip(jobs, procs) if pr.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     if force or _newer(objs, LIB):
         cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC'] + objs + ['-o', LIB]
         if verbose:

@@ -3387,7 +3387,10 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
         const int tap = TW8 ? (todd ? (j < 2 ? 5 * wave + 2 * j + 1 : 20 + wave) : 5 * wave + 2 * j) : (j < 5 ? 5 * wave + j : 20 + wave);
         float* ot = ob + tap * tapstride;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2)) * CSi] = acc[j][r];
+        for (int r = 0; r < 16; ++r) {
+            if (a.abl & 16) __builtin_nontemporal_store(acc[j][r], ot + ((r & 3) + 8 * (r >> 2)) * CSi);    // experiment: streaming slab stores
+            else ot[((r & 3) + 8 * (r >> 2)) * CSi] = acc[j][r];
+        }
     }
     // tap (4, 4): the four rows' shares are folded through LDS in a fixed order
     __syncthreads();
@@ -3419,7 +3422,12 @@ inline W5Choice choose_w5(const UadConvDesc& d) {
     if (d.CB % 32 || d.CS % 32 || d.HS % 8 || d.WS % 8) return c;
     c.total_tiles = d.N * (d.HS / 8) * (d.WS / 8);
     const int blocks = (d.CB / 32) * (d.CS / 32);
-    int splits = (512 + blocks - 1) / blocks;
+    // UAD_W5_TARGET / UAD_W5_MINTILES (experiment knobs): workgroup-slab target of a launch, fewest tiles a split may walk.  Every split
+    // costs one [25][CB][CS] slab written and re-read (52 MB per launch at the defaults), every tile ~2.6 us of a workgroup's life.
+    static const int target = getenv("UAD_W5_TARGET") ? atoi(getenv("UAD_W5_TARGET")) : 512;
+    static const int mintiles = getenv("UAD_W5_MINTILES") ? atoi(getenv("UAD_W5_MINTILES")) : 1;
+    int splits = (target + blocks - 1) / blocks;
+    if (mintiles > 1 && splits * mintiles > c.total_tiles) splits = c.total_tiles / mintiles;
     if (splits > c.total_tiles) splits = c.total_tiles;
     if (splits < 1) splits = 1;
     c.tiles_per_split = (c.total_tiles + splits - 1) / splits;
