@@ -203,7 +203,13 @@ class AEMODEL(DLMODEL):
     def _num_batches(self, dataset, phase):
         """Steps of one epoch: the dataset is walked in GLOBAL batches of config.batchsize * world slices (every rank takes its share, _shard)."""
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
-        return dataset.num_batches(self.config.batchsize * getattr(getattr(self, 'dp', None), 'world', 1), set=phase.value)
+        world = getattr(getattr(self, 'dp', None), 'world', 1)
+        nb = dataset.num_batches(self.config.batchsize * world, set=phase.value)
+        if nb == 0:
+            # (the reference's loop would run zero steps and then fail on the empty scalar dict: say what is wrong instead)
+            raise ValueError(f'{phase.value} split holds fewer slices than one global batch (batchsize {self.config.batchsize} x {world} rank(s)): '
+                             f'lower config.batchsize or the rank count')
+        return nb
 
     def process(self, dataset, epoch, phase, optim=None):       # trainers/VAE.py:76-103
         """One epoch.  The loop body only ENQUEUES work: the batch comes from the dataset (device tensors when it is an HBM-resident
