@@ -12,7 +12,9 @@ interpreter with the switch set:
   UAD_NO_D16S              round-2 ConvT-class kernel (LDS-transposed epilogue) instead of the lane = pixel one
   UAD_PP                   lane = pixel kernel in its two-group ping-pong form (opt-in experiment)
   UAD_D16S_MF2             ... with two 32-pixel fragments per wave (opt-in experiment)
-  UAD_W_TW8                filter-gradient kernel with eight tap-waves per cs block, four waves per SIMD (opt-in experiment)"""
+  UAD_W_TW8                filter-gradient kernel with eight tap-waves per cs block, four waves per SIMD (opt-in experiment)
+  UAD_NO_REDUCE_NT         slab reductions with plain instead of streaming (non-temporal) loads
+  UAD_W5_MINTILES          (value 4) fewer, fatter filter-gradient workgroups: every split walks at least four tiles (opt-in experiment)"""
 import os
 import subprocess
 import sys
@@ -24,9 +26,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_EVENT_SYSFENCE', 'UAD_NO_W_T', 'UAD_NO_INKERNEL_SPLITK',
-                                  'UAD_PG', 'UAD_NO_D16S', 'UAD_PP', 'UAD_D16S_MF2', 'UAD_W_TW8'])
+                                  'UAD_PG', 'UAD_NO_D16S', 'UAD_PP', 'UAD_D16S_MF2', 'UAD_W_TW8', 'UAD_NO_REDUCE_NT', 'UAD_W5_MINTILES=4'])
 def test_model_parity_with_switch(knob):
-    env = dict(os.environ, **{knob: '1'})
+    name, _, val = knob.partition('=')
+    env = dict(os.environ, **{name: val or '1'})
     sel = 'test_forward_backward_parity or test_train_trajectory_vae_matches_oracle'
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_model.py', '-q', '-x', '-m', 'gpu', '-k', sel, '-p', 'no:cacheprovider'],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
