@@ -87,9 +87,20 @@ __device__ __forceinline__ void group_exchange(const UadBottArgs& a, int n, int 
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(a.flags + n * Q + q, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < Q)
-        while (__hip_atomic_load(a.flags + n * Q + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) __builtin_amdgcn_s_sleep(2);
+    if (tid == 0 && !(a.fault && n == 0 && q == 1)) __hip_atomic_store(a.flags + n * Q + q, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < Q) {
+        // Bounded: the argument above needs in-order dispatch per XCD; if that ever fails (a serialising tool, a masked queue) the step must not
+        // hang the device.  ~2^22 polls of ~0.5-1 us: seconds, far beyond any preemption of a healthy run.  The workgroup then carries on with
+        // whatever the slots hold and reports through the host-visible word; the next uad_forward() fails with that report.
+        unsigned polls = 0;
+        while (__hip_atomic_load(a.flags + n * Q + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++polls > (1u << 22)) {
+                if (a.err) __hip_atomic_store(a.err, a.epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __syncthreads();
     if (tid < count) {
@@ -541,6 +552,8 @@ void uad_launch_bottleneck_fwd(const UadBottArgs& a, int n, hipStream_t st) {
     static unsigned long long* sbuf = nullptr;
     static int calls = 0;
     UadBottArgs b = a;
+    static const int fault = getenv("UAD_BOTT_FAULT") ? 1 : 0;      // tests/test_gpu_knobs.py: the bounded sibling exchange reports instead of hanging
+    b.fault = fault;
     const bool on = dbg && ++calls > 20 && calls <= 24;
     if (on) { if (!sbuf) (void)hipMalloc((void**)&sbuf, 16 * 8); b.stamps = sbuf; }
     if (uad_bottleneck_group(a) == 4) hipLaunchKernelGGL(bottleneck_fwd_kernel<4>, dim3(4 * n), dim3(NT), uad_bottleneck_lds_bytes(a, false), st, b);
@@ -554,8 +567,10 @@ void uad_launch_bottleneck_fwd(const UadBottArgs& a, int n, hipStream_t st) {
         fprintf(stderr, " | total %llu\n", h[8] - h[0]);
     }
 }
-void uad_launch_bottleneck_bwd(const UadBottArgs& a, int n, hipStream_t st) {
+void uad_launch_bottleneck_bwd(const UadBottArgs& a0, int n, hipStream_t st) {
     bott_attrs();
+    UadBottArgs a = a0;
+    a.fault = 0;
     if (uad_bottleneck_group(a) == 4) hipLaunchKernelGGL(bottleneck_bwd_kernel<4>, dim3(4 * n), dim3(NT), uad_bottleneck_lds_bytes(a, true), st, a);
     else hipLaunchKernelGGL(bottleneck_bwd_kernel<1>, dim3(n), dim3(NT), uad_bottleneck_lds_bytes(a, true), st, a);
 }

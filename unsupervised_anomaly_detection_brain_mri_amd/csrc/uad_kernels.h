@@ -214,6 +214,8 @@ struct UadBottArgs {
     float* wpart;                        // optional: per-workgroup shares of conv2d / conv2d_1's parameter gradients, [wg][2*C*M + M]
     // exchange between the workgroups of one sample (uad_bott.hip): partial vectors, completion flags, this launch's epoch
     float* xch; unsigned* flags; unsigned epoch; int xw;
+    unsigned* err;                       // optional, host-visible (pinned): a workgroup that gives up waiting for its siblings stores (epoch | 1 << 31) here
+    int fault;                           // tests (UAD_BOTT_FAULT=1): workgroup 1 of sample 0 never publishes its flag
     unsigned long long* stamps;          // debug (UAD_BOTT_DBG): phase clocks of workgroup 0
     float *dd, *dmu, *dls, *dflat, *g_out, *colpart;   // colpart [n][2][cenc]
 };

@@ -108,6 +108,7 @@ struct uad_model {
     bool pg_on = false;                // bf16x3 mode and UAD_NO_PG unset
     float* dcb_keep;                  // copy of d loss / d cb for conv2d_1's kernel gradient (SIDE)
     float* bott_xch; unsigned* bott_flags; unsigned bott_epoch;
+    unsigned* bott_err_host; unsigned* bott_err_dev;      // pinned word the fused bottleneck kernels report a timed-out sibling exchange through
     float* bnfin_scratch;             // counters + partials of the 2-D BN-gradient finalize (SIDE stream only)
     float* bott_wpart;                // [4 * max_batch][2*cenc*cmid + cmid] shares of conv2d / conv2d_1's parameter gradients
     float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
@@ -245,6 +246,7 @@ UadBottArgs bott_args(uad_model* m, const uad_io_t& io, const float* mask_dec, i
     a.mask_dec = vae ? mask_dec : nullptr;        // AE: the dec_dense dropout is never active (autoencoder.py:30)
     a.t = m->t; a.mu = m->mu; a.ls = m->ls; a.sigma = m->sigma; a.z = m->z; a.kl = m->kl; a.dvec = m->dvec; a.cb = m->cb;
     a.xch = m->bott_xch; a.flags = m->bott_flags; a.xw = 2 * m->cfg.zdim; a.epoch = 0;      // epoch: set at each launch
+    a.err = m->bott_err_dev;
     return a;
 }
 
@@ -444,6 +446,11 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->dcb_keep, NB * ir * ir * m->cenc);
     ALLOC(m->bott_xch, NB * 4 * 2 * (size_t)cfg->zdim);
     { float* fl = nullptr; ALLOC(fl, NB * 4); m->bott_flags = reinterpret_cast<unsigned*>(fl); m->bott_epoch = 0; }
+    m->bott_err_host = m->bott_err_dev = nullptr;
+    if (rc == UAD_OK && hipHostMalloc((void**)&m->bott_err_host, sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
+        *m->bott_err_host = 0u;
+        if (hipHostGetDevicePointer((void**)&m->bott_err_dev, m->bott_err_host, 0) != hipSuccess) m->bott_err_dev = nullptr;
+    }
     ALLOC(m->bnfin_scratch, uad_bn_grad_finalize_scratch_floats(512));
     ALLOC(m->bott_wpart, NB * 4 * (2 * (size_t)m->cenc * m->cmid + m->cmid));
     // column-partial scratch: worst case 64-row tiles
@@ -501,6 +508,7 @@ int uad_destroy(uad_model_t* m) {
     for (void* p : m->allocs) hipFree(p);
     for (hipEvent_t e : m->sync_events) (void)hipEventDestroy(e);
     if (m->side) (void)hipStreamDestroy(m->side);
+    if (m->bott_err_host) (void)hipHostFree(m->bott_err_host);
     delete m;
     return UAD_OK;
 }
@@ -618,6 +626,14 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
     if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
     if (!io->x) return fail(UAD_ERR_INVALID, "io.x is null");
+    if (m->bott_err_host) {
+        const unsigned e = *reinterpret_cast<volatile unsigned*>(m->bott_err_host);
+        if (e) {
+            *m->bott_err_host = 0u;
+            return fail(UAD_ERR_HIP, "fused bottleneck: a workgroup gave up waiting for its sibling workgroups (launch epoch %u); the results of that "
+                                     "step are invalid. UAD_BOTT_Q1=1 selects the one-workgroup-per-sample form", e & 0x7fffffffu);
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool vae = m->cfg.arch == UAD_ARCH_VAE || m->cfg.arch == UAD_ARCH_CEVAE;
     const bool cevae = m->cfg.arch == UAD_ARCH_CEVAE;
