@@ -1,7 +1,10 @@
 #!/bin/bash
-# round-3 probe (second session): instruction-cache behaviour of the fully unrolled k5 kernels (code objects of 35-64 KB against a 64 KB I-cache per CU pair)
+# round-3 probe (second session): data-gradient kernels launched with the AQL barrier bit cleared (may start while the layer's filter gradient drains)
 mkdir -p gpurun_out/r3
-export TMPDIR=/tmp
-rocprofv3 --list-avail 2>/dev/null | grep -i -o "SQC_ICACHE[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQ_INST_LEVEL_[A-Z_]*\|SQC_TC_INST[A-Z_]*\|SQ_WAIT_INST_ANY\|SQ_WAIT_IFETCH[A-Z_]*\|SQ_IFETCH_LEVEL" | sort -u | tr '\n' ' '; echo
-tools/pmc.sh ic1 "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" --quick --rounds 1 > /dev/null 2>&1; cut -c1-330 gpurun_out/pmc_ic1.csv | head -14
-tools/pmc.sh ic2 "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" --quick --rounds 1 > /dev/null 2>&1; cut -c1-330 gpurun_out/pmc_ic2.csv | head -14
+T="loss.finalize dec3.wgrad dec3.dgrad dec2.wgrad dec2.dgrad dec1.wgrad dec1.dgrad dec0.wgrad dec0.dgrad enc3.wgrad enc3.dgrad enc2.wgrad enc2.dgrad enc1.wgrad enc1.dgrad"
+for round in 1 2 3; do for cfg in "UAD_X=1" "UAD_ANYORDER=1"; do
+  env $cfg python bench.py --steps 60 --warmup 10 --quick --rounds 3 > gpurun_out/r3/p.json 2>gpurun_out/r3/p.err
+  echo -n "[$cfg]: "; python tools/kshow.py gpurun_out/r3/p.json $T
+done; done
+UAD_ANYORDER=1 UAD_MATH=bf16x3 timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_scale_parity.py tests/test_gpu_trainers.py tests/test_gpu_cevae.py tests/test_gpu_dp_rehearsal.py -x -q 2>&1 | tail -2
+tail -3 gpurun_out/r3/p.err

@@ -15,6 +15,7 @@
 // permutation k = 8*kk + 4*(lane>>5) + s so that one ds_read_b128 feeds four MFMAs.
 #include <type_traits>
 #include "uad_kernels.h"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -2228,6 +2229,25 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     if (stp) stp[5] = wall_clock64();
 }
 
+// Launches without the AQL barrier bit (hipExtAnyOrderLaunch).  Packets of a queue are still DEQUEUED in order, so such a kernel starts once
+// everything before its predecessor has completed (the predecessor's own barrier bit saw to that) -- but it does not wait for the predecessor
+// itself.  The backward uses it for the two launches per layer that do not depend on the kernel enqueued right before them: a layer's data
+// gradient behind its filter gradient (both read d loss / d c, neither reads the other's output), and the first filter gradient behind the
+// forward's single-workgroup loss.finalize.  The successor's workgroups fill the CUs the predecessor's last workgroups are still draining:
+// -0.7 % per step (profiles/r03_y_gpurun11/12.log); unlike a second stream (+36 %) the predecessor is dispatched in full first.
+// UAD_NO_ANYORDER=1 (read in uad_model.hip) keeps every launch ordered.
+static bool g_any_order_next = false;
+static bool g_any_order_w_next = false;      // ... the same for the next channel-major filter-gradient launch (the first one of a backward, behind loss.finalize)
+#define UAD_W_LAUNCH(kern, grid, block, lds, st, ...)                                                                       \
+    do {                                                                                                                    \
+        if (g_any_order_w_next) { g_any_order_w_next = false; hipExtLaunchKernelGGL(kern, grid, block, lds, st, nullptr, nullptr, 1u, __VA_ARGS__); } \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                   \
+    } while (0)
+#define UAD_SPATIAL_LAUNCH(kern, grid, block, lds, st, arg)                                                                 \
+    do {                                                                                                                    \
+        if (g_any_order_next) { g_any_order_next = false; hipExtLaunchKernelGGL(kern, grid, block, lds, st, nullptr, nullptr, 1u, arg); } \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, arg);                                                           \
+    } while (0)
 #include "uad_conv16s.inc"
 
 template <int TH, int TW, int CK, int WGM, int WGN>
@@ -2244,7 +2264,7 @@ void launch_conv5_f16_v(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB>), grid, dim3(64 * WGM * WGN), lds, st, a);
+    UAD_SPATIAL_LAUNCH((conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB>), grid, dim3(64 * WGM * WGN), lds, st, a);
 }
 template <int TH, int TW, int CK, int WGM, int WGN>
 void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
@@ -3844,19 +3864,19 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                         t8_attr = true;
                     }
                     if (xfb.fb_bits) {
-                        if (two) hipLaunchKernelGGL((conv5_w_bf16_t_kernel<2, true, true>), grid, dim3(1024), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                        else hipLaunchKernelGGL((conv5_w_bf16_t_kernel<1, true, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                        if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, true, true>), grid, dim3(1024), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                        else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, true, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
                     } else {
-                        if (two) hipLaunchKernelGGL((conv5_w_bf16_t_kernel<2, false, true>), grid, dim3(1024), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                        else hipLaunchKernelGGL((conv5_w_bf16_t_kernel<1, false, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                        if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, false, true>), grid, dim3(1024), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                        else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, false, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
                     }
                 } else
                 if (xfb.fb_bits) {
-                    if (two) hipLaunchKernelGGL((conv5_w_bf16_t_kernel<2, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                    else hipLaunchKernelGGL((conv5_w_bf16_t_kernel<1, true>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                    if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                    else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, true>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
                 } else {
-                    if (two) hipLaunchKernelGGL((conv5_w_bf16_t_kernel<2, false>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                    else hipLaunchKernelGGL((conv5_w_bf16_t_kernel<1, false>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                    if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, false>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                    else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, false>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
                 }
             } else
             if (xfb.fb_bits) {          // compressed d loss / d c of the last decoder block (callers check uad_conv_w_supports_fb_bits)
@@ -3908,6 +3928,8 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
     if (c.splits > 1 && !defer_reduce) uad_launch_reduce_partials(partial, c.splits, a.Mtot * d.CS, 1.0f, dW, hop());
 }
 
+void uad_conv_any_order_next(bool on) { g_any_order_next = on; }
+void uad_conv_w_any_order_next(bool on) { g_any_order_w_next = on; }
 void uad_launch_conv_w_reduce(const UadConvDesc& d, float* dW, float* partial, hipStream_t st) {
     const W5Choice w5 = choose_w5(d);
     const int splits = w5.ok ? w5.splits : choose_w(d).splits;

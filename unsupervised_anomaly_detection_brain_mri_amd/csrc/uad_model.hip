@@ -125,6 +125,7 @@ struct uad_model {
     unsigned* fin_bits;                // training step: the last block's d loss / d c in compressed form -- activation-pattern word per output
     float* fin_dxh;                    //   pixel + sign(x_hat - x) / n per pixel (UadEpilogue::fin_bits, UadXform::fb_bits)
     bool last_fin_bits;                // the last forward left its loss gradient in that form (G0 was not written)
+    bool fwd_tail_is_loss;            // the last operation the last forward enqueued was its loss.finalize kernel (nothing the backward reads)
     bool last_fused_final;             // the last forward ran the last block's BN / final conv / loss inside the ConvT epilogue (its c is not written)
     std::vector<void*> allocs;
     // second stream + events of the backward pass; per-layer scratch touched by that stream
@@ -256,6 +257,9 @@ UadConvDesc conv1x1_desc(int n, int h, int w, int cin, int cout) { return UadCon
 int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 }  // namespace
+
+void uad_conv_any_order_next(bool on);      // uad_gemm.hip: the next spatial F / D launch (filter-gradient launch) leaves the AQL barrier bit clear
+void uad_conv_w_any_order_next(bool on);
 
 extern "C" {
 
@@ -837,6 +841,8 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     m->x_eff = xin; m->mask_dec_eff = mask_dec; m->data_only = want_backward == 2;
     m->last_fused_final = fused_final && !(m->restore && want_backward);
     m->last_fin_bits = fin_bits_mode;
+    // the first filter gradient of the backward may then start beside that single-workgroup kernel instead of behind it (UAD_NO_ANYORDER=1: off)
+    m->fwd_tail_is_loss = !m->restore && !gm && !cevae && !io->z_mu && !io->z_log_sigma && !io->z_sigma;      // (no copy was enqueued behind it)
     HIP_TRY(hipGetLastError());
     return UAD_OK;
 }
@@ -902,9 +908,14 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
         if (fbb) { gbits = bn_xform(m, DL.gamma, DL.beta, kLrelu); gbits.fb_dxhat = m->fin_dxh; gbits.fb_wf = P(m, m->fw); gbits.fb_bits = m->fin_bits; }
         const bool w_pg = pg_mode(m) && uad_conv_w_pg_ok(d, bf);
         const void* in_act_pg = (w_pg && i >= 1 && m->dec[i - 1].pg_valid) ? m->dec[i - 1].pg : nullptr;
+        { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr;
+          if (anyo && pg && bf && last && m->fwd_tail_is_loss && !m->prof_on) uad_conv_w_any_order_next(true);
+          m->fwd_tail_is_loss = false; }
         if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, nullptr, nullptr, false, true,
                                                           (w_pg && g_pg && !fbb) ? gp : nullptr, in_act_pg); }
+        uad_conv_w_any_order_next(false);
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
+        { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg && bf) uad_conv_any_order_next(true); }
         { PROF(kDecD[i & 7]); UadEpilogue e = epi_bwd(m, in, ig, ib, ia); e.colpart = cp;
           const bool fb = m->restore && m->fb_on_load && last;
           UadXform gx = fbb ? gbits : no_xform();
@@ -1136,6 +1147,7 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
         const bool w_pg = pg_mode(m) && uad_conv_w_pg_ok(d, bf);
         if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true,
                                                           (w_pg && PL.pg_valid) ? PL.pg : nullptr, (w_pg && g_pg) ? gp : nullptr); }
+        { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg && bf) uad_conv_any_order_next(true); }
         { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
           UadPgIO io;
           bool gn_pg = false;
