@@ -1,8 +1,11 @@
 #!/bin/bash
-# round-3 probe (second session): the other workloads on the round's final build (streaming slab reads + any-order launches are shared by all handles)
-mkdir -p gpurun_out/r3
-python bench.py --arch ceVAE --steps 40 --warmup 5 --quick 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ceVAE16', d['value'], d['ms_per_step'])"
-python bench.py --arch ceVAE --batch 64 --steps 40 --warmup 5 --quick 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ceVAE64', d['value'], d['ms_per_step'])"
-python bench.py --arch GMVAE_spatial --steps 3 --warmup 1 --quick 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('GMVAE_spatial', d['value'], d['ms_per_step'], d['config'].get('workload','')[:80])"
-python bench.py --arch fAnoGAN --steps 10 --warmup 2 --quick 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fAnoGAN unified', d['value'], d['ms_per_step'])"
-python bench.py --arch fAnoGAN --variant resnet --steps 5 --warmup 2 --quick 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fAnoGAN resnet', d['value'], d['ms_per_step'])"
+# round-3 probe (second session): dispatch timeline of one train step on the final build (rocprofv3 --kernel-trace, no counters)
+export TMPDIR=/tmp
+REPO=$PWD; OUT=$REPO/gpurun_out/r3/tl; rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python $REPO/bench.py --steps 20 --warmup 5 --quick --rounds 1 > $OUT/bench.json 2>$OUT/err.log
+cd $REPO
+F=$(find $OUT -name "*kernel_trace.csv" | head -1)
+python tools/timeline.py $F adam_kernel > gpurun_out/r3/timeline.txt 2>&1
+cat gpurun_out/r3/timeline.txt | cut -c1-110
+find $OUT -name "*.csv" -size +1M -delete; find $OUT -name "*.db" -delete
