@@ -603,6 +603,23 @@ def main():
                     break
             except Exception:
                 continue
+        # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command (the profiler's clock instead
+        # of HIP events around the launch group; bf16x3 only: the summary is of the default mode), with the commit it was taken at
+        rocprof = None
+        if math != 'f32':
+            try:
+                import csv
+                doc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_traffic_bf16x3.json')))
+                kname = doc[dom]['kernel']
+                for row in csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r03_z_kernel_stats.csv'))):
+                    if kname in row['Name']:
+                        avg_ms = float(row['AverageNs']) * 1e-6
+                        rocprof = {'avg_launch_ms': round(avg_ms, 4), 'calls': int(row['Calls']), 'frac': round(fl[dom] / (avg_ms * 1e-3) / 1e12 / peak, 4),
+                                   'source': f'profiles/r03_z_kernel_stats.csv (bench.py --steps 10 --warmup 3 --quick under rocprofv3 --kernel-trace --stats), '
+                                             f'commit {doc.get("_commit")}; not re-measured in this run'}
+                        break
+            except Exception:
+                rocprof = None
         kernels = {t: {'ms': round(ms / c, 4), 'tflops': round(fl[t] / (ms / c * 1e-3) / 1e12, 2) if t in fl else None,
                        'gbs': round(by[t] / (ms / c * 1e-3) / 1e9, 1) if t in by else None}
                    for t, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
@@ -610,7 +627,7 @@ def main():
                 'frac': round(alg / peak, 4), 'mfma_fraction': round(alg / peak, 4),
                 'hbm_fraction': round(gbs / PEAK_HBM_GBS, 4), 'hbm_achieved_gbs': round(gbs, 1), 'hbm_peak_gbs': PEAK_HBM_GBS,
                 'algorithmic_bytes_per_launch': int(by[dom]), 'algorithmic_flop_per_launch': int(fl[dom]),
-                'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'instruction': note}
+                'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'rocprof': rocprof, 'instruction': note}
         return roof, kernels
 
     dt, loss, round_ms = timed(args.steps, args.warmup, args.rounds)
