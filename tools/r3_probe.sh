@@ -1,11 +1,9 @@
 #!/bin/bash
-# round-3 probe (second session): dispatch timeline of one train step on the final build (rocprofv3 --kernel-trace, no counters)
-export TMPDIR=/tmp
-REPO=$PWD; OUT=$REPO/gpurun_out/r3/tl; rm -rf $OUT; mkdir -p $OUT
-cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python $REPO/bench.py --steps 20 --warmup 5 --quick --rounds 1 > $OUT/bench.json 2>$OUT/err.log
-cd $REPO
-F=$(find $OUT -name "*kernel_trace.csv" | head -1)
-python tools/timeline.py $F adam_kernel > gpurun_out/r3/timeline.txt 2>&1
-cat gpurun_out/r3/timeline.txt | cut -c1-110
-find $OUT -name "*.csv" -size +1M -delete; find $OUT -name "*.db" -delete
+# round-3 probe (second session): two columns per thread in the slab reduction (8-byte streaming loads)
+mkdir -p gpurun_out/r3
+T="bn.gradfin dec3.wgrad dec2.dgrad dec0.dgrad enc3.wgrad enc1.dgrad"
+for round in 1 2 3; do for cfg in "UAD_X=1" "UAD_REDUCE2=1"; do
+  env $cfg python bench.py --steps 60 --warmup 10 --quick --rounds 3 > gpurun_out/r3/p.json 2>gpurun_out/r3/p.err
+  echo -n "[$cfg]: "; python tools/kshow.py gpurun_out/r3/p.json $T
+done; done
+UAD_REDUCE2=1 UAD_MATH=bf16x3 timeout 600 python -m pytest tests/test_gpu_model.py -x -q 2>&1 | tail -2
