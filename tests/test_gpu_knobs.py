@@ -14,6 +14,7 @@ interpreter with the switch set:
   UAD_D16S_MF2             ... with two 32-pixel fragments per wave (opt-in experiment)
   UAD_W_TW8                filter-gradient kernel with eight tap-waves per cs block, four waves per SIMD (opt-in experiment)
   UAD_NO_REDUCE_NT         slab reductions with plain instead of streaming (non-temporal) loads
+  UAD_NO_PACK8             per-element bf16 weight repack (four 2-byte stores per element) instead of one 16-byte group per thread
   UAD_NO_ANYORDER          every launch with the AQL barrier bit (no data gradient starting while its layer's filter gradient drains)
   UAD_W5_MINTILES          (value 4) fewer, fatter filter-gradient workgroups: every split walks at least four tiles (opt-in experiment)"""
 import os
@@ -27,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_EVENT_SYSFENCE', 'UAD_NO_W_T', 'UAD_NO_INKERNEL_SPLITK',
-                                  'UAD_PG', 'UAD_NO_D16S', 'UAD_PP', 'UAD_D16S_MF2', 'UAD_W_TW8', 'UAD_NO_REDUCE_NT', 'UAD_NO_ANYORDER', 'UAD_W5_MINTILES=4'])
+                                  'UAD_PG', 'UAD_NO_D16S', 'UAD_PP', 'UAD_D16S_MF2', 'UAD_W_TW8', 'UAD_NO_REDUCE_NT', 'UAD_NO_ANYORDER', 'UAD_NO_PACK8', 'UAD_W5_MINTILES=4'])
 def test_model_parity_with_switch(knob):
     name, _, val = knob.partition('=')
     env = dict(os.environ, **{name: val or '1'})

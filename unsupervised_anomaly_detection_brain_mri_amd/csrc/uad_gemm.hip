@@ -2417,6 +2417,48 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, unsigned s
 }
 
 // eligibility + tile choice of the spatial kernels (shared by the launchers and the *_tiles() queries)
+// The same packing, one 16-byte group of a packed layout per thread (blockIdx.y: 0 = the F layout, 8 consecutive cb of one (tap, cs); 1 = the D
+// layout, 8 consecutive cs of one (tap, cb)): coalesced 16-byte stores instead of four scattered 2-byte stores per element (the repack runs on the
+// side stream behind the optimizer step; at 20 us it outlasted the main-stream work before the first packed-weight consumer).  Same bits.
+__global__ void __launch_bounds__(256) pack_weights_bf16_v8_kernel(const float* __restrict__ W, unsigned short* __restrict__ Wf, unsigned short* __restrict__ Wd, PackDesc pd) {
+    long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // group index inside the tensor list
+    int t = 0;
+    while (t < pd.n && g >= pd.count[t] / 8) { g -= pd.count[t] / 8; ++t; }
+    if (t >= pd.n) return;
+    const int CB = pd.cb[t], CS = pd.cs[t];
+    const float* w = W + pd.off[t];
+    float v[8];
+    size_t dst;      // first element of the group inside the tensor's packed plane
+    if (blockIdx.y == 0) {
+        const int cs = (int)(g % CS);
+        const int r = (int)(g / CS);
+        const int cb8 = r % (CB / 8), tap = r / (CB / 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w[((size_t)tap * CB + cb8 * 8 + e) * CS + cs];
+        dst = ((size_t)(tap * (CB / 8) + cb8) * CS + cs) * 8;
+    } else {
+        const int cb = (int)(g % CB);
+        const int r = (int)(g / CB);
+        const int cs8 = r % (CS / 8), tap = r / (CS / 8);
+        const float4 a = *reinterpret_cast<const float4*>(w + ((size_t)tap * CB + cb) * CS + cs8 * 8);
+        const float4 b = *reinterpret_cast<const float4*>(w + ((size_t)tap * CB + cb) * CS + cs8 * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        dst = ((size_t)(tap * (CS / 8) + cs8) * CB + cb) * 8;
+    }
+    unsigned hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = bf16_rne_bits(v[e]);
+        lo[e] = bf16_rne_bits(v[e] - __uint_as_float(hi[e] << 16));
+    }
+    const uint4 h4 = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+    const uint4 l4 = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+    unsigned short* out = blockIdx.y == 0 ? Wf : Wd;
+    const size_t base = 2 * (size_t)pd.off[t], cnt = (size_t)pd.count[t];
+    *reinterpret_cast<uint4*>(out + base + dst) = h4;
+    *reinterpret_cast<uint4*>(out + base + cnt + dst) = l4;
+}
+
 struct SpatialChoice { bool ok; int TH, TW, BN, CK; };
 inline SpatialChoice choose_spatial(const UadConvDesc& d, int CA, int Nn, bool f_type = true) {
     SpatialChoice c{false, 0, 0, 0, 0};
@@ -3702,7 +3744,11 @@ void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, un
         pd.off[i] = offs[i]; pd.cb[i] = cbs[i]; pd.cs[i] = css[i]; pd.count[i] = taps[i] * cbs[i] * css[i];
         total += pd.count[i];
     }
-    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w16_f, w16_d, pd);
+    static const bool no8 = getenv("UAD_NO_PACK8") != nullptr;
+    bool v8 = !no8 && (((uintptr_t)params | (uintptr_t)w16_f | (uintptr_t)w16_d) & 15) == 0;
+    for (int i = 0; i < n; ++i) v8 = v8 && pd.off[i] % 4 == 0 && pd.cb[i] % 8 == 0 && pd.cs[i] % 8 == 0;
+    if (v8) hipLaunchKernelGGL(pack_weights_bf16_v8_kernel, dim3((unsigned)((total / 8 + 255) / 256), 2), dim3(256), 0, st, params, w16_f, w16_d, pd);
+    else hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w16_f, w16_d, pd);
 }
 
 namespace {
