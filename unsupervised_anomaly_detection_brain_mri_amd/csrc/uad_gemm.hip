@@ -2236,8 +2236,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 // forward's single-workgroup loss.finalize.  The successor's workgroups fill the CUs the predecessor's last workgroups are still draining:
 // -0.7 % per step (profiles/r03_y_gpurun11/12.log); unlike a second stream (+36 %) the predecessor is dispatched in full first.
 // UAD_NO_ANYORDER=1 (read in uad_model.hip) keeps every launch ordered.
-static bool g_any_order_next = false;
-static bool g_any_order_w_next = false;      // ... the same for the next channel-major filter-gradient launch (the first one of a backward, behind loss.finalize)
+static thread_local bool g_any_order_next = false;      // (per host thread: another thread's launch must not consume it)
+static thread_local bool g_any_order_w_next = false;      // ... the same for the next channel-major filter-gradient launch (the first one of a backward, behind loss.finalize)
 #define UAD_W_LAUNCH(kern, grid, block, lds, st, ...)                                                                       \
     do {                                                                                                                    \
         if (g_any_order_w_next) { g_any_order_w_next = false; hipExtLaunchKernelGGL(kern, grid, block, lds, st, nullptr, nullptr, 1u, __VA_ARGS__); } \
