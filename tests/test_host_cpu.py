@@ -271,3 +271,19 @@ def test_batch_cursor_reproduces_the_reference_next_batch():
                 vi += 1
         lut = sc.brainmask_lut()
         assert np.array_equal(lut[g[f'bm_labels{case}'].astype(np.uint8)], g[f'bm{case}'].astype(np.uint8))
+
+
+def test_epoch_without_one_global_batch_is_a_clear_error():
+    """trainers/AEMODEL._num_batches: a split smaller than batchsize x world used to run zero steps and fail later with KeyError('loss')."""
+    import types
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers.AEMODEL import AEMODEL, Phase
+
+    class Split:
+        def num_batches(self, bs, set):
+            return 0 if bs > 64 else 3
+
+    tr = types.SimpleNamespace(config=types.SimpleNamespace(batchsize=64), dp=types.SimpleNamespace(world=2))
+    with pytest.raises(ValueError, match='fewer slices than one global batch'):
+        AEMODEL._num_batches(tr, Split(), Phase.VAL)
+    tr.dp.world = 1
+    assert AEMODEL._num_batches(tr, Split(), 'VAL') == 3
