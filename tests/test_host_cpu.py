@@ -287,3 +287,19 @@ def test_epoch_without_one_global_batch_is_a_clear_error():
         AEMODEL._num_batches(tr, Split(), Phase.VAL)
     tr.dp.world = 1
     assert AEMODEL._num_batches(tr, Split(), 'VAL') == 3
+
+
+def test_every_environment_switch_is_documented():
+    """Every UAD_* switch the library, the package or bench.py reads appears in README.md's switch section."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, 'unsupervised_anomaly_detection_brain_mri_amd')
+    names = set()
+    for f in glob.glob(os.path.join(pkg, 'csrc', '*')):
+        names |= set(re.findall(r'getenv\("(UAD_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(pkg, '*.py')) + glob.glob(os.path.join(pkg, '*', '*.py')) + [os.path.join(root, 'bench.py'), os.path.join(root, 'run.py')]:
+        names |= set(re.findall(r"environ(?:\.get)?\(?\[?'(UAD_[A-Z0-9_]+)'", open(f).read()))
+    readme = open(os.path.join(root, 'README.md')).read()
+    missing = sorted(n for n in names if n not in readme)
+    assert not missing, f'undocumented switches: {missing}'
