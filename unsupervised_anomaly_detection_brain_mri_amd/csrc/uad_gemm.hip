@@ -3709,12 +3709,12 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
                 else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_D>(a, grid, st);
             }
         } else if (f_type) {
-            if (p.sc.BN == 64) hipLaunchKernelGGL((conv5_f_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv5_f_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
+            if (p.sc.BN == 64) UAD_SPATIAL_LAUNCH((conv5_f_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
+            else UAD_SPATIAL_LAUNCH((conv5_f_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
         } else {
-            if (p.sc.BN == 64) hipLaunchKernelGGL((conv5_d_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
-            else if (p.sc.CK == 32) hipLaunchKernelGGL((conv5_d_kernel<8, 16, 32, 4, 1>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv5_d_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
+            if (p.sc.BN == 64) UAD_SPATIAL_LAUNCH((conv5_d_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
+            else if (p.sc.CK == 32) UAD_SPATIAL_LAUNCH((conv5_d_kernel<8, 16, 32, 4, 1>), grid, dim3(256), 0, st, a);
+            else UAD_SPATIAL_LAUNCH((conv5_d_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
         }
         if (p.nsplit > 1 && !a.sk_counter) {
             dim3 g2((p.out_rows + 63) / 64, (a.Nn + 63) / 64);

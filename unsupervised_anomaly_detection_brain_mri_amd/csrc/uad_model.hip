@@ -915,7 +915,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
                                                           (w_pg && g_pg && !fbb) ? gp : nullptr, in_act_pg); }
         uad_conv_w_any_order_next(false);
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
-        { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg && bf) uad_conv_any_order_next(true); }
+        { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg) uad_conv_any_order_next(true); }
         { PROF(kDecD[i & 7]); UadEpilogue e = epi_bwd(m, in, ig, ib, ia); e.colpart = cp;
           const bool fb = m->restore && m->fb_on_load && last;
           UadXform gx = fbb ? gbits : no_xform();
@@ -930,6 +930,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
               }
           }
           uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i]), false, io);
+          uad_conv_any_order_next(false);      // (a launch that did not take a spatial kernel must not leave the request to a later one)
           g_pg = gn_pg; g_f32 = !gn_pg; }
         edge(m, st, sd);   // ONE edge per layer: its filter-gradient slabs and column partials are ready
         if (pg && last) {
@@ -1147,7 +1148,7 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
         const bool w_pg = pg_mode(m) && uad_conv_w_pg_ok(d, bf);
         if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true,
                                                           (w_pg && PL.pg_valid) ? PL.pg : nullptr, (w_pg && g_pg) ? gp : nullptr); }
-        { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg && bf) uad_conv_any_order_next(true); }
+        { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg) uad_conv_any_order_next(true); }
         { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
           UadPgIO io;
           bool gn_pg = false;
@@ -1159,6 +1160,7 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
               }
           }
           uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i]), false, io);
+          uad_conv_any_order_next(false);
           g_pg = gn_pg; }
         edge(m, st, sd);
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd);
