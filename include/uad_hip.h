@@ -37,6 +37,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libuad_hip.so is built with -fvisibility=hidden (build.py): everything declared between this push and the pop at the end of the file -- and
+ * nothing else -- is exported, so `nm -D --defined-only libuad_hip.so` lists exactly this header's functions (tests/test_host_cpu.py). */
+#pragma GCC visibility push(default)
 
 enum { UAD_OK = 0, UAD_ERR_INVALID = 1, UAD_ERR_HIP = 2, UAD_ERR_UNSUPPORTED = 3 };
 enum { UAD_ARCH_AE = 0, UAD_ARCH_VAE = 1, UAD_ARCH_CEVAE = 2, UAD_ARCH_GMVAE_SPATIAL = 3,
@@ -151,6 +154,12 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
  * TensorFlow initialises to ONE: set it before the first UAD_OPT_RMS step).  RMSProp: decay 0.9, eps 1e-10 are TF's defaults. */
 enum { UAD_OPT_SGD = 1, UAD_OPT_MOMENTUM = 2, UAD_OPT_RMS = 3 };
 int uad_optimizer_step(uad_model_t* m, int kind, float lr, float momentum, float decay, float eps, float grad_scale, void* stream);
+/* Fault word of the fused bottleneck kernels (their sibling-workgroup exchange is bounded: uad_bott.hip).  A fault makes every optimizer launch
+ * behind it a no-op ON THE DEVICE (parameters and slots stay those of the last good step) and is reported -- once, with the step counter rolled
+ * back by the number of skipped updates -- by the next uad_forward / uad_get_buffer / uad_check_fault on the handle.  synchronize != 0 waits
+ * for `stream` first (call it so at the end of an epoch, before a checkpoint, and -- under data parallelism -- before agreeing on the flag
+ * across ranks: trainers/AEMODEL.py).  Returns UAD_OK when no fault is pending. */
+int uad_check_fault(uad_model_t* m, int synchronize, void* stream);
 /* uad_forward(want_backward=1) + uad_backward(ALL) + uad_adam_step */
 int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float beta1, float beta2, float eps,
                    void* stream);
@@ -339,13 +348,6 @@ int uad_gan_reconstruct(uad_gan_t* g, const uad_gan_io_t* io, int n, void* strea
  * io supplies the noise / dropout masks of this run.  No parameter gradient is produced. */
 int uad_gan_restore_step(uad_gan_t* g, float* x_restored, const uad_gan_io_t* io, int n, float tv_lambda, float restore_lr, float* grads_out,
                          void* stream);
-/* hipGraph replay of whole phases (they are 60-250 launches of mostly tiny kernels): on = 1 makes uad_gan_phase / uad_gan_reconstruct /
- * uad_gan_restore_step capture their launch sequence the second time a (phase, n, want_backward, io pointer set, math mode) combination
- * is seen and replay it with one hipGraphLaunch afterwards (48 cached graphs, least-recently-used eviction).  The caller must keep the io
- * pointers stable across calls to benefit; results are identical to the plain path (same kernels, same order).  Work runs on a stream
- * owned by the handle, fenced against `stream` with events on both sides. */
-int uad_gan_set_graph_mode(uad_gan_t* g, int on);
-int uad_gan_graph_stats(const uad_gan_t* g, long long* captures, long long* replays, int* enabled);
 /* tests: device pointer + element count of a named intermediate of the last phase (NULL name table entry -> error) */
 int uad_gan_debug_buffer(uad_gan_t* g, const char* name, float** ptr, long long* count);
 
@@ -374,6 +376,7 @@ int uad_op_conv_first_wgrad(const uad_conv_desc_t* d, const float* x, const floa
 int uad_op_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float beta1, float beta2,
                 float eps, float gscale, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -143,8 +143,8 @@ def test_cevae_gradients_at_baseline_batch(n):
     for math in MODES:
         eng.set_math(math)
         got = eng.forward(x, eps, masks, want_backward=True, x_ce=x_ce)
-        act_v, fl_v = device_activation_pattern(eng, p32, x, got['x_hat'], caches[1], 4, VAE_BN, rows=slice(0, n), math=math)
-        act_c, fl_c = device_activation_pattern(eng, p32, x_ce, got['x_hat_ce'], caches[3], 4, VAE_BN, rows=slice(n, 2 * n), math=math)
+        act_v, fl_v = device_activation_pattern(eng, p32, x, got['x_hat'], caches[1], 4, VAE_BN, rows=slice(0, n), math=math, xhat_oracle=out['x_hat'])
+        act_c, fl_c = device_activation_pattern(eng, p32, x_ce, got['x_hat_ce'], caches[3], 4, VAE_BN, rows=slice(n, 2 * n), math=math, xhat_oracle=out['x_hat_ce'])
         eng.backward()
         torch.cuda.synchronize()
         assert_close(got['x_hat'].cpu().numpy(), out['x_hat'], name='x_hat')
@@ -153,8 +153,10 @@ def test_cevae_gradients_at_baseline_batch(n):
         for idx, key in ((0, 'reconstructionLoss'), (1, 'kl'), (2, 'loss'), (4, 'Rec_vae'), (5, 'Rec_ce'), (6, 'loss_vae')):
             assert abs(sc[idx] - ls[key]) <= 1e-4 * abs(ls[key]), (key, sc[idx], ls[key])
         g = m.ce_backward(p64, x64, xc64, out, caches, m64, act_v=act_v, act_c=act_c)
-        flips = {f'vae/{k}': v for k, v in fl_v.items()}
+        flips = type(fl_v)({f'vae/{k}': v for k, v in fl_v.items()})
         flips.update({f'ce/{k}': v for k, v in fl_c.items()})
+        flips.l1_sign = getattr(fl_v, 'l1_sign', 0) + getattr(fl_c, 'l1_sign', 0)      # counted and bounded (rounding ties only) per branch
+        flips.mag = {**{f'vae/{k}': v for k, v in fl_v.mag.items()}, **{f'ce/{k}': v for k, v in fl_c.mag.items()}}
         worst = assert_grads_close(eng.get_grads(), g, names, flips=flips)
         assert_close(got['anomaly'].cpu().numpy(), g['anomaly'], tol=2e-4, name='anomaly')
         tot = _report(f'ceVAE N={n}', math, flips, worst)
@@ -183,7 +185,7 @@ def test_gmvae_spatial_gradients_at_baseline_batch():
     for math in MODES:
         eng.set_math(math)
         got = eng.gm_forward(x, e_w, e_z, want_backward=True)
-        act, flips = device_activation_pattern(eng, p32, x, got['x_hat'], cache, 5, bn, final_kernel='dec_Conv2D_final/kernel', math=math)
+        act, flips = device_activation_pattern(eng, p32, x, got['x_hat'], cache, 5, bn, final_kernel='dec_Conv2D_final/kernel', math=math, xhat_oracle=out['xz_mu'])
         eng.backward()
         torch.cuda.synchronize()
         assert_close(got['x_hat'].cpu().numpy(), out['xz_mu'], name='xz_mu')

@@ -29,6 +29,22 @@ def test_library_exports_every_declared_symbol():
     assert b'gfx950' in _lib.load().uad_version()
 
 
+def test_library_exports_nothing_but_the_header():
+    """Built with -fvisibility=hidden (build.py): the dynamic symbol table defines exactly the functions include/uad_hip.h declares -- none of
+    the C++ launch layer (uad_launch_*, uad_fail, ...) leaks out of the boundary."""
+    import shutil
+    import subprocess
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    if not os.path.exists(nm):
+        pytest.skip('no nm in this image')
+    out = subprocess.run([nm, '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in 'TtWwBbDdRrVv'}
+    exported = {s for s in exported if not s.startswith(('__hip_', '_init', '_fini', '__bss', '_edata', '_end'))}
+    header = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'uad_hip.h')).read(), flags=re.S)
+    declared = set(re.findall(r'\b(uad_[a-z0-9_]+)\s*\(', header))
+    assert exported == declared, (sorted(exported - declared)[:10], sorted(declared - exported)[:10])
+
+
 def test_library_contains_gfx950_code_object():
     blob = open(_lib.LIB_PATH, 'rb').read()
     assert b'gfx950' in blob and b'conv_gemm_kernel' in blob

@@ -87,38 +87,5 @@ res['caae_chen_64_b32_f32_ms'] = {'AE': timed(lambda: (eng.aae_phase('AE', x64, 
                                   'Discriminator': timed(lambda: (eng.aae_phase('Discriminator', x64, z=z32, eps=e32), eng.adam('Discriminator', 1e-4)), reps=5),
                                   'Encoder(gen)': timed(lambda: (eng.aae_phase('Encoder', x64), eng.adam('Encoder', 1e-4)), reps=5)}
 eng.close()
-# hipGraph replay (uad_gan_set_graph_mode) vs plain launches: one f-AnoGAN WGAN iteration (1 generator + 5 critic phases) + encoder step
-for (variant, h, bs) in (('unified', 64, 64), ('unified', 128, 64)):
-    row = {}
-    for graph in (False, True):
-        eng = GanEngine(h, h, 1, 8, 128, max_batch=bs, variant=variant, graph=graph)
-        init(eng)
-        xx = torch.from_numpy(synthetic_slices(bs, h, h, seed=1)).cuda()
-        zz = torch.randn(bs, 128, device='cuda', generator=g); aa = torch.rand(bs, device='cuda', generator=g)
-
-        def wgan():
-            eng.phase('Generator', z=zz, want_images=False); eng.adam('Generator', 1e-4)
-            for _ in range(5):
-                eng.phase('Discriminator', x=xx, z=zz, alpha=aa, want_images=False); eng.adam('Discriminator', 1e-4)
-        row['graph' if graph else 'plain'] = {'wgan_iteration': timed(wgan), 'encoder_step': timed(lambda: (eng.phase('Encoder', x=xx, want_images=False), eng.adam('Encoder', 1e-4)))}
-        if graph:
-            row['graph_stats'] = eng.graph_stats()
-        eng.close()
-    res[f'fanogan_{variant}_{h}_b{bs}_ms'] = row
-for kind, kw in (('aae', {}), ('gmvae', dict(dim=6, dim_w=1))):
-    row = {}
-    for graph in (False, True):
-        zd = 1 if kind == 'gmvae' else 128
-        eng = GanEngine(128, 128, 1, 8, zdim=zd, max_batch=64, variant='aae', aae_kind=kind, graph=graph, **kw)
-        init(eng)
-        if kind == 'gmvae':
-            ew = torch.randn(64, 1, device='cuda', generator=g); ez = torch.randn(64, 1, device='cuda', generator=g)
-            xr = x.clone()
-            row['graph' if graph else 'plain'] = {'train': timed(lambda: (eng.gm_phase(x, ew, ez, want_l1=False), eng.adam('AE', 1e-4, 0.5, 0.999))),
-                                                  'restore_step': timed(lambda: eng.gm_restore_step(xr, ew, ez))}
-        else:
-            row['graph' if graph else 'plain'] = {'AE': timed(lambda: (eng.aae_phase('AE', x, want_images=False), eng.adam('AE', 1e-4))),
-                                                  'Discriminator': timed(lambda: (eng.aae_phase('Discriminator', x, z=z, eps=e), eng.adam('Discriminator', 1e-4)))}
-        eng.close()
-    res[f'{kind}_128_b64_graph_vs_plain_ms'] = row
+# (the hipGraph-replay comparison that lived here went with uad_gan_set_graph_mode in round 4: profiles/r01_m_graph_replay.json holds its numbers)
 print(json.dumps(res))

@@ -89,6 +89,7 @@ SYMBOLS = {
     'uad_set_step': (C.c_int, [C.c_void_p, C.c_longlong]),
     'uad_forward': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_int, C.c_void_p]),
     'uad_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'uad_check_fault': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'uad_adam_step': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_optimizer_step': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_train_step': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -128,8 +129,6 @@ SYMBOLS = {
     'uad_gan_phase': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(UadGanIO), C.c_int, C.c_int, C.c_void_p]),
     'uad_gan_adam': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_gan_reconstruct': (C.c_int, [C.c_void_p, C.POINTER(UadGanIO), C.c_int, C.c_void_p]),
-    'uad_gan_set_graph_mode': (C.c_int, [C.c_void_p, C.c_int]),
-    'uad_gan_graph_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     'uad_gan_restore_step': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(UadGanIO), C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     'uad_debug_buffer': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     'uad_gan_debug_buffer': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),

@@ -37,7 +37,8 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, 'uad_kernels.h'), os.path.join(ROOT, 'include', 'uad_hip.h'), os.path.join(CSRC, 'uad_gan_kernels.inc'),
                os.path.join(CSRC, 'uad_gan_create.inc'), os.path.join(CSRC, 'uad_conv16s.inc')]      # the .inc files are textual parts of uad_gan.hip
     objs = []
-    flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
+    # hidden visibility: the library exports exactly the functions include/uad_hip.h declares (its visibility push), none of the C++ launch layer
+    flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fvisibility-inlines-hidden', '-Wno-unused-value', '-Wno-unused-result']
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -53,8 +54,8 @@ def build(force=False, verbose=False):
     failed = [cmd for cmd, pr in zip(jobs, procs) if pr.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
-    if force or _newer(objs, LIB):
-        cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    if force or _newer(objs + [os.path.join(CSRC, 'libuad_hip.map')], LIB):
+        cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-Wl,--version-script=' + os.path.join(CSRC, 'libuad_hip.map')] + objs + ['-o', LIB]
         if verbose:
             print(' '.join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

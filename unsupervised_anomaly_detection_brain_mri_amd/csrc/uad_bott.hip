@@ -97,6 +97,7 @@ __device__ __forceinline__ void group_exchange(const UadBottArgs& a, int n, int 
             __builtin_amdgcn_s_sleep(2);
             if (++polls > (1u << 22)) {
                 if (a.err) __hip_atomic_store(a.err, a.epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (a.err_dev) __hip_atomic_store(a.err_dev, a.epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // what the optimizer kernels read
                 break;
             }
         }

@@ -143,20 +143,6 @@ struct uad_gan {
     float *s_ta, *s_tb, *s_sp, *s_sct;               // temporaries: conv2 / conv1 data gradients, pooled shortcut, shortcut conv output
     std::map<std::string, std::pair<float*, long long>> dbg;
     std::vector<void*> allocs;
-    // ---- hipGraph replay of whole phases (uad_gan_set_graph_mode) ----
-    struct GraphKey {                  // everything a phase's launch sequence depends on besides the buffers' contents
-        int kind, phase, n, wb, math, generic16, packed;
-        float tv, rlr;
-        void *xr, *gout;
-        uad_gan_io_t io;
-    };
-    struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; int seen; };
-    bool graph_on;
-    hipStream_t gstream;
-    hipEvent_t gev_in, gev_out;
-    std::vector<GraphEntry> graphs;
-    unsigned long long graph_tick;
-    long long graph_replays, graph_captures;
 };
 
 namespace {
@@ -1353,73 +1339,6 @@ int you_phase(uad_gan* m, const uad_gan_io_t* io, const float* x, int n, int wan
     return UAD_OK;
 }
 
-// ---- hipGraph replay ----
-// A phase is 60-250 launches of mostly tiny kernels (LayerNorm statistics, reductions, skinny products): launch-bound.  In graph mode
-// the launch sequence of a phase is captured once per distinct (phase, batch, flags, io pointers) and replayed with one hipGraphLaunch.
-// First sight of a key runs the plain path (one-time initialisations happen outside any capture), the second captures, later ones replay.
-// Capture needs a non-default stream: the handle owns one and fences it against the caller's stream with events on both sides.
-const int kMaxGraphs = 48;
-template <typename Body>
-int run_graphed(uad_gan* m, uad_gan::GraphKey key, hipStream_t user, Body body) {
-    key.math = m->math; key.generic16 = m->generic16 ? 1 : 0; key.packed = m->packed_valid ? 1 : 0;
-    uad_gan::GraphEntry* e = nullptr;
-    for (auto& g : m->graphs) if (!memcmp(&g.key, &key, sizeof key)) { e = &g; break; }
-    ++m->graph_tick;
-    if (!e) {
-        if ((int)m->graphs.size() >= kMaxGraphs) {                      // evict the least recently used entry
-            size_t lru = 0;
-            for (size_t i = 1; i < m->graphs.size(); ++i) if (m->graphs[i].last_use < m->graphs[lru].last_use) lru = i;
-            if (m->graphs[lru].exec) (void)hipGraphExecDestroy(m->graphs[lru].exec);
-            if (m->graphs[lru].graph) (void)hipGraphDestroy(m->graphs[lru].graph);
-            m->graphs.erase(m->graphs.begin() + lru);
-        }
-        uad_gan::GraphEntry ne;
-        ne.key = key; ne.graph = nullptr; ne.exec = nullptr; ne.last_use = m->graph_tick; ne.seen = 1;
-        m->graphs.push_back(ne);
-        return body(user);                                               // first sight: plain launches on the caller's stream
-    }
-    e->last_use = m->graph_tick;
-    HIP_TRY(hipEventRecord(m->gev_in, user));
-    HIP_TRY(hipStreamWaitEvent(m->gstream, m->gev_in, 0));
-    if (!e->exec) {
-        const bool packed_before = m->packed_valid;
-        HIP_TRY(hipStreamBeginCapture(m->gstream, hipStreamCaptureModeThreadLocal));
-        const int rc = body(m->gstream);
-        hipGraph_t g = nullptr;
-        const hipError_t ce = hipStreamEndCapture(m->gstream, &g);
-        if (rc != UAD_OK || ce != hipSuccess || !g) {
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipGetLastError();
-            m->packed_valid = packed_before;
-            m->graph_on = false;                                         // fall back to plain launches for good
-            if (rc != UAD_OK) return rc;
-            return body(user);
-        }
-        hipGraphExec_t ex = nullptr;
-        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess || !ex) {
-            (void)hipGraphDestroy(g); (void)hipGetLastError();
-            m->packed_valid = packed_before;
-            m->graph_on = false;
-            return body(user);
-        }
-        e->graph = g; e->exec = ex;
-        ++m->graph_captures;
-    } else {
-        ++m->graph_replays;
-    }
-    HIP_TRY(hipGraphLaunch(e->exec, m->gstream));
-    m->packed_valid = true;                                              // the one host-side effect of a phase body (refresh_packs)
-    HIP_TRY(hipEventRecord(m->gev_out, m->gstream));
-    HIP_TRY(hipStreamWaitEvent(user, m->gev_out, 0));
-    return UAD_OK;
-}
-uad_gan::GraphKey graph_key(int kind, int phase, const uad_gan_io_t* io, int n, int wb) {
-    uad_gan::GraphKey k;
-    memset(&k, 0, sizeof k);
-    k.kind = kind; k.phase = phase; k.n = n; k.wb = wb; k.io = *io;
-    return k;
-}
-
 }  // namespace
 
 extern "C" {
@@ -1428,8 +1347,6 @@ extern "C" {
 
 int uad_gan_destroy(uad_gan_t* m) {
     if (!m) return UAD_OK;
-    for (auto& g : m->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
-    if (m->gstream) { (void)hipStreamDestroy(m->gstream); (void)hipEventDestroy(m->gev_in); (void)hipEventDestroy(m->gev_out); }
     for (void* p : m->allocs) hipFree(p);
     delete m;
     return UAD_OK;
@@ -1703,43 +1620,17 @@ int uad_gan_restore_step(uad_gan_t* m, float* x_restored, const uad_gan_io_t* io
         HIP_TRY(hipGetLastError());
         return (int)UAD_OK;
     };
-    if (!m->graph_on) return body((hipStream_t)stream);
-    uad_gan::GraphKey k = graph_key(2, 0, io, n, 1);
-    k.io.x = nullptr;                          // ignored by this entry
-    k.tv = tv_lambda; k.rlr = restore_lr; k.xr = x_restored; k.gout = grads_out;
-    return run_graphed(m, k, (hipStream_t)stream, body);
+    return body((hipStream_t)stream);
 }
 
 int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int want_backward, void* stream) {
     if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
-    if (!m->graph_on) return gan_phase_body(m, phase, io, n, want_backward, stream);
-    return run_graphed(m, graph_key(0, phase, io, n, want_backward), (hipStream_t)stream,
-                       [&](hipStream_t st) { return gan_phase_body(m, phase, io, n, want_backward, (void*)st); });
+    return gan_phase_body(m, phase, io, n, want_backward, stream);
 }
 int uad_gan_reconstruct(uad_gan_t* m, const uad_gan_io_t* io, int n, void* stream) {
     if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
-    if (!m->graph_on) return gan_reconstruct_body(m, io, n, stream);
-    return run_graphed(m, graph_key(1, 0, io, n, 0), (hipStream_t)stream,
-                       [&](hipStream_t st) { return gan_reconstruct_body(m, io, n, (void*)st); });
+    return gan_reconstruct_body(m, io, n, stream);
 }
-int uad_gan_set_graph_mode(uad_gan_t* m, int on) {
-    if (!m) return fail(UAD_ERR_INVALID, "null handle");
-    if (on && !m->gstream) {
-        HIP_TRY(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&m->gev_in, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&m->gev_out, hipEventDisableTiming));
-    }
-    m->graph_on = on != 0;
-    return UAD_OK;
-}
-int uad_gan_graph_stats(const uad_gan_t* m, long long* captures, long long* replays, int* enabled) {
-    if (!m) return fail(UAD_ERR_INVALID, "null handle");
-    if (captures) *captures = m->graph_captures;
-    if (replays) *replays = m->graph_replays;
-    if (enabled) *enabled = m->graph_on ? 1 : 0;
-    return UAD_OK;
-}
-
 int uad_gan_adam(uad_gan_t* m, int group, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
     if (!m || group < 0 || group > 2) return fail(UAD_ERR_INVALID, "bad group");
     m->step[group] += 1;

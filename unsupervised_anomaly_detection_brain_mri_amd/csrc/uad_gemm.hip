@@ -46,13 +46,6 @@ struct ConvGemmArgs {
     unsigned long long* dbgbuf;   // per-phase clock stamps of a few workgroups (UAD_DBG & 8)
     int dbg;       // ablation switches for kernel tuning (UAD_DBG): 1 = no epilogue stores, 2 = no MFMA loop, 4 = no staging
     int math16;    // generic kernel: bf16x3 products (conv_gemm16_kernel) where the tile shape allows
-    // plane-group tensors (uad_conv16s.inc): the A operand already activated and split into bf16 hi | lo groups (replaces A + xf), and an
-    // optional second output in that form -- the activated value under oxf (EPI_BIAS) or the raw gradient (EPI_BWD_ACT)
-    const uint4* Apg = nullptr;
-    uint4* OutPg = nullptr;
-    UadXform oxf;
-    int stagger = 0;   // UAD_STAGGER: the second wave of workgroups (linear ids [256, 512)) sleeps this many x 8k cycles before it starts, so that
-                       // the two workgroups resident on a CU do not walk through their staging / MFMA / epilogue phases in lockstep
 };
 
 __device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int lws, int& n, int& i, int& j) {
@@ -1901,7 +1894,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 // too large to hold every channel at once, so channels are walked in CK-wide chunks (restaged per chunk, accumulators live
 // across chunks); the weight ring runs through the chunk boundary.
 // ------------------------------------------------------------------------------------------------
-template <int TH, int TW, int CK, int WGM, int WGN, int FB>      // FB: 0 plain | 1 final-backward on load from c | 2 ... from the pattern bits | 3 plain, plane-group input (ConvGemmArgs::Apg)
+template <int TH, int TW, int CK, int WGM, int WGN, int FB>      // FB: 0 plain | 1 final-backward on load from c | 2 ... from the pattern bits
 __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_per_eu(2))) conv5_f16_kernel(const ConvGemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int IH = 2 * TH + 3, IW = 2 * TW + 3;
@@ -1929,11 +1922,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     const int CA = a.CA, Nn = a.Nn;
     const int AH = d.HB, AW = d.WB;
 
-    const bool xf = a.xf.scale != nullptr && !(FB == 3);
+    const bool xf = a.xf.scale != nullptr;
     constexpr bool fb = FB == 1 || FB == 2;  // final-backward on load (UadXform::fb_*): its own instantiation, the extra
                                              // prefetch registers would otherwise spill the 64-column variant
     constexpr bool fbb = FB == 2;            // ... from one pattern word per pixel instead of the 32 pre-BN values (UadXform::fb_bits)
-    constexpr bool pin = FB == 3;            // the input is a plane-group tensor: staging is a copy (no activation, no split)
     if (xf)
         for (int c = tid; c < CA; c += NT) {
             s_xf[c] = a.xf.scale[c] * a.xf.mult;
@@ -1985,9 +1977,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 
     const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
     const float* inb = a.A + (size_t)n * AH * AW * CA;
-    const size_t sample_q = (size_t)AH * AW * (CA / 4);
-    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(pin ? (void*)(const_cast<uint4*>(a.Apg) + (size_t)n * sample_q) : (void*)const_cast<float*>(inb),
-                                                                          0, (unsigned)(sample_q * 16), 0x00020000);
     __syncthreads();
 
     // The activation tile of chunk ch+1 is fetched into registers while chunk ch is contracted (the tile's two dependent
@@ -2007,10 +1996,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             const bool ok = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
             const int gp = ok ? (gy * AW + gx) : 0;
             if (fbb) pb[u] = a.xf.fb_bits[(size_t)n * AH * AW + gp];
-            else if (pin) {         // out-of-image pixels read through the buffer's bounds check: zeros
-                const uint4 q = buf_load16(irs, ok ? (unsigned)((gp * (CA / 4) + (c0 >> 2) + cq) * 16) : 0x80000000u, 0);
-                pf[u] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
-            } else pf[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok ? cq * 4 : 0));
+            else pf[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok ? cq * 4 : 0));
             if (fb) pg[u] = a.xf.fb_dxhat[(size_t)n * AH * AW + gp];
         }
     };
@@ -2029,11 +2015,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             const int gy = gy0 + iy, gx = gx0 + ix;
             const bool ok = (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
             float4 t = pf[fbb ? 0 : u];
-            if (pin) {
-                *reinterpret_cast<uint2*>(sHi + pix * LDH + cq * 4) = make_uint2(__float_as_uint(t.x), __float_as_uint(t.y));
-                *reinterpret_cast<uint2*>(sLo + pix * LDH + cq * 4) = make_uint2(__float_as_uint(t.z), __float_as_uint(t.w));
-                continue;
-            }
             if (fbb) {
                 // the same from the pattern word the fused forward epilogue left: the derivative side of every channel is one bit
                 const float4 sc = t_sc, wf = t_wf;
@@ -2154,12 +2135,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     if (!bwd) {
         float4 e_a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.ep.bias) e_a = *reinterpret_cast<const float4*>(a.ep.bias + ecol);
-        float4 o_sc = make_float4(1.f, 1.f, 1.f, 1.f), o_sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.OutPg && a.oxf.scale) {
-            o_sc = *reinterpret_cast<const float4*>(a.oxf.scale + ecol);
-            o_sc.x *= a.oxf.mult; o_sc.y *= a.oxf.mult; o_sc.z *= a.oxf.mult; o_sc.w *= a.oxf.mult;
-            o_sh = *reinterpret_cast<const float4*>(a.oxf.shift + ecol);
-        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float4 t = v[k];
@@ -2167,15 +2142,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             if (a.ep.mul) { const float4 q = *reinterpret_cast<const float4*>(a.ep.mul + off[k]); t.x *= q.x; t.y *= q.y; t.z *= q.z; t.w *= q.w; }
             if (a.ep.add) { const float4 q = *reinterpret_cast<const float4*>(a.ep.add + off[k]); t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
             if (outp) *reinterpret_cast<float4*>(outp + off[k]) = t;
-            if (a.OutPg) {          // the activated output, split for the next contraction (UadPgIO)
-                float4 q;
-                q.x = fmaf(t.x, o_sc.x, o_sh.x); q.y = fmaf(t.y, o_sc.y, o_sh.y); q.z = fmaf(t.z, o_sc.z, o_sh.z); q.w = fmaf(t.w, o_sc.w, o_sh.w);
-                q.x = q.x > 0.f ? q.x : q.x * a.oxf.alpha; q.y = q.y > 0.f ? q.y : q.y * a.oxf.alpha;
-                q.z = q.z > 0.f ? q.z : q.z * a.oxf.alpha; q.w = q.w > 0.f ? q.w : q.w * a.oxf.alpha;
-                uint2 hi, lo;
-                split_bf16(q, hi, lo);
-                a.OutPg[off[k] >> 2] = make_uint4(hi.x, hi.y, lo.x, lo.y);
-            }
         }
         { if (stp) stp[5] = wall_clock64(); return; }
     }
@@ -2201,11 +2167,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         }
         const float4 o4 = make_float4(oo[0], oo[1], oo[2], oo[3]);
         if (outp) *reinterpret_cast<float4*>(outp + off[k]) = o4;
-        if (a.OutPg) {              // the gradient, split for its consumers (next data-gradient kernel, filter-gradient kernel)
-            uint2 hi, lo;
-            split_bf16(o4, hi, lo);
-            a.OutPg[off[k] >> 2] = make_uint4(hi.x, hi.y, lo.x, lo.y);
-        }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -2270,7 +2231,6 @@ template <int TH, int TW, int CK, int WGM, int WGN>
 void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
     if (a.xf.fb_bits) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 2>(a, grid, st);
     else if (a.xf.fb_dxhat) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 1>(a, grid, st);
-    else if (a.Apg) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 3>(a, grid, st);
     else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0>(a, grid, st);
 }
 
@@ -2488,10 +2448,8 @@ struct ConvWArgs {
     int kper;  // positions per split (multiple of BK)
     int lws, lhs;
     unsigned long long* dbgbuf;   // UAD_DBG & 32: per-workgroup start / end clocks
-    // plane-group operands (conv5_w_bf16_t_kernel): the operand already activated and split (UadPgIO) -- replaces the pointer and its transform
-    const uint4* big_pg = nullptr;
-    const uint4* small_pg = nullptr;
-    int abl = 0;   // UAD_W_ABL, kernel-tuning ablations (results are wrong): 1 no big-tile LDS stores | 2 no MFMAs | 4 no big-tile global loads | 8 no slab stores
+    int abl = 0;   // UAD_W_ABL, kernel-tuning ablations (results are wrong): 1 no big-tile LDS stores | 2 no MFMAs | 4 no big-tile global loads | 8 no slab stores;
+                   // 32 (results stay right): every workgroup sleeps before its slab store (ordering stress test)
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN>
@@ -3155,17 +3113,11 @@ conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
 // kx >> 1, so one segment read (2 x ds_read_b64 + 1 x ds_read_b32 per plane) serves every tap of that row and parity: offsets 0 and 2 are
 // register selections, offset 1 four v_alignbit.  Taps are dealt to the four waves by kernel ROW (wave w: the five taps of row w, tap (4, w), and
 // its quarter of tap (4, 4)) so that a wave's taps share its segment reads: ~20 LDS reads and <= 24 VALU per 16-position step instead of ~100 each.
-// TW8: EIGHT tap-waves per cs block instead of four (512 threads per cs block).  The round-3 ablations (profiles/README.md) put ~45 % of this
-// kernel's time in staging work that neither the loads, the LDS stores nor the MFMAs account for -- a latency-bound conversion / scatter loop
-// at two waves per SIMD.  With the taps dealt to eight waves (three or four 32 x 32 accumulators each instead of seven) a wave needs < 128
-// registers: four waves per SIMD, twice the threads staging every tile, the same MFMA work per tile.
-//   tap group 2 r     (r = kernel row 0..3): taps (r, 0), (r, 2), (r, 4) -- one even-column segment read serves all three -- and, at step
-//                     js == r, its share of tap (4, 4);
-//   tap group 2 r + 1: taps (r, 1), (r, 3) -- one odd-column segment read -- and tap (4, r).
-template <int NCSB, bool FBB = false, bool TW8 = false>
-__global__ void __launch_bounds__((TW8 ? 512 : 256) * NCSB) __attribute__((amdgpu_waves_per_eu(TW8 ? 4 : 2)))
+// (An eight-tap-wave form at four waves per SIMD -- round 3, tools/experiments/r03_pruned_opt_in_paths.patch -- measured slower and was removed.)
+template <int NCSB, bool FBB = false>
+__global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
 conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
-    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = (TW8 ? 512 : 256) * NCSB, CSQ = 8 * NCSB;
+    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256 * NCSB, CSQ = 8 * NCSB;
     constexpr int XHP = 12;                       // 16-bit slots per (channel, row, parity) segment: columns 0,2,..,18 / 1,3,..,17 (+ slack)
     constexpr int CSTP = IH * 2 * XHP + 4;        // channel stride (ushorts): 920 B = an odd number of 8-byte units -> the lanes' b64 reads spread over all banks
     constexpr int BIGP = CK * CSTP;               // ushorts per plane
@@ -3182,9 +3134,8 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
 
     const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
-    const int wave = TW8 ? ((wave_all & 7) >> 1) : (wave_all & 3);   // kernel row of this wave's taps
-    const int csb = TW8 ? (wave_all >> 3) : (wave_all >> 2);          // its cs block
-    const bool todd = TW8 && (wave_all & 1);                          // TW8: the odd-column tap group of the row
+    const int wave = wave_all & 3;   // kernel row of this wave's taps
+    const int csb = wave_all >> 2;    // its cs block
     const int l31 = lane & 31, lh = lane >> 5;
     const UadConvDesc& d = a.d;
     const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32 * NCSB;
@@ -3193,9 +3144,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     const int t_end = min(t_begin + tiles_per_split, total_tiles);
 
     const int cq = tid % CQ;
-    const uint4* bpg = FBB ? nullptr : a.big_pg;
-    const uint4* spg = a.small_pg;
-    const bool xfa = !FBB && !bpg && a.xfb.scale != nullptr, xfs = !spg && a.xfs.scale != nullptr;
+    const bool xfa = !FBB && a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
     // activation-on-load tables in LDS
     if (tid < 32) {
         sXf[tid] = xfa ? a.xfb.scale[cb0 + tid] * a.xfb.mult : 1.f;
@@ -3216,7 +3165,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
         }
     }
 
-    constexpr int MAXT = TW8 ? 4 : 7;
+    constexpr int MAXT = 7;
     // segment base of this lane's channel for kernel row ky at tile-row half lh (ushorts): row y = 4 js + 2 lh + ky
     const int seg_own = l31 * CSTP + ((2 * lh + wave) * 2) * XHP;          // ky = wave, parity 0; parity 1 at + XHP; step js at + 8 js XHP
     const int seg_k4 = l31 * CSTP + ((2 * lh + 4) * 2) * XHP;              // ky = 4
@@ -3259,7 +3208,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     float4 v[FBB ? 1 : PER];
     unsigned vb[FBB ? PER : 1];
     float vg[FBB ? PER : 1];
-    constexpr int SPER = TH * TW * CSQ / NT;          // 16-byte elements of the small tile per thread (2, or 1 with TW8)
+    constexpr int SPER = TH * TW * CSQ / NT;          // 16-byte elements of the small tile per thread
     float4 sv[SPER];
     auto tile_origin = [&](int t, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
         tx0 = (t % tilesx) * TW;
@@ -3281,9 +3230,6 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
             if (FBB) {
                 vb[FBB ? u : 0] = a.xfb.fb_bits[pixbase + gp];
                 vg[FBB ? u : 0] = a.xfb.fb_dxhat[pixbase + gp];
-            } else if (bpg) {
-                const uint4 q = bpg[(pixbase + gp) * (d.CB / 4) + (cb0 >> 2) + cq];
-                v[FBB ? 0 : u] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
             } else if (a.abl & 4) {
                 v[FBB ? 0 : u] = make_float4(1.f, 2.f, 3.f, 4.f);
             } else {
@@ -3298,10 +3244,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
             const int idx = tid + u * NT;
             const int pos = idx / CSQ, csq = idx % CSQ;
             const unsigned po = (unsigned)((pos / TW) * d.WS + (pos % TW));
-            if (spg) {
-                const uint4 q = spg[(spix + po) * (d.CS / 4) + (cs0 >> 2) + csq];
-                sv[u] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
-            } else sv[u] = *reinterpret_cast<const float4*>(a.small_ + (spix + po) * d.CS + cs0 + csq * 4);
+            sv[u] = *reinterpret_cast<const float4*>(a.small_ + (spix + po) * d.CS + cs0 + csq * 4);
         }
     };
     auto commit = [&](int t, int buf) __attribute__((always_inline)) {
@@ -3328,13 +3271,8 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
                     tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
                 } else if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
                 uint2 hi, lo;
-                if (!FBB && bpg) {      // plane-group operand: the words are the planes' (padding: zeros)
-                    hi = make_uint2(ok ? __float_as_uint(tv.x) : 0u, ok ? __float_as_uint(tv.y) : 0u);
-                    lo = make_uint2(ok ? __float_as_uint(tv.z) : 0u, ok ? __float_as_uint(tv.w) : 0u);
-                } else {
-                    tv = keep4(ok, tv);
-                    split_bf16(tv, hi, lo);
-                }
+                tv = keep4(ok, tv);
+                split_bf16(tv, hi, lo);
                 if (!(a.abl & 1)) {   // channel-major scatter: 4 channels x (hi, lo) 16-bit stores
                     const int o = (cq * 4) * CSTP + (iy * 2 + (ix & 1)) * XHP + (ix >> 1);
                     bHi[o] = (unsigned short)hi.x; bHi[o + CSTP] = (unsigned short)(hi.x >> 16);
@@ -3353,8 +3291,7 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
             float4 tv = sv[u];
             if (xfs) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + 64 + csq * 4), *reinterpret_cast<const float4*>(sXf + 128 + csq * 4), a.xfs.alpha);
             uint2 hi, lo;
-            if (spg) { hi = make_uint2(__float_as_uint(tv.x), __float_as_uint(tv.y)); lo = make_uint2(__float_as_uint(tv.z), __float_as_uint(tv.w)); }
-            else split_bf16(tv, hi, lo);
+            split_bf16(tv, hi, lo);
             unsigned short* ph = sHiT + (csq * 4) * LDP + pos;
             unsigned short* pl = sLoT + (csq * 4) * LDP + pos;
             ph[0] = (unsigned short)hi.x; ph[LDP] = (unsigned short)(hi.x >> 16);
@@ -3391,26 +3328,6 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
             const uint4 bh = *reinterpret_cast<const uint4*>(sHiT + baddr + 16 * js);
             const uint4 bl = *reinterpret_cast<const uint4*>(sLoT + baddr + 16 * js);
             const int so = seg_own + (8 * js) * XHP, sk = seg_k4 + (8 * js) * XHP;
-            if constexpr (TW8) {
-                if (!todd) {   // even columns of the own row: taps kx = 0, 2, 4
-                    const Seg h = read_seg(bHi, so), l = read_seg(bLo, so);
-                    mma3(acc[0], frag(h, 0), frag(l, 0), bh, bl);
-                    mma3(acc[1], frag(h, 1), frag(l, 1), bh, bl);
-                    mma3(acc[2], frag(h, 2), frag(l, 2), bh, bl);
-                    if (js == wave) {   // this row's share of tap (4, 4)
-                        const Seg h4 = read_seg(bHi, sk), l4 = read_seg(bLo, sk);
-                        mma3(acc[3], frag(h4, 2), frag(l4, 2), bh, bl);
-                    }
-                } else {       // odd columns: taps kx = 1, 3, and tap (4, row)
-                    const Seg h = read_seg(bHi, so + XHP), l = read_seg(bLo, so + XHP);
-                    mma3(acc[0], frag(h, 0), frag(l, 0), bh, bl);
-                    mma3(acc[1], frag(h, 1), frag(l, 1), bh, bl);
-                    const int a4 = sk + (wave & 1) * XHP;
-                    const Seg h4 = read_seg(bHi, a4), l4 = read_seg(bLo, a4);
-                    const bool one = (wave >> 1) != 0;
-                    mma3(acc[2], one ? frag(h4, 1) : frag(h4, 0), one ? frag(l4, 1) : frag(l4, 0), bh, bl);
-                }
-            } else {
             {   // own kernel row, even columns: taps kx = 0, 2, 4
                 const Seg h = read_seg(bHi, so), l = read_seg(bLo, so);
                 mma3(acc[0], frag(h, 0), frag(l, 0), bh, bl);
@@ -3432,7 +3349,6 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
                 const Seg h = read_seg(bHi, sk), l = read_seg(bLo, sk);
                 mma3(acc[6], frag(h, 2), frag(l, 2), bh, bl);
             }
-            }
         }
         if (DB) __syncthreads();               // buffer `cur` is consumed, buffer `cur ^ 1` is written
     }
@@ -3442,11 +3358,14 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     const int CSi = d.CS;
     float* ob = a.partial + (size_t)blockIdx.z * a.Mtot * CSi + (size_t)(cb0 + 4 * lh) * CSi + cs0 + csb * 32 + l31;
     const int tapstride = d.CB * CSi;
+    if (a.abl & 32) {       // stress test (tests/test_gpu_knobs.py): every workgroup idles ~100 us before it writes its slab, so that the filter gradient
+                            // OUTLASTS the any-order data gradient launched behind it -- results stay correct, only the timing changes
+        for (int i = 0; i < 32; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     if (!(a.abl & 8))
 #pragma unroll
     for (int j = 0; j < MAXT - 1; ++j) {
-        // TW8: even group -> taps (row, 0 / 2 / 4); odd group -> (row, 1), (row, 3), (4, row).  Else: (row, 0..4), (4, row).
-        const int tap = TW8 ? (todd ? (j < 2 ? 5 * wave + 2 * j + 1 : 20 + wave) : 5 * wave + 2 * j) : (j < 5 ? 5 * wave + j : 20 + wave);
+        const int tap = j < 5 ? 5 * wave + j : 20 + wave;      // (row, 0..4), (4, row)
         float* ot = ob + tap * tapstride;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -3456,12 +3375,10 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     }
     // tap (4, 4): the four rows' shares are folded through LDS in a fixed order
     __syncthreads();
-    if (!TW8 || !todd) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sRed[((csb * 4 + wave) * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
-    }
+    for (int r = 0; r < 16; ++r) sRed[((csb * 4 + wave) * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
     __syncthreads();
-    if (wave == 0 && !todd) {
+    if (wave == 0) {
         float* ot = ob + 24 * tapstride;
         const float* q = sRed + (size_t)csb * 64 * 64;
 #pragma unroll
@@ -3484,12 +3401,10 @@ inline W5Choice choose_w5(const UadConvDesc& d) {
     if (d.CB % 32 || d.CS % 32 || d.HS % 8 || d.WS % 8) return c;
     c.total_tiles = d.N * (d.HS / 8) * (d.WS / 8);
     const int blocks = (d.CB / 32) * (d.CS / 32);
-    // UAD_W5_TARGET / UAD_W5_MINTILES (experiment knobs): workgroup-slab target of a launch, fewest tiles a split may walk.  Every split
-    // costs one [25][CB][CS] slab written and re-read (52 MB per launch at the defaults), every tile ~2.6 us of a workgroup's life.
+    // UAD_W5_TARGET (tuning knob): workgroup-slab target of a launch.  Every split costs one [25][CB][CS] slab written and re-read (52 MB per
+    // launch at the default), every tile ~2.6 us of a workgroup's life.
     static const int target = getenv("UAD_W5_TARGET") ? atoi(getenv("UAD_W5_TARGET")) : 512;
-    static const int mintiles = getenv("UAD_W5_MINTILES") ? atoi(getenv("UAD_W5_MINTILES")) : 1;
     int splits = (target + blocks - 1) / blocks;
-    if (mintiles > 1 && splits * mintiles > c.total_tiles) splits = c.total_tiles / mintiles;
     if (splits > c.total_tiles) splits = c.total_tiles;
     if (splits < 1) splits = 1;
     c.tiles_per_split = (c.total_tiles + splits - 1) / splits;
@@ -3643,7 +3558,6 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
     const UadConvDesc& d = a.d;
     a.nsplit = 1; a.out_elems = p.out_elems;
     { static const int dbg = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0; a.dbg = dbg; a.dbgbuf = nullptr; }
-    { static const int stg = getenv("UAD_STAGGER") ? atoi(getenv("UAD_STAGGER")) : 0; a.stagger = stg; }
     static unsigned long long* dbgbuf = nullptr;
     static int dbg_calls = 0;
     const bool dbg_f = (a.dbg & 16) && f_type && a.Wp16 && a.Nn == 64 && a.CA == 32 && dbg_calls >= 40 && dbg_calls < 44;
@@ -3751,33 +3665,9 @@ void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, un
     else hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w16_f, w16_d, pd);
 }
 
-namespace {
-// the kernel that will run understands ConvGemmArgs::Apg / OutPg: bf16x3 spatial path, lane = pixel D-kind kernel (uad_conv16s.inc) or the
-// F-kind conv5_f16_kernel, split launches only with the in-kernel reducer
-bool plan_takes_pg(const GemmPlan& p, const UadConvDesc& d, bool f_type) {
-    if (p.path != PATH_SPATIAL) return false;
-    if (p.nsplit > 1 && !p.inkernel) return false;
-    const int CA = f_type ? d.CB : d.CS, Nn = f_type ? d.CS : d.CB;
-    if (f_type) return getenv("UAD_NO_F16") == nullptr && CA % 4 == 0;
-    if (getenv("UAD_NO_D16") || getenv("UAD_NO_D16S") || Nn % 32 || CA % p.nsplit) return false;
-    const int cst = CA / p.nsplit;
-    return p.sc.BN == 64 ? (cst == 128 || cst == 64 || cst == 32) : (cst == 64 || cst == 32);
-}
-void apply_pg(ConvGemmArgs& a, const UadPgIO& pg, bool ok) {
-    if (!ok) return;
-    a.Apg = reinterpret_cast<const uint4*>(pg.in_pg);
-    a.OutPg = reinterpret_cast<uint4*>(pg.out_pg);
-    a.oxf = pg.oxf;
-    if (pg.skip_f32 && pg.out_pg) a.Out = nullptr;
-}
-}  // namespace
-bool uad_conv_pg_ok(const UadConvDesc& d, bool f_type, size_t ws_floats, int ncounters) {
-    return plan_takes_pg(plan_gemm(d, f_type, true, ws_floats, ncounters), d, f_type);
-}
-
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W, float* small_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
-                       long long w16_plane, bool generic_bf16x3, UadPgIO pg) {
+                       long long w16_plane, bool generic_bf16x3) {
     ConvGemmArgs a;
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
@@ -3786,13 +3676,12 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
     a.sk_counter = nullptr; a.out_final = nullptr;
     const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
     if (p.inkernel) a.sk_counter = ws.counters;
-    apply_pg(a, pg, Wp16 != nullptr && plan_takes_pg(p, d, true));
     run_plan(p, a, true, ws.ptr, st);
 }
 
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W, float* big_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
-                       long long w16_plane, bool generic_bf16x3, UadPgIO pg) {
+                       long long w16_plane, bool generic_bf16x3) {
     ConvGemmArgs a;
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
@@ -3801,7 +3690,6 @@ void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf,
     a.sk_counter = nullptr; a.out_final = nullptr;
     const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
     if (p.inkernel) a.sk_counter = ws.counters;
-    apply_pg(a, pg, Wp16 != nullptr && plan_takes_pg(p, d, false));
     run_plan(p, a, false, ws.ptr, st);
 }
 
@@ -3838,13 +3726,8 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
     return (size_t)c.splits * d.KS * d.KS * d.CB * d.CS;
 }
 
-bool uad_conv_w_pg_ok(const UadConvDesc& d, bool math_bf16x3) {
-    return math_bf16x3 && choose_w5(d).ok && !getenv("UAD_NO_W_T");
-}
-
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
-                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev, bool generic_bf16x3, bool defer_reduce,
-                       const void* big_pg, const void* small_pg) {
+                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev, bool generic_bf16x3, bool defer_reduce) {
     // reduce_st/ev (optional): run the split-K slab reduction on a second stream, ordered after the main kernel by `ev`.
     // defer_reduce: leave the reduction to a later uad_launch_conv_w_reduce (the caller orders it after this kernel with ONE event per layer:
     // every event recorded on the main stream costs a ~6 us bubble before its next kernel)
@@ -3861,7 +3744,6 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         a.xfb = xfb; a.xfs = xfs; a.d = d;
         a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = 0; a.lws = a.lhs = -1; a.dbgbuf = nullptr;
         { static const int abl = getenv("UAD_W_ABL") ? atoi(getenv("UAD_W_ABL")) : 0; a.abl = abl; }
-        if (uad_conv_w_pg_ok(d, math_bf16x3)) { a.big_pg = reinterpret_cast<const uint4*>(big_pg); a.small_pg = reinterpret_cast<const uint4*>(small_pg); }
         dim3 grid(d.CB / 32, d.CS / 32, w5.splits);
         if (math_bf16x3) {
             static bool attr_set = false;
@@ -3897,26 +3779,6 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                 const bool two = pair_ok && d.CS % 64 == 0;
                 if (two) grid.y = d.CS / 64;
                 const size_t lds = conv5_w_bf16_t_lds_bytes(two ? 2 : 1);
-                // eight tap-waves per cs block (four waves per SIMD): measured 15-50 % SLOWER in round 3 (spills at 128 registers, twice the
-                // small-tile fragment reads) -- opt-in experiment
-                static const bool tw8 = getenv("UAD_W_TW8") != nullptr;
-                if (tw8) {
-                    static bool t8_attr = false;
-                    if (!t8_attr) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(1));
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(2));
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(1));
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(2));
-                        t8_attr = true;
-                    }
-                    if (xfb.fb_bits) {
-                        if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, true, true>), grid, dim3(1024), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                        else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, true, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                    } else {
-                        if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, false, true>), grid, dim3(1024), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                        else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, false, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                    }
-                } else
                 if (xfb.fb_bits) {
                     if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
                     else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, true>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);

@@ -74,32 +74,18 @@ struct UadEpilogue {
     float fin_inv_batch;
 };
 
-// Plane-group ("PG") side tensors of one launch (bf16x3 spatial kernels only; uad_conv16s.inc).  A PG tensor holds, per (pixel, channel quad),
-// the 16-byte group { hi01, hi23, lo01, lo23 } of bf16 pairs with value = hi + lo: the operand exactly as the bf16x3 contraction stages it
-// (activation applied, split done), same bytes per element as fp32.  in_pg replaces the fp32 input pointer and its activation-on-load;
-// out_pg is a second output: the result under `oxf` (EPI_BIAS: the producing block's own BN + (Leaky)ReLU) or the raw gradient (EPI_BWD_ACT).
-// The launchers ignore the PG pointers when the kernel that runs cannot honour them -- ask uad_conv_pg_ok() first.
-struct UadPgIO {
-    const void* in_pg = nullptr;
-    void* out_pg = nullptr;
-    UadXform oxf;
-    bool skip_f32 = false;     // do not write the fp32 output (every consumer takes out_pg)
-};
-// true when uad_launch_conv_f / _d with these arguments runs a kernel that reads in_pg and writes out_pg
-bool uad_conv_pg_ok(const UadConvDesc& d, bool f_type, size_t ws_floats, int ncounters);
-
 // F-type: small_out[n,i,j,cs] = sum_{tap,cb} xf(big_in)[n,S*i-P+ky,S*j-P+kx,cb] * W[tap][cb][cs]
 // Wpacked (optional): this tensor inside the F-pack buffer written by uad_launch_pack_weights; enables the k5 s2
 // spatial kernel.  The tile count of EPI_BWD_ACT (uad_conv_*_tiles) assumes Wpacked is given whenever it can be used.
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W,
                        float* small_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr,
                        UadGemmWs ws = UadGemmWs{nullptr, 0}, const unsigned short* Wp16 = nullptr, long long w16_plane = 0,
-                       bool generic_bf16x3 = false, UadPgIO pg = UadPgIO{});
+                       bool generic_bf16x3 = false);
 // D-type: big_out[n,S*i-P+ky,S*j-P+kx,cb] += xf(small_in)[n,i,j,cs] * W[tap][cb][cs]
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W,
                        float* big_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr,
                        UadGemmWs ws = UadGemmWs{nullptr, 0}, const unsigned short* Wp16 = nullptr, long long w16_plane = 0,
-                       bool generic_bf16x3 = false, UadPgIO pg = UadPgIO{});
+                       bool generic_bf16x3 = false);
 // generic_bf16x3: when no specialised kernel applies, let the generic kernel use bf16x3 products (identity xf, BK = 32 tiles)
 // bf16x3 math mode: Wp16 = this tensor's hi plane inside the bf16 pack buffer (ushort index 2*offset), w16_plane = its
 // element count (the lo plane follows the hi plane)
@@ -127,10 +113,7 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d);
 bool uad_conv_w_supports_fb_bits(const UadConvDesc& d, bool math_bf16x3);
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
                        float* dW, float* partial, hipStream_t st, bool math_bf16x3 = false,
-                       hipStream_t reduce_st = nullptr, hipEvent_t ev = nullptr, bool generic_bf16x3 = false, bool defer_reduce = false,
-                       const void* big_pg = nullptr, const void* small_pg = nullptr);
-// (big_pg / small_pg: the operand as a PG tensor -- replaces the fp32 pointer and its transform; k5 s2 bf16x3 kernel only: uad_conv_w_pg_ok)
-bool uad_conv_w_pg_ok(const UadConvDesc& d, bool math_bf16x3);
+                       hipStream_t reduce_st = nullptr, hipEvent_t ev = nullptr, bool generic_bf16x3 = false, bool defer_reduce = false);
 // the split-K slab reduction of a uad_launch_conv_w(..., defer_reduce = true) call (no-op when that launch did not split)
 void uad_launch_conv_w_reduce(const UadConvDesc& d, float* dW, float* partial, hipStream_t st);
 
@@ -149,10 +132,8 @@ void uad_launch_colsum(const float* g, int rows, int C, float* out, float* scrat
 size_t uad_colsum_scratch_floats(int rows, int C);
 
 // first layer (tiny Cin, raw image input): direct conv + bias, and its weight gradient
-// out_pg (optional, 32-channel k5 s2 shape only: uad_conv_first_pg_ok): the output under oxf as a PG tensor
 void uad_launch_conv_first_fwd(const UadConvDesc& d, const float* x, const float* W, const float* bias,
-                               float* out, hipStream_t st, void* out_pg = nullptr, UadXform oxf = UadXform{});
-bool uad_conv_first_pg_ok(const UadConvDesc& d);
+                               float* out, hipStream_t st);
 size_t uad_conv_first_wgrad_partial_floats(const UadConvDesc& d);
 void uad_launch_conv_first_wgrad(const UadConvDesc& d, const float* x, const float* g, float* dW,
                                  float* partial, hipStream_t st);
@@ -215,6 +196,7 @@ struct UadBottArgs {
     // exchange between the workgroups of one sample (uad_bott.hip): partial vectors, completion flags, this launch's epoch
     float* xch; unsigned* flags; unsigned epoch; int xw;
     unsigned* err;                       // optional, host-visible (pinned): a workgroup that gives up waiting for its siblings stores (epoch | 1 << 31) here
+    unsigned* err_dev;                   // optional, device memory: the same word for the optimizer kernels (uad_launch_adam / _optim `fault`): they skip their update
     int fault;                           // tests (UAD_BOTT_FAULT=1): workgroup 1 of sample 0 never publishes its flag
     unsigned long long* stamps;          // debug (UAD_BOTT_DBG): phase clocks of workgroup 0
     float *dd, *dmu, *dls, *dflat, *g_out, *colpart;   // colpart [n][2][cenc]
@@ -330,10 +312,12 @@ void uad_launch_loss_finalize(const float* rec_partial, int n, int n_vae, int bp
                               float inv_batch, float rec_scale, float* rec_per_sample, float* scalars, hipStream_t st);
 
 // TF-form Adam over a flat parameter buffer: g is multiplied by gscale first
+// fault (optional, device word): non-zero = the gradients of this step are invalid (fused bottleneck: UadBottArgs::err_dev) -> the kernel leaves
+// parameters and slots untouched
 void uad_launch_optim(int kind, float* p, const float* g, float* s1, float* s2, size_t n, float lr, float momentum, float decay, float eps,
-                      float gscale, hipStream_t st);
+                      float gscale, hipStream_t st, const unsigned* fault = nullptr);
 void uad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2,
-                     float eps, float gscale, hipStream_t st);
+                     float eps, float gscale, hipStream_t st, const unsigned* fault = nullptr);
 
 // residual anomaly map (utils/Evaluation.py:282-289): out = mask * (pos_only ? max(x-xr,0) : |x-xr|),
 // zeroed where x < prior_thresh (pass -inf to disable); per-sample sum|x-xr| into l1err[n] (may be null)

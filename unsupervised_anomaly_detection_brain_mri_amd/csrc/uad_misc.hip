@@ -308,8 +308,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // 16-byte reads fetch the 12 input columns the 4 pixels touch and ten fetch the 5 x 8 weights: 13 reads per 160 FMAs (packed pairs).
 template <int WS>
 __global__ void __launch_bounds__(256) conv_first_fwd32_kernel(UadConvDesc d, const float* __restrict__ x, const float* __restrict__ W,
-                                                               const float* __restrict__ bias, float* __restrict__ out,
-                                                               uint4* __restrict__ out_pg, UadXform oxf) {
+                                                               const float* __restrict__ bias, float* __restrict__ out) {
     constexpr int OR = 256 / WS, IR = 2 * OR + 3, XW = 2 * WS + 4;
     __shared__ __attribute__((aligned(16))) float ws[25 * 32];
     __shared__ __attribute__((aligned(16))) float xs[IR * XW];      // column xx holds input column xx - 1
@@ -356,31 +355,6 @@ __global__ void __launch_bounds__(256) conv_first_fwd32_kernel(UadConvDesc d, co
     for (int j = 0; j < 4; ++j) {
         *reinterpret_cast<float4*>(o + j * 32) = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
         *reinterpret_cast<float4*>(o + j * 32 + 4) = make_float4(acc[j][2].x, acc[j][2].y, acc[j][3].x, acc[j][3].y);
-    }
-    if (out_pg) {
-        // plane-group copy of the ACTIVATED output (this block's frozen BN + LeakyReLU), already split into bf16 hi | lo for the next
-        // contraction (uad_kernels.h: UadPgIO): 16 bytes per (pixel, channel quad), next to the pre-BN fp32 the backward needs
-        float sc[8], sh[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { sc[c] = oxf.scale[q * 8 + c] * oxf.mult; sh[c] = oxf.shift[q * 8 + c]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v[8] = {acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y, acc[j][2].x, acc[j][2].y, acc[j][3].x, acc[j][3].y};
-            unsigned hi[4], lo[4];
-#pragma unroll
-            for (int c = 0; c < 8; c += 2) {
-                float a0 = fmaf(v[c], sc[c], sh[c]), a1 = fmaf(v[c + 1], sc[c + 1], sh[c + 1]);
-                a0 = a0 > 0.f ? a0 : a0 * oxf.alpha; a1 = a1 > 0.f ? a1 : a1 * oxf.alpha;
-                unsigned h;
-                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(a0), "v"(a1));
-                const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xFFFF0000u);
-                unsigned l;
-                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
-                hi[c / 2] = h; lo[c / 2] = l;
-            }
-            out_pg[(oe + (size_t)j * 32) / 4] = make_uint4(hi[0], hi[1], lo[0], lo[1]);
-            out_pg[(oe + (size_t)j * 32) / 4 + 1] = make_uint4(hi[2], hi[3], lo[2], lo[3]);
-        }
     }
 }
 
@@ -812,9 +786,10 @@ __global__ void __launch_bounds__(256) conv_first_dgrad_kernel(UadConvDesc d, co
 
 // TF-1.15 AdamOptimizer update (trainers/DLMODEL.py:112-131): lr_t is computed on the host.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, float gscale) {
+                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, float gscale, const unsigned* __restrict__ fault) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (fault && *fault) return;      // this step's gradients are invalid (timed-out bottleneck exchange): no update; the host reports it (uad_model.hip: check_fault)
     const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -829,9 +804,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 //   kind 3 RMSPropOptimizer(decay .9, momentum, eps 1e-10)   ms = decay ms + (1 - decay) g^2 ; mom = momentum mom + lr g / sqrt(ms + eps) ; p -= mom
 //                                                            (slots ms = s2, ONE-initialised by TF, mom = s1)
 __global__ void optim_kernel(int kind, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1, float* __restrict__ s2, size_t n,
-                             float lr, float momentum, float decay, float eps, float gscale) {
+                             float lr, float momentum, float decay, float eps, float gscale, const unsigned* __restrict__ fault) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (fault && *fault) return;
     const float gi = g[i] * gscale;
     if (kind == 1) { p[i] -= lr * gi; return; }
     if (kind == 2) { const float a = momentum * s1[i] + gi; s1[i] = a; p[i] -= lr * a; return; }
@@ -1079,18 +1055,16 @@ static inline bool first32_ok(const UadConvDesc& d) {
     return !off && d.CB == 1 && d.CS == 32 && d.KS == 5 && d.S == 2 && d.P == 1 && d.HB == 2 * d.HS && d.WB == 2 * d.WS &&
            (d.WS == 32 || d.WS == 64 || d.WS == 128) && d.HS % 8 == 0;
 }
-bool uad_conv_first_pg_ok(const UadConvDesc& d) { return first32_ok(d); }
 void uad_launch_conv_first_fwd(const UadConvDesc& d, const float* x, const float* W, const float* bias, float* out,
-                               hipStream_t st, void* out_pg, UadXform oxf) {
-    uint4* opg = first32_ok(d) ? reinterpret_cast<uint4*>(out_pg) : nullptr;
+                               hipStream_t st) {
     const int tpp = d.CS / 8, ppb = 256 / tpp;
     const int xw = d.S * ppb + d.KS;
     const size_t lds = ((size_t)d.KS * d.KS * d.CB * d.CS + (size_t)d.KS * xw * d.CB) * sizeof(float);
     const int bpr = (d.WS + ppb - 1) / ppb;
     if (first32_ok(d)) {
-        if (d.WS == 32) hipLaunchKernelGGL(conv_first_fwd32_kernel<32>, dim3(d.N * d.HS / 8), dim3(256), 0, st, d, x, W, bias, out, opg, oxf);
-        else if (d.WS == 64) hipLaunchKernelGGL(conv_first_fwd32_kernel<64>, dim3(d.N * d.HS / 4), dim3(256), 0, st, d, x, W, bias, out, opg, oxf);
-        else hipLaunchKernelGGL(conv_first_fwd32_kernel<128>, dim3(d.N * d.HS / 2), dim3(256), 0, st, d, x, W, bias, out, opg, oxf);
+        if (d.WS == 32) hipLaunchKernelGGL(conv_first_fwd32_kernel<32>, dim3(d.N * d.HS / 8), dim3(256), 0, st, d, x, W, bias, out);
+        else if (d.WS == 64) hipLaunchKernelGGL(conv_first_fwd32_kernel<64>, dim3(d.N * d.HS / 4), dim3(256), 0, st, d, x, W, bias, out);
+        else hipLaunchKernelGGL(conv_first_fwd32_kernel<128>, dim3(d.N * d.HS / 2), dim3(256), 0, st, d, x, W, bias, out);
         return;
     }
     hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(d.N * d.HS * bpr), dim3(256), lds, st, d, x, W, bias, out);
@@ -1204,13 +1178,13 @@ void uad_launch_loss_finalize(const float* rec_partial, int n, int n_vae, int bp
                        inv_batch, rec_scale, rec_per_sample, scalars);
 }
 void uad_launch_optim(int kind, float* p, const float* g, float* s1, float* s2, size_t n, float lr, float momentum, float decay, float eps,
-                      float gscale, hipStream_t st) {
-    hipLaunchKernelGGL(optim_kernel, dim3((n + 255) / 256), dim3(256), 0, st, kind, p, g, s1, s2, n, lr, momentum, decay, eps, gscale);
+                      float gscale, hipStream_t st, const unsigned* fault) {
+    hipLaunchKernelGGL(optim_kernel, dim3((n + 255) / 256), dim3(256), 0, st, kind, p, g, s1, s2, n, lr, momentum, decay, eps, gscale, fault);
 }
 void uad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2,
-                     float eps, float gscale, hipStream_t st) {
+                     float eps, float gscale, hipStream_t st, const unsigned* fault) {
     hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, n, lr_t, beta1, beta2, eps,
-                       gscale);
+                       gscale, fault);
 }
 void uad_launch_residual(const float* x, const float* xr, const float* mask, int n, int hw, int pos_only,
                          float prior_thresh, float* out, float* l1err, hipStream_t st) {

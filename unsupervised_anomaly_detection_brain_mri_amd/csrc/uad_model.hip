@@ -54,8 +54,6 @@ struct ConvLayer {        // conv / convT block followed by BN + (Leaky)ReLU
     UadConvDesc d;        // geometry at batch 1 (N filled per call)
     long long w, b, gamma, beta;   // flat offsets
     float* c;             // pre-BN output [N, ., ., C]
-    float* pg = nullptr;  // plane-group copy of the ACTIVATED output (UadPgIO; bf16x3 mode): what the next block and the filter gradients stage
-    bool pg_valid = false;   // ... written by the last forward
 };
 
 }  // namespace
@@ -103,12 +101,11 @@ struct uad_model {
     float* restore_grads;              // optional gradient output
     // gradient ping-pong + small grads
     float *G0, *G1;
-    float *GP0 = nullptr, *GP1 = nullptr;   // plane-group forms of the gradients that only bf16x3 kernels read (swap together with G0 / G1)
-    bool g_f32 = true, g_pg = false;   // what the current d loss / d c (G0 / GP0) exists as
-    bool pg_on = false;                // bf16x3 mode and UAD_NO_PG unset
     float* dcb_keep;                  // copy of d loss / d cb for conv2d_1's kernel gradient (SIDE)
     float* bott_xch; unsigned* bott_flags; unsigned bott_epoch;
     unsigned* bott_err_host; unsigned* bott_err_dev;      // pinned word the fused bottleneck kernels report a timed-out sibling exchange through
+    unsigned* bott_fault;                                 // the same word in device memory: the optimizer kernels read it and skip their update
+    unsigned opt_epoch[64]; unsigned opt_calls;           // bottleneck launch epoch at each of the last optimizer calls (ring): how many updates a fault skipped
     float* bnfin_scratch;             // counters + partials of the 2-D BN-gradient finalize (SIDE stream only)
     float* bott_wpart;                // [4 * max_batch][2*cenc*cmid + cmid] shares of conv2d / conv2d_1's parameter gradients
     float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
@@ -247,7 +244,7 @@ UadBottArgs bott_args(uad_model* m, const uad_io_t& io, const float* mask_dec, i
     a.mask_dec = vae ? mask_dec : nullptr;        // AE: the dec_dense dropout is never active (autoencoder.py:30)
     a.t = m->t; a.mu = m->mu; a.ls = m->ls; a.sigma = m->sigma; a.z = m->z; a.kl = m->kl; a.dvec = m->dvec; a.cb = m->cb;
     a.xch = m->bott_xch; a.flags = m->bott_flags; a.xw = 2 * m->cfg.zdim; a.epoch = 0;      // epoch: set at each launch
-    a.err = m->bott_err_dev;
+    a.err = m->bott_err_dev; a.err_dev = m->bott_fault;
     return a;
 }
 
@@ -437,12 +434,6 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     if (cfg->arch == UAD_ARCH_VAE) ALLOC(m->gm_dxhat, NB * H * Wd * cfg->channels);     // restoration mode (trainers/VAE_You.py)
     m->dec_in0 = (gm || sp) ? m->gm_h : m->cb;
     ALLOC(m->G0, maxact); ALLOC(m->G1, maxact);
-    {   // plane-group tensors (same bytes per element as fp32): activations every k5 block hands to the next one, gradients below the last block
-        size_t maxpg = 4;
-        for (size_t i = 0; i + 1 < m->enc.size(); ++i) { auto& L = m->enc[i]; size_t n = NB * L.d.HS * L.d.WS * L.d.CS; ALLOC(L.pg, n); if (i >= 1 && n > maxpg) maxpg = n; }
-        for (size_t i = 0; i + 1 < m->dec.size(); ++i) { auto& L = m->dec[i]; size_t n = NB * L.d.HB * L.d.WB * L.d.CB; ALLOC(L.pg, n); if (n > maxpg) maxpg = n; }
-        ALLOC(m->GP0, maxpg); ALLOC(m->GP1, maxpg);
-    }
     { float* fbw = nullptr; ALLOC(fbw, NB * H * Wd); m->fin_bits = reinterpret_cast<unsigned*>(fbw); ALLOC(m->fin_dxh, NB * H * Wd); }
     m->last_fin_bits = false;
     ALLOC(m->g_small[0], nflat); ALLOC(m->g_small[1], nz); ALLOC(m->g_small[2], nz); ALLOC(m->g_small[3], nz);
@@ -451,6 +442,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->bott_xch, NB * 4 * 2 * (size_t)cfg->zdim);
     { float* fl = nullptr; ALLOC(fl, NB * 4); m->bott_flags = reinterpret_cast<unsigned*>(fl); m->bott_epoch = 0; }
     m->bott_err_host = m->bott_err_dev = nullptr;
+    { float* fw = nullptr; ALLOC(fw, 4); m->bott_fault = reinterpret_cast<unsigned*>(fw); m->opt_calls = 0; }      // (ALLOC zero-fills)
     if (rc == UAD_OK && hipHostMalloc((void**)&m->bott_err_host, sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
         *m->bott_err_host = 0u;
         if (hipHostGetDevicePointer((void**)&m->bott_err_dev, m->bott_err_host, 0) != hipSuccess) m->bott_err_dev = nullptr;
@@ -531,15 +523,22 @@ int uad_tensor_info(const uad_model_t* m, int idx, char* name, int name_cap, lon
 }
 
 static void invalidate_pack(uad_model* m);
-float* uad_buffer(uad_model_t* m, int which) {
+static int check_fault(uad_model* m);
+static float* buffer_ptr(uad_model* m, int which) {      // no side effect: the readers inside the library
     if (!m) return nullptr;
     switch (which) {
-        case UAD_BUF_PARAMS: invalidate_pack(m); return m->params;      // the caller may write through the pointer (DP broadcast, checkpoint restore)
+        case UAD_BUF_PARAMS: return m->params;
         case UAD_BUF_GRADS: return m->grads;
         case UAD_BUF_ADAM_M: return m->adam_m;
         case UAD_BUF_ADAM_V: return m->adam_v;
     }
     return nullptr;
+}
+float* uad_buffer(uad_model_t* m, int which) {
+    // the caller may WRITE through the parameter pointer (DP broadcast, checkpoint restore): an in-flight repack is waited for and the packed
+    // copies are marked stale.  Read-only users inside the library (uad_get_buffer: checkpoint save) go through buffer_ptr and trigger neither.
+    if (m && which == UAD_BUF_PARAMS) invalidate_pack(m);
+    return buffer_ptr(m, which);
 }
 
 int uad_grad_segment(const uad_model_t* m, int segment, long long* offset, long long* count) {
@@ -550,16 +549,17 @@ int uad_grad_segment(const uad_model_t* m, int segment, long long* offset, long 
 }
 
 int uad_set_buffer(uad_model_t* m, int which, const float* host, long long count) {
-    float* p = uad_buffer(m, which);
+    float* p = buffer_ptr(m, which);
     if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "set_buffer: bad arguments (count=%lld, expected %lld)", count, m ? m->nparams : -1);
     if (which == UAD_BUF_PARAMS) invalidate_pack(m);
     HIP_TRY(hipMemcpy(p, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
     return UAD_OK;
 }
 int uad_get_buffer(uad_model_t* m, int which, float* host, long long count) {
-    float* p = uad_buffer(m, which);
+    float* p = buffer_ptr(m, which);
     if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "get_buffer: bad arguments");
     HIP_TRY(hipDeviceSynchronize());
+    { const int frc = check_fault(m); if (frc != UAD_OK) return frc; }      // (a checkpoint must not be written across an unreported fault)
     HIP_TRY(hipMemcpy(host, p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
     return UAD_OK;
 }
@@ -621,23 +621,41 @@ static void invalidate_pack(uad_model* m) {
 
 // ------------------------------------------------------------------------------------------------ forward
 static int sk_counters(const uad_model* m);
-// plane-group tensors: opt-in (UAD_PG=1), split-bf16 mode only.  Measured in round 3 (profiles/README.md): every consumer stages them with plain
-// copies and all parity tests hold, but the step is 2 % SLOWER -- the producers' second 16-byte-per-quad store stream costs more than the
-// conversions it saves, because the staging phases are bound by memory / LDS latency at two waves per SIMD, not by VALU issue.
-static bool pg_mode(const uad_model* m) { static const bool on = getenv("UAD_PG") != nullptr; return on && m->math == UAD_MATH_BF16X3; }
-static bool conv_pg_ok(const uad_model* m, const UadConvDesc& d, bool f_type) { return pg_mode(m) && uad_conv_pg_ok(d, f_type, m->ws.floats, sk_counters(m)); }
+// A timed-out sibling exchange of the fused bottleneck (uad_bott.hip: group_exchange) leaves that step's activations / gradients invalid.  The
+// kernels raise two words: a device one, which every optimizer launch reads -- the update of the faulted step, and of every step enqueued
+// behind it before the host noticed, is SKIPPED on the device, so parameters and optimizer slots are never touched by invalid gradients -- and a
+// pinned host one, which this check turns into an error at the next uad_forward / uad_get_buffer / uad_check_fault.  The step counter is
+// rolled back by the number of skipped updates, so a caller that handles the error resumes from a consistent state.
+static int check_fault(uad_model* m) {
+    if (!m->bott_err_host) return UAD_OK;
+    const unsigned e = *reinterpret_cast<volatile unsigned*>(m->bott_err_host);
+    if (!e) return UAD_OK;
+    (void)hipDeviceSynchronize();            // error path: everything enqueued behind the fault has run (and skipped its update)
+    *m->bott_err_host = 0u;
+    if (m->bott_fault) (void)hipMemset(m->bott_fault, 0, sizeof(unsigned));
+    const unsigned ep = e & 0x7fffffffu;
+    int skipped = 0;
+    for (unsigned k = 0; k < 64 && k < m->opt_calls; ++k)
+        if (m->opt_epoch[(m->opt_calls - 1 - k) & 63] >= ep) ++skipped;
+    m->step -= skipped; if (m->step < 0) m->step = 0;
+    m->opt_calls = 0;
+    invalidate_pack(m);
+    return fail(UAD_ERR_HIP, "fused bottleneck: a workgroup gave up waiting for its sibling workgroups (launch epoch %u); the results of that "
+                             "step are invalid and %d optimizer update(s) behind it were skipped on the device (parameters and slots are those "
+                             "of the last good step). UAD_BOTT_Q1=1 selects the one-workgroup-per-sample form", ep, skipped);
+}
+int uad_check_fault(uad_model_t* m, int synchronize, void* stream) {
+    if (!m) return fail(UAD_ERR_INVALID, "null model");
+    if (synchronize) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return check_fault(m);
+}
+// (Plane-group tensors -- every producer also writing its ACTIVATED output pre-split into bf16 hi | lo groups for the consumers -- were built and
+// measured in round 3: parity-green, 2 % slower; removed in round 4, tools/experiments/r03_pruned_opt_in_paths.patch.)
 int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, void* stream) {
     if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
     if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
     if (!io->x) return fail(UAD_ERR_INVALID, "io.x is null");
-    if (m->bott_err_host) {
-        const unsigned e = *reinterpret_cast<volatile unsigned*>(m->bott_err_host);
-        if (e) {
-            *m->bott_err_host = 0u;
-            return fail(UAD_ERR_HIP, "fused bottleneck: a workgroup gave up waiting for its sibling workgroups (launch epoch %u); the results of that "
-                                     "step are invalid. UAD_BOTT_Q1=1 selects the one-workgroup-per-sample form", e & 0x7fffffffu);
-        }
-    }
+    { const int frc = check_fault(m); if (frc != UAD_OK) return frc; }
     hipStream_t st = (hipStream_t)stream;
     const bool vae = m->cfg.arch == UAD_ARCH_VAE || m->cfg.arch == UAD_ARCH_CEVAE;
     const bool cevae = m->cfg.arch == UAD_ARCH_CEVAE;
@@ -682,30 +700,17 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     // encoder
     static const char* kEncF[] = {"enc0.fwd", "enc1.fwd", "enc2.fwd", "enc3.fwd", "enc4.fwd", "enc5.fwd", "enc6.fwd", "enc7.fwd"};
     static const char* kDecF[] = {"dec0.fwd", "dec1.fwd", "dec2.fwd", "dec3.fwd", "dec4.fwd", "dec5.fwd", "dec6.fwd", "dec7.fwd"};
-    for (auto& L : m->enc) L.pg_valid = false;
-    for (auto& L : m->dec) L.pg_valid = false;
     {
         PROF(kEncF[0]);
         UadConvDesc d = m->enc[0].d; d.N = n;
-        // next to the pre-BN fp32 output every block leaves its ACTIVATED output as a plane-group tensor (UadPgIO): the next block and the
-        // filter gradients stage that with plain copies
-        const bool opg = pg_mode(m) && m->enc[0].pg && uad_conv_first_pg_ok(d);
-        uad_launch_conv_first_fwd(d, xin, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st, opg ? m->enc[0].pg : nullptr,
-                                  bn_xform(m, m->enc[0].gamma, m->enc[0].beta, kLrelu));
-        m->enc[0].pg_valid = opg;
+        uad_launch_conv_first_fwd(d, xin, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st);
     }
     if (wait_pack) (void)hipStreamWaitEvent(st, m->ev_pack, 0);
     for (size_t i = 1; i < m->enc.size(); ++i) {
         PROF(kEncF[i & 7]);
         UadConvDesc d = m->enc[i].d; d.N = n;
-        UadPgIO io;
-        if (conv_pg_ok(m, d, true)) {
-            if (m->enc[i - 1].pg_valid) io.in_pg = m->enc[i - 1].pg;
-            if (m->enc[i].pg) { io.out_pg = m->enc[i].pg; io.oxf = bn_xform(m, m->enc[i].gamma, m->enc[i].beta, kLrelu); m->enc[i].pg_valid = true; }
-        }
         uad_launch_conv_f(d, m->enc[i - 1].c, bn_xform(m, m->enc[i - 1].gamma, m->enc[i - 1].beta, kLrelu),
-                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, PKF(m, m->enc[i].w), m->ws, PK16F(m, m->enc[i].w), PLANE(m->enc[i]),
-                          false, io);
+                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, PKF(m, m->enc[i].w), m->ws, PK16F(m, m->enc[i].w), PLANE(m->enc[i]));
     }
     const ConvLayer& EL = m->enc.back();
     // bottleneck
@@ -777,12 +782,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
             ep.fin_inv_batch = 1.0f / (float)nu;
             out = restore_bwd ? DL.c : nullptr;
         }
-        UadPgIO io;
-        if (conv_pg_ok(m, d, false)) {
-            if (i >= 1 && m->dec[i - 1].pg_valid) io.in_pg = m->dec[i - 1].pg;
-            if (m->dec[i].pg && ep.kind == UAD_EPI_BIAS) { io.out_pg = m->dec[i].pg; io.oxf = bn_xform(m, m->dec[i].gamma, m->dec[i].beta, kLrelu); m->dec[i].pg_valid = true; }
-        }
-        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), out, ep, st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]), false, io);
+        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), out, ep, st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]));
     }
     // final 1x1 conv + L1 loss (+ start of the backward)
     UadFinalArgs fa;
@@ -866,6 +866,14 @@ static hipEvent_t next_event(uad_model* m) {
     }
     return m->sync_events[m->ev_next++];
 }
+// Ordering contract of an edge recorded behind an ANY-ORDER launch (a layer's data gradient is launched without the AQL barrier bit, so it may
+// finish before or after the filter gradient enqueued ahead of it; the side stream's slab reduction needs BOTH).  hipEventRecord on ROCm
+// (ROCclr, 6.x / 7.x) always submits its own marker command -- an AQL barrier-AND packet with the BARRIER BIT SET -- and the packet processor
+// does not consume a barrier-bit packet until every earlier packet of that queue has COMPLETED, whatever those packets' own barrier bits were.
+// The event's signal is that marker's completion signal, not the last dispatch's, so a waiter on `to` starts after the filter gradient AND
+// the data gradient.  Pinned by tests/test_gpu_knobs.py::test_any_order_edge_waits_for_the_slower_filter_gradient: with UAD_W_ABL=32 every
+// filter-gradient workgroup sleeps ~100 us before writing its slab (it then outlasts the data gradient by far) and the gradients of a step on
+// fresh inputs must equal, bit for bit, those of a UAD_NO_ANYORDER run -- stale or half-written slabs would show.
 static void edge(uad_model* m, hipStream_t from, hipStream_t to) {
     hipEvent_t e = next_event(m);
     (void)hipEventRecord(e, from);
@@ -888,11 +896,6 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
     m->ev_next = 0;
     float* g = m->G0;      // d loss / d c of dec[i]
     float* gn = m->G1;
-    // Gradients that only the bf16x3 kernels read travel as plane-group tensors (GP0 / GP1, UadPgIO): the data-gradient epilogue that produces
-    // d loss / d c of block i - 1 writes it split, and block i - 1's filter- and data-gradient kernels stage it with copies.  The gradient of the
-    // first block goes to the bottleneck kernels and stays fp32.
-    bool g_f32 = true, g_pg = false;
-    float *gp = m->GP0, *gpn = m->GP1;
     for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
         UadConvDesc d = m->dec[i].d; d.N = n;
         const float* in = (i == 0) ? m->dec_in0 : m->dec[i - 1].c;
@@ -906,13 +909,10 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
         const bool fbb = last && m->last_fin_bits;      // d loss / d c of the last block exists only as pattern bits + d objective / d x_hat
         UadXform gbits = no_xform();
         if (fbb) { gbits = bn_xform(m, DL.gamma, DL.beta, kLrelu); gbits.fb_dxhat = m->fin_dxh; gbits.fb_wf = P(m, m->fw); gbits.fb_bits = m->fin_bits; }
-        const bool w_pg = pg_mode(m) && uad_conv_w_pg_ok(d, bf);
-        const void* in_act_pg = (w_pg && i >= 1 && m->dec[i - 1].pg_valid) ? m->dec[i - 1].pg : nullptr;
         { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr;
           if (anyo && pg && bf && last && m->fwd_tail_is_loss && !m->prof_on) uad_conv_w_any_order_next(true);
           m->fwd_tail_is_loss = false; }
-        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, nullptr, nullptr, false, true,
-                                                          (w_pg && g_pg && !fbb) ? gp : nullptr, in_act_pg); }
+        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, nullptr, nullptr, false, true); }
         uad_conv_w_any_order_next(false);
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
         { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg) uad_conv_any_order_next(true); }
@@ -920,18 +920,8 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
           const bool fb = m->restore && m->fb_on_load && last;
           UadXform gx = fbb ? gbits : no_xform();
           if (fb) { gx = bn_xform(m, DL.gamma, DL.beta, kLrelu); gx.fb_dxhat = m->gm_dxhat; gx.fb_wf = P(m, m->fw); }
-          UadPgIO io;
-          bool gn_pg = false;
-          if (conv_pg_ok(m, d, true)) {
-              if (g_pg && !fbb && !fb) io.in_pg = gp;
-              if (i >= 1) {     // both consumers of d loss / d c of block i - 1 take the plane-group form: write only that
-                  UadConvDesc d1 = m->dec[i - 1].d; d1.N = n;
-                  if (uad_conv_w_pg_ok(d1, bf) && conv_pg_ok(m, d1, true)) { io.out_pg = gpn; io.skip_f32 = true; gn_pg = true; }
-              }
-          }
-          uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i]), false, io);
-          uad_conv_any_order_next(false);      // (a launch that did not take a spatial kernel must not leave the request to a later one)
-          g_pg = gn_pg; g_f32 = !gn_pg; }
+          uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i]));
+          uad_conv_any_order_next(false); }    // (a launch that did not take a spatial kernel must not leave the request to a later one)
         edge(m, st, sd);   // ONE edge per layer: its filter-gradient slabs and column partials are ready
         if (pg && last) {
             // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials (forward results; riding on
@@ -942,10 +932,8 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
         }
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats, sk_counters(m)), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
-        tsw = gp; gp = gpn; gpn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
-    m->GP0 = gp; m->GP1 = gpn; m->g_f32 = g_f32; m->g_pg = g_pg;      // (block 0's gradient is always fp32)
     if (join_now) edge(m, sd, st);         // join: decoder gradients complete (inside UAD_SEG_ALL the join is the encoder segment's)
     return UAD_OK;
 }
@@ -1135,8 +1123,6 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
     const bool pg = !m->data_only;
     float* g = m->G0;
     float* gn = m->G1;
-    float *gp = m->GP0, *gpn = m->GP1;
-    bool g_pg = m->g_pg;          // d loss / d c of the block about to be back-propagated exists as a plane-group tensor (then ONLY as that)
     static const char* kEncW[] = {"enc0.wgrad", "enc1.wgrad", "enc2.wgrad", "enc3.wgrad", "enc4.wgrad", "enc5.wgrad", "enc6.wgrad", "enc7.wgrad"};
     static const char* kEncD[] = {"enc0.dgrad", "enc1.dgrad", "enc2.dgrad", "enc3.dgrad", "enc4.dgrad", "enc5.dgrad", "enc6.dgrad", "enc7.dgrad"};
     const int hi_from = (int)m->enc.size() - 1, hi_to = m->enc.size() >= 3 ? 2 : hi_from + 1;      // ENCODER_HI runs blocks hi_from .. hi_to
@@ -1145,31 +1131,17 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
         UadConvDesc d = m->enc[i].d; d.N = n;
         const ConvLayer& PL = m->enc[i - 1];
         float* cp = m->cp_slot[8 + (i & 7)];
-        const bool w_pg = pg_mode(m) && uad_conv_w_pg_ok(d, bf);
-        if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true,
-                                                          (w_pg && PL.pg_valid) ? PL.pg : nullptr, (w_pg && g_pg) ? gp : nullptr); }
+        if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true); }
         { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg) uad_conv_any_order_next(true); }
         { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
-          UadPgIO io;
-          bool gn_pg = false;
-          if (conv_pg_ok(m, d, false)) {
-              if (g_pg) io.in_pg = gp;
-              if (i >= 2) {     // d loss / d c of block i - 1 is read by that block's filter- and data-gradient kernels only
-                  UadConvDesc d1 = m->enc[i - 1].d; d1.N = n;
-                  if (uad_conv_w_pg_ok(d1, bf) && conv_pg_ok(m, d1, false)) { io.out_pg = gpn; io.skip_f32 = true; gn_pg = true; }
-              }
-          }
-          uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i]), false, io);
-          uad_conv_any_order_next(false);
-          g_pg = gn_pg; }
+          uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i]));
+          uad_conv_any_order_next(false); }
         edge(m, st, sd);
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd);
                   uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats, sk_counters(m)), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
-        tsw = gp; gp = gpn; gpn = tsw;
     }
-    m->GP0 = gp; m->GP1 = gpn; m->g_pg = g_pg; m->g_f32 = !g_pg;
     if (part == 1) {
         m->G0 = g; m->G1 = gn;
         edge(m, sd, st);   // join: the deep blocks' gradients are complete
@@ -1221,7 +1193,8 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
     hipStream_t st = (hipStream_t)stream;
     invalidate_pack(m);
-    { PROF("adam"); uad_launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr_t, beta1, beta2, eps, grad_scale, st); }
+    m->opt_epoch[m->opt_calls++ & 63] = m->bott_epoch;
+    { PROF("adam"); uad_launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr_t, beta1, beta2, eps, grad_scale, st, m->bott_fault); }
     repack_on_side(m, st);
     HIP_TRY(hipGetLastError());
     return UAD_OK;
@@ -1233,7 +1206,8 @@ int uad_optimizer_step(uad_model_t* m, int kind, float lr, float momentum, float
     m->step += 1;
     invalidate_pack(m);
     hipStream_t st = (hipStream_t)stream;
-    { PROF("optim"); uad_launch_optim(kind, m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr, momentum, decay, eps, grad_scale, st); }
+    m->opt_epoch[m->opt_calls++ & 63] = m->bott_epoch;
+    { PROF("optim"); uad_launch_optim(kind, m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr, momentum, decay, eps, grad_scale, st, m->bott_fault); }
     repack_on_side(m, st);
     HIP_TRY(hipGetLastError());
     return UAD_OK;

@@ -163,16 +163,22 @@ class Engine(_EvalOps):
             pass
 
     # ---------------------------------------------------------------- buffers
-    def buffer(self, which=_lib.BUF_PARAMS):
-        """Zero-copy torch view (1-D fp32) of a handle-owned flat buffer."""
-        # Every access of the parameter buffer goes through the library: uad_buffer(PARAMS) waits for a weight repack still running on the
-        # handle's side stream and marks the packed copies stale, so a write through the (cached) view -- a second DP broadcast, a checkpoint
-        # restore -- can neither race with the repack nor leave the next forward on old packed kernels.
-        if which not in self._views or which == _lib.BUF_PARAMS:
+    def buffer(self, which=_lib.BUF_PARAMS, write=True):
+        """Zero-copy torch view (1-D fp32) of a handle-owned flat buffer.  write=False: the caller promises only to READ the parameter view."""
+        # A WRITE access of the parameter buffer goes through the library every time: uad_buffer(PARAMS) waits for a weight repack still
+        # running on the handle's side stream and marks the packed copies stale, so a write through the (cached) view -- a second DP broadcast,
+        # a checkpoint restore -- can neither race with the repack nor leave the next forward on old packed kernels.  Readers (write=False)
+        # take the cached view and cost nothing; the other buffers are never repacked.
+        if which not in self._views or (which == _lib.BUF_PARAMS and write):
             ptr = self.lib.uad_buffer(self.handle, which)
             if which not in self._views:
                 self._views[which] = torch.as_tensor(_DevArray(ptr, self.nparams), device=self.device)
         return self._views[which]
+
+    def check_fault(self, sync=True):
+        """Raises RuntimeError when a fused bottleneck launch reported a timed-out sibling exchange (include/uad_hip.h: uad_check_fault);
+        the optimizer updates behind such a launch were skipped on the device."""
+        _lib.check(self.lib.uad_check_fault(self.handle, 1 if sync else 0, self._stream()))
 
     def grad_segment(self, seg):
         off, cnt = C.c_longlong(), C.c_longlong()

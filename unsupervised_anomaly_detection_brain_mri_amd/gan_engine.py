@@ -2,7 +2,6 @@
 the reference (trainers/fAnoGAN.py:18-43) -- the three variable groups, their Adam slots and the compiled phases.  PyTorch is
 plumbing only (device buffers, the current HIP stream, zero-copy views for the RCCL all-reduce)."""
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -16,7 +15,7 @@ GROUPS = {'Encoder': _lib.GAN_ENCODER, 'Generator': _lib.GAN_GENERATOR, 'Discrim
 
 class GanEngine(_EvalOps):
     def __init__(self, height=128, width=128, channels=1, inter_res=8, zdim=128, max_batch=64, scale=10.0, kappa=1.0,
-                 device=None, math='bf16x3', variant='unified', dim=64, kl_weight=1.0, aae_kind='aae', rho=1.0, dim_w=1, c_lambda=1.0, graph=None):
+                 device=None, math='bf16x3', variant='unified', dim=64, kl_weight=1.0, aae_kind='aae', rho=1.0, dim_w=1, c_lambda=1.0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('uad_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback')
@@ -51,10 +50,7 @@ class GanEngine(_EvalOps):
         else:
             self.flat = [s for n, s, _ in self.spec if n == (dec_dense[aae_kind] if variant == 'aae' else 'Generator/dense/kernel')][0][1]
         self._views = {}
-        self.graph, self._pool, self._slot = False, {}, None
         self.set_math(math)
-        if graph if graph is not None else os.environ.get('UAD_GAN_GRAPH', '') not in ('', '0'):
-            self.set_graph_mode(True)
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -144,54 +140,17 @@ class GanEngine(_EvalOps):
         _lib.check(self.lib.uad_gan_debug_buffer(self.handle, name.encode(), C.byref(ptr), C.byref(cnt)))
         return torch.as_tensor(_DevArray(ptr.value, cnt.value), device=self.device)
 
-    # ---------------------------------------------------------------- hipGraph replay (uad_gan_set_graph_mode)
-    def set_graph_mode(self, on=True):
-        """Replay whole phases as hipGraphs (include/uad_hip.h).  A graph is keyed on the io POINTERS, so in this mode every input is
-        staged into, and every output returned from, handle-lifetime buffers (one per call site and shape): tensors returned by a phase
-        method stay valid only until the next call of that method."""
-        _lib.check(self.lib.uad_gan_set_graph_mode(self.handle, 1 if on else 0))
-        self.graph = bool(on)
-
-    def graph_stats(self):
-        cap, rep, en = C.c_longlong(), C.c_longlong(), C.c_int()
-        _lib.check(self.lib.uad_gan_graph_stats(self.handle, C.byref(cap), C.byref(rep), C.byref(en)))
-        return {'captures': int(cap.value), 'replays': int(rep.value), 'enabled': bool(en.value)}
-
-    def _begin(self, method):
-        self._slot = [method, 0]
-
-    def _pooled(self, shape):
-        key = (self._slot[0], self._slot[1], tuple(shape))
-        self._slot[1] += 1
-        buf = self._pool.get(key)
-        if buf is None:
-            buf = self._pool[key] = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
-        return buf
-
     def _new(self, shape, zero=False):
         shape = (shape,) if isinstance(shape, int) else tuple(shape)
-        if not self.graph or self._slot is None:
-            return (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=torch.float32)
-        buf = self._pooled(shape)
-        if zero:
-            buf.zero_()
-        return buf
+        return (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=torch.float32)
 
     def _dev(self, a, shape=None):
-        pooled = self.graph and self._slot is not None          # only inside a phase method (between _begin and its return)
         if a is None:
-            if pooled:
-                self._slot[1] += 1            # keep the call-site numbering independent of which optional inputs are given
             return None
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, np.float32))
         t = t.to(self.device, torch.float32).contiguous()
         if shape is not None and tuple(t.shape) != tuple(shape):
             raise ValueError(f'expected shape {tuple(shape)}, got {tuple(t.shape)}')
-        if pooled:
-            buf = self._pooled(t.shape)
-            if buf.data_ptr() != t.data_ptr():
-                buf.copy_(t)
-            return buf
         return t
 
     def _stream(self):
@@ -204,7 +163,6 @@ class GanEngine(_EvalOps):
         'Discriminator' (optim_dis; z = prior sample [n,zDim], eps [n] of z_hat = z + eps (z - z_)) | 'Encoder' (optim_gen: -mean d_).
         Returns device tensors: AE -> loss, L2, Rec_z, reconstructionLoss, reconstruction, z, L1; critic -> disc_loss, disc_fake,
         disc_real, penalty; generator -> gen_loss."""
-        self._begin('aae_phase')
         if self.variant != 'aae':
             raise ValueError('aae_phase needs an AAE-family engine')
         g = {'AE': _lib.GAN_GENERATOR, 'Discriminator': _lib.GAN_DISCRIMINATOR, 'Encoder': _lib.GAN_ENCODER}[which]
@@ -234,7 +192,6 @@ class GanEngine(_EvalOps):
         else:
             out['gen_loss'] = scal[S.index('gen_loss')]
         self._keep = (x, z, eps, mask_z, mask_dec, mask_rec, scal, out)
-        self._slot = None
         return out
 
     # ---------------------------------------------------------------- Zimmerer VAE (variant 'aae', aae_kind 'vae_zimmerer')
@@ -248,7 +205,6 @@ class GanEngine(_EvalOps):
         ce = self.aae_kind == 'cevae_zimmerer'
         if x_ce is not None and not ce:
             raise ValueError('x_ce is an input of the context-encoding VAE')
-        self._begin('zim_phase')
         n = x.shape[0]
         img = (n, self.h, self.w, self.c)
         x = self._dev(x, img)
@@ -276,7 +232,6 @@ class GanEngine(_EvalOps):
         if ce:
             out.update(Rec_vae=scal[S.index('loss_img')], Rec_ce=scal[S.index('loss_fts')], loss_vae=scal[S.index('gm_loss')])
         self._keep = (x, eps, x_ce, scal, out)
-        self._slot = None
         return out
 
     # ---------------------------------------------------------------- dense GMVAE (variant 'aae', aae_kind 'gmvae')
@@ -302,7 +257,6 @@ class GanEngine(_EvalOps):
     def gm_phase(self, x, eps_w=None, eps_z=None, masks=None, want_backward=True, want_l1=True):
         """One sess.run of trainers/GMVAE.py:122-139: forward + the four loss terms (+ the gradient of `loss` w.r.t. every variable).
         masks: dict with optional 'w_mu', 'w_ls' [n,dim_w], 'z_mu' [n,dim_z], 'dec' [n,flat] keep masks (already / (1 - rate))."""
-        self._begin('gm_phase')
         if self.aae_kind not in ('gmvae', 'gmvae_you'):
             raise ValueError('gm_phase needs a GMVAE engine (aae_kind gmvae | gmvae_you)')
         n = x.shape[0]
@@ -320,12 +274,10 @@ class GanEngine(_EvalOps):
         out.update(loss=scal[S.index('gm_loss')], mean_p_loss=scal[S.index('reconstructionLoss')], reconstructionLoss=scal[S.index('reconstructionLoss')],
                    conditional_prior_loss=scal[S.index('gm_con')], w_prior_loss=scal[S.index('gm_w')], c_prior_loss=scal[S.index('gm_c')])
         self._keep = (x, keep, scal, out)
-        self._slot = None
         return out
 
     def gm_restore_step(self, x_restored, eps_w=None, eps_z=None, masks=None, tv_lambda=1.8, restore_lr=1e-3, want_grads=False):
         """trainers/GMVAE.py:172-184 on device: x_restored (a DEVICE tensor, updated in place) -= restore_lr * d(n loss + sum tv TV_n)/dx."""
-        self._begin('gm_restore_step')
         if self.aae_kind not in ('gmvae', 'gmvae_you'):
             raise ValueError('gm_restore_step needs a GMVAE engine (aae_kind gmvae | gmvae_you)')
         if not isinstance(x_restored, torch.Tensor) or x_restored.device != self.device or x_restored.dtype != torch.float32 or not x_restored.is_contiguous():
@@ -338,14 +290,12 @@ class GanEngine(_EvalOps):
         _lib.check(self.lib.uad_gan_restore_step(self.handle, _ptr(x_restored), C.byref(io), n, float(tv_lambda), float(restore_lr),
                                                  _ptr(grads), self._stream()))
         self._keep = (keep, grads)
-        self._slot = None
         return grads
 
     def phase(self, group, x=None, z=None, alpha=None, mask_z=None, mask_g=None, want_backward=True, want_images=True,
               want_l1=False, eps=None, mask_sigma=None):
         """Run one phase ('Generator' | 'Discriminator' | 'Encoder').  Returns a dict of device tensors: the 0-d losses of the
         phase (trainers/fAnoGAN.py:50-66 names) and, per phase, 'generated' | 'reconstruction', 'z_enc', 'L1'."""
-        self._begin('phase')
         g = GROUPS[group]
         n = (x if x is not None else z).shape[0]
         img = (n, self.h, self.w, self.c)
@@ -392,7 +342,6 @@ class GanEngine(_EvalOps):
         if g == _lib.GAN_ENCODER:
             out['loss'] = out['reconstructionLoss']
         self._keep = (x, z, alpha, mask_z, mask_g, scal, out, eps, mask_sigma)
-        self._slot = None
         return out
 
     def adam(self, group, lr, beta1=0.5, beta2=0.9, eps=1e-8, grad_scale=1.0):
@@ -401,7 +350,6 @@ class GanEngine(_EvalOps):
         _lib.check(self.lib.uad_gan_adam(self.handle, gid, lr, beta1, beta2, eps, grad_scale, self._stream()))
 
     def reconstruct(self, x, mask_z=None, mask_g=None, want_l1=False, eps=None, mask_sigma=None):
-        self._begin('reconstruct')
         n = x.shape[0]
         img = (n, self.h, self.w, self.c)
         x = self._dev(x, img)
@@ -418,7 +366,6 @@ class GanEngine(_EvalOps):
             io.l1_map = _ptr(out['L1'])
         _lib.check(self.lib.uad_gan_reconstruct(self.handle, C.byref(io), n, self._stream()))
         self._keep = (x, mask_z, mask_g, out, eps, mask_sigma)
-        self._slot = None
         return out
 
 

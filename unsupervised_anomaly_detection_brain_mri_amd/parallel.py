@@ -61,25 +61,31 @@ class DataParallelStep:
     """train_step() for rank-local shards; equal per-rank batch sizes are assumed (weak scaling).
     buckets (default: env UAD_DP_BUCKETS, else 4): how the four gradient segments are merged into all-reduce calls (bucket_plan).
     no_allreduce (default: env UAD_DP_NO_ALLREDUCE): skip the collectives -- the step then trains on the local gradient; bench.py uses the
-    difference of the two step times as the communication the backward did not hide."""
+    difference of the two step times as the communication the backward did not hide.
+    force_collectives (default: env UAD_DP_FORCE_COLLECTIVES): take the segmented backward + per-bucket all-reduce path even at world 1 (an
+    all-reduce over one rank is the identity, so the step must end on the bits of the plain one): lets a ONE-GPU box run RCCL on the
+    engine-owned gradient view (tests/test_gpu_dp_nccl.py) before the 8-GPU node does."""
 
-    def __init__(self, engine, world=None, buckets=None, no_allreduce=None):
+    def __init__(self, engine, world=None, buckets=None, no_allreduce=None, force_collectives=None):
         self.eng = engine
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        self.grads = engine.buffer(_lib.BUF_GRADS) if self.world > 1 else None
+        self.force = bool(int(os.environ.get('UAD_DP_FORCE_COLLECTIVES', '0'))) if force_collectives is None else bool(force_collectives)
+        if self.force and not dist.is_initialized():
+            raise RuntimeError('force_collectives needs an initialised process group')
+        self.grads = engine.buffer(_lib.BUF_GRADS) if (self.world > 1 or self.force) else None
         self.segs = {s: engine.grad_segment(s) for s in SEGMENT_ORDER}
         self.buckets = int(buckets if buckets is not None else os.environ.get('UAD_DP_BUCKETS', '4'))
         self.plan = bucket_plan(self.segs, self.buckets)
         self.no_allreduce = bool(int(os.environ.get('UAD_DP_NO_ALLREDUCE', '0'))) if no_allreduce is None else bool(no_allreduce)
 
     def broadcast_params(self, src=0):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.broadcast(self.eng.buffer(_lib.BUF_PARAMS), src=src)
 
     def train_step(self, x, eps=None, masks=None, lr=1e-4, beta1=0.5, beta2=0.999, adam_eps=1e-8, **kw):
         eng = self.eng
         out = eng.forward(x, eps, masks, want_backward=True, **kw)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             eng.backward(_lib.SEG_ALL)
             eng.adam_step(lr, beta1, beta2, adam_eps, 1.0)
             return out
@@ -97,7 +103,7 @@ class DataParallelStep:
         return out
 
     def allreduce_scalars(self, scalars):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(scalars, op=dist.ReduceOp.SUM)
             scalars /= self.world
         return scalars

@@ -240,7 +240,20 @@ class AEMODEL(DLMODEL):
                 run = self._scalars_to_run(out['scalars'].cpu().numpy())
                 run['reconstruction'], run['L1'] = out['x_hat'].cpu().numpy(), out['L1'].cpu().numpy()
                 visuals.append(get_summary_dict(b, run)[1])
-        rows = self.dp.allreduce_scalars(table).cpu().numpy()[:num_batches]          # the epoch's one host synchronisation
+        # Fault word of the fused bottleneck (uad_check_fault): read after a stream sync and agreed on across ranks IN the epoch's one collective
+        # (an extra table row), so that a rank whose kernels timed out does not raise alone while the others block in the next all-reduce.
+        fault = None
+        if hasattr(self.engine, 'check_fault'):
+            try:
+                self.engine.check_fault(sync=True)
+            except RuntimeError as e:
+                fault = e
+        table = torch.cat([table, torch.full((1, 8), 1.0 if fault else 0.0, device=table.device)])
+        allrows = self.dp.allreduce_scalars(table).cpu().numpy()                      # the epoch's one host synchronisation
+        if fault is not None or allrows[-1, 0] > 0:
+            raise fault if fault is not None else RuntimeError('another rank reported a fused-bottleneck fault in this epoch (its optimizer updates were '
+                                                               'skipped on the device): replicas have diverged, restart from the last checkpoint')
+        rows = allrows[:num_batches]
         scalars = defaultdict(list)
         quiet = bool(getattr(self.config, 'quiet', False))
         for idx, sc in enumerate(rows):
@@ -281,6 +294,9 @@ class AEMODEL(DLMODEL):
     def train(self, dataset):       # trainers/VAE.py:31-74
         self.create_optimizer(type=getattr(self.config, 'optimizer', 'ADAM'))
         best_cost, last_improvement = inf, 0
+        # both splits must hold one global batch (batchsize x ranks): _num_batches raises the clear error NOW, not after the first TRAIN epoch
+        self._num_batches(dataset, Phase.TRAIN)
+        self._num_batches(dataset, Phase.VAL)
         last_epoch = self.load_checkpoint()
         for epoch in range(last_epoch, self.config.numEpochs):
             self.process(dataset, epoch, Phase.TRAIN, optim=True)
@@ -288,10 +304,6 @@ class AEMODEL(DLMODEL):
             if self.rank == 0:                      # replicas are identical: one writer
                 self.save(self.checkpointDir, last_epoch)
             val_scalars = self.process(dataset, epoch, Phase.VAL)
-            if 'loss' not in val_scalars:
-                # no full validation batch (num_batches floors, dataloaders/BRAINWEB.py:406-409: e.g. fewer VAL slices than batchsize * world):
-                # nothing to stop early on -- the reference would raise KeyError here
-                continue
             best_cost, last_improvement, stop = indicate_early_stopping(val_scalars['loss'], best_cost, last_improvement)
             if stop:
                 print('Early stopping was triggered due to no improvement over the last 5 epochs')

@@ -6,7 +6,14 @@ array-level core `evaluate_arrays` / `evaluate_volume` (PNG / PDF / NIfTI export
 slices of a volume are reconstructed in ONE batched call (the reference runs one sess.run per slice, :246-250), the brain
 masks are eroded (uad_erode_cross), residual map + mask + hyper-intensity prior come from uad_residual, the 5x5x5 median is
 uad_median3d, and AUROC / AUPRC / the Dice threshold sweep read one device sort of all voxels (uad_scores_*).
-erode_brainmask / apply_3d_median_filter keep the reference's scipy calls for host-side use."""
+erode_brainmask / apply_3d_median_filter keep the reference's scipy calls for host-side use.
+
+Multi-GPU (SURVEY.md 8e "Inference / config 5"): when torch.distributed is initialised the per-patient loop is SHARDED BY PATIENT (patient k of
+the walk -> rank k mod world; the 5x5x5 median couples slices of one patient only, so a patient never straddles ranks), every rank
+reconstructs and post-processes its patients, and the finished residual volumes are exchanged (`_sharded_map`: one broadcast per patient
+from its owner -- RCCL over xGMI under backend nccl -- plus one all_gather_object of the small host-side records) so that EVERY rank holds the
+same, identically ordered patient list as a single process; the global AUROC / AUPRC / Dice are then computed from that list exactly as
+before (bit-identical to world 1: tests/test_eval_sharded_gloo.py).  Only rank 0 writes evalPC.npy / evalPC.txt."""
 import time
 
 import numpy as np
@@ -18,6 +25,41 @@ from ..trainers import Metrics
 
 def should(dictionary, key):
     return key in dictionary and dictionary[key]
+
+
+def _dp_rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _sharded_map(n_items, fn, device):
+    """Patient-sharded evaluation.  fn(k) -> (residual volume as a float32 tensor on `device`, picklable host record) or None for item k.
+    Item k is computed by rank k mod world; returns {k: (tensor, record)} over all items that produced something, identical on every rank
+    (tensors broadcast from their owner, records through one all_gather_object).  world == 1: a plain loop, no collective."""
+    rank, world = _dp_rank_world()
+    local = {}
+    for k in range(rank, n_items, world):
+        r = fn(k)
+        if r is not None:
+            local[k] = (r[0].to(torch.float32).contiguous(), r[1])
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    meta = [None] * world
+    dist.all_gather_object(meta, {k: (tuple(t.shape), rec) for k, (t, rec) in local.items()})
+    out = {}
+    for owner, m in enumerate(meta):
+        for k in m:
+            assert k % world == owner, 'patient shard bookkeeping broke'
+    for k in sorted(k for m in meta for k in m):
+        owner = k % world
+        shape, rec = meta[owner][k]
+        t = local[k][0] if owner == rank else torch.empty(shape, device=device, dtype=torch.float32)
+        dist.broadcast(t, src=owner)
+        out[k] = (t, rec)
+    return out
 
 
 def erode_brainmask(brainmask):
@@ -104,8 +146,9 @@ def compute_detection_rate(predicted_volume, groundtruth_volume):
 def determine_threshold_on_arrays(volumes, labels, brainmasks, model, options, eps=None):
     """utils/Evaluation.py:529-570: the Dice-optimal threshold of the residual maps of labelled VALIDATION patients
     (granularity-10 sweep), on the device path.  Returns (bestDiceScore, bestThreshold)."""
-    diffs = [evaluate_volume(model, v, b, options, eps, device_out=True)[0] for v, b in zip(volumes, brainmasks)]
-    return _best_dice_of(model, diffs, labels)
+    got = _sharded_map(len(volumes), lambda k: (evaluate_volume(model, volumes[k], brainmasks[k], options, eps, device_out=True)[0], None),
+                       model.engine.device)
+    return _best_dice_of(model, [got[k][0] for k in sorted(got)], labels)
 
 
 def _best_dice_of(model, diffs, labels):
@@ -163,14 +206,15 @@ def evaluate_arrays(volumes, labels, brainmasks, model, options, eps=None, prior
     (utils/Evaluation.py:416-470): diff_AUC, diff_AUPRC, bestDiceScore, bestThreshold, DiceScore, DiceScorePerPatient,
     PrecisionPerPatient, RecallPerPatient (after the small-component filter)."""
     _time = {'evaluation': time.time()}
-    diffs, variances = [], []
-    l1s = []
-    for k, (v, b) in enumerate(zip(volumes, brainmasks)):
-        d, l1 = evaluate_volume(model, v, b, options, eps, device_out=True, prior=None if priors is None else priors[k])
-        diffs.append(d)
-        l1s.append(l1)
-        if int(options.get('numMonteCarloSamples') or 0) > 1:
-            variances.append(model.last_epistemic_variance.cpu().numpy())
+    mc = int(options.get('numMonteCarloSamples') or 0) > 1
+
+    def one(k):
+        d, l1 = evaluate_volume(model, volumes[k], brainmasks[k], options, eps, device_out=True, prior=None if priors is None else priors[k])
+        return d, (l1, model.last_epistemic_variance.cpu().numpy() if mc else None)
+    got = _sharded_map(len(volumes), one, model.engine.device)
+    diffs = [got[k][0] for k in sorted(got)]
+    l1s = [got[k][1][0] for k in sorted(got)]
+    variances = [got[k][1][1] for k in sorted(got)] if mc else []
     ev = _score_diffs(model, diffs, labels, options, variances)
     l1all = np.concatenate(l1s) if l1s else np.zeros(0)
     # (trainers' l2err == l1err, sic: SURVEY.md A4)
@@ -265,27 +309,33 @@ def _evaluate(datasetObj, modelObj, sampleDir, options, split="TEST", eps=None):
     variances = []               # numMonteCarloSamples > 1: every patient's epistemic-variance volume (utils/Evaluation.py:238-266,404-408)
     mc = int(options.get('numMonteCarloSamples') or 0) > 1
     used = []
-    for p, patient in enumerate(patients):
+
+    def one(p):
+        patient = patients[p]
         files = patient['filtered_files']
         if type(files) is not list:
             files = [files]
-        done = False
-        for nii_filename in files:
-            if done:                                             # `if len(_eval_dict['diffs']) == 0` (:203): the first usable file of a patient
-                break
+        for nii_filename in files:                               # `if len(_eval_dict['diffs']) == 0` (:203): the first usable file of a patient
             got = collect_patient_volume(datasetObj, patient, nii_filename, options)
             if got is None:
                 continue
-            done = True
             x, seg, skull, prior_q, _ = got
             t0 = time.time()
             d, l1 = evaluate_volume(modelObj, x, skull, options, eps, device_out=True, prior=prior_q)
-            ev['reconstructionTimes'].append((time.time() - t0) / max(len(x), 1))
-            diffs_dev.append(d)
-            if mc:
-                variances.append(modelObj.last_epistemic_variance.cpu().numpy())
-            ev['x'].append(x); ev['labelmaps'].append(seg); ev['l1reconstructionErrors'] += list(l1)
-            used.append(patient)
+            rec = {'x': x, 'seg': seg, 'l1': list(l1), 'time': (time.time() - t0) / max(len(x), 1),
+                   'var': modelObj.last_epistemic_variance.cpu().numpy() if mc else None}
+            return d, rec
+        return None
+    # patients are sharded over the ranks of an initialised process group (module docstring); every rank ends up with the full, ordered list
+    got = _sharded_map(len(patients), one, modelObj.engine.device)
+    for p in sorted(got):
+        d, rec = got[p]
+        ev['reconstructionTimes'].append(rec['time'])
+        diffs_dev.append(d)
+        if mc:
+            variances.append(rec['var'])
+        ev['x'].append(rec['x']); ev['labelmaps'].append(rec['seg']); ev['l1reconstructionErrors'] += rec['l1']
+        used.append(patients[p])
     print("Done.")
     ev['_diffs_device'] = diffs_dev
     ev['_variances'] = variances
@@ -315,6 +365,7 @@ def evaluate(datasetPC, gan, options, epoch='last', description=None, eps=None):
     <description>]/ and -- unlike the reference, which returns None -- hands the scalar dictionary back."""
     import os
     t_all = time.time()
+    rank0 = _dp_rank_world()[0] == 0          # every rank scores the same gathered patient list; rank 0 alone writes the files
     eval_dir = _eval_dir(gan, options, epoch, description)
     sample_dir = os.path.join(eval_dir, 'samples_test_PC')
     eval_pc, patients_pc = _evaluate(datasetPC, gan, sample_dir, options, split="TEST", eps=eps)
@@ -325,7 +376,7 @@ def evaluate(datasetPC, gan, options, epoch='last', description=None, eps=None):
     for k in ('l1reconstructionErrorMean', 'l1reconstructionErrorVariance', 'l2reconstructionErrorMean', 'l2reconstructionErrorVariance',
               'reconstructionTimes'):
         ev[k] = eval_pc[k]
-    if should(options, 'exportROC') or should(options, 'exportPRC'):
+    if rank0 and (should(options, 'exportROC') or should(options, 'exportPRC')):
         flat_l = eval_pc['labelmaps'].astype(bool).flatten()
         if should(options, 'exportROC'):
             _, fpr, tpr, th = Metrics.compute_roc(eval_pc['diffs'].flatten(), flat_l)
@@ -335,9 +386,10 @@ def evaluate(datasetPC, gan, options, epoch='last', description=None, eps=None):
             np.save(os.path.join(eval_dir, 'prcPC.npy'), {"precisions": pr, "recalls": rc, "threshs": th}, allow_pickle=True)
     ev['time'] = {'evaluation': time.time() - t_all}
     out = {k: v for k, v in ev.items() if k not in ('epistemic_variance',)}
-    np.save(os.path.join(eval_dir, 'evalPC.npy'), out)
-    with open(os.path.join(eval_dir, 'evalPC.txt'), "w") as f:
-        f.write(str(out))
+    if rank0:
+        np.save(os.path.join(eval_dir, 'evalPC.npy'), out)
+        with open(os.path.join(eval_dir, 'evalPC.txt'), "w") as f:
+            f.write(str(out))
     ev['eval_dir'] = eval_dir
     return ev
 
