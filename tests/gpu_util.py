@@ -151,7 +151,11 @@ class _Flips(dict):
 # oracle must sit this close to the kink, else the disagreement is a bug, not a rounding tie.  f32: 64 ulp of the largest value; bf16x3: 2^-15
 # (three bf16 products per fp32 product, ~2^-17 each, accumulated over the contraction); bf16x3_all (opt-in, every contraction of a 20-layer
 # residual stack in bf16x3, documented drift 1e-4 .. 3e-4): 2^-12.
-FLIP_BOUND = {'f32': 64.0 * 2.0 ** -24, 'bf16x3': 2.0 ** -15, 'bf16x3_all': 2.0 ** -12}
+FLIP_BOUND = {'f32': 64.0 * 2.0 ** -24, 'bf16x3': 2.0 ** -15, 'bf16x3_all': 2.0 ** -12,
+              # ResNet f-AnoGAN graph in bf16x3 mode (round 4: its k3 contractions run in bf16x3 too, 8-20 of them in a chain with a LayerNorm between
+              # each pair): a pre-activation may differ from the oracle's by up to the parity tolerance itself (1e-4 of the tensor's max, north_star), so
+              # an element within that of the kink may land on either side; anything further out is still reported as a bug
+              'bf16x3_rn': 1.0e-4}
 
 
 def kink_overrides(pairs, math='bf16x3', bound=None, tag=''):

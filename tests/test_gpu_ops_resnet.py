@@ -1,7 +1,10 @@
-"""GPU parity of the generic F / D / W contractions at the geometries of the ResNet f-AnoGAN graph (models/fanogan_schlegl.py):
+"""GPU parity of the F / D / W contractions at the geometries of the ResNet f-AnoGAN graph (models/fanogan_schlegl.py):
 k3 s1 and k3 s2 SAME convolutions, k3 s1 / k3 s2 / k1 s2 transposed convolutions, their data and filter gradients, and the
-Cin = 1 k3 first layer -- through the C-ABI op entry points vs the fp64 numpy oracle (1e-4 max-norm relative)."""
+Cin = 1 k3 first layer -- through the C-ABI op entry points vs the fp64 numpy oracle (1e-4 max-norm relative), in BOTH math modes of the op
+entry points: 'f32' = the generic exact-fp32 kernels, 'bf16x3' (UAD_MATH=bf16x3, read per call) = the round-4 tap-list spatial kernel
+(csrc/uad_convk16.inc) wherever its shape conditions hold, the generic bf16x3 kernels elsewhere."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -22,9 +25,23 @@ def lib():
     return _lib.load()
 
 
+@pytest.fixture(params=['f32', 'bf16x3'], autouse=True)
+def math_mode(request):
+    old = os.environ.get('UAD_MATH')
+    if request.param == 'bf16x3':
+        os.environ['UAD_MATH'] = 'bf16x3'
+    else:
+        os.environ.pop('UAD_MATH', None)
+    yield request.param
+    if old is None:
+        os.environ.pop('UAD_MATH', None)
+    else:
+        os.environ['UAD_MATH'] = old
+
+
 # Conv2D (big = input): (N, H, Cin, Cout, k, s)
 CONV = [(2, 16, 64, 128, 3, 1), (3, 8, 128, 128, 3, 2), (2, 16, 32, 64, 3, 2), (1, 32, 64, 64, 3, 1), (2, 8, 256, 256, 3, 1),
-        (2, 16, 64, 128, 1, 1)]
+        (2, 16, 64, 128, 1, 1), (2, 16, 128, 256, 3, 2), (1, 64, 64, 128, 3, 1), (2, 8, 512, 512, 3, 1)]
 
 
 @pytest.mark.parametrize('N,H,Cin,Cout,k,s', CONV)
@@ -51,7 +68,8 @@ def test_conv2d_generic_fwd_dgrad_wgrad(N, H, Cin, Cout, k, s):
 
 
 # Conv2DTranspose (big = output): (N, H, Cin, Cout, k, s)
-CONVT = [(2, 8, 128, 128, 3, 1), (2, 8, 128, 64, 3, 2), (3, 16, 64, 32, 3, 2), (2, 8, 128, 64, 1, 2), (1, 16, 64, 32, 1, 2)]
+CONVT = [(2, 8, 128, 128, 3, 1), (2, 8, 128, 64, 3, 2), (3, 16, 64, 32, 3, 2), (2, 8, 128, 64, 1, 2), (1, 16, 64, 32, 1, 2), (2, 8, 512, 256, 3, 2),
+         (1, 32, 128, 64, 3, 2), (2, 8, 512, 512, 3, 1)]
 
 
 @pytest.mark.parametrize('N,H,Cin,Cout,k,s', CONVT)

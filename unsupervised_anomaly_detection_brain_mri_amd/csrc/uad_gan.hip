@@ -124,6 +124,7 @@ struct uad_gan {
     UadConvDesc y_fd;                  // p_x_z/y_mu (k3, 64 -> 1) as the image-side relation, taps reversed
     float *y_ones, *y_zeros, *y_loc, *y_colpart, *y_dheads, *y_da7, *y_dM, *y_dLq, *y_ws, *y_mid, *y_partial, *y_dzdec, *y_h;
     bool generic16;                    // UAD_MATH_BF16X3_ALL: generic contractions in bf16x3 too (opt-in, not parity-rated)
+    int exact_from;                    // ResNet graph, bf16x3 mode: samples from this index on take the exact-fp32 kernels in g_conv_f / g_conv_d (-1: none)
     struct RB {                        // pre-activation residual block: LN -> ReLU -> conv1 (k3 s1) -> LN -> ReLU -> conv2, + shortcut
         bool gen;                      // generator block: conv2 / shortcut are transposed convolutions
         int stride, Hin, Hout, Cin, Cout;
@@ -239,6 +240,19 @@ int refresh_packs(uad_gan* m, hipStream_t st) {
             uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
         else
             uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
+    }
+    if (m->variant == 1 && m->math == UAD_MATH_BF16X3) {
+        // ResNet graph: bf16 hi | lo planes of the residual blocks' k3 kernels for the tap-list spatial kernel (uad_convk16.inc), 16 tensors per launch
+        np = 0;
+        auto flush = [&]() { if (np > 0) uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st); np = 0; };
+        auto addk = [&](long long w, const UadConvDesc& d) {
+            if (d.KS != 3 || d.CB % 8 || d.CS % 8) return;
+            offs[np] = w; cbs[np] = d.CB; css[np] = d.CS; taps[np] = 9;
+            if (++np == 16) flush();
+        };
+        for (auto& B : m->GB) { addk(B.w1, B.d1); addk(B.w2, B.d2); }
+        for (auto& B : m->DB) { addk(B.w1, B.d1); addk(B.w2, B.d2); }
+        flush();
     }
     m->packed_valid = true;
     return UAD_OK;
@@ -787,19 +801,47 @@ int aae_phase(uad_gan* m, int phase, const uad_gan_io_t* io, int n, int want_bac
 // ================================================================================================ ResNet variant
 // models/fanogan_schlegl.py:119-161.  Every k3 / k1 contraction runs on the generic F / D / W kernels (any KS / S / P).
 typedef uad_gan::RB RB;
+// Math of the k3 / k1 contractions (round 4).  UAD_MATH_BF16X3: the k3 data-path contractions run on the tap-list bf16x3 spatial kernel
+// (uad_convk16.inc) -- EXCEPT for the samples from m->exact_from on (pass A's x_hat third and all of pass B of a critic phase, set by the
+// phase code): the penalty (||d D(x_hat) / d x_hat|| - 1)^2 is an ill-conditioned function of that gradient (a 1e-5 relative error of the norm
+// is a 1e-4 error of the penalty when the norm is within 0.1 of 1), so the two passes that determine its VALUE stay on the exact-fp32 kernels;
+// its gradient is linear in (norm - 1) and takes the bf16x3 passes C / D.  UAD_MATH_BF16X3_ALL: everything in bf16x3 (not parity-rated).
+static bool k3_packs(const uad_gan* m, const UadConvDesc& d) { return m->variant == 1 && m->math == UAD_MATH_BF16X3 && d.KS == 3 && d.CB % 8 == 0 && d.CS % 8 == 0; }
 void g_conv_f(uad_gan* m, UadConvDesc d, int N, const float* big_in, long long w, const float* bias, const float* add, float* small_out, hipStream_t st) {
-    d.N = N;
-    uad_launch_conv_f(d, big_in, no_xform(), P(m, w), small_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, nullptr, 0,
-                      m->generic16);
+    const bool pk = k3_packs(m, d);
+    const long long plane = 9LL * d.CB * d.CS;
+    const int nfast = (pk && !m->generic16 && m->exact_from >= 0) ? (m->exact_from < N ? m->exact_from : N) : N;      // samples [nfast, N) exact
+    if (nfast > 0) {
+        d.N = nfast;
+        uad_launch_conv_f(d, big_in, no_xform(), P(m, w), small_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, pk ? PK16F(m, w) : nullptr, plane,
+                          m->generic16);
+    }
+    if (nfast < N) {
+        const size_t ob = (size_t)nfast * d.HB * d.WB * d.CB, os = (size_t)nfast * d.HS * d.WS * d.CS;
+        d.N = N - nfast;
+        uad_launch_conv_f(d, big_in + ob, no_xform(), P(m, w), small_out + os, epi_bias(bias, nullptr, add ? add + os : nullptr), st, nullptr, m->ws, nullptr, 0, false);
+    }
 }
 void g_conv_d(uad_gan* m, UadConvDesc d, int N, const float* small_in, long long w, const float* bias, const float* add, float* big_out, hipStream_t st) {
-    d.N = N;
-    uad_launch_conv_d(d, small_in, no_xform(), P(m, w), big_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, nullptr, 0,
-                      m->generic16);
+    const bool pk = k3_packs(m, d);
+    const long long plane = 9LL * d.CB * d.CS;
+    const int nfast = (pk && !m->generic16 && m->exact_from >= 0) ? (m->exact_from < N ? m->exact_from : N) : N;
+    if (nfast > 0) {
+        d.N = nfast;
+        uad_launch_conv_d(d, small_in, no_xform(), P(m, w), big_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, pk ? PK16D(m, w) : nullptr, plane,
+                          m->generic16);
+    }
+    if (nfast < N) {
+        const size_t ob = (size_t)nfast * d.HB * d.WB * d.CB, os = (size_t)nfast * d.HS * d.WS * d.CS;
+        d.N = N - nfast;
+        uad_launch_conv_d(d, small_in + os, no_xform(), P(m, w), big_out + ob, epi_bias(bias, nullptr, add ? add + ob : nullptr), st, nullptr, m->ws, nullptr, 0, false);
+    }
 }
 void g_conv_w(uad_gan* m, UadConvDesc d, int N, const float* big, const float* small_, long long w, hipStream_t st) {
     d.N = N;
-    uad_launch_conv_w(d, big, no_xform(), small_, no_xform(), Gr(m, w), m->wpartial, st, false, nullptr, nullptr, m->generic16);
+    // bf16x3 mode: the k3 filter gradients run on convk_w16_kernel (leaves of the graph: their round-off does not propagate)
+    const bool fast = m->variant == 1 && m->math == UAD_MATH_BF16X3 && d.KS == 3;
+    uad_launch_conv_w(d, big, no_xform(), small_, no_xform(), Gr(m, w), m->wpartial, st, false, nullptr, nullptr, m->generic16 || fast);
 }
 void avgpool_fwd(const float* x, int N, int H, int C, float* y, hipStream_t st) {
     const size_t t4 = (size_t)N * (H / 2) * (H / 2) * C / 4;
@@ -1452,6 +1494,13 @@ static int gan_phase_body(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n
     };
     auto disc_fwd = [&](int N, bool head) { if (rn) s_disc_forward(m, N, head, st); else disc_forward(m, N, head, st); };
     auto disc_bwd = [&](int N, bool pg, int ntail, int inj_lo, float* dx) { if (rn) s_disc_backward(m, N, pg, ntail, inj_lo, dx, st); else disc_backward(m, N, pg, ntail, inj_lo, dx, st); };
+    // ResNet graph, bf16x3 mode: the generator and encoder phases (7 of the ~69 n sample-passes of a WGAN iteration + the encoder stage) keep
+    // their k3 DATA path on the exact-fp32 kernels (g_conv_f / _d).  Measured in round 4 (profiles/README.md): with the generator's 8 + 8
+    // contractions in bf16x3 the last gradients of those chains (the generator's first LayerNorm gamma, the encoder's first kernel) sit at
+    // 1.00-1.20e-4 of their tensor's max off the oracle -- at the parity bar, not inside it -- whether or not the critic between them is exact.
+    // The critic phases (5 x 12 n sample-passes: pass A's x / x_ thirds, C, D and every filter gradient) hold 1e-4 in bf16x3 and carry the speed-up.
+    struct ExactPhase { uad_gan* m; bool on; ExactPhase(uad_gan* m_, bool on_) : m(m_), on(on_) { if (on) m->exact_from = 0; } ~ExactPhase() { if (on) m->exact_from = -1; } };
+    ExactPhase exact_phase(m, rn && phase != UAD_GAN_DISCRIMINATOR);
 
     if (phase == UAD_GAN_GENERATOR) {
         // trainers/fAnoGAN.py:52,75: gen_loss = -mean(D(G(z))), gradient w.r.t. the Generator variables
@@ -1474,7 +1523,9 @@ static int gan_phase_body(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n
         if ((!av && !io->z) || !io->x || !io->alpha) return fail(UAD_ERR_INVALID, "critic phase needs io.x, io.z and io.alpha");
         gen_fwd(io->z);
         hipLaunchKernelGGL(interp_kernel, dim3(blocks256(img)), dim3(256), 0, st, m->xg, io->x, io->alpha, (int)HW, img, m->din);
+        m->exact_from = 2 * n;                     // the x_hat third of pass A and all of pass B fix the penalty's VALUE: exact fp32 (see g_conv_f)
         disc_fwd(3 * n, true);                                                                    // pass A
+        m->exact_from = 0;
         reduce_to<0>(m, 0, m->Dd, nullptr, (size_t)n * P2, 1.0f / (float)(n * P2), nullptr, st);
         reduce_to<0>(m, 1, m->Dd + (size_t)n * P2, nullptr, (size_t)n * P2, 1.0f / (float)(n * P2), nullptr, st);
         // pass B: ddx = d sum(d_hat) / d x_hat on samples [2n, 3n)
@@ -1505,6 +1556,7 @@ static int gan_phase_body(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n
                 }
             }
         }
+        m->exact_from = -1;
         const int cols = n * H;
         hipLaunchKernelGGL(pen_col_kernel, dim3(blocks256(cols)), dim3(256), 0, st, m->Gx, n, H, H, m->slopes, m->redpart);
         uad_launch_reduce_partials(m->redpart, (int)blocks256(cols), 1, m->cfg.scale / (float)cols, m->raw + 2, st);

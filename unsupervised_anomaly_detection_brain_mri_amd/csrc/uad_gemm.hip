@@ -17,6 +17,7 @@
 #include "uad_kernels.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -3394,6 +3395,8 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
 constexpr size_t conv5_w_bf16_t_lds_bytes(int ncsb) { return (size_t)2 * 32 * (19 * 2 * 12 + 4) * 2 + (size_t)ncsb * 2 * 32 * 72 * 2 + 192 * 4; }
 constexpr size_t conv5_w_bf16_lds_bytes(int ncsb) { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)ncsb * 2 * 32 * 72 * 2 + 192 * 4; }
 
+#include "uad_convk16.inc"
+
 struct W5Choice { bool ok; int splits, tiles_per_split, total_tiles; };
 inline W5Choice choose_w5(const UadConvDesc& d) {
     W5Choice c{false, 0, 0, 0};
@@ -3524,6 +3527,7 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
 }  // namespace
 
 bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
+    if (convk16_shape_ok(d, f_type)) return true;      // k3 tap-list kernel (bf16x3 planes only: the fp32 pack of such a tensor is simply not used)
     return f_type ? choose_spatial(d, d.CB, d.CS, true).ok : choose_spatial(d, d.CS, d.CB, false).ok;
 }
 int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats, int ncounters) { return plan_gemm(d, true, have_pack, ws_floats, ncounters).tiles; }
@@ -3668,6 +3672,7 @@ void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, un
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W, float* small_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
                        long long w16_plane, bool generic_bf16x3) {
+    if (convk16_takes(d, true, xf, ep, Wp16)) { run_convk16(d, true, big_in, small_out, ep, Wp16, w16_plane, st); return; }      // k3 s1 / s2, bf16x3
     ConvGemmArgs a;
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
@@ -3682,6 +3687,7 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W, float* big_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
                        long long w16_plane, bool generic_bf16x3) {
+    if (convk16_takes(d, false, xf, ep, Wp16)) { run_convk16(d, false, small_in, big_out, ep, Wp16, w16_plane, st); return; }
     ConvGemmArgs a;
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
@@ -3723,7 +3729,9 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
     const W5Choice w5 = choose_w5(d);
     if (w5.ok) return (size_t)w5.splits * d.KS * d.KS * d.CB * d.CS;
     const WChoice c = choose_w(d);
-    return (size_t)c.splits * d.KS * d.KS * d.CB * d.CS;
+    const WK3Choice k3 = choose_wk3(d);      // (which of the two runs depends on the math mode of the launch: size for both)
+    const int splits = (k3.ok && k3.splits > c.splits) ? k3.splits : c.splits;
+    return (size_t)splits * d.KS * d.KS * d.CB * d.CS;
 }
 
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
@@ -3810,6 +3818,18 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
             hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
         }
         if (w5.splits > 1 && !defer_reduce) uad_launch_reduce_partials(partial, w5.splits, a.Mtot * d.CS, 1.0f, dW, hop());
+        return;
+    }
+    const WK3Choice k3 = choose_wk3(d);
+    if (k3.ok && (math_bf16x3 || generic_bf16x3) && !defer_reduce && !xfb.scale && !xfs.scale && !xfb.fb_bits) {
+        // k3 s1 / s2 filter gradient in bf16x3 (uad_convk16.inc): channel-major LDS tiles, slabs + fixed-order reduction
+        ConvWArgs a;
+        a.big = big; a.small_ = small; a.partial = (k3.splits == 1) ? dW : partial;
+        a.xfb = xfb; a.xfs = xfs; a.d = d;
+        a.Mtot = 9 * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = 0; a.lws = a.lhs = -1; a.dbgbuf = nullptr;
+        if (d.S == 1) { if (k3.ncb == 2) launch_convk_w16<1, 2>(a, k3, st); else launch_convk_w16<1, 1>(a, k3, st); }
+        else launch_convk_w16<2, 1>(a, k3, st);
+        if (k3.splits > 1) uad_launch_reduce_partials(partial, k3.splits, a.Mtot * d.CS, 1.0f, dW, hop());
         return;
     }
     const WChoice c = choose_w(d);
