@@ -113,3 +113,46 @@ def test_first_layer_k3s1(N, H, Cout):
     dw = torch.empty((3, 3, 1, Cout), device='cuda')
     _lib.check(lib().uad_op_conv_first_wgrad(C.byref(d), ptr(xd), ptr(gd), ptr(dw), stream()))
     assert_close(dw.cpu().numpy(), dw_ref, name='first wgrad')
+
+
+@pytest.mark.parametrize('kind,N,H,Cin,Cout,s', [('conv', 2, 16, 128, 128, 1), ('conv', 2, 16, 128, 256, 2), ('convT', 2, 8, 256, 128, 2), ('conv', 1, 8, 512, 512, 1)])
+def test_bf16x6_products_are_fp32_grade(kind, N, H, Cin, Cout, s, math_mode):
+    """UAD_MATH=bf16x6: the k3 tap-list kernel with THREE bf16 planes per operand and six products (uad_convk16.inc) -- what the ResNet graph's
+    exact passes run on.  Its error against the fp64 oracle has to be of the exact-fp32 kernel's order (<= 3x + 1e-7 of the output's max) and
+    well below the bf16x3 kernel's (< 1/2) on the same inputs, forward (F or D kind) and data gradient (the other kind)."""
+    if math_mode != 'f32':
+        pytest.skip('runs its three modes itself')
+    rng = np.random.default_rng(N * 1000 + H + Cin)
+    k = 3
+    if kind == 'conv':
+        x = rng.standard_normal((N, H, H, Cin)); w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
+        oh, pt, _ = onn.same_pads(H, k, s)
+        g = rng.standard_normal((N, oh, oh, Cout))
+        ref_f = onn.conv2d_fwd(x, w, None, s); ref_d = onn.conv2d_bwd(x, w, g, s)[0]
+        d = desc(N, H, H, Cin, oh, oh, Cout, k, s, pt)
+        f_in, d_in = x, g
+    else:
+        x = rng.standard_normal((N, H, H, Cin)); w = rng.standard_normal((k, k, Cout, Cin)) / np.sqrt(k * k * Cin)
+        OH = H * s
+        _, pt, _ = onn.same_pads(OH, k, s)
+        g = rng.standard_normal((N, OH, OH, Cout))
+        ref_d = onn.conv2d_transpose_fwd(x, w, None, s); ref_f = onn.conv2d_transpose_bwd(x, w, g, s)[0]
+        d = desc(N, OH, OH, Cout, H, H, Cin, k, s, pt)
+        f_in, d_in = g, x
+    wd, fi, di = dev(w), dev(f_in), dev(d_in)
+    errs = {}
+    for mode in ('f32', 'bf16x3', 'bf16x6'):
+        if mode == 'f32':
+            os.environ.pop('UAD_MATH', None)
+        else:
+            os.environ['UAD_MATH'] = mode
+        of = torch.empty(ref_f.shape, device='cuda'); od = torch.empty(ref_d.shape, device='cuda')
+        _lib.check(lib().uad_op_conv_f(C.byref(d), ptr(fi), None, ptr(wd), None, None, None, ptr(of), stream()))
+        _lib.check(lib().uad_op_conv_d(C.byref(d), ptr(di), None, ptr(wd), None, None, None, ptr(od), stream()))
+        errs[mode] = (np.abs(of.cpu().numpy() - ref_f).max() / np.abs(ref_f).max(), np.abs(od.cpu().numpy() - ref_d).max() / np.abs(ref_d).max())
+    os.environ.pop('UAD_MATH', None)
+    print(f'\n[{kind} N={N} H={H} {Cin}->{Cout} s{s}] max-norm relative error  F kind: f32 {errs["f32"][0]:.2e} bf16x3 {errs["bf16x3"][0]:.2e} bf16x6 {errs["bf16x6"][0]:.2e}'
+          f' | D kind: f32 {errs["f32"][1]:.2e} bf16x3 {errs["bf16x3"][1]:.2e} bf16x6 {errs["bf16x6"][1]:.2e}')
+    for i in (0, 1):
+        assert errs['bf16x6'][i] <= 3 * errs['f32'][i] + 1e-7, errs
+        assert errs['bf16x6'][i] < 0.5 * errs['bf16x3'][i], errs

@@ -65,6 +65,7 @@ struct uad_gan {
     float *params, *grads, *adam_m, *adam_v;
     float *adam_m2, *adam_v2;          // AnoVAE-GAN: the Generator's slots inside optim_vae (its optim_gen slots are adam_m / adam_v)
     float *wpack_f, *wpack_d, *wpack16_f, *wpack16_d;
+    float *wpack3_f, *wpack3_d;        // ResNet graph: THREE bf16 planes of the k3 kernels (bf16x6 products of the exact passes), 4 * nparams ushorts each; null: fp32 kernels
     int math;
     bool packed_valid;
     UadGemmWs ws;
@@ -244,7 +245,13 @@ int refresh_packs(uad_gan* m, hipStream_t st) {
     if (m->variant == 1 && m->math == UAD_MATH_BF16X3) {
         // ResNet graph: bf16 hi | lo planes of the residual blocks' k3 kernels for the tap-list spatial kernel (uad_convk16.inc), 16 tensors per launch
         np = 0;
-        auto flush = [&]() { if (np > 0) uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st); np = 0; };
+        auto flush = [&]() {
+            if (np > 0) {
+                uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
+                if (m->wpack3_f) uad_launch_pack_weights_bf16_3p(m->params, (unsigned short*)m->wpack3_f, (unsigned short*)m->wpack3_d, offs, cbs, css, taps, np, st);
+            }
+            np = 0;
+        };
         auto addk = [&](long long w, const UadConvDesc& d) {
             if (d.KS != 3 || d.CB % 8 || d.CS % 8) return;
             offs[np] = w; cbs[np] = d.CB; css[np] = d.CS; taps[np] = 9;
@@ -817,9 +824,12 @@ void g_conv_f(uad_gan* m, UadConvDesc d, int N, const float* big_in, long long w
                           m->generic16);
     }
     if (nfast < N) {
+        // the exact range: bf16x6 on the same spatial kernel (three planes, six products: fp32-grade) where it takes the shape, else the fp32 MFMA kernels
         const size_t ob = (size_t)nfast * d.HB * d.WB * d.CB, os = (size_t)nfast * d.HS * d.WS * d.CS;
         d.N = N - nfast;
-        uad_launch_conv_f(d, big_in + ob, no_xform(), P(m, w), small_out + os, epi_bias(bias, nullptr, add ? add + os : nullptr), st, nullptr, m->ws, nullptr, 0, false);
+        const bool x6 = m->wpack3_f && uad_conv_k3_takes(d, true);
+        uad_launch_conv_f(d, big_in + ob, no_xform(), P(m, w), small_out + os, epi_bias(bias, nullptr, add ? add + os : nullptr), st, nullptr, m->ws,
+                          x6 ? (const unsigned short*)m->wpack3_f + 4 * w : nullptr, x6 ? plane : 0, false, x6 ? 3 : 2);
     }
 }
 void g_conv_d(uad_gan* m, UadConvDesc d, int N, const float* small_in, long long w, const float* bias, const float* add, float* big_out, hipStream_t st) {
@@ -834,7 +844,9 @@ void g_conv_d(uad_gan* m, UadConvDesc d, int N, const float* small_in, long long
     if (nfast < N) {
         const size_t ob = (size_t)nfast * d.HB * d.WB * d.CB, os = (size_t)nfast * d.HS * d.WS * d.CS;
         d.N = N - nfast;
-        uad_launch_conv_d(d, small_in + os, no_xform(), P(m, w), big_out + ob, epi_bias(bias, nullptr, add ? add + ob : nullptr), st, nullptr, m->ws, nullptr, 0, false);
+        const bool x6 = m->wpack3_d && uad_conv_k3_takes(d, false);
+        uad_launch_conv_d(d, small_in + os, no_xform(), P(m, w), big_out + ob, epi_bias(bias, nullptr, add ? add + ob : nullptr), st, nullptr, m->ws,
+                          x6 ? (const unsigned short*)m->wpack3_d + 4 * w : nullptr, x6 ? plane : 0, false, x6 ? 3 : 2);
     }
 }
 void g_conv_w(uad_gan* m, UadConvDesc d, int N, const float* big, const float* small_, long long w, hipStream_t st) {

@@ -16,6 +16,7 @@
 #include <type_traits>
 #include "uad_kernels.h"
 #include <hip/hip_ext.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -2377,6 +2378,29 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, unsigned s
     Wd[base + di] = (unsigned short)hi; Wd[base + cnt + di] = (unsigned short)lo;
 }
 
+// Three planes (bf16x6, uad_convk16.inc): x = h + m + l; planes of a tensor at ushort index 4 * off + p * count in buffers of 4 * nparams ushorts
+// (4, not 3: a tensor's first plane then starts 8 * off bytes in -- dword-aligned for the fragment loads whatever the offset's parity).
+__global__ void pack_weights_bf16_3p_kernel(const float* __restrict__ W, unsigned short* __restrict__ Wf, unsigned short* __restrict__ Wd, PackDesc pd) {
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int t = 0;
+    while (t < pd.n && gid >= pd.count[t]) { gid -= pd.count[t]; ++t; }
+    if (t >= pd.n) return;
+    const int CB = pd.cb[t], CS = pd.cs[t];
+    const int cs = (int)(gid % CS);
+    const int r = (int)(gid / CS);
+    const int cb = r % CB, tap = r / CB;
+    const float v = W[pd.off[t] + gid];
+    const unsigned h = bf16_rne_bits(v);
+    const float r1 = v - __uint_as_float(h << 16);
+    const unsigned m = bf16_rne_bits(r1);
+    const unsigned l = bf16_rne_bits(r1 - __uint_as_float(m << 16));
+    const size_t base = 4 * (size_t)pd.off[t], cnt = (size_t)pd.count[t];
+    const size_t fi = ((size_t)(tap * (CB / 8) + cb / 8) * CS + cs) * 8 + (cb & 7);
+    const size_t di = ((size_t)(tap * (CS / 8) + cs / 8) * CB + cb) * 8 + (cs & 7);
+    Wf[base + fi] = (unsigned short)h; Wf[base + cnt + fi] = (unsigned short)m; Wf[base + 2 * cnt + fi] = (unsigned short)l;
+    Wd[base + di] = (unsigned short)h; Wd[base + cnt + di] = (unsigned short)m; Wd[base + 2 * cnt + di] = (unsigned short)l;
+}
+
 // eligibility + tile choice of the spatial kernels (shared by the launchers and the *_tiles() queries)
 // The same packing, one 16-byte group of a packed layout per thread (blockIdx.y: 0 = the F layout, 8 consecutive cb of one (tap, cs); 1 = the D
 // layout, 8 consecutive cs of one (tap, cb)): coalesced 16-byte stores instead of four scattered 2-byte stores per element (the repack runs on the
@@ -3526,6 +3550,7 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
 }
 }  // namespace
 
+bool uad_conv_k3_takes(const UadConvDesc& d, bool f_type) { return convk16_shape_ok(d, f_type); }
 bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
     if (convk16_shape_ok(d, f_type)) return true;      // k3 tap-list kernel (bf16x3 planes only: the fp32 pack of such a tensor is simply not used)
     return f_type ? choose_spatial(d, d.CB, d.CS, true).ok : choose_spatial(d, d.CS, d.CB, false).ok;
@@ -3555,6 +3580,15 @@ void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d
         total += pd.count[i];
     }
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, wpack_f, wpack_d, pd);
+}
+
+void uad_launch_pack_weights_bf16_3p(const float* params, unsigned short* w3_f, unsigned short* w3_d, const long long* offs,
+                                     const int* cbs, const int* css, const int* taps, int n, hipStream_t st) {
+    PackDesc pd;
+    pd.n = n;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) { pd.off[i] = offs[i]; pd.cb[i] = cbs[i]; pd.cs[i] = css[i]; pd.count[i] = taps[i] * cbs[i] * css[i]; total += pd.count[i]; }
+    hipLaunchKernelGGL(pack_weights_bf16_3p_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w3_f, w3_d, pd);
 }
 
 namespace {
@@ -3671,8 +3705,9 @@ void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, un
 
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W, float* small_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
-                       long long w16_plane, bool generic_bf16x3) {
-    if (convk16_takes(d, true, xf, ep, Wp16)) { run_convk16(d, true, big_in, small_out, ep, Wp16, w16_plane, st); return; }      // k3 s1 / s2, bf16x3
+                       long long w16_plane, bool generic_bf16x3, int planes16) {
+    if (convk16_takes(d, true, xf, ep, Wp16)) { run_convk16(d, true, big_in, small_out, ep, Wp16, w16_plane, planes16, st); return; }      // k3 s1 / s2, bf16x3 / bf16x6
+    if (planes16 == 3) { fprintf(stderr, "uad: three-plane weights are understood by the k3 tap-list kernel only (check uad_conv_k3_takes first)\n"); abort(); }
     ConvGemmArgs a;
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
@@ -3686,8 +3721,9 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
 
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W, float* big_out,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
-                       long long w16_plane, bool generic_bf16x3) {
-    if (convk16_takes(d, false, xf, ep, Wp16)) { run_convk16(d, false, small_in, big_out, ep, Wp16, w16_plane, st); return; }
+                       long long w16_plane, bool generic_bf16x3, int planes16) {
+    if (convk16_takes(d, false, xf, ep, Wp16)) { run_convk16(d, false, small_in, big_out, ep, Wp16, w16_plane, planes16, st); return; }
+    if (planes16 == 3) { fprintf(stderr, "uad: three-plane weights are understood by the k3 tap-list kernel only (check uad_conv_k3_takes first)\n"); abort(); }
     ConvGemmArgs a;
     a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;

@@ -80,17 +80,23 @@ struct UadEpilogue {
 void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, const float* W,
                        float* small_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr,
                        UadGemmWs ws = UadGemmWs{nullptr, 0}, const unsigned short* Wp16 = nullptr, long long w16_plane = 0,
-                       bool generic_bf16x3 = false);
+                       bool generic_bf16x3 = false, int planes16 = 2);
 // D-type: big_out[n,S*i-P+ky,S*j-P+kx,cb] += xf(small_in)[n,i,j,cs] * W[tap][cb][cs]
 void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf, const float* W,
                        float* big_out, UadEpilogue ep, hipStream_t st, const float* Wpacked = nullptr,
                        UadGemmWs ws = UadGemmWs{nullptr, 0}, const unsigned short* Wp16 = nullptr, long long w16_plane = 0,
-                       bool generic_bf16x3 = false);
+                       bool generic_bf16x3 = false, int planes16 = 2);
 // generic_bf16x3: when no specialised kernel applies, let the generic kernel use bf16x3 products (identity xf, BK = 32 tiles)
 // bf16x3 math mode: Wp16 = this tensor's hi plane inside the bf16 pack buffer (ushort index 2*offset), w16_plane = its
 // element count (the lo plane follows the hi plane)
 void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, unsigned short* w16_d, const long long* offs,
                                   const int* cbs, const int* css, const int* taps, int n, hipStream_t st);
+// planes16 = 3 ("bf16x6", k3 tap-list kernel only -- uad_conv_k3_takes): Wp16 = the tensor's first plane inside a THREE-plane pack buffer (ushort
+// index 4 * offset, planes w16_plane elements apart) written by this function; products are fp32-grade (six bf16 MFMAs per K = 16)
+void uad_launch_pack_weights_bf16_3p(const float* params, unsigned short* w3_f, unsigned short* w3_d, const long long* offs,
+                                     const int* cbs, const int* css, const int* taps, int n, hipStream_t st);
+// true when uad_launch_conv_f / _d would run the k3 tap-list kernel for this shape when bf16 planes are given (identity activation, bias / addend epilogue)
+bool uad_conv_k3_takes(const UadConvDesc& d, bool f_type);
 // re-layout of n (<= 8) weight tensors W[tap][cb][cs] living at params+offs[i] into the F-pack / D-pack buffers
 void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d, const long long* offs, const int* cbs,
                              const int* css, const int* taps, int n, hipStream_t st);

@@ -1373,21 +1373,26 @@ static int ws_for_op(const UadConvDesc& d, bool f_type, bool have_pack, UadGemmW
     }
     return UAD_OK;
 }
-static bool op_bf16x3() { const char* e = getenv("UAD_MATH"); return e && !strcmp(e, "bf16x3"); }
+// UAD_MATH of the op-level entry points: unset / "f32" = exact fp32, "bf16x3", or "bf16x6" = three-plane products on the k3 tap-list kernel where
+// it takes the shape (everything else as bf16x3)
+static bool op_bf16x6() { const char* e = getenv("UAD_MATH"); return e && !strcmp(e, "bf16x6"); }
+static bool op_bf16x3() { const char* e = getenv("UAD_MATH"); return e && (!strcmp(e, "bf16x3") || !strcmp(e, "bf16x6")); }
+static int op_planes(const UadConvDesc& d, bool f_type) { return (op_bf16x6() && uad_conv_k3_takes(d, f_type)) ? 3 : 2; }
 static int pack_for_op(const UadConvDesc& d, const float* W, bool f_type, float** pf, float** pd, hipStream_t st) {
     *pf = *pd = nullptr;
     if (!uad_conv_spatial_ok(d, f_type)) return UAD_OK;
     const size_t n = (size_t)d.KS * d.KS * d.CB * d.CS;
-    HIP_TRY(hipMalloc((void**)pf, n * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)pd, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)pf, 2 * n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)pd, 2 * n * sizeof(float)));
     long long off = 0; int cb = d.CB, cs = d.CS, taps = d.KS * d.KS;
-    if (op_bf16x3()) uad_launch_pack_weights_bf16(W, (unsigned short*)*pf, (unsigned short*)*pd, &off, &cb, &cs, &taps, 1, st);
+    if (op_planes(d, f_type) == 3) uad_launch_pack_weights_bf16_3p(W, (unsigned short*)*pf, (unsigned short*)*pd, &off, &cb, &cs, &taps, 1, st);
+    else if (op_bf16x3()) uad_launch_pack_weights_bf16(W, (unsigned short*)*pf, (unsigned short*)*pd, &off, &cb, &cs, &taps, 1, st);
     else uad_launch_pack_weights(W, *pf, *pd, &off, &cb, &cs, &taps, 1, st);
     return UAD_OK;
 }
 // launch arguments for the op-level entry points in the selected math mode
-#define OP_PACK_ARGS(pk, d) (op_bf16x3() ? nullptr : (pk)), ws, (op_bf16x3() ? (const unsigned short*)(pk) : nullptr), \
-                            (long long)(d).KS * (d).KS * (d).CB * (d).CS, op_bf16x3()
+#define OP_PACK_ARGS(pk, d, f) (op_bf16x3() ? nullptr : (pk)), ws, (op_bf16x3() ? (const unsigned short*)(pk) : nullptr), \
+                               (long long)(d).KS * (d).KS * (d).CB * (d).CS, op_bf16x3(), op_planes(to_desc(&(d)), f)
 static int finish_op(float* pf, float* pd, hipStream_t st, float* wsp = nullptr) {
     if (pf || pd || wsp) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(pf); (void)hipFree(pd); (void)hipFree(wsp); }
     HIP_TRY(hipGetLastError());
@@ -1401,7 +1406,7 @@ int uad_op_conv_f(const uad_conv_desc_t* d, const float* big_in, const uad_xform
     if (int rc = pack_for_op(to_desc(d), W, true, &pf, &pd, (hipStream_t)stream)) return rc;
     UadGemmWs ws;
     if (int rc = ws_for_op(to_desc(d), true, pf != nullptr, &ws)) return rc;
-    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pf, *d));
+    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pf, *d, true));
     return finish_op(pf, pd, (hipStream_t)stream, ws.ptr);
 }
 int uad_op_conv_d(const uad_conv_desc_t* d, const float* small_in, const uad_xform_t* xf, const float* W, const float* bias,
@@ -1411,7 +1416,7 @@ int uad_op_conv_d(const uad_conv_desc_t* d, const float* small_in, const uad_xfo
     if (int rc = pack_for_op(to_desc(d), W, false, &pf, &pd, (hipStream_t)stream)) return rc;
     UadGemmWs ws;
     if (int rc = ws_for_op(to_desc(d), false, pd != nullptr, &ws)) return rc;
-    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pd, *d));
+    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pd, *d, false));
     return finish_op(pf, pd, (hipStream_t)stream, ws.ptr);
 }
 
@@ -1436,8 +1441,9 @@ static int bwdact_common(bool f_type, const uad_conv_desc_t* dd, const float* in
     hipStream_t st = (hipStream_t)stream;
     float *pf = nullptr, *pd = nullptr;
     if (int rc = pack_for_op(d, W, f_type, &pf, &pd, st)) return rc;
-    if (f_type) uad_launch_conv_f(d, in, no_xform(), W, out, e, st, OP_PACK_ARGS(pf, d));
-    else uad_launch_conv_d(d, in, no_xform(), W, out, e, st, OP_PACK_ARGS(pd, d));
+    const long long plane = (long long)d.KS * d.KS * d.CB * d.CS;       // (the activation-backward epilogue never runs the three-plane kernel)
+    if (f_type) uad_launch_conv_f(d, in, no_xform(), W, out, e, st, op_bf16x3() ? nullptr : pf, ws, op_bf16x3() ? (const unsigned short*)pf : nullptr, plane, op_bf16x3());
+    else uad_launch_conv_d(d, in, no_xform(), W, out, e, st, op_bf16x3() ? nullptr : pd, ws, op_bf16x3() ? (const unsigned short*)pd : nullptr, plane, op_bf16x3());
     // rstd = 1, gamma unused for dbias=null: dbeta -> s1, dgamma -> s2
     uad_launch_bn_grad_finalize(colpart, T, C, act->scale, 1.0f, s2, s1, nullptr, st);
     HIP_TRY(hipStreamSynchronize(st));
