@@ -425,8 +425,9 @@ def bench_fanogan(args):
         res = {'metric': f'MRI slices/sec {name}, {hh}x{hh}, bs={bs}/GPU)',
                'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               # the ResNet graph's k3 / k1 contractions run on the generic kernels: fp32 MFMA unless --math bf16x3_all (not parity-rated)
-               'dtype': ('f32' if args.math != 'bf16x3_all' else 'bf16x3_all') if args.variant == 'resnet' else args.math,
+               # ResNet graph (round 4): bf16x3 = the k3 contractions on the bf16x3 spatial kernels, the penalty-value passes and the generator /
+               # encoder phases on their fp32-grade three-plane form (bf16x6) -- parity-rated at 1e-4; bf16x3_all = every contraction in bf16x3 (not rated)
+               'dtype': args.math,
                'data': 'synthetic',
                'config': {'workload': f'BASELINE.json configs[3]: f-AnoGAN {graph} {hh}x{hh}x1, zDim {zd}, '
                                       f'{bs} slices per GPU; step = ' + ('1 VAE + 1 generator + 5 critic phases with Adam (trainers/AnoVAEGAN.py:97-150)' if av else '1 generator + 5 critic phases with Adam (trainers/fAnoGAN.py:97-130)'),
@@ -439,12 +440,62 @@ def bench_fanogan(args):
         if av:       # the encoder runs in front of every generator pass; plus the VAE step (E and G forward + backward)
             macs += 7 * e_m + 3 * (e_m + g_m)
         tfl = 2.0 * macs * value / 1e12
-        peak = 157.3 if (args.variant == 'resnet' and args.math != 'bf16x3_all') else 2500.0 / 3.0
-        res['roofline'] = {'bound': 'mfma', 'kernel': 'whole WGAN-GP iteration (this handle has no per-kernel event profiler; per-kernel '
-                           'durations: profiles/r01_h_* / r01_i_* rocprofv3 summaries)', 'achieved': round(tfl, 2), 'peak': round(peak, 1),
-                           'unit': 'TFLOP/s', 'frac': round(tfl / peak, 4), 'traffic': None,
-                           'note': 'algorithmic FLOP of the iteration / wall time; peak = fp32 MFMA (ResNet graph: generic fp32 kernels) or the '
-                                   'bf16 matrix peak / 3 products per fp32 product (bf16x3 kernels)'}
+        peak = 157.3 if args.math == 'f32' else 2500.0 / 3.0
+        whole = {'bound': 'mfma', 'kernel': 'whole WGAN-GP iteration', 'achieved': round(tfl, 2), 'peak': round(peak, 1),
+                 'unit': 'TFLOP/s', 'frac': round(tfl / peak, 4), 'traffic': None,
+                 'note': 'algorithmic FLOP of the iteration / wall time; peak = fp32 MFMA (f32 mode) or the bf16 matrix peak / 3 products per fp32 product'}
+        res['roofline'] = whole
+        if args.variant == 'resnet' and args.math != 'f32':
+            # dominant kernel of the iteration, measured live: HIP events around every k3 launch (uad_k3_profile_*) over two more iterations
+            import ctypes as C
+            from unsupervised_anomaly_detection_brain_mri_amd import _lib
+            lib = _lib.load()
+            lib.uad_k3_profile_enable(1)
+            wgan_step(); wgan_step()
+            need = lib.uad_k3_profile_read(None, 0)
+            buf = C.create_string_buffer(need + 16)
+            lib.uad_k3_profile_read(buf, need + 16)
+            lib.uad_k3_profile_enable(0)
+            rows = []
+            for ln in buf.value.decode().splitlines():
+                v = ln.split()
+                kind, p1, p2, ntaps, npl, N, MH, MW, CA, Nn, calls = map(int, v[:11])
+                rows.append(dict(kind=kind, p1=p1, p2=p2, ntaps=ntaps, planes=npl, N=N, MH=MH, MW=MW, CA=CA, Nn=Nn, calls=calls, total_ms=float(v[11])))
+            if rows:
+                # group by kernel INSTANCE (kind, stride, halo / cb blocks, taps, planes): the group with the largest summed time is the dominant kernel
+                groups = {}
+                for r in rows:
+                    groups.setdefault((r['kind'], r['p1'], r['p2'], r['ntaps'], r['planes']), []).append(r)
+                gkey, grp = max(groups.items(), key=lambda kv: sum(r['total_ms'] for r in kv[1]))
+                top = max(grp, key=lambda r: r['total_ms'])                       # its most expensive launch shape
+                flop = 2.0 * top['N'] * top['MH'] * top['MW'] * top['ntaps'] * top['CA'] * top['Nn']
+                avg_ms = top['total_ms'] / top['calls']
+                ach = flop / (avg_ms * 1e-3) / 1e12
+                pk = 2500.0 / (3.0 if top['planes'] == 2 else 6.0)
+                if top['kind'] == 0:
+                    name = f"convk16_kernel<8,8,32,2,2,{top['p1']},{top['p2']},{top['ntaps']},{top['planes']}> (tap-list k3 kernel, input stride {top['p1']})"
+                    ain = top['N'] * (top['p1'] * top['MH']) * (top['p1'] * top['MW']) * top['CA'] * 4
+                    aout = top['N'] * top['MH'] * top['MW'] * top['Nn'] * 4
+                else:
+                    name = f"convk_w16_kernel<{top['p1']},{top['p2']}> (k3 filter gradient, stride {top['p1']})"
+                    ain = top['N'] * top['MH'] * top['MW'] * (top['p1'] ** 2 * top['CA'] + top['Nn']) * 4
+                    aout = 9 * top['CA'] * top['Nn'] * 4
+                abytes = ain + aout + 9 * top['CA'] * top['Nn'] * 2 * top['planes'] * (1 if top['kind'] == 0 else 0)
+                res['roofline'] = {'bound': 'mfma', 'kernel': name,
+                                   'shape': {k: top[k] for k in ('N', 'MH', 'MW', 'CA', 'Nn', 'ntaps', 'planes')},
+                                   'achieved': round(ach, 2), 'peak': round(pk, 1), 'unit': 'TFLOP/s', 'frac': round(ach / pk, 4),
+                                   'mfma_fraction': round(ach / pk, 4), 'hbm_fraction': round(abytes / (avg_ms * 1e-3) / 8e12, 4),
+                                   'algorithmic_flop_per_launch': flop, 'algorithmic_bytes_per_launch': abytes, 'avg_launch_ms': round(avg_ms, 4),
+                                   'launches_timed': top['calls'], 'group_share_of_k3_time': round(sum(r['total_ms'] for r in grp) / sum(r['total_ms'] for r in rows), 3),
+                                   'instruction': f"{3 if top['planes'] == 2 else 6} x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = dense bf16 MFMA 2500 TFLOP/s / products",
+                                   'traffic': None,
+                                   'rocprof': 'profiles/r04_c_fanogan_resnet64_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command)',
+                                   'whole_iteration': whole}
+                res['k3_kernels'] = sorted(({'kind': 'FD' if r['kind'] == 0 else 'W', 'stride': r['p1'], 'ntaps': r['ntaps'], 'planes': r['planes'],
+                                             'N': r['N'], 'grid': [r['MH'], r['MW']], 'CA': r['CA'], 'Nn': r['Nn'], 'calls': r['calls'],
+                                             'avg_ms': round(r['total_ms'] / r['calls'], 4),
+                                             'tflops': round(2.0 * r['N'] * r['MH'] * r['MW'] * r['ntaps'] * r['CA'] * r['Nn'] / (r['total_ms'] / r['calls'] * 1e-3) / 1e12, 1)}
+                                            for r in rows), key=lambda r: -r['avg_ms'] * r['calls'])[:24]
         if not args.no_cpu_baseline and not av:
             res['cpu_baseline'] = gan_cpu_baseline(args.variant, hh, zd)
         print(json.dumps(res))

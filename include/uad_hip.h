@@ -348,6 +348,13 @@ int uad_gan_reconstruct(uad_gan_t* g, const uad_gan_io_t* io, int n, void* strea
  * io supplies the noise / dropout masks of this run.  No parameter gradient is produced. */
 int uad_gan_restore_step(uad_gan_t* g, float* x_restored, const uad_gan_io_t* io, int n, float tv_lambda, float restore_lr, float* grads_out,
                          void* stream);
+/* HIP-event profiler of the k3 spatial kernels of the ResNet graph (csrc/uad_convk16.inc; process-wide, bench.py's roofline leg for BASELINE
+ * configs[3]): while enabled every launch is bracketed by two events on its stream.  uad_k3_profile_read synchronises the device and writes one
+ * text line per launch shape -- "kind p1 p2 ntaps planes N MH MW CA Nn calls total_ms" (kind 0: tap-list F / D kernel, p1 = input stride, p2 =
+ * halo extent, MH x MW = iteration grid, CA -> Nn channels; kind 1: filter gradient, p1 = stride, MH x MW = small grid, CA = CB, Nn = CS) --
+ * and returns the bytes the whole table needs. */
+int uad_k3_profile_enable(int on);
+int uad_k3_profile_read(char* buf, int cap);
 /* tests: device pointer + element count of a named intermediate of the last phase (NULL name table entry -> error) */
 int uad_gan_debug_buffer(uad_gan_t* g, const char* name, float** ptr, long long* count);
 

@@ -1695,6 +1695,9 @@ int uad_gan_reconstruct(uad_gan_t* m, const uad_gan_io_t* io, int n, void* strea
     if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
     return gan_reconstruct_body(m, io, n, stream);
 }
+int uad_k3_profile_enable(int on) { uad_k3_prof_enable(on != 0); return UAD_OK; }
+int uad_k3_profile_read(char* buf, int cap) { return uad_k3_prof_read(buf, cap); }
+
 int uad_gan_adam(uad_gan_t* m, int group, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
     if (!m || group < 0 || group > 2) return fail(UAD_ERR_INVALID, "bad group");
     m->step[group] += 1;

@@ -19,6 +19,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <array>
+#include <string>
+#include <vector>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -3551,6 +3555,33 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
 }  // namespace
 
 bool uad_conv_k3_takes(const UadConvDesc& d, bool f_type) { return convk16_shape_ok(d, f_type); }
+void uad_k3_prof_enable(bool on) {
+    if (on && !g_k3prof) { for (auto& r : g_k3recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } g_k3recs.clear(); }
+    g_k3prof = on;
+}
+// one text line per launch shape: "kind p1 p2 ntaps npl N MH MW CA Nn calls total_ms"; returns the number of bytes the full table needs
+int uad_k3_prof_read(char* buf, int cap) {
+    (void)hipDeviceSynchronize();
+    std::map<std::array<int, 10>, std::pair<int, double>> agg;
+    for (auto& r : g_k3recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        std::array<int, 10> k;
+        for (int i = 0; i < 10; ++i) k[i] = r.key[i];
+        auto& e = agg[k];
+        e.first += 1; e.second += ms;
+    }
+    std::string out;
+    char line[256];
+    for (auto& kv : agg) {
+        int n = 0;
+        for (int i = 0; i < 10; ++i) n += snprintf(line + n, sizeof line - n, "%d ", kv.first[i]);
+        snprintf(line + n, sizeof line - n, "%d %.6f\n", kv.second.first, kv.second.second);
+        out += line;
+    }
+    if (buf && cap > 0) { const size_t c = out.size() < (size_t)cap - 1 ? out.size() : (size_t)cap - 1; memcpy(buf, out.data(), c); buf[c] = 0; }
+    return (int)out.size() + 1;
+}
 bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
     if (convk16_shape_ok(d, f_type)) return true;      // k3 tap-list kernel (bf16x3 planes only: the fp32 pack of such a tensor is simply not used)
     return f_type ? choose_spatial(d, d.CB, d.CS, true).ok : choose_spatial(d, d.CS, d.CB, false).ok;

@@ -97,6 +97,9 @@ void uad_launch_pack_weights_bf16_3p(const float* params, unsigned short* w3_f, 
                                      const int* cbs, const int* css, const int* taps, int n, hipStream_t st);
 // true when uad_launch_conv_f / _d would run the k3 tap-list kernel for this shape when bf16 planes are given (identity activation, bias / addend epilogue)
 bool uad_conv_k3_takes(const UadConvDesc& d, bool f_type);
+// HIP-event profiler of the k3 launches (uad_convk16.inc): per launch shape, calls and summed duration as text lines
+void uad_k3_prof_enable(bool on);
+int uad_k3_prof_read(char* buf, int cap);
 // re-layout of n (<= 8) weight tensors W[tap][cb][cs] living at params+offs[i] into the F-pack / D-pack buffers
 void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d, const long long* offs, const int* cbs,
                              const int* css, const int* taps, int n, hipStream_t st);
