@@ -3528,8 +3528,14 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
         const long wgs = (long)d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW) * (Nn / p.sc.BN);
         const int chunks = CA / p.sc.CK;
         int sp = 1;
-        while (wgs * sp < 512 && sp * 2 <= chunks && (size_t)(sp * 2) * p.out_elems <= ws_cap) sp *= 2;
-        if (wgs * sp >= 512 || wgs * sp >= 256) {
+        // Workgroups a spatial launch is split up to.  Round 4, same-box sweep (profiles/r04_d_split_target_sweep.log): the gather (F) kernels
+        // want two workgroups per CU (enc3.fwd 22 us at 512 / 23 at 256 / 30 unsplit); the class-sequential scatter (D) kernels stage their whole
+        // channel range once and pay the slab exchange four times (once per parity class): they are faster with HALF the splits (dec0.fwd 30 -> 25,
+        // dec1.fwd 37 -> 31, enc3.dgrad 35 -> 31, enc2.dgrad 38 -> 32 us).  UAD_SPLIT_TARGET=n overrides both (tuning knob).
+        static const int split_env = getenv("UAD_SPLIT_TARGET") ? atoi(getenv("UAD_SPLIT_TARGET")) : 0;
+        const int split_target = split_env > 0 ? split_env : (f_type ? 512 : 256);
+        while (wgs * sp < split_target && sp * 2 <= chunks && (size_t)(sp * 2) * p.out_elems <= ws_cap) sp *= 2;
+        if (wgs * sp >= (split_target < 256 ? split_target : 256)) {
             p.path = PATH_SPATIAL;
             p.nsplit = sp;
             p.ws_floats = sp > 1 ? (size_t)sp * p.out_elems : 0;
