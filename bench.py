@@ -642,7 +642,7 @@ def main():
         by = bytes_per_tag(BATCH * (2 if cevae else 1), fin_bits=(math != 'f32'))
         gbs = by[dom] / (dom_ms * 1e-3) / 1e9
         traffic = None
-        for cand in (f'r03_traffic_{math}.json', f'r02_traffic_{math}.json', f'r01_traffic_{math}.json'):
+        for cand in (f'r04_traffic_{math}.json', f'r03_traffic_{math}.json', f'r02_traffic_{math}.json', f'r01_traffic_{math}.json'):
             try:
                 doc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
                 tr = doc.get(dom)
@@ -654,21 +654,25 @@ def main():
                     break
             except Exception:
                 continue
-        # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command (the profiler's clock instead
-        # of HIP events around the launch group; bf16x3 only: the summary is of the default mode), with the commit it was taken at
+        # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command in this math mode (the
+        # profiler's clock instead of HIP events around the launch group), with the commit it was taken at
         rocprof = None
-        if math != 'f32':
+        for tj, ks in ((f'r04_traffic_{math}.json', 'r04_z_kernel_stats.csv' if math != 'f32' else 'r04_z_kernel_stats_f32.csv'),
+                       ('r03_traffic_bf16x3.json', 'r03_z_kernel_stats.csv') if math != 'f32' else (None, None)):
+            if rocprof is not None or tj is None:
+                continue
             try:
                 import csv
-                doc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_traffic_bf16x3.json')))
+                doc = json.load(open(os.path.join(ROOT, 'profiles', tj)))
                 kname = doc[dom]['kernel']
-                for row in csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r03_z_kernel_stats.csv'))):
-                    if kname in row['Name']:
-                        avg_ms = float(row['AverageNs']) * 1e-6
-                        rocprof = {'avg_launch_ms': round(avg_ms, 4), 'calls': int(row['Calls']), 'frac': round(fl[dom] / (avg_ms * 1e-3) / 1e12 / peak, 4),
-                                   'source': f'profiles/r03_z_kernel_stats.csv (bench.py --steps 10 --warmup 3 --quick under rocprofv3 --kernel-trace --stats), '
-                                             f'commit {doc.get("_commit")}; not re-measured in this run'}
-                        break
+                cands = [row for row in csv.DictReader(open(os.path.join(ROOT, 'profiles', ks))) if kname in row['Name']]
+                if cands:
+                    row = max(cands, key=lambda r: float(r['TotalDurationNs']))
+                    avg_ms = float(row['AverageNs']) * 1e-6
+                    rocprof = {'avg_launch_ms': round(avg_ms, 4), 'calls': int(row['Calls']), 'frac': round(fl[dom] / (avg_ms * 1e-3) / 1e12 / peak, 4),
+                               'source': f'profiles/{ks} (bench.py --steps 10 --warmup 3 --quick --math {math} under rocprofv3 --kernel-trace --stats), '
+                                         f'commit {doc.get("_commit")}; not re-measured in this run'
+                                         + ('; the summary row averages every launch of this kernel template (other layers share it)' if math == 'f32' else '')}
             except Exception:
                 rocprof = None
         kernels = {t: {'ms': round(ms / c, 4), 'tflops': round(fl[t] / (ms / c * 1e-3) / 1e12, 2) if t in fl else None,
