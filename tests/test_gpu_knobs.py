@@ -6,7 +6,8 @@ interpreter with the switch set:
   UAD_NO_FIRST32           generic first-layer kernels instead of conv_first_fwd32 / conv_first_wgrad32
   UAD_NO_SIDE_PACK         weight repack on the caller's stream inside the next forward instead of on the side stream after the optimizer step
   UAD_EVENT_SYSFENCE       stream-ordering events with the default system-scope fence
-  UAD_NO_W_T               pixel-major filter-gradient kernel instead of the channel-major one
+  UAD_NO_W_TR              round-3 channel-major filter-gradient kernel instead of the transpose-read one (ds_read_b64_tr_b16 fragments)
+  UAD_NO_W_T               ... and the round-2 pixel-major gather kernel instead of either
   UAD_NO_INKERNEL_SPLITK   split-K slabs summed by splitk_epilogue_kernel launches instead of the conv kernels' last-arriver reduction
   UAD_NO_D16S              round-2 ConvT-class kernel (LDS-transposed epilogue) instead of the lane = pixel one
   UAD_NO_REDUCE_NT         slab reductions with plain instead of streaming (non-temporal) loads
@@ -24,7 +25,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_EVENT_SYSFENCE', 'UAD_NO_W_T', 'UAD_NO_INKERNEL_SPLITK',
+@pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_EVENT_SYSFENCE', 'UAD_NO_W_TR', 'UAD_NO_W_T', 'UAD_NO_INKERNEL_SPLITK',
                                   'UAD_NO_D16S', 'UAD_NO_REDUCE_NT', 'UAD_NO_ANYORDER', 'UAD_NO_PACK8'])
 def test_model_parity_with_switch(knob):
     name, _, val = knob.partition('=')

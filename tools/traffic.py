@@ -45,8 +45,8 @@ TAGS = {
     'dec3.dgrad': ('conv5_f16_kernel<8, 16, 16, 4, 1', 32 * 64 * 256),
     'dec2.dgrad': ('conv5_f16_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
     'enc1.fwd': ('conv5_f16_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
-    'dec3.wgrad': ('conv5_w_bf16_t_kernel<1, true', 512 * 256),
-    'enc1.wgrad': ('conv5_w_bf16_t_kernel<2, false', 256 * 512),
+    'dec3.wgrad': ('conv5_w_bf16_tr_kernel<1, true', 512 * 256),       # round 4: the transpose-read kernel
+    'enc1.wgrad': ('conv5_w_bf16_tr_kernel<2, false', 256 * 512),
     'final.fwd+bwd': ('final_kernel<true>', 32 * 64 * 256),
 } if MATH != 'f32' else {
     # exact-fp32 mode (v_mfma_f32_32x32x2_f32 kernels)

@@ -3420,6 +3420,250 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
         a.dbgbuf[2 * b + 1] = wall_clock64();
     }
 }
+// Transpose-read form (round 4).  gfx950's ds_read_b64_tr_b16 gathers, per 16-lane group, four rows of 16 bf16 columns -- each lane supplies the
+// 8-byte-aligned address of four CONTIGUOUS columns of one row, row stride free -- and hands lane j column j's four row values (probe:
+// tools/tr_probe.hip, profiles/r04_g_tr_probe.log).  With rows = positions and columns = channels that IS the W-kind MFMA fragment (lane = channel,
+// eight consecutive positions per lane = two reads), read straight from a PIXEL-major tile: lane (i = l & 15, chalf = (l >> 4) & 1, lh = l >> 5) points
+// at pixel (2 (2 js + lh) + ky, 2 (4 t + i / 4) + kx), channels 16 chalf + 4 (i & 3) .. + 3.  The big halo and the small tile are therefore staged
+// exactly as the F-kind kernels stage theirs -- two 8-byte LDS stores per float4 instead of eight 2-byte scatter stores with their shifts -- and the
+// taps need no segment shifting (v_alignbit) at all.  Bank check: the four rows of a group sit 160 B (big, pixel stride 2) / 144 B (small) apart,
+// 32 B each: dword banks [0-7] [40-47] [16-23] [56-63] / [0-7] [36-43] [8-15] [44-51], disjoint.  Same tap-to-wave assignment, slabs and fold order as
+// conv5_w_bf16_t_kernel: the results are the same bits.
+template <int NCSB, bool FBB = false>
+__global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
+conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
+    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256 * NCSB, CSQ = 8 * NCSB;
+    constexpr int LDH = CK + 8;                   // ushorts per big pixel (80 B)
+    constexpr int BIGP = IH * IW * LDH;           // ushorts per plane
+    constexpr int LDQ = 32 * NCSB + 8;            // ushorts per small position (144 B at NCSB = 2)
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    // (A double-buffered tile loop -- one barrier per tile, the next tile's conversion beside this tile's MFMAs -- measured neutral on this kernel too:
+    // profiles/r04_h_w_tr_ab.log.)
+    constexpr int BUFP = 2 * BIGP + 2 * TH * TW * LDQ;         // ushorts of one tile buffer
+    unsigned short* bHi0 = reinterpret_cast<unsigned short*>(dsm);
+    float* sXf = reinterpret_cast<float*>(bHi0 + BUFP);   // [32] big scale, [32] big shift, [64] small scale, [64] small shift
+    float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
+
+    const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+    const int wave = wave_all & 3;   // kernel row of this wave's taps
+    const int csb = wave_all >> 2;    // its cs block
+    const int l31 = lane & 31, lh = lane >> 5;
+    const UadConvDesc& d = a.d;
+    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32 * NCSB;
+    const int tilesx = d.WS / TW, tilesy = d.HS / TH;
+    const int t_begin = blockIdx.z * tiles_per_split;
+    const int t_end = min(t_begin + tiles_per_split, total_tiles);
+
+    const int cq = tid % CQ;
+    const bool xfa = !FBB && a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
+    // activation-on-load tables in LDS
+    if (tid < 32) {
+        sXf[tid] = xfa ? a.xfb.scale[cb0 + tid] * a.xfb.mult : 1.f;
+        sXf[32 + tid] = xfa ? a.xfb.shift[cb0 + tid] : 0.f;
+    }
+    if (tid < 32 * NCSB) {
+        sXf[64 + tid] = xfs ? a.xfs.scale[cs0 + tid] * a.xfs.mult : 1.f;
+        sXf[128 + tid] = xfs ? a.xfs.shift[cs0 + tid] : 0.f;
+    }
+
+    float fb_wf[4] = {0.f, 0.f, 0.f, 0.f}, fb_s1[4] = {0.f, 0.f, 0.f, 0.f}, fb_s0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FBB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            fb_wf[e] = a.xfb.fb_wf[cb0 + cq * 4 + e];
+            fb_s1[e] = a.xfb.scale[cb0 + cq * 4 + e] * a.xfb.mult;
+            fb_s0[e] = fb_s1[e] * a.xfb.alpha;
+        }
+    }
+
+    constexpr int MAXT = 7;
+    // fragment addressing (ushort indices): group g = lane >> 4 -> channel half g & 1, position half lh = g >> 1; lane i of the group -> row i >> 2
+    // of the 4-position block, columns 4 (i & 3)
+    const int li = lane & 15, chalf = (lane >> 4) & 1;
+    const int a_base = ((2 * lh) * IW + 2 * (li >> 2)) * LDH + 16 * chalf + 4 * (li & 3);      // + (4 js IW + ky IW + kx + 8 t) LDH
+    const int b_base = (8 * lh + (li >> 2)) * LDQ + csb * 32 + 16 * chalf + 4 * (li & 3);        // + (16 js + 4 t) LDQ
+
+    v16f acc[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    auto tr8 = [&](const unsigned short* plane, const int addr, const int step) __attribute__((always_inline)) {      // 8 consecutive k of this lane's channel
+        const v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(const_cast<unsigned short*>(plane) + addr));
+        const v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(const_cast<unsigned short*>(plane) + addr + step));
+        const uint2 lo2 = __builtin_bit_cast(uint2, r0), hi2 = __builtin_bit_cast(uint2, r1);
+        return make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+    };
+    auto mma3 = [&](v16f& c, uint4 ah, uint4 al, uint4 bh, uint4 bl) {
+        c = mfma_bf16(ah, bh, c);
+        c = mfma_bf16(ah, bl, c);
+        c = mfma_bf16(al, bh, c);
+    };
+
+    // ---- tile loop, software-pipelined: the global loads of tile t + 1 are in flight while tile t is contracted (round 3: with the loads, the
+    // LDS stores and the MFMAs all ablated the kernel still ran at 55 % of its time -- per-tile load latency that nothing covered, and
+    // per-element index arithmetic: three divisions by non-powers of two and 64-bit address products per 16 bytes staged) ----
+    constexpr int TOT = IH * IW * CQ;
+    constexpr int PER = (TOT + NT - 1) / NT;          // 16-byte elements of the big tile per thread: 12 (NT 256) or 6 (NT 512)
+    constexpr int DP = NT / CQ, DIY = DP / IW, DIX = DP % IW;      // element u + 1 of a thread is DP pixels further: (iy, ix) += (DIY, DIX), one wrap
+    const int pix0 = tid / CQ, iy0 = pix0 / IW, ix0 = pix0 % IW;
+    float4 v[FBB ? 1 : PER];
+    unsigned vb[FBB ? PER : 1];
+    float vg[FBB ? PER : 1];
+    constexpr int SPER = TH * TW * CSQ / NT;          // 16-byte elements of the small tile per thread
+    float4 sv[SPER];
+    auto tile_origin = [&](int t, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
+        tx0 = (t % tilesx) * TW;
+        ty0 = ((t / tilesx) % tilesy) * TH;
+        n = t / (tilesx * tilesy);
+    };
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        int n, ty0, tx0;
+        tile_origin(t, n, ty0, tx0);
+        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
+        const size_t pixbase = (size_t)n * d.HB * d.WB;
+        const float* bigb = a.big + pixbase * d.CB + cb0 + cq * 4;
+        int iy = iy0, ix = ix0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            const bool ok = (u + 1 < PER || tid + u * NT < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
+            const int gp = ok ? (gy * d.WB + gx) : 0;
+            if (FBB) {
+                vb[FBB ? u : 0] = a.xfb.fb_bits[pixbase + gp];
+                vg[FBB ? u : 0] = a.xfb.fb_dxhat[pixbase + gp];
+            } else if (a.abl & 4) {
+                v[FBB ? 0 : u] = make_float4(1.f, 2.f, 3.f, 4.f);
+            } else {
+                v[FBB ? 0 : u] = *reinterpret_cast<const float4*>(bigb + (unsigned)(gp * d.CB));
+            }
+            ix += DIX; iy += DIY;
+            if (ix >= IW) { ix -= IW; ++iy; }
+        }
+        const size_t spix = ((size_t)(n * d.HS + ty0) * d.WS + tx0);
+#pragma unroll
+        for (int u = 0; u < SPER; ++u) {
+            const int idx = tid + u * NT;
+            const int pos = idx / CSQ, csq = idx % CSQ;
+            const unsigned po = (unsigned)((pos / TW) * d.WS + (pos % TW));
+            sv[u] = *reinterpret_cast<const float4*>(a.small_ + (spix + po) * d.CS + cs0 + csq * 4);
+        }
+    };
+    auto commit = [&](int t, int buf) __attribute__((always_inline)) {
+        unsigned short* bHi = bHi0 + buf * BUFP;
+        unsigned short* bLo = bHi + BIGP;
+        unsigned short* sHiT = bLo + BIGP;
+        unsigned short* sLoT = sHiT + TH * TW * LDQ;
+        int n, ty0, tx0;
+        tile_origin(t, n, ty0, tx0);
+        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
+        int iy = iy0, ix = ix0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const bool valid = u + 1 < PER || tid + u * NT < TOT;
+            const bool ok = valid && (unsigned)(gy0 + iy) < (unsigned)d.HB && (unsigned)(gx0 + ix) < (unsigned)d.WB;
+            if (valid) {
+                float4 tv = v[FBB ? 0 : u];
+                if (FBB) {
+                    const unsigned b = vb[FBB ? u : 0] >> (cb0 + cq * 4);
+                    const float gq = vg[FBB ? u : 0];
+                    tv.x = gq * fb_wf[0] * ((b & 1u) ? fb_s1[0] : fb_s0[0]);
+                    tv.y = gq * fb_wf[1] * ((b & 2u) ? fb_s1[1] : fb_s0[1]);
+                    tv.z = gq * fb_wf[2] * ((b & 4u) ? fb_s1[2] : fb_s0[2]);
+                    tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
+                } else if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
+                uint2 hi, lo;
+                tv = keep4(ok, tv);
+                split_bf16(tv, hi, lo);
+                if (!(a.abl & 1)) {   // pixel-major: two 8-byte stores
+                    const int o = (iy * IW + ix) * LDH + cq * 4;
+                    *reinterpret_cast<uint2*>(bHi + o) = hi;
+                    *reinterpret_cast<uint2*>(bLo + o) = lo;
+                }
+            }
+            ix += DIX; iy += DIY;
+            if (ix >= IW) { ix -= IW; ++iy; }
+        }
+#pragma unroll
+        for (int u = 0; u < SPER; ++u) {
+            const int idx = tid + u * NT;
+            const int pos = idx / CSQ, csq = idx % CSQ;
+            float4 tv = sv[u];
+            if (xfs) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + 64 + csq * 4), *reinterpret_cast<const float4*>(sXf + 128 + csq * 4), a.xfs.alpha);
+            uint2 hi, lo;
+            split_bf16(tv, hi, lo);
+            *reinterpret_cast<uint2*>(sHiT + pos * LDQ + csq * 4) = hi;
+            *reinterpret_cast<uint2*>(sLoT + pos * LDQ + csq * 4) = lo;
+        }
+    };
+    if (t_begin < t_end) issue(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();                   // the previous tile's fragments are consumed (first pass: the sXf tables are written)
+        commit(t, 0);
+        if (t + 1 < t_end) issue(t + 1);   // in flight across the barrier and the MFMA loop below
+        __syncthreads();
+        const unsigned short* bHi = bHi0;
+        const unsigned short* bLo = bHi + BIGP;
+        const unsigned short* sHiT = bLo + BIGP;
+        const unsigned short* sLoT = sHiT + TH * TW * LDQ;
+        if (!(a.abl & 2))
+#pragma unroll
+        for (int js = 0; js < TH * TW / 16; ++js) {
+            // positions 16 js .. 16 js + 15 = tile rows 2 js (k half 0) and 2 js + 1 (k half 1)
+            const int bo = b_base + 16 * js * LDQ;
+            const uint4 bh = tr8(sHiT, bo, 4 * LDQ), bl = tr8(sLoT, bo, 4 * LDQ);
+            const int ao = a_base + (4 * js * IW + wave * IW) * LDH;          // this wave's kernel row
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) mma3(acc[kx], tr8(bHi, ao + kx * LDH, 8 * LDH), tr8(bLo, ao + kx * LDH, 8 * LDH), bh, bl);
+            const int a4 = a_base + (4 * js * IW + 4 * IW) * LDH;             // kernel row 4
+            mma3(acc[5], tr8(bHi, a4 + wave * LDH, 8 * LDH), tr8(bLo, a4 + wave * LDH, 8 * LDH), bh, bl);        // tap (4, wave)
+            if (js == wave) mma3(acc[6], tr8(bHi, a4 + 4 * LDH, 8 * LDH), tr8(bLo, a4 + 4 * LDH, 8 * LDH), bh, bl);   // this wave's quarter of tap (4, 4)
+        }
+    }
+
+    // Accumulator block -> slab.  One 64-bit address per lane; everything else is a wave-uniform 32-bit offset (the plain form
+    // `out[((size_t)tap * CB + cb) * CS + col]` cost ~400 quarter-rate 64-bit multiply-adds per wave: 8 of this kernel's ~47 us).
+    const int CSi = d.CS;
+    float* ob = a.partial + (size_t)blockIdx.z * a.Mtot * CSi + (size_t)(cb0 + 4 * lh) * CSi + cs0 + csb * 32 + l31;
+    const int tapstride = d.CB * CSi;
+    if (a.abl & 32) {       // stress test (tests/test_gpu_knobs.py): every workgroup idles ~100 us before it writes its slab, so that the filter gradient
+                            // OUTLASTS the any-order data gradient launched behind it -- results stay correct, only the timing changes
+        for (int i = 0; i < 32; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    if (!(a.abl & 8))
+#pragma unroll
+    for (int j = 0; j < MAXT - 1; ++j) {
+        const int tap = j < 5 ? 5 * wave + j : 20 + wave;      // (row, 0..4), (4, row)
+        float* ot = ob + tap * tapstride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (a.abl & 16) __builtin_nontemporal_store(acc[j][r], ot + ((r & 3) + 8 * (r >> 2)) * CSi);    // experiment: streaming slab stores
+            else ot[((r & 3) + 8 * (r >> 2)) * CSi] = acc[j][r];
+        }
+    }
+    // tap (4, 4): the four rows' shares are folded through LDS in a fixed order
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[((csb * 4 + wave) * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
+    __syncthreads();
+    if (wave == 0) {
+        float* ot = ob + 24 * tapstride;
+        const float* q = sRed + (size_t)csb * 64 * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ot[((r & 3) + 8 * (r >> 2)) * CSi] = (q[r * 64 + lane] + q[(16 + r) * 64 + lane]) + (q[(32 + r) * 64 + lane] + q[(48 + r) * 64 + lane]);
+    }
+    if (a.dbgbuf && tid == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        a.dbgbuf[2 * b] = dbg_t0;
+        a.dbgbuf[2 * b + 1] = wall_clock64();
+    }
+}
+
+constexpr size_t conv5_w_bf16_tr_lds_bytes(int ncsb) { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)2 * 64 * (32 * ncsb + 8) * 2 + 192 * 4; }
 constexpr size_t conv5_w_bf16_t_lds_bytes(int ncsb) { return (size_t)2 * 32 * (19 * 2 * 12 + 4) * 2 + (size_t)ncsb * 2 * 32 * 72 * 2 + 192 * 4; }
 constexpr size_t conv5_w_bf16_lds_bytes(int ncsb) { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)ncsb * 2 * 32 * 72 * 2 + 192 * 4; }
 
@@ -3859,6 +4103,27 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                 }
                 const bool two = pair_ok && d.CS % 64 == 0;
                 if (two) grid.y = d.CS / 64;
+                // transpose-read form (pixel-major tiles, ds_read_b64_tr_b16 fragments): the default since round 4 (same bits, every k5 filter-gradient
+                // launch 3-12 % faster: profiles/r04_h_w_tr_ab.log); UAD_NO_W_TR=1: the channel-major kernel
+                static const bool tr_on = getenv("UAD_NO_W_TR") == nullptr;
+                if (tr_on) {
+                    static bool tr_attr = false;
+                    if (!tr_attr) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(1));
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(2));
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(1));
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(2));
+                        tr_attr = true;
+                    }
+                    const size_t ldt = conv5_w_bf16_tr_lds_bytes(two ? 2 : 1);
+                    if (xfb.fb_bits) {
+                        if (two) UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<2, true>), grid, dim3(512), ldt, st, a, w5.tiles_per_split, w5.total_tiles);
+                        else UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<1, true>), grid, dim3(256), ldt, st, a, w5.tiles_per_split, w5.total_tiles);
+                    } else {
+                        if (two) UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<2, false>), grid, dim3(512), ldt, st, a, w5.tiles_per_split, w5.total_tiles);
+                        else UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<1, false>), grid, dim3(256), ldt, st, a, w5.tiles_per_split, w5.total_tiles);
+                    }
+                } else {
                 const size_t lds = conv5_w_bf16_t_lds_bytes(two ? 2 : 1);
                 if (xfb.fb_bits) {
                     if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
@@ -3866,6 +4131,7 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                 } else {
                     if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, false>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
                     else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, false>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
+                }
                 }
             } else
             if (xfb.fb_bits) {          // compressed d loss / d c of the last decoder block (callers check uad_conv_w_supports_fb_bits)
