@@ -481,6 +481,22 @@ def bench_fanogan(args):
                     ain = top['N'] * top['MH'] * top['MW'] * (top['p1'] ** 2 * top['CA'] + top['Nn']) * 4
                     aout = 9 * top['CA'] * top['Nn'] * 4
                 abytes = ain + aout + 9 * top['CA'] * top['Nn'] * 2 * top['planes'] * (1 if top['kind'] == 0 else 0)
+                # HBM bytes per launch of that (kernel, grid) from the committed rocprofv3 PMC passes of this command (tools/r4_gpu12.sh)
+                traffic = None
+                try:
+                    tdoc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_traffic_fanogan_resnet64.json')))
+                    if top['kind'] == 0:
+                        kn = f"convk16_kernel<8, 8, 32, 2, 2, {top['p1']}, {top['p2']}, {top['ntaps']}, {top['planes']},"
+                        gt = str((top['MH'] // 8) * (top['MW'] // 8) * top['N'] * (top['Nn'] // 64) * 256)
+                        for row in tdoc['rows']:
+                            if row['kernel'].startswith(kn) and row['grid_threads'] == gt and row['write_bytes'] is not None:
+                                traffic = {'bytes': int(row['fetch_bytes'] + row['write_bytes']), 'fetch_bytes': int(row['fetch_bytes']), 'write_bytes': int(row['write_bytes']),
+                                           'source': f"profiles/r04_traffic_fanogan_resnet64.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH x2 gfx950 "
+                                                     f"correction), commit {tdoc.get('_commit')}; not re-measured in this run.  Above the algorithmic bytes: every 64-channel output "
+                                                     "block of a tile is its own workgroup and re-reads the input tile (8 blocks at 512 channels) and its weight slice"}
+                                break
+                except Exception:
+                    traffic = None
                 res['roofline'] = {'bound': 'mfma', 'kernel': name,
                                    'shape': {k: top[k] for k in ('N', 'MH', 'MW', 'CA', 'Nn', 'ntaps', 'planes')},
                                    'achieved': round(ach, 2), 'peak': round(pk, 1), 'unit': 'TFLOP/s', 'frac': round(ach / pk, 4),
@@ -488,8 +504,9 @@ def bench_fanogan(args):
                                    'algorithmic_flop_per_launch': flop, 'algorithmic_bytes_per_launch': abytes, 'avg_launch_ms': round(avg_ms, 4),
                                    'launches_timed': top['calls'], 'group_share_of_k3_time': round(sum(r['total_ms'] for r in grp) / sum(r['total_ms'] for r in rows), 3),
                                    'instruction': f"{3 if top['planes'] == 2 else 6} x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = dense bf16 MFMA 2500 TFLOP/s / products",
-                                   'traffic': None,
-                                   'rocprof': 'profiles/r04_c_fanogan_resnet64_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command)',
+                                   'traffic': traffic,
+                                   'rocprof': 'profiles/r04_z_fanogan_resnet64_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command; the summary row of this kernel '
+                                              'template averages all its launch shapes)',
                                    'whole_iteration': whole}
                 res['k3_kernels'] = sorted(({'kind': 'FD' if r['kind'] == 0 else 'W', 'stride': r['p1'], 'ntaps': r['ntaps'], 'planes': r['planes'],
                                              'N': r['N'], 'grid': [r['MH'], r['MW']], 'CA': r['CA'], 'Nn': r['Nn'], 'calls': r['calls'],
