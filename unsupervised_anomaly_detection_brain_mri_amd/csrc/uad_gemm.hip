@@ -3676,9 +3676,11 @@ inline W5Choice choose_w5(const UadConvDesc& d) {
     if (d.CB % 32 || d.CS % 32 || d.HS % 8 || d.WS % 8) return c;
     c.total_tiles = d.N * (d.HS / 8) * (d.WS / 8);
     const int blocks = (d.CB / 32) * (d.CS / 32);
-    // UAD_W5_TARGET (tuning knob): workgroup-slab target of a launch.  Every split costs one [25][CB][CS] slab written and re-read (52 MB per
-    // launch at the default), every tile ~2.6 us of a workgroup's life.
-    static const int target = getenv("UAD_W5_TARGET") ? atoi(getenv("UAD_W5_TARGET")) : 512;
+    // UAD_W5_TARGET (tuning knob): workgroup-slab target of a launch.  Every split costs one [25][CB][CS] slab written and re-read, every tile
+    // ~2.6 us of a workgroup's life.  Default 448 (round 4, profiles/r04_i_w5_target_sweep.log): the kernel itself is fastest at 512 (two
+    // workgroups on every CU: dec3.wgrad 61 us, 68 at 448), but the layer's data gradient is launched right behind it without the barrier bit and
+    // fills the slots a 410-workgroup filter gradient leaves free -- the STEP is 2.5 % faster (0.916 -> 0.894 ms), and the slabs are a fifth smaller.
+    static const int target = getenv("UAD_W5_TARGET") ? atoi(getenv("UAD_W5_TARGET")) : 448;
     int splits = (target + blocks - 1) / blocks;
     if (splits > c.total_tiles) splits = c.total_tiles;
     if (splits < 1) splits = 1;
