@@ -3670,7 +3670,7 @@ constexpr size_t conv5_w_bf16_lds_bytes(int ncsb) { return (size_t)2 * 19 * 19 *
 #include "uad_convk16.inc"
 
 struct W5Choice { bool ok; int splits, tiles_per_split, total_tiles; };
-inline W5Choice choose_w5(const UadConvDesc& d) {
+inline W5Choice choose_w5(const UadConvDesc& d, bool bf16 = true) {
     W5Choice c{false, 0, 0, 0};
     if (!(d.KS == 5 && d.S == 2 && d.P == 1 && d.HB == 2 * d.HS && d.WB == 2 * d.WS)) return c;
     if (d.CB % 32 || d.CS % 32 || d.HS % 8 || d.WS % 8) return c;
@@ -3680,7 +3680,9 @@ inline W5Choice choose_w5(const UadConvDesc& d) {
     // ~2.6 us of a workgroup's life.  Default 448 (round 4, profiles/r04_i_w5_target_sweep.log): the kernel itself is fastest at 512 (two
     // workgroups on every CU: dec3.wgrad 61 us, 68 at 448), but the layer's data gradient is launched right behind it without the barrier bit and
     // fills the slots a 410-workgroup filter gradient leaves free -- the STEP is 2.5 % faster (0.916 -> 0.894 ms), and the slabs are a fifth smaller.
-    static const int target = getenv("UAD_W5_TARGET") ? atoi(getenv("UAD_W5_TARGET")) : 448;
+    // The exact-fp32 kernel (bf16 = false) is bound by the matrix pipe, not by latency: it keeps 512 (448 cost that mode 4 %: 1.704 -> 1.772 ms).
+    static const int target_env = getenv("UAD_W5_TARGET") ? atoi(getenv("UAD_W5_TARGET")) : 0;
+    const int target = target_env > 0 ? target_env : (bf16 ? 448 : 512);
     int splits = (target + blocks - 1) / blocks;
     if (splits > c.total_tiles) splits = c.total_tiles;
     if (splits < 1) splits = 1;
@@ -4045,8 +4047,8 @@ bool uad_conv_w_supports_fb_bits(const UadConvDesc& d, bool math_bf16x3) {
 }
 
 size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
-    const W5Choice w5 = choose_w5(d);
-    if (w5.ok) return (size_t)w5.splits * d.KS * d.KS * d.CB * d.CS;
+    const W5Choice w5 = choose_w5(d, false), w5b = choose_w5(d, true);      // (the launch's math mode picks one of the two: size for the larger)
+    if (w5.ok) return (size_t)(w5.splits > w5b.splits ? w5.splits : w5b.splits) * d.KS * d.KS * d.CB * d.CS;
     const WChoice c = choose_w(d);
     const WK3Choice k3 = choose_wk3(d);      // (which of the two runs depends on the math mode of the launch: size for both)
     const int splits = (k3.ok && k3.splits > c.splits) ? k3.splits : c.splits;
@@ -4064,7 +4066,7 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         (void)hipStreamWaitEvent(reduce_st, ev, 0);
         return reduce_st;
     };
-    const W5Choice w5 = choose_w5(d);
+    const W5Choice w5 = choose_w5(d, math_bf16x3);
     if (w5.ok) {
         ConvWArgs a;
         a.big = big; a.small_ = small; a.partial = (w5.splits == 1) ? dW : partial;
@@ -4199,8 +4201,8 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
 
 void uad_conv_any_order_next(bool on) { g_any_order_next = on; }
 void uad_conv_w_any_order_next(bool on) { g_any_order_w_next = on; }
-void uad_launch_conv_w_reduce(const UadConvDesc& d, float* dW, float* partial, hipStream_t st) {
-    const W5Choice w5 = choose_w5(d);
+void uad_launch_conv_w_reduce(const UadConvDesc& d, float* dW, float* partial, hipStream_t st, bool math_bf16x3) {
+    const W5Choice w5 = choose_w5(d, math_bf16x3);
     const int splits = w5.ok ? w5.splits : choose_w(d).splits;
     if (splits > 1) uad_launch_reduce_partials(partial, splits, d.KS * d.KS * d.CB * d.CS, 1.0f, dW, st);
 }

@@ -123,8 +123,9 @@ bool uad_conv_w_supports_fb_bits(const UadConvDesc& d, bool math_bf16x3);
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
                        float* dW, float* partial, hipStream_t st, bool math_bf16x3 = false,
                        hipStream_t reduce_st = nullptr, hipEvent_t ev = nullptr, bool generic_bf16x3 = false, bool defer_reduce = false);
-// the split-K slab reduction of a uad_launch_conv_w(..., defer_reduce = true) call (no-op when that launch did not split)
-void uad_launch_conv_w_reduce(const UadConvDesc& d, float* dW, float* partial, hipStream_t st);
+// the split-K slab reduction of a uad_launch_conv_w(..., math_bf16x3, ..., defer_reduce = true) call (no-op when that launch did not split); the
+// math mode has to be the launch's: the k5 kernels split differently in the two modes
+void uad_launch_conv_w_reduce(const UadConvDesc& d, float* dW, float* partial, hipStream_t st, bool math_bf16x3);
 
 // out[j] = scale * sum_{s<S} partial[s*L + j]
 void uad_launch_reduce_partials(const float* partial, int S, int L, float scale, float* out, hipStream_t st);

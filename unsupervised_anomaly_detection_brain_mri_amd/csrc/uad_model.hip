@@ -930,7 +930,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
             uad_launch_reduce_partials(m->red_partial, T, L, 1.0f, m->colscratch, sd);
             uad_launch_final_gradfin(m->colscratch, C, P(m, DL.gamma), rstd, Gr(m, m->fw), Gr(m, m->fb), Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), sd);
         }
-        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats, sk_counters(m)), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd, bf); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats, sk_counters(m)), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
@@ -1137,7 +1137,7 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
           uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i]));
           uad_conv_any_order_next(false); }
         edge(m, st, sd);
-        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd);
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd, bf);
                   uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats, sk_counters(m)), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
