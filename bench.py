@@ -179,7 +179,12 @@ def bench_gmvae(args):
     from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import synthetic_slices
     world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))    # single-GPU rehearsal of the multi-process path: every rank on cuda:0, gloo instead of RCCL
+    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))
+    if os.environ.get('UAD_BENCH_REHEARSAL'):
+        # several processes on ONE GPU: the fused bottleneck's groups of four sibling workgroups (uad_bott.hip) need all four resident at once; two processes'
+        # kernels can hold each other's slots until the bounded exchange gives up (it reports, it does not hang).  The one-workgroup-per-sample form has no
+        # inter-workgroup wait.  (One process per GPU -- the deployment this library is written for -- is unaffected.)
+        os.environ.setdefault('UAD_BOTT_Q1', '1')    # single-GPU rehearsal of the multi-process path: every rank on cuda:0, gloo instead of RCCL
     if rehearsal:
         local_rank = 0
     if world != args.gpus:
@@ -342,7 +347,12 @@ def bench_fanogan(args):
     from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import synthetic_slices
     world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))    # single-GPU rehearsal of the multi-process path: every rank on cuda:0, gloo instead of RCCL
+    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))
+    if os.environ.get('UAD_BENCH_REHEARSAL'):
+        # several processes on ONE GPU: the fused bottleneck's groups of four sibling workgroups (uad_bott.hip) need all four resident at once; two processes'
+        # kernels can hold each other's slots until the bounded exchange gives up (it reports, it does not hang).  The one-workgroup-per-sample form has no
+        # inter-workgroup wait.  (One process per GPU -- the deployment this library is written for -- is unaffected.)
+        os.environ.setdefault('UAD_BOTT_Q1', '1')    # single-GPU rehearsal of the multi-process path: every rank on cuda:0, gloo instead of RCCL
     if rehearsal:
         local_rank = 0
     if world != args.gpus:
@@ -560,7 +570,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))    # single-GPU rehearsal of the multi-process path: every rank on cuda:0, gloo instead of RCCL
+    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))
+    if os.environ.get('UAD_BENCH_REHEARSAL'):
+        # several processes on ONE GPU: the fused bottleneck's groups of four sibling workgroups (uad_bott.hip) need all four resident at once; two processes'
+        # kernels can hold each other's slots until the bounded exchange gives up (it reports, it does not hang).  The one-workgroup-per-sample form has no
+        # inter-workgroup wait.  (One process per GPU -- the deployment this library is written for -- is unaffected.)
+        os.environ.setdefault('UAD_BOTT_Q1', '1')    # single-GPU rehearsal of the multi-process path: every rank on cuda:0, gloo instead of RCCL
     if rehearsal:
         local_rank = 0
     if world != args.gpus:
