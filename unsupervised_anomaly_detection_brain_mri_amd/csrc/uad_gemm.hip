@@ -642,7 +642,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_f_kernel(const ConvGemmA
     }
 }
 
-template <int TH, int TW, int CK, int WGM, int WGN>
+__device__ __forceinline__ float sum8_dpp(float v);      // (DPP butterfly over 8 consecutive lanes, defined with the bf16 kernels below)
+// FIN (round 4): the last decoder block of the exact-fp32 mode -- its BN + LeakyReLU, the final 1 x 1 convolution, the L1 loss and the loss
+// gradient run in this kernel's epilogue exactly as in conv5_d16_kernel (UAD_EPI_FINAL), instead of a final_kernel pass that re-reads the
+// block's 128 B / pixel output; the epilogue's tiles alias the halo tile, so the instance needs no more LDS than the plain one.
+template <int TH, int TW, int CK, int WGM, int WGN, bool FIN = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int IH = TH + 2, IW = TW + 2;
@@ -758,6 +762,120 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmA
             }
         }
         b0 = b1;
+    }
+
+    if constexpr (FIN) {
+        // (models/customlayers.py:35-37 + trainers/VAE.py:36-40 behind the last Conv2DTranspose; partials in final_kernel's layout)
+        static_assert(WGN == 1, "one 32-channel column block holds every channel of the last block");
+        constexpr int EPI_LD = 36;
+        float* s_epi = sIn;                                   // per-wave 32 x EPI_LD transpose tile (the halo tile is dead by now)
+        float* s_fx = s_epi + WGM * 32 * EPI_LD;              // target | reconstruction | L1 tiles of the 2TH x 2TW output block
+        float* s_fo = s_fx + 4 * TH * TW;                     // (s_fo | s_fl adjacent)
+        static_assert(WGM * 32 * EPI_LD + 3 * 4 * TH * TW <= IH * IW * LDC, "epilogue tiles fit in the halo tile");
+        __syncthreads();
+        for (int idx = tid; idx < 4 * TH * TW; idx += NT) {
+            const int yl = idx / (2 * TW), xl = idx % (2 * TW);
+            s_fx[idx] = a.ep.fin_x[((size_t)n * d.HB + 2 * ty0 + yl) * d.WB + 2 * tx0 + xl];
+        }
+        __syncthreads();
+        float* etile = s_epi + wave * 32 * EPI_LD;
+        const int ec4 = (lane & 7) * 4, erow = lane >> 3;
+        const int ecol = n0 + ec4;                            // CB == 32: always in range
+        float4 e_a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.ep.bias) e_a = *reinterpret_cast<const float4*>(a.ep.bias + ecol);
+        float4 f_sc = *reinterpret_cast<const float4*>(a.ep.escale + ecol);
+        f_sc.x *= a.ep.emult; f_sc.y *= a.ep.emult; f_sc.z *= a.ep.emult; f_sc.w *= a.ep.emult;
+        const float4 f_sh = *reinterpret_cast<const float4*>(a.ep.eshift + ecol);
+        const float4 f_w = *reinterpret_cast<const float4*>(a.ep.fin_wf + ecol);
+        const float f_bf = a.ep.fin_bf[0];
+        const float scv[4] = {f_sc.x, f_sc.y, f_sc.z, f_sc.w}, shv[4] = {f_sh.x, f_sh.y, f_sh.z, f_sh.w};
+        const float wv[4] = {f_w.x, f_w.y, f_w.z, f_w.w};
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, dwf[4] = {0.f, 0.f, 0.f, 0.f};
+        float rec = 0.f, dbf = 0.f;
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) etile[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + l31] = acc[cls][r];
+            __builtin_amdgcn_wave_barrier();
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(etile + (erow + 8 * k) * EPI_LD + ec4);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int mm = wm * 32 + erow + 8 * k;
+                const int Y = 2 * (ty0 + mm / TW) + py, X = 2 * (tx0 + mm % TW) + px;
+                const size_t off = ((size_t)(n * d.HB + Y) * d.WB + X) * CB + ecol;
+                const int lidx = (2 * (mm / TW) + py) * (2 * TW) + 2 * (mm % TW) + px;
+                const float cc[4] = {v[k].x + e_a.x, v[k].y + e_a.y, v[k].z + e_a.z, v[k].w + e_a.w};
+                float bn[4], av[4];
+                float dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bn[e] = fmaf(cc[e], scv[e], shv[e]);
+                    av[e] = bn[e] > 0.f ? bn[e] : bn[e] * a.ep.ealpha;
+                    dot = fmaf(av[e], wv[e], dot);
+                }
+                dot = sum8_dpp(dot);                          // the 8 lanes that share the pixel
+                const float xh = dot + f_bf;
+                const float diff = xh - s_fx[lidx];
+                rec += fabsf(diff);
+                if (a.Out) *reinterpret_cast<float4*>(a.Out + off) = make_float4(cc[0], cc[1], cc[2], cc[3]);
+                if (a.ep.fin_dc) {
+                    const float sgn = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * a.ep.fin_inv_batch;
+                    float dc[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float da = sgn * wv[e];
+                        const float dbn = bn[e] > 0.f ? da : da * a.ep.ealpha;
+                        dc[e] = dbn * scv[e];
+                        dwf[e] = fmaf(sgn, av[e], dwf[e]);
+                        s1[e] += dbn;
+                        s2[e] = fmaf(dbn, cc[e], s2[e]);
+                    }
+                    *reinterpret_cast<float4*>(a.ep.fin_dc + off) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+                    dbf += sgn;
+                }
+                if ((lane & 6) == 0) s_fo[(lane & 1) * (4 * TH * TW) + lidx] = (lane & 1) ? fabsf(diff) : xh;
+            }
+        }
+        __syncthreads();                                      // every wave is done with its transpose tile (reused below)
+        for (int idx = tid; idx < 4 * TH * TW; idx += NT) {
+            const int yl = idx / (2 * TW), xl = idx % (2 * TW);
+            const size_t pix = ((size_t)n * d.HB + 2 * ty0 + yl) * d.WB + 2 * tx0 + xl;
+            a.ep.fin_xhat[pix] = s_fo[idx];
+            if (a.ep.fin_l1) a.ep.fin_l1[pix] = s_fo[4 * TH * TW + idx];
+        }
+        // workgroup partials: red_partial[tile][3C + 1] = {dwf[C], S1[C], S2[C], dbf}, rec_partial[tile]
+        float* fr = s_epi;
+        constexpr int FL = 3 * BN + 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t0 = dwf[e], t1 = s1[e], t2 = s2[e];
+            t0 += __shfl_xor(t0, 8); t0 += __shfl_xor(t0, 16); t0 += __shfl_xor(t0, 32);
+            t1 += __shfl_xor(t1, 8); t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
+            t2 += __shfl_xor(t2, 8); t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
+            if (lane < 8) {
+                fr[wave * FL + 0 * BN + ec4 + e] = t0;
+                fr[wave * FL + 1 * BN + ec4 + e] = t1;
+                fr[wave * FL + 2 * BN + ec4 + e] = t2;
+            }
+        }
+        float r0 = rec, r1 = dbf;
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); }
+        if (lane == 0) { fr[wave * FL + 3 * BN] = r1; fr[wave * FL + 3 * BN + 1] = r0; }
+        __syncthreads();
+        const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        if (tid < FL) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) t += fr[w * FL + tid];
+            if (tid == 3 * BN + 1) a.ep.fin_rec_partial[tile] = t;
+            else if (a.ep.fin_dc) a.ep.fin_red_partial[tile * (3 * BN + 1) + tid] = t;
+        }
+        return;
     }
 
     const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
@@ -3853,6 +3971,12 @@ bool uad_conv_d_can_fuse_final(const UadConvDesc& d, bool have_pack16, size_t ws
     // conv5_d16_kernel<8,16,CST,4,1> with the whole channel range in one workgroup column block
     return p.path == PATH_SPATIAL && p.nsplit == 1 && p.sc.BN == 32 && d.CB == 32 && (d.CS == 32 || d.CS == 64) && !getenv("UAD_NO_D16");
 }
+// exact-fp32 mode: conv5_d_kernel<8,16,32,4,1,FIN> (UAD_NO_FUSED_FINAL_F32=1: the separate final_kernel pass)
+bool uad_conv_d_can_fuse_final_f32(const UadConvDesc& d, bool have_pack, size_t ws_floats) {
+    if (!have_pack || getenv("UAD_NO_FUSED_FINAL") || getenv("UAD_NO_FUSED_FINAL_F32")) return false;
+    const GemmPlan p = plan_gemm(d, false, true, ws_floats);
+    return p.path == PATH_SPATIAL && p.nsplit == 1 && p.sc.TH == 8 && p.sc.TW == 16 && p.sc.BN == 32 && p.sc.CK == 32 && d.CB == 32;
+}
 size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack) { return plan_gemm(d, f_type, have_pack, (size_t)1 << 40).ws_floats; }
 
 void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d, const long long* offs, const int* cbs,
@@ -3949,7 +4073,9 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
             if (p.sc.BN == 64) UAD_SPATIAL_LAUNCH((conv5_f_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
             else UAD_SPATIAL_LAUNCH((conv5_f_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
         } else {
-            if (p.sc.BN == 64) UAD_SPATIAL_LAUNCH((conv5_d_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
+            if (p.sc.BN == 64 && a.ep.kind != UAD_EPI_FINAL) UAD_SPATIAL_LAUNCH((conv5_d_kernel<8, 8, 32, 2, 2>), grid, dim3(256), 0, st, a);
+            else if (p.sc.CK == 32 && a.ep.kind == UAD_EPI_FINAL && p.nsplit == 1 && a.Nn == 32) UAD_SPATIAL_LAUNCH((conv5_d_kernel<8, 16, 32, 4, 1, true>), grid, dim3(256), 0, st, a);
+            else if (a.ep.kind == UAD_EPI_FINAL) { fprintf(stderr, "uad: fused final epilogue asked of an exact-fp32 launch that cannot run it (check uad_conv_d_can_fuse_final_f32 first)\n"); abort(); }
             else if (p.sc.CK == 32) UAD_SPATIAL_LAUNCH((conv5_d_kernel<8, 16, 32, 4, 1>), grid, dim3(256), 0, st, a);
             else UAD_SPATIAL_LAUNCH((conv5_d_kernel<8, 16, 16, 4, 1>), grid, dim3(256), 0, st, a);
         }

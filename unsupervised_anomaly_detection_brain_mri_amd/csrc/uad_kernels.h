@@ -110,6 +110,7 @@ int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floa
 // true when uad_launch_conv_d(d, ..., UAD_EPI_FINAL) is available: bf16x3 planes given, class-sequential spatial kernel, all
 // output channels (32) in one workgroup, no split
 bool uad_conv_d_can_fuse_final(const UadConvDesc& d, bool have_pack16, size_t ws_floats);
+bool uad_conv_d_can_fuse_final_f32(const UadConvDesc& d, bool have_pack, size_t ws_floats);
 // true when uad_launch_conv_f would run the bf16x3 spatial kernel that understands UadXform::fb_* (see there)
 bool uad_conv_f_supports_final_bwd(const UadConvDesc& d, bool have_pack16, size_t ws_floats);
 int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0, int ncounters = 0);

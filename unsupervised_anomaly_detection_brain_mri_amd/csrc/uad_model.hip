@@ -758,7 +758,8 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
                                : bn_xform(m, m->dec[i - 1].gamma, m->dec[i - 1].beta, kLrelu);
         UadEpilogue ep = epi_bias(P(m, m->dec[i].b));
         float* out = m->dec[i].c;
-        if (i + 1 == m->dec.size() && m->math == UAD_MATH_BF16X3 && uad_conv_d_can_fuse_final(d, true, m->ws.floats) &&
+        const bool bfm = m->math == UAD_MATH_BF16X3;
+        if (i + 1 == m->dec.size() && (bfm ? uad_conv_d_can_fuse_final(d, true, m->ws.floats) : uad_conv_d_can_fuse_final_f32(d, m->math == UAD_MATH_F32, m->ws.floats)) &&
             (d.HS / 8) * (d.WS / 16) == bps) {
             // last block: its BN + LeakyReLU, the final 1x1 conv, the L1 loss and (training) the loss gradient run in the
             // ConvT kernel's epilogue; the pre-BN output is only written when a later pass needs it (restoration: TV term)
@@ -772,7 +773,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
             ep.fin_rec_partial = m->rec_partial; ep.fin_red_partial = m->red_partial;
             ep.fin_dc = (want_backward && !restore_bwd) ? m->G0 : nullptr;
             ep.fin_bits = nullptr; ep.fin_dxhat = nullptr;
-            if (ep.fin_dc && d.CB <= 32 && uad_conv_f_supports_final_bwd(d, true, m->ws.floats) &&
+            if (bfm && ep.fin_dc && d.CB <= 32 && uad_conv_f_supports_final_bwd(d, true, m->ws.floats) &&
                 (want_backward == 2 || uad_conv_w_supports_fb_bits(d, true))) {
                 // both consumers of d loss / d c (this layer's data- and filter-gradient kernels) can expand it from one pattern word +
                 // one float per pixel: 8 B instead of 128 B per pixel written here and read twice in the backward
