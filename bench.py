@@ -88,6 +88,9 @@ def bytes_per_tag(n, fin_bits=True):
         if name == last and fin_bits:
             d_out = 8.0 * n * H * W
             by[f'{name}.fwd'] = b_in + d_out + 12.0 * n * H * W        # + target read, x_hat and L1 written
+        elif name == last:
+            # exact-fp32 mode (round 4: final conv + loss fused there too): d loss / d c leaves as fp32, in place of the block's output
+            by[f'{name}.fwd'] = b_in + b_out + 12.0 * n * H * W
         else:
             by[f'{name}.fwd'] = b_in + b_out
         by[f'{name}.dgrad'] = d_out + 2.0 * b_in
