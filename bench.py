@@ -700,14 +700,17 @@ def main():
                 import csv
                 doc = json.load(open(os.path.join(ROOT, 'profiles', tj)))
                 kname = doc[dom]['kernel']
-                cands = [row for row in csv.DictReader(open(os.path.join(ROOT, 'profiles', ks))) if kname in row['Name']]
+                rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', ks))))
+                cands = [row for row in rows if kname in row['Name']]
                 if cands:
                     row = max(cands, key=lambda r: float(r['TotalDurationNs']))
                     avg_ms = float(row['AverageNs']) * 1e-6
+                    per_step = min([int(r['Calls']) for r in rows if 'adam_kernel' in r['Name']] or [0])      # launches of a once-per-step kernel
+                    shared = per_step > 0 and int(row['Calls']) > per_step
                     rocprof = {'avg_launch_ms': round(avg_ms, 4), 'calls': int(row['Calls']), 'frac': round(fl[dom] / (avg_ms * 1e-3) / 1e12 / peak, 4),
                                'source': f'profiles/{ks} (bench.py --steps 10 --warmup 3 --quick --math {math} under rocprofv3 --kernel-trace --stats), '
                                          f'commit {doc.get("_commit")}; not re-measured in this run'
-                                         + ('; the summary row averages every launch of this kernel template (other layers share it)' if math == 'f32' else '')}
+                                         + ('; the summary row averages every launch of this kernel template (other layers share it)' if shared else '')}
             except Exception:
                 rocprof = None
         kernels = {t: {'ms': round(ms / c, 4), 'tflops': round(fl[t] / (ms / c * 1e-3) / 1e12, 2) if t in fl else None,

@@ -50,12 +50,12 @@ TAGS = {
     'final.fwd+bwd': ('final_kernel<true>', 32 * 64 * 256),
 } if MATH != 'f32' else {
     # exact-fp32 mode (v_mfma_f32_32x32x2_f32 kernels)
-    'dec3.fwd': ('conv5_d_kernel<8, 16, 32, 4, 1', 32 * 64 * 256),
+    'dec3.fwd': ('conv5_d_kernel<8, 16, 32, 4, 1, true', 32 * 64 * 256),       # round 4: the instance with the fused final epilogue
     'dec3.dgrad': ('conv5_f_kernel<8, 16, 16, 4, 1', 32 * 64 * 256),
     'dec2.dgrad': ('conv5_f_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
     'enc1.fwd': ('conv5_f_kernel<8, 8, 32, 2, 2', 16 * 64 * 256),
     'dec3.wgrad': ('conv5_w_kernel', 512 * 256),
-    'final.fwd+bwd': ('final_kernel<true>', 32 * 64 * 256),
+    'final.fwd+bwd': ('final_kernel<true>', 32 * 64 * 256),      # (only with UAD_NO_FUSED_FINAL_F32=1 since round 4)
 }
 out = {}
 for tag, (sub, grid) in TAGS.items():
