@@ -573,8 +573,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))
-    if os.environ.get('UAD_BENCH_REHEARSAL'):
+    # UAD_BENCH_REHEARSAL=nccl1 (with --gpus 1 under torch.distributed.run --nproc-per-node 1): this file's N > 1 code path -- process-group init from the launcher's
+    # environment, barriers, the MAX-reduced clock, the segmented backward with one async all-reduce per bucket, the no-all-reduce leg, the stand-alone segment
+    # timings -- under backend nccl (= RCCL) on the ONE rank a one-GPU box has.  Any other value: several ranks on cuda:0 over gloo.
+    nccl1 = os.environ.get('UAD_BENCH_REHEARSAL') == 'nccl1'
+    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL')) and not nccl1
+    if rehearsal:
         # several processes on ONE GPU: the fused bottleneck's groups of four sibling workgroups (uad_bott.hip) need all four resident at once; two processes'
         # kernels can hold each other's slots until the bounded exchange gives up (it reports, it does not hang).  The one-workgroup-per-sample form has no
         # inter-workgroup wait.  (One process per GPU -- the deployment this library is written for -- is unaffected.)
@@ -584,7 +588,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or nccl1
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world) if rehearsal else dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
@@ -620,7 +625,7 @@ def main():
         got = rng_fill(noise_jobs, BATCH, 1, step_no[0], rank * BATCH)
         step_no[0] += 1
         return got.pop('eps'), got
-    dp = DataParallelStep(eng, world)
+    dp = DataParallelStep(eng, world, force_collectives=True if nccl1 else None)
 
     def step():
         eps, masks = draw()
@@ -634,18 +639,18 @@ def main():
         per_round = []
         for _ in range(max(1, rounds)):
             torch.cuda.synchronize()
-            if world > 1:
+            if multi:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 out = step()
             torch.cuda.synchronize()
-            if world > 1:
+            if multi:
                 dist.barrier()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            if world > 1:
+            if multi:
                 t = torch.tensor([dt], device='cuda', dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
@@ -738,14 +743,14 @@ def main():
 
     # per-segment gradient all-reduce, timed on its own after the timed region (N > 1): what the backward has to hide
     allreduce = None
-    if world > 1:
+    if multi:
         # communication the backward did NOT hide = (step with the gradient all-reduces) - (same step without them), same ranks, same run
         dp.no_allreduce = True
         ndt, _, nround_ms = timed(args.steps, 2, args.rounds)
         dp.no_allreduce = False
         exposed_ms = (dt - ndt) / args.steps * 1e3
         names = {_lib.SEG_DECODER: 'decoder', _lib.SEG_BOTTLENECK: 'bottleneck', _lib.SEG_ENCODER_HI: 'encoder_deep', _lib.SEG_ENCODER_LO: 'encoder_first_blocks'}
-        allreduce = {'ranks': dist.get_world_size(), 'backend': dist.get_backend() + (' (RCCL over xGMI)' if not rehearsal else ' (single-GPU rehearsal)'),
+        allreduce = {'ranks': dist.get_world_size(), 'backend': dist.get_backend() + (' (single-GPU rehearsal)' if rehearsal else ' (RCCL, one rank: code-path rehearsal)' if nccl1 else ' (RCCL over xGMI)'),
                      'buckets': dp.buckets, 'bucket_bytes': [int(c * 4) for _, _, c in dp.plan],
                      'exposed_comm_ms': round(exposed_ms, 4), 'ms_per_step_without_allreduce': round(ndt / args.steps * 1e3, 4),
                      'round_ms_per_step_without_allreduce': nround_ms,
@@ -838,7 +843,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.quick and not cevae:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
