@@ -147,6 +147,14 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
 /* gradient of `loss` w.r.t. every parameter into the UAD_BUF_GRADS buffer; segment = UAD_SEG_* (call DECODER,
  * BOTTLENECK, ENCODER in that order -- ENCODER may be given as ENCODER_HI followed by ENCODER_LO -- or UAD_SEG_ALL). */
 int uad_backward(uad_model_t* m, int segment, void* stream);
+/* Data-parallel form of a segmented uad_backward: the same launches, but a segment whose parameter gradients are all written on the handle's
+ * own side stream (DECODER, BOTTLENECK where it runs fused, ENCODER_HI) returns WITHOUT making `stream` wait for that side stream -- three stalls of
+ * `stream` per step (each exposing the tail of a slab reduction) that only the collective needs, not the next segment's kernels.  *ready_stream
+ * receives the stream in whose order the segment's gradient slice is complete: the side stream where the join was skipped, else `stream`.  The caller
+ * issues the slice's all-reduce in THAT stream's order (torch: dist.all_reduce under torch.cuda.stream(ExternalStream(ready))) and goes on with the
+ * next segment on `stream`.  The last segment (ENCODER / ENCODER_LO) always joins: after it every gradient is complete in `stream`'s order too.
+ * The reference has no counterpart (single process); parallel.DataParallelStep is the caller. */
+int uad_backward_deferred(uad_model_t* m, int segment, void* stream, void** ready_stream);
 /* TF-1.15 Adam: t += 1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps); grads scaled by grad_scale first */
 int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 /* the other optimizers of DLMODEL.create_optimizer (trainers/DLMODEL.py:113-123) with TF-1.15's update rules; the two slot buffers are the

@@ -116,6 +116,24 @@ def test_segmented_backward_equals_the_whole_one(arch, h, zdim, n):
     assert torch.equal(eng.buffer(_lib.BUF_GRADS), whole)
     with pytest.raises(Exception):
         eng.backward(_lib.SEG_ENCODER_LO)                   # the forward state was consumed
+    # deferred joins (uad_backward_deferred, what DataParallelStep issues since round 4): a segment either is complete in the caller's stream
+    # (None) or names the stream it is complete in; the LAST segment always joins, after which the whole buffer is final in the caller's stream
+    eng.buffer(_lib.BUF_GRADS).zero_()
+    eng.forward(x, e, masks, want_backward=True)
+    deferred = 0
+    for s in SEGMENT_ORDER:
+        ready = eng.backward_deferred(s)
+        off, cnt = segs[s]
+        if ready is None:
+            torch.cuda.current_stream().synchronize()
+        else:
+            deferred += 1
+            assert s != _lib.SEG_ENCODER_LO
+            ready.synchronize()                             # ONLY the stream the call named
+        assert torch.equal(eng.buffer(_lib.BUF_GRADS)[off:off + cnt], whole[off:off + cnt]), ('deferred', s)
+    torch.cuda.current_stream().synchronize()
+    assert torch.equal(eng.buffer(_lib.BUF_GRADS), whole)
+    assert deferred >= 1                                    # (the decoder segment's reductions always sit on the side stream)
     eng.close()
 
 

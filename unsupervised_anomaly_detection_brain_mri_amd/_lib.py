@@ -89,6 +89,7 @@ SYMBOLS = {
     'uad_set_step': (C.c_int, [C.c_void_p, C.c_longlong]),
     'uad_forward': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_int, C.c_void_p]),
     'uad_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'uad_backward_deferred': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     'uad_check_fault': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'uad_adam_step': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_optimizer_step': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),

@@ -123,6 +123,7 @@ struct uad_model {
     float* fin_dxh;                    //   pixel + sign(x_hat - x) / n per pixel (UadEpilogue::fin_bits, UadXform::fb_bits)
     bool last_fin_bits;                // the last forward left its loss gradient in that form (G0 was not written)
     bool fwd_tail_is_loss;            // the last operation the last forward enqueued was its loss.finalize kernel (nothing the backward reads)
+    bool joined;                       // uad_backward_deferred: the segment just run ended with the side stream joined into the caller's
     bool last_fused_final;             // the last forward ran the last block's BN / final conv / loss inside the ConvT epilogue (its c is not written)
     std::vector<void*> allocs;
     // second stream + events of the backward pass; per-layer scratch touched by that stream
@@ -881,6 +882,8 @@ static void edge(uad_model* m, hipStream_t from, hipStream_t to) {
     (void)hipStreamWaitEvent(to, e, 0);
 }
 #define PROF_ON(tag, stream) ProfScope prof_scope_s_##__LINE__(m, tag, stream)
+// the side stream joined into the caller's stream: everything the handle has enqueued so far is complete in the caller's stream order
+static void join_side(uad_model* m, hipStream_t st) { edge(m, m->side, st); m->joined = true; }
 
 static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
     const int n = m->last_n;
@@ -935,7 +938,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
         float* tsw = g; g = gn; gn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
-    if (join_now) edge(m, sd, st);         // join: decoder gradients complete (inside UAD_SEG_ALL the join is the encoder segment's)
+    if (join_now) join_side(m, st);        // join: decoder gradients complete (inside UAD_SEG_ALL the join is the encoder segment's)
     return UAD_OK;
 }
 
@@ -1006,7 +1009,7 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
                 uad_launch_bn_grad_finalize(cp, uad_bottleneck_colpart_rows(ba, n), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma), Gr(m, EL.beta), Gr(m, EL.b), sd);
             }
             float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;
-            if (join_now) edge(m, sd, st);
+            if (join_now) join_side(m, st);
             return UAD_OK;
         }
     }
@@ -1051,7 +1054,7 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
       uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d_b, false, m->ws.floats), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma),
                                   Gr(m, EL.beta), Gr(m, EL.b), sd); }
     float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;   // G0 = d loss / d c of the last encoder conv
-    edge(m, sd, st);   // join: bottleneck gradients complete (SIDE no longer reads dcb, now G1)
+    join_side(m, st);  // join: bottleneck gradients complete (SIDE no longer reads dcb, now G1)
     return UAD_OK;
 }
 
@@ -1096,7 +1099,7 @@ static int backward_gm_heads(uad_model* m, hipStream_t st) {
         uad_launch_gm_heads_wgrad(wa, Gr(m, base), sd);
     }
     float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;   // G0 = d loss / d c of the last encoder conv
-    edge(m, sd, st);
+    join_side(m, st);
     return UAD_OK;
 }
 
@@ -1111,12 +1114,12 @@ static int backward_spatial_z(uad_model* m, hipStream_t st) {
     edge(m, st, sd);
     if (!m->data_only) { PROF_ON("bn.gradfin", sd); uad_launch_bn_grad_finalize(cp, uad_spatial_z_bwd_blocks(rows), m->cenc, P(m, EL.gamma), rstd, Gr(m, EL.gamma), Gr(m, EL.beta), Gr(m, EL.b), sd); }
     float* tsw = m->G0; m->G0 = m->G1; m->G1 = tsw;   // G0 = d loss / d c of the last encoder conv
-    edge(m, sd, st);
+    join_side(m, st);
     return UAD_OK;
 }
 
 // part: 0 = the whole segment; 1 = ENCODER_HI (blocks >= 2, joined: their variables are complete); 2 = ENCODER_LO (the rest)
-static int backward_encoder(uad_model* m, hipStream_t st, int part) {
+static int backward_encoder(uad_model* m, hipStream_t st, int part, bool defer = false) {
     const int n = m->last_n;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
     hipStream_t sd = m->side;
@@ -1145,7 +1148,7 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
     }
     if (part == 1) {
         m->G0 = g; m->G1 = gn;
-        edge(m, sd, st);   // join: the deep blocks' gradients are complete
+        if (!defer) join_side(m, st);   // join: the deep blocks' gradients are complete (deferred: they are in the side stream's order)
         return UAD_OK;
     }
     UadConvDesc d0 = m->enc[0].d; d0.N = n;
@@ -1164,26 +1167,36 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part) {
                                     m->last_io.anomaly, nullptr, st);
     }
     m->G0 = g; m->G1 = gn;
-    edge(m, sd, st);   // join: all gradients complete
+    join_side(m, st);  // join: all gradients complete
     return UAD_OK;
 }
 
-int uad_backward(uad_model_t* m, int segment, void* stream) {
+// defer: a segment whose gradient writes all sit on the side stream (DECODER, the fused BOTTLENECK, ENCODER_HI) ends WITHOUT the side -> caller join
+static int backward_impl(uad_model_t* m, int segment, void* stream, bool defer) {
     if (!m) return fail(UAD_ERR_INVALID, "null model");
     if (!m->have_fwd) return fail(UAD_ERR_INVALID, "uad_backward without a preceding uad_forward(want_backward=1)");
     if (segment < UAD_SEG_ALL || segment > UAD_SEG_ENCODER_LO) return fail(UAD_ERR_INVALID, "bad segment %d", segment);
     hipStream_t st = (hipStream_t)stream;
     int rc = UAD_OK;
-    if (segment == UAD_SEG_ALL || segment == UAD_SEG_DECODER) rc = backward_decoder(m, st, segment == UAD_SEG_DECODER);
+    m->joined = false;
+    if (segment == UAD_SEG_ALL || segment == UAD_SEG_DECODER) rc = backward_decoder(m, st, segment == UAD_SEG_DECODER && !defer);
     if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_BOTTLENECK))
         rc = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL ? backward_gm_heads(m, st)
-             : m->cfg.arch == UAD_ARCH_AE_SPATIAL ? backward_spatial_z(m, st) : backward_bottleneck(m, st, segment == UAD_SEG_BOTTLENECK);
-    if (rc == UAD_OK && segment == UAD_SEG_ENCODER_HI) rc = backward_encoder(m, st, 1);
+             : m->cfg.arch == UAD_ARCH_AE_SPATIAL ? backward_spatial_z(m, st) : backward_bottleneck(m, st, segment == UAD_SEG_BOTTLENECK && !defer);
+    if (rc == UAD_OK && segment == UAD_SEG_ENCODER_HI) rc = backward_encoder(m, st, 1, defer);
     if (rc == UAD_OK && (segment == UAD_SEG_ALL || segment == UAD_SEG_ENCODER || segment == UAD_SEG_ENCODER_LO)) {
         rc = backward_encoder(m, st, segment == UAD_SEG_ENCODER_LO ? 2 : 0);
         m->have_fwd = false;
     }
     HIP_TRY(hipGetLastError());
+    return rc;
+}
+
+int uad_backward(uad_model_t* m, int segment, void* stream) { return backward_impl(m, segment, stream, false); }
+
+int uad_backward_deferred(uad_model_t* m, int segment, void* stream, void** ready_stream) {
+    const int rc = backward_impl(m, segment, stream, true);
+    if (rc == UAD_OK && ready_stream) *ready_stream = m->joined ? stream : (void*)m->side;
     return rc;
 }
 

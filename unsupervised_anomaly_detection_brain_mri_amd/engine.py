@@ -359,6 +359,20 @@ class Engine(_EvalOps):
     def backward(self, segment=_lib.SEG_ALL):
         _lib.check(self.lib.uad_backward(self.handle, segment, self._stream()))
 
+    def backward_deferred(self, segment):
+        """uad_backward_deferred: runs the segment and returns None when its gradient slice is complete in the current stream's order, else a
+        torch stream (the handle's side stream) in whose order it is -- the data-parallel layer issues the slice's all-reduce under that stream
+        instead of stalling the compute stream on it."""
+        cur = self._stream()
+        ready = C.c_void_p()
+        _lib.check(self.lib.uad_backward_deferred(self.handle, segment, cur, C.byref(ready)))
+        if (ready.value or 0) == (cur.value or 0):
+            return None
+        cache = self.__dict__.setdefault('_ext_streams', {})
+        if ready.value not in cache:
+            cache[ready.value] = torch.cuda.ExternalStream(ready.value, device=self.device)
+        return cache[ready.value]
+
     OPTIMIZERS = {'ADAM': 0, 'SGD': 1, 'MOMENTUM': 2, 'RMS': 3}
 
     def set_optimizer(self, kind='ADAM', momentum=0.9):

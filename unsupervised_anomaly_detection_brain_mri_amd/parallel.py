@@ -64,7 +64,12 @@ class DataParallelStep:
     difference of the two step times as the communication the backward did not hide.
     force_collectives (default: env UAD_DP_FORCE_COLLECTIVES): take the segmented backward + per-bucket all-reduce path even at world 1 (an
     all-reduce over one rank is the identity, so the step must end on the bits of the plain one): lets a ONE-GPU box run RCCL on the
-    engine-owned gradient view (tests/test_gpu_dp_nccl.py) before the 8-GPU node does."""
+    engine-owned gradient view (tests/test_gpu_dp_nccl.py) before the 8-GPU node does.
+    Deferred joins (round 4; env UAD_DP_NO_DEFER=1 turns them off): a segment's parameter gradients are written on the engine's side stream, and
+    `uad_backward(segment)` makes the compute stream wait for that stream before it returns -- three extra stalls per step, each exposing the tail of
+    a slab reduction (measured with RCCL on one rank: 1.07 ms per step against 0.86 for the unsegmented backward).  Only the collective needs that
+    order: `Engine.backward_deferred` skips the wait and names the stream the slice is complete in, the all-reduce is issued under THAT stream (the
+    process group's stream then waits for it, not the compute stream), and the compute stream goes straight on with the next segment."""
 
     def __init__(self, engine, world=None, buckets=None, no_allreduce=None, force_collectives=None):
         self.eng = engine
@@ -77,6 +82,7 @@ class DataParallelStep:
         self.buckets = int(buckets if buckets is not None else os.environ.get('UAD_DP_BUCKETS', '4'))
         self.plan = bucket_plan(self.segs, self.buckets)
         self.no_allreduce = bool(int(os.environ.get('UAD_DP_NO_ALLREDUCE', '0'))) if no_allreduce is None else bool(no_allreduce)
+        self.defer = not bool(int(os.environ.get('UAD_DP_NO_DEFER', '0'))) and hasattr(engine, 'backward_deferred')
 
     def broadcast_params(self, src=0):
         if self.world > 1 or self.force:
@@ -92,10 +98,14 @@ class DataParallelStep:
         works = []
         issue = {after: (off, cnt) for after, off, cnt in self.plan}
         for seg in SEGMENT_ORDER:
-            eng.backward(seg)
+            ready = eng.backward_deferred(seg) if self.defer else eng.backward(seg)      # a stream, or None = the current one
             off, cnt = issue.get(seg, (0, 0))
             if cnt > 0 and not self.no_allreduce:          # (the spatial AE has no bottleneck variables)
-                works.append(dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
+                if ready is not None:
+                    with torch.cuda.stream(ready):         # the collective is ordered behind the side stream's reductions, the compute stream is not
+                        works.append(dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
+                else:
+                    works.append(dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
         # local grads are d(mean over the local batch); sum / world = d(mean over the global batch)
