@@ -27,6 +27,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before the HIP runtime initialises (see the package's __init__): the engine's two streams and RCCL's need their own hardware queues
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 H = W = 128
 BATCH = 64
