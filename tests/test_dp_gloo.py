@@ -129,6 +129,13 @@ class _OracleEngine:
         off, cnt = self.segs[seg]
         self.grads[off:off + cnt] = self._full[off:off + cnt]
 
+    def backward_deferred(self, seg):
+        """Engine.backward_deferred's contract on a host without streams: the slice is complete in the caller's order -> None (the device engine
+        names its side stream for the first three segments; tests/test_gpu_model.py and tests/test_gpu_dp_nccl.py cover that form)."""
+        self.deferred_calls = getattr(self, 'deferred_calls', 0) + 1
+        self.backward(seg)
+        return None
+
     def adam_step(self, lr, beta1, beta2, eps, grad_scale):
         self.t += 1
         onn.adam_tf_step(self.flat, self.grads.numpy() * grad_scale, self.mm, self.vv, self.t, lr, beta1, beta2, eps)
