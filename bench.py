@@ -101,6 +101,43 @@ def bytes_per_tag(n, fin_bits=True):
     return by
 
 
+def spec_conv_tags(spec, h, n):
+    """{launch-group tag: (flop, algorithmic bytes)} of the k x k stride-2 conv / transposed-conv layers of ANY graph of the family, from the handle's
+    tensor table (names `...enc_conv2D_<i>/kernel` [k,k,cin,cout], `...dec_Conv2DT_<i>/kernel` [k,k,cout,cin]; models/customlayers.py:16-38): the
+    spatial GMVAE's bench line takes its roofline object from this (flops_per_tag / bytes_per_tag above are the VAE's closed forms; a CPU test holds the
+    two against each other).  fwd: input + output; dgrad: d_out + the producer's pre-BN output + d_in; wgrad: layer input + d_out -- fp32, read / written once."""
+    import re
+    enc, dec = {}, {}
+    for name, shape, *_ in spec:
+        m = re.search(r'enc_conv2D_(\d+)/kernel$', name)
+        if m:
+            enc[int(m.group(1))] = tuple(shape)
+        m = re.search(r'dec_Conv2DT_(\d+)/kernel$', name)
+        if m:
+            dec[int(m.group(1))] = tuple(shape)
+    out = {}
+    res = h
+    for i in sorted(enc):
+        k, _, cin, cout = enc[i]
+        big, small = res * res, (res // 2) ** 2
+        f = 2.0 * n * small * k * k * cin * cout
+        b_in, b_out = 4.0 * n * big * cin, 4.0 * n * small * cout
+        out[f'enc{i}.fwd'] = (f, b_in + b_out)
+        out[f'enc{i}.dgrad'] = (f, b_out + 2.0 * b_in)
+        out[f'enc{i}.wgrad'] = (f, b_in + b_out)
+        res //= 2
+    for i in sorted(dec):
+        k, _, cout, cin = dec[i]
+        small, big = res * res, (2 * res) ** 2
+        f = 2.0 * n * small * k * k * cin * cout
+        b_in, b_out = 4.0 * n * small * cin, 4.0 * n * big * cout
+        out[f'dec{i}.fwd'] = (f, b_in + b_out)
+        out[f'dec{i}.dgrad'] = (f, b_out + 2.0 * b_in)
+        out[f'dec{i}.wgrad'] = (f, b_in + b_out)
+        res *= 2
+    return out
+
+
 def train_flops_per_slice():
     """371.5 M MAC fwd -> 0.743 GFLOP; train step = 3x fwd minus the enc0 data-grad."""
     fwd_macs = sum(pos * k for _, pos, k in conv_layers())
@@ -262,6 +299,24 @@ def bench_gmvae(args):
                           'ms_per_restore_iteration': round(dt / args.steps / rs * 1e3, 4),
                           'algorithmic_tflops': round(value * rs * flop_slice_step / 1e12, 2), 'parallelism': f'replicas{world}'},
                'kernels': {t: {'ms': round(ms / c, 4)} for t, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}}
+        # roofline of the restoration iteration's dominant conv launch group, measured live (HIP events around the group, profiling pass above)
+        tags = spec_conv_tags(eng.spec, hh, bs)
+        conv = {t: ms / c for t, (c, ms) in rep.items() if t in tags}
+        if conv:
+            dom = max(conv, key=conv.get)
+            fl, by = tags[dom]
+            peak = PEAK_F32_MFMA_TFLOPS if args.math == 'f32' else PEAK_BF16_MFMA_TFLOPS / 3.0
+            alg, gbs = fl / (conv[dom] * 1e-3) / 1e12, by / (conv[dom] * 1e-3) / 1e9
+            for t in res['kernels']:
+                if t in tags:
+                    res['kernels'][t]['tflops'] = round(tags[t][0] / (conv[t] * 1e-3) / 1e12, 2)
+            res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(alg, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(alg / peak, 4),
+                               'mfma_fraction': round(alg / peak, 4), 'hbm_fraction': round(gbs / PEAK_HBM_GBS, 4), 'hbm_achieved_gbs': round(gbs, 1),
+                               'hbm_peak_gbs': PEAK_HBM_GBS, 'algorithmic_bytes_per_launch': int(by), 'algorithmic_flop_per_launch': int(fl),
+                               'traffic': None, 'avg_launch_ms': round(conv[dom], 4),
+                               'instruction': 'v_mfma_f32_32x32x2_f32 (exact fp32)' if args.math == 'f32' else
+                                              '3 x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = dense bf16 MFMA 2500 TFLOP/s / 3 products',
+                               'note': 'restoration iteration = forward + data-gradient backward: no filter gradients; traffic not collected for this command'}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
@@ -685,7 +740,9 @@ def main():
         by = bytes_per_tag(BATCH * (2 if cevae else 1), fin_bits=(math != 'f32'))
         gbs = by[dom] / (dom_ms * 1e-3) / 1e9
         traffic = None
-        for cand in (f'r04_traffic_{math}.json', f'r03_traffic_{math}.json', f'r02_traffic_{math}.json', f'r01_traffic_{math}.json'):
+        # the committed PMC passes and rocprofv3 summaries are of the DEFAULT command (VAE, 64 slices per launch): other workloads of this function carry none
+        evidence_applies = (not cevae) and args.arch == 'VAE' and BATCH == 64
+        for cand in (f'r04_traffic_{math}.json', f'r03_traffic_{math}.json', f'r02_traffic_{math}.json', f'r01_traffic_{math}.json') if evidence_applies else ():
             try:
                 doc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
                 tr = doc.get(dom)
@@ -702,7 +759,7 @@ def main():
         rocprof = None
         for tj, ks in ((f'r04_traffic_{math}.json', 'r04_z_kernel_stats.csv' if math != 'f32' else 'r04_z_kernel_stats_f32.csv'),
                        ('r03_traffic_bf16x3.json', 'r03_z_kernel_stats.csv') if math != 'f32' else (None, None)):
-            if rocprof is not None or tj is None:
+            if rocprof is not None or tj is None or not evidence_applies:
                 continue
             try:
                 import csv

@@ -319,3 +319,23 @@ def test_every_environment_switch_is_documented():
     readme = open(os.path.join(root, 'README.md')).read()
     missing = sorted(n for n in names if n not in readme)
     assert not missing, f'undocumented switches: {missing}'
+
+
+def test_bench_conv_tags_from_the_tensor_table():
+    """bench.spec_conv_tags (the spatial GMVAE line's roofline: FLOP / algorithmic bytes of a launch group from the handle's tensor table) against the VAE's
+    closed forms (bench.flops_per_tag / bytes_per_tag) and SURVEY.md 8d's per-slice figure of the 256 x 256 restoration pass."""
+    import bench
+    from oracle import gmvae as og
+    from oracle import vae as ov
+    n = 64
+    tags = bench.spec_conv_tags(ov.param_spec('VAE', 128, 128, 1, 8, 128), 128, n)
+    fl, by = bench.flops_per_tag(n), bench.bytes_per_tag(n, fin_bits=False)
+    assert set(tags) == set(fl)
+    for t in fl:
+        assert tags[t][0] == fl[t], t
+        if t != 'dec3.fwd':                      # (the fused last block also reads the target and writes x_hat / L1: 12 B per pixel more)
+            assert tags[t][1] == by[t], t
+    assert by['dec3.fwd'] - tags['dec3.fwd'][1] == 12.0 * n * 128 * 128
+    g = bench.spec_conv_tags(og.param_spec(256, 256, 1, 8, 9, 1, 1), 256, 1)
+    per_slice = sum(v[0] for k, v in g.items() if k.endswith('.fwd')) + sum(v[0] for k, v in g.items() if k.endswith('.dgrad') and k != 'enc0.dgrad')
+    assert abs(per_slice / 4.88e9 - 1.0) < 0.01          # SURVEY.md 8d counts the 1 x 1 heads and the final conv too (0.6 %)
