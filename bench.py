@@ -788,8 +788,31 @@ def main():
                 'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'rocprof': rocprof, 'instruction': note}
         return roof, kernels
 
+    SPEC_CLOCK_GHZ = 2.4
+
+    def with_clock(roof):
+        """The roofline peaks are priced at the 2.4 GHz spec clock; the chip runs this kernel mix under its power limit.  Measured here, live,
+        beside the same step (engine.shader_clock_under: a probe wave reads s_memtime against the 100 MHz s_memrealtime while steps run):
+        `clock_ghz_measured`, and every fraction re-priced at that clock (`frac_at_measured_clock` = frac x 2.4 / clock)."""
+        from unsupervised_anomaly_detection_brain_mri_amd.engine import shader_clock_under
+        try:
+            ghz = shader_clock_under(step, window_ms=30.0)
+        except Exception as e:            # an older library build behind UAD_LIB
+            roof['clock_ghz_measured'] = None
+            roof['clock_note'] = f'not measured: {e}'
+            return roof
+        roof['clock_ghz_spec'] = SPEC_CLOCK_GHZ
+        roof['clock_ghz_measured'] = round(ghz, 3)
+        roof['frac_at_measured_clock'] = round(roof['frac'] * SPEC_CLOCK_GHZ / ghz, 4)
+        if roof.get('rocprof'):
+            roof['rocprof']['frac_at_measured_clock'] = round(roof['rocprof']['frac'] * SPEC_CLOCK_GHZ / ghz, 4)
+        roof['clock_note'] = ('shader clock sustained under this step (whole-chip DVFS), sampled for 30 ms by one probe wave beside the running steps; '
+                              'peak x clock / 2.4 GHz is the matrix-pipe ceiling at that clock')
+        return roof
+
     dt, loss, round_ms = timed(args.steps, args.warmup, args.rounds)
     roof, kernels = profiled(args.math)
+    roof = with_clock(roof)
     # the other math mode, same handle, for the record (rank 0 / single GPU only; not the headline value)
     other = None
     if world == 1 and not args.quick:
@@ -797,6 +820,7 @@ def main():
         eng.set_math(om)
         odt, _, oround_ms = timed(args.steps, max(2, args.warmup), args.rounds)
         oroof, _ = profiled(om)
+        oroof = with_clock(oroof)
         other = {'math': om, 'value': round(BATCH * args.steps / odt, 1), 'ms_per_step': round(odt / args.steps * 1e3, 4),
                  'round_ms_per_step': oround_ms, 'roofline': oroof}
         eng.set_math(args.math)
@@ -892,6 +916,8 @@ def main():
             'algorithmic_tflops': res['config']['step_tflops'], 'mfma_fraction': round(res['config']['step_tflops'] / roof['peak'], 4),
             'algorithmic_gbytes': round(step_bytes / 1e9, 3),
             'hbm_fraction': round(step_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 4),
+            'mfma_fraction_at_measured_clock': (round(res['config']['step_tflops'] / roof['peak'] * SPEC_CLOCK_GHZ / roof['clock_ghz_measured'], 4)
+                                                if roof.get('clock_ghz_measured') else None),
             'note': 'conv launch groups only (the first / final single-channel kernels, the bottleneck and Adam add < 8 % of the bytes)'}
         if other:
             res['other_math_mode'] = other

@@ -155,6 +155,28 @@ int uad_backward(uad_model_t* m, int segment, void* stream);
  * next segment on `stream`.  The last segment (ENCODER / ENCODER_LO) always joins: after it every gradient is complete in `stream`'s order too.
  * The reference has no counterpart (single process); parallel.DataParallelStep is the caller. */
 int uad_backward_deferred(uad_model_t* m, int segment, void* stream, void** ready_stream);
+/* ---- library-issued gradient all-reduce (RCCL over xGMI) -------------------------------------------------------------
+ * SURVEY.md section 8b's `allreduce_attach(comm)`.  The reference is single-process; under slice-batch data parallelism (one process per GPU) the
+ * flat fp32 gradient buffer is summed over the ranks once per step.  With a communicator attached the LIBRARY enqueues ncclAllReduce itself --
+ * in place on its own gradient buffer, on a stream of its own that one event orders behind the side stream's slab reductions of the bucket --
+ * while the caller's stream runs on with the next backward segment: no process-group hand-off per collective (torch.distributed costs an event
+ * record + wait on both sides of every all-reduce, 40-80 us per step at four buckets).  librccl.so.1 is bound at run time (dlopen; the copy the
+ * process already holds, e.g. PyTorch-ROCm's, else the loader path or UAD_RCCL_LIB): libuad_hip.so does not link it.
+ *   uad_rccl_unique_id      rank 0: a fresh ncclUniqueId (128 bytes) -- hand it to the other ranks by any channel (parallel.py: one broadcast over
+ *                           the existing torch.distributed group)
+ *   uad_rccl_comm_create    every rank, on its own device: ncclCommInitRank(world, id, rank) -> opaque communicator (collective call)
+ *   uad_rccl_allreduce      in-place float sum over the ranks of any device buffer, enqueued on `stream` (the GAN handle's per-phase group gradient)
+ *   uad_allreduce_attach    comm + bucket plan: bucket i = gradient elements [offset[i], offset[i] + count[i]), all-reduced right after backward segment
+ *                           after_segment[i] (UAD_SEG_DECODER | BOTTLENECK | ENCODER_HI | ENCODER_LO); comm == NULL detaches.  The caller applies
+ *                           grad_scale = 1 / world in uad_adam_step (the sum of per-rank batch-mean gradients / world = the global batch mean).
+ *   uad_backward_allreduce  one backward segment (as uad_backward_deferred: DECODER, BOTTLENECK, ENCODER_HI, ENCODER_LO in this order) + its buckets'
+ *                           all-reduces; after ENCODER_LO `stream` has been made to wait for every bucket, so the optimizer step can follow on it. */
+int uad_rccl_unique_id(void* id_out, int cap);
+int uad_rccl_comm_create(const void* id_bytes, int world, int rank, void** comm_out);
+int uad_rccl_comm_destroy(void* comm);
+int uad_rccl_allreduce(void* comm, float* buf, long long count, void* stream);
+int uad_allreduce_attach(uad_model_t* m, void* comm, int world, int nbuckets, const int* after_segment, const long long* offset, const long long* count);
+int uad_backward_allreduce(uad_model_t* m, int segment, void* stream);
 /* TF-1.15 Adam: t += 1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps); grads scaled by grad_scale first */
 int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 /* the other optimizers of DLMODEL.create_optimizer (trainers/DLMODEL.py:113-123) with TF-1.15's update rules; the two slot buffers are the
@@ -164,10 +186,16 @@ enum { UAD_OPT_SGD = 1, UAD_OPT_MOMENTUM = 2, UAD_OPT_RMS = 3 };
 int uad_optimizer_step(uad_model_t* m, int kind, float lr, float momentum, float decay, float eps, float grad_scale, void* stream);
 /* Fault word of the fused bottleneck kernels (their sibling-workgroup exchange is bounded: uad_bott.hip).  A fault makes every optimizer launch
  * behind it a no-op ON THE DEVICE (parameters and slots stay those of the last good step) and is reported -- once, with the step counter rolled
- * back by the number of skipped updates -- by the next uad_forward / uad_get_buffer / uad_check_fault on the handle.  synchronize != 0 waits
+ * back by the number of skipped updates (every optimizer call since the FIRST faulted launch) -- by the next uad_forward / uad_get_buffer /
+ * uad_check_fault on the handle.  synchronize != 0 waits
  * for `stream` first (call it so at the end of an epoch, before a checkpoint, and -- under data parallelism -- before agreeing on the flag
  * across ranks: trainers/AEMODEL.py).  Returns UAD_OK when no fault is pending. */
 int uad_check_fault(uad_model_t* m, int synchronize, void* stream);
+/* on != 0: uad_forward / uad_get_buffer no longer report a pending fault -- only uad_check_fault does.  For data-parallel runs: a rank that raised
+ * alone in the middle of an epoch would leave the other ranks blocked in the next gradient all-reduce; with deferred reporting every rank keeps
+ * issuing the epoch's collectives (the faulted rank's optimizer launches stay no-ops on the device), all ranks agree on the word in the epoch's
+ * scalar all-reduce (trainers/AEMODEL.py: process) and raise TOGETHER; the run restarts from the last checkpoint.  Default off. */
+int uad_set_fault_deferred(uad_model_t* m, int on);
 /* uad_forward(want_backward=1) + uad_backward(ALL) + uad_adam_step */
 int uad_train_step(uad_model_t* m, const uad_io_t* io, int n, float lr, float beta1, float beta2, float eps,
                    void* stream);
@@ -238,6 +266,12 @@ int uad_scores_destroy(uad_scores_t* s);
 enum { UAD_RNG_NORMAL = 0, UAD_RNG_KEEP_MASK = 1 };
 typedef struct { float* out; int per_sample; int kind; float rate; int stream; } uad_rng_job_t;
 int uad_rng_fill(const uad_rng_job_t* jobs, int njobs, int n, unsigned long long seed, unsigned long long step, long long sample0, void* stream);
+
+/* ---- measurement: the shader clock under load ---------------------------------------------------------------------
+ * One wave, launched on `stream` (give it a stream of its own, beside the workload), samples s_memtime (shader cycles) and s_memrealtime
+ * (100 MHz) for ticks_100mhz ticks and writes out2[0] = shader cycles, out2[1] = 100 MHz ticks (device memory): clock [GHz] =
+ * out2[0] / out2[1] / 10.  bench.py prices `roofline.frac` at the 2.4 GHz spec clock and reports `frac_at_measured_clock` beside it. */
+int uad_clock_probe(unsigned long long* out2, unsigned long long ticks_100mhz, void* stream);
 
 /* ---- batch assembly from an HBM-resident slice cache ------------------------------------------------------------
  * Replaces the host-side batch slicing of dataloaders/BRAINWEB.py:411-478 (`next_batch`: images[images_in_set[start:end]], the label

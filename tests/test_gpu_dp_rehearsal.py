@@ -177,3 +177,56 @@ def test_two_rank_train_step_equals_big_batch(tmp_path):
         assert r['loss_dp'] == pytest.approx(r['loss_1'], rel=2e-4), (name, r)
         # one Adam step moves a weight by ~lr * sign(g): the DP and big-batch runs agree except where a gradient is rounding noise
         assert r['mean_diff'] <= 0.02 * r['mean_step'] and r['frac_far'] <= 0.01, (name, r)
+
+
+def _fault_worker(rank, world, port, tmp, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    if rank == 1:
+        os.environ['UAD_BOTT_FAULT'] = '1'          # this rank's fused bottleneck launches time out (uad_bott.hip: the bounded sibling exchange reports)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from unsupervised_anomaly_detection_brain_mri_amd import models, trainers
+        from unsupervised_anomaly_detection_brain_mri_amd.trainers import Phase
+        from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_config, get_options
+        from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset
+        # 128 x 128, zDim 128: the shape whose bottleneck runs as groups of four workgroups per sample (the form that has a sibling exchange)
+        opt = get_options(batchsize=2, learningrate=1e-3, numEpochs=1, outputWidth=128, outputHeight=128, zDim=128,
+                          config={'CHECKPOINTDIR': os.path.join(tmp, f'ck{rank}'), 'SAMPLEDIR': os.path.join(tmp, f'smp{rank}')})
+        ds = SyntheticDataset(8, 8, 128, 128, seed=4)              # two global batches of 2 x 2 slices per epoch
+        cfg = get_config(trainers.VAE, opt, 'ADAM', [8, 8], 0.0, ds)
+        cfg.quiet = True
+        tm = trainers.VAE(None, cfg, network=models.variational_autoencoder, seed=9, world=world, device='cuda:0')
+        try:
+            tm.process(ds, 0, Phase.TRAIN)
+            q.put((rank, 'NO-ERROR'))
+        except RuntimeError as e:
+            msg = str(e)
+            q.put((rank, 'OWN' if 'gave up waiting' in msg else 'OTHER' if 'another rank reported' in msg else 'UNEXPECTED ' + msg))
+        tm.engine.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bottleneck_fault_on_one_rank_is_raised_by_both_at_the_end_of_the_epoch(tmp_path):
+    """a rank whose fused bottleneck kernels time out must not raise alone out of a mid-epoch forward -- the other rank would block
+    in the next per-bucket all-reduce until the collective timeout.  Under data parallelism the handle reports faults only through uad_check_fault
+    (uad_set_fault_deferred), every rank issues every collective of the epoch, and the agreement row of the epoch's scalar all-reduce makes BOTH ranks
+    raise together.  Rank 1 runs with UAD_BOTT_FAULT=1; both must finish (no hang) with an error: rank 1 its own, rank 0 'another rank reported'."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fault_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0, 'a rank hung or crashed'
+    res = {}
+    while not q.empty():
+        k, v = q.get()
+        res[k] = v
+    assert res.get(1) == 'OWN', res
+    assert res.get(0) in ('OTHER', 'OWN'), res          # (two processes time-slicing ONE device may starve rank 0's own sibling groups too)

@@ -1,0 +1,70 @@
+#!/bin/bash
+# Round-5 GPU calls, one parameterised script (replaces the per-call r4_gpu<N>.sh files):  gpurun -- 'bash tools/r5_gpu.sh <step>'
+# Every step writes under gpurun_out/r5_<step>/ ; what is kept is copied to profiles/r05_<step>_*.
+export TMPDIR=/tmp
+STEP=${1:?step}
+OUT=gpurun_out/r5_$STEP; rm -rf $OUT; mkdir -p $OUT
+Q="--quick --no-cpu-baseline"
+case $STEP in
+a)  # verdict item 1, step A: issue-port micro-benchmark, shader clock under load, phase clocks of the dec3 filter gradient and of dec3.fwd, same-box baseline
+    timeout 120 tools/issue_ubench > $OUT/issue_ubench.log 2>&1
+    UAD_DBG=160 timeout 200 python bench.py --steps 5 --warmup 2 --rounds 1 $Q > $OUT/w_tr_phase.json 2> $OUT/w_tr_phase.log
+    UAD_DBG=64 timeout 200 python bench.py --steps 20 --warmup 30 --rounds 1 $Q > $OUT/d16s_phase.json 2> $OUT/d16s_phase.log
+    timeout 200 python bench.py --steps 50 --warmup 10 $Q > $OUT/bench_bf16x3.json 2> $OUT/bench_bf16x3.err
+    timeout 200 python bench.py --steps 30 --warmup 10 --math f32 $Q > $OUT/bench_f32.json 2> $OUT/bench_f32.err
+    cat $OUT/issue_ubench.log; grep -h "w5 CB\|wg0 w0\|wg5 w3\|wg10 w6" $OUT/w_tr_phase.log | head -40; grep -h "d16s wg" $OUT/d16s_phase.log | head -8
+    python - <<'PY'
+import json
+for f in ('bench_bf16x3', 'bench_f32'):
+    try:
+        d = json.load(open(f'gpurun_out/r5_a/{f}.json'))
+        r = d['roofline']
+        print(f, d['ms_per_step'], d['value'], r['kernel'], r['avg_launch_ms'], r['frac'], r.get('clock_ghz_measured'), r.get('frac_at_measured_clock'))
+    except Exception as e:
+        print(f, 'failed', e)
+PY
+    ;;
+b)  # f32 pipelined filter gradient (parity: same bits as the round-2 kernel) + A/B; library-issued RCCL tests; DP fault test
+    timeout 600 python -m pytest tests/test_gpu_dp_nccl.py tests/test_gpu_dp_rehearsal.py "tests/test_gpu_knobs.py::test_bottleneck_sibling_exchange_is_bounded_and_reports" -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15 > $OUT/pytest_dp.log
+    cat $OUT/pytest_dp.log
+    UAD_MATH=f32 timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_ops_large.py -m gpu -q -x -p no:cacheprovider -k "conv_w" 2>&1 | tail -5 > $OUT/pytest_w_f32.log
+    cat $OUT/pytest_w_f32.log
+    timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5 > $OUT/pytest_model.log
+    cat $OUT/pytest_model.log
+    for r in 1 2; do
+      UAD_NO_W_F32P=1 timeout 200 python bench.py --steps 30 --warmup 5 --math f32 $Q > $OUT/f32_old_$r.json 2>/dev/null
+      timeout 200 python bench.py --steps 30 --warmup 5 --math f32 $Q > $OUT/f32_new_$r.json 2>/dev/null
+    done
+    python - <<'PY'
+import json, glob
+for f in sorted(glob.glob('gpurun_out/r5_b/f32_*.json')):
+    try:
+        d = json.load(open(f)); k = d['kernels']
+        print(f.split('/')[-1], d['ms_per_step'], d['value'], ' '.join(f"{t}={k[t]['ms']*1e3:.1f}" for t in k if t.endswith('wgrad')))
+    except Exception as e:
+        print(f, 'failed', e)
+PY
+    ;;
+c)  # A/B of two library builds: ablibs/libA.so (before) vs the tree's (after); [TESTS="pytest args"] MODES="bf16x3 f32" bash tools/r5_gpu.sh c
+    [ -n "$TESTS" ] && { UAD_MATH=bf16x3 timeout 900 python -m pytest $TESTS -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4; }
+    for r in 1 2 3; do for v in A B; do for m in ${MODES:-bf16x3}; do
+      L=$PWD/ablibs/libA.so; [ $v = B ] && L=$PWD/unsupervised_anomaly_detection_brain_mri_amd/libuad_hip.so
+      UAD_LIB=$L timeout 200 python bench.py --steps 40 --warmup 5 --math $m $Q > $OUT/${m}_${v}_$r.json 2>/dev/null
+    done; done; done
+    python tools/ab_table.py $OUT $TAGS
+    ;;
+e)  # same-box A/B of two ENVIRONMENTS on the tree's library: ENVA="K=V .." ENVB="K=V .." MODES="bf16x3 f32" [TESTS="pytest args"] bash tools/r5_gpu.sh e
+    [ -n "$TESTS" ] && timeout 900 python -m pytest $TESTS -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4
+    for r in 1 2 3; do for v in A B; do for m in ${MODES:-bf16x3}; do
+      E="$ENVA"; [ $v = B ] && E="$ENVB"
+      env $E timeout 200 python bench.py --steps 40 --warmup 5 --math $m $Q > $OUT/${m}_${v}_$r.json 2>/dev/null
+    done; done; done
+    echo "A: $ENVA | B: $ENVB"
+    python tools/ab_table.py $OUT
+    ;;
+f)  # phase clocks of the filter-gradient kernel of the given math mode:  MODE=f32 bash tools/r5_gpu.sh f
+    UAD_DBG=160 timeout 200 python bench.py --steps 5 --warmup 2 --rounds 1 --math ${MODE:-f32} $Q > $OUT/phase.json 2> $OUT/phase.log
+    grep -h "w5 CB\|wg0 w\|wg5 w\|wg10 w" $OUT/phase.log | head -60
+    ;;
+*)  echo "unknown step $STEP"; exit 2;;
+esac

@@ -91,6 +91,13 @@ SYMBOLS = {
     'uad_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'uad_backward_deferred': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     'uad_check_fault': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'uad_rccl_unique_id': (C.c_int, [C.c_void_p, C.c_int]),
+    'uad_rccl_comm_create': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    'uad_rccl_comm_destroy': (C.c_int, [C.c_void_p]),
+    'uad_rccl_allreduce': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    'uad_allreduce_attach': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    'uad_backward_allreduce': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'uad_set_fault_deferred': (C.c_int, [C.c_void_p, C.c_int]),
     'uad_adam_step': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_optimizer_step': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'uad_train_step': (C.c_int, [C.c_void_p, C.POINTER(UadIO), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -114,6 +121,7 @@ SYMBOLS = {
     'uad_scores_dice': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     'uad_scores_destroy': (C.c_int, [C.c_void_p]),
     'uad_rng_fill': (C.c_int, [C.POINTER(UadRngJob), C.c_int, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_longlong, C.c_void_p]),
+    'uad_clock_probe': (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_void_p]),
     'uad_gan_create': (C.c_int, [C.POINTER(UadGanConfig), C.POINTER(C.c_void_p)]),
     'uad_gan_destroy': (C.c_int, [C.c_void_p]),
     'uad_gan_param_count': (C.c_longlong, [C.c_void_p]),

@@ -96,8 +96,12 @@ __device__ __forceinline__ void group_exchange(const UadBottArgs& a, int n, int 
         while (__hip_atomic_load(a.flags + n * Q + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
             __builtin_amdgcn_s_sleep(2);
             if (++polls > (1u << 22)) {
-                if (a.err) __hip_atomic_store(a.err, a.epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (a.err_dev) __hip_atomic_store(a.err_dev, a.epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // what the optimizer kernels read
+                // the FIRST fault wins (compare-and-swap from 0): the host counts the optimizer calls since THAT launch epoch, every one of which the
+                // device word has made a no-op; a later timeout must not move the epoch forward
+                unsigned zero = 0u;
+                if (a.err) __hip_atomic_compare_exchange_strong(a.err, &zero, a.epoch | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                zero = 0u;
+                if (a.err_dev) __hip_atomic_compare_exchange_strong(a.err_dev, &zero, a.epoch | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // what the optimizer kernels read
                 break;
             }
         }

@@ -1515,7 +1515,9 @@ static int gan_phase_body(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n
     // contractions in bf16x3 the last gradients of those chains (the generator's first LayerNorm gamma, the encoder's first kernel) sit at
     // 1.00-1.20e-4 of their tensor's max off the oracle -- at the parity bar, not inside it -- whether or not the critic between them is exact.
     // The critic phases (5 x 12 n sample-passes: pass A's x / x_ thirds, C, D and every filter gradient) hold 1e-4 in bf16x3 and carry the speed-up.
-    struct ExactPhase { uad_gan* m; bool on; ExactPhase(uad_gan* m_, bool on_) : m(m_), on(on_) { if (on) m->exact_from = 0; } ~ExactPhase() { if (on) m->exact_from = -1; } };
+    // (scope guard: EVERY way out of this function -- an early `return fail(...)`, a HIP_TRY -- leaves exact_from at -1; a stale value would silently
+    // route a later phase's or reconstruct()'s samples to the exact kernels.  The critic phase moves the mark by hand inside the guard's scope.)
+    struct ExactPhase { uad_gan* m; ExactPhase(uad_gan* m_, bool on) : m(m_) { m->exact_from = on ? 0 : -1; } ~ExactPhase() { m->exact_from = -1; } };
     ExactPhase exact_phase(m, rn && phase != UAD_GAN_DISCRIMINATOR);
 
     if (phase == UAD_GAN_GENERATOR) {

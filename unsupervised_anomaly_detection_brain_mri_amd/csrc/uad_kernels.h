@@ -313,6 +313,8 @@ void uad_launch_spatial_z_bwd(const float* dz, const float* c, const float* gamm
 struct UadRngJob { float* out; int per_sample; int kind; float rate; int stream; };
 void uad_launch_rng_fill(const UadRngJob* jobs, int njobs, int n, unsigned long long seed, unsigned long long step, long long sample0,
                          hipStream_t st);
+// shader-clock probe: one wave samples s_memtime / s_memrealtime for `ticks` 100 MHz ticks (uad_misc.hip: clock_probe_kernel)
+void uad_launch_clock_probe(unsigned long long* out, unsigned long long ticks, hipStream_t st);
 void uad_launch_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, hipStream_t st);
 void uad_launch_gather_mask(const unsigned char* labels, const int* idx, int n, long long slice_px, const unsigned char* lut,
                             float* out, hipStream_t st);

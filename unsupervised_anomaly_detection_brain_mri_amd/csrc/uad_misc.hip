@@ -993,6 +993,23 @@ void uad_launch_rng_fill(const UadRngJob* jobs, int njobs, int n, unsigned long 
                        (unsigned)step, (unsigned)(step >> 32), sample0);
 }
 
+namespace {
+// One wave that watches both clocks for `ticks` 100 MHz ticks: out[0] = shader cycles (s_memtime), out[1] = 100 MHz ticks (s_memrealtime).
+// Launched on a stream of its own beside a workload it measures the clock the chip actually sustains under that load (DVFS: the 2.4 GHz the
+// MFMA peaks are priced at is the ceiling, not what a power-limited kernel mix runs at).  It sleeps between samples: one wave slot, no issue pressure.
+__global__ void __launch_bounds__(64) clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
+    const unsigned long long r0 = wall_clock64();
+    const unsigned long long c0 = (unsigned long long)clock64();
+    unsigned long long r = r0;
+    while (r - r0 < ticks) { __builtin_amdgcn_s_sleep(64); r = wall_clock64(); }
+    const unsigned long long c1 = (unsigned long long)clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r - r0; }
+}
+}  // namespace
+void uad_launch_clock_probe(unsigned long long* out, unsigned long long ticks, hipStream_t st) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, out, ticks);
+}
+
 void uad_launch_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, hipStream_t st) {
     const long long f4 = slice_elems / 4;
     int bx = (int)((f4 + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;

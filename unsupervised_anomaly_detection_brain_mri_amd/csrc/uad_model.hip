@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is bound at run time (rccl_api below), libuad_hip.so does not link it
 #include "../../include/uad_hip.h"
 #include "uad_kernels.h"
 
@@ -105,7 +107,8 @@ struct uad_model {
     float* bott_xch; unsigned* bott_flags; unsigned bott_epoch;
     unsigned* bott_err_host; unsigned* bott_err_dev;      // pinned word the fused bottleneck kernels report a timed-out sibling exchange through
     unsigned* bott_fault;                                 // the same word in device memory: the optimizer kernels read it and skip their update
-    unsigned opt_epoch[64]; unsigned opt_calls;           // bottleneck launch epoch at each of the last optimizer calls (ring): how many updates a fault skipped
+    std::vector<unsigned> opt_epochs;                     // bottleneck launch epoch at every optimizer call since the last fault check: how many updates a fault skipped
+    bool fault_deferred;                                  // uad_set_fault_deferred: only uad_check_fault reports (data-parallel runs agree on the word first)
     float* bnfin_scratch;             // counters + partials of the 2-D BN-gradient finalize (SIDE stream only)
     float* bott_wpart;                // [4 * max_batch][2*cenc*cmid + cmid] shares of conv2d / conv2d_1's parameter gradients
     float *g_small[6];                // d_cb-side temporaries: dd, dz, dmu_raw, dls_raw, dflat, dflat2
@@ -126,6 +129,10 @@ struct uad_model {
     bool joined;                       // uad_backward_deferred: the segment just run ended with the side stream joined into the caller's
     bool last_fused_final;             // the last forward ran the last block's BN / final conv / loss inside the ConvT epilogue (its c is not written)
     std::vector<void*> allocs;
+    // library-issued gradient all-reduce (uad_allreduce_attach): RCCL communicator of this rank, the stream the collectives run on, the bucket plan
+    void* ar_comm; int ar_world; hipStream_t ar_stream; bool ar_own_stream;
+    int ar_nb; int ar_after[4]; long long ar_off[4], ar_cnt[4];
+    hipEvent_t ar_ev_in[4], ar_ev_out; bool ar_pending;
     // second stream + events of the backward pass; per-layer scratch touched by that stream
     hipStream_t side;
     std::vector<hipEvent_t> sync_events;
@@ -285,6 +292,8 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     m->step = 0;
     m->have_fwd = false;
     m->prof_on = false;
+    m->ar_comm = nullptr; m->ar_world = 1; m->ar_stream = nullptr; m->ar_own_stream = false; m->ar_nb = 0; m->ar_ev_out = nullptr; m->ar_pending = false;
+    for (int i = 0; i < 4; ++i) m->ar_ev_in[i] = nullptr;
     const int npool = ilog2i(H) - ilog2i(cfg->inter_res);
     m->n_pool = npool;
     if (npool < 1 || npool > 7) { delete m; return fail(UAD_ERR_UNSUPPORTED, "log2(height/inter_res) = %d: 1..7 conv blocks supported", npool); }
@@ -443,7 +452,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->bott_xch, NB * 4 * 2 * (size_t)cfg->zdim);
     { float* fl = nullptr; ALLOC(fl, NB * 4); m->bott_flags = reinterpret_cast<unsigned*>(fl); m->bott_epoch = 0; }
     m->bott_err_host = m->bott_err_dev = nullptr;
-    { float* fw = nullptr; ALLOC(fw, 4); m->bott_fault = reinterpret_cast<unsigned*>(fw); m->opt_calls = 0; }      // (ALLOC zero-fills)
+    { float* fw = nullptr; ALLOC(fw, 4); m->bott_fault = reinterpret_cast<unsigned*>(fw); m->opt_epochs.clear(); m->fault_deferred = false; }      // (ALLOC zero-fills)
     if (rc == UAD_OK && hipHostMalloc((void**)&m->bott_err_host, sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
         *m->bott_err_host = 0u;
         if (hipHostGetDevicePointer((void**)&m->bott_err_dev, m->bott_err_host, 0) != hipSuccess) m->bott_err_dev = nullptr;
@@ -504,6 +513,9 @@ int uad_destroy(uad_model_t* m) {
     if (!m) return UAD_OK;
     for (void* p : m->allocs) hipFree(p);
     for (hipEvent_t e : m->sync_events) (void)hipEventDestroy(e);
+    for (int i = 0; i < 4; ++i) if (m->ar_ev_in[i]) (void)hipEventDestroy(m->ar_ev_in[i]);
+    if (m->ar_ev_out) (void)hipEventDestroy(m->ar_ev_out);
+    if (m->ar_own_stream && m->ar_stream) (void)hipStreamDestroy(m->ar_stream);
     if (m->side) (void)hipStreamDestroy(m->side);
     if (m->bott_err_host) (void)hipHostFree(m->bott_err_host);
     delete m;
@@ -560,7 +572,7 @@ int uad_get_buffer(uad_model_t* m, int which, float* host, long long count) {
     float* p = buffer_ptr(m, which);
     if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "get_buffer: bad arguments");
     HIP_TRY(hipDeviceSynchronize());
-    { const int frc = check_fault(m); if (frc != UAD_OK) return frc; }      // (a checkpoint must not be written across an unreported fault)
+    if (!m->fault_deferred) { const int frc = check_fault(m); if (frc != UAD_OK) return frc; }      // (a checkpoint must not be written across an unreported fault; deferred mode: the trainer has agreed on the word before it saves)
     HIP_TRY(hipMemcpy(host, p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
     return UAD_OK;
 }
@@ -630,16 +642,20 @@ static int sk_counters(const uad_model* m);
 static int check_fault(uad_model* m) {
     if (!m->bott_err_host) return UAD_OK;
     const unsigned e = *reinterpret_cast<volatile unsigned*>(m->bott_err_host);
-    if (!e) return UAD_OK;
+    if (!e) {
+        // no fault so far: calls older than the newest one can no longer be "behind a fault" the host has not seen only if the stream is drained,
+        // which this function does not know -- keep the list, but bound it (a fault older than 65536 optimizer calls rolls back at most that many)
+        if (m->opt_epochs.size() > 65536) m->opt_epochs.erase(m->opt_epochs.begin(), m->opt_epochs.end() - 32768);
+        return UAD_OK;
+    }
     (void)hipDeviceSynchronize();            // error path: everything enqueued behind the fault has run (and skipped its update)
     *m->bott_err_host = 0u;
     if (m->bott_fault) (void)hipMemset(m->bott_fault, 0, sizeof(unsigned));
-    const unsigned ep = e & 0x7fffffffu;
+    const unsigned ep = e & 0x7fffffffu;     // launch epoch of the FIRST fault (group_exchange: compare-and-swap from 0)
     int skipped = 0;
-    for (unsigned k = 0; k < 64 && k < m->opt_calls; ++k)
-        if (m->opt_epoch[(m->opt_calls - 1 - k) & 63] >= ep) ++skipped;
+    for (unsigned oe : m->opt_epochs) if (oe >= ep) ++skipped;      // every optimizer launch since that epoch found the device word raised
     m->step -= skipped; if (m->step < 0) m->step = 0;
-    m->opt_calls = 0;
+    m->opt_epochs.clear();
     invalidate_pack(m);
     return fail(UAD_ERR_HIP, "fused bottleneck: a workgroup gave up waiting for its sibling workgroups (launch epoch %u); the results of that "
                              "step are invalid and %d optimizer update(s) behind it were skipped on the device (parameters and slots are those "
@@ -648,7 +664,14 @@ static int check_fault(uad_model* m) {
 int uad_check_fault(uad_model_t* m, int synchronize, void* stream) {
     if (!m) return fail(UAD_ERR_INVALID, "null model");
     if (synchronize) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return check_fault(m);
+    const int rc = check_fault(m);
+    if (rc == UAD_OK && synchronize) m->opt_epochs.clear();       // drained and clean: nothing enqueued so far sits behind a fault
+    return rc;
+}
+int uad_set_fault_deferred(uad_model_t* m, int on) {
+    if (!m) return fail(UAD_ERR_INVALID, "null model");
+    m->fault_deferred = on != 0;
+    return UAD_OK;
 }
 // (Plane-group tensors -- every producer also writing its ACTIVATED output pre-split into bf16 hi | lo groups for the consumers -- were built and
 // measured in round 3: parity-green, 2 % slower; removed in round 4, tools/experiments/r03_pruned_opt_in_paths.patch.)
@@ -656,7 +679,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
     if (n <= 0 || n > m->cfg.max_batch) return fail(UAD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", n, m->cfg.max_batch);
     if (!io->x) return fail(UAD_ERR_INVALID, "io.x is null");
-    { const int frc = check_fault(m); if (frc != UAD_OK) return frc; }
+    if (!m->fault_deferred) { const int frc = check_fault(m); if (frc != UAD_OK) return frc; }
     hipStream_t st = (hipStream_t)stream;
     const bool vae = m->cfg.arch == UAD_ARCH_VAE || m->cfg.arch == UAD_ARCH_CEVAE;
     const bool cevae = m->cfg.arch == UAD_ARCH_CEVAE;
@@ -1200,6 +1223,145 @@ int uad_backward_deferred(uad_model_t* m, int segment, void* stream, void** read
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------ library-issued RCCL all-reduce
+// RCCL is bound at run time: librccl.so.1 as the process already has it (the copy PyTorch-ROCm loads), else from the loader path.  libuad_hip.so
+// itself has no link-time dependency on it -- single-GPU users and the CPU-side symbol tests never touch it.
+namespace {
+struct RcclApi {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclAllReduce) allReduce = nullptr;
+    decltype(&ncclGetErrorString) errString = nullptr;
+    bool ok = false;
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.ok ? &api : nullptr;
+    tried = true;
+    const char* names[] = {getenv("UAD_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        if (!nm) continue;
+        api.h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);       // the copy the process already uses (torch's), if any
+        if (api.h) break;
+    }
+    for (const char* nm : names) {
+        if (api.h) break;
+        if (nm) api.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!api.h) return nullptr;
+    api.getUniqueId = reinterpret_cast<decltype(api.getUniqueId)>(dlsym(api.h, "ncclGetUniqueId"));
+    api.commInitRank = reinterpret_cast<decltype(api.commInitRank)>(dlsym(api.h, "ncclCommInitRank"));
+    api.commDestroy = reinterpret_cast<decltype(api.commDestroy)>(dlsym(api.h, "ncclCommDestroy"));
+    api.allReduce = reinterpret_cast<decltype(api.allReduce)>(dlsym(api.h, "ncclAllReduce"));
+    api.errString = reinterpret_cast<decltype(api.errString)>(dlsym(api.h, "ncclGetErrorString"));
+    api.ok = api.getUniqueId && api.commInitRank && api.commDestroy && api.allReduce && api.errString;
+    return api.ok ? &api : nullptr;
+}
+#define RCCL_API(A)                                                                                                         \
+    RcclApi* A = rccl_api();                                                                                                \
+    if (!A) return fail(UAD_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded or lacks the nccl* entry points (set UAD_RCCL_LIB to its path)")
+#define RCCL_TRY(A, expr)                                                                              \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) return fail(UAD_ERR_HIP, "%s failed: %s", #expr, (A)->errString(r_));   \
+    } while (0)
+}  // namespace
+
+int uad_rccl_unique_id(void* id_out, int cap) {
+    if (!id_out || cap < (int)sizeof(ncclUniqueId)) return fail(UAD_ERR_INVALID, "uad_rccl_unique_id: need a buffer of %d bytes", (int)sizeof(ncclUniqueId));
+    RCCL_API(api);
+    ncclUniqueId id;
+    RCCL_TRY(api, api->getUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return UAD_OK;
+}
+int uad_rccl_comm_create(const void* id_bytes, int world, int rank, void** comm_out) {
+    if (!id_bytes || !comm_out || world < 1 || rank < 0 || rank >= world) return fail(UAD_ERR_INVALID, "uad_rccl_comm_create: bad arguments");
+    RCCL_API(api);
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    ncclComm_t c = nullptr;
+    RCCL_TRY(api, api->commInitRank(&c, world, id, rank));        // collective over the ranks: every rank calls it with rank 0's id, on its own device
+    *comm_out = (void*)c;
+    return UAD_OK;
+}
+int uad_rccl_comm_destroy(void* comm) {
+    if (!comm) return UAD_OK;
+    RCCL_API(api);
+    RCCL_TRY(api, api->commDestroy((ncclComm_t)comm));
+    return UAD_OK;
+}
+int uad_rccl_allreduce(void* comm, float* buf, long long count, void* stream) {
+    if (!comm || !buf || count <= 0) return fail(UAD_ERR_INVALID, "uad_rccl_allreduce: bad arguments");
+    RCCL_API(api);
+    RCCL_TRY(api, api->allReduce(buf, buf, (size_t)count, ncclFloat, ncclSum, (ncclComm_t)comm, (hipStream_t)stream));
+    return UAD_OK;
+}
+
+int uad_allreduce_attach(uad_model_t* m, void* comm, int world, int nbuckets, const int* after_segment, const long long* offset, const long long* count) {
+    if (!m) return fail(UAD_ERR_INVALID, "null model");
+    if (!comm) { m->ar_comm = nullptr; m->ar_world = 1; m->ar_nb = 0; return UAD_OK; }      // detach
+    if (world < 1 || nbuckets < 1 || nbuckets > 4 || !after_segment || !offset || !count) return fail(UAD_ERR_INVALID, "uad_allreduce_attach: 1..4 buckets");
+    RCCL_API(api);
+    (void)api;
+    for (int i = 0; i < nbuckets; ++i) {
+        if (after_segment[i] < UAD_SEG_DECODER || after_segment[i] > UAD_SEG_ENCODER_LO || offset[i] < 0 || count[i] < 0 || offset[i] + count[i] > m->nparams)
+            return fail(UAD_ERR_INVALID, "uad_allreduce_attach: bucket %d (after segment %d, [%lld, +%lld)) outside the gradient buffer", i, after_segment[i], offset[i], count[i]);
+        m->ar_after[i] = after_segment[i]; m->ar_off[i] = offset[i]; m->ar_cnt[i] = count[i];
+    }
+    m->ar_nb = nbuckets; m->ar_comm = comm; m->ar_world = world;
+    // The collectives run on a stream of the handle's own (default), ordered behind the side stream by ONE event per bucket and joined into the
+    // caller's stream by one event before the optimizer step: the side stream goes straight on with the next layers' slab reductions while a
+    // ring is on the wire.  UAD_AR_STREAM=side enqueues them on the side stream itself (no event at all, but the reductions queue behind the ring).
+    static const bool on_side = getenv("UAD_AR_STREAM") && !strcmp(getenv("UAD_AR_STREAM"), "side");
+    if (on_side) { m->ar_stream = m->side; m->ar_own_stream = false; }
+    else if (!m->ar_own_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&m->ar_stream, hipStreamNonBlocking));
+        m->ar_own_stream = true;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (!m->ar_ev_in[i] && hipEventCreateWithFlags(&m->ar_ev_in[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
+            HIP_TRY(hipEventCreateWithFlags(&m->ar_ev_in[i], hipEventDisableTiming));
+    if (!m->ar_ev_out && hipEventCreateWithFlags(&m->ar_ev_out, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
+        HIP_TRY(hipEventCreateWithFlags(&m->ar_ev_out, hipEventDisableTiming));
+    return UAD_OK;
+}
+
+int uad_backward_allreduce(uad_model_t* m, int segment, void* stream) {
+    if (!m) return fail(UAD_ERR_INVALID, "null model");
+    if (!m->ar_comm) return fail(UAD_ERR_INVALID, "uad_backward_allreduce without uad_allreduce_attach");
+    if (segment == UAD_SEG_ALL || segment == UAD_SEG_ENCODER) return fail(UAD_ERR_INVALID, "uad_backward_allreduce runs ONE of DECODER, BOTTLENECK, ENCODER_HI, ENCODER_LO per call, in that order");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = backward_impl(m, segment, stream, true);
+    if (rc != UAD_OK) return rc;
+    RCCL_API(api);
+    hipStream_t ready = m->joined ? st : m->side;      // the stream in whose order this segment's gradients are complete
+    static const bool skip = getenv("UAD_AR_SKIP") != nullptr;       // measurement: everything but the ncclAllReduce call itself
+    for (int i = 0; i < m->ar_nb; ++i) {
+        if (m->ar_after[i] != segment || m->ar_cnt[i] == 0) continue;
+        if (m->ar_stream != ready) {
+            (void)hipEventRecord(m->ar_ev_in[i], ready);
+            (void)hipStreamWaitEvent(m->ar_stream, m->ar_ev_in[i], 0);
+        }
+        float* g = m->grads + m->ar_off[i];
+        if (!skip) RCCL_TRY(api, api->allReduce(g, g, (size_t)m->ar_cnt[i], ncclFloat, ncclSum, (ncclComm_t)m->ar_comm, m->ar_stream));
+        m->ar_pending = true;
+    }
+    if (segment == UAD_SEG_ENCODER_LO && m->ar_pending) {
+        // every bucket is on ar_stream's queue: the caller's stream (optimizer step next) waits for them once
+        if (m->ar_stream != st) {
+            (void)hipEventRecord(m->ar_ev_out, m->ar_stream);
+            (void)hipStreamWaitEvent(st, m->ar_ev_out, 0);
+        }
+        m->ar_pending = false;
+    }
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
 int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
     if (!m) return fail(UAD_ERR_INVALID, "null model");
     m->step += 1;
@@ -1207,7 +1369,7 @@ int uad_adam_step(uad_model_t* m, float lr, float beta1, float beta2, float eps,
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
     hipStream_t st = (hipStream_t)stream;
     invalidate_pack(m);
-    m->opt_epoch[m->opt_calls++ & 63] = m->bott_epoch;
+    m->opt_epochs.push_back(m->bott_epoch);
     { PROF("adam"); uad_launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr_t, beta1, beta2, eps, grad_scale, st, m->bott_fault); }
     repack_on_side(m, st);
     HIP_TRY(hipGetLastError());
@@ -1220,7 +1382,7 @@ int uad_optimizer_step(uad_model_t* m, int kind, float lr, float momentum, float
     m->step += 1;
     invalidate_pack(m);
     hipStream_t st = (hipStream_t)stream;
-    m->opt_epoch[m->opt_calls++ & 63] = m->bott_epoch;
+    m->opt_epochs.push_back(m->bott_epoch);
     { PROF("optim"); uad_launch_optim(kind, m->params, m->grads, m->adam_m, m->adam_v, (size_t)m->nparams, lr, momentum, decay, eps, grad_scale, st, m->bott_fault); }
     repack_on_side(m, st);
     HIP_TRY(hipGetLastError());
@@ -1345,6 +1507,13 @@ int uad_rng_fill(const uad_rng_job_t* jobs, int njobs, int n, unsigned long long
     return UAD_OK;
 }
 
+int uad_clock_probe(unsigned long long* out2, unsigned long long ticks_100mhz, void* stream) {
+    if (!out2 || ticks_100mhz == 0 || ticks_100mhz > 1000000000ull) return fail(UAD_ERR_INVALID, "clock_probe: null output or a duration outside (0, 10 s]");
+    uad_launch_clock_probe(out2, ticks_100mhz, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAD_OK;
+}
+
 int uad_gather_slices(const float* src, const int* idx, int n, long long slice_elems, float* out, void* stream) {
     if (!src || !idx || !out || n <= 0 || slice_elems <= 0 || slice_elems % 4) return fail(UAD_ERR_INVALID, "gather_slices: bad arguments (slice elements must be a multiple of 4)");
     if (n > 65535) return fail(UAD_ERR_UNSUPPORTED, "gather_slices: at most 65535 slices per call");
@@ -1391,22 +1560,24 @@ static int ws_for_op(const UadConvDesc& d, bool f_type, bool have_pack, UadGemmW
 // it takes the shape (everything else as bf16x3)
 static bool op_bf16x6() { const char* e = getenv("UAD_MATH"); return e && !strcmp(e, "bf16x6"); }
 static bool op_bf16x3() { const char* e = getenv("UAD_MATH"); return e && (!strcmp(e, "bf16x3") || !strcmp(e, "bf16x6")); }
-static int op_planes(const UadConvDesc& d, bool f_type) { return (op_bf16x6() && uad_conv_k3_takes(d, f_type)) ? 3 : 2; }
-static int pack_for_op(const UadConvDesc& d, const float* W, bool f_type, float** pf, float** pd, hipStream_t st) {
+// plain: identity activation on load, bias (+ addend) epilogue without `mul` -- what the k3 tap-list kernel takes besides the shape (uad_convk16.inc:
+// convk16_takes); any other launch of a k3 shape runs the generic kernels, which understand TWO planes only
+static int op_planes(const UadConvDesc& d, bool f_type, bool plain) { return (op_bf16x6() && plain && uad_conv_k3_takes(d, f_type)) ? 3 : 2; }
+static int pack_for_op(const UadConvDesc& d, const float* W, bool f_type, float** pf, float** pd, hipStream_t st, bool plain = false) {
     *pf = *pd = nullptr;
     if (!uad_conv_spatial_ok(d, f_type)) return UAD_OK;
     const size_t n = (size_t)d.KS * d.KS * d.CB * d.CS;
     HIP_TRY(hipMalloc((void**)pf, 2 * n * sizeof(float)));
     HIP_TRY(hipMalloc((void**)pd, 2 * n * sizeof(float)));
     long long off = 0; int cb = d.CB, cs = d.CS, taps = d.KS * d.KS;
-    if (op_planes(d, f_type) == 3) uad_launch_pack_weights_bf16_3p(W, (unsigned short*)*pf, (unsigned short*)*pd, &off, &cb, &cs, &taps, 1, st);
+    if (op_planes(d, f_type, plain) == 3) uad_launch_pack_weights_bf16_3p(W, (unsigned short*)*pf, (unsigned short*)*pd, &off, &cb, &cs, &taps, 1, st);
     else if (op_bf16x3()) uad_launch_pack_weights_bf16(W, (unsigned short*)*pf, (unsigned short*)*pd, &off, &cb, &cs, &taps, 1, st);
     else uad_launch_pack_weights(W, *pf, *pd, &off, &cb, &cs, &taps, 1, st);
     return UAD_OK;
 }
 // launch arguments for the op-level entry points in the selected math mode
-#define OP_PACK_ARGS(pk, d, f) (op_bf16x3() ? nullptr : (pk)), ws, (op_bf16x3() ? (const unsigned short*)(pk) : nullptr), \
-                               (long long)(d).KS * (d).KS * (d).CB * (d).CS, op_bf16x3(), op_planes(to_desc(&(d)), f)
+#define OP_PACK_ARGS(pk, d, f, plain) (op_bf16x3() ? nullptr : (pk)), ws, (op_bf16x3() ? (const unsigned short*)(pk) : nullptr), \
+                               (long long)(d).KS * (d).KS * (d).CB * (d).CS, op_bf16x3(), op_planes(to_desc(&(d)), f, plain)
 static int finish_op(float* pf, float* pd, hipStream_t st, float* wsp = nullptr) {
     if (pf || pd || wsp) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(pf); (void)hipFree(pd); (void)hipFree(wsp); }
     HIP_TRY(hipGetLastError());
@@ -1417,20 +1588,22 @@ int uad_op_conv_f(const uad_conv_desc_t* d, const float* big_in, const uad_xform
                   const float* mul, const float* add, float* small_out, void* stream) {
     if (int rc = check_gemm_desc(d, true)) return rc;
     float *pf = nullptr, *pd = nullptr;
-    if (int rc = pack_for_op(to_desc(d), W, true, &pf, &pd, (hipStream_t)stream)) return rc;
+    const bool plain = !(xf && xf->scale) && !mul;
+    if (int rc = pack_for_op(to_desc(d), W, true, &pf, &pd, (hipStream_t)stream, plain)) return rc;
     UadGemmWs ws;
     if (int rc = ws_for_op(to_desc(d), true, pf != nullptr, &ws)) return rc;
-    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pf, *d, true));
+    uad_launch_conv_f(to_desc(d), big_in, to_xf(xf), W, small_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pf, *d, true, plain));
     return finish_op(pf, pd, (hipStream_t)stream, ws.ptr);
 }
 int uad_op_conv_d(const uad_conv_desc_t* d, const float* small_in, const uad_xform_t* xf, const float* W, const float* bias,
                   const float* mul, const float* add, float* big_out, void* stream) {
     if (int rc = check_gemm_desc(d, false)) return rc;
     float *pf = nullptr, *pd = nullptr;
-    if (int rc = pack_for_op(to_desc(d), W, false, &pf, &pd, (hipStream_t)stream)) return rc;
+    const bool plain = !(xf && xf->scale) && !mul;
+    if (int rc = pack_for_op(to_desc(d), W, false, &pf, &pd, (hipStream_t)stream, plain)) return rc;
     UadGemmWs ws;
     if (int rc = ws_for_op(to_desc(d), false, pd != nullptr, &ws)) return rc;
-    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pd, *d, false));
+    uad_launch_conv_d(to_desc(d), small_in, to_xf(xf), W, big_out, epi_bias(bias, mul, add), (hipStream_t)stream, OP_PACK_ARGS(pd, *d, false, plain));
     return finish_op(pf, pd, (hipStream_t)stream, ws.ptr);
 }
 

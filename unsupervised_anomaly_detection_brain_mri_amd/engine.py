@@ -41,6 +41,32 @@ def rng_fill(jobs, n, seed, step, sample0=0, device=None, stream=None):
     return out
 
 
+def shader_clock_under(enqueue, window_ms=30.0, device=None):
+    """The shader clock [GHz] the GPU sustains while `enqueue()`'s work runs (include/uad_hip.h: uad_clock_probe): one probe wave on a stream
+    of its own samples s_memtime against the 100 MHz s_memrealtime for window_ms while the caller's work -- enqueue() is called until about
+    1.5 x window_ms of it is queued -- runs beside it on the current stream.  DVFS keeps a power-limited kernel mix well under the 2.4 GHz spec
+    clock the MFMA peaks are priced at; bench.py reports its roofline fraction at both."""
+    import time
+    lib = _lib.load()
+    dev = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    enqueue()
+    torch.cuda.synchronize(dev)
+    per_call = max(time.perf_counter() - t0, 1e-5)
+    calls = int(np.ceil(1.5 * window_ms * 1e-3 / per_call)) + 2
+    for _ in range(2):
+        enqueue()                                   # the load is running when the probe starts
+    _lib.check(lib.uad_clock_probe(C.c_void_p(out.data_ptr()), int(window_ms * 1e5), C.c_void_p(side.cuda_stream)))
+    for _ in range(calls):
+        enqueue()
+    torch.cuda.synchronize(dev)
+    cyc, ticks = (int(v) for v in out.cpu().tolist())
+    return cyc / max(ticks, 1) / 10.0
+
+
 class _EvalOps:
     """Model-independent device ops of the evaluation path (erosion, 3-D median, residual maps, sort-based metrics); shared by
     the AE-family Engine and the f-AnoGAN GanEngine.  Needs self.lib, self.device, self._dev, self._stream."""
@@ -133,6 +159,8 @@ class Engine(_EvalOps):
         h = C.c_void_p()
         _lib.check(self.lib.uad_create(C.byref(cfg), C.byref(h)))
         self.handle = h
+        # (parallel.DataParallelStep's torch.distributed/nccl path refuses a handle that is older than the process group: hardware-queue order)
+        self.created_before_process_group = not (torch.distributed.is_available() and torch.distributed.is_initialized())
         self.nparams = int(self.lib.uad_param_count(h))
         self.spec = []
         name = C.create_string_buffer(160)
@@ -179,6 +207,11 @@ class Engine(_EvalOps):
         """Raises RuntimeError when a fused bottleneck launch reported a timed-out sibling exchange (include/uad_hip.h: uad_check_fault);
         the optimizer updates behind such a launch were skipped on the device."""
         _lib.check(self.lib.uad_check_fault(self.handle, 1 if sync else 0, self._stream()))
+
+    def set_fault_deferred(self, on=True):
+        """Data-parallel runs: forward() / get_buffer_host() stop reporting a pending bottleneck fault; only check_fault() does, so that every rank
+        reaches the epoch's agreement collective (include/uad_hip.h: uad_set_fault_deferred)."""
+        _lib.check(self.lib.uad_set_fault_deferred(self.handle, 1 if on else 0))
 
     def grad_segment(self, seg):
         off, cnt = C.c_longlong(), C.c_longlong()
@@ -372,6 +405,23 @@ class Engine(_EvalOps):
         if ready.value not in cache:
             cache[ready.value] = torch.cuda.ExternalStream(ready.value, device=self.device)
         return cache[ready.value]
+
+    def allreduce_attach(self, comm, world, plan):
+        """uad_allreduce_attach: comm = a parallel.RcclComm (or None to detach), plan = [(segment after which to issue, offset, count)] as
+        parallel.bucket_plan returns it.  From then on backward_allreduce(segment) enqueues the buckets' RCCL all-reduces itself."""
+        if comm is None:
+            _lib.check(self.lib.uad_allreduce_attach(self.handle, None, 1, 0, None, None, None))
+            return
+        n = len(plan)
+        after = (C.c_int * n)(*[int(p[0]) for p in plan])
+        off = (C.c_longlong * n)(*[int(p[1]) for p in plan])
+        cnt = (C.c_longlong * n)(*[int(p[2]) for p in plan])
+        _lib.check(self.lib.uad_allreduce_attach(self.handle, C.c_void_p(comm.handle), int(world), n, after, off, cnt))
+        self._ar_comm = comm                  # keep the communicator alive as long as the handle refers to it
+
+    def backward_allreduce(self, segment):
+        """uad_backward_allreduce: one backward segment + the library-issued all-reduce of the buckets that complete with it."""
+        _lib.check(self.lib.uad_backward_allreduce(self.handle, segment, self._stream()))
 
     OPTIMIZERS = {'ADAM': 0, 'SGD': 1, 'MOMENTUM': 2, 'RMS': 3}
 

@@ -19,6 +19,50 @@ from . import _lib
 SEGMENT_ORDER = (_lib.SEG_DECODER, _lib.SEG_BOTTLENECK, _lib.SEG_ENCODER_HI, _lib.SEG_ENCODER_LO)
 
 
+class RcclComm:
+    """An RCCL communicator owned by libuad_hip.so (include/uad_hip.h: uad_rccl_*), one rank per process, created over an EXISTING torch.distributed
+    group: rank 0 draws the ncclUniqueId, one broadcast over the group hands it to the others, every rank joins with ncclCommInitRank on its current
+    device.  The library enqueues its all-reduces on this communicator itself -- torch's process group is only the bootstrap channel."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        self.lib = _lib.load()
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        idbuf = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.check(self.lib.uad_rccl_unique_id(idbuf, 128))
+        on_dev = dist.get_backend(group) == 'nccl'
+        t = torch.tensor(list(idbuf), dtype=torch.uint8, device='cuda' if on_dev else 'cpu')
+        if self.world > 1:
+            dist.broadcast(t, src=0, group=group)
+        raw = bytes(t.cpu().tolist())
+        comm = C.c_void_p()
+        torch.cuda.synchronize()
+        _lib.check(self.lib.uad_rccl_comm_create(raw, self.world, self.rank, C.byref(comm)))
+        self.handle = comm.value
+
+    def allreduce_(self, tensor, stream=None):
+        """In-place float32 sum over the ranks, enqueued on `stream` (default: the current stream); returns at once."""
+        import ctypes as C
+        assert tensor.dtype == torch.float32 and tensor.is_contiguous() and tensor.is_cuda
+        st = stream if stream is not None else torch.cuda.current_stream(tensor.device).cuda_stream
+        _lib.check(self.lib.uad_rccl_allreduce(C.c_void_p(self.handle), C.c_void_p(tensor.data_ptr()), tensor.numel(), C.c_void_p(st)))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            torch.cuda.synchronize()
+            self.lib.uad_rccl_comm_destroy(self.handle)
+            self.handle = None
+
+
+def _library_allreduce_default():
+    """The library-issued path is the default when the process group's backend is RCCL ("nccl") and UAD_DP_LIBRARY_AR is not 0."""
+    if os.environ.get('UAD_DP_LIBRARY_AR', '1') == '0':
+        return False
+    return dist.is_initialized() and dist.get_backend() == 'nccl'
+
+
 def allreduce_segments(grads_flat, segments, world, async_op=True):
     """grads_flat: 1-D tensor (device or CPU); segments: [(offset, count)] -> list of work handles."""
     works = []
@@ -71,7 +115,7 @@ class DataParallelStep:
     order: `Engine.backward_deferred` skips the wait and names the stream the slice is complete in, the all-reduce is issued under THAT stream (the
     process group's stream then waits for it, not the compute stream), and the compute stream goes straight on with the next segment."""
 
-    def __init__(self, engine, world=None, buckets=None, no_allreduce=None, force_collectives=None):
+    def __init__(self, engine, world=None, buckets=None, no_allreduce=None, force_collectives=None, library_allreduce=None):
         self.eng = engine
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.force = bool(int(os.environ.get('UAD_DP_FORCE_COLLECTIVES', '0'))) if force_collectives is None else bool(force_collectives)
@@ -83,6 +127,19 @@ class DataParallelStep:
         self.plan = bucket_plan(self.segs, self.buckets)
         self.no_allreduce = bool(int(os.environ.get('UAD_DP_NO_ALLREDUCE', '0'))) if no_allreduce is None else bool(no_allreduce)
         self.defer = not bool(int(os.environ.get('UAD_DP_NO_DEFER', '0'))) and hasattr(engine, 'backward_deferred')
+        # library-issued all-reduce (round 5; uad_allreduce_attach): the engine enqueues ncclAllReduce itself right behind each bucket's slab
+        # reductions -- no torch process-group hand-off per collective.  Needs RCCL (backend "nccl") and an engine with the export; the
+        # torch.distributed path below stays as the fallback (gloo CPU tests, UAD_DP_LIBRARY_AR=0).
+        want_lib = _library_allreduce_default() if library_allreduce is None else bool(library_allreduce)
+        self.comm = None
+        if want_lib and (self.world > 1 or self.force) and hasattr(engine, 'allreduce_attach'):
+            self.comm = RcclComm()
+            engine.allreduce_attach(self.comm, self.world, self.plan)
+        elif (self.world > 1 or self.force) and dist.is_initialized() and dist.get_backend() == 'nccl' and getattr(engine, 'created_before_process_group', False):
+            # torch path under RCCL: with the handle created BEFORE the communicator the process group's stream lands on a hardware queue it shares
+            # with a stream it waits for -- every all-reduce then costs ~0.2 ms of stall (measured).  Enforced, not only documented.
+            raise RuntimeError('DataParallelStep over torch.distributed/nccl: create the process group (init_process_group(..., device_id=...)) BEFORE the '
+                               'engine, or use the library-issued all-reduce (UAD_DP_LIBRARY_AR=1, the default)')
 
     def broadcast_params(self, src=0):
         if self.world > 1 or self.force:
@@ -94,6 +151,13 @@ class DataParallelStep:
         if self.world == 1 and not self.force:
             eng.backward(_lib.SEG_ALL)
             eng.adam_step(lr, beta1, beta2, adam_eps, 1.0)
+            return out
+        if self.comm is not None and not self.no_allreduce:
+            # library-issued: each call runs one backward segment and enqueues the all-reduce of the buckets it completes; after the last one the
+            # compute stream has been ordered behind every bucket
+            for seg in SEGMENT_ORDER:
+                eng.backward_allreduce(seg)
+            eng.adam_step(lr, beta1, beta2, adam_eps, 1.0 / self.world)
             return out
         works = []
         issue = {after: (off, cnt) for after, off, cnt in self.plan}
@@ -125,10 +189,16 @@ class GanDataParallel:
     slice equals the big-batch gradient.  One all-reduce per phase, over that group's slice only (Encoder 1.2 M, Generator
     1.5 M, Discriminator 0.7 M floats at 128x128)."""
 
-    def __init__(self, engine, world=None):
+    def __init__(self, engine, world=None, library_allreduce=None):
         self.eng = engine
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.grads = engine.buffer(_lib.BUF_GRADS) if self.world > 1 else None
+        # library-issued RCCL (round 5): the group's slice is all-reduced ON THE PHASE'S STREAM by libuad_hip.so's own communicator -- stream-ordered
+        # between the phase's last gradient kernel and the group's Adam launch, the host does not block and no process-group stream is involved.
+        # (The phases of a WGAN iteration form a dependency chain -- every forward reads the parameters the previous phase's Adam wrote -- so there is
+        # no later work the collective could legally overlap with; what the library path removes is the blocking host wait and the event hand-off.)
+        want_lib = _library_allreduce_default() if library_allreduce is None else bool(library_allreduce)
+        self.comm = RcclComm() if (want_lib and self.world > 1) else None
 
     def broadcast_params(self, src=0):
         if self.world > 1:
@@ -140,7 +210,10 @@ class GanDataParallel:
             # AnoVAE-GAN's 'Encoder' phase is optim_vae: Encoder + Generator variables (one contiguous slice)
             red = 'VAE' if (getattr(self.eng, 'variant', '') == 'anovaegan' and group == 'Encoder') else group
             off, cnt = self.eng.group(red)
-            dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM)
+            if self.comm is not None:
+                self.comm.allreduce_(self.grads[off:off + cnt])
+            else:
+                dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM)
         self.eng.adam(group, lr, beta1, beta2, adam_eps, 1.0 / self.world)
         return out
 

@@ -58,6 +58,10 @@ class AEMODEL(DLMODEL):
         self.checkpointDir = os.path.join(c.checkpointDir or 'checkpoints', self.network.__name__)
         self.engine = self._make_engine(device)
         self.dp = self._make_dp(world)
+        if getattr(self.dp, 'world', 1) > 1 and hasattr(self.engine, 'set_fault_deferred'):
+            # data parallel: a bottleneck fault is reported only by the agreement at the end of process() -- a rank raising alone out of a mid-epoch
+            # forward would leave the others blocked in the next gradient all-reduce
+            self.engine.set_fault_deferred(True)
         self.rng = np.random.default_rng(seed)       # host RNG: variable initialisation, and eps / masks when device_noise is off
         # eps / dropout masks of a step are drawn ON THE DEVICE by a counter-based generator keyed (seed, step, global sample index):
         # no host RNG, no H2D copy per step, and the same noise whichever rank holds the sample
@@ -241,7 +245,9 @@ class AEMODEL(DLMODEL):
                 run['reconstruction'], run['L1'] = out['x_hat'].cpu().numpy(), out['L1'].cpu().numpy()
                 visuals.append(get_summary_dict(b, run)[1])
         # Fault word of the fused bottleneck (uad_check_fault): read after a stream sync and agreed on across ranks IN the epoch's one collective
-        # (an extra table row), so that a rank whose kernels timed out does not raise alone while the others block in the next all-reduce.
+        # (an extra table row), so that a rank whose kernels timed out does not raise alone while the others block in the next all-reduce.  Under
+        # data parallelism the handle is in deferred-report mode (__init__): no forward of the loop above can have raised on one rank only, every
+        # rank has issued every collective of the epoch, and all ranks raise here together.
         fault = None
         if hasattr(self.engine, 'check_fault'):
             try:
@@ -294,15 +300,25 @@ class AEMODEL(DLMODEL):
     def train(self, dataset):       # trainers/VAE.py:31-74
         self.create_optimizer(type=getattr(self.config, 'optimizer', 'ADAM'))
         best_cost, last_improvement = inf, 0
-        # both splits must hold one global batch (batchsize x ranks): _num_batches raises the clear error NOW, not after the first TRAIN epoch
+        # TRAIN must hold one global batch (batchsize x ranks): _num_batches raises the clear error NOW, not after the first epoch.  A VAL split that
+        # is too small for one global batch -- the global batch grows with the rank count, so a split that validates on 1 GPU may not on 8 -- only
+        # switches validation and early stopping off, as before round 4 (a resumed run keeps working); said once, on rank 0.
         self._num_batches(dataset, Phase.TRAIN)
-        self._num_batches(dataset, Phase.VAL)
+        try:
+            self._num_batches(dataset, Phase.VAL)
+            have_val = True
+        except ValueError as e:
+            have_val = False
+            if self.rank == 0:
+                print(f'warning: {e}; training without validation / early stopping')
         last_epoch = self.load_checkpoint()
         for epoch in range(last_epoch, self.config.numEpochs):
             self.process(dataset, epoch, Phase.TRAIN, optim=True)
             last_epoch += 1
             if self.rank == 0:                      # replicas are identical: one writer
                 self.save(self.checkpointDir, last_epoch)
+            if not have_val:
+                continue
             val_scalars = self.process(dataset, epoch, Phase.VAL)
             best_cost, last_improvement, stop = indicate_early_stopping(val_scalars['loss'], best_cost, last_improvement)
             if stop:
