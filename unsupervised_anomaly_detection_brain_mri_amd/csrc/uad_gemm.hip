@@ -3045,192 +3045,6 @@ __global__ void __launch_bounds__(256) conv5_w_kernel(const ConvWArgs a, int til
     }
 }
 
-// Software-pipelined form of conv5_w_kernel (round 5): the same tile, tap-to-wave assignment, K order and slab layout -- hence the same bits -- but
-// the global loads of tile t + 1 are issued BEFORE tile t is contracted and sit in registers across its 200 MFMAs per wave (12 + 2 float4 per thread),
-// so a workgroup's life is [commit 14 LDS stores][MFMA loop] instead of [three dependent global round trips][LDS stores][MFMA loop].  The exact-fp32
-// products run at 64 matrix-pipe cycles per MFMA: the kernel is bound by that pipe as long as nothing else is serial with it, and the staging latency was
-// (rocprofv3, round 4: 7 x 73.6 us = 31 % of the f32 step at 0.58 of the fp32 matrix peak).  Index arithmetic of the staged elements is incremental
-// (element u + 1 of a thread is NT / 8 pixels further) instead of three divisions per 16 bytes.  UAD_NO_W_F32P=1 selects the round-2 kernel.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) conv5_w_f32p_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
-    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256;
-    __shared__ __attribute__((aligned(16))) float sBig[IH * IW * CK];
-    __shared__ __attribute__((aligned(16))) float sSmall[TH * TW * CK];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const UadConvDesc& d = a.d;
-    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32;
-    const int tilesx = d.WS / TW, tilesy = d.HS / TH;
-    const int t_begin = blockIdx.z * tiles_per_split;
-    const int t_end = min(t_begin + tiles_per_split, total_tiles);
-
-    const int cq = tid % CQ;
-    const bool xfa = a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
-    float4 scA = make_float4(1, 1, 1, 1), shA = make_float4(0, 0, 0, 0), scB = scA, shB = shA;
-    if (xfa) {
-        scA = *reinterpret_cast<const float4*>(a.xfb.scale + cb0 + cq * 4);
-        shA = *reinterpret_cast<const float4*>(a.xfb.shift + cb0 + cq * 4);
-        scA.x *= a.xfb.mult; scA.y *= a.xfb.mult; scA.z *= a.xfb.mult; scA.w *= a.xfb.mult;
-    }
-    if (xfs) {
-        scB = *reinterpret_cast<const float4*>(a.xfs.scale + cs0 + cq * 4);
-        shB = *reinterpret_cast<const float4*>(a.xfs.shift + cs0 + cq * 4);
-        scB.x *= a.xfs.mult; scB.y *= a.xfs.mult; scB.z *= a.xfs.mult; scB.w *= a.xfs.mult;
-    }
-
-    constexpr int MAXT = 7;
-    int aaddr[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-        const int tap = (j < MAXT - 1) ? wave + 4 * j : 24;
-        const int ky = tap / 5, kx = tap % 5;
-        aaddr[j] = ((ky * IW + kx) + 2 * lh) * CK + l31;
-    }
-    const int baddr = lh * CK + l31;
-
-    v16f acc[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    constexpr int TOT = IH * IW * CQ;                 // 2888 float4 of the big halo tile
-    constexpr int PER = (TOT + NT - 1) / NT;          // 12 per thread
-    constexpr int DP = NT / CQ, DIY = DP / IW, DIX = DP % IW;      // element u + 1 of a thread is DP pixels further: (iy, ix) += (DIY, DIX), one wrap
-    constexpr int SPER = TH * TW * CQ / NT;           // 2 float4 of the small tile per thread
-    const int pix0 = tid / CQ, iy0 = pix0 / IW, ix0 = pix0 % IW;
-    float4 v[PER], sv[SPER];
-    auto tile_origin = [&](int t, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
-        tx0 = (t % tilesx) * TW;
-        ty0 = ((t / tilesx) % tilesy) * TH;
-        n = t / (tilesx * tilesy);
-    };
-    auto issue = [&](int t) __attribute__((always_inline)) {
-        int n, ty0, tx0;
-        tile_origin(t, n, ty0, tx0);
-        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-        const float* bigb = a.big + (size_t)n * d.HB * d.WB * d.CB + cb0 + cq * 4;
-        int iy = iy0, ix = ix0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int gy = gy0 + iy, gx = gx0 + ix;
-            const bool ok = (u + 1 < PER || tid + u * NT < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
-            const int gp = ok ? (gy * d.WB + gx) : 0;
-            v[u] = *reinterpret_cast<const float4*>(bigb + (unsigned)(gp * d.CB));
-            ix += DIX; iy += DIY;
-            if (ix >= IW) { ix -= IW; ++iy; }
-        }
-        const float* smb = a.small_ + ((size_t)(n * d.HS + ty0) * d.WS + tx0) * d.CS + cs0 + cq * 4;
-#pragma unroll
-        for (int u = 0; u < SPER; ++u) {
-            const int pos = (tid + u * NT) / CQ;
-            sv[u] = *reinterpret_cast<const float4*>(smb + (unsigned)(((pos / TW) * d.WS + (pos % TW)) * d.CS));
-        }
-    };
-    auto commit = [&](int t) __attribute__((always_inline)) {
-        int n, ty0, tx0;
-        tile_origin(t, n, ty0, tx0);
-        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-        int iy = iy0, ix = ix0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const bool valid = u + 1 < PER || tid + u * NT < TOT;
-            const bool ok = valid && (unsigned)(gy0 + iy) < (unsigned)d.HB && (unsigned)(gx0 + ix) < (unsigned)d.WB;
-            if (valid) {
-                float4 tv = v[u];
-                if (xfa) tv = xform4(tv, scA, shA, a.xfb.alpha);
-                *reinterpret_cast<float4*>(sBig + (iy * IW + ix) * CK + cq * 4) = keep4(ok, tv);      // padding is zero AFTER the activation
-            }
-            ix += DIX; iy += DIY;
-            if (ix >= IW) { ix -= IW; ++iy; }
-        }
-#pragma unroll
-        for (int u = 0; u < SPER; ++u) {
-            const int pos = (tid + u * NT) / CQ;
-            float4 tv = sv[u];
-            if (xfs) tv = xform4(tv, scB, shB, a.xfs.alpha);
-            *reinterpret_cast<float4*>(sSmall + pos * CK + cq * 4) = tv;
-        }
-    };
-
-    // UAD_DBG = 32 + 128: per-wave phase clocks as in conv5_w_bf16_tr_kernel (barrier | commit | issue | barrier | fragment reads + MFMAs)
-    const bool ph_on = a.dbgbuf && (a.abl & 64) && lane == 0;
-    const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0, dbg_c0 = a.dbgbuf ? (unsigned long long)clock64() : 0;
-    unsigned long long ph[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
-    if (t_begin < t_end) issue(t_begin);
-    for (int t = t_begin; t < t_end; ++t) {
-        const unsigned long long c0 = ph_on ? wall_clock64() : 0ull;
-        __syncthreads();                   // the previous tile is consumed
-        const unsigned long long c1 = ph_on ? wall_clock64() : 0ull;
-        commit(t);
-        const unsigned long long c2 = ph_on ? wall_clock64() : 0ull;
-        if (t + 1 < t_end) issue(t + 1);   // in flight across the barrier and the MFMA loop below
-        const unsigned long long c3 = ph_on ? wall_clock64() : 0ull;
-        __syncthreads();
-        const unsigned long long c4 = ph_on ? wall_clock64() : 0ull;
-        // ONE basic block per tile: the six full taps over all 32 K-steps, then this wave's quarter of tap 24 (K-steps 8 wave .. 8 wave + 7) addressed by a
-        // run-time offset.  With the quarter as `if ((st >> 3) == wave)` inside the K loop (round 2) every K-step was its own basic block: seven LDS reads
-        // issued, then waited for, in front of six MFMAs -- the read latency exposed 32 times per tile.  Each accumulator still sums its K-steps in the same order.
-#pragma unroll
-        for (int st = 0; st < TH * TW / 2; ++st) {
-            // positions 2*st + lh: row st/4, column 2*(st%4) + lh
-            const int cst = ((2 * (st / 4)) * IW + 4 * (st % 4)) * CK;
-            const float bv = sSmall[baddr + (2 * st) * CK];
-#pragma unroll
-            for (int j = 0; j < MAXT - 1; ++j) {
-                const float av = sBig[aaddr[j] + cst];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-            }
-        }
-        {
-            const int a24 = aaddr[MAXT - 1] + wave * (4 * IW * CK), b24 = baddr + wave * (16 * CK);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float bv = sSmall[b24 + (2 * i) * CK];
-                const float av = sBig[a24 + ((2 * (i / 4)) * IW + 4 * (i % 4)) * CK];
-                acc[MAXT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[MAXT - 1], 0, 0, 0);
-            }
-        }
-        if (ph_on) { asm volatile("s_nop 0" ::: "memory"); const unsigned long long c5 = wall_clock64();
-            ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4; }
-    }
-
-    // accumulator block -> slab: one 64-bit address per lane, wave-uniform 32-bit offsets (as conv5_w_bf16_tr_kernel)
-    const int CSi = d.CS;
-    float* ob = a.partial + (size_t)blockIdx.z * a.Mtot * CSi + (size_t)(cb0 + 4 * lh) * CSi + cs0 + l31;
-    const int tapstride = d.CB * CSi;
-#pragma unroll
-    for (int j = 0; j < MAXT - 1; ++j) {
-        float* ot = ob + (wave + 4 * j) * tapstride;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2)) * CSi] = acc[j][r];
-    }
-    // tap 24: fixed-order sum of the four waves' quarter-tile partials
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sBig[(wave * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
-    __syncthreads();
-    if (wave == 0) {
-        float* ot = ob + 24 * tapstride;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            ot[((r & 3) + 8 * (r >> 2)) * CSi] = (sBig[r * 64 + lane] + sBig[(16 + r) * 64 + lane]) + (sBig[(32 + r) * 64 + lane] + sBig[(48 + r) * 64 + lane]);
-    }
-    if (a.dbgbuf && tid == 0) {
-        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.dbgbuf[2 * b] = dbg_t0;
-        a.dbgbuf[2 * b + 1] = wall_clock64();
-    }
-    if (ph_on) {
-        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        if (b < 16) {
-            unsigned long long* o = a.dbgbuf + 2 * 2048 + (b * 8 + wave) * 8;
-            for (int i = 0; i < 5; ++i) o[i] = ph[i];
-            o[5] = wall_clock64() - dbg_t0; o[6] = (unsigned long long)(t_end - t_begin); o[7] = (unsigned long long)clock64() - dbg_c0;
-        }
-    }
-}
-
 // bf16x3 form of the spatial filter gradient.  The contraction runs over positions, so the MFMA wants 8 consecutive
 // positions per lane for a fixed channel: the small tile is stored transposed ([cs][pos] bf16 planes -> one aligned
 // ds_read_b128 per fragment, shared by the wave's 6-7 taps), the big tile stays [pixel][cb] and each A fragment is
@@ -4504,9 +4318,7 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                 hipLaunchKernelGGL(conv5_w_bf16_kernel<1>, grid, dim3(256), conv5_w_bf16_lds_bytes(1), st, a, w5.tiles_per_split, w5.total_tiles);
             }
         } else {
-            static const bool f32p = !getenv("UAD_NO_W_F32P");        // software-pipelined tile loop (round 5); the round-2 kernel otherwise
-            if (f32p) hipLaunchKernelGGL(conv5_w_f32p_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
-            else hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
+            hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);
         }
         if (w5.splits > 1 && !defer_reduce) uad_launch_reduce_partials(partial, w5.splits, a.Mtot * d.CS, 1.0f, dW, hop());
         return;
