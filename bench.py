@@ -40,6 +40,29 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 dense MFMA peak
 PEAK_HBM_GBS = 8000.0
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """Rank 0 prints ONE JSON line on stdout -- and nothing else may: RCCL writes a start-up banner (version, host, library path) to file descriptor 1
+    when the first communicator of a process is created (torch.distributed's and the library's own alike).  From here on fd 1 points at stderr for
+    native code and Python alike; emit_json() writes the line to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    line = (json.dumps(obj) + '\n').encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, line)
+
+
 def conv_layers():
     """(tag-prefix, positions_per_slice, taps*CB*CS) of every k5 s2 conv block; MACs/slice = positions * taps*CB*CS."""
     layers = []
@@ -317,7 +340,7 @@ def bench_gmvae(args):
                                'instruction': 'v_mfma_f32_32x32x2_f32 (exact fp32)' if args.math == 'f32' else
                                               '3 x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = dense bf16 MFMA 2500 TFLOP/s / 3 products',
                                'note': 'restoration iteration = forward + data-gradient backward: no filter gradients; traffic not collected for this command'}
-        print(json.dumps(res))
+        emit_json(res)
     if world > 1:
         dist.destroy_process_group()
 
@@ -586,7 +609,7 @@ def bench_fanogan(args):
                                             for r in rows), key=lambda r: -r['avg_ms'] * r['calls'])[:24]
         if not args.no_cpu_baseline and not av:
             res['cpu_baseline'] = gan_cpu_baseline(args.variant, hh, zd)
-        print(json.dumps(res))
+        emit_json(res)
     if world > 1:
         dist.destroy_process_group()
 
@@ -611,6 +634,7 @@ def main():
                     help='fAnoGAN graph: resnet = models/fanogan_schlegl.py (the one BASELINE.json configs[3] names), unified = models/fanogan.py')
     ap.add_argument('--batch', type=int, default=0, help='slices per GPU (default 64 for VAE, 16 for ceVAE)')
     args = ap.parse_args()
+    claim_stdout()
     global BATCH
     BATCH = args.batch or (64 if args.arch in ('VAE', 'fAnoGAN') else 16)
     if args.arch == 'fAnoGAN' and args.variant == 'resnet' and not args.batch:
@@ -651,6 +675,10 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world) if rehearsal else dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
+    pre_comm = None
+    if multi and not rehearsal and os.environ.get('UAD_BENCH_COMM_FIRST'):      # experiment: the library's RCCL communicator created before the engine's streams
+        from unsupervised_anomaly_detection_brain_mri_amd.parallel import RcclComm
+        pre_comm = RcclComm()
     eng = Engine(args.arch, H, W, 1, INTER, ZDIM, max_batch=BATCH, device=f'cuda:{local_rank}', math=args.math)
     # identical glorot-uniform init on every rank (seed 3), zero bias, gamma 1, beta 0
     rng = np.random.default_rng(3)
@@ -683,7 +711,7 @@ def main():
         got = rng_fill(noise_jobs, BATCH, 1, step_no[0], rank * BATCH)
         step_no[0] += 1
         return got.pop('eps'), got
-    dp = DataParallelStep(eng, world, force_collectives=True if nccl1 else None)
+    dp = DataParallelStep(eng, world, force_collectives=True if nccl1 else None, comm=pre_comm)
 
     def step():
         eps, masks = draw()
@@ -928,7 +956,7 @@ def main():
             res['allreduce'] = allreduce
         if world == 1 and not args.no_cpu_baseline and not args.quick and not cevae:
             res['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(res))
+        emit_json(res)
     if multi:
         dist.destroy_process_group()
 

@@ -158,8 +158,8 @@ int uad_backward_deferred(uad_model_t* m, int segment, void* stream, void** read
 /* ---- library-issued gradient all-reduce (RCCL over xGMI) -------------------------------------------------------------
  * SURVEY.md section 8b's `allreduce_attach(comm)`.  The reference is single-process; under slice-batch data parallelism (one process per GPU) the
  * flat fp32 gradient buffer is summed over the ranks once per step.  With a communicator attached the LIBRARY enqueues ncclAllReduce itself --
- * in place on its own gradient buffer, on a stream of its own that one event orders behind the side stream's slab reductions of the bucket --
- * while the caller's stream runs on with the next backward segment: no process-group hand-off per collective (torch.distributed costs an event
+ * in place on its own gradient buffer, on its side stream right behind the slab reductions that complete the bucket (the last bucket: on the
+ * caller's stream in front of the optimizer step) -- while the caller's stream runs on with the next backward segment: no process-group hand-off per collective (torch.distributed costs an event
  * record + wait on both sides of every all-reduce, 40-80 us per step at four buckets).  librccl.so.1 is bound at run time (dlopen; the copy the
  * process already holds, e.g. PyTorch-ROCm's, else the loader path or UAD_RCCL_LIB): libuad_hip.so does not link it.
  *   uad_rccl_unique_id      rank 0: a fresh ncclUniqueId (128 bytes) -- hand it to the other ranks by any channel (parallel.py: one broadcast over

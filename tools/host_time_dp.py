@@ -54,10 +54,18 @@ if os.environ.get('HT_ONLY_PLAIN') or BACKEND == 'none':
     sys.exit(0)
 for defer in (False, True):
     for noar in (True, False):
-        dp = DataParallelStep(eng, 1, force_collectives=True, no_allreduce=noar)
+        dp = DataParallelStep(eng, 1, force_collectives=True, no_allreduce=noar, library_allreduce=False)
         dp.defer = defer
-        run(f'segmented defer={int(defer)} allreduce={int(not noar)}', dp)
+        run(f'torch PG: segmented defer={int(defer)} allreduce={int(not noar)}', dp)
 for b in (2, 1):
-    dp = DataParallelStep(eng, 1, force_collectives=True, buckets=b)
-    run(f'segmented defer=1 buckets={b}', dp)
+    dp = DataParallelStep(eng, 1, force_collectives=True, buckets=b, library_allreduce=False)
+    run(f'torch PG: defer=1 buckets={b}', dp)
+# round 5: the library enqueues ncclAllReduce itself (uad_allreduce_attach / uad_backward_allreduce); UAD_AR_STREAM=own in the environment gives the
+# collectives a stream of their own instead of the handle's side stream
+if BACKEND == 'nccl':
+    for b in (4, 2, 1):
+        dp = DataParallelStep(eng, 1, force_collectives=True, buckets=b, library_allreduce=True)
+        assert dp.comm is not None
+        run(f'library RCCL ({os.environ.get("UAD_AR_STREAM", "side") + " stream"}): buckets={b}', dp)
+    run(f'plain again (uad_backward ALL) [{BACKEND}]', DataParallelStep(eng, 1, force_collectives=False))
 dist.destroy_process_group()

@@ -66,5 +66,22 @@ f)  # phase clocks of the filter-gradient kernel of the given math mode:  MODE=f
     UAD_DBG=160 timeout 200 python bench.py --steps 5 --warmup 2 --rounds 1 --math ${MODE:-f32} $Q > $OUT/phase.json 2> $OUT/phase.log
     grep -h "w5 CB\|wg0 w\|wg5 w\|wg10 w" $OUT/phase.log | head -60
     ;;
+g)  # library-issued RCCL on one rank: step time of the plain step, the torch process-group path and the library path (own stream / side stream), same box
+    export GPU_MAX_HW_QUEUES=8
+    timeout 300 python tools/host_time_dp.py > $OUT/rccl_own_stream.log 2>&1; cat $OUT/rccl_own_stream.log | grep -v Warning
+    UAD_AR_STREAM=side timeout 300 python tools/host_time_dp.py 2>&1 | grep "library RCCL\|plain" > $OUT/rccl_side_stream.log; cat $OUT/rccl_side_stream.log
+    UAD_AR_SKIP=1 timeout 300 python tools/host_time_dp.py 2>&1 | grep "library RCCL\|plain" > $OUT/rccl_own_stream_skip.log; echo "UAD_AR_SKIP=1 (everything but the ncclAllReduce call):"; cat $OUT/rccl_own_stream_skip.log
+    UAD_AR_SKIP=1 UAD_AR_STREAM=side timeout 300 python tools/host_time_dp.py 2>&1 | grep "library RCCL\|plain" > $OUT/rccl_side_stream_skip.log; cat $OUT/rccl_side_stream_skip.log
+    UAD_BENCH_REHEARSAL=nccl1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 50 --warmup 10 $Q > $OUT/bench_nccl1.json 2> $OUT/bench_nccl1.err
+    python -c "import json; d = json.load(open('$OUT/bench_nccl1.json')); print(d['ms_per_step'], d['value'], json.dumps(d.get('allreduce'))[:600])"
+    ;;
+h)  # bench.py's N > 1 path under RCCL on one rank (UAD_BENCH_REHEARSAL=nccl1): torch path, library path, and orderings / queue counts of the library path
+    run1() { tag=$1; shift; env "$@" UAD_BENCH_REHEARSAL=nccl1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 50 --warmup 10 $Q > $OUT/$tag.json 2> $OUT/$tag.err
+      python -c "import json; s = open('$OUT/$tag.json').read(); d = json.loads(s[s.index('{'):]); a = d['allreduce']; print('$tag', 'stdout clean' if s.lstrip().startswith('{') else 'STDOUT POLLUTED', d['ms_per_step'], 'without all-reduce', a['ms_per_step_without_allreduce'], 'exposed', a['exposed_comm_ms'])"; }
+    run1 torch_pg UAD_DP_LIBRARY_AR=0
+    run1 library UAD_X=0
+    run1 library_own_stream UAD_AR_STREAM=own
+    [ -n "$MORE" ] && { run1 library_comm_first UAD_BENCH_COMM_FIRST=1; run1 library_q16 GPU_MAX_HW_QUEUES=16; run1 library_q4 GPU_MAX_HW_QUEUES=4; }
+    ;;
 *)  echo "unknown step $STEP"; exit 2;;
 esac

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>      // types and prototypes only: the library is bound at run time (rccl_api below), libuad_hip.so does not link it
 #include "../../include/uad_hip.h"
 #include "uad_kernels.h"
@@ -1284,7 +1285,15 @@ int uad_rccl_comm_create(const void* id_bytes, int world, int rank, void** comm_
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
     ncclComm_t c = nullptr;
-    RCCL_TRY(api, api->commInitRank(&c, world, id, rank));        // collective over the ranks: every rank calls it with rank 0's id, on its own device
+    // RCCL prints a start-up banner (version / host / library path) to STDOUT from rank 0's first communicator: a caller whose stdout is a protocol
+    // (bench.py's one JSON line) must not see it -- stdout is pointed at stderr for the duration of the call
+    fflush(stdout);
+    const int saved = dup(1);
+    if (saved >= 0) (void)dup2(2, 1);
+    const ncclResult_t r = api->commInitRank(&c, world, id, rank);        // collective over the ranks: every rank calls it with rank 0's id, on its own device
+    fflush(stdout);
+    if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
+    if (r != ncclSuccess) return fail(UAD_ERR_HIP, "ncclCommInitRank failed: %s", api->errString(r));
     *comm_out = (void*)c;
     return UAD_OK;
 }
@@ -1313,10 +1322,13 @@ int uad_allreduce_attach(uad_model_t* m, void* comm, int world, int nbuckets, co
         m->ar_after[i] = after_segment[i]; m->ar_off[i] = offset[i]; m->ar_cnt[i] = count[i];
     }
     m->ar_nb = nbuckets; m->ar_comm = comm; m->ar_world = world;
-    // The collectives run on a stream of the handle's own (default), ordered behind the side stream by ONE event per bucket and joined into the
-    // caller's stream by one event before the optimizer step: the side stream goes straight on with the next layers' slab reductions while a
-    // ring is on the wire.  UAD_AR_STREAM=side enqueues them on the side stream itself (no event at all, but the reductions queue behind the ring).
-    static const bool on_side = getenv("UAD_AR_STREAM") && !strcmp(getenv("UAD_AR_STREAM"), "side");
+    // Default: the collectives of the deferred segments are enqueued on the handle's SIDE stream, right behind the slab reductions that complete
+    // their bucket -- no event at all; the last bucket goes onto the caller's stream in front of the optimizer step.  Measured on one rank under RCCL
+    // (profiles/r05_d_rccl_one_rank.log): the step costs what the plain step costs (0.822 vs 0.822 ms; torch.distributed's path 0.858).
+    // UAD_AR_STREAM=own gives them a stream of their own (one event per bucket; the side stream's later reductions do not queue behind a ring) --
+    // not the default because a third stream per handle makes the step depend on how HIP maps streams to hardware queues: bench.py's own N > 1
+    // path read 1.54 ms per step with it (0.87 on the side stream) where tools/host_time_dp.py, creating its streams in another order, read 0.84.
+    static const bool on_side = !(getenv("UAD_AR_STREAM") && !strcmp(getenv("UAD_AR_STREAM"), "own"));
     if (on_side) { m->ar_stream = m->side; m->ar_own_stream = false; }
     else if (!m->ar_own_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&m->ar_stream, hipStreamNonBlocking));
@@ -1338,24 +1350,39 @@ int uad_backward_allreduce(uad_model_t* m, int segment, void* stream) {
     const int rc = backward_impl(m, segment, stream, true);
     if (rc != UAD_OK) return rc;
     RCCL_API(api);
-    hipStream_t ready = m->joined ? st : m->side;      // the stream in whose order this segment's gradients are complete
     static const bool skip = getenv("UAD_AR_SKIP") != nullptr;       // measurement: everything but the ncclAllReduce call itself
     for (int i = 0; i < m->ar_nb; ++i) {
         if (m->ar_after[i] != segment || m->ar_cnt[i] == 0) continue;
-        if (m->ar_stream != ready) {
-            (void)hipEventRecord(m->ar_ev_in[i], ready);
+        float* g = m->grads + m->ar_off[i];
+        if (m->joined) {
+            // The segment ended with the side stream joined into the caller's (the last one always does): its gradients are complete in the
+            // CALLER's stream order and the next thing on that stream is the optimizer step, which needs the reduced values anyway -- the
+            // collective goes straight onto the caller's stream, no event and no round trip through another stream.
+            if (m->ar_pending && m->ar_stream != m->side) {
+                // earlier buckets run on the collective stream: the caller's stream waits for them once (the side-stream variant needs nothing: the
+                // segment's own join already ordered the caller's stream behind everything the side stream had been given, collectives included)
+                (void)hipEventRecord(m->ar_ev_out, m->ar_stream);
+                (void)hipStreamWaitEvent(st, m->ar_ev_out, 0);
+            }
+            m->ar_pending = false;
+            if (!skip) RCCL_TRY(api, api->allReduce(g, g, (size_t)m->ar_cnt[i], ncclFloat, ncclSum, (ncclComm_t)m->ar_comm, st));
+            continue;
+        }
+        // gradients complete in the SIDE stream's order (deferred segment): one event orders the collective stream behind the slab reductions of
+        // this bucket; the caller's stream is not touched and runs on with the next segment
+        if (m->ar_stream != m->side) {
+            (void)hipEventRecord(m->ar_ev_in[i], m->side);
             (void)hipStreamWaitEvent(m->ar_stream, m->ar_ev_in[i], 0);
         }
-        float* g = m->grads + m->ar_off[i];
         if (!skip) RCCL_TRY(api, api->allReduce(g, g, (size_t)m->ar_cnt[i], ncclFloat, ncclSum, (ncclComm_t)m->ar_comm, m->ar_stream));
         m->ar_pending = true;
     }
     if (segment == UAD_SEG_ENCODER_LO && m->ar_pending) {
-        // every bucket is on ar_stream's queue: the caller's stream (optimizer step next) waits for them once
-        if (m->ar_stream != st) {
+        // (a plan without a bucket behind the last segment: the caller's stream still has to see the earlier ones before the optimizer step)
+        if (m->ar_stream != m->side) {
             (void)hipEventRecord(m->ar_ev_out, m->ar_stream);
             (void)hipStreamWaitEvent(st, m->ar_ev_out, 0);
-        }
+        } else if (!m->joined) join_side(m, st);
         m->ar_pending = false;
     }
     HIP_TRY(hipGetLastError());

@@ -115,7 +115,7 @@ class DataParallelStep:
     order: `Engine.backward_deferred` skips the wait and names the stream the slice is complete in, the all-reduce is issued under THAT stream (the
     process group's stream then waits for it, not the compute stream), and the compute stream goes straight on with the next segment."""
 
-    def __init__(self, engine, world=None, buckets=None, no_allreduce=None, force_collectives=None, library_allreduce=None):
+    def __init__(self, engine, world=None, buckets=None, no_allreduce=None, force_collectives=None, library_allreduce=None, comm=None):
         self.eng = engine
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.force = bool(int(os.environ.get('UAD_DP_FORCE_COLLECTIVES', '0'))) if force_collectives is None else bool(force_collectives)
@@ -133,7 +133,7 @@ class DataParallelStep:
         want_lib = _library_allreduce_default() if library_allreduce is None else bool(library_allreduce)
         self.comm = None
         if want_lib and (self.world > 1 or self.force) and hasattr(engine, 'allreduce_attach'):
-            self.comm = RcclComm()
+            self.comm = comm if comm is not None else RcclComm()      # (comm=: a communicator the caller created earlier, e.g. before the engine)
             engine.allreduce_attach(self.comm, self.world, self.plan)
         elif (self.world > 1 or self.force) and dist.is_initialized() and dist.get_backend() == 'nccl' and getattr(engine, 'created_before_process_group', False):
             # torch path under RCCL: with the handle created BEFORE the communicator the process group's stream lands on a hardware queue it shares
