@@ -675,10 +675,6 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world) if rehearsal else dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    pre_comm = None
-    if multi and not rehearsal and os.environ.get('UAD_BENCH_COMM_FIRST'):      # experiment: the library's RCCL communicator created before the engine's streams
-        from unsupervised_anomaly_detection_brain_mri_amd.parallel import RcclComm
-        pre_comm = RcclComm()
     eng = Engine(args.arch, H, W, 1, INTER, ZDIM, max_batch=BATCH, device=f'cuda:{local_rank}', math=args.math)
     # identical glorot-uniform init on every rank (seed 3), zero bias, gamma 1, beta 0
     rng = np.random.default_rng(3)
@@ -711,7 +707,7 @@ def main():
         got = rng_fill(noise_jobs, BATCH, 1, step_no[0], rank * BATCH)
         step_no[0] += 1
         return got.pop('eps'), got
-    dp = DataParallelStep(eng, world, force_collectives=True if nccl1 else None, comm=pre_comm)
+    dp = DataParallelStep(eng, world, force_collectives=True if nccl1 else None)
 
     def step():
         eps, masks = draw()

@@ -81,7 +81,7 @@ h)  # bench.py's N > 1 path under RCCL on one rank (UAD_BENCH_REHEARSAL=nccl1): 
     run1 torch_pg UAD_DP_LIBRARY_AR=0
     run1 library UAD_X=0
     run1 library_own_stream UAD_AR_STREAM=own
-    [ -n "$MORE" ] && { run1 library_comm_first UAD_BENCH_COMM_FIRST=1; run1 library_q16 GPU_MAX_HW_QUEUES=16; run1 library_q4 GPU_MAX_HW_QUEUES=4; }
+    [ -n "$MORE" ] && { run1 library_q16 GPU_MAX_HW_QUEUES=16; run1 library_q4 GPU_MAX_HW_QUEUES=4; }
     ;;
 *)  echo "unknown step $STEP"; exit 2;;
 esac
