@@ -161,6 +161,42 @@ def spec_conv_tags(spec, h, n):
     return out
 
 
+def last_block_kernel(tag, nblocks, math='bf16x3'):
+    """Kernel-template substring of the three launch groups of the LAST decoder block (the dominant kernels of every AE-family graph) in the committed
+    rocprofv3 files; None for any other tag (several layers share a template there)."""
+    if tag.split('.')[0] != f'dec{nblocks - 1}':
+        return None
+    kind = tag.split('.')[1]
+    if math == 'f32':
+        return {'fwd': 'conv5_d_kernel<8, 16, 32, 4, 1, true', 'dgrad': 'conv5_f_kernel<8, 16, 16, 4, 1', 'wgrad': 'conv5_w_kernel'}.get(kind)
+    return {'fwd': 'conv5_d16s_kernel<8, 16, 32, 4, 1, 1, 2', 'dgrad': 'conv5_f16_kernel<8, 16, 16, 4, 1', 'wgrad': 'conv5_w_bf16_tr_kernel<1, true'}.get(kind)
+
+
+def evidence_for(workload, kernel_substr, flop, peak):
+    """(traffic, rocprof) objects of a roofline line from profiles/r05_evidence_<workload>.json (tools/evidence.py: PMC FETCH_SIZE / WRITE_SIZE passes and the
+    rocprofv3 --kernel-trace --stats summary of the SAME bench command), for the kernel whose name contains kernel_substr; (None, None) when absent."""
+    if not kernel_substr:
+        return None, None
+    try:
+        doc = json.load(open(os.path.join(ROOT, 'profiles', f'r05_evidence_{workload}.json')))
+    except Exception:
+        return None, None
+    src = (f"profiles/r05_evidence_{workload}.json: `{doc.get('_command')}` under rocprofv3 at commit {doc.get('_commit')}; not re-measured in this run "
+           "(PMC counters need the profiler)")
+    traffic = rocprof = None
+    rows = [r for r in doc.get('traffic', []) if kernel_substr in r['name']]
+    if rows:
+        r = max(rows, key=lambda r: r['fetch_bytes'] + r['write_bytes'])
+        traffic = {'bytes': int(r['fetch_bytes'] + r['write_bytes']), 'fetch_bytes': int(r['fetch_bytes']), 'write_bytes': int(r['write_bytes']),
+                   'launches_averaged': r['launches'], 'source': src + '; --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 (gfx950 correction)'}
+    rows = [r for r in doc.get('stats', []) if kernel_substr in r['name']]
+    if rows:
+        r = max(rows, key=lambda r: r['total_ns'])
+        avg_ms = r['avg_ns'] * 1e-6
+        rocprof = {'avg_launch_ms': round(avg_ms, 4), 'calls': r['calls'], 'frac': round(flop / (avg_ms * 1e-3) / 1e12 / peak, 4), 'source': src + '; --kernel-trace --stats'}
+    return traffic, rocprof
+
+
 def train_flops_per_slice():
     """371.5 M MAC fwd -> 0.743 GFLOP; train step = 3x fwd minus the enc0 data-grad."""
     fwd_macs = sum(pos * k for _, pos, k in conv_layers())
@@ -330,16 +366,18 @@ def bench_gmvae(args):
             fl, by = tags[dom]
             peak = PEAK_F32_MFMA_TFLOPS if args.math == 'f32' else PEAK_BF16_MFMA_TFLOPS / 3.0
             alg, gbs = fl / (conv[dom] * 1e-3) / 1e12, by / (conv[dom] * 1e-3) / 1e9
+            nblk = len([1 for name, *_ in eng.spec if 'dec_Conv2DT_' in name and name.endswith('/kernel')])
+            ev_traffic, ev_rocprof = evidence_for(f'gmvae_restore_b{bs}', last_block_kernel(dom, nblk, args.math), fl, peak) if args.math != 'f32' else (None, None)
             for t in res['kernels']:
                 if t in tags:
                     res['kernels'][t]['tflops'] = round(tags[t][0] / (conv[t] * 1e-3) / 1e12, 2)
             res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(alg, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(alg / peak, 4),
                                'mfma_fraction': round(alg / peak, 4), 'hbm_fraction': round(gbs / PEAK_HBM_GBS, 4), 'hbm_achieved_gbs': round(gbs, 1),
                                'hbm_peak_gbs': PEAK_HBM_GBS, 'algorithmic_bytes_per_launch': int(by), 'algorithmic_flop_per_launch': int(fl),
-                               'traffic': None, 'avg_launch_ms': round(conv[dom], 4),
+                               'traffic': ev_traffic, 'rocprof': ev_rocprof, 'avg_launch_ms': round(conv[dom], 4),
                                'instruction': 'v_mfma_f32_32x32x2_f32 (exact fp32)' if args.math == 'f32' else
                                               '3 x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = dense bf16 MFMA 2500 TFLOP/s / 3 products',
-                               'note': 'restoration iteration = forward + data-gradient backward: no filter gradients; traffic not collected for this command'}
+                               'note': 'restoration iteration = forward + data-gradient backward: no filter gradients'}
         emit_json(res)
     if world > 1:
         dist.destroy_process_group()
@@ -766,7 +804,7 @@ def main():
         traffic = None
         # the committed PMC passes and rocprofv3 summaries are of the DEFAULT command (VAE, 64 slices per launch): other workloads of this function carry none
         evidence_applies = (not cevae) and args.arch == 'VAE' and BATCH == 64
-        for cand in (f'r04_traffic_{math}.json', f'r03_traffic_{math}.json', f'r02_traffic_{math}.json', f'r01_traffic_{math}.json') if evidence_applies else ():
+        for cand in (f'r05_traffic_{math}.json', f'r04_traffic_{math}.json', f'r03_traffic_{math}.json', f'r02_traffic_{math}.json', f'r01_traffic_{math}.json') if evidence_applies else ():
             try:
                 doc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
                 tr = doc.get(dom)
@@ -778,10 +816,14 @@ def main():
                     break
             except Exception:
                 continue
+        cev_traffic, cev_rocprof = evidence_for(f'cevae_b{BATCH}', last_block_kernel(dom, len(conv_layers()) // 2, math), fl[dom], peak) if (cevae and math != 'f32') else (None, None)
+        if cev_traffic:
+            traffic = cev_traffic
         # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command in this math mode (the
         # profiler's clock instead of HIP events around the launch group), with the commit it was taken at
         rocprof = None
-        for tj, ks in ((f'r04_traffic_{math}.json', 'r04_z_kernel_stats.csv' if math != 'f32' else 'r04_z_kernel_stats_f32.csv'),
+        for tj, ks in ((f'r05_traffic_{math}.json', 'r05_z_kernel_stats.csv' if math != 'f32' else 'r05_z_kernel_stats_f32.csv'),
+                       (f'r04_traffic_{math}.json', 'r04_z_kernel_stats.csv' if math != 'f32' else 'r04_z_kernel_stats_f32.csv'),
                        ('r03_traffic_bf16x3.json', 'r03_z_kernel_stats.csv') if math != 'f32' else (None, None)):
             if rocprof is not None or tj is None or not evidence_applies:
                 continue
@@ -809,7 +851,7 @@ def main():
                 'frac': round(alg / peak, 4), 'mfma_fraction': round(alg / peak, 4),
                 'hbm_fraction': round(gbs / PEAK_HBM_GBS, 4), 'hbm_achieved_gbs': round(gbs, 1), 'hbm_peak_gbs': PEAK_HBM_GBS,
                 'algorithmic_bytes_per_launch': int(by[dom]), 'algorithmic_flop_per_launch': int(fl[dom]),
-                'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'rocprof': rocprof, 'instruction': note}
+                'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'rocprof': rocprof or cev_rocprof, 'instruction': note}
         return roof, kernels
 
     SPEC_CLOCK_GHZ = 2.4

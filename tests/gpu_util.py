@@ -1,5 +1,6 @@
 """Helpers for the -m gpu parity tests: call the C-ABI (include/uad_hip.h) through ctypes with torch device buffers."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -179,6 +180,12 @@ def kink_overrides(pairs, math='bf16x3', bound=None, tag=''):
             scale = max(float(np.abs(ref).max()), 1e-30)
             mag = float(np.maximum(np.abs(dev[diff].astype(np.float64)), np.abs(ref[diff].astype(np.float64))).max()) / scale
             worst = max(worst, mag)
+            if os.environ.get('UAD_FLIP_CENSUS'):      # one JSON line per site with flips: every flipped element's distance from the kink (relative to the site's max)
+                import json
+                mags = np.maximum(np.abs(dev[diff].astype(np.float64)), np.abs(ref[diff].astype(np.float64))) / scale
+                with open(os.environ['UAD_FLIP_CENSUS'], 'a') as fh:
+                    fh.write(json.dumps({'tag': tag, 'site': k, 'elements': int(ref.size), 'flips': nf, 'math': math, 'bound': bound,
+                                         'mags': sorted((float(v) for v in mags), reverse=True)[:64]}) + '\n')
             assert mag <= bound, (f'{tag} site {k}: {nf} activation(s) on different sides of the kink with |value| up to {mag:.2e} of the '
                                   f'site max (round-off bound of {math}: {bound:.2e}) -- not a rounding tie')
             flips += nf

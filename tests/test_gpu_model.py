@@ -56,7 +56,7 @@ def test_forward_backward_parity(arch, h, inter, zdim, n, math):
     if n > 16 and math == 'bf16x3':
         # 80 x 64 x 64 ReLU inputs: a few sit within the split-bf16 round-off of the kink and take the other derivative (measured: dense_dec/kernel
         # 1.3e-3 off at n = 64 and 80 alike, seed-independent, with and without the fused gradient kernel, 6e-7 in f32 mode:
-        # tests/debug/n80_bottleneck_grad.py); the flip-aware comparison at these sample counts is tests/test_gpu_scale_parity.py
+        # tools/debug/n80_bottleneck_grad.py); the flip-aware comparison at these sample counts is tests/test_gpu_scale_parity.py
         pytest.skip('needs the flip-aware comparison (tests/test_gpu_scale_parity.py); the ragged-chunk logic under test is math-mode independent')
     m, p32, x, eps, masks = _setup(arch, h, inter, zdim, n)
     p64 = _f64(p32)

@@ -89,7 +89,7 @@ def test_vae_small_width_ragged_batch():
     """32 x 32, zDim 64, 80 slices: the narrow graph (two blocks per side; its bottleneck does not split over four workgroups per sample) at a
     batch that is one full 64-sample chunk + a ragged one in the fused bottleneck gradient kernel.  Without the activation pattern the split-bf16
     mode is 1.3e-3 off on Bottleneck/dense_dec/kernel (a handful of the 80 x 64 x 64 ReLU inputs of the decoder sit inside its round-off of the
-    kink, tests/debug/n80_bottleneck_grad.py); with the device's pattern injected every tensor has to meet the usual bar."""
+    kink, tools/debug/n80_bottleneck_grad.py); with the device's pattern injected every tensor has to meet the usual bar."""
     h, zdim, n = 32, 64, 80
     m = ovae.Model('VAE', h, h, 1, 8, zdim)
     p32 = ovae.init_params(m.spec, seed=3, perturb=True)

@@ -468,7 +468,7 @@ def test_context_encoder_trainer(tmp_path, mname):
     for math in ('f32', 'bf16x3'):
         # round 1's red run of this test (enc0 filter gradient 1.9e-4 off) was activation-kink flips, not arithmetic: with freshly
         # initialised weights the decoder pre-activations are ~1e-2 and hundreds of them lie within 1e-6 of zero
-        # (tests/debug/ce_spatial_rootcause.py), and the masked batch was drawn from the unseeded `random` module, so the flip set changed
+        # (tools/debug/ce_spatial_rootcause.py), and the masked batch was drawn from the unseeded `random` module, so the flip set changed
         # from run to run.  The oracle is therefore differentiated with the device's activation pattern and EVERY tensor is held to 1e-4.
         model.engine.set_math(math)
         got = model.engine.forward(x, None, masks, want_backward=True, x_ce=x_ce)

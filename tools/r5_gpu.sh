@@ -83,5 +83,25 @@ h)  # bench.py's N > 1 path under RCCL on one rank (UAD_BENCH_REHEARSAL=nccl1): 
     run1 library_own_stream UAD_AR_STREAM=own
     [ -n "$MORE" ] && { run1 library_q16 GPU_MAX_HW_QUEUES=16; run1 library_q4 GPU_MAX_HW_QUEUES=4; }
     ;;
+i)  # planner: minimum workgroup count of a spatial launch (small batches: the 8x8 / 16x16 layers of the 16-slice workloads)
+    for v in 256 128 64 32; do
+      UAD_SPATIAL_MIN_WGS=$v timeout 300 python bench.py --arch GMVAE_spatial --steps 1 --warmup 1 --restore-steps 50 --no-cpu-baseline > $OUT/gmvae_$v.json 2>/dev/null
+      UAD_SPATIAL_MIN_WGS=$v timeout 300 python bench.py --arch ceVAE --steps 40 --warmup 5 $Q > $OUT/cevae_$v.json 2>/dev/null
+      python -c "
+import json
+g = json.load(open('$OUT/gmvae_$v.json')); c = json.load(open('$OUT/cevae_$v.json'))
+print('min_wgs $v: gmvae restore', g['value'], 'slices/s', g['config']['ms_per_restore_iteration'], 'ms/iter |', ' '.join(f\"{t}={g['kernels'][t]['ms']*1e3:.0f}\" for t in ('enc4.fwd','enc4.dgrad','dec0.fwd','dec0.dgrad','enc3.fwd','dec1.dgrad') if t in g['kernels']), '| cevae16', c['value'], c['ms_per_step'])"
+    done
+    ;;
+j)  # restoration through the pattern word: parity (GMVAE / VAE_You restore tests, small-batch model tests for the planner change), then same-box A/B
+    timeout 900 python -m pytest tests/test_gpu_gmvae.py tests/test_gpu_vae_you.py tests/test_gpu_model.py tests/test_gpu_shapes.py tests/test_gpu_cevae.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4
+    for r in 1 2; do for v in UAD_NO_RESTORE_BITS=1 UAD_X=0; do
+      env $v timeout 300 python bench.py --arch GMVAE_spatial --steps 1 --warmup 1 --restore-steps 50 --no-cpu-baseline > $OUT/gmvae_${v%%=*}_$r.json 2>/dev/null
+      python -c "
+import json
+g = json.load(open('$OUT/gmvae_${v%%=*}_$r.json')); k = g['kernels']
+print('$v', g['config']['ms_per_restore_iteration'], 'ms/iter ->', round(16 / (150 * g['config']['ms_per_restore_iteration'] * 1e-3), 1), 'slices/s at 150 steps |', ' '.join(f\"{t}={k[t]['ms']*1e3:.0f}\" for t in list(k)[:8]))"
+    done; done
+    ;;
 *)  echo "unknown step $STEP"; exit 2;;
 esac

@@ -3929,7 +3929,15 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
         static const int split_env = getenv("UAD_SPLIT_TARGET") ? atoi(getenv("UAD_SPLIT_TARGET")) : 0;
         const int split_target = split_env > 0 ? split_env : (f_type ? 512 : 256);
         while (wgs * sp < split_target && sp * 2 <= chunks && (size_t)(sp * 2) * p.out_elems <= ws_cap) sp *= 2;
-        if (wgs * sp >= (split_target < 256 ? split_target : 256)) {
+        // Fewest workgroups a spatial launch may have; below it the launch falls back to the generic implicit-GEMM kernel (+ a separate split-K epilogue
+        // launch).  Round 5: 128 (was 256): at the 16-slice workloads of BASELINE configs[2] / [4] the 8 x 8 layers come to 128 workgroups after
+        // splitting, and the spatial kernel with its in-kernel slab reduction beats generic + epilogue by 2x there (spatial-GMVAE restoration:
+        // enc4.fwd 40 -> 16 us, dec0.dgrad 41 -> 17, the iteration 0.699 -> 0.632 ms; profiles/r05_e_planner_min_wgs.log).  UAD_SPATIAL_MIN_WGS=n overrides.
+        static const int min_env = getenv("UAD_SPATIAL_MIN_WGS") ? atoi(getenv("UAD_SPATIAL_MIN_WGS")) : 0;
+        // (only for SPLIT launches whose slabs are reduced inside the kernel -- bf16x3 handles with ticket counters: that is the case measured; unsplit
+        // launches and the exact-fp32 kernels, which would still need the separate epilogue launch, keep 256)
+        const int min_wgs = min_env > 0 ? min_env : ((ncounters > 0 && sp > 1) ? 128 : 256);
+        if (wgs * sp >= (split_target < min_wgs ? split_target : min_wgs)) {
             p.path = PATH_SPATIAL;
             p.nsplit = sp;
             p.ws_floats = sp > 1 ? (size_t)sp * p.out_elems : 0;

@@ -774,7 +774,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
     // decoder
     const ConvLayer& DL = m->dec.back();
     const int bps = uad_final_blocks_per_sample(m->cfg.height, m->cfg.width);
-    bool fused_final = false, fin_bits_mode = false;
+    bool fused_final = false, fin_bits_mode = false, restore_bits = false;
     for (size_t i = 0; i < m->dec.size(); ++i) {
         PROF(kDecF[i & 7]);
         UadConvDesc d = m->dec[i].d; d.N = n;
@@ -806,7 +806,17 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
                 fin_bits_mode = true;
             }
             ep.fin_inv_batch = 1.0f / (float)nu;
-            out = restore_bwd ? DL.c : nullptr;
+            // Restoration (round 5): the data gradient of the last block needs, per output element, only (d objective / d x_hat of its pixel) and
+            // whether its BN output was positive -- the pattern word this epilogue already knows how to write.  With it the block's 128 B / pixel
+            // pre-BN output is neither written here nor re-read by the data-gradient kernel (16 slices at 256 x 256: 134 MB each way per
+            // iteration); tv_dxhat supplies d / d x_hat from the finished reconstruction as before.  UAD_NO_RESTORE_BITS=1: the round-2 path
+            // (pre-BN output written, gradient formed from it on load).
+            static const bool no_rbits = getenv("UAD_NO_RESTORE_BITS") != nullptr;
+            if (restore_bwd && bfm && !no_rbits && d.CB <= 32 && uad_conv_f_supports_final_bwd(d, true, m->ws.floats)) {
+                ep.fin_bits = m->fin_bits; ep.fin_dxhat = m->fin_dxh;      // (fin_dxh receives the L1 sign term only: unused, tv_dxhat's output is what the backward reads)
+                fin_bits_mode = true; restore_bits = true;
+            }
+            out = (restore_bwd && !restore_bits) ? DL.c : nullptr;
         }
         uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), out, ep, st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]));
     }
@@ -832,8 +842,8 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         if (!fused_final) uad_launch_final_fwd_bwd(fa, st);
         uad_launch_tv_dxhat(xin, fa.x_hat, n, fa.H, fa.W, m->restore_scale, m->restore_tv, m->gm_dxhat, st);
         fa.d_c = dc; fa.dxhat_in = m->gm_dxhat;
-        m->fb_on_load = fused_final && restore_fb_on_load(m, n);
-        if (!m->fb_on_load) uad_launch_final_fwd_bwd(fa, st);   // else: folded into dec.back()'s data gradient
+        m->fb_on_load = fused_final && !restore_bits && restore_fb_on_load(m, n);
+        if (!m->fb_on_load && !restore_bits) uad_launch_final_fwd_bwd(fa, st);   // else: folded into dec.back()'s data gradient
     } else {
         PROF(want_backward ? "final.fwd+bwd" : "final.fwd"); uad_launch_final_fwd_bwd(fa, st);
     }
@@ -936,7 +946,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
         const bool last = i + 1 == (int)m->dec.size();
         const bool fbb = last && m->last_fin_bits;      // d loss / d c of the last block exists only as pattern bits + d objective / d x_hat
         UadXform gbits = no_xform();
-        if (fbb) { gbits = bn_xform(m, DL.gamma, DL.beta, kLrelu); gbits.fb_dxhat = m->fin_dxh; gbits.fb_wf = P(m, m->fw); gbits.fb_bits = m->fin_bits; }
+        if (fbb) { gbits = bn_xform(m, DL.gamma, DL.beta, kLrelu); gbits.fb_dxhat = m->restore ? m->gm_dxhat : m->fin_dxh; gbits.fb_wf = P(m, m->fw); gbits.fb_bits = m->fin_bits; }      // (restoration: d objective / d x_hat incl. the TV term, from tv_dxhat)
         { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr;
           if (anyo && pg && bf && last && m->fwd_tail_is_loss && !m->prof_on) uad_conv_w_any_order_next(true);
           m->fwd_tail_is_loss = false; }
