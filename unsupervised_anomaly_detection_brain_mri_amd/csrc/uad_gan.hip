@@ -68,6 +68,7 @@ struct uad_gan {
     float *wpack3_f, *wpack3_d;        // ResNet graph: THREE bf16 planes of the k3 kernels (bf16x6 products of the exact passes), 4 * nparams ushorts each; null: fp32 kernels
     int math;
     bool packed_valid;
+    bool pack_all; long long dirty_lo, dirty_hi;      // which parameters changed since the last pack: everything, or [dirty_lo, dirty_hi) (an optimizer step touches ONE group)
     UadGemmWs ws;
     std::vector<Block> E, G, D;
     long long e_cw, e_cb, e_dw, e_db;                   // Encoder/conv2d, Encoder/dense
@@ -230,9 +231,15 @@ void reduce_to(uad_gan* m, int k, const float* a, const float* b, size_t n, floa
 
 int refresh_packs(uad_gan* m, hipStream_t st) {
     if (m->packed_valid) return UAD_OK;
-    if (m->zim || m->you || m->chen) { m->packed_valid = true; return UAD_OK; }       // no k5 layers: nothing is packed
+    if (m->zim || m->you || m->chen) { m->packed_valid = true; m->pack_all = false; m->dirty_lo = (1ll << 62); m->dirty_hi = -1; return UAD_OK; }       // no k5 layers: nothing is packed
     long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
-    auto add = [&](const Block& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
+    // an optimizer step changes ONE group's variables (round 5: a WGAN-GP iteration of the ResNet graph repacked all 21 M parameters twelve times --
+    // 2 x 80 launches of 72 / 115 us in the round-4 rocprofv3 summary, 4.5 % of the iteration): only tensors inside the dirty range are repacked
+    static const bool always_all = getenv("UAD_GAN_PACK_ALL") != nullptr;      // A/B: repack every tensor after every optimizer step, as before round 5
+    const bool all = m->pack_all || always_all;
+    const long long dlo = m->dirty_lo, dhi = m->dirty_hi;
+    auto stale = [&](long long w) { return all || (w >= dlo && w < dhi); };
+    auto add = [&](const Block& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0 && stale(L.w)) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
     for (size_t i = 1; i < m->E.size(); ++i) add(m->E[i]);
     for (auto& L : m->G) add(L);
     for (size_t i = 1; i < m->D.size(); ++i) add(m->D[i]);
@@ -253,7 +260,7 @@ int refresh_packs(uad_gan* m, hipStream_t st) {
             np = 0;
         };
         auto addk = [&](long long w, const UadConvDesc& d) {
-            if (w < 0 || (d.KS != 3 && d.KS != 1) || d.CB % 8 || d.CS % 8) return;
+            if (w < 0 || (d.KS != 3 && d.KS != 1) || d.CB % 8 || d.CS % 8 || !stale(w)) return;
             offs[np] = w; cbs[np] = d.CB; css[np] = d.CS; taps[np] = d.KS * d.KS;
             if (++np == 16) flush();
         };
@@ -261,7 +268,7 @@ int refresh_packs(uad_gan* m, hipStream_t st) {
         for (auto& B : m->DB) { addk(B.w1, B.d1); addk(B.w2, B.d2); addk(B.ws, B.ds); }
         flush();
     }
-    m->packed_valid = true;
+    m->packed_valid = true; m->pack_all = false; m->dirty_lo = (1ll << 62); m->dirty_hi = -1;
     return UAD_OK;
 }
 
@@ -1423,7 +1430,7 @@ int uad_gan_tensor_info(const uad_gan_t* m, int idx, char* name, int name_cap, l
 float* uad_gan_buffer(uad_gan_t* m, int which) {
     if (!m) return nullptr;
     switch (which) {
-        case UAD_BUF_PARAMS: m->packed_valid = false; return m->params;      // the caller may write through the pointer (DP broadcast): repack before the next phase
+        case UAD_BUF_PARAMS: m->packed_valid = false; m->pack_all = true; return m->params;      // the caller may write through the pointer (DP broadcast): repack before the next phase
         case UAD_BUF_GRADS: return m->grads;
         case UAD_BUF_ADAM_M: return m->adam_m;
         case UAD_BUF_ADAM_V: return m->adam_v;
@@ -1447,7 +1454,7 @@ int uad_gan_set_buffer(uad_gan_t* m, int which, const float* host, long long cou
     float* p = uad_gan_buffer(m, which);
     if (!p || !host || count != m->nparams) return fail(UAD_ERR_INVALID, "gan set_buffer: bad arguments (count=%lld, expected %lld)", count, m ? m->nparams : -1);
     HIP_TRY(hipMemcpy(p, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
-    if (which == UAD_BUF_PARAMS) m->packed_valid = false;
+    if (which == UAD_BUF_PARAMS) { m->packed_valid = false; m->pack_all = true; }
     return UAD_OK;
 }
 int uad_gan_get_buffer(uad_gan_t* m, int which, float* host, long long count) {
@@ -1459,7 +1466,7 @@ int uad_gan_get_buffer(uad_gan_t* m, int which, float* host, long long count) {
 }
 int uad_gan_set_math_mode(uad_gan_t* m, int mode) {
     if (!m || (mode != UAD_MATH_F32 && mode != UAD_MATH_BF16X3 && mode != UAD_MATH_BF16X3_ALL)) return fail(UAD_ERR_INVALID, "bad math mode");
-    m->math = mode == UAD_MATH_F32 ? UAD_MATH_F32 : UAD_MATH_BF16X3; m->generic16 = mode == UAD_MATH_BF16X3_ALL; m->packed_valid = false;
+    m->math = mode == UAD_MATH_F32 ? UAD_MATH_F32 : UAD_MATH_BF16X3; m->generic16 = mode == UAD_MATH_BF16X3_ALL; m->packed_valid = false; m->pack_all = true;
     return UAD_OK;
 }
 long long uad_gan_get_step(const uad_gan_t* m, int group) { return (m && group >= 0 && group < 3) ? m->step[group] : 0; }
@@ -1711,6 +1718,8 @@ int uad_gan_adam(uad_gan_t* m, int group, float lr, float beta1, float beta2, fl
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
     const long long off = m->grp_off[group];
     m->packed_valid = false;
+    auto dirty = [&](long long lo, long long hi) { if (lo < m->dirty_lo) m->dirty_lo = lo; if (hi > m->dirty_hi) m->dirty_hi = hi; };
+    dirty(off, off + m->grp_cnt[group]);
     // AAE family: optim_gen (group 0) shares its variables with optim_ae (group 1) and keeps slots of its own
     float* am = (m->variant == UAD_GAN_AAE && group == 0) ? m->adam_m2 : m->adam_m;
     float* avv = (m->variant == UAD_GAN_AAE && group == 0) ? m->adam_v2 : m->adam_v;
@@ -1719,6 +1728,7 @@ int uad_gan_adam(uad_gan_t* m, int group, float lr, float beta1, float beta2, fl
     if (m->variant == UAD_GAN_ANOVAEGAN && group == UAD_GAN_ENCODER) {
         // optim_vae also owns the Generator variables (trainers/AnoVAEGAN.py:84), with slots of its own and the same step count
         const long long go = m->grp_off[UAD_GAN_GENERATOR];
+        dirty(go, go + m->grp_cnt[UAD_GAN_GENERATOR]);
         uad_launch_adam(m->params + go, m->grads + go, m->adam_m2 + go, m->adam_v2 + go, (size_t)m->grp_cnt[UAD_GAN_GENERATOR], lr_t, beta1,
                         beta2, eps, grad_scale, (hipStream_t)stream);
     }
