@@ -74,7 +74,7 @@ struct uad_model {
     UadGemmWs ws;                      // split-K slabs for the GEMMs that cannot fill the chip on their own
     bool packed_valid;
     bool pack_inflight;               // the repack of the updated parameters was launched on SIDE by the optimizer step (ev_pack)
-    hipEvent_t ev_opt, ev_pack;
+    hipEvent_t ev_opt, ev_pack, ev_pack_head; bool pack_head;      // ev_pack_head: the first packed consumer's tensor is ready (the rest: ev_pack)
     long long step;
     // layers
     std::vector<ConvLayer> enc, dec;
@@ -422,7 +422,7 @@ int uad_create(const uad_config_t* cfg, uad_model_t** out) {
     ALLOC(m->wpack_f, (size_t)m->nparams); ALLOC(m->wpack_d, (size_t)m->nparams);
     ALLOC(m->wpack16_f, (size_t)m->nparams); ALLOC(m->wpack16_d, (size_t)m->nparams);
     m->math = UAD_MATH_F32;
-    m->packed_valid = false; m->pack_inflight = false; m->ev_opt = m->ev_pack = nullptr;
+    m->packed_valid = false; m->pack_inflight = false; m->ev_opt = m->ev_pack = m->ev_pack_head = nullptr; m->pack_head = false;
     size_t maxact = 0;
     for (auto& L : m->enc) { size_t n = NB * L.d.HS * L.d.WS * L.d.CS; ALLOC(L.c, n); if (n > maxact) maxact = n; }
     for (auto& L : m->dec) { size_t n = NB * L.d.HB * L.d.WB * L.d.CB; ALLOC(L.c, n); if (n > maxact) maxact = n; }
@@ -591,18 +591,30 @@ long long uad_get_step(const uad_model_t* m) { return m ? m->step : 0; }
 int uad_set_step(uad_model_t* m, long long t) { if (!m || t < 0) return fail(UAD_ERR_INVALID, "bad step"); m->step = t; return UAD_OK; }
 
 // packed (bf16 hi|lo or fp32) copies of the 5x5 kernels + transposed dense kernels: the forms the conv / fused bottleneck kernels read
-static void pack_weights(uad_model* m, hipStream_t st) {
+// head_done (optional): the second conv block's tensor -- the FIRST packed-weight consumer of a forward -- is packed by a launch of its own and the
+// event recorded behind it; everything else follows.  Round 5: the step's timeline showed enc1.fwd waiting ~20 us at the head of every step for the
+// whole repack (17 us of packing + the dense transposes + two event hops behind the optimizer step) although its own tensor is 3 % of the bytes.
+static void pack_weights(uad_model* m, hipStream_t st, hipEvent_t head_done = nullptr) {
     const bool gm = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL, sp = m->cfg.arch == UAD_ARCH_AE_SPATIAL;
     long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
     auto add = [&](const ConvLayer& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
-    for (size_t i = 1; i < m->enc.size(); ++i) add(m->enc[i]);
-    for (auto& L : m->dec) add(L);
-    if (np > 0) {
-        if (m->math == UAD_MATH_BF16X3)
-            uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
-        else
-            uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
+    auto flush = [&]() {
+        if (np > 0) {
+            if (m->math == UAD_MATH_BF16X3)
+                uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
+            else
+                uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
+        }
+        np = 0;
+    };
+    size_t first = 1;
+    if (head_done) {
+        if (m->enc.size() > 1) { add(m->enc[1]); flush(); first = 2; }
+        (void)hipEventRecord(head_done, st);
     }
+    for (size_t i = first; i < m->enc.size(); ++i) add(m->enc[i]);
+    for (auto& L : m->dec) add(L);
+    flush();
     if (!gm && !sp) {
         // transposed copies of the dense kernels for the fused bottleneck backward
         const float* tin[3] = {P(m, m->dw), P(m, m->muw), m->sgw >= 0 ? P(m, m->sgw) : nullptr};
@@ -620,10 +632,13 @@ static void repack_on_side(uad_model* m, hipStream_t st) {
     if (!m->ev_opt) {
         if (hipEventCreateWithFlags(&m->ev_opt, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) (void)hipEventCreateWithFlags(&m->ev_opt, hipEventDisableTiming);
         if (hipEventCreateWithFlags(&m->ev_pack, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) (void)hipEventCreateWithFlags(&m->ev_pack, hipEventDisableTiming);
+        if (hipEventCreateWithFlags(&m->ev_pack_head, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) (void)hipEventCreateWithFlags(&m->ev_pack_head, hipEventDisableTiming);
     }
+    static const bool no_head = getenv("UAD_NO_PACK_HEAD") != nullptr;      // A/B: one event behind the whole repack, as before round 5
     (void)hipEventRecord(m->ev_opt, st);
     (void)hipStreamWaitEvent(m->side, m->ev_opt, 0);
-    pack_weights(m, m->side);
+    m->pack_head = !no_head;
+    pack_weights(m, m->side, m->pack_head ? m->ev_pack_head : nullptr);
     (void)hipEventRecord(m->ev_pack, m->side);
     m->pack_inflight = true;
 }
@@ -730,13 +745,17 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         UadConvDesc d = m->enc[0].d; d.N = n;
         uad_launch_conv_first_fwd(d, xin, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st);
     }
-    if (wait_pack) (void)hipStreamWaitEvent(st, m->ev_pack, 0);
+    bool wait_full = wait_pack;
+    if (wait_pack && m->pack_head) (void)hipStreamWaitEvent(st, m->ev_pack_head, 0);       // enc1's tensor only; everything else is waited for one layer later
+    else if (wait_pack) { (void)hipStreamWaitEvent(st, m->ev_pack, 0); wait_full = false; }
     for (size_t i = 1; i < m->enc.size(); ++i) {
+        if (i >= 2 && wait_full) { (void)hipStreamWaitEvent(st, m->ev_pack, 0); wait_full = false; }
         PROF(kEncF[i & 7]);
         UadConvDesc d = m->enc[i].d; d.N = n;
         uad_launch_conv_f(d, m->enc[i - 1].c, bn_xform(m, m->enc[i - 1].gamma, m->enc[i - 1].beta, kLrelu),
                           P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, PKF(m, m->enc[i].w), m->ws, PK16F(m, m->enc[i].w), PLANE(m->enc[i]));
     }
+    if (wait_full) { (void)hipStreamWaitEvent(st, m->ev_pack, 0); wait_full = false; }
     const ConvLayer& EL = m->enc.back();
     // bottleneck
     if (gm) {
