@@ -27,7 +27,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_EVENT_SYSFENCE', 'UAD_NO_W_TR', 'UAD_NO_W_T', 'UAD_NO_INKERNEL_SPLITK',
-                                  'UAD_NO_D16S', 'UAD_NO_REDUCE_NT', 'UAD_NO_ANYORDER', 'UAD_NO_PACK8', 'UAD_NO_FUSED_FINAL_F32'])
+                                  'UAD_NO_D16S', 'UAD_NO_REDUCE_NT', 'UAD_NO_ANYORDER', 'UAD_NO_PACK8', 'UAD_NO_FUSED_FINAL_F32', 'UAD_NO_PACK_HEAD',
+                                  'UAD_SPATIAL_MIN_WGS=256'])
 def test_model_parity_with_switch(knob):
     name, _, val = knob.partition('=')
     env = dict(os.environ, **{name: val or '1'})
@@ -101,3 +102,13 @@ def test_bottleneck_sibling_exchange_is_bounded_and_reports():
     r = subprocess.run([sys.executable, '-c', _FAULT_SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert 'REPORTED' in r.stdout and 'DONE' in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
+
+
+def test_restoration_parity_without_the_pattern_word():
+    """Round 5: restoration iterations hand the last block's activation pattern to the data gradient as one word per pixel (uad_model.hip: restore_bits)
+    instead of the block's pre-BN output.  UAD_NO_RESTORE_BITS=1 keeps the round-2 path; both must meet the oracle."""
+    env = dict(os.environ, UAD_NO_RESTORE_BITS='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_gmvae.py', 'tests/test_gpu_vae_you.py', '-q', '-x', '-m', 'gpu', '-k', 'restore', '-p', 'no:cacheprovider'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
