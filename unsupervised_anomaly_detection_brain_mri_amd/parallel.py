@@ -133,8 +133,15 @@ class DataParallelStep:
         want_lib = _library_allreduce_default() if library_allreduce is None else bool(library_allreduce)
         self.comm = None
         if want_lib and (self.world > 1 or self.force) and hasattr(engine, 'allreduce_attach'):
-            self.comm = comm if comm is not None else RcclComm()      # (comm=: a communicator the caller created earlier, e.g. before the engine)
-            engine.allreduce_attach(self.comm, self.world, self.plan)
+            try:
+                self.comm = comm if comm is not None else RcclComm()      # (comm=: a communicator the caller created earlier)
+                engine.allreduce_attach(self.comm, self.world, self.plan)
+            except Exception as e:      # librccl not loadable, communicator creation refused ...: the torch.distributed path still works
+                if library_allreduce:   # asked for explicitly: do not hide the failure
+                    raise
+                import sys
+                print(f'uad: library-issued all-reduce unavailable ({e}); falling back to torch.distributed', file=sys.stderr)
+                self.comm = None
         elif (self.world > 1 or self.force) and dist.is_initialized() and dist.get_backend() == 'nccl' and getattr(engine, 'created_before_process_group', False):
             # torch path under RCCL: with the handle created BEFORE the communicator the process group's stream lands on a hardware queue it shares
             # with a stream it waits for -- every all-reduce then costs ~0.2 ms of stall (measured).  Enforced, not only documented.
@@ -198,7 +205,15 @@ class GanDataParallel:
         # (The phases of a WGAN iteration form a dependency chain -- every forward reads the parameters the previous phase's Adam wrote -- so there is
         # no later work the collective could legally overlap with; what the library path removes is the blocking host wait and the event hand-off.)
         want_lib = _library_allreduce_default() if library_allreduce is None else bool(library_allreduce)
-        self.comm = RcclComm() if (want_lib and self.world > 1) else None
+        self.comm = None
+        if want_lib and self.world > 1:
+            try:
+                self.comm = RcclComm()
+            except Exception as e:
+                if library_allreduce:
+                    raise
+                import sys
+                print(f'uad: library-issued all-reduce unavailable ({e}); falling back to torch.distributed', file=sys.stderr)
 
     def broadcast_params(self, src=0):
         if self.world > 1:
