@@ -514,6 +514,9 @@ int uad_destroy(uad_model_t* m) {
     if (!m) return UAD_OK;
     for (void* p : m->allocs) hipFree(p);
     for (hipEvent_t e : m->sync_events) (void)hipEventDestroy(e);
+    if (m->ev_opt) (void)hipEventDestroy(m->ev_opt);
+    if (m->ev_pack) (void)hipEventDestroy(m->ev_pack);
+    if (m->ev_pack_head) (void)hipEventDestroy(m->ev_pack_head);
     for (int i = 0; i < 4; ++i) if (m->ar_ev_in[i]) (void)hipEventDestroy(m->ar_ev_in[i]);
     if (m->ar_ev_out) (void)hipEventDestroy(m->ar_ev_out);
     if (m->ar_own_stream && m->ar_stream) (void)hipStreamDestroy(m->ar_stream);
