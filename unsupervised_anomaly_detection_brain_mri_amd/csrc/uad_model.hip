@@ -1274,15 +1274,15 @@ RcclApi* rccl_api() {
     static bool tried = false;
     if (tried) return api.ok ? &api : nullptr;
     tried = true;
-    const char* names[] = {getenv("UAD_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    if (const char* over = getenv("UAD_RCCL_LIB")) api.h = dlopen(over, RTLD_NOW | RTLD_LOCAL);      // explicit override wins (tests: a stub whose "all-reduce" doubles)
     for (const char* nm : names) {
-        if (!nm) continue;
-        api.h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);       // the copy the process already uses (torch's), if any
         if (api.h) break;
+        api.h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);       // the copy the process already uses (torch's), if any
     }
     for (const char* nm : names) {
         if (api.h) break;
-        if (nm) api.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        api.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!api.h) return nullptr;
     api.getUniqueId = reinterpret_cast<decltype(api.getUniqueId)>(dlsym(api.h, "ncclGetUniqueId"));
