@@ -1048,14 +1048,22 @@ void uad_launch_bn_grad_finalize(const float* colpart, int T, int C, const float
                        dgamma, dbeta, dbias);
 }
 
-static inline int colsum_chunks(int rows) {
+// Row chunks of a column sum.  Round 5: up to 1024 (was 64) as long as the partials fit the 64 x 1024-float scratch every handle allocates: the ResNet f-AnoGAN
+// graph sums [393 k rows x 64 channels] tensors (100 MB) for its residual-stream bias gradients with 2 x 64 = 128 workgroups -- half the CUs, 1.8 TB/s, 3 % of an
+// iteration (profiles/r04_z_fanogan_resnet64_kernel_stats.csv).  UAD_COLSUM_CHUNKS=n caps it (64: the old plan).
+static inline int colsum_chunks(int rows, int C) {
+    static const int cap_env = getenv("UAD_COLSUM_CHUNKS") ? atoi(getenv("UAD_COLSUM_CHUNKS")) : 0;
+    int cap = cap_env > 0 ? cap_env : 1024;
+    const int fit = 65536 / (C < 1 ? 1 : C);
+    if (cap > fit) cap = fit;
+    if (cap < 1) cap = 1;
     int ch = (rows + 255) / 256;
-    return ch < 1 ? 1 : (ch > 64 ? 64 : ch);
+    return ch < 1 ? 1 : (ch > cap ? cap : ch);
 }
-size_t uad_colsum_scratch_floats(int rows, int C) { return (size_t)colsum_chunks(rows) * C; }
+size_t uad_colsum_scratch_floats(int rows, int C) { return (size_t)colsum_chunks(rows, C) * C; }
 
 void uad_launch_colsum(const float* g, int rows, int C, float* out, float* scratch, hipStream_t st) {
-    const int ch = colsum_chunks(rows);
+    const int ch = colsum_chunks(rows, C);
     const int rpc = (rows + ch - 1) / ch;
     dim3 grid((C + 31) / 32, ch);
     if (ch == 1) {
