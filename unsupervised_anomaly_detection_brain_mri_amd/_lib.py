@@ -173,6 +173,10 @@ def load():
             f'{LIB_PATH} is missing: the HIP extension has not been built '
             f'(run `python -m unsupervised_anomaly_detection_brain_mri_amd.build` or __graft_entry__.build()). '
             f'There is no CPU fallback.')
+    # PyTorch-ROCm first: libuad_hip.so's HIP runtime dependency must resolve to the copy torch ships and initialises -- loaded on its own before torch, the
+    # library binds the system runtime instead and the process then holds two, of which the library's reports "no ROCm-capable device" at the first hipMalloc
+    # (seen with `python __graft_entry__.py smoke`, whose build() loads the library before smoke() imports torch)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
