@@ -339,3 +339,55 @@ def test_bench_conv_tags_from_the_tensor_table():
     g = bench.spec_conv_tags(og.param_spec(256, 256, 1, 8, 9, 1, 1), 256, 1)
     per_slice = sum(v[0] for k, v in g.items() if k.endswith('.fwd')) + sum(v[0] for k, v in g.items() if k.endswith('.dgrad') and k != 'enc0.dgrad')
     assert abs(per_slice / 4.88e9 - 1.0) < 0.01          # SURVEY.md 8d counts the 1 x 1 heads and the final conv too (0.6 %)
+
+
+def test_bench_evidence_loader_and_stdout_claim(tmp_path):
+    """bench.py (round 5): a line's `roofline.traffic` / `roofline.rocprof` for the workloads other than the default one come from profiles/r05_evidence_<workload>.json
+    (tools/evidence.py) through the kernel template of the LAST decoder block's launch groups; and rank 0's one JSON line is written to the real stdout while
+    everything else -- RCCL's start-up banner on fd 1 included -- goes to stderr."""
+    import json
+    import subprocess
+    import sys
+    import bench
+    assert bench.last_block_kernel('dec3.fwd', 4) == 'conv5_d16s_kernel<8, 16, 32, 4, 1, 1, 2'
+    assert bench.last_block_kernel('dec4.dgrad', 5).startswith('conv5_f16_kernel<8, 16, 16')
+    assert bench.last_block_kernel('dec3.wgrad', 4, 'f32') == 'conv5_w_kernel'
+    assert bench.last_block_kernel('dec2.fwd', 4) is None and bench.last_block_kernel('enc1.fwd', 4) is None          # several layers share those templates
+    for wl, tag, nblk in (('cevae_b16', 'dec3.wgrad', 4), ('gmvae_restore_b16', 'dec4.fwd', 5)):
+        flop = 13.42e9
+        tr, rp = bench.evidence_for(wl, bench.last_block_kernel(tag, nblk), flop, 2500.0 / 3)
+        assert tr and rp, wl
+        assert tr['bytes'] == tr['fetch_bytes'] + tr['write_bytes'] and 2e7 < tr['bytes'] < 3e8, (wl, tr)
+        assert 0.05 < rp['frac'] < 0.6 and rp['calls'] > 0 and 'r05_evidence_' + wl in rp['source'], (wl, rp)
+    assert bench.evidence_for('no_such_workload', 'x', 1.0, 1.0) == (None, None) and bench.evidence_for('cevae_b16', None, 1.0, 1.0) == (None, None)
+    # fd 1 is protected: a child that claims stdout, then writes to fd 1 natively (as RCCL does) and prints, still leaves exactly the JSON line on stdout
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); os.write(1, b'RCCL version : banner\\n'); print('chatter'); "
+            "bench.emit_json({'metric': 'm', 'value': 1})" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == {'metric': 'm', 'value': 1} and r.stdout.count('\n') == 1
+    assert 'banner' in r.stderr and 'chatter' in r.stderr
+
+
+def test_data_parallel_step_prefers_the_library_path_only_under_rccl(monkeypatch):
+    """parallel._library_allreduce_default: the library-issued all-reduce is the default only when the process group's backend is RCCL ("nccl") and
+    UAD_DP_LIBRARY_AR is not 0; gloo (every CPU test) and an uninitialised group keep the torch.distributed path."""
+    from unsupervised_anomaly_detection_brain_mri_amd import parallel
+    import torch.distributed as dist
+    monkeypatch.delenv('UAD_DP_LIBRARY_AR', raising=False)
+    monkeypatch.setattr(dist, 'is_initialized', lambda: False)
+    assert parallel._library_allreduce_default() is False
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_backend', lambda *a, **k: 'gloo')
+    assert parallel._library_allreduce_default() is False
+    monkeypatch.setattr(dist, 'get_backend', lambda *a, **k: 'nccl')
+    assert parallel._library_allreduce_default() is True
+    monkeypatch.setenv('UAD_DP_LIBRARY_AR', '0')
+    assert parallel._library_allreduce_default() is False
+    # the bucket plan handed to uad_allreduce_attach: contiguous slices, every gradient element in exactly one bucket
+    segs = {parallel._lib.SEG_DECODER: (1000, 700), parallel._lib.SEG_BOTTLENECK: (600, 400), parallel._lib.SEG_ENCODER_HI: (50, 550), parallel._lib.SEG_ENCODER_LO: (0, 50)}
+    for b in (4, 3, 2, 1):
+        plan = parallel.bucket_plan(segs, b)
+        assert len(plan) == b and sum(c for _, _, c in plan) == 1700
+        covered = sorted((o, o + c) for _, o, c in plan)
+        assert covered[0][0] == 0 and covered[-1][1] == 1700 and all(a[1] == b_[0] for a, b_ in zip(covered, covered[1:]))
