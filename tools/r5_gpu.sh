@@ -48,7 +48,7 @@ PY
 c)  # A/B of two library builds: ablibs/libA.so (before) vs the tree's (after); [TESTS="pytest args"] MODES="bf16x3 f32" bash tools/r5_gpu.sh c
     [ -n "$TESTS" ] && { UAD_MATH=bf16x3 timeout 900 python -m pytest $TESTS -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4; }
     for r in 1 2 3; do for v in A B; do for m in ${MODES:-bf16x3}; do
-      L=$PWD/ablibs/libA.so; [ $v = B ] && L=$PWD/unsupervised_anomaly_detection_brain_mri_amd/libuad_hip.so
+      L=$PWD/ablibs/libA.so; [ $v = B ] && L=${LIBB:-$PWD/unsupervised_anomaly_detection_brain_mri_amd/libuad_hip.so}
       UAD_LIB=$L timeout 200 python bench.py --steps 40 --warmup 5 --math $m $Q > $OUT/${m}_${v}_$r.json 2>/dev/null
     done; done; done
     python tools/ab_table.py $OUT $TAGS
