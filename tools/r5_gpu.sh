@@ -103,5 +103,16 @@ g = json.load(open('$OUT/gmvae_${v%%=*}_$r.json')); k = g['kernels']
 print('$v', g['config']['ms_per_restore_iteration'], 'ms/iter ->', round(16 / (150 * g['config']['ms_per_restore_iteration'] * 1e-3), 1), 'slices/s at 150 steps |', ' '.join(f\"{t}={k[t]['ms']*1e3:.0f}\" for t in list(k)[:8]))"
     done; done
     ;;
+k)  # configs[3] (ResNet f-AnoGAN): parity tests of the GAN handle, then same-box A/B of two library builds (ablibs/libA.so = before, the tree's = after)
+    timeout 900 python -m pytest tests/test_gpu_fanogan.py tests/test_gpu_ops_resnet.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4
+    for r in 1 2; do for v in A B; do
+      L=$PWD/ablibs/libA.so; [ $v = B ] && L=$PWD/unsupervised_anomaly_detection_brain_mri_amd/libuad_hip.so
+      UAD_LIB=$L timeout 300 python bench.py --arch fAnoGAN --variant resnet --steps 5 --warmup 2 --no-cpu-baseline > $OUT/resnet_${v}_$r.json 2>/dev/null
+      python -c "
+import json
+d = json.load(open('$OUT/resnet_${v}_$r.json')); k = d.get('k3_kernels') or {}
+print('$v', d['ms_per_step'], 'ms/step', d['value'], 'slices/s')"
+    done; done
+    ;;
 *)  echo "unknown step $STEP"; exit 2;;
 esac
