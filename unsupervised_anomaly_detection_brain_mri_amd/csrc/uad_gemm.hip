@@ -3547,24 +3547,34 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
 // taps need no segment shifting (v_alignbit) at all.  Bank check: the four rows of a group sit 160 B (big, pixel stride 2) / 144 B (small) apart,
 // 32 B each: dword banks [0-7] [40-47] [16-23] [56-63] / [0-7] [36-43] [8-15] [44-51], disjoint.  Same tap-to-wave assignment, slabs and fold order as
 // conv5_w_bf16_t_kernel: the results are the same bits.
-template <int NCSB, bool FBB = false>
+template <int NCSB, bool FBB, bool XFA, bool XFS>
 __global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
 conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
+    // Round 6 ("VALU diet"): the staging half of this kernel issued ~45 VALU instructions per 16 bytes staged, a third of them 64-bit pointer
+    // arithmetic and border compares redone per element in BOTH the load-issue and the convert phase, chopped into ~40 basic blocks per tile by
+    // run-time switches (activation-on-load or not, tuning ablations, phase clocks).  Now: the switches are template parameters (one straight-line
+    // block per phase); every tile-invariant quantity of a thread's elements is computed ONCE before the tile loop -- per-element byte offsets
+    // (the loads go through buffer descriptors: wave-uniform base + wave-uniform tile offset + 32-bit lane offset, no 64-bit VALU), four
+    // border-class bit masks, the transform rows of the thread's channel quad (registers, not LDS re-reads), LDS store addresses (one base +
+    // instruction immediates); the tile coordinates advance incrementally (no divisions); the halo's zero padding comes from the descriptor's
+    // range check (an out-of-image element's offset is replaced by 2^31 = the descriptor's size) and costs a select per VALUE only where an activation is applied on load.
+    // Same elements to the same threads, same arithmetic per element, same MFMA order: the slabs are bit-identical to round 5's.
     constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256 * NCSB, CSQ = 8 * NCSB;
-    constexpr int LDH = CK + 8;                   // ushorts per big pixel (80 B)
+    constexpr int LDH = CK + 8;                   // ushorts per big pixel (80 B: 64 B of channels + 16 B pad)
     constexpr int BIGP = IH * IW * LDH;           // ushorts per plane
     constexpr int LDQ = 32 * NCSB + 8;            // ushorts per small position (144 B at NCSB = 2)
+    static_assert(!(FBB && XFA), "the pattern-word form replaces the big operand's transform");
     typedef short v4s __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     // (A double-buffered tile loop -- one barrier per tile, the next tile's conversion beside this tile's MFMAs -- measured neutral on this kernel too:
     // profiles/r04_h_w_tr_ab.log.)
-    constexpr int BUFP = 2 * BIGP + 2 * TH * TW * LDQ;         // ushorts of one tile buffer
-    unsigned short* bHi0 = reinterpret_cast<unsigned short*>(dsm);
-    float* sXf = reinterpret_cast<float*>(bHi0 + BUFP);   // [32] big scale, [32] big shift, [64] small scale, [64] small shift
+    unsigned short* bHi = reinterpret_cast<unsigned short*>(dsm);
+    unsigned short* bLo = bHi + BIGP;
+    unsigned short* sHiT = bLo + BIGP;
+    unsigned short* sLoT = sHiT + TH * TW * LDQ;
     float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
 
     const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
-    const unsigned long long dbg_c0 = a.dbgbuf ? (unsigned long long)clock64() : 0;   // shader-clock twin of dbg_t0 (s_memtime): clock = cycles / (10 ns ticks)
     const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
     const int wave = wave_all & 3;   // kernel row of this wave's taps
     const int csb = wave_all >> 2;    // its cs block
@@ -3575,18 +3585,54 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
     const int t_begin = blockIdx.z * tiles_per_split;
     const int t_end = min(t_begin + tiles_per_split, total_tiles);
 
-    const int cq = tid % CQ;
-    const bool xfa = !FBB && a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
-    // activation-on-load tables in LDS
-    if (tid < 32) {
-        sXf[tid] = xfa ? a.xfb.scale[cb0 + tid] * a.xfb.mult : 1.f;
-        sXf[32 + tid] = xfa ? a.xfb.shift[cb0 + tid] : 0.f;
+    // ---- this thread's share of a tile: elements (pixel pix0 + u DP, channel quad cq), u < PER, of the 19 x 19 halo; (position pos0 + 32 u,
+    // channel quad csq), u < SPER, of the 8 x 8 small tile.  Everything below is the same for every tile. ----
+    constexpr int TOT = IH * IW * CQ;
+    constexpr int PER = (TOT + NT - 1) / NT;          // 16-byte elements of the big tile per thread: 12 (NT 256) or 6 (NT 512)
+    constexpr int DP = NT / CQ;                       // pixels between a thread's consecutive elements
+    constexpr int SPER = TH * TW * CSQ / NT;          // 16-byte elements of the small tile per thread (2)
+    static_assert(NT % CQ == 0 && NT % CSQ == 0 && (PER - 1) * DP < IH * IW, "only a thread's LAST element can fall off the tile");
+    const int cq = tid % CQ, pix0 = tid / CQ;
+    const int csq = tid % CSQ, pos0 = tid / CSQ;
+    unsigned voff[PER];                               // byte offset of element u from the halo's origin pixel (FBB: of its pixel's 4-byte word)
+    unsigned clsT = 0, clsB = 0, clsL = 0, clsR = 0;  // bit u: element u lies in halo row 0 | rows 17, 18 | column 0 | columns 17, 18
+    const unsigned pixbytes = FBB ? 4u : (unsigned)d.CB * 4u;
+    const unsigned chanbytes = FBB ? 0u : (unsigned)(cb0 + cq * 4) * 4u;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int p = pix0 + u * DP, iy = p / IW, ix = p % IW;
+        const bool valid = u + 1 < PER || p < IH * IW;
+        voff[u] = valid ? (unsigned)(iy * d.WB + ix) * pixbytes + chanbytes : 0x80000000u;
+        clsT |= (iy == 0 ? 1u : 0u) << u; clsB |= (iy >= IH - 2 ? 1u : 0u) << u;
+        clsL |= (ix == 0 ? 1u : 0u) << u; clsR |= (ix >= IW - 2 ? 1u : 0u) << u;
     }
-    if (tid < 32 * NCSB) {
-        sXf[64 + tid] = xfs ? a.xfs.scale[cs0 + tid] * a.xfs.mult : 1.f;
-        sXf[128 + tid] = xfs ? a.xfs.shift[cs0 + tid] : 0.f;
+    // LDS byte address of element u's hi store = lds_b + u * DP * LDH * 2 (an instruction immediate); the lo plane is BIGP * 2 bytes further.  A thread
+    // whose last element is off the tile stores it into pixel 0's pad bytes (never read) instead of branching around the store.
+    const unsigned lds_b = (unsigned)(pix0 * LDH + cq * 4) * 2u;
+    const bool last_valid = pix0 + (PER - 1) * DP < IH * IW;
+    const unsigned lds_last = last_valid ? lds_b + (unsigned)((PER - 1) * DP * LDH) * 2u : (unsigned)CK * 2u;
+    unsigned svoff[SPER];
+#pragma unroll
+    for (int u = 0; u < SPER; ++u) {
+        const int pos = pos0 + u * (NT / CSQ);
+        svoff[u] = (unsigned)(((pos / TW) * d.WS + (pos % TW)) * d.CS + cs0 + csq * 4) * 4u;
     }
+    const unsigned slds_b = (unsigned)(pos0 * LDQ + csq * 4) * 2u;       // + u * 32 * LDQ * 2; lo plane TH * TW * LDQ * 2 bytes further
 
+    // activation-on-load rows of this thread's channel quads (registers)
+    float4 bsc = make_float4(1.f, 1.f, 1.f, 1.f), bsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ssc = bsc, ssh = bsh;
+    if (XFA) {
+        const float4 g = *reinterpret_cast<const float4*>(a.xfb.scale + cb0 + cq * 4);
+        bsc = make_float4(g.x * a.xfb.mult, g.y * a.xfb.mult, g.z * a.xfb.mult, g.w * a.xfb.mult);
+        bsh = *reinterpret_cast<const float4*>(a.xfb.shift + cb0 + cq * 4);
+    }
+    if (XFS) {
+        const float4 g = *reinterpret_cast<const float4*>(a.xfs.scale + cs0 + csq * 4);
+        ssc = make_float4(g.x * a.xfs.mult, g.y * a.xfs.mult, g.z * a.xfs.mult, g.w * a.xfs.mult);
+        ssh = *reinterpret_cast<const float4*>(a.xfs.shift + cs0 + csq * 4);
+    }
+    const float balpha = a.xfb.alpha, salpha = a.xfs.alpha;
     float fb_wf[4] = {0.f, 0.f, 0.f, 0.f}, fb_s1[4] = {0.f, 0.f, 0.f, 0.f}, fb_s0[4] = {0.f, 0.f, 0.f, 0.f};
     if (FBB) {
 #pragma unroll
@@ -3596,6 +3642,7 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
             fb_s0[e] = fb_s1[e] * a.xfb.alpha;
         }
     }
+    const unsigned fb_shift = (unsigned)(cb0 + cq * 4);
 
     constexpr int MAXT = 7;
     // fragment addressing (ushort indices): group g = lane >> 4 -> channel half g & 1, position half lh = g >> 1; lane i of the group -> row i >> 2
@@ -3622,125 +3669,84 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
         c = mfma_bf16(al, bh, c);
     };
 
-    // ---- tile loop, software-pipelined: the global loads of tile t + 1 are in flight while tile t is contracted (round 3: with the loads, the
-    // LDS stores and the MFMAs all ablated the kernel still ran at 55 % of its time -- per-tile load latency that nothing covered, and
-    // per-element index arithmetic: three divisions by non-powers of two and 64-bit address products per 16 bytes staged) ----
-    constexpr int TOT = IH * IW * CQ;
-    constexpr int PER = (TOT + NT - 1) / NT;          // 16-byte elements of the big tile per thread: 12 (NT 256) or 6 (NT 512)
-    constexpr int DP = NT / CQ, DIY = DP / IW, DIX = DP % IW;      // element u + 1 of a thread is DP pixels further: (iy, ix) += (DIY, DIX), one wrap
-    const int pix0 = tid / CQ, iy0 = pix0 / IW, ix0 = pix0 % IW;
-    float4 v[FBB ? 1 : PER];
+    // ---- tile loop, software-pipelined: the global loads of tile t + 1 are in flight while tile t is contracted ----
+    uint4 v[FBB ? 1 : PER];
     unsigned vb[FBB ? PER : 1];
     float vg[FBB ? PER : 1];
-    constexpr int SPER = TH * TW * CSQ / NT;          // 16-byte elements of the small tile per thread
-    float4 sv[SPER];
-    auto tile_origin = [&](int t, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
-        tx0 = (t % tilesx) * TW;
-        ty0 = ((t / tilesx) % tilesy) * TH;
-        n = t / (tilesx * tilesy);
+    uint4 sv[SPER];
+    // coordinates of the NEXT tile to be issued (wave-uniform, advanced incrementally)
+    int nx_tx0 = (t_begin % tilesx) * TW, nx_ty0 = ((t_begin / tilesx) % tilesy) * TH, nx_n = t_begin / (tilesx * tilesy);
+    unsigned bad = 0;            // bit u: element u of the tile in flight is outside the image
+    const size_t big_img = (size_t)d.HB * d.WB * (FBB ? 1 : d.CB);          // elements of one sample of the big operand (FBB: of the per-pixel words)
+    const size_t origin_back = (size_t)(d.WB + 1) * (FBB ? 1 : d.CB);      // the halo's origin is one row and one column before the tile's first pixel
+    auto issue = [&]() __attribute__((always_inline)) {
+        const int tx0 = nx_tx0, ty0 = nx_ty0, n = nx_n;
+        bad = ((ty0 == 0) ? clsT : 0u) | ((ty0 + TH == d.HS) ? clsB : 0u) | ((tx0 == 0) ? clsL : 0u) | ((tx0 + TW == d.WS) ? clsR : 0u);
+        const unsigned tile_b = (unsigned)((2 * ty0) * d.WB + 2 * tx0) * pixbytes;
+        if (FBB) {
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(const_cast<unsigned*>(a.xfb.fb_bits) + (size_t)n * big_img - origin_back), 0, 0x80000000u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(const_cast<float*>(a.xfb.fb_dxhat) + (size_t)n * big_img - origin_back), 0, 0x80000000u, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const unsigned off = (bad >> u) & 1u ? 0x80000000u : voff[u];
+                vb[FBB ? u : 0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rb, (int)off, (int)tile_b, 0);
+                vg[FBB ? u : 0] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, (int)off, (int)tile_b, 0));
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(const_cast<float*>(a.big) + (size_t)n * big_img - origin_back), 0, 0x80000000u, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const unsigned off = (bad >> u) & 1u ? 0x80000000u : voff[u];
+                v[FBB ? 0 : u] = buf_load16(rs, off, tile_b);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(const_cast<float*>(a.small_) + ((size_t)(n * d.HS + ty0) * d.WS + tx0) * d.CS), 0, 0x80000000u, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < SPER; ++u) sv[u] = buf_load16(rq, svoff[u], 0);
+        nx_tx0 += TW;
+        if (nx_tx0 == d.WS) { nx_tx0 = 0; nx_ty0 += TH; if (nx_ty0 == d.HS) { nx_ty0 = 0; ++nx_n; } }
     };
-    auto issue = [&](int t) __attribute__((always_inline)) {
-        int n, ty0, tx0;
-        tile_origin(t, n, ty0, tx0);
-        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-        const size_t pixbase = (size_t)n * d.HB * d.WB;
-        const float* bigb = a.big + pixbase * d.CB + cb0 + cq * 4;
-        int iy = iy0, ix = ix0;
+    auto as_f4 = [](uint4 q) { return make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)); };
+    auto lds_store8 = [&](unsigned byte_addr, uint2 q) __attribute__((always_inline)) { *reinterpret_cast<uint2*>(dsm + byte_addr) = q; };
+    auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int gy = gy0 + iy, gx = gx0 + ix;
-            const bool ok = (u + 1 < PER || tid + u * NT < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
-            const int gp = ok ? (gy * d.WB + gx) : 0;
+            float4 tv;
             if (FBB) {
-                vb[FBB ? u : 0] = a.xfb.fb_bits[pixbase + gp];
-                vg[FBB ? u : 0] = a.xfb.fb_dxhat[pixbase + gp];
-            } else if (a.abl & 4) {
-                v[FBB ? 0 : u] = make_float4(1.f, 2.f, 3.f, 4.f);
+#pragma clang fp contract(off)      // (the products are ROUNDED before the hi | lo split subtracts from them, as in round 5 where a select stood between the two)
+                const unsigned b = vb[FBB ? u : 0] >> fb_shift;
+                const float gq = vg[FBB ? u : 0];      // 0 outside the image (descriptor range check): the products below are zeros
+                tv.x = gq * fb_wf[0] * ((b & 1u) ? fb_s1[0] : fb_s0[0]);
+                tv.y = gq * fb_wf[1] * ((b & 2u) ? fb_s1[1] : fb_s0[1]);
+                tv.z = gq * fb_wf[2] * ((b & 4u) ? fb_s1[2] : fb_s0[2]);
+                tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
             } else {
-                v[FBB ? 0 : u] = *reinterpret_cast<const float4*>(bigb + (unsigned)(gp * d.CB));
+                tv = as_f4(v[FBB ? 0 : u]);
+                if (XFA) tv = keep4(!((bad >> u) & 1u), xform4(tv, bsc, bsh, balpha));      // padding is zero AFTER the activation
             }
-            ix += DIX; iy += DIY;
-            if (ix >= IW) { ix -= IW; ++iy; }
-        }
-        const size_t spix = ((size_t)(n * d.HS + ty0) * d.WS + tx0);
-#pragma unroll
-        for (int u = 0; u < SPER; ++u) {
-            const int idx = tid + u * NT;
-            const int pos = idx / CSQ, csq = idx % CSQ;
-            const unsigned po = (unsigned)((pos / TW) * d.WS + (pos % TW));
-            sv[u] = *reinterpret_cast<const float4*>(a.small_ + (spix + po) * d.CS + cs0 + csq * 4);
-        }
-    };
-    auto commit = [&](int t, int buf) __attribute__((always_inline)) {
-        unsigned short* bHi = bHi0 + buf * BUFP;
-        unsigned short* bLo = bHi + BIGP;
-        unsigned short* sHiT = bLo + BIGP;
-        unsigned short* sLoT = sHiT + TH * TW * LDQ;
-        int n, ty0, tx0;
-        tile_origin(t, n, ty0, tx0);
-        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-        int iy = iy0, ix = ix0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const bool valid = u + 1 < PER || tid + u * NT < TOT;
-            const bool ok = valid && (unsigned)(gy0 + iy) < (unsigned)d.HB && (unsigned)(gx0 + ix) < (unsigned)d.WB;
-            if (valid) {
-                float4 tv = v[FBB ? 0 : u];
-                if (FBB) {
-                    const unsigned b = vb[FBB ? u : 0] >> (cb0 + cq * 4);
-                    const float gq = vg[FBB ? u : 0];
-                    tv.x = gq * fb_wf[0] * ((b & 1u) ? fb_s1[0] : fb_s0[0]);
-                    tv.y = gq * fb_wf[1] * ((b & 2u) ? fb_s1[1] : fb_s0[1]);
-                    tv.z = gq * fb_wf[2] * ((b & 4u) ? fb_s1[2] : fb_s0[2]);
-                    tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
-                } else if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
-                uint2 hi, lo;
-                tv = keep4(ok, tv);
-                split_bf16(tv, hi, lo);
-                if (!(a.abl & 1)) {   // pixel-major: two 8-byte stores
-                    const int o = (iy * IW + ix) * LDH + cq * 4;
-                    *reinterpret_cast<uint2*>(bHi + o) = hi;
-                    *reinterpret_cast<uint2*>(bLo + o) = lo;
-                }
-            }
-            ix += DIX; iy += DIY;
-            if (ix >= IW) { ix -= IW; ++iy; }
-        }
-#pragma unroll
-        for (int u = 0; u < SPER; ++u) {
-            const int idx = tid + u * NT;
-            const int pos = idx / CSQ, csq = idx % CSQ;
-            float4 tv = sv[u];
-            if (xfs) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + 64 + csq * 4), *reinterpret_cast<const float4*>(sXf + 128 + csq * 4), a.xfs.alpha);
             uint2 hi, lo;
             split_bf16(tv, hi, lo);
-            *reinterpret_cast<uint2*>(sHiT + pos * LDQ + csq * 4) = hi;
-            *reinterpret_cast<uint2*>(sLoT + pos * LDQ + csq * 4) = lo;
+            const unsigned o = (u + 1 < PER) ? lds_b + (unsigned)(u * DP * LDH) * 2u : lds_last;
+            lds_store8(o, hi);
+            lds_store8(o + (unsigned)BIGP * 2u, lo);
+        }
+#pragma unroll
+        for (int u = 0; u < SPER; ++u) {
+            float4 tv = as_f4(sv[u]);
+            if (XFS) tv = xform4(tv, ssc, ssh, salpha);
+            uint2 hi, lo;
+            split_bf16(tv, hi, lo);
+            const unsigned o = (unsigned)(2 * BIGP) * 2u + slds_b + (unsigned)(u * (NT / CSQ) * LDQ) * 2u;
+            lds_store8(o, hi);
+            lds_store8(o + (unsigned)(TH * TW * LDQ) * 2u, lo);
         }
     };
-    // UAD_DBG & 128: per-wave phase clocks (100 MHz ticks) summed over the tile loop -- wait at the first barrier | commit (convert + LDS stores) | issue of the
-    // next tile's loads | wait at the second barrier | fragment reads + MFMAs -- for the first workgroups of the launch
-    const bool ph_on = a.dbgbuf && (a.abl & 64) && lane == 0;
-    unsigned long long ph[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
-    if (t_begin < t_end) issue(t_begin);
+    if (t_begin < t_end) issue();
     for (int t = t_begin; t < t_end; ++t) {
-        const unsigned long long c0 = ph_on ? wall_clock64() : 0ull;
-        __syncthreads();                   // the previous tile's fragments are consumed (first pass: the sXf tables are written)
-        const unsigned long long c1 = ph_on ? wall_clock64() : 0ull;
-        commit(t, 0);
-        const unsigned long long c2 = ph_on ? wall_clock64() : 0ull;
-        if (t + 1 < t_end) issue(t + 1);   // in flight across the barrier and the MFMA loop below
-        const unsigned long long c3 = ph_on ? wall_clock64() : 0ull;
+        __syncthreads();                   // the previous tile's fragments are consumed
+        commit();
+        if (t + 1 < t_end) issue();        // in flight across the barrier and the MFMA loop below
         __syncthreads();
-        const unsigned long long c4 = ph_on ? wall_clock64() : 0ull;
-        struct PhEnd { bool on; unsigned long long* ph; unsigned long long c0, c1, c2, c3, c4;
-            __device__ ~PhEnd() { if (!on) return; asm volatile("s_nop 0" ::: "memory"); const unsigned long long c5 = wall_clock64();
-                ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4; } } ph_end{ph_on, ph, c0, c1, c2, c3, c4};
-        const unsigned short* bHi = bHi0;
-        const unsigned short* bLo = bHi + BIGP;
-        const unsigned short* sHiT = bLo + BIGP;
-        const unsigned short* sLoT = sHiT + TH * TW * LDQ;
-        if (!(a.abl & 2))
 #pragma unroll
         for (int js = 0; js < TH * TW / 16; ++js) {
             // positions 16 js .. 16 js + 15 = tile rows 2 js (k half 0) and 2 js + 1 (k half 1)
@@ -3752,7 +3758,7 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
             const int a4 = a_base + (4 * js * IW + 4 * IW) * LDH;             // kernel row 4
             mma3(acc[5], tr8(bHi, a4 + wave * LDH, 8 * LDH), tr8(bLo, a4 + wave * LDH, 8 * LDH), bh, bl);        // tap (4, wave)
         }
-        if (!(a.abl & 2)) {
+        {
             // this wave's quarter of tap (4, 4) = position block js = wave, addressed by a run-time offset BEHIND the straight-line loop: with the
             // `if (js == wave)` inside it (round 4) every js step was its own basic block and the fragment reads of a block could not be hoisted
             // above the previous block's MFMAs.  acc[6] receives the same three products in the same order.
@@ -3771,16 +3777,12 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
                             // OUTLASTS the any-order data gradient launched behind it -- results stay correct, only the timing changes
         for (int i = 0; i < 32; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    if (!(a.abl & 8))
 #pragma unroll
     for (int j = 0; j < MAXT - 1; ++j) {
         const int tap = j < 5 ? 5 * wave + j : 20 + wave;      // (row, 0..4), (4, row)
         float* ot = ob + tap * tapstride;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (a.abl & 16) __builtin_nontemporal_store(acc[j][r], ot + ((r & 3) + 8 * (r >> 2)) * CSi);    // experiment: streaming slab stores
-            else ot[((r & 3) + 8 * (r >> 2)) * CSi] = acc[j][r];
-        }
+        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2)) * CSi] = acc[j][r];
     }
     // tap (4, 4): the four rows' shares are folded through LDS in a fixed order
     __syncthreads();
@@ -3798,14 +3800,6 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
         const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         a.dbgbuf[2 * b] = dbg_t0;
         a.dbgbuf[2 * b + 1] = wall_clock64();
-    }
-    if (ph_on) {
-        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        if (b < 16) {      // behind the 2 x 2048 start / end words: [16 workgroups][8 waves][8]
-            unsigned long long* o = a.dbgbuf + 2 * 2048 + (b * 8 + wave_all) * 8;
-            for (int i = 0; i < 5; ++i) o[i] = ph[i];
-            o[5] = wall_clock64() - dbg_t0; o[6] = (unsigned long long)(t_end - t_begin); o[7] = (unsigned long long)clock64() - dbg_c0;
-        }
     }
 }
 
@@ -4205,6 +4199,15 @@ inline WChoice choose_w(const UadConvDesc& d) {
 }
 }  // namespace
 
+namespace {
+template <int NCSB, bool FBB, bool XFA, bool XFS>
+void launch_w_tr(const ConvWArgs& a, dim3 grid, const W5Choice& w5, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(NCSB)); attr = true; }
+    UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS>), grid, dim3(256 * NCSB), conv5_w_bf16_tr_lds_bytes(NCSB), st, a, w5.tiles_per_split, w5.total_tiles);
+}
+}  // namespace
+
 bool uad_conv_w_supports_fb_bits(const UadConvDesc& d, bool math_bf16x3) {
     return math_bf16x3 && choose_w5(d).ok && d.CB == 32 && !getenv("UAD_NO_FB_BITS");
 }
@@ -4279,22 +4282,14 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                 // launch 3-12 % faster: profiles/r04_h_w_tr_ab.log); UAD_NO_W_TR=1: the channel-major kernel
                 static const bool tr_on = getenv("UAD_NO_W_TR") == nullptr;
                 if (tr_on) {
-                    static bool tr_attr = false;
-                    if (!tr_attr) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(1));
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(2));
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(1));
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(2));
-                        tr_attr = true;
-                    }
-                    const size_t ldt = conv5_w_bf16_tr_lds_bytes(two ? 2 : 1);
-                    if (xfb.fb_bits) {
-                        if (two) UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<2, true>), grid, dim3(512), ldt, st, a, w5.tiles_per_split, w5.total_tiles);
-                        else UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<1, true>), grid, dim3(256), ldt, st, a, w5.tiles_per_split, w5.total_tiles);
-                    } else {
-                        if (two) UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<2, false>), grid, dim3(512), ldt, st, a, w5.tiles_per_split, w5.total_tiles);
-                        else UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<1, false>), grid, dim3(256), ldt, st, a, w5.tiles_per_split, w5.total_tiles);
-                    }
+                    const bool xa = xfb.scale != nullptr && !xfb.fb_bits, xs = xfs.scale != nullptr;
+                    // <cs blocks per workgroup, big operand from the pattern word, activation on load of big, ... of small>
+                    if (xfb.fb_bits) { if (two) { if (xs) launch_w_tr<2, true, false, true>(a, grid, w5, st); else launch_w_tr<2, true, false, false>(a, grid, w5, st); }
+                                       else     { if (xs) launch_w_tr<1, true, false, true>(a, grid, w5, st); else launch_w_tr<1, true, false, false>(a, grid, w5, st); } }
+                    else if (two) { if (xa) { if (xs) launch_w_tr<2, false, true, true>(a, grid, w5, st); else launch_w_tr<2, false, true, false>(a, grid, w5, st); }
+                                    else    { if (xs) launch_w_tr<2, false, false, true>(a, grid, w5, st); else launch_w_tr<2, false, false, false>(a, grid, w5, st); } }
+                    else          { if (xa) { if (xs) launch_w_tr<1, false, true, true>(a, grid, w5, st); else launch_w_tr<1, false, true, false>(a, grid, w5, st); }
+                                    else    { if (xs) launch_w_tr<1, false, false, true>(a, grid, w5, st); else launch_w_tr<1, false, false, false>(a, grid, w5, st); } }
                 } else {
                 const size_t lds = conv5_w_bf16_t_lds_bytes(two ? 2 : 1);
                 if (xfb.fb_bits) {
