@@ -114,5 +114,12 @@ d = json.load(open('$OUT/resnet_${v}_$r.json')); k = d.get('k3_kernels') or {}
 print('$v', d['ms_per_step'], 'ms/step', d['value'], 'slices/s')"
     done; done
     ;;
+bits)  # bit identity of two library builds over three seeded VAE steps (x_hat, every gradient tensor, parameters): MODES="bf16x3 f32" bash tools/r6_gpu.sh bits
+    for m in ${MODES:-bf16x3}; do
+      UAD_LIB=$PWD/ablibs/libA.so timeout 300 python tools/ab_bits.py $m > $OUT/bits_${m}_A.txt 2> $OUT/bits_${m}_A.err
+      timeout 300 python tools/ab_bits.py $m > $OUT/bits_${m}_B.txt 2> $OUT/bits_${m}_B.err
+      if diff -q $OUT/bits_${m}_A.txt $OUT/bits_${m}_B.txt > /dev/null && [ -s $OUT/bits_${m}_A.txt ]; then echo "$m: BIT-IDENTICAL ($(wc -l < $OUT/bits_${m}_A.txt) digests)"; else echo "$m: DIFFERENT"; diff $OUT/bits_${m}_A.txt $OUT/bits_${m}_B.txt | head -20; tail -3 $OUT/bits_${m}_B.err; fi
+    done
+    ;;
 *)  echo "unknown step $STEP"; exit 2;;
 esac

@@ -2018,7 +2018,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 // too large to hold every channel at once, so channels are walked in CK-wide chunks (restaged per chunk, accumulators live
 // across chunks); the weight ring runs through the chunk boundary.
 // ------------------------------------------------------------------------------------------------
-template <int TH, int TW, int CK, int WGM, int WGN, int FB>      // FB: 0 plain | 1 final-backward on load from c | 2 ... from the pattern bits
+// Round 6: the staging phases on the same diet as conv5_w_bf16_tr_kernel -- the tile is fixed for a workgroup, so the byte offset of each of a
+// thread's elements (out-of-image elements: 2^31 = the descriptor's size, the range check returns zeros), the padding mask and the LDS store
+// addresses are computed ONCE; a chunk adds a wave-uniform channel offset.  Activation-on-load or not is a template parameter (XF).
+template <int TH, int TW, int CK, int WGM, int WGN, int FB, bool XF>      // FB: 0 plain | 1 final-backward on load from c | 2 ... from the pattern bits
 __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_per_eu(2))) conv5_f16_kernel(const ConvGemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int IH = 2 * TH + 3, IW = 2 * TW + 3;
@@ -2046,10 +2049,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     const int CA = a.CA, Nn = a.Nn;
     const int AH = d.HB, AW = d.WB;
 
-    const bool xf = a.xf.scale != nullptr;
+    constexpr bool xf = XF;
     constexpr bool fb = FB == 1 || FB == 2;  // final-backward on load (UadXform::fb_*): its own instantiation, the extra
                                              // prefetch registers would otherwise spill the 64-column variant
     constexpr bool fbb = FB == 2;            // ... from one pattern word per pixel instead of the 32 pre-BN values (UadXform::fb_bits)
+    static_assert(!(fb && !XF), "the final-backward forms are instantiated with XF = true (they read the scale table)");
     if (xf)
         for (int c = tid; c < CA; c += NT) {
             s_xf[c] = a.xf.scale[c] * a.xf.mult;
@@ -2100,83 +2104,94 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
 
     const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-    const float* inb = a.A + (size_t)n * AH * AW * CA;
+
+    // ---- this thread's share of the halo tile: elements (pixel pix0 + u DP, channel quad cq), the same for every chunk ----
+    constexpr int TOT = IH * IW * CQ;
+    constexpr int PER = (TOT + NT - 1) / NT;
+    constexpr int DP = NT / CQ;
+    static_assert(NT % CQ == 0 && (PER - 1) * DP < IH * IW, "only a thread's LAST element can fall off the tile");
+    const int cq = tid % CQ, pix0 = tid / CQ;
+    unsigned voff[PER];                        // byte offset inside the sample (FB 2: of the pixel's 4-byte word), 2^31 when the element is padding
+    unsigned voffg[FB == 1 ? PER : 1];         // FB 1 only: the pixel's word of d objective / d x_hat beside its channel quad
+    unsigned bad = 0;                          // bit u: element u is padding (zero AFTER the activation)
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pix = pix0 + u * DP, iy = pix / IW, ix = pix % IW;
+        const int gy = gy0 + iy, gx = gx0 + ix;
+        const bool ok = (u + 1 < PER || pix < IH * IW) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
+        const unsigned gp = (unsigned)(gy * AW + gx);
+        voff[u] = ok ? (fbb ? gp * 4u : (gp * (unsigned)CA + (unsigned)(cq * 4)) * 4u) : 0x80000000u;
+        if (FB == 1) voffg[FB == 1 ? u : 0] = ok ? gp * 4u : 0x80000000u;
+        bad |= (ok ? 0u : 1u) << u;
+    }
+    // LDS byte address of element u's hi store = lds_b + u DP LDH 2 (an instruction immediate), lo plane IH IW LDH 2 bytes further; a last element
+    // that is off the tile lands in pixel 0's pad bytes (never read) instead of being branched around
+    const unsigned lds_b = (unsigned)(pix0 * LDH + cq * 4) * 2u;
+    const unsigned lds_last = (pix0 + (PER - 1) * DP < IH * IW) ? lds_b + (unsigned)((PER - 1) * DP * LDH) * 2u : (unsigned)CK * 2u;
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)(const_cast<float*>(a.A) + (size_t)n * AH * AW * CA), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(const_cast<float*>(a.xf.fb_dxhat) + (size_t)n * AH * AW), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(const_cast<unsigned*>(a.xf.fb_bits) + (size_t)n * AH * AW), 0, 0x80000000u, 0x00020000);
     __syncthreads();
 
     // The activation tile of chunk ch+1 is fetched into registers while chunk ch is contracted (the tile's two dependent
     // HBM/L2 latencies were ~60 % of a workgroup's lifetime); conversion + LDS store happen once every wave has left chunk ch.
-    constexpr int TOT = IH * IW * CQ;
-    constexpr int PER = (TOT + NT - 1) / NT;
-    float4 pf[fbb ? 1 : PER];
+    uint4 pf[fbb ? 1 : PER];
     float pg[fb ? PER : 1];                  // fb mode: the pixel's d objective / d x_hat, fetched with the tile
     unsigned pb[fbb ? PER : 1];              // bits mode: the pixel's activation-pattern word
-    auto issue_stage = [&](int c0) {
+    auto issue_stage = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int f = tid + u * NT;
-            const int pix = f / CQ, cq = f % CQ;
-            const int iy = pix / IW, ix = pix % IW;
-            const int gy = gy0 + iy, gx = gx0 + ix;
-            const bool ok = (f < TOT) && (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
-            const int gp = ok ? (gy * AW + gx) : 0;
-            if (fbb) pb[u] = a.xf.fb_bits[(size_t)n * AH * AW + gp];
-            else pf[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CA + c0 + (ok ? cq * 4 : 0));
-            if (fb) pg[u] = a.xf.fb_dxhat[(size_t)n * AH * AW + gp];
+            if (fbb) pb[fbb ? u : 0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(brs, (int)voff[u], 0, 0);
+            else pf[fbb ? 0 : u] = buf_load16(irs, voff[u], (unsigned)c0 * 4u);
+            if (fb) pg[fb ? u : 0] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(grs, (int)(FB == 1 ? voffg[FB == 1 ? u : 0] : voff[u]), 0, 0));
         }
     };
-    auto convert_stage = [&](int c0) {
+    auto convert_stage = [&](int c0) __attribute__((always_inline)) {
         // this thread's channel quad is the same for every element (NT % CQ == 0): its table rows are read once per chunk, not once per element
-        const int cq_t = tid % CQ;
-        const float4 t_sc = (xf || fb) ? *reinterpret_cast<const float4*>(s_xf + c0 + cq_t * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 t_sh = (xf || FB == 1) ? *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq_t * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 t_wf = fb ? *reinterpret_cast<const float4*>(s_xf + 2 * XF_LDS_CH + c0 + cq_t * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 t_sc = (xf || fb) ? *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 t_sh = (xf || FB == 1) ? *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 t_wf = fb ? *reinterpret_cast<const float4*>(s_xf + 2 * XF_LDS_CH + c0 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned bshift = (unsigned)(c0 + cq * 4);
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int f = tid + u * NT;
-            if (f >= TOT) continue;
-            const int pix = f / CQ, cq = f % CQ;
-            const int iy = pix / IW, ix = pix % IW;
-            const int gy = gy0 + iy, gx = gx0 + ix;
-            const bool ok = (unsigned)gy < (unsigned)AH && (unsigned)gx < (unsigned)AW;
-            float4 t = pf[fbb ? 0 : u];
+            const uint4 q = pf[fbb ? 0 : u];
+            float4 t = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
             if (fbb) {
+#pragma clang fp contract(off)      // (the products are rounded before the hi | lo split subtracts from them, as when a padding select stood between the two)
                 // the same from the pattern word the fused forward epilogue left: the derivative side of every channel is one bit
                 const float4 sc = t_sc, wf = t_wf;
-                const float g = ok ? pg[u] : 0.f;
-                const unsigned b = pb[u] >> (c0 + cq * 4);
+                const float g = pg[fb ? u : 0];          // padding: 0 through the descriptor's range check -> the products are zeros
+                const unsigned b = pb[fbb ? u : 0] >> bshift;
                 t.x = g * wf.x * ((b & 1u) ? sc.x : sc.x * a.xf.alpha);
                 t.y = g * wf.y * ((b & 2u) ? sc.y : sc.y * a.xf.alpha);
                 t.z = g * wf.z * ((b & 4u) ? sc.z : sc.z * a.xf.alpha);
                 t.w = g * wf.w * ((b & 8u) ? sc.w : sc.w * a.xf.alpha);
             } else if (fb) {
+#pragma clang fp contract(off)
                 // final-backward on load: t = dxhat[pixel] * wf * lrelu'(bn(c)) * scale  (see UadXform::fb_*)
                 const float4 sc = t_sc, sh = t_sh, wf = t_wf;
-                const float g = ok ? pg[u] : 0.f;
-                t.x = g * wf.x * (fmaf(t.x, sc.x, sh.x) > 0.f ? sc.x : sc.x * a.xf.alpha);
-                t.y = g * wf.y * (fmaf(t.y, sc.y, sh.y) > 0.f ? sc.y : sc.y * a.xf.alpha);
-                t.z = g * wf.z * (fmaf(t.z, sc.z, sh.z) > 0.f ? sc.z : sc.z * a.xf.alpha);
-                t.w = g * wf.w * (fmaf(t.w, sc.w, sh.w) > 0.f ? sc.w : sc.w * a.xf.alpha);
+                const float g = pg[fb ? u : 0];
+                t.x = g * wf.x * (__builtin_fmaf(t.x, sc.x, sh.x) > 0.f ? sc.x : sc.x * a.xf.alpha);
+                t.y = g * wf.y * (__builtin_fmaf(t.y, sc.y, sh.y) > 0.f ? sc.y : sc.y * a.xf.alpha);
+                t.z = g * wf.z * (__builtin_fmaf(t.z, sc.z, sh.z) > 0.f ? sc.z : sc.z * a.xf.alpha);
+                t.w = g * wf.w * (__builtin_fmaf(t.w, sc.w, sh.w) > 0.f ? sc.w : sc.w * a.xf.alpha);
             } else if (xf) {
-                t = xform4(t, t_sc, t_sh, a.xf.alpha);
+                t = keep4(!((bad >> u) & 1u), xform4(t, t_sc, t_sh, a.xf.alpha));      // padding is zero AFTER the activation
             }
-            t = keep4(ok, t);
             uint2 hi, lo;
             split_bf16(t, hi, lo);
-            *reinterpret_cast<uint2*>(sHi + pix * LDH + cq * 4) = hi;
-            *reinterpret_cast<uint2*>(sLo + pix * LDH + cq * 4) = lo;
+            const unsigned o = (u + 1 < PER) ? lds_b + (unsigned)(u * DP * LDH) * 2u : lds_last;
+            *reinterpret_cast<uint2*>(dsm + o) = hi;
+            *reinterpret_cast<uint2*>(dsm + o + (unsigned)(IH * IW * LDH) * 2u) = lo;
         }
     };
-    unsigned long long* stp = (a.dbgbuf && lane == 0 && blockIdx.y == 1 && blockIdx.z == 0 && blockIdx.x < 8) ? a.dbgbuf + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
-    if (stp) stp[0] = wall_clock64();
     issue_stage(ch0 * CK);
     for (int ch = ch0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
         if (ch > ch0) __syncthreads();
         convert_stage(c0);
-        if (stp && ch == ch0) stp[1] = wall_clock64();
         if (ch + 1 < nchunks) issue_stage(c0 + CK);
         __syncthreads();
-        if (stp && ch == ch0) stp[2] = wall_clock64();
         loadA(a0, 0);
         const bool more = ch + 1 < nchunks;
         auto unit = [&](const BFrag16<NKS>& bc, BFrag16<NKS>& bpf, const BFrag16<NKS>& ac, BFrag16<NKS>& an, const int t) {
@@ -2202,10 +2217,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         b0 = b1; b1 = b2; b2 = b3;
     }
 
-    if (stp) stp[3] = wall_clock64();
     // ---- epilogue: transpose through a wave-private LDS tile, 16-byte accesses (see conv5_d16_kernel) ----
     __syncthreads();
-    if (stp) stp[4] = wall_clock64();                                   // every wave is done with the activation tile
     constexpr int EPI_LD = 36;
     static_assert((size_t)WGM * WGN * 32 * EPI_LD * 4 <= (size_t)2 * IH * IW * LDH * 2, "epilogue tile fits in the activation tile");
     const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
@@ -2233,13 +2246,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             float* slab = a.Out + (size_t)split * a.out_elems;
 #pragma unroll
             for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(slab + off[k]) = v[k];
-            { if (stp) stp[5] = wall_clock64(); return; }
+            return;
         }
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.Out, 0, 0xffffffff, 0x00020000);
 #pragma unroll
         for (int k = 0; k < 4; ++k) sk_store16(srs, (unsigned)(((size_t)split * a.out_elems + off[k]) * 4), v[k]);
         const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) * (gridDim.z / nsplit) + blockIdx.z / nsplit;
-        if (!sk_last_arriver(a.sk_counter + slot, nsplit, reinterpret_cast<int*>(s_red), tid)) { if (stp) stp[5] = wall_clock64(); return; }
+        if (!sk_last_arriver(a.sk_counter + slot, nsplit, reinterpret_cast<int*>(s_red), tid)) return;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int sp = 0; sp < nsplit; sp += 2) {          // nsplit is a power of two >= 2; two slabs (8 loads) in flight
@@ -2267,7 +2280,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             if (a.ep.add) { const float4 q = *reinterpret_cast<const float4*>(a.ep.add + off[k]); t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
             if (outp) *reinterpret_cast<float4*>(outp + off[k]) = t;
         }
-        { if (stp) stp[5] = wall_clock64(); return; }
+        return;
     }
     float4 e_a = *reinterpret_cast<const float4*>(a.ep.escale + ecol);
     e_a.x *= a.ep.emult; e_a.y *= a.ep.emult; e_a.z *= a.ep.emult; e_a.w *= a.ep.emult;
@@ -2311,7 +2324,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
         if (n0 + c < Nn) a.ep.colpart[(tile * 2 + which) * Nn + n0 + c] = t;
     }
-    if (stp) stp[5] = wall_clock64();
 }
 
 // Launches without the AQL barrier bit (hipExtAnyOrderLaunch).  Packets of a queue are still DEQUEUED in order, so such a kernel starts once
@@ -2340,22 +2352,25 @@ constexpr size_t conv5_f16_lds_bytes() {
     return (size_t)2 * (2 * TH + 3) * (2 * TW + 3) * (CK + 8) * 2 + (size_t)3 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
 }
 
-template <int TH, int TW, int CK, int WGM, int WGN, int FB>
+template <int TH, int TW, int CK, int WGM, int WGN, int FB, bool XF>
 void launch_conv5_f16_v(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = conv5_f16_lds_bytes<TH, TW, CK, WGM, WGN>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB, XF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    UAD_SPATIAL_LAUNCH((conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB>), grid, dim3(64 * WGM * WGN), lds, st, a);
+    UAD_SPATIAL_LAUNCH((conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB, XF>), grid, dim3(64 * WGM * WGN), lds, st, a);
 }
 template <int TH, int TW, int CK, int WGM, int WGN>
 void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
-    if (a.xf.fb_bits) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 2>(a, grid, st);
-    else if (a.xf.fb_dxhat) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 1>(a, grid, st);
-    else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0>(a, grid, st);
+    if (a.xf.fb_bits || a.xf.fb_dxhat) {
+        if (!a.xf.scale) { fprintf(stderr, "uad: final-backward on load needs the block's scale / shift tables\n"); abort(); }
+        if (a.xf.fb_bits) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 2, true>(a, grid, st);
+        else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 1, true>(a, grid, st);
+    } else if (a.xf.scale) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0, true>(a, grid, st);
+    else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0, false>(a, grid, st);
 }
 
 template <int TH, int TW, int CST, int WGM, int WGN>
