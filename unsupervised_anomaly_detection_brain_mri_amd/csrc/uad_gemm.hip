@@ -2060,7 +2060,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             s_xf[XF_LDS_CH + c] = a.xf.shift[c];
             if (fb) s_xf[2 * XF_LDS_CH + c] = a.xf.fb_wf[c];
         }
-
     const int m = wm * 32 + l31;
     const int pty = m / TW, ptx = m % TW;
     const int aoff = ((2 * pty) * IW + 2 * ptx) * LDH + 8 * lh;
@@ -2367,6 +2366,7 @@ template <int TH, int TW, int CK, int WGM, int WGN>
 void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
     if (a.xf.fb_bits || a.xf.fb_dxhat) {
         if (!a.xf.scale) { fprintf(stderr, "uad: final-backward on load needs the block's scale / shift tables\n"); abort(); }
+        if (a.xf.fb_bits && a.CA > 32) { fprintf(stderr, "uad: the pattern-word form holds one bit per channel of a 32-bit word (CA = %d)\n", a.CA); abort(); }
         if (a.xf.fb_bits) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 2, true>(a, grid, st);
         else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 1, true>(a, grid, st);
     } else if (a.xf.scale) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0, true>(a, grid, st);
@@ -3648,6 +3648,9 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
         ssh = *reinterpret_cast<const float4*>(a.xfs.shift + cs0 + csq * 4);
     }
     const float balpha = a.xfb.alpha, salpha = a.xfs.alpha;
+    // Pattern-word form: element = (dxhat * w_f[ch]) * (bit ch ? scale : scale * alpha).  (Round 6 also tried the four selects of a channel quad as ONE
+    // 16-byte LDS table row indexed by the quad's nibble of the word -- 133 fewer VALU instructions per tile and wave, same bits -- and measured it
+    // SLOWER: dec3.wgrad 0.86 -> 0.89-0.91 of the round-5 kernel's time, with or without bank padding: profiles/r06_b_fb_nibble_table_ab.md.)
     float fb_wf[4] = {0.f, 0.f, 0.f, 0.f}, fb_s1[4] = {0.f, 0.f, 0.f, 0.f}, fb_s0[4] = {0.f, 0.f, 0.f, 0.f};
     if (FBB) {
 #pragma unroll
