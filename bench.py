@@ -383,6 +383,164 @@ def bench_gmvae(args):
         dist.destroy_process_group()
 
 
+def gmvae_volume_cpu_baseline(hh, rs, slices):
+    """CPU leg of the full-volume line: the oracle's restoration gradient (numpy fp64 restatement of trainers/GMVAE_spatial.py:91-92, 168-199) on ONE
+    256 x 256 slice for a bounded number of iterations, plus the host post-processing the reference runs per volume (scipy erosion of every brain
+    mask, 5 x 5 x 5 median filter: utils/Evaluation.py:84-127) on the full volume size -- scaled to slices/s of the whole pipeline.  kind = "port"."""
+    import scipy.ndimage
+    from oracle import gmvae as og
+    m = og.GMVAE(hh, hh, 1, 8, 9, 1, 1, 1.0)
+    p = {k: v.astype(np.float64) for k, v in og.init_params(m.spec, seed=3).items()}
+    rng = np.random.default_rng(0)
+    x = rng.random((1, hh, hh, 1))
+    e_w, e_z = rng.standard_normal((1, 8, 8, 1)), rng.standard_normal((1, 8, 8, 1))
+    m.restore_grads(p, x, e_w, e_z, 1.8)                      # warm-up
+    it, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 12.0 and it < 50:
+        x = x - 1e-3 * m.restore_grads(p, x, e_w, e_z, 1.8)
+        it += 1
+    t_iter = (time.perf_counter() - t0) / max(it, 1)
+    vol = rng.random((slices, hh, hh)) * (rng.random((slices, hh, hh)) < 0.4)
+    yy, xx = np.mgrid[0:hh, 0:hh]
+    mask = ((yy - hh / 2) / (0.4 * hh)) ** 2 + ((xx - hh / 2) / (0.36 * hh)) ** 2 <= 1
+    t1 = time.perf_counter()
+    strel = scipy.ndimage.generate_binary_structure(2, 1)
+    for _ in range(slices):
+        scipy.ndimage.binary_erosion(mask, structure=strel, iterations=12)
+    scipy.ndimage.median_filter(vol, (5, 5, 5))
+    t_post = time.perf_counter() - t1
+    per_volume = slices * rs * t_iter + t_post
+    return {'value': round(slices / per_volume, 5), 'unit': 'slices/s', 'cores': 1, 'kind': 'port', 'cpu_model': _cpu_model(),
+            'seconds_per_volume': round(per_volume, 1),
+            'sample': f'{it} restoration iterations of ONE {hh} x {hh} slice with the numpy fp64 oracle ({t_iter:.3f} s each; a volume needs {slices} x {rs}) + scipy '
+                      f'erosion of {slices} masks and the 5x5x5 median filter of the [{slices},{hh},{hh}] volume ({t_post:.1f} s), one thread; '
+                      f'{time.perf_counter() - t0:.1f} s of CPU work'}
+
+
+def bench_gmvae_volume(args):
+    """BASELINE.json configs[4] as the config states it -- FULL-VOLUME restoration-mode inference: one synthetic patient per GPU ([110, 256, 256]) through
+    the product path of utils/Evaluation.py:223-312 + trainers/GMVAE_spatial.py:168-199 -- GMVAE_spatial.reconstruct() (restore_steps restoration iterations,
+    slices batched 16 at a time, on device) -> uad_residual (brain-masked positive residual, hyper-intensity prior) -> uad_erode_cross -> uad_median3d ->
+    uad_scores_* (AUROC / AUPRC / Dice sweep) -> uad_cc_filter.  Patients are sharded over the ranks (Evaluation._sharded_map: no collective on the
+    restoration path, the residual volumes are exchanged for the pooled metrics).  One 'step' = one volume per GPU; value = slices per second."""
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from unsupervised_anomaly_detection_brain_mri_amd.models import gaussian_mixture_variational_autoencoder_spatial as net
+    from unsupervised_anomaly_detection_brain_mri_amd.trainers import GMVAE_spatial
+    from unsupervised_anomaly_detection_brain_mri_amd.utils import Evaluation
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.default_config_setup import get_options, get_config
+    from unsupervised_anomaly_detection_brain_mri_amd.utils.synthetic import SyntheticDataset, synthetic_slices
+    world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    rehearsal = bool(os.environ.get('UAD_BENCH_REHEARSAL'))
+    if rehearsal:
+        os.environ.setdefault('UAD_BOTT_Q1', '1')
+        local_rank = 0
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world) if rehearsal else dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    hh, bs, rs, S = 256, BATCH, args.restore_steps, args.volume_slices
+    tmp = tempfile.mkdtemp(prefix='uad_bench_')
+    opt = get_options(batchsize=bs, learningrate=5e-5, numEpochs=1, zDim=128, outputWidth=hh, outputHeight=hh,
+                      config={'CHECKPOINTDIR': os.path.join(tmp, 'ck'), 'SAMPLEDIR': os.path.join(tmp, 'smp')})
+    cfg = get_config(GMVAE_spatial, opt, 'ADAM', [8, 8], 0.2, SyntheticDataset(4, 4, hh, hh, seed=0))
+    cfg.dim_c, cfg.dim_z, cfg.dim_w, cfg.restore_steps, cfg.restore_lr, cfg.tv_lambda = 9, 1, 1, rs, 1e-3, 1.8
+    model = GMVAE_spatial(None, cfg, network=net, world=1, device=f'cuda:{local_rank}')      # (inference only: no gradient all-reduce to set up)
+    eng = model.engine
+    eng.set_math(args.math)
+    # one synthetic patient per rank: phantom slices with planted hyper-intense lesions, their label map and the brain mask
+    volumes, labels, masks = [], [], []
+    for k in range(world):
+        img, lab, msk = synthetic_slices(S, hh, hh, seed=2000 + k, lesions=True)
+        volumes.append(img[..., 0].astype(np.float32)); labels.append(lab.astype(np.uint8)); masks.append(msk.astype(np.float32))
+    options = dict(opt)
+    options.update({'keepOnlyPositiveResiduals': True, 'applyHyperIntensityPrior': True, 'medianFiltering': True, 'erodeBrainmask': True, 'threshold': 'bestdice'})
+
+    def step():
+        return Evaluation.evaluate_arrays(volumes, labels, masks, model, options)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # phase shares (untimed pass, own patient): restoration | residual + erosion + median | scoring (sort, scans, Dice sweep, small-component filter)
+    ph = {}
+    k = rank
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    rec = np.concatenate([model.reconstruct(volumes[k][s0:s0 + bs, ..., None])['reconstruction'] for s0 in range(0, S, bs)])
+    torch.cuda.synchronize(); ph['restoration_s'] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    em = eng.erode_cross(masks[k], 12)
+    d, _ = eng.residual(volumes[k][..., None], rec, em[..., None], pos_only=True, prior_thresh=float(np.quantile(volumes[k], 0.9)))
+    dm = eng.median3d(d[..., 0], 5)
+    torch.cuda.synchronize(); ph['residual_erode_median_s'] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    Evaluation._score_diffs(model, [dm], [labels[k]], options)
+    torch.cuda.synchronize(); ph['scoring_s'] = time.perf_counter() - t1
+    eng.profile(True)
+    xr = torch.from_numpy(volumes[k][:bs, ..., None].copy()).to(eng.device)
+    g = torch.Generator(device='cuda').manual_seed(1 + rank)
+    e_w = torch.randn(bs, 8, 8, 1, device='cuda', generator=g); e_z = torch.randn(bs, 8, 8, 1, device='cuda', generator=g)
+    for _ in range(5):
+        eng.restore_step(xr, e_w, e_z, tv_lambda=1.8, restore_lr=1e-3)
+    rep = eng.profile_report()
+    eng.profile(False)
+    if rank == 0:
+        per_volume = dt / args.steps
+        value = S * world * args.steps / dt
+        tot = sum(ph.values())
+        res = {'metric': f'MRI slices/sec GMVAE-spatial full-volume restoration inference ({rs} steps, {S} x 256x256 per volume, {bs} slices in flight)',
+               'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(per_volume * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
+               'config': {'workload': f'BASELINE.json configs[4]: spatial GMVAE 256x256x1 full-volume restoration-mode inference -- one [{S},256,256] patient per GPU: '
+                                      f'reconstruct() = {rs} restoration iterations per slice ({bs} slices in flight) -> masked positive residual + hyper-intensity prior '
+                                      f'-> 12 x cross erosion of the brain masks -> 5x5x5 median -> AUROC / AUPRC / greedy Dice sweep -> <= 7-voxel component filter '
+                                      f'(utils/Evaluation.py:223-312, trainers/GMVAE_spatial.py:168-199), dim_c 9 dim_z 1 dim_w 1',
+                          'seconds_per_volume': round(per_volume, 3), 'parallelism': f'patients{world}',
+                          'phase_seconds_one_volume': {k2: round(v, 4) for k2, v in ph.items()},
+                          'post_processing_share': round((tot - ph['restoration_s']) / tot, 4),
+                          'metrics_of_the_random_init_model': {'diff_AUC': round(float(ev['diff_AUC']), 6), 'diff_AUPRC': round(float(ev['diff_AUPRC']), 6),
+                                                               'bestDiceScore': round(float(ev['bestDiceScore']), 6)}},
+               'kernels': {t: {'ms': round(ms / c, 4)} for t, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}}
+        tags = spec_conv_tags(eng.spec, hh, bs)
+        conv = {t: ms / c for t, (c, ms) in rep.items() if t in tags}
+        if conv:
+            dom = max(conv, key=conv.get)
+            fl, by = tags[dom]
+            peak = PEAK_F32_MFMA_TFLOPS if args.math == 'f32' else PEAK_BF16_MFMA_TFLOPS / 3.0
+            alg, gbs = fl / (conv[dom] * 1e-3) / 1e12, by / (conv[dom] * 1e-3) / 1e9
+            nblk = len([1 for name, *_ in eng.spec if 'dec_Conv2DT_' in name and name.endswith('/kernel')])
+            ev_traffic, ev_rocprof = evidence_for(f'gmvae_restore_b{bs}', last_block_kernel(dom, nblk, args.math), fl, peak) if args.math != 'f32' else (None, None)
+            res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(alg, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(alg / peak, 4),
+                               'hbm_fraction': round(gbs / PEAK_HBM_GBS, 4), 'algorithmic_bytes_per_launch': int(by), 'algorithmic_flop_per_launch': int(fl),
+                               'traffic': ev_traffic, 'rocprof': ev_rocprof, 'avg_launch_ms': round(conv[dom], 4),
+                               'note': 'dominant launch of the restoration iteration (forward + data-gradient backward), which is '
+                                       f'{100 * ph["restoration_s"] / tot:.1f} % of a volume; same kernel as the restoration-only line'}
+        if not args.no_cpu_baseline and not args.quick:
+            res['cpu_baseline'] = gmvae_volume_cpu_baseline(hh, rs, S)
+        emit_json(res)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def gan_macs(variant, h, zdim=128, dim=64):
     """Multiply-accumulates per sample and forward pass of the encoder, generator and critic."""
     if variant == 'resnet':
@@ -664,6 +822,8 @@ def main():
                     help='bf16x3 (default): split-bf16 products on the bf16 matrix cores, fp32 accumulate, parity 1e-4 vs the '
                          'fp32 oracle; f32: exact fp32 MFMA')
     ap.add_argument('--restore-steps', type=int, default=150, help='GMVAE_spatial: restoration iterations per slice')
+    ap.add_argument('--volume', action='store_true', help='GMVAE_spatial: the full-volume line (one [110,256,256] patient per GPU through restoration + post-processing + scoring)')
+    ap.add_argument('--volume-slices', type=int, default=110)
     ap.add_argument('--arch', default='VAE', choices=['VAE', 'ceVAE', 'GMVAE_spatial', 'fAnoGAN'],
                     help='VAE = the headline workload (BASELINE.json configs[1]); ceVAE = configs[3] (16 slices per GPU: both '
                          'branches + the input-gradient anomaly map every step), reported for the record')
@@ -679,7 +839,7 @@ def main():
         BATCH = 32
     cevae = args.arch == 'ceVAE'
     if args.arch == 'GMVAE_spatial':
-        return bench_gmvae(args)
+        return bench_gmvae_volume(args) if args.volume else bench_gmvae(args)
     if args.arch == 'fAnoGAN':
         return bench_fanogan(args)
 

@@ -121,5 +121,19 @@ bits)  # bit identity of two library builds over three seeded VAE steps (x_hat, 
       if diff -q $OUT/bits_${m}_A.txt $OUT/bits_${m}_B.txt > /dev/null && [ -s $OUT/bits_${m}_A.txt ]; then echo "$m: BIT-IDENTICAL ($(wc -l < $OUT/bits_${m}_A.txt) digests)"; else echo "$m: DIFFERENT"; diff $OUT/bits_${m}_A.txt $OUT/bits_${m}_B.txt | head -20; tail -3 $OUT/bits_${m}_B.err; fi
     done
     ;;
+sweep)  # one environment variable over a list of values, default bench line each:  VAR=UAD_W5_TARGET VALS="384 448 512 640" [MODES=bf16x3] bash tools/r6_gpu.sh sweep
+    for r in 1 2; do for v in $VALS; do for m in ${MODES:-bf16x3}; do
+      env $VAR=$v timeout 200 python bench.py --steps 40 --warmup 5 --math $m $Q > $OUT/${m}_${v}_$r.json 2>/dev/null
+      python - <<PY
+import json
+try:
+    j = json.load(open('$OUT/${m}_${v}_$r.json')); k = j['kernels']
+    w = sum(k[t]['ms'] for t in k if t.endswith('.wgrad') and t not in ('enc0.wgrad', 'bott.wgrad')) * 1e3
+    print('$VAR=$v', '$m', 'round $r', j['ms_per_step'], 'ms  sum k5 wgrad %.1f' % w, ' '.join('%s=%.1f' % (t, k[t]['ms'] * 1e3) for t in ('dec3.wgrad', 'dec2.wgrad', 'enc1.wgrad', 'enc3.wgrad', 'dec3.dgrad', 'dec3.fwd', 'enc3.fwd', 'dec0.fwd')))
+except Exception as e:
+    print('$VAR=$v failed', e)
+PY
+    done; done; done
+    ;;
 *)  echo "unknown step $STEP"; exit 2;;
 esac

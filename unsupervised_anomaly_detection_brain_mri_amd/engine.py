@@ -181,6 +181,7 @@ class Engine(_EvalOps):
     def close(self):
         if getattr(self, 'handle', None):
             torch.cuda.synchronize(self.device)
+            self._ar_comm = None              # (the communicator belongs to the DataParallelStep that attached it: parallel.DataParallelStep.close)
             self.lib.uad_destroy(self.handle)
             self.handle = None
 
@@ -411,6 +412,7 @@ class Engine(_EvalOps):
         parallel.bucket_plan returns it.  From then on backward_allreduce(segment) enqueues the buckets' RCCL all-reduces itself."""
         if comm is None:
             _lib.check(self.lib.uad_allreduce_attach(self.handle, None, 1, 0, None, None, None))
+            self._ar_comm = None
             return
         n = len(plan)
         after = (C.c_int * n)(*[int(p[0]) for p in plan])

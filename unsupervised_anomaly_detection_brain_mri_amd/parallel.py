@@ -19,19 +19,41 @@ from . import _lib
 SEGMENT_ORDER = (_lib.SEG_DECODER, _lib.SEG_BOTTLENECK, _lib.SEG_ENCODER_HI, _lib.SEG_ENCODER_LO)
 
 
+def _all_ok(ok, group=None):
+    """True iff `ok` holds on EVERY rank of the group (one MIN all-reduce): the outcome of a step that can fail on one rank only becomes a
+    collective decision, so that all ranks take the same path afterwards (library-issued vs torch.distributed all-reduce) or raise together."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    on_dev = dist.get_backend(group) == 'nccl'
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device='cuda' if on_dev else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
 class RcclComm:
     """An RCCL communicator owned by libuad_hip.so (include/uad_hip.h: uad_rccl_*), one rank per process, created over an EXISTING torch.distributed
     group: rank 0 draws the ncclUniqueId, one broadcast over the group hands it to the others, every rank joins with ncclCommInitRank on its current
-    device.  The library enqueues its all-reduces on this communicator itself -- torch's process group is only the bootstrap channel."""
+    device.  The library enqueues its all-reduces on this communicator itself -- torch's process group is only the bootstrap channel.
+
+    Every step that can fail on one rank alone is agreed on over the group before the next collective: (1) every rank draws an id (which loads
+    librccl; rank 0's is the one used) and the ranks agree that all could; (2) rank 0 ALWAYS broadcasts -- a rank that failed never leaves the others
+    waiting in a broadcast that it then pairs with some later collective of a different size; (3) after ncclCommInitRank the ranks agree again, and a
+    rank that succeeded where another failed destroys its communicator.  The constructor therefore raises on all ranks or on none."""
 
     def __init__(self, group=None):
         import ctypes as C
         self.lib = _lib.load()
+        self.handle = None
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         idbuf = (C.c_ubyte * 128)()
-        if self.rank == 0:
+        err = None
+        try:
             _lib.check(self.lib.uad_rccl_unique_id(idbuf, 128))
+        except Exception as e:      # librccl not loadable on this rank, ncclGetUniqueId refused ...
+            err = e
+        if not _all_ok(err is None, group):
+            raise RuntimeError('RCCL is not usable on every rank' + (f' (this rank: {err})' if err else ' (another rank failed)'))
         on_dev = dist.get_backend(group) == 'nccl'
         t = torch.tensor(list(idbuf), dtype=torch.uint8, device='cuda' if on_dev else 'cpu')
         if self.world > 1:
@@ -39,8 +61,14 @@ class RcclComm:
         raw = bytes(t.cpu().tolist())
         comm = C.c_void_p()
         torch.cuda.synchronize()
-        _lib.check(self.lib.uad_rccl_comm_create(raw, self.world, self.rank, C.byref(comm)))
-        self.handle = comm.value
+        try:
+            _lib.check(self.lib.uad_rccl_comm_create(raw, self.world, self.rank, C.byref(comm)))
+            self.handle = comm.value
+        except Exception as e:
+            err = e
+        if not _all_ok(err is None, group):
+            self.close()
+            raise RuntimeError('ncclCommInitRank did not succeed on every rank' + (f' (this rank: {err})' if err else ' (another rank failed)'))
 
     def allreduce_(self, tensor, stream=None):
         """In-place float32 sum over the ranks, enqueued on `stream` (default: the current stream); returns at once."""
@@ -132,21 +160,52 @@ class DataParallelStep:
         # torch.distributed path below stays as the fallback (gloo CPU tests, UAD_DP_LIBRARY_AR=0).
         want_lib = _library_allreduce_default() if library_allreduce is None else bool(library_allreduce)
         self.comm = None
+        self._own_comm = False
         if want_lib and (self.world > 1 or self.force) and hasattr(engine, 'allreduce_attach'):
+            # Whether the library path is taken is a COLLECTIVE decision: RcclComm() raises on all ranks or on none, and the attach
+            # -- which can fail on one rank alone -- is agreed on before anybody uses it: a rank on the torch process group beside ranks issuing
+            # ncclAllReduce on the library's communicator would deadlock the first train_step.
+            err = None
             try:
                 self.comm = comm if comm is not None else RcclComm()      # (comm=: a communicator the caller created earlier)
-                engine.allreduce_attach(self.comm, self.world, self.plan)
-            except Exception as e:      # librccl not loadable, communicator creation refused ...: the torch.distributed path still works
-                if library_allreduce:   # asked for explicitly: do not hide the failure
-                    raise
+                self._own_comm = comm is None
+            except Exception as e:      # librccl not loadable, communicator creation refused ...: on every rank (RcclComm agrees before it raises)
+                err = e
+            if err is None:
+                try:
+                    engine.allreduce_attach(self.comm, self.world, self.plan)
+                except Exception as e:
+                    err = e
+            if not _all_ok(err is None):
+                self._drop_comm()
+                if library_allreduce:   # asked for explicitly: do not hide the failure (raised on every rank)
+                    raise RuntimeError(f'library-issued all-reduce unavailable: {err if err else "another rank failed"}')
                 import sys
-                print(f'uad: library-issued all-reduce unavailable ({e}); falling back to torch.distributed', file=sys.stderr)
-                self.comm = None
-        elif (self.world > 1 or self.force) and dist.is_initialized() and dist.get_backend() == 'nccl' and getattr(engine, 'created_before_process_group', False):
+                print(f'uad: library-issued all-reduce unavailable ({err if err else "another rank failed"}); every rank falls back to torch.distributed', file=sys.stderr)
+        if self.comm is None and hasattr(engine, 'allreduce_attach') and getattr(engine, '_ar_comm', None) is not None:
+            engine.allreduce_attach(None, 1, None)      # a communicator an earlier DataParallelStep left attached must not outlive the choice of the torch path
+            engine._ar_comm = None
+        if self.comm is None and (self.world > 1 or self.force) and dist.is_initialized() and dist.get_backend() == 'nccl' and getattr(engine, 'created_before_process_group', False):
             # torch path under RCCL: with the handle created BEFORE the communicator the process group's stream lands on a hardware queue it shares
             # with a stream it waits for -- every all-reduce then costs ~0.2 ms of stall (measured).  Enforced, not only documented.
             raise RuntimeError('DataParallelStep over torch.distributed/nccl: create the process group (init_process_group(..., device_id=...)) BEFORE the '
                                'engine, or use the library-issued all-reduce (UAD_DP_LIBRARY_AR=1, the default)')
+
+    def _drop_comm(self):
+        if self.comm is not None:
+            try:
+                if getattr(self.eng, 'handle', None) and hasattr(self.eng, 'allreduce_attach'):
+                    self.eng.allreduce_attach(None, 1, None)
+                    self.eng._ar_comm = None
+            finally:
+                if self._own_comm:
+                    self.comm.close()
+                self.comm = None
+
+    def close(self):
+        """Detaches the library-issued all-reduce from the engine and destroys the communicator this object created (one per DataParallelStep: re-creating
+        the step on the same engine without close() leaked one communicator each time)."""
+        self._drop_comm()
 
     def broadcast_params(self, src=0):
         if self.world > 1 or self.force:
@@ -208,12 +267,17 @@ class GanDataParallel:
         self.comm = None
         if want_lib and self.world > 1:
             try:
-                self.comm = RcclComm()
+                self.comm = RcclComm()          # raises on every rank or on none (it agrees over the group first)
             except Exception as e:
                 if library_allreduce:
                     raise
                 import sys
-                print(f'uad: library-issued all-reduce unavailable ({e}); falling back to torch.distributed', file=sys.stderr)
+                print(f'uad: library-issued all-reduce unavailable ({e}); every rank falls back to torch.distributed', file=sys.stderr)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
     def broadcast_params(self, src=0):
         if self.world > 1:
