@@ -5,17 +5,13 @@ interpreter with the switch set:
   UAD_NO_FUSED_BOTT_WGRAD  bottleneck parameter gradients as batched GEMMs + column sums instead of bottleneck_wgrad_kernel
   UAD_NO_FIRST32           generic first-layer kernels instead of conv_first_fwd32 / conv_first_wgrad32
   UAD_NO_SIDE_PACK         weight repack on the caller's stream inside the next forward instead of on the side stream after the optimizer step
-  UAD_EVENT_SYSFENCE       stream-ordering events with the default system-scope fence
-  UAD_NO_W_TR              round-3 channel-major filter-gradient kernel instead of the transpose-read one (ds_read_b64_tr_b16 fragments)
-  UAD_NO_W_T               ... and the round-2 pixel-major gather kernel instead of either
   UAD_NO_INKERNEL_SPLITK   split-K slabs summed by splitk_epilogue_kernel launches instead of the conv kernels' last-arriver reduction
   UAD_NO_D16S              round-2 ConvT-class kernel (LDS-transposed epilogue) instead of the lane = pixel one
-  UAD_NO_REDUCE_NT         slab reductions with plain instead of streaming (non-temporal) loads
-  UAD_NO_PACK8             per-element bf16 weight repack (four 2-byte stores per element) instead of one 16-byte group per thread
   UAD_NO_FUSED_FINAL_F32   exact-fp32 mode: separate final 1x1 conv + loss kernel instead of the last ConvT's fused epilogue (round 4)
   UAD_NO_ANYORDER          every launch with the AQL barrier bit (no data gradient starting while its layer's filter gradient drains)
 (The opt-in experiments of round 3 -- UAD_PG, UAD_PP, UAD_D16S_MF2, UAD_W_TW8, UAD_W5_MINTILES, UAD_STAGGER -- measured slower or neutral and
-were removed in round 4; the code is kept as tools/experiments/r03_pruned_opt_in_paths.patch.)"""
+were removed in round 4; round 6 removed every path that had been the non-default for two rounds -- UAD_NO_F16, UAD_NO_D16, UAD_NO_W_T, UAD_NO_W_TR,
+UAD_NO_W2, UAD_NO_FB_BITS, UAD_NO_FB_ON_LOAD, UAD_NO_REDUCE_NT, UAD_NO_PACK8, UAD_EVENT_SYSFENCE -- with their kernels; git history has them.)"""
 import os
 import subprocess
 import sys
@@ -26,8 +22,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_EVENT_SYSFENCE', 'UAD_NO_W_TR', 'UAD_NO_W_T', 'UAD_NO_INKERNEL_SPLITK',
-                                  'UAD_NO_D16S', 'UAD_NO_REDUCE_NT', 'UAD_NO_ANYORDER', 'UAD_NO_PACK8', 'UAD_NO_FUSED_FINAL_F32', 'UAD_NO_PACK_HEAD',
+@pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_NO_INKERNEL_SPLITK',
+                                  'UAD_NO_D16S', 'UAD_NO_ANYORDER', 'UAD_NO_FUSED_FINAL_F32', 'UAD_NO_PACK_HEAD',
                                   'UAD_SPATIAL_MIN_WGS=256'])
 def test_model_parity_with_switch(knob):
     name, _, val = knob.partition('=')

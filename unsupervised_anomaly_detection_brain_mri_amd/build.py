@@ -35,7 +35,8 @@ def build(force=False, verbose=False):
     objdir = os.path.join(ROOT, 'build', 'uad_hip')
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, 'uad_kernels.h'), os.path.join(ROOT, 'include', 'uad_hip.h'), os.path.join(CSRC, 'uad_gan_kernels.inc'),
-               os.path.join(CSRC, 'uad_gan_create.inc'), os.path.join(CSRC, 'uad_conv16s.inc'), os.path.join(CSRC, 'uad_convk16.inc')]      # the .inc files are textual parts of uad_gan.hip
+               os.path.join(CSRC, 'uad_gan_create.inc'), os.path.join(CSRC, 'uad_conv16s.inc'), os.path.join(CSRC, 'uad_convk16.inc'),
+               os.path.join(CSRC, 'uad_conv5_f32.inc'), os.path.join(CSRC, 'uad_conv5_f32w.inc')]      # the .inc files are textual parts of uad_gan.hip
     objs = []
     # hidden visibility: the library exports exactly the functions include/uad_hip.h declares (its visibility push), none of the C++ launch layer
     flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fvisibility-inlines-hidden', '-Wno-unused-value', '-Wno-unused-result']

@@ -437,489 +437,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
     }
 }
 
-// ================================================================================================
-// k5 s2 SAME specialisations ("spatial" kernels): the input halo tile of one channel chunk is staged in LDS ONCE
-// (activation applied on the way in) and all 25 taps are contracted from it; the weight fragments go global -> VGPR,
-// prefetched one tap ahead, so the tap loop has no barrier and no per-tap address arithmetic (tap offsets are
-// immediates).  One workgroup = TH x TW output positions (F) / input-resolution positions (D) x 32*WGN channels.
-// ================================================================================================
-template <int NKK>
-struct BFragF { float v[NKK][4]; };
-template <int NKK>
-struct BFragD { float4 v[NKK]; };
-
-// common epilogue for one 32x32 accumulator fragment whose 16 row offsets are known
-template <int KIND_UNUSED>
-__device__ __forceinline__ void epilogue_frag(const ConvGemmArgs& a, const v16f& acc, const size_t (&obase)[16],
-                                              bool colok, int colc, float c_a, float c_b, float& s1, float& s2) {
-    if (a.ep.kind != UAD_EPI_BWD_ACT) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (!colok) continue;
-            const size_t off = obase[r] + colc;
-            float v = acc[r] + c_a;
-            if (a.ep.mul) v *= a.ep.mul[off];
-            if (a.ep.add) v += a.ep.add[off];
-            a.Out[off] = v;
-        }
-    } else {
-        float cp[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cp[r] = a.ep.cprev[colok ? (obase[r] + colc) : 0];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float c = cp[r];
-            const float bn = fmaf(c_a, c, c_b);
-            float dbn = bn > 0.f ? acc[r] : acc[r] * a.ep.ealpha;
-            dbn = colok ? dbn : 0.f;
-            if (colok) a.Out[obase[r] + colc] = dbn * c_a;
-            s1 += dbn;
-            s2 = fmaf(dbn, c, s2);
-        }
-    }
-}
-
-template <int TH, int TW, int CK, int WGM, int WGN>
-__global__ void __launch_bounds__(64 * WGM * WGN) conv5_f_kernel(const ConvGemmArgs a) {
-    constexpr int NT = 64 * WGM * WGN;
-    constexpr int IH = 2 * TH + 3, IW = 2 * TW + 3;
-    constexpr int LDC = CK + 4, NKK = CK / 8, CQ = CK / 4;
-    constexpr int BN = 32 * WGN;
-    static_assert(TH * TW == 32 * WGM, "one 32-row fragment per wave along M");
-    __shared__ __attribute__((aligned(16))) float sIn[IH * IW * LDC];
-    __shared__ __attribute__((aligned(16))) float s_xf[2 * XF_LDS_CH];
-    __shared__ float s_red[WGM * 2 * BN];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const UadConvDesc& d = a.d;
-    const int tilesx = d.WS / TW;
-    const int ty0 = (blockIdx.x / tilesx) * TH, tx0 = (blockIdx.x % tilesx) * TW;
-    const int n = blockIdx.y;
-    const int nsplit = a.nsplit;
-    const int n0 = (blockIdx.z / nsplit) * BN;
-    const int split = blockIdx.z % nsplit;
-    const int CB = d.CB, CS = d.CS;
-
-    const bool xf = a.xf.scale != nullptr;
-    if (xf)
-        for (int c = tid; c < CB; c += NT) {
-            s_xf[c] = a.xf.scale[c] * a.xf.mult;
-            s_xf[XF_LDS_CH + c] = a.xf.shift[c];
-        }
-
-    const int m = wm * 32 + l31;
-    const int pty = m / TW, ptx = m % TW;
-    const int aoff = ((2 * pty) * IW + 2 * ptx) * LDC + 4 * lh;
-    const int col = n0 + wn * 32 + l31;
-    const bool colok = col < CS;
-    const int colc = colok ? col : 0;
-    // packed weights Wp[tap][cb/4][cs][4]: the lane's four k-slots of one k-slice are ONE 16-byte load and the
-    // 32 lanes of a half-wave read 512 contiguous bytes
-    const float* wptr = a.Wp + ((size_t)lh * CS + colc) * 4;
-
-    BFragD<NKK> b0, b1;
-    auto loadB = [&](BFragD<NKK>& b, int tap, int c0) {
-        const float* w = wptr + ((size_t)tap * CB + c0) * CS;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) b.v[kk] = *reinterpret_cast<const float4*>(w + (size_t)(kk * 2) * CS * 4);
-    };
-
-    // four independent accumulator chains (one per k-slot of the float4 fragment): an MFMA never waits on its
-    // predecessor, so the ds_reads / weight loads interleaved between them cost no matrix-pipe time
-    v16f acc4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
-
-    // split-K: this workgroup contracts channel chunks [ch0, nchunks)
-    const int cper = (CB / CK + nsplit - 1) / nsplit;
-    const int ch0 = split * cper;
-    const int nchunks = min(CB / CK, ch0 + cper);
-    const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-    const float* inb = a.A + (size_t)n * d.HB * d.WB * CB;
-    loadB(b0, 0, ch0 * CK);
-    __syncthreads();  // s_xf visible
-
-    for (int ch = ch0; ch < nchunks; ++ch) {
-        const int c0 = ch * CK;
-        if (ch > ch0) __syncthreads();  // everyone is done reading the previous chunk's tile
-        // ---- stage the halo tile of this channel chunk (activation on the way in, padding = exact 0) ----
-        constexpr int TOT = IH * IW * CQ;
-        constexpr int BATCH = 6;
-        for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
-            float4 v[BATCH];
-            bool ok[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int f = f0 + u * NT;
-                const int pix = f / CQ, cq = f % CQ;
-                const int iy = pix / IW, ix = pix % IW;
-                const int gy = gy0 + iy, gx = gx0 + ix;
-                ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
-                const int gp = ok[u] ? (gy * d.WB + gx) : 0;
-                v[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CB + c0 + (ok[u] ? cq * 4 : 0));
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int f = f0 + u * NT;
-                if (f >= TOT) continue;
-                const int pix = f / CQ, cq = f % CQ;
-                float4 t = v[u];
-                if (xf) {
-                    const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
-                    const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
-                    t = xform4(t, sc, sh, a.xf.alpha);
-                }
-                *reinterpret_cast<float4*>(sIn + pix * LDC + cq * 4) = keep4(ok[u], t);
-            }
-        }
-        __syncthreads();
-        // ---- 25 taps from LDS; weights one tap ahead in registers ----
-#pragma unroll
-        for (int tap = 0; tap < 25; ++tap) {
-            const int ky = tap / 5, kx = tap % 5;
-            BFragD<NKK>& cur = (tap & 1) ? b1 : b0;
-            BFragD<NKK>& nxt = (tap & 1) ? b0 : b1;
-            if (tap < 24) loadB(nxt, tap + 1, c0);
-            else if (ch + 1 < nchunks) loadB(nxt, 0, c0 + CK);
-            // keep the prefetch a full tap ahead: without this fence the scheduler sinks the loads to their first
-            // use (vmcnt(0) right behind the issue) and every tap eats an L2 round trip
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const float4 av = *reinterpret_cast<const float4*>(sIn + aoff + (ky * IW + kx) * LDC + kk * 8);
-                acc4[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, cur.v[kk].x, acc4[0], 0, 0, 0);
-                acc4[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, cur.v[kk].y, acc4[1], 0, 0, 0);
-                acc4[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, cur.v[kk].z, acc4[2], 0, 0, 0);
-                acc4[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, cur.v[kk].w, acc4[3], 0, 0, 0);
-            }
-        }
-        b0 = b1;  // 25 taps is odd: the prefetched tap 0 of the next chunk sits in b1
-    }
-
-    // ---- epilogue ----
-    v16f acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
-    const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
-    float c_a, c_b = 0.f;
-    if (!bwd) c_a = a.ep.bias ? a.ep.bias[colc] : 0.f;
-    else { c_a = a.ep.escale[colc] * a.ep.emult; c_b = a.ep.eshift[colc]; }
-    size_t obase[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mm = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int oy = ty0 + mm / TW, ox = tx0 + mm % TW;
-        obase[r] = ((size_t)(n * d.HS + oy) * d.WS + ox) * CS;
-    }
-    float s1 = 0.f, s2 = 0.f;
-    if (nsplit > 1) {   // raw partial tile into this split's slab; splitk_epilogue_kernel finishes the job
-        float* slab = a.Out + (size_t)split * a.out_elems;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (colok) slab[obase[r] + colc] = acc[r];
-        return;
-    }
-    epilogue_frag<0>(a, acc, obase, colok, colc, c_a, c_b, s1, s2);
-    if (bwd) {
-        const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
-        if (lh == 0) {
-            s_red[(wm * 2 + 0) * BN + wn * 32 + l31] = t1;
-            s_red[(wm * 2 + 1) * BN + wn * 32 + l31] = t2;
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid % BN;
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < WGM; ++w) t += s_red[(w * 2 + which) * BN + c];
-            const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-            if (n0 + c < CS) a.ep.colpart[(tile * 2 + which) * CS + n0 + c] = t;
-        }
-    }
-}
-
-__device__ __forceinline__ float sum8_dpp(float v);      // (DPP butterfly over 8 consecutive lanes, defined with the bf16 kernels below)
-// FIN (round 4): the last decoder block of the exact-fp32 mode -- its BN + LeakyReLU, the final 1 x 1 convolution, the L1 loss and the loss
-// gradient run in this kernel's epilogue exactly as in conv5_d16_kernel (UAD_EPI_FINAL), instead of a final_kernel pass that re-reads the
-// block's 128 B / pixel output; the epilogue's tiles alias the halo tile, so the instance needs no more LDS than the plain one.
-template <int TH, int TW, int CK, int WGM, int WGN, bool FIN = false>
-__global__ void __launch_bounds__(64 * WGM * WGN) conv5_d_kernel(const ConvGemmArgs a) {
-    constexpr int NT = 64 * WGM * WGN;
-    constexpr int IH = TH + 2, IW = TW + 2;
-    constexpr int LDC = CK + 4, NKK = CK / 8, CQ = CK / 4;
-    constexpr int BN = 32 * WGN;
-    static_assert(TH * TW == 32 * WGM, "one 32-row fragment per wave along M");
-    __shared__ __attribute__((aligned(16))) float sIn[IH * IW * LDC];
-    __shared__ __attribute__((aligned(16))) float s_xf[2 * XF_LDS_CH];
-    __shared__ float s_red[WGM * 2 * BN];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const UadConvDesc& d = a.d;
-    const int tilesx = d.WS / TW;
-    const int ty0 = (blockIdx.x / tilesx) * TH, tx0 = (blockIdx.x % tilesx) * TW;
-    const int n = blockIdx.y;
-    const int nsplit = a.nsplit;
-    const int n0 = (blockIdx.z / nsplit) * BN;
-    const int split = blockIdx.z % nsplit;
-    const int CB = d.CB, CS = d.CS;   // output channels = CB, contraction = CS
-
-    const bool xf = a.xf.scale != nullptr;
-    if (xf)
-        for (int c = tid; c < CS; c += NT) {
-            s_xf[c] = a.xf.scale[c] * a.xf.mult;
-            s_xf[XF_LDS_CH + c] = a.xf.shift[c];
-        }
-
-    const int m = wm * 32 + l31;
-    const int pty = m / TW, ptx = m % TW;
-    const int aoff = ((pty + 1) * IW + ptx + 1) * LDC + 4 * lh;
-    const int col = n0 + wn * 32 + l31;
-    const bool colok = col < CB;
-    const int colc = colok ? col : 0;
-    // packed weights Wq[tap][cs/4][cb][4] (contraction quad innermost, output channel next): coalesced 16-byte loads
-    const float* wptr = a.Wp + ((size_t)lh * CB + colc) * 4;
-
-    BFragD<NKK> b0, b1;
-    auto loadB = [&](BFragD<NKK>& b, int tap, int c0) {
-        const float* w = wptr + ((size_t)tap * CS + c0) * CB;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) b.v[kk] = *reinterpret_cast<const float4*>(w + (size_t)(kk * 2) * CB * 4);
-    };
-
-    v16f acc[4];   // output-parity classes (py, px)
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-
-    const int cper = (CS / CK + nsplit - 1) / nsplit;
-    const int ch0 = split * cper;
-    const int nchunks = min(CS / CK, ch0 + cper);
-    const float* inb = a.A + (size_t)n * d.HS * d.WS * CS;
-    loadB(b0, 0, ch0 * CK);
-    __syncthreads();
-
-    for (int ch = ch0; ch < nchunks; ++ch) {
-        const int c0 = ch * CK;
-        if (ch > ch0) __syncthreads();
-        constexpr int TOT = IH * IW * CQ;
-        constexpr int BATCH = 4;
-        for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
-            float4 v[BATCH];
-            bool ok[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int f = f0 + u * NT;
-                const int pix = f / CQ, cq = f % CQ;
-                const int iy = pix / IW, ix = pix % IW;
-                const int gy = ty0 - 1 + iy, gx = tx0 - 1 + ix;
-                ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HS && (unsigned)gx < (unsigned)d.WS;
-                const int gp = ok[u] ? (gy * d.WS + gx) : 0;
-                v[u] = *reinterpret_cast<const float4*>(inb + (size_t)gp * CS + c0 + (ok[u] ? cq * 4 : 0));
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int f = f0 + u * NT;
-                if (f >= TOT) continue;
-                const int pix = f / CQ, cq = f % CQ;
-                float4 t = v[u];
-                if (xf) {
-                    const float4 sc = *reinterpret_cast<const float4*>(s_xf + c0 + cq * 4);
-                    const float4 sh = *reinterpret_cast<const float4*>(s_xf + XF_LDS_CH + c0 + cq * 4);
-                    t = xform4(t, sc, sh, a.xf.alpha);
-                }
-                *reinterpret_cast<float4*>(sIn + pix * LDC + cq * 4) = keep4(ok[u], t);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tap = 0; tap < 25; ++tap) {
-            const int ky = tap / 5, kx = tap % 5;
-            // y[2i-1+ky] += x[i]: output parity py = (ky+1)&1, source row i + dy with dy = (py + 1 - ky) / 2
-            const int py = (ky + 1) & 1, px = (kx + 1) & 1;
-            const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
-            const int cls = py * 2 + px;
-            BFragD<NKK>& cur = (tap & 1) ? b1 : b0;
-            BFragD<NKK>& nxt = (tap & 1) ? b0 : b1;
-            if (tap < 24) loadB(nxt, tap + 1, c0);
-            else if (ch + 1 < nchunks) loadB(nxt, 0, c0 + CK);
-            // keep the prefetch a full tap ahead: without this fence the scheduler sinks the loads to their first
-            // use (vmcnt(0) right behind the issue) and every tap eats an L2 round trip
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const float4 av = *reinterpret_cast<const float4*>(sIn + aoff + (dy * IW + dx) * LDC + kk * 8);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, cur.v[kk].x, acc[cls], 0, 0, 0);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, cur.v[kk].y, acc[cls], 0, 0, 0);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, cur.v[kk].z, acc[cls], 0, 0, 0);
-                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, cur.v[kk].w, acc[cls], 0, 0, 0);
-            }
-        }
-        b0 = b1;
-    }
-
-    if constexpr (FIN) {
-        // (models/customlayers.py:35-37 + trainers/VAE.py:36-40 behind the last Conv2DTranspose; partials in final_kernel's layout)
-        static_assert(WGN == 1, "one 32-channel column block holds every channel of the last block");
-        constexpr int EPI_LD = 36;
-        float* s_epi = sIn;                                   // per-wave 32 x EPI_LD transpose tile (the halo tile is dead by now)
-        float* s_fx = s_epi + WGM * 32 * EPI_LD;              // target | reconstruction | L1 tiles of the 2TH x 2TW output block
-        float* s_fo = s_fx + 4 * TH * TW;                     // (s_fo | s_fl adjacent)
-        static_assert(WGM * 32 * EPI_LD + 3 * 4 * TH * TW <= IH * IW * LDC, "epilogue tiles fit in the halo tile");
-        __syncthreads();
-        for (int idx = tid; idx < 4 * TH * TW; idx += NT) {
-            const int yl = idx / (2 * TW), xl = idx % (2 * TW);
-            s_fx[idx] = a.ep.fin_x[((size_t)n * d.HB + 2 * ty0 + yl) * d.WB + 2 * tx0 + xl];
-        }
-        __syncthreads();
-        float* etile = s_epi + wave * 32 * EPI_LD;
-        const int ec4 = (lane & 7) * 4, erow = lane >> 3;
-        const int ecol = n0 + ec4;                            // CB == 32: always in range
-        float4 e_a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.ep.bias) e_a = *reinterpret_cast<const float4*>(a.ep.bias + ecol);
-        float4 f_sc = *reinterpret_cast<const float4*>(a.ep.escale + ecol);
-        f_sc.x *= a.ep.emult; f_sc.y *= a.ep.emult; f_sc.z *= a.ep.emult; f_sc.w *= a.ep.emult;
-        const float4 f_sh = *reinterpret_cast<const float4*>(a.ep.eshift + ecol);
-        const float4 f_w = *reinterpret_cast<const float4*>(a.ep.fin_wf + ecol);
-        const float f_bf = a.ep.fin_bf[0];
-        const float scv[4] = {f_sc.x, f_sc.y, f_sc.z, f_sc.w}, shv[4] = {f_sh.x, f_sh.y, f_sh.z, f_sh.w};
-        const float wv[4] = {f_w.x, f_w.y, f_w.z, f_w.w};
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, dwf[4] = {0.f, 0.f, 0.f, 0.f};
-        float rec = 0.f, dbf = 0.f;
-#pragma unroll
-        for (int cls = 0; cls < 4; ++cls) {
-            const int py = cls >> 1, px = cls & 1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) etile[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + l31] = acc[cls][r];
-            __builtin_amdgcn_wave_barrier();
-            float4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(etile + (erow + 8 * k) * EPI_LD + ec4);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int mm = wm * 32 + erow + 8 * k;
-                const int Y = 2 * (ty0 + mm / TW) + py, X = 2 * (tx0 + mm % TW) + px;
-                const size_t off = ((size_t)(n * d.HB + Y) * d.WB + X) * CB + ecol;
-                const int lidx = (2 * (mm / TW) + py) * (2 * TW) + 2 * (mm % TW) + px;
-                const float cc[4] = {v[k].x + e_a.x, v[k].y + e_a.y, v[k].z + e_a.z, v[k].w + e_a.w};
-                float bn[4], av[4];
-                float dot = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bn[e] = fmaf(cc[e], scv[e], shv[e]);
-                    av[e] = bn[e] > 0.f ? bn[e] : bn[e] * a.ep.ealpha;
-                    dot = fmaf(av[e], wv[e], dot);
-                }
-                dot = sum8_dpp(dot);                          // the 8 lanes that share the pixel
-                const float xh = dot + f_bf;
-                const float diff = xh - s_fx[lidx];
-                rec += fabsf(diff);
-                if (a.Out) *reinterpret_cast<float4*>(a.Out + off) = make_float4(cc[0], cc[1], cc[2], cc[3]);
-                if (a.ep.fin_dc) {
-                    const float sgn = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * a.ep.fin_inv_batch;
-                    float dc[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float da = sgn * wv[e];
-                        const float dbn = bn[e] > 0.f ? da : da * a.ep.ealpha;
-                        dc[e] = dbn * scv[e];
-                        dwf[e] = fmaf(sgn, av[e], dwf[e]);
-                        s1[e] += dbn;
-                        s2[e] = fmaf(dbn, cc[e], s2[e]);
-                    }
-                    *reinterpret_cast<float4*>(a.ep.fin_dc + off) = make_float4(dc[0], dc[1], dc[2], dc[3]);
-                    dbf += sgn;
-                }
-                if ((lane & 6) == 0) s_fo[(lane & 1) * (4 * TH * TW) + lidx] = (lane & 1) ? fabsf(diff) : xh;
-            }
-        }
-        __syncthreads();                                      // every wave is done with its transpose tile (reused below)
-        for (int idx = tid; idx < 4 * TH * TW; idx += NT) {
-            const int yl = idx / (2 * TW), xl = idx % (2 * TW);
-            const size_t pix = ((size_t)n * d.HB + 2 * ty0 + yl) * d.WB + 2 * tx0 + xl;
-            a.ep.fin_xhat[pix] = s_fo[idx];
-            if (a.ep.fin_l1) a.ep.fin_l1[pix] = s_fo[4 * TH * TW + idx];
-        }
-        // workgroup partials: red_partial[tile][3C + 1] = {dwf[C], S1[C], S2[C], dbf}, rec_partial[tile]
-        float* fr = s_epi;
-        constexpr int FL = 3 * BN + 2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t0 = dwf[e], t1 = s1[e], t2 = s2[e];
-            t0 += __shfl_xor(t0, 8); t0 += __shfl_xor(t0, 16); t0 += __shfl_xor(t0, 32);
-            t1 += __shfl_xor(t1, 8); t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
-            t2 += __shfl_xor(t2, 8); t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
-            if (lane < 8) {
-                fr[wave * FL + 0 * BN + ec4 + e] = t0;
-                fr[wave * FL + 1 * BN + ec4 + e] = t1;
-                fr[wave * FL + 2 * BN + ec4 + e] = t2;
-            }
-        }
-        float r0 = rec, r1 = dbf;
-#pragma unroll
-        for (int o = 8; o < 64; o <<= 1) { r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); }
-        if (lane == 0) { fr[wave * FL + 3 * BN] = r1; fr[wave * FL + 3 * BN + 1] = r0; }
-        __syncthreads();
-        const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        if (tid < FL) {
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < WGM; ++w) t += fr[w * FL + tid];
-            if (tid == 3 * BN + 1) a.ep.fin_rec_partial[tile] = t;
-            else if (a.ep.fin_dc) a.ep.fin_red_partial[tile * (3 * BN + 1) + tid] = t;
-        }
-        return;
-    }
-
-    const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
-    float c_a, c_b = 0.f;
-    if (!bwd) c_a = a.ep.bias ? a.ep.bias[colc] : 0.f;
-    else { c_a = a.ep.escale[colc] * a.ep.emult; c_b = a.ep.eshift[colc]; }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int cls = 0; cls < 4; ++cls) {
-        const int py = cls >> 1, px = cls & 1;
-        size_t obase[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mm = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int Y = 2 * (ty0 + mm / TW) + py, X = 2 * (tx0 + mm % TW) + px;
-            obase[r] = ((size_t)(n * d.HB + Y) * d.WB + X) * CB;
-        }
-        if (nsplit > 1) {
-            float* slab = a.Out + (size_t)split * a.out_elems;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (colok) slab[obase[r] + colc] = acc[cls][r];
-        } else {
-            epilogue_frag<0>(a, acc[cls], obase, colok, colc, c_a, c_b, s1, s2);
-        }
-    }
-    if (nsplit > 1) return;
-    if (bwd) {
-        const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
-        if (lh == 0) {
-            s_red[(wm * 2 + 0) * BN + wn * 32 + l31] = t1;
-            s_red[(wm * 2 + 1) * BN + wn * 32 + l31] = t2;
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid % BN;
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < WGM; ++w) t += s_red[(w * 2 + which) * BN + c];
-            const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-            if (n0 + c < CB) a.ep.colpart[(tile * 2 + which) * CB + n0 + c] = t;
-        }
-    }
-}
+#include "uad_conv5_f32.inc"      // conv5_f_kernel / conv5_d_kernel: the exact-fp32 k5 s2 spatial kernels
 
 // ================================================================================================
 // bf16x3 math mode ("split-bf16"): every fp32 operand x is written x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
@@ -2916,643 +2434,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_w16_kernel(const ConvWArg
         }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k5 s2 SAME filter gradient, spatial form: one workgroup owns a 32(cb) x 32(cs) channel block and walks a list of
-// 8x8 tiles of the small image.  Per tile the big halo tile [19x19][32] and the small tile [64][32] are staged in LDS
-// once; wave w accumulates taps {w, w+4, ...} (7/6/6/6 independent 32x32 accumulators), contraction = the 64
-// positions of the tile (A[m=cb][k=pos], B[k=pos][n=cs]: both read from LDS with conflict-free ds_read_b32).
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) conv5_w_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
-    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256;
-    __shared__ __attribute__((aligned(16))) float sBig[IH * IW * CK];
-    __shared__ __attribute__((aligned(16))) float sSmall[TH * TW * CK];
+#include "uad_conv5_f32w.inc"      // conv5_w_kernel: the exact-fp32 k5 s2 filter gradient
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const UadConvDesc& d = a.d;
-    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32;
-    const int tilesx = d.WS / TW, tilesy = d.HS / TH;
-    const int t_begin = blockIdx.z * tiles_per_split;
-    const int t_end = min(t_begin + tiles_per_split, total_tiles);
-
-    // this thread's channel quad is the same for every float4 it stages (NT % CQ == 0)
-    const int cq = tid % CQ;
-    const bool xfa = a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
-    float4 scA = make_float4(1, 1, 1, 1), shA = make_float4(0, 0, 0, 0), scB = scA, shB = shA;
-    if (xfa) {
-        scA = *reinterpret_cast<const float4*>(a.xfb.scale + cb0 + cq * 4);
-        shA = *reinterpret_cast<const float4*>(a.xfb.shift + cb0 + cq * 4);
-        scA.x *= a.xfb.mult; scA.y *= a.xfb.mult; scA.z *= a.xfb.mult; scA.w *= a.xfb.mult;
-    }
-    if (xfs) {
-        scB = *reinterpret_cast<const float4*>(a.xfs.scale + cs0 + cq * 4);
-        shB = *reinterpret_cast<const float4*>(a.xfs.shift + cs0 + cq * 4);
-        scB.x *= a.xfs.mult; scB.y *= a.xfs.mult; scB.z *= a.xfs.mult; scB.w *= a.xfs.mult;
-    }
-
-    // taps of this wave and their LDS offsets: taps {w, w+4, .., w+20} in full, and the 25th tap (24) for one quarter of
-    // the tile's positions per wave (its four partial tiles are folded through LDS at the end) -> perfectly balanced
-    constexpr int MAXT = 7;
-    int aaddr[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-        const int tap = (j < MAXT - 1) ? wave + 4 * j : 24;
-        const int ky = tap / 5, kx = tap % 5;
-        aaddr[j] = ((ky * IW + kx) + 2 * lh) * CK + l31;   // + lane part: pixel x offset 2*lh, channel l31
-    }
-    const int baddr = lh * CK + l31;
-
-    v16f acc[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    for (int t = t_begin; t < t_end; ++t) {
-        const int tx0 = (t % tilesx) * TW;
-        const int ty0 = ((t / tilesx) % tilesy) * TH;
-        const int n = t / (tilesx * tilesy);
-        const float* bigb = a.big + (size_t)n * d.HB * d.WB * d.CB + cb0;
-        const float* smb = a.small_ + ((size_t)(n * d.HS + ty0) * d.WS + tx0) * d.CS + cs0;
-        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-        __syncthreads();   // previous tile fully consumed
-        {
-            constexpr int TOT = IH * IW * CQ;   // 2888 float4
-            constexpr int BATCH = 6;
-            for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
-                float4 v[BATCH];
-                bool ok[BATCH];
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    const int f = f0 + u * NT;
-                    const int pix = f / CQ;
-                    const int iy = pix / IW, ix = pix % IW;
-                    const int gy = gy0 + iy, gx = gx0 + ix;
-                    ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
-                    const int gp = ok[u] ? (gy * d.WB + gx) : 0;
-                    v[u] = *reinterpret_cast<const float4*>(bigb + (size_t)gp * d.CB + cq * 4);
-                }
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    const int f = f0 + u * NT;
-                    if (f >= TOT) continue;
-                    float4 tv = v[u];
-                    if (xfa) tv = xform4(tv, scA, shA, a.xfb.alpha);
-                    *reinterpret_cast<float4*>(sBig + (f / CQ) * CK + cq * 4) = keep4(ok[u], tv);
-                }
-            }
-            // small tile: 64 positions x 8 quads = 512 float4 -> 2 per thread
-            float4 sv[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int f = tid + u * NT;
-                const int pos = f / CQ;
-                sv[u] = *reinterpret_cast<const float4*>(smb + (size_t)((pos / TW) * d.WS + (pos % TW)) * d.CS + cq * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int f = tid + u * NT;
-                float4 tv = sv[u];
-                if (xfs) tv = xform4(tv, scB, shB, a.xfs.alpha);
-                *reinterpret_cast<float4*>(sSmall + (f / CQ) * CK + cq * 4) = tv;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int st = 0; st < TH * TW / 2; ++st) {
-            // positions 2*st + lh: row st/4, column 2*(st%4) + lh
-            const int cst = ((2 * (st / 4)) * IW + 4 * (st % 4)) * CK;
-            const float bv = sSmall[baddr + (2 * st) * CK];
-#pragma unroll
-            for (int j = 0; j < MAXT - 1; ++j) {
-                const float av = sBig[aaddr[j] + cst];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-            }
-            if ((st >> 3) == wave) {   // wave-uniform: this wave's quarter of tap 24
-                const float av = sBig[aaddr[MAXT - 1] + cst];
-                acc[MAXT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[MAXT - 1], 0, 0, 0);
-            }
-        }
-    }
-
-    float* out = a.partial + (size_t)blockIdx.z * a.Mtot * d.CS;
-#pragma unroll
-    for (int j = 0; j < MAXT - 1; ++j) {
-        const int tap = wave + 4 * j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[((size_t)tap * d.CB + cb) * d.CS + cs0 + l31] = acc[j][r];
-        }
-    }
-    // tap 24: fixed-order sum of the four waves' quarter-tile partials
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sBig[(wave * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = (sBig[r * 64 + lane] + sBig[(16 + r) * 64 + lane]) + (sBig[(32 + r) * 64 + lane] + sBig[(48 + r) * 64 + lane]);
-            const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[((size_t)24 * d.CB + cb) * d.CS + cs0 + l31] = v;
-        }
-    }
-}
-
-// bf16x3 form of the spatial filter gradient.  The contraction runs over positions, so the MFMA wants 8 consecutive
-// positions per lane for a fixed channel: the small tile is stored transposed ([cs][pos] bf16 planes -> one aligned
-// ds_read_b128 per fragment, shared by the wave's 6-7 taps), the big tile stays [pixel][cb] and each A fragment is
-// gathered with eight 16-bit LDS reads per plane (lane = channel, so a wave reads 64 contiguous bytes per pixel).
-// NCSB = 1: one 32-cb x 32-cs block per 4-wave workgroup.  NCSB = 2: two cs blocks share ONE staged big tile in an 8-wave
-// workgroup (waves 0-3 / 4-7): the big tile (46 KB of fp32 per 8x8 positions, the kernel's dominant cost) is staged once for
-// twice the MFMA work and by twice the threads (one round of loads instead of two).
-// FBB: `big` is the last decoder block's d loss / d c in its compressed form (UadXform::fb_bits: pattern word + d objective / d x_hat
-// per pixel, CB == 32): the 46 KB fp32 halo tile becomes 2.9 KB of loads, expanded while it is written to LDS.
-template <int NCSB, bool FBB = false>
-__global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
-conv5_w_bf16_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
-    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256 * NCSB, CSQ = 8 * NCSB;
-    constexpr int LDH = CK + 8;       // ushorts per big-tile pixel
-    constexpr int LDP = TH * TW + 8;  // ushorts per channel row of the transposed small tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    unsigned short* bHi = reinterpret_cast<unsigned short*>(dsm);
-    unsigned short* bLo = bHi + IH * IW * LDH;
-    unsigned short* sHiT = bLo + IH * IW * LDH;
-    unsigned short* sLoT = sHiT + NCSB * CK * LDP;
-    float* sXf = reinterpret_cast<float*>(sLoT + NCSB * CK * LDP);   // [32] big scale, [32] big shift, [64] small scale, [64] small shift
-    float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
-
-    const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
-    const int wave = wave_all & 3, csb = wave_all >> 2;   // tap group / cs block of this wave
-    const int l31 = lane & 31, lh = lane >> 5;
-    const UadConvDesc& d = a.d;
-    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32 * NCSB;
-    const int tilesx = d.WS / TW, tilesy = d.HS / TH;
-    const int t_begin = blockIdx.z * tiles_per_split;
-    const int t_end = min(t_begin + tiles_per_split, total_tiles);
-
-    const int cq = tid % CQ;
-    const bool xfa = !FBB && a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
-    // activation-on-load tables in LDS
-    if (tid < 32) {
-        sXf[tid] = xfa ? a.xfb.scale[cb0 + tid] * a.xfb.mult : 1.f;
-        sXf[32 + tid] = xfa ? a.xfb.shift[cb0 + tid] : 0.f;
-    }
-    if (tid < 32 * NCSB) {
-        sXf[64 + tid] = xfs ? a.xfs.scale[cs0 + tid] * a.xfs.mult : 1.f;
-        sXf[128 + tid] = xfs ? a.xfs.shift[cs0 + tid] : 0.f;
-    }
-
-    float fb_wf[4] = {0.f, 0.f, 0.f, 0.f}, fb_s1[4] = {0.f, 0.f, 0.f, 0.f}, fb_s0[4] = {0.f, 0.f, 0.f, 0.f};
-    if (FBB) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            fb_wf[e] = a.xfb.fb_wf[cb0 + cq * 4 + e];
-            fb_s1[e] = a.xfb.scale[cb0 + cq * 4 + e] * a.xfb.mult;
-            fb_s0[e] = fb_s1[e] * a.xfb.alpha;
-        }
-    }
-
-    constexpr int MAXT = 7;
-    int aaddr[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-        const int tap = (j < MAXT - 1) ? wave + 4 * j : 24;
-        const int ky = tap / 5, kx = tap % 5;
-        aaddr[j] = ((ky + 2 * lh) * IW + kx) * LDH + l31;   // tile row 2*jstep + lh -> pixel row 4*jstep + 2*lh + ky
-    }
-    const int baddr = (csb * 32 + l31) * LDP + 8 * lh;
-
-    v16f acc[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    auto gatherA = [&](const unsigned short* plane, int addr) {
-        uint4 r;
-        r.x = (unsigned)plane[addr] | ((unsigned)plane[addr + 2 * LDH] << 16);
-        r.y = (unsigned)plane[addr + 4 * LDH] | ((unsigned)plane[addr + 6 * LDH] << 16);
-        r.z = (unsigned)plane[addr + 8 * LDH] | ((unsigned)plane[addr + 10 * LDH] << 16);
-        r.w = (unsigned)plane[addr + 12 * LDH] | ((unsigned)plane[addr + 14 * LDH] << 16);
-        return r;
-    };
-
-    for (int t = t_begin; t < t_end; ++t) {
-        const int tx0 = (t % tilesx) * TW;
-        const int ty0 = ((t / tilesx) % tilesy) * TH;
-        const int n = t / (tilesx * tilesy);
-        const float* bigb = a.big + (size_t)n * d.HB * d.WB * d.CB + cb0;
-        const float* smb = a.small_ + ((size_t)(n * d.HS + ty0) * d.WS + tx0) * d.CS + cs0;
-        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-        __syncthreads();
-        {
-            constexpr int TOT = IH * IW * CQ;
-            constexpr int BATCH = 6;
-            for (int f0 = tid; f0 < TOT; f0 += NT * BATCH) {
-                float4 v[FBB ? 1 : BATCH];
-                unsigned vb[FBB ? BATCH : 1];
-                float vg[FBB ? BATCH : 1];
-                bool ok[BATCH];
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    const int f = f0 + u * NT;
-                    const int pix = f / CQ;
-                    const int iy = pix / IW, ix = pix % IW;
-                    const int gy = gy0 + iy, gx = gx0 + ix;
-                    ok[u] = (f < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
-                    const int gp = ok[u] ? (gy * d.WB + gx) : 0;
-                    if (FBB) {
-                        vb[u] = a.xfb.fb_bits[(size_t)n * d.HB * d.WB + gp];
-                        vg[u] = a.xfb.fb_dxhat[(size_t)n * d.HB * d.WB + gp];
-                    } else {
-                        v[u] = *reinterpret_cast<const float4*>(bigb + (size_t)gp * d.CB + cq * 4);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    const int f = f0 + u * NT;
-                    if (f >= TOT) continue;
-                    float4 tv = v[FBB ? 0 : u];
-                    if (FBB) {
-                        const unsigned b = vb[u] >> (cb0 + cq * 4);
-                        const float gq = vg[u];
-                        tv.x = gq * fb_wf[0] * ((b & 1u) ? fb_s1[0] : fb_s0[0]);
-                        tv.y = gq * fb_wf[1] * ((b & 2u) ? fb_s1[1] : fb_s0[1]);
-                        tv.z = gq * fb_wf[2] * ((b & 4u) ? fb_s1[2] : fb_s0[2]);
-                        tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
-                    } else if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
-                    tv = keep4(ok[u], tv);
-                    uint2 hi, lo;
-                    split_bf16(tv, hi, lo);
-                    *reinterpret_cast<uint2*>(bHi + (f / CQ) * LDH + cq * 4) = hi;
-                    *reinterpret_cast<uint2*>(bLo + (f / CQ) * LDH + cq * 4) = lo;
-                }
-            }
-            float4 sv[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + u * NT;
-                const int pos = idx / CSQ, csq = idx % CSQ;
-                sv[u] = *reinterpret_cast<const float4*>(smb + (size_t)((pos / TW) * d.WS + (pos % TW)) * d.CS + csq * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + u * NT;
-                const int pos = idx / CSQ, csq = idx % CSQ;
-                float4 tv = sv[u];
-                if (xfs) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + 64 + csq * 4), *reinterpret_cast<const float4*>(sXf + 128 + csq * 4), a.xfs.alpha);
-                uint2 hi, lo;
-                split_bf16(tv, hi, lo);
-                unsigned short* ph = sHiT + (csq * 4) * LDP + pos;
-                unsigned short* pl = sLoT + (csq * 4) * LDP + pos;
-                ph[0] = (unsigned short)hi.x; ph[LDP] = (unsigned short)(hi.x >> 16);
-                ph[2 * LDP] = (unsigned short)hi.y; ph[3 * LDP] = (unsigned short)(hi.y >> 16);
-                pl[0] = (unsigned short)lo.x; pl[LDP] = (unsigned short)(lo.x >> 16);
-                pl[2 * LDP] = (unsigned short)lo.y; pl[3 * LDP] = (unsigned short)(lo.y >> 16);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int js = 0; js < TH * TW / 16; ++js) {
-            // positions 16*js .. 16*js+15 = tile rows 2*js (lanes 0-31) and 2*js+1 (lanes 32-63), tx = element index
-            const uint4 bh = *reinterpret_cast<const uint4*>(sHiT + baddr + 16 * js);
-            const uint4 bl = *reinterpret_cast<const uint4*>(sLoT + baddr + 16 * js);
-            const int cst = (4 * js) * IW * LDH;
-#pragma unroll
-            for (int j = 0; j < MAXT - 1; ++j) {
-                const uint4 ah = gatherA(bHi, aaddr[j] + cst);
-                const uint4 al = gatherA(bLo, aaddr[j] + cst);
-                acc[j] = mfma_bf16(ah, bh, acc[j]);
-                acc[j] = mfma_bf16(ah, bl, acc[j]);
-                acc[j] = mfma_bf16(al, bh, acc[j]);
-            }
-            if (js == wave) {   // wave-uniform: this wave's quarter of tap 24
-                const uint4 ah = gatherA(bHi, aaddr[MAXT - 1] + cst);
-                const uint4 al = gatherA(bLo, aaddr[MAXT - 1] + cst);
-                acc[MAXT - 1] = mfma_bf16(ah, bh, acc[MAXT - 1]);
-                acc[MAXT - 1] = mfma_bf16(ah, bl, acc[MAXT - 1]);
-                acc[MAXT - 1] = mfma_bf16(al, bh, acc[MAXT - 1]);
-            }
-        }
-    }
-
-    float* out = a.partial + (size_t)blockIdx.z * a.Mtot * d.CS;
-#pragma unroll
-    for (int j = 0; j < MAXT - 1; ++j) {
-        const int tap = wave + 4 * j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[((size_t)tap * d.CB + cb) * d.CS + cs0 + csb * 32 + l31] = acc[j][r];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sRed[(wave_all * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* q = sRed + (size_t)csb * 64 * 64;
-            const float v = (q[r * 64 + lane] + q[(16 + r) * 64 + lane]) + (q[(32 + r) * 64 + lane] + q[(48 + r) * 64 + lane]);
-            const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[((size_t)24 * d.CB + cb) * d.CS + cs0 + csb * 32 + l31] = v;
-        }
-    }
-    if (a.dbgbuf && tid == 0) {
-        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.dbgbuf[2 * b] = dbg_t0;
-        a.dbgbuf[2 * b + 1] = wall_clock64();
-    }
-}
-// Channel-major form of conv5_w_bf16_kernel.  The MFMA wants, per lane, 8 consecutive POSITIONS of one channel; in the [pixel][channel] tile
-// that is eight strided 16-bit LDS reads + four packing instructions per fragment and plane (448 reads + 448 VALU per wave and tile -- the
-// round-2 counters show this kernel bound by instruction issue, not by a pipe).  Here the big tile is stored [channel][row][column parity][x/2]:
-// the 8 positions a k5 s2 tap touches along x (columns 2 tx + kx) are 8 CONSECUTIVE 16-bit slots of one (row, parity) segment starting at slot
-// kx >> 1, so one segment read (2 x ds_read_b64 + 1 x ds_read_b32 per plane) serves every tap of that row and parity: offsets 0 and 2 are
-// register selections, offset 1 four v_alignbit.  Taps are dealt to the four waves by kernel ROW (wave w: the five taps of row w, tap (4, w), and
-// its quarter of tap (4, 4)) so that a wave's taps share its segment reads: ~20 LDS reads and <= 24 VALU per 16-position step instead of ~100 each.
-// (An eight-tap-wave form at four waves per SIMD -- round 3, tools/experiments/r03_pruned_opt_in_paths.patch -- measured slower and was removed.)
-template <int NCSB, bool FBB = false>
-__global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
-conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
-    constexpr int TH = 8, TW = 8, IH = 2 * TH + 3, IW = 2 * TW + 3, CK = 32, CQ = CK / 4, NT = 256 * NCSB, CSQ = 8 * NCSB;
-    constexpr int XHP = 12;                       // 16-bit slots per (channel, row, parity) segment: columns 0,2,..,18 / 1,3,..,17 (+ slack)
-    constexpr int CSTP = IH * 2 * XHP + 4;        // channel stride (ushorts): 920 B = an odd number of 8-byte units -> the lanes' b64 reads spread over all banks
-    constexpr int BIGP = CK * CSTP;               // ushorts per plane
-    constexpr int LDP = TH * TW + 8;  // ushorts per channel row of the transposed small tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    // DB: two tile buffers (NCSB = 2: one 8-wave workgroup per CU, 2 x 77 KB of its 160 KB): tile t + 1 is converted and scattered into one
-    // buffer while tile t is contracted out of the other, ONE barrier per tile.  Measured in round 3: neutral (+- 1 us on every layer) -- the
-    // tile loop is not waiting at its barriers -- so it stays off (the second buffer would cost the LDS of a second resident workgroup).
-    constexpr bool DB = false;
-    constexpr int BUFP = 2 * BIGP + 2 * NCSB * CK * LDP;         // ushorts of one tile buffer
-    unsigned short* bHi0 = reinterpret_cast<unsigned short*>(dsm);
-    float* sXf = reinterpret_cast<float*>(bHi0 + (DB ? 2 : 1) * BUFP);   // [32] big scale, [32] big shift, [64] small scale, [64] small shift
-    float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
-
-    const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
-    const int wave = wave_all & 3;   // kernel row of this wave's taps
-    const int csb = wave_all >> 2;    // its cs block
-    const int l31 = lane & 31, lh = lane >> 5;
-    const UadConvDesc& d = a.d;
-    const int cb0 = blockIdx.x * 32, cs0 = blockIdx.y * 32 * NCSB;
-    const int tilesx = d.WS / TW, tilesy = d.HS / TH;
-    const int t_begin = blockIdx.z * tiles_per_split;
-    const int t_end = min(t_begin + tiles_per_split, total_tiles);
-
-    const int cq = tid % CQ;
-    const bool xfa = !FBB && a.xfb.scale != nullptr, xfs = a.xfs.scale != nullptr;
-    // activation-on-load tables in LDS
-    if (tid < 32) {
-        sXf[tid] = xfa ? a.xfb.scale[cb0 + tid] * a.xfb.mult : 1.f;
-        sXf[32 + tid] = xfa ? a.xfb.shift[cb0 + tid] : 0.f;
-    }
-    if (tid < 32 * NCSB) {
-        sXf[64 + tid] = xfs ? a.xfs.scale[cs0 + tid] * a.xfs.mult : 1.f;
-        sXf[128 + tid] = xfs ? a.xfs.shift[cs0 + tid] : 0.f;
-    }
-
-    float fb_wf[4] = {0.f, 0.f, 0.f, 0.f}, fb_s1[4] = {0.f, 0.f, 0.f, 0.f}, fb_s0[4] = {0.f, 0.f, 0.f, 0.f};
-    if (FBB) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            fb_wf[e] = a.xfb.fb_wf[cb0 + cq * 4 + e];
-            fb_s1[e] = a.xfb.scale[cb0 + cq * 4 + e] * a.xfb.mult;
-            fb_s0[e] = fb_s1[e] * a.xfb.alpha;
-        }
-    }
-
-    constexpr int MAXT = 7;
-    // segment base of this lane's channel for kernel row ky at tile-row half lh (ushorts): row y = 4 js + 2 lh + ky
-    const int seg_own = l31 * CSTP + ((2 * lh + wave) * 2) * XHP;          // ky = wave, parity 0; parity 1 at + XHP; step js at + 8 js XHP
-    const int seg_k4 = l31 * CSTP + ((2 * lh + 4) * 2) * XHP;              // ky = 4
-    const int baddr = (csb * 32 + l31) * LDP + 8 * lh;
-
-    v16f acc[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    struct Seg { unsigned d0, d1, d2, d3, d4; };
-    auto read_seg = [&](const unsigned short* plane, int addr) {           // 10 consecutive 16-bit slots (8-byte aligned)
-        Seg r;
-        const uint2 a0 = *reinterpret_cast<const uint2*>(plane + addr);
-        const uint2 a1 = *reinterpret_cast<const uint2*>(plane + addr + 4);
-        r.d0 = a0.x; r.d1 = a0.y; r.d2 = a1.x; r.d3 = a1.y;
-        r.d4 = *reinterpret_cast<const unsigned*>(plane + addr + 8);
-        return r;
-    };
-    auto frag = [&](const Seg& r, int xh0) {                               // slots xh0 .. xh0 + 7
-        if (xh0 == 0) return make_uint4(r.d0, r.d1, r.d2, r.d3);
-        if (xh0 == 2) return make_uint4(r.d1, r.d2, r.d3, r.d4);
-        return make_uint4(__builtin_amdgcn_alignbit(r.d1, r.d0, 16), __builtin_amdgcn_alignbit(r.d2, r.d1, 16),
-                          __builtin_amdgcn_alignbit(r.d3, r.d2, 16), __builtin_amdgcn_alignbit(r.d4, r.d3, 16));
-    };
-    auto mma3 = [&](v16f& c, uint4 ah, uint4 al, uint4 bh, uint4 bl) {
-        c = mfma_bf16(ah, bh, c);
-        c = mfma_bf16(ah, bl, c);
-        c = mfma_bf16(al, bh, c);
-    };
-
-    // ---- tile loop, software-pipelined: the global loads of tile t + 1 are in flight while tile t is contracted (round 3: with the loads, the
-    // LDS stores and the MFMAs all ablated the kernel still ran at 55 % of its time -- per-tile load latency that nothing covered, and
-    // per-element index arithmetic: three divisions by non-powers of two and 64-bit address products per 16 bytes staged) ----
-    constexpr int TOT = IH * IW * CQ;
-    constexpr int PER = (TOT + NT - 1) / NT;          // 16-byte elements of the big tile per thread: 12 (NT 256) or 6 (NT 512)
-    constexpr int DP = NT / CQ, DIY = DP / IW, DIX = DP % IW;      // element u + 1 of a thread is DP pixels further: (iy, ix) += (DIY, DIX), one wrap
-    const int pix0 = tid / CQ, iy0 = pix0 / IW, ix0 = pix0 % IW;
-    float4 v[FBB ? 1 : PER];
-    unsigned vb[FBB ? PER : 1];
-    float vg[FBB ? PER : 1];
-    constexpr int SPER = TH * TW * CSQ / NT;          // 16-byte elements of the small tile per thread
-    float4 sv[SPER];
-    auto tile_origin = [&](int t, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
-        tx0 = (t % tilesx) * TW;
-        ty0 = ((t / tilesx) % tilesy) * TH;
-        n = t / (tilesx * tilesy);
-    };
-    auto issue = [&](int t) __attribute__((always_inline)) {
-        int n, ty0, tx0;
-        tile_origin(t, n, ty0, tx0);
-        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-        const size_t pixbase = (size_t)n * d.HB * d.WB;
-        const float* bigb = a.big + pixbase * d.CB + cb0 + cq * 4;
-        int iy = iy0, ix = ix0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int gy = gy0 + iy, gx = gx0 + ix;
-            const bool ok = (u + 1 < PER || tid + u * NT < TOT) && (unsigned)gy < (unsigned)d.HB && (unsigned)gx < (unsigned)d.WB;
-            const int gp = ok ? (gy * d.WB + gx) : 0;
-            if (FBB) {
-                vb[FBB ? u : 0] = a.xfb.fb_bits[pixbase + gp];
-                vg[FBB ? u : 0] = a.xfb.fb_dxhat[pixbase + gp];
-            } else if (a.abl & 4) {
-                v[FBB ? 0 : u] = make_float4(1.f, 2.f, 3.f, 4.f);
-            } else {
-                v[FBB ? 0 : u] = *reinterpret_cast<const float4*>(bigb + (unsigned)(gp * d.CB));
-            }
-            ix += DIX; iy += DIY;
-            if (ix >= IW) { ix -= IW; ++iy; }
-        }
-        const size_t spix = ((size_t)(n * d.HS + ty0) * d.WS + tx0);
-#pragma unroll
-        for (int u = 0; u < SPER; ++u) {
-            const int idx = tid + u * NT;
-            const int pos = idx / CSQ, csq = idx % CSQ;
-            const unsigned po = (unsigned)((pos / TW) * d.WS + (pos % TW));
-            sv[u] = *reinterpret_cast<const float4*>(a.small_ + (spix + po) * d.CS + cs0 + csq * 4);
-        }
-    };
-    auto commit = [&](int t, int buf) __attribute__((always_inline)) {
-        unsigned short* bHi = bHi0 + buf * BUFP;
-        unsigned short* bLo = bHi + BIGP;
-        unsigned short* sHiT = bLo + BIGP;
-        unsigned short* sLoT = sHiT + NCSB * CK * LDP;
-        int n, ty0, tx0;
-        tile_origin(t, n, ty0, tx0);
-        const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
-        int iy = iy0, ix = ix0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const bool valid = u + 1 < PER || tid + u * NT < TOT;
-            const bool ok = valid && (unsigned)(gy0 + iy) < (unsigned)d.HB && (unsigned)(gx0 + ix) < (unsigned)d.WB;
-            if (valid) {
-                float4 tv = v[FBB ? 0 : u];
-                if (FBB) {
-                    const unsigned b = vb[FBB ? u : 0] >> (cb0 + cq * 4);
-                    const float gq = vg[FBB ? u : 0];
-                    tv.x = gq * fb_wf[0] * ((b & 1u) ? fb_s1[0] : fb_s0[0]);
-                    tv.y = gq * fb_wf[1] * ((b & 2u) ? fb_s1[1] : fb_s0[1]);
-                    tv.z = gq * fb_wf[2] * ((b & 4u) ? fb_s1[2] : fb_s0[2]);
-                    tv.w = gq * fb_wf[3] * ((b & 8u) ? fb_s1[3] : fb_s0[3]);
-                } else if (xfa) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + cq * 4), *reinterpret_cast<const float4*>(sXf + 32 + cq * 4), a.xfb.alpha);
-                uint2 hi, lo;
-                tv = keep4(ok, tv);
-                split_bf16(tv, hi, lo);
-                if (!(a.abl & 1)) {   // channel-major scatter: 4 channels x (hi, lo) 16-bit stores
-                    const int o = (cq * 4) * CSTP + (iy * 2 + (ix & 1)) * XHP + (ix >> 1);
-                    bHi[o] = (unsigned short)hi.x; bHi[o + CSTP] = (unsigned short)(hi.x >> 16);
-                    bHi[o + 2 * CSTP] = (unsigned short)hi.y; bHi[o + 3 * CSTP] = (unsigned short)(hi.y >> 16);
-                    bLo[o] = (unsigned short)lo.x; bLo[o + CSTP] = (unsigned short)(lo.x >> 16);
-                    bLo[o + 2 * CSTP] = (unsigned short)lo.y; bLo[o + 3 * CSTP] = (unsigned short)(lo.y >> 16);
-                }
-            }
-            ix += DIX; iy += DIY;
-            if (ix >= IW) { ix -= IW; ++iy; }
-        }
-#pragma unroll
-        for (int u = 0; u < SPER; ++u) {
-            const int idx = tid + u * NT;
-            const int pos = idx / CSQ, csq = idx % CSQ;
-            float4 tv = sv[u];
-            if (xfs) tv = xform4(tv, *reinterpret_cast<const float4*>(sXf + 64 + csq * 4), *reinterpret_cast<const float4*>(sXf + 128 + csq * 4), a.xfs.alpha);
-            uint2 hi, lo;
-            split_bf16(tv, hi, lo);
-            unsigned short* ph = sHiT + (csq * 4) * LDP + pos;
-            unsigned short* pl = sLoT + (csq * 4) * LDP + pos;
-            ph[0] = (unsigned short)hi.x; ph[LDP] = (unsigned short)(hi.x >> 16);
-            ph[2 * LDP] = (unsigned short)hi.y; ph[3 * LDP] = (unsigned short)(hi.y >> 16);
-            pl[0] = (unsigned short)lo.x; pl[LDP] = (unsigned short)(lo.x >> 16);
-            pl[2 * LDP] = (unsigned short)lo.y; pl[3 * LDP] = (unsigned short)(lo.y >> 16);
-        }
-    };
-    if (t_begin < t_end) issue(t_begin);
-    if (DB) {
-        __syncthreads();                       // the sXf tables are written
-        if (t_begin < t_end) commit(t_begin, 0);
-        if (t_begin + 1 < t_end) issue(t_begin + 1);
-        __syncthreads();
-    }
-    for (int t = t_begin; t < t_end; ++t) {
-        const int cur = DB ? ((t - t_begin) & 1) : 0;
-        if (DB) {
-            if (t + 1 < t_end) { commit(t + 1, cur ^ 1); if (t + 2 < t_end) issue(t + 2); }
-        } else {
-            __syncthreads();                   // the previous tile's fragments are consumed (first pass: the sXf tables are written)
-            commit(t, 0);
-            if (t + 1 < t_end) issue(t + 1);   // in flight across the barrier and the MFMA loop below
-            __syncthreads();
-        }
-        const unsigned short* bHi = bHi0 + cur * BUFP;
-        const unsigned short* bLo = bHi + BIGP;
-        const unsigned short* sHiT = bLo + BIGP;
-        const unsigned short* sLoT = sHiT + NCSB * CK * LDP;
-        if (!(a.abl & 2))
-#pragma unroll
-        for (int js = 0; js < TH * TW / 16; ++js) {
-            // positions 16*js .. 16*js+15 = tile rows 2*js (lanes 0-31) and 2*js+1 (lanes 32-63), tx = element index
-            const uint4 bh = *reinterpret_cast<const uint4*>(sHiT + baddr + 16 * js);
-            const uint4 bl = *reinterpret_cast<const uint4*>(sLoT + baddr + 16 * js);
-            const int so = seg_own + (8 * js) * XHP, sk = seg_k4 + (8 * js) * XHP;
-            {   // own kernel row, even columns: taps kx = 0, 2, 4
-                const Seg h = read_seg(bHi, so), l = read_seg(bLo, so);
-                mma3(acc[0], frag(h, 0), frag(l, 0), bh, bl);
-                mma3(acc[2], frag(h, 1), frag(l, 1), bh, bl);
-                mma3(acc[4], frag(h, 2), frag(l, 2), bh, bl);
-            }
-            {   // odd columns: taps kx = 1, 3
-                const Seg h = read_seg(bHi, so + XHP), l = read_seg(bLo, so + XHP);
-                mma3(acc[1], frag(h, 0), frag(l, 0), bh, bl);
-                mma3(acc[3], frag(h, 1), frag(l, 1), bh, bl);
-            }
-            {   // kernel row 4: tap (4, wave)
-                const int a4 = sk + (wave & 1) * XHP;
-                const Seg h = read_seg(bHi, a4), l = read_seg(bLo, a4);
-                const bool one = (wave >> 1) != 0;                      // slots from (wave >> 1): wave-uniform
-                mma3(acc[5], one ? frag(h, 1) : frag(h, 0), one ? frag(l, 1) : frag(l, 0), bh, bl);
-            }
-            if (js == wave) {   // wave-uniform: this wave's quarter of tap (4, 4)
-                const Seg h = read_seg(bHi, sk), l = read_seg(bLo, sk);
-                mma3(acc[6], frag(h, 2), frag(l, 2), bh, bl);
-            }
-        }
-        if (DB) __syncthreads();               // buffer `cur` is consumed, buffer `cur ^ 1` is written
-    }
-
-    // Accumulator block -> slab.  One 64-bit address per lane; everything else is a wave-uniform 32-bit offset (the plain form
-    // `out[((size_t)tap * CB + cb) * CS + col]` cost ~400 quarter-rate 64-bit multiply-adds per wave: 8 of this kernel's ~47 us).
-    const int CSi = d.CS;
-    float* ob = a.partial + (size_t)blockIdx.z * a.Mtot * CSi + (size_t)(cb0 + 4 * lh) * CSi + cs0 + csb * 32 + l31;
-    const int tapstride = d.CB * CSi;
-    if (a.abl & 32) {       // stress test (tests/test_gpu_knobs.py): every workgroup idles ~100 us before it writes its slab, so that the filter gradient
-                            // OUTLASTS the any-order data gradient launched behind it -- results stay correct, only the timing changes
-        for (int i = 0; i < 32; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    if (!(a.abl & 8))
-#pragma unroll
-    for (int j = 0; j < MAXT - 1; ++j) {
-        const int tap = j < 5 ? 5 * wave + j : 20 + wave;      // (row, 0..4), (4, row)
-        float* ot = ob + tap * tapstride;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (a.abl & 16) __builtin_nontemporal_store(acc[j][r], ot + ((r & 3) + 8 * (r >> 2)) * CSi);    // experiment: streaming slab stores
-            else ot[((r & 3) + 8 * (r >> 2)) * CSi] = acc[j][r];
-        }
-    }
-    // tap (4, 4): the four rows' shares are folded through LDS in a fixed order
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sRed[((csb * 4 + wave) * 16 + r) * 64 + lane] = acc[MAXT - 1][r];
-    __syncthreads();
-    if (wave == 0) {
-        float* ot = ob + 24 * tapstride;
-        const float* q = sRed + (size_t)csb * 64 * 64;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            ot[((r & 3) + 8 * (r >> 2)) * CSi] = (q[r * 64 + lane] + q[(16 + r) * 64 + lane]) + (q[(32 + r) * 64 + lane] + q[(48 + r) * 64 + lane]);
-    }
-    if (a.dbgbuf && tid == 0) {
-        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.dbgbuf[2 * b] = dbg_t0;
-        a.dbgbuf[2 * b + 1] = wall_clock64();
-    }
-}
 // Transpose-read form (round 4).  gfx950's ds_read_b64_tr_b16 gathers, per 16-lane group, four rows of 16 bf16 columns -- each lane supplies the
 // 8-byte-aligned address of four CONTIGUOUS columns of one row, row stride free -- and hands lane j column j's four row values (probe:
 // tools/tr_probe.hip, profiles/r04_g_tr_probe.log).  With rows = positions and columns = channels that IS the W-kind MFMA fragment (lane = channel,
@@ -3560,8 +2443,10 @@ conv5_w_bf16_t_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
 // at pixel (2 (2 js + lh) + ky, 2 (4 t + i / 4) + kx), channels 16 chalf + 4 (i & 3) .. + 3.  The big halo and the small tile are therefore staged
 // exactly as the F-kind kernels stage theirs -- two 8-byte LDS stores per float4 instead of eight 2-byte scatter stores with their shifts -- and the
 // taps need no segment shifting (v_alignbit) at all.  Bank check: the four rows of a group sit 160 B (big, pixel stride 2) / 144 B (small) apart,
-// 32 B each: dword banks [0-7] [40-47] [16-23] [56-63] / [0-7] [36-43] [8-15] [44-51], disjoint.  Same tap-to-wave assignment, slabs and fold order as
-// conv5_w_bf16_t_kernel: the results are the same bits.
+// 32 B each: dword banks [0-7] [40-47] [16-23] [56-63] / [0-7] [36-43] [8-15] [44-51], disjoint.  Tap-to-wave assignment: wave w of a cs block owns kernel row w's
+// five taps + tap (4, w) + a quarter of tap (4, 4) (folded through LDS in a fixed order); one [25][CB][CS] slab per workgroup, summed in split order by
+// reduce_partials_kernel.  (Its predecessors -- the pixel-major gather kernel of round 2 and the channel-major scatter kernel of round 3, same bits -- were
+// dropped in round 6; git history has them.)
 template <int NCSB, bool FBB, bool XFA, bool XFS>
 __global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
 conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
@@ -3822,8 +2707,6 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
 }
 
 constexpr size_t conv5_w_bf16_tr_lds_bytes(int ncsb) { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)2 * 64 * (32 * ncsb + 8) * 2 + 192 * 4; }
-constexpr size_t conv5_w_bf16_t_lds_bytes(int ncsb) { return (size_t)2 * 32 * (19 * 2 * 12 + 4) * 2 + (size_t)ncsb * 2 * 32 * 72 * 2 + 192 * 4; }
-constexpr size_t conv5_w_bf16_lds_bytes(int ncsb) { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)ncsb * 2 * 32 * 72 * 2 + 192 * 4; }
 
 #include "uad_convk16.inc"
 
@@ -3954,9 +2837,9 @@ inline GemmPlan plan_gemm(const UadConvDesc& d, bool f_type, bool have_pack, siz
             p.nsplit = sp;
             p.ws_floats = sp > 1 ? (size_t)sp * p.out_elems : 0;
             if (sp > 1 && ncounters > 0 && wgs <= ncounters && (size_t)sp * p.out_elems * 4 < ((size_t)1 << 32)) {
-                static const bool off = getenv("UAD_NO_INKERNEL_SPLITK") != nullptr, no_f16 = getenv("UAD_NO_F16") != nullptr, no_d16 = getenv("UAD_NO_D16") != nullptr;
+                static const bool off = getenv("UAD_NO_INKERNEL_SPLITK") != nullptr;
                 const int cst = CA / sp;
-                const bool inst = f_type ? !no_f16 : (!no_d16 && CA % sp == 0 && (cst == 32 || cst == 64 || (cst == 128 && p.sc.BN == 64)));
+                const bool inst = f_type || (CA % sp == 0 && (cst == 32 || cst == 64 || (cst == 128 && p.sc.BN == 64)));
                 p.inkernel = !off && inst;
             }
             p.tiles = (sp > 1 && !p.inkernel) ? (p.out_rows + 63) / 64 : d.N * (d.HS / p.sc.TH) * (d.WS / p.sc.TW);
@@ -4009,7 +2892,7 @@ bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
 int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats, int ncounters) { return plan_gemm(d, true, have_pack, ws_floats, ncounters).tiles; }
 int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats, int ncounters) { return plan_gemm(d, false, have_pack, ws_floats, ncounters).tiles; }
 bool uad_conv_f_supports_final_bwd(const UadConvDesc& d, bool have_pack16, size_t ws_floats) {
-    if (!have_pack16 || getenv("UAD_NO_F16") || getenv("UAD_NO_FB_ON_LOAD")) return false;
+    if (!have_pack16) return false;
     const GemmPlan p = plan_gemm(d, true, true, ws_floats);
     return p.path == PATH_SPATIAL;
 }
@@ -4017,7 +2900,7 @@ bool uad_conv_d_can_fuse_final(const UadConvDesc& d, bool have_pack16, size_t ws
     if (!have_pack16 || getenv("UAD_NO_FUSED_FINAL")) return false;
     const GemmPlan p = plan_gemm(d, false, true, ws_floats);
     // conv5_d16_kernel<8,16,CST,4,1> with the whole channel range in one workgroup column block
-    return p.path == PATH_SPATIAL && p.nsplit == 1 && p.sc.BN == 32 && d.CB == 32 && (d.CS == 32 || d.CS == 64) && !getenv("UAD_NO_D16");
+    return p.path == PATH_SPATIAL && p.nsplit == 1 && p.sc.BN == 32 && d.CB == 32 && (d.CS == 32 || d.CS == 64);
 }
 // exact-fp32 mode: conv5_d_kernel<8,16,32,4,1,FIN> (UAD_NO_FUSED_FINAL_F32=1: the separate final_kernel pass)
 bool uad_conv_d_can_fuse_final_f32(const UadConvDesc& d, bool have_pack, size_t ws_floats) {
@@ -4052,41 +2935,7 @@ namespace {
 void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStream_t st) {
     const UadConvDesc& d = a.d;
     a.nsplit = 1; a.out_elems = p.out_elems;
-    { static const int dbg = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0; a.dbg = dbg; a.dbgbuf = nullptr; }
-    static unsigned long long* dbgbuf = nullptr;
-    static int dbg_calls = 0;
-    const bool dbg_f = (a.dbg & 16) && f_type && a.Wp16 && a.Nn == 64 && a.CA == 32 && dbg_calls >= 40 && dbg_calls < 44;
-    if ((a.dbg & 16) && f_type && a.Wp16 && a.Nn == 64 && a.CA == 32 && !dbg_f) ++dbg_calls;
-    // UAD_DBG & 64: phase clocks of the lane = pixel D-kind kernel; UAD_DBG_SHAPE="Nn,CA,kind" picks the launch (default 32,32,2 = dec3.fwd)
-    static int dq_nn = 32, dq_ca = 32, dq_kind = 2, dq_init = 0;
-    if (!dq_init) { dq_init = 1; if (const char* e = getenv("UAD_DBG_SHAPE")) sscanf(e, "%d,%d,%d", &dq_nn, &dq_ca, &dq_kind); }
-    const bool dq_match = (a.dbg & 64) && !f_type && a.Wp16 && a.Nn == dq_nn && a.CA == dq_ca && a.ep.kind == dq_kind;
-    const bool dbg_d = dq_match && dbg_calls >= 40 && dbg_calls < 43;
-    if (dq_match && !dbg_d) ++dbg_calls;
-    const bool dbg_this = dbg_f || dbg_d;
-    if (dbg_this) {
-        if (!dbgbuf) (void)hipMalloc((void**)&dbgbuf, 8 * 4 * 32 * sizeof(unsigned long long));
-        (void)hipMemsetAsync(dbgbuf, 0, 8 * 4 * 32 * sizeof(unsigned long long), st);
-        a.dbgbuf = dbgbuf;
-    }
-    struct DbgDump { bool on; hipStream_t st; unsigned long long* buf; int* calls; int dstride;
-        ~DbgDump() { if (!on) return; (void)hipStreamSynchronize(st); unsigned long long h[8 * 4 * 32];
-            (void)hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost); ++*calls;
-            for (int b = 0; b < 8; b += 3) for (int w = 0; w < 4; w += 3) { const unsigned long long* p = h + (b * 4 + w) * (dstride);
-                if (!p[0]) continue;
-                if (p[11]) { fprintf(stderr, "[d16s wg%d w%d] (x10ns) stage=%llu bar=%llu", b, w, p[1] - p[0], p[2] - p[1]);
-                    unsigned long long prev = p[2];
-                    for (int c = 0; c < 4; ++c) { fprintf(stderr, " | cls%d mma=%llu epi=%llu", c, p[3 + 2 * c] - prev, p[4 + 2 * c] - p[3 + 2 * c]); prev = p[4 + 2 * c]; }
-                    fprintf(stderr, " | tail=%llu end=%llu total=%llu", p[11] - prev, p[12] ? p[12] - p[11] : 0ull, (p[12] ? p[12] : p[11]) - p[0]);
-                    fprintf(stderr, " || pre=%llu issue=%llu params=%llu bar=%llu conv=%llu", p[16] - p[0], p[17] - p[16], p[18] - p[17], p[19] - p[18], p[1] - p[19]);
-                    if (p[22]) fprintf(stderr, " || e.out=%llu e.sum=%llu e.bar=%llu e.fin=%llu", p[20] - p[11], p[21] - p[20], p[22] - p[21], p[12] - p[22]);
-                    if (p[25]) fprintf(stderr, " || shader clock %.3f GHz", (double)(p[25] - p[24]) / (double)((p[12] ? p[12] : p[11]) - p[0]) * 0.1);
-                    fprintf(stderr, "\n"); continue; }
-                if (p[5]) { fprintf(stderr, "[f16 wg%d w%d] (x10ns) load+convert=%llu barrier=%llu mma=%llu barrier=%llu epilogue=%llu | total=%llu\n", b, w, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[5] - p[0]); continue; }
-                fprintf(stderr, "[d16 wg%d w%d] stage=%llu bstore+bar=%llu", b, w, p[1] - p[0], p[2] - p[1]);
-                unsigned long long prev = p[2];
-                for (int c = 0; c < 4; ++c) { fprintf(stderr, " | cls%d mma=%llu epi=%llu", c, p[3 + 2 * c] - prev, p[4 + 2 * c] - p[3 + 2 * c]); prev = p[4 + 2 * c]; }
-                fprintf(stderr, " | total=%llu\n", prev - p[0]); } } } dbg_dump{dbg_this, st, dbgbuf, &dbg_calls, dbg_d ? 32 : 16};
+    a.dbg = 0; a.dbgbuf = nullptr;
     if (p.path == PATH_SPATIAL) {
         float* out = a.Out;
         if (p.nsplit > 1) { a.Out = ws; a.nsplit = p.nsplit; a.out_final = out; }
@@ -4094,13 +2943,12 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
         dim3 grid((d.HS / p.sc.TH) * (d.WS / p.sc.TW), d.N, (a.Nn / p.sc.BN) * p.nsplit);
         if (a.Wp16) {   // bf16x3 math mode
             if (f_type) {
-                const bool f16 = !getenv("UAD_NO_F16");
-                if (p.sc.BN == 64) { if (f16) launch_conv5_f16<8, 8, 32, 2, 2>(a, grid, st); else launch_conv5_bf16<8, 8, 32, 2, 2, KIND_F>(a, grid, st); }
-                else { if (f16) launch_conv5_f16<8, 16, 16, 4, 1>(a, grid, st); else launch_conv5_bf16<8, 16, 16, 4, 1, KIND_F>(a, grid, st); }
+                if (p.sc.BN == 64) launch_conv5_f16<8, 8, 32, 2, 2>(a, grid, st);
+                else launch_conv5_f16<8, 16, 16, 4, 1>(a, grid, st);
             } else {
                 // class-sequential kernel whenever the workgroup's whole channel range fits in LDS (CA == cst * nsplit)
                 const int cst = (a.CA % p.nsplit == 0) ? a.CA / p.nsplit : 0;
-                const bool seq = !getenv("UAD_NO_D16");
+                constexpr bool seq = true;      // class-sequential generation (conv5_d16_kernel): the fallback of the lane = pixel one
                 const bool lp = seq && conv5_d16s_takes(a);      // lane = pixel generation (uad_conv16s.inc)
                 if (lp && p.sc.BN == 64 && cst == 128) launch_conv5_d16s_bn64<128>(a, grid, st);
                 else if (lp && p.sc.BN == 64 && cst == 64) launch_conv5_d16s_bn64<64>(a, grid, st);
@@ -4156,8 +3004,7 @@ void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, un
         pd.off[i] = offs[i]; pd.cb[i] = cbs[i]; pd.cs[i] = css[i]; pd.count[i] = taps[i] * cbs[i] * css[i];
         total += pd.count[i];
     }
-    static const bool no8 = getenv("UAD_NO_PACK8") != nullptr;
-    bool v8 = !no8 && (((uintptr_t)params | (uintptr_t)w16_f | (uintptr_t)w16_d) & 15) == 0;
+    bool v8 = ((((uintptr_t)params | (uintptr_t)w16_f | (uintptr_t)w16_d) & 15) == 0);
     for (int i = 0; i < n; ++i) v8 = v8 && pd.off[i] % 4 == 0 && pd.cb[i] % 8 == 0 && pd.cs[i] % 8 == 0;
     if (v8) hipLaunchKernelGGL(pack_weights_bf16_v8_kernel, dim3((unsigned)((total / 8 + 255) / 256), 2), dim3(256), 0, st, params, w16_f, w16_d, pd);
     else hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w16_f, w16_d, pd);
@@ -4227,7 +3074,7 @@ void launch_w_tr(const ConvWArgs& a, dim3 grid, const W5Choice& w5, hipStream_t 
 }  // namespace
 
 bool uad_conv_w_supports_fb_bits(const UadConvDesc& d, bool math_bf16x3) {
-    return math_bf16x3 && choose_w5(d).ok && d.CB == 32 && !getenv("UAD_NO_FB_BITS");
+    return math_bf16x3 && choose_w5(d).ok && d.CB == 32;
 }
 
 size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
@@ -4262,8 +3109,8 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         static unsigned long long* wbuf = nullptr;
         static int wcalls = 0;
         const bool dbg_this = (dbgw & 32) && wcalls < 8;
-        constexpr size_t kWbuf = (2 * 2048 + 16 * 8 * 8) * 8;
-        if (dbg_this) { if (!wbuf) (void)hipMalloc((void**)&wbuf, kWbuf); (void)hipMemsetAsync(wbuf, 0, kWbuf, st); a.dbgbuf = wbuf; if (dbgw & 128) a.abl |= 64; }
+        constexpr size_t kWbuf = (size_t)2 * 2048 * 8;
+        if (dbg_this) { if (!wbuf) (void)hipMalloc((void**)&wbuf, kWbuf); (void)hipMemsetAsync(wbuf, 0, kWbuf, st); a.dbgbuf = wbuf; }
         struct Dump { bool on; hipStream_t st; unsigned long long* buf; dim3* g; int* calls; UadConvDesc d;
             ~Dump() { if (!on) return; (void)hipStreamSynchronize(st); const int nb = g->x * g->y * g->z; static unsigned long long h[2 * 2048];
                 (void)hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost); ++*calls;
@@ -4271,72 +3118,19 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                 for (int b = 0; b < nb && b < 2048; ++b) { if (h[2 * b] < t0) t0 = h[2 * b]; if (h[2 * b + 1] > t1) t1 = h[2 * b + 1]; }
                 for (int b = 0; b < nb && b < 2048; ++b) { const unsigned long long dd = h[2 * b + 1] - h[2 * b]; dsum += dd; if (dd < dmin) dmin = dd; if (dd > dmax) dmax = dd; if (h[2 * b] - t0 > smax) smax = h[2 * b] - t0; }
                 fprintf(stderr, "[w5 CB=%d CS=%d HS=%d grid=%d,%d,%d] span=%llu (100MHz ticks) wg dur min=%llu avg=%llu max=%llu latest start=%llu\n", d.CB, d.CS, d.HS, g->x, g->y, g->z,
-                        t1 - t0, dmin, dsum / nb, dmax, smax);
-                static unsigned long long ph[16 * 8 * 8];
-                (void)hipMemcpy(ph, buf + 2 * 2048, sizeof ph, hipMemcpyDeviceToHost);
-                for (int b = 0; b < 16; b += 5) for (int w = 0; w < 8; w += 3) { const unsigned long long* q = ph + (b * 8 + w) * 8; if (!q[5]) continue;
-                    fprintf(stderr, "   [wg%d w%d, %llu tiles] (x10ns, sums) bar1=%llu commit=%llu issue=%llu bar2=%llu frag+mma=%llu | kernel=%llu | shader clock %.3f GHz\n", b, w, q[6], q[0], q[1], q[2], q[3], q[4], q[5], q[5] ? (double)q[7] / (double)q[5] * 0.1 : 0.0); } } } dump{dbg_this, st, wbuf, &grid, &wcalls, d};
+                        t1 - t0, dmin, dsum / nb, dmax, smax); } } dump{dbg_this, st, wbuf, &grid, &wcalls, d};
         if (math_bf16x3) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_lds_bytes(1));
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_lds_bytes(2));
-                attr_set = true;
-            }
-            static const bool pair_ok = !getenv("UAD_NO_W2");
-            static const bool tlay = !getenv("UAD_NO_W_T");          // channel-major big tile (conv5_w_bf16_t_kernel); UAD_NO_W_T=1: the pixel-major kernel
-            if (tlay) {
-                static bool t_attr = false;
-                if (!t_attr) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(1));
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(2));
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(1));
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_t_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_t_lds_bytes(2));
-                    t_attr = true;
-                }
-                const bool two = pair_ok && d.CS % 64 == 0;
-                if (two) grid.y = d.CS / 64;
-                // transpose-read form (pixel-major tiles, ds_read_b64_tr_b16 fragments): the default since round 4 (same bits, every k5 filter-gradient
-                // launch 3-12 % faster: profiles/r04_h_w_tr_ab.log); UAD_NO_W_TR=1: the channel-major kernel
-                static const bool tr_on = getenv("UAD_NO_W_TR") == nullptr;
-                if (tr_on) {
-                    const bool xa = xfb.scale != nullptr && !xfb.fb_bits, xs = xfs.scale != nullptr;
-                    // <cs blocks per workgroup, big operand from the pattern word, activation on load of big, ... of small>
-                    if (xfb.fb_bits) { if (two) { if (xs) launch_w_tr<2, true, false, true>(a, grid, w5, st); else launch_w_tr<2, true, false, false>(a, grid, w5, st); }
-                                       else     { if (xs) launch_w_tr<1, true, false, true>(a, grid, w5, st); else launch_w_tr<1, true, false, false>(a, grid, w5, st); } }
-                    else if (two) { if (xa) { if (xs) launch_w_tr<2, false, true, true>(a, grid, w5, st); else launch_w_tr<2, false, true, false>(a, grid, w5, st); }
-                                    else    { if (xs) launch_w_tr<2, false, false, true>(a, grid, w5, st); else launch_w_tr<2, false, false, false>(a, grid, w5, st); } }
-                    else          { if (xa) { if (xs) launch_w_tr<1, false, true, true>(a, grid, w5, st); else launch_w_tr<1, false, true, false>(a, grid, w5, st); }
-                                    else    { if (xs) launch_w_tr<1, false, false, true>(a, grid, w5, st); else launch_w_tr<1, false, false, false>(a, grid, w5, st); } }
-                } else {
-                const size_t lds = conv5_w_bf16_t_lds_bytes(two ? 2 : 1);
-                if (xfb.fb_bits) {
-                    if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, true>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                    else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, true>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                } else {
-                    if (two) UAD_W_LAUNCH((conv5_w_bf16_t_kernel<2, false>), grid, dim3(512), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                    else UAD_W_LAUNCH((conv5_w_bf16_t_kernel<1, false>), grid, dim3(256), lds, st, a, w5.tiles_per_split, w5.total_tiles);
-                }
-                }
-            } else
-            if (xfb.fb_bits) {          // compressed d loss / d c of the last decoder block (callers check uad_conv_w_supports_fb_bits)
-                static bool fb_attr = false;
-                if (!fb_attr) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_lds_bytes(1));
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_lds_bytes(2));
-                    fb_attr = true;
-                }
-                if (pair_ok && d.CS % 64 == 0) {
-                    grid.y = d.CS / 64;
-                    hipLaunchKernelGGL((conv5_w_bf16_kernel<2, true>), grid, dim3(512), conv5_w_bf16_lds_bytes(2), st, a, w5.tiles_per_split, w5.total_tiles);
-                } else {
-                    hipLaunchKernelGGL((conv5_w_bf16_kernel<1, true>), grid, dim3(256), conv5_w_bf16_lds_bytes(1), st, a, w5.tiles_per_split, w5.total_tiles);
-                }
-            } else if (pair_ok && d.CS % 64 == 0) {
-                grid.y = d.CS / 64;
-                hipLaunchKernelGGL(conv5_w_bf16_kernel<2>, grid, dim3(512), conv5_w_bf16_lds_bytes(2), st, a, w5.tiles_per_split, w5.total_tiles);
-            } else {
-                hipLaunchKernelGGL(conv5_w_bf16_kernel<1>, grid, dim3(256), conv5_w_bf16_lds_bytes(1), st, a, w5.tiles_per_split, w5.total_tiles);
+            const bool two = d.CS % 64 == 0;       // two 32-channel cs blocks per workgroup (512 threads) where the layer has them
+            if (two) grid.y = d.CS / 64;
+            {
+                const bool xa = xfb.scale != nullptr && !xfb.fb_bits, xs = xfs.scale != nullptr;
+                // <cs blocks per workgroup, big operand from the pattern word, activation on load of big, ... of small>
+                if (xfb.fb_bits) { if (two) { if (xs) launch_w_tr<2, true, false, true>(a, grid, w5, st); else launch_w_tr<2, true, false, false>(a, grid, w5, st); }
+                                   else     { if (xs) launch_w_tr<1, true, false, true>(a, grid, w5, st); else launch_w_tr<1, true, false, false>(a, grid, w5, st); } }
+                else if (two) { if (xa) { if (xs) launch_w_tr<2, false, true, true>(a, grid, w5, st); else launch_w_tr<2, false, true, false>(a, grid, w5, st); }
+                                else    { if (xs) launch_w_tr<2, false, false, true>(a, grid, w5, st); else launch_w_tr<2, false, false, false>(a, grid, w5, st); } }
+                else          { if (xa) { if (xs) launch_w_tr<1, false, true, true>(a, grid, w5, st); else launch_w_tr<1, false, true, false>(a, grid, w5, st); }
+                                else    { if (xs) launch_w_tr<1, false, false, true>(a, grid, w5, st); else launch_w_tr<1, false, false, false>(a, grid, w5, st); } }
             }
         } else {
             hipLaunchKernelGGL(conv5_w_kernel, grid, dim3(256), 0, st, a, w5.tiles_per_split, w5.total_tiles);

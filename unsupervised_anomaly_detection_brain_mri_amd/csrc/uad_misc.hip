@@ -1023,8 +1023,8 @@ void uad_launch_gather_mask(const unsigned char* labels, const int* idx, int n, 
 void uad_launch_reduce_partials(const float* partial, int S, int L, float scale, float* out, hipStream_t st) {
     const int blocks = (L + 63) / 64;
     // streaming (non-temporal) loads: the slabs are read exactly once; plain loads pushed 52 MB per launch through the L2s the heavy kernels
-    // on the main stream were working out of (same-box A/B, round 3: 0.945 -> 0.926 ms per step).  UAD_NO_REDUCE_NT=1: plain loads.
-    static const int nt = getenv("UAD_NO_REDUCE_NT") ? 0 : 1;
+    // on the main stream were working out of (same-box A/B, round 3: 0.945 -> 0.926 ms per step).
+    constexpr int nt = 1;
     if (blocks >= 256 || S <= 8)
         hipLaunchKernelGGL((reduce_partials_kernel<4>), dim3(blocks), dim3(256), 0, st, partial, S, L, scale, out, nt);
     else

@@ -918,7 +918,7 @@ static hipEvent_t next_event(uad_model* m) {
     if (m->ev_next == m->sync_events.size()) {
         hipEvent_t e;
         // same-device stream ordering only: no system-scope fence (cache writeback) at the record
-        if (getenv("UAD_EVENT_SYSFENCE") || hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
             (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
         m->sync_events.push_back(e);
     }
