@@ -58,6 +58,10 @@ enum { UAD_MATH_F32 = 0, UAD_MATH_BF16X3 = 1,
                                        drifts to ~3e-4 of its value, so for THAT graph this mode is opt-in and not parity-rated.
                                        The shorter generic-kernel graphs (aae_kind 4-6: Zimmerer VAE / ceVAE, GMVAE (You)) pass the
                                        same 1e-4 gradient checks in this mode as in fp32; their trainers default to it */
+enum { UAD_MATH_BF16X6 = 3 };       /* uad_create handles (AE / VAE / ceVAE / spatial GMVAE) only, round 6: THREE bf16 planes per operand (x = h + m + l),
+                                       six products per multiply on the bf16 matrix cores, fp32 accumulate -- fp32-grade results (the dropped terms are
+                                       below 2^-26 of a product; tests hold 1e-5 against the fp64 oracle) at 6 x 32 instead of 8 x 64 matrix-pipe cycles
+                                       per K = 16 of an fp32 MFMA.  The k5 s2 spatial kernels carry it; launches they do not take run exact fp32 */
 
 typedef struct uad_model uad_model_t;
 

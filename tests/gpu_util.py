@@ -153,6 +153,8 @@ class _Flips(dict):
 # (three bf16 products per fp32 product, ~2^-17 each, accumulated over the contraction); bf16x3_all (opt-in, every contraction of a 20-layer
 # residual stack in bf16x3, documented drift 1e-4 .. 3e-4): 2^-12.
 FLIP_BOUND = {'f32': 64.0 * 2.0 ** -24, 'bf16x3': 2.0 ** -15, 'bf16x3_all': 2.0 ** -12,
+              'bf16x6': 64.0 * 2.0 ** -24,      # three planes, six products: fp32-grade, held to the exact-fp32 mode's bound
+
               # ResNet f-AnoGAN graph in bf16x3 mode.  Round 4 widened this to the parity tolerance itself (1e-4) when the k3 contractions moved to bf16x3;
               # the round-5 census (profiles/r05_f_resnet_flip_census.jsonl: UAD_FLIP_CENSUS over every ResNet / residual-block CAAE test, 887 flipped
               # elements in bf16x3) has its largest flip at 2.54e-5 of the site max -- inside the ordinary bf16x3 bound -- so the ordinary bound it is again.

@@ -10,7 +10,7 @@ UAD_OK = 0
 ARCH_AE, ARCH_VAE, ARCH_CEVAE, ARCH_GMVAE_SPATIAL, ARCH_AE_SPATIAL = 0, 1, 2, 3, 4
 BUF_PARAMS, BUF_GRADS, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
 SEG_DECODER, SEG_BOTTLENECK, SEG_ENCODER, SEG_ENCODER_HI, SEG_ENCODER_LO, SEG_ALL = 0, 1, 2, 3, 4, -1
-MATH_F32, MATH_BF16X3, MATH_BF16X3_ALL = 0, 1, 2
+MATH_F32, MATH_BF16X3, MATH_BF16X3_ALL, MATH_BF16X6 = 0, 1, 2, 3      # (BF16X3_ALL: uad_gan_* handles only; BF16X6: uad_create handles only)
 
 c_float_p = C.c_void_p  # device pointers are passed as integers
 

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, 'libuad_hip.so')
-SOURCES = ['uad_gemm.hip', 'uad_misc.hip', 'uad_gmvae.hip', 'uad_gmd.hip', 'uad_bott.hip', 'uad_eval.hip', 'uad_gan.hip', 'uad_model.hip']
+SOURCES = ['uad_gemm.hip', 'uad_gemm_d16s.hip', 'uad_gemm_d16s3.hip', 'uad_misc.hip', 'uad_gmvae.hip', 'uad_gmd.hip', 'uad_bott.hip', 'uad_eval.hip', 'uad_gan.hip', 'uad_model.hip']
 ARCH = 'gfx950'
 
 
@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, 'uad_kernels.h'), os.path.join(ROOT, 'include', 'uad_hip.h'), os.path.join(CSRC, 'uad_gan_kernels.inc'),
                os.path.join(CSRC, 'uad_gan_create.inc'), os.path.join(CSRC, 'uad_conv16s.inc'), os.path.join(CSRC, 'uad_convk16.inc'),
-               os.path.join(CSRC, 'uad_conv5_f32.inc'), os.path.join(CSRC, 'uad_conv5_f32w.inc')]      # the .inc files are textual parts of uad_gan.hip
+               os.path.join(CSRC, 'uad_conv5_f32.inc'), os.path.join(CSRC, 'uad_conv5_f32w.inc'), os.path.join(CSRC, 'uad_gemm_common.h'), os.path.join(CSRC, 'uad_gemm_d16s_body.inc')]      # the .inc files are textual parts of uad_gan.hip
     objs = []
     # hidden visibility: the library exports exactly the functions include/uad_hip.h declares (its visibility push), none of the C++ launch layer
     flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fvisibility-inlines-hidden', '-Wno-unused-value', '-Wno-unused-result']

@@ -24,63 +24,9 @@
 #include <string>
 #include <vector>
 
-typedef float v16f __attribute__((ext_vector_type(16)));
-
-#define KIND_F 0
-#define KIND_D 1
+#include "uad_gemm_common.h"
 
 namespace {
-
-struct ConvGemmArgs {
-    const float* A;
-    const float* W;
-    const float* Wp;   // k-quad-interleaved copy of W for the spatial kernels (uad_launch_pack_weights)
-    const unsigned short* Wp16;   // bf16 hi|lo planes, k-octet-interleaved (bf16x3 math mode)
-    long long w16_plane;          // elements per plane
-    float* Out;
-    UadXform xf;
-    UadEpilogue ep;
-    UadConvDesc d;
-    int M;         // N*HS*WS rows (small-image positions)
-    int CA;        // channels of the A operand (contraction per tap)
-    int Nn;        // output channels
-    int lws, lhs;  // log2(WS), log2(HS) or -1 when not a power of two
-    int nsplit;    // split-K factor (>1: raw partial tiles go to Out + split*out_elems, see splitk_epilogue_kernel)
-    long long out_elems;
-    unsigned* sk_counter;   // split-K with in-kernel reduction: arrival counters, one per (spatial tile, column block); null = splitk_epilogue_kernel
-    float* out_final;       // ... and the real output (Out points at the slabs)
-    unsigned long long* dbgbuf;   // per-phase clock stamps of a few workgroups (UAD_DBG & 8)
-    int dbg;       // ablation switches for kernel tuning (UAD_DBG): 1 = no epilogue stores, 2 = no MFMA loop, 4 = no staging
-    int math16;    // generic kernel: bf16x3 products (conv_gemm16_kernel) where the tile shape allows
-};
-
-__device__ __forceinline__ void decode_pos(int m, int HS, int WS, int lhs, int lws, int& n, int& i, int& j) {
-    if (lws >= 0 && lhs >= 0) {
-        j = m & (WS - 1);
-        int t = m >> lws;
-        i = t & (HS - 1);
-        n = t >> lhs;
-    } else {
-        j = m % WS;
-        int t = m / WS;
-        i = t % HS;
-        n = t / HS;
-    }
-}
-
-// component-wise select (a float4 `c ? v : zero` is lowered through scratch memory by the compiler)
-__device__ __forceinline__ float4 keep4(bool c, float4 v) {
-    return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f);
-}
-
-__device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, float alpha) {
-    float4 r;
-    r.x = fmaf(v.x, sc.x, sh.x); r.x = r.x > 0.f ? r.x : r.x * alpha;
-    r.y = fmaf(v.y, sc.y, sh.y); r.y = r.y > 0.f ? r.y : r.y * alpha;
-    r.z = fmaf(v.z, sc.z, sh.z); r.z = r.z > 0.f ? r.z : r.z * alpha;
-    r.w = fmaf(v.w, sc.w, sh.w); r.w = r.w > 0.f ? r.w : r.w * alpha;
-    return r;
-}
 
 constexpr int XF_LDS_CH = 512;  // activation-on-load tables (gamma', beta) staged once per workgroup
 
@@ -439,94 +385,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvGem
 
 #include "uad_conv5_f32.inc"      // conv5_f_kernel / conv5_d_kernel: the exact-fp32 k5 s2 spatial kernels
 
-// ================================================================================================
-// bf16x3 math mode ("split-bf16"): every fp32 operand x is written x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
-// a product is computed as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (products exact, fp32 accumulate), i.e. with
-// ~2^-17 relative error per product -- inside the 1e-4 parity bar -- at 3 x 32-cycle v_mfma_f32_32x32x16_bf16 per K=16
-// instead of 8 x 64-cycle fp32 MFMAs.  Activations are split while they are staged into LDS (two bf16 planes, same
-// bytes as fp32), weights are pre-split by pack_weights_bf16_kernel.
-// ================================================================================================
-typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float x, float y) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));   // lo16 = bf16_rne(x), hi16 = bf16_rne(y)
-    return r;
-}
-__device__ __forceinline__ void split_bf16(float4 v, uint2& hi, uint2& lo) {
-    hi.x = cvt_pk_bf16(v.x, v.y);
-    hi.y = cvt_pk_bf16(v.z, v.w);
-    const float rx = v.x - __uint_as_float(hi.x << 16), ry = v.y - __uint_as_float(hi.x & 0xFFFF0000u);
-    const float rz = v.z - __uint_as_float(hi.y << 16), rw = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
-    lo.x = cvt_pk_bf16(rx, ry);
-    lo.y = cvt_pk_bf16(rz, rw);
-}
-// 16-byte load through a buffer descriptor: wave-uniform base (descriptor) + wave-uniform byte offset (SGPR) + 32-bit per-lane byte
-// offset.  The flat form spends a 64-bit VALU add per load on the same address.
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes) {
-    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_bytes, (int)uniform_bytes, 0);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-// Butterfly over 8 consecutive lanes with DPP (one VALU op per step instead of a ds_bpermute round trip through the LDS unit): swap
-// inside pairs, swap pairs inside quads, mirror the half row.  Every lane ends with the same value as the xor-shuffle butterfly (the
-// operands of each add / or are the same pair, the operations commute).
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
-__device__ __forceinline__ float sum8_dpp(float v) {
-    v += __uint_as_float(dpp_u32<0xB1>(__float_as_uint(v)));       // quad_perm [1,0,3,2]
-    v += __uint_as_float(dpp_u32<0x4E>(__float_as_uint(v)));       // quad_perm [2,3,0,1]
-    v += __uint_as_float(dpp_u32<0x141>(__float_as_uint(v)));      // row_half_mirror
-    return v;
-}
-__device__ __forceinline__ unsigned or8_dpp(unsigned v) {
-    v |= dpp_u32<0xB1>(v);
-    v |= dpp_u32<0x4E>(v);
-    v |= dpp_u32<0x141>(v);
-    return v;
-}
-
-// Split-K with in-kernel reduction (guide: cross-workgroup hand-off, counter form).  The slabs are written with sc1 (write-through) 16-byte
-// buffer stores and read back by the reducer with sc1 loads: performed at the device's coherence point, whichever XCD the contributors of a
-// tile ran on, without a release fence (= write-back of the XCD's whole L2).  Order: slab stores -> every wave drains them (s_waitcnt) ->
-// barrier -> one relaxed agent-scope ticket per workgroup; the workgroup that draws nsplit - 1 sums the slabs in split order (the order
-// splitk_epilogue_kernel uses) and runs the normal epilogue.  The counter is reset by the reducer (zero-initialised at allocation).
-__device__ __forceinline__ void sk_store16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float4 v) {
-    const v4u u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)byte_off, 0, 16);
-}
-__device__ __forceinline__ float4 sk_load16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
-    const v4u u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
-    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-}
-// true in exactly one of the nsplit workgroups of a tile: the last to arrive.  flag: one int of LDS nobody else touches around the call.
-__device__ __forceinline__ bool sk_last_arriver(unsigned* counter, int nsplit, int* flag, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const bool last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
-        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = last ? 1 : 0;
-    }
-    __syncthreads();
-    const bool r = *flag != 0;
-    __syncthreads();          // the flag's LDS word may be reused right away
-    return r;
-}
-
-// Compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
-template <int I0, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I0 < N) {
-        f(std::integral_constant<int, I0>{});
-        static_for<I0 + 1, N>(f);
-    }
-}
-
-__device__ __forceinline__ v16f mfma_bf16(uint4 a, uint4 b, v16f c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
-}
 // ---- generic (any KS / S / P) contraction in bf16x3 math: the fp32 tiles are split into bf16 hi | lo planes while they are stored
 // to LDS (same bytes as fp32), both operands K-contiguous, so a fragment is one ds_read_b128 per plane and a K = 16 slice costs
 // three v_mfma_f32_32x32x16_bf16 instead of eight fp32 MFMAs.  Identity activation-on-load only.
@@ -894,9 +752,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm16_kernel(const ConvG
 }
 
 
-template <int NKS>
-struct BFrag16 { uint4 hi[NKS], lo[NKS]; };
-
 // KIND_F: halo (2TH+3)x(2TW+3), stride-2 gather;  KIND_D: halo (TH+2)x(TW+2), four output-parity classes
 template <int TH, int TW, int CK, int WGM, int WGN, int KIND>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv5_bf16_kernel(const ConvGemmArgs a) {
@@ -1102,22 +957,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv5_bf16_kernel(const ConvGe
 // (340 -> ~150 registers: two-three waves per SIMD instead of one), and each class's epilogue stores overlap the next
 // class's MFMAs.  Requires CA == CST * nsplit.
 // ------------------------------------------------------------------------------------------------
-struct TapOrderD { int tap[25]; int start[5]; };
-constexpr TapOrderD make_tap_order_d() {
-    TapOrderD o{};
-    int n = 0;
-    for (int cls = 0; cls < 4; ++cls) {
-        o.start[cls] = n;
-        for (int tap = 0; tap < 25; ++tap) {
-            const int ky = tap / 5, kx = tap % 5;
-            const int py = (ky + 1) & 1, px = (kx + 1) & 1;
-            if (py * 2 + px == cls) o.tap[n++] = tap;
-        }
-    }
-    o.start[4] = n;
-    return o;
-}
-constexpr TapOrderD kTapOrderD = make_tap_order_d();
 
 template <int TH, int TW, int CST, int WGM, int WGN>
 __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_per_eu(2))) conv5_d16_kernel(const ConvGemmArgs a) {
@@ -1539,7 +1378,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 // Round 6: the staging phases on the same diet as conv5_w_bf16_tr_kernel -- the tile is fixed for a workgroup, so the byte offset of each of a
 // thread's elements (out-of-image elements: 2^31 = the descriptor's size, the range check returns zeros), the padding mask and the LDS store
 // addresses are computed ONCE; a chunk adds a wave-uniform channel offset.  Activation-on-load or not is a template parameter (XF).
-template <int TH, int TW, int CK, int WGM, int WGN, int FB, bool XF>      // FB: 0 plain | 1 final-backward on load from c | 2 ... from the pattern bits
+template <int TH, int TW, int CK, int WGM, int WGN, int FB, bool XF, int NPL = 2>      // FB: 0 plain | 1 final-backward on load from c | 2 ... from the pattern bits; NPL: bf16 planes per operand (3 = bf16x6)
 __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_per_eu(2))) conv5_f16_kernel(const ConvGemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int IH = 2 * TH + 3, IW = 2 * TW + 3;
@@ -1548,9 +1387,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     constexpr int BN = 32 * WGN;
     static_assert(TH * TW == 32 * WGM, "one 32-row fragment per wave along M");
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    unsigned short* sHi = reinterpret_cast<unsigned short*>(dsm);
-    unsigned short* sLo = sHi + IH * IW * LDH;
-    float* s_xf = reinterpret_cast<float*>(sLo + IH * IW * LDH);
+    constexpr int PLANE = IH * IW * LDH;
+    unsigned short* sPl = reinterpret_cast<unsigned short*>(dsm);      // NPL planes of IH x IW x LDH
+    float* s_xf = reinterpret_cast<float*>(sPl + NPL * PLANE);
     float* s_red = s_xf + 3 * XF_LDS_CH;      // s_xf: scale | shift | final-conv kernel (fb mode)
     float* s_epi = reinterpret_cast<float*>(dsm);      // aliases the activation tile (dead after the last chunk)
 
@@ -1590,27 +1429,25 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     const int ch0 = split * cper;
     const int nchunks = min(CA / CK, ch0 + cper);
 
-    BFrag16<NKS> b0, b1, b2, b3, a0, a1;
+    KFrag<NKS, NPL> b0, b1, b2, b3, a0, a1;
     // wave-uniform base (SGPR pair, scalar arithmetic) + one 32-bit per-lane offset: no 64-bit VALU add per load
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.Wp16), 0, 0xffffffff, 0x00020000);
     const unsigned lb = (unsigned)(wq - reinterpret_cast<const uint4*>(a.Wp16)) * 16u;      // byte offsets, 32 bits: the packed weights of a layer are < 4 GB
     const unsigned plane_b = (unsigned)plane_q * 16u;
-    auto loadB = [&](BFrag16<NKS>& b, int tap, int c0) {
+    auto loadB = [&](KFrag<NKS, NPL>& b, int tap, int c0) {
         const unsigned u = (unsigned)((tap * (CA / 8) + c0 / 8) * Nn) * 16u;
 #pragma unroll
-        for (int j = 0; j < NKS; ++j) {
-            b.hi[j] = buf_load16(wrs, lb, u + (unsigned)(2 * j * Nn) * 16u);
-            b.lo[j] = buf_load16(wrs, lb, u + (unsigned)(2 * j * Nn) * 16u + plane_b);
-        }
+        for (int j = 0; j < NKS; ++j)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) b.p[p][j] = buf_load16(wrs, lb, u + (unsigned)(2 * j * Nn) * 16u + (unsigned)p * plane_b);
     };
 
-    auto loadA = [&](BFrag16<NKS>& f, int tap) {
+    auto loadA = [&](KFrag<NKS, NPL>& f, int tap) {
         const int toff = ((tap / 5) * IW + (tap % 5)) * LDH;
 #pragma unroll
-        for (int j = 0; j < NKS; ++j) {
-            f.hi[j] = *reinterpret_cast<const uint4*>(sHi + aoff + toff + 16 * j);
-            f.lo[j] = *reinterpret_cast<const uint4*>(sLo + aoff + toff + 16 * j);
-        }
+        for (int j = 0; j < NKS; ++j)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) f.p[p][j] = *reinterpret_cast<const uint4*>(sPl + p * PLANE + aoff + toff + 16 * j);
     };
     loadB(b0, 0, ch0 * CK);
     loadB(b1, 1, ch0 * CK);
@@ -1695,11 +1532,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
             } else if (xf) {
                 t = keep4(!((bad >> u) & 1u), xform4(t, t_sc, t_sh, a.xf.alpha));      // padding is zero AFTER the activation
             }
-            uint2 hi, lo;
-            split_bf16(t, hi, lo);
+            uint2 pl[NPL];
+            split_planes<NPL>(t, pl);
             const unsigned o = (u + 1 < PER) ? lds_b + (unsigned)(u * DP * LDH) * 2u : lds_last;
-            *reinterpret_cast<uint2*>(dsm + o) = hi;
-            *reinterpret_cast<uint2*>(dsm + o + (unsigned)(IH * IW * LDH) * 2u) = lo;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(dsm + o + (unsigned)(p * PLANE) * 2u) = pl[p];
         }
     };
     issue_stage(ch0 * CK);
@@ -1711,16 +1548,21 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
         __syncthreads();
         loadA(a0, 0);
         const bool more = ch + 1 < nchunks;
-        auto unit = [&](const BFrag16<NKS>& bc, BFrag16<NKS>& bpf, const BFrag16<NKS>& ac, BFrag16<NKS>& an, const int t) {
+        auto unit = [&](const KFrag<NKS, NPL>& bc, KFrag<NKS, NPL>& bpf, const KFrag<NKS, NPL>& ac, KFrag<NKS, NPL>& an, const int t) {
             if (t + 3 < 25) loadB(bpf, t + 3, c0);
             else if (more) loadB(bpf, t + 3 - 25, c0 + CK);
             if (t + 1 < 25) loadA(an, t + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NKS; ++j) {
-                acc0 = mfma_bf16(ac.hi[j], bc.hi[j], acc0);
-                acc1 = mfma_bf16(ac.hi[j], bc.lo[j], acc1);
-                acc2 = mfma_bf16(ac.lo[j], bc.hi[j], acc2);
+                acc0 = mfma_bf16(ac.p[0][j], bc.p[0][j], acc0);
+                acc1 = mfma_bf16(ac.p[0][j], bc.p[1][j], acc1);
+                acc2 = mfma_bf16(ac.p[1][j], bc.p[0][j], acc2);
+                if constexpr (NPL == 3) {      // bf16x6: + a0 w2, a2 w0, a1 w1
+                    acc1 = mfma_bf16(ac.p[0][j], bc.p[2][j], acc1);
+                    acc2 = mfma_bf16(ac.p[2][j], bc.p[0][j], acc2);
+                    acc1 = mfma_bf16(ac.p[1][j], bc.p[1][j], acc1);
+                }
             }
         };
 #pragma unroll
@@ -1737,7 +1579,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
     // ---- epilogue: transpose through a wave-private LDS tile, 16-byte accesses (see conv5_d16_kernel) ----
     __syncthreads();
     constexpr int EPI_LD = 36;
-    static_assert((size_t)WGM * WGN * 32 * EPI_LD * 4 <= (size_t)2 * IH * IW * LDH * 2, "epilogue tile fits in the activation tile");
+    static_assert((size_t)WGM * WGN * 32 * EPI_LD * 4 <= (size_t)NPL * IH * IW * LDH * 2, "epilogue tile fits in the activation tile");
     const bool bwd = (a.ep.kind == UAD_EPI_BWD_ACT);
     float* etile = s_epi + wave * 32 * EPI_LD;
     const int ec4 = (lane & 7) * 4, erow = lane >> 3;
@@ -1850,45 +1692,46 @@ __global__ void __launch_bounds__(64 * WGM * WGN) __attribute__((amdgpu_waves_pe
 // forward's single-workgroup loss.finalize.  The successor's workgroups fill the CUs the predecessor's last workgroups are still draining:
 // -0.7 % per step (profiles/r03_y_gpurun11/12.log); unlike a second stream (+36 %) the predecessor is dispatched in full first.
 // UAD_NO_ANYORDER=1 (read in uad_model.hip) keeps every launch ordered.
-static thread_local bool g_any_order_next = false;      // (per host thread: another thread's launch must not consume it)
-static thread_local bool g_any_order_w_next = false;      // ... the same for the next channel-major filter-gradient launch (the first one of a backward, behind loss.finalize)
-#define UAD_W_LAUNCH(kern, grid, block, lds, st, ...)                                                                       \
-    do {                                                                                                                    \
-        if (g_any_order_w_next) { g_any_order_w_next = false; hipExtLaunchKernelGGL(kern, grid, block, lds, st, nullptr, nullptr, 1u, __VA_ARGS__); } \
-        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                   \
-    } while (0)
-#define UAD_SPATIAL_LAUNCH(kern, grid, block, lds, st, arg)                                                                 \
-    do {                                                                                                                    \
-        if (g_any_order_next) { g_any_order_next = false; hipExtLaunchKernelGGL(kern, grid, block, lds, st, nullptr, nullptr, 1u, arg); } \
-        else hipLaunchKernelGGL(kern, grid, block, lds, st, arg);                                                           \
-    } while (0)
-#include "uad_conv16s.inc"
-
-template <int TH, int TW, int CK, int WGM, int WGN>
-constexpr size_t conv5_f16_lds_bytes() {
-    return (size_t)2 * (2 * TH + 3) * (2 * TW + 3) * (CK + 8) * 2 + (size_t)3 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
+// (g_any_order_next / g_any_order_w_next and the two launch macros: uad_gemm_common.h)
+// The lane = pixel D-kind family (uad_conv16s.inc) is compiled in uad_gemm_d16s.hip; ConvGemmArgs is the same header-defined struct in both units and
+// crosses the boundary as an untyped pointer (anonymous-namespace types are unit-local).
+}  // namespace
+bool uad_d16s_takes_v(const void* conv_gemm_args);
+void uad_d16s_launch_v2(const void* conv_gemm_args, unsigned gx, unsigned gy, unsigned gz, int bn, int cst, bool any_order, hipStream_t st);      // uad_gemm_d16s.hip: two planes
+void uad_d16s_launch_v3(const void* conv_gemm_args, unsigned gx, unsigned gy, unsigned gz, int bn, int cst, bool any_order, hipStream_t st);      // uad_gemm_d16s3.hip: three
+namespace {
+inline bool conv5_d16s_takes(const ConvGemmArgs& a) { return uad_d16s_takes_v(&a); }
+inline void launch_conv5_d16s_any(const ConvGemmArgs& a, dim3 grid, int bn, int cst, hipStream_t st) {
+    const bool any = g_any_order_next;
+    g_any_order_next = false;
+    if (a.npl == 3) uad_d16s_launch_v3(&a, grid.x, grid.y, grid.z, bn, cst, any, st); else uad_d16s_launch_v2(&a, grid.x, grid.y, grid.z, bn, cst, any, st);
 }
 
-template <int TH, int TW, int CK, int WGM, int WGN, int FB, bool XF>
+template <int TH, int TW, int CK, int WGM, int WGN, int NPL = 2>
+constexpr size_t conv5_f16_lds_bytes() {
+    return (size_t)NPL * (2 * TH + 3) * (2 * TW + 3) * (CK + 8) * 2 + (size_t)3 * XF_LDS_CH * 4 + (size_t)WGM * 2 * 32 * WGN * 4;
+}
+
+template <int TH, int TW, int CK, int WGM, int WGN, int FB, bool XF, int NPL>
 void launch_conv5_f16_v(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = conv5_f16_lds_bytes<TH, TW, CK, WGM, WGN>();
+    constexpr size_t lds = conv5_f16_lds_bytes<TH, TW, CK, WGM, WGN, NPL>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB, XF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB, XF, NPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    UAD_SPATIAL_LAUNCH((conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB, XF>), grid, dim3(64 * WGM * WGN), lds, st, a);
+    UAD_SPATIAL_LAUNCH((conv5_f16_kernel<TH, TW, CK, WGM, WGN, FB, XF, NPL>), grid, dim3(64 * WGM * WGN), lds, st, a);
 }
-template <int TH, int TW, int CK, int WGM, int WGN>
+template <int TH, int TW, int CK, int WGM, int WGN, int NPL = 2>
 void launch_conv5_f16(const ConvGemmArgs& a, dim3 grid, hipStream_t st) {
     if (a.xf.fb_bits || a.xf.fb_dxhat) {
         if (!a.xf.scale) { fprintf(stderr, "uad: final-backward on load needs the block's scale / shift tables\n"); abort(); }
         if (a.xf.fb_bits && a.CA > 32) { fprintf(stderr, "uad: the pattern-word form holds one bit per channel of a 32-bit word (CA = %d)\n", a.CA); abort(); }
-        if (a.xf.fb_bits) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 2, true>(a, grid, st);
-        else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 1, true>(a, grid, st);
-    } else if (a.xf.scale) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0, true>(a, grid, st);
-    else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0, false>(a, grid, st);
+        if (a.xf.fb_bits) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 2, true, NPL>(a, grid, st);
+        else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 1, true, NPL>(a, grid, st);
+    } else if (a.xf.scale) launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0, true, NPL>(a, grid, st);
+    else launch_conv5_f16_v<TH, TW, CK, WGM, WGN, 0, false, NPL>(a, grid, st);
 }
 
 template <int TH, int TW, int CST, int WGM, int WGN>
@@ -2128,6 +1971,7 @@ struct ConvWArgs {
     int kper;  // positions per split (multiple of BK)
     int lws, lhs;
     unsigned long long* dbgbuf;   // UAD_DBG & 32: per-workgroup start / end clocks
+    int npl = 2;   // bf16 planes per operand of the k5 s2 kernel (2: bf16x3 products, 3: bf16x6)
     int abl = 0;   // UAD_W_ABL, kernel-tuning ablations (results are wrong): 1 no big-tile LDS stores | 2 no MFMAs | 4 no big-tile global loads | 8 no slab stores;
                    // 32 (results stay right): every workgroup sleeps before its slab store (ordering stress test)
 };
@@ -2447,7 +2291,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_w16_kernel(const ConvWArg
 // five taps + tap (4, w) + a quarter of tap (4, 4) (folded through LDS in a fixed order); one [25][CB][CS] slab per workgroup, summed in split order by
 // reduce_partials_kernel.  (Its predecessors -- the pixel-major gather kernel of round 2 and the channel-major scatter kernel of round 3, same bits -- were
 // dropped in round 6; git history has them.)
-template <int NCSB, bool FBB, bool XFA, bool XFS>
+template <int NCSB, bool FBB, bool XFA, bool XFS, int NPL = 2>      // NPL: bf16 planes per operand (2: bf16x3 products, 3: bf16x6)
 __global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
 conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     // Round 6 ("VALU diet"): the staging half of this kernel issued ~45 VALU instructions per 16 bytes staged, a third of them 64-bit pointer
@@ -2468,10 +2312,9 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     // (A double-buffered tile loop -- one barrier per tile, the next tile's conversion beside this tile's MFMAs -- measured neutral on this kernel too:
     // profiles/r04_h_w_tr_ab.log.)
-    unsigned short* bHi = reinterpret_cast<unsigned short*>(dsm);
-    unsigned short* bLo = bHi + BIGP;
-    unsigned short* sHiT = bLo + BIGP;
-    unsigned short* sLoT = sHiT + TH * TW * LDQ;
+    constexpr int SMALLP = TH * TW * LDQ;         // ushorts per small plane
+    unsigned short* bPl = reinterpret_cast<unsigned short*>(dsm);       // NPL big planes, then NPL small planes
+    unsigned short* sPlT = bPl + NPL * BIGP;
     float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
 
     const unsigned long long dbg_t0 = a.dbgbuf ? wall_clock64() : 0;
@@ -2566,10 +2409,22 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
         const uint2 lo2 = __builtin_bit_cast(uint2, r0), hi2 = __builtin_bit_cast(uint2, r1);
         return make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
     };
-    auto mma3 = [&](v16f& c, uint4 ah, uint4 al, uint4 bh, uint4 bl) {
-        c = mfma_bf16(ah, bh, c);
-        c = mfma_bf16(ah, bl, c);
-        c = mfma_bf16(al, bh, c);
+    struct Pl { uint4 p[NPL]; };
+    auto trp = [&](const unsigned short* planes, const int plane_stride, const int addr, const int step) __attribute__((always_inline)) {
+        Pl r;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) r.p[p] = tr8(planes + p * plane_stride, addr, step);
+        return r;
+    };
+    auto mma3 = [&](v16f& c, const Pl& a_, const Pl& b_) __attribute__((always_inline)) {
+        c = mfma_bf16(a_.p[0], b_.p[0], c);
+        c = mfma_bf16(a_.p[0], b_.p[1], c);
+        c = mfma_bf16(a_.p[1], b_.p[0], c);
+        if constexpr (NPL == 3) {      // bf16x6: + a0 b2, a2 b0, a1 b1
+            c = mfma_bf16(a_.p[0], b_.p[2], c);
+            c = mfma_bf16(a_.p[2], b_.p[0], c);
+            c = mfma_bf16(a_.p[1], b_.p[1], c);
+        }
     };
 
     // ---- tile loop, software-pipelined: the global loads of tile t + 1 are in flight while tile t is contracted ----
@@ -2627,21 +2482,21 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
                 tv = as_f4(v[FBB ? 0 : u]);
                 if (XFA) tv = keep4(!((bad >> u) & 1u), xform4(tv, bsc, bsh, balpha));      // padding is zero AFTER the activation
             }
-            uint2 hi, lo;
-            split_bf16(tv, hi, lo);
+            uint2 pl[NPL];
+            split_planes<NPL>(tv, pl);
             const unsigned o = (u + 1 < PER) ? lds_b + (unsigned)(u * DP * LDH) * 2u : lds_last;
-            lds_store8(o, hi);
-            lds_store8(o + (unsigned)BIGP * 2u, lo);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) lds_store8(o + (unsigned)(p * BIGP) * 2u, pl[p]);
         }
 #pragma unroll
         for (int u = 0; u < SPER; ++u) {
             float4 tv = as_f4(sv[u]);
             if (XFS) tv = xform4(tv, ssc, ssh, salpha);
-            uint2 hi, lo;
-            split_bf16(tv, hi, lo);
-            const unsigned o = (unsigned)(2 * BIGP) * 2u + slds_b + (unsigned)(u * (NT / CSQ) * LDQ) * 2u;
-            lds_store8(o, hi);
-            lds_store8(o + (unsigned)(TH * TW * LDQ) * 2u, lo);
+            uint2 pl[NPL];
+            split_planes<NPL>(tv, pl);
+            const unsigned o = (unsigned)(NPL * BIGP) * 2u + slds_b + (unsigned)(u * (NT / CSQ) * LDQ) * 2u;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) lds_store8(o + (unsigned)(p * SMALLP) * 2u, pl[p]);
         }
     };
     if (t_begin < t_end) issue();
@@ -2654,12 +2509,12 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
         for (int js = 0; js < TH * TW / 16; ++js) {
             // positions 16 js .. 16 js + 15 = tile rows 2 js (k half 0) and 2 js + 1 (k half 1)
             const int bo = b_base + 16 * js * LDQ;
-            const uint4 bh = tr8(sHiT, bo, 4 * LDQ), bl = tr8(sLoT, bo, 4 * LDQ);
+            const Pl bq_ = trp(sPlT, SMALLP, bo, 4 * LDQ);
             const int ao = a_base + (4 * js * IW + wave * IW) * LDH;          // this wave's kernel row
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) mma3(acc[kx], tr8(bHi, ao + kx * LDH, 8 * LDH), tr8(bLo, ao + kx * LDH, 8 * LDH), bh, bl);
+            for (int kx = 0; kx < 5; ++kx) mma3(acc[kx], trp(bPl, BIGP, ao + kx * LDH, 8 * LDH), bq_);
             const int a4 = a_base + (4 * js * IW + 4 * IW) * LDH;             // kernel row 4
-            mma3(acc[5], tr8(bHi, a4 + wave * LDH, 8 * LDH), tr8(bLo, a4 + wave * LDH, 8 * LDH), bh, bl);        // tap (4, wave)
+            mma3(acc[5], trp(bPl, BIGP, a4 + wave * LDH, 8 * LDH), bq_);        // tap (4, wave)
         }
         {
             // this wave's quarter of tap (4, 4) = position block js = wave, addressed by a run-time offset BEHIND the straight-line loop: with the
@@ -2667,7 +2522,7 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
             // above the previous block's MFMAs.  acc[6] receives the same three products in the same order.
             const int bo = b_base + 16 * wave * LDQ;
             const int a4 = a_base + (4 * wave * IW + 4 * IW) * LDH;
-            mma3(acc[6], tr8(bHi, a4 + 4 * LDH, 8 * LDH), tr8(bLo, a4 + 4 * LDH, 8 * LDH), tr8(sHiT, bo, 4 * LDQ), tr8(sLoT, bo, 4 * LDQ));
+            mma3(acc[6], trp(bPl, BIGP, a4 + 4 * LDH, 8 * LDH), trp(sPlT, SMALLP, bo, 4 * LDQ));
         }
     }
 
@@ -2706,7 +2561,7 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
     }
 }
 
-constexpr size_t conv5_w_bf16_tr_lds_bytes(int ncsb) { return (size_t)2 * 19 * 19 * 40 * 2 + (size_t)2 * 64 * (32 * ncsb + 8) * 2 + 192 * 4; }
+constexpr size_t conv5_w_bf16_tr_lds_bytes(int ncsb, int npl = 2) { return (size_t)npl * 19 * 19 * 40 * 2 + (size_t)npl * 64 * (32 * ncsb + 8) * 2 + 192 * 4; }
 
 #include "uad_convk16.inc"
 
@@ -2889,8 +2744,26 @@ bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type) {
     if (convk16_shape_ok(d, f_type)) return true;      // k3 tap-list kernel (bf16x3 planes only: the fp32 pack of such a tensor is simply not used)
     return f_type ? choose_spatial(d, d.CB, d.CS, true).ok : choose_spatial(d, d.CS, d.CB, false).ok;
 }
-int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats, int ncounters) { return plan_gemm(d, true, have_pack, ws_floats, ncounters).tiles; }
-int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats, int ncounters) { return plan_gemm(d, false, have_pack, ws_floats, ncounters).tiles; }
+namespace {
+// bf16x6 (three-plane) launches run on the F-kind and the lane = pixel spatial kernels; every other launch of a handle in that mode takes the exact-fp32
+// route (its fp32 pack is kept beside the planes).  One decision for the launchers and the tile queries.
+bool x6_route(const UadConvDesc& d, bool f_type, const GemmPlan& p) {
+    if (p.path != PATH_SPATIAL) return false;
+    if (f_type) return true;       // (final-backward-on-load forms: the 32-column instance only -- they have CA <= 32, which the planner gives that instance)
+    if (d.CB % 32) return false;
+    if (p.nsplit > 1 && !p.inkernel) return false;
+    const int cst = (d.CS % p.nsplit == 0) ? d.CS / p.nsplit : 0;
+    return p.sc.BN == 64 ? (cst == 32 || cst == 64 || cst == 128) : (cst == 32 || cst == 64);
+}
+GemmPlan plan_for(const UadConvDesc& d, bool f_type, bool have_pack, size_t ws_floats, int ncounters, int planes16) {
+    GemmPlan p = plan_gemm(d, f_type, have_pack, ws_floats, ncounters);
+    if (planes16 == 3 && !x6_route(d, f_type, p)) p = plan_gemm(d, f_type, have_pack, ws_floats, 0);      // the exact-fp32 kernels: no in-kernel slab reduction
+    return p;
+}
+}  // namespace
+bool uad_conv_x6_takes(const UadConvDesc& d, bool f_type, size_t ws_floats, int ncounters) { return x6_route(d, f_type, plan_gemm(d, f_type, true, ws_floats, ncounters)); }
+int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats, int ncounters, int planes16) { return plan_for(d, true, have_pack, ws_floats, ncounters, planes16).tiles; }
+int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack, size_t ws_floats, int ncounters, int planes16) { return plan_for(d, false, have_pack, ws_floats, ncounters, planes16).tiles; }
 bool uad_conv_f_supports_final_bwd(const UadConvDesc& d, bool have_pack16, size_t ws_floats) {
     if (!have_pack16) return false;
     const GemmPlan p = plan_gemm(d, true, true, ws_floats);
@@ -2943,6 +2816,12 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
         dim3 grid((d.HS / p.sc.TH) * (d.WS / p.sc.TW), d.N, (a.Nn / p.sc.BN) * p.nsplit);
         if (a.Wp16) {   // bf16x3 math mode
             if (f_type) {
+                if (a.npl == 3) {      // bf16x6: 16-channel chunks in the 64-column instance too (three planes of a 32-channel 19 x 19 halo = 87 KB: one workgroup per CU)
+                    if (p.sc.BN == 64) {
+                        if (a.xf.fb_bits || a.xf.fb_dxhat) { fprintf(stderr, "uad: final-backward on load runs on the 32-column instance (CA <= 32)\n"); abort(); }
+                        if (a.xf.scale) launch_conv5_f16_v<8, 8, 16, 2, 2, 0, true, 3>(a, grid, st); else launch_conv5_f16_v<8, 8, 16, 2, 2, 0, false, 3>(a, grid, st);
+                    } else launch_conv5_f16<8, 16, 16, 4, 1, 3>(a, grid, st);
+                } else
                 if (p.sc.BN == 64) launch_conv5_f16<8, 8, 32, 2, 2>(a, grid, st);
                 else launch_conv5_f16<8, 16, 16, 4, 1>(a, grid, st);
             } else {
@@ -2950,11 +2829,8 @@ void run_plan(const GemmPlan& p, ConvGemmArgs& a, bool f_type, float* ws, hipStr
                 const int cst = (a.CA % p.nsplit == 0) ? a.CA / p.nsplit : 0;
                 constexpr bool seq = true;      // class-sequential generation (conv5_d16_kernel): the fallback of the lane = pixel one
                 const bool lp = seq && conv5_d16s_takes(a);      // lane = pixel generation (uad_conv16s.inc)
-                if (lp && p.sc.BN == 64 && cst == 128) launch_conv5_d16s_bn64<128>(a, grid, st);
-                else if (lp && p.sc.BN == 64 && cst == 64) launch_conv5_d16s_bn64<64>(a, grid, st);
-                else if (lp && p.sc.BN == 64 && cst == 32) launch_conv5_d16s_bn64<32>(a, grid, st);
-                else if (lp && p.sc.BN == 32 && cst == 64) launch_conv5_d16s_bn32<64>(a, grid, st);
-                else if (lp && p.sc.BN == 32 && cst == 32) launch_conv5_d16s_bn32<32>(a, grid, st);
+                if (lp && ((p.sc.BN == 64 && (cst == 128 || cst == 64 || cst == 32)) || (p.sc.BN == 32 && (cst == 64 || cst == 32)))) launch_conv5_d16s_any(a, grid, p.sc.BN, cst, st);
+                else if (a.npl == 3) { fprintf(stderr, "uad: a bf16x6 launch reached a kernel without the three-plane form (x6_route decides before run_plan)\n"); abort(); }
                 else
                 if (p.sc.BN == 64) {
                     if (seq && cst == 128) launch_conv5_d16<8, 8, 128, 2, 2>(a, grid, st);
@@ -3014,14 +2890,21 @@ void uad_launch_conv_f(const UadConvDesc& d, const float* big_in, UadXform xf, c
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
                        long long w16_plane, bool generic_bf16x3, int planes16) {
     if (convk16_takes(d, true, xf, ep, Wp16)) { run_convk16(d, true, big_in, small_out, ep, Wp16, w16_plane, planes16, st); return; }      // k3 s1 / s2, bf16x3 / bf16x6
-    if (planes16 == 3) { fprintf(stderr, "uad: three-plane weights are understood by the k3 tap-list kernel only (check uad_conv_k3_takes first)\n"); abort(); }
     ConvGemmArgs a;
-    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
+    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0; a.npl = 2;
     a.A = big_in; a.W = W; a.Out = small_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CB; a.Nn = d.CS;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;
     a.sk_counter = nullptr; a.out_final = nullptr;
-    const GemmPlan p = plan_gemm(d, true, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
+    GemmPlan p = plan_gemm(d, true, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
+    if (planes16 == 3) {
+        if (x6_route(d, true, p)) a.npl = 3;
+        else {      // bf16x6 handle, launch outside the three-plane kernels: the exact-fp32 route
+            if (!Wpacked && d.KS == 5) { fprintf(stderr, "uad: a bf16x6 launch outside the three-plane spatial kernels needs the fp32 pack (uad_conv_x6_takes / uad_conv_k3_takes)\n"); abort(); }
+            a.Wp16 = nullptr;
+            p = plan_gemm(d, true, Wpacked != nullptr, ws.ptr ? ws.floats : 0, 0);
+        }
+    }
     if (p.inkernel) a.sk_counter = ws.counters;
     run_plan(p, a, true, ws.ptr, st);
 }
@@ -3030,14 +2913,24 @@ void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf,
                        UadEpilogue ep, hipStream_t st, const float* Wpacked, UadGemmWs ws, const unsigned short* Wp16,
                        long long w16_plane, bool generic_bf16x3, int planes16) {
     if (convk16_takes(d, false, xf, ep, Wp16)) { run_convk16(d, false, small_in, big_out, ep, Wp16, w16_plane, planes16, st); return; }
-    if (planes16 == 3) { fprintf(stderr, "uad: three-plane weights are understood by the k3 tap-list kernel only (check uad_conv_k3_takes first)\n"); abort(); }
     ConvGemmArgs a;
-    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0;
+    a.Wp = Wpacked; a.Wp16 = Wp16; a.w16_plane = w16_plane; a.math16 = generic_bf16x3 ? 1 : 0; a.npl = 2;
     a.A = small_in; a.W = W; a.Out = big_out; a.xf = xf; a.ep = ep; a.d = d;
     a.M = d.N * d.HS * d.WS; a.CA = d.CS; a.Nn = d.CB;
     a.lws = ilog2_exact(d.WS); a.lhs = ilog2_exact(d.HS); a.dbgbuf = nullptr;
     a.sk_counter = nullptr; a.out_final = nullptr;
-    const GemmPlan p = plan_gemm(d, false, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
+    GemmPlan p = plan_gemm(d, false, Wpacked != nullptr || Wp16 != nullptr, ws.ptr ? ws.floats : 0, (Wp16 && ws.counters) ? ws.ncounters : 0);
+    if (planes16 == 3) {
+        // (the lane = pixel kernel's instance list: conv5_d16s_takes)
+        const bool has_xf = xf.scale != nullptr;
+        const bool inst_ok = ep.kind == UAD_EPI_FINAL ? (ep.fin_dc == nullptr && ep.ealpha >= 0.f && ep.ealpha <= 1.f && has_xf) : ep.kind == UAD_EPI_BWD_ACT ? !has_xf : has_xf;
+        if (x6_route(d, false, p) && inst_ok) a.npl = 3;
+        else {
+            if (!Wpacked && d.KS == 5) { fprintf(stderr, "uad: a bf16x6 launch outside the three-plane spatial kernels needs the fp32 pack (uad_conv_x6_takes / uad_conv_k3_takes)\n"); abort(); }
+            a.Wp16 = nullptr;
+            p = plan_gemm(d, false, Wpacked != nullptr, ws.ptr ? ws.floats : 0, 0);
+        }
+    }
     if (p.inkernel) a.sk_counter = ws.counters;
     run_plan(p, a, false, ws.ptr, st);
 }
@@ -3065,11 +2958,19 @@ inline WChoice choose_w(const UadConvDesc& d) {
 }  // namespace
 
 namespace {
+template <int NCSB, bool FBB, bool XFA, bool XFS, int NPL>
+void launch_w_tr_n(const ConvWArgs& a, dim3 grid, const W5Choice& w5, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(NCSB, NPL)); attr = true; }
+    UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS, NPL>), grid, dim3(256 * NCSB), conv5_w_bf16_tr_lds_bytes(NCSB, NPL), st, a, w5.tiles_per_split, w5.total_tiles);
+}
+// bf16x6 instances: the three operand forms the model's backward uses -- (pattern word | plain gradient, activated input) in the decoder, (activated input,
+// plain gradient) in the encoder; w_tr_x6_takes() tells the launcher, other forms of a bf16x6 launch run on the exact-fp32 generic kernels
+inline bool w_tr_x6_takes(bool fbb, bool xa, bool xs) { return fbb ? xs : (xa != xs); }
 template <int NCSB, bool FBB, bool XFA, bool XFS>
 void launch_w_tr(const ConvWArgs& a, dim3 grid, const W5Choice& w5, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(NCSB)); attr = true; }
-    UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS>), grid, dim3(256 * NCSB), conv5_w_bf16_tr_lds_bytes(NCSB), st, a, w5.tiles_per_split, w5.total_tiles);
+    if constexpr (FBB ? XFS : (XFA != XFS)) { if (a.npl == 3) { launch_w_tr_n<NCSB, FBB, XFA, XFS, 3>(a, grid, w5, st); return; } }
+    launch_w_tr_n<NCSB, FBB, XFA, XFS, 2>(a, grid, w5, st);
 }
 }  // namespace
 
@@ -3087,7 +2988,8 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d) {
 }
 
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
-                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev, bool generic_bf16x3, bool defer_reduce) {
+                       float* dW, float* partial, hipStream_t st, bool math_bf16x3, hipStream_t reduce_st, hipEvent_t ev, bool generic_bf16x3, bool defer_reduce, int planes16) {
+    // planes16 == 3 (with math_bf16x3): bf16x6 products in the k5 s2 kernel; a shape that kernel does not take runs on the exact-fp32 generic kernels
     // reduce_st/ev (optional): run the split-K slab reduction on a second stream, ordered after the main kernel by `ev`.
     // defer_reduce: leave the reduction to a later uad_launch_conv_w_reduce (the caller orders it after this kernel with ONE event per layer:
     // every event recorded on the main stream costs a ~6 us bubble before its next kernel)
@@ -3098,12 +3000,18 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         return reduce_st;
     };
     const W5Choice w5 = choose_w5(d, math_bf16x3);
+    bool use16 = math_bf16x3;
+    if (w5.ok && math_bf16x3 && planes16 == 3 && !w_tr_x6_takes(xfb.fb_bits != nullptr, xfb.scale != nullptr && !xfb.fb_bits, xfs.scale != nullptr)) {
+        if (xfb.fb_bits) { fprintf(stderr, "uad: bf16x6 filter gradient from the pattern word needs the small operand's activation on load\n"); abort(); }
+        use16 = false;      // the exact-fp32 k5 kernel on the SAME split (uad_launch_conv_w_reduce is told the launch's math mode, not the kernel)
+    }
     if (w5.ok) {
         ConvWArgs a;
         a.big = big; a.small_ = small; a.partial = (w5.splits == 1) ? dW : partial;
         a.xfb = xfb; a.xfs = xfs; a.d = d;
         a.Mtot = d.KS * d.KS * d.CB; a.Kt = d.N * d.HS * d.WS; a.kper = 0; a.lws = a.lhs = -1; a.dbgbuf = nullptr;
         { static const int abl = getenv("UAD_W_ABL") ? atoi(getenv("UAD_W_ABL")) : 0; a.abl = abl; }
+        a.npl = (use16 && planes16 == 3) ? 3 : 2;
         dim3 grid(d.CB / 32, d.CS / 32, w5.splits);
         static const int dbgw = getenv("UAD_DBG") ? atoi(getenv("UAD_DBG")) : 0;
         static unsigned long long* wbuf = nullptr;
@@ -3119,7 +3027,7 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
                 for (int b = 0; b < nb && b < 2048; ++b) { const unsigned long long dd = h[2 * b + 1] - h[2 * b]; dsum += dd; if (dd < dmin) dmin = dd; if (dd > dmax) dmax = dd; if (h[2 * b] - t0 > smax) smax = h[2 * b] - t0; }
                 fprintf(stderr, "[w5 CB=%d CS=%d HS=%d grid=%d,%d,%d] span=%llu (100MHz ticks) wg dur min=%llu avg=%llu max=%llu latest start=%llu\n", d.CB, d.CS, d.HS, g->x, g->y, g->z,
                         t1 - t0, dmin, dsum / nb, dmax, smax); } } dump{dbg_this, st, wbuf, &grid, &wcalls, d};
-        if (math_bf16x3) {
+        if (use16) {
             const bool two = d.CS % 64 == 0;       // two 32-channel cs blocks per workgroup (512 threads) where the layer has them
             if (two) grid.y = d.CS / 64;
             {
@@ -3139,7 +3047,7 @@ void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, con
         return;
     }
     const WK3Choice k3 = choose_wk3(d);
-    if (k3.ok && (math_bf16x3 || generic_bf16x3) && !defer_reduce && !xfb.scale && !xfs.scale && !xfb.fb_bits) {
+    if (k3.ok && (math_bf16x3 || generic_bf16x3) && planes16 != 3 && !defer_reduce && !xfb.scale && !xfs.scale && !xfb.fb_bits) {
         // k3 s1 / s2 filter gradient in bf16x3 (uad_convk16.inc): channel-major LDS tiles, slabs + fixed-order reduction
         ConvWArgs a;
         a.big = big; a.small_ = small; a.partial = (k3.splits == 1) ? dW : partial;

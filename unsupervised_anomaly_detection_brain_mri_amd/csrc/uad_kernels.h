@@ -91,8 +91,10 @@ void uad_launch_conv_d(const UadConvDesc& d, const float* small_in, UadXform xf,
 // element count (the lo plane follows the hi plane)
 void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, unsigned short* w16_d, const long long* offs,
                                   const int* cbs, const int* css, const int* taps, int n, hipStream_t st);
-// planes16 = 3 ("bf16x6", k3 tap-list kernel only -- uad_conv_k3_takes): Wp16 = the tensor's first plane inside a THREE-plane pack buffer (ushort
-// index 4 * offset, planes w16_plane elements apart) written by this function; products are fp32-grade (six bf16 MFMAs per K = 16)
+// planes16 = 3 ("bf16x6"): Wp16 = the tensor's first plane inside a THREE-plane pack buffer (ushort index 4 * offset, planes w16_plane elements apart)
+// written by this function; products are fp32-grade (six bf16 MFMAs per K = 16).  Understood by the k3 tap-list kernel (uad_conv_k3_takes) and, since
+// round 6, by the k5 s2 spatial kernels (F-kind, lane = pixel D-kind, filter gradient): a k5 launch those do not take (uad_conv_x6_takes) runs on the
+// exact-fp32 kernels and needs Wpacked beside the planes.
 void uad_launch_pack_weights_bf16_3p(const float* params, unsigned short* w3_f, unsigned short* w3_d, const long long* offs,
                                      const int* cbs, const int* css, const int* taps, int n, hipStream_t st);
 // true when uad_launch_conv_f / _d would run the k3 tap-list kernel for this shape when bf16 planes are given (identity activation, bias / addend epilogue)
@@ -106,14 +108,15 @@ void uad_launch_pack_weights(const float* params, float* wpack_f, float* wpack_d
 bool uad_conv_spatial_ok(const UadConvDesc& d, bool f_type);
 // number of colpart tiles the above launches write for EPI_BWD_ACT
 // (the same have_pack / workspace capacity as the launch must be passed: they select the kernel path)
-int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0, int ncounters = 0);      // ncounters: UadGemmWs::ncounters when the launch will run in the split-bf16 mode, else 0
+int uad_conv_f_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0, int ncounters = 0, int planes16 = 2);      // ncounters: UadGemmWs::ncounters when the launch will run in a split-bf16 mode, else 0; planes16: as the launch
+bool uad_conv_x6_takes(const UadConvDesc& d, bool f_type, size_t ws_floats, int ncounters);      // a planes16 = 3 launch of this k5 s2 shape runs on the three-plane spatial kernels
 // true when uad_launch_conv_d(d, ..., UAD_EPI_FINAL) is available: bf16x3 planes given, class-sequential spatial kernel, all
 // output channels (32) in one workgroup, no split
 bool uad_conv_d_can_fuse_final(const UadConvDesc& d, bool have_pack16, size_t ws_floats);
 bool uad_conv_d_can_fuse_final_f32(const UadConvDesc& d, bool have_pack, size_t ws_floats);
 // true when uad_launch_conv_f would run the bf16x3 spatial kernel that understands UadXform::fb_* (see there)
 bool uad_conv_f_supports_final_bwd(const UadConvDesc& d, bool have_pack16, size_t ws_floats);
-int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0, int ncounters = 0);
+int uad_conv_d_tiles(const UadConvDesc& d, bool have_pack = true, size_t ws_floats = 0, int ncounters = 0, int planes16 = 2);
 // workspace floats the split-K path would like for this op (0 = it would not split)
 size_t uad_conv_ws_floats(const UadConvDesc& d, bool f_type, bool have_pack);
 // W-type: dW[tap][cb][cs] = sum_{n,i,j} xfb(big)[..tap..,cb] * xfs(small)[n,i,j,cs]
@@ -123,7 +126,7 @@ size_t uad_conv_w_partial_floats(const UadConvDesc& d);
 bool uad_conv_w_supports_fb_bits(const UadConvDesc& d, bool math_bf16x3);
 void uad_launch_conv_w(const UadConvDesc& d, const float* big, UadXform xfb, const float* small, UadXform xfs,
                        float* dW, float* partial, hipStream_t st, bool math_bf16x3 = false,
-                       hipStream_t reduce_st = nullptr, hipEvent_t ev = nullptr, bool generic_bf16x3 = false, bool defer_reduce = false);
+                       hipStream_t reduce_st = nullptr, hipEvent_t ev = nullptr, bool generic_bf16x3 = false, bool defer_reduce = false, int planes16 = 2);
 // the split-K slab reduction of a uad_launch_conv_w(..., math_bf16x3, ..., defer_reduce = true) call (no-op when that launch did not split); the
 // math mode has to be the launch's: the k5 kernels split differently in the two modes
 void uad_launch_conv_w_reduce(const UadConvDesc& d, float* dW, float* partial, hipStream_t st, bool math_bf16x3);

@@ -70,7 +70,8 @@ struct uad_model {
     float *params, *grads, *adam_m, *adam_v;
     float *wpack_f, *wpack_d;          // k-quad-interleaved copies of the 5x5 kernels (refreshed once per forward)
     float *wpack16_f, *wpack16_d;      // bf16 hi|lo planes of the same kernels (bf16x3 math mode); 2*nparams ushorts each
-    int math;                          // UAD_MATH_F32 | UAD_MATH_BF16X3
+    int math;                          // UAD_MATH_F32 | UAD_MATH_BF16X3 | UAD_MATH_BF16X6
+    float *wpack3_f, *wpack3_d;        // bf16x6: three bf16 planes of the 5x5 kernels, 4 * nparams ushorts each (allocated when the mode is first set)
     UadGemmWs ws;                      // split-K slabs for the GEMMs that cannot fill the chip on their own
     bool packed_valid;
     bool pack_inflight;               // the repack of the updated parameters was launched on SIDE by the optimizer step (ev_pack)
@@ -166,10 +167,17 @@ struct ProfScope {
 
 float* P(uad_model* m, long long off) { return m->params + off; }
 // packed-weight views of one 5x5 tensor for the current math mode (the unused one is null)
-const float* PKF(uad_model* m, long long off) { return m->math == UAD_MATH_F32 ? m->wpack_f + off : nullptr; }
-const float* PKD(uad_model* m, long long off) { return m->math == UAD_MATH_F32 ? m->wpack_d + off : nullptr; }
-const unsigned short* PK16F(uad_model* m, long long off) { return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_f + 2 * off : nullptr; }
-const unsigned short* PK16D(uad_model* m, long long off) { return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_d + 2 * off : nullptr; }
+// (bf16x6 keeps BOTH: the three planes for the k5 spatial kernels and the fp32 pack for the launches those do not take)
+inline bool bf_mode(const uad_model* m) { return m->math == UAD_MATH_BF16X3 || m->math == UAD_MATH_BF16X6; }
+inline int planes_of(const uad_model* m) { return m->math == UAD_MATH_BF16X6 ? 3 : 2; }
+const float* PKF(uad_model* m, long long off) { return m->math != UAD_MATH_BF16X3 ? m->wpack_f + off : nullptr; }
+const float* PKD(uad_model* m, long long off) { return m->math != UAD_MATH_BF16X3 ? m->wpack_d + off : nullptr; }
+const unsigned short* PK16F(uad_model* m, long long off) {
+    return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_f + 2 * off : m->math == UAD_MATH_BF16X6 ? (const unsigned short*)m->wpack3_f + 4 * off : nullptr;
+}
+const unsigned short* PK16D(uad_model* m, long long off) {
+    return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_d + 2 * off : m->math == UAD_MATH_BF16X6 ? (const unsigned short*)m->wpack3_d + 4 * off : nullptr;
+}
 long long PLANE(const ConvLayer& L) { return (long long)L.d.KS * L.d.KS * L.d.CB * L.d.CS; }
 float* Gr(uad_model* m, long long off) { return m->grads + off; }
 
@@ -181,7 +189,7 @@ UadXform bn_xform(uad_model* m, long long gamma, long long beta, float alpha) {
 UadXform no_xform() { UadXform x; x.scale = nullptr; x.shift = nullptr; x.alpha = 1.f; x.mult = 1.f; return x; }
 // restoration: d loss / d c of the last block is formed while the data-gradient kernel stages its input (no final<BWD> pass)
 bool restore_fb_on_load(uad_model* m, int n) {
-    if (!m->restore || m->math != UAD_MATH_BF16X3) return false;
+    if (!m->restore || !bf_mode(m)) return false;
     UadConvDesc d = m->dec.back().d; d.N = n;
     return uad_conv_f_supports_final_bwd(d, true, m->ws.floats);
 }
@@ -607,6 +615,8 @@ static void pack_weights(uad_model* m, hipStream_t st, hipEvent_t head_done = nu
                 uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
             else
                 uad_launch_pack_weights(m->params, m->wpack_f, m->wpack_d, offs, cbs, css, taps, np, st);
+            if (m->math == UAD_MATH_BF16X6)
+                uad_launch_pack_weights_bf16_3p(m->params, (unsigned short*)m->wpack3_f, (unsigned short*)m->wpack3_d, offs, cbs, css, taps, np, st);
         }
         np = 0;
     };
@@ -756,7 +766,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         PROF(kEncF[i & 7]);
         UadConvDesc d = m->enc[i].d; d.N = n;
         uad_launch_conv_f(d, m->enc[i - 1].c, bn_xform(m, m->enc[i - 1].gamma, m->enc[i - 1].beta, kLrelu),
-                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, PKF(m, m->enc[i].w), m->ws, PK16F(m, m->enc[i].w), PLANE(m->enc[i]));
+                          P(m, m->enc[i].w), m->enc[i].c, epi_bias(P(m, m->enc[i].b)), st, PKF(m, m->enc[i].w), m->ws, PK16F(m, m->enc[i].w), PLANE(m->enc[i]), false, planes_of(m));
     }
     if (wait_full) { (void)hipStreamWaitEvent(st, m->ev_pack, 0); wait_full = false; }
     const ConvLayer& EL = m->enc.back();
@@ -805,7 +815,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
                                : bn_xform(m, m->dec[i - 1].gamma, m->dec[i - 1].beta, kLrelu);
         UadEpilogue ep = epi_bias(P(m, m->dec[i].b));
         float* out = m->dec[i].c;
-        const bool bfm = m->math == UAD_MATH_BF16X3;
+        const bool bfm = bf_mode(m);
         if (i + 1 == m->dec.size() && (bfm ? uad_conv_d_can_fuse_final(d, true, m->ws.floats) : uad_conv_d_can_fuse_final_f32(d, m->math == UAD_MATH_F32, m->ws.floats)) &&
             (d.HS / 8) * (d.WS / 16) == bps) {
             // last block: its BN + LeakyReLU, the final 1x1 conv, the L1 loss and (training) the loss gradient run in the
@@ -840,7 +850,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
             }
             out = (restore_bwd && !restore_bits) ? DL.c : nullptr;
         }
-        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), out, ep, st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]));
+        uad_launch_conv_d(d, in, xf, P(m, m->dec[i].w), out, ep, st, PKD(m, m->dec[i].w), m->ws, PK16D(m, m->dec[i].w), PLANE(m->dec[i]), false, planes_of(m));
     }
     // final 1x1 conv + L1 loss (+ start of the backward)
     UadFinalArgs fa;
@@ -913,7 +923,7 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
 // waiting for SIDE, so the caller (Adam, or the DP all-reduce of that gradient segment) sees complete gradients.
 // Scratch touched by SIDE is per layer (column partials, split-K slabs), so MAIN never overwrites what SIDE still reads.
 // counters the split launches of this handle may use for the in-kernel reduction (split-bf16 mode only: the fp32 kernels have no such path)
-static int sk_counters(const uad_model* m) { return (m->math == UAD_MATH_BF16X3 && m->ws.counters) ? m->ws.ncounters : 0; }
+static int sk_counters(const uad_model* m) { return (bf_mode(m) && m->ws.counters) ? m->ws.ncounters : 0; }
 static hipEvent_t next_event(uad_model* m) {
     if (m->ev_next == m->sync_events.size()) {
         hipEvent_t e;
@@ -945,7 +955,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
     const int n = m->last_n;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
     hipStream_t sd = m->side;
-    const bool bf = m->math == UAD_MATH_BF16X3;
+    const bool bf = bf_mode(m);
     const ConvLayer& DL = m->dec.back();
     const int C = DL.d.CB;
     const int bps = uad_final_blocks_per_sample(m->cfg.height, m->cfg.width);
@@ -972,7 +982,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
         { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr;
           if (anyo && pg && bf && last && m->fwd_tail_is_loss && !m->prof_on) uad_conv_w_any_order_next(true);
           m->fwd_tail_is_loss = false; }
-        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, nullptr, nullptr, false, true); }
+        if (pg) { PROF(kDecW[i & 7]); uad_launch_conv_w(d, g, fbb ? gbits : no_xform(), in, bn_xform(m, ig, ib, ia), Gr(m, m->dec[i].w), m->wp_slot[i], st, bf, nullptr, nullptr, false, true, planes_of(m)); }
         uad_conv_w_any_order_next(false);
         // data gradient (F-type on the ConvT kernel) fused with the producer's activation backward
         { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg) uad_conv_any_order_next(true); }
@@ -980,7 +990,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
           const bool fb = m->restore && m->fb_on_load && last;
           UadXform gx = fbb ? gbits : no_xform();
           if (fb) { gx = bn_xform(m, DL.gamma, DL.beta, kLrelu); gx.fb_dxhat = m->gm_dxhat; gx.fb_wf = P(m, m->fw); }
-          uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i]));
+          uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i]), false, planes_of(m));
           uad_conv_any_order_next(false); }    // (a launch that did not take a spatial kernel must not leave the request to a later one)
         edge(m, st, sd);   // ONE edge per layer: its filter-gradient slabs and column partials are ready
         if (pg && last) {
@@ -990,7 +1000,7 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
             uad_launch_reduce_partials(m->red_partial, T, L, 1.0f, m->colscratch, sd);
             uad_launch_final_gradfin(m->colscratch, C, P(m, DL.gamma), rstd, Gr(m, m->fw), Gr(m, m->fb), Gr(m, DL.gamma), Gr(m, DL.beta), Gr(m, DL.b), sd);
         }
-        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd, bf); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats, sk_counters(m)), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
+        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->dec[i].w), m->wp_slot[i], sd, bf); uad_launch_bn_grad_finalize(cp, uad_conv_f_tiles(d, true, m->ws.floats, sk_counters(m), planes_of(m)), d.CS, P(m, ig), rstd, Gr(m, ig), Gr(m, ib), ibias >= 0 ? Gr(m, ibias) : nullptr, sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
     }
     m->G0 = g; m->G1 = gn;   // G0 = d loss / d cb (pre-BN output of Bottleneck/conv2d_1)
@@ -1179,7 +1189,7 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part, bool defer =
     const int n = m->last_n;
     const float rstd = 1.0f / sqrtf(1.0f + kBnEps);
     hipStream_t sd = m->side;
-    const bool bf = m->math == UAD_MATH_BF16X3;
+    const bool bf = bf_mode(m);
     const bool pg = !m->data_only;
     float* g = m->G0;
     float* gn = m->G1;
@@ -1191,14 +1201,14 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part, bool defer =
         UadConvDesc d = m->enc[i].d; d.N = n;
         const ConvLayer& PL = m->enc[i - 1];
         float* cp = m->cp_slot[8 + (i & 7)];
-        if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true); }
+        if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true, planes_of(m)); }
         { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg) uad_conv_any_order_next(true); }
         { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
-          uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i]));
+          uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i]), false, planes_of(m));
           uad_conv_any_order_next(false); }
         edge(m, st, sd);
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd, bf);
-                  uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats, sk_counters(m)), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
+                  uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats, sk_counters(m), planes_of(m)), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
     }
@@ -1477,7 +1487,12 @@ int uad_restore_step(uad_model_t* m, float* x_restored, const float* eps_w, cons
 }
 
 int uad_set_math_mode(uad_model_t* m, int mode) {
-    if (!m || (mode != UAD_MATH_F32 && mode != UAD_MATH_BF16X3)) return fail(UAD_ERR_INVALID, "bad math mode");
+    if (!m || (mode != UAD_MATH_F32 && mode != UAD_MATH_BF16X3 && mode != UAD_MATH_BF16X6)) return fail(UAD_ERR_INVALID, "bad math mode");
+    if (mode == UAD_MATH_BF16X6 && !m->wpack3_f) {      // three bf16 planes of the 5x5 kernels (4 ushorts per parameter: uad_launch_pack_weights_bf16_3p)
+        int rc = dev_alloc(m, &m->wpack3_f, (size_t)m->nparams * 2);      // (floats: 8 bytes per parameter; freed with the handle's other buffers)
+        if (rc == UAD_OK) rc = dev_alloc(m, &m->wpack3_d, (size_t)m->nparams * 2);
+        if (rc != UAD_OK) return rc;
+    }
     m->math = mode;
     invalidate_pack(m);
     return UAD_OK;

@@ -460,8 +460,9 @@ class Engine(_EvalOps):
         return torch.as_tensor(_DevArray(ptr.value, cnt.value), device=self.device)
 
     def set_math(self, math):
-        """'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 on the bf16 matrix cores, ~2^-17 relative product error)."""
-        modes = {'f32': _lib.MATH_F32, 'bf16x3': _lib.MATH_BF16X3}
+        """'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 on the bf16 matrix cores, ~2^-17 relative product error) or 'bf16x6' (three bf16 planes per
+        operand, six products: fp32-grade results -- tests hold 1e-5 against the fp64 oracle -- at 3/8 of the fp32 MFMA's matrix-pipe time)."""
+        modes = {'f32': _lib.MATH_F32, 'bf16x3': _lib.MATH_BF16X3, 'bf16x6': _lib.MATH_BF16X6}
         if math not in modes:
             raise ValueError(f'unknown math mode {math!r}')
         _lib.check(self.lib.uad_set_math_mode(self.handle, modes[math]))
