@@ -173,15 +173,21 @@ def last_block_kernel(tag, nblocks, math='bf16x3'):
 
 
 def evidence_for(workload, kernel_substr, flop, peak):
-    """(traffic, rocprof) objects of a roofline line from profiles/r05_evidence_<workload>.json (tools/evidence.py: PMC FETCH_SIZE / WRITE_SIZE passes and the
+    """(traffic, rocprof) objects of a roofline line from profiles/r06_evidence_<workload>.json (r05_ as fallback) (tools/evidence.py: PMC FETCH_SIZE / WRITE_SIZE passes and the
     rocprofv3 --kernel-trace --stats summary of the SAME bench command), for the kernel whose name contains kernel_substr; (None, None) when absent."""
     if not kernel_substr:
         return None, None
-    try:
-        doc = json.load(open(os.path.join(ROOT, 'profiles', f'r05_evidence_{workload}.json')))
-    except Exception:
+    doc = fname = None
+    for rnd in ('r06', 'r05'):
+        try:
+            fname = f'{rnd}_evidence_{workload}.json'
+            doc = json.load(open(os.path.join(ROOT, 'profiles', fname)))
+            break
+        except Exception:
+            doc = None
+    if doc is None:
         return None, None
-    src = (f"profiles/r05_evidence_{workload}.json: `{doc.get('_command')}` under rocprofv3 at commit {doc.get('_commit')}; not re-measured in this run "
+    src = (f"profiles/{fname}: `{doc.get('_command')}` under rocprofv3 at commit {doc.get('_commit')}; not re-measured in this run "
            "(PMC counters need the profiler)")
     traffic = rocprof = None
     rows = [r for r in doc.get('traffic', []) if kernel_substr in r['name']]
@@ -771,22 +777,32 @@ def bench_fanogan(args):
                     ain = top['N'] * top['MH'] * top['MW'] * (top['p1'] ** 2 * top['CA'] + top['Nn']) * 4
                     aout = 9 * top['CA'] * top['Nn'] * 4
                 abytes = ain + aout + 9 * top['CA'] * top['Nn'] * 2 * top['planes'] * (1 if top['kind'] == 0 else 0)
-                # HBM bytes per launch of that (kernel, grid) from the committed rocprofv3 PMC passes of this command (tools/r4_gpu12.sh)
-                traffic = None
+                # HBM bytes per launch of that (kernel, grid) and the profiler's own average duration, from the committed rocprofv3 passes of THIS command
+                # (tools/final_round6.sh -> profiles/r06_evidence_fanogan_resnet64.json, tools/evidence.py format)
+                traffic = rocprof = None
                 try:
-                    tdoc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_traffic_fanogan_resnet64.json')))
+                    tdoc = json.load(open(os.path.join(ROOT, 'profiles', 'r06_evidence_fanogan_resnet64.json')))
+                    srcs = (f"profiles/r06_evidence_fanogan_resnet64.json: `{tdoc.get('_command')}` under rocprofv3 at commit {tdoc.get('_commit')}; not re-measured in this run")
                     if top['kind'] == 0:
                         kn = f"convk16_kernel<8, 8, 32, 2, 2, {top['p1']}, {top['p2']}, {top['ntaps']}, {top['planes']},"
                         gt = str((top['MH'] // 8) * (top['MW'] // 8) * top['N'] * (top['Nn'] // 64) * 256)
-                        for row in tdoc['rows']:
-                            if row['kernel'].startswith(kn) and row['grid_threads'] == gt and row['write_bytes'] is not None:
-                                traffic = {'bytes': int(row['fetch_bytes'] + row['write_bytes']), 'fetch_bytes': int(row['fetch_bytes']), 'write_bytes': int(row['write_bytes']),
-                                           'source': f"profiles/r04_traffic_fanogan_resnet64.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH x2 gfx950 "
-                                                     f"correction), commit {tdoc.get('_commit')}; not re-measured in this run.  Above the algorithmic bytes: every 64-channel output "
-                                                     "block of a tile is its own workgroup and re-reads the input tile (8 blocks at 512 channels) and its weight slice"}
-                                break
+                    else:
+                        kn, gt = f"convk_w16_kernel<{top['p1']}, {top['p2']}>", None
+                    trows = [r for r in tdoc.get('traffic', []) if kn in r['name'] and (gt is None or str(r['grid']) == gt)]
+                    if trows:
+                        r = max(trows, key=lambda r: r['fetch_bytes'] + r['write_bytes'])
+                        traffic = {'bytes': int(r['fetch_bytes'] + r['write_bytes']), 'fetch_bytes': int(r['fetch_bytes']), 'write_bytes': int(r['write_bytes']),
+                                   'launches_averaged': r['launches'],
+                                   'source': srcs + '; --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 (gfx950 correction).  Above the algorithmic bytes: every 64-channel output '
+                                             'block of a tile is its own workgroup and re-reads the input tile (8 blocks at 512 channels) and its weight slice'}
+                    srows = [r for r in tdoc.get('stats', []) if kn in r['name']]
+                    if srows:
+                        r = max(srows, key=lambda r: r['total_ns'])
+                        rocprof = {'avg_launch_ms_all_shapes': round(r['avg_ns'] * 1e-6, 4), 'calls': r['calls'],
+                                   'source': srcs + '; --kernel-trace --stats (the summary row of a kernel template averages all its launch shapes: the per-shape time is the '
+                                             'HIP-event figure above)'}
                 except Exception:
-                    traffic = None
+                    traffic = rocprof = None
                 res['roofline'] = {'bound': 'mfma', 'kernel': name,
                                    'shape': {k: top[k] for k in ('N', 'MH', 'MW', 'CA', 'Nn', 'ntaps', 'planes')},
                                    'achieved': round(ach, 2), 'peak': round(pk, 1), 'unit': 'TFLOP/s', 'frac': round(ach / pk, 4),
@@ -795,8 +811,7 @@ def bench_fanogan(args):
                                    'launches_timed': top['calls'], 'group_share_of_k3_time': round(sum(r['total_ms'] for r in grp) / sum(r['total_ms'] for r in rows), 3),
                                    'instruction': f"{3 if top['planes'] == 2 else 6} x v_mfma_f32_32x32x16_bf16 per fp32 product; peak = dense bf16 MFMA 2500 TFLOP/s / products",
                                    'traffic': traffic,
-                                   'rocprof': 'profiles/r04_z_fanogan_resnet64_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command; the summary row of this kernel '
-                                              'template averages all its launch shapes)',
+                                   'rocprof': rocprof,
                                    'whole_iteration': whole}
                 res['k3_kernels'] = sorted(({'kind': 'FD' if r['kind'] == 0 else 'W', 'stride': r['p1'], 'ntaps': r['ntaps'], 'planes': r['planes'],
                                              'N': r['N'], 'grid': [r['MH'], r['MW']], 'CA': r['CA'], 'Nn': r['Nn'], 'calls': r['calls'],
@@ -967,7 +982,7 @@ def main():
         traffic = None
         # the committed PMC passes and rocprofv3 summaries are of the DEFAULT command (VAE, 64 slices per launch): other workloads of this function carry none
         evidence_applies = (not cevae) and args.arch == 'VAE' and BATCH == 64
-        for cand in (f'r05_traffic_{math}.json', f'r04_traffic_{math}.json', f'r03_traffic_{math}.json', f'r02_traffic_{math}.json', f'r01_traffic_{math}.json') if evidence_applies else ():
+        for cand in (f'r06_traffic_{math}.json', f'r05_traffic_{math}.json', f'r04_traffic_{math}.json', f'r03_traffic_{math}.json', f'r02_traffic_{math}.json', f'r01_traffic_{math}.json') if evidence_applies else ():
             try:
                 doc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
                 tr = doc.get(dom)
@@ -985,7 +1000,8 @@ def main():
         # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command in this math mode (the
         # profiler's clock instead of HIP events around the launch group), with the commit it was taken at
         rocprof = None
-        for tj, ks in ((f'r05_traffic_{math}.json', 'r05_z_kernel_stats.csv' if math != 'f32' else 'r05_z_kernel_stats_f32.csv'),
+        for tj, ks in ((f'r06_traffic_{math}.json', {'f32': 'r06_z_kernel_stats_f32.csv', 'bf16x6': 'r06_z_kernel_stats_bf16x6.csv'}.get(math, 'r06_z_kernel_stats.csv')),
+                       (f'r05_traffic_{math}.json', 'r05_z_kernel_stats.csv' if math != 'f32' else 'r05_z_kernel_stats_f32.csv'),
                        (f'r04_traffic_{math}.json', 'r04_z_kernel_stats.csv' if math != 'f32' else 'r04_z_kernel_stats_f32.csv'),
                        ('r03_traffic_bf16x3.json', 'r03_z_kernel_stats.csv') if math != 'f32' else (None, None)):
             if rocprof is not None or tj is None or not evidence_applies:

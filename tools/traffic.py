@@ -48,7 +48,17 @@ TAGS = {
     'dec3.wgrad': ('conv5_w_bf16_tr_kernel<1, true', 512 * 256),       # round 4: the transpose-read kernel
     'enc1.wgrad': ('conv5_w_bf16_tr_kernel<2, false', 256 * 512),
     'final.fwd+bwd': ('final_kernel<true>', 32 * 64 * 256),
-} if MATH != 'f32' else {
+} if MATH == 'bf16x3' else {
+    # bf16x6 (round 6): the same three families with three planes per operand; the 64-column F-kind instance walks 16-channel chunks
+    'dec3.fwd': ('conv5_d16s_kernel<8, 16, 32, 4, 1, 1, 2', 32 * 64 * 256),
+    'dec2.fwd': ('conv5_d16s_kernel<8, 16, 64, 4, 1, 1, 0', 8 * 64 * 256),
+    'enc1.dgrad': ('conv5_d16s_kernel<8, 16, 64, 4, 1, 1, 1', 8 * 64 * 256),
+    'dec3.dgrad': ('conv5_f16_kernel<8, 16, 16, 4, 1', 32 * 64 * 256),
+    'dec2.dgrad': ('conv5_f16_kernel<8, 8, 16, 2, 2', 16 * 64 * 256),
+    'enc1.fwd': ('conv5_f16_kernel<8, 8, 16, 2, 2', 16 * 64 * 256),
+    'dec3.wgrad': ('conv5_w_bf16_tr_kernel<1, true', 512 * 256),
+    'enc1.wgrad': ('conv5_w_bf16_tr_kernel<2, false', 256 * 512),
+} if MATH == 'bf16x6' else {
     # exact-fp32 mode (v_mfma_f32_32x32x2_f32 kernels)
     'dec3.fwd': ('conv5_d_kernel<8, 16, 32, 4, 1, true', 32 * 64 * 256),       # round 4: the instance with the fused final epilogue
     'dec3.dgrad': ('conv5_f_kernel<8, 16, 16, 4, 1', 32 * 64 * 256),

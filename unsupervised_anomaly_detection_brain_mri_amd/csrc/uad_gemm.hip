@@ -1903,6 +1903,7 @@ __global__ void pack_weights_bf16_3p_kernel(const float* __restrict__ W, unsigne
 // The same packing, one 16-byte group of a packed layout per thread (blockIdx.y: 0 = the F layout, 8 consecutive cb of one (tap, cs); 1 = the D
 // layout, 8 consecutive cs of one (tap, cb)): coalesced 16-byte stores instead of four scattered 2-byte stores per element (the repack runs on the
 // side stream behind the optimizer step; at 20 us it outlasted the main-stream work before the first packed-weight consumer).  Same bits.
+template <int NPL>      // 2: hi | lo planes at ushort index 2 * off (bf16x3); 3: h | m | l at 4 * off (bf16x6; round 6 -- the per-element 3p kernel was 4.5 % of a configs[3] iteration)
 __global__ void __launch_bounds__(256) pack_weights_bf16_v8_kernel(const float* __restrict__ W, unsigned short* __restrict__ Wf, unsigned short* __restrict__ Wd, PackDesc pd) {
     long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // group index inside the tensor list
     int t = 0;
@@ -1928,18 +1929,21 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_v8_kernel(const float* 
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         dst = ((size_t)(tap * (CS / 8) + cs8) * CB + cb) * 8;
     }
-    unsigned hi[8], lo[8];
+    unsigned pl[NPL][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        hi[e] = bf16_rne_bits(v[e]);
-        lo[e] = bf16_rne_bits(v[e] - __uint_as_float(hi[e] << 16));
+        float r = v[e];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {      // same arithmetic as the per-element kernels: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
+            pl[q][e] = bf16_rne_bits(r);
+            r -= __uint_as_float(pl[q][e] << 16);
+        }
     }
-    const uint4 h4 = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-    const uint4 l4 = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
     unsigned short* out = blockIdx.y == 0 ? Wf : Wd;
-    const size_t base = 2 * (size_t)pd.off[t], cnt = (size_t)pd.count[t];
-    *reinterpret_cast<uint4*>(out + base + dst) = h4;
-    *reinterpret_cast<uint4*>(out + base + cnt + dst) = l4;
+    const size_t base = (NPL == 3 ? 4 : 2) * (size_t)pd.off[t], cnt = (size_t)pd.count[t];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q)
+        *reinterpret_cast<uint4*>(out + base + q * cnt + dst) = make_uint4(pl[q][0] | (pl[q][1] << 16), pl[q][2] | (pl[q][3] << 16), pl[q][4] | (pl[q][5] << 16), pl[q][6] | (pl[q][7] << 16));
 }
 
 struct SpatialChoice { bool ok; int TH, TW, BN, CK; };
@@ -2801,7 +2805,10 @@ void uad_launch_pack_weights_bf16_3p(const float* params, unsigned short* w3_f, 
     pd.n = n;
     long long total = 0;
     for (int i = 0; i < n; ++i) { pd.off[i] = offs[i]; pd.cb[i] = cbs[i]; pd.cs[i] = css[i]; pd.count[i] = taps[i] * cbs[i] * css[i]; total += pd.count[i]; }
-    hipLaunchKernelGGL(pack_weights_bf16_3p_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w3_f, w3_d, pd);
+    bool v8 = ((((uintptr_t)params | (uintptr_t)w3_f | (uintptr_t)w3_d) & 15) == 0);
+    for (int i = 0; i < n; ++i) v8 = v8 && pd.off[i] % 4 == 0 && pd.count[i] % 8 == 0 && pd.cb[i] % 8 == 0 && pd.cs[i] % 8 == 0;      // 16-byte aligned float4 reads and groups (planes at 8 * off + 2 q count bytes)
+    if (v8) hipLaunchKernelGGL(pack_weights_bf16_v8_kernel<3>, dim3((unsigned)((total / 8 + 255) / 256), 2), dim3(256), 0, st, params, w3_f, w3_d, pd);
+    else hipLaunchKernelGGL(pack_weights_bf16_3p_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w3_f, w3_d, pd);
 }
 
 namespace {
@@ -2882,7 +2889,7 @@ void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, un
     }
     bool v8 = ((((uintptr_t)params | (uintptr_t)w16_f | (uintptr_t)w16_d) & 15) == 0);
     for (int i = 0; i < n; ++i) v8 = v8 && pd.off[i] % 4 == 0 && pd.cb[i] % 8 == 0 && pd.cs[i] % 8 == 0;
-    if (v8) hipLaunchKernelGGL(pack_weights_bf16_v8_kernel, dim3((unsigned)((total / 8 + 255) / 256), 2), dim3(256), 0, st, params, w16_f, w16_d, pd);
+    if (v8) hipLaunchKernelGGL(pack_weights_bf16_v8_kernel<2>, dim3((unsigned)((total / 8 + 255) / 256), 2), dim3(256), 0, st, params, w16_f, w16_d, pd);
     else hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w16_f, w16_d, pd);
 }
 
