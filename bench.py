@@ -644,9 +644,14 @@ def bench_fanogan(args):
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    nccl1 = os.environ.get('UAD_BENCH_REHEARSAL') == 'nccl1' and world == 1      # the N > 1 code path (library-issued bucketed all-reduce) on ONE rank under RCCL
+    if world > 1 or nccl1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo', rank=rank, world_size=world) if rehearsal else dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if nccl1:
+            os.environ.setdefault('MASTER_PORT', '29613')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world) if rehearsal else dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     hh, bs, zd = args.size or (128 if args.variant == 'anovaegan' else 64), BATCH, 128
     eng = GanEngine(hh, hh, 1, hh // 8 if args.variant == 'resnet' else 8, zd, max_batch=bs, device=f'cuda:{local_rank}', math=args.math,
                     variant=args.variant)
@@ -663,7 +668,7 @@ def bench_fanogan(args):
         elif name.endswith('gamma'):
             flat[off:off + cnt] = 1.0
     eng.set_params(flat)
-    dp = GanDataParallel(eng, world)
+    dp = GanDataParallel(eng, world, library_allreduce=True, force_collectives=True) if nccl1 else GanDataParallel(eng, world)
     dp.broadcast_params(0)
     x = torch.from_numpy(synthetic_slices(bs, hh, hh, seed=1000 + rank)).cuda()
     g = torch.Generator(device='cuda').manual_seed(1 + rank)
@@ -715,6 +720,17 @@ def bench_fanogan(args):
     assert bool(torch.isfinite(out['disc_loss']))
     dt_e, out_e = timed(enc_step, args.steps, max(args.warmup, 1))
     assert bool(torch.isfinite(out_e['enc_loss']))
+    ar_rehearsal = None
+    if nccl1:
+        # the same iterations WITHOUT the collectives (plain phases): the one-rank price of the data-parallel path (bucket events, the collective stream, RCCL's
+        # own launches of a one-rank all-reduce)
+        in_phase = dp.in_phase
+        dp.close()
+        dp = GanDataParallel(eng, 1, library_allreduce=False)
+        dt_p, _ = timed(wgan_step, args.steps, 1)
+        ar_rehearsal = {'backend': 'nccl (RCCL, one rank: code-path rehearsal)', 'library_issued_in_phase': bool(in_phase),
+                        'ms_per_step_data_parallel_path': round(dt / args.steps * 1e3, 3), 'ms_per_step_plain': round(dt_p / args.steps * 1e3, 3),
+                        'ratio': round(dt / dt_p, 4), 'buckets_per_phase': 'up to 4, on tensor boundaries, issued per residual block (uad_gan_allreduce_attach)'}
     if rank == 0:
         value = bs * world * args.steps / dt
         name = 'AnoVAE-GAN batch iteration (1 VAE + 1 G + 5 D steps' if av else f'f-AnoGAN ({args.variant}) WGAN-GP batch iteration (1 G + 5 D steps'
@@ -729,6 +745,8 @@ def bench_fanogan(args):
                                       f'{bs} slices per GPU; step = ' + ('1 VAE + 1 generator + 5 critic phases with Adam (trainers/AnoVAEGAN.py:97-150)' if av else '1 generator + 5 critic phases with Adam (trainers/fAnoGAN.py:97-130)'),
                           'encoder_stage_ms_per_step': round(dt_e / args.steps * 1e3, 3),
                           'encoder_stage_slices_per_s': round(bs * world * args.steps / dt_e, 2), 'parallelism': f'dp{world}'}}
+        if ar_rehearsal:
+            res['allreduce'] = ar_rehearsal
         e_m, g_m, d_m = gan_macs('unified' if av else args.variant, hh, zd)
         # per WGAN iteration and sample: G step = G fwd + bwd (3 passes) + critic fwd + data gradient; each of the 5 critic steps =
         # G fwd + critic fwd of 3 samples, input gradient, its adjoint, data gradient of 3 and filter gradients of 4 sample-slots

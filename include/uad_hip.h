@@ -387,6 +387,14 @@ int uad_gan_set_step(uad_gan_t* g, int group, long long t);
 /* phase = the variable group being trained: GENERATOR (gen_loss), DISCRIMINATOR (disc_loss incl. penalty), ENCODER (enc_loss) */
 int uad_gan_phase(uad_gan_t* g, int phase, const uad_gan_io_t* io, int n, int want_backward, void* stream);
 int uad_gan_adam(uad_gan_t* g, int group, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* Data parallelism of the GAN handles, library-issued (round 6; the reference is single-process: trainers/fAnoGAN.py:70-77,96-129 run one sess.run per phase).
+ * With a communicator attached (uad_rccl_comm_create) uad_gan_phase(..., want_backward = 1) all-reduces the TRAINED group's gradient slice itself: the slice is
+ * cut into up to four buckets on tensor boundaries and a bucket's ncclAllReduce is enqueued on a collective stream as soon as the last kernel that writes one of
+ * its tensors is enqueued -- i.e. while the backward of the earlier layers still runs (ResNet graph: per residual block; the other f-AnoGAN graphs: at the end
+ * of the phase) -- and the phase's stream waits for the last bucket before the call returns to the caller, whose next launch is uad_gan_adam with
+ * grad_scale = 1 / world.  comm == NULL detaches.  AAE-family handles (aae_kind != 0): UAD_ERR_UNSUPPORTED -- the caller all-reduces the slice with
+ * uad_rccl_allreduce as before. */
+int uad_gan_allreduce_attach(uad_gan_t* g, void* comm, int world);
 int uad_gan_reconstruct(uad_gan_t* g, const uad_gan_io_t* io, int n, void* stream);
 /* dense GMVAE restoration (trainers/GMVAE.py:172-184): one `sess.run(grads)` + the host update, on device.  grads = d( n * loss +
  * sum_n tv_lambda * TV_n(x - xz_mu) ) / d x at the current x_restored (= io->x is ignored; tf.gradients sums the [n]-shaped `loss + restore`,

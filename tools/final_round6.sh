@@ -69,6 +69,7 @@ fi
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
 rm -rf $OUT/stats_* $OUT/fetch_* $OUT/write_* $OUT/sq_insts $OUT/sq_cycles 2>/dev/null
 cd $REPO
+[ "${NO_BENCH:-0}" = "1" ] && { ls $OUT; head -12 $OUT/pmc_sq_insts.csv 2>/dev/null; head -30 $OUT/fanogan_resnet64_kernel_stats.csv 2>/dev/null | cut -c1-200; exit 0; }
 # ---- the bench lines (they read the files written above)
 timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 300 python bench.py --arch ceVAE --no-cpu-baseline > $OUT/bench_cevae_b16.json 2> $OUT/bench_cevae.err

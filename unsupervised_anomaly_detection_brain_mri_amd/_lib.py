@@ -137,6 +137,7 @@ SYMBOLS = {
     'uad_gan_set_step': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong]),
     'uad_gan_phase': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(UadGanIO), C.c_int, C.c_int, C.c_void_p]),
     'uad_gan_adam': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'uad_gan_allreduce_attach': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     'uad_gan_reconstruct': (C.c_int, [C.c_void_p, C.POINTER(UadGanIO), C.c_int, C.c_void_p]),
     'uad_gan_restore_step': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(UadGanIO), C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     'uad_debug_buffer': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -68,6 +69,15 @@ struct uad_gan {
     float *wpack3_f, *wpack3_d;        // ResNet graph: THREE bf16 planes of the k3 kernels (bf16x6 products of the exact passes), 4 * nparams ushorts each; null: fp32 kernels
     int math;
     bool packed_valid;
+    // library-issued, bucketed gradient all-reduce of a phase's trained group (uad_gan_allreduce_attach, round 6): the group's tensors are cut into up to four
+    // contiguous buckets; a bucket's ncclAllReduce is enqueued on ar_stream as soon as the LAST kernel that writes one of its tensors is enqueued
+    // (gan_grad_final marks a tensor; the pending count of its bucket reaching zero issues it), i.e. while the backward of the earlier layers still runs
+    void* ar_comm; int ar_world;
+    hipStream_t ar_stream; hipEvent_t ar_ev_in[4], ar_ev_out;
+    struct ArBucket { long long off, cnt; int pending; bool issued; } ar_b[4];
+    int ar_nb; bool ar_active; hipStream_t ar_st;
+    std::vector<std::pair<long long, int>> ar_tb;      // (tensor offset, bucket) of the trained group's tensors, and whether it was marked
+    std::vector<char> ar_marked;
     bool pack_all; long long dirty_lo, dirty_hi;      // which parameters changed since the last pack: everything, or [dirty_lo, dirty_hi) (an optimizer step touches ONE group)
     UadGemmWs ws;
     std::vector<Block> E, G, D;
@@ -152,6 +162,70 @@ namespace {
 
 float* P(uad_gan* m, long long off) { return m->params + off; }
 float* Gr(uad_gan* m, long long off) { return m->grads + off; }
+
+// ---- bucketed all-reduce of the trained group's gradients (data parallelism, library-issued RCCL) --------------------------------------------
+static void gan_ar_issue(uad_gan* m, int b) {
+    uad_gan::ArBucket& B = m->ar_b[b];
+    if (B.issued || B.cnt == 0) { B.issued = true; return; }
+    B.issued = true;
+    (void)hipEventRecord(m->ar_ev_in[b], m->ar_st);                 // behind the kernels that wrote the bucket's tensors ...
+    (void)hipStreamWaitEvent(m->ar_stream, m->ar_ev_in[b], 0);
+    static const bool skip = getenv("UAD_AR_SKIP") != nullptr;      // measurement: everything but the collective itself
+    if (!skip) (void)uad_rccl_allreduce(m->ar_comm, m->grads + B.off, B.cnt, m->ar_stream);      // ... on the collective stream: the phase's stream runs on
+}
+// phase start: buckets over the tensors inside [off, off + cnt), by cumulative size, on tensor boundaries, in offset order
+static void gan_ar_begin(uad_gan* m, long long off, long long cnt, hipStream_t st) {
+    m->ar_active = false;
+    if (!m->ar_comm || cnt <= 0) return;
+    std::vector<const Tensor*> ts;
+    for (const Tensor& t : m->tensors) if (t.off >= off && t.off + t.count() <= off + cnt) ts.push_back(&t);
+    std::sort(ts.begin(), ts.end(), [](const Tensor* a, const Tensor* b) { return a->off < b->off; });
+    constexpr int K = 4;
+    m->ar_nb = K; m->ar_tb.clear(); m->ar_marked.assign(ts.size(), 0);
+    for (int b = 0; b < K; ++b) m->ar_b[b] = {0, 0, 0, false};
+    long long cum = 0;
+    for (const Tensor* t : ts) {
+        int b = (int)((cum + t->count() / 2) * K / cnt);
+        if (b >= K) b = K - 1;
+        cum += t->count();
+        uad_gan::ArBucket& B = m->ar_b[b];
+        if (B.pending == 0) B.off = t->off;
+        B.cnt = t->off + t->count() - B.off;
+        B.pending += 1;
+        m->ar_tb.push_back({t->off, b});
+    }
+    // the buckets must tile the slice (gaps between tensors would go unreduced): stretch each bucket to its successor / the slice's ends
+    int prev = -1;
+    for (int b = 0; b < K; ++b) {
+        if (m->ar_b[b].pending == 0) continue;
+        if (prev < 0) { m->ar_b[b].cnt += m->ar_b[b].off - off; m->ar_b[b].off = off; }
+        else m->ar_b[prev].cnt = m->ar_b[b].off - m->ar_b[prev].off;
+        prev = b;
+    }
+    if (prev >= 0) m->ar_b[prev].cnt = off + cnt - m->ar_b[prev].off;
+    m->ar_st = st;
+    m->ar_active = prev >= 0;
+}
+// the kernels that write the gradient of the tensor at `off` are enqueued and nothing later in this phase writes it again
+void gan_grad_final(uad_gan* m, long long off) {
+    if (!m->ar_active || off < 0) return;
+    for (size_t i = 0; i < m->ar_tb.size(); ++i) {
+        if (m->ar_tb[i].first != off || m->ar_marked[i]) continue;
+        m->ar_marked[i] = 1;
+        uad_gan::ArBucket& B = m->ar_b[m->ar_tb[i].second];
+        if (--B.pending == 0) gan_ar_issue(m, m->ar_tb[i].second);
+        return;
+    }
+}
+// phase end: whatever was not marked (zero gradients that stay at their initialisation, graphs without hooks) goes now; the phase's stream -- the
+// optimizer step comes next on it -- waits for the collective stream once
+static void gan_ar_end(uad_gan* m) {
+    if (!m->ar_active) return;
+    for (int b = 0; b < m->ar_nb; ++b) if (!m->ar_b[b].issued) gan_ar_issue(m, b);
+    (void)hipEventRecord(m->ar_ev_out, m->ar_stream);
+    (void)hipStreamWaitEvent(m->ar_st, m->ar_ev_out, 0);
+    m->ar_active = false;
+}
 const float* PKF(uad_gan* m, long long off) { return m->math == UAD_MATH_F32 ? m->wpack_f + off : nullptr; }
 const float* PKD(uad_gan* m, long long off) { return m->math == UAD_MATH_F32 ? m->wpack_d + off : nullptr; }
 const unsigned short* PK16F(uad_gan* m, long long off) { return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_f + 2 * off : nullptr; }
@@ -950,6 +1024,7 @@ void rb_param_grads(uad_gan* m, RB& B, int M, int Nb, hipStream_t st) {
         hipMemcpyAsync(Gr(m, B.bs), Gr(m, B.b2), B.Cout * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
     // conv1's bias feeds a LayerNorm over (H, W): identically zero gradient (stays at its zero initialisation)
+    for (long long o : {B.ln2g, B.ln2b, B.ln1g, B.ln1b, B.w2, B.w1, B.b2, B.b1, B.ws, B.bs}) gan_grad_final(m, o);      // (data parallelism: this block's gradients are final)
 }
 // adjoint of the data-gradient map of a critic block on the x_hat third (pass C): reads the adjoint of d / d x from X's tail,
 // leaves the adjoint of d / d out in OUT's tail, the pass-C operands of the filter gradients in H1 / H2's tails, the injections
@@ -994,11 +1069,13 @@ void s_enc_backward(uad_gan* m, const float* x, int n, hipStream_t st) {
     const UadConvDesc dd = dense_desc(n, m->flat, zd);
     uad_launch_conv_w(dd, m->ea[m->E.size()], no_xform(), m->dzr, no_xform(), Gr(m, m->e_dw), m->wpartial, st);
     uad_launch_colsum(m->dzr, n, zd, Gr(m, m->e_db), m->colscratch, st);
+    gan_grad_final(m, m->e_dw); gan_grad_final(m, m->e_db);
     float* g = m->Ga; float* gn = m->Gb;
     uad_launch_conv_d(dd, m->dzr, no_xform(), P(m, m->e_dw), g, epi_bias(nullptr), st, nullptr, m->ws);
     for (int i = (int)m->E.size() - 1; i >= 0; --i) {
         bn_act_bwd(m, m->E[i], g, m->ec[i], n, gn, st);
         conv_wgrad(m, m->E[i], n, i == 0 ? x : m->ea[i], gn, st);
+        for (long long o : {m->E[i].w, m->E[i].b, m->E[i].gamma, m->E[i].beta}) gan_grad_final(m, o);
         if (i > 0) conv_dgrad(m, m->E[i], n, gn, g, st);
     }
 }
@@ -1029,7 +1106,10 @@ void s_gen_backward(uad_gan* m, const float* z, const float* dx, int n, bool pg,
     l.da = m->Ga; l.c = L.OUT; l.stats = m->s_stf; l.gamma = P(m, m->s_glg); l.beta = P(m, m->s_glb); l.alpha = 0.0f; l.HW = HW; l.C = L.Cout;
     l.dc = L.DOUT; l.gpart = pg ? m->lnpart_g : nullptr;
     ln_bwd(l, n, st);
-    if (pg) uad_launch_reduce_partials(m->lnpart_g, n * (L.Cout / 32), 2 * HW, 1.0f, Gr(m, m->s_glg), st);
+    if (pg) {
+        uad_launch_reduce_partials(m->lnpart_g, n * (L.Cout / 32), 2 * HW, 1.0f, Gr(m, m->s_glg), st);
+        for (long long o : {m->g_fw, m->g_fb, m->s_glg, m->s_glb}) gan_grad_final(m, o);
+    }
     RbBwd a{n, 0, 0, pg, 0, false, -1};
     for (int k = (int)m->GB.size() - 1; k >= 0; --k) rb_backward(m, m->GB[k], a, st);
     const int flatg = m->cfg.inter_res * m->cfg.inter_res * 8 * m->dim;
@@ -1037,6 +1117,7 @@ void s_gen_backward(uad_gan* m, const float* z, const float* dx, int n, bool pg,
     if (pg) {
         uad_launch_conv_w(dd, z, no_xform(), m->s_dg0, no_xform(), Gr(m, m->g_dw), m->wpartial, st);
         uad_launch_colsum(m->s_dg0, n, flatg, Gr(m, m->g_db), m->colscratch, st);
+        gan_grad_final(m, m->g_dw); gan_grad_final(m, m->g_db);
     }
     if (dz_out) uad_launch_conv_d(dd, m->s_dg0, no_xform(), P(m, m->g_dw), dz_out, epi_bias(nullptr), st, nullptr, m->ws);
 }
@@ -1058,6 +1139,7 @@ void s_disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float
         d0.N = N + ntail;
         uad_launch_conv_first_wgrad(d0, m->din, m->s_dout0, Gr(m, m->s_d0w), m->wpartial, st);
         uad_launch_colsum(m->s_dout0, N * d0.HS * d0.WS, d0.CS, Gr(m, m->s_d0b), m->colscratch, st);
+        gan_grad_final(m, m->s_d0w); gan_grad_final(m, m->s_d0b);
     }
     if (dx_out) { d0.N = N; uad_launch_conv_first_dgrad_plain(d0, m->s_dout0, P(m, m->s_d0w), dx_out, st); }
 }
@@ -1617,6 +1699,7 @@ static int gan_phase_body(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n
                 const int rows = 4 * n * P2, rpb = (rows + 255) / 256, blocks = (rows + rpb - 1) / rpb;
                 hipLaunchKernelGGL(coef_colsum_kernel, dim3(blocks), dim3(256), 0, st, feat, rows, rpb, n * P2, FC, cf, m->finpart);
                 uad_launch_reduce_partials(m->finpart, blocks, FC, 1.0f, Gr(m, m->d_hw), st);
+                gan_grad_final(m, m->d_hw);
                 // Dense(1) bias: +1/(nP) over the fake rows, -1/(nP) over the real rows = 0 (stays at its zero initialisation)
             }
             disc_bwd(3 * n, true, n, 2 * n, nullptr);
@@ -1702,7 +1785,36 @@ int uad_gan_restore_step(uad_gan_t* m, float* x_restored, const uad_gan_io_t* io
 
 int uad_gan_phase(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n, int want_backward, void* stream) {
     if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");
-    return gan_phase_body(m, phase, io, n, want_backward, stream);
+    if (m->ar_comm && want_backward && phase >= 0 && phase <= 2 && m->variant != UAD_GAN_AAE) {
+        // data parallelism, library-issued: the trained group's slice (AnoVAE-GAN's Encoder phase trains Encoder + Generator, one contiguous slice)
+        long long off = m->grp_off[phase], cnt = m->grp_cnt[phase];
+        if (m->variant == UAD_GAN_ANOVAEGAN && phase == UAD_GAN_ENCODER) { off = 0; cnt = m->grp_cnt[UAD_GAN_ENCODER] + m->grp_cnt[UAD_GAN_GENERATOR]; }
+        gan_ar_begin(m, off, cnt, (hipStream_t)stream);
+    }
+    const int rc = gan_phase_body(m, phase, io, n, want_backward, stream);
+    if (rc == UAD_OK) gan_ar_end(m); else m->ar_active = false;
+    return rc;
+}
+// Attaches an RCCL communicator (uad_rccl_comm_create) to the handle: from then on uad_gan_phase(..., want_backward) all-reduces the trained group's
+// gradient slice itself, in up to four buckets issued on a collective stream while the phase's backward still runs; the phase's stream waits for the last
+// one before it returns to the caller (whose next launch is uad_gan_adam with grad_scale = 1 / world).  comm = NULL detaches.  The AAE-family graphs have no
+// bucket hooks: UAD_ERR_UNSUPPORTED, the caller all-reduces their slice itself (uad_rccl_allreduce).
+int uad_gan_allreduce_attach(uad_gan_t* m, void* comm, int world) {
+    if (!m) return fail(UAD_ERR_INVALID, "null handle");
+    if (!comm) { m->ar_comm = nullptr; m->ar_world = 1; m->ar_active = false; return UAD_OK; }
+    if (world < 1) return fail(UAD_ERR_INVALID, "uad_gan_allreduce_attach: world %d", world);
+    if (m->variant == UAD_GAN_AAE) return fail(UAD_ERR_UNSUPPORTED, "uad_gan_allreduce_attach: the AAE-family phases are all-reduced by the caller");
+    if (!m->ar_stream) {
+        // HIGH-priority, non-blocking.  Measured on one rank under RCCL with GPU_MAX_HW_QUEUES=8 (the package's multi-process default): a normal-priority
+        // stream here made the WGAN iteration 1.62x the plain one (83 vs 51 ms) WITH OR WITHOUT the collectives being issued -- the extra stream's hardware
+        // queue, not RCCL; a blocking stream 2.2x; the high-priority stream 1.016x, as do 4-6 hardware queues (profiles/r06_e_gan_dp_one_rank.md).
+        { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIP_TRY(hipStreamCreateWithPriority(&m->ar_stream, hipStreamNonBlocking, hi)); }
+        for (int i = 0; i < 4; ++i)
+            if (hipEventCreateWithFlags(&m->ar_ev_in[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) HIP_TRY(hipEventCreateWithFlags(&m->ar_ev_in[i], hipEventDisableTiming));
+        if (hipEventCreateWithFlags(&m->ar_ev_out, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) HIP_TRY(hipEventCreateWithFlags(&m->ar_ev_out, hipEventDisableTiming));
+    }
+    m->ar_comm = comm; m->ar_world = world;
+    return UAD_OK;
 }
 int uad_gan_reconstruct(uad_gan_t* m, const uad_gan_io_t* io, int n, void* stream) {
     if (!m || !io) return fail(UAD_ERR_INVALID, "null argument");

@@ -344,6 +344,14 @@ class GanEngine(_EvalOps):
         self._keep = (x, z, alpha, mask_z, mask_g, scal, out, eps, mask_sigma)
         return out
 
+    def allreduce_attach(self, comm, world):
+        """uad_gan_allreduce_attach: comm = a parallel.RcclComm (None detaches).  From then on phase(..., want_backward=True) all-reduces the trained group's
+        gradient slice itself, in buckets issued while its backward still runs; adam(..., grad_scale=1 / world) follows on the same stream.
+        Raises for the AAE-family graphs (their caller all-reduces the slice)."""
+        import ctypes as C
+        _lib.check(self.lib.uad_gan_allreduce_attach(self.handle, C.c_void_p(comm.handle) if comm is not None else None, int(world)))
+        self._ar_comm = comm
+
     def adam(self, group, lr, beta1=0.5, beta2=0.9, eps=1e-8, grad_scale=1.0):
         """group: 'Encoder' | 'Generator' | 'Discriminator'; for the AAE family 'AE' (= optim_ae), 'Discriminator', 'Encoder' (= optim_gen)."""
         gid = _lib.GAN_GENERATOR if (self.variant == 'aae' and group == 'AE') else GROUPS[group]

@@ -255,7 +255,8 @@ class GanDataParallel:
     slice equals the big-batch gradient.  One all-reduce per phase, over that group's slice only (Encoder 1.2 M, Generator
     1.5 M, Discriminator 0.7 M floats at 128x128)."""
 
-    def __init__(self, engine, world=None, library_allreduce=None):
+    def __init__(self, engine, world=None, library_allreduce=None, comm=None, force_collectives=False):
+        """comm: a communicator the caller created (tests: a stand-in librccl); force_collectives: take the collective path at world 1 too."""
         self.eng = engine
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.grads = engine.buffer(_lib.BUF_GRADS) if self.world > 1 else None
@@ -264,28 +265,55 @@ class GanDataParallel:
         # (The phases of a WGAN iteration form a dependency chain -- every forward reads the parameters the previous phase's Adam wrote -- so there is
         # no later work the collective could legally overlap with; what the library path removes is the blocking host wait and the event hand-off.)
         want_lib = _library_allreduce_default() if library_allreduce is None else bool(library_allreduce)
-        self.comm = None
-        if want_lib and self.world > 1:
+        self.comm = comm
+        self._own_comm = False
+        self.in_phase = False          # True: uad_gan_phase all-reduces the trained group itself, in buckets overlapped with its backward (round 6)
+        self.force = bool(force_collectives)
+        if self.force and self.grads is None:
+            self.grads = engine.buffer(_lib.BUF_GRADS)
+        if want_lib and (self.world > 1 or self.force):
+            err = None
             try:
-                self.comm = RcclComm()          # raises on every rank or on none (it agrees over the group first)
+                if self.comm is None:
+                    self.comm = RcclComm()      # raises on every rank or on none (it agrees over the group first)
+                    self._own_comm = True
             except Exception as e:
+                err = e
+            if err is None and hasattr(engine, 'allreduce_attach') and getattr(engine, 'variant', '') != 'aae':
+                try:
+                    engine.allreduce_attach(self.comm, self.world)
+                    self.in_phase = True
+                except Exception as e:
+                    err = e
+            if not _all_ok(err is None):        # (the attach can fail on one rank alone: agree before anybody relies on it)
+                if self.in_phase:
+                    engine.allreduce_attach(None, 1)
+                self.in_phase = False
+                if self._own_comm and self.comm is not None:
+                    self.comm.close()
+                self.comm = None
                 if library_allreduce:
-                    raise
+                    raise RuntimeError(f'library-issued all-reduce unavailable: {err if err else "another rank failed"}')
                 import sys
-                print(f'uad: library-issued all-reduce unavailable ({e}); every rank falls back to torch.distributed', file=sys.stderr)
+                print(f'uad: library-issued all-reduce unavailable ({err if err else "another rank failed"}); every rank falls back to torch.distributed', file=sys.stderr)
 
     def close(self):
-        if self.comm is not None:
+        if self.in_phase and getattr(self.eng, 'handle', None):
+            self.eng.allreduce_attach(None, 1)
+        self.in_phase = False
+        if self.comm is not None and self._own_comm:
             self.comm.close()
-            self.comm = None
+        self.comm = None
 
     def broadcast_params(self, src=0):
-        if self.world > 1:
+        if self.world > 1 and dist.is_initialized():
             dist.broadcast(self.eng.buffer(_lib.BUF_PARAMS), src=src)
 
     def train_phase(self, group, lr, beta1=0.5, beta2=0.9, adam_eps=1e-8, **kw):
         out = self.eng.phase(group, want_backward=True, **kw)
-        if self.world > 1:
+        if self.in_phase:
+            pass          # the library enqueued the group's bucketed all-reduce behind (and beside) the phase's own backward kernels
+        elif self.world > 1 or self.force:
             # AnoVAE-GAN's 'Encoder' phase is optim_vae: Encoder + Generator variables (one contiguous slice)
             red = 'VAE' if (getattr(self.eng, 'variant', '') == 'anovaegan' and group == 'Encoder') else group
             off, cnt = self.eng.group(red)
