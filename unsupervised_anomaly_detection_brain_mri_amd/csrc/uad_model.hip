@@ -16,7 +16,17 @@
 
 #include <dlfcn.h>
 #include <unistd.h>
-#include <rccl/rccl.h>      // types and prototypes only: the library is bound at run time (rccl_api below), libuad_hip.so does not link it
+// RCCL: types only -- the library is bound at run time (rccl_api below), libuad_hip.so does not link it.  Without the development header (a single-GPU ROCm
+// install) the few opaque types are declared here and the uad_rccl_* entry points still work whenever librccl.so.1 itself can be loaded.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+#endif
 #include "../../include/uad_hip.h"
 #include "uad_kernels.h"
 
@@ -1327,14 +1337,9 @@ int uad_rccl_comm_create(const void* id_bytes, int world, int rank, void** comm_
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
     ncclComm_t c = nullptr;
-    // RCCL prints a start-up banner (version / host / library path) to STDOUT from rank 0's first communicator: a caller whose stdout is a protocol
-    // (bench.py's one JSON line) must not see it -- stdout is pointed at stderr for the duration of the call
-    fflush(stdout);
-    const int saved = dup(1);
-    if (saved >= 0) (void)dup2(2, 1);
+    // (RCCL prints a start-up banner -- version / host / library path -- to STDOUT from rank 0's first communicator.  A caller whose stdout is a protocol
+    // points its file descriptor 1 elsewhere itself, as bench.py's claim_stdout() does: the library does not touch process-wide descriptors -- ADVICE r5.)
     const ncclResult_t r = api->commInitRank(&c, world, id, rank);        // collective over the ranks: every rank calls it with rank 0's id, on its own device
-    fflush(stdout);
-    if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
     if (r != ncclSuccess) return fail(UAD_ERR_HIP, "ncclCommInitRank failed: %s", api->errString(r));
     *comm_out = (void*)c;
     return UAD_OK;

@@ -222,6 +222,20 @@ class AEMODEL(DLMODEL):
         config.tfSummaryImages restores the reference's per-step map fetch for its TensorBoard image strip."""
         import torch
         phase = Phase(phase) if not isinstance(phase, Phase) else phase
+        # Data parallel: for the duration of THIS epoch loop a bottleneck fault is only recorded on the device and reported by the cross-rank agreement
+        # below -- a rank raising alone out of a mid-epoch forward would leave the others blocked in the next gradient all-reduce.  Outside the loop
+        # (reconstruct(), evaluation, save()) the handle reports at once again.
+        deferred = getattr(self.dp, 'world', 1) > 1 and hasattr(self.engine, 'set_fault_deferred')
+        if deferred:
+            self.engine.set_fault_deferred(True)
+        try:
+            return self._process_epoch(dataset, epoch, phase, optim)
+        finally:
+            if deferred and getattr(self.engine, 'handle', None):
+                self.engine.set_fault_deferred(False)
+
+    def _process_epoch(self, dataset, epoch, phase, optim):
+        import torch
         if getattr(self.step, '__func__', None) is not AEMODEL.step:
             return self._process_via_step(dataset, epoch, phase)
         visuals = []
