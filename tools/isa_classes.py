@@ -47,7 +47,7 @@ def kernels(lines, keys):
 def demangle(names):
     import subprocess
     try:
-        out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt'] + names, capture_output=True, text=True).stdout.split('\n')
+        out = subprocess.run(['c++filt'] + names, capture_output=True, text=True).stdout.split('\n')
         return dict(zip(names, out))
     except Exception:
         return {n: n for n in names}
@@ -92,7 +92,7 @@ def main():
             elif mn.startswith(('global_', 'buffer_', 'flat_', 'scratch_')): other['vmem'] += 1
             elif mn.startswith('s_') and not mn.startswith(('s_waitcnt', 's_nop', 's_barrier')): other['salu'] += 1
         valu = sum(c.values())
-        short = re.sub(r'^void ', '', dm.get(name, name)).split('(')[0]
+        short = re.sub(r'^void ', '', dm.get(name, name)).replace('(anonymous namespace)::', '').split('(')[0]
         pct = lambda k: f'{c[k]} ({100.0 * c[k] / max(valu, 1):.0f} %)'
         if md:
             print(f'| `{short}` | {other["mfma"]} | {valu} | {valu / max(other["mfma"], 1):.1f} | ' + ' | '.join(pct(k) for k in order) + f' | {other["lds"]} | {other["vmem"]} | {other["salu"]} |')
