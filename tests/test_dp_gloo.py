@@ -331,3 +331,34 @@ def test_two_rank_gan_phases_equal_big_batch():
         assert res[g + '_grad_err'] < 1e-10, res
         assert res[g + '_param_err'] < 1e-9, res
     assert res['replica_diff'] == 0.0
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from unsupervised_anomaly_detection_brain_mri_amd.parallel import _all_ok
+        # a step that fails on ONE rank only must come out as a failure on EVERY rank (a rank on the torch path beside ranks
+        # issuing ncclAllReduce on the library's communicator deadlocks the first step)
+        a = _all_ok(True)
+        b = _all_ok(rank != 1)
+        c = _all_ok(rank != 0)
+        d = _all_ok(False)
+        q.put((rank, a, b, c, d))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_library_path_decision_is_collective():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, True, False, False, False), (1, True, False, False, False)], got

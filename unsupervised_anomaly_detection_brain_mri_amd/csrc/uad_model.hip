@@ -85,7 +85,7 @@ struct uad_model {
     UadGemmWs ws;                      // split-K slabs for the GEMMs that cannot fill the chip on their own
     bool packed_valid;
     bool pack_inflight;               // the repack of the updated parameters was launched on SIDE by the optimizer step (ev_pack)
-    hipEvent_t ev_opt, ev_pack, ev_pack_head; bool pack_head;      // ev_pack_head: the first packed consumer's tensor is ready (the rest: ev_pack)
+    hipEvent_t ev_opt, ev_pack, ev_pack_head; bool pack_head; bool pack_head_main; hipStream_t pack_head_stream;      // ev_pack_head: the first packed consumer's tensor is ready (the rest: ev_pack)
     long long step;
     // layers
     std::vector<ConvLayer> enc, dec;
@@ -615,7 +615,8 @@ int uad_set_step(uad_model_t* m, long long t) { if (!m || t < 0) return fail(UAD
 // head_done (optional): the second conv block's tensor -- the FIRST packed-weight consumer of a forward -- is packed by a launch of its own and the
 // event recorded behind it; everything else follows.  Round 5: the step's timeline showed enc1.fwd waiting ~20 us at the head of every step for the
 // whole repack (17 us of packing + the dense transposes + two event hops behind the optimizer step) although its own tensor is 3 % of the bytes.
-static void pack_weights(uad_model* m, hipStream_t st, hipEvent_t head_done = nullptr) {
+// part: 0 = everything; 1 = the head tensor only (enc[1]); 2 = everything but the head tensor
+static void pack_weights(uad_model* m, hipStream_t st, hipEvent_t head_done = nullptr, int part = 0) {
     const bool gm = m->cfg.arch == UAD_ARCH_GMVAE_SPATIAL, sp = m->cfg.arch == UAD_ARCH_AE_SPATIAL;
     long long offs[16]; int cbs[16], css[16], taps[16]; int np = 0;
     auto add = [&](const ConvLayer& L) { if (np < 16 && L.d.CB % 4 == 0 && L.d.CS % 4 == 0) { offs[np] = L.w; cbs[np] = L.d.CB; css[np] = L.d.CS; taps[np] = 25; ++np; } };
@@ -631,6 +632,8 @@ static void pack_weights(uad_model* m, hipStream_t st, hipEvent_t head_done = nu
         np = 0;
     };
     size_t first = 1;
+    if (part == 1) { if (m->enc.size() > 1) { add(m->enc[1]); flush(); } return; }
+    if (part == 2) first = 2;
     if (head_done) {
         if (m->enc.size() > 1) { add(m->enc[1]); flush(); first = 2; }
         (void)hipEventRecord(head_done, st);
@@ -661,7 +664,17 @@ static void repack_on_side(uad_model* m, hipStream_t st) {
     (void)hipEventRecord(m->ev_opt, st);
     (void)hipStreamWaitEvent(m->side, m->ev_opt, 0);
     m->pack_head = !no_head;
-    pack_weights(m, m->side, m->pack_head ? m->ev_pack_head : nullptr);
+    // Round 6: the head tensor -- the next forward's FIRST packed-weight consumer's, 3 % of the bytes -- is packed on the CALLER's stream right behind the
+    // optimizer step, the rest on SIDE: a forward on the same stream then needs no cross-stream wait in front of enc1.fwd (the step timeline showed ~13 us
+    // between conv_first and enc1.fwd although the head pack had finished long before: the price of the wait itself; same-box A/B -0.5 % per step,
+    // profiles/r06_f_pack_head_main_ab.log).  A forward on ANOTHER stream waits for ev_pack_head as before.  UAD_NO_PACK_HEAD=1: one event behind the whole repack.
+    m->pack_head_main = m->pack_head;
+    if (m->pack_head_main) {
+        pack_weights(m, st, nullptr, 1);
+        (void)hipEventRecord(m->ev_pack_head, st);
+        m->pack_head_stream = st;
+        pack_weights(m, m->side, nullptr, 2);
+    } else pack_weights(m, m->side, nullptr);
     (void)hipEventRecord(m->ev_pack, m->side);
     m->pack_inflight = true;
 }
@@ -769,7 +782,8 @@ int uad_forward(uad_model_t* m, const uad_io_t* io, int n, int want_backward, vo
         uad_launch_conv_first_fwd(d, xin, P(m, m->enc[0].w), P(m, m->enc[0].b), m->enc[0].c, st);
     }
     bool wait_full = wait_pack;
-    if (wait_pack && m->pack_head) (void)hipStreamWaitEvent(st, m->ev_pack_head, 0);       // enc1's tensor only; everything else is waited for one layer later
+    if (wait_pack && m->pack_head && m->pack_head_main && st == m->pack_head_stream) { }     // enc1's tensor was packed on this stream, in order
+    else if (wait_pack && m->pack_head) (void)hipStreamWaitEvent(st, m->ev_pack_head, 0);       // enc1's tensor only; everything else is waited for one layer later
     else if (wait_pack) { (void)hipStreamWaitEvent(st, m->ev_pack, 0); wait_full = false; }
     for (size_t i = 1; i < m->enc.size(); ++i) {
         if (i >= 2 && wait_full) { (void)hipStreamWaitEvent(st, m->ev_pack, 0); wait_full = false; }
