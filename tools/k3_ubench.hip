@@ -1,0 +1,48 @@
+// Micro-benchmark of the k3 tap-list kernel (csrc/uad_convk16.inc) outside the library: one launch shape, HIP-event timing, compile-time
+// ablations (-DK3_ABL=<bits>: 1 no weight loads in the loop | 2 no LDS fragment reads | 4 no staging | 8 no MFMAs).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DK3_ABL=n] tools/k3_ubench.hip -o tools/k3_ubench[_n]
+//   tools/k3_ubench N H W CA Nn [planes]        (k3 s1 forward form)
+#include <vector>
+#include <string.h>
+#include "../unsupervised_anomaly_detection_brain_mri_amd/csrc/uad_gemm_common.h"
+
+namespace {
+struct ConvWArgs {
+    const float* big; const float* small_; float* partial; UadXform xfb, xfs; UadConvDesc d;
+    int Mtot, Kt, kper, lws, lhs; unsigned long long* dbgbuf; int npl = 2; int abl = 0;
+};
+#include "../unsupervised_anomaly_detection_brain_mri_amd/csrc/uad_convk16.inc"
+}
+
+#define CK_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 96, H = argc > 2 ? atoi(argv[2]) : 8, W = argc > 3 ? atoi(argv[3]) : 8;
+    const int CA = argc > 4 ? atoi(argv[4]) : 512, Nn = argc > 5 ? atoi(argv[5]) : 512, planes = argc > 6 ? atoi(argv[6]) : 2;
+    const size_t in_e = (size_t)N * H * W * CA, out_e = (size_t)N * H * W * Nn, w_e = (size_t)9 * CA * Nn;
+    float *in, *out; unsigned short* w16;
+    CK_(hipMalloc(&in, in_e * 4)); CK_(hipMalloc(&out, out_e * 4)); CK_(hipMalloc(&w16, w_e * 2 * 3));
+    std::vector<float> h(in_e);
+    unsigned s = 12345u;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.f - 0.5f; }
+    CK_(hipMemcpy(in, h.data(), in_e * 4, hipMemcpyHostToDevice));
+    std::vector<unsigned short> hw(w_e * 3);
+    for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((s >> 12) & 0x1ff)); }       // bf16 values near 0.01 .. 0.03
+    CK_(hipMemcpy(w16, hw.data(), w_e * 2 * 3, hipMemcpyHostToDevice));
+    UadConvDesc d{N, H, W, CA, H, W, Nn, 3, 1, 1};
+    UadEpilogue ep; memset(&ep, 0, sizeof ep); ep.kind = UAD_EPI_BIAS;
+    hipStream_t st; CK_(hipStreamCreate(&st));
+    hipEvent_t a, b; CK_(hipEventCreate(&a)); CK_(hipEventCreate(&b));
+    for (int i = 0; i < 5; ++i) run_convk16(d, true, in, out, ep, w16, (long long)w_e, planes, st);
+    CK_(hipStreamSynchronize(st));
+    const int reps = 50;
+    CK_(hipEventRecord(a, st));
+    for (int i = 0; i < reps; ++i) run_convk16(d, true, in, out, ep, w16, (long long)w_e, planes, st);
+    CK_(hipEventRecord(b, st));
+    CK_(hipEventSynchronize(b));
+    float ms = 0; CK_(hipEventElapsedTime(&ms, a, b));
+    const double us = ms * 1e3 / reps, flop = 2.0 * N * H * W * 9.0 * CA * Nn;
+    printf("K3_ABL=%d N=%d %dx%d CA=%d Nn=%d planes=%d: %.1f us  %.1f TFLOP/s algorithmic  (x%d executed = %.3f of 2500)\n", K3_ABL, N, H, W, CA, Nn, planes, us,
+           flop / us * 1e-6, planes == 3 ? 6 : 3, flop * (planes == 3 ? 6 : 3) / us * 1e-6 / 2500.0);
+    return 0;
+}

@@ -401,11 +401,13 @@ void enc_backward(uad_gan* m, const float* x, const float* mask_z, int n, hipStr
     uad_launch_conv_d(dd, m->dzr, no_xform(), P(m, m->e_dw), m->dflat, epi_bias(nullptr), st, nullptr, m->ws);
     uad_launch_conv_w(dc1, m->ea[m->E.size()], no_xform(), m->dflat, no_xform(), Gr(m, m->e_cw), m->wpartial, st);
     uad_launch_colsum(m->dflat, n * r * r, m->cmid, Gr(m, m->e_cb), m->colscratch, st);
+    for (long long o : {m->e_dw, m->e_db, m->e_cw, m->e_cb}) gan_grad_final(m, o);
     float* g = m->Ga; float* gn = m->Gb;
     uad_launch_conv_d(dc1, m->dflat, no_xform(), P(m, m->e_cw), g, epi_bias(nullptr), st, nullptr, m->ws);
     for (int i = (int)m->E.size() - 1; i >= 0; --i) {
         bn_act_bwd(m, m->E[i], g, m->ec[i], n, gn, st);          // gn = d loss / d c_i ; gamma, beta, bias gradients
         conv_wgrad(m, m->E[i], n, i == 0 ? x : m->ea[i], gn, st);
+        for (long long o : {m->E[i].w, m->E[i].b, m->E[i].gamma, m->E[i].beta}) gan_grad_final(m, o);
         if (i > 0) conv_dgrad(m, m->E[i], n, gn, g, st);
     }
 }
@@ -492,6 +494,7 @@ void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* 
             convT_wgrad(m, L, n, m->ga[i], gn, st);
             // a bias in front of a LayerNorm over (H, W) is removed by the mean subtraction: its gradient is identically zero.
             // The gradient buffer is zero-initialised and nothing writes those entries, so they stay exact zeros.
+            for (long long o : {L.w, L.b, L.gamma, L.beta}) gan_grad_final(m, o);
         }
         convT_dgrad(m, L, n, gn, g, st);
     }
@@ -546,6 +549,7 @@ void disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float* 
         if (pg) {
             uad_launch_reduce_partials(m->lnpart[i], (N + ntail) * (L.C / 32), 2 * a.HW, 1.0f, Gr(m, L.gamma), st);
             conv_wgrad(m, L, N + ntail, i == 0 ? m->din : m->Da[i], m->Dg[i], st);
+            for (long long o : {L.w, L.b, L.gamma, L.beta}) gan_grad_final(m, o);
         }
         if (i > 0) { conv_dgrad(m, L, N, m->Dg[i], gn, st); float* t = g; g = gn; gn = t; }
         else if (dx_out) conv_dgrad(m, L, N, m->Dg[0], dx_out, st);
