@@ -1,5 +1,14 @@
+# tools/k3_ubench variants over the dominant shapes of configs[3] (gpurun -- 'bash tools/k3_abl.sh "<variant suffixes>"')
 mkdir -p gpurun_out/r6_k3abl
-for sh in "96 8 8 512 512" "96 64 64 128 64" "96 16 16 512 256"; do
-for n in "" _1 _2 _4 _8 _3 _7 _14 _13 _11; do timeout 60 tools/k3_ubench$n $sh; done
-done 2>&1 | tee gpurun_out/r6_k3abl/abl.log
-timeout 900 python -m pytest tests/test_gpu_dp_stub_collective.py tests/test_gpu_fanogan.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4
+V=${1:-"_f0 _f1 _f2 _f3"}
+while read sh; do
+for n in $V; do [ $n = _ ] && n=""; echo -n "[$n] "; timeout 60 tools/k3_ubench$n $sh | tr '\n' ' ' | sed 's/TFLOP.s algorithmic//; s/output digest//; s/K3_ABL=0 //'; echo; done
+done 2>&1 <<SHAPES | tee gpurun_out/r6_k3abl/abl_$(date +%H%M%S).log
+96 8 8 512 512 2 d2
+96 16 16 256 256 2 d2
+96 32 32 128 128 2 d2
+32 8 8 512 512 3 d2
+32 16 16 256 256 3 d2
+32 32 32 128 128 3 d2
+64 32 32 128 128 2 d2
+SHAPES

@@ -19,7 +19,9 @@ struct ConvWArgs {
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 96, H = argc > 2 ? atoi(argv[2]) : 8, W = argc > 3 ? atoi(argv[3]) : 8;
     const int CA = argc > 4 ? atoi(argv[4]) : 512, Nn = argc > 5 ? atoi(argv[5]) : 512, planes = argc > 6 ? atoi(argv[6]) : 2;
-    const size_t in_e = (size_t)N * H * W * CA, out_e = (size_t)N * H * W * Nn, w_e = (size_t)9 * CA * Nn;
+    const char* mode = argc > 7 ? argv[7] : "f1";      // f1: k3 s1 forward form | f2: k3 s2 forward form (input 2H x 2W) | d2: k3 s2 transposed form (output 2H x 2W, four class launches)
+    const bool f2 = !strcmp(mode, "f2"), d2 = !strcmp(mode, "d2");
+    const size_t in_e = (size_t)N * H * W * CA * (f2 ? 4 : 1), out_e = (size_t)N * H * W * Nn * (d2 ? 4 : 1), w_e = (size_t)9 * CA * Nn;
     float *in, *out; unsigned short* w16;
     CK_(hipMalloc(&in, in_e * 4)); CK_(hipMalloc(&out, out_e * 4)); CK_(hipMalloc(&w16, w_e * 2 * 3));
     std::vector<float> h(in_e);
@@ -30,19 +32,27 @@ int main(int argc, char** argv) {
     for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((s >> 12) & 0x1ff)); }       // bf16 values near 0.01 .. 0.03
     CK_(hipMemcpy(w16, hw.data(), w_e * 2 * 3, hipMemcpyHostToDevice));
     UadConvDesc d{N, H, W, CA, H, W, Nn, 3, 1, 1};
+    if (f2) d = UadConvDesc{N, 2 * H, 2 * W, CA, H, W, Nn, 3, 2, 0};
+    if (d2) d = UadConvDesc{N, 2 * H, 2 * W, Nn, H, W, CA, 3, 2, 0};
+    const bool ft = !d2;
     UadEpilogue ep; memset(&ep, 0, sizeof ep); ep.kind = UAD_EPI_BIAS;
     hipStream_t st; CK_(hipStreamCreate(&st));
     hipEvent_t a, b; CK_(hipEventCreate(&a)); CK_(hipEventCreate(&b));
-    for (int i = 0; i < 5; ++i) run_convk16(d, true, in, out, ep, w16, (long long)w_e, planes, st);
+    for (int i = 0; i < 5; ++i) run_convk16(d, ft, in, out, ep, w16, (long long)w_e, planes, st);
     CK_(hipStreamSynchronize(st));
     const int reps = 50;
     CK_(hipEventRecord(a, st));
-    for (int i = 0; i < reps; ++i) run_convk16(d, true, in, out, ep, w16, (long long)w_e, planes, st);
+    for (int i = 0; i < reps; ++i) run_convk16(d, ft, in, out, ep, w16, (long long)w_e, planes, st);
     CK_(hipEventRecord(b, st));
     CK_(hipEventSynchronize(b));
     float ms = 0; CK_(hipEventElapsedTime(&ms, a, b));
     const double us = ms * 1e3 / reps, flop = 2.0 * N * H * W * 9.0 * CA * Nn;
-    printf("K3_ABL=%d N=%d %dx%d CA=%d Nn=%d planes=%d: %.1f us  %.1f TFLOP/s algorithmic  (x%d executed = %.3f of 2500)\n", K3_ABL, N, H, W, CA, Nn, planes, us,
+    printf("K3_ABL=%d %s N=%d %dx%d CA=%d Nn=%d planes=%d: %.1f us  %.1f TFLOP/s algorithmic  (x%d executed = %.3f of 2500)\n", K3_ABL, mode, N, H, W, CA, Nn, planes, us,
            flop / us * 1e-6, planes == 3 ? 6 : 3, flop * (planes == 3 ? 6 : 3) / us * 1e-6 / 2500.0);
+    std::vector<float> ho(out_e);
+    CK_(hipMemcpy(ho.data(), out, out_e * 4, hipMemcpyDeviceToHost));
+    unsigned long long x = 0; double sum = 0;
+    for (size_t i = 0; i < out_e; ++i) { unsigned u; memcpy(&u, &ho[i], 4); x = x * 1099511628211ull ^ u; sum += ho[i]; }
+    printf("   output digest %016llx  sum %.9g\n", x, sum);
     return 0;
 }
