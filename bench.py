@@ -774,26 +774,43 @@ def bench_fanogan(args):
             for ln in buf.value.decode().splitlines():
                 v = ln.split()
                 kind, p1, p2, ntaps, npl, N, MH, MW, CA, Nn, calls = map(int, v[:11])
-                rows.append(dict(kind=kind, p1=p1, p2=p2, ntaps=ntaps, planes=npl, N=N, MH=MH, MW=MW, CA=CA, Nn=Nn, calls=calls, total_ms=float(v[11])))
+                rows.append(dict(kind=kind, p1=p1, p2=p2, ntaps=ntaps, planes=npl, N=N, MH=MH, MW=MW, CA=CA, Nn=Nn, calls=calls, total_ms=float(v[11]),
+                                 form=int(v[12]) if len(v) > 12 else 0))
             if rows:
                 # group by kernel INSTANCE (kind, stride, halo / cb blocks, taps, planes): the group with the largest summed time is the dominant kernel
                 groups = {}
                 for r in rows:
-                    groups.setdefault((r['kind'], r['p1'], r['p2'], r['ntaps'], r['planes']), []).append(r)
+                    groups.setdefault((r['kind'], r['p1'], r['p2'], r['ntaps'], r['planes'], r['form']), []).append(r)
                 gkey, grp = max(groups.items(), key=lambda kv: sum(r['total_ms'] for r in kv[1]))
                 top = max(grp, key=lambda r: r['total_ms'])                       # its most expensive launch shape
                 flop = 2.0 * top['N'] * top['MH'] * top['MW'] * top['ntaps'] * top['CA'] * top['Nn']
                 avg_ms = top['total_ms'] / top['calls']
                 ach = flop / (avg_ms * 1e-3) / 1e12
                 pk = 2500.0 / (3.0 if top['planes'] == 2 else 6.0)
+                # kernel instance by form (csrc/uad_convk16.inc): tap-list 0 first kernel | 1 convk16p (pipelined) | 2 / 3 convk16q with 64 / 128 output channels per
+                # workgroup; filter gradient 0 first kernel | 1 convk_w16p (pipelined, twelve waves)
+                tiles = (top['MH'] // 8) * (top['MW'] // 8)
                 if top['kind'] == 0:
-                    name = f"convk16_kernel<8,8,32,2,2,{top['p1']},{top['p2']},{top['ntaps']},{top['planes']}> (tap-list k3 kernel, input stride {top['p1']})"
+                    tp = f"{top['p1']}, {top['p2']}, {top['ntaps']}, {top['planes']}"
+                    kn, wgs, thr, what = {0: (f"convk16_kernel<8, 8, 32, 2, 2, {tp},", top['Nn'] // 64, 256, 'first form'),
+                                          1: (f"convk16p_kernel<8, 8, 32, 2, 2, {tp}>", top['Nn'] // 64, 256, 'pipelined, 32 x 32 wave tiles'),
+                                          2: (f"convk16q_kernel<8, 8, 32, 2, {tp}>", top['Nn'] // 64, 128, 'pipelined, 64 x 32 wave tiles, 64 channels per workgroup'),
+                                          3: (f"convk16q_kernel<8, 8, 32, 4, {tp}>", top['Nn'] // 128, 256, 'pipelined, 64 x 32 wave tiles, 128 channels per workgroup')}[top['form']]
+                    name = f"{kn.rstrip(',')} (tap-list k3 kernel, input stride {top['p1']}; {what})"
+                    gt = str(tiles * top['N'] * wgs * thr)
                     ain = top['N'] * (top['p1'] * top['MH']) * (top['p1'] * top['MW']) * top['CA'] * 4
                     aout = top['N'] * top['MH'] * top['MW'] * top['Nn'] * 4
+                    reread = {0: 'every 64-channel output block of a tile is its own workgroup and re-reads the input tile and its weight slice',
+                              1: 'every 64-channel output block of a tile is its own workgroup and re-reads the input tile and its weight slice',
+                              2: 'every 64-channel output block of a tile is its own workgroup and re-reads the input tile and its weight slice',
+                              3: 'a workgroup owns 128 output channels of a tile: the input tile is read once per 128 channels'}[top['form']]
                 else:
-                    name = f"convk_w16_kernel<{top['p1']},{top['p2']}> (k3 filter gradient, stride {top['p1']})"
+                    kn = f"convk_w16p_kernel<{top['p1']}, {8 if top['p1'] == 1 else 4}>" if top['form'] == 1 else f"convk_w16_kernel<{top['p1']}, {top['p2']}>"
+                    name = f"{kn} (k3 filter gradient, stride {top['p1']}" + ('; pipelined, twelve waves)' if top['form'] == 1 else ')')
+                    gt = None
                     ain = top['N'] * top['MH'] * top['MW'] * (top['p1'] ** 2 * top['CA'] + top['Nn']) * 4
                     aout = 9 * top['CA'] * top['Nn'] * 4
+                    reread = 'every (64 x 64)-channel block re-reads its operand slices; the slabs of the split launch are written and re-read by the reduction'
                 abytes = ain + aout + 9 * top['CA'] * top['Nn'] * 2 * top['planes'] * (1 if top['kind'] == 0 else 0)
                 # HBM bytes per launch of that (kernel, grid) and the profiler's own average duration, from the committed rocprofv3 passes of THIS command
                 # (tools/final_round6.sh -> profiles/r06_evidence_fanogan_resnet64.json, tools/evidence.py format)
@@ -801,18 +818,12 @@ def bench_fanogan(args):
                 try:
                     tdoc = json.load(open(os.path.join(ROOT, 'profiles', 'r06_evidence_fanogan_resnet64.json')))
                     srcs = (f"profiles/r06_evidence_fanogan_resnet64.json: `{tdoc.get('_command')}` under rocprofv3 at commit {tdoc.get('_commit')}; not re-measured in this run")
-                    if top['kind'] == 0:
-                        kn = f"convk16_kernel<8, 8, 32, 2, 2, {top['p1']}, {top['p2']}, {top['ntaps']}, {top['planes']},"
-                        gt = str((top['MH'] // 8) * (top['MW'] // 8) * top['N'] * (top['Nn'] // 64) * 256)
-                    else:
-                        kn, gt = f"convk_w16_kernel<{top['p1']}, {top['p2']}>", None
                     trows = [r for r in tdoc.get('traffic', []) if kn in r['name'] and (gt is None or str(r['grid']) == gt)]
                     if trows:
                         r = max(trows, key=lambda r: r['fetch_bytes'] + r['write_bytes'])
                         traffic = {'bytes': int(r['fetch_bytes'] + r['write_bytes']), 'fetch_bytes': int(r['fetch_bytes']), 'write_bytes': int(r['write_bytes']),
                                    'launches_averaged': r['launches'],
-                                   'source': srcs + '; --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 (gfx950 correction).  Above the algorithmic bytes: every 64-channel output '
-                                             'block of a tile is its own workgroup and re-reads the input tile (8 blocks at 512 channels) and its weight slice'}
+                                   'source': srcs + '; --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 (gfx950 correction).  Above the algorithmic bytes: ' + reread}
                     srows = [r for r in tdoc.get('stats', []) if kn in r['name']]
                     if srows:
                         r = max(srows, key=lambda r: r['total_ns'])
@@ -831,7 +842,7 @@ def bench_fanogan(args):
                                    'traffic': traffic,
                                    'rocprof': rocprof,
                                    'whole_iteration': whole}
-                res['k3_kernels'] = sorted(({'kind': 'FD' if r['kind'] == 0 else 'W', 'stride': r['p1'], 'ntaps': r['ntaps'], 'planes': r['planes'],
+                res['k3_kernels'] = sorted(({'kind': 'FD' if r['kind'] == 0 else 'W', 'form': r['form'], 'stride': r['p1'], 'ntaps': r['ntaps'], 'planes': r['planes'],
                                              'N': r['N'], 'grid': [r['MH'], r['MW']], 'CA': r['CA'], 'Nn': r['Nn'], 'calls': r['calls'],
                                              'avg_ms': round(r['total_ms'] / r['calls'], 4),
                                              'tflops': round(2.0 * r['N'] * r['MH'] * r['MW'] * r['ntaps'] * r['CA'] * r['Nn'] / (r['total_ms'] / r['calls'] * 1e-3) / 1e12, 1)}

@@ -9,6 +9,9 @@ interpreter with the switch set:
   UAD_NO_D16S              round-2 ConvT-class kernel (LDS-transposed epilogue) instead of the lane = pixel one
   UAD_NO_FUSED_FINAL_F32   exact-fp32 mode: separate final 1x1 conv + loss kernel instead of the last ConvT's fused epilogue (round 4)
   UAD_NO_ANYORDER          every launch with the AQL barrier bit (no data gradient starting while its layer's filter gradient drains)
+  UAD_K3_FORM=0..3         kernel form of the k3 / k1 tap-list launches (round 6: first kernel | pipelined 32 x 32 wave tiles | 64 x 32 wave tiles with 64 / 128
+                           output channels per workgroup); the library picks one per launch shape, the forms are bit-identical (test_k3_forms_*)
+  UAD_K3_WFORM=0           k3 filter gradient on the first kernel instead of the pipelined twelve-wave one (bit-identical slabs)
 (The opt-in experiments of round 3 -- UAD_PG, UAD_PP, UAD_D16S_MF2, UAD_W_TW8, UAD_W5_MINTILES, UAD_STAGGER -- measured slower or neutral and
 were removed in round 4; round 6 removed every path that had been the non-default for two rounds -- UAD_NO_F16, UAD_NO_D16, UAD_NO_W_T, UAD_NO_W_TR,
 UAD_NO_W2, UAD_NO_FB_BITS, UAD_NO_FB_ON_LOAD, UAD_NO_REDUCE_NT, UAD_NO_PACK8, UAD_EVENT_SYSFENCE -- with their kernels; git history has them.)"""
@@ -107,4 +110,74 @@ def test_restoration_parity_without_the_pattern_word():
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_gmvae.py', 'tests/test_gpu_vae_you.py', '-q', '-x', '-m', 'gpu', '-k', 'restore', '-p', 'no:cacheprovider'],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+_K3_SCRIPT = r'''
+import ctypes as C, hashlib, os, numpy as np, torch
+os.environ['UAD_MATH'] = 'bf16x3'
+from unsupervised_anomaly_detection_brain_mri_amd import _lib
+from tests.gpu_util import dev, ptr, desc, stream
+from oracle import nn as onn
+lib = _lib.load()
+h = hashlib.sha256()
+rng = np.random.default_rng(5)
+# (kind, N, H, Cin, Cout, k, s): k3 s1 / s2 convolutions and transposed convolutions, a k1 shortcut; N and Cout large enough for every form's grid rule to matter
+for kind, N, H, Cin, Cout, k, s in [('conv', 5, 16, 128, 128, 3, 1), ('conv', 4, 16, 64, 128, 3, 2), ('convT', 4, 8, 128, 128, 3, 2), ('conv', 4, 16, 128, 256, 1, 1),
+                                    ('convT', 3, 8, 256, 128, 3, 1), ('conv', 2, 8, 512, 512, 3, 1)]:
+    if kind == 'conv':
+        x = rng.standard_normal((N, H, H, Cin)); w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
+        oh, pt, _ = onn.same_pads(H, k, s)
+        g = rng.standard_normal((N, oh, oh, Cout))
+        d = desc(N, H, H, Cin, oh, oh, Cout, k, s, pt)
+        xd, wd, gd = dev(x), dev(w), dev(g)
+        out = torch.empty((N, oh, oh, Cout), device='cuda'); dx = torch.empty((N, H, H, Cin), device='cuda'); dw = torch.empty((k, k, Cin, Cout), device='cuda')
+        _lib.check(lib.uad_op_conv_f(C.byref(d), ptr(xd), None, ptr(wd), None, None, None, ptr(out), stream()))
+        _lib.check(lib.uad_op_conv_d(C.byref(d), ptr(gd), None, ptr(wd), None, None, None, ptr(dx), stream()))
+        _lib.check(lib.uad_op_conv_w(C.byref(d), ptr(xd), None, ptr(gd), None, ptr(dw), stream()))
+    else:
+        x = rng.standard_normal((N, H, H, Cin)); w = rng.standard_normal((k, k, Cout, Cin)) / np.sqrt(k * k * Cin)
+        OH = H * s
+        g = rng.standard_normal((N, OH, OH, Cout))
+        _, pt, _ = onn.same_pads(OH, k, s)
+        d = desc(N, OH, OH, Cout, H, H, Cin, k, s, pt)
+        xd, wd, gd = dev(x), dev(w), dev(g)
+        out = torch.empty((N, OH, OH, Cout), device='cuda'); dx = torch.empty((N, H, H, Cin), device='cuda'); dw = torch.empty((k, k, Cout, Cin), device='cuda')
+        _lib.check(lib.uad_op_conv_d(C.byref(d), ptr(xd), None, ptr(wd), None, None, None, ptr(out), stream()))
+        _lib.check(lib.uad_op_conv_f(C.byref(d), ptr(gd), None, ptr(wd), None, None, None, ptr(dx), stream()))
+        _lib.check(lib.uad_op_conv_w(C.byref(d), ptr(gd), None, ptr(xd), None, ptr(dw), stream()))
+    torch.cuda.synchronize()
+    for t in (out, dx, dw):
+        a = t.cpu().numpy()
+        assert np.isfinite(a).all()
+        h.update(a.tobytes())
+print('DIGEST', h.hexdigest())
+'''
+
+
+def test_k3_forms_are_bit_identical():
+    """Round 6: the pipelined forms of the k3 tap-list kernel and of the k3 filter gradient keep the first kernels' products and summation order --
+    forcing any form (UAD_K3_FORM, UAD_K3_WFORM) over forward, data gradient and filter gradient of k3 s1 / s2 / transposed / k1 launches gives the
+    SAME BITS as the library's own per-shape choice."""
+    digests = {}
+    for knob in ('', 'UAD_K3_FORM=0', 'UAD_K3_FORM=1', 'UAD_K3_FORM=2', 'UAD_K3_FORM=3', 'UAD_K3_WFORM=0'):
+        env = dict(os.environ)
+        if knob:
+            name, _, val = knob.partition('=')
+            env[name] = val
+        r = subprocess.run([sys.executable, '-c', _K3_SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and 'DIGEST' in r.stdout, (knob, r.stdout[-2000:], r.stderr[-2000:])
+        digests[knob or 'default'] = r.stdout.split('DIGEST')[1].split()[0]
+    assert len(set(digests.values())) == 1, digests
+
+
+@pytest.mark.parametrize('knob', ['UAD_K3_FORM=0', 'UAD_K3_FORM=2', 'UAD_K3_FORM=3', 'UAD_K3_WFORM=0'])
+def test_k3_op_parity_with_forced_form(knob):
+    """... and each forced form meets the fp64 oracle on the op-level parity tests of the ResNet geometries (the default choice at these small batches is
+    the pipelined 32 x 32 form; the 64 x 32 forms are what the bench-size launches run)."""
+    name, _, val = knob.partition('=')
+    env = dict(os.environ, **{name: val})
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_ops_resnet.py', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (knob, r.stdout[-2000:], r.stderr[-1000:])
     assert ' passed' in r.stdout and 'failed' not in r.stdout

@@ -2721,15 +2721,15 @@ void uad_k3_prof_enable(bool on) {
     if (on && !g_k3prof) { for (auto& r : g_k3recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } g_k3recs.clear(); }
     g_k3prof = on;
 }
-// one text line per launch shape: "kind p1 p2 ntaps npl N MH MW CA Nn calls total_ms"; returns the number of bytes the full table needs
+// one text line per launch shape: "kind p1 p2 ntaps npl N MH MW CA Nn calls total_ms form"; returns the number of bytes the full table needs
 int uad_k3_prof_read(char* buf, int cap) {
     (void)hipDeviceSynchronize();
-    std::map<std::array<int, 10>, std::pair<int, double>> agg;
+    std::map<std::array<int, 11>, std::pair<int, double>> agg;
     for (auto& r : g_k3recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
-        std::array<int, 10> k;
-        for (int i = 0; i < 10; ++i) k[i] = r.key[i];
+        std::array<int, 11> k;
+        for (int i = 0; i < 11; ++i) k[i] = r.key[i];
         auto& e = agg[k];
         e.first += 1; e.second += ms;
     }
@@ -2738,7 +2738,7 @@ int uad_k3_prof_read(char* buf, int cap) {
     for (auto& kv : agg) {
         int n = 0;
         for (int i = 0; i < 10; ++i) n += snprintf(line + n, sizeof line - n, "%d ", kv.first[i]);
-        snprintf(line + n, sizeof line - n, "%d %.6f\n", kv.second.first, kv.second.second);
+        snprintf(line + n, sizeof line - n, "%d %.6f %d\n", kv.second.first, kv.second.second, kv.first[10]);
         out += line;
     }
     if (buf && cap > 0) { const size_t c = out.size() < (size_t)cap - 1 ? out.size() : (size_t)cap - 1; memcpy(buf, out.data(), c); buf[c] = 0; }
