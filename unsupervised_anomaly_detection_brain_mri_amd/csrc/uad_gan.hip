@@ -230,6 +230,12 @@ const float* PKF(uad_gan* m, long long off) { return m->math == UAD_MATH_F32 ? m
 const float* PKD(uad_gan* m, long long off) { return m->math == UAD_MATH_F32 ? m->wpack_d + off : nullptr; }
 const unsigned short* PK16F(uad_gan* m, long long off) { return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_f + 2 * off : nullptr; }
 const unsigned short* PK16D(uad_gan* m, long long off) { return m->math == UAD_MATH_BF16X3 ? (const unsigned short*)m->wpack16_d + 2 * off : nullptr; }
+// k3 / k1 tensors of the ResNet graph: the first two planes of the three-plane pack (h = bf16(x), m = bf16(x - h)) ARE the hi | lo planes of the two-plane
+// pack, at the same plane stride -- with the three-plane buffers present the bf16x3 launches of the tap-list kernel read those and the tensors are packed
+// once per optimizer step instead of twice (round 6; `generic16` = bf16x3_all keeps the two-plane pack for the generic kernels).
+static bool k3_one_pack(const uad_gan* m) { return m->wpack3_f && m->wpack3_d && !m->generic16; }
+const unsigned short* K3F(uad_gan* m, long long off) { return k3_one_pack(m) ? (const unsigned short*)m->wpack3_f + 4 * off : PK16F(m, off); }
+const unsigned short* K3D(uad_gan* m, long long off) { return k3_one_pack(m) ? (const unsigned short*)m->wpack3_d + 4 * off : PK16D(m, off); }
 long long PLANE(const Block& L) { return (long long)L.d.KS * L.d.KS * L.d.CB * L.d.CS; }
 UadXform no_xform() { UadXform x; x.scale = nullptr; x.shift = nullptr; x.alpha = 1.f; x.mult = 1.f; return x; }
 UadEpilogue epi_bias(const float* bias, const float* mul = nullptr, const float* add = nullptr) {
@@ -328,7 +334,7 @@ int refresh_packs(uad_gan* m, hipStream_t st) {
         np = 0;
         auto flush = [&]() {
             if (np > 0) {
-                uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
+                if (!k3_one_pack(m)) uad_launch_pack_weights_bf16(m->params, (unsigned short*)m->wpack16_f, (unsigned short*)m->wpack16_d, offs, cbs, css, taps, np, st);
                 if (m->wpack3_f) uad_launch_pack_weights_bf16_3p(m->params, (unsigned short*)m->wpack3_f, (unsigned short*)m->wpack3_d, offs, cbs, css, taps, np, st);
             }
             np = 0;
@@ -908,7 +914,7 @@ void g_conv_f(uad_gan* m, UadConvDesc d, int N, const float* big_in, long long w
     if (pk && !m->generic16 && d.KS == 1 && m->wpack3_f) nfast = 0;
     if (nfast > 0) {
         d.N = nfast;
-        uad_launch_conv_f(d, big_in, no_xform(), P(m, w), small_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, pk ? PK16F(m, w) : nullptr, plane,
+        uad_launch_conv_f(d, big_in, no_xform(), P(m, w), small_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, pk ? K3F(m, w) : nullptr, plane,
                           m->generic16);
     }
     if (nfast < N) {
@@ -927,7 +933,7 @@ void g_conv_d(uad_gan* m, UadConvDesc d, int N, const float* small_in, long long
     if (pk && !m->generic16 && d.KS == 1 && m->wpack3_d) nfast = 0;
     if (nfast > 0) {
         d.N = nfast;
-        uad_launch_conv_d(d, small_in, no_xform(), P(m, w), big_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, pk ? PK16D(m, w) : nullptr, plane,
+        uad_launch_conv_d(d, small_in, no_xform(), P(m, w), big_out, epi_bias(bias, nullptr, add), st, nullptr, m->ws, pk ? K3D(m, w) : nullptr, plane,
                           m->generic16);
     }
     if (nfast < N) {

@@ -1903,6 +1903,11 @@ __global__ void pack_weights_bf16_3p_kernel(const float* __restrict__ W, unsigne
 // The same packing, one 16-byte group of a packed layout per thread (blockIdx.y: 0 = the F layout, 8 consecutive cb of one (tap, cs); 1 = the D
 // layout, 8 consecutive cs of one (tap, cb)): coalesced 16-byte stores instead of four scattered 2-byte stores per element (the repack runs on the
 // side stream behind the optimizer step; at 20 us it outlasted the main-stream work before the first packed-weight consumer).  Same bits.
+// A tensor's offset in the flat parameter vector need not be a multiple of four floats (the ResNet graph's critic starts one float after the generator's
+// one-channel 1x1 convolution: every critic tensor sat at offset 1 mod 4 and took the per-element kernels -- 133 + 81 us per phase in the round-6 trace):
+// the 16-byte accesses are typed dword-aligned, which the hardware serves at any dword address.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4)));
 template <int NPL>      // 2: hi | lo planes at ushort index 2 * off (bf16x3); 3: h | m | l at 4 * off (bf16x6; round 6 -- the per-element 3p kernel was 4.5 % of a configs[3] iteration)
 __global__ void __launch_bounds__(256) pack_weights_bf16_v8_kernel(const float* __restrict__ W, unsigned short* __restrict__ Wf, unsigned short* __restrict__ Wd, PackDesc pd) {
     long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // group index inside the tensor list
@@ -1924,8 +1929,8 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_v8_kernel(const float* 
         const int cb = (int)(g % CB);
         const int r = (int)(g / CB);
         const int cs8 = r % (CS / 8), tap = r / (CS / 8);
-        const float4 a = *reinterpret_cast<const float4*>(w + ((size_t)tap * CB + cb) * CS + cs8 * 8);
-        const float4 b = *reinterpret_cast<const float4*>(w + ((size_t)tap * CB + cb) * CS + cs8 * 8 + 4);
+        const f4u a = *reinterpret_cast<const f4u*>(w + ((size_t)tap * CB + cb) * CS + cs8 * 8);
+        const f4u b = *reinterpret_cast<const f4u*>(w + ((size_t)tap * CB + cb) * CS + cs8 * 8 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         dst = ((size_t)(tap * (CS / 8) + cs8) * CB + cb) * 8;
     }
@@ -1943,7 +1948,7 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_v8_kernel(const float* 
     const size_t base = (NPL == 3 ? 4 : 2) * (size_t)pd.off[t], cnt = (size_t)pd.count[t];
 #pragma unroll
     for (int q = 0; q < NPL; ++q)
-        *reinterpret_cast<uint4*>(out + base + q * cnt + dst) = make_uint4(pl[q][0] | (pl[q][1] << 16), pl[q][2] | (pl[q][3] << 16), pl[q][4] | (pl[q][5] << 16), pl[q][6] | (pl[q][7] << 16));
+        *reinterpret_cast<u4u*>(out + base + q * cnt + dst) = u4u{pl[q][0] | (pl[q][1] << 16), pl[q][2] | (pl[q][3] << 16), pl[q][4] | (pl[q][5] << 16), pl[q][6] | (pl[q][7] << 16)};
 }
 
 struct SpatialChoice { bool ok; int TH, TW, BN, CK; };
@@ -2806,7 +2811,7 @@ void uad_launch_pack_weights_bf16_3p(const float* params, unsigned short* w3_f, 
     long long total = 0;
     for (int i = 0; i < n; ++i) { pd.off[i] = offs[i]; pd.cb[i] = cbs[i]; pd.cs[i] = css[i]; pd.count[i] = taps[i] * cbs[i] * css[i]; total += pd.count[i]; }
     bool v8 = ((((uintptr_t)params | (uintptr_t)w3_f | (uintptr_t)w3_d) & 15) == 0);
-    for (int i = 0; i < n; ++i) v8 = v8 && pd.off[i] % 4 == 0 && pd.count[i] % 8 == 0 && pd.cb[i] % 8 == 0 && pd.cs[i] % 8 == 0;      // 16-byte aligned float4 reads and groups (planes at 8 * off + 2 q count bytes)
+    for (int i = 0; i < n; ++i) v8 = v8 && pd.count[i] % 8 == 0 && pd.cb[i] % 8 == 0 && pd.cs[i] % 8 == 0;      // whole 8-element groups (any dword-aligned offset: f4u / u4u)
     if (v8) hipLaunchKernelGGL(pack_weights_bf16_v8_kernel<3>, dim3((unsigned)((total / 8 + 255) / 256), 2), dim3(256), 0, st, params, w3_f, w3_d, pd);
     else hipLaunchKernelGGL(pack_weights_bf16_3p_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w3_f, w3_d, pd);
 }
@@ -2888,7 +2893,7 @@ void uad_launch_pack_weights_bf16(const float* params, unsigned short* w16_f, un
         total += pd.count[i];
     }
     bool v8 = ((((uintptr_t)params | (uintptr_t)w16_f | (uintptr_t)w16_d) & 15) == 0);
-    for (int i = 0; i < n; ++i) v8 = v8 && pd.off[i] % 4 == 0 && pd.cb[i] % 8 == 0 && pd.cs[i] % 8 == 0;
+    for (int i = 0; i < n; ++i) v8 = v8 && pd.cb[i] % 8 == 0 && pd.cs[i] % 8 == 0;      // (any dword-aligned offset: f4u / u4u)
     if (v8) hipLaunchKernelGGL(pack_weights_bf16_v8_kernel<2>, dim3((unsigned)((total / 8 + 255) / 256), 2), dim3(256), 0, st, params, w16_f, w16_d, pd);
     else hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, w16_f, w16_d, pd);
 }
