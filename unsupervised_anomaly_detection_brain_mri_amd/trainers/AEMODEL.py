@@ -225,7 +225,7 @@ class AEMODEL(DLMODEL):
         # Data parallel: for the duration of THIS epoch loop a bottleneck fault is only recorded on the device and reported by the cross-rank agreement
         # below -- a rank raising alone out of a mid-epoch forward would leave the others blocked in the next gradient all-reduce.  Outside the loop
         # (reconstruct(), evaluation, save()) the handle reports at once again.
-        deferred = getattr(self.dp, 'world', 1) > 1 and hasattr(self.engine, 'set_fault_deferred')
+        deferred = getattr(getattr(self, 'dp', None), 'world', 1) > 1 and hasattr(self.engine, 'set_fault_deferred')
         if deferred:
             self.engine.set_fault_deferred(True)
         try:
