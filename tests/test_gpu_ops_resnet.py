@@ -41,7 +41,8 @@ def math_mode(request):
 
 # Conv2D (big = input): (N, H, Cin, Cout, k, s)
 CONV = [(2, 16, 64, 128, 3, 1), (3, 8, 128, 128, 3, 2), (2, 16, 32, 64, 3, 2), (1, 32, 64, 64, 3, 1), (2, 8, 256, 256, 3, 1),
-        (2, 16, 64, 128, 1, 1), (2, 16, 128, 256, 3, 2), (1, 64, 64, 128, 3, 1), (2, 8, 512, 512, 3, 1)]
+        (2, 16, 64, 128, 1, 1), (2, 16, 128, 256, 3, 2), (1, 64, 64, 128, 3, 1), (2, 8, 512, 512, 3, 1),
+        (2, 16, 32, 64, 3, 1), (3, 8, 64, 64, 3, 2), (2, 16, 128, 128, 1, 1)]      # (round 6: one-chunk k3 s1, 64 x 64-channel s2 filter gradient, four-chunk k1)
 
 
 @pytest.mark.parametrize('N,H,Cin,Cout,k,s', CONV)
