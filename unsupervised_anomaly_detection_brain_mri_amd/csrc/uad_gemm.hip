@@ -2300,7 +2300,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_w16_kernel(const ConvWArg
 // five taps + tap (4, w) + a quarter of tap (4, 4) (folded through LDS in a fixed order); one [25][CB][CS] slab per workgroup, summed in split order by
 // reduce_partials_kernel.  (Its predecessors -- the pixel-major gather kernel of round 2 and the channel-major scatter kernel of round 3, same bits -- were
 // dropped in round 6; git history has them.)
-template <int NCSB, bool FBB, bool XFA, bool XFS, int NPL = 2>      // NPL: bf16 planes per operand (2: bf16x3 products, 3: bf16x6)
+template <int NCSB, bool FBB, bool XFA, bool XFS, int NPL = 2, bool DB = false>      // NPL: bf16 planes per operand (2: bf16x3 products, 3: bf16x6); DB: double-buffered tiles
 __global__ void __launch_bounds__(256 * NCSB) __attribute__((amdgpu_waves_per_eu(2)))
 conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) {
     // Round 6 ("VALU diet"): the staging half of this kernel issued ~45 VALU instructions per 16 bytes staged, a third of them 64-bit pointer
@@ -2319,10 +2319,13 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
     static_assert(!(FBB && XFA), "the pattern-word form replaces the big operand's transform");
     typedef short v4s __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    // (A double-buffered tile loop -- one barrier per tile, the next tile's conversion beside this tile's MFMAs -- measured neutral on this kernel too:
-    // profiles/r04_h_w_tr_ab.log.)
+    // DB (round 6, the eight-wave 64-column instances in bf16x3): both tiles double-buffered -- tile t + 1 is converted into the other buffer between the
+    // second and the third position block of tile t's MFMAs, the global loads of tile t + 2 follow it, ONE barrier per tile.  (Round 4 measured this neutral on
+    // the pre-diet kernel, profiles/r04_h_w_tr_ab.log; on the straight-line tile body it is what it was worth on the k3 kernel: profiles/r06_g_k3_forms.md.)
+    // Same elements, same products, same order: bit-identical slabs.
     constexpr int SMALLP = TH * TW * LDQ;         // ushorts per small plane
-    unsigned short* bPl = reinterpret_cast<unsigned short*>(dsm);       // NPL big planes, then NPL small planes
+    constexpr int BUFU = NPL * BIGP + NPL * SMALLP;      // ushorts per buffer
+    unsigned short* bPl = reinterpret_cast<unsigned short*>(dsm);       // NPL big planes, then NPL small planes (DB: twice)
     unsigned short* sPlT = bPl + NPL * BIGP;
     float* sRed = reinterpret_cast<float*>(dsm);   // reused after the tile loop
 
@@ -2475,7 +2478,7 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
     };
     auto as_f4 = [](uint4 q) { return make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)); };
     auto lds_store8 = [&](unsigned byte_addr, uint2 q) __attribute__((always_inline)) { *reinterpret_cast<uint2*>(dsm + byte_addr) = q; };
-    auto commit = [&]() __attribute__((always_inline)) {
+    auto commit = [&](const unsigned bufb) __attribute__((always_inline)) {      // bufb: byte offset of the buffer written
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             float4 tv;
@@ -2495,7 +2498,7 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
             split_planes<NPL>(tv, pl);
             const unsigned o = (u + 1 < PER) ? lds_b + (unsigned)(u * DP * LDH) * 2u : lds_last;
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) lds_store8(o + (unsigned)(p * BIGP) * 2u, pl[p]);
+            for (int p = 0; p < NPL; ++p) lds_store8(bufb + o + (unsigned)(p * BIGP) * 2u, pl[p]);
         }
 #pragma unroll
         for (int u = 0; u < SPER; ++u) {
@@ -2505,25 +2508,39 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
             split_planes<NPL>(tv, pl);
             const unsigned o = (unsigned)(NPL * BIGP) * 2u + slds_b + (unsigned)(u * (NT / CSQ) * LDQ) * 2u;
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) lds_store8(o + (unsigned)(p * SMALLP) * 2u, pl[p]);
+            for (int p = 0; p < NPL; ++p) lds_store8(bufb + o + (unsigned)(p * SMALLP) * 2u, pl[p]);
         }
     };
-    if (t_begin < t_end) issue();
+    if (t_begin < t_end) {
+        issue();
+        if (DB) { commit(0u); if (t_begin + 1 < t_end) issue(); __syncthreads(); }
+    }
     for (int t = t_begin; t < t_end; ++t) {
-        __syncthreads();                   // the previous tile's fragments are consumed
-        commit();
-        if (t + 1 < t_end) issue();        // in flight across the barrier and the MFMA loop below
-        __syncthreads();
+        const int cur = DB ? ((t - t_begin) & 1) * BUFU : 0;      // ushort offset of the buffer read
+        if (!DB) {
+            __syncthreads();                   // the previous tile's fragments are consumed
+            commit(0u);
+            if (t + 1 < t_end) issue();        // in flight across the barrier and the MFMA loop below
+            __syncthreads();
+        }
+        const unsigned short* bP = bPl + cur;
+        const unsigned short* sP = sPlT + cur;
 #pragma unroll
         for (int js = 0; js < TH * TW / 16; ++js) {
             // positions 16 js .. 16 js + 15 = tile rows 2 js (k half 0) and 2 js + 1 (k half 1)
             const int bo = b_base + 16 * js * LDQ;
-            const Pl bq_ = trp(sPlT, SMALLP, bo, 4 * LDQ);
+            const Pl bq_ = trp(sP, SMALLP, bo, 4 * LDQ);
             const int ao = a_base + (4 * js * IW + wave * IW) * LDH;          // this wave's kernel row
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) mma3(acc[kx], trp(bPl, BIGP, ao + kx * LDH, 8 * LDH), bq_);
+            for (int kx = 0; kx < 5; ++kx) mma3(acc[kx], trp(bP, BIGP, ao + kx * LDH, 8 * LDH), bq_);
             const int a4 = a_base + (4 * js * IW + 4 * IW) * LDH;             // kernel row 4
-            mma3(acc[5], trp(bPl, BIGP, a4 + wave * LDH, 8 * LDH), bq_);        // tap (4, wave)
+            mma3(acc[5], trp(bP, BIGP, a4 + wave * LDH, 8 * LDH), bq_);        // tap (4, wave)
+            if (DB && js == 1) {
+                // tile t + 1 (in registers since tile t - 1's MFMAs) -> the other buffer; then the loads of tile t + 2
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < t_end) { commit((unsigned)(BUFU - cur) * 2u); if (t + 2 < t_end) issue(); }      // (unconditional, clamped forms measured the same)
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         {
             // this wave's quarter of tap (4, 4) = position block js = wave, addressed by a run-time offset BEHIND the straight-line loop: with the
@@ -2531,8 +2548,9 @@ conv5_w_bf16_tr_kernel(const ConvWArgs a, int tiles_per_split, int total_tiles) 
             // above the previous block's MFMAs.  acc[6] receives the same three products in the same order.
             const int bo = b_base + 16 * wave * LDQ;
             const int a4 = a_base + (4 * wave * IW + 4 * IW) * LDH;
-            mma3(acc[6], trp(bPl, BIGP, a4 + 4 * LDH, 8 * LDH), trp(sPlT, SMALLP, bo, 4 * LDQ));
+            mma3(acc[6], trp(bP, BIGP, a4 + 4 * LDH, 8 * LDH), trp(sP, SMALLP, bo, 4 * LDQ));
         }
+        if (DB) __syncthreads();          // tile t + 1 is complete in LDS, and every wave is done with tile t's buffer
     }
 
     // Accumulator block -> slab.  One 64-bit address per lane; everything else is a wave-uniform 32-bit offset (the plain form
@@ -2972,6 +2990,17 @@ inline WChoice choose_w(const UadConvDesc& d) {
 namespace {
 template <int NCSB, bool FBB, bool XFA, bool XFS, int NPL>
 void launch_w_tr_n(const ConvWArgs& a, dim3 grid, const W5Choice& w5, hipStream_t st) {
+    if constexpr (NCSB == 2 && NPL == 2) {
+        // double-buffered form: 2 x 76 KB of LDS, one eight-wave workgroup per CU as before (UAD_NO_W5_DB: the single-buffered loop)
+        static const bool nodb = getenv("UAD_NO_W5_DB") != nullptr;
+        if (!nodb) {
+            constexpr size_t ldsd = 2 * conv5_w_bf16_tr_lds_bytes(NCSB, NPL);
+            static bool attrd = false;
+            if (!attrd) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS, NPL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd); attrd = true; }
+            UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS, NPL, true>), grid, dim3(256 * NCSB), ldsd, st, a, w5.tiles_per_split, w5.total_tiles);
+            return;
+        }
+    }
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv5_w_bf16_tr_lds_bytes(NCSB, NPL)); attr = true; }
     UAD_W_LAUNCH((conv5_w_bf16_tr_kernel<NCSB, FBB, XFA, XFS, NPL>), grid, dim3(256 * NCSB), conv5_w_bf16_tr_lds_bytes(NCSB, NPL), st, a, w5.tiles_per_split, w5.total_tiles);
