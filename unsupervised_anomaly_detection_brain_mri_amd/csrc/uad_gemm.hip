@@ -2605,7 +2605,9 @@ inline W5Choice choose_w5(const UadConvDesc& d, bool bf16 = true) {
     // fills the slots a 410-workgroup filter gradient leaves free -- the STEP is 2.5 % faster (0.916 -> 0.894 ms), and the slabs are a fifth smaller.
     // The exact-fp32 kernel (bf16 = false) is bound by the matrix pipe, not by latency: it keeps 512 (448 cost that mode 4 %: 1.704 -> 1.772 ms).
     static const int target_env = getenv("UAD_W5_TARGET") ? atoi(getenv("UAD_W5_TARGET")) : 0;
-    const int target = target_env > 0 ? target_env : (bf16 ? 448 : 512);
+    // Round 6, double-buffered kernel: re-swept on two boxes (profiles/r06_i_w5_target_sweep_db.log) -- 384 is 1 % faster over the step than 448 in all four pairs
+    // (0.822 / 0.830 vs 0.833 / 0.836 ms; 0.848 / 0.841 vs 0.856 / 0.852), although the kernels' own tags sum to 260 us instead of 250.
+    const int target = target_env > 0 ? target_env : (bf16 ? 384 : 512);
     int splits = (target + blocks - 1) / blocks;
     if (splits > c.total_tiles) splits = c.total_tiles;
     if (splits < 1) splits = 1;
