@@ -342,7 +342,7 @@ def test_bench_conv_tags_from_the_tensor_table():
 
 
 def test_bench_evidence_loader_and_stdout_claim(tmp_path):
-    """bench.py (round 5): a line's `roofline.traffic` / `roofline.rocprof` for the workloads other than the default one come from profiles/r05_evidence_<workload>.json
+    """bench.py (round 5): a line's `roofline.traffic` / `roofline.rocprof` for the workloads other than the default one come from profiles/r06_evidence_<workload>.json (r05_ as fallback)
     (tools/evidence.py) through the kernel template of the LAST decoder block's launch groups; and rank 0's one JSON line is written to the real stdout while
     everything else -- RCCL's start-up banner on fd 1 included -- goes to stderr."""
     import json
@@ -358,7 +358,7 @@ def test_bench_evidence_loader_and_stdout_claim(tmp_path):
         tr, rp = bench.evidence_for(wl, bench.last_block_kernel(tag, nblk), flop, 2500.0 / 3)
         assert tr and rp, wl
         assert tr['bytes'] == tr['fetch_bytes'] + tr['write_bytes'] and 2e7 < tr['bytes'] < 3e8, (wl, tr)
-        assert 0.05 < rp['frac'] < 0.6 and rp['calls'] > 0 and 'r05_evidence_' + wl in rp['source'], (wl, rp)
+        assert 0.05 < rp['frac'] < 0.6 and rp['calls'] > 0 and '_evidence_' + wl in rp['source'], (wl, rp)
     assert bench.evidence_for('no_such_workload', 'x', 1.0, 1.0) == (None, None) and bench.evidence_for('cevae_b16', None, 1.0, 1.0) == (None, None)
     # fd 1 is protected: a child that claims stdout, then writes to fd 1 natively (as RCCL does) and prints, still leaves exactly the JSON line on stdout
     code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); os.write(1, b'RCCL version : banner\\n'); print('chatter'); "
