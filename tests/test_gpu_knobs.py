@@ -13,6 +13,7 @@ interpreter with the switch set:
   UAD_K3_FORM=0..3         kernel form of the k3 / k1 tap-list launches (round 6: first kernel | pipelined 32 x 32 wave tiles | 64 x 32 wave tiles with 64 / 128
                            output channels per workgroup); the library picks one per launch shape, the forms are bit-identical (test_k3_forms_*)
   UAD_K3_WFORM=0           k3 filter gradient on the first kernel instead of the pipelined twelve-wave one (bit-identical slabs)
+  UAD_NO_LN1               two-pass LayerNorm forward / backward kernels on every map size instead of the one-pass register-resident forms (<= 1024 pixels)
 (The opt-in experiments of round 3 -- UAD_PG, UAD_PP, UAD_D16S_MF2, UAD_W_TW8, UAD_W5_MINTILES, UAD_STAGGER -- measured slower or neutral and
 were removed in round 4; round 6 removed every path that had been the non-default for two rounds -- UAD_NO_F16, UAD_NO_D16, UAD_NO_W_T, UAD_NO_W_TR,
 UAD_NO_W2, UAD_NO_FB_BITS, UAD_NO_FB_ON_LOAD, UAD_NO_REDUCE_NT, UAD_NO_PACK8, UAD_EVENT_SYSFENCE -- with their kernels; git history has them.)"""
@@ -110,6 +111,18 @@ def test_restoration_parity_without_the_pattern_word():
     env = dict(os.environ, UAD_NO_RESTORE_BITS='1')
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_gmvae.py', 'tests/test_gpu_vae_you.py', '-q', '-x', '-m', 'gpu', '-k', 'restore', '-p', 'no:cacheprovider'],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+def test_layernorm_two_pass_kernels_still_meet_the_oracle():
+    """Round 6: on maps of up to 1024 pixels the LayerNorm forward / backward kernels of the f-AnoGAN graphs keep a workgroup's (sample, 32-channel)
+    slice in registers between the statistics sweep and the apply sweep (one pass over HBM, same accumulation order).  UAD_NO_LN1=1 keeps the two-pass
+    kernels everywhere; that path must still meet the oracle on the ResNet critic (first- and second-order LayerNorm adjoints, gamma / beta gradients)
+    and on the unified graphs."""
+    env = dict(os.environ, UAD_NO_LN1='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_fanogan.py', '-q', '-x', '-m', 'gpu', '-k', 'resnet_critic_phase or test_critic_phase or resnet_generator_phase',
+                        '-p', 'no:cacheprovider'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
     assert ' passed' in r.stdout and 'failed' not in r.stdout
 

@@ -275,11 +275,27 @@ void rowdot(const float* feat, const float* w, const float* b, int rows, int C, 
     if (lpr > 64) lpr = 64;
     hipLaunchKernelGGL((rowdot_kernel<ACT>), dim3(blocks256((size_t)rows * lpr)), dim3(256), 0, st, feat, w, b, rows, C, lpr, out);
 }
+// One-pass LayerNorm forms (uad_gan_kernels.inc: the slice in registers between the statistics and the apply sweep) for maps of up to 1024 pixels, with
+// the pixel-lane count the two-pass kernels use for that map (same bits).  UAD_NO_LN1 keeps the two-pass kernels everywhere.
+inline bool ln_one_pass(int HW) {
+    static const bool on = getenv("UAD_NO_LN1") == nullptr;
+    return on && (HW <= 256 || (HW >= 512 && HW <= 1024));
+}
 void ln_fwd(const float* c, const float* gamma, const float* beta, float alpha, int N, int HW, int C, float* a, float* stats, hipStream_t st) {
+    if (ln_one_pass(HW)) {
+        if (HW >= 512) hipLaunchKernelGGL((ln_fwd1_kernel<8, 128, 8>), dim3(C / 32, N), dim3(1024), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
+        else hipLaunchKernelGGL((ln_fwd1_kernel<8, 32, 8>), dim3(C / 32, N), dim3(256), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
+        return;
+    }
     if (HW >= 512) hipLaunchKernelGGL((ln_fwd_kernel<128>), dim3(C / 32, N), dim3(1024), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
     else hipLaunchKernelGGL((ln_fwd_kernel<32>), dim3(C / 32, N), dim3(256), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
 }
 void ln_bwd(const LnBwdArgs& a, int N, hipStream_t st) {
+    if (ln_one_pass(a.HW)) {
+        if (a.HW >= 512) hipLaunchKernelGGL((ln_bwd1_kernel<8, 128, 8>), dim3(a.C / 32, N), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((ln_bwd1_kernel<8, 32, 8>), dim3(a.C / 32, N), dim3(256), 0, st, a);
+        return;
+    }
     if (a.HW >= 512) hipLaunchKernelGGL((ln_bwd_kernel<128>), dim3(a.C / 32, N), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL((ln_bwd_kernel<32>), dim3(a.C / 32, N), dim3(256), 0, st, a);
 }
