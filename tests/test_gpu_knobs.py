@@ -118,13 +118,47 @@ def test_restoration_parity_without_the_pattern_word():
 def test_layernorm_two_pass_kernels_still_meet_the_oracle():
     """Round 6: on maps of up to 1024 pixels the LayerNorm forward / backward kernels of the f-AnoGAN graphs keep a workgroup's (sample, 32-channel)
     slice in registers between the statistics sweep and the apply sweep (one pass over HBM, same accumulation order).  UAD_NO_LN1=1 keeps the two-pass
-    kernels everywhere; that path must still meet the oracle on the ResNet critic (first- and second-order LayerNorm adjoints, gamma / beta gradients)
+    kernels everywhere (UAD_NO_LNQ=1: on the 64 x 64 maps only, where the one-pass form is a cluster of workgroups that exchange partial sums); that
+    path must still meet the oracle on the ResNet critic (first- and second-order LayerNorm adjoints, gamma / beta gradients)
     and on the unified graphs."""
     env = dict(os.environ, UAD_NO_LN1='1')
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_fanogan.py', '-q', '-x', '-m', 'gpu', '-k', 'resnet_critic_phase or test_critic_phase or resnet_generator_phase',
                         '-p', 'no:cacheprovider'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
     assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+_LNQ_SCRIPT = r"""
+import hashlib, numpy as np, torch
+from tests.test_gpu_fanogan import _setup_rn, _engine_rn
+from unsupervised_anomaly_detection_brain_mri_amd import _lib
+m, p, x, z, alpha = _setup_rn(64, 32, 32, 3, seed=4)
+eng = _engine_rn(m, p, 3, 'bf16x3')
+h = hashlib.sha256()
+for it in range(2):
+    eng.phase('Discriminator', x=x, z=z, alpha=alpha)
+    h.update(np.ascontiguousarray(eng.get_buffer_host(_lib.BUF_GRADS)).tobytes())
+    eng.phase('Generator', z=z)
+    h.update(np.ascontiguousarray(eng.get_buffer_host(_lib.BUF_GRADS)).tobytes())
+torch.cuda.synchronize()
+print('DIGEST', h.hexdigest())
+"""
+
+
+def test_layernorm_cluster_without_a_sibling_recomputes_the_same_bits():
+    """Round 6: on the 64 x 64 maps the one-pass LayerNorm is a cluster of workgroups per (sample, 32-channel) slice that exchange their partial sums through
+    global memory (bounded poll).  A sibling that never raises its flag (UAD_LNQ_FAULT=1: workgroup 1 of every slice) must cost time only: the others
+    recompute its partial vector through the same lane mapping, so the critic's and the generator's gradients come out bit-identical."""
+    digests = {}
+    for knob in ('', 'UAD_LNQ_FAULT=1'):
+        env = dict(os.environ)
+        if knob:
+            k, v = knob.split('=')
+            env[k] = v
+        r = subprocess.run([sys.executable, '-c', _LNQ_SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (knob, r.stdout[-2000:], r.stderr[-2000:])
+        digests[knob] = [l for l in r.stdout.splitlines() if l.startswith('DIGEST')][0]
+    assert digests[''] == digests['UAD_LNQ_FAULT=1'], digests
 
 
 _K3_SCRIPT = r'''

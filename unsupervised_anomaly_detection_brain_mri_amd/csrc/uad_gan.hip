@@ -66,6 +66,7 @@ struct uad_gan {
     float *params, *grads, *adam_m, *adam_v;
     float *adam_m2, *adam_v2;          // AnoVAE-GAN: the Generator's slots inside optim_vae (its optim_gen slots are adam_m / adam_v)
     float *wpack_f, *wpack_d, *wpack16_f, *wpack16_d;
+    float* ln_xch = nullptr; unsigned* ln_flags = nullptr; size_t ln_xcap = 0; unsigned ln_epoch = 0;     // exchange scratch of the clustered LayerNorm kernels (grown on first use)
     float *wpack3_f, *wpack3_d;        // ResNet graph: THREE bf16 planes of the k3 kernels (bf16x6 products of the exact passes), 4 * nparams ushorts each; null: fp32 kernels
     int math;
     bool packed_valid;
@@ -275,25 +276,62 @@ void rowdot(const float* feat, const float* w, const float* b, int rows, int C, 
     if (lpr > 64) lpr = 64;
     hipLaunchKernelGGL((rowdot_kernel<ACT>), dim3(blocks256((size_t)rows * lpr)), dim3(256), 0, st, feat, w, b, rows, C, lpr, out);
 }
-// One-pass LayerNorm forms (uad_gan_kernels.inc: the slice in registers between the statistics and the apply sweep) for maps of up to 1024 pixels, with
-// the pixel-lane count the two-pass kernels use for that map (same bits).  UAD_NO_LN1 keeps the two-pass kernels everywhere.
+// One-pass LayerNorm forms (uad_gan_kernels.inc: the slice in registers between the statistics and the apply sweep).  Maps of up to 1024 pixels: one
+// workgroup per (sample, 32 channels), with the pixel-lane count the two-pass kernels use for that map (same bits).  Larger maps: Q workgroups per slice
+// that exchange their partial sums once (clustered forms).  UAD_NO_LN1 keeps the two-pass kernels everywhere, UAD_NO_LNQ on the large maps.
 inline bool ln_one_pass(int HW) {
     static const bool on = getenv("UAD_NO_LN1") == nullptr;
     return on && (HW <= 256 || (HW >= 512 && HW <= 1024));
 }
-void ln_fwd(const float* c, const float* gamma, const float* beta, float alpha, int N, int HW, int C, float* a, float* stats, hipStream_t st) {
+constexpr int kLnqPL = 128;           // pixel lanes per workgroup of the clustered forms (x 8 pixels per lane = 1024 pixels per workgroup; 128 / 64 / 32 lanes measured within 0.3 % of each other)
+inline int ln_cluster_pl() { return kLnqPL; }
+inline bool ln_clustered(int HW) {
+    static const bool on = getenv("UAD_NO_LN1") == nullptr && getenv("UAD_NO_LNQ") == nullptr;
+    return on && HW > 1024;
+}
+// exchange scratch for a launch of `wgs` workgroups; null when it cannot be had (the caller then takes the two-pass kernel)
+inline bool ln_xch_for(uad_gan* m, int HW, size_t wgs, LnXch* x) {
+    x->Q = (HW + ln_cluster_pl() * 8 - 1) / (ln_cluster_pl() * 8);
+    wgs *= (size_t)x->Q;
+    if (wgs > m->ln_xcap) {
+        (void)hipDeviceSynchronize();
+        float* xp = nullptr; float* fp = nullptr;
+        const size_t cap = wgs + wgs / 2;
+        if (dev_alloc(m, &xp, cap * 64) != UAD_OK || dev_alloc(m, &fp, cap) != UAD_OK) return false;
+        (void)hipDeviceSynchronize();          // dev_alloc's memset runs on the null stream; the phases' streams do not wait for it
+        m->ln_xch = xp; m->ln_flags = reinterpret_cast<unsigned*>(fp); m->ln_xcap = cap;
+    }
+    static const int fault = getenv("UAD_LNQ_FAULT") ? 1 : 0;      // tests/test_gpu_knobs.py: a sibling that never shows up costs time, not correctness
+    x->fault = fault;
+    x->xch = m->ln_xch; x->flags = m->ln_flags; x->epoch = ++m->ln_epoch;
+    if (x->epoch == 0) x->epoch = ++m->ln_epoch;          // 0 is the scratch's initial content
+    return true;
+}
+void ln_fwd(uad_gan* m, const float* c, const float* gamma, const float* beta, float alpha, int N, int HW, int C, float* a, float* stats, hipStream_t st) {
     if (ln_one_pass(HW)) {
         if (HW >= 512) hipLaunchKernelGGL((ln_fwd1_kernel<8, 128, 8>), dim3(C / 32, N), dim3(1024), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
         else hipLaunchKernelGGL((ln_fwd1_kernel<8, 32, 8>), dim3(C / 32, N), dim3(256), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
         return;
     }
+    LnXch x;
+    if (ln_clustered(HW) && ln_xch_for(m, HW, (size_t)(C / 32) * N, &x)) {
+        const dim3 g((C / 32) * x.Q, N);
+        hipLaunchKernelGGL((ln_fwdq_kernel<kLnqPL, 8>), g, dim3(8 * kLnqPL), 0, st, c, gamma, beta, alpha, HW, C, a, stats, x);
+        return;
+    }
     if (HW >= 512) hipLaunchKernelGGL((ln_fwd_kernel<128>), dim3(C / 32, N), dim3(1024), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
     else hipLaunchKernelGGL((ln_fwd_kernel<32>), dim3(C / 32, N), dim3(256), 0, st, c, gamma, beta, alpha, HW, C, a, stats);
 }
-void ln_bwd(const LnBwdArgs& a, int N, hipStream_t st) {
+void ln_bwd(uad_gan* m, const LnBwdArgs& a, int N, hipStream_t st) {
     if (ln_one_pass(a.HW)) {
         if (a.HW >= 512) hipLaunchKernelGGL((ln_bwd1_kernel<8, 128, 8>), dim3(a.C / 32, N), dim3(1024), 0, st, a);
         else hipLaunchKernelGGL((ln_bwd1_kernel<8, 32, 8>), dim3(a.C / 32, N), dim3(256), 0, st, a);
+        return;
+    }
+    LnXch x;
+    if (ln_clustered(a.HW) && ln_xch_for(m, a.HW, (size_t)(a.C / 32) * N, &x)) {
+        const dim3 g((a.C / 32) * x.Q, N);
+        hipLaunchKernelGGL((ln_bwdq_kernel<kLnqPL, 8>), g, dim3(8 * kLnqPL), 0, st, a, x);
         return;
     }
     if (a.HW >= 512) hipLaunchKernelGGL((ln_bwd_kernel<128>), dim3(a.C / 32, N), dim3(1024), 0, st, a);
@@ -477,11 +515,11 @@ void gen_forward(uad_gan* m, const float* z, const float* mask_g, int n, hipStre
     const int r = m->cfg.inter_res;
     uad_launch_conv_f(dense_desc(n, m->cfg.zdim, m->flat), z, no_xform(), P(m, m->g_dw), m->gdv, epi_bias(P(m, m->g_db), mask_g), st, nullptr, m->ws);
     uad_launch_conv_f(conv1x1_desc(n, r, r, m->cmid, m->cenc), m->gdv, no_xform(), P(m, m->g_cw), m->gc[0], epi_bias(P(m, m->g_cb)), st, nullptr, m->ws);
-    ln_fwd(m->gc[0], P(m, m->g_ln0g), P(m, m->g_ln0b), 0.0f, n, r * r, m->cenc, m->ga[0], m->gstat[0], st);
+    ln_fwd(m, m->gc[0], P(m, m->g_ln0g), P(m, m->g_ln0b), 0.0f, n, r * r, m->cenc, m->ga[0], m->gstat[0], st);
     for (size_t i = 0; i < m->G.size(); ++i) {
         const Block& L = m->G[i];
         convT_fwd(m, L, n, m->ga[i], m->gc[i + 1], st);
-        ln_fwd(m->gc[i + 1], P(m, L.gamma), P(m, L.beta), kLrelu, n, L.H * L.W, L.C, m->ga[i + 1], m->gstat[i + 1], st);
+        ln_fwd(m, m->gc[i + 1], P(m, L.gamma), P(m, L.beta), kLrelu, n, L.H * L.W, L.C, m->ga[i + 1], m->gstat[i + 1], st);
     }
     const Block& LL = m->G.back();
     const int rows = n * LL.H * LL.W;
@@ -510,7 +548,7 @@ void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* 
         memset(&a, 0, sizeof a);
         a.da = g; a.c = m->gc[i + 1]; a.stats = m->gstat[i + 1]; a.gamma = P(m, L.gamma); a.beta = P(m, L.beta); a.alpha = kLrelu;
         a.HW = L.H * L.W; a.C = L.C; a.dc = gn; a.gpart = pg ? m->lnpart_g : nullptr;
-        ln_bwd(a, n, st);
+        ln_bwd(m, a, n, st);
         if (pg) {
             uad_launch_reduce_partials(m->lnpart_g, n * (L.C / 32), 2 * a.HW, 1.0f, Gr(m, L.gamma), st);   // gamma | beta adjacent
             convT_wgrad(m, L, n, m->ga[i], gn, st);
@@ -524,7 +562,7 @@ void gen_backward(uad_gan* m, const float* z, const float* mask_g, const float* 
     memset(&a, 0, sizeof a);
     a.da = g; a.c = m->gc[0]; a.stats = m->gstat[0]; a.gamma = P(m, m->g_ln0g); a.beta = P(m, m->g_ln0b); a.alpha = 0.0f;
     a.HW = r * r; a.C = m->cenc; a.dc = gn; a.gpart = pg ? m->lnpart_g : nullptr;
-    ln_bwd(a, n, st);
+    ln_bwd(m, a, n, st);
     const UadConvDesc dc1 = conv1x1_desc(n, r, r, m->cmid, m->cenc), dd = dense_desc(n, m->cfg.zdim, m->flat);
     if (pg) {
         uad_launch_reduce_partials(m->lnpart_g, n * (m->cenc / 32), 2 * r * r, 1.0f, Gr(m, m->g_ln0g), st);
@@ -545,7 +583,7 @@ void disc_forward(uad_gan* m, int N, bool head, hipStream_t st) {
     for (size_t i = 0; i < m->D.size(); ++i) {
         const Block& L = m->D[i];
         conv_fwd(m, L, N, in, m->Dc[i], true, st);
-        ln_fwd(m->Dc[i], P(m, L.gamma), P(m, L.beta), kLrelu, N, L.H * L.W, L.C, m->Da[i + 1], m->Dstat[i], st);
+        ln_fwd(m, m->Dc[i], P(m, L.gamma), P(m, L.beta), kLrelu, N, L.H * L.W, L.C, m->Da[i + 1], m->Dstat[i], st);
         in = m->Da[i + 1];
     }
     if (head) {
@@ -567,7 +605,7 @@ void disc_backward(uad_gan* m, int N, bool pg, int ntail, int inject_lo, float* 
         a.da = g; a.c = m->Dc[i]; a.stats = m->Dstat[i]; a.gamma = P(m, L.gamma); a.beta = P(m, L.beta); a.alpha = kLrelu;
         a.HW = L.H * L.W; a.C = L.C; a.dc = m->Dg[i]; a.gpart = pg ? m->lnpart[i] : nullptr;
         if (inject_lo >= 0) { a.add = m->inj[i]; a.add_lo = inject_lo; a.add_hi = inject_lo + ntail; }
-        ln_bwd(a, N, st);
+        ln_bwd(m, a, N, st);
         if (pg) {
             uad_launch_reduce_partials(m->lnpart[i], (N + ntail) * (L.C / 32), 2 * a.HW, 1.0f, Gr(m, L.gamma), st);
             conv_wgrad(m, L, N + ntail, i == 0 ? m->din : m->Da[i], m->Dg[i], st);
@@ -980,9 +1018,9 @@ void rb_forward(uad_gan* m, RB& B, int N, hipStream_t st, size_t off = 0) {     
     const int HW = B.Hin * B.Hin;
     const float* X = B.X + off * B.sx;
     float* H1 = B.H1 + off * B.sx; float* C1 = B.C1 + off * B.sc1; float* H2 = B.H2 + off * B.sc1; float* OUT = B.OUT + off * B.sout;
-    ln_fwd(X, P(m, B.ln1g), P(m, B.ln1b), 0.0f, N, HW, B.Cin, H1, B.ST1 + off * 2 * B.Cin, st);
+    ln_fwd(m, X, P(m, B.ln1g), P(m, B.ln1b), 0.0f, N, HW, B.Cin, H1, B.ST1 + off * 2 * B.Cin, st);
     g_conv_f(m, B.d1, N, H1, B.w1, P(m, B.b1), nullptr, C1, st);
-    ln_fwd(C1, P(m, B.ln2g), P(m, B.ln2b), 0.0f, N, HW, B.Cout, H2, B.ST2 + off * 2 * B.Cout, st);
+    ln_fwd(m, C1, P(m, B.ln2g), P(m, B.ln2b), 0.0f, N, HW, B.Cout, H2, B.ST2 + off * 2 * B.Cout, st);
     const float* add = X;                                     // identity shortcut
     if (B.ws >= 0) {
         if (B.gen) g_conv_d(m, B.ds, N, X, B.ws, P(m, B.bs), nullptr, m->s_sp, st);
@@ -1015,7 +1053,7 @@ void rb_backward(uad_gan* m, RB& B, const RbBwd& a, hipStream_t st) {
     l.da = m->s_ta; l.c = B.C1 + a.in_off * B.sc1; l.stats = B.ST2 + a.in_off * 2 * B.Cout; l.gamma = P(m, B.ln2g); l.beta = P(m, B.ln2b);
     l.alpha = 0.0f; l.HW = HW; l.C = B.Cout; l.dc = g1; l.v_out = a.store_v ? B.V2 : nullptr; l.gpart = (a.pg || a.lnpart) ? B.LP2 : nullptr; l.slot0 = a.lnpart ? (int)a.out_off : 0;
     if (a.inj_lo >= 0) { l.add = B.INJC1; l.add_lo = a.inj_lo; l.add_hi = a.inj_lo + a.ntail; }
-    ln_bwd(l, N, st);
+    ln_bwd(m, l, N, st);
     g_conv_d(m, B.d1, N, g1, B.w1, nullptr, nullptr, m->s_tb, st);
     const float* addp = dout;                                  // identity shortcut: d / d x gets d / d out
     if (B.ws >= 0) {
@@ -1032,7 +1070,7 @@ void rb_backward(uad_gan* m, RB& B, const RbBwd& a, hipStream_t st) {
     l.alpha = 0.0f; l.HW = HW; l.C = B.Cin; l.dc = dx; l.v_out = a.store_v ? B.V1 : nullptr; l.gpart = (a.pg || a.lnpart) ? B.LP1 : nullptr; l.slot0 = a.lnpart ? (int)a.out_off : 0;
     l.add = addp; l.add_lo = 0; l.add_hi = N;
     if (a.inj_lo >= 0) { l.add2 = B.INJX; l.add2_lo = a.inj_lo; l.add2_hi = a.inj_lo + a.ntail; }
-    ln_bwd(l, N, st);
+    ln_bwd(m, l, N, st);
     if (!a.pg) return;
     rb_param_grads(m, B, N + a.ntail, N, st);
 }
@@ -1110,7 +1148,7 @@ void s_gen_forward(uad_gan* m, const float* z, int n, hipStream_t st, bool linea
     uad_launch_conv_f(dense_desc(n, m->cfg.zdim, flatg), z, no_xform(), P(m, m->g_dw), m->s_g0, epi_bias(P(m, m->g_db)), st, nullptr, m->ws);
     for (auto& B : m->GB) rb_forward(m, B, n, st);
     const RB& L = m->GB.back();
-    ln_fwd(L.OUT, P(m, m->s_glg), P(m, m->s_glb), 0.0f, n, L.Hout * L.Hout, L.Cout, m->s_hf, m->s_stf, st);
+    ln_fwd(m, L.OUT, P(m, m->s_glg), P(m, m->s_glb), 0.0f, n, L.Hout * L.Hout, L.Cout, m->s_hf, m->s_stf, st);
     if (linear) rowdot<0>(m->s_hf, P(m, m->g_fw), P(m, m->g_fb), n * L.Hout * L.Hout, L.Cout, m->xg, st);
     else rowdot<2>(m->s_hf, P(m, m->g_fw), P(m, m->g_fb), n * L.Hout * L.Hout, L.Cout, m->xg, st);
 }
@@ -1131,7 +1169,7 @@ void s_gen_backward(uad_gan* m, const float* z, const float* dx, int n, bool pg,
     memset(&l, 0, sizeof l);
     l.da = m->Ga; l.c = L.OUT; l.stats = m->s_stf; l.gamma = P(m, m->s_glg); l.beta = P(m, m->s_glb); l.alpha = 0.0f; l.HW = HW; l.C = L.Cout;
     l.dc = L.DOUT; l.gpart = pg ? m->lnpart_g : nullptr;
-    ln_bwd(l, n, st);
+    ln_bwd(m, l, n, st);
     if (pg) {
         uad_launch_reduce_partials(m->lnpart_g, n * (L.Cout / 32), 2 * HW, 1.0f, Gr(m, m->s_glg), st);
         for (long long o : {m->g_fw, m->g_fb, m->s_glg, m->s_glb}) gan_grad_final(m, o);
@@ -1683,7 +1721,7 @@ static int gan_phase_body(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n
                     a.da = u; a.c = m->Dc[i] + 2 * n * per; a.stats = m->Dstat[i] + (size_t)2 * n * 2 * B.C;
                     a.gamma = P(m, B.gamma); a.beta = P(m, B.beta); a.alpha = kLrelu; a.HW = B.H * B.W; a.C = B.C;
                     a.dc = m->Dg[i] + 3 * n * per; a.v_out = m->V[i];
-                    ln_bwd(a, n, st);
+                    ln_bwd(m, a, n, st);
                     if (i > 0) { conv_dgrad(m, B, n, a.dc, un, st); float* t = u; u = un; un = t; }
                     else conv_dgrad(m, B, n, a.dc, m->Gx, st);
                 }
