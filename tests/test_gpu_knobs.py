@@ -13,7 +13,8 @@ interpreter with the switch set:
   UAD_K3_FORM=0..3         kernel form of the k3 / k1 tap-list launches (round 6: first kernel | pipelined 32 x 32 wave tiles | 64 x 32 wave tiles with 64 / 128
                            output channels per workgroup); the library picks one per launch shape, the forms are bit-identical (test_k3_forms_*)
   UAD_K3_WFORM=0           k3 filter gradient on the first kernel instead of the pipelined twelve-wave one (bit-identical slabs)
-  UAD_NO_LN1               two-pass LayerNorm forward / backward kernels on every map size instead of the one-pass register-resident forms (<= 1024 pixels)
+  UAD_NO_LN1               two-pass LayerNorm kernels on every map size instead of the one-pass register-resident forms (UAD_NO_LNQ / UAD_NO_LN2Q: only the clustered
+                           forward + backward of the 64 x 64 maps / only the second-order adjoint)
 (The opt-in experiments of round 3 -- UAD_PG, UAD_PP, UAD_D16S_MF2, UAD_W_TW8, UAD_W5_MINTILES, UAD_STAGGER -- measured slower or neutral and
 were removed in round 4; round 6 removed every path that had been the non-default for two rounds -- UAD_NO_F16, UAD_NO_D16, UAD_NO_W_T, UAD_NO_W_TR,
 UAD_NO_W2, UAD_NO_FB_BITS, UAD_NO_FB_ON_LOAD, UAD_NO_REDUCE_NT, UAD_NO_PACK8, UAD_EVENT_SYSFENCE -- with their kernels; git history has them.)"""

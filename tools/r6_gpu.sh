@@ -137,7 +137,7 @@ PY
     ;;
 ln)  # clustered one-pass LayerNorm on the 64 x 64 maps: parity, then same-box comparison against the two-pass kernels (UAD_NO_LNQ=1); the pixel-lane sweep 128 / 64 / 32 of the first run is in profiles/README.md
     timeout 900 python -m pytest tests/test_gpu_fanogan.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4
-    for r in 1 2; do for v in UAD_NO_LNQ=1 UAD_X=0 $EXTRA; do
+    for r in 1 2; do for v in ${BASE:-UAD_NO_LNQ=1} UAD_X=0 $EXTRA; do
       env $v timeout 300 python bench.py --arch fAnoGAN --variant resnet --steps 5 --warmup 2 --no-cpu-baseline > $OUT/resnet_${v}_$r.json 2>/dev/null
       python -c "
 import json

@@ -290,19 +290,21 @@ inline bool ln_clustered(int HW) {
     return on && HW > 1024;
 }
 // exchange scratch for a launch of `wgs` workgroups; null when it cannot be had (the caller then takes the two-pass kernel)
-inline bool ln_xch_for(uad_gan* m, int HW, size_t wgs, LnXch* x) {
-    x->Q = (HW + ln_cluster_pl() * 8 - 1) / (ln_cluster_pl() * 8);
+inline bool ln_xch_for(uad_gan* m, int HW, size_t wgs, LnXch* x, int px_per_wg = kLnqPL * 8, int nv = 2) {
+    x->Q = (HW + px_per_wg - 1) / px_per_wg;
     wgs *= (size_t)x->Q;
-    if (wgs > m->ln_xcap) {
+    static const int fault = getenv("UAD_LNQ_FAULT") ? 1 : 0;      // tests/test_gpu_knobs.py: a sibling that never shows up costs time, not correctness
+    x->fault = fault;
+    x->xch = nullptr; x->flags = nullptr; x->epoch = 0;
+    if (x->Q == 1) return true;                 // no exchange
+    if (wgs * 32 * nv > m->ln_xcap) {
         (void)hipDeviceSynchronize();
         float* xp = nullptr; float* fp = nullptr;
-        const size_t cap = wgs + wgs / 2;
-        if (dev_alloc(m, &xp, cap * 64) != UAD_OK || dev_alloc(m, &fp, cap) != UAD_OK) return false;
+        const size_t cap = (wgs + wgs / 2) * 160;
+        if (dev_alloc(m, &xp, cap) != UAD_OK || dev_alloc(m, &fp, cap / 32) != UAD_OK) return false;
         (void)hipDeviceSynchronize();          // dev_alloc's memset runs on the null stream; the phases' streams do not wait for it
         m->ln_xch = xp; m->ln_flags = reinterpret_cast<unsigned*>(fp); m->ln_xcap = cap;
     }
-    static const int fault = getenv("UAD_LNQ_FAULT") ? 1 : 0;      // tests/test_gpu_knobs.py: a sibling that never shows up costs time, not correctness
-    x->fault = fault;
     x->xch = m->ln_xch; x->flags = m->ln_flags; x->epoch = ++m->ln_epoch;
     if (x->epoch == 0) x->epoch = ++m->ln_epoch;          // 0 is the scratch's initial content
     return true;
@@ -337,7 +339,17 @@ void ln_bwd(uad_gan* m, const LnBwdArgs& a, int N, hipStream_t st) {
     if (a.HW >= 512) hipLaunchKernelGGL((ln_bwd_kernel<128>), dim3(a.C / 32, N), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL((ln_bwd_kernel<32>), dim3(a.C / 32, N), dim3(256), 0, st, a);
 }
-void ln_bwd2(const LnBwd2Args& a, int N, hipStream_t st) {
+void ln_bwd2(uad_gan* m, const LnBwd2Args& a, int N, hipStream_t st) {
+    static const bool one_pass = getenv("UAD_NO_LN1") == nullptr && getenv("UAD_NO_LN2Q") == nullptr;
+    LnXch x;
+    if (one_pass && a.HW <= 256 && ln_xch_for(m, a.HW, (size_t)(a.C / 32) * N, &x, 256, 5)) {
+        hipLaunchKernelGGL((ln_bwd2q_kernel<32, 8>), dim3(a.C / 32, N), dim3(256), 0, st, a, x);
+        return;
+    }
+    if (one_pass && a.HW >= 512 && ln_xch_for(m, a.HW, (size_t)(a.C / 32) * N, &x, 512, 5)) {
+        hipLaunchKernelGGL((ln_bwd2q_kernel<128, 4>), dim3((a.C / 32) * x.Q, N), dim3(1024), 0, st, a, x);
+        return;
+    }
     if (a.HW >= 512) hipLaunchKernelGGL((ln_bwd2_kernel<128>), dim3(a.C / 32, N), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL((ln_bwd2_kernel<32>), dim3(a.C / 32, N), dim3(256), 0, st, a);
 }
@@ -1100,12 +1112,12 @@ void rb_adjoint(uad_gan* m, RB& B, int n, hipStream_t st) {
     memset(&a, 0, sizeof a);
     a.q = ubx; a.v = B.V1; a.c = B.X + hat * B.sx; a.stats = B.ST1 + hat * 2 * B.Cin; a.gamma = P(m, B.ln1g); a.beta = P(m, B.ln1b);
     a.alpha = 0.0f; a.HW = HW; a.C = B.Cin; a.ubar = B.H1 + tail * B.sx; a.inj = B.INJX; a.gpart = B.LP1; a.slot0 = 3 * n;
-    ln_bwd2(a, n, st);
+    ln_bwd2(m, a, n, st);
     g_conv_f(m, B.d1, n, B.H1 + tail * B.sx, B.w1, nullptr, nullptr, m->Q, st);
     memset(&a, 0, sizeof a);
     a.q = m->Q; a.v = B.V2; a.c = B.C1 + hat * B.sc1; a.stats = B.ST2 + hat * 2 * B.Cout; a.gamma = P(m, B.ln2g); a.beta = P(m, B.ln2b);
     a.alpha = 0.0f; a.HW = HW; a.C = B.Cout; a.ubar = B.H2 + tail * B.sc1; a.inj = B.INJC1; a.gpart = B.LP2; a.slot0 = 3 * n;
-    ln_bwd2(a, n, st);
+    ln_bwd2(m, a, n, st);
     const float* add = ubx;
     if (B.ws >= 0) {
         g_conv_f(m, B.ds, n, ubx, B.ws, nullptr, nullptr, m->s_sct, st);
@@ -1751,7 +1763,7 @@ static int gan_phase_body(uad_gan_t* m, int phase, const uad_gan_io_t* io, int n
                     a.q = m->Q; a.v = m->V[i]; a.c = m->Dc[i] + 2 * n * per; a.stats = m->Dstat[i] + (size_t)2 * n * 2 * B.C;
                     a.gamma = P(m, B.gamma); a.beta = P(m, B.beta); a.alpha = kLrelu; a.HW = B.H * B.W; a.C = B.C;
                     a.ubar = m->Da[i + 1] + 3 * n * per; a.inj = m->inj[i]; a.gpart = m->lnpart[i]; a.slot0 = 3 * n;
-                    ln_bwd2(a, n, st);
+                    ln_bwd2(m, a, n, st);
                 }
             }
             // pass D: ordinary backward of all 3n samples; top gradient +1/(n P) fake, -1/(n P) real, 0 for x_hat
