@@ -169,7 +169,9 @@ def last_block_kernel(tag, nblocks, math='bf16x3'):
     kind = tag.split('.')[1]
     if math == 'f32':
         return {'fwd': 'conv5_d_kernel<8, 16, 32, 4, 1, true', 'dgrad': 'conv5_f_kernel<8, 16, 16, 4, 1', 'wgrad': 'conv5_w_kernel'}.get(kind)
-    return {'fwd': 'conv5_d16s_kernel<8, 16, 32, 4, 1, 1, 2', 'dgrad': 'conv5_f16_kernel<8, 16, 16, 4, 1', 'wgrad': 'conv5_w_bf16_tr_kernel<1, true'}.get(kind)
+    # (round 6: the bf16x3 training instance of the fused-final ConvT kernel runs 16 x 16 tiles, two fragments per wave; bf16x6 keeps 8 x 16)
+    fwd = 'conv5_d16s_kernel<16, 16, 32, 4, 1, 2, 2' if math == 'bf16x3' else 'conv5_d16s_kernel<8, 16, 32, 4, 1, 1, 2'
+    return {'fwd': fwd, 'dgrad': 'conv5_f16_kernel<8, 16, 16, 4, 1', 'wgrad': 'conv5_w_bf16_tr_kernel<1, true'}.get(kind)
 
 
 def evidence_for(workload, kernel_substr, flop, peak):

@@ -349,7 +349,7 @@ def test_bench_evidence_loader_and_stdout_claim(tmp_path):
     import subprocess
     import sys
     import bench
-    assert bench.last_block_kernel('dec3.fwd', 4) == 'conv5_d16s_kernel<8, 16, 32, 4, 1, 1, 2'
+    assert bench.last_block_kernel('dec3.fwd', 4) == 'conv5_d16s_kernel<16, 16, 32, 4, 1, 2, 2' and bench.last_block_kernel('dec3.fwd', 4, 'bf16x6') == 'conv5_d16s_kernel<8, 16, 32, 4, 1, 1, 2'
     assert bench.last_block_kernel('dec4.dgrad', 5).startswith('conv5_f16_kernel<8, 16, 16')
     assert bench.last_block_kernel('dec3.wgrad', 4, 'f32') == 'conv5_w_kernel'
     assert bench.last_block_kernel('dec2.fwd', 4) is None and bench.last_block_kernel('enc1.fwd', 4) is None          # several layers share those templates

@@ -39,7 +39,7 @@ for (name, grid, wg), n, f, w in rows[:40]:
 MATH = sys.argv[5] if len(sys.argv) > 5 else 'bf16x3'
 TAGS = {
     # round 3: the ConvT-class launches run the lane = pixel kernel (uad_conv16s.inc): <TH, TW, CST, WGM, WGN, MF, EPI, PP>
-    'dec3.fwd': ('conv5_d16s_kernel<8, 16, 32, 4, 1, 1, 2', 32 * 64 * 256),
+    'dec3.fwd': ('conv5_d16s_kernel<16, 16, 32, 4, 1, 2, 2', 16 * 64 * 256),      # round 6 (late): 16 x 16 tiles, two fragments per wave (UAD_NO_D16S_T16: <8, 16, 32, 4, 1, 1, 2, grid 32 * 64 * 256)
     'dec2.fwd': ('conv5_d16s_kernel<8, 16, 64, 4, 1, 1, 0', 8 * 64 * 256),
     'enc1.dgrad': ('conv5_d16s_kernel<8, 16, 64, 4, 1, 1, 1', 8 * 64 * 256),
     'dec3.dgrad': ('conv5_f16_kernel<8, 16, 16, 4, 1', 32 * 64 * 256),
