@@ -1016,7 +1016,10 @@ static int backward_decoder(uad_model* m, hipStream_t st, bool join_now) {
           if (fb) { gx = bn_xform(m, DL.gamma, DL.beta, kLrelu); gx.fb_dxhat = m->gm_dxhat; gx.fb_wf = P(m, m->fw); }
           uad_launch_conv_f(d, fb ? DL.c : g, gx, P(m, m->dec[i].w), gn, e, st, PKF(m, m->dec[i].w), m->ws, PK16F(m, m->dec[i].w), PLANE(m->dec[i]), false, planes_of(m));
           uad_conv_any_order_next(false); }    // (a launch that did not take a spatial kernel must not leave the request to a later one)
-        edge(m, st, sd);   // ONE edge per layer: its filter-gradient slabs and column partials are ready
+        // ONE edge per layer: its filter-gradient slabs and column partials are ready.  Without parameter gradients (restoration, anomaly maps) nothing runs on SIDE and the
+        // event record -- a marker packet with the barrier bit on the MAIN queue -- is skipped: -2.3 % per restoration iteration.  (Releasing the side work of SEVERAL layers behind
+        // one edge was measured too, round 6: 0.808 -> 0.817 / 0.839 / 0.848 ms per VAE step at 2 / 3 / 4 layers per edge -- the side stream falls behind; one edge per layer stays.)
+        if (pg) edge(m, st, sd);
         if (pg && last) {
             // final conv kernel/bias grads + BN grads of the last block from the fused loss kernel's partials (forward results; riding on
             // this layer's edge instead of one of their own): red_partial[T][3C+1] = {dwf[C], S1[C], S2[C], dbf}
@@ -1067,7 +1070,7 @@ static int backward_bottleneck(uad_model* m, hipStream_t st, bool join_now) {
             ba.dcb_copy = pg ? m->dcb_keep : nullptr;     // conv2d_1's kernel gradient reads this copy on SIDE: dcb's buffer becomes encoder scratch
             ba.epoch = ++m->bott_epoch;
             { PROF("bott.bwd"); uad_launch_bottleneck_bwd(ba, n, st); }
-            edge(m, st, sd);
+            if (pg) edge(m, st, sd);
             UadBottWgradArgs wa;
             memset(&wa, 0, sizeof wa);
             wa.n = n; wa.cenc = m->cenc; wa.cmid = m->cmid; wa.npos = ir * ir; wa.zdim = zd; wa.alpha = kLrelu; wa.mult = rstd;
@@ -1230,7 +1233,7 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part, bool defer =
         { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
           uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i]), false, planes_of(m));
           uad_conv_any_order_next(false); }
-        edge(m, st, sd);
+        if (pg) edge(m, st, sd);
         if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd, bf);
                   uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats, sk_counters(m), planes_of(m)), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd, m->bnfin_scratch); }
