@@ -3,6 +3,7 @@
 // All are HBM-roofline kernels: 16-byte coalesced NHWC accesses, wavefront (64-lane) shuffle reductions,
 // deterministic two-level partial sums (no float atomics).
 #include "uad_kernels.h"
+#include <stdint.h>
 
 namespace {
 
@@ -13,6 +14,37 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 6 (late): the same sum with 16-byte streaming loads -- JL lanes of four adjacent columns x SL slab lanes (512 threads), four slabs in flight per thread.  The
+// scalar form below keeps four 4-byte loads in flight per thread: a 373-slab reduction (dec3's filter gradient) is 24 dependent round trips, 29 us for 38 MB,
+// and the LAST reduction of a step sits in front of the optimizer.  Fixed order (per lane: four interleaved chains over its slabs, then the slab lanes in index
+// order): deterministic, not the scalar form's order.  UAD_NO_REDUCE4 keeps the scalar form.
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+template <int JL, int SL>
+__global__ void __launch_bounds__(JL * SL) reduce_partials4_kernel(const float* __restrict__ partial, int S, int L, float scale, float* __restrict__ out) {
+    __shared__ v4f_nt red[SL][JL];
+    const int jl = threadIdx.x % JL, sl = threadIdx.x / JL;
+    const int j4 = blockIdx.x * JL + jl, L4 = L >> 2;
+    v4f_nt a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (j4 < L4) {
+        const v4f_nt* p = reinterpret_cast<const v4f_nt*>(partial) + j4;
+        int s = sl;
+        for (; s + 3 * SL < S; s += 4 * SL) {
+            const v4f_nt v0 = __builtin_nontemporal_load(p + (size_t)s * L4), v1 = __builtin_nontemporal_load(p + (size_t)(s + SL) * L4);
+            const v4f_nt v2 = __builtin_nontemporal_load(p + (size_t)(s + 2 * SL) * L4), v3 = __builtin_nontemporal_load(p + (size_t)(s + 3 * SL) * L4);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; s < S; s += SL) a0 += __builtin_nontemporal_load(p + (size_t)s * L4);
+    }
+    red[sl][jl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && j4 < L4) {
+        v4f_nt t = red[0][jl];
+#pragma unroll
+        for (int k = 1; k < SL; ++k) t += red[k][jl];
+        reinterpret_cast<v4f_nt*>(out)[j4] = t * scale;
+    }
+}
+
 // out[j] = scale * sum_s partial[s][j].  Block = 64 j-lanes x SL s-lanes; each thread walks s with stride SL and four
 // independent accumulators (loads in flight), then the s-lanes are folded through LDS in a fixed order (deterministic).
 template <int SL>
@@ -1025,6 +1057,14 @@ void uad_launch_reduce_partials(const float* partial, int S, int L, float scale,
     // streaming (non-temporal) loads: the slabs are read exactly once; plain loads pushed 52 MB per launch through the L2s the heavy kernels
     // on the main stream were working out of (same-box A/B, round 3: 0.945 -> 0.926 ms per step).
     constexpr int nt = 1;
+    static const bool r4 = getenv("UAD_NO_REDUCE4") == nullptr;
+    if (r4 && S > 8 && L % 4 == 0 && L >= 1024 && ((uintptr_t)partial & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+        const int L4 = L / 4;
+        if ((L4 + 63) / 64 >= 256) hipLaunchKernelGGL((reduce_partials4_kernel<64, 8>), dim3((L4 + 63) / 64), dim3(512), 0, st, partial, S, L, scale, out);
+        else if ((L4 + 31) / 32 >= 256) hipLaunchKernelGGL((reduce_partials4_kernel<32, 16>), dim3((L4 + 31) / 32), dim3(512), 0, st, partial, S, L, scale, out);
+        else hipLaunchKernelGGL((reduce_partials4_kernel<16, 32>), dim3((L4 + 15) / 16), dim3(512), 0, st, partial, S, L, scale, out);
+        return;
+    }
     if (blocks >= 256 || S <= 8)
         hipLaunchKernelGGL((reduce_partials_kernel<4>), dim3(blocks), dim3(256), 0, st, partial, S, L, scale, out, nt);
     else
