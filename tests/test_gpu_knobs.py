@@ -9,6 +9,7 @@ interpreter with the switch set:
   UAD_NO_D16S              round-2 ConvT-class kernel (LDS-transposed epilogue) instead of the lane = pixel one
   UAD_NO_D16S_T16          fused-final training instance of the lane = pixel kernel on 8 x 16 tiles (one fragment per wave) instead of 16 x 16 (two)
   UAD_NO_REDUCE4           slab reductions (filter-gradient slabs, LayerNorm parameter partials) on the scalar-load kernel instead of the 16-byte streaming one
+  UAD_NO_TAIL_SPLIT        one main -> side edge behind both kernels of the last encoder block instead of one behind its filter gradient and one behind its data gradient
   UAD_NO_FUSED_FINAL_F32   exact-fp32 mode: separate final 1x1 conv + loss kernel instead of the last ConvT's fused epilogue (round 4)
   UAD_NO_W5_DB             k5 filter gradient of the 64-column layers on the single-buffered tile loop (two barriers per tile) instead of the double-buffered one
   UAD_NO_ANYORDER          every launch with the AQL barrier bit (no data gradient starting while its layer's filter gradient drains)
@@ -31,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize('knob', ['UAD_BOTT_Q1', 'UAD_NO_FUSED_BOTT_WGRAD', 'UAD_NO_FIRST32', 'UAD_NO_SIDE_PACK', 'UAD_NO_INKERNEL_SPLITK',
-                                  'UAD_NO_D16S', 'UAD_NO_D16S_T16', 'UAD_NO_REDUCE4', 'UAD_NO_ANYORDER', 'UAD_NO_FUSED_FINAL_F32', 'UAD_NO_PACK_HEAD', 'UAD_NO_W5_DB',
+                                  'UAD_NO_D16S', 'UAD_NO_D16S_T16', 'UAD_NO_REDUCE4', 'UAD_NO_TAIL_SPLIT', 'UAD_NO_ANYORDER', 'UAD_NO_FUSED_FINAL_F32', 'UAD_NO_PACK_HEAD', 'UAD_NO_W5_DB',
                                   'UAD_SPATIAL_MIN_WGS=256'])
 def test_model_parity_with_switch(knob):
     name, _, val = knob.partition('=')

@@ -1229,12 +1229,18 @@ static int backward_encoder(uad_model* m, hipStream_t st, int part, bool defer =
         const ConvLayer& PL = m->enc[i - 1];
         float* cp = m->cp_slot[8 + (i & 7)];
         if (pg) { PROF(kEncW[i & 7]); uad_launch_conv_w(d, PL.c, bn_xform(m, PL.gamma, PL.beta, kLrelu), g, no_xform(), Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], st, bf, nullptr, nullptr, false, true, planes_of(m)); }
+        // The step's tail is the side stream's chain behind the LAST block's edge (event latency, slab reduction -- 79 MB for enc1 --, BN finalize, join).  For that block
+        // the slab reduction is released by an edge of its own right behind the filter gradient, so that it runs beside the data gradient and the first layer's
+        // filter gradient instead of after them; the block gives up the any-order overlap of its two kernels for it.  UAD_NO_TAIL_SPLIT: one edge behind both.
+        static const bool tail_split_on = getenv("UAD_NO_TAIL_SPLIT") == nullptr;
+        const bool tail_split = tail_split_on && pg && part != 1 && i == i_last && !m->prof_on;
+        if (tail_split) { edge(m, st, sd); PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd, bf); }
         { static const bool anyo = getenv("UAD_NO_ANYORDER") == nullptr; if (anyo && pg) uad_conv_any_order_next(true); }
         { PROF(kEncD[i & 7]); UadEpilogue e = epi_bwd(m, PL.c, PL.gamma, PL.beta, kLrelu); e.colpart = cp;
           uad_launch_conv_d(d, g, no_xform(), P(m, m->enc[i].w), gn, e, st, PKD(m, m->enc[i].w), m->ws, PK16D(m, m->enc[i].w), PLANE(m->enc[i]), false, planes_of(m));
           uad_conv_any_order_next(false); }
         if (pg) edge(m, st, sd);
-        if (pg) { PROF_ON("bn.gradfin", sd); uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd, bf);
+        if (pg) { PROF_ON("bn.gradfin", sd); if (!tail_split) uad_launch_conv_w_reduce(d, Gr(m, m->enc[i].w), m->wp_slot[8 + (i & 7)], sd, bf);
                   uad_launch_bn_grad_finalize(cp, uad_conv_d_tiles(d, true, m->ws.floats, sk_counters(m), planes_of(m)), d.CB, P(m, PL.gamma), rstd, Gr(m, PL.gamma),
                                     Gr(m, PL.beta), Gr(m, PL.b), sd, m->bnfin_scratch); }
         float* tsw = g; g = gn; gn = tsw;
